@@ -1,0 +1,94 @@
+"""CPU: pin the oracle (oracle/mirror_oracle.py) against golden vectors recorded from the
+reference itself (tools/make_golden.py).  fp32 vs fp32: tolerances are rounding-level."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mirror_oracle as O
+from tests.golden_util import GOLDEN, ModelCase, TEMPLATE_W, DEFAULT_W
+
+
+@pytest.mark.parametrize("name", ["tiny", "h12", "mid", "c1"])
+def test_model_forward_and_loss_match_reference(name):
+    case = ModelCase(name)
+    torch.set_num_threads(8)
+    sd = {k: v.clone().requires_grad_(True) for k, v in case.sd.items()}
+    outs = O.mirror_forward(sd, case.cfg, case.wsi, case.rna, case.noise, *case.ratios)
+    case.check_outputs(outs, rtol=2e-4)
+    lt = O.mirror_loss(outs, TEMPLATE_W)
+    ld = O.mirror_loss([o.detach() for o in outs], DEFAULT_W)
+    np.testing.assert_allclose([float(x.detach()) for x in lt], case.z["loss_template"], rtol=2e-5)
+    np.testing.assert_allclose([float(x) for x in ld], case.z["loss_default"], rtol=2e-5)
+    # gradients of the total (template-weighted) loss w.r.t. every parameter
+    lt[0].backward()
+    gn = np.array([0.0 if sd[k].grad is None else float(sd[k].grad.double().norm()) for k in case.keys])
+    ref = case.z["grad_norm"]
+    np.testing.assert_allclose(gn, ref, rtol=2e-3, atol=1e-6 * float(ref.max()))
+    for k in case.keys:
+        if f"grad/{k}" in case.z.files:
+            g = case.z[f"grad/{k}"]
+            tol = 2e-3 * max(float(np.abs(g).max()), 1e-7)
+            np.testing.assert_allclose(sd[k].grad.numpy(), g, atol=tol, rtol=0)
+
+
+def test_mirror_loss_matches_reference():
+    z = np.load(os.path.join(GOLDEN, "golden_losses.npz"))
+    for tag, w in (("default", DEFAULT_W), ("template", TEMPLATE_W)):
+        ins = [torch.from_numpy(z[f"in/{nm}"]).clone() for nm in O.OUTPUT_NAMES]
+        for t in ins:
+            if f"grad_{tag}/x" is not None:
+                t.requires_grad_(t.dtype.is_floating_point)
+        out = O.mirror_loss(ins, w)
+        np.testing.assert_allclose([float(x) for x in out], z[f"loss_{tag}"], rtol=1e-5)
+        out[0].backward()
+        for nm, t in zip(O.OUTPUT_NAMES, ins):
+            key = f"grad_{tag}/{nm}"
+            if key in z.files:
+                g = z[key]
+                np.testing.assert_allclose(t.grad.numpy(), g, atol=1e-5 * max(np.abs(g).max(), 1e-6), rtol=1e-4)
+    w = torch.from_numpy(z["in/wsi_alignment_emb"])
+    r = torch.from_numpy(z["in/rna_alignment_emb"])
+    s = torch.from_numpy(z["in/logit_scale"])
+    np.testing.assert_allclose(float(O.clip_loss(w, r, s)), float(z["clip_loss"]), rtol=1e-5)
+
+
+def test_info_nce_matches_reference():
+    z = np.load(os.path.join(GOLDEN, "golden_infonce.npz"))
+    q0, k0 = torch.from_numpy(z["q"]), torch.from_numpy(z["k"])
+    n = 0
+    for key in z.files:
+        if not key.startswith("loss/"):
+            continue
+        tag = key[5:]
+        sym, red, tau = tag.split("_")
+        q, k = q0.clone().requires_grad_(True), k0.clone().requires_grad_(True)
+        out = O.info_nce(q, k, float(tau), red, sym == "sym1")
+        np.testing.assert_allclose(out.detach().numpy(), z[key], rtol=2e-5, atol=1e-6)
+        out.sum().backward()
+        np.testing.assert_allclose(q.grad.numpy(), z[f"gq/{tag}"], rtol=1e-3, atol=1e-6)
+        np.testing.assert_allclose(k.grad.numpy(), z[f"gk/{tag}"], rtol=1e-3, atol=1e-6)
+        n += 1
+    assert n == 12
+
+
+def test_pinv_converges_to_inverse():
+    """Property with no oracle needed (SURVEY §8c iii): a2 @ pinv(a2) -> I as iterations grow."""
+    g = torch.Generator().manual_seed(3)
+    a = (torch.randn(2, 3, 24, 24, generator=g) * 2).softmax(-1) + 0.5 * torch.eye(24)
+    a = a / a.sum(-1, keepdim=True)
+    e6 = (a @ O.pinv_iter(a, 6) - torch.eye(24)).abs().max()
+    e20 = (a @ O.pinv_iter(a, 20) - torch.eye(24)).abs().max()
+    assert e20 < 1e-4 and e20 <= e6
+
+
+def test_nystrom_equals_softmax_attention_when_landmarks_are_tokens():
+    """With l == 1 (m == n) and an exact inverse, Nystrom attention reduces to
+    softmax(qk^T)v + res_conv(v); here checked as a1 @ pinv(a2) @ a3 ~= softmax(q k^T)."""
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(1, 1, 12, 8, generator=g) * 0.3
+    k = torch.randn(1, 1, 12, 8, generator=g) * 0.3
+    a = (q @ k.transpose(-1, -2)).softmax(-1)
+    approx = a @ O.pinv_iter(a, 30) @ a
+    assert (approx - a).abs().max() < 1e-3
