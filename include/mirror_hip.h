@@ -1,0 +1,196 @@
+/* libmirror_hip.so — C ABI of the MI355X (gfx950) kernels behind the MIRROR pre-training hot path.
+ *
+ * The reference (TianyiFranklinWang/MIRROR) contains no native code: every entry point below
+ * replaces the ATen ops that one reference call site dispatches (file:line are relative to the
+ * reference tree; [3P] = arithmetic that lives in the pip packages nystrom_attention~=0.0.14 /
+ * timm~=1.0.15, called from the cited line).  The Python host (mirror_amd/) binds these with
+ * ctypes and wraps them in torch.autograd.Function; INTEGRATION.md shows the binding.
+ *
+ * Contract: plain device pointers + sizes, explicit dtypes, caller-owned memory
+ * and workspaces, a hipStream_t per call, int status return (0 ok, <0 error, text via
+ * mh_last_error()); no allocation, no synchronisation, no exceptions; re-entrant across streams.
+ */
+#ifndef MIRROR_HIP_H
+#define MIRROR_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MH_OK 0
+#define MH_EINVAL (-1)
+#define MH_EUNSUP (-2)
+#define MH_EHIP (-3)
+
+#define MH_F32 0
+#define MH_BF16 1
+
+#define MH_ACT_NONE 0
+#define MH_ACT_RELU 1
+#define MH_ACT_GELU 2
+
+typedef void* mh_stream; /* hipStream_t */
+
+const char* mh_last_error(void);
+int mh_version(void);
+/* number of visible HIP devices whose arch is gfx950; <=0 means the library cannot run here */
+int mh_device_ok(void);
+
+/* ---------------------------------------------------------------- MFMA GEMM (all contractions)
+ * C[z] (+)= act(alpha * op(A[z]) x op(B[z]) + diag*I + bias)   z = (b1, b2) two-level batch
+ *   A(m,k) at A[m*lda + k] if a_kc else A[k*lda + m];  B(k,n) at B[n*ldb + k] if b_kc else B[k*ldb + n]
+ *   mma = MH_F32  -> v_mfma_f32_32x32x2_f32 (exact fp32, parity mode; dtA=dtB=dtC=f32)
+ *   mma = MH_BF16 -> v_mfma_f32_32x32x16_bf16, fp32 accumulate; f32 operands are rounded to bf16
+ *                    while being staged into LDS (dtA must equal dtB)
+ * Replaces: nn.Linear fwd/bwd (models/mirror.py:346, :70-74, :470-495, :594-605, :823-827),
+ * [3P] NystromAttention's to_qkv / einsum similarities / attn@v / pinv matmuls / to_out
+ * (models/mirror.py:312), ClipLoss logits (losses/mirror_loss.py:39-40).                      */
+typedef struct {
+    const void* A; const void* B; void* C;
+    const float* bias;            /* [N] f32 or NULL */
+    int32_t M, N, K;
+    int64_t lda, ldb, ldc;
+    int32_t a_kc, b_kc;
+    int32_t dtA, dtB, dtC, mma;
+    int32_t batch1, batch2;
+    int64_t sA1, sA2, sB1, sB2, sC1, sC2;   /* element strides of the two batch levels */
+    float alpha, diag;
+    int32_t act;                  /* MH_ACT_* (needs split_k == 1) */
+    int32_t accumulate;           /* 0: C = r, 1: C += r */
+    int32_t split_k;              /* >1: K split over workgroups, f32 atomics into C (needs accumulate=1, dtC=f32) */
+} mh_gemm_desc;
+int mh_gemm(const mh_gemm_desc* d, mh_stream s);
+
+/* ---------------------------------------------------------------- LayerNorm (models/mirror.py:298, :350, :604, :210)
+ * rows are addressed as (b, i): x + b*x_bs + i*D, y + b*y_bs + i*D, i < rows_per_batch (lets the
+ * output land inside the front-zero-padded Nystrom buffer, or skip the square-pad rows :679). */
+int mh_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                     int batches, int rows_per_batch, int D, int64_t x_bs, int64_t y_bs, float eps,
+                     int dt_x, int dt_y, mh_stream s);
+/* dx = d/dx, dgamma/dbeta accumulated with f32 atomics (caller zeroes them). dy uses y's addressing. */
+int mh_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                     void* dx, float* dgamma, float* dbeta,
+                     int batches, int rows_per_batch, int D, int64_t x_bs, int64_t y_bs,
+                     int dt_x, int dt_dy, int dt_dx, int accumulate_dx, mh_stream s);
+
+/* ---------------------------------------------------------------- row softmax ([3P] sim.softmax(-1); Attention :95)
+ * x/y: rows x cols, row stride ld (elements). In place allowed when dtypes match. */
+int mh_softmax_fwd(const void* x, void* y, int64_t rows, int cols, int64_t ldx, int64_t ldy,
+                   int dt_x, int dt_y, mh_stream s);
+/* dx = y * (dy - sum(dy*y)) ; in place on dy allowed */
+int mh_softmax_bwd(const void* y, const void* dy, void* dx, int64_t rows, int cols, int64_t ldy, int64_t lddy,
+                   int64_t lddx, int dt_y, int dt_dy, int dt_dx, mh_stream s);
+
+/* ---------------------------------------------------------------- Nystrom pieces ([3P], called at models/mirror.py:312)
+ * qkv: [B, n_p, 3D] (q | k | v column blocks, heads are dh-wide column slices).
+ * landmarks: lm[b, j, c] = mean_{t<l} qkv[b, j*l+t, c], c < 2D  -> lm [B, m, 2D]            */
+int mh_landmark_fwd(const void* qkv, void* lm, int B, int n_p, int D, int l, int dt, mh_stream s);
+/* dqkv[b, r, c] += dlm[b, r/l, c] / l for c < 2D */
+int mh_landmark_bwd(const void* dlm, void* dqkv, int B, int n_p, int D, int l, int dt, mh_stream s);
+/* out[b,t,h*dh+d] += sum_j w[h][j] * v[b, t+j-K/2, h*dh+d]; v = qkv[..., 2D:3D] (ldv = 3D), out ld = ldo.
+ * transpose=1 applies the adjoint (data gradient).                                           */
+int mh_resconv_fwd(const void* v, int64_t ldv, int64_t v_bs, const float* w, void* out, int64_t ldo, int64_t o_bs,
+                   int B, int n_p, int heads, int dh, int taps, int transpose, int accumulate,
+                   int dt_v, int dt_o, mh_stream s);
+/* dw[h][j] += sum_{b,t,d} dout[b,t,h,d] * v[b,t+j-K/2,h,d]  (f32 atomics) */
+int mh_resconv_wgrad(const void* v, int64_t ldv, int64_t v_bs, const void* dout, int64_t ldo, int64_t o_bs,
+                     float* dw, int B, int n_p, int heads, int dh, int taps, int dt_v, int dt_o, mh_stream s);
+/* moore_penrose_iter_pinv initial scaling: stats[0]=max_i sum_j|x|, stats[1]=max_j sum_i|x| over the
+ * WHOLE [BH,m,m] tensor (couples the batch), with arg positions packed in stats64. */
+int mh_pinv_absmax(const float* x, uint64_t* stats64, int BH, int m, mh_stream s);
+/* z0[bh,i,j] = x[bh,j,i] / (c*r) */
+int mh_pinv_z0(const float* x, const uint64_t* stats64, float* z0, int BH, int m, mh_stream s);
+/* dx += dz0^T/(c r) + sub-gradients through the two max() */
+int mh_pinv_z0_bwd(const float* x, const float* z0, const float* dz0, const uint64_t* stats64, float* dx,
+                   float* scratch1, int BH, int m, mh_stream s);
+/* T = d*I - P  (batched [BH,m,m] f32) */
+int mh_eye_minus(const float* P, float* T, float d, int BH, int m, mh_stream s);
+
+/* ---------------------------------------------------------------- TransMIL glue (models/mirror.py:657-665, :317-331)
+ * seq [B, n, D]: row 0 <- cls, rows 1+N.. <- copies of rows 1..add (square pad). */
+int mh_seq_finish(void* seq, const float* cls, int B, int N, int add, int D, int dt, mh_stream s);
+/* dseq[b,1+i] += dseq[b,1+N+i] (i<add); dcls[c] += sum_b dseq[b,0,c] */
+int mh_seq_finish_bwd(void* dseq, float* dcls, int B, int N, int add, int D, int dt, mh_stream s);
+/* merged[49][D] = w7 + embed(w5) + embed(w3) + centre 1 ; bsum[D] = b7+b5+b3 */
+int mh_ppeg_merge(const float* w7, const float* w5, const float* w3, const float* b7, const float* b5,
+                  const float* b3, float* merged, float* bsum, int D, mh_stream s);
+/* depthwise 7x7 on tokens 1..S*S of seq [B, 1+S*S, D]; cls row copied. flip=1 -> adjoint (no bias). */
+int mh_ppeg_fwd(const void* x, void* y, const float* merged, const float* bsum, int B, int S, int D,
+                int flip, int dt_x, int dt_y, mh_stream s);
+/* dmerged[tap][c] += sum dout*x(shifted); dbsum[c] += sum dout  (f32 atomics) */
+int mh_ppeg_wgrad(const void* x, const void* dout, float* dmerged, float* dbsum, int B, int S, int D,
+                  int dt_x, int dt_o, mh_stream s);
+
+/* ---------------------------------------------------------------- masking (models/mirror.py:624-649, :510-533)
+ * mask[b,i] = 1 if rank(noise[b,i]) >= len_keep (rank by ascending noise, ties by index) */
+int mh_rank_mask(const float* noise, float* mask, int B, int N, int len_keep, mh_stream s);
+/* x [B, T, D] rows t>=first: x = mask[b,t-first] ? token : x ; then x += pos[t]  (pos [T,D]) */
+int mh_mask_apply_fwd(void* x, const float* mask, const float* token, const float* pos, int B, int T, int D,
+                      int first, int token_scalar, int dt, mh_stream s);
+/* dx = dy*(1-mask) (in place); dtoken += sum mask*dy ; dpos[t] += sum_b dy */
+int mh_mask_apply_bwd(void* dy, const float* mask, float* dtoken, float* dpos, int B, int T, int D,
+                      int first, int token_scalar, int dt, mh_stream s);
+
+/* ---------------------------------------------------------------- RNA encoder pieces (models/mirror.py:77-102)
+ * qkv [B, 3D] -> softmax over the HEADS axis -> out[b, d*H + h]; attn [B,H,H] saved for backward */
+int mh_headattn_fwd(const void* qkv, void* out, float* attn, int B, int H, int hd, int dt, mh_stream s);
+int mh_headattn_bwd(const void* qkv, const float* attn, const void* dout, void* dqkv, int B, int H, int hd,
+                    int dt, mh_stream s);
+
+/* ---------------------------------------------------------------- elementwise / reductions */
+int mh_add(const void* a, const void* b, void* y, int64_t n, int dt_a, int dt_b, int dt_y, mh_stream s);
+int mh_cast(const void* x, void* y, int64_t n, int dt_x, int dt_y, mh_stream s);
+int mh_gelu_fwd(const void* x, void* y, int64_t n, int dt_x, int dt_y, mh_stream s);
+int mh_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int dt_x, int dt_dy, int dt_dx, mh_stream s);
+/* dx = dy * (y > 0) */
+int mh_relu_bwd(const void* y, const void* dy, void* dx, int64_t n, int dt_y, int dt_dy, int dt_dx, mh_stream s);
+/* y = x * keep/(1-p); keep from Philox4x32-10(seed, offset + i)  ([3P] nn.Dropout in to_out; :75, :142) */
+int mh_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, uint64_t offset, int dt_x, int dt_y,
+               mh_stream s);
+/* out[c] += sum_r x[r*ld + c]  (bias gradients; f32 atomics) */
+int mh_colsum(const void* x, float* out, int64_t rows, int cols, int64_t ld, int dt, mh_stream s);
+/* y[r] = x[r*x_rs .. +D] / max(||.||, eps) (F.normalize, models/mirror.py:540, :683); norm[r] saved */
+int mh_l2norm_fwd(const void* x, void* y, float* nrm, int rows, int D, int64_t x_rs, float eps, int dt_x, int dt_y,
+                  mh_stream s);
+int mh_l2norm_bwd(const void* y, const float* nrm, const void* dy, void* dx, int rows, int D, int64_t dx_rs,
+                  float eps, int dt_y, int dt_dy, int dt_dx, int accumulate, mh_stream s);
+/* z = mu + eps*exp(0.5*logstd) (models/mirror.py:830-833) */
+int mh_reparam_fwd(const float* mu, const float* logstd, const float* eps, float* z, int64_t n, mh_stream s);
+int mh_reparam_bwd(const float* logstd, const float* eps, const float* dz, float* dmu, float* dlogstd, int64_t n,
+                   mh_stream s);
+
+/* ---------------------------------------------------------------- losses (losses/mirror_loss.py, losses/info_nce.py)
+ * cross-entropy of rows of scale*G against label (label_off + row); G [R x C] f32.
+ * out[0] += coef * sum_r (lse_r - scale*G[r,label]) ; lse [R] saved. scale read from device. */
+int mh_ce_rows_fwd(const float* G, int64_t ldg, const float* scale, float scale_mul, int R, int C, int label_off,
+                   float coef, float* loss_rows, float* lse, float* out, mh_stream s);
+/* dG[r,c] = gcoef * g[0 or r] * scale * (softmax - onehot); dscale += sum dG_unscaled*G  */
+int mh_ce_rows_bwd(const float* G, int64_t ldg, const float* scale, float scale_mul, const float* lse, const float* g,
+                   int g_per_row, float gcoef, float* dG, float* dscale, int R, int C, int label_off, mh_stream s);
+/* acc[0] += sum_r mask[r] * mean_D (p-t)^2 ; acc[1] += sum_r mask[r]   (losses/mirror_loss.py:98-103) */
+int mh_mse_masked_fwd(const void* pred, const void* tgt, const float* mask, float* acc, int64_t rows, int D,
+                      int dt_p, int dt_t, mh_stream s);
+/* dpred = g * 2*mask*(p-t)/(D*acc[1]); dtgt = -dpred */
+int mh_mse_masked_bwd(const void* pred, const void* tgt, const float* mask, const float* acc, const float* g,
+                      void* dpred, void* dtgt, int64_t rows, int D, int dt_p, int dt_t, int dt_d, mh_stream s);
+/* out[0] += coef * sum (exp(ls) + mu^2 - 1 - ls)   (losses/mirror_loss.py:105-112) */
+int mh_kl_fwd(const float* mu, const float* ls, float* out, int64_t n, float coef, mh_stream s);
+int mh_kl_bwd(const float* mu, const float* ls, const float* g, float* dmu, float* dls, int64_t n, float coef,
+              mh_stream s);
+/* out[0] += coef * sum_b sum_k (p_r - p_w)(log p_r - log p_w)  (losses/mirror_loss.py:114-119) */
+int mh_symkl_fwd(const float* w, const float* r, float* out, int B, int P, float coef, mh_stream s);
+int mh_symkl_bwd(const float* w, const float* r, const float* g, float* dw, float* dr, int B, int P, float coef,
+                 mh_stream s);
+
+/* ---------------------------------------------------------------- step glue (train_mirror.py:1133-1136, :1230, :1254-1255) */
+int mh_rownorm_(float* w, int rows, int D, float eps, mh_stream s);
+int mh_clamp_(float* x, int64_t n, float lo, float hi, mh_stream s);
+/* torch.optim.Adam (wd=0): flat f32 params/grads/moments; optional bf16 shadow copy of the params */
+int mh_adam(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr, float beta1,
+            float beta2, float eps, float bias_c1, float bias_c2, float grad_scale, mh_stream s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,117 @@
+"""ctypes binding of libmirror_hip.so (C ABI declared in include/mirror_hip.h).
+
+The product path has no fallback: if the shared library is missing or a call fails this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmirror_hip.so")
+
+MH_F32, MH_BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64),
+        ("a_kc", C.c_int32), ("b_kc", C.c_int32),
+        ("dtA", C.c_int32), ("dtB", C.c_int32), ("dtC", C.c_int32), ("mma", C.c_int32),
+        ("batch1", C.c_int32), ("batch2", C.c_int32),
+        ("sA1", C.c_int64), ("sA2", C.c_int64), ("sB1", C.c_int64), ("sB2", C.c_int64),
+        ("sC1", C.c_int64), ("sC2", C.c_int64),
+        ("alpha", C.c_float), ("diag", C.c_float),
+        ("act", C.c_int32), ("accumulate", C.c_int32), ("split_k", C.c_int32),
+    ]
+
+
+P, I, L, F, U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
+
+# name -> argtypes (the trailing stream argument is appended automatically)
+_SIGS = {
+    "mh_gemm": [C.POINTER(GemmDesc)],
+    "mh_layernorm_fwd": [P, P, P, P, P, P, I, I, I, L, L, F, I, I],
+    "mh_layernorm_bwd": [P, P, P, P, P, P, P, P, I, I, I, L, L, I, I, I, I],
+    "mh_softmax_fwd": [P, P, L, I, L, L, I, I],
+    "mh_softmax_bwd": [P, P, P, L, I, L, L, L, I, I, I],
+    "mh_landmark_fwd": [P, P, I, I, I, I, I],
+    "mh_landmark_bwd": [P, P, I, I, I, I, I],
+    "mh_resconv_fwd": [P, L, L, P, P, L, L, I, I, I, I, I, I, I, I, I],
+    "mh_resconv_wgrad": [P, L, L, P, L, L, P, I, I, I, I, I, I, I],
+    "mh_pinv_absmax": [P, P, I, I],
+    "mh_pinv_z0": [P, P, P, I, I],
+    "mh_pinv_z0_bwd": [P, P, P, P, P, P, I, I],
+    "mh_eye_minus": [P, P, F, I, I],
+    "mh_seq_finish": [P, P, I, I, I, I, I],
+    "mh_seq_finish_bwd": [P, P, I, I, I, I, I],
+    "mh_ppeg_merge": [P, P, P, P, P, P, P, P, I],
+    "mh_ppeg_fwd": [P, P, P, P, I, I, I, I, I, I],
+    "mh_ppeg_wgrad": [P, P, P, P, I, I, I, I, I],
+    "mh_rank_mask": [P, P, I, I, I],
+    "mh_mask_apply_fwd": [P, P, P, P, I, I, I, I, I, I],
+    "mh_mask_apply_bwd": [P, P, P, P, I, I, I, I, I, I],
+    "mh_headattn_fwd": [P, P, P, I, I, I, I],
+    "mh_headattn_bwd": [P, P, P, P, I, I, I, I],
+    "mh_add": [P, P, P, L, I, I, I],
+    "mh_cast": [P, P, L, I, I],
+    "mh_gelu_fwd": [P, P, L, I, I],
+    "mh_gelu_bwd": [P, P, P, L, I, I, I],
+    "mh_relu_bwd": [P, P, P, L, I, I, I],
+    "mh_dropout": [P, P, L, F, U64, U64, I, I],
+    "mh_colsum": [P, P, L, I, L, I],
+    "mh_l2norm_fwd": [P, P, P, I, I, L, F, I, I],
+    "mh_l2norm_bwd": [P, P, P, P, I, I, L, F, I, I, I, I],
+    "mh_reparam_fwd": [P, P, P, P, L],
+    "mh_reparam_bwd": [P, P, P, P, P, L],
+    "mh_ce_rows_fwd": [P, L, P, F, I, I, I, F, P, P, P],
+    "mh_ce_rows_bwd": [P, L, P, F, P, P, I, F, P, P, I, I, I],
+    "mh_mse_masked_fwd": [P, P, P, P, L, I, I, I],
+    "mh_mse_masked_bwd": [P, P, P, P, P, P, P, L, I, I, I, I],
+    "mh_kl_fwd": [P, P, P, L, F],
+    "mh_kl_bwd": [P, P, P, P, P, L, F],
+    "mh_symkl_fwd": [P, P, P, I, I, F],
+    "mh_symkl_bwd": [P, P, P, P, P, I, I, F],
+    "mh_rownorm_": [P, I, I, F],
+    "mh_clamp_": [P, L, F, F],
+    "mh_adam": [P, P, P, P, P, L, F, F, F, F, F, F, F],
+}
+EXPORTS = sorted(list(_SIGS) + ["mh_last_error", "mh_version", "mh_device_ok"])
+
+_lib = None
+
+
+class MirrorHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the library (once). Raises MirrorHipError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MirrorHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C mirror_amd/csrc` — mirror_amd has no CPU/PyTorch fallback path")
+    lib = C.CDLL(LIB_PATH)
+    lib.mh_last_error.restype = C.c_char_p
+    lib.mh_last_error.argtypes = []
+    lib.mh_version.restype = C.c_int
+    lib.mh_device_ok.restype = C.c_int
+    for name, sig in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = list(sig) + [C.c_void_p]
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args, stream: int = 0) -> None:
+    lib = load()
+    rc = getattr(lib, name)(*args, stream)
+    if rc != 0:
+        raise MirrorHipError(f"{name} failed ({rc}): {lib.mh_last_error().decode()}")

@@ -1,0 +1,367 @@
+// Elementwise and small reduction kernels: add / cast / GELU / ReLU-bwd / Philox dropout / column sums,
+// MAE-style masking (rank select + token fill + positional add), reparameterisation, RNA heads-axis attention.
+#include "common.h"
+
+#define EW_GRID(n) dim3((unsigned)min((long)mh_cdiv((n), 256), 16384L))
+#define EW_LOOP(i, n) for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (n); i += (long)gridDim.x * 256)
+
+template <typename TA, typename TB, typename TY>
+__global__ __launch_bounds__(256) void add_kernel(const TA* a, const TB* b, TY* y, long n) {
+    EW_LOOP(i, n) stf(y + i, ldf(a + i) + ldf(b + i));
+}
+template <typename TX, typename TY>
+__global__ __launch_bounds__(256) void cast_kernel(const TX* x, TY* y, long n) {
+    EW_LOOP(i, n) stf(y + i, ldf(x + i));
+}
+template <typename TX, typename TY>
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const TX* x, TY* y, long n) {
+    EW_LOOP(i, n) stf(y + i, gelu_f(ldf(x + i)));
+}
+template <typename TX, typename TDY, typename TDX>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const TX* x, const TDY* dy, TDX* dx, long n) {
+    EW_LOOP(i, n) stf(dx + i, ldf(dy + i) * gelu_grad_f(ldf(x + i)));
+}
+template <typename TY, typename TDY, typename TDX>
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const TY* y, const TDY* dy, TDX* dx, long n) {
+    EW_LOOP(i, n) stf(dx + i, ldf(y + i) > 0.f ? ldf(dy + i) : 0.f);
+}
+
+#define DISPATCH2(dt0, dt1, MACRO)                                     \
+    if ((dt0) == MH_F32 && (dt1) == MH_F32) { MACRO(float, float); }   \
+    else if ((dt0) == MH_F32) { MACRO(float, bf16_t); }                \
+    else if ((dt1) == MH_F32) { MACRO(bf16_t, float); }                \
+    else { MACRO(bf16_t, bf16_t); }
+
+extern "C" int mh_add(const void* a, const void* b, void* y, int64_t n, int dt_a, int dt_b, int dt_y, mh_stream s) {
+    if (n == 0) return MH_OK;
+#define ADD_(TA, TB)                                                                                                     \
+    if (dt_y == MH_F32) hipLaunchKernelGGL((add_kernel<TA, TB, float>), EW_GRID(n), dim3(256), 0, (hipStream_t)s, (const TA*)a, (const TB*)b, (float*)y, (long)n); \
+    else hipLaunchKernelGGL((add_kernel<TA, TB, bf16_t>), EW_GRID(n), dim3(256), 0, (hipStream_t)s, (const TA*)a, (const TB*)b, (bf16_t*)y, (long)n)
+    DISPATCH2(dt_a, dt_b, ADD_)
+#undef ADD_
+    MH_LAUNCH_CHECK("mh_add");
+    return MH_OK;
+}
+
+extern "C" int mh_cast(const void* x, void* y, int64_t n, int dt_x, int dt_y, mh_stream s) {
+    if (n == 0) return MH_OK;
+#define CAST_(TX, TY) hipLaunchKernelGGL((cast_kernel<TX, TY>), EW_GRID(n), dim3(256), 0, (hipStream_t)s, (const TX*)x, (TY*)y, (long)n)
+    DISPATCH2(dt_x, dt_y, CAST_)
+#undef CAST_
+    MH_LAUNCH_CHECK("mh_cast");
+    return MH_OK;
+}
+
+extern "C" int mh_gelu_fwd(const void* x, void* y, int64_t n, int dt_x, int dt_y, mh_stream s) {
+    if (n == 0) return MH_OK;
+#define GELU_(TX, TY) hipLaunchKernelGGL((gelu_fwd_kernel<TX, TY>), EW_GRID(n), dim3(256), 0, (hipStream_t)s, (const TX*)x, (TY*)y, (long)n)
+    DISPATCH2(dt_x, dt_y, GELU_)
+#undef GELU_
+    MH_LAUNCH_CHECK("mh_gelu_fwd");
+    return MH_OK;
+}
+
+extern "C" int mh_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int dt_x, int dt_dy, int dt_dx, mh_stream s) {
+    MH_REQUIRE(dt_dy == dt_dx, "mh_gelu_bwd: dy/dx dtype mismatch");
+    if (n == 0) return MH_OK;
+#define GELUB_(TX, TD) hipLaunchKernelGGL((gelu_bwd_kernel<TX, TD, TD>), EW_GRID(n), dim3(256), 0, (hipStream_t)s, (const TX*)x, (const TD*)dy, (TD*)dx, (long)n)
+    DISPATCH2(dt_x, dt_dy, GELUB_)
+#undef GELUB_
+    MH_LAUNCH_CHECK("mh_gelu_bwd");
+    return MH_OK;
+}
+
+extern "C" int mh_relu_bwd(const void* y, const void* dy, void* dx, int64_t n, int dt_y, int dt_dy, int dt_dx, mh_stream s) {
+    MH_REQUIRE(dt_dy == dt_dx, "mh_relu_bwd: dy/dx dtype mismatch");
+    if (n == 0) return MH_OK;
+#define RELUB_(TY, TD) hipLaunchKernelGGL((relu_bwd_kernel<TY, TD, TD>), EW_GRID(n), dim3(256), 0, (hipStream_t)s, (const TY*)y, (const TD*)dy, (TD*)dx, (long)n)
+    DISPATCH2(dt_y, dt_dy, RELUB_)
+#undef RELUB_
+    MH_LAUNCH_CHECK("mh_relu_bwd");
+    return MH_OK;
+}
+
+// ------------------------------------------------------------------ Philox4x32-10 dropout
+__device__ __forceinline__ void philox4x32_10(uint32_t (&ctr)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * ctr[0];
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * ctr[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ ctr[1] ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ ctr[3] ^ k1;
+        ctr[0] = n0; ctr[1] = (uint32_t)p1; ctr[2] = n2; ctr[3] = (uint32_t)p0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+// element i uses word (i & 3) of the Philox block with counter (offset + i) >> 2: the mask is a pure
+// function of (seed, offset, i), so the backward pass regenerates it instead of storing it.
+template <typename TX, typename TY>
+__global__ __launch_bounds__(256) void dropout_kernel(const TX* x, TY* y, long n, float p, uint64_t seed, uint64_t offset) {
+    const float scale = 1.f / (1.f - p);
+    const uint32_t thr = (uint32_t)fminf(p * 4294967296.f, 4294967295.f);
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q * 4 < n; q += (long)gridDim.x * 256) {
+        const uint64_t blk = (offset >> 2) + (uint64_t)q;
+        uint32_t ctr[4] = {(uint32_t)blk, (uint32_t)(blk >> 32), 0u, 0u};
+        philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const long i = q * 4 + e;
+            if (i < n) stf(y + i, ctr[e] >= thr ? ldf(x + i) * scale : 0.f);
+        }
+    }
+}
+
+extern "C" int mh_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, uint64_t offset, int dt_x, int dt_y,
+                          mh_stream s) {
+    MH_REQUIRE(p >= 0.f && p < 1.f, "mh_dropout: p=%f out of range", (double)p);
+    MH_REQUIRE((offset & 3) == 0, "mh_dropout: offset must be a multiple of 4");
+    if (n == 0) return MH_OK;
+#define DROP_(TX, TY) hipLaunchKernelGGL((dropout_kernel<TX, TY>), EW_GRID((n + 3) / 4), dim3(256), 0, (hipStream_t)s, (const TX*)x, (TY*)y, (long)n, p, seed, offset)
+    DISPATCH2(dt_x, dt_y, DROP_)
+#undef DROP_
+    MH_LAUNCH_CHECK("mh_dropout");
+    return MH_OK;
+}
+
+// ------------------------------------------------------------------ column sums (bias gradients)
+// block = 64 columns x 4 row-slices; partial sums over a band of rows, then one f32 atomic per column.
+#define CS_BAND 512
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, long rows, int cols, long ld) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const long r0 = (long)blockIdx.y * CS_BAND, r1 = min(rows, r0 + CS_BAND);
+    float s = 0.f;
+    if (c < cols)
+        for (long r = r0 + slice; r < r1; r += 4) s += ldf(x + r * ld + c);
+    red[slice][lane] = s;
+    __syncthreads();
+    if (slice == 0 && c < cols) atomicAdd(out + c, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+}
+
+extern "C" int mh_colsum(const void* x, float* out, int64_t rows, int cols, int64_t ld, int dt, mh_stream s) {
+    if (rows == 0 || cols == 0) return MH_OK;
+    dim3 grid(mh_cdiv(cols, 64), mh_cdiv(rows, CS_BAND));
+    MH_DISPATCH_DT(dt, T, hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(256), 0, (hipStream_t)s, (const T*)x, out, (long)rows, cols, (long)ld));
+    MH_LAUNCH_CHECK("mh_colsum");
+    return MH_OK;
+}
+
+// ------------------------------------------------------------------ masking
+// rank by ascending noise with index tie-break == argsort(argsort(noise)) of the reference for distinct values
+__global__ __launch_bounds__(256) void rank_mask_kernel(const float* __restrict__ noise, float* __restrict__ mask, int N, int len_keep) {
+    extern __shared__ float row[];
+    const long b = blockIdx.y;
+    const float* nb = noise + b * N;
+    for (int j = threadIdx.x; j < N; j += 256) row[j] = nb[j];
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float v = row[i];
+    int rank = 0;
+    for (int j = 0; j < N; j++) {
+        const float u = row[j];
+        rank += (u < v) || (u == v && j < i);
+    }
+    mask[b * N + i] = rank >= len_keep ? 1.f : 0.f;
+}
+
+extern "C" int mh_rank_mask(const float* noise, float* mask, int B, int N, int len_keep, mh_stream s) {
+    MH_REQUIRE(N >= 1 && N <= 16384, "mh_rank_mask: N=%d unsupported (max 16384)", N);
+    if (B == 0) return MH_OK;
+    hipLaunchKernelGGL(rank_mask_kernel, dim3(mh_cdiv(N, 256), B), dim3(256), N * sizeof(float), (hipStream_t)s, noise, mask, N, len_keep);
+    MH_LAUNCH_CHECK("mh_rank_mask");
+    return MH_OK;
+}
+
+// x [B,T,D]: rows t >= first take the mask token where mask[b,t-first] != 0; every row gets + pos[t]
+template <typename T>
+__global__ __launch_bounds__(256) void mask_apply_fwd_kernel(T* x, const float* __restrict__ mask, const float* __restrict__ token,
+                                                             const float* __restrict__ pos, int B, int Tn, int D, int first,
+                                                             int token_scalar) {
+    const long total = (long)B * Tn * D;
+    EW_LOOP(idx, total) {
+        const int c = idx % D;
+        const long bt = idx / D;
+        const int t = bt % Tn;
+        const long b = bt / Tn;
+        float v = ldf(x + idx);
+        if (t >= first && mask[b * (Tn - first) + (t - first)] != 0.f) v = token[token_scalar ? 0 : c];
+        stf(x + idx, v + pos[(long)t * D + c]);
+    }
+}
+
+// block = 64 columns x 4 row-slices over a band of MB_BAND rows t; each thread loops over b, so dpos needs no
+// atomics and the mask-token gradient costs one f32 atomic per column per block.
+#define MB_BAND 64
+template <typename T>
+__global__ __launch_bounds__(256) void mask_apply_bwd_kernel(T* dy, const float* __restrict__ mask, float* __restrict__ dtoken,
+                                                             float* __restrict__ dpos, int B, int Tn, int D, int first,
+                                                             int token_scalar) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int t0 = blockIdx.y * MB_BAND, t1 = min(Tn, t0 + MB_BAND);
+    float st = 0.f;
+    if (c < D) {
+        for (int t = t0 + slice; t < t1; t += 4) {
+            float sp = 0.f;
+            for (int b = 0; b < B; b++) {
+                T* p = dy + ((long)b * Tn + t) * D + c;
+                const float g = ldf(p);
+                sp += g;
+                if (t >= first && mask[(long)b * (Tn - first) + (t - first)] != 0.f) { st += g; stf(p, 0.f); }
+            }
+            dpos[(long)t * D + c] += sp;
+        }
+    }
+    red[slice][lane] = st;
+    __syncthreads();
+    if (slice == 0 && c < D) {
+        const float tot = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        if (tot != 0.f) atomicAdd(dtoken + (token_scalar ? 0 : c), tot);
+    }
+}
+
+extern "C" int mh_mask_apply_fwd(void* x, const float* mask, const float* token, const float* pos, int B, int T, int D,
+                                 int first, int token_scalar, int dt, mh_stream s) {
+    const long total = (long)B * T * D;
+    if (total == 0) return MH_OK;
+    MH_DISPATCH_DT(dt, TT, hipLaunchKernelGGL((mask_apply_fwd_kernel<TT>), EW_GRID(total), dim3(256), 0, (hipStream_t)s, (TT*)x, mask, token, pos, B, T, D, first, token_scalar));
+    MH_LAUNCH_CHECK("mh_mask_apply_fwd");
+    return MH_OK;
+}
+
+extern "C" int mh_mask_apply_bwd(void* dy, const float* mask, float* dtoken, float* dpos, int B, int T, int D, int first,
+                                 int token_scalar, int dt, mh_stream s) {
+    if (T == 0 || D == 0 || B == 0) return MH_OK;
+    dim3 grid(mh_cdiv(D, 64), mh_cdiv(T, MB_BAND));
+    MH_DISPATCH_DT(dt, TT, hipLaunchKernelGGL((mask_apply_bwd_kernel<TT>), grid, dim3(256), 0, (hipStream_t)s, (TT*)dy, mask, dtoken, dpos, B, T, D, first, token_scalar));
+    MH_LAUNCH_CHECK("mh_mask_apply_bwd");
+    return MH_OK;
+}
+
+// ------------------------------------------------------------------ reparameterisation (models/mirror.py:830-833)
+__global__ __launch_bounds__(256) void reparam_fwd_kernel(const float* mu, const float* ls, const float* eps, float* z, long n) {
+    EW_LOOP(i, n) z[i] = mu[i] + eps[i] * __expf(0.5f * ls[i]);
+}
+__global__ __launch_bounds__(256) void reparam_bwd_kernel(const float* ls, const float* eps, const float* dz, float* dmu, float* dls, long n) {
+    EW_LOOP(i, n) {
+        dmu[i] = dz[i];
+        dls[i] = dz[i] * eps[i] * 0.5f * __expf(0.5f * ls[i]);
+    }
+}
+extern "C" int mh_reparam_fwd(const float* mu, const float* logstd, const float* eps, float* z, int64_t n, mh_stream s) {
+    if (n == 0) return MH_OK;
+    hipLaunchKernelGGL(reparam_fwd_kernel, EW_GRID(n), dim3(256), 0, (hipStream_t)s, mu, logstd, eps, z, (long)n);
+    MH_LAUNCH_CHECK("mh_reparam_fwd");
+    return MH_OK;
+}
+extern "C" int mh_reparam_bwd(const float* logstd, const float* eps, const float* dz, float* dmu, float* dlogstd, int64_t n,
+                              mh_stream s) {
+    if (n == 0) return MH_OK;
+    hipLaunchKernelGGL(reparam_bwd_kernel, EW_GRID(n), dim3(256), 0, (hipStream_t)s, logstd, eps, dz, dmu, dlogstd, (long)n);
+    MH_LAUNCH_CHECK("mh_reparam_bwd");
+    return MH_OK;
+}
+
+// ------------------------------------------------------------------ RNA encoder attention (models/mirror.py:77-102)
+// The reference feeds a 2-D [B, D] tensor: q,k,v are [B, H, hd] and SDPA attends over the HEADS axis (an H x H
+// matrix per sample); the result is permuted by transpose(1,2).reshape(B, D): out[b, d*H + h] = o[h][d].
+#define HA_MAXH 16
+template <typename T>
+__global__ __launch_bounds__(256) void headattn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, float* __restrict__ attn,
+                                                           int H, int hd) {
+    extern __shared__ float sm[];  // q,k,v [3][H*hd] + a [H*H]
+    const int D = H * hd;
+    const long b = blockIdx.x;
+    float* q = sm; float* k = sm + D; float* v = sm + 2 * D; float* a = sm + 3 * D;
+    for (int i = threadIdx.x; i < 3 * D; i += 256) sm[i] = ldf(qkv + b * 3 * D + i);
+    __syncthreads();
+    const float scale = rsqrtf((float)hd);
+    for (int p = threadIdx.x; p < H * H; p += 256) {
+        const int h = p / H, g = p % H;
+        float s = 0.f;
+        for (int d = 0; d < hd; d++) s += q[h * hd + d] * k[g * hd + d];
+        a[p] = s * scale;
+    }
+    __syncthreads();
+    if (threadIdx.x < H) {
+        float* ar = a + threadIdx.x * H;
+        float m = -INFINITY;
+        for (int g = 0; g < H; g++) m = fmaxf(m, ar[g]);
+        float sum = 0.f;
+        for (int g = 0; g < H; g++) { ar[g] = __expf(ar[g] - m); sum += ar[g]; }
+        for (int g = 0; g < H; g++) { ar[g] /= sum; attn[b * H * H + threadIdx.x * H + g] = ar[g]; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < D; i += 256) {
+        const int d = i / H, h = i % H;  // output column i = d*H + h
+        float s = 0.f;
+        for (int g = 0; g < H; g++) s += a[h * H + g] * v[g * hd + d];
+        stf(out + b * D + i, s);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void headattn_bwd_kernel(const T* __restrict__ qkv, const float* __restrict__ attn,
+                                                           const T* __restrict__ dout, T* __restrict__ dqkv, int H, int hd) {
+    extern __shared__ float sm[];  // q,k,v [3D], do [D] (as [h][d]), a [H*H], ds [H*H]
+    const int D = H * hd;
+    const long b = blockIdx.x;
+    float* q = sm; float* k = sm + D; float* v = sm + 2 * D; float* dO = sm + 3 * D;
+    float* a = sm + 4 * D; float* ds = a + H * H;
+    for (int i = threadIdx.x; i < 3 * D; i += 256) sm[i] = ldf(qkv + b * 3 * D + i);
+    for (int i = threadIdx.x; i < D; i += 256) { const int d = i / H, h = i % H; dO[h * hd + d] = ldf(dout + b * D + i); }
+    for (int i = threadIdx.x; i < H * H; i += 256) a[i] = attn[b * H * H + i];
+    __syncthreads();
+    // da[h][g] = sum_d dO[h][d] v[g][d]
+    for (int p = threadIdx.x; p < H * H; p += 256) {
+        const int h = p / H, g = p % H;
+        float s = 0.f;
+        for (int d = 0; d < hd; d++) s += dO[h * hd + d] * v[g * hd + d];
+        ds[p] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < H) {
+        const int h = threadIdx.x;
+        float dot = 0.f;
+        for (int g = 0; g < H; g++) dot += ds[h * H + g] * a[h * H + g];
+        for (int g = 0; g < H; g++) ds[h * H + g] = a[h * H + g] * (ds[h * H + g] - dot);
+    }
+    __syncthreads();
+    const float scale = rsqrtf((float)hd);
+    for (int i = threadIdx.x; i < D; i += 256) {
+        const int h = i / hd, d = i % hd;
+        float dq = 0.f, dk = 0.f, dv = 0.f;
+        for (int g = 0; g < H; g++) {
+            dq += ds[h * H + g] * k[g * hd + d];
+            dk += ds[g * H + h] * q[g * hd + d];
+            dv += a[g * H + h] * dO[g * hd + d];
+        }
+        stf(dqkv + b * 3 * D + i, dq * scale);
+        stf(dqkv + b * 3 * D + D + i, dk * scale);
+        stf(dqkv + b * 3 * D + 2 * D + i, dv);
+    }
+}
+
+extern "C" int mh_headattn_fwd(const void* qkv, void* out, float* attn, int B, int H, int hd, int dt, mh_stream s) {
+    MH_REQUIRE(H >= 1 && H <= 64 && (long)H * hd <= 4096, "mh_headattn_fwd: H=%d hd=%d unsupported", H, hd);
+    if (B == 0) return MH_OK;
+    const size_t lds = (3 * (size_t)H * hd + (size_t)H * H) * sizeof(float);
+    MH_DISPATCH_DT(dt, T, hipLaunchKernelGGL((headattn_fwd_kernel<T>), dim3(B), dim3(256), lds, (hipStream_t)s, (const T*)qkv, (T*)out, attn, H, hd));
+    MH_LAUNCH_CHECK("mh_headattn_fwd");
+    return MH_OK;
+}
+
+extern "C" int mh_headattn_bwd(const void* qkv, const float* attn, const void* dout, void* dqkv, int B, int H, int hd, int dt,
+                               mh_stream s) {
+    MH_REQUIRE(H >= 1 && H <= 64 && (long)H * hd <= 4096, "mh_headattn_bwd: H=%d hd=%d unsupported", H, hd);
+    if (B == 0) return MH_OK;
+    const size_t lds = (4 * (size_t)H * hd + 2 * (size_t)H * H) * sizeof(float);
+    MH_DISPATCH_DT(dt, T, hipLaunchKernelGGL((headattn_bwd_kernel<T>), dim3(B), dim3(256), lds, (hipStream_t)s, (const T*)qkv, attn, (const T*)dout, (T*)dqkv, H, hd));
+    MH_LAUNCH_CHECK("mh_headattn_bwd");
+    return MH_OK;
+}

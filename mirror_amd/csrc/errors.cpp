@@ -1,0 +1,32 @@
+// Error string + device probe for libmirror_hip.
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void mh_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* mh_last_error(void) { return g_err; }
+extern "C" int mh_version(void) { return 100; }
+
+extern "C" int mh_device_ok(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        mh_set_error("mh_device_ok: no HIP device visible");
+        return 0;
+    }
+    int ok = 0;
+    for (int i = 0; i < n; i++) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, i) == hipSuccess && strstr(p.gcnArchName, "gfx950")) ok++;
+    }
+    if (!ok) mh_set_error("mh_device_ok: no gfx950 device (this library is MI355X-only)");
+    return ok;
+}

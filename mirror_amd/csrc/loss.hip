@@ -1,0 +1,318 @@
+// Loss kernels: CLIP / InfoNCE cross-entropy over logit rows, masked MSE (retention), style KL, symmetric
+// KL between prototype soft assignments (losses/mirror_loss.py:74-135, losses/info_nce.py:144-164), plus
+// the step glue of train_mirror.py (prototype row-normalise :1133-1136, logit_scale clamp :1254-1255, Adam :1230).
+// Scalars accumulate with f32 atomics into caller-zeroed device words: no host synchronisation anywhere.
+#include "common.h"
+
+// ------------------------------------------------------------------ cross-entropy rows
+// logits L = (scale*scale_mul) * G; row r has label (label_off + r). One wave per row.
+__global__ __launch_bounds__(256) void ce_rows_fwd_kernel(const float* __restrict__ G, long ldg, const float* __restrict__ scale,
+                                                          float scale_mul, int R, int C, int label_off, float coef,
+                                                          float* __restrict__ loss_rows, float* __restrict__ lse,
+                                                          float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float s = (scale ? scale[0] : 1.f) * scale_mul;
+    const float* g = G + (long)r * ldg;
+    float m = -INFINITY;
+    for (int c = lane; c < C; c += 64) m = fmaxf(m, s * g[c]);
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int c = lane; c < C; c += 64) sum += __expf(s * g[c] - m);
+    sum = wave_sum(sum);
+    if (lane == 0) {
+        const float l = m + __logf(sum);
+        const float loss = l - s * g[label_off + r];
+        lse[r] = l;
+        if (loss_rows) loss_rows[r] = loss;
+        if (out) atomicAdd(out, coef * loss);
+    }
+}
+
+// dG[r,c] = w_r * s * (softmax(L)[r,c] - [c == label]);  dscale += scale_mul * sum_rc w_r * (softmax - onehot) * G
+// w_r = gcoef * (g_per_row ? g[r] : g[0])
+__global__ __launch_bounds__(256) void ce_rows_bwd_kernel(const float* __restrict__ G, long ldg, const float* __restrict__ scale,
+                                                          float scale_mul, const float* __restrict__ lse,
+                                                          const float* __restrict__ g, int g_per_row, float gcoef,
+                                                          float* __restrict__ dG, float* __restrict__ dscale, int R, int C,
+                                                          int label_off) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float s = (scale ? scale[0] : 1.f) * scale_mul;
+    const float w = gcoef * (g_per_row ? g[r] : g[0]);
+    const float* gr = G + (long)r * ldg;
+    const float l = lse[r];
+    float ds = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float p = __expf(s * gr[c] - l) - (c == label_off + r ? 1.f : 0.f);
+        dG[(long)r * C + c] = w * s * p;
+        ds += w * p * gr[c];
+    }
+    ds = wave_sum(ds);
+    if (lane == 0 && dscale) atomicAdd(dscale, ds * scale_mul);
+}
+
+extern "C" int mh_ce_rows_fwd(const float* G, int64_t ldg, const float* scale, float scale_mul, int R, int C, int label_off,
+                              float coef, float* loss_rows, float* lse, float* out, mh_stream s) {
+    MH_REQUIRE(label_off >= 0 && label_off + R <= C, "mh_ce_rows_fwd: labels [%d,%d) outside %d columns", label_off, label_off + R, C);
+    if (R == 0) return MH_OK;
+    hipLaunchKernelGGL(ce_rows_fwd_kernel, dim3(mh_cdiv(R, 4)), dim3(256), 0, (hipStream_t)s, G, (long)ldg, scale, scale_mul, R, C, label_off, coef, loss_rows, lse, out);
+    MH_LAUNCH_CHECK("mh_ce_rows_fwd");
+    return MH_OK;
+}
+
+extern "C" int mh_ce_rows_bwd(const float* G, int64_t ldg, const float* scale, float scale_mul, const float* lse, const float* g,
+                              int g_per_row, float gcoef, float* dG, float* dscale, int R, int C, int label_off, mh_stream s) {
+    if (R == 0) return MH_OK;
+    hipLaunchKernelGGL(ce_rows_bwd_kernel, dim3(mh_cdiv(R, 4)), dim3(256), 0, (hipStream_t)s, G, (long)ldg, scale, scale_mul, lse, g, g_per_row, gcoef, dG, dscale, R, C, label_off);
+    MH_LAUNCH_CHECK("mh_ce_rows_bwd");
+    return MH_OK;
+}
+
+// ------------------------------------------------------------------ masked MSE (retention losses)
+// acc[0] += sum_r mask[r] * (1/D) sum_d (p-t)^2 ; acc[1] += sum_r mask[r]; one wave per row, grid-stride
+template <typename TP, typename TT>
+__global__ __launch_bounds__(256) void mse_masked_fwd_kernel(const TP* __restrict__ pred, const TT* __restrict__ tgt,
+                                                             const float* __restrict__ mask, float* __restrict__ acc, long rows, int D) {
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float num = 0.f, den = 0.f;
+    for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
+        const float mk = mask[r];
+        den += mk;  // every lane carries it; only lane 0's copy is used below
+        if (mk != 0.f) {
+            float s = 0.f;
+            for (int c = lane; c < D; c += 64) {
+                const float d = ldf(pred + r * D + c) - ldf(tgt + r * D + c);
+                s += d * d;
+            }
+            num += mk * s / D;
+        }
+    }
+    num = block_sum256(num, red);
+    den = block_sum256(lane == 0 ? den : 0.f, red);
+    if (threadIdx.x == 0) { atomicAdd(acc, num); atomicAdd(acc + 1, den); }
+}
+
+template <typename TP, typename TT, typename TD>
+__global__ __launch_bounds__(256) void mse_masked_bwd_kernel(const TP* __restrict__ pred, const TT* __restrict__ tgt,
+                                                             const float* __restrict__ mask, const float* __restrict__ acc,
+                                                             const float* __restrict__ g, TD* __restrict__ dpred, TD* __restrict__ dtgt,
+                                                             long rows, int D) {
+    const float k = g[0] * 2.f / ((float)D * acc[1]);
+    const long total = rows * D;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const float mk = mask[i / D];
+        const float d = mk != 0.f ? k * mk * (ldf(pred + i) - ldf(tgt + i)) : 0.f;
+        stf(dpred + i, d);
+        stf(dtgt + i, -d);
+    }
+}
+
+extern "C" int mh_mse_masked_fwd(const void* pred, const void* tgt, const float* mask, float* acc, int64_t rows, int D,
+                                 int dt_p, int dt_t, mh_stream s) {
+    if (rows == 0) return MH_OK;
+    dim3 grid((unsigned)min((long)mh_cdiv(rows, 4), 2048L));
+#define MSEF(TP, TT) hipLaunchKernelGGL((mse_masked_fwd_kernel<TP, TT>), grid, dim3(256), 0, (hipStream_t)s, (const TP*)pred, (const TT*)tgt, mask, acc, (long)rows, D)
+    if (dt_p == MH_F32 && dt_t == MH_F32) MSEF(float, float);
+    else if (dt_p == MH_BF16 && dt_t == MH_BF16) MSEF(bf16_t, bf16_t);
+    else if (dt_p == MH_F32) MSEF(float, bf16_t);
+    else MSEF(bf16_t, float);
+#undef MSEF
+    MH_LAUNCH_CHECK("mh_mse_masked_fwd");
+    return MH_OK;
+}
+
+extern "C" int mh_mse_masked_bwd(const void* pred, const void* tgt, const float* mask, const float* acc, const float* g,
+                                 void* dpred, void* dtgt, int64_t rows, int D, int dt_p, int dt_t, int dt_d, mh_stream s) {
+    if (rows == 0) return MH_OK;
+    MH_REQUIRE(dt_p == dt_t, "mh_mse_masked_bwd: pred/target dtype mismatch");
+    dim3 grid((unsigned)min((long)mh_cdiv(rows * D, 256), 16384L));
+#define MSEB(TP, TD) hipLaunchKernelGGL((mse_masked_bwd_kernel<TP, TP, TD>), grid, dim3(256), 0, (hipStream_t)s, (const TP*)pred, (const TP*)tgt, mask, acc, g, (TD*)dpred, (TD*)dtgt, (long)rows, D)
+    if (dt_p == MH_F32 && dt_d == MH_F32) MSEB(float, float);
+    else if (dt_p == MH_BF16 && dt_d == MH_BF16) MSEB(bf16_t, bf16_t);
+    else if (dt_p == MH_F32) MSEB(float, bf16_t);
+    else MSEB(bf16_t, float);
+#undef MSEB
+    MH_LAUNCH_CHECK("mh_mse_masked_bwd");
+    return MH_OK;
+}
+
+// ------------------------------------------------------------------ style KL to N(0, I)
+__global__ __launch_bounds__(256) void kl_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ ls, float* __restrict__ out,
+                                                     long n, float coef) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        s += __expf(ls[i]) + mu[i] * mu[i] - 1.f - ls[i];
+    s = block_sum256(s, red);
+    if (threadIdx.x == 0) atomicAdd(out, coef * s);
+}
+__global__ __launch_bounds__(256) void kl_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ ls, const float* __restrict__ g,
+                                                     float* __restrict__ dmu, float* __restrict__ dls, long n, float coef) {
+    const float k = g[0] * coef;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        dmu[i] = k * 2.f * mu[i];
+        dls[i] = k * (__expf(ls[i]) - 1.f);
+    }
+}
+extern "C" int mh_kl_fwd(const float* mu, const float* ls, float* out, int64_t n, float coef, mh_stream s) {
+    if (n == 0) return MH_OK;
+    hipLaunchKernelGGL(kl_fwd_kernel, dim3((unsigned)min((long)mh_cdiv(n, 256), 1024L)), dim3(256), 0, (hipStream_t)s, mu, ls, out, (long)n, coef);
+    MH_LAUNCH_CHECK("mh_kl_fwd");
+    return MH_OK;
+}
+extern "C" int mh_kl_bwd(const float* mu, const float* ls, const float* g, float* dmu, float* dls, int64_t n, float coef, mh_stream s) {
+    if (n == 0) return MH_OK;
+    hipLaunchKernelGGL(kl_bwd_kernel, dim3((unsigned)min((long)mh_cdiv(n, 256), 1024L)), dim3(256), 0, (hipStream_t)s, mu, ls, g, dmu, dls, (long)n, coef);
+    MH_LAUNCH_CHECK("mh_kl_bwd");
+    return MH_OK;
+}
+
+// ------------------------------------------------------------------ symmetric KL of two softmaxes (cluster loss)
+// per row: term = sum_k (p_r - p_w)(log p_r - log p_w); one 256-thread block per row
+struct RowStats { float mw, sw, mr, sr; };
+__device__ __forceinline__ RowStats row_stats(const float* w, const float* r, int P, float* red) {
+    float mw = -INFINITY, mr = -INFINITY;
+    for (int k = threadIdx.x; k < P; k += 256) { mw = fmaxf(mw, w[k]); mr = fmaxf(mr, r[k]); }
+    mw = block_max256(mw, red);
+    mr = block_max256(mr, red);
+    float sw = 0.f, sr = 0.f;
+    for (int k = threadIdx.x; k < P; k += 256) { sw += __expf(w[k] - mw); sr += __expf(r[k] - mr); }
+    sw = block_sum256(sw, red);
+    sr = block_sum256(sr, red);
+    return {mw, __logf(sw), mr, __logf(sr)};
+}
+
+__global__ __launch_bounds__(256) void symkl_fwd_kernel(const float* __restrict__ w, const float* __restrict__ r, float* __restrict__ out,
+                                                        int P, float coef) {
+    __shared__ float red[4];
+    const float* wr = w + (long)blockIdx.x * P;
+    const float* rr = r + (long)blockIdx.x * P;
+    const RowStats st = row_stats(wr, rr, P, red);
+    float s = 0.f;
+    for (int k = threadIdx.x; k < P; k += 256) {
+        const float lw = wr[k] - st.mw - st.sw, lr = rr[k] - st.mr - st.sr;
+        s += (__expf(lr) - __expf(lw)) * (lr - lw);
+    }
+    s = block_sum256(s, red);
+    if (threadIdx.x == 0) atomicAdd(out, coef * s);
+}
+
+// d term / d r_k = p_r,k (d_k - E_r[d]) + q_k ;  d term / d w_k = -p_w,k (d_k - E_w[d]) - q_k ;  d = lr - lw, q = p_r - p_w
+__global__ __launch_bounds__(256) void symkl_bwd_kernel(const float* __restrict__ w, const float* __restrict__ r, const float* __restrict__ g,
+                                                        float* __restrict__ dw, float* __restrict__ dr, int P, float coef) {
+    __shared__ float red[4];
+    const long base = (long)blockIdx.x * P;
+    const float* wr = w + base;
+    const float* rr = r + base;
+    const RowStats st = row_stats(wr, rr, P, red);
+    float er = 0.f, ew = 0.f;
+    for (int k = threadIdx.x; k < P; k += 256) {
+        const float lw = wr[k] - st.mw - st.sw, lr = rr[k] - st.mr - st.sr;
+        er += __expf(lr) * (lr - lw);
+        ew += __expf(lw) * (lr - lw);
+    }
+    er = block_sum256(er, red);
+    ew = block_sum256(ew, red);
+    const float c = g[0] * coef;
+    for (int k = threadIdx.x; k < P; k += 256) {
+        const float lw = wr[k] - st.mw - st.sw, lr = rr[k] - st.mr - st.sr;
+        const float pw = __expf(lw), pr = __expf(lr), d = lr - lw, q = pr - pw;
+        dr[base + k] = c * (pr * (d - er) + q);
+        dw[base + k] = c * (-pw * (d - ew) - q);
+    }
+}
+
+extern "C" int mh_symkl_fwd(const float* w, const float* r, float* out, int B, int P, float coef, mh_stream s) {
+    if (B == 0) return MH_OK;
+    hipLaunchKernelGGL(symkl_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)s, w, r, out, P, coef);
+    MH_LAUNCH_CHECK("mh_symkl_fwd");
+    return MH_OK;
+}
+extern "C" int mh_symkl_bwd(const float* w, const float* r, const float* g, float* dw, float* dr, int B, int P, float coef, mh_stream s) {
+    if (B == 0) return MH_OK;
+    hipLaunchKernelGGL(symkl_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)s, w, r, g, dw, dr, P, coef);
+    MH_LAUNCH_CHECK("mh_symkl_bwd");
+    return MH_OK;
+}
+
+// ------------------------------------------------------------------ step glue
+__global__ __launch_bounds__(256) void rownorm_kernel(float* w, int rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* wr = w + (long)row * D;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) s += wr[c] * wr[c];
+    const float n = fmaxf(sqrtf(wave_sum(s)), eps);
+    for (int c = lane; c < D; c += 64) wr[c] = wr[c] / n;
+}
+extern "C" int mh_rownorm_(float* w, int rows, int D, float eps, mh_stream s) {
+    if (rows == 0) return MH_OK;
+    hipLaunchKernelGGL(rownorm_kernel, dim3(mh_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)s, w, rows, D, eps);
+    MH_LAUNCH_CHECK("mh_rownorm_");
+    return MH_OK;
+}
+
+__global__ void clamp_kernel(float* x, long n, float lo, float hi) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] = fminf(fmaxf(x[i], lo), hi);
+}
+extern "C" int mh_clamp_(float* x, int64_t n, float lo, float hi, mh_stream s) {
+    if (n == 0) return MH_OK;
+    hipLaunchKernelGGL(clamp_kernel, dim3((unsigned)min((long)mh_cdiv(n, 256), 1024L)), dim3(256), 0, (hipStream_t)s, x, (long)n, lo, hi);
+    MH_LAUNCH_CHECK("mh_clamp_");
+    return MH_OK;
+}
+
+// torch.optim.Adam semantics (no weight decay, no amsgrad): 4 floats per thread, 16-B accesses (HBM-bound: 28 B/param)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, bf16_t* __restrict__ shadow, long n, float lr, float b1,
+                                                   float b2, float eps, float bc1, float bc2, float gscale) {
+    const float step = lr / bc1;
+    const float isq = rsqrtf(bc2);
+    const long n4 = n / 4;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long)gridDim.x * 256) {
+        float4 pp = reinterpret_cast<float4*>(p)[q];
+        const float4 gg = reinterpret_cast<const float4*>(g)[q];
+        float4 mm = reinterpret_cast<float4*>(m)[q];
+        float4 vv = reinterpret_cast<float4*>(v)[q];
+        float* pa = &pp.x; const float* ga = &gg.x; float* ma = &mm.x; float* va = &vv.x;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const float gr = ga[e] * gscale;
+            ma[e] = b1 * ma[e] + (1.f - b1) * gr;
+            va[e] = b2 * va[e] + (1.f - b2) * gr * gr;
+            pa[e] -= step * ma[e] / (sqrtf(va[e]) * isq + eps);
+        }
+        reinterpret_cast<float4*>(p)[q] = pp;
+        reinterpret_cast<float4*>(m)[q] = mm;
+        reinterpret_cast<float4*>(v)[q] = vv;
+        if (shadow) {
+            uint2 sh;
+            sh.x = (uint32_t)f2bf(pa[0]) | ((uint32_t)f2bf(pa[1]) << 16);
+            sh.y = (uint32_t)f2bf(pa[2]) | ((uint32_t)f2bf(pa[3]) << 16);
+            reinterpret_cast<uint2*>(shadow)[q] = sh;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long i = n4 * 4 + threadIdx.x;
+        const float gr = g[i] * gscale;
+        m[i] = b1 * m[i] + (1.f - b1) * gr;
+        v[i] = b2 * v[i] + (1.f - b2) * gr * gr;
+        p[i] -= step * m[i] / (sqrtf(v[i]) * isq + eps);
+        if (shadow) shadow[i] = f2bf(p[i]);
+    }
+}
+
+extern "C" int mh_adam(float* p, const float* g, float* m, float* v, void* shadow, int64_t n, float lr, float b1, float b2,
+                       float eps, float bc1, float bc2, float gscale, mh_stream s) {
+    if (n == 0) return MH_OK;
+    MH_REQUIRE(((uintptr_t)p & 15) == 0 && ((uintptr_t)g & 15) == 0 && ((uintptr_t)m & 15) == 0 && ((uintptr_t)v & 15) == 0 &&
+                   ((uintptr_t)shadow & 7) == 0, "mh_adam: buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)min((long)mh_cdiv(mh_cdiv(n, 4), 256), 8192L)), dim3(256), 0, (hipStream_t)s, p, g, m, v, (bf16_t*)shadow, (long)n, lr, b1, b2, eps, bc1, bc2, gscale);
+    MH_LAUNCH_CHECK("mh_adam");
+    return MH_OK;
+}

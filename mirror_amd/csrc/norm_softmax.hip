@@ -1,0 +1,281 @@
+// Row-wise kernels: LayerNorm fwd/bwd, softmax fwd/bwd, L2-normalise fwd/bwd.
+// One wave64 per row (shuffle reductions); long softmax rows use one 256-thread block per row.
+#include "common.h"
+
+#define LN_MAXPL 32  // values per lane kept in registers -> D <= 2048
+
+template <typename TX, typename TY>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const TX* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, TY* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd,
+                                                            long rows, int rpb, int D, long x_bs, long y_bs, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const long b = row / rpb, i = row % rpb;
+    const TX* xr = x + b * x_bs + i * D;
+    TY* yr = y + b * y_bs + i * D;
+    float v[LN_MAXPL];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXPL; k++) {
+        const int c = lane + 64 * k;
+        v[k] = (c < D) ? ldf(xr + c) : 0.f;
+        s += v[k];
+    }
+    const float mu = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXPL; k++) {
+        const int c = lane + 64 * k;
+        const float d = (c < D) ? v[k] - mu : 0.f;
+        q += d * d;
+    }
+    const float rs = rsqrtf(wave_sum(q) / D + eps);
+#pragma unroll
+    for (int k = 0; k < LN_MAXPL; k++) {
+        const int c = lane + 64 * k;
+        if (c < D) stf(yr + c, (v[k] - mu) * rs * gamma[c] + beta[c]);
+    }
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+// dx = rstd * (g*dy - mean(g*dy) - xhat*mean(g*dy*xhat)); dgamma += dy*xhat; dbeta += dy
+template <typename TX, typename TDY, typename TDX>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, TDX* __restrict__ dx,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            long rows, int rpb, int D, long x_bs, long y_bs, int acc_dx) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float pg[LN_MAXPL], pb[LN_MAXPL];
+#pragma unroll
+    for (int k = 0; k < LN_MAXPL; k++) { pg[k] = 0.f; pb[k] = 0.f; }
+    for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+        const long b = row / rpb, i = row % rpb;
+        const TX* xr = x + b * x_bs + i * D;
+        const TDY* dyr = dy + b * y_bs + i * D;
+        TDX* dxr = dx + b * x_bs + i * D;
+        const float mu = mean[row], rs = rstd[row];
+        float xh[LN_MAXPL], gd[LN_MAXPL];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < LN_MAXPL; k++) {
+            const int c = lane + 64 * k;
+            if (c < D) {
+                const float d = ldf(dyr + c);
+                xh[k] = (ldf(xr + c) - mu) * rs;
+                gd[k] = d * gamma[c];
+                pg[k] += d * xh[k];
+                pb[k] += d;
+                s1 += gd[k];
+                s2 += gd[k] * xh[k];
+            } else { xh[k] = 0.f; gd[k] = 0.f; }
+        }
+        s1 = wave_sum(s1) / D;
+        s2 = wave_sum(s2) / D;
+#pragma unroll
+        for (int k = 0; k < LN_MAXPL; k++) {
+            const int c = lane + 64 * k;
+            if (c < D) {
+                float r = rs * (gd[k] - s1 - xh[k] * s2);
+                if (acc_dx) r += ldf(dxr + c);
+                stf(dxr + c, r);
+            }
+        }
+    }
+    // reduce the 4 waves' column partials through LDS, one atomic per column per block
+    __shared__ float red[2][4][64];
+#pragma unroll
+    for (int k = 0; k < LN_MAXPL; k++) {
+        if (64 * k >= D) break;
+        __syncthreads();
+        red[0][wave][lane] = pg[k];
+        red[1][wave][lane] = pb[k];
+        __syncthreads();
+        if (wave == 0) {
+            const int c = lane + 64 * k;
+            if (c < D) {
+                atomicAdd(dgamma + c, red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]);
+                atomicAdd(dbeta + c, red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]);
+            }
+        }
+    }
+}
+
+extern "C" int mh_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                int batches, int rpb, int D, int64_t x_bs, int64_t y_bs, float eps, int dt_x, int dt_y,
+                                mh_stream s) {
+    MH_REQUIRE(D >= 1 && D <= 64 * LN_MAXPL, "mh_layernorm_fwd: D=%d unsupported (max %d)", D, 64 * LN_MAXPL);
+    const long rows = (long)batches * rpb;
+    if (rows == 0) return MH_OK;
+    dim3 grid(mh_cdiv(rows, 4));
+#define LN_F(TX, TY) hipLaunchKernelGGL((layernorm_fwd_kernel<TX, TY>), grid, dim3(256), 0, (hipStream_t)s, (const TX*)x, gamma, beta, (TY*)y, mean, rstd, rows, rpb, D, (long)x_bs, (long)y_bs, eps)
+    if (dt_x == MH_F32 && dt_y == MH_F32) LN_F(float, float);
+    else if (dt_x == MH_F32 && dt_y == MH_BF16) LN_F(float, bf16_t);
+    else if (dt_x == MH_BF16 && dt_y == MH_BF16) LN_F(bf16_t, bf16_t);
+    else LN_F(bf16_t, float);
+#undef LN_F
+    MH_LAUNCH_CHECK("mh_layernorm_fwd");
+    return MH_OK;
+}
+
+extern "C" int mh_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                void* dx, float* dgamma, float* dbeta, int batches, int rpb, int D, int64_t x_bs,
+                                int64_t y_bs, int dt_x, int dt_dy, int dt_dx, int acc_dx, mh_stream s) {
+    MH_REQUIRE(D >= 1 && D <= 64 * LN_MAXPL, "mh_layernorm_bwd: D=%d unsupported", D);
+    MH_REQUIRE(dt_dx == dt_x, "mh_layernorm_bwd: dx dtype must equal x dtype");
+    const long rows = (long)batches * rpb;
+    if (rows == 0) return MH_OK;
+    dim3 grid((unsigned)min((long)mh_cdiv(rows, 4), 1024L));
+#define LN_B(TX, TDY) hipLaunchKernelGGL((layernorm_bwd_kernel<TX, TDY, TX>), grid, dim3(256), 0, (hipStream_t)s, (const TDY*)dy, (const TX*)x, gamma, mean, rstd, (TX*)dx, dgamma, dbeta, rows, rpb, D, (long)x_bs, (long)y_bs, acc_dx)
+    if (dt_x == MH_F32 && dt_dy == MH_F32) LN_B(float, float);
+    else if (dt_x == MH_F32 && dt_dy == MH_BF16) LN_B(float, bf16_t);
+    else if (dt_x == MH_BF16 && dt_dy == MH_BF16) LN_B(bf16_t, bf16_t);
+    else LN_B(bf16_t, float);
+#undef LN_B
+    MH_LAUNCH_CHECK("mh_layernorm_bwd");
+    return MH_OK;
+}
+
+// ------------------------------------------------------------------------------ softmax
+// WAVE=true: one wave per row (4 rows per block); WAVE=false: one block per row.
+template <typename TX, typename TY, bool WAVE>
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const TX* x, TY* y, long rows,
+                                                          int cols, long ldx, long ldy) {
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63;
+    const long row = WAVE ? (long)blockIdx.x * 4 + (threadIdx.x >> 6) : (long)blockIdx.x;
+    if (WAVE && row >= rows) return;
+    const int t0 = WAVE ? lane : threadIdx.x, step = WAVE ? 64 : 256;
+    const TX* xr = x + row * ldx;
+    TY* yr = y + row * ldy;
+    float m = -INFINITY;
+    for (int c = t0; c < cols; c += step) m = fmaxf(m, ldf(xr + c));
+    m = WAVE ? wave_max(m) : block_max256(m, red);
+    float sum = 0.f;
+    for (int c = t0; c < cols; c += step) sum += __expf(ldf(xr + c) - m);
+    sum = WAVE ? wave_sum(sum) : block_sum256(sum, red);
+    const float inv = 1.f / sum;
+    for (int c = t0; c < cols; c += step) stf(yr + c, __expf(ldf(xr + c) - m) * inv);
+}
+
+template <typename TY, typename TDY, typename TDX, bool WAVE>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const TY* y, const TDY* dy,
+                                                          TDX* dx, long rows, int cols, long ldy, long lddy,
+                                                          long lddx) {
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63;
+    const long row = WAVE ? (long)blockIdx.x * 4 + (threadIdx.x >> 6) : (long)blockIdx.x;
+    if (WAVE && row >= rows) return;
+    const int t0 = WAVE ? lane : threadIdx.x, step = WAVE ? 64 : 256;
+    const TY* yr = y + row * ldy;
+    const TDY* dyr = dy + row * lddy;
+    TDX* dxr = dx + row * lddx;
+    float dot = 0.f;
+    for (int c = t0; c < cols; c += step) dot += ldf(yr + c) * ldf(dyr + c);
+    dot = WAVE ? wave_sum(dot) : block_sum256(dot, red);
+    for (int c = t0; c < cols; c += step) stf(dxr + c, ldf(yr + c) * (ldf(dyr + c) - dot));
+}
+
+extern "C" int mh_softmax_fwd(const void* x, void* y, int64_t rows, int cols, int64_t ldx, int64_t ldy, int dt_x,
+                              int dt_y, mh_stream s) {
+    MH_REQUIRE(cols >= 1, "mh_softmax_fwd: cols=%d", cols);
+    if (rows == 0) return MH_OK;
+    const bool wave = cols <= 1024;
+    dim3 grid(wave ? mh_cdiv(rows, 4) : (unsigned)rows);
+#define SM_F(TX, TY)                                                                                                   \
+    if (wave) hipLaunchKernelGGL((softmax_fwd_kernel<TX, TY, true>), grid, dim3(256), 0, (hipStream_t)s, (const TX*)x, (TY*)y, (long)rows, cols, (long)ldx, (long)ldy); \
+    else hipLaunchKernelGGL((softmax_fwd_kernel<TX, TY, false>), grid, dim3(256), 0, (hipStream_t)s, (const TX*)x, (TY*)y, (long)rows, cols, (long)ldx, (long)ldy)
+    if (dt_x == MH_F32 && dt_y == MH_F32) { SM_F(float, float); }
+    else if (dt_x == MH_F32 && dt_y == MH_BF16) { SM_F(float, bf16_t); }
+    else if (dt_x == MH_BF16 && dt_y == MH_BF16) { SM_F(bf16_t, bf16_t); }
+    else { SM_F(bf16_t, float); }
+#undef SM_F
+    MH_LAUNCH_CHECK("mh_softmax_fwd");
+    return MH_OK;
+}
+
+extern "C" int mh_softmax_bwd(const void* y, const void* dy, void* dx, int64_t rows, int cols, int64_t ldy, int64_t lddy,
+                              int64_t lddx, int dt_y, int dt_dy, int dt_dx, mh_stream s) {
+    MH_REQUIRE(cols >= 1, "mh_softmax_bwd: cols=%d", cols);
+    MH_REQUIRE(dt_dy == dt_dx, "mh_softmax_bwd: dy and dx dtypes must match");
+    if (rows == 0) return MH_OK;
+    const bool wave = cols <= 1024;
+    dim3 grid(wave ? mh_cdiv(rows, 4) : (unsigned)rows);
+#define SM_B(TY, TD)                                                                                                   \
+    if (wave) hipLaunchKernelGGL((softmax_bwd_kernel<TY, TD, TD, true>), grid, dim3(256), 0, (hipStream_t)s, (const TY*)y, (const TD*)dy, (TD*)dx, (long)rows, cols, (long)ldy, (long)lddy, (long)lddx); \
+    else hipLaunchKernelGGL((softmax_bwd_kernel<TY, TD, TD, false>), grid, dim3(256), 0, (hipStream_t)s, (const TY*)y, (const TD*)dy, (TD*)dx, (long)rows, cols, (long)ldy, (long)lddy, (long)lddx)
+    if (dt_y == MH_F32 && dt_dy == MH_F32) { SM_B(float, float); }
+    else if (dt_y == MH_F32 && dt_dy == MH_BF16) { SM_B(float, bf16_t); }
+    else if (dt_y == MH_BF16 && dt_dy == MH_BF16) { SM_B(bf16_t, bf16_t); }
+    else { SM_B(bf16_t, float); }
+#undef SM_B
+    MH_LAUNCH_CHECK("mh_softmax_bwd");
+    return MH_OK;
+}
+
+// ------------------------------------------------------------------------------ L2 normalise
+template <typename TX, typename TY>
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const TX* __restrict__ x, TY* __restrict__ y, float* __restrict__ nrm,
+                                                         int rows, int D, long x_rs, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const TX* xr = x + (long)row * x_rs;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) { const float v = ldf(xr + c); s += v * v; }
+    const float n = fmaxf(sqrtf(wave_sum(s)), eps);
+    for (int c = lane; c < D; c += 64) stf(y + (long)row * D + c, ldf(xr + c) / n);
+    if (lane == 0) nrm[row] = n;
+}
+
+// dx = (dy - y*(y.dy)) / n
+template <typename TY, typename TDY, typename TDX>
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const TY* __restrict__ y, const float* __restrict__ nrm,
+                                                         const TDY* __restrict__ dy, TDX* __restrict__ dx, int rows, int D,
+                                                         long dx_rs, int acc) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float dot = 0.f;
+    for (int c = lane; c < D; c += 64) dot += ldf(y + (long)row * D + c) * ldf(dy + (long)row * D + c);
+    dot = wave_sum(dot);
+    const float inv = 1.f / nrm[row];
+    for (int c = lane; c < D; c += 64) {
+        float r = (ldf(dy + (long)row * D + c) - ldf(y + (long)row * D + c) * dot) * inv;
+        TDX* p = dx + (long)row * dx_rs + c;
+        if (acc) r += ldf(p);
+        stf(p, r);
+    }
+}
+
+extern "C" int mh_l2norm_fwd(const void* x, void* y, float* nrm, int rows, int D, int64_t x_rs, float eps, int dt_x,
+                             int dt_y, mh_stream s) {
+    if (rows == 0) return MH_OK;
+    dim3 grid(mh_cdiv(rows, 4));
+#define L2_F(TX, TY) hipLaunchKernelGGL((l2norm_fwd_kernel<TX, TY>), grid, dim3(256), 0, (hipStream_t)s, (const TX*)x, (TY*)y, nrm, rows, D, (long)x_rs, eps)
+    if (dt_x == MH_F32 && dt_y == MH_F32) L2_F(float, float);
+    else if (dt_x == MH_F32 && dt_y == MH_BF16) L2_F(float, bf16_t);
+    else if (dt_x == MH_BF16 && dt_y == MH_BF16) L2_F(bf16_t, bf16_t);
+    else L2_F(bf16_t, float);
+#undef L2_F
+    MH_LAUNCH_CHECK("mh_l2norm_fwd");
+    return MH_OK;
+}
+
+extern "C" int mh_l2norm_bwd(const void* y, const float* nrm, const void* dy, void* dx, int rows, int D, int64_t dx_rs,
+                             float eps, int dt_y, int dt_dy, int dt_dx, int acc, mh_stream s) {
+    (void)eps;
+    MH_REQUIRE(dt_y == dt_dy, "mh_l2norm_bwd: y and dy dtypes must match");
+    if (rows == 0) return MH_OK;
+    dim3 grid(mh_cdiv(rows, 4));
+#define L2_B(TY, TDX) hipLaunchKernelGGL((l2norm_bwd_kernel<TY, TY, TDX>), grid, dim3(256), 0, (hipStream_t)s, (const TY*)y, nrm, (const TY*)dy, (TDX*)dx, rows, D, (long)dx_rs, acc)
+    if (dt_y == MH_F32 && dt_dx == MH_F32) L2_B(float, float);
+    else if (dt_y == MH_F32 && dt_dx == MH_BF16) L2_B(float, bf16_t);
+    else if (dt_y == MH_BF16 && dt_dx == MH_BF16) L2_B(bf16_t, bf16_t);
+    else L2_B(bf16_t, float);
+#undef L2_B
+    MH_LAUNCH_CHECK("mh_l2norm_bwd");
+    return MH_OK;
+}

@@ -1,0 +1,142 @@
+// PPEG (models/mirror.py:317-331): proj7(x) + x + proj5(x) + proj3(x) on the sqrt(N) x sqrt(N) token grid.
+// The three depthwise convs and the identity are merged on the fly into ONE 7x7 depthwise filter
+// (5x5 / 3x3 zero-embedded at the centre, +1 at the centre tap, biases summed): exact, and the tokens
+// stay token-major [B, 1+S*S, D] so channel reads are coalesced (no NCHW round trip).
+#include "common.h"
+
+__global__ __launch_bounds__(256) void ppeg_merge_kernel(const float* __restrict__ w7, const float* __restrict__ w5,
+                                                         const float* __restrict__ w3, const float* __restrict__ b7,
+                                                         const float* __restrict__ b5, const float* __restrict__ b3,
+                                                         float* __restrict__ merged, float* __restrict__ bsum, int D) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < 49 * D) {
+        const int tap = idx / D, c = idx % D;
+        const int ky = tap / 7, kx = tap % 7;
+        float v = w7[c * 49 + tap];
+        if (ky >= 1 && ky <= 5 && kx >= 1 && kx <= 5) v += w5[c * 25 + (ky - 1) * 5 + (kx - 1)];
+        if (ky >= 2 && ky <= 4 && kx >= 2 && kx <= 4) v += w3[c * 9 + (ky - 2) * 3 + (kx - 2)];
+        if (ky == 3 && kx == 3) v += 1.f;
+        merged[idx] = v;
+    }
+    if (idx < D) bsum[idx] = b7[idx] + b5[idx] + b3[idx];
+}
+
+extern "C" int mh_ppeg_merge(const float* w7, const float* w5, const float* w3, const float* b7, const float* b5,
+                             const float* b3, float* merged, float* bsum, int D, mh_stream s) {
+    hipLaunchKernelGGL(ppeg_merge_kernel, dim3(mh_cdiv(49 * D, 256)), dim3(256), 0, (hipStream_t)s, w7, w5, w3, b7, b5, b3, merged, bsum, D);
+    MH_LAUNCH_CHECK("mh_ppeg_merge");
+    return MH_OK;
+}
+
+// y[b, 1 + yy*S + xx, c] = bsum[c] + sum_tap merged[tap'][c] * x[b, 1 + (yy+ky-3)*S + (xx+kx-3), c]
+// flip: tap' = 48 - tap and no bias (adjoint, used for the data gradient). cls row (token 0) is copied.
+// Block: 256 channels x PX_T pixels along x for one (b, yy); weights for the thread's channel live in registers.
+#define PX_T 8
+template <typename TX, typename TY>
+__global__ __launch_bounds__(256) void ppeg_kernel(const TX* __restrict__ x, TY* __restrict__ y, const float* __restrict__ merged,
+                                                   const float* __restrict__ bsum, int S, int D, int flip) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= D) return;
+    const int tiles_x = (S + PX_T - 1) / PX_T;
+    const int yy = blockIdx.y / tiles_x, x0 = (blockIdx.y % tiles_x) * PX_T;
+    const long b = blockIdx.z;
+    const long n = 1 + (long)S * S;
+    const TX* xb = x + b * n * D + c;
+    TY* yb = y + b * n * D + c;
+    if (blockIdx.y == 0) stf(yb, ldf(xb));  // cls token passes through
+    float w[49];
+#pragma unroll
+    for (int t = 0; t < 49; t++) w[t] = merged[(flip ? 48 - t : t) * D + c];
+    float acc[PX_T];
+    const float bias = flip ? 0.f : bsum[c];
+#pragma unroll
+    for (int i = 0; i < PX_T; i++) acc[i] = bias;
+#pragma unroll
+    for (int ky = 0; ky < 7; ky++) {
+        const int sy = yy + ky - 3;
+        if (sy < 0 || sy >= S) continue;
+        const TX* row = xb + (1 + (long)sy * S) * D;
+#pragma unroll
+        for (int u = 0; u < PX_T + 6; u++) {
+            const int sx = x0 - 3 + u;
+            const float v = (sx >= 0 && sx < S) ? ldf(row + (long)sx * D) : 0.f;
+#pragma unroll
+            for (int i = 0; i < PX_T; i++) {
+                const int kx = u - i;
+                if (kx >= 0 && kx < 7) acc[i] += w[ky * 7 + kx] * v;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PX_T; i++) {
+        const int xx = x0 + i;
+        if (xx < S) stf(yb + (1 + (long)yy * S + xx) * D, acc[i]);
+    }
+}
+
+extern "C" int mh_ppeg_fwd(const void* x, void* y, const float* merged, const float* bsum, int B, int S, int D, int flip,
+                           int dt_x, int dt_y, mh_stream s) {
+    MH_REQUIRE(S >= 1 && D >= 1, "mh_ppeg_fwd: bad shape S=%d D=%d", S, D);
+    if (B == 0) return MH_OK;
+    dim3 grid(mh_cdiv(D, 256), S * mh_cdiv(S, PX_T), B);
+#define PP(TX, TY) hipLaunchKernelGGL((ppeg_kernel<TX, TY>), grid, dim3(256), 0, (hipStream_t)s, (const TX*)x, (TY*)y, merged, bsum, S, D, flip)
+    if (dt_x == MH_F32 && dt_y == MH_F32) PP(float, float);
+    else if (dt_x == MH_BF16 && dt_y == MH_BF16) PP(bf16_t, bf16_t);
+    else if (dt_x == MH_F32 && dt_y == MH_BF16) PP(float, bf16_t);
+    else PP(bf16_t, float);
+#undef PP
+    MH_LAUNCH_CHECK("mh_ppeg_fwd");
+    return MH_OK;
+}
+
+// dmerged[tap][c] += sum_{b,yy,xx} dout[b,yy,xx,c] * x[b,yy+ky-3,xx+kx-3,c]; dbsum[c] += sum dout.
+// Block = 256 channels x one (b, band of WG_ROWS grid rows); 49 register accumulators per thread, one atomic each.
+#define WG_ROWS 4
+template <typename TX, typename TO>
+__global__ __launch_bounds__(256) void ppeg_wgrad_kernel(const TX* __restrict__ x, const TO* __restrict__ dout,
+                                                         float* __restrict__ dmerged, float* __restrict__ dbsum, int S, int D) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= D) return;
+    const long b = blockIdx.z;
+    const long n = 1 + (long)S * S;
+    const TX* xb = x + b * n * D + c;
+    const TO* db = dout + b * n * D + c;
+    float acc[49];
+#pragma unroll
+    for (int t = 0; t < 49; t++) acc[t] = 0.f;
+    float bacc = 0.f;
+    const int y0 = blockIdx.y * WG_ROWS;
+    for (int yy = y0; yy < min(S, y0 + WG_ROWS); yy++) {
+        for (int xx = 0; xx < S; xx++) {
+            const float g = ldf(db + (1 + (long)yy * S + xx) * D);
+            bacc += g;
+#pragma unroll
+            for (int ky = 0; ky < 7; ky++) {
+                const int sy = yy + ky - 3;
+                if (sy < 0 || sy >= S) continue;
+#pragma unroll
+                for (int kx = 0; kx < 7; kx++) {
+                    const int sx = xx + kx - 3;
+                    if (sx >= 0 && sx < S) acc[ky * 7 + kx] += g * ldf(xb + (1 + (long)sy * S + sx) * D);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 49; t++) atomicAdd(dmerged + t * D + c, acc[t]);
+    atomicAdd(dbsum + c, bacc);
+}
+
+extern "C" int mh_ppeg_wgrad(const void* x, const void* dout, float* dmerged, float* dbsum, int B, int S, int D, int dt_x,
+                             int dt_o, mh_stream s) {
+    if (B == 0) return MH_OK;
+    dim3 grid(mh_cdiv(D, 256), mh_cdiv(S, WG_ROWS), B);
+#define PW(TX, TO) hipLaunchKernelGGL((ppeg_wgrad_kernel<TX, TO>), grid, dim3(256), 0, (hipStream_t)s, (const TX*)x, (const TO*)dout, dmerged, dbsum, S, D)
+    if (dt_x == MH_F32 && dt_o == MH_F32) PW(float, float);
+    else if (dt_x == MH_BF16 && dt_o == MH_BF16) PW(bf16_t, bf16_t);
+    else if (dt_x == MH_F32 && dt_o == MH_BF16) PW(float, bf16_t);
+    else PW(bf16_t, float);
+#undef PW
+    MH_LAUNCH_CHECK("mh_ppeg_wgrad");
+    return MH_OK;
+}

@@ -1,0 +1,483 @@
+"""Tensor-level launchers for the C-ABI kernels (no autograd here; see functional.py).
+
+Every function takes HIP tensors, checks shapes on the host (a faulting kernel can take the whole
+node down) and launches on torch's current stream.  There is no CPU / PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, MH_BF16, MH_F32, GemmDesc, MirrorHipError
+
+_DT = {torch.float32: MH_F32, torch.bfloat16: MH_BF16}
+
+
+def dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise MirrorHipError(f"unsupported dtype {t.dtype} (f32 / bf16 only)") from None
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(*ts: Optional[torch.Tensor]) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise MirrorHipError("mirror_amd kernels need HIP device tensors: there is no CPU fallback path")
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _contig(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_contiguous():
+        raise MirrorHipError(f"{name} must be contiguous, got strides {t.stride()} for shape {tuple(t.shape)}")
+    return t
+
+
+# ----------------------------------------------------------------------------- GEMM
+def _mat(t: torch.Tensor):
+    """[.., R, C] view (<= 2 batch dims) -> (t4, rowmajor, ld, s1, s2)."""
+    if t.dim() < 2 or t.dim() > 4:
+        raise MirrorHipError(f"gemm operand must have 2..4 dims, got {tuple(t.shape)}")
+    while t.dim() < 4:
+        t = t.unsqueeze(0)
+    b1, b2, r, c = t.shape
+    st = t.stride()
+    if st[3] == 1 or c == 1:
+        rowmajor, ld = True, (st[2] if r > 1 else max(c, 1))
+    elif st[2] == 1 or r == 1:
+        rowmajor, ld = False, (st[3] if c > 1 else max(r, 1))
+    else:
+        raise MirrorHipError(f"gemm operand needs a unit stride in one of its last two dims: {st}")
+    return t, rowmajor, ld, (st[0] if b1 > 1 else 0), (st[1] if b2 > 1 else 0)
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *, alpha: float = 1.0,
+         diag: float = 0.0, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, accumulate: bool = False,
+         split_k: int = 1, mma: int = MH_F32, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """out[..] (+)= act(alpha * a @ b + diag*I + bias) with a [..,M,K], b [..,K,N] given as (possibly
+    transposed / strided / broadcast) views; <= 2 leading batch dims."""
+    _chk(a, b, out, bias)
+    nd = max(a.dim(), b.dim())
+    a4, a_rm, lda, sa1, sa2 = _mat(a)
+    b4, b_rm, ldb, sb1, sb2 = _mat(b)
+    M, K = a4.shape[2], a4.shape[3]
+    K2, N = b4.shape[2], b4.shape[3]
+    if K != K2:
+        raise MirrorHipError(f"gemm: inner dims differ: {tuple(a.shape)} @ {tuple(b.shape)}")
+    B1 = max(a4.shape[0], b4.shape[0])
+    B2 = max(a4.shape[1], b4.shape[1])
+    for t4 in (a4, b4):
+        if t4.shape[0] not in (1, B1) or t4.shape[1] not in (1, B2):
+            raise MirrorHipError(f"gemm: batch dims do not broadcast: {tuple(a.shape)} @ {tuple(b.shape)}")
+    if a4.dtype != b4.dtype:
+        raise MirrorHipError(f"gemm: operand dtypes differ: {a4.dtype} vs {b4.dtype}")
+    if out is None:
+        if accumulate:
+            raise MirrorHipError("gemm: accumulate needs an explicit output")
+        out = torch.empty((B1, B2, M, N), device=a.device, dtype=out_dtype or a.dtype)
+        o4 = out
+        out = out.reshape(out.shape[4 - nd:])
+    else:
+        o4 = out
+        while o4.dim() < 4:
+            o4 = o4.unsqueeze(0)
+        if tuple(o4.shape) != (B1, B2, M, N):
+            raise MirrorHipError(f"gemm: output shape {tuple(out.shape)} != {(B1, B2, M, N)}")
+    so = o4.stride()
+    if not (so[3] == 1 or N == 1):
+        raise MirrorHipError("gemm: output must have unit stride in its last dim")
+    if mma == MH_F32 and (a4.dtype != torch.float32 or o4.dtype != torch.float32):
+        raise MirrorHipError("gemm: f32 MMA needs f32 operands and output")
+    if bias is not None:
+        if bias.dtype != torch.float32 or bias.numel() != N or not bias.is_contiguous():
+            raise MirrorHipError("gemm: bias must be contiguous f32 [N]")
+    d = GemmDesc()
+    d.A, d.B, d.C, d.bias = a4.data_ptr(), b4.data_ptr(), o4.data_ptr(), _p(bias)
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc = lda, ldb, (so[2] if M > 1 else max(N, 1))
+    d.a_kc, d.b_kc = int(a_rm), int(not b_rm)
+    d.dtA, d.dtB, d.dtC, d.mma = dt(a4), dt(b4), dt(o4), mma
+    d.batch1, d.batch2 = B1, B2
+    d.sA1, d.sA2, d.sB1, d.sB2 = sa1, sa2, sb1, sb2
+    d.sC1, d.sC2 = (so[0] if B1 > 1 else 0), (so[1] if B2 > 1 else 0)
+    d.alpha, d.diag, d.act, d.accumulate, d.split_k = alpha, diag, act, int(accumulate), max(1, int(split_k))
+    _lib.call("mh_gemm", C.byref(d), stream=_stream())
+    return out
+
+
+# ----------------------------------------------------------------------------- row kernels
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, batches, rpb, D, x_bs, y_bs, eps):
+    _chk(x, gamma, beta, y, mean, rstd)
+    _lib.call("mh_layernorm_fwd", _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), batches, rpb, D, x_bs, y_bs,
+              eps, dt(x), dt(y), stream=_stream())
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, batches, rpb, D, x_bs, y_bs, accumulate_dx=False):
+    _chk(dy, x, gamma, mean, rstd, dx, dgamma, dbeta)
+    _lib.call("mh_layernorm_bwd", _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma), _p(dbeta),
+              batches, rpb, D, x_bs, y_bs, dt(x), dt(dy), dt(dx), int(accumulate_dx), stream=_stream())
+
+
+def softmax_fwd(x: torch.Tensor, y: Optional[torch.Tensor] = None, out_dtype=None) -> torch.Tensor:
+    """softmax over the last dim of a contiguous tensor (in place when y is x)."""
+    _chk(x, y)
+    _contig(x, "softmax input")
+    cols = x.shape[-1]
+    if y is None:
+        y = torch.empty_like(x, dtype=out_dtype or x.dtype)
+    _contig(y, "softmax output")
+    _lib.call("mh_softmax_fwd", _p(x), _p(y), x.numel() // max(cols, 1), cols, cols, cols, dt(x), dt(y), stream=_stream())
+    return y
+
+
+def softmax_bwd(y: torch.Tensor, dy: torch.Tensor, dx: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(y, dy, dx)
+    _contig(y, "softmax y"), _contig(dy, "softmax dy")
+    cols = y.shape[-1]
+    if dx is None:
+        dx = dy
+    _lib.call("mh_softmax_bwd", _p(y), _p(dy), _p(dx), y.numel() // max(cols, 1), cols, cols, cols, cols, dt(y), dt(dy),
+              dt(dx), stream=_stream())
+    return dx
+
+
+def l2norm_fwd(x2d_rows: torch.Tensor, rows: int, D: int, x_rs: int, eps: float, out_dtype):
+    _chk(x2d_rows)
+    y = torch.empty((rows, D), device=x2d_rows.device, dtype=out_dtype)
+    nrm = torch.empty((rows,), device=x2d_rows.device, dtype=torch.float32)
+    _lib.call("mh_l2norm_fwd", _p(x2d_rows), _p(y), _p(nrm), rows, D, x_rs, eps, dt(x2d_rows), dt(y), stream=_stream())
+    return y, nrm
+
+
+def l2norm_bwd(y, nrm, dy, dx, rows, D, dx_rs, accumulate):
+    _chk(y, nrm, dy, dx)
+    _lib.call("mh_l2norm_bwd", _p(y), _p(nrm), _p(dy), _p(dx), rows, D, dx_rs, 0.0, dt(y), dt(dy), dt(dx),
+              int(accumulate), stream=_stream())
+
+
+# ----------------------------------------------------------------------------- Nystrom pieces
+def landmark_fwd(qkv: torch.Tensor, l: int) -> torch.Tensor:
+    _chk(qkv)
+    _contig(qkv, "qkv")
+    B, n_p, D3 = qkv.shape
+    D = D3 // 3
+    lm = torch.empty((B, n_p // l, 2 * D), device=qkv.device, dtype=qkv.dtype)
+    _lib.call("mh_landmark_fwd", _p(qkv), _p(lm), B, n_p, D, l, dt(qkv), stream=_stream())
+    return lm
+
+
+def landmark_bwd(dlm: torch.Tensor, dqkv: torch.Tensor, l: int) -> None:
+    _chk(dlm, dqkv)
+    _contig(dlm, "dlm"), _contig(dqkv, "dqkv")
+    B, n_p, D3 = dqkv.shape
+    if dlm.dtype != dqkv.dtype or tuple(dlm.shape) != (B, n_p // l, 2 * (D3 // 3)):
+        raise MirrorHipError("landmark_bwd: shape/dtype mismatch")
+    _lib.call("mh_landmark_bwd", _p(dlm), _p(dqkv), B, n_p, D3 // 3, l, dt(dqkv), stream=_stream())
+
+
+def resconv(v_src: torch.Tensor, w: torch.Tensor, out: torch.Tensor, heads: int, transpose: bool, accumulate: bool) -> None:
+    """v_src / out: [B, n_p, C] views with unit last stride (e.g. the v column block of qkv)."""
+    _chk(v_src, w, out)
+    B, n_p, Cc = v_src.shape
+    if tuple(out.shape) != (B, n_p, Cc) or v_src.stride(2) != 1 or out.stride(2) != 1:
+        raise MirrorHipError("resconv: bad views")
+    taps = w.numel() // heads
+    _lib.call("mh_resconv_fwd", _p(v_src), v_src.stride(1), v_src.stride(0), _p(_contig(w, "res_conv weight")), _p(out),
+              out.stride(1), out.stride(0), B, n_p, heads, Cc // heads, taps, int(transpose), int(accumulate), dt(v_src),
+              dt(out), stream=_stream())
+
+
+def resconv_wgrad(v_src: torch.Tensor, dout: torch.Tensor, dw: torch.Tensor, heads: int) -> None:
+    _chk(v_src, dout, dw)
+    B, n_p, Cc = v_src.shape
+    if tuple(dout.shape) != (B, n_p, Cc) or v_src.stride(2) != 1 or dout.stride(2) != 1 or dw.dtype != torch.float32:
+        raise MirrorHipError("resconv_wgrad: bad views")
+    taps = dw.numel() // heads
+    _lib.call("mh_resconv_wgrad", _p(v_src), v_src.stride(1), v_src.stride(0), _p(dout), dout.stride(1), dout.stride(0),
+              _p(dw), B, n_p, heads, Cc // heads, taps, dt(v_src), dt(dout), stream=_stream())
+
+
+def pinv_absmax(x: torch.Tensor) -> torch.Tensor:
+    _chk(x)
+    _contig(x, "pinv input")
+    m = x.shape[-1]
+    stats = torch.zeros(2, device=x.device, dtype=torch.int64)
+    _lib.call("mh_pinv_absmax", _p(x), _p(stats), x.numel() // (m * m), m, stream=_stream())
+    return stats
+
+
+def pinv_z0(x: torch.Tensor, stats: torch.Tensor) -> torch.Tensor:
+    m = x.shape[-1]
+    z0 = torch.empty_like(x)
+    _lib.call("mh_pinv_z0", _p(x), _p(stats), _p(z0), x.numel() // (m * m), m, stream=_stream())
+    return z0
+
+
+def pinv_z0_bwd(x, z0, dz0, stats, dx) -> None:
+    _chk(x, z0, dz0, stats, dx)
+    m = x.shape[-1]
+    scratch = torch.empty(1, device=x.device, dtype=torch.float32)
+    _lib.call("mh_pinv_z0_bwd", _p(x), _p(z0), _p(_contig(dz0, "dz0")), _p(stats), _p(dx), _p(scratch),
+              x.numel() // (m * m), m, stream=_stream())
+
+
+def eye_minus(P: torch.Tensor, d: float) -> torch.Tensor:
+    _chk(P)
+    _contig(P, "eye_minus input")
+    m = P.shape[-1]
+    T = torch.empty_like(P)
+    _lib.call("mh_eye_minus", _p(P), _p(T), d, P.numel() // (m * m), m, stream=_stream())
+    return T
+
+
+def seq_finish(seq: torch.Tensor, cls: torch.Tensor, N: int, add: int) -> None:
+    _chk(seq, cls)
+    B, n, D = seq.shape
+    assert n == 1 + N + add and seq.is_contiguous() and cls.numel() == D and cls.dtype == torch.float32
+    _lib.call("mh_seq_finish", _p(seq), _p(cls), B, N, add, D, dt(seq), stream=_stream())
+
+
+def seq_finish_bwd(dseq: torch.Tensor, dcls: torch.Tensor, N: int, add: int) -> None:
+    _chk(dseq, dcls)
+    B, n, D = dseq.shape
+    assert n == 1 + N + add and dseq.is_contiguous() and dcls.numel() == D and dcls.dtype == torch.float32
+    _lib.call("mh_seq_finish_bwd", _p(dseq), _p(dcls), B, N, add, D, dt(dseq), stream=_stream())
+
+
+def ppeg_merge(w7, w5, w3, b7, b5, b3):
+    _chk(w7, w5, w3, b7, b5, b3)
+    D = b7.numel()
+    merged = torch.empty((49, D), device=w7.device, dtype=torch.float32)
+    bsum = torch.empty((D,), device=w7.device, dtype=torch.float32)
+    _lib.call("mh_ppeg_merge", _p(_contig(w7, "w7")), _p(_contig(w5, "w5")), _p(_contig(w3, "w3")), _p(b7), _p(b5), _p(b3),
+              _p(merged), _p(bsum), D, stream=_stream())
+    return merged, bsum
+
+
+def ppeg(x: torch.Tensor, merged, bsum, S: int, flip: bool, out_dtype=None) -> torch.Tensor:
+    _chk(x, merged, bsum)
+    B, n, D = x.shape
+    assert n == 1 + S * S and x.is_contiguous()
+    y = torch.empty_like(x, dtype=out_dtype or x.dtype)
+    _lib.call("mh_ppeg_fwd", _p(x), _p(y), _p(merged), _p(bsum), B, S, D, int(flip), dt(x), dt(y), stream=_stream())
+    return y
+
+
+def ppeg_wgrad(x, dout, dmerged, dbsum, S: int) -> None:
+    _chk(x, dout, dmerged, dbsum)
+    B, n, D = x.shape
+    assert n == 1 + S * S and x.is_contiguous() and dout.is_contiguous() and dout.shape == x.shape
+    _lib.call("mh_ppeg_wgrad", _p(x), _p(dout), _p(dmerged), _p(dbsum), B, S, D, dt(x), dt(dout), stream=_stream())
+
+
+# ----------------------------------------------------------------------------- masking
+def rank_mask(noise: torch.Tensor, len_keep: int) -> torch.Tensor:
+    _chk(noise)
+    noise = _contig(noise.float(), "noise")
+    B, N = noise.shape
+    mask = torch.empty_like(noise)
+    _lib.call("mh_rank_mask", _p(noise), _p(mask), B, N, len_keep, stream=_stream())
+    return mask
+
+
+def mask_apply_fwd(x, mask, token, pos, B, T, D, first, token_scalar) -> None:
+    _chk(x, mask, token, pos)
+    assert x.is_contiguous() and x.numel() == B * T * D and mask.numel() == B * (T - first) and pos.numel() == T * D
+    _lib.call("mh_mask_apply_fwd", _p(x), _p(mask), _p(token), _p(pos), B, T, D, first, int(token_scalar), dt(x),
+              stream=_stream())
+
+
+def mask_apply_bwd(dy, mask, dtoken, dpos, B, T, D, first, token_scalar) -> None:
+    _chk(dy, mask, dtoken, dpos)
+    assert dy.is_contiguous() and dy.numel() == B * T * D and dpos.numel() == T * D
+    _lib.call("mh_mask_apply_bwd", _p(dy), _p(mask), _p(dtoken), _p(dpos), B, T, D, first, int(token_scalar), dt(dy),
+              stream=_stream())
+
+
+# ----------------------------------------------------------------------------- RNA attention
+def headattn_fwd(qkv: torch.Tensor, H: int):
+    _chk(qkv)
+    _contig(qkv, "qkv")
+    B, D3 = qkv.shape
+    D = D3 // 3
+    out = torch.empty((B, D), device=qkv.device, dtype=qkv.dtype)
+    attn = torch.empty((B, H, H), device=qkv.device, dtype=torch.float32)
+    _lib.call("mh_headattn_fwd", _p(qkv), _p(out), _p(attn), B, H, D // H, dt(qkv), stream=_stream())
+    return out, attn
+
+
+def headattn_bwd(qkv, attn, dout, H: int) -> torch.Tensor:
+    _chk(qkv, attn, dout)
+    B, D3 = qkv.shape
+    dqkv = torch.empty_like(qkv)
+    dout = _contig(dout, "dout")
+    if dout.dtype != qkv.dtype:
+        raise MirrorHipError("headattn_bwd: dtype mismatch")
+    _lib.call("mh_headattn_bwd", _p(qkv), _p(attn), _p(dout), _p(dqkv), B, H, D3 // 3 // H, dt(qkv), stream=_stream())
+    return dqkv
+
+
+# ----------------------------------------------------------------------------- elementwise
+def add(a: torch.Tensor, b: torch.Tensor, out_dtype=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(a, b, out)
+    _contig(a, "add a"), _contig(b, "add b")
+    if a.shape != b.shape:
+        raise MirrorHipError(f"add: shapes differ {tuple(a.shape)} vs {tuple(b.shape)}")
+    y = out if out is not None else torch.empty_like(a, dtype=out_dtype or a.dtype)
+    _lib.call("mh_add", _p(a), _p(b), _p(y), a.numel(), dt(a), dt(b), dt(y), stream=_stream())
+    return y
+
+
+def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    if x.dtype == dtype:
+        return x
+    _chk(x)
+    _contig(x, "cast input")
+    y = torch.empty_like(x, dtype=dtype)
+    _lib.call("mh_cast", _p(x), _p(y), x.numel(), dt(x), dt(y), stream=_stream())
+    return y
+
+
+def gelu_fwd(x: torch.Tensor, out_dtype=None) -> torch.Tensor:
+    _chk(x)
+    _contig(x, "gelu input")
+    y = torch.empty_like(x, dtype=out_dtype or x.dtype)
+    _lib.call("mh_gelu_fwd", _p(x), _p(y), x.numel(), dt(x), dt(y), stream=_stream())
+    return y
+
+
+def gelu_bwd(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    _chk(x, dy)
+    dy = _contig(dy, "gelu dy")
+    dx = torch.empty_like(dy)
+    _lib.call("mh_gelu_bwd", _p(x), _p(dy), _p(dx), x.numel(), dt(x), dt(dy), dt(dx), stream=_stream())
+    return dx
+
+
+def relu_bwd(y: torch.Tensor, dy: torch.Tensor, dx: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(y, dy, dx)
+    _contig(y, "relu y"), _contig(dy, "relu dy")
+    if dx is None:
+        dx = torch.empty_like(dy)
+    _lib.call("mh_relu_bwd", _p(y), _p(dy), _p(dx), y.numel(), dt(y), dt(dy), dt(dx), stream=_stream())
+    return dx
+
+
+def dropout(x: torch.Tensor, p: float, seed: int, offset: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(x, out)
+    _contig(x, "dropout input")
+    y = out if out is not None else torch.empty_like(x)
+    _lib.call("mh_dropout", _p(x), _p(y), x.numel(), p, seed, offset, dt(x), dt(y), stream=_stream())
+    return y
+
+
+def colsum(x2d: torch.Tensor, out: torch.Tensor) -> None:
+    """out[c] += sum_r x2d[r, c]; x2d may be row-strided."""
+    _chk(x2d, out)
+    rows, cols = x2d.shape
+    if x2d.stride(1) != 1 and cols > 1:
+        raise MirrorHipError("colsum: unit column stride required")
+    assert out.dtype == torch.float32 and out.numel() == cols
+    _lib.call("mh_colsum", _p(x2d), _p(out), rows, cols, x2d.stride(0) if rows > 1 else cols, dt(x2d), stream=_stream())
+
+
+def reparam_fwd(mu, logstd, eps) -> torch.Tensor:
+    _chk(mu, logstd, eps)
+    z = torch.empty_like(mu)
+    _lib.call("mh_reparam_fwd", _p(_contig(mu, "mu")), _p(_contig(logstd, "logstd")), _p(_contig(eps, "eps")), _p(z),
+              mu.numel(), stream=_stream())
+    return z
+
+
+def reparam_bwd(logstd, eps, dz):
+    _chk(logstd, eps, dz)
+    dmu, dls = torch.empty_like(logstd), torch.empty_like(logstd)
+    _lib.call("mh_reparam_bwd", _p(logstd), _p(eps), _p(_contig(dz, "dz")), _p(dmu), _p(dls), logstd.numel(), stream=_stream())
+    return dmu, dls
+
+
+# ----------------------------------------------------------------------------- losses / step glue
+def ce_rows_fwd(G, scale, scale_mul, label_off, coef, out, loss_rows=None):
+    _chk(G, scale, out, loss_rows)
+    R, Cc = G.shape
+    assert G.dtype == torch.float32 and G.stride(1) == 1
+    lse = torch.empty((R,), device=G.device, dtype=torch.float32)
+    _lib.call("mh_ce_rows_fwd", _p(G), G.stride(0), _p(scale), scale_mul, R, Cc, label_off, coef, _p(loss_rows), _p(lse),
+              _p(out), stream=_stream())
+    return lse
+
+
+def ce_rows_bwd(G, scale, scale_mul, lse, g, g_per_row, gcoef, dscale, label_off):
+    _chk(G, scale, lse, g, dscale)
+    R, Cc = G.shape
+    dG = torch.empty((R, Cc), device=G.device, dtype=torch.float32)
+    _lib.call("mh_ce_rows_bwd", _p(G), G.stride(0), _p(scale), scale_mul, _p(lse), _p(g), int(g_per_row), gcoef, _p(dG),
+              _p(dscale), R, Cc, label_off, stream=_stream())
+    return dG
+
+
+def mse_masked_fwd(pred, tgt, mask, acc, rows, D):
+    _chk(pred, tgt, mask, acc)
+    _lib.call("mh_mse_masked_fwd", _p(pred), _p(tgt), _p(mask), _p(acc), rows, D, dt(pred), dt(tgt), stream=_stream())
+
+
+def mse_masked_bwd(pred, tgt, mask, acc, g, dpred, dtgt, rows, D):
+    _chk(pred, tgt, mask, acc, g, dpred, dtgt)
+    _lib.call("mh_mse_masked_bwd", _p(pred), _p(tgt), _p(mask), _p(acc), _p(g), _p(dpred), _p(dtgt), rows, D, dt(pred),
+              dt(tgt), dt(dpred), stream=_stream())
+
+
+def kl_fwd(mu, ls, out, coef):
+    _chk(mu, ls, out)
+    _lib.call("mh_kl_fwd", _p(mu), _p(ls), _p(out), mu.numel(), coef, stream=_stream())
+
+
+def kl_bwd(mu, ls, g, coef):
+    _chk(mu, ls, g)
+    dmu, dls = torch.empty_like(mu), torch.empty_like(ls)
+    _lib.call("mh_kl_bwd", _p(mu), _p(ls), _p(g), _p(dmu), _p(dls), mu.numel(), coef, stream=_stream())
+    return dmu, dls
+
+
+def symkl_fwd(w, r, out, coef):
+    _chk(w, r, out)
+    B, P = w.shape
+    _lib.call("mh_symkl_fwd", _p(w), _p(r), _p(out), B, P, coef, stream=_stream())
+
+
+def symkl_bwd(w, r, g, coef):
+    _chk(w, r, g)
+    B, P = w.shape
+    dw, dr = torch.empty_like(w), torch.empty_like(r)
+    _lib.call("mh_symkl_bwd", _p(w), _p(r), _p(g), _p(dw), _p(dr), B, P, coef, stream=_stream())
+    return dw, dr
+
+
+def rownorm_(w: torch.Tensor, eps: float = 1e-12) -> None:
+    _chk(w)
+    assert w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 2
+    _lib.call("mh_rownorm_", _p(w), w.shape[0], w.shape[1], eps, stream=_stream())
+
+
+def clamp_(x: torch.Tensor, lo: float, hi: float) -> None:
+    _chk(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    _lib.call("mh_clamp_", _p(x), x.numel(), lo, hi, stream=_stream())
+
+
+def adam(p, g, m, v, shadow, lr, b1, b2, eps, bc1, bc2, grad_scale=1.0) -> None:
+    _chk(p, g, m, v, shadow)
+    for t in (p, g, m, v):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel()
+    _lib.call("mh_adam", _p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), lr, b1, b2, eps, bc1, bc2, grad_scale,
+              stream=_stream())

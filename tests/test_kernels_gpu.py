@@ -1,0 +1,513 @@
+"""GPU: every C-ABI kernel against a plain PyTorch fp32/fp64 CPU reference of the same op."""
+import itertools
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from mirror_amd import kernels as K  # noqa: E402
+from mirror_amd._lib import ACT_GELU, ACT_NONE, ACT_RELU, MH_BF16, MH_F32  # noqa: E402
+
+DEV = "cuda"
+
+
+def g(seed=0):
+    return torch.Generator().manual_seed(seed)
+
+
+def ints(shape, gen, lo=-3, hi=4):
+    return torch.randint(lo, hi, shape, generator=gen).float()
+
+
+def close(got, ref, rtol, atol, msg=""):
+    got, ref = got.detach().float().cpu().double(), ref.detach().double()
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = err > tol
+    assert not bad.any(), f"{msg}: {int(bad.sum())}/{bad.numel()} off, max err {float(err.max()):.3e} at {np.unravel_index(int(err.argmax()), err.shape) if err.numel() else ()}"
+
+
+# --------------------------------------------------------------------------------------- GEMM
+LAYOUTS = list(itertools.product([True, False], [True, False]))  # (a row-major?, b "KC" i.e. given as [N,K]^T)
+
+
+def _mk(a_rm, shape, gen, dtype, integer):
+    """Return (device view with math shape `shape`, cpu math tensor)."""
+    r, c = shape[-2], shape[-1]
+    base = ints(shape, gen) if integer else torch.randn(shape, generator=gen)
+    if a_rm:
+        dev = base.to(DEV, dtype)
+    else:
+        dev = base.transpose(-1, -2).contiguous().to(DEV, dtype).transpose(-1, -2)
+    return dev, base
+
+
+@pytest.mark.parametrize("mma,dtype,out_dtype", [
+    (MH_F32, torch.float32, torch.float32),
+    (MH_BF16, torch.bfloat16, torch.bfloat16),
+    (MH_BF16, torch.bfloat16, torch.float32),
+    (MH_BF16, torch.float32, torch.float32),
+    (MH_BF16, torch.float32, torch.bfloat16),
+])
+@pytest.mark.parametrize("a_rm,b_t", LAYOUTS)
+@pytest.mark.parametrize("M,N,Kd", [(128, 128, 64), (200, 72, 100), (37, 3000, 17), (256, 64, 4352), (5, 5, 4), (130, 257, 33)])
+def test_gemm_layouts_dtypes_tails(mma, dtype, out_dtype, a_rm, b_t, M, N, Kd):
+    gen = g(M * 7 + N * 3 + Kd)
+    integer = mma == MH_BF16  # small integers are exact in bf16 -> bit-exact check of the MFMA data path
+    a_dev, a = _mk(a_rm, (M, Kd), gen, dtype, integer)
+    b_dev, b = _mk(not b_t, (Kd, N), gen, dtype, integer)
+    out = K.gemm(a_dev, b_dev, mma=mma, out_dtype=out_dtype)
+    ref = a.double() @ b.double()
+    if integer:
+        if out_dtype == torch.bfloat16:
+            ref = ref.float().bfloat16().double()
+        close(out, ref, 0, 0, "integer gemm must be exact")
+    else:
+        close(out, ref, 2e-5, 2e-5 * math.sqrt(Kd), "f32 gemm")
+
+
+@pytest.mark.parametrize("mma,dtype", [(MH_F32, torch.float32), (MH_BF16, torch.bfloat16)])
+def test_gemm_batched_strided_views(mma, dtype):
+    """The Nystrom use: heads are column slices of a [B, n, 3D] buffer; output written into a [B, n, D] view."""
+    gen = g(5)
+    B, n, h, dh, m = 2, 96, 4, 16, 24
+    D = h * dh
+    qkv = ints((B, n, 3 * D), gen)
+    lm = ints((B, m, 2 * D), gen)
+    qkv_d, lm_d = qkv.to(DEV, dtype), lm.to(DEV, dtype)
+    q = qkv_d.view(B, n, 3, h, dh)[:, :, 0].permute(0, 2, 1, 3)        # [B,h,n,dh]
+    kl = lm_d.view(B, m, 2, h, dh)[:, :, 1].permute(0, 2, 1, 3)        # [B,h,m,dh]
+    sim = K.gemm(q, kl.transpose(-1, -2), alpha=0.5, mma=mma, out_dtype=torch.float32)   # [B,h,n,m]
+    qc = qkv.view(B, n, 3, h, dh)[:, :, 0].permute(0, 2, 1, 3).double()
+    klc = lm.view(B, m, 2, h, dh)[:, :, 1].permute(0, 2, 1, 3).double()
+    close(sim, 0.5 * qc @ klc.transpose(-1, -2), 0, 0, "sim1")
+    # attn-like [B,h,n,m] @ [B,h,m,dh] -> columns of a [B,n,D] buffer
+    w2 = ints((B, h, m, dh), gen).to(DEV, dtype)
+    a1 = ints((B, h, n, m), gen, 0, 2).to(DEV, dtype)
+    out = torch.zeros((B, n, D), device=DEV, dtype=dtype)
+    K.gemm(a1, w2, out=out.view(B, n, h, dh).permute(0, 2, 1, 3), mma=mma)
+    ref = (a1.cpu().double() @ w2.cpu().double()).permute(0, 2, 1, 3).reshape(B, n, D)
+    close(out, ref, 0, 0, "attn@w2 into head columns")
+    # K-strided both: a1^T @ dout  (TN, the weight-gradient shape)
+    dout = ints((B, h, n, dh), gen).to(DEV, dtype)
+    dw2 = K.gemm(a1.transpose(-1, -2), dout, mma=mma, out_dtype=torch.float32)
+    close(dw2, a1.cpu().double().transpose(-1, -2) @ dout.cpu().double(), 0, 0, "TN batched")
+    # broadcast weight across batch
+    W = ints((D, D), gen).to(DEV, dtype)
+    y = K.gemm(out, W.t(), mma=mma, out_dtype=torch.float32)
+    close(y, out.cpu().double() @ W.cpu().double().t(), 0, 0, "broadcast weight")
+
+
+@pytest.mark.parametrize("mma,dtype", [(MH_F32, torch.float32), (MH_BF16, torch.bfloat16)])
+def test_gemm_epilogues_and_split_k(mma, dtype):
+    gen = g(9)
+    M, N, Kd = 150, 130, 96
+    a, b = ints((M, Kd), gen), ints((N, Kd), gen)
+    bias = ints((N,), gen)
+    a_d, b_d, bias_d = a.to(DEV, dtype), b.to(DEV, dtype), bias.to(DEV)
+    base = a.double() @ b.double().t()
+    y = K.gemm(a_d, b_d.t(), bias=bias_d, act=ACT_RELU, mma=mma, out_dtype=torch.float32)
+    close(y, F.relu(base + bias.double()), 0, 0, "bias+relu")
+    y = K.gemm(a_d, b_d.t(), bias=bias_d, act=ACT_GELU, alpha=0.125, mma=mma, out_dtype=torch.float32)
+    close(y, F.gelu(0.125 * base + bias.double()), 1e-5, 1e-5, "bias+gelu")
+    sq = ints((64, 64), gen).to(DEV, dtype)
+    y = K.gemm(sq, sq, alpha=-1.0, diag=15.0, mma=mma, out_dtype=torch.float32)
+    close(y, 15 * torch.eye(64, dtype=torch.float64) - sq.cpu().double() @ sq.cpu().double(), 0, 0, "diag")
+    # accumulate and split-K (weight gradient: dW[N,K] += dY^T X over many rows)
+    rows = 3000
+    dy, x = ints((rows, 70), gen), ints((rows, 50), gen)
+    dy_d, x_d = dy.to(DEV, dtype), x.to(DEV, dtype)
+    acc = torch.ones((70, 50), device=DEV)
+    K.gemm(dy_d.t(), x_d, out=acc, accumulate=True, split_k=7, mma=mma)
+    close(acc, 1 + dy.double().t() @ x.double(), 0, 0, "split-k atomics")
+    acc2 = torch.ones((70, 50), device=DEV)
+    K.gemm(dy_d.t(), x_d, out=acc2, accumulate=True, mma=mma)
+    close(acc2, 1 + dy.double().t() @ x.double(), 0, 0, "accumulate")
+
+
+def test_gemm_f32_accuracy_vs_fp64():
+    gen = g(11)
+    a, b = torch.randn(300, 1024, generator=gen), torch.randn(1024, 200, generator=gen)
+    y = K.gemm(a.to(DEV), b.to(DEV), mma=MH_F32)
+    # exact-f32 fma chain: error ~1e-7 * sum|a*b| (~650 here), cf. cdna_hip_programming.md §3
+    close(y, a.double() @ b.double(), 1e-5, 3e-4, "f32 MFMA K=1024")
+    y = K.gemm(a.to(DEV).bfloat16(), b.to(DEV).bfloat16(), mma=MH_BF16, out_dtype=torch.float32)
+    ref = a.bfloat16().double() @ b.bfloat16().double()
+    close(y, ref, 1e-5, 1e-3, "bf16 MFMA on bf16-rounded data, f32 accumulate")
+
+
+# --------------------------------------------------------------------------------------- row kernels
+@pytest.mark.parametrize("D", [32, 96, 512, 1536])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layernorm_fwd_bwd(D, dtype):
+    gen = g(D)
+    B, rpb, pad = 3, 7, 2
+    x = torch.randn(B, rpb, D, generator=gen) * 2 + 0.5
+    gam, bet = torch.randn(D, generator=gen), torch.randn(D, generator=gen)
+    xd = x.to(DEV)  # residual stream is f32 in both modes
+    y = torch.zeros((B, rpb + pad, D), device=DEV, dtype=dtype)
+    mean = torch.empty(B * rpb, device=DEV)
+    rstd = torch.empty(B * rpb, device=DEV)
+    K.layernorm_fwd(xd, gam.to(DEV), bet.to(DEV), y[:, pad:], mean, rstd, B, rpb, D, rpb * D, (rpb + pad) * D, 1e-5)
+    xr = x.clone().requires_grad_(True)
+    gr, br = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (D,), gr, br, 1e-5)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    close(y[:, pad:], ref, tol, tol, "ln fwd")
+    assert float(y[:, :pad].abs().max()) == 0.0
+    dy = torch.randn(B, rpb + pad, D, generator=gen)
+    ref.backward(dy[:, pad:])
+    dyd = dy.to(DEV, dtype)
+    dx = torch.empty_like(xd)
+    dg, db = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    K.layernorm_bwd(dyd[:, pad:], xd, gam.to(DEV), mean, rstd, dx, dg, db, B, rpb, D, rpb * D, (rpb + pad) * D)
+    close(dx, xr.grad, 10 * tol, 10 * tol, "ln dx")
+    close(dg, gr.grad, 10 * tol, 20 * tol, "ln dgamma")
+    close(db, br.grad, 10 * tol, 20 * tol, "ln dbeta")
+
+
+@pytest.mark.parametrize("cols", [16, 256, 1000, 4352])
+@pytest.mark.parametrize("din,dout", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16)])
+def test_softmax_fwd_bwd(cols, din, dout):
+    gen = g(cols)
+    x = torch.randn(2, 3, 5, cols, generator=gen) * 3
+    y = K.softmax_fwd(x.to(DEV, din), out_dtype=dout)
+    ref = x.softmax(-1)
+    tol = 1e-6 if dout == torch.float32 else 1e-2
+    close(y, ref, tol * 10, tol * 0.1, "softmax fwd")
+    dy = torch.randn(x.shape, generator=gen)
+    yc = y.float().cpu()
+    dx = K.softmax_bwd(y, dy.to(DEV, dout).clone())
+    dyc = dy.to(dout).float()
+    close(dx, yc * (dyc - (dyc * yc).sum(-1, keepdim=True)), 2e-2 if dout == torch.bfloat16 else 1e-5, 1e-5 if dout == torch.float32 else 2e-3, "softmax bwd")
+
+
+def test_l2norm():
+    gen = g(3)
+    x = torch.randn(4, 6, 40, generator=gen)
+    xd = x.to(DEV)
+    y, nrm = K.l2norm_fwd(xd, 4, 40, 6 * 40, 1e-12, torch.float32)  # row 0 of each batch
+    xr = x.clone().requires_grad_(True)
+    ref = F.normalize(xr, dim=-1)[:, 0]
+    close(y, ref, 1e-6, 1e-6, "l2 fwd")
+    dy = torch.randn(4, 40, generator=gen)
+    ref.backward(dy)
+    dx = torch.zeros_like(xd)
+    K.l2norm_bwd(y, nrm, dy.to(DEV), dx, 4, 40, 6 * 40, accumulate=True)
+    close(dx, xr.grad, 1e-5, 1e-6, "l2 bwd")
+
+
+# --------------------------------------------------------------------------------------- Nystrom pieces
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_landmarks(dtype):
+    gen = g(1)
+    B, n_p, D, l = 2, 24, 16, 3
+    qkv = ints((B, n_p, 3 * D), gen)
+    lm = K.landmark_fwd(qkv.to(DEV, dtype), l)
+    ref = qkv[..., : 2 * D].reshape(B, n_p // l, l, 2 * D).mean(2)
+    close(lm, ref, 1e-2 if dtype == torch.bfloat16 else 1e-6, 1e-6, "landmark fwd")
+    dlm = ints((B, n_p // l, 2 * D), gen, -6, 7) * 3
+    dq = ints((B, n_p, 3 * D), gen)
+    dq_d = dq.to(DEV, dtype)
+    K.landmark_bwd(dlm.to(DEV, dtype), dq_d, l)
+    exp = dq.clone()
+    exp[..., : 2 * D] += dlm.repeat_interleave(l, dim=1) / l
+    close(dq_d, exp, 1e-2 if dtype == torch.bfloat16 else 1e-6, 1e-6, "landmark bwd")
+
+
+@pytest.mark.parametrize("dh,n_p", [(4, 32), (64, 100), (32, 384)])
+def test_resconv_fwd_adjoint_wgrad(dh, n_p):
+    gen = g(dh)
+    B, h, taps = 2, 8, 33
+    D = h * dh
+    qkv = torch.randn(B, n_p, 3 * D, generator=gen)
+    w = torch.randn(h, 1, taps, 1, generator=gen) * 0.2
+    v = qkv[..., 2 * D:].reshape(B, n_p, h, dh).permute(0, 2, 1, 3).contiguous().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    ref = F.conv2d(v, wr, padding=(taps // 2, 0), groups=h)          # [B,h,n_p,dh]
+    qkv_d = qkv.to(DEV)
+    out = torch.ones((B, n_p, D), device=DEV)
+    K.resconv(qkv_d[..., 2 * D:], w.to(DEV), out, h, transpose=False, accumulate=True)
+    close(out, 1 + ref.permute(0, 2, 1, 3).reshape(B, n_p, D), 1e-5, 1e-5, "resconv fwd")
+    dout = torch.randn(B, n_p, D, generator=gen)
+    ref.backward(dout.reshape(B, n_p, h, dh).permute(0, 2, 1, 3))
+    dqkv = torch.zeros((B, n_p, 3 * D), device=DEV)
+    K.resconv(dout.to(DEV), w.to(DEV), dqkv[..., 2 * D:], h, transpose=True, accumulate=True)
+    close(dqkv[..., 2 * D:], v.grad.permute(0, 2, 1, 3).reshape(B, n_p, D), 1e-5, 1e-5, "resconv adjoint")
+    dw = torch.zeros((h, taps), device=DEV)
+    K.resconv_wgrad(qkv_d[..., 2 * D:], dout.to(DEV), dw, h)
+    close(dw, wr.grad.reshape(h, taps), 1e-4, 1e-3, "resconv wgrad")
+
+
+def test_pinv_init_and_adjoint():
+    gen = g(2)
+    BH, m = 6, 40
+    x = (torch.randn(BH, m, m, generator=gen)).softmax(-1)
+    xd = x.to(DEV)
+    st = K.pinv_absmax(xd)
+    z0 = K.pinv_z0(xd, st)
+    xr = x.clone().requires_grad_(True)
+    ax = xr.abs()
+    ref = xr.transpose(-1, -2) / (ax.sum(-1).max() * ax.sum(-2).max())
+    close(z0, ref, 1e-6, 1e-7, "z0")
+    dz0 = torch.randn(BH, m, m, generator=gen)
+    ref.backward(dz0)
+    dx = torch.zeros_like(xd)
+    K.pinv_z0_bwd(xd, z0, dz0.to(DEV), st, dx)
+    # the row-sum max of a softmax matrix is 1 up to rounding: its arg-max row is arbitrary, and the
+    # gradient through it is annihilated by the softmax backward.  Compare after projecting both.
+    def proj(gx):
+        return x * (gx - (gx * x).sum(-1, keepdim=True))
+    close(proj(dx.cpu()), proj(xr.grad), 1e-4, 1e-6, "z0 adjoint (after softmax bwd)")
+    T = K.eye_minus(xd, 7.0)
+    close(T, 7 * torch.eye(m) - x, 0, 1e-7, "eye_minus")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,add", [(20, 5), (16, 0)])
+def test_seq_finish(dtype, N, add):
+    gen = g(N)
+    B, D = 2, 24
+    n = 1 + N + add
+    h = ints((B, N, D), gen)
+    cls = ints((D,), gen)
+    seq = torch.zeros((B, n, D), device=DEV, dtype=dtype)
+    seq[:, 1:1 + N] = h.to(DEV, dtype)
+    K.seq_finish(seq, cls.to(DEV), N, add)
+    ref = torch.cat([cls.expand(B, 1, D), h, h[:, :add]], dim=1)
+    close(seq, ref, 0, 0, "seq finish")
+    d = ints((B, n, D), gen)
+    dd = d.to(DEV, dtype)
+    dcls = torch.zeros(D, device=DEV)
+    K.seq_finish_bwd(dd, dcls, N, add)
+    exp = d[:, 1:1 + N].clone()
+    exp[:, :add] += d[:, 1 + N:]
+    close(dd[:, 1:1 + N], exp, 0, 0, "seq finish bwd rows")
+    close(dcls, d[:, 0].sum(0), 0, 0, "dcls")
+
+
+@pytest.mark.parametrize("S,D", [(5, 32), (16, 256), (9, 300)])
+def test_ppeg(S, D):
+    gen = g(S)
+    B = 2
+    x = torch.randn(B, 1 + S * S, D, generator=gen)
+    ws = [torch.randn(D, 1, k, k, generator=gen) * 0.2 for k in (7, 5, 3)]
+    bs = [torch.randn(D, generator=gen) * 0.1 for _ in range(3)]
+    xr = x.clone().requires_grad_(True)
+    wr = [w.clone().requires_grad_(True) for w in ws]
+    br = [b.clone().requires_grad_(True) for b in bs]
+    grid = xr[:, 1:].transpose(1, 2).reshape(B, D, S, S)
+    y = sum(F.conv2d(grid, wr[i], br[i], padding=(7 - 2 * i) // 2, groups=D) for i in range(3)) + grid
+    ref = torch.cat([xr[:, :1], y.flatten(2).transpose(1, 2)], dim=1)
+    merged, bsum = K.ppeg_merge(*[w.to(DEV) for w in ws], *[b.to(DEV) for b in bs])
+    out = K.ppeg(x.to(DEV), merged, bsum, S, flip=False)
+    close(out, ref, 1e-5, 1e-5, "ppeg fwd")
+    dy = torch.randn(ref.shape, generator=gen)
+    ref.backward(dy)
+    dx = K.ppeg(dy.to(DEV), merged, bsum, S, flip=True)
+    close(dx, xr.grad, 1e-5, 1e-5, "ppeg adjoint")
+    dm, dbs = torch.zeros_like(merged), torch.zeros_like(bsum)
+    K.ppeg_wgrad(x.to(DEV), dy.to(DEV), dm, dbs, S)
+    dm = dm.cpu().t().reshape(D, 7, 7)
+    close(dm, wr[0].grad[:, 0], 1e-4, 1e-3, "ppeg dw7")
+    close(dm[:, 1:6, 1:6], wr[1].grad[:, 0], 1e-4, 1e-3, "ppeg dw5")
+    close(dm[:, 2:5, 2:5], wr[2].grad[:, 0], 1e-4, 1e-3, "ppeg dw3")
+    close(dbs, br[0].grad, 1e-4, 1e-3, "ppeg db")
+
+
+# --------------------------------------------------------------------------------------- masking / RNA
+def test_rank_mask_matches_double_argsort():
+    gen = g(4)
+    noise = torch.rand(3, 200, generator=gen)
+    for keep in (0, 50, 199, 200):
+        mask = K.rank_mask(noise.to(DEV), keep)
+        rank = torch.argsort(torch.argsort(noise, dim=1), dim=1)
+        assert torch.equal(mask.cpu(), (rank >= keep).float())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_mask_apply(dtype):
+    gen = g(6)
+    B, T, D = 3, 9, 20
+    x = ints((B, T, D), gen)
+    mask = (torch.rand(B, T - 1, generator=gen) > 0.5).float()
+    tok, pos = ints((D,), gen), ints((T, D), gen)
+    xd = x.to(DEV, dtype)
+    K.mask_apply_fwd(xd, mask.to(DEV), tok.to(DEV), pos.to(DEV), B, T, D, 1, False)
+    ref = x.clone()
+    ref[:, 1:] = torch.where(mask[..., None] > 0, tok.expand(B, T - 1, D), x[:, 1:])
+    close(xd, ref + pos, 0, 0, "mask fwd")
+    dy = ints((B, T, D), gen)
+    dyd = dy.to(DEV, dtype)
+    dtok, dpos = torch.zeros(D, device=DEV), torch.zeros((T, D), device=DEV)
+    K.mask_apply_bwd(dyd, mask.to(DEV), dtok, dpos, B, T, D, 1, False)
+    keep = torch.cat([torch.ones(B, 1), 1 - mask], dim=1)[..., None]
+    close(dyd, dy * keep, 0, 0, "mask dx")
+    close(dtok, (dy[:, 1:] * mask[..., None]).sum((0, 1)), 0, 0, "dtoken")
+    close(dpos, dy.sum(0), 0, 0, "dpos")
+    # RNA form: channels masked with a scalar token -> B x (T=D) x 1
+    xr = ints((B, D), gen)
+    mr = (torch.rand(B, D, generator=gen) > 0.4).float()
+    t1, p1 = torch.tensor([2.0]), ints((D,), gen)
+    xrd = xr.to(DEV, dtype)
+    K.mask_apply_fwd(xrd, mr.to(DEV), t1.to(DEV), p1.to(DEV), B, D, 1, 0, True)
+    close(xrd, torch.where(mr > 0, t1.expand(B, D), xr) + p1, 0, 0, "rna mask fwd")
+    dy = ints((B, D), gen)
+    dyd = dy.to(DEV, dtype)
+    dt1, dp1 = torch.zeros(1, device=DEV), torch.zeros(D, device=DEV)
+    K.mask_apply_bwd(dyd, mr.to(DEV), dt1, dp1, B, D, 1, 0, True)
+    close(dyd, dy * (1 - mr), 0, 0, "rna mask dx")
+    close(dt1, (dy * mr).sum().reshape(1), 0, 0, "rna dtoken")
+    close(dp1, dy.sum(0), 0, 0, "rna dpos")
+
+
+@pytest.mark.parametrize("H,hd", [(8, 4), (12, 8), (8, 64)])
+def test_headattn(H, hd):
+    gen = g(H * hd)
+    B, D = 5, H * hd
+    qkv = torch.randn(B, 3 * D, generator=gen)
+    qr = qkv.clone().requires_grad_(True)
+    q, k, v = qr.reshape(B, 3, H, hd).unbind(1)
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, D)
+    out, attn = K.headattn_fwd(qkv.to(DEV), H)
+    close(out, ref, 1e-5, 1e-5, "headattn fwd")
+    dy = torch.randn(B, D, generator=gen)
+    ref.backward(dy)
+    dq = K.headattn_bwd(qkv.to(DEV), attn, dy.to(DEV), H)
+    close(dq, qr.grad, 1e-4, 1e-5, "headattn bwd")
+
+
+# --------------------------------------------------------------------------------------- elementwise
+def test_elementwise_family():
+    gen = g(8)
+    x = torch.randn(1000, generator=gen) * 2
+    y = torch.randn(1000, generator=gen)
+    close(K.add(x.to(DEV), y.to(DEV).bfloat16(), out_dtype=torch.float32), x + y.bfloat16().float(), 0, 1e-7, "add")
+    close(K.cast(x.to(DEV), torch.bfloat16), x.bfloat16().float(), 0, 0, "cast")
+    close(K.gelu_fwd(x.to(DEV)), F.gelu(x), 1e-6, 1e-6, "gelu")
+    xr = x.clone().requires_grad_(True)
+    F.gelu(xr).backward(y)
+    close(K.gelu_bwd(x.to(DEV), y.to(DEV)), xr.grad, 1e-5, 1e-6, "gelu bwd")
+    r = F.relu(x)
+    close(K.relu_bwd(r.to(DEV), y.to(DEV)), y * (r > 0), 0, 0, "relu bwd")
+    m = torch.randn(300, 70, generator=gen)
+    out = torch.ones(70, device=DEV)
+    K.colsum(m.to(DEV)[:, :], out)
+    close(out, 1 + m.sum(0), 1e-5, 1e-4, "colsum")
+    mu, ls, eps = (torch.randn(4, 16, generator=gen) for _ in range(3))
+    mr, lr = mu.clone().requires_grad_(True), ls.clone().requires_grad_(True)
+    zr = mr + eps * torch.exp(0.5 * lr)
+    close(K.reparam_fwd(mu.to(DEV), ls.to(DEV), eps.to(DEV)), zr, 1e-6, 1e-6, "reparam")
+    dz = torch.randn(4, 16, generator=gen)
+    zr.backward(dz)
+    dmu, dls = K.reparam_bwd(ls.to(DEV), eps.to(DEV), dz.to(DEV))
+    close(dmu, mr.grad, 0, 0, "reparam dmu")
+    close(dls, lr.grad, 1e-6, 1e-6, "reparam dls")
+
+
+def test_dropout_is_deterministic_and_unbiased():
+    x = torch.ones(1 << 20, device=DEV)
+    a = K.dropout(x, 0.1, seed=123, offset=0)
+    b = K.dropout(x, 0.1, seed=123, offset=0)
+    c = K.dropout(x, 0.1, seed=124, offset=0)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    keep = float((a > 0).float().mean())
+    assert abs(keep - 0.9) < 2e-3
+    assert abs(float(a.mean()) - 1.0) < 3e-3
+    assert float(a.max()) == pytest.approx(1 / 0.9, rel=1e-6)
+    # offset shifts the stream: elements [4:] of offset 0 == elements [:-4] of offset 4
+    d = K.dropout(x, 0.1, seed=123, offset=4)
+    assert torch.equal(a[4:], d[:-4])
+    assert torch.equal(K.dropout(x, 0.0, seed=1, offset=0), x)
+
+
+# --------------------------------------------------------------------------------------- losses / step glue
+def test_ce_rows_clip_loss():
+    gen = g(10)
+    B, D = 8, 32
+    w, r = torch.randn(B, D, generator=gen), torch.randn(B, D, generator=gen)
+    s = torch.tensor(14.28)
+    wr, rr, sr = (t.clone().requires_grad_(True) for t in (w, r, s))
+    lab = torch.arange(B)
+    ref = 0.5 * (F.cross_entropy(sr * wr @ rr.T, lab) + F.cross_entropy(sr * rr @ wr.T, lab))
+    ref.backward()
+    G = K.gemm(w.to(DEV), r.to(DEV).t(), mma=MH_F32)
+    out = torch.zeros(1, device=DEV)
+    sd = s.to(DEV).reshape(1)
+    lse1 = K.ce_rows_fwd(G, sd, 1.0, 0, 0.5 / B, out)
+    lse2 = K.ce_rows_fwd(G.t().contiguous(), sd, 1.0, 0, 0.5 / B, out)
+    close(out, ref.reshape(1), 1e-5, 1e-5, "clip loss")
+    gone = torch.ones(1, device=DEV)
+    ds = torch.zeros(1, device=DEV)
+    dG1 = K.ce_rows_bwd(G, sd, 1.0, lse1, gone, False, 0.5 / B, ds, 0)
+    dG2 = K.ce_rows_bwd(G.t().contiguous(), sd, 1.0, lse2, gone, False, 0.5 / B, ds, 0)
+    dG = dG1 + dG2.t()
+    close(dG.cpu() @ r, wr.grad, 1e-4, 1e-5, "dW")
+    close(dG.cpu().t() @ w, rr.grad, 1e-4, 1e-5, "dR")
+    close(ds, sr.grad.reshape(1), 1e-4, 1e-5, "dscale")
+
+
+def test_retention_style_cluster_losses():
+    gen = g(12)
+    B, N, D, P = 4, 10, 24, 300
+    pred, tgt = torch.randn(B, N, D, generator=gen), torch.randn(B, N, D, generator=gen)
+    mask = (torch.rand(B, N, generator=gen) > 0.4).float()
+    pr, tr = pred.clone().requires_grad_(True), tgt.clone().requires_grad_(True)
+    ref = (((pr - tr) ** 2).mean(-1) * mask).sum() / mask.sum()
+    ref.backward()
+    acc = torch.zeros(2, device=DEV)
+    K.mse_masked_fwd(pred.to(DEV), tgt.to(DEV), mask.to(DEV), acc, B * N, D)
+    close(acc[0] / acc[1], ref, 1e-5, 1e-6, "masked mse")
+    dp, dtg = torch.empty(B, N, D, device=DEV), torch.empty(B, N, D, device=DEV)
+    K.mse_masked_bwd(pred.to(DEV), tgt.to(DEV), mask.to(DEV), acc, torch.ones(1, device=DEV), dp, dtg, B * N, D)
+    close(dp, pr.grad, 1e-5, 1e-7, "mse dpred")
+    close(dtg, tr.grad, 1e-5, 1e-7, "mse dtgt")
+    mu, ls = torch.randn(B, 16, generator=gen), torch.randn(B, 16, generator=gen) * 0.5
+    mr, lr = mu.clone().requires_grad_(True), ls.clone().requires_grad_(True)
+    ref = 0.5 * (lr.exp() + mr ** 2 - 1 - lr).sum(1).mean()
+    ref.backward()
+    out = torch.zeros(1, device=DEV)
+    K.kl_fwd(mu.to(DEV), ls.to(DEV), out, 0.5 / B)
+    close(out, ref.reshape(1), 1e-5, 1e-6, "style kl")
+    dmu, dls = K.kl_bwd(mu.to(DEV), ls.to(DEV), torch.ones(1, device=DEV), 0.5 / B)
+    close(dmu, mr.grad, 1e-5, 1e-7, "kl dmu")
+    close(dls, lr.grad, 1e-5, 1e-7, "kl dls")
+    w, r = torch.randn(B, P, generator=gen) * 2, torch.randn(B, P, generator=gen) * 2
+    wr, rr = w.clone().requires_grad_(True), r.clone().requires_grad_(True)
+    pw, prr = wr.softmax(-1), rr.softmax(-1)
+    ref = 0.5 * (F.kl_div(pw.log(), prr, reduction="batchmean") + F.kl_div(prr.log(), pw, reduction="batchmean"))
+    ref.backward()
+    out = torch.zeros(1, device=DEV)
+    K.symkl_fwd(w.to(DEV), r.to(DEV), out, 0.5 / B)
+    close(out, ref.reshape(1), 1e-5, 1e-6, "cluster loss")
+    dw, dr = K.symkl_bwd(w.to(DEV), r.to(DEV), torch.ones(1, device=DEV), 0.5 / B)
+    close(dw, wr.grad, 1e-4, 1e-7, "symkl dw")
+    close(dr, rr.grad, 1e-4, 1e-7, "symkl dr")
+
+
+def test_step_glue_rownorm_clamp_adam():
+    gen = g(13)
+    w = torch.randn(300, 40, generator=gen)
+    wd = w.to(DEV)
+    K.rownorm_(wd)
+    close(wd, F.normalize(w, dim=1), 1e-6, 1e-7, "rownorm")
+    s = torch.tensor([5.3], device=DEV)
+    K.clamp_(s, 0.0, math.log(100))
+    assert float(s) == pytest.approx(math.log(100))
+    n = 10007
+    p, gr = torch.randn(n, generator=gen), torch.randn(n, generator=gen)
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=2e-5)
+    pd, m, v = p.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    sh = torch.zeros(n, device=DEV, dtype=torch.bfloat16)
+    for step in range(1, 4):
+        gstep = gr * step
+        pr.grad = gstep.clone()
+        opt.step()
+        K.adam(pd, gstep.to(DEV), m, v, sh, 2e-5, 0.9, 0.999, 1e-8, 1 - 0.9 ** step, 1 - 0.999 ** step)
+    close(pd, pr.detach(), 1e-6, 1e-7, "adam")
+    close(sh, pr.detach().bfloat16().float(), 1e-2, 1e-6, "adam bf16 shadow")
