@@ -58,7 +58,8 @@ typedef struct {
     float alpha, diag;
     int32_t act;                  /* MH_ACT_* (needs split_k == 1) */
     int32_t accumulate;           /* 0: C = r, 1: C += r */
-    int32_t split_k;              /* >1: K split over workgroups, f32 atomics into C (needs accumulate=1, dtC=f32) */
+    int32_t split_k;              /* >1: K split over workgroups, f32 atomics into C (needs accumulate=1, dtC=f32).
+                                     A batch whose sC1 = sC2 = 0 with accumulate=1 also reduces into C with atomics. */
 } mh_gemm_desc;
 int mh_gemm(const mh_gemm_desc* d, mh_stream s);
 
@@ -143,8 +144,9 @@ int mh_add(const void* a, const void* b, void* y, int64_t n, int dt_a, int dt_b,
 int mh_cast(const void* x, void* y, int64_t n, int dt_x, int dt_y, mh_stream s);
 int mh_gelu_fwd(const void* x, void* y, int64_t n, int dt_x, int dt_y, mh_stream s);
 int mh_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int dt_x, int dt_dy, int dt_dx, mh_stream s);
-/* dx = dy * (y > 0) */
-int mh_relu_bwd(const void* y, const void* dy, void* dx, int64_t n, int dt_y, int dt_dy, int dt_dx, mh_stream s);
+/* dx = dy * (y > 0); `batches` blocks of n_per_batch contiguous elements at the given batch strides */
+int mh_relu_bwd(const void* y, const void* dy, void* dx, int64_t n_per_batch, int batches, int64_t y_bs, int64_t dy_bs,
+                int64_t dx_bs, int dt_y, int dt_dy, int dt_dx, mh_stream s);
 /* y = x * keep/(1-p); keep from Philox4x32-10(seed, offset + i)  ([3P] nn.Dropout in to_out; :75, :142) */
 int mh_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, uint64_t offset, int dt_x, int dt_y,
                mh_stream s);
@@ -162,7 +164,8 @@ int mh_reparam_bwd(const float* logstd, const float* eps, const float* dz, float
 
 /* ---------------------------------------------------------------- losses (losses/mirror_loss.py, losses/info_nce.py)
  * cross-entropy of rows of scale*G against label (label_off + row); G [R x C] f32.
- * out[0] += coef * sum_r (lse_r - scale*G[r,label]) ; lse [R] saved. scale read from device. */
+ * out[0] += coef * sum_r (lse_r - scale*G[r,label]) ; loss_rows[r] = coef * (...) ; lse [R] saved.
+ * scale is read from device memory (no host sync). */
 int mh_ce_rows_fwd(const float* G, int64_t ldg, const float* scale, float scale_mul, int R, int C, int label_off,
                    float coef, float* loss_rows, float* lse, float* out, mh_stream s);
 /* dG[r,c] = gcoef * g[0 or r] * scale * (softmax - onehot); dscale += sum dG_unscaled*G  */

@@ -60,7 +60,7 @@ _SIGS = {
     "mh_cast": [P, P, L, I, I],
     "mh_gelu_fwd": [P, P, L, I, I],
     "mh_gelu_bwd": [P, P, P, L, I, I, I],
-    "mh_relu_bwd": [P, P, P, L, I, I, I],
+    "mh_relu_bwd": [P, P, P, L, I, L, L, L, I, I, I],
     "mh_dropout": [P, P, L, F, U64, U64, I, I],
     "mh_colsum": [P, P, L, I, L, I],
     "mh_l2norm_fwd": [P, P, P, I, I, L, F, I, I],

@@ -22,8 +22,9 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const TX* x, const TDY* d
     EW_LOOP(i, n) stf(dx + i, ldf(dy + i) * gelu_grad_f(ldf(x + i)));
 }
 template <typename TY, typename TDY, typename TDX>
-__global__ __launch_bounds__(256) void relu_bwd_kernel(const TY* y, const TDY* dy, TDX* dx, long n) {
-    EW_LOOP(i, n) stf(dx + i, ldf(y + i) > 0.f ? ldf(dy + i) : 0.f);
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const TY* y, const TDY* dy, TDX* dx, long npb, long y_bs, long dy_bs, long dx_bs) {
+    const long b = blockIdx.y;
+    EW_LOOP(i, npb) stf(dx + b * dx_bs + i, ldf(y + b * y_bs + i) > 0.f ? ldf(dy + b * dy_bs + i) : 0.f);
 }
 
 #define DISPATCH2(dt0, dt1, MACRO)                                     \
@@ -71,11 +72,17 @@ extern "C" int mh_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, i
     return MH_OK;
 }
 
-extern "C" int mh_relu_bwd(const void* y, const void* dy, void* dx, int64_t n, int dt_y, int dt_dy, int dt_dx, mh_stream s) {
-    MH_REQUIRE(dt_dy == dt_dx, "mh_relu_bwd: dy/dx dtype mismatch");
-    if (n == 0) return MH_OK;
-#define RELUB_(TY, TD) hipLaunchKernelGGL((relu_bwd_kernel<TY, TD, TD>), EW_GRID(n), dim3(256), 0, (hipStream_t)s, (const TY*)y, (const TD*)dy, (TD*)dx, (long)n)
+extern "C" int mh_relu_bwd(const void* y, const void* dy, void* dx, int64_t n_per_batch, int batches, int64_t y_bs,
+                           int64_t dy_bs, int64_t dx_bs, int dt_y, int dt_dy, int dt_dx, mh_stream s) {
+    if (n_per_batch == 0 || batches == 0) return MH_OK;
+    MH_REQUIRE(batches <= 65535, "mh_relu_bwd: too many batches");
+    dim3 grid((unsigned)min((long)mh_cdiv(n_per_batch, 256), 4096L), batches);
+#define RELUB2_(TY, TDY)                                                                                                   \
+    if (dt_dx == MH_F32) hipLaunchKernelGGL((relu_bwd_kernel<TY, TDY, float>), grid, dim3(256), 0, (hipStream_t)s, (const TY*)y, (const TDY*)dy, (float*)dx, (long)n_per_batch, (long)y_bs, (long)dy_bs, (long)dx_bs); \
+    else hipLaunchKernelGGL((relu_bwd_kernel<TY, TDY, bf16_t>), grid, dim3(256), 0, (hipStream_t)s, (const TY*)y, (const TDY*)dy, (bf16_t*)dx, (long)n_per_batch, (long)y_bs, (long)dy_bs, (long)dx_bs)
+#define RELUB_(TY, TD) RELUB2_(TY, TD)
     DISPATCH2(dt_y, dt_dy, RELUB_)
+#undef RELUB2_
 #undef RELUB_
     MH_LAUNCH_CHECK("mh_relu_bwd");
     return MH_OK;

@@ -26,6 +26,7 @@ struct GemmArgs {
     float alpha, diag;
     int act, accumulate, split_k, k_per_split;
     int vecA, vecB;
+    int atomic;  // f32 atomicAdd into C: split-K, or a batch that broadcasts into one C
 };
 
 template <int MMA, bool KC, int ROWS>
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
     // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     const int r = lane & 31, hh = lane >> 5;
-    const int atomic = (g.split_k > 1);
+    const int atomic = g.atomic;
     const bool lead = (split == 0);
 #pragma unroll
     for (int j = 0; j < WN; j++) {
@@ -307,6 +308,9 @@ extern "C" int mh_gemm(const mh_gemm_desc* d, mh_stream stream) {
     a.vecA = aligned16(d->A) && d->lda % vec == 0 && d->sA1 % vec == 0 && d->sA2 % vec == 0;
     a.vecB = aligned16(d->B) && d->ldb % vec == 0 && d->sB1 % vec == 0 && d->sB2 % vec == 0;
     const int batch = d->batch1 * d->batch2;
+    a.atomic = (a.split_k > 1) || (d->accumulate && batch > 1 && d->sC1 == 0 && d->sC2 == 0);
+    MH_REQUIRE(!a.atomic || (d->dtC == MH_F32 && d->act == MH_ACT_NONE && d->accumulate),
+               "mh_gemm: atomic accumulation (split-K / batch broadcast into C) needs f32 C, accumulate=1, no activation");
     hipStream_t s = (hipStream_t)stream;
     if (d->mma == MH_F32) {
         launch_l<0, float, float, float>(a, d->a_kc, d->b_kc, batch, s);

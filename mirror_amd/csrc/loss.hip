@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void ce_rows_fwd_kernel(const float* __restric
         const float l = m + __logf(sum);
         const float loss = l - s * g[label_off + r];
         lse[r] = l;
-        if (loss_rows) loss_rows[r] = loss;
+        if (loss_rows) loss_rows[r] = coef * loss;
         if (out) atomicAdd(out, coef * loss);
     }
 }

@@ -1,0 +1,668 @@
+"""torch.autograd.Function wrappers around the HIP kernels (forward AND hand-derived backward).
+
+torch is used here for what the task calls plumbing: device memory (empty/zeros/views), the
+autograd tape, streams.  Every arithmetic step is a kernel launch from kernels.py.
+
+Precision policies
+  FP32  : f32 storage, v_mfma_f32_32x32x2_f32 everywhere  -> parity mode (vs the CPU oracle)
+  BF16  : bf16 GEMM operands / f32 accumulate, f32 residual stream, LN/softmax/loss maths in f32,
+          pseudo-inverse iterations in exact f32 MFMA                     -> training mode
+  BF16_FAST : as BF16 but the pseudo-inverse GEMMs round their f32 operands to bf16 (what the
+          reference's fp16 autocast does to them, SURVEY.md §7 hard part b)
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+from torch.autograd import Function
+
+from . import kernels as K
+from ._lib import ACT_NONE, ACT_RELU, MH_BF16, MH_F32
+
+f32, bf16 = torch.float32, torch.bfloat16
+
+
+@dataclass(frozen=True)
+class Precision:
+    name: str
+    mma: int
+    act: torch.dtype
+    pinv_mma: int
+
+
+FP32 = Precision("fp32", MH_F32, f32, MH_F32)
+BF16 = Precision("bf16", MH_BF16, bf16, MH_F32)
+BF16_FAST = Precision("bf16_fast", MH_BF16, bf16, MH_BF16)
+POLICIES = {p.name: p for p in (FP32, BF16, BF16_FAST)}
+
+# ------------------------------------------------------------------ bf16 shadows of f32 master weights
+_shadow_cache: dict = {}
+
+
+def shadow(w: torch.Tensor, prec: Precision) -> torch.Tensor:
+    """The weight in the policy's GEMM operand dtype; bf16 copies are cached per (storage, version)."""
+    wd = w.detach()
+    if wd.dtype == prec.act:
+        return wd
+    key = (wd.data_ptr(), tuple(wd.shape))
+    hit = _shadow_cache.get(key)
+    if hit is not None and hit[0] == w._version and hit[1].dtype == prec.act:
+        return hit[1]
+    s = K.cast(wd.contiguous(), prec.act)
+    _shadow_cache[key] = (w._version, s)
+    return s
+
+
+def register_shadow(w: torch.Tensor, s: torch.Tensor) -> None:
+    """Let an optimizer that maintains the bf16 copy itself (mh_adam) publish it."""
+    _shadow_cache[(w.data_ptr(), tuple(w.shape))] = (w._version, s)
+
+
+def _split_k_for(rows: int, n: int, k: int) -> int:
+    """Weight-gradient GEMMs have a huge contraction (rows) and few output tiles: split K to fill 256 CUs."""
+    tiles = ((n + 127) // 128) * ((k + 127) // 128)
+    want = max(1, 1024 // max(tiles, 1))
+    return int(max(1, min(want, rows // 256)))
+
+
+# ------------------------------------------------------------------ Linear (+ReLU)
+class LinearFn(Function):
+    """y = act(x @ W^T + b).  x: [R, K] or [B, R, K] (a row window of a larger buffer is fine);
+    W: [N, K] f32 master.  Replaces nn.Linear (+ nn.ReLU for _fc1, models/mirror.py:346)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act, prec, out_dtype):
+        xa = x if x.dtype == prec.act else K.cast(x.contiguous(), prec.act)
+        wa = shadow(w, prec)
+        y = K.gemm(xa, wa.t(), bias=None if b is None else b.detach(), act=act, mma=prec.mma,
+                   out_dtype=out_dtype or prec.act)
+        ctx.save_for_backward(xa, wa, y if act == ACT_RELU else None)
+        ctx.act, ctx.prec, ctx.has_b, ctx.x_dtype = act, prec, b is not None, x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xa, wa, y = ctx.saved_tensors
+        prec = ctx.prec
+        if ctx.act == ACT_RELU:
+            dy = K.relu_bwd(y, dy if _blk_ok(dy) else dy.contiguous(), out_dtype=prec.act)
+        else:
+            if not dy.is_contiguous():
+                dy = dy.contiguous()
+            if dy.dtype != prec.act:
+                dy = K.cast(dy, prec.act)
+        N, Kd = wa.shape
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = K.gemm(dy, wa, mma=prec.mma, out_dtype=ctx.x_dtype)
+        if ctx.needs_input_grad[1]:
+            dw = _wgrad(dy, xa, N, Kd, prec)
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            db = torch.zeros((N,), device=dy.device, dtype=f32)
+            K.colsum(dy.reshape(-1, N), db)
+        return dx, dw, db, None, None, None
+
+
+def _blk_ok(t: torch.Tensor) -> bool:
+    return t.is_contiguous() or (t.dim() == 3 and t.stride(2) == 1 and t.stride(1) == t.shape[2])
+
+
+def _wgrad(dy: torch.Tensor, x: torch.Tensor, N: int, Kd: int, prec: Precision) -> torch.Tensor:
+    """dW[N, K] = sum over every row of dy^T x (f32, split-K atomics). dy contiguous; x may be a row window."""
+    dw = torch.zeros((N, Kd), device=dy.device, dtype=f32)
+    if dy.dim() > 2 and x.is_contiguous():
+        dy, x = dy.reshape(-1, N), x.reshape(-1, Kd)
+    if dy.dim() == 2:
+        K.gemm(dy.t(), x, out=dw, accumulate=True, split_k=_split_k_for(dy.shape[0], N, Kd), mma=prec.mma)
+    else:  # batched window: every batch reduces into the same dW (atomics)
+        K.gemm(dy.transpose(-1, -2), x, out=dw.expand(*dy.shape[:-2], N, Kd), accumulate=True,
+               split_k=_split_k_for(dy.shape[-2], N, Kd), mma=prec.mma)
+    return dw
+
+
+def linear(x, w, b=None, *, act=ACT_NONE, prec: Precision, out_dtype=None):
+    return LinearFn.apply(x, w, b, act, prec, out_dtype)
+
+
+class LinearRowsFn(Function):
+    """y = x[:, r0:r0+R] @ W^T + b for a [B, T, K] buffer: only a row window is consumed (Nystrom's
+    `to_out(out)[:, -n:]`: rows that are sliced away are never computed).  dx is zero outside the window."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, r0, R, prec, out_dtype):
+        wa = shadow(w, prec)
+        xv = x[:, r0:r0 + R]
+        y = K.gemm(xv, wa.t(), bias=None if b is None else b.detach(), mma=prec.mma, out_dtype=out_dtype or prec.act)
+        ctx.save_for_backward(x, wa)
+        ctx.r0, ctx.R, ctx.prec, ctx.has_b = r0, R, prec, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wa = ctx.saved_tensors
+        prec, r0, R = ctx.prec, ctx.r0, ctx.R
+        if not dy.is_contiguous():
+            dy = dy.contiguous()
+        if dy.dtype != prec.act:
+            dy = K.cast(dy, prec.act)
+        N, Kd = wa.shape
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.zeros_like(x)
+            K.gemm(dy, wa, out=dx[:, r0:r0 + R], mma=prec.mma)
+        if ctx.needs_input_grad[1]:
+            dw = _wgrad(dy, x[:, r0:r0 + R], N, Kd, prec)
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            db = torch.zeros((N,), device=dy.device, dtype=f32)
+            K.colsum(dy.reshape(-1, N), db)
+        return dx, dw, db, None, None, None, None
+
+
+# ------------------------------------------------------------------ LayerNorm
+class LayerNormFn(Function):
+    """LayerNorm over the last dim of x [B, T, D] (f32 residual stream) using only the first `rows` rows
+    of every batch (models/mirror.py:677-679) and writing them behind `pad` zero rows (the front padding of
+    [3P] NystromAttention).  Output [B, pad + rows, D] in `out_dtype`."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, rows, pad, out_dtype):
+        x = x.contiguous()
+        Bn, T, D = x.shape
+        y = torch.empty((Bn, pad + rows, D), device=x.device, dtype=out_dtype)
+        if pad:
+            y[:, :pad].zero_()
+        mean = torch.empty((Bn * rows,), device=x.device, dtype=f32)
+        rstd = torch.empty_like(mean)
+        K.layernorm_fwd(x, gamma.detach(), beta.detach(), y[:, pad:], mean, rstd, Bn, rows, D, T * D, (pad + rows) * D, eps)
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.rows, ctx.pad = rows, pad
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        Bn, T, D = x.shape
+        rows, pad = ctx.rows, ctx.pad
+        if not dy.is_contiguous():
+            dy = dy.contiguous()
+        dx = torch.zeros_like(x) if rows < T else torch.empty_like(x)
+        dg = torch.zeros((D,), device=x.device, dtype=f32)
+        db = torch.zeros((D,), device=x.device, dtype=f32)
+        K.layernorm_bwd(dy[:, pad:], x, gamma.detach(), mean, rstd, dx, dg, db, Bn, rows, D, T * D, (pad + rows) * D)
+        return dx, dg, db, None, None, None, None
+
+
+def layer_norm(x, gamma, beta, eps, *, rows=None, pad=0, out_dtype=f32):
+    squeeze = x.dim() == 2
+    if squeeze:
+        x = x.unsqueeze(0)
+    y = LayerNormFn.apply(x, gamma, beta, eps, x.shape[1] if rows is None else rows, pad, out_dtype)
+    return y.squeeze(0) if squeeze else y
+
+
+# ------------------------------------------------------------------ elementwise with autograd
+class AddFn(Function):
+    """a + b -> out_dtype (residual adds; a and b may differ in dtype)."""
+
+    @staticmethod
+    def forward(ctx, a, b, out_dtype):
+        ctx.da, ctx.db = a.dtype, b.dtype
+        return K.add(a.contiguous(), b.contiguous(), out_dtype=out_dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        return K.cast(dy, ctx.da), K.cast(dy, ctx.db), None
+
+
+def add(a, b, out_dtype=f32):
+    return AddFn.apply(a, b, out_dtype)
+
+
+class GeluFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return K.gelu_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        return K.gelu_bwd(x, dy if dy.dtype == x.dtype else K.cast(dy, x.dtype))
+
+
+gelu = GeluFn.apply
+
+_dropout_state = {"seed": 0x5EED, "offset": 0}
+
+
+def manual_seed(seed: int) -> None:
+    _dropout_state["seed"], _dropout_state["offset"] = int(seed) & ((1 << 63) - 1), 0
+
+
+class DropoutFn(Function):
+    """nn.Dropout in training mode; the Philox mask is regenerated in backward from (seed, offset)."""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        x = x.contiguous()
+        ctx.p, ctx.seed, ctx.offset = p, _dropout_state["seed"], _dropout_state["offset"]
+        _dropout_state["offset"] += (x.numel() + 3) // 4 * 4
+        return K.dropout(x, p, ctx.seed, ctx.offset)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return K.dropout(dy.contiguous(), ctx.p, ctx.seed, ctx.offset), None
+
+
+def dropout(x, p: float, training: bool):
+    if not training or p == 0.0:
+        return x
+    return DropoutFn.apply(x, p)
+
+
+# ------------------------------------------------------------------ TransMIL sequence assembly
+class Fc1SeqFn(Function):
+    """seq = [cls | relu(wsi @ W^T + b) | first `add` tokens again]  (models/mirror.py:652-665).
+    The GEMM epilogue (bias + ReLU) writes straight into rows 1..N of the f32 sequence buffer."""
+
+    @staticmethod
+    def forward(ctx, wsi, w, b, cls, add_len, prec):
+        Bn, N, Fd = wsi.shape
+        D = w.shape[0]
+        xa = wsi if wsi.dtype == prec.act else K.cast(wsi.contiguous(), prec.act)
+        wa = shadow(w, prec)
+        seq = torch.empty((Bn, 1 + N + add_len, D), device=wsi.device, dtype=f32)
+        K.gemm(xa, wa.t(), out=seq[:, 1:1 + N], bias=b.detach(), act=ACT_RELU, mma=prec.mma)
+        K.seq_finish(seq, cls.detach().reshape(-1).contiguous(), N, add_len)
+        ctx.save_for_backward(xa, wa, seq)
+        ctx.add_len, ctx.prec = add_len, prec
+        return seq
+
+    @staticmethod
+    def backward(ctx, dseq):
+        xa, wa, seq = ctx.saved_tensors
+        prec, add_len = ctx.prec, ctx.add_len
+        Bn, N, Fd = xa.shape
+        D = wa.shape[0]
+        dseq = dseq.contiguous()
+        if add_len:
+            dseq = dseq.clone()  # the fold below is in place; autograd owns the incoming buffer
+        dcls = torch.zeros((D,), device=dseq.device, dtype=f32)
+        K.seq_finish_bwd(dseq, dcls, N, add_len)
+        dh = K.relu_bwd(seq[:, 1:1 + N], dseq[:, 1:1 + N], out_dtype=prec.act)   # [B,N,D] contiguous
+        dw = torch.zeros((D, Fd), device=dseq.device, dtype=f32)
+        K.gemm(dh.reshape(Bn * N, D).t(), xa.reshape(Bn * N, Fd), out=dw, accumulate=True,
+               split_k=_split_k_for(Bn * N, D, Fd), mma=prec.mma)
+        db = torch.zeros((D,), device=dseq.device, dtype=f32)
+        K.colsum(dh.reshape(Bn * N, D), db)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = K.gemm(dh, wa, mma=prec.mma, out_dtype=f32)
+        return dx, dw, db, dcls.reshape(1, 1, D), None, None
+
+
+class PPEGFn(Function):
+    """PPEG.forward (models/mirror.py:324-331) as one merged depthwise 7x7 on the token-major sequence."""
+
+    @staticmethod
+    def forward(ctx, x, w7, b7, w5, b5, w3, b3, S):
+        x = x.contiguous()
+        merged, bsum = K.ppeg_merge(w7.detach(), w5.detach(), w3.detach(), b7.detach(), b5.detach(), b3.detach())
+        ctx.save_for_backward(x, merged, bsum)
+        ctx.S = S
+        return K.ppeg(x, merged, bsum, S, flip=False)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, merged, bsum = ctx.saved_tensors
+        S = ctx.S
+        D = x.shape[-1]
+        dy = dy.contiguous()
+        dx = K.ppeg(dy, merged, bsum, S, flip=True)
+        dm = torch.zeros_like(merged)
+        dbs = torch.zeros_like(bsum)
+        K.ppeg_wgrad(x, dy, dm, dbs, S)
+        dm = dm.t().reshape(D, 1, 7, 7)
+        return (dx, dm.contiguous(), dbs, dm[:, :, 1:6, 1:6].contiguous(), dbs.clone(),
+                dm[:, :, 2:5, 2:5].contiguous(), dbs.clone(), None)
+
+
+# ------------------------------------------------------------------ Nystrom attention core
+def _heads(t3: torch.Tensor, which: int, parts: int, h: int) -> torch.Tensor:
+    """[B, T, parts*D] buffer -> [B, h, T, dh] view of column block `which` (heads are dh-wide column slices)."""
+    Bn, T, Dt = t3.shape
+    dh = Dt // parts // h
+    return t3.view(Bn, T, parts, h, dh)[:, :, which].permute(0, 2, 1, 3)
+
+
+def _pinv_step(a2, z, pm):
+    P = K.gemm(a2, z, mma=pm)
+    T1 = K.eye_minus(P, 7.0)
+    T2 = K.gemm(P, T1, alpha=-1.0, diag=15.0, mma=pm)
+    T3 = K.gemm(P, T2, alpha=-1.0, diag=13.0, mma=pm)
+    return P, T1, T2, T3
+
+
+def pinv_forward(a2: torch.Tensor, iters: int, pm: int):
+    """[3P] moore_penrose_iter_pinv: z0 = a2^T / (max rowsum * max colsum) over the WHOLE tensor, then
+    z <- 1/4 z (13I - a2 z (15I - a2 z (7I - a2 z))).  Returns every iterate (kept for the backward)."""
+    st = K.pinv_absmax(a2)
+    zs = [K.pinv_z0(a2, st)]
+    for _ in range(iters):
+        _, _, _, T3 = _pinv_step(a2, zs[-1], pm)
+        zs.append(K.gemm(zs[-1], T3, alpha=0.25, mma=pm))
+    return zs, st
+
+
+def pinv_backward(a2, zs, st, dZ, pm):
+    """Reverse mode through the iterations (intermediates recomputed from the saved iterates)."""
+    dX = torch.zeros_like(a2)
+    dz = dZ
+    tr = lambda t: t.transpose(-1, -2)  # noqa: E731
+    for k in range(len(zs) - 2, -1, -1):
+        z = zs[k]
+        P, T1, T2, T3 = _pinv_step(a2, z, pm)
+        dT3 = K.gemm(tr(z), dz, alpha=0.25, mma=pm)
+        dz_new = K.gemm(dz, tr(T3), alpha=0.25, mma=pm)
+        dP = K.gemm(dT3, tr(T2), alpha=-1.0, mma=pm)
+        dT2 = K.gemm(tr(P), dT3, alpha=-1.0, mma=pm)
+        K.gemm(dT2, tr(T1), out=dP, alpha=-1.0, accumulate=True, mma=pm)
+        K.gemm(tr(P), dT2, out=dP, accumulate=True, mma=pm)       # dP += -dT1 = P^T dT2
+        K.gemm(dP, tr(z), out=dX, accumulate=True, mma=pm)
+        K.gemm(tr(a2), dP, out=dz_new, accumulate=True, mma=pm)
+        dz = dz_new
+    K.pinv_z0_bwd(a2, zs[0], dz, st, dX)
+    return dX
+
+
+class NystromCoreFn(Function):
+    """[3P] NystromAttention between to_qkv and to_out (called at models/mirror.py:312):
+    qkv [B, n_p, 3D] -> out [B, n_p, D] = softmax(q k_l^T) . pinv(softmax(q_l k_l^T)) . softmax(q_l k^T) v + res_conv(v).
+    The product is associated as a1 @ (a2inv @ (a3 @ v)) (algebraically equal to the reference's
+    (a1 @ a2inv) @ (a3 @ v), 2 m^2 D instead of 2 n_p m^2 h flops)."""
+
+    @staticmethod
+    def forward(ctx, qkv, res_w, heads, l, iters, prec):
+        qkv = qkv.contiguous()
+        Bn, n_p, D3 = qkv.shape
+        D, h = D3 // 3, heads
+        dh = D // h
+        A, mma, pm = prec.act, prec.mma, prec.pinv_mma
+        scale = dh ** -0.5
+        q, k, v = (_heads(qkv, i, 3, h) for i in range(3))
+        lm = K.landmark_fwd(qkv, l)
+        ql, kl = _heads(lm, 0, 2, h), _heads(lm, 1, 2, h)
+        a1 = K.gemm(q, kl.transpose(-1, -2), alpha=scale, mma=mma, out_dtype=f32)       # [B,h,n_p,m]
+        a1 = K.softmax_fwd(a1, a1 if A == f32 else None, out_dtype=A)
+        a2 = K.gemm(ql, kl.transpose(-1, -2), alpha=scale, mma=mma, out_dtype=f32)      # [B,h,m,m]
+        K.softmax_fwd(a2, a2)
+        a3 = K.gemm(ql, k.transpose(-1, -2), alpha=scale, mma=mma, out_dtype=f32)       # [B,h,m,n_p]
+        a3 = K.softmax_fwd(a3, a3 if A == f32 else None, out_dtype=A)
+        zs, st = pinv_forward(a2, iters, pm)
+        av = K.gemm(a3, v, mma=mma, out_dtype=f32)                                       # [B,h,m,dh]
+        w2 = K.cast(K.gemm(zs[-1], av, mma=pm), A)
+        out = torch.empty((Bn, n_p, D), device=qkv.device, dtype=A)
+        K.gemm(a1, w2, out=_heads(out, 0, 1, h), mma=mma)
+        K.resconv(qkv[..., 2 * D:], res_w.detach().contiguous(), out, h, transpose=False, accumulate=True)
+        ctx.save_for_backward(qkv, res_w, lm, a1, a2, a3, av, w2, st, *zs)
+        ctx.cfg = (heads, l, prec)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, res_w, lm, a1, a2, a3, av, w2, st, *zs = ctx.saved_tensors
+        heads, l, prec = ctx.cfg
+        A, mma, pm = prec.act, prec.mma, prec.pinv_mma
+        Bn, n_p, D3 = qkv.shape
+        D, h = D3 // 3, heads
+        dh = D // h
+        m = n_p // l
+        scale = dh ** -0.5
+        tr = lambda t: t.transpose(-1, -2)  # noqa: E731
+        dout = dout.contiguous()
+        if dout.dtype != A:
+            dout = K.cast(dout, A)
+        q, k, v = (_heads(qkv, i, 3, h) for i in range(3))
+        ql, kl = _heads(lm, 0, 2, h), _heads(lm, 1, 2, h)
+        dO = _heads(dout, 0, 1, h)
+        dqkv = torch.empty_like(qkv)
+        dq, dk, dv = (_heads(dqkv, i, 3, h) for i in range(3))
+        rw = res_w.detach().contiguous()
+        dres = torch.zeros((rw.numel(),), device=qkv.device, dtype=f32)
+        K.resconv_wgrad(qkv[..., 2 * D:], dout, dres, h)
+        # out = a1 @ w2
+        dS1 = K.gemm(dO, tr(w2), mma=mma, out_dtype=A)                                   # [B,h,n_p,m]
+        dW2 = K.gemm(tr(a1), dO, mma=mma, out_dtype=f32)                                 # [B,h,m,dh]
+        K.softmax_bwd(a1, dS1)
+        # w2 = Z @ av ; av = a3 @ v
+        dZ = K.gemm(dW2, tr(av), mma=pm)                                                 # [B,h,m,m]
+        dAV = K.cast(K.gemm(tr(zs[-1]), dW2, mma=pm), A)                                 # [B,h,m,dh]
+        dS3 = K.gemm(dAV, tr(v), mma=mma, out_dtype=A)                                   # [B,h,m,n_p]
+        K.gemm(tr(a3), dAV, out=dv, mma=mma)
+        K.resconv(dout, rw, dqkv[..., 2 * D:], h, transpose=True, accumulate=True)
+        K.softmax_bwd(a3, dS3)
+        dS2 = pinv_backward(a2, list(zs), st, dZ, pm)
+        K.softmax_bwd(a2, dS2)
+        # similarities: s1 = scale q kl^T, s2 = scale ql kl^T, s3 = scale ql k^T
+        K.gemm(dS1, kl, out=dq, alpha=scale, mma=mma)
+        K.gemm(tr(dS3), ql, out=dk, alpha=scale, mma=mma)
+        lmf = K.cast(lm, f32)
+        qlf, klf = _heads(lmf, 0, 2, h), _heads(lmf, 1, 2, h)
+        dlm = torch.empty((Bn, m, 2 * D), device=qkv.device, dtype=f32)
+        dql, dkl = _heads(dlm, 0, 2, h), _heads(dlm, 1, 2, h)
+        K.gemm(tr(dS1), q, out=dkl, alpha=scale, mma=mma)
+        K.gemm(tr(dS2), qlf, out=dkl, alpha=scale, accumulate=True, mma=pm)
+        K.gemm(dS3, k, out=dql, alpha=scale, mma=mma)
+        K.gemm(dS2, klf, out=dql, alpha=scale, accumulate=True, mma=pm)
+        K.landmark_bwd(K.cast(dlm, A), dqkv, l)
+        return dqkv, dres.view_as(res_w), None, None, None, None
+
+
+# ------------------------------------------------------------------ masking
+def rank_mask(noise: torch.Tensor, len_keep: int) -> torch.Tensor:
+    return K.rank_mask(noise, len_keep)
+
+
+class MaskApplyFn(Function):
+    """x[b,t] <- mask_token where mask[b,t-first]; x += pos  (models/mirror.py:636-643 + :693; :521-527 + :549)."""
+
+    @staticmethod
+    def forward(ctx, x, mask, token, pos, first, token_scalar):
+        x = x.contiguous().clone()
+        if x.dim() == 2:           # RNA: channels are the masked axis -> [B, T=D, 1]
+            Bn, T, D = x.shape[0], x.shape[1], 1
+        else:
+            Bn, T, D = x.shape
+        K.mask_apply_fwd(x, mask, token.detach().reshape(-1).contiguous(), pos.detach().reshape(-1).contiguous(),
+                         Bn, T, D, first, token_scalar)
+        ctx.save_for_backward(mask)
+        ctx.geom = (Bn, T, D, first, token_scalar, token.shape, pos.shape)
+        return x
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        Bn, T, D, first, token_scalar, tshape, pshape = ctx.geom
+        dy = dy.contiguous().clone()
+        dtok = torch.zeros((1 if token_scalar else D,), device=dy.device, dtype=f32)
+        dpos = torch.zeros((T * D,), device=dy.device, dtype=f32)
+        K.mask_apply_bwd(dy, mask, dtok, dpos, Bn, T, D, first, token_scalar)
+        return dy, None, dtok.reshape(tshape), dpos.reshape(pshape), None, None
+
+
+# ------------------------------------------------------------------ small heads
+class L2NormRowFn(Function):
+    """F.normalize(x, dim=-1)[:, row] for x [B, T, D] (or [B, D]); only that row is touched."""
+
+    @staticmethod
+    def forward(ctx, x, eps, out_dtype):
+        x = x.contiguous()
+        if x.dim() == 3:
+            Bn, T, D = x.shape
+            rs = T * D
+        else:
+            (Bn, D), rs = x.shape, x.shape[1]
+        y, nrm = K.l2norm_fwd(x, Bn, D, rs, eps, out_dtype)
+        ctx.save_for_backward(y, nrm)
+        ctx.geom = (tuple(x.shape), rs, x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, nrm = ctx.saved_tensors
+        shape, rs, xdt = ctx.geom
+        dy = dy.contiguous()
+        if dy.dtype != y.dtype:
+            dy = K.cast(dy, y.dtype)
+        dx = torch.zeros(shape, device=dy.device, dtype=xdt)
+        K.l2norm_bwd(y, nrm, dy, dx, shape[0], shape[-1], rs, accumulate=False)
+        return dx, None, None
+
+
+class HeadAttnFn(Function):
+    """Attention.forward on [B, D] inputs (models/mirror.py:77-99): softmax over the heads axis + permutation."""
+
+    @staticmethod
+    def forward(ctx, qkv, H):
+        qkv = qkv.contiguous()
+        out, attn = K.headattn_fwd(qkv, H)
+        ctx.save_for_backward(qkv, attn)
+        ctx.H = H
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, attn = ctx.saved_tensors
+        dout = dout.contiguous()
+        if dout.dtype != qkv.dtype:
+            dout = K.cast(dout, qkv.dtype)
+        return K.headattn_bwd(qkv, attn, dout, ctx.H), None
+
+
+class ReparamFn(Function):
+    @staticmethod
+    def forward(ctx, mu, logstd, eps):
+        mu, logstd, eps = mu.contiguous(), logstd.contiguous(), eps.contiguous()
+        ctx.save_for_backward(logstd, eps)
+        return K.reparam_fwd(mu, logstd, eps)
+
+    @staticmethod
+    def backward(ctx, dz):
+        logstd, eps = ctx.saved_tensors
+        dmu, dls = K.reparam_bwd(logstd, eps, dz.contiguous())
+        return dmu, dls, None
+
+
+# ------------------------------------------------------------------ losses
+class CERowsFn(Function):
+    """sum_r coef * CE(scale * scale_mul * G[r, :], label_off + r) as a [1] tensor (or per-row losses)."""
+
+    @staticmethod
+    def forward(ctx, G, scale, scale_mul, label_off, coef, per_row):
+        G = G.contiguous()
+        R = G.shape[0]
+        out = torch.zeros((1,), device=G.device, dtype=f32)
+        rows = torch.empty((R,), device=G.device, dtype=f32) if per_row else None
+        sc = None if scale is None else scale.detach().reshape(1)
+        lse = K.ce_rows_fwd(G, sc, scale_mul, label_off, coef, out, rows)
+        ctx.save_for_backward(G, sc, lse)
+        ctx.cfg = (scale_mul, label_off, coef, per_row, scale is not None and scale.requires_grad, None if scale is None else scale.shape)
+        return rows if per_row else out
+
+    @staticmethod
+    def backward(ctx, g):
+        G, sc, lse = ctx.saved_tensors
+        scale_mul, label_off, coef, per_row, want_ds, sshape = ctx.cfg
+        g = g.contiguous().float()
+        ds = torch.zeros((1,), device=G.device, dtype=f32) if sc is not None else None
+        dG = K.ce_rows_bwd(G, sc, scale_mul, lse, g, per_row, coef, ds, label_off)
+        return dG, (ds.reshape(sshape) if want_ds else None), None, None, None, None
+
+
+class MaskedMSEFn(Function):
+    """sum(mask * mean_D (p - t)^2) / sum(mask)  (losses/mirror_loss.py:98-103); gradients flow to BOTH p and t."""
+
+    @staticmethod
+    def forward(ctx, pred, tgt, mask, D):
+        pred, tgt = pred.contiguous(), tgt.contiguous()
+        if tgt.dtype != pred.dtype:
+            tgt = K.cast(tgt, pred.dtype)
+        mask = mask.contiguous().float()
+        rows = pred.numel() // D
+        acc = torch.zeros((2,), device=pred.device, dtype=f32)
+        K.mse_masked_fwd(pred, tgt, mask, acc, rows, D)
+        ctx.save_for_backward(pred, tgt, mask, acc)
+        ctx.D = D
+        return _div(acc)
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, tgt, mask, acc = ctx.saved_tensors
+        D = ctx.D
+        dp, dtg = torch.empty_like(pred), torch.empty_like(tgt)
+        K.mse_masked_bwd(pred, tgt, mask, acc, g.contiguous().float().reshape(1), dp, dtg, pred.numel() // D, D)
+        return dp, dtg, None, None
+
+
+def _div(acc: torch.Tensor) -> torch.Tensor:
+    # one scalar division: the only arithmetic left to torch in the loss (0-d glue, no host sync)
+    return (acc[0] / acc[1]).reshape(())
+
+
+class StyleKLFn(Function):
+    """coef * sum(exp(ls) + mu^2 - 1 - ls)  (losses/mirror_loss.py:105-112)."""
+
+    @staticmethod
+    def forward(ctx, mu, ls, coef):
+        mu, ls = mu.contiguous().float(), ls.contiguous().float()
+        out = torch.zeros((1,), device=mu.device, dtype=f32)
+        K.kl_fwd(mu, ls, out, coef)
+        ctx.save_for_backward(mu, ls)
+        ctx.coef = coef
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        mu, ls = ctx.saved_tensors
+        dmu, dls = K.kl_bwd(mu, ls, g.contiguous().float().reshape(1), ctx.coef)
+        return dmu, dls, None
+
+
+class SymKLFn(Function):
+    """coef * sum_b sum_k (p_r - p_w)(log p_r - log p_w)  (losses/mirror_loss.py:114-119)."""
+
+    @staticmethod
+    def forward(ctx, w, r, coef):
+        w, r = w.contiguous().float(), r.contiguous().float()
+        out = torch.zeros((1,), device=w.device, dtype=f32)
+        K.symkl_fwd(w, r, out, coef)
+        ctx.save_for_backward(w, r)
+        ctx.coef = coef
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        w, r = ctx.saved_tensors
+        dw, dr = K.symkl_bwd(w, r, g.contiguous().float().reshape(1), ctx.coef)
+        return dw, dr, None
+
+
+class MatmulNTFn(Function):
+    """G = a @ b^T in f32 (similarity logits of ClipLoss / InfoNCE, losses/mirror_loss.py:39-40)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous().float(), b.contiguous().float()
+        ctx.save_for_backward(a, b)
+        return K.gemm(a, b.t(), mma=MH_F32)
+
+    @staticmethod
+    def backward(ctx, dG):
+        a, b = ctx.saved_tensors
+        dG = dG.contiguous()
+        return K.gemm(dG, b, mma=MH_F32), K.gemm(dG.t(), a, mma=MH_F32)

@@ -364,12 +364,29 @@ def gelu_bwd(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
     return dx
 
 
-def relu_bwd(y: torch.Tensor, dy: torch.Tensor, dx: Optional[torch.Tensor] = None) -> torch.Tensor:
-    _chk(y, dy, dx)
-    _contig(y, "relu y"), _contig(dy, "relu dy")
-    if dx is None:
-        dx = torch.empty_like(dy)
-    _lib.call("mh_relu_bwd", _p(y), _p(dy), _p(dx), y.numel(), dt(y), dt(dy), dt(dx), stream=_stream())
+def relu_bwd(y: torch.Tensor, dy: torch.Tensor, out_dtype=None) -> torch.Tensor:
+    """dx = dy * (y > 0).  y / dy: same shape; either contiguous, or 3-D with a contiguous [R, D] block per batch."""
+    _chk(y, dy)
+    if y.shape != dy.shape:
+        raise MirrorHipError("relu_bwd: shape mismatch")
+    dx = torch.empty(y.shape, device=y.device, dtype=out_dtype or dy.dtype)
+
+    def blk(t):
+        if t.is_contiguous():
+            return 1, t.numel(), 0
+        if t.dim() == 3 and t.stride(2) == 1 and t.stride(1) == t.shape[2]:
+            return t.shape[0], t.shape[1] * t.shape[2], t.stride(0)
+        raise MirrorHipError(f"relu_bwd: unsupported strides {t.stride()}")
+
+    by, ny, sy = blk(y)
+    bd, nd, sd = blk(dy)
+    batches = max(by, bd)
+    npb = y.numel() // batches
+    if by == 1:
+        sy = npb
+    if bd == 1:
+        sd = npb
+    _lib.call("mh_relu_bwd", _p(y), _p(dy), _p(dx), npb, batches, sy, sd, npb, dt(y), dt(dy), dt(dx), stream=_stream())
     return dx
 
 

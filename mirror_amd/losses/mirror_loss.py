@@ -1,0 +1,99 @@
+"""MIRRORLoss / ClipLoss on HIP kernels — host-side mirror of the reference's `losses/mirror_loss.py`.
+
+Same constructor kwargs, argument order and 6-tuple result (losses/mirror_loss.py:55-135).  Each term is one
+fused kernel pair (forward + hand-derived backward); only the weighted sum of five 0-d scalars is left to torch.
+
+Build-only extension: `gather_distributed=True` contrasts the local rows against the embeddings of ALL ranks
+(one RCCL all-gather of [B, 2D]; backward = reduce-scatter).  Default False = the reference's rank-local loss.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from .. import functional as Fn
+
+f32 = torch.float32
+
+
+class _AllGatherCat(torch.autograd.Function):
+    """all_gather along dim 0 with a gradient: backward reduce-scatters (sums) the slices back to their owners."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        world = dist.get_world_size()
+        out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)
+        dist.all_gather_into_tensor(out, x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        world = dist.get_world_size()
+        out = torch.empty((g.shape[0] // world,) + tuple(g.shape[1:]), device=g.device, dtype=g.dtype)
+        dist.reduce_scatter_tensor(out, g, op=dist.ReduceOp.SUM)
+        return out
+
+
+def clip_loss_terms(wsi, rna, logit_scale, gather: bool = False):
+    """0.5 * (CE(s W R^T) + CE(s R W^T)) with labels on the (rank-shifted) diagonal; returns a 0-d tensor."""
+    w, r = wsi.float(), rna.float()
+    B = w.shape[0]
+    off = 0
+    w_all, r_all = w, r
+    if gather and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        both = _AllGatherCat.apply(torch.cat([w, r], dim=1))          # one message: [P*B, 2D]
+        D = w.shape[1]
+        w_all, r_all = both[:, :D], both[:, D:]
+        off = dist.get_rank() * B
+    g_img = Fn.MatmulNTFn.apply(w, r_all)                            # [B, P*B]
+    g_txt = Fn.MatmulNTFn.apply(r, w_all)
+    li = Fn.CERowsFn.apply(g_img, logit_scale, 1.0, off, 0.5 / B, False)
+    lt = Fn.CERowsFn.apply(g_txt, logit_scale, 1.0, off, 0.5 / B, False)
+    return (li + lt).reshape(())
+
+
+class ClipLoss(nn.Module):
+    """losses/mirror_loss.py:16-52 (labels are implicit: the kernel indexes the diagonal, nothing to cache)."""
+
+    def __init__(self, cache_labels: bool = False, gather_distributed: bool = False):
+        super().__init__()
+        self.cache_labels = cache_labels
+        self.gather_distributed = gather_distributed
+
+    def forward(self, wsi_features, rna_features, logit_scale, output_dict: bool = False):
+        total = clip_loss_terms(wsi_features, rna_features, logit_scale, self.gather_distributed)
+        return {"contrastive_loss": total} if output_dict else total
+
+
+class MIRRORLoss(nn.Module):
+    def __init__(self, clip_loss_cache_labels=True, alignment_loss_weight=0.5, wsi_retention_loss_weight=0.1,
+                 rna_retention_loss_weight=0.1, style_loss_weight=0.1, cluster_loss_weight=0.2,
+                 gather_distributed: bool = False):
+        super().__init__()
+        self.clip_loss = ClipLoss(cache_labels=clip_loss_cache_labels, gather_distributed=gather_distributed)
+        self.alignment_loss_weight = alignment_loss_weight
+        self.wsi_retention_loss_weight = wsi_retention_loss_weight
+        self.rna_retention_loss_weight = rna_retention_loss_weight
+        self.style_loss_weight = style_loss_weight
+        self.cluster_loss_weight = cluster_loss_weight
+
+    def forward(self, wsi_alignment_emb, wsi_retention_emb, wsi_retention_target, wsi_mask, wsi_score, wsi_mu,
+                wsi_logstd, rna_alignment_emb, rna_retention_emb, rna_retention_target, rna_mask, rna_score, rna_mu,
+                rna_logstd, logit_scale):
+        alignment_loss = self.clip_loss(wsi_alignment_emb, rna_alignment_emb, logit_scale)
+        D = wsi_retention_emb.shape[-1]
+        wsi_retention_loss = Fn.MaskedMSEFn.apply(wsi_retention_emb, wsi_retention_target, wsi_mask, D)
+        rna_retention_loss = Fn.MaskedMSEFn.apply(rna_retention_emb, rna_retention_target, rna_mask, 1)
+        B = wsi_mu.shape[0]
+        style_loss = (Fn.StyleKLFn.apply(wsi_mu, wsi_logstd, 0.5 / B)
+                      + Fn.StyleKLFn.apply(rna_mu, rna_logstd, 0.5 / rna_mu.shape[0]))
+        cluster_loss = Fn.SymKLFn.apply(wsi_score, rna_score, 0.5 / wsi_score.shape[0])
+        total_loss = (self.alignment_loss_weight * alignment_loss
+                      + self.wsi_retention_loss_weight * wsi_retention_loss
+                      + self.rna_retention_loss_weight * rna_retention_loss
+                      + self.style_loss_weight * style_loss
+                      + self.cluster_loss_weight * cluster_loss)
+        return total_loss, alignment_loss, wsi_retention_loss, rna_retention_loss, style_loss, cluster_loss

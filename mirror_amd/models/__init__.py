@@ -1,0 +1,24 @@
+"""Drop-in for the reference's `models` package (models/__init__.py:1-4) for the pre-training path."""
+from .mirror import MIRROR, mirror, set_precision, resolve_precision  # noqa: F401
+
+__all__ = ["mirror"]
+
+_REGISTRY = {"mirror": mirror}
+
+
+def create_model(model_name: str, pretrained: bool = False, checkpoint_path: str = "", scriptable=None, **kwargs):
+    """Minimal stand-in for timm.models.create_model as called at train_mirror.py:689-694 (timm is optional)."""
+    import torch
+    model = _REGISTRY[model_name](**kwargs)
+    if checkpoint_path:
+        state = torch.load(checkpoint_path, map_location="cpu")
+        model.load_state_dict(state.get("state_dict", state))
+    return model
+
+
+try:  # register with timm when it is installed so `timm.create_model("mirror")` resolves to this build
+    from timm.models import register_model as _register_model
+
+    _register_model(mirror)
+except Exception:  # timm absent: the local create_model above is the entry point
+    pass

@@ -1,0 +1,481 @@
+"""MIRROR pre-training model on hand-written gfx950 kernels — host-side mirror of the reference's
+`models/mirror.py` (same class names, constructor kwargs, forward signatures, 15-tuple order and
+state-dict keys), with every arithmetic step dispatched to libmirror_hip.so through
+`mirror_amd.functional`.  nn.Linear / nn.LayerNorm / nn.Conv2d objects are used as *parameter
+containers only* (identical keys, shapes and default initialisation); their forward() is never called.
+
+Build-only extensions (default = reference behaviour):
+  * `rna_num_heads` kwarg (the reference hard-wires 12, models/mirror.py:392/:798-811, which rejects D=256/512);
+  * `noise=` dict for the four random draws of MIRROR.forward (reproducible parity runs);
+  * `precision` attribute / `mirror_amd.set_precision()` : "fp32" | "bf16" | "bf16_fast" | None (follow autocast).
+"""
+from __future__ import annotations
+
+import logging
+import math
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import functional as Fn
+from ..functional import FP32, BF16, POLICIES, Precision
+from .._lib import ACT_NONE, MirrorHipError
+
+_logger = logging.getLogger(__name__)
+f32 = torch.float32
+
+_DEFAULT_PRECISION: Optional[str] = None
+
+
+def set_precision(name: Optional[str]) -> None:
+    """Process-wide default policy for modules whose `.precision` is None."""
+    global _DEFAULT_PRECISION
+    if name is not None and name not in POLICIES:
+        raise ValueError(f"unknown precision {name!r}; choose from {sorted(POLICIES)}")
+    _DEFAULT_PRECISION = name
+
+
+def resolve_precision(pref: Optional[str]) -> Precision:
+    name = pref or _DEFAULT_PRECISION
+    if name is not None:
+        return POLICIES[name]
+    if torch.is_autocast_enabled():  # train_mirror.py:759-761 wraps the step in torch.autocast
+        return BF16
+    return FP32
+
+
+def _trunc_normal_(t: torch.Tensor, std: float) -> None:
+    nn.init.trunc_normal_(t, mean=0.0, std=std, a=-2.0, b=2.0)
+
+
+class _Mlp(nn.Module):
+    """Parameter layout of timm.layers.Mlp: fc1 -> act -> drop1 -> norm -> fc2 -> drop2 ([3P], models/mirror.py:217-224)."""
+
+    def __init__(self, in_features, hidden_features, out_features, norm_eps: Optional[float], drop: float):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.norm = nn.LayerNorm(hidden_features, eps=norm_eps) if norm_eps is not None else nn.Identity()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop = drop
+
+    def forward(self, x, prec: Precision, extra_bias: Optional[torch.Tensor] = None, out_dtype=None):
+        h = Fn.gelu(Fn.linear(x, self.fc1.weight, self.fc1.bias, prec=prec))
+        h = Fn.dropout(h, self.drop, self.training)
+        if isinstance(self.norm, nn.LayerNorm):
+            h = Fn.layer_norm(h, self.norm.weight, self.norm.bias, self.norm.eps, out_dtype=prec.act)
+        b2 = self.fc2.bias if extra_bias is None else Fn.add(self.fc2.bias, extra_bias.reshape(-1), f32)
+        y = Fn.linear(h, self.fc2.weight, b2, prec=prec, out_dtype=out_dtype)
+        return Fn.dropout(y, self.drop, self.training)
+
+
+# ===========================================
+#  Transformer for Transcriptomics Data (RNA)
+# ===========================================
+class Attention(nn.Module):
+    """models/mirror.py:50-102: on a 2-D [B, D] input the SDPA runs over the heads axis."""
+
+    def __init__(self, dim: int, num_heads: int = 8, qkv_bias: bool = False, proj_drop: float = 0.0):
+        super().__init__()
+        assert dim % num_heads == 0, "dim should be divisible by num_heads"
+        self.num_heads = num_heads
+        self.head_dim = dim // num_heads
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = proj_drop
+
+    def forward(self, x, prec: Precision):
+        qkv = Fn.linear(x, self.qkv.weight, self.qkv.bias, prec=prec)
+        o = Fn.HeadAttnFn.apply(qkv, self.num_heads)
+        y = Fn.linear(o, self.proj.weight, self.proj.bias, prec=prec)
+        return Fn.dropout(y, self.proj_drop, self.training)
+
+
+class Block(nn.Module):
+    """models/mirror.py:105-152 with LayerScale / DropPath at their identity settings."""
+
+    def __init__(self, dim: int, num_heads: int, mlp_ratio: float = 4.0, qkv_bias: bool = False,
+                 proj_drop: float = 0.0, norm_eps: float = 1e-6):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=norm_eps)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, proj_drop=proj_drop)
+        self.norm2 = nn.LayerNorm(dim, eps=norm_eps)
+        self.mlp = _Mlp(dim, int(dim * mlp_ratio), dim, None, proj_drop)
+
+    def forward(self, x, prec: Precision):
+        h = Fn.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, out_dtype=prec.act)
+        x = Fn.add(x, self.attn(h, prec), f32)
+        h = Fn.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, out_dtype=prec.act)
+        return Fn.add(x, self.mlp(h, prec), f32)
+
+
+class TransFormer(nn.Module):
+    """models/mirror.py:155-289 (embedding = Mlp(G -> 2D -> D, LayerNorm(2D)), learnt gene_embed, blocks, norm)."""
+
+    def __init__(self, input_dim: int, embed_dim: int = 768, depth: int = 2, num_heads: int = 12,
+                 mlp_ratio: float = 4.0, qkv_bias: bool = True, gene_embed: str = "learn",
+                 embed_drop_rate: float = 0.0, pos_drop_rate: float = 0.0, proj_drop_rate: float = 0.0,
+                 norm_eps: float = 1e-6, **unused):
+        super().__init__()
+        assert gene_embed in ("", "none", "learn")
+        self.num_features = self.head_hidden_size = self.embed_dim = embed_dim
+        self.num_heads = num_heads
+        self.norm_eps = norm_eps
+        self.embedding = _Mlp(input_dim, embed_dim * 2, embed_dim, norm_eps, embed_drop_rate)
+        if not gene_embed or gene_embed == "none":
+            self.gene_embed = None
+        else:
+            self.gene_embed = nn.Parameter(torch.randn(1, embed_dim) * 0.02)
+            _trunc_normal_(self.gene_embed, std=0.02)
+        self.pos_drop_rate = pos_drop_rate
+        self.blocks = nn.Sequential(*[
+            Block(embed_dim, num_heads, mlp_ratio, qkv_bias, proj_drop_rate, norm_eps) for _ in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim, eps=norm_eps)
+        self.precision: Optional[str] = None
+
+    def forward(self, x):
+        prec = resolve_precision(self.precision)
+        x = self.embedding(x, prec, extra_bias=self.gene_embed, out_dtype=f32)
+        x = Fn.dropout(x, self.pos_drop_rate, self.training)
+        for blk in self.blocks:
+            x = blk(x, prec)
+        return Fn.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps, out_dtype=f32)
+
+
+# ===========================================
+#  TransMIL for Histopathology Data (WSI)
+# ===========================================
+class NystromAttention(nn.Module):
+    """Parameter layout of [3P] nystrom_attention.NystromAttention as configured at models/mirror.py:299-309."""
+
+    def __init__(self, dim, dim_head=64, heads=8, num_landmarks=256, pinv_iterations=6, residual=True,
+                 residual_conv_kernel=33, eps=1e-8, dropout=0.0):
+        super().__init__()
+        assert residual, "the reference always enables the residual conv (models/mirror.py:306)"
+        inner = heads * dim_head
+        self.heads, self.num_landmarks, self.pinv_iterations = heads, num_landmarks, pinv_iterations
+        self.eps, self.drop = eps, dropout
+        self.to_qkv = nn.Linear(dim, inner * 3, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner, dim), nn.Dropout(dropout))
+        ks = residual_conv_kernel
+        self.res_conv = nn.Conv2d(heads, heads, (ks, 1), padding=(ks // 2, 0), groups=heads, bias=False)
+
+
+class TransLayer(nn.Module):
+    """models/mirror.py:295-314: x + NystromAttention(LayerNorm(x)); dim_head = D//8, m = D//2 landmarks."""
+
+    def __init__(self, dim: int = 512):
+        super().__init__()
+        self.norm = nn.LayerNorm(dim)
+        self.attn = NystromAttention(dim=dim, dim_head=dim // 8, heads=8, num_landmarks=dim // 2,
+                                     pinv_iterations=6, residual=True, dropout=0.1)
+
+    def forward(self, x, prec: Precision, mask=None):
+        if mask is not None:
+            raise NotImplementedError("key-padding mask path (BASELINE config 4) is not built yet; "
+                                      "the reference never passes one (models/mirror.py:312)")
+        a = self.attn
+        n, m = x.shape[1], a.num_landmarks
+        pad = (m - n % m) % m
+        l = math.ceil(n / m)  # noqa: E741
+        xp = Fn.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps, pad=pad, out_dtype=prec.act)
+        qkv = Fn.linear(xp, a.to_qkv.weight, None, prec=prec)
+        core = Fn.NystromCoreFn.apply(qkv, a.res_conv.weight, a.heads, l, a.pinv_iterations, prec)
+        y = Fn.LinearRowsFn.apply(core, a.to_out[0].weight, a.to_out[0].bias, pad, n, prec, prec.act)
+        y = Fn.dropout(y, a.drop, self.training)
+        return Fn.add(x, y, f32)
+
+
+class PPEG(nn.Module):
+    """models/mirror.py:317-331 (three depthwise convs + identity, merged into one kernel)."""
+
+    def __init__(self, dim: int = 512):
+        super().__init__()
+        self.proj = nn.Conv2d(dim, dim, 7, 1, 7 // 2, groups=dim)
+        self.proj1 = nn.Conv2d(dim, dim, 5, 1, 5 // 2, groups=dim)
+        self.proj2 = nn.Conv2d(dim, dim, 3, 1, 3 // 2, groups=dim)
+
+    def forward(self, x, H, W):  # noqa: N803
+        assert H == W and x.shape[1] == 1 + H * W
+        return Fn.PPEGFn.apply(x, self.proj.weight, self.proj.bias, self.proj1.weight, self.proj1.bias,
+                               self.proj2.weight, self.proj2.bias, H)
+
+
+class FeatureTransMIL(nn.Module):
+    """models/mirror.py:334-380 (downstream encoder; forward returns the normalised cls token)."""
+
+    def __init__(self, input_dim: int = 1024, embed_dim: int = 512):
+        super().__init__()
+        self.input_dim, self.embed_dim = input_dim, embed_dim
+        self.pos_layer = PPEG(dim=embed_dim)
+        self._fc1 = nn.Sequential(nn.Linear(input_dim, embed_dim), nn.ReLU())
+        self.cls_token = nn.Parameter(torch.randn(1, 1, embed_dim))
+        self.layer1 = TransLayer(dim=embed_dim)
+        self.layer2 = TransLayer(dim=embed_dim)
+        self.norm = nn.LayerNorm(embed_dim)
+        self.precision: Optional[str] = None
+
+    def _encode(self, h, keep_rows: Optional[int]):
+        prec = resolve_precision(self.precision)
+        if not h.is_cuda:
+            raise MirrorHipError("mirror_amd models run on MI355X only (no CPU fallback): move the inputs to the GPU")
+        n_tok = h.shape[1]
+        side = int(np.ceil(np.sqrt(n_tok)))
+        add = side * side - n_tok
+        seq = Fn.Fc1SeqFn.apply(h, self._fc1[0].weight, self._fc1[0].bias, self.cls_token, add, prec)
+        seq = self.layer1(seq, prec)
+        seq = self.pos_layer(seq, side, side)
+        seq = self.layer2(seq, prec)
+        rows = seq.shape[1] - add if keep_rows is None else keep_rows
+        return Fn.layer_norm(seq, self.norm.weight, self.norm.bias, self.norm.eps, rows=rows, out_dtype=f32)
+
+    def forward(self, h):
+        return self._encode(h, keep_rows=1)[:, 0]
+
+
+# ===========================================
+#  Hybrid (pre-training) encoders
+# ===========================================
+class TransFormerHybrid(TransFormer):
+    """models/mirror.py:386-569."""
+
+    def __init__(self, input_dim: int, embed_dim: int = 768, depth: int = 2, num_heads: int = 12,
+                 mlp_ratio: float = 4.0, qkv_bias: bool = True, gene_embed: str = "learn",
+                 embed_drop_rate: float = 0.0, pos_drop_rate: float = 0.0, proj_drop_rate: float = 0.0,
+                 norm_eps: float = 1e-6, retention_decoder_depth: int = 1, **unused):
+        super().__init__(input_dim, embed_dim, depth, num_heads, mlp_ratio, qkv_bias, gene_embed,
+                         embed_drop_rate, pos_drop_rate, proj_drop_rate, norm_eps)
+        self.alignment_head = nn.Linear(embed_dim, embed_dim)
+        self.retention_embed = nn.Linear(embed_dim, embed_dim)
+        self.mask_token = nn.Parameter(torch.zeros(1, 1))
+        self.retention_gene_embed = nn.Parameter(torch.randn(1, embed_dim) * 0.02)
+        self.retention_blocks = nn.ModuleList([
+            Block(embed_dim, num_heads, mlp_ratio, qkv_bias, proj_drop_rate, norm_eps)
+            for _ in range(retention_decoder_depth)])
+        self.retention_norm = nn.LayerNorm(embed_dim, eps=norm_eps)
+        self.retention_head = nn.Linear(embed_dim, embed_dim)
+        nn.init.normal_(self.mask_token, std=0.02)
+        _trunc_normal_(self.retention_gene_embed, std=0.02)
+        with torch.no_grad():  # models/mirror.py:503-508
+            for layer_id, layer in enumerate(self.retention_blocks):
+                layer.attn.proj.weight.div_(math.sqrt(2.0 * (layer_id + 1)))
+                layer.mlp.fc2.weight.div_(math.sqrt(2.0 * (layer_id + 1)))
+
+    def forward_encoder(self, x):
+        if not x.is_cuda:
+            raise MirrorHipError("mirror_amd models run on MI355X only (no CPU fallback): move the inputs to the GPU")
+        return TransFormer.forward(self, x)
+
+    def forward_alignment_head(self, x):
+        prec = resolve_precision(self.precision)
+        y = Fn.L2NormRowFn.apply(x, 1e-12, f32)
+        return Fn.linear(y, self.alignment_head.weight, self.alignment_head.bias, prec=prec, out_dtype=f32)
+
+    def random_masking(self, x, mask_ratio: float, noise: Optional[torch.Tensor] = None):
+        B, N = x.shape  # noqa: N806
+        len_keep = int(N * (1 - mask_ratio))
+        if noise is None:
+            noise = torch.rand(B, N, device=x.device)
+        mask = Fn.rank_mask(noise, len_keep)
+        return mask
+
+    def forward_retention_head(self, x, mask_ratio: float, noise: Optional[torch.Tensor] = None):
+        prec = resolve_precision(self.precision)
+        r = Fn.linear(x, self.retention_embed.weight, self.retention_embed.bias, prec=prec, out_dtype=f32)
+        mask = self.random_masking(r, mask_ratio, noise)
+        r = Fn.MaskApplyFn.apply(r, mask, self.mask_token, self.retention_gene_embed, 0, True)
+        for blk in self.retention_blocks:
+            r = blk(r, prec)
+        r = Fn.layer_norm(r, self.retention_norm.weight, self.retention_norm.bias, self.retention_norm.eps,
+                          out_dtype=prec.act)
+        r = Fn.linear(r, self.retention_head.weight, self.retention_head.bias, prec=prec, out_dtype=f32)
+        return r, mask
+
+    def forward_decoders(self, x, mask_ratio: float, noise: Optional[torch.Tensor] = None):
+        alignment_x = self.forward_alignment_head(x)
+        retention_x, mask = self.forward_retention_head(x, mask_ratio, noise)
+        return alignment_x, retention_x, mask
+
+    def forward(self, x, mask_ratio: float = 0.75):
+        x = self.forward_encoder(x)
+        alignment_x, retention_x, mask = self.forward_decoders(x, mask_ratio)
+        return alignment_x, retention_x, x, mask
+
+
+class FeatureTransMILHybrid(FeatureTransMIL):
+    """models/mirror.py:575-714."""
+
+    def __init__(self, input_dim: int = 1024, embed_dim: int = 512, num_tokens: int = 2048,
+                 retention_decoder_depth: int = 1):
+        super().__init__(input_dim, embed_dim)
+        self.num_tokens = num_tokens
+        self.alignment_head = nn.Linear(embed_dim, embed_dim)
+        self.retention_embed = nn.Linear(embed_dim, embed_dim)
+        self.mask_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.retention_gene_embed = nn.Parameter(torch.randn(1, num_tokens + 1, embed_dim) * 0.02)
+        self.retention_blocks = nn.ModuleList([TransLayer(dim=embed_dim) for _ in range(retention_decoder_depth)])
+        self.retention_norm = nn.LayerNorm(embed_dim)
+        self.retention_head = nn.Linear(embed_dim, embed_dim)
+        self.init_weights()
+
+    def init_weights(self) -> None:  # models/mirror.py:609-622
+        nn.init.normal_(self.mask_token, std=0.02)
+        nn.init.normal_(self.cls_token, std=0.02)
+        _trunc_normal_(self.retention_gene_embed, std=0.02)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.LayerNorm):
+                nn.init.constant_(m.bias, 0)
+                nn.init.constant_(m.weight, 1.0)
+
+    def forward_encoder(self, h):
+        return self._encode(h, keep_rows=None)
+
+    def forward_alignment_head(self, h):
+        prec = resolve_precision(self.precision)
+        y = Fn.L2NormRowFn.apply(h, 1e-12, f32)         # only the cls row is consumed (models/mirror.py:684)
+        return Fn.linear(y, self.alignment_head.weight, self.alignment_head.bias, prec=prec, out_dtype=f32)
+
+    def random_masking(self, h, mask_ratio: float, noise: Optional[torch.Tensor] = None):
+        B, N = h.shape[0], h.shape[1]  # noqa: N806
+        len_keep = int(N * (1 - mask_ratio))
+        if noise is None:
+            noise = torch.rand(B, N, device=h.device)
+        return Fn.rank_mask(noise, len_keep)
+
+    def forward_retention_head(self, h, mask_ratio: float, noise: Optional[torch.Tensor] = None):
+        prec = resolve_precision(self.precision)
+        if h.shape[1] != self.num_tokens + 1:
+            raise ValueError(f"wsi_num_tokens={self.num_tokens} but the batch has {h.shape[1] - 1} tokens")
+        r = Fn.linear(h, self.retention_embed.weight, self.retention_embed.bias, prec=prec, out_dtype=f32)
+        mask = self.random_masking(r[:, 1:], mask_ratio, noise)
+        r = Fn.MaskApplyFn.apply(r, mask, self.mask_token, self.retention_gene_embed, 1, False)
+        for blk in self.retention_blocks:
+            r = blk(r, prec)
+        r = Fn.layer_norm(r, self.retention_norm.weight, self.retention_norm.bias, self.retention_norm.eps,
+                          out_dtype=prec.act)
+        # retention_head(...)[:, 1:]: the cls row is sliced away, so it is never computed
+        r = Fn.LinearRowsFn.apply(r, self.retention_head.weight, self.retention_head.bias, 1, r.shape[1] - 1, prec, f32)
+        return r, mask
+
+    def forward_decoders(self, h, mask_ratio: float, noise: Optional[torch.Tensor] = None):
+        alignment_h = self.forward_alignment_head(h)
+        retention_h, mask = self.forward_retention_head(h, mask_ratio, noise)
+        return alignment_h, retention_h, mask
+
+    def forward(self, h, mask_ratio: float = 0.75):
+        h = self.forward_encoder(h)
+        alignment_h, retention_h, mask = self.forward_decoders(h, mask_ratio)
+        return alignment_h, retention_h, h[:, 1:, :], mask
+
+
+# ===========================================
+#  MIRROR for Pre-training
+# ===========================================
+class MIRROR(nn.Module):
+    """models/mirror.py:720-915."""
+
+    def __init__(self, wsi_embed_dim: int, rna_embed_dim: int, embed_dim: int, wsi_num_tokens: int = 2048,
+                 wsi_retention_decoder_depth: int = 1, rna_encoder_depth: int = 2, rna_gene_embed: str = "learn",
+                 rna_mlp_ratio: float = 2.572, rna_pos_drop_rate: float = 0.0, rna_proj_drop_rate: float = 0.1,
+                 rna_attn_drop_rate: float = 0.0, rna_drop_path_rate: float = 0.0, rna_norm_layer=None,
+                 rna_act_layer=None, rna_retention_decoder_depth: int = 1,
+                 init_logit_scale: float = float(np.log(1 / 0.07)), style_mlp_hidden_dim: int = 512,
+                 style_mlp_out_dim: int = 256, style_norm_layer=None, style_act_layer=None,
+                 style_latent_dim: int = 128, num_prototypes: int = 3000, rna_num_heads: int = 12):
+        super().__init__()
+        for nm, v, ok in (("rna_norm_layer", rna_norm_layer, (None, "layernorm")), ("rna_act_layer", rna_act_layer, (None, "gelu")),
+                          ("style_norm_layer", style_norm_layer, (None,)), ("style_act_layer", style_act_layer, (None, "gelu"))):
+            if v not in ok:
+                raise NotImplementedError(f"{nm}={v!r}: only {ok} have HIP kernels")
+        if rna_attn_drop_rate or rna_drop_path_rate:
+            raise NotImplementedError("attention dropout / drop-path are 0 in every reference config")
+        self.wsi_embed_dim, self.rna_embed_dim, self.embed_dim = wsi_embed_dim, rna_embed_dim, embed_dim
+        self.wsi_num_tokens = wsi_num_tokens
+        self.style_latent_dim = style_latent_dim
+        self.logit_scale = nn.Parameter(torch.ones([]) * init_logit_scale)
+        self.wsi_encoder = FeatureTransMILHybrid(wsi_embed_dim, embed_dim, wsi_num_tokens, wsi_retention_decoder_depth)
+        self.rna_encoder = TransFormerHybrid(
+            input_dim=rna_embed_dim, embed_dim=embed_dim, depth=rna_encoder_depth, num_heads=rna_num_heads,
+            mlp_ratio=rna_mlp_ratio, gene_embed=rna_gene_embed, pos_drop_rate=rna_pos_drop_rate,
+            proj_drop_rate=rna_proj_drop_rate, retention_decoder_depth=rna_retention_decoder_depth)
+        self.style_encoder_mlp = _Mlp(embed_dim, style_mlp_hidden_dim, style_mlp_out_dim, None, 0.0)
+        self.style_mu = nn.Linear(style_mlp_out_dim, style_latent_dim)
+        self.style_logstd = nn.Linear(style_mlp_out_dim, style_latent_dim)
+        self.style_decoder = nn.Linear(style_latent_dim, embed_dim)
+        self.prototypes = nn.Linear(embed_dim, num_prototypes, bias=False)
+        nn.init.orthogonal_(self.prototypes.weight)
+        self._precision: Optional[str] = None
+
+    @property
+    def precision(self) -> Optional[str]:
+        return self._precision
+
+    @precision.setter
+    def precision(self, name: Optional[str]) -> None:
+        if name is not None and name not in POLICIES:
+            raise ValueError(f"unknown precision {name!r}")
+        self._precision = name
+        self.wsi_encoder.precision = name
+        self.rna_encoder.precision = name
+
+    def reparameterize(self, mu, logstd, eps: Optional[torch.Tensor] = None):
+        if eps is None:
+            eps = torch.randn_like(mu)
+        return Fn.ReparamFn.apply(mu, logstd, eps)
+
+    def _style_branch(self, emb, eps, prec):
+        h = self.style_encoder_mlp(emb, prec)
+        mu = Fn.linear(h, self.style_mu.weight, self.style_mu.bias, prec=prec, out_dtype=f32)
+        logstd = Fn.linear(h, self.style_logstd.weight, self.style_logstd.bias, prec=prec, out_dtype=f32)
+        z = self.reparameterize(mu, logstd, eps)
+        z = Fn.linear(z, self.style_decoder.weight, self.style_decoder.bias, prec=prec)
+        score = Fn.linear(z, self.prototypes.weight, None, prec=prec, out_dtype=f32)
+        return score, mu, logstd
+
+    def forward_style_clustering(self, wsi_emb, rna_emb, wsi_eps=None, rna_eps=None):
+        prec = resolve_precision(self._precision)
+        wsi_score, wsi_mu, wsi_logstd = self._style_branch(wsi_emb, wsi_eps, prec)
+        rna_score, rna_mu, rna_logstd = self._style_branch(rna_emb, rna_eps, prec)
+        return wsi_score, wsi_mu, wsi_logstd, rna_score, rna_mu, rna_logstd
+
+    def forward(self, wsi_emb, rna_emb, wsi_mask_ratio: float = 0.75, rna_mask_ratio: float = 0.75,
+                noise: Optional[Dict[str, torch.Tensor]] = None):
+        noise = noise or {}
+        # the reference draws: rand(B,N) -> rand(B,D) -> eps_wsi -> eps_rna (models/mirror.py:630, :516, :832-833)
+        wsi_emb = self.wsi_encoder.forward_encoder(wsi_emb)
+        wsi_alignment_emb, wsi_retention_emb, wsi_mask = self.wsi_encoder.forward_decoders(
+            wsi_emb, mask_ratio=wsi_mask_ratio, noise=noise.get("wsi_mask"))
+        wsi_retention_target = wsi_emb[:, 1:, :]
+        rna_emb = self.rna_encoder.forward_encoder(rna_emb)
+        rna_alignment_emb, rna_retention_emb, rna_mask = self.rna_encoder.forward_decoders(
+            rna_emb, mask_ratio=rna_mask_ratio, noise=noise.get("rna_mask"))
+        rna_retention_target = rna_emb
+        wsi_score, wsi_mu, wsi_logstd, rna_score, rna_mu, rna_logstd = self.forward_style_clustering(
+            wsi_emb[:, 0, :], rna_emb, noise.get("wsi_eps"), noise.get("rna_eps"))
+        return (wsi_alignment_emb, wsi_retention_emb, wsi_retention_target, wsi_mask, wsi_score, wsi_mu, wsi_logstd,
+                rna_alignment_emb, rna_retention_emb, rna_retention_target, rna_mask, rna_score, rna_mu, rna_logstd,
+                self.logit_scale.exp())
+
+
+_ACCEPTED = {
+    "wsi_embed_dim", "rna_embed_dim", "embed_dim", "wsi_num_tokens", "wsi_retention_decoder_depth",
+    "rna_encoder_depth", "rna_gene_embed", "rna_mlp_ratio", "rna_pos_drop_rate", "rna_proj_drop_rate",
+    "rna_attn_drop_rate", "rna_drop_path_rate", "rna_norm_layer", "rna_act_layer", "rna_retention_decoder_depth",
+    "init_logit_scale", "style_mlp_hidden_dim", "style_mlp_out_dim", "style_norm_layer", "style_act_layer",
+    "style_latent_dim", "num_prototypes",
+    "rna_num_heads",  # build-only extension
+}
+
+
+def mirror(**kwargs) -> MIRROR:
+    """Registry entry point (models/mirror.py:1018-1053): unknown kwargs (e.g. timm's pretrained*) are dropped with a warning."""
+    kept = {k: v for k, v in kwargs.items() if k in _ACCEPTED}
+    dropped = [k for k in kwargs if k not in _ACCEPTED]
+    if dropped:
+        _logger.warning("Filtered model kwargs: %s", ", ".join(dropped))
+    return MIRROR(**kept)

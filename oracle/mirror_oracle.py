@@ -33,6 +33,13 @@ Tensor = torch.Tensor
 SD = Dict[str, Tensor]
 
 
+def exact_cpu_convs():
+    """Context manager for parity runs: torch 2.10's oneDNN CPU conv2d weight-gradient is wrong for some
+    depthwise shapes (33-tap res_conv at n_p=256: error O(10) against an explicit sum; found while pinning the
+    HIP path).  With oneDNN off ATen's native kernels are used, which agree with the explicit sum."""
+    return torch.backends.mkldnn.flags(enabled=False)
+
+
 @dataclass
 class Cfg:
     """Model hyper-parameters (names follow `models/mirror.py:721-745`)."""

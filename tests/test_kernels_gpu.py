@@ -394,6 +394,11 @@ def test_elementwise_family():
     close(K.gelu_bwd(x.to(DEV), y.to(DEV)), xr.grad, 1e-5, 1e-6, "gelu bwd")
     r = F.relu(x)
     close(K.relu_bwd(r.to(DEV), y.to(DEV)), y * (r > 0), 0, 0, "relu bwd")
+    r3 = F.relu(torch.randn(3, 7, 8, generator=gen))
+    big = torch.zeros(3, 9, 8)
+    big[:, 1:8] = r3
+    d3 = torch.randn(3, 7, 8, generator=gen)
+    close(K.relu_bwd(big.to(DEV)[:, 1:8], d3.to(DEV), out_dtype=torch.bfloat16), (d3 * (r3 > 0)).bfloat16().float(), 0, 0, "relu bwd strided")
     m = torch.randn(300, 70, generator=gen)
     out = torch.ones(70, device=DEV)
     K.colsum(m.to(DEV)[:, :], out)

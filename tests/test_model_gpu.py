@@ -1,0 +1,155 @@
+"""GPU parity proper: the HIP path (through the C ABI) vs golden vectors recorded from the reference and
+vs the CPU oracle on the same seeded inputs.  fp32 policy, eval mode (dropout off), injected noise.
+
+Tolerances (SURVEY.md §8d / BASELINE.json): every loss term within 1e-4 relative; embeddings within
+1e-4 x max|ref| (max-abs); gradients within 2e-3 (norms) of the reference's autograd."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import mirror_amd.models as M  # noqa: E402
+from mirror_amd.losses import ClipLoss, InfoNCE, MIRRORLoss  # noqa: E402
+from oracle import mirror_oracle as O  # noqa: E402
+from tests.golden_util import GOLDEN, ModelCase, TEMPLATE_W, DEFAULT_W  # noqa: E402
+
+DEV = "cuda"
+LOSS_RTOL = 1e-4
+EMB_TOL = 1e-4
+W_KW = ("alignment_loss_weight", "wsi_retention_loss_weight", "rna_retention_loss_weight", "style_loss_weight",
+        "cluster_loss_weight")
+
+
+def build(case: ModelCase, precision="fp32"):
+    c = case.cfg
+    model = M.mirror(
+        wsi_embed_dim=c.wsi_embed_dim, rna_embed_dim=c.rna_embed_dim, embed_dim=c.embed_dim,
+        wsi_num_tokens=c.wsi_num_tokens, wsi_retention_decoder_depth=c.wsi_retention_decoder_depth,
+        rna_encoder_depth=c.rna_encoder_depth, rna_mlp_ratio=c.rna_mlp_ratio, rna_norm_layer="layernorm",
+        rna_act_layer="gelu", rna_retention_decoder_depth=c.rna_retention_decoder_depth,
+        style_mlp_hidden_dim=c.style_mlp_hidden_dim, style_mlp_out_dim=c.style_mlp_out_dim,
+        style_latent_dim=c.style_latent_dim, num_prototypes=c.num_prototypes, rna_num_heads=c.rna_num_heads)
+    model.load_state_dict(case.sd, strict=True)
+    model.precision = precision
+    return model.to(DEV).eval()
+
+
+def run(case, model):
+    noise = {k: v.to(DEV) for k, v in case.noise.items()}
+    return model(case.wsi.to(DEV), case.rna.to(DEV), wsi_mask_ratio=case.ratios[0], rna_mask_ratio=case.ratios[1],
+                 noise=noise)
+
+
+@pytest.mark.parametrize("name", ["tiny", "h12", "mid", "c1"])
+def test_forward_loss_backward_match_reference_golden(name):
+    case = ModelCase(name)
+    model = build(case)
+    outs = run(case, model)
+    assert len(outs) == 15
+    case.check_outputs(outs, rtol=EMB_TOL)
+    lt = MIRRORLoss(**dict(zip(W_KW, TEMPLATE_W)))(*outs)
+    ld = MIRRORLoss()(*[o.detach() for o in outs])
+    got_t = np.array([float(x.detach()) for x in lt])
+    got_d = np.array([float(x.detach()) for x in ld])
+    np.testing.assert_allclose(got_t, case.z["loss_template"], rtol=LOSS_RTOL)
+    np.testing.assert_allclose(got_d, case.z["loss_default"], rtol=LOSS_RTOL)
+    lt[0].backward()
+    params = dict(model.named_parameters())
+    gn = np.array([0.0 if params[k].grad is None else float(params[k].grad.double().norm()) for k in case.keys])
+    ref = case.z["grad_norm"]
+    bad = np.abs(gn - ref) > 2e-3 * ref + 1e-6 * ref.max()
+    assert not bad.any(), "grad-norm mismatch: " + ", ".join(
+        f"{k}: {a:.6g} vs {b:.6g}" for k, a, b, f in zip(case.keys, gn, ref, bad) if f)
+    for k in case.keys:
+        if f"grad/{k}" in case.z.files:
+            g = case.z[f"grad/{k}"]
+            tol = 2e-3 * max(float(np.abs(g).max()), 1e-7)
+            np.testing.assert_allclose(params[k].grad.cpu().numpy(), g, atol=tol, rtol=0, err_msg=k)
+
+
+def test_hip_path_matches_cpu_oracle_live():
+    """Same seeded inputs through the oracle (CPU) and the HIP path, no fixture in between."""
+    case = ModelCase("mid")
+    outs_ref = O.mirror_forward(case.sd, case.cfg, case.wsi, case.rna, case.noise, *case.ratios)
+    model = build(case)
+    outs = run(case, model)
+    for nm, a, b in zip(O.OUTPUT_NAMES, outs, outs_ref):
+        scale = max(float(b.abs().max()), 1e-6)
+        err = float((a.detach().cpu() - b).abs().max()) / scale
+        assert err <= EMB_TOL, f"{nm}: {err:.3e}"
+    got = [float(x.detach()) for x in MIRRORLoss()(*outs)]
+    ref = [float(x) for x in O.mirror_loss(outs_ref, DEFAULT_W)]
+    np.testing.assert_allclose(got, ref, rtol=LOSS_RTOL)
+
+
+def test_mirror_loss_module_matches_reference_golden():
+    z = np.load(os.path.join(GOLDEN, "golden_losses.npz"))
+    for tag, w in (("default", DEFAULT_W), ("template", TEMPLATE_W)):
+        ins = []
+        for nm in O.OUTPUT_NAMES:
+            t = torch.from_numpy(z[f"in/{nm}"]).to(DEV)
+            ins.append(t.requires_grad_(f"grad_{tag}/{nm}" in z.files))
+        out = MIRRORLoss(**dict(zip(W_KW, w)))(*ins)
+        np.testing.assert_allclose([float(x.detach()) for x in out], z[f"loss_{tag}"], rtol=LOSS_RTOL)
+        out[0].backward()
+        for nm, t in zip(O.OUTPUT_NAMES, ins):
+            key = f"grad_{tag}/{nm}"
+            if key in z.files:
+                g = z[key]
+                np.testing.assert_allclose(t.grad.cpu().numpy(), g, atol=2e-4 * max(np.abs(g).max(), 1e-6), rtol=1e-3,
+                                           err_msg=f"{tag}:{nm}")
+    cl = ClipLoss()(torch.from_numpy(z["in/wsi_alignment_emb"]).to(DEV), torch.from_numpy(z["in/rna_alignment_emb"]).to(DEV),
+                    torch.from_numpy(z["in/logit_scale"]).to(DEV))
+    np.testing.assert_allclose(float(cl), float(z["clip_loss"]), rtol=LOSS_RTOL)
+
+
+def test_info_nce_module_matches_reference_golden():
+    z = np.load(os.path.join(GOLDEN, "golden_infonce.npz"))
+    q0, k0 = torch.from_numpy(z["q"]).to(DEV), torch.from_numpy(z["k"]).to(DEV)
+    n = 0
+    for key in z.files:
+        if not key.startswith("loss/"):
+            continue
+        tag = key[5:]
+        sym, red, tau = tag.split("_")
+        q, k = q0.clone().requires_grad_(True), k0.clone().requires_grad_(True)
+        out = InfoNCE(temperature=float(tau), reduction=red, symmetric=(sym == "sym1"))(q, k)
+        np.testing.assert_allclose(out.detach().cpu().numpy(), z[key], rtol=LOSS_RTOL, atol=1e-6, err_msg=tag)
+        out.sum().backward()
+        np.testing.assert_allclose(q.grad.cpu().numpy(), z[f"gq/{tag}"], rtol=2e-3, atol=2e-6, err_msg=tag)
+        np.testing.assert_allclose(k.grad.cpu().numpy(), z[f"gk/{tag}"], rtol=2e-3, atol=2e-6, err_msg=tag)
+        n += 1
+    assert n == 12
+    with pytest.raises(ValueError):
+        InfoNCE()(q0[:, None], k0)
+    with pytest.raises(ValueError):
+        InfoNCE()(q0[:5], k0)
+
+
+def test_bf16_policy_is_close_and_runs_train_mode():
+    """bf16 MFMA policy: reported accuracy band (not the fp32 parity gate) + a train-mode step with dropout."""
+    case = ModelCase("c1")
+    model = build(case, precision="bf16")
+    outs = run(case, model)
+    got = np.array([float(x.detach()) for x in MIRRORLoss(**dict(zip(W_KW, TEMPLATE_W)))(*outs)])
+    ref = case.z["loss_template"]
+    rel = np.abs(got - ref) / np.abs(ref)
+    assert (rel < 5e-2).all(), f"bf16 loss rel err {rel}"
+    model.train()
+    outs = run(case, model)
+    loss = MIRRORLoss()(*outs)[0]
+    loss.backward()
+    assert torch.isfinite(loss)
+    for k, p in model.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+
+
+def test_model_refuses_cpu_tensors():
+    case = ModelCase("tiny")
+    model = build(case)
+    from mirror_amd import MirrorHipError
+    with pytest.raises(MirrorHipError):
+        model(case.wsi, case.rna)

@@ -15,6 +15,11 @@ def test_model_forward_and_loss_match_reference(name):
     case = ModelCase(name)
     torch.set_num_threads(8)
     sd = {k: v.clone().requires_grad_(True) for k, v in case.sd.items()}
+    with O.exact_cpu_convs():
+        _check_case(case, sd)
+
+
+def _check_case(case, sd):
     outs = O.mirror_forward(sd, case.cfg, case.wsi, case.rna, case.noise, *case.ratios)
     case.check_outputs(outs, rtol=2e-4)
     lt = O.mirror_loss(outs, TEMPLATE_W)

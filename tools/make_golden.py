@@ -225,6 +225,10 @@ def main():
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     torch.set_num_threads(8)
+    # torch 2.10 CPU: the oneDNN conv2d weight-gradient is WRONG for some depthwise shapes (e.g. the 33-tap
+    # res_conv at n_p=256: error O(10) vs an explicit sum; forward and input-gradient are fine).  Recording the
+    # reference with oneDNN off uses ATen's native convolution, which agrees with the explicit sum.
+    torch.backends.mkldnn.enabled = False
     ref_losses, ClipLoss = load_reference_losses()
     gen_losses(ref_losses, ClipLoss, a.out)
     mod, used = load_reference_model_module(a.use_installed)
