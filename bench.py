@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""MIRROR pre-training step benchmark on MI355X (BASELINE.json metric: SSL samples/s, slide+RNA pairs).
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A step = prototype renorm -> forward -> MIRRORLoss -> backward (+ RCCL gradient all-reduce) -> Adam -> logit clamp
+on one synthetic batch per GPU (BASELINE config 2: B x [4096 patch tokens x 1024-d] + [B x 2048 genes], D=512,
+6-layer RNA encoder, bf16 MFMA, dropout on).  Weak scaling: per-GPU batch fixed.  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16 peak, MI355X_MICROARCH.md §Chip-level parameters
+PEAK_F32_TFLOPS = 157.3     # f32-input MFMA peak (same guide)
+
+
+def model_flops_fwd(N, F, D, G, L, P=3000, mlp_ratio=4.0, style=(512, 256, 128)):
+    """Canonical (re-associated) forward GEMM/conv FLOPs per sample, SURVEY.md §8d."""
+    h, m = 8, D // 2
+    side = math.ceil(math.sqrt(N))
+    nsq = side * side
+    n, nr = nsq + 1, N + 1
+
+    def layer(length):
+        p = math.ceil(length / m) * m
+        return (6 * p * D * D + 2 * p * m * D + 2 * m * m * D + 2 * m * p * D + 48 * h * m ** 3 + 2 * m * p * D
+                + 2 * m * m * D + 2 * p * m * D + 66 * p * D + 2 * p * D * D)
+    hh = int(D * mlp_ratio)
+    rna = 4 * G * D + 4 * D * D + (L + 1) * (8 * D * D + 4 * D * hh) + 6 * D * D
+    sty = 4 * (style[0] * D + style[0] * style[1] + 2 * style[1] * style[2] + style[2] * D + D * P)
+    return 2 * N * F * D + 2 * layer(n) + 166 * nsq * D + 4 * (N + 1) * D * D + layer(nr) + 2 * D * D + rna + sty
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16_fast", "fp32"])
+    ap.add_argument("--config", default="c2", choices=["c1", "c2"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="rank-local InfoNCE even when N>1 (reference behaviour)")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from mirror_amd import _lib, kernels as K
+    import mirror_amd.models as M
+    from mirror_amd.engine import TrainEngine
+    from mirror_amd.losses import MIRRORLoss
+    from mirror_amd import functional as Fn
+
+    lib = _lib.load()
+    if lib.mh_device_ok() <= 0:
+        raise SystemExit("bench.py needs an MI355X: " + lib.mh_last_error().decode())
+
+    if a.config == "c2":
+        shp = dict(N=4096, F=1024, G=2048, D=512, L=6)
+    else:
+        shp = dict(N=256, F=1024, G=512, D=256, L=2)
+    torch.manual_seed(42)   # configs/pretrain/mirror.template.yaml:123
+    model = M.mirror(wsi_embed_dim=shp["F"], rna_embed_dim=shp["G"], embed_dim=shp["D"], wsi_num_tokens=shp["N"],
+                     rna_encoder_depth=shp["L"], rna_mlp_ratio=4.0, rna_norm_layer="layernorm", rna_act_layer="gelu",
+                     rna_num_heads=8).to(dev).train()
+    loss_fn = MIRRORLoss(alignment_loss_weight=0.5, wsi_retention_loss_weight=0.15, rna_retention_loss_weight=0.15,
+                         style_loss_weight=0.1, cluster_loss_weight=0.1,
+                         gather_distributed=(world > 1 and not a.no_gather))
+    eng = TrainEngine(model, loss_fn, lr=2e-5, precision=a.precision)
+    Fn.manual_seed(1234 + rank)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    in_dtype = torch.float32 if a.precision == "fp32" else torch.bfloat16
+    wsi = torch.randn(a.batch, shp["N"], shp["F"], device=dev, generator=g).to(in_dtype)
+    rna = torch.randn(a.batch, shp["G"], device=dev, generator=g)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up; its first step also profiles every GEMM variant to find the dominant kernel
+    K.gemm_profiler = K.GemmProfiler()
+    eng.step(wsi, rna)
+    torch.cuda.synchronize()
+    summ = K.gemm_profiler.summary()
+    K.gemm_profiler = None
+    dominant = max(summ, key=lambda v: summ[v]["total_ms"])
+    for _ in range(max(0, a.warmup - 1)):
+        eng.step(wsi, rna)
+
+    # ---- timed region: exactly K steps, barrier + synchronize on both sides; the dominant GEMM variant
+    #      carries HIP event pairs on its launch stream (torch's current stream) for the roofline entry
+    K.gemm_profiler = K.GemmProfiler(only=dominant)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        losses = eng.step(wsi, rna)
+    sync_all()
+    dt = time.perf_counter() - t0
+    prof = K.gemm_profiler.summary().get(dominant, {"launches": 0, "total_ms": 0.0, "flops": 0.0})
+    K.gemm_profiler = None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    loss_vals = [float(x) for x in losses]
+
+    if rank == 0:
+        samples = a.batch * world * a.steps
+        value = samples / dt
+        fl_fwd = model_flops_fwd(shp["N"], shp["F"], shp["D"], shp["G"], shp["L"])
+        step_tflops = 3 * fl_fwd * a.batch * world * a.steps / dt / 1e12
+        is_f32 = dominant.startswith("gemm_kernel<0")
+        peak = PEAK_F32_TFLOPS if is_f32 else PEAK_BF16_TFLOPS
+        avg_ms = prof["total_ms"] / max(prof["launches"], 1)
+        ach = (prof["flops"] / max(prof["launches"], 1)) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "SSL samples/sec (slide+RNA pairs)", "value": round(value, 3), "unit": "samples/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {"bf16": "bf16", "bf16_fast": "bf16", "fp32": "f32"}[a.precision], "data": "synthetic",
+            "config": {"workload": f"BASELINE {a.config}: B={a.batch}/GPU x [{shp['N']} patch tokens x {shp['F']}-d] + "
+                                   f"[{shp['G']} genes], D={shp['D']}, RNA depth {shp['L']}, train mode, "
+                                   f"{'global' if (world > 1 and not a.no_gather) else 'local'}-batch InfoNCE",
+                       "precision_policy": a.precision, "per_gpu_batch": a.batch, "global_batch": a.batch * world,
+                       "parallelism": f"dp{world}"},
+            "model_tflops_per_s": round(step_tflops, 2),
+            "model_flops_frac_of_bf16_peak": round(step_tflops / world / PEAK_BF16_TFLOPS, 4),
+            "losses": [round(x, 5) for x in loss_vals],
+            "roofline": {"bound": "mfma", "kernel": dominant, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(ach / peak, 4), "traffic": None, "launches_timed": prof["launches"],
+                         "avg_launch_ms": round(avg_ms, 5),
+                         "share_of_gemm_time_in_profiled_step": round(summ[dominant]["total_ms"] / max(sum(s["total_ms"] for s in summ.values()), 1e-9), 3)},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            from oracle import mirror_oracle as O
+            from oracle.cpu_step import time_cpu_steps
+            cfg = O.Cfg(wsi_embed_dim=shp["F"], rna_embed_dim=shp["G"], embed_dim=shp["D"], wsi_num_tokens=shp["N"],
+                        rna_encoder_depth=shp["L"], rna_mlp_ratio=4.0, rna_num_heads=8)
+            cb = 2 if a.config == "c2" else 8
+            r = time_cpu_steps(cfg, batch=cb, steps=2, warmup=1, threads=os.cpu_count() or 1)
+            out["cpu_baseline"] = {"value": round(r["samples_per_s"], 4), "unit": "samples/s", "cores": r["cores"],
+                                   "kind": "port",
+                                   "sample": f"oracle (torch fp32 CPU restatement of the reference), same shapes, B={cb}, "
+                                             f"{r['steps']} timed steps of fwd+loss+bwd+Adam after 1 warm-up "
+                                             f"({r['s_per_step']:.2f} s/step)"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,159 @@
+"""Training step engine for the MIRROR hot path: the per-step semantics of `train_one_epoch`
+(train_mirror.py:1126-1284) on MI355X, one process per GPU.
+
+  * flat arenas: f32 master params, f32 grads, Adam m/v and a bf16 shadow live in five contiguous HBM
+    buffers; module parameters are views into them.  Adam (+ the bf16 shadow refresh) is ONE kernel over
+    the arena, zero-grad is one memset, and gradient all-reduce works on arena slices (no flatten copies).
+  * data parallel = DDP semantics (gradient AVG across ranks, train_mirror.py:811-813): arena buckets are
+    all-reduced over RCCL on a side HIP stream as soon as autograd has finished the parameters they hold,
+    overlapping the WSI backward; the arena is laid out in reverse registration order so buckets complete
+    roughly front to back.
+  * step glue kept from the reference: prototype rows L2-normalised before every batch (:1133-1136),
+    logit_scale clamped to [0, ln 100] after the update (:1254-1255) — both as kernels, no host sync.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+from . import functional as Fn
+from . import kernels as K
+from .functional import POLICIES
+
+f32, bf16 = torch.float32, torch.bfloat16
+_ALIGN = 8  # elements: keeps every parameter 32-B aligned in f32 and 16-B aligned in the bf16 shadow
+
+
+def plan_buckets(sizes: Sequence[int], cap_elems: int, align: int = _ALIGN):
+    """Cut the arena (parameters laid out back to back, each padded to `align` elements) into all-reduce
+    buckets of at least `cap_elems` elements (the last one takes the remainder).
+    Returns ([[start, end, n_params], ...], owner) with owner[i] = bucket index of parameter i."""
+    buckets: List[List[int]] = []
+    owner: List[int] = []
+    start = off = count = 0
+    for i, n in enumerate(sizes):
+        off += (n + align - 1) // align * align
+        owner.append(len(buckets))
+        count += 1
+        if off - start >= cap_elems or i == len(sizes) - 1:
+            buckets.append([start, off, count])
+            start, count = off, 0
+    return buckets, owner
+
+
+class TrainEngine:
+    def __init__(self, model: torch.nn.Module, loss_fn, *, lr: float = 2e-5, betas=(0.9, 0.999), eps: float = 1e-8,
+                 precision: str = "bf16", wsi_mask_ratio: float = 0.75, rna_mask_ratio: float = 0.75,
+                 bucket_mb: float = 25.0, process_group=None):
+        if precision not in POLICIES:
+            raise ValueError(f"unknown precision {precision!r}")
+        self.model, self.loss_fn = model, loss_fn
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.precision = precision
+        self.wsi_mask_ratio, self.rna_mask_ratio = wsi_mask_ratio, rna_mask_ratio
+        self.step_count = 0
+        model.precision = precision
+        self.pg = process_group
+        self.world = dist.get_world_size(self.pg) if (dist.is_available() and dist.is_initialized()) else 1
+        params = [p for p in model.parameters() if p.requires_grad]
+        if not params or not params[0].is_cuda:
+            raise Fn.K.MirrorHipError("TrainEngine needs the model on an MI355X device (model.to('cuda') first)")
+        self.device = params[0].device
+        # arena order: reverse registration order ~ the order in which autograd finishes gradients
+        order = list(reversed(params))
+        offs, total = [], 0
+        for p in order:
+            offs.append(total)
+            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.numel = total
+        self.master = torch.zeros(total, device=self.device, dtype=f32)
+        self.grad = torch.zeros(total, device=self.device, dtype=f32)
+        self.m = torch.zeros(total, device=self.device, dtype=f32)
+        self.v = torch.zeros(total, device=self.device, dtype=f32)
+        self.shadow = torch.zeros(total, device=self.device, dtype=bf16) if POLICIES[precision].act == bf16 else None
+        self.params, self.offsets = order, offs
+        with torch.no_grad():
+            for p, o in zip(order, offs):
+                n = p.numel()
+                self.master[o:o + n].copy_(p.detach().reshape(-1))
+                p.data = self.master[o:o + n].view(p.shape)
+                p.grad = self.grad[o:o + n].view(p.shape)
+        self.sync_shadows()
+        self._proto = getattr(model, "prototypes", None)
+        self._logit = getattr(model, "logit_scale", None)
+        if self.world > 1:
+            dist.broadcast(self.master, src=0, group=self.pg)  # DDP's parameter broadcast at wrap time
+            self.sync_shadows()
+            self._build_buckets(bucket_mb)
+
+    # ------------------------------------------------------------------ shadows
+    def sync_shadows(self) -> None:
+        """(Re)publish the bf16 copies after the master arena was written by anything but step()."""
+        if self.shadow is None:
+            return
+        K.cast(self.master, bf16, out=self.shadow)
+        for p, o in zip(self.params, self.offsets):
+            Fn.register_shadow(p, self.shadow[o:o + p.numel()].view(p.shape))
+
+    # ------------------------------------------------------------------ gradient buckets (data parallel)
+    def _build_buckets(self, bucket_mb: float) -> None:
+        self.buckets, owner = plan_buckets([p.numel() for p in self.params], int(bucket_mb * (1 << 20) / 4))
+        self._bucket_of: Dict[int, int] = {id(p): b for p, b in zip(self.params, owner)}
+        self._pending = [b[2] for b in self.buckets]
+        self._works = []
+        self.comm_stream = torch.cuda.Stream(device=self.device)
+        for p in self.params:
+            p.register_post_accumulate_grad_hook(self._on_grad)
+
+    def _on_grad(self, p: torch.Tensor) -> None:
+        b = self._bucket_of[id(p)]
+        self._pending[b] -= 1
+        if self._pending[b] == 0:
+            s, e, _ = self.buckets[b]
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                w = dist.all_reduce(self.grad[s:e], op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
+            self._works.append(w)
+
+    def _finish_reduce(self) -> None:
+        if self.world == 1:
+            return
+        if any(c != 0 for c in self._pending):  # a parameter got no gradient this step: reduce what is left
+            for b, c in enumerate(self._pending):
+                if c != 0:
+                    s, e, _ = self.buckets[b]
+                    self.comm_stream.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(self.comm_stream):
+                        self._works.append(dist.all_reduce(self.grad[s:e], op=dist.ReduceOp.AVG, group=self.pg, async_op=True))
+        for w in self._works:
+            w.wait()
+        torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self._works = []
+        self._pending = [b[2] for b in self.buckets]
+
+    # ------------------------------------------------------------------ one optimizer step
+    def step(self, wsi: torch.Tensor, rna: torch.Tensor, noise: Optional[dict] = None):
+        """prototype renorm -> forward -> MIRRORLoss -> backward (+ overlapped all-reduce) -> Adam -> clamp.
+        Returns the 6 loss tensors (device scalars; nothing is synchronised here)."""
+        if self._proto is not None:
+            w = self._proto.weight
+            K.rownorm_(w.data)
+            if self.shadow is not None:
+                K.cast(w.data, bf16, out=Fn.shadow(w, POLICIES[self.precision]))
+        outs = self.model(wsi, rna, wsi_mask_ratio=self.wsi_mask_ratio, rna_mask_ratio=self.rna_mask_ratio, noise=noise)
+        losses = self.loss_fn(*outs)
+        losses[0].backward()
+        self._finish_reduce()
+        self.step_count += 1
+        b1, b2 = self.betas
+        K.adam(self.master, self.grad, self.m, self.v, self.shadow, self.lr, b1, b2, self.eps,
+               1.0 - b1 ** self.step_count, 1.0 - b2 ** self.step_count)
+        if self._logit is not None:
+            K.clamp_(self._logit.data.reshape(1), 0.0, math.log(100.0))
+            if self.shadow is not None:
+                K.cast(self._logit.data.reshape(1), bf16, out=Fn.shadow(self._logit, POLICIES[self.precision]).reshape(1))
+        self.grad.zero_()
+        return tuple(x.detach() for x in losses)

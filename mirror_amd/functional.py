@@ -47,6 +47,9 @@ def shadow(w: torch.Tensor, prec: Precision) -> torch.Tensor:
     if wd.dtype == prec.act:
         return wd
     key = (wd.data_ptr(), tuple(wd.shape))
+    man = _managed_shadows.get(key)
+    if man is not None and man.dtype == prec.act:
+        return man
     hit = _shadow_cache.get(key)
     if hit is not None and hit[0] == w._version and hit[1].dtype == prec.act:
         return hit[1]
@@ -55,9 +58,17 @@ def shadow(w: torch.Tensor, prec: Precision) -> torch.Tensor:
     return s
 
 
-def register_shadow(w: torch.Tensor, s: torch.Tensor) -> None:
-    """Let an optimizer that maintains the bf16 copy itself (mh_adam) publish it."""
-    _shadow_cache[(w.data_ptr(), tuple(w.shape))] = (w._version, s)
+_managed_shadows: dict = {}
+
+
+def register_shadow(w: torch.Tensor, s: Optional[torch.Tensor]) -> None:
+    """An optimizer that maintains the bf16 copy itself (mh_adam writes master + shadow in one pass) publishes it
+    here; whoever rewrites the master outside that optimizer must refresh the shadow (TrainEngine.sync_shadows)."""
+    key = (w.data_ptr(), tuple(w.shape))
+    if s is None:
+        _managed_shadows.pop(key, None)
+    else:
+        _managed_shadows[key] = s
 
 
 def _split_k_for(rows: int, n: int, k: int) -> int:

@@ -111,8 +111,56 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *
     d.sA1, d.sA2, d.sB1, d.sB2 = sa1, sa2, sb1, sb2
     d.sC1, d.sC2 = (so[0] if B1 > 1 else 0), (so[1] if B2 > 1 else 0)
     d.alpha, d.diag, d.act, d.accumulate, d.split_k = alpha, diag, act, int(accumulate), max(1, int(split_k))
-    _lib.call("mh_gemm", C.byref(d), stream=_stream())
+    prof = gemm_profiler
+    if prof is None:
+        _lib.call("mh_gemm", C.byref(d), stream=_stream())
+    else:
+        prof.launch(d, lambda: _lib.call("mh_gemm", C.byref(d), stream=_stream()))
     return out
+
+
+_TN = {MH_F32: "float", MH_BF16: "bf16"}
+
+
+def gemm_variant(d: GemmDesc) -> str:
+    """The template instance mh_gemm dispatches to (matches the kernel symbol rocprofv3 reports)."""
+    wn = 1 if d.N <= 64 else 2
+    tc = "float" if d.mma == MH_F32 else _TN[d.dtC]
+    return (f"gemm_kernel<{d.mma},{_TN[d.dtA]},{_TN[d.dtB]},{tc},{'true' if d.a_kc else 'false'},"
+            f"{'true' if d.b_kc else 'false'},2,{wn}>")
+
+
+class GemmProfiler:
+    """Times GEMM launches with HIP events on the launch stream (bench.py's roofline leg).
+    only=None: every launch; only=<variant>: just that template instance (cheap enough for the timed region)."""
+
+    def __init__(self, only: Optional[str] = None):
+        self.only = only
+        self.records = []   # (variant, flops, start_event, end_event)
+
+    def launch(self, d: GemmDesc, fn) -> None:
+        v = gemm_variant(d)
+        if self.only is not None and v != self.only:
+            fn()
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        self.records.append((v, 2.0 * d.M * d.N * d.K * d.batch1 * d.batch2, e0, e1))
+
+    def summary(self):
+        """variant -> dict(launches, total_ms, flops); call after a device synchronise."""
+        out = {}
+        for v, fl, e0, e1 in self.records:
+            s = out.setdefault(v, {"launches": 0, "total_ms": 0.0, "flops": 0.0})
+            s["launches"] += 1
+            s["total_ms"] += e0.elapsed_time(e1)
+            s["flops"] += fl
+        return out
+
+
+gemm_profiler: Optional[GemmProfiler] = None
 
 
 # ----------------------------------------------------------------------------- row kernels
@@ -338,12 +386,14 @@ def add(a: torch.Tensor, b: torch.Tensor, out_dtype=None, out: Optional[torch.Te
     return y
 
 
-def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
-    if x.dtype == dtype:
+def cast(x: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if x.dtype == dtype and out is None:
         return x
-    _chk(x)
+    _chk(x, out)
     _contig(x, "cast input")
-    y = torch.empty_like(x, dtype=dtype)
+    y = torch.empty_like(x, dtype=dtype) if out is None else _contig(out, "cast output")
+    if y.numel() != x.numel():
+        raise MirrorHipError("cast: size mismatch")
     _lib.call("mh_cast", _p(x), _p(y), x.numel(), dt(x), dt(y), stream=_stream())
     return y
 
