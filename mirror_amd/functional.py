@@ -5,10 +5,10 @@ autograd tape, streams.  Every arithmetic step is a kernel launch from kernels.p
 
 Precision policies
   FP32  : f32 storage, v_mfma_f32_32x32x2_f32 everywhere  -> parity mode (vs the CPU oracle)
-  BF16  : bf16 GEMM operands / f32 accumulate, f32 residual stream, LN/softmax/loss maths in f32,
-          pseudo-inverse iterations in exact f32 MFMA                     -> training mode
-  BF16_FAST : as BF16 but the pseudo-inverse GEMMs round their f32 operands to bf16 (what the
-          reference's fp16 autocast does to them, SURVEY.md §7 hard part b)
+  BF16  : bf16 GEMM operands / f32 accumulate, f32 residual stream, LN/softmax/loss maths in f32; the
+          pseudo-inverse GEMMs keep f32 storage and round operands to bf16 in the LDS staging pass (what the
+          reference's own fp16 autocast does to them; measured: same loss/gradient error band as f32 pinv)
+  BF16_PINV32 : as BF16 with the pseudo-inverse iterations in exact f32 MFMA (conservative, ~1.6x slower step)
 """
 from __future__ import annotations
 
@@ -33,9 +33,9 @@ class Precision:
 
 
 FP32 = Precision("fp32", MH_F32, f32, MH_F32)
-BF16 = Precision("bf16", MH_BF16, bf16, MH_F32)
-BF16_FAST = Precision("bf16_fast", MH_BF16, bf16, MH_BF16)
-POLICIES = {p.name: p for p in (FP32, BF16, BF16_FAST)}
+BF16 = Precision("bf16", MH_BF16, bf16, MH_BF16)
+BF16_PINV32 = Precision("bf16_pinv32", MH_BF16, bf16, MH_F32)
+POLICIES = {p.name: p for p in (FP32, BF16, BF16_PINV32)}
 
 # ------------------------------------------------------------------ bf16 shadows of f32 master weights
 _shadow_cache: dict = {}

@@ -126,8 +126,18 @@ def gemm_variant(d: GemmDesc) -> str:
     """The template instance mh_gemm dispatches to (matches the kernel symbol rocprofv3 reports)."""
     wn = 1 if d.N <= 64 else 2
     tc = "float" if d.mma == MH_F32 else _TN[d.dtC]
+    bk = 64 if d.mma == MH_BF16 else 16
+    vec = 4 if d.dtA == MH_F32 else 8
+    split = max(1, d.split_k)
+    kps = -(-(-(-d.K // split)) // bk) * bk
+
+    def ok(ptr, ld, s1, s2):
+        return ptr % 16 == 0 and ld % vec == 0 and s1 % vec == 0 and s2 % vec == 0
+
+    full = (ok(d.A, d.lda, d.sA1, d.sA2) and ok(d.B, d.ldb, d.sB1, d.sB2) and d.M % 128 == 0
+            and d.N % (64 * wn) == 0 and d.K % bk == 0 and d.K % kps == 0)
     return (f"gemm_kernel<{d.mma},{_TN[d.dtA]},{_TN[d.dtB]},{tc},{'true' if d.a_kc else 'false'},"
-            f"{'true' if d.b_kc else 'false'},2,{wn}>")
+            f"{'true' if d.b_kc else 'false'},2,{wn},{'true' if full else 'false'}>")
 
 
 class GemmProfiler:

@@ -7,7 +7,7 @@ containers only* (identical keys, shapes and default initialisation); their forw
 Build-only extensions (default = reference behaviour):
   * `rna_num_heads` kwarg (the reference hard-wires 12, models/mirror.py:392/:798-811, which rejects D=256/512);
   * `noise=` dict for the four random draws of MIRROR.forward (reproducible parity runs);
-  * `precision` attribute / `mirror_amd.set_precision()` : "fp32" | "bf16" | "bf16_fast" | None (follow autocast).
+  * `precision` attribute / `mirror_amd.set_precision()` : "fp32" | "bf16" | "bf16_pinv32" | None (follow autocast).
 """
 from __future__ import annotations
 

@@ -112,8 +112,23 @@ def test_gemm_epilogues_and_split_k(mma, dtype):
     base = a.double() @ b.double().t()
     y = K.gemm(a_d, b_d.t(), bias=bias_d, act=ACT_RELU, mma=mma, out_dtype=torch.float32)
     close(y, F.relu(base + bias.double()), 0, 0, "bias+relu")
-    y = K.gemm(a_d, b_d.t(), bias=bias_d, act=ACT_GELU, alpha=0.125, mma=mma, out_dtype=torch.float32)
-    close(y, F.gelu(0.125 * base + bias.double()), 1e-5, 1e-5, "bias+gelu")
+    y = K.gemm(a_d, b_d.t(), bias=bias_d, alpha=0.125, mma=mma, out_dtype=torch.float32)
+    close(y, 0.125 * base + bias.double(), 0, 0, "alpha+bias")
+    from mirror_amd import MirrorHipError
+    with pytest.raises(MirrorHipError):  # GELU is not fused into the GEMM epilogue (mh_gelu_fwd)
+        K.gemm(a_d, b_d.t(), act=ACT_GELU, mma=mma)
+    # a FULL-tile problem exercises the LDS-staged wide-store epilogue, incl. read-modify-write accumulate
+    af, bf_ = ints((256, 128), gen).to(DEV, dtype), ints((128, 128), gen).to(DEV, dtype)
+    cf = ints((256, 128), gen).to(DEV, dtype)
+    ref_f = af.cpu().double() @ bf_.cpu().double().t() + ints((128,), g(1)).double()
+    y = K.gemm(af, bf_.t(), bias=ints((128,), g(1)).to(DEV), act=ACT_RELU, mma=mma)
+    close(y, F.relu(ref_f), 0, 0, "full tile bias+relu")
+    acc_f = cf.clone()
+    K.gemm(af, bf_.t(), out=acc_f, accumulate=True, mma=mma)
+    exp = cf.cpu().double() + af.cpu().double() @ bf_.cpu().double().t()
+    if dtype == torch.bfloat16:
+        exp = exp.float().bfloat16().double()
+    close(acc_f, exp, 0, 0, "full tile accumulate")
     sq = ints((64, 64), gen).to(DEV, dtype)
     y = K.gemm(sq, sq, alpha=-1.0, diag=15.0, mma=mma, out_dtype=torch.float32)
     close(y, 15 * torch.eye(64, dtype=torch.float64) - sq.cpu().double() @ sq.cpu().double(), 0, 0, "diag")
