@@ -3,17 +3,8 @@
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-extern "C" int mh_gemm(const mh_gemm_desc* d, mh_stream stream) {
-    MH_REQUIRE(d && d->A && d->B && d->C, "mh_gemm: null pointer");
-    MH_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "mh_gemm: empty problem M=%d N=%d K=%d", d->M, d->N, d->K);
-    MH_REQUIRE(d->batch1 >= 1 && d->batch2 >= 1 && (long)d->batch1 * d->batch2 <= 65535, "mh_gemm: bad batch");
-    MH_REQUIRE(d->dtA == d->dtB, "mh_gemm: dtA must equal dtB");
-    MH_REQUIRE(d->mma == MH_BF16 || (d->dtA == MH_F32 && d->dtC == MH_F32), "mh_gemm: f32 MMA needs f32 operands");
+static int launch_one(const mh_gemm_desc* d, hipStream_t s) {
     const int split = d->split_k < 1 ? 1 : d->split_k;
-    MH_REQUIRE(split == 1 || (d->accumulate && d->dtC == MH_F32 && d->act == MH_ACT_NONE),
-               "mh_gemm: split_k>1 needs accumulate=1, f32 C, no activation");
-    MH_REQUIRE(split <= 65535, "mh_gemm: split_k too large");
-    MH_REQUIRE(d->act == MH_ACT_NONE || d->act == MH_ACT_RELU, "mh_gemm: only ReLU is fused (GELU runs as mh_gelu_fwd)");
     GemmArgs a;
     a.A = d->A; a.B = d->B; a.C = d->C; a.bias = d->bias;
     a.M = d->M; a.N = d->N; a.K = d->K;
@@ -35,10 +26,44 @@ extern "C" int mh_gemm(const mh_gemm_desc* d, mh_stream stream) {
     a.atomic = (a.split_k > 1) || (d->accumulate && batch > 1 && d->sC1 == 0 && d->sC2 == 0);
     MH_REQUIRE(!a.atomic || (d->dtC == MH_F32 && d->act == MH_ACT_NONE && d->accumulate),
                "mh_gemm: atomic accumulation (split-K / batch broadcast into C) needs f32 C, accumulate=1, no activation");
-    hipStream_t s = (hipStream_t)stream;
     if (d->mma == MH_F32) gemm_launch_f32(a, d->a_kc, d->b_kc, batch, s);
     else if (d->dtA == MH_BF16) gemm_launch_bf16(a, d->a_kc, d->b_kc, d->dtC, batch, s);
     else gemm_launch_mixed(a, d->a_kc, d->b_kc, d->dtC, batch, s);
     MH_LAUNCH_CHECK("mh_gemm");
     return MH_OK;
+}
+
+extern "C" int mh_gemm(const mh_gemm_desc* d, mh_stream stream) {
+    MH_REQUIRE(d && d->A && d->B && d->C, "mh_gemm: null pointer");
+    MH_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "mh_gemm: empty problem M=%d N=%d K=%d", d->M, d->N, d->K);
+    MH_REQUIRE(d->batch1 >= 1 && d->batch2 >= 1 && (long)d->batch1 * d->batch2 <= 65535, "mh_gemm: bad batch");
+    MH_REQUIRE(d->dtA == d->dtB, "mh_gemm: dtA must equal dtB");
+    MH_REQUIRE(d->mma == MH_BF16 || (d->dtA == MH_F32 && d->dtC == MH_F32), "mh_gemm: f32 MMA needs f32 operands");
+    const int split = d->split_k < 1 ? 1 : d->split_k;
+    MH_REQUIRE(split == 1 || (d->accumulate && d->dtC == MH_F32 && d->act == MH_ACT_NONE),
+               "mh_gemm: split_k>1 needs accumulate=1, f32 C, no activation");
+    MH_REQUIRE(split <= 65535, "mh_gemm: split_k too large");
+    MH_REQUIRE(d->act == MH_ACT_NONE || d->act == MH_ACT_RELU, "mh_gemm: only ReLU is fused (GELU runs as mh_gelu_fwd)");
+    hipStream_t s = (hipStream_t)stream;
+    // A ragged K (e.g. a weight gradient over B*(N+1) rows) would push the whole launch onto the guarded kernel:
+    // run the BK-multiple part on the fast path and add the short tail with a second (accumulating) launch.
+    const int BK = d->mma == MH_BF16 ? 64 : 16;
+    const int tail = d->K % BK;
+    if (tail != 0 && d->K >= 8 * BK && d->dtC == MH_F32 && d->act == MH_ACT_NONE) {
+        mh_gemm_desc m = *d, t = *d;
+        const long esz = d->dtA == MH_F32 ? 4 : 2;
+        const int kmain = d->K - tail;
+        m.K = kmain;
+        t.K = tail;
+        t.A = (const char*)d->A + esz * (d->a_kc ? (long)kmain : (long)kmain * d->lda);
+        t.B = (const char*)d->B + esz * (d->b_kc ? (long)kmain : (long)kmain * d->ldb);
+        t.bias = nullptr;
+        t.diag = 0.f;
+        t.accumulate = 1;
+        t.split_k = 1;
+        const int rc = launch_one(&m, s);
+        if (rc != MH_OK) return rc;
+        return launch_one(&t, s);
+    }
+    return launch_one(d, s);
 }

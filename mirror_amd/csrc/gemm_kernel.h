@@ -68,7 +68,8 @@ struct Stager {
             const int r = cid / CPR, c = cid % CPR;
             int gm, gk;
             long off;
-            if (KC) { gm = tile0 + r; gk = k0 + c * VEC; off = (long)gm * ld + gk; }
+            // FULL + K-contiguous rows: a ragged last row-tile re-reads row dim-1 (its results are never stored)
+            if (KC) { gm = FULL ? min(tile0 + r, dim - 1) : tile0 + r; gk = k0 + c * VEC; off = (long)gm * ld + gk; }
             else    { gk = k0 + r; gm = tile0 + c * VEC; off = (long)gk * ld + gm; }
             if constexpr (FULL) {
                 regs[i] = *reinterpret_cast<const u32x4*>(base + off);
@@ -229,6 +230,7 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& g, TC* C, f32x16 (&
         const int cid = tid + i * 256;
         const int lr = cid / CPR, c = cid % CPR;
         const float* src = t + lr * PITCH + c * EPC;
+        if (tile_row0 + lr >= g.M) continue;           // ragged last row-tile (K-contiguous A only)
         TC* dst = C + (long)(tile_row0 + lr) * g.ldc + tile_col0 + c * EPC;
         f32x4 x0 = *reinterpret_cast<const f32x4*>(src);
         u32x4 o;
@@ -355,9 +357,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
             return;
         }
     }
-    if (g.atomic) epilogue<TC, WM, WN, FULL, 2>(g, C, acc, row_base, col_base, lane, lead);
-    else if (g.accumulate) epilogue<TC, WM, WN, FULL, 1>(g, C, acc, row_base, col_base, lane, lead);
-    else epilogue<TC, WM, WN, FULL, 0>(g, C, acc, row_base, col_base, lane, lead);
+    if (FULL && tile_m * BM + BM <= g.M) {   // interior tile: unguarded stores
+        if (g.atomic) epilogue<TC, WM, WN, true, 2>(g, C, acc, row_base, col_base, lane, lead);
+        else if (g.accumulate) epilogue<TC, WM, WN, true, 1>(g, C, acc, row_base, col_base, lane, lead);
+        else epilogue<TC, WM, WN, true, 0>(g, C, acc, row_base, col_base, lane, lead);
+    } else {
+        if (g.atomic) epilogue<TC, WM, WN, false, 2>(g, C, acc, row_base, col_base, lane, lead);
+        else if (g.accumulate) epilogue<TC, WM, WN, false, 1>(g, C, acc, row_base, col_base, lane, lead);
+        else epilogue<TC, WM, WN, false, 0>(g, C, acc, row_base, col_base, lane, lead);
+    }
 }
 
 // ------------------------------------------------------------------ host dispatch (per family)
@@ -368,8 +376,9 @@ static void launch_w(GemmArgs& a, int batch, hipStream_t s) {
     const int BN = narrow ? 64 : 128;
     a.tiles_m = mh_cdiv(a.M, 128);
     a.tiles_n = mh_cdiv(a.N, BN);
-    const bool full = a.vecA && a.vecB && a.M % 128 == 0 && a.N % BN == 0 && a.K % BK == 0 && a.k_per_split % BK == 0 &&
-                      a.K % a.k_per_split == 0;
+    // a ragged M is fine when A's rows are K-contiguous (loads clamp to the last row, stores are guarded)
+    const bool full = a.vecA && a.vecB && (AKC || a.M % 128 == 0) && a.N % BN == 0 && a.K % BK == 0 &&
+                      a.k_per_split % BK == 0 && a.K % a.k_per_split == 0;
     dim3 grid(a.tiles_m * a.tiles_n, a.split_k, batch);
     if (narrow) {
         if (full) hipLaunchKernelGGL((gemm_kernel<MMA, TA, TB, TC, AKC, BKC, 2, 1, true>), grid, dim3(256), 0, s, a);

@@ -103,6 +103,146 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restric
     }
 }
 
+// ------------------------------------------------------------------ 4-wide vector access (f32: 16 B, bf16: 8 B)
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+template <typename T> __device__ __forceinline__ f4 ld4(const T* p);
+template <> __device__ __forceinline__ f4 ld4<float>(const float* p) { return *reinterpret_cast<const f4*>(p); }
+template <> __device__ __forceinline__ f4 ld4<bf16_t>(const bf16_t* p) {
+    const u2 r = *reinterpret_cast<const u2*>(p);
+    f4 o;
+    o[0] = __uint_as_float(r[0] << 16); o[1] = __uint_as_float(r[0] & 0xffff0000u);
+    o[2] = __uint_as_float(r[1] << 16); o[3] = __uint_as_float(r[1] & 0xffff0000u);
+    return o;
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, f4 v);
+template <> __device__ __forceinline__ void st4<float>(float* p, f4 v) { *reinterpret_cast<f4*>(p) = v; }
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, f4 v) {
+    u2 r;
+    r[0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+    r[1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+    *reinterpret_cast<u2*>(p) = r;
+}
+
+// Vectorised LayerNorm (D % 4 == 0): lane owns elements [256k + 4*lane, +4), k < LNV_CH (D <= 2048).
+#define LNV_CH 8
+template <typename TX, typename TY>
+__global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const TX* __restrict__ x, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, TY* __restrict__ y,
+                                                                float* __restrict__ mean, float* __restrict__ rstd,
+                                                                long rows, int rpb, int D, long x_bs, long y_bs, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const long b = row / rpb, i = row % rpb;
+    const TX* xr = x + b * x_bs + i * D;
+    TY* yr = y + b * y_bs + i * D;
+    f4 v[LNV_CH];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < LNV_CH; k++) {
+        const int c = 256 * k + 4 * lane;
+        if (c < D) { v[k] = ld4(xr + c); s += v[k][0] + v[k][1] + v[k][2] + v[k][3]; }
+        else v[k] = (f4){0.f, 0.f, 0.f, 0.f};
+    }
+    const float mu = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < LNV_CH; k++) {
+        const int c = 256 * k + 4 * lane;
+        if (c < D) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) { const float d = v[k][e] - mu; q += d * d; }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / D + eps);
+#pragma unroll
+    for (int k = 0; k < LNV_CH; k++) {
+        const int c = 256 * k + 4 * lane;
+        if (c < D) {
+            const f4 g = ld4(gamma + c), bt = ld4(beta + c);
+            f4 o;
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[e] = (v[k][e] - mu) * rs * g[e] + bt[e];
+            st4(yr + c, o);
+        }
+    }
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+template <typename TX, typename TDY>
+__global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x,
+                                                                const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, TX* __restrict__ dx,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                long rows, int rpb, int D, long x_bs, long y_bs, int acc_dx) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f4 pg[LNV_CH], pb[LNV_CH], gm[LNV_CH];
+#pragma unroll
+    for (int k = 0; k < LNV_CH; k++) {
+        pg[k] = (f4){0.f, 0.f, 0.f, 0.f};
+        pb[k] = pg[k];
+        const int c = 256 * k + 4 * lane;
+        gm[k] = (c < D) ? ld4(gamma + c) : pg[k];
+    }
+    for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+        const long b = row / rpb, i = row % rpb;
+        const TX* xr = x + b * x_bs + i * D;
+        const TDY* dyr = dy + b * y_bs + i * D;
+        TX* dxr = dx + b * x_bs + i * D;
+        const float mu = mean[row], rs = rstd[row];
+        f4 xh[LNV_CH], gd[LNV_CH];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < LNV_CH; k++) {
+            const int c = 256 * k + 4 * lane;
+            if (c < D) {
+                const f4 d = ld4(dyr + c), xv = ld4(xr + c);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    xh[k][e] = (xv[e] - mu) * rs;
+                    gd[k][e] = d[e] * gm[k][e];
+                    pg[k][e] += d[e] * xh[k][e];
+                    pb[k][e] += d[e];
+                    s1 += gd[k][e];
+                    s2 += gd[k][e] * xh[k][e];
+                }
+            }
+        }
+        s1 = wave_sum(s1) / D;
+        s2 = wave_sum(s2) / D;
+#pragma unroll
+        for (int k = 0; k < LNV_CH; k++) {
+            const int c = 256 * k + 4 * lane;
+            if (c < D) {
+                f4 r;
+#pragma unroll
+                for (int e = 0; e < 4; e++) r[e] = rs * (gd[k][e] - s1 - xh[k][e] * s2);
+                if (acc_dx) r += ld4(dxr + c);
+                st4(dxr + c, r);
+            }
+        }
+    }
+    __shared__ f4 red[2][4][64];
+#pragma unroll
+    for (int k = 0; k < LNV_CH; k++) {
+        if (256 * k >= D) break;
+        __syncthreads();
+        red[0][wave][lane] = pg[k];
+        red[1][wave][lane] = pb[k];
+        __syncthreads();
+        if (wave == 0) {
+            const int c = 256 * k + 4 * lane;
+            if (c < D) {
+                const f4 g = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
+                const f4 bb = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
+#pragma unroll
+                for (int e = 0; e < 4; e++) { atomicAdd(dgamma + c + e, g[e]); atomicAdd(dbeta + c + e, bb[e]); }
+            }
+        }
+    }
+}
+
 extern "C" int mh_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                                 int batches, int rpb, int D, int64_t x_bs, int64_t y_bs, float eps, int dt_x, int dt_y,
                                 mh_stream s) {
@@ -110,6 +250,18 @@ extern "C" int mh_layernorm_fwd(const void* x, const float* gamma, const float* 
     const long rows = (long)batches * rpb;
     if (rows == 0) return MH_OK;
     dim3 grid(mh_cdiv(rows, 4));
+    const bool vecok = D % 4 == 0 && x_bs % 4 == 0 && y_bs % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
+                       ((uintptr_t)gamma & 15) == 0 && ((uintptr_t)beta & 15) == 0;
+#define LN_FV(TX, TY) hipLaunchKernelGGL((layernorm_fwd_vec_kernel<TX, TY>), grid, dim3(256), 0, (hipStream_t)s, (const TX*)x, gamma, beta, (TY*)y, mean, rstd, rows, rpb, D, (long)x_bs, (long)y_bs, eps)
+    if (vecok) {
+        if (dt_x == MH_F32 && dt_y == MH_F32) LN_FV(float, float);
+        else if (dt_x == MH_F32 && dt_y == MH_BF16) LN_FV(float, bf16_t);
+        else if (dt_x == MH_BF16 && dt_y == MH_BF16) LN_FV(bf16_t, bf16_t);
+        else LN_FV(bf16_t, float);
+        MH_LAUNCH_CHECK("mh_layernorm_fwd");
+        return MH_OK;
+    }
+#undef LN_FV
 #define LN_F(TX, TY) hipLaunchKernelGGL((layernorm_fwd_kernel<TX, TY>), grid, dim3(256), 0, (hipStream_t)s, (const TX*)x, gamma, beta, (TY*)y, mean, rstd, rows, rpb, D, (long)x_bs, (long)y_bs, eps)
     if (dt_x == MH_F32 && dt_y == MH_F32) LN_F(float, float);
     else if (dt_x == MH_F32 && dt_y == MH_BF16) LN_F(float, bf16_t);
@@ -127,7 +279,19 @@ extern "C" int mh_layernorm_bwd(const void* dy, const void* x, const float* gamm
     MH_REQUIRE(dt_dx == dt_x, "mh_layernorm_bwd: dx dtype must equal x dtype");
     const long rows = (long)batches * rpb;
     if (rows == 0) return MH_OK;
-    dim3 grid((unsigned)min((long)mh_cdiv(rows, 4), 1024L));
+    dim3 grid((unsigned)min((long)mh_cdiv(rows, 4), 2048L));
+    const bool vecok = D % 4 == 0 && x_bs % 4 == 0 && y_bs % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0 &&
+                       ((uintptr_t)dx & 15) == 0 && ((uintptr_t)gamma & 15) == 0;
+#define LN_BV(TX, TDY) hipLaunchKernelGGL((layernorm_bwd_vec_kernel<TX, TDY>), grid, dim3(256), 0, (hipStream_t)s, (const TDY*)dy, (const TX*)x, gamma, mean, rstd, (TX*)dx, dgamma, dbeta, rows, rpb, D, (long)x_bs, (long)y_bs, acc_dx)
+    if (vecok) {
+        if (dt_x == MH_F32 && dt_dy == MH_F32) LN_BV(float, float);
+        else if (dt_x == MH_F32 && dt_dy == MH_BF16) LN_BV(float, bf16_t);
+        else if (dt_x == MH_BF16 && dt_dy == MH_BF16) LN_BV(bf16_t, bf16_t);
+        else LN_BV(bf16_t, float);
+        MH_LAUNCH_CHECK("mh_layernorm_bwd");
+        return MH_OK;
+    }
+#undef LN_BV
 #define LN_B(TX, TDY) hipLaunchKernelGGL((layernorm_bwd_kernel<TX, TDY, TX>), grid, dim3(256), 0, (hipStream_t)s, (const TDY*)dy, (const TX*)x, gamma, mean, rstd, (TX*)dx, dgamma, dbeta, rows, rpb, D, (long)x_bs, (long)y_bs, acc_dx)
     if (dt_x == MH_F32 && dt_dy == MH_F32) LN_B(float, float);
     else if (dt_x == MH_F32 && dt_dy == MH_BF16) LN_B(float, bf16_t);
@@ -178,12 +342,91 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const TY* y, const TDY
     for (int c = t0; c < cols; c += step) stf(dxr + c, ldf(yr + c) * (ldf(dyr + c) - dot));
 }
 
+// Register-cached, 4-wide variants (cols % 4 == 0): every element is read from HBM exactly once.
+// WAVE: one wave per row, cols <= 1024 (lane keeps <= 4 f4); block: one 256-thread block per row, cols <= 12288.
+template <typename TX, typename TY, bool WAVE, int NV>
+__global__ __launch_bounds__(256) void softmax_fwd_vec_kernel(const TX* x, TY* y, long rows, int cols, long ldx, long ldy) {
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63;
+    const long row = WAVE ? (long)blockIdx.x * 4 + (threadIdx.x >> 6) : (long)blockIdx.x;
+    if (WAVE && row >= rows) return;
+    const int t0 = (WAVE ? lane : threadIdx.x) * 4, step = (WAVE ? 64 : 256) * 4;
+    const TX* xr = x + row * ldx;
+    TY* yr = y + row * ldy;
+    f4 v[NV];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        const int c = t0 + k * step;
+        if (c < cols) { v[k] = ld4(xr + c); m = fmaxf(fmaxf(fmaxf(m, v[k][0]), fmaxf(v[k][1], v[k][2])), v[k][3]); }
+    }
+    m = WAVE ? wave_max(m) : block_max256(m, red);
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        const int c = t0 + k * step;
+        if (c < cols) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) { v[k][e] = __expf(v[k][e] - m); sum += v[k][e]; }
+        }
+    }
+    sum = WAVE ? wave_sum(sum) : block_sum256(sum, red);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        const int c = t0 + k * step;
+        if (c < cols) st4(yr + c, v[k] * inv);
+    }
+}
+
+template <typename TY, typename TD, bool WAVE, int NV>
+__global__ __launch_bounds__(256) void softmax_bwd_vec_kernel(const TY* y, const TD* dy, TD* dx, long rows, int cols, long ldy,
+                                                              long lddy, long lddx) {
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63;
+    const long row = WAVE ? (long)blockIdx.x * 4 + (threadIdx.x >> 6) : (long)blockIdx.x;
+    if (WAVE && row >= rows) return;
+    const int t0 = (WAVE ? lane : threadIdx.x) * 4, step = (WAVE ? 64 : 256) * 4;
+    const TY* yr = y + row * ldy;
+    const TD* dyr = dy + row * lddy;
+    TD* dxr = dx + row * lddx;
+    f4 yv[NV], dv[NV];
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        const int c = t0 + k * step;
+        if (c < cols) {
+            yv[k] = ld4(yr + c);
+            dv[k] = ld4(dyr + c);
+            dot += yv[k][0] * dv[k][0] + yv[k][1] * dv[k][1] + yv[k][2] * dv[k][2] + yv[k][3] * dv[k][3];
+        }
+    }
+    dot = WAVE ? wave_sum(dot) : block_sum256(dot, red);
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        const int c = t0 + k * step;
+        if (c < cols) st4(dxr + c, yv[k] * (dv[k] - dot));
+    }
+}
+
 extern "C" int mh_softmax_fwd(const void* x, void* y, int64_t rows, int cols, int64_t ldx, int64_t ldy, int dt_x,
                               int dt_y, mh_stream s) {
     MH_REQUIRE(cols >= 1, "mh_softmax_fwd: cols=%d", cols);
     if (rows == 0) return MH_OK;
     const bool wave = cols <= 1024;
     dim3 grid(wave ? mh_cdiv(rows, 4) : (unsigned)rows);
+    if (cols % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && cols <= 12288 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0) {
+#define SM_FV(TX, TY)                                                                                                     \
+    if (wave) hipLaunchKernelGGL((softmax_fwd_vec_kernel<TX, TY, true, 4>), grid, dim3(256), 0, (hipStream_t)s, (const TX*)x, (TY*)y, (long)rows, cols, (long)ldx, (long)ldy); \
+    else hipLaunchKernelGGL((softmax_fwd_vec_kernel<TX, TY, false, 12>), grid, dim3(256), 0, (hipStream_t)s, (const TX*)x, (TY*)y, (long)rows, cols, (long)ldx, (long)ldy)
+        if (dt_x == MH_F32 && dt_y == MH_F32) { SM_FV(float, float); }
+        else if (dt_x == MH_F32 && dt_y == MH_BF16) { SM_FV(float, bf16_t); }
+        else if (dt_x == MH_BF16 && dt_y == MH_BF16) { SM_FV(bf16_t, bf16_t); }
+        else { SM_FV(bf16_t, float); }
+#undef SM_FV
+        MH_LAUNCH_CHECK("mh_softmax_fwd");
+        return MH_OK;
+    }
 #define SM_F(TX, TY)                                                                                                   \
     if (wave) hipLaunchKernelGGL((softmax_fwd_kernel<TX, TY, true>), grid, dim3(256), 0, (hipStream_t)s, (const TX*)x, (TY*)y, (long)rows, cols, (long)ldx, (long)ldy); \
     else hipLaunchKernelGGL((softmax_fwd_kernel<TX, TY, false>), grid, dim3(256), 0, (hipStream_t)s, (const TX*)x, (TY*)y, (long)rows, cols, (long)ldx, (long)ldy)
@@ -203,6 +446,19 @@ extern "C" int mh_softmax_bwd(const void* y, const void* dy, void* dx, int64_t r
     if (rows == 0) return MH_OK;
     const bool wave = cols <= 1024;
     dim3 grid(wave ? mh_cdiv(rows, 4) : (unsigned)rows);
+    if (cols % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && cols <= 12288 && ((uintptr_t)y & 15) == 0 &&
+        ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dx & 15) == 0) {
+#define SM_BV(TY, TD)                                                                                                     \
+    if (wave) hipLaunchKernelGGL((softmax_bwd_vec_kernel<TY, TD, true, 4>), grid, dim3(256), 0, (hipStream_t)s, (const TY*)y, (const TD*)dy, (TD*)dx, (long)rows, cols, (long)ldy, (long)lddy, (long)lddx); \
+    else hipLaunchKernelGGL((softmax_bwd_vec_kernel<TY, TD, false, 12>), grid, dim3(256), 0, (hipStream_t)s, (const TY*)y, (const TD*)dy, (TD*)dx, (long)rows, cols, (long)ldy, (long)lddy, (long)lddx)
+        if (dt_y == MH_F32 && dt_dy == MH_F32) { SM_BV(float, float); }
+        else if (dt_y == MH_F32 && dt_dy == MH_BF16) { SM_BV(float, bf16_t); }
+        else if (dt_y == MH_BF16 && dt_dy == MH_BF16) { SM_BV(bf16_t, bf16_t); }
+        else { SM_BV(bf16_t, float); }
+#undef SM_BV
+        MH_LAUNCH_CHECK("mh_softmax_bwd");
+        return MH_OK;
+    }
 #define SM_B(TY, TD)                                                                                                   \
     if (wave) hipLaunchKernelGGL((softmax_bwd_kernel<TY, TD, TD, true>), grid, dim3(256), 0, (hipStream_t)s, (const TY*)y, (const TD*)dy, (TD*)dx, (long)rows, cols, (long)ldy, (long)lddy, (long)lddx); \
     else hipLaunchKernelGGL((softmax_bwd_kernel<TY, TD, TD, false>), grid, dim3(256), 0, (hipStream_t)s, (const TY*)y, (const TD*)dy, (TD*)dx, (long)rows, cols, (long)ldy, (long)lddy, (long)lddx)

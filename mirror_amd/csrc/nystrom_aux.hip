@@ -109,6 +109,89 @@ __global__ __launch_bounds__(256) void resconv_kernel(const TV* __restrict__ v, 
     }
 }
 
+// Vectorised variant (dh % 8 == 0): a thread owns 8 adjacent columns (one 16-B bf16 load per input row) and
+// RV_RT consecutive output rows; block = 64 column groups x 4 row blocks.
+#define RV_RT 8
+typedef float rf4 __attribute__((ext_vector_type(4)));
+typedef unsigned ru4 __attribute__((ext_vector_type(4)));
+template <typename T> __device__ __forceinline__ void ld8(const T* p, float (&o)[8]);
+template <> __device__ __forceinline__ void ld8<float>(const float* p, float (&o)[8]) {
+    const rf4 a = *reinterpret_cast<const rf4*>(p), b = *reinterpret_cast<const rf4*>(p + 4);
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+}
+template <> __device__ __forceinline__ void ld8<bf16_t>(const bf16_t* p, float (&o)[8]) {
+    const ru4 r = *reinterpret_cast<const ru4*>(p);
+#pragma unroll
+    for (int e = 0; e < 4; e++) { o[2 * e] = __uint_as_float(r[e] << 16); o[2 * e + 1] = __uint_as_float(r[e] & 0xffff0000u); }
+}
+template <typename T> __device__ __forceinline__ void st8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void st8<float>(float* p, const float (&v)[8]) {
+    *reinterpret_cast<rf4*>(p) = (rf4){v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<rf4*>(p + 4) = (rf4){v[4], v[5], v[6], v[7]};
+}
+template <> __device__ __forceinline__ void st8<bf16_t>(bf16_t* p, const float (&v)[8]) {
+    ru4 r;
+#pragma unroll
+    for (int e = 0; e < 4; e++) r[e] = (unsigned)f2bf(v[2 * e]) | ((unsigned)f2bf(v[2 * e + 1]) << 16);
+    *reinterpret_cast<ru4*>(p) = r;
+}
+
+template <typename TV, typename TO>
+__global__ __launch_bounds__(256) void resconv_vec_kernel(const TV* __restrict__ v, long ldv, long v_bs, const float* __restrict__ w,
+                                                          TO* out, long ldo, long o_bs, int n_p, int C, int dh, int taps,
+                                                          int transpose, int accumulate) {
+    __shared__ float ws[8 * RC_MAXTAPS];
+    const int cg = threadIdx.x & 63, rb = threadIdx.x >> 6;
+    const int c = blockIdx.x * 512 + cg * 8;
+    const int t0 = (blockIdx.y * 4 + rb) * RV_RT;
+    const int b = blockIdx.z;
+    const int h0 = (blockIdx.x * 512) / dh;
+    const int nh = min((blockIdx.x * 512 + 511) / dh, (C - 1) / dh) - h0 + 1;
+    for (int i = threadIdx.x; i < nh * taps; i += 256) {
+        const int hh = i / taps, j = i % taps;
+        ws[hh * RC_MAXTAPS + j] = w[(h0 + hh) * taps + (transpose ? taps - 1 - j : j)];
+    }
+    __syncthreads();
+    if (c >= C || t0 >= n_p) return;
+    const float* wl = ws + (c / dh - h0) * RC_MAXTAPS;
+    const int half = taps / 2;
+    float acc[RV_RT][8];
+#pragma unroll
+    for (int i = 0; i < RV_RT; i++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[i][e] = 0.f;
+    const TV* vb = v + (long)b * v_bs + c;
+    for (int u = 0; u < RV_RT + taps - 1; u++) {
+        const int t = t0 - half + u;
+        if (t < 0 || t >= n_p) continue;
+        float x[8];
+        ld8(vb + (long)t * ldv, x);
+#pragma unroll
+        for (int i = 0; i < RV_RT; i++) {
+            const int j = u - i;
+            if (j >= 0 && j < taps) {
+                const float wj = wl[j];
+#pragma unroll
+                for (int e = 0; e < 8; e++) acc[i][e] += wj * x[e];
+            }
+        }
+    }
+    TO* ob = out + (long)b * o_bs + c;
+#pragma unroll
+    for (int i = 0; i < RV_RT; i++) {
+        const int t = t0 + i;
+        if (t < n_p) {
+            if (accumulate) {
+                float old[8];
+                ld8(ob + (long)t * ldo, old);
+#pragma unroll
+                for (int e = 0; e < 8; e++) acc[i][e] += old[e];
+            }
+            st8(ob + (long)t * ldo, acc[i]);
+        }
+    }
+}
+
 extern "C" int mh_resconv_fwd(const void* v, int64_t ldv, int64_t v_bs, const float* w, void* out, int64_t ldo,
                               int64_t o_bs, int B, int n_p, int heads, int dh, int taps, int transpose, int accumulate,
                               int dt_v, int dt_o, mh_stream s) {
@@ -116,6 +199,18 @@ extern "C" int mh_resconv_fwd(const void* v, int64_t ldv, int64_t v_bs, const fl
     const int C = heads * dh;
     MH_REQUIRE(heads <= 8 || 255 / dh + 2 <= 8, "mh_resconv_fwd: more than 8 heads per 256 columns (heads=%d dh=%d)", heads, dh);
     if (B == 0 || n_p == 0) return MH_OK;
+    if (dh % 8 == 0 && ldv % 8 == 0 && v_bs % 8 == 0 && ldo % 8 == 0 && o_bs % 8 == 0 && ((uintptr_t)v & 15) == 0 &&
+        ((uintptr_t)out & 15) == 0 && (heads <= 8 || 511 / dh + 2 <= 8)) {
+        dim3 vgrid(mh_cdiv(C, 512), mh_cdiv(n_p, 4 * RV_RT), B);
+#define RCV(TV, TO) hipLaunchKernelGGL((resconv_vec_kernel<TV, TO>), vgrid, dim3(256), 0, (hipStream_t)s, (const TV*)v, (long)ldv, (long)v_bs, w, (TO*)out, (long)ldo, (long)o_bs, n_p, C, dh, taps, transpose, accumulate)
+        if (dt_v == MH_F32 && dt_o == MH_F32) RCV(float, float);
+        else if (dt_v == MH_BF16 && dt_o == MH_BF16) RCV(bf16_t, bf16_t);
+        else if (dt_v == MH_BF16 && dt_o == MH_F32) RCV(bf16_t, float);
+        else RCV(float, bf16_t);
+#undef RCV
+        MH_LAUNCH_CHECK("mh_resconv_fwd");
+        return MH_OK;
+    }
     dim3 grid(mh_cdiv(C, 256), mh_cdiv(n_p, RC_RT), B);
 #define RC(TV, TO) hipLaunchKernelGGL((resconv_kernel<TV, TO>), grid, dim3(256), 0, (hipStream_t)s, (const TV*)v, (long)ldv, (long)v_bs, w, (TO*)out, (long)ldo, (long)o_bs, n_p, C, dh, taps, transpose, accumulate)
     if (dt_v == MH_F32 && dt_o == MH_F32) RC(float, float);
@@ -127,50 +222,63 @@ extern "C" int mh_resconv_fwd(const void* v, int64_t ldv, int64_t v_bs, const fl
     return MH_OK;
 }
 
-// dw[h][j] += sum_{b,t,d} dout[b,t,h,d] * v[b,t+j-half,h,d]. Block = (head h, chunk of rows, b); thread (tt, d-lane).
+// dw[h][j] += sum_{b,t,d} dout[b,t,h,d] * v[b,t+j-half,h,d].  Block = (head h, 64 rows, b): the dout tile [64][64]
+// and the v tile [64+taps-1][64] sit in LDS (f32, pitch 68: the two rows a 16-lane ds_read_b128 group touches land
+// on disjoint banks); thread (tap j = tid>>3, q = tid&7) dots 8-column slices over the 64 rows, the 8 q-lanes
+// are combined with shuffles, one f32 atomic per (head, tap) per block.
 #define RW_ROWS 64
+#define RW_PITCH 68
 template <typename TV, typename TO>
 __global__ __launch_bounds__(256) void resconv_wgrad_kernel(const TV* __restrict__ v, long ldv, long v_bs,
                                                             const TO* __restrict__ dout, long ldo, long o_bs,
                                                             float* __restrict__ dw, int n_p, int dh, int taps) {
-    // LDS: v rows [RW_ROWS + taps - 1][dh_chunk=64] and dout rows [RW_ROWS][64]
-    __shared__ float vs[(RW_ROWS + RC_MAXTAPS) * 64];
-    __shared__ float ds[RW_ROWS * 64];
+    __shared__ __attribute__((aligned(16))) float vs[(RW_ROWS + RC_MAXTAPS) * RW_PITCH];
+    __shared__ __attribute__((aligned(16))) float ds[RW_ROWS * RW_PITCH];
     const int h = blockIdx.x, t0 = blockIdx.y * RW_ROWS, b = blockIdx.z;
     const int half = taps / 2;
     const int tid = threadIdx.x;
-    // each thread accumulates tap j = tid % 64 (if < taps) over a quarter of the rows: simple 2-D split
-    const int j = tid & 63, quarter = tid >> 6;
-    float acc = 0.f;
+    const int q = tid & 7, j0 = tid >> 3;
+    float acc[2] = {0.f, 0.f};   // taps j0 and j0 + 32
     for (int d0 = 0; d0 < dh; d0 += 64) {
-        const int dw_ = min(64, dh - d0);
+        const int dwd = min(64, dh - d0);
         __syncthreads();
         for (int i = tid; i < (RW_ROWS + taps - 1) * 64; i += 256) {
-            const int rr = i / 64, dd = i % 64;
+            const int rr = i >> 6, dd = i & 63;
             const int t = t0 - half + rr;
-            vs[i] = (dd < dw_ && t >= 0 && t < n_p) ? ldf(v + (long)b * v_bs + (long)t * ldv + h * dh + d0 + dd) : 0.f;
+            vs[rr * RW_PITCH + dd] = (dd < dwd && t >= 0 && t < n_p) ? ldf(v + (long)b * v_bs + (long)t * ldv + h * dh + d0 + dd) : 0.f;
         }
         for (int i = tid; i < RW_ROWS * 64; i += 256) {
-            const int rr = i / 64, dd = i % 64;
+            const int rr = i >> 6, dd = i & 63;
             const int t = t0 + rr;
-            ds[i] = (dd < dw_ && t < n_p) ? ldf(dout + (long)b * o_bs + (long)t * ldo + h * dh + d0 + dd) : 0.f;
+            ds[rr * RW_PITCH + dd] = (dd < dwd && t < n_p) ? ldf(dout + (long)b * o_bs + (long)t * ldo + h * dh + d0 + dd) : 0.f;
         }
         __syncthreads();
-        if (j < taps) {
-            for (int rr = quarter; rr < RW_ROWS; rr += 4) {
-                const float* dr = ds + rr * 64;
-                const float* vr = vs + (rr + j) * 64;
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++) {
+            const int j = j0 + 32 * pass;
+            if (j < taps) {
                 float s = 0.f;
-                for (int dd = 0; dd < 64; dd++) s += dr[(dd + j) & 63] * vr[(dd + j) & 63];  // skewed: no bank conflicts
-                acc += s;
+                for (int rr = 0; rr < RW_ROWS; rr++) {
+                    const rf4 g0 = *reinterpret_cast<const rf4*>(ds + rr * RW_PITCH + q * 8);
+                    const rf4 g1 = *reinterpret_cast<const rf4*>(ds + rr * RW_PITCH + q * 8 + 4);
+                    const rf4 x0 = *reinterpret_cast<const rf4*>(vs + (rr + j) * RW_PITCH + q * 8);
+                    const rf4 x1 = *reinterpret_cast<const rf4*>(vs + (rr + j) * RW_PITCH + q * 8 + 4);
+                    s += g0[0] * x0[0] + g0[1] * x0[1] + g0[2] * x0[2] + g0[3] * x0[3] + g1[0] * x1[0] + g1[1] * x1[1] +
+                         g1[2] * x1[2] + g1[3] * x1[3];
+                }
+                acc[pass] += s;
             }
         }
     }
-    // sum the 4 quarters per tap
-    __shared__ float accs[4][64];
-    accs[quarter][j] = acc;
-    __syncthreads();
-    if (quarter == 0 && j < taps) atomicAdd(dw + h * taps + j, accs[0][j] + accs[1][j] + accs[2][j] + accs[3][j]);
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        float s = acc[pass];
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        const int j = j0 + 32 * pass;
+        if (q == 0 && j < taps) atomicAdd(dw + h * taps + j, s);
+    }
 }
 
 extern "C" int mh_resconv_wgrad(const void* v, int64_t ldv, int64_t v_bs, const void* dout, int64_t ldo, int64_t o_bs,

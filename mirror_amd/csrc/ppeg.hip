@@ -90,47 +90,71 @@ extern "C" int mh_ppeg_fwd(const void* x, void* y, const float* merged, const fl
 }
 
 // dmerged[tap][c] += sum_{b,yy,xx} dout[b,yy,xx,c] * x[b,yy+ky-3,xx+kx-3,c]; dbsum[c] += sum dout.
-// Block = 256 channels x one (b, band of WG_ROWS grid rows); 49 register accumulators per thread, one atomic each.
+// Block = 64 channels x 4 grid rows (one wave per row, lanes = channels: 256-B coalesced loads).  Each thread
+// sweeps its row with a 7x7 register window of x (column X lives in slot X mod 7; the sweep is unrolled by 7 so
+// every slot index is a compile-time constant): 7 loads + 49 FMAs per pixel.  The 4 rows are reduced through
+// LDS, then one f32 atomic per (tap, channel) per block.
 #define WG_ROWS 4
 template <typename TX, typename TO>
 __global__ __launch_bounds__(256) void ppeg_wgrad_kernel(const TX* __restrict__ x, const TO* __restrict__ dout,
                                                          float* __restrict__ dmerged, float* __restrict__ dbsum, int S, int D) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= D) return;
+    __shared__ float red[4][50][64];
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int yy = blockIdx.y * WG_ROWS + slice;
     const long b = blockIdx.z;
     const long n = 1 + (long)S * S;
-    const TX* xb = x + b * n * D + c;
-    const TO* db = dout + b * n * D + c;
-    float acc[49];
+    const bool live = (c < D) && (yy < S);
+    const TX* xb = x + b * n * D + (live ? c : 0);
+    const TO* db = dout + b * n * D + (live ? c : 0);
+    float acc[49], win[7][7];
 #pragma unroll
     for (int t = 0; t < 49; t++) acc[t] = 0.f;
     float bacc = 0.f;
-    const int y0 = blockIdx.y * WG_ROWS;
-    for (int yy = y0; yy < min(S, y0 + WG_ROWS); yy++) {
-        for (int xx = 0; xx < S; xx++) {
-            const float g = ldf(db + (1 + (long)yy * S + xx) * D);
-            bacc += g;
+    if (live) {
+        bool rowok[7];
 #pragma unroll
-            for (int ky = 0; ky < 7; ky++) {
-                const int sy = yy + ky - 3;
-                if (sy < 0 || sy >= S) continue;
+        for (int ky = 0; ky < 7; ky++) {
+            const int sy = yy + ky - 3;
+            rowok[ky] = (sy >= 0 && sy < S);
 #pragma unroll
-                for (int kx = 0; kx < 7; kx++) {
-                    const int sx = xx + kx - 3;
-                    if (sx >= 0 && sx < S) acc[ky * 7 + kx] += g * ldf(xb + (1 + (long)sy * S + sx) * D);
-                }
+            for (int sl = 0; sl < 7; sl++)
+                win[ky][sl] = (sl < 3 && sl < S && rowok[ky]) ? ldf(xb + (1 + (long)sy * S + sl) * D) : 0.f;
+        }
+        for (int xx0 = 0; xx0 < S; xx0 += 7) {
+#pragma unroll
+            for (int u = 0; u < 7; u++) {
+                const int xx = xx0 + u;
+                const int xn = xx + 3;  // column entering the window
+#pragma unroll
+                for (int ky = 0; ky < 7; ky++)
+                    win[ky][(u + 3) % 7] = (xn < S && rowok[ky]) ? ldf(xb + (1 + (long)(yy + ky - 3) * S + xn) * D) : 0.f;
+                const float g = (xx < S) ? ldf(db + (1 + (long)yy * S + xx) * D) : 0.f;
+                bacc += g;
+#pragma unroll
+                for (int ky = 0; ky < 7; ky++)
+#pragma unroll
+                    for (int kx = 0; kx < 7; kx++) acc[ky * 7 + kx] += g * win[ky][(u + kx + 4) % 7];
             }
         }
     }
 #pragma unroll
-    for (int t = 0; t < 49; t++) atomicAdd(dmerged + t * D + c, acc[t]);
-    atomicAdd(dbsum + c, bacc);
+    for (int t = 0; t < 49; t++) red[slice][t][lane] = acc[t];
+    red[slice][49][lane] = bacc;
+    __syncthreads();
+    if (c < D) {
+        for (int t = slice; t < 50; t += 4) {
+            const float v = red[0][t][lane] + red[1][t][lane] + red[2][t][lane] + red[3][t][lane];
+            if (t < 49) atomicAdd(dmerged + t * D + c, v);
+            else atomicAdd(dbsum + c, v);
+        }
+    }
 }
 
 extern "C" int mh_ppeg_wgrad(const void* x, const void* dout, float* dmerged, float* dbsum, int B, int S, int D, int dt_x,
                              int dt_o, mh_stream s) {
     if (B == 0) return MH_OK;
-    dim3 grid(mh_cdiv(D, 256), mh_cdiv(S, WG_ROWS), B);
+    dim3 grid(mh_cdiv(D, 64), mh_cdiv(S, WG_ROWS), B);
 #define PW(TX, TO) hipLaunchKernelGGL((ppeg_wgrad_kernel<TX, TO>), grid, dim3(256), 0, (hipStream_t)s, (const TX*)x, (const TO*)dout, dmerged, dbsum, S, D)
     if (dt_x == MH_F32 && dt_o == MH_F32) PW(float, float);
     else if (dt_x == MH_BF16 && dt_o == MH_BF16) PW(bf16_t, bf16_t);
