@@ -5,7 +5,7 @@
     buffers; module parameters are views into them.  Adam (+ the bf16 shadow refresh) is ONE kernel over
     the arena, zero-grad is one memset, and gradient all-reduce works on arena slices (no flatten copies).
   * data parallel = DDP semantics (gradient AVG across ranks, train_mirror.py:811-813): arena buckets are
-    all-reduced over RCCL on a side HIP stream as soon as autograd has finished the parameters they hold,
+    all-reduced (SUM; the 1/world factor is folded into the Adam kernel) over RCCL on a side HIP stream as soon as autograd has finished the parameters they hold,
     overlapping the WSI backward; the arena is laid out in reverse registration order so buckets complete
     roughly front to back.
   * step glue kept from the reference: prototype rows L2-normalised before every batch (:1133-1136),
@@ -115,7 +115,7 @@ class TrainEngine:
             s, e, _ = self.buckets[b]
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
-                w = dist.all_reduce(self.grad[s:e], op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
+                w = dist.all_reduce(self.grad[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
             self._works.append(w)
 
     def _finish_reduce(self) -> None:
@@ -127,7 +127,7 @@ class TrainEngine:
                     s, e, _ = self.buckets[b]
                     self.comm_stream.wait_stream(torch.cuda.current_stream())
                     with torch.cuda.stream(self.comm_stream):
-                        self._works.append(dist.all_reduce(self.grad[s:e], op=dist.ReduceOp.AVG, group=self.pg, async_op=True))
+                        self._works.append(dist.all_reduce(self.grad[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         for w in self._works:
             w.wait()
         torch.cuda.current_stream().wait_stream(self.comm_stream)
@@ -150,7 +150,8 @@ class TrainEngine:
         self.step_count += 1
         b1, b2 = self.betas
         K.adam(self.master, self.grad, self.m, self.v, self.shadow, self.lr, b1, b2, self.eps,
-               1.0 - b1 ** self.step_count, 1.0 - b2 ** self.step_count)
+               1.0 - b1 ** self.step_count, 1.0 - b2 ** self.step_count,
+               grad_scale=1.0 / self.world)   # buckets are SUM-reduced; the DDP average is folded into Adam
         if self._logit is not None:
             K.clamp_(self._logit.data.reshape(1), 0.0, math.log(100.0))
             if self.shadow is not None:
