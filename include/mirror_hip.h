@@ -38,7 +38,7 @@ int mh_version(void);
 int mh_device_ok(void);
 
 /* ---------------------------------------------------------------- MFMA GEMM (all contractions)
- * C[z] (+)= act(alpha * op(A[z]) x op(B[z]) + diag*I + bias)   z = (b1, b2) two-level batch
+ * C[z] (+)= act(alpha * op(A[z]) x op(B[z]) + diag*I + bias + rcoef*R[z])   z = (b1, b2) two-level batch
  *   A(m,k) at A[m*lda + k] if a_kc else A[k*lda + m];  B(k,n) at B[n*ldb + k] if b_kc else B[k*ldb + n]
  *   mma = MH_F32  -> v_mfma_f32_32x32x2_f32 (exact fp32, parity mode; dtA=dtB=dtC=f32)
  *   mma = MH_BF16 -> v_mfma_f32_32x32x16_bf16, fp32 accumulate; f32 operands are rounded to bf16
@@ -60,8 +60,22 @@ typedef struct {
     int32_t accumulate;           /* 0: C = r, 1: C += r */
     int32_t split_k;              /* >1: K split over workgroups, f32 atomics into C (needs accumulate=1, dtC=f32).
                                      A batch whose sC1 = sC2 = 0 with accumulate=1 also reduces into C with atomics. */
+    const void* R; float rcoef;   /* optional addend: C (+)= ... + rcoef * R; R has C's dtype, ldc and batch strides
+                                     (lets the pinv polynomial 15I - 7P + P.P come out of one launch) */
 } mh_gemm_desc;
 int mh_gemm(const mh_gemm_desc* d, mh_stream s);
+
+/* ---------------------------------------------------------------- skinny-M linears (RNA encoder / style heads: every
+ * tensor is [B, D], models/mirror.py:77-102, :217-224, :845-857): weight-streaming kernels, bf16 operands.
+ * y[M<=32, N] = act(x[M,K] W[N,K]^T + bias); K % 32 == 0; the data gradient is the same call on the W^T shadow. */
+int mh_skinny_fwd(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, void* y, int64_t ldy,
+                  int M, int N, int K, int act, int dt_y, mh_stream s);
+/* dW[N,K] (+)= dy[M,N]^T x[M,K]  (f32, plain read-modify-write: one block owns each output tile) */
+int mh_skinny_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw, int64_t lddw, int M, int N,
+                    int K, int accumulate, mh_stream s);
+/* bf16 [R,C] -> [C,R]; the batched form walks table[i] = {src_off, dst_off, R, C} (int64 element offsets) */
+int mh_transpose_bf16(const void* in, void* out, int R, int C, mh_stream s);
+int mh_transpose_bf16_many(const void* src, void* dst, const int64_t* table, int n, int max_r, int max_c, mh_stream s);
 
 /* ---------------------------------------------------------------- LayerNorm (models/mirror.py:298, :350, :604, :210)
  * rows are addressed as (b, i): x + b*x_bs + i*D, y + b*y_bs + i*D, i < rows_per_batch (lets the
@@ -105,6 +119,13 @@ int mh_pinv_z0(const float* x, const uint64_t* stats64, float* z0, int BH, int m
 /* dx += dz0^T/(c r) + sub-gradients through the two max() */
 int mh_pinv_z0_bwd(const float* x, const float* z0, const float* dz0, const uint64_t* stats64, float* dx,
                    float* scratch1, int BH, int m, mh_stream s);
+/* The whole iteration as ONE launch per pass (bf16 policy, m = 128 or 256): one 1024-thread workgroup per (b,h) walks
+ * the chain of m x m products; sums of products stay in the MFMA accumulators.  All matrices contiguous [m][m] bf16.
+ * saved: [iters][4][BH][m][m] = {z_k, P_k, T2_k, T3_k} (z_0 pre-filled by the caller), zf = z_iters.
+ * bwd: dzf = d z_iters (bf16), work like saved = {dT3, dT2, dP, dz_k}; dX (f32) = sum_k dP_k z_k^T, dz0 (f32) = d z_0. */
+int mh_pinv_chain_fwd(const void* X, void* saved, void* zf, int BH, int m, int iters, mh_stream s);
+int mh_pinv_chain_bwd(const void* X, const void* saved, const void* dzf, void* work, float* dX, float* dz0, int BH, int m,
+                      int iters, mh_stream s);
 /* T = d*I - P  (batched [BH,m,m] f32) */
 int mh_eye_minus(const float* P, float* T, float d, int BH, int m, mh_stream s);
 

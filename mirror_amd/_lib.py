@@ -26,6 +26,7 @@ class GemmDesc(C.Structure):
         ("sC1", C.c_int64), ("sC2", C.c_int64),
         ("alpha", C.c_float), ("diag", C.c_float),
         ("act", C.c_int32), ("accumulate", C.c_int32), ("split_k", C.c_int32),
+        ("R", C.c_void_p), ("rcoef", C.c_float),
     ]
 
 
@@ -34,6 +35,10 @@ P, I, L, F, U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 # name -> argtypes (the trailing stream argument is appended automatically)
 _SIGS = {
     "mh_gemm": [C.POINTER(GemmDesc)],
+    "mh_skinny_fwd": [P, L, P, L, P, P, L, I, I, I, I, I],
+    "mh_skinny_wgrad": [P, L, P, L, P, L, I, I, I, I],
+    "mh_transpose_bf16": [P, P, I, I],
+    "mh_transpose_bf16_many": [P, P, P, I, I, I],
     "mh_layernorm_fwd": [P, P, P, P, P, P, I, I, I, L, L, F, I, I],
     "mh_layernorm_bwd": [P, P, P, P, P, P, P, P, I, I, I, L, L, I, I, I, I],
     "mh_softmax_fwd": [P, P, L, I, L, L, I, I],
@@ -46,6 +51,8 @@ _SIGS = {
     "mh_pinv_z0": [P, P, P, I, I],
     "mh_pinv_z0_bwd": [P, P, P, P, P, P, I, I],
     "mh_eye_minus": [P, P, F, I, I],
+    "mh_pinv_chain_fwd": [P, P, P, I, I, I],
+    "mh_pinv_chain_bwd": [P, P, P, P, P, P, I, I, I],
     "mh_seq_finish": [P, P, I, I, I, I, I],
     "mh_seq_finish_bwd": [P, P, I, I, I, I, I],
     "mh_ppeg_merge": [P, P, P, P, P, P, P, P, I],

@@ -34,6 +34,7 @@ struct GemmArgs {
     int atomic;  // f32 atomicAdd into C: split-K, or a batch that broadcasts into one C
     int tiles_m, tiles_n;
     int vecC;    // C rows are 16-B aligned (LDS-staged wide-store epilogue allowed)
+    const void* R; float rcoef;   // optional addend rcoef * R, R laid out exactly like C (same dtype and strides)
 };
 
 template <int MMA, bool KC, int ROWS>
@@ -51,20 +52,20 @@ struct TileGeom {
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-template <int MMA, typename TG, bool KC, int ROWS, bool FULL>
+template <int MMA, typename TG, bool KC, int ROWS, bool FULL, int NT = 256>
 struct Stager {
     using G = TileGeom<MMA, KC, ROWS>;
     static constexpr int VEC = 16 / (int)sizeof(TG);
     static constexpr int CONTIG = KC ? G::BK : ROWS;
     static constexpr int CPR = CONTIG / VEC;
-    static constexpr int NCH = G::LROWS * CPR / 256;
-    static_assert(G::LROWS * CPR % 256 == 0, "tile must split evenly over 256 threads");
+    static constexpr int NCH = G::LROWS * CPR / NT;
+    static_assert(G::LROWS * CPR % NT == 0, "tile must split evenly over the block's threads");
 
     static __device__ __forceinline__ void load(u32x4 (&regs)[NCH], const TG* __restrict__ base, long ld, int tile0,
                                                 int dim, int k0, int kend, bool vec_ok, int tid) {
 #pragma unroll
         for (int i = 0; i < NCH; i++) {
-            const int cid = tid + i * 256;
+            const int cid = tid + i * NT;
             const int r = cid / CPR, c = cid % CPR;
             int gm, gk;
             long off;
@@ -99,7 +100,7 @@ struct Stager {
     static __device__ __forceinline__ void store(const u32x4 (&regs)[NCH], char* tile, int tid) {
 #pragma unroll
         for (int i = 0; i < NCH; i++) {
-            const int cid = tid + i * 256;
+            const int cid = tid + i * NT;
             const int r = cid / CPR, c = cid % CPR;
             const u32x4 v = regs[i];
             if constexpr ((int)sizeof(TG) == G::ESZ) {
@@ -168,8 +169,8 @@ template <typename TC, int MODE> __device__ __forceinline__ void c_store(TC* p, 
 }
 
 template <typename TC, int WM, int WN, bool FULL, int MODE>
-__device__ __forceinline__ void epilogue(const GemmArgs& g, TC* C, f32x16 (&acc)[WM][WN], int row_base, int col_base,
-                                         int lane, bool lead) {
+__device__ __forceinline__ void epilogue(const GemmArgs& g, TC* C, const TC* R, f32x16 (&acc)[WM][WN], int row_base,
+                                         int col_base, int lane, bool lead) {
     // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     const int r = lane & 31, hh = lane >> 5;
     const float diag = lead ? g.diag : 0.f;
@@ -186,8 +187,11 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, TC* C, f32x16 (&acc)
                 const int row = rbase + (reg & 3) + 8 * (reg >> 2);
                 float v = g.alpha * acc[i][j][reg] + bias;
                 if (row == col) v += diag;
-                if (g.act == MH_ACT_RELU) v = fmaxf(v, 0.f);
-                if (FULL || (col_ok && row < g.M)) c_store<TC, MODE>(C + (long)row * g.ldc + col, v);
+                if (FULL || (col_ok && row < g.M)) {
+                    if (R) v += g.rcoef * ldf(R + (long)row * g.ldc + col);
+                    if (g.act == MH_ACT_RELU) v = fmaxf(v, 0.f);
+                    c_store<TC, MODE>(C + (long)row * g.ldc + col, v);
+                }
             }
         }
     }
@@ -197,7 +201,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, TC* C, f32x16 (&acc)
 // 16-B row-contiguous stores (4 rows x 256/512 B per wave-instruction).  The direct path issues 64 narrow stores
 // per lane (2-byte ones for bf16 C), which made the epilogue longer than the K=512 main loop.
 template <typename TC, int WM, int WN, int MODE>
-__device__ __forceinline__ void epilogue_lds(const GemmArgs& g, TC* C, f32x16 (&acc)[WM][WN], char* smem, int tile_row0,
+__device__ __forceinline__ void epilogue_lds(const GemmArgs& g, TC* C, const TC* R, f32x16 (&acc)[WM][WN], char* smem, int tile_row0,
                                              int tile_col0, int wm, int wn, int lane, int tid, bool lead) {
     constexpr int BM = 64 * WM, BN = 64 * WN, PITCH = BN + 4;
     float* t = reinterpret_cast<float*>(smem);
@@ -216,6 +220,7 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& g, TC* C, f32x16 (&
                 const int lr = lr0 + (reg & 3) + 8 * (reg >> 2);
                 float v = g.alpha * acc[i][j][reg] + bias;
                 if (tile_row0 + lr == col) v += diag;
+                if (R && tile_row0 + lr < g.M) v += g.rcoef * ldf(R + (long)(tile_row0 + lr) * g.ldc + col);
                 if (g.act == MH_ACT_RELU) v = fmaxf(v, 0.f);
                 t[lr * PITCH + lc] = v;
             }
@@ -278,6 +283,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     const TA* A = reinterpret_cast<const TA*>(g.A) + b1 * g.sA1 + b2 * g.sA2;
     const TB* B = reinterpret_cast<const TB*>(g.B) + b1 * g.sB1 + b2 * g.sB2;
     TC* C = reinterpret_cast<TC*>(g.C) + b1 * g.sC1 + b2 * g.sC2;
+    const TC* R = g.R ? reinterpret_cast<const TC*>(g.R) + b1 * g.sC1 + b2 * g.sC2 : nullptr;
     const int split = blockIdx.y;
     const int kbeg = split * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);
@@ -352,19 +358,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     if constexpr (FULL && MMA == 1) {
         static_assert(BM * (BN + 4) * 4 <= 2 * STAGE, "epilogue tile must fit the staging LDS");
         if (g.vecC && !g.atomic) {
-            if (g.accumulate) epilogue_lds<TC, WM, WN, 1>(g, C, acc, smem, tile_m * BM, tile_n * BN, wm, wn, lane, tid, lead);
-            else epilogue_lds<TC, WM, WN, 0>(g, C, acc, smem, tile_m * BM, tile_n * BN, wm, wn, lane, tid, lead);
+            if (g.accumulate) epilogue_lds<TC, WM, WN, 1>(g, C, R, acc, smem, tile_m * BM, tile_n * BN, wm, wn, lane, tid, lead);
+            else epilogue_lds<TC, WM, WN, 0>(g, C, R, acc, smem, tile_m * BM, tile_n * BN, wm, wn, lane, tid, lead);
             return;
         }
     }
     if (FULL && tile_m * BM + BM <= g.M) {   // interior tile: unguarded stores
-        if (g.atomic) epilogue<TC, WM, WN, true, 2>(g, C, acc, row_base, col_base, lane, lead);
-        else if (g.accumulate) epilogue<TC, WM, WN, true, 1>(g, C, acc, row_base, col_base, lane, lead);
-        else epilogue<TC, WM, WN, true, 0>(g, C, acc, row_base, col_base, lane, lead);
+        if (g.atomic) epilogue<TC, WM, WN, true, 2>(g, C, R, acc, row_base, col_base, lane, lead);
+        else if (g.accumulate) epilogue<TC, WM, WN, true, 1>(g, C, R, acc, row_base, col_base, lane, lead);
+        else epilogue<TC, WM, WN, true, 0>(g, C, R, acc, row_base, col_base, lane, lead);
     } else {
-        if (g.atomic) epilogue<TC, WM, WN, false, 2>(g, C, acc, row_base, col_base, lane, lead);
-        else if (g.accumulate) epilogue<TC, WM, WN, false, 1>(g, C, acc, row_base, col_base, lane, lead);
-        else epilogue<TC, WM, WN, false, 0>(g, C, acc, row_base, col_base, lane, lead);
+        if (g.atomic) epilogue<TC, WM, WN, false, 2>(g, C, R, acc, row_base, col_base, lane, lead);
+        else if (g.accumulate) epilogue<TC, WM, WN, false, 1>(g, C, R, acc, row_base, col_base, lane, lead);
+        else epilogue<TC, WM, WN, false, 0>(g, C, R, acc, row_base, col_base, lane, lead);
     }
 }
 
@@ -400,4 +406,6 @@ static void launch_l(GemmArgs& a, int akc, int bkc, int batch, hipStream_t s) {
 // family entry points (one translation unit each)
 void gemm_launch_f32(GemmArgs& a, int akc, int bkc, int batch, hipStream_t s);                 // MMA f32
 void gemm_launch_bf16(GemmArgs& a, int akc, int bkc, int dtC, int batch, hipStream_t s);       // bf16 operands
-void gemm_launch_mixed(GemmArgs& a, int akc, int bkc, int dtC, int batch, hipStream_t s);      // f32 operands, bf16 MMA
+void gemm_launch_mixed_ff(GemmArgs& a, int akc, int bkc, int dtC, int batch, hipStream_t s);   // f32 x f32 operands, bf16 MMA
+void gemm_launch_mixed_fb(GemmArgs& a, int akc, int bkc, int dtC, int batch, hipStream_t s);   // f32 A, bf16 B
+void gemm_launch_mixed_bf(GemmArgs& a, int akc, int bkc, int dtC, int batch, hipStream_t s);   // bf16 A, f32 B

@@ -1,0 +1,198 @@
+// Skinny-M linears of the RNA encoder / style heads (models/mirror.py:70-100, :217-224, :845-857): every tensor
+// there is [B, D] with B = the per-GPU batch (16), so the GEMMs are weight-streaming problems (25 M parameters read
+// once per pass) — the 128x128-tile kernel ran them on 8-64 workgroups at 2 TF/s.
+//
+//   mh_skinny_fwd   y[M<=32, N] = act(x[M,K] . W[N,K]^T + b)      weights go HBM -> VGPR in MFMA B-fragment layout
+//                   (v_mfma_f32_16x16x32_bf16: lane l holds k = 8(l>>4)+j of column l&15 = one 16-B load of a W row),
+//                   one wave per 16 output columns per K-slice, 4 K-slices per block reduced through LDS.
+//                   The data gradient uses the same kernel on the transposed shadow W^T[K,N].
+//   mh_skinny_wgrad dW[N,K] (+)= dy[M,N]^T . x[M,K]               rank-M outer products, 64x256 output tile per block,
+//                   operands staged once in LDS, 8x8 outputs per thread, f32 read-modify-write (no atomics).
+//   mh_transpose    bf16 [R,C] -> [C,R] (keeps the W^T shadows fresh)
+#include "common.h"
+
+typedef __bf16 sk_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float sk_f4 __attribute__((ext_vector_type(4)));
+typedef unsigned sk_u4 __attribute__((ext_vector_type(4)));
+
+template <typename TY, int MT>   // MT = number of 16-row tiles of x (1 or 2)
+__global__ __launch_bounds__(256) void skinny_fwd_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ w,
+                                                         long ldw, const float* __restrict__ bias, TY* __restrict__ y, long ldy,
+                                                         int M, int N, int K, int act) {
+    __shared__ float red[4][MT][16][17];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n0 = blockIdx.x * 16;
+    const int col = lane & 15, kq = lane >> 4;
+    const int nrow = min(n0 + col, N - 1);                 // ragged last column group: re-read row N-1, never stored
+    const bf16_t* wp = w + (long)nrow * ldw + 8 * kq;
+    const bf16_t* xp[MT];
+#pragma unroll
+    for (int t = 0; t < MT; t++) xp[t] = x + (long)min(16 * t + col, M - 1) * ldx + 8 * kq;
+    sk_f4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; t++) acc[t] = (sk_f4){0.f, 0.f, 0.f, 0.f};
+    // wave `wave` owns k-steps wave, wave+4, ... (32 k per step): four independent 16-B streams per lane
+    const int steps = K / 32;
+#pragma unroll 4
+    for (int s = wave; s < steps; s += 4) {
+        const sk_bf16x8 b = *reinterpret_cast<const sk_bf16x8*>(wp + 32 * s);
+#pragma unroll
+        for (int t = 0; t < MT; t++) {
+            const sk_bf16x8 a = *reinterpret_cast<const sk_bf16x8*>(xp[t] + 32 * s);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[t], 0, 0, 0);
+        }
+    }
+    // C/D map of 16x16x32: col = lane&15, row = (lane>>4)*4 + r
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) red[wave][t][kq * 4 + r][col] = acc[t][r];
+    __syncthreads();
+    for (int i = threadIdx.x; i < MT * 256; i += 256) {
+        const int t = i >> 8, rr = (i >> 4) & 15, cc = i & 15;
+        const int m = 16 * t + rr, n = n0 + cc;
+        if (m < M && n < N) {
+            float v = red[0][t][rr][cc] + red[1][t][rr][cc] + red[2][t][rr][cc] + red[3][t][rr][cc];
+            if (bias) v += bias[n];
+            if (act == MH_ACT_RELU) v = fmaxf(v, 0.f);
+            else if (act == MH_ACT_GELU) v = gelu_f(v);
+            stf(y + (long)m * ldy + n, v);
+        }
+    }
+}
+
+extern "C" int mh_skinny_fwd(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, void* y, int64_t ldy,
+                             int M, int N, int K, int act, int dt_y, mh_stream s) {
+    MH_REQUIRE(M >= 1 && M <= 32, "mh_skinny_fwd: M=%d (needs 1..32)", M);
+    MH_REQUIRE(K % 32 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0,
+               "mh_skinny_fwd: K %% 32 == 0 and 16-byte aligned rows required (K=%d ldx=%ld ldw=%ld)", K, (long)ldx, (long)ldw);
+    if (N == 0) return MH_OK;
+    dim3 grid(mh_cdiv(N, 16));
+#define SKF(TY, MT) hipLaunchKernelGGL((skinny_fwd_kernel<TY, MT>), grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (long)ldx, (const bf16_t*)w, (long)ldw, bias, (TY*)y, (long)ldy, M, N, K, act)
+    if (dt_y == MH_F32) { if (M <= 16) SKF(float, 1); else SKF(float, 2); }
+    else { if (M <= 16) SKF(bf16_t, 1); else SKF(bf16_t, 2); }
+#undef SKF
+    MH_LAUNCH_CHECK("mh_skinny_fwd");
+    return MH_OK;
+}
+
+// dW tile = 64 (n) x 256 (k) per block; thread (tn = tid>>5, tk = tid&31) owns n = 8*tn.., k = 8*tk..
+#define SW_TN 64
+#define SW_TK 256
+__global__ __launch_bounds__(256) void skinny_wgrad_kernel(const bf16_t* __restrict__ dy, long lddy, const bf16_t* __restrict__ x,
+                                                           long ldx, float* __restrict__ dw, long lddw, int M, int N, int K,
+                                                           int accumulate) {
+    __shared__ __attribute__((aligned(16))) float sdy[32][SW_TN];
+    __shared__ __attribute__((aligned(16))) float sx[32][SW_TK];
+    const int n0 = blockIdx.x * SW_TN, k0 = blockIdx.y * SW_TK;
+    for (int i = threadIdx.x; i < M * SW_TN; i += 256) {
+        const int m = i / SW_TN, c = i % SW_TN;
+        sdy[m][c] = (n0 + c < N) ? bf2f(dy[(long)m * lddy + n0 + c]) : 0.f;
+    }
+    for (int i = threadIdx.x; i < M * SW_TK; i += 256) {
+        const int m = i / SW_TK, c = i % SW_TK;
+        sx[m][c] = (k0 + c < K) ? bf2f(x[(long)m * ldx + k0 + c]) : 0.f;
+    }
+    __syncthreads();
+    const int tn = threadIdx.x >> 5, tk = threadIdx.x & 31;
+    float acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[i][j] = 0.f;
+    for (int m = 0; m < M; m++) {
+        const sk_f4 a0 = *reinterpret_cast<const sk_f4*>(&sdy[m][8 * tn]), a1 = *reinterpret_cast<const sk_f4*>(&sdy[m][8 * tn + 4]);
+        const sk_f4 b0 = *reinterpret_cast<const sk_f4*>(&sx[m][8 * tk]), b1 = *reinterpret_cast<const sk_f4*>(&sx[m][8 * tk + 4]);
+        const float a[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        const float b[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc[i][j] += a[i] * b[j];
+    }
+    const bool kvec = (k0 + 8 * tk + 8 <= K) && (lddw % 4 == 0);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int n = n0 + 8 * tn + i;
+        if (n >= N) continue;
+        float* dst = dw + (long)n * lddw + k0 + 8 * tk;
+        if (kvec) {
+            sk_f4 o0 = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]}, o1 = {acc[i][4], acc[i][5], acc[i][6], acc[i][7]};
+            if (accumulate) { o0 += *reinterpret_cast<const sk_f4*>(dst); o1 += *reinterpret_cast<const sk_f4*>(dst + 4); }
+            *reinterpret_cast<sk_f4*>(dst) = o0;
+            *reinterpret_cast<sk_f4*>(dst + 4) = o1;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (k0 + 8 * tk + j < K) dst[j] = (accumulate ? dst[j] : 0.f) + acc[i][j];
+        }
+    }
+}
+
+extern "C" int mh_skinny_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw, int64_t lddw, int M, int N,
+                               int K, int accumulate, mh_stream s) {
+    MH_REQUIRE(M >= 1 && M <= 32, "mh_skinny_wgrad: M=%d (needs 1..32)", M);
+    MH_REQUIRE(((uintptr_t)dw & 15) == 0, "mh_skinny_wgrad: dW must be 16-byte aligned");
+    if (N == 0 || K == 0) return MH_OK;
+    dim3 grid(mh_cdiv(N, SW_TN), mh_cdiv(K, SW_TK));
+    hipLaunchKernelGGL(skinny_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)dy, (long)lddy, (const bf16_t*)x,
+                       (long)ldx, dw, (long)lddw, M, N, K, accumulate);
+    MH_LAUNCH_CHECK("mh_skinny_wgrad");
+    return MH_OK;
+}
+
+// out[c][r] = in[r][c] (bf16), 64x64 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int R, int Cc) {
+    __shared__ bf16_t tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < Cc) ? in[(long)r * Cc + c] : (bf16_t)0;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (r < R && c < Cc) out[(long)c * R + r] = tile[tx][i];
+    }
+}
+
+extern "C" int mh_transpose_bf16(const void* in, void* out, int R, int Cc, mh_stream s) {
+    if (R == 0 || Cc == 0) return MH_OK;
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3(mh_cdiv(Cc, 64), mh_cdiv(R, 64)), dim3(256), 0, (hipStream_t)s,
+                       (const bf16_t*)in, (bf16_t*)out, R, Cc);
+    MH_LAUNCH_CHECK("mh_transpose_bf16");
+    return MH_OK;
+}
+
+// Batched form: table[i] = {src_off, dst_off, R, C} (element offsets into one bf16 arena each); one launch refreshes
+// every W^T shadow after the optimizer step.
+__global__ __launch_bounds__(256) void transpose_bf16_many_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+                                                                  const long* __restrict__ table) {
+    __shared__ bf16_t tile[64][66];
+    const long* e = table + 4 * blockIdx.z;
+    const int R = (int)e[2], Cc = (int)e[3];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    if (r0 >= R || c0 >= Cc) return;
+    const bf16_t* in = src + e[0];
+    bf16_t* out = dst + e[1];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < Cc) ? in[(long)r * Cc + c] : (bf16_t)0;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (r < R && c < Cc) out[(long)c * R + r] = tile[tx][i];
+    }
+}
+
+extern "C" int mh_transpose_bf16_many(const void* src, void* dst, const int64_t* table, int n, int max_r, int max_c, mh_stream s) {
+    if (n == 0) return MH_OK;
+    MH_REQUIRE(n <= 65535, "mh_transpose_bf16_many: too many tensors");
+    hipLaunchKernelGGL(transpose_bf16_many_kernel, dim3(mh_cdiv(max_c, 64), mh_cdiv(max_r, 64), n), dim3(256), 0, (hipStream_t)s,
+                       (const bf16_t*)src, (bf16_t*)dst, (const long*)table);
+    MH_LAUNCH_CHECK("mh_transpose_bf16_many");
+    return MH_OK;
+}

@@ -81,6 +81,19 @@ class TrainEngine:
                 self.master[o:o + n].copy_(p.detach().reshape(-1))
                 p.data = self.master[o:o + n].view(p.shape)
                 p.grad = self.grad[o:o + n].view(p.shape)
+        # W^T shadows of the 2-D weights (skinny data-gradient kernels stream them like forward weights)
+        self.shadow_t = None
+        if self.shadow is not None:
+            two_d = [(p, o) for p, o in zip(order, offs) if p.dim() == 2 and p.shape[1] % 32 == 0 and p.shape[0] % 32 == 0]
+            if two_d:
+                self.shadow_t = torch.zeros(total, device=self.device, dtype=bf16)
+                tab = []
+                for p, o in two_d:
+                    tab += [o, o, p.shape[0], p.shape[1]]
+                self._t_table = torch.tensor(tab, device=self.device, dtype=torch.int64)
+                self._t_n = len(two_d)
+                self._t_max = (max(p.shape[0] for p, _ in two_d), max(p.shape[1] for p, _ in two_d))
+                self._t_params = two_d
         self.sync_shadows()
         self._proto = getattr(model, "prototypes", None)
         self._logit = getattr(model, "logit_scale", None)
@@ -97,6 +110,14 @@ class TrainEngine:
         K.cast(self.master, bf16, out=self.shadow)
         for p, o in zip(self.params, self.offsets):
             Fn.register_shadow(p, self.shadow[o:o + p.numel()].view(p.shape))
+        self._refresh_transposes()
+        if self.shadow_t is not None:
+            for p, o in self._t_params:
+                Fn.register_shadow_t(p, self.shadow_t[o:o + p.numel()].view(p.shape[1], p.shape[0]))
+
+    def _refresh_transposes(self) -> None:
+        if self.shadow_t is not None:
+            K.transpose_bf16_many(self.shadow, self.shadow_t, self._t_table, self._t_n, self._t_max[0], self._t_max[1])
 
     # ------------------------------------------------------------------ gradient buckets (data parallel)
     def _build_buckets(self, bucket_mb: float) -> None:
@@ -152,6 +173,7 @@ class TrainEngine:
         K.adam(self.master, self.grad, self.m, self.v, self.shadow, self.lr, b1, b2, self.eps,
                1.0 - b1 ** self.step_count, 1.0 - b2 ** self.step_count,
                grad_scale=1.0 / self.world)   # buckets are SUM-reduced; the DDP average is folded into Adam
+        self._refresh_transposes()
         if self._logit is not None:
             K.clamp_(self._logit.data.reshape(1), 0.0, math.log(100.0))
             if self.shadow is not None:

@@ -59,6 +59,30 @@ def shadow(w: torch.Tensor, prec: Precision) -> torch.Tensor:
 
 
 _managed_shadows: dict = {}
+_managed_shadows_t: dict = {}
+_shadow_t_cache: dict = {}
+
+
+def shadow_t(w: torch.Tensor, prec: Precision) -> torch.Tensor:
+    """bf16 W^T [K, N] of a 2-D master weight (skinny data-gradient path streams it like a forward weight)."""
+    key = (w.data_ptr(), tuple(w.shape))
+    man = _managed_shadows_t.get(key)
+    if man is not None:
+        return man
+    hit = _shadow_t_cache.get(key)
+    if hit is not None and hit[0] == w._version:
+        return hit[1]
+    t = K.transpose_bf16(shadow(w, prec).contiguous())
+    _shadow_t_cache[key] = (w._version, t)
+    return t
+
+
+def register_shadow_t(w: torch.Tensor, t: Optional[torch.Tensor]) -> None:
+    key = (w.data_ptr(), tuple(w.shape))
+    if t is None:
+        _managed_shadows_t.pop(key, None)
+    else:
+        _managed_shadows_t[key] = t
 
 
 def register_shadow(w: torch.Tensor, s: Optional[torch.Tensor]) -> None:
@@ -87,15 +111,19 @@ class LinearFn(Function):
     def forward(ctx, x, w, b, act, prec, out_dtype):
         xa = x if x.dtype == prec.act else K.cast(x.contiguous(), prec.act)
         wa = shadow(w, prec)
-        y = K.gemm(xa, wa.t(), bias=None if b is None else b.detach(), act=act, mma=prec.mma,
-                   out_dtype=out_dtype or prec.act)
-        ctx.save_for_backward(xa, wa, y if act == ACT_RELU else None)
+        bd = None if b is None else b.detach()
+        ctx.skinny = prec.act == bf16 and K.skinny_ok(xa, wa)      # [B, D] activations: weight-streaming kernels
+        if ctx.skinny:
+            y = K.skinny_fwd(xa, wa, bd, act, out_dtype or prec.act)
+        else:
+            y = K.gemm(xa, wa.t(), bias=bd, act=act, mma=prec.mma, out_dtype=out_dtype or prec.act)
+        ctx.save_for_backward(xa, wa, y if act == ACT_RELU else None, w)
         ctx.act, ctx.prec, ctx.has_b, ctx.x_dtype = act, prec, b is not None, x.dtype
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        xa, wa, y = ctx.saved_tensors
+        xa, wa, y, w = ctx.saved_tensors
         prec = ctx.prec
         if ctx.act == ACT_RELU:
             dy = K.relu_bwd(y, dy if _blk_ok(dy) else dy.contiguous(), out_dtype=prec.act)
@@ -107,9 +135,16 @@ class LinearFn(Function):
         N, Kd = wa.shape
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = K.gemm(dy, wa, mma=prec.mma, out_dtype=ctx.x_dtype)
+            if ctx.skinny and N % 32 == 0:
+                dx = K.skinny_fwd(dy, shadow_t(w, prec), None, ACT_NONE, ctx.x_dtype)
+            else:
+                dx = K.gemm(dy, wa, mma=prec.mma, out_dtype=ctx.x_dtype)
         if ctx.needs_input_grad[1]:
-            dw = _wgrad(dy, xa, N, Kd, prec)
+            if ctx.skinny:
+                dw = torch.empty((N, Kd), device=dy.device, dtype=f32)
+                K.skinny_wgrad(dy, xa, dw, accumulate=False)
+            else:
+                dw = _wgrad(dy, xa, N, Kd, prec)
         if ctx.has_b and ctx.needs_input_grad[2]:
             db = torch.zeros((N,), device=dy.device, dtype=f32)
             K.colsum(dy.reshape(-1, N), db)
@@ -351,43 +386,42 @@ def _heads(t3: torch.Tensor, which: int, parts: int, h: int) -> torch.Tensor:
     return t3.view(Bn, T, parts, h, dh)[:, :, which].permute(0, 2, 1, 3)
 
 
-def _pinv_step(a2, z, pm):
-    P = K.gemm(a2, z, mma=pm)
-    T1 = K.eye_minus(P, 7.0)
-    T2 = K.gemm(P, T1, alpha=-1.0, diag=15.0, mma=pm)
-    T3 = K.gemm(P, T2, alpha=-1.0, diag=13.0, mma=pm)
-    return P, T1, T2, T3
-
-
-def pinv_forward(a2: torch.Tensor, iters: int, pm: int):
+def pinv_forward(a2: torch.Tensor, iters: int, pm: int, sd: torch.dtype):
     """[3P] moore_penrose_iter_pinv: z0 = a2^T / (max rowsum * max colsum) over the WHOLE tensor, then
-    z <- 1/4 z (13I - a2 z (15I - a2 z (7I - a2 z))).  Returns every iterate (kept for the backward)."""
+    z <- 1/4 z (13I - P (15I - P (7I - P))), P = a2 z.  The middle factor is expanded, T2 = 15I - 7P + P.P, so every
+    step is one GEMM with an epilogue (diag / R addend) and nothing else is launched.  Iterates and intermediates
+    are stored in `sd` (f32, or bf16 when the GEMMs round their operands to bf16 anyway) and KEPT for the backward.
+    Returns (z_final, [(z_k, P_k, T2_k, T3_k)], stats)."""
     st = K.pinv_absmax(a2)
-    zs = [K.pinv_z0(a2, st)]
+    z = K.cast(K.pinv_z0(a2, st), sd)
+    saved = []
     for _ in range(iters):
-        _, _, _, T3 = _pinv_step(a2, zs[-1], pm)
-        zs.append(K.gemm(zs[-1], T3, alpha=0.25, mma=pm))
-    return zs, st
+        P = K.gemm(a2, z, mma=pm, out_dtype=sd)
+        T2 = K.gemm(P, P, diag=15.0, R=P, rcoef=-7.0, mma=pm, out_dtype=sd)
+        T3 = K.gemm(P, T2, alpha=-1.0, diag=13.0, mma=pm, out_dtype=sd)
+        zn = K.gemm(z, T3, alpha=0.25, mma=pm, out_dtype=sd)
+        saved.append((z, P, T2, T3))
+        z = zn
+    return z, saved, st
 
 
-def pinv_backward(a2, zs, st, dZ, pm):
-    """Reverse mode through the iterations (intermediates recomputed from the saved iterates)."""
+def pinv_backward(a2, saved, st, dZ, pm, sd):
+    """Reverse mode through the iterations: 8 GEMMs per step, gradients accumulate in f32."""
     dX = torch.zeros_like(a2)
     dz = dZ
     tr = lambda t: t.transpose(-1, -2)  # noqa: E731
-    for k in range(len(zs) - 2, -1, -1):
-        z = zs[k]
-        P, T1, T2, T3 = _pinv_step(a2, z, pm)
-        dT3 = K.gemm(tr(z), dz, alpha=0.25, mma=pm)
-        dz_new = K.gemm(dz, tr(T3), alpha=0.25, mma=pm)
-        dP = K.gemm(dT3, tr(T2), alpha=-1.0, mma=pm)
-        dT2 = K.gemm(tr(P), dT3, alpha=-1.0, mma=pm)
-        K.gemm(dT2, tr(T1), out=dP, alpha=-1.0, accumulate=True, mma=pm)
-        K.gemm(tr(P), dT2, out=dP, accumulate=True, mma=pm)       # dP += -dT1 = P^T dT2
-        K.gemm(dP, tr(z), out=dX, accumulate=True, mma=pm)
+    for z, P, T2, T3 in reversed(saved):
+        dT3 = K.gemm(tr(z), dz, alpha=0.25, mma=pm, out_dtype=sd)                  # z' = 1/4 z T3
+        dz_new = K.gemm(dz, tr(T3), alpha=0.25, mma=pm, out_dtype=f32)
+        dP = K.gemm(dT3, tr(T2), alpha=-1.0, mma=pm, out_dtype=f32)                # T3 = 13I - P T2
+        dT2 = K.gemm(tr(P), dT3, alpha=-1.0, mma=pm, out_dtype=f32)
+        K.gemm(dT2, tr(P), out=dP, accumulate=True, R=dT2, rcoef=-7.0, mma=pm)     # T2 = 15I - 7P + P P
+        K.gemm(tr(P), dT2, out=dP, accumulate=True, mma=pm)
+        K.gemm(dP, tr(z), out=dX, accumulate=True, mma=pm)                         # P = a2 z
         K.gemm(tr(a2), dP, out=dz_new, accumulate=True, mma=pm)
         dz = dz_new
-    K.pinv_z0_bwd(a2, zs[0], dz, st, dX)
+    z0 = saved[0][0]
+    K.pinv_z0_bwd(a2, K.cast(z0, f32), dz, st, dX)
     return dX
 
 
@@ -414,19 +448,37 @@ class NystromCoreFn(Function):
         K.softmax_fwd(a2, a2)
         a3 = K.gemm(ql, k.transpose(-1, -2), alpha=scale, mma=mma, out_dtype=f32)       # [B,h,m,n_p]
         a3 = K.softmax_fwd(a3, a3 if A == f32 else None, out_dtype=A)
-        zs, st = pinv_forward(a2, iters, pm)
+        sd = f32 if pm == MH_F32 else bf16
+        m_l = a2.shape[-1]
+        chain = pm == MH_BF16 and m_l in (128, 256)     # whole iteration in one launch (pinv_chain.hip)
+        if chain:
+            st = K.pinv_absmax(a2)
+            z0 = K.pinv_z0(a2, st)
+            xb = K.cast(a2, bf16)
+            chain_saved = torch.empty((iters, 4, Bn * h, m_l, m_l), device=qkv.device, dtype=bf16)
+            K.cast(z0.reshape(Bn * h, m_l, m_l), bf16, out=chain_saved[0, 0])
+            zf = torch.empty((Bn, h, m_l, m_l), device=qkv.device, dtype=bf16)
+            K.pinv_chain_fwd(xb, chain_saved, zf, iters)
+            saved = [(xb, chain_saved, z0)]
+        else:
+            zf, saved, st = pinv_forward(a2, iters, pm, sd)
         av = K.gemm(a3, v, mma=mma, out_dtype=f32)                                       # [B,h,m,dh]
-        w2 = K.cast(K.gemm(zs[-1], av, mma=pm), A)
+        # GEMMs that meet activation-dtype tensors cannot use the exact-f32 MFMA unless the activations are f32 too
+        pio = pm if (pm == MH_BF16 or A == f32) else mma
+        w2 = K.gemm(zf, av, mma=pio, out_dtype=A)
         out = torch.empty((Bn, n_p, D), device=qkv.device, dtype=A)
         K.gemm(a1, w2, out=_heads(out, 0, 1, h), mma=mma)
         K.resconv(qkv[..., 2 * D:], res_w.detach().contiguous(), out, h, transpose=False, accumulate=True)
-        ctx.save_for_backward(qkv, res_w, lm, a1, a2, a3, av, w2, st, *zs)
+        ctx.save_for_backward(qkv, res_w, lm, a1, a2, a3, av, w2, st, zf, *[t for it in saved for t in it])
         ctx.cfg = (heads, l, prec)
+        ctx.chain = (chain, iters)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        qkv, res_w, lm, a1, a2, a3, av, w2, st, *zs = ctx.saved_tensors
+        qkv, res_w, lm, a1, a2, a3, av, w2, st, zf, *flat = ctx.saved_tensors
+        chain, iters = ctx.chain
+        saved = None if chain else [tuple(flat[i:i + 4]) for i in range(0, len(flat), 4)]
         heads, l, prec = ctx.cfg
         A, mma, pm = prec.act, prec.mma, prec.pinv_mma
         Bn, n_p, D3 = qkv.shape
@@ -451,25 +503,34 @@ class NystromCoreFn(Function):
         dW2 = K.gemm(tr(a1), dO, mma=mma, out_dtype=f32)                                 # [B,h,m,dh]
         K.softmax_bwd(a1, dS1)
         # w2 = Z @ av ; av = a3 @ v
-        dZ = K.gemm(dW2, tr(av), mma=pm)                                                 # [B,h,m,m]
-        dAV = K.cast(K.gemm(tr(zs[-1]), dW2, mma=pm), A)                                 # [B,h,m,dh]
+        sd = f32 if pm == MH_F32 else bf16
+        dZ = K.gemm(dW2, tr(av), mma=pm, out_dtype=f32)                                  # [B,h,m,m]
+        pio = pm if (pm == MH_BF16 or A == f32) else mma
+        dAV = K.gemm(tr(zf), dW2, mma=pio, out_dtype=A)                                  # [B,h,m,dh]
         dS3 = K.gemm(dAV, tr(v), mma=mma, out_dtype=A)                                   # [B,h,m,n_p]
         K.gemm(tr(a3), dAV, out=dv, mma=mma)
         K.resconv(dout, rw, dqkv[..., 2 * D:], h, transpose=True, accumulate=True)
         K.softmax_bwd(a3, dS3)
-        dS2 = pinv_backward(a2, list(zs), st, dZ, pm)
+        if chain:
+            xb, chain_saved, z0 = flat
+            work = torch.empty_like(chain_saved)
+            dS2 = torch.empty_like(a2)
+            dz0 = torch.empty_like(a2)
+            K.pinv_chain_bwd(xb, chain_saved, K.cast(dZ, bf16), work, dS2, dz0, iters)
+            K.pinv_z0_bwd(a2, z0, dz0, st, dS2)
+            del work
+        else:
+            dS2 = pinv_backward(a2, saved, st, dZ, pm, sd)
         K.softmax_bwd(a2, dS2)
         # similarities: s1 = scale q kl^T, s2 = scale ql kl^T, s3 = scale ql k^T
         K.gemm(dS1, kl, out=dq, alpha=scale, mma=mma)
         K.gemm(tr(dS3), ql, out=dk, alpha=scale, mma=mma)
-        lmf = K.cast(lm, f32)
-        qlf, klf = _heads(lmf, 0, 2, h), _heads(lmf, 1, 2, h)
         dlm = torch.empty((Bn, m, 2 * D), device=qkv.device, dtype=f32)
         dql, dkl = _heads(dlm, 0, 2, h), _heads(dlm, 1, 2, h)
         K.gemm(tr(dS1), q, out=dkl, alpha=scale, mma=mma)
-        K.gemm(tr(dS2), qlf, out=dkl, alpha=scale, accumulate=True, mma=pm)
+        K.gemm(tr(dS2), ql, out=dkl, alpha=scale, accumulate=True, mma=pio)
         K.gemm(dS3, k, out=dql, alpha=scale, mma=mma)
-        K.gemm(dS2, klf, out=dql, alpha=scale, accumulate=True, mma=pm)
+        K.gemm(dS2, kl, out=dql, alpha=scale, accumulate=True, mma=pio)
         K.landmark_bwd(K.cast(dlm, A), dqkv, l)
         return dqkv, dres.view_as(res_w), None, None, None, None
 

@@ -63,8 +63,9 @@ def _mat(t: torch.Tensor):
 
 def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *, alpha: float = 1.0,
          diag: float = 0.0, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, accumulate: bool = False,
-         split_k: int = 1, mma: int = MH_F32, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
-    """out[..] (+)= act(alpha * a @ b + diag*I + bias) with a [..,M,K], b [..,K,N] given as (possibly
+         split_k: int = 1, mma: int = MH_F32, out_dtype: Optional[torch.dtype] = None,
+         R: Optional[torch.Tensor] = None, rcoef: float = 0.0) -> torch.Tensor:
+    """out[..] (+)= act(alpha * a @ b + diag*I + bias + rcoef*R) with a [..,M,K], b [..,K,N] given as (possibly
     transposed / strided / broadcast) views; <= 2 leading batch dims."""
     _chk(a, b, out, bias)
     nd = max(a.dim(), b.dim())
@@ -79,8 +80,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *
     for t4 in (a4, b4):
         if t4.shape[0] not in (1, B1) or t4.shape[1] not in (1, B2):
             raise MirrorHipError(f"gemm: batch dims do not broadcast: {tuple(a.shape)} @ {tuple(b.shape)}")
-    if a4.dtype != b4.dtype:
-        raise MirrorHipError(f"gemm: operand dtypes differ: {a4.dtype} vs {b4.dtype}")
+    if a4.dtype != b4.dtype and mma == MH_F32:
+        raise MirrorHipError(f"gemm: f32 MMA needs f32 operands, got {a4.dtype} x {b4.dtype}")
     if out is None:
         if accumulate:
             raise MirrorHipError("gemm: accumulate needs an explicit output")
@@ -96,7 +97,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *
     so = o4.stride()
     if not (so[3] == 1 or N == 1):
         raise MirrorHipError("gemm: output must have unit stride in its last dim")
-    if mma == MH_F32 and (a4.dtype != torch.float32 or o4.dtype != torch.float32):
+    if mma == MH_F32 and (a4.dtype != torch.float32 or b4.dtype != torch.float32 or o4.dtype != torch.float32):
         raise MirrorHipError("gemm: f32 MMA needs f32 operands and output")
     if bias is not None:
         if bias.dtype != torch.float32 or bias.numel() != N or not bias.is_contiguous():
@@ -111,6 +112,11 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *
     d.sA1, d.sA2, d.sB1, d.sB2 = sa1, sa2, sb1, sb2
     d.sC1, d.sC2 = (so[0] if B1 > 1 else 0), (so[1] if B2 > 1 else 0)
     d.alpha, d.diag, d.act, d.accumulate, d.split_k = alpha, diag, act, int(accumulate), max(1, int(split_k))
+    if R is not None:
+        _chk(R)
+        if R.dtype != o4.dtype or R.numel() != o4.numel() or tuple(R.stride()) != tuple(out.stride()):
+            raise MirrorHipError("gemm: R must have the output's dtype, shape and strides")
+        d.R, d.rcoef = R.data_ptr(), rcoef
     prof = gemm_profiler
     if prof is None:
         _lib.call("mh_gemm", C.byref(d), stream=_stream())
@@ -171,6 +177,50 @@ class GemmProfiler:
 
 
 gemm_profiler: Optional[GemmProfiler] = None
+
+
+# ----------------------------------------------------------------------------- skinny-M linears
+def skinny_ok(x2d: torch.Tensor, w: torch.Tensor) -> bool:
+    """bf16 x [M<=32, K] (row-strided ok) against bf16 W [N, K] contiguous, K % 32 == 0, 16-B aligned rows."""
+    return (x2d.dim() == 2 and w.dim() == 2 and x2d.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
+            and 1 <= x2d.shape[0] <= 32 and x2d.shape[1] == w.shape[1] and w.shape[1] % 32 == 0 and w.is_contiguous()
+            and (x2d.stride(1) == 1) and x2d.stride(0) % 8 == 0 and x2d.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0)
+
+
+def skinny_fwd(x2d: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act: int, out_dtype) -> torch.Tensor:
+    _chk(x2d, w, bias)
+    M, Kd = x2d.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), device=x2d.device, dtype=out_dtype)
+    _lib.call("mh_skinny_fwd", _p(x2d), x2d.stride(0), _p(w), w.stride(0), _p(bias), _p(y), N, M, N, Kd, act, dt(y),
+              stream=_stream())
+    return y
+
+
+def skinny_wgrad(dy2d: torch.Tensor, x2d: torch.Tensor, dw: torch.Tensor, accumulate: bool) -> None:
+    _chk(dy2d, x2d, dw)
+    M, N = dy2d.shape
+    Kd = x2d.shape[1]
+    if (dy2d.dtype != torch.bfloat16 or x2d.dtype != torch.bfloat16 or dw.dtype != torch.float32 or x2d.shape[0] != M
+            or tuple(dw.shape) != (N, Kd) or dy2d.stride(1) != 1 or x2d.stride(1) != 1 or dw.stride(1) != 1):
+        raise MirrorHipError("skinny_wgrad: bad operands")
+    _lib.call("mh_skinny_wgrad", _p(dy2d), dy2d.stride(0), _p(x2d), x2d.stride(0), _p(dw), dw.stride(0), M, N, Kd,
+              int(accumulate), stream=_stream())
+
+
+def transpose_bf16(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(x, out)
+    _contig(x, "transpose input")
+    R, Cc = x.shape
+    y = out if out is not None else torch.empty((Cc, R), device=x.device, dtype=torch.bfloat16)
+    _lib.call("mh_transpose_bf16", _p(x), _p(y), R, Cc, stream=_stream())
+    return y
+
+
+def transpose_bf16_many(src: torch.Tensor, dst: torch.Tensor, table: torch.Tensor, n: int, max_r: int, max_c: int) -> None:
+    _chk(src, dst, table)
+    assert table.dtype == torch.int64 and table.is_contiguous() and table.numel() == 4 * n
+    _lib.call("mh_transpose_bf16_many", _p(src), _p(dst), _p(table), n, max_r, max_c, stream=_stream())
 
 
 # ----------------------------------------------------------------------------- row kernels
@@ -287,6 +337,29 @@ def pinv_z0_bwd(x, z0, dz0, stats, dx) -> None:
     scratch = torch.empty(1, device=x.device, dtype=torch.float32)
     _lib.call("mh_pinv_z0_bwd", _p(x), _p(z0), _p(_contig(dz0, "dz0")), _p(stats), _p(dx), _p(scratch),
               x.numel() // (m * m), m, stream=_stream())
+
+
+def pinv_chain_fwd(Xb: torch.Tensor, saved: torch.Tensor, zf: torch.Tensor, iters: int) -> None:
+    _chk(Xb, saved, zf)
+    m = Xb.shape[-1]
+    BH = Xb.numel() // (m * m)
+    bf = torch.bfloat16
+    if not (Xb.dtype == bf and saved.dtype == bf and zf.dtype == bf and Xb.is_contiguous() and saved.is_contiguous()
+            and zf.is_contiguous() and saved.numel() == iters * 4 * BH * m * m and zf.numel() == BH * m * m):
+        raise MirrorHipError("pinv_chain_fwd: bad operands")
+    _lib.call("mh_pinv_chain_fwd", _p(Xb), _p(saved), _p(zf), BH, m, iters, stream=_stream())
+
+
+def pinv_chain_bwd(Xb, saved, dzf, work, dX, dz0, iters: int) -> None:
+    _chk(Xb, saved, dzf, work, dX, dz0)
+    m = Xb.shape[-1]
+    BH = Xb.numel() // (m * m)
+    bf = torch.bfloat16
+    if not (all(t.dtype == bf and t.is_contiguous() for t in (Xb, saved, dzf, work))
+            and all(t.dtype == torch.float32 and t.is_contiguous() and t.numel() == BH * m * m for t in (dX, dz0))
+            and saved.numel() == iters * 4 * BH * m * m and work.numel() == saved.numel() and dzf.numel() == BH * m * m):
+        raise MirrorHipError("pinv_chain_bwd: bad operands")
+    _lib.call("mh_pinv_chain_bwd", _p(Xb), _p(saved), _p(dzf), _p(work), _p(dX), _p(dz0), BH, m, iters, stream=_stream())
 
 
 def eye_minus(P: torch.Tensor, d: float) -> torch.Tensor:

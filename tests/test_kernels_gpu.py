@@ -531,3 +531,74 @@ def test_step_glue_rownorm_clamp_adam():
         K.adam(pd, gstep.to(DEV), m, v, sh, 2e-5, 0.9, 0.999, 1e-8, 1 - 0.9 ** step, 1 - 0.999 ** step)
     close(pd, pr.detach(), 1e-6, 1e-7, "adam")
     close(sh, pr.detach().bfloat16().float(), 1e-2, 1e-6, "adam bf16 shadow")
+
+
+# --------------------------------------------------------------------------------------- skinny-M linears
+@pytest.mark.parametrize("M,N,Kd", [(16, 1024, 2048), (3, 3000, 512), (32, 96, 64), (20, 16, 32)])
+def test_skinny_fwd_wgrad_transpose(M, N, Kd):
+    gen = g(M + N)
+    x, w, dy = ints((M, Kd), gen), ints((N, Kd), gen), ints((M, N), gen)
+    bias = ints((N,), gen)
+    xd, wd, dyd = x.to(DEV).bfloat16(), w.to(DEV).bfloat16(), dy.to(DEV).bfloat16()
+    assert K.skinny_ok(xd, wd)
+    y = K.skinny_fwd(xd, wd, bias.to(DEV), ACT_RELU, torch.float32)
+    close(y, F.relu(x.double() @ w.double().t() + bias.double()), 0, 0, "skinny fwd")
+    yb = K.skinny_fwd(xd, wd, None, ACT_NONE, torch.bfloat16)
+    close(yb, (x.double() @ w.double().t()).float().bfloat16().double(), 0, 0, "skinny fwd bf16")
+    wt = K.transpose_bf16(wd)
+    close(wt, w.t(), 0, 0, "transpose")
+    if N % 32 == 0:
+        dx = K.skinny_fwd(dyd, wt, None, ACT_NONE, torch.float32)
+        close(dx, dy.double() @ w.double(), 0, 0, "skinny dgrad via W^T")
+    dw = torch.full((N, Kd), 2.0, device=DEV)
+    K.skinny_wgrad(dyd, xd, dw, accumulate=True)
+    close(dw, 2 + dy.double().t() @ x.double(), 0, 0, "skinny wgrad accumulate")
+    K.skinny_wgrad(dyd, xd, dw, accumulate=False)
+    close(dw, dy.double().t() @ x.double(), 0, 0, "skinny wgrad")
+    # batched transpose table
+    src = torch.cat([wd.reshape(-1), xd.reshape(-1)])
+    dst = torch.zeros_like(src)
+    tab = torch.tensor([0, 0, N, Kd, N * Kd, N * Kd, M, Kd], device=DEV, dtype=torch.int64)
+    K.transpose_bf16_many(src, dst, tab, 2, max(N, M), Kd)
+    close(dst[:N * Kd].view(Kd, N), w.t(), 0, 0, "batched transpose 0")
+    close(dst[N * Kd:].view(Kd, M), x.t(), 0, 0, "batched transpose 1")
+
+
+# --------------------------------------------------------------------------------------- fused pinv chain
+@pytest.mark.parametrize("m", [128, 256])
+def test_pinv_chain_matches_reference_iteration(m):
+    """One-launch Moore-Penrose chain (bf16 operands, f32 accumulate) vs the f64 iteration and its autograd."""
+    from oracle import mirror_oracle as O
+    gen = g(m)
+    BH, iters = 3, 6
+    x = (torch.randn(1, BH, m, m, generator=gen) * 2).softmax(-1)
+    xd = x.to(DEV)
+    st = K.pinv_absmax(xd)
+    z0 = K.pinv_z0(xd, st)
+    saved = torch.zeros((iters, 4, BH, m, m), device=DEV, dtype=torch.bfloat16)
+    K.cast(z0.reshape(BH, m, m), torch.bfloat16, out=saved[0, 0])
+    zf = torch.empty((BH, m, m), device=DEV, dtype=torch.bfloat16)
+    xb = K.cast(xd, torch.bfloat16)
+    K.pinv_chain_fwd(xb, saved, zf, iters)
+    xr = x.double().requires_grad_(True)
+    ref = O.pinv_iter(xr, iters)
+    scale = float(ref.abs().max())
+    err = float((zf.float().cpu().double() - ref[0].detach()).abs().max()) / scale
+    assert err < 3e-2, f"chain fwd rel-to-max err {err}"
+    # backward: d/dX of sum(G * z_final), G random; compare direction and size with f64 autograd
+    G = torch.randn(1, BH, m, m, generator=gen).double()
+    (ref * G).sum().backward()
+    work = torch.empty_like(saved)
+    dX = torch.empty((BH, m, m), device=DEV)
+    dz0 = torch.empty((BH, m, m), device=DEV)
+    K.pinv_chain_bwd(xb, saved, K.cast(G[0].float().to(DEV), torch.bfloat16), work, dX, dz0, iters)
+    K.pinv_z0_bwd(xd.reshape(BH, m, m), z0.reshape(BH, m, m), dz0, st, dX)
+    got = dX.cpu().double()
+    want = xr.grad[0]
+    # project both through the softmax backward (the row-sum max sub-gradient is arbitrary, see test_pinv_init_and_adjoint)
+    xs = x[0].double()
+    proj = lambda gx: xs * (gx - (gx * xs).sum(-1, keepdim=True))  # noqa: E731
+    a, b = proj(got).flatten(), proj(want).flatten()
+    cos = float((a @ b) / (a.norm() * b.norm()))
+    ratio = float(a.norm() / b.norm())
+    assert cos > 0.995 and 0.97 < ratio < 1.03, (cos, ratio)
