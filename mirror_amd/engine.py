@@ -95,6 +95,11 @@ class TrainEngine:
                 self._t_max = (max(p.shape[0] for p, _ in two_d), max(p.shape[1] for p, _ in two_d))
                 self._t_params = two_d
         self.sync_shadows()
+        # gradient sink: Functions accumulate weight gradients straight into the arena (mirror_amd.functional._gbuf)
+        self._slot_of = {p.data_ptr(): i for i, p in enumerate(order)}
+        self._uses = [0] * len(order)        # sink writes per parameter per step, learnt during the first step
+        self._seen = [0] * len(order)
+        self._counting = True
         self._proto = getattr(model, "prototypes", None)
         self._logit = getattr(model, "logit_scale", None)
         if self.world > 1:
@@ -118,6 +123,19 @@ class TrainEngine:
     def _refresh_transposes(self) -> None:
         if self.shadow_t is not None:
             K.transpose_bf16_many(self.shadow, self.shadow_t, self._t_table, self._t_n, self._t_max[0], self._t_max[1])
+
+    # ------------------------------------------------------------------ gradient sink protocol
+    def slot(self, t: torch.Tensor):
+        i = self._slot_of.get(t.data_ptr())
+        return None if i is None else self.params[i].grad
+
+    def done(self, t: torch.Tensor) -> None:
+        i = self._slot_of[t.data_ptr()]
+        self._seen[i] += 1
+        if self._counting:
+            self._uses[i] += 1
+        elif self.world > 1 and self._seen[i] == self._uses[i]:
+            self._on_grad(self.params[i])
 
     # ------------------------------------------------------------------ gradient buckets (data parallel)
     def _build_buckets(self, bucket_mb: float) -> None:
@@ -166,7 +184,16 @@ class TrainEngine:
                 K.cast(w.data, bf16, out=Fn.shadow(w, POLICIES[self.precision]))
         outs = self.model(wsi, rna, wsi_mask_ratio=self.wsi_mask_ratio, rna_mask_ratio=self.rna_mask_ratio, noise=noise)
         losses = self.loss_fn(*outs)
-        losses[0].backward()
+        Fn.set_grad_sink(self)
+        try:
+            losses[0].backward()
+        finally:
+            Fn.set_grad_sink(None)
+        if self._counting:
+            # first step: sink-written parameters were only counted; their buckets are reduced below (_finish_reduce
+            # reduces every bucket that is still pending)
+            self._counting = False
+        self._seen = [0] * len(self.params)
         self._finish_reduce()
         self.step_count += 1
         b1, b2 = self.betas

@@ -95,6 +95,34 @@ def register_shadow(w: torch.Tensor, s: Optional[torch.Tensor]) -> None:
         _managed_shadows[key] = s
 
 
+# ------------------------------------------------------------------ gradient sink (TrainEngine's flat grad arena)
+# With a sink installed, weight/bias/LayerNorm gradients are accumulated straight into the arena view of the parameter
+# (no zeros() + autograd "grad += new" pass per parameter) and the Function returns None for them; the sink is told
+# when a parameter's gradient is complete so that the data-parallel bucket logic keeps working without autograd hooks.
+_sink = None
+
+
+def set_grad_sink(sink) -> None:
+    global _sink
+    _sink = sink
+
+
+def _gbuf(param: torch.Tensor, shape):
+    """(f32 buffer to ACCUMULATE into, came_from_sink)."""
+    if _sink is not None:
+        v = _sink.slot(param)
+        if v is not None:
+            return v.view(shape), True
+    return torch.zeros(shape, device=param.device, dtype=f32), False
+
+
+def _gret(param: torch.Tensor, buf: torch.Tensor, via_sink: bool):
+    if via_sink:
+        _sink.done(param)
+        return None
+    return buf
+
+
 def _split_k_for(rows: int, n: int, k: int) -> int:
     """Weight-gradient GEMMs have a huge contraction (rows) and few output tiles: split K to fill 256 CUs."""
     tiles = ((n + 127) // 128) * ((k + 127) // 128)
@@ -117,13 +145,13 @@ class LinearFn(Function):
             y = K.skinny_fwd(xa, wa, bd, act, out_dtype or prec.act)
         else:
             y = K.gemm(xa, wa.t(), bias=bd, act=act, mma=prec.mma, out_dtype=out_dtype or prec.act)
-        ctx.save_for_backward(xa, wa, y if act == ACT_RELU else None, w)
+        ctx.save_for_backward(xa, wa, y if act == ACT_RELU else None, w, b)
         ctx.act, ctx.prec, ctx.has_b, ctx.x_dtype = act, prec, b is not None, x.dtype
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        xa, wa, y, w = ctx.saved_tensors
+        xa, wa, y, w, b = ctx.saved_tensors
         prec = ctx.prec
         if ctx.act == ACT_RELU:
             dy = K.relu_bwd(y, dy if _blk_ok(dy) else dy.contiguous(), out_dtype=prec.act)
@@ -140,14 +168,16 @@ class LinearFn(Function):
             else:
                 dx = K.gemm(dy, wa, mma=prec.mma, out_dtype=ctx.x_dtype)
         if ctx.needs_input_grad[1]:
+            dw, sunk = _gbuf(w, (N, Kd))
             if ctx.skinny:
-                dw = torch.empty((N, Kd), device=dy.device, dtype=f32)
-                K.skinny_wgrad(dy, xa, dw, accumulate=False)
+                K.skinny_wgrad(dy, xa, dw, accumulate=True)
             else:
-                dw = _wgrad(dy, xa, N, Kd, prec)
+                _wgrad(dy, xa, N, Kd, prec, dw)
+            dw = _gret(w, dw, sunk)
         if ctx.has_b and ctx.needs_input_grad[2]:
-            db = torch.zeros((N,), device=dy.device, dtype=f32)
+            db, sunk = _gbuf(b, (N,))
             K.colsum(dy.reshape(-1, N), db)
+            db = _gret(b, db, sunk)
         return dx, dw, db, None, None, None
 
 
@@ -155,9 +185,10 @@ def _blk_ok(t: torch.Tensor) -> bool:
     return t.is_contiguous() or (t.dim() == 3 and t.stride(2) == 1 and t.stride(1) == t.shape[2])
 
 
-def _wgrad(dy: torch.Tensor, x: torch.Tensor, N: int, Kd: int, prec: Precision) -> torch.Tensor:
-    """dW[N, K] = sum over every row of dy^T x (f32, split-K atomics). dy contiguous; x may be a row window."""
-    dw = torch.zeros((N, Kd), device=dy.device, dtype=f32)
+def _wgrad(dy: torch.Tensor, x: torch.Tensor, N: int, Kd: int, prec: Precision, dw: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dW[N, K] += sum over every row of dy^T x (f32, split-K atomics). dy contiguous; x may be a row window."""
+    if dw is None:
+        dw = torch.zeros((N, Kd), device=dy.device, dtype=f32)
     if dy.dim() > 2 and x.is_contiguous():
         dy, x = dy.reshape(-1, N), x.reshape(-1, Kd)
     if dy.dim() == 2:
@@ -181,13 +212,13 @@ class LinearRowsFn(Function):
         wa = shadow(w, prec)
         xv = x[:, r0:r0 + R]
         y = K.gemm(xv, wa.t(), bias=None if b is None else b.detach(), mma=prec.mma, out_dtype=out_dtype or prec.act)
-        ctx.save_for_backward(x, wa)
+        ctx.save_for_backward(x, wa, w, b)
         ctx.r0, ctx.R, ctx.prec, ctx.has_b = r0, R, prec, b is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, wa = ctx.saved_tensors
+        x, wa, w, b = ctx.saved_tensors
         prec, r0, R = ctx.prec, ctx.r0, ctx.R
         if not dy.is_contiguous():
             dy = dy.contiguous()
@@ -199,10 +230,13 @@ class LinearRowsFn(Function):
             dx = torch.zeros_like(x)
             K.gemm(dy, wa, out=dx[:, r0:r0 + R], mma=prec.mma)
         if ctx.needs_input_grad[1]:
-            dw = _wgrad(dy, x[:, r0:r0 + R], N, Kd, prec)
+            dw, sunk = _gbuf(w, (N, Kd))
+            _wgrad(dy, x[:, r0:r0 + R], N, Kd, prec, dw)
+            dw = _gret(w, dw, sunk)
         if ctx.has_b and ctx.needs_input_grad[2]:
-            db = torch.zeros((N,), device=dy.device, dtype=f32)
+            db, sunk = _gbuf(b, (N,))
             K.colsum(dy.reshape(-1, N), db)
+            db = _gret(b, db, sunk)
         return dx, dw, db, None, None, None, None
 
 
@@ -222,22 +256,22 @@ class LayerNormFn(Function):
         mean = torch.empty((Bn * rows,), device=x.device, dtype=f32)
         rstd = torch.empty_like(mean)
         K.layernorm_fwd(x, gamma.detach(), beta.detach(), y[:, pad:], mean, rstd, Bn, rows, D, T * D, (pad + rows) * D, eps)
-        ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.save_for_backward(x, gamma, mean, rstd, beta)
         ctx.rows, ctx.pad = rows, pad
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, gamma, mean, rstd = ctx.saved_tensors
+        x, gamma, mean, rstd, beta = ctx.saved_tensors
         Bn, T, D = x.shape
         rows, pad = ctx.rows, ctx.pad
         if not dy.is_contiguous():
             dy = dy.contiguous()
         dx = torch.zeros_like(x) if rows < T else torch.empty_like(x)
-        dg = torch.zeros((D,), device=x.device, dtype=f32)
-        db = torch.zeros((D,), device=x.device, dtype=f32)
+        dg, sunk_g = _gbuf(gamma, (D,))
+        db, sunk_b = _gbuf(beta, (D,))
         K.layernorm_bwd(dy[:, pad:], x, gamma.detach(), mean, rstd, dx, dg, db, Bn, rows, D, T * D, (pad + rows) * D)
-        return dx, dg, db, None, None, None, None
+        return dx, _gret(gamma, dg, sunk_g), _gret(beta, db, sunk_b), None, None, None, None
 
 
 def layer_norm(x, gamma, beta, eps, *, rows=None, pad=0, out_dtype=f32):
@@ -325,13 +359,13 @@ class Fc1SeqFn(Function):
         seq = torch.empty((Bn, 1 + N + add_len, D), device=wsi.device, dtype=f32)
         K.gemm(xa, wa.t(), out=seq[:, 1:1 + N], bias=b.detach(), act=ACT_RELU, mma=prec.mma)
         K.seq_finish(seq, cls.detach().reshape(-1).contiguous(), N, add_len)
-        ctx.save_for_backward(xa, wa, seq)
+        ctx.save_for_backward(xa, wa, seq, w, b)
         ctx.add_len, ctx.prec = add_len, prec
         return seq
 
     @staticmethod
     def backward(ctx, dseq):
-        xa, wa, seq = ctx.saved_tensors
+        xa, wa, seq, w, b = ctx.saved_tensors
         prec, add_len = ctx.prec, ctx.add_len
         Bn, N, Fd = xa.shape
         D = wa.shape[0]
@@ -341,11 +375,13 @@ class Fc1SeqFn(Function):
         dcls = torch.zeros((D,), device=dseq.device, dtype=f32)
         K.seq_finish_bwd(dseq, dcls, N, add_len)
         dh = K.relu_bwd(seq[:, 1:1 + N], dseq[:, 1:1 + N], out_dtype=prec.act)   # [B,N,D] contiguous
-        dw = torch.zeros((D, Fd), device=dseq.device, dtype=f32)
+        dw, sunk_w = _gbuf(w, (D, Fd))
         K.gemm(dh.reshape(Bn * N, D).t(), xa.reshape(Bn * N, Fd), out=dw, accumulate=True,
                split_k=_split_k_for(Bn * N, D, Fd), mma=prec.mma)
-        db = torch.zeros((D,), device=dseq.device, dtype=f32)
+        dw = _gret(w, dw, sunk_w)
+        db, sunk_b = _gbuf(b, (D,))
         K.colsum(dh.reshape(Bn * N, D), db)
+        db = _gret(b, db, sunk_b)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = K.gemm(dh, wa, mma=prec.mma, out_dtype=f32)
