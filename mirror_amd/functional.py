@@ -415,6 +415,17 @@ class PPEGFn(Function):
 
 
 # ------------------------------------------------------------------ Nystrom attention core
+_side_streams: dict = {}
+
+
+def _side_stream(device) -> torch.cuda.Stream:
+    key = torch.device(device).index or 0
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 def _heads(t3: torch.Tensor, which: int, parts: int, h: int) -> torch.Tensor:
     """[B, T, parts*D] buffer -> [B, h, T, dh] view of column block `which` (heads are dh-wide column slices)."""
     Bn, T, Dt = t3.shape
@@ -478,27 +489,36 @@ class NystromCoreFn(Function):
         q, k, v = (_heads(qkv, i, 3, h) for i in range(3))
         lm = K.landmark_fwd(qkv, l)
         ql, kl = _heads(lm, 0, 2, h), _heads(lm, 1, 2, h)
-        a1 = K.gemm(q, kl.transpose(-1, -2), alpha=scale, mma=mma, out_dtype=f32)       # [B,h,n_p,m]
-        a1 = K.softmax_fwd(a1, a1 if A == f32 else None, out_dtype=A)
         a2 = K.gemm(ql, kl.transpose(-1, -2), alpha=scale, mma=mma, out_dtype=f32)      # [B,h,m,m]
         K.softmax_fwd(a2, a2)
-        a3 = K.gemm(ql, k.transpose(-1, -2), alpha=scale, mma=mma, out_dtype=f32)       # [B,h,m,n_p]
-        a3 = K.softmax_fwd(a3, a3 if A == f32 else None, out_dtype=A)
         sd = f32 if pm == MH_F32 else bf16
         m_l = a2.shape[-1]
         chain = pm == MH_BF16 and m_l in (128, 256)     # whole iteration in one launch (pinv_chain.hip)
+        side = None
         if chain:
+            # B*h workgroups of 1024 threads / 144 KiB LDS: the chain owns B*h CUs and nothing else.  At B*h = 128 that
+            # is half of the chip, so it runs on a side stream while the other half computes the two big softmax
+            # kernels (sim1, sim3) and a3 @ v on the main stream; they meet again at w2 = pinv @ (a3 v).
             st = K.pinv_absmax(a2)
             z0 = K.pinv_z0(a2, st)
             xb = K.cast(a2, bf16)
             chain_saved = torch.empty((iters, 4, Bn * h, m_l, m_l), device=qkv.device, dtype=bf16)
             K.cast(z0.reshape(Bn * h, m_l, m_l), bf16, out=chain_saved[0, 0])
             zf = torch.empty((Bn, h, m_l, m_l), device=qkv.device, dtype=bf16)
-            K.pinv_chain_fwd(xb, chain_saved, zf, iters)
+            side = _side_stream(qkv.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                K.pinv_chain_fwd(xb, chain_saved, zf, iters)
             saved = [(xb, chain_saved, z0)]
-        else:
+        a1 = K.gemm(q, kl.transpose(-1, -2), alpha=scale, mma=mma, out_dtype=f32)       # [B,h,n_p,m]
+        a1 = K.softmax_fwd(a1, a1 if A == f32 else None, out_dtype=A)
+        a3 = K.gemm(ql, k.transpose(-1, -2), alpha=scale, mma=mma, out_dtype=f32)       # [B,h,m,n_p]
+        a3 = K.softmax_fwd(a3, a3 if A == f32 else None, out_dtype=A)
+        if not chain:
             zf, saved, st = pinv_forward(a2, iters, pm, sd)
         av = K.gemm(a3, v, mma=mma, out_dtype=f32)                                       # [B,h,m,dh]
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
         # GEMMs that meet activation-dtype tensors cannot use the exact-f32 MFMA unless the activations are f32 too
         pio = pm if (pm == MH_BF16 or A == f32) else mma
         w2 = K.gemm(zf, av, mma=pio, out_dtype=A)
@@ -534,38 +554,45 @@ class NystromCoreFn(Function):
         rw = res_w.detach().contiguous()
         dres = torch.zeros((rw.numel(),), device=qkv.device, dtype=f32)
         K.resconv_wgrad(qkv[..., 2 * D:], dout, dres, h)
-        # out = a1 @ w2
-        dS1 = K.gemm(dO, tr(w2), mma=mma, out_dtype=A)                                   # [B,h,n_p,m]
+        # out = a1 @ w2 ; w2 = Z @ av ; av = a3 @ v.  dZ first: it is all the pinv backward needs.
         dW2 = K.gemm(tr(a1), dO, mma=mma, out_dtype=f32)                                 # [B,h,m,dh]
-        K.softmax_bwd(a1, dS1)
-        # w2 = Z @ av ; av = a3 @ v
         sd = f32 if pm == MH_F32 else bf16
         dZ = K.gemm(dW2, tr(av), mma=pm, out_dtype=f32)                                  # [B,h,m,m]
         pio = pm if (pm == MH_BF16 or A == f32) else mma
-        dAV = K.gemm(tr(zf), dW2, mma=pio, out_dtype=A)                                  # [B,h,m,dh]
-        dS3 = K.gemm(dAV, tr(v), mma=mma, out_dtype=A)                                   # [B,h,m,n_p]
-        K.gemm(tr(a3), dAV, out=dv, mma=mma)
-        K.resconv(dout, rw, dqkv[..., 2 * D:], h, transpose=True, accumulate=True)
-        K.softmax_bwd(a3, dS3)
+        side = None
         if chain:
             xb, chain_saved, z0 = flat
             work = torch.empty_like(chain_saved)
             dS2 = torch.empty_like(a2)
             dz0 = torch.empty_like(a2)
-            K.pinv_chain_bwd(xb, chain_saved, K.cast(dZ, bf16), work, dS2, dz0, iters)
-            K.pinv_z0_bwd(a2, z0, dz0, st, dS2)
-            del work
-        else:
-            dS2 = pinv_backward(a2, saved, st, dZ, pm, sd)
-        K.softmax_bwd(a2, dS2)
+            dzb = K.cast(dZ, bf16)
+            side = _side_stream(qkv.device)      # half-chip chain again, beside the softmax backward / dq / dk work
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                K.pinv_chain_bwd(xb, chain_saved, dzb, work, dS2, dz0, iters)
+                K.pinv_z0_bwd(a2, z0, dz0, st, dS2)
+                K.softmax_bwd(a2, dS2)
+        dS1 = K.gemm(dO, tr(w2), mma=mma, out_dtype=A)                                   # [B,h,n_p,m]
+        K.softmax_bwd(a1, dS1)
+        dAV = K.gemm(tr(zf), dW2, mma=pio, out_dtype=A)                                  # [B,h,m,dh]
+        dS3 = K.gemm(dAV, tr(v), mma=mma, out_dtype=A)                                   # [B,h,m,n_p]
+        K.gemm(tr(a3), dAV, out=dv, mma=mma)
+        K.resconv(dout, rw, dqkv[..., 2 * D:], h, transpose=True, accumulate=True)
+        K.softmax_bwd(a3, dS3)
         # similarities: s1 = scale q kl^T, s2 = scale ql kl^T, s3 = scale ql k^T
         K.gemm(dS1, kl, out=dq, alpha=scale, mma=mma)
         K.gemm(tr(dS3), ql, out=dk, alpha=scale, mma=mma)
         dlm = torch.empty((Bn, m, 2 * D), device=qkv.device, dtype=f32)
         dql, dkl = _heads(dlm, 0, 2, h), _heads(dlm, 1, 2, h)
         K.gemm(tr(dS1), q, out=dkl, alpha=scale, mma=mma)
-        K.gemm(tr(dS2), ql, out=dkl, alpha=scale, accumulate=True, mma=pio)
         K.gemm(dS3, k, out=dql, alpha=scale, mma=mma)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+            del work
+        else:
+            dS2 = pinv_backward(a2, saved, st, dZ, pm, sd)
+            K.softmax_bwd(a2, dS2)
+        K.gemm(tr(dS2), ql, out=dkl, alpha=scale, accumulate=True, mma=pio)
         K.gemm(dS2, kl, out=dql, alpha=scale, accumulate=True, mma=pio)
         K.landmark_bwd(K.cast(dlm, A), dqkv, l)
         return dqkv, dres.view_as(res_w), None, None, None, None
