@@ -125,8 +125,7 @@ template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, f4 v) {
 }
 
 // Vectorised LayerNorm (D % 4 == 0): lane owns elements [256k + 4*lane, +4), k < LNV_CH (D <= 2048).
-#define LNV_CH 8
-template <typename TX, typename TY>
+template <typename TX, typename TY, int LNV_CH>
 __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const TX* __restrict__ x, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, TY* __restrict__ y,
                                                                 float* __restrict__ mean, float* __restrict__ rstd,
@@ -170,7 +169,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const TX* __rest
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
-template <typename TX, typename TDY>
+template <typename TX, typename TDY, int LNV_CH>
 __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x,
                                                                 const float* __restrict__ gamma, const float* __restrict__ mean,
                                                                 const float* __restrict__ rstd, TX* __restrict__ dx,
@@ -252,7 +251,8 @@ extern "C" int mh_layernorm_fwd(const void* x, const float* gamma, const float* 
     dim3 grid(mh_cdiv(rows, 4));
     const bool vecok = D % 4 == 0 && x_bs % 4 == 0 && y_bs % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
                        ((uintptr_t)gamma & 15) == 0 && ((uintptr_t)beta & 15) == 0;
-#define LN_FV(TX, TY) hipLaunchKernelGGL((layernorm_fwd_vec_kernel<TX, TY>), grid, dim3(256), 0, (hipStream_t)s, (const TX*)x, gamma, beta, (TY*)y, mean, rstd, rows, rpb, D, (long)x_bs, (long)y_bs, eps)
+#define LN_FV1(TX, TY, NC) hipLaunchKernelGGL((layernorm_fwd_vec_kernel<TX, TY, NC>), grid, dim3(256), 0, (hipStream_t)s, (const TX*)x, gamma, beta, (TY*)y, mean, rstd, rows, rpb, D, (long)x_bs, (long)y_bs, eps)
+#define LN_FV(TX, TY) do { if (D <= 512) LN_FV1(TX, TY, 2); else if (D <= 1024) LN_FV1(TX, TY, 4); else LN_FV1(TX, TY, 8); } while (0)
     if (vecok) {
         if (dt_x == MH_F32 && dt_y == MH_F32) LN_FV(float, float);
         else if (dt_x == MH_F32 && dt_y == MH_BF16) LN_FV(float, bf16_t);
@@ -262,6 +262,7 @@ extern "C" int mh_layernorm_fwd(const void* x, const float* gamma, const float* 
         return MH_OK;
     }
 #undef LN_FV
+#undef LN_FV1
 #define LN_F(TX, TY) hipLaunchKernelGGL((layernorm_fwd_kernel<TX, TY>), grid, dim3(256), 0, (hipStream_t)s, (const TX*)x, gamma, beta, (TY*)y, mean, rstd, rows, rpb, D, (long)x_bs, (long)y_bs, eps)
     if (dt_x == MH_F32 && dt_y == MH_F32) LN_F(float, float);
     else if (dt_x == MH_F32 && dt_y == MH_BF16) LN_F(float, bf16_t);
@@ -282,7 +283,8 @@ extern "C" int mh_layernorm_bwd(const void* dy, const void* x, const float* gamm
     dim3 grid((unsigned)min((long)mh_cdiv(rows, 4), 2048L));
     const bool vecok = D % 4 == 0 && x_bs % 4 == 0 && y_bs % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0 &&
                        ((uintptr_t)dx & 15) == 0 && ((uintptr_t)gamma & 15) == 0;
-#define LN_BV(TX, TDY) hipLaunchKernelGGL((layernorm_bwd_vec_kernel<TX, TDY>), grid, dim3(256), 0, (hipStream_t)s, (const TDY*)dy, (const TX*)x, gamma, mean, rstd, (TX*)dx, dgamma, dbeta, rows, rpb, D, (long)x_bs, (long)y_bs, acc_dx)
+#define LN_BV1(TX, TDY, NC) hipLaunchKernelGGL((layernorm_bwd_vec_kernel<TX, TDY, NC>), grid, dim3(256), 0, (hipStream_t)s, (const TDY*)dy, (const TX*)x, gamma, mean, rstd, (TX*)dx, dgamma, dbeta, rows, rpb, D, (long)x_bs, (long)y_bs, acc_dx)
+#define LN_BV(TX, TDY) do { if (D <= 512) LN_BV1(TX, TDY, 2); else if (D <= 1024) LN_BV1(TX, TDY, 4); else LN_BV1(TX, TDY, 8); } while (0)
     if (vecok) {
         if (dt_x == MH_F32 && dt_dy == MH_F32) LN_BV(float, float);
         else if (dt_x == MH_F32 && dt_dy == MH_BF16) LN_BV(float, bf16_t);
@@ -292,6 +294,7 @@ extern "C" int mh_layernorm_bwd(const void* dy, const void* x, const float* gamm
         return MH_OK;
     }
 #undef LN_BV
+#undef LN_BV1
 #define LN_B(TX, TDY) hipLaunchKernelGGL((layernorm_bwd_kernel<TX, TDY, TX>), grid, dim3(256), 0, (hipStream_t)s, (const TDY*)dy, (const TX*)x, gamma, mean, rstd, (TX*)dx, dgamma, dbeta, rows, rpb, D, (long)x_bs, (long)y_bs, acc_dx)
     if (dt_x == MH_F32 && dt_dy == MH_F32) LN_B(float, float);
     else if (dt_x == MH_F32 && dt_dy == MH_BF16) LN_B(float, bf16_t);

@@ -40,6 +40,11 @@ __global__ __launch_bounds__(256) void landmark_bwd_kernel(const T* __restrict__
     }
 }
 
+// 8 columns per thread (16-B bf16 / 2 x 16-B f32 accesses); needs D % 4 == 0 and 16-B aligned rows
+template <typename T>
+__global__ __launch_bounds__(256) void landmark_bwd_vec_kernel(const T* __restrict__ dlm, T* __restrict__ dqkv, int B, int n_p,
+                                                               int D, int l);
+
 extern "C" int mh_landmark_fwd(const void* qkv, void* lm, int B, int n_p, int D, int l, int dt, mh_stream s) {
     MH_REQUIRE(l >= 1 && n_p % l == 0, "mh_landmark_fwd: n_p=%d not a multiple of l=%d", n_p, l);
     const long total = (long)B * (n_p / l) * 2 * D;
@@ -54,6 +59,12 @@ extern "C" int mh_landmark_bwd(const void* dlm, void* dqkv, int B, int n_p, int 
     MH_REQUIRE(l >= 1 && n_p % l == 0, "mh_landmark_bwd: n_p=%d not a multiple of l=%d", n_p, l);
     const long total = (long)B * n_p * 2 * D;
     if (total == 0) return MH_OK;
+    if (D % 8 == 0 && ((uintptr_t)dlm & 15) == 0 && ((uintptr_t)dqkv & 15) == 0) {
+        dim3 vgrid((unsigned)min((long)mh_cdiv(total / 8, 256), 8192L));
+        MH_DISPATCH_DT(dt, T, hipLaunchKernelGGL((landmark_bwd_vec_kernel<T>), vgrid, dim3(256), 0, (hipStream_t)s, (const T*)dlm, (T*)dqkv, B, n_p, D, l));
+        MH_LAUNCH_CHECK("mh_landmark_bwd");
+        return MH_OK;
+    }
     dim3 grid((unsigned)min((long)mh_cdiv(total, 256), 8192L));
     MH_DISPATCH_DT(dt, T, hipLaunchKernelGGL((landmark_bwd_kernel<T>), grid, dim3(256), 0, (hipStream_t)s, (const T*)dlm, (T*)dqkv, B, n_p, D, l));
     MH_LAUNCH_CHECK("mh_landmark_bwd");
@@ -134,6 +145,28 @@ template <> __device__ __forceinline__ void st8<bf16_t>(bf16_t* p, const float (
 #pragma unroll
     for (int e = 0; e < 4; e++) r[e] = (unsigned)f2bf(v[2 * e]) | ((unsigned)f2bf(v[2 * e + 1]) << 16);
     *reinterpret_cast<ru4*>(p) = r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void landmark_bwd_vec_kernel(const T* __restrict__ dlm, T* __restrict__ dqkv, int B, int n_p,
+                                                               int D, int l) {
+    const int m = n_p / l;
+    const int cpr = 2 * D / 8;                       // 8-column chunks per row (q and k blocks)
+    const long total = (long)B * n_p * cpr;
+    const float inv = 1.f / l;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (idx % cpr) * 8;
+        const long br = idx / cpr;
+        const int r = br % n_p;
+        const long b = br / n_p;
+        T* dst = dqkv + (b * n_p + r) * 3 * D + c;
+        float a[8], g[8];
+        ld8(dst, a);
+        ld8(dlm + (b * m + r / l) * 2 * D + c, g);
+#pragma unroll
+        for (int e = 0; e < 8; e++) a[e] += g[e] * inv;
+        st8(dst, a);
+    }
 }
 
 template <typename TV, typename TO>
@@ -231,7 +264,7 @@ extern "C" int mh_resconv_fwd(const void* v, int64_t ldv, int64_t v_bs, const fl
 template <typename TV, typename TO>
 __global__ __launch_bounds__(256) void resconv_wgrad_kernel(const TV* __restrict__ v, long ldv, long v_bs,
                                                             const TO* __restrict__ dout, long ldo, long o_bs,
-                                                            float* __restrict__ dw, int n_p, int dh, int taps) {
+                                                            float* __restrict__ dw, int n_p, int dh, int taps, int vec8) {
     __shared__ __attribute__((aligned(16))) float vs[(RW_ROWS + RC_MAXTAPS) * RW_PITCH];
     __shared__ __attribute__((aligned(16))) float ds[RW_ROWS * RW_PITCH];
     const int h = blockIdx.x, t0 = blockIdx.y * RW_ROWS, b = blockIdx.z;
@@ -242,15 +275,34 @@ __global__ __launch_bounds__(256) void resconv_wgrad_kernel(const TV* __restrict
     for (int d0 = 0; d0 < dh; d0 += 64) {
         const int dwd = min(64, dh - d0);
         __syncthreads();
-        for (int i = tid; i < (RW_ROWS + taps - 1) * 64; i += 256) {
-            const int rr = i >> 6, dd = i & 63;
-            const int t = t0 - half + rr;
-            vs[rr * RW_PITCH + dd] = (dd < dwd && t >= 0 && t < n_p) ? ldf(v + (long)b * v_bs + (long)t * ldv + h * dh + d0 + dd) : 0.f;
-        }
-        for (int i = tid; i < RW_ROWS * 64; i += 256) {
-            const int rr = i >> 6, dd = i & 63;
-            const int t = t0 + rr;
-            ds[rr * RW_PITCH + dd] = (dd < dwd && t < n_p) ? ldf(dout + (long)b * o_bs + (long)t * ldo + h * dh + d0 + dd) : 0.f;
+        if (vec8) {
+            for (int i = tid; i < (RW_ROWS + taps - 1) * 8; i += 256) {
+                const int rr = i >> 3, dd = (i & 7) * 8;
+                const int t = t0 - half + rr;
+                float x8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (dd < dwd && t >= 0 && t < n_p) ld8(v + (long)b * v_bs + (long)t * ldv + h * dh + d0 + dd, x8);
+#pragma unroll
+                for (int e = 0; e < 8; e++) vs[rr * RW_PITCH + dd + e] = x8[e];
+            }
+            for (int i = tid; i < RW_ROWS * 8; i += 256) {
+                const int rr = i >> 3, dd = (i & 7) * 8;
+                const int t = t0 + rr;
+                float x8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (dd < dwd && t < n_p) ld8(dout + (long)b * o_bs + (long)t * ldo + h * dh + d0 + dd, x8);
+#pragma unroll
+                for (int e = 0; e < 8; e++) ds[rr * RW_PITCH + dd + e] = x8[e];
+            }
+        } else {
+            for (int i = tid; i < (RW_ROWS + taps - 1) * 64; i += 256) {
+                const int rr = i >> 6, dd = i & 63;
+                const int t = t0 - half + rr;
+                vs[rr * RW_PITCH + dd] = (dd < dwd && t >= 0 && t < n_p) ? ldf(v + (long)b * v_bs + (long)t * ldv + h * dh + d0 + dd) : 0.f;
+            }
+            for (int i = tid; i < RW_ROWS * 64; i += 256) {
+                const int rr = i >> 6, dd = i & 63;
+                const int t = t0 + rr;
+                ds[rr * RW_PITCH + dd] = (dd < dwd && t < n_p) ? ldf(dout + (long)b * o_bs + (long)t * ldo + h * dh + d0 + dd) : 0.f;
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -286,7 +338,8 @@ extern "C" int mh_resconv_wgrad(const void* v, int64_t ldv, int64_t v_bs, const 
     MH_REQUIRE(taps >= 1 && taps <= 63 && (taps & 1), "mh_resconv_wgrad: taps=%d unsupported", taps);
     if (B == 0 || n_p == 0) return MH_OK;
     dim3 grid(heads, mh_cdiv(n_p, RW_ROWS), B);
-#define RW(TV, TO) hipLaunchKernelGGL((resconv_wgrad_kernel<TV, TO>), grid, dim3(256), 0, (hipStream_t)s, (const TV*)v, (long)ldv, (long)v_bs, (const TO*)dout, (long)ldo, (long)o_bs, dw, n_p, dh, taps)
+#define RW(TV, TO) hipLaunchKernelGGL((resconv_wgrad_kernel<TV, TO>), grid, dim3(256), 0, (hipStream_t)s, (const TV*)v, (long)ldv, (long)v_bs, (const TO*)dout, (long)ldo, (long)o_bs, dw, n_p, dh, taps, vec8)
+    const int vec8 = dh % 8 == 0 && ldv % 8 == 0 && v_bs % 8 == 0 && ldo % 8 == 0 && o_bs % 8 == 0 && ((uintptr_t)v & 15) == 0 && ((uintptr_t)dout & 15) == 0;
     if (dt_v == MH_F32 && dt_o == MH_F32) RW(float, float);
     else if (dt_v == MH_BF16 && dt_o == MH_BF16) RW(bf16_t, bf16_t);
     else if (dt_v == MH_BF16 && dt_o == MH_F32) RW(bf16_t, float);

@@ -140,8 +140,14 @@ def gemm_variant(d: GemmDesc) -> str:
     def ok(ptr, ld, s1, s2):
         return ptr % 16 == 0 and ld % vec == 0 and s1 % vec == 0 and s2 % vec == 0
 
-    full = (ok(d.A, d.lda, d.sA1, d.sA2) and ok(d.B, d.ldb, d.sB1, d.sB2) and d.M % 128 == 0
-            and d.N % (64 * wn) == 0 and d.K % bk == 0 and d.K % kps == 0)
+    vb = 4 if d.dtB == MH_F32 else 8
+    kk = d.K
+    if d.K % bk and d.K >= 8 * bk and d.dtC == MH_F32 and d.act == 0:
+        kk = d.K - d.K % bk            # the ragged tail runs as a second, tiny launch
+        kps = -(-(-(-kk // split)) // bk) * bk
+    okb = d.B % 16 == 0 and d.ldb % vb == 0 and d.sB1 % vb == 0 and d.sB2 % vb == 0
+    full = (ok(d.A, d.lda, d.sA1, d.sA2) and okb and (d.a_kc or d.M % 128 == 0)
+            and d.N % (64 * wn) == 0 and kk % bk == 0 and kk % kps == 0)
     return (f"gemm_kernel<{d.mma},{_TN[d.dtA]},{_TN[d.dtB]},{tc},{'true' if d.a_kc else 'false'},"
             f"{'true' if d.b_kc else 'false'},2,{wn},{'true' if full else 'false'}>")
 
@@ -155,15 +161,17 @@ class GemmProfiler:
         self.records = []   # (variant, flops, start_event, end_event)
 
     def launch(self, d: GemmDesc, fn) -> None:
-        v = gemm_variant(d)
+        self.launch_named(gemm_variant(d), 2.0 * d.M * d.N * d.K * d.batch1 * d.batch2, fn)
+
+    def launch_named(self, v: str, flops: float, fn) -> None:
         if self.only is not None and v != self.only:
             fn()
             return
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        e0.record()          # recorded on the stream the kernel is launched on (torch's current stream)
         fn()
         e1.record()
-        self.records.append((v, 2.0 * d.M * d.N * d.K * d.batch1 * d.batch2, e0, e1))
+        self.records.append((v, flops, e0, e1))
 
     def summary(self):
         """variant -> dict(launches, total_ms, flops); call after a device synchronise."""
@@ -347,7 +355,11 @@ def pinv_chain_fwd(Xb: torch.Tensor, saved: torch.Tensor, zf: torch.Tensor, iter
     if not (Xb.dtype == bf and saved.dtype == bf and zf.dtype == bf and Xb.is_contiguous() and saved.is_contiguous()
             and zf.is_contiguous() and saved.numel() == iters * 4 * BH * m * m and zf.numel() == BH * m * m):
         raise MirrorHipError("pinv_chain_fwd: bad operands")
-    _lib.call("mh_pinv_chain_fwd", _p(Xb), _p(saved), _p(zf), BH, m, iters, stream=_stream())
+    fn = lambda: _lib.call("mh_pinv_chain_fwd", _p(Xb), _p(saved), _p(zf), BH, m, iters, stream=_stream())  # noqa: E731
+    if gemm_profiler is None:
+        fn()
+    else:
+        gemm_profiler.launch_named(f"pinv_chain_fwd_kernel<{m}>", iters * 4 * 2.0 * m ** 3 * BH, fn)
 
 
 def pinv_chain_bwd(Xb, saved, dzf, work, dX, dz0, iters: int) -> None:
@@ -359,7 +371,12 @@ def pinv_chain_bwd(Xb, saved, dzf, work, dX, dz0, iters: int) -> None:
             and all(t.dtype == torch.float32 and t.is_contiguous() and t.numel() == BH * m * m for t in (dX, dz0))
             and saved.numel() == iters * 4 * BH * m * m and work.numel() == saved.numel() and dzf.numel() == BH * m * m):
         raise MirrorHipError("pinv_chain_bwd: bad operands")
-    _lib.call("mh_pinv_chain_bwd", _p(Xb), _p(saved), _p(dzf), _p(work), _p(dX), _p(dz0), BH, m, iters, stream=_stream())
+    fn = lambda: _lib.call("mh_pinv_chain_bwd", _p(Xb), _p(saved), _p(dzf), _p(work), _p(dX), _p(dz0), BH, m, iters,  # noqa: E731
+                           stream=_stream())
+    if gemm_profiler is None:
+        fn()
+    else:
+        gemm_profiler.launch_named(f"pinv_chain_bwd_kernel<{m}>", iters * 8 * 2.0 * m ** 3 * BH, fn)
 
 
 def eye_minus(P: torch.Tensor, d: float) -> torch.Tensor:
