@@ -418,8 +418,9 @@ class PPEGFn(Function):
 _side_streams: dict = {}
 
 
-def _side_stream(device) -> torch.cuda.Stream:
-    key = torch.device(device).index or 0
+def _side_stream(device, which: int = 0) -> torch.cuda.Stream:
+    """Per-device helper streams: 0 = half-chip pinv chain, 1 = RNA encoder."""
+    key = (torch.device(device).index or 0, which)
     st = _side_streams.get(key)
     if st is None:
         st = _side_streams[key] = torch.cuda.Stream(device=device)

@@ -445,15 +445,37 @@ class MIRROR(nn.Module):
 
     def forward(self, wsi_emb, rna_emb, wsi_mask_ratio: float = 0.75, rna_mask_ratio: float = 0.75,
                 noise: Optional[Dict[str, torch.Tensor]] = None):
-        noise = noise or {}
-        # the reference draws: rand(B,N) -> rand(B,D) -> eps_wsi -> eps_rna (models/mirror.py:630, :516, :832-833)
+        noise = dict(noise or {})
+        if not wsi_emb.is_cuda:
+            raise MirrorHipError("mirror_amd models run on MI355X only (no CPU fallback): move the inputs to the GPU")
+        # the reference draws: rand(B,N) -> rand(B,D) -> eps_wsi -> eps_rna (models/mirror.py:630, :516, :832-833);
+        # draw them up front in that order so the two encoders can then run on different streams
+        B, dev = wsi_emb.shape[0], wsi_emb.device
+        if "wsi_mask" not in noise:
+            noise["wsi_mask"] = torch.rand(B, wsi_emb.shape[1], device=dev)
+        if "rna_mask" not in noise:
+            noise["rna_mask"] = torch.rand(B, self.embed_dim, device=dev)
+        if "wsi_eps" not in noise:
+            noise["wsi_eps"] = torch.randn(B, self.style_latent_dim, device=dev)
+        if "rna_eps" not in noise:
+            noise["rna_eps"] = torch.randn(B, self.style_latent_dim, device=dev)
+        # The RNA encoder is ~100 launch-bound [B, D] kernels (0.06 % of the FLOPs): it runs on a side stream
+        # underneath the WSI encoder; autograd replays each backward node on its forward stream, so the RNA
+        # backward overlaps the WSI backward as well.
+        main = torch.cuda.current_stream()
+        side = Fn._side_stream(dev, 1)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            rna_emb = self.rna_encoder.forward_encoder(rna_emb)
+            rna_alignment_emb, rna_retention_emb, rna_mask = self.rna_encoder.forward_decoders(
+                rna_emb, mask_ratio=rna_mask_ratio, noise=noise.get("rna_mask"))
         wsi_emb = self.wsi_encoder.forward_encoder(wsi_emb)
         wsi_alignment_emb, wsi_retention_emb, wsi_mask = self.wsi_encoder.forward_decoders(
             wsi_emb, mask_ratio=wsi_mask_ratio, noise=noise.get("wsi_mask"))
         wsi_retention_target = wsi_emb[:, 1:, :]
-        rna_emb = self.rna_encoder.forward_encoder(rna_emb)
-        rna_alignment_emb, rna_retention_emb, rna_mask = self.rna_encoder.forward_decoders(
-            rna_emb, mask_ratio=rna_mask_ratio, noise=noise.get("rna_mask"))
+        main.wait_stream(side)
+        for t in (rna_emb, rna_alignment_emb, rna_retention_emb, rna_mask):
+            t.record_stream(main)       # allocated in the side stream's pool, consumed on the main stream
         rna_retention_target = rna_emb
         wsi_score, wsi_mu, wsi_logstd, rna_score, rna_mu, rna_logstd = self.forward_style_clustering(
             wsi_emb[:, 0, :], rna_emb, noise.get("wsi_eps"), noise.get("rna_eps"))
