@@ -126,6 +126,25 @@ int mh_pinv_z0_bwd(const float* x, const float* z0, const float* dz0, const uint
 int mh_pinv_chain_fwd(const void* X, void* saved, void* zf, int BH, int m, int iters, mh_stream s);
 int mh_pinv_chain_bwd(const void* X, const void* saved, const void* dzf, void* work, float* dX, float* dz0, int BH, int m,
                       int iters, mh_stream s);
+/* Fused attention sides of the Nystrom core (bf16 policy, dh = 64, m = 256 landmarks; anything else returns
+ * MH_EINVAL and the caller composes mh_gemm + mh_softmax).  The [n_p x m] / [m x n_p] similarity matrices stay in MFMA
+ * accumulators; only row statistics reach HBM.  Replaces, in [3P] NystromAttention.forward (called at
+ * models/mirror.py:312): sim1/sim3 einsum + softmax + the two products with them, and their autograd.
+ *   qkv [B,n_p,3D] bf16 (D = 64 h, heads are 64-wide column slices), lm [B,m,2D] bf16 = q_l | k_l,
+ *   w2 [B,h,m,64] bf16, out/dout [B,n_p,D] bf16, av [B,h,m,64] f32, dav [B,h,m,64] bf16,
+ *   lse1/delta1 [B,h,n_p] f32, lse3 [B,h,m] f32, dqkv like qkv, dw2 [B,h,m,64] f32, dlm [B,m,2D] f32.
+ * attn1_fwd: out[:, :, head] = softmax_m(scale q k_l^T) w2 (overwrites), lse1 = row logsumexp.
+ * attn3_fwd: av = softmax_n(scale q_l k^T) v, lse3.
+ * attn1_bwd: writes the q block of dqkv and delta1; ADDS (f32 atomics) into dw2 and the k_l half of dlm.
+ * attn3_bwd: writes the k and v blocks of dqkv; ADDS into the q_l half of dlm. */
+int mh_nys_attn1_fwd(const void* qkv, const void* lm, const void* w2, void* out, float* lse1, int B, int h, int n_p, int m,
+                     int dh, float scale, mh_stream s);
+int mh_nys_attn3_fwd(const void* qkv, const void* lm, float* av, float* lse3, int B, int h, int n_p, int m, int dh, float scale,
+                     mh_stream s);
+int mh_nys_attn1_bwd(const void* qkv, const void* lm, const void* w2, const void* dout, const float* lse1, float* delta1,
+                     void* dqkv, float* dw2, float* dlm, int B, int h, int n_p, int m, int dh, float scale, mh_stream s);
+int mh_nys_attn3_bwd(const void* qkv, const void* lm, const float* av, const void* dav, const float* lse3, void* dqkv,
+                     float* dlm, int B, int h, int n_p, int m, int dh, float scale, mh_stream s);
 /* T = d*I - P  (batched [BH,m,m] f32) */
 int mh_eye_minus(const float* P, float* T, float d, int BH, int m, mh_stream s);
 

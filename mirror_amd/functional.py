@@ -511,30 +511,40 @@ class NystromCoreFn(Function):
             with torch.cuda.stream(side):
                 K.pinv_chain_fwd(xb, chain_saved, zf, iters)
             saved = [(xb, chain_saved, z0)]
-        a1 = K.gemm(q, kl.transpose(-1, -2), alpha=scale, mma=mma, out_dtype=f32)       # [B,h,n_p,m]
-        a1 = K.softmax_fwd(a1, a1 if A == f32 else None, out_dtype=A)
-        a3 = K.gemm(ql, k.transpose(-1, -2), alpha=scale, mma=mma, out_dtype=f32)       # [B,h,m,n_p]
-        a3 = K.softmax_fwd(a3, a3 if A == f32 else None, out_dtype=A)
+        fused = K.nys_fused_ok(qkv, h, m_l) and lm.dtype == bf16      # nystrom_fused.hip: sim1 / sim3 never reach HBM
+        lse1 = lse3 = a1 = a3 = None
+        if fused:
+            av, lse3 = K.nys_attn3_fwd(qkv, lm, h, scale)                                # [B,h,m,dh] f32
+        else:
+            a1 = K.gemm(q, kl.transpose(-1, -2), alpha=scale, mma=mma, out_dtype=f32)   # [B,h,n_p,m]
+            a1 = K.softmax_fwd(a1, a1 if A == f32 else None, out_dtype=A)
+            a3 = K.gemm(ql, k.transpose(-1, -2), alpha=scale, mma=mma, out_dtype=f32)   # [B,h,m,n_p]
+            a3 = K.softmax_fwd(a3, a3 if A == f32 else None, out_dtype=A)
         if not chain:
             zf, saved, st = pinv_forward(a2, iters, pm, sd)
-        av = K.gemm(a3, v, mma=mma, out_dtype=f32)                                       # [B,h,m,dh]
+        if not fused:
+            av = K.gemm(a3, v, mma=mma, out_dtype=f32)                                   # [B,h,m,dh]
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
         # GEMMs that meet activation-dtype tensors cannot use the exact-f32 MFMA unless the activations are f32 too
         pio = pm if (pm == MH_BF16 or A == f32) else mma
         w2 = K.gemm(zf, av, mma=pio, out_dtype=A)
         out = torch.empty((Bn, n_p, D), device=qkv.device, dtype=A)
-        K.gemm(a1, w2, out=_heads(out, 0, 1, h), mma=mma)
+        if fused:
+            lse1 = K.nys_attn1_fwd(qkv, lm, w2, out, h, scale)
+        else:
+            K.gemm(a1, w2, out=_heads(out, 0, 1, h), mma=mma)
         K.resconv(qkv[..., 2 * D:], res_w.detach().contiguous(), out, h, transpose=False, accumulate=True)
-        ctx.save_for_backward(qkv, res_w, lm, a1, a2, a3, av, w2, st, zf, *[t for it in saved for t in it])
+        stats = (lse1, lse3) if fused else (a1, a3)
+        ctx.save_for_backward(qkv, res_w, lm, stats[0], a2, stats[1], av, w2, st, zf, *[t for it in saved for t in it])
         ctx.cfg = (heads, l, prec)
-        ctx.chain = (chain, iters)
+        ctx.chain = (chain, iters, fused)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         qkv, res_w, lm, a1, a2, a3, av, w2, st, zf, *flat = ctx.saved_tensors
-        chain, iters = ctx.chain
+        chain, iters, fused = ctx.chain
         saved = None if chain else [tuple(flat[i:i + 4]) for i in range(0, len(flat), 4)]
         heads, l, prec = ctx.cfg
         A, mma, pm = prec.act, prec.mma, prec.pinv_mma
@@ -556,7 +566,15 @@ class NystromCoreFn(Function):
         dres = torch.zeros((rw.numel(),), device=qkv.device, dtype=f32)
         K.resconv_wgrad(qkv[..., 2 * D:], dout, dres, h)
         # out = a1 @ w2 ; w2 = Z @ av ; av = a3 @ v.  dZ first: it is all the pinv backward needs.
-        dW2 = K.gemm(tr(a1), dO, mma=mma, out_dtype=f32)                                 # [B,h,m,dh]
+        if fused:
+            lse1, lse3 = a1, a3
+            dW2 = torch.zeros((Bn, h, m, dh), device=qkv.device, dtype=f32)
+            dlm = torch.zeros((Bn, m, 2 * D), device=qkv.device, dtype=f32)
+            K.nys_attn1_bwd(qkv, lm, w2, dout, lse1, dqkv, dW2, dlm, h, scale)          # dq, dW2, dk_l
+        else:
+            dW2 = K.gemm(tr(a1), dO, mma=mma, out_dtype=f32)                             # [B,h,m,dh]
+            dlm = torch.empty((Bn, m, 2 * D), device=qkv.device, dtype=f32)
+        dql, dkl = _heads(dlm, 0, 2, h), _heads(dlm, 1, 2, h)
         sd = f32 if pm == MH_F32 else bf16
         dZ = K.gemm(dW2, tr(av), mma=pm, out_dtype=f32)                                  # [B,h,m,m]
         pio = pm if (pm == MH_BF16 or A == f32) else mma
@@ -573,20 +591,22 @@ class NystromCoreFn(Function):
                 K.pinv_chain_bwd(xb, chain_saved, dzb, work, dS2, dz0, iters)
                 K.pinv_z0_bwd(a2, z0, dz0, st, dS2)
                 K.softmax_bwd(a2, dS2)
-        dS1 = K.gemm(dO, tr(w2), mma=mma, out_dtype=A)                                   # [B,h,n_p,m]
-        K.softmax_bwd(a1, dS1)
         dAV = K.gemm(tr(zf), dW2, mma=pio, out_dtype=A)                                  # [B,h,m,dh]
-        dS3 = K.gemm(dAV, tr(v), mma=mma, out_dtype=A)                                   # [B,h,m,n_p]
-        K.gemm(tr(a3), dAV, out=dv, mma=mma)
-        K.resconv(dout, rw, dqkv[..., 2 * D:], h, transpose=True, accumulate=True)
-        K.softmax_bwd(a3, dS3)
-        # similarities: s1 = scale q kl^T, s2 = scale ql kl^T, s3 = scale ql k^T
-        K.gemm(dS1, kl, out=dq, alpha=scale, mma=mma)
-        K.gemm(tr(dS3), ql, out=dk, alpha=scale, mma=mma)
-        dlm = torch.empty((Bn, m, 2 * D), device=qkv.device, dtype=f32)
-        dql, dkl = _heads(dlm, 0, 2, h), _heads(dlm, 1, 2, h)
-        K.gemm(tr(dS1), q, out=dkl, alpha=scale, mma=mma)
-        K.gemm(dS3, k, out=dql, alpha=scale, mma=mma)
+        if fused:
+            K.nys_attn3_bwd(qkv, lm, av, dAV, lse3, dqkv, dlm, h, scale)                # dk, dv, dq_l
+            K.resconv(dout, rw, dqkv[..., 2 * D:], h, transpose=True, accumulate=True)
+        else:
+            dS1 = K.gemm(dO, tr(w2), mma=mma, out_dtype=A)                               # [B,h,n_p,m]
+            K.softmax_bwd(a1, dS1)
+            dS3 = K.gemm(dAV, tr(v), mma=mma, out_dtype=A)                               # [B,h,m,n_p]
+            K.gemm(tr(a3), dAV, out=dv, mma=mma)
+            K.resconv(dout, rw, dqkv[..., 2 * D:], h, transpose=True, accumulate=True)
+            K.softmax_bwd(a3, dS3)
+            # similarities: s1 = scale q kl^T, s2 = scale ql kl^T, s3 = scale ql k^T
+            K.gemm(dS1, kl, out=dq, alpha=scale, mma=mma)
+            K.gemm(tr(dS3), ql, out=dk, alpha=scale, mma=mma)
+            K.gemm(tr(dS1), q, out=dkl, alpha=scale, mma=mma)
+            K.gemm(dS3, k, out=dql, alpha=scale, mma=mma)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
             del work

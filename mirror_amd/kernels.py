@@ -379,6 +379,85 @@ def pinv_chain_bwd(Xb, saved, dzf, work, dX, dz0, iters: int) -> None:
         gemm_profiler.launch_named(f"pinv_chain_bwd_kernel<{m}>", iters * 8 * 2.0 * m ** 3 * BH, fn)
 
 
+# ------------------------------------------------------------------ fused Nystrom attention sides (nystrom_fused.hip)
+NYS_FUSED_M, NYS_FUSED_DH = 256, 64
+
+
+def nys_fused_ok(qkv: torch.Tensor, heads: int, m: int) -> bool:
+    """The fused kernels cover the TransMIL geometry: bf16 qkv, 64-wide heads, 256 landmarks."""
+    D = qkv.shape[-1] // 3
+    return qkv.dtype == torch.bfloat16 and D == heads * NYS_FUSED_DH and m == NYS_FUSED_M and qkv.shape[1] % m == 0
+
+
+def _nys_check(name: str, B: int, h: int, n_p: int, **tensors) -> None:
+    D = h * NYS_FUSED_DH
+    want = {"qkv": ((B, n_p, 3 * D), torch.bfloat16), "dqkv": ((B, n_p, 3 * D), torch.bfloat16),
+            "lm": ((B, NYS_FUSED_M, 2 * D), torch.bfloat16), "dlm": ((B, NYS_FUSED_M, 2 * D), torch.float32),
+            "w2": ((B, h, NYS_FUSED_M, NYS_FUSED_DH), torch.bfloat16), "dw2": ((B, h, NYS_FUSED_M, NYS_FUSED_DH), torch.float32),
+            "av": ((B, h, NYS_FUSED_M, NYS_FUSED_DH), torch.float32), "dav": ((B, h, NYS_FUSED_M, NYS_FUSED_DH), torch.bfloat16),
+            "out": ((B, n_p, D), torch.bfloat16), "dout": ((B, n_p, D), torch.bfloat16),
+            "lse1": ((B, h, n_p), torch.float32), "delta1": ((B, h, n_p), torch.float32),
+            "lse3": ((B, h, NYS_FUSED_M), torch.float32)}
+    for k, t in tensors.items():
+        shape, dtype = want[k]
+        if tuple(t.shape) != shape or t.dtype != dtype or not t.is_contiguous():
+            raise MirrorHipError(f"{name}: {k} must be contiguous {dtype} {shape}, got {t.dtype} {tuple(t.shape)} "
+                                 f"contiguous={t.is_contiguous()}")
+
+
+def _nys_launch(name: str, flops: float, fn) -> None:
+    if gemm_profiler is None:
+        fn()
+    else:
+        gemm_profiler.launch_named(name, flops, fn)
+
+
+def nys_attn1_fwd(qkv, lm, w2, out, heads: int, scale: float) -> torch.Tensor:
+    """out[:, :, head] = softmax_m(scale q k_l^T) w2; returns the row logsumexp [B, h, n_p]."""
+    _chk(qkv, lm, w2, out)
+    B, n_p, _ = qkv.shape
+    lse1 = torch.empty((B, heads, n_p), device=qkv.device, dtype=torch.float32)
+    _nys_check("nys_attn1_fwd", B, heads, n_p, qkv=qkv, lm=lm, w2=w2, out=out)
+    _nys_launch("nys_a1_fwd_kernel", 2 * 2.0 * n_p * NYS_FUSED_M * NYS_FUSED_DH * B * heads,
+                lambda: _lib.call("mh_nys_attn1_fwd", _p(qkv), _p(lm), _p(w2), _p(out), _p(lse1), B, heads, n_p, NYS_FUSED_M,
+                                  NYS_FUSED_DH, scale, stream=_stream()))
+    return lse1
+
+
+def nys_attn3_fwd(qkv, lm, heads: int, scale: float):
+    """av = softmax_n(scale q_l k^T) v as [B, h, m, dh] f32, and the row logsumexp [B, h, m]."""
+    _chk(qkv, lm)
+    B, n_p, _ = qkv.shape
+    av = torch.empty((B, heads, NYS_FUSED_M, NYS_FUSED_DH), device=qkv.device, dtype=torch.float32)
+    lse3 = torch.empty((B, heads, NYS_FUSED_M), device=qkv.device, dtype=torch.float32)
+    _nys_check("nys_attn3_fwd", B, heads, n_p, qkv=qkv, lm=lm)
+    _nys_launch("nys_a3_fwd_kernel", 2 * 2.0 * n_p * NYS_FUSED_M * NYS_FUSED_DH * B * heads,
+                lambda: _lib.call("mh_nys_attn3_fwd", _p(qkv), _p(lm), _p(av), _p(lse3), B, heads, n_p, NYS_FUSED_M,
+                                  NYS_FUSED_DH, scale, stream=_stream()))
+    return av, lse3
+
+
+def nys_attn1_bwd(qkv, lm, w2, dout, lse1, dqkv, dw2, dlm, heads: int, scale: float) -> None:
+    """Writes the q block of dqkv; ADDS into dw2 and into the k_l half of dlm (both f32, zeroed by the caller)."""
+    _chk(qkv, lm, w2, dout, lse1, dqkv, dw2, dlm)
+    B, n_p, _ = qkv.shape
+    _nys_check("nys_attn1_bwd", B, heads, n_p, qkv=qkv, lm=lm, w2=w2, dout=dout, lse1=lse1, dqkv=dqkv, dw2=dw2, dlm=dlm)
+    delta1 = torch.empty_like(lse1)
+    _nys_launch("nys_a1_bwd_kernels", 7 * 2.0 * n_p * NYS_FUSED_M * NYS_FUSED_DH * B * heads,
+                lambda: _lib.call("mh_nys_attn1_bwd", _p(qkv), _p(lm), _p(w2), _p(dout), _p(lse1), _p(delta1), _p(dqkv),
+                                  _p(dw2), _p(dlm), B, heads, n_p, NYS_FUSED_M, NYS_FUSED_DH, scale, stream=_stream()))
+
+
+def nys_attn3_bwd(qkv, lm, av, dav, lse3, dqkv, dlm, heads: int, scale: float) -> None:
+    """Writes the k and v blocks of dqkv; ADDS into the q_l half of dlm."""
+    _chk(qkv, lm, av, dav, lse3, dqkv, dlm)
+    B, n_p, _ = qkv.shape
+    _nys_check("nys_attn3_bwd", B, heads, n_p, qkv=qkv, lm=lm, av=av, dav=dav, lse3=lse3, dqkv=dqkv, dlm=dlm)
+    _nys_launch("nys_a3_bwd_kernels", 7 * 2.0 * n_p * NYS_FUSED_M * NYS_FUSED_DH * B * heads,
+                lambda: _lib.call("mh_nys_attn3_bwd", _p(qkv), _p(lm), _p(av), _p(dav), _p(lse3), _p(dqkv), _p(dlm), B, heads,
+                                  n_p, NYS_FUSED_M, NYS_FUSED_DH, scale, stream=_stream()))
+
+
 def eye_minus(P: torch.Tensor, d: float) -> torch.Tensor:
     _chk(P)
     _contig(P, "eye_minus input")

@@ -602,3 +602,59 @@ def test_pinv_chain_matches_reference_iteration(m):
     cos = float((a @ b) / (a.norm() * b.norm()))
     ratio = float(a.norm() / b.norm())
     assert cos > 0.995 and 0.97 < ratio < 1.03, (cos, ratio)
+
+
+# --------------------------------------------------------------------------------------- fused Nystrom attention sides
+@pytest.mark.parametrize("B,h,l", [(1, 1, 1), (2, 2, 3), (1, 8, 17)])
+def test_nys_fused_attention_sides(B, h, l):
+    """mh_nys_attn{1,3}_{fwd,bwd} against autograd through the plain softmax(q k^T) products (f64 on CPU)."""
+    gen = g(100 * B + 10 * h + l)
+    m, dh = 256, 64
+    D, n_p, scale = h * dh, m * l, dh ** -0.5
+    bf = torch.bfloat16
+    qkv = (torch.randn((B, n_p, 3 * D), generator=gen) * 1.5).to(bf)
+    lm = (torch.randn((B, m, 2 * D), generator=gen) * 1.5).to(bf)
+    w2 = torch.randn((B, h, m, dh), generator=gen).to(bf)
+    dout = torch.randn((B, n_p, D), generator=gen).to(bf)
+    dav = torch.randn((B, h, m, dh), generator=gen).to(bf)
+
+    def heads(t, which, parts):
+        return t.double().view(B, t.shape[1], parts, h, dh)[:, :, which].permute(0, 2, 1, 3)
+
+    qkv_r, lm_r, w2_r = (t.double().requires_grad_() for t in (qkv, lm, w2))
+    q, k, v = (heads(qkv_r, i, 3) for i in range(3))
+    ql, kl = heads(lm_r, 0, 2), heads(lm_r, 1, 2)
+    s1 = scale * q @ kl.transpose(-1, -2)
+    out_ref = (torch.softmax(s1, -1) @ w2_r).permute(0, 2, 1, 3).reshape(B, n_p, D)
+    s3 = scale * ql @ k.transpose(-1, -2)
+    av_ref = torch.softmax(s3, -1) @ v
+    ((out_ref * dout.double()).sum() + (av_ref * dav.double()).sum()).backward()
+
+    qkv_d, lm_d, w2_d, dout_d, dav_d = (t.to(DEV) for t in (qkv, lm, w2, dout, dav))
+    out = torch.full((B, n_p, D), float("nan"), device=DEV, dtype=bf)
+    lse1 = K.nys_attn1_fwd(qkv_d, lm_d, w2_d, out, h, scale)
+    av, lse3 = K.nys_attn3_fwd(qkv_d, lm_d, h, scale)
+    out_ref, av_ref, s1, s3 = (t.detach() for t in (out_ref, av_ref, s1, s3))
+    close(out, out_ref, 0.0, 2e-2 * float(out_ref.abs().max()), "attn1 out")
+    close(lse1, torch.logsumexp(s1, -1), 1e-5, 1e-4, "lse1")
+    close(av, av_ref, 0.0, 1e-2 * float(av_ref.abs().max()), "attn3 av")
+    close(lse3, torch.logsumexp(s3, -1), 1e-5, 1e-4, "lse3")
+
+    dqkv = torch.full_like(qkv_d, float("nan"))
+    dw2 = torch.zeros((B, h, m, dh), device=DEV)
+    dlm = torch.zeros((B, m, 2 * D), device=DEV)
+    K.nys_attn1_bwd(qkv_d, lm_d, w2_d, dout_d, lse1, dqkv, dw2, dlm, h, scale)
+    K.nys_attn3_bwd(qkv_d, lm_d, av, dav_d, lse3, dqkv, dlm, h, scale)
+    for name, got, ref in (("dqkv", dqkv, qkv_r.grad), ("dw2", dw2, w2_r.grad), ("dlm", dlm, lm_r.grad)):
+        close(got, ref, 0.0, 2e-2 * float(ref.abs().max()), name)
+        rel = float((got.float().cpu().double() - ref).norm() / ref.norm())
+        assert rel < 1e-2, (name, rel)
+
+
+def test_nys_fused_rejects_other_geometry():
+    from mirror_amd._lib import MirrorHipError
+    bf = torch.bfloat16
+    qkv = torch.zeros((1, 128, 3 * 32), device=DEV, dtype=bf)
+    assert not K.nys_fused_ok(qkv, 1, 128)
+    with pytest.raises(MirrorHipError):
+        K.nys_attn3_fwd(qkv, torch.zeros((1, 128, 64), device=DEV, dtype=bf), 1, 1.0)

@@ -27,7 +27,7 @@ for r in rows:
     elif "at::native" in name or "rocclr" in name:
         c = "torch glue (add/fill/copy)"
     else:
-        c = name.split("(")[0].replace("void ", "").split("<")[0]
+        c = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").split("<")[0]
     cat_t[c] += d
     cat_n[c] += 1
 tot = sum(cat_t.values())
