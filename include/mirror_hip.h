@@ -119,12 +119,21 @@ int mh_pinv_z0(const float* x, const uint64_t* stats64, float* z0, int BH, int m
 /* dx += dz0^T/(c r) + sub-gradients through the two max() */
 int mh_pinv_z0_bwd(const float* x, const float* z0, const float* dz0, const uint64_t* stats64, float* dx,
                    float* scratch1, int BH, int m, mh_stream s);
-/* The whole iteration as ONE launch per pass (bf16 policy, m = 128 or 256): one 1024-thread workgroup per (b,h) walks
- * the chain of m x m products; sums of products stay in the MFMA accumulators.  All matrices contiguous [m][m] bf16.
- * saved: [iters][4][BH][m][m] = {z_k, P_k, T2_k, T3_k} (z_0 pre-filled by the caller), zf = z_iters.
- * bwd: dzf = d z_iters (bf16), work like saved = {dT3, dT2, dP, dz_k}; dX (f32) = sum_k dP_k z_k^T, dz0 (f32) = d z_0. */
-int mh_pinv_chain_fwd(const void* X, void* saved, void* zf, int BH, int m, int iters, mh_stream s);
-int mh_pinv_chain_bwd(const void* X, const void* saved, const void* dzf, void* work, float* dX, float* dz0, int BH, int m,
+/* The whole iteration as ONE launch per pass (bf16 policy, m = 256; other sizes return MH_EINVAL and the caller
+ * composes mh_gemm): one 256-thread workgroup per (b,h) walks the chain of m x m products; a wave owns 64 columns of
+ * every product, its B operand never leaves the register file, A is one LDS image (pinv_panel.hip).
+ * Chain-private matrices are "panel native" (PN): PN(M)[jblk][T][lane][e] = M[16T + 4hl + (e&3) + 8(e>>2)][32 jblk + c],
+ * c = lane & 31, hl = lane >> 5 — the 16 bytes one lane feeds to one MFMA k-step, lanes consecutive (coalesced).
+ *   prep : x [BH,m,m] f32 (attn2) + stats64 -> z0 = x^T/(c r) f32 row-major (as mh_pinv_z0), xp = PN(x),
+ *          z0p = PN(z0) (the caller places it at saved[0][0])
+ *   pack : dz [BH,m,m] f32 row-major (d z_iters) -> up = PN(dz^T), the backward's input
+ *   fwd  : XP = xp; saved [iters][4][BH][m][m] bf16 = PN{z_k, P_k, T2_k, T3_k}; zfT[j][i] = z_iters[i][j] (column-major,
+ *          i.e. the row-major transpose of the pseudo-inverse)
+ *   bwd  : dzf = up; work like saved (scratch); dX (f32, row-major) = sum_k dP_k z_k^T, dz0 (f32, row-major) = d z_0 */
+int mh_pinv_chain_prep(const float* x, const uint64_t* stats64, float* z0, void* xp, void* z0p, int BH, int m, mh_stream s);
+int mh_pinv_chain_pack(const float* dz, void* up, int BH, int m, mh_stream s);
+int mh_pinv_chain_fwd(const void* XP, void* saved, void* zfT, int BH, int m, int iters, mh_stream s);
+int mh_pinv_chain_bwd(const void* XP, const void* saved, const void* dzf, void* work, float* dX, float* dz0, int BH, int m,
                       int iters, mh_stream s);
 /* Fused attention sides of the Nystrom core (bf16 policy, dh = 64, m = 256 landmarks; anything else returns
  * MH_EINVAL and the caller composes mh_gemm + mh_softmax).  The [n_p x m] / [m x n_p] similarity matrices stay in MFMA

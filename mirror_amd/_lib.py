@@ -51,6 +51,8 @@ _SIGS = {
     "mh_pinv_z0": [P, P, P, I, I],
     "mh_pinv_z0_bwd": [P, P, P, P, P, P, I, I],
     "mh_eye_minus": [P, P, F, I, I],
+    "mh_pinv_chain_prep": [P, P, P, P, P, I, I],
+    "mh_pinv_chain_pack": [P, P, I, I],
     "mh_pinv_chain_fwd": [P, P, P, I, I, I],
     "mh_pinv_chain_bwd": [P, P, P, P, P, P, I, I, I],
     "mh_nys_attn1_fwd": [P, P, P, P, P, I, I, I, I, I, F],

@@ -1,0 +1,514 @@
+// Moore-Penrose iteration ([3P] moore_penrose_iter_pinv, called at models/mirror.py:312) as ONE launch per pass,
+// m = 256, bf16 MFMA with f32 accumulation — "column panel" formulation.
+//
+//   z <- 1/4 z (13I - P (15I - P (7I - P))),  P = X z        24 (forward) / 48 (backward) dependent 256^3 products
+//
+// One 256-thread workgroup (4 waves, one per SIMD, the whole 512-register budget each) owns one (batch, head).  Wave w
+// owns COLUMNS [64w, 64w+64) of every product C = A B: it needs all of A and only its own 64 columns of B.
+//   * A lives in LDS as one whole 128 KiB image, image[k][i] = A[i][k], read with ds_read_b64_tr_b16;
+//   * the B panel lives in registers as 16 x 2 bf16x8 MFMA operands — and that is exactly what the accumulator layout
+//     of v_mfma_f32_32x32x16_bf16 produces (column = lane & 31, rows in registers), so a product's result panel
+//     is the next product's B operand without leaving the register file (rows inside a 16-row k-step appear in the
+//     order 4hl+{0..3}, 8+4hl+{0..3}; the A fragments are read in the same order);
+//   * a result that the next product needs as A is written from the panels into the LDS image (8-byte stores, one
+//     image row per lane) — no global round trip on the critical path.
+// Every matrix the kernels keep in HBM (saved iterates, backward work space, X, z_0, d z_iters) is stored "panel
+// native" (PN): the 16 bytes a lane feeds to one k-step are contiguous and lanes are consecutive, so panel loads and
+// stores are fully coalesced 16-byte accesses and an A image is the same two 8-byte LDS stores per item that a panel
+// held in registers takes.  The backward pass is run on the transposed quantities
+// (U = dz^T, V3 = dT3^T, V2 = dT2^T, W = dP^T) so that no product ever needs a transposed operand:
+//     V3 = 1/4 U Z        V2 = -V3 P        W = V2 P - 7 V2 + P V2 - T2 V3        U' = W X + 1/4 T3 U
+//     dX^T = sum_k Z_k W_k
+// which also makes the column-major results the row-major dX / dz0 the caller wants (U = PN of dZ^T is packed by
+// mh_pinv_chain_pack).
+//
+// LDS image swizzle (pitch = 512 B, no padding): the 8-byte chunk ch of image row k is stored at chunk ch ^ swz(k),
+//   swz(k) = (k1 k2 k3 k0 k1) as bits 0..4.  Transposing reads (4 rows x 64 B per 32 lanes) then hit 64 distinct
+//   banks, panel writes (16 lanes, one row each, same chunk) hit 16 distinct chunk slots, and 16-byte row copies
+//   stay 16-byte (the two halves swap when k1 = 1).
+#include "gemm_kernel.h"
+
+namespace {
+
+constexpr int CM = 256;        // matrix size
+constexpr int CT = 256;        // threads per workgroup
+constexpr int NJ = 2;          // 32-column blocks per wave
+constexpr int NCH = CM * CM / 8 / CT;   // 16-byte chunks per thread in a row copy
+constexpr long MAT = (long)CM * CM;
+constexpr int IMG = CM * CM * 2;
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ int swz(int k) { return ((k >> 1) & 7) | ((k & 1) << 3) | (((k >> 1) & 1) << 4); }
+
+__device__ __forceinline__ bf16x8 tr_pair(const char* img, unsigned lo, unsigned hi) {
+    s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + lo));
+    s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + hi));
+    s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// Addresses of this lane's transposing reads.  Row block blk, k-step T reads image rows 16T + kl (+8) at chunk
+// (8 blk + cl) ^ swz(row): the swizzle touches chunk bits 0..4 only, so the address splits into four lane-dependent
+// bases (blk & 3, through the XOR) plus the compile-time offset 256 (blk >> 2) + 8192 (T & 7) that fits the ds_read
+// immediate; k-steps 8..15 use a second set of bases 64 KiB further on (made opaque, or the compiler folds them back
+// into base + constant, materialises all 128 sums and spills them).  16 address registers in all.
+__device__ __forceinline__ void read_bases(unsigned (&blo)[2][4], unsigned (&bhi)[2][4], int lane) {
+    const int g16 = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const int kl = 4 * (g16 >> 1) + q, cl = 4 * (g16 & 1) + p;
+    const int slo = swz(kl), shi = swz(kl + 8);
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        blo[0][b] = kl * 512 + (((8 * b + cl) ^ slo) << 3);
+        bhi[0][b] = (kl + 8) * 512 + (((8 * b + cl) ^ shi) << 3);
+        blo[1][b] = blo[0][b] + 65536;
+        bhi[1][b] = bhi[0][b] + 65536;
+        asm volatile("" : "+v"(blo[0][b]), "+v"(bhi[0][b]), "+v"(blo[1][b]), "+v"(bhi[1][b]));
+    }
+}
+
+// the 8 A fragments (one per 32-row block) of k-step T
+template <int T>
+__device__ __forceinline__ void load_frags(bf16x8 (&af)[8], const char* img, const unsigned (&blo)[2][4], const unsigned (&bhi)[2][4]) {
+#pragma unroll
+    for (int blk = 0; blk < 8; blk++) {
+        constexpr int hs = T >> 3;
+        const int off = (blk >> 2) * 256 + (T & 7) * 8192;
+        s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + blo[hs][blk & 3] + off));
+        s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + bhi[hs][blk & 3] + off));
+        af[blk] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+    }
+}
+
+// acc[blk][jb] += A(rows 32 blk ..) . B panel (column block jb) over all 256 k.  The fragments of k-step T+1 are
+// requested before the 16 MFMAs of k-step T are issued (one wave per SIMD: nobody else hides the LDS latency).
+template <int T>
+__device__ __forceinline__ void gemm_step(f32x16 (&acc)[8][NJ], bf16x8 (&cur)[8], bf16x8 (&nxt)[8], const char* img,
+                                          const unsigned (&blo)[2][4], const unsigned (&bhi)[2][4], const bf16x8 (&pB)[16][NJ]) {
+    if constexpr (T + 1 < 16) load_frags<(T + 1) & 15>(nxt, img, blo, bhi);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int blk = 0; blk < 8; blk++)
+#pragma unroll
+        for (int jb = 0; jb < NJ; jb++) acc[blk][jb] = MFMA(cur[blk], pB[T][jb], acc[blk][jb]);
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void panel_gemm(f32x16 (&acc)[8][NJ], const char* img, const unsigned (&blo)[2][4],
+                                           const unsigned (&bhi)[2][4], const bf16x8 (&pB)[16][NJ]) {
+    bf16x8 f0[8], f1[8];
+    load_frags<0>(f0, img, blo, bhi);
+    gemm_step<0>(acc, f0, f1, img, blo, bhi, pB);
+    gemm_step<1>(acc, f1, f0, img, blo, bhi, pB);
+    gemm_step<2>(acc, f0, f1, img, blo, bhi, pB);
+    gemm_step<3>(acc, f1, f0, img, blo, bhi, pB);
+    gemm_step<4>(acc, f0, f1, img, blo, bhi, pB);
+    gemm_step<5>(acc, f1, f0, img, blo, bhi, pB);
+    gemm_step<6>(acc, f0, f1, img, blo, bhi, pB);
+    gemm_step<7>(acc, f1, f0, img, blo, bhi, pB);
+    gemm_step<8>(acc, f0, f1, img, blo, bhi, pB);
+    gemm_step<9>(acc, f1, f0, img, blo, bhi, pB);
+    gemm_step<10>(acc, f0, f1, img, blo, bhi, pB);
+    gemm_step<11>(acc, f1, f0, img, blo, bhi, pB);
+    gemm_step<12>(acc, f0, f1, img, blo, bhi, pB);
+    gemm_step<13>(acc, f1, f0, img, blo, bhi, pB);
+    gemm_step<14>(acc, f0, f1, img, blo, bhi, pB);
+    gemm_step<15>(acc, f1, f0, img, blo, bhi, pB);
+}
+
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[8][NJ]) {
+#pragma unroll
+    for (int blk = 0; blk < 8; blk++)
+#pragma unroll
+        for (int jb = 0; jb < NJ; jb++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[blk][jb][r] = 0.f;
+}
+__device__ __forceinline__ void scale_acc(f32x16 (&acc)[8][NJ], float a) {
+#pragma unroll
+    for (int blk = 0; blk < 8; blk++)
+#pragma unroll
+        for (int jb = 0; jb < NJ; jb++) acc[blk][jb] *= a;
+}
+
+// out = alpha acc + diag I + rcoef R as the packed bf16 panel (R = another packed panel, same positions).
+// The diagonal of column block jb lies in row block 2 wave + jb, at accumulator register dreg of the lanes whose
+// half matches (dreg = -1 elsewhere): one compare against a constant per element, nothing to precompute.
+template <bool HASR>
+__device__ __forceinline__ void finish(const f32x16 (&acc)[8][NJ], float alpha, float diag, const bf16x8 (&pR)[16][NJ],
+                                       float rcoef, bf16x8 (&pO)[16][NJ], int wave, int dreg) {
+#pragma unroll
+    for (int blk = 0; blk < 8; blk++)
+#pragma unroll
+        for (int jb = 0; jb < NJ; jb++) {
+            const float dg = (blk == 2 * wave + jb) ? diag : 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int r = 8 * t + e;
+                    float v = alpha * acc[blk][jb][r];
+                    if (r == dreg) v += dg;
+                    if constexpr (HASR) v += rcoef * (float)pR[2 * blk + t][jb][e];
+                    o[e] = (__bf16)v;
+                }
+                pO[2 * blk + t][jb] = o;
+                __builtin_amdgcn_sched_barrier(0);   // one block at a time: hoisting all accumulator reads would spill
+            }
+        }
+}
+
+// HBM storage of chain-private matrices, "panel native": PN[jblk][T][lane][8] holds the bf16x8 that lane (c = lane & 31,
+// hl = lane >> 5) of column block jblk feeds to k-step T, i.e. M[16T + 4hl + {0..3}, 16T + 8 + 4hl + {0..3}][32 jblk + c]:
+// every panel load / store is one fully coalesced 16-byte access per lane.
+__device__ __forceinline__ void store_panel(bf16_t* __restrict__ G, const bf16x8 (&p)[16][NJ], int wave, int lane) {
+#pragma unroll
+    for (int jb = 0; jb < NJ; jb++)
+#pragma unroll
+        for (int T = 0; T < 16; T++)
+            *reinterpret_cast<u32x4*>(G + ((((2 * wave + jb) * 16 + T) * 64 + lane) << 3)) = __builtin_bit_cast(u32x4, p[T][jb]);
+}
+__device__ __forceinline__ void load_panel(bf16x8 (&p)[16][NJ], const bf16_t* __restrict__ G, int wave, int lane) {
+#pragma unroll
+    for (int jb = 0; jb < NJ; jb++)
+#pragma unroll
+        for (int T = 0; T < 16; T++)
+            p[T][jb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(G + ((((2 * wave + jb) * 16 + T) * 64 + lane) << 3)));
+}
+__device__ __forceinline__ void negate_panel(bf16x8 (&p)[16][NJ]) {
+#pragma unroll
+    for (int T = 0; T < 16; T++)
+#pragma unroll
+        for (int jb = 0; jb < NJ; jb++) {
+            u32x4 v = __builtin_bit_cast(u32x4, p[T][jb]);
+            v ^= 0x80008000u;
+            p[T][jb] = __builtin_bit_cast(bf16x8, v);
+        }
+}
+// f32 column-major store of alpha * acc (i.e. row-major of the transposed matrix)
+__device__ __forceinline__ void store_f32(float* __restrict__ G, const f32x16 (&acc)[8][NJ], float alpha, int j0, int hl) {
+#pragma unroll
+    for (int jb = 0; jb < NJ; jb++) {
+        float* row = G + (long)(j0 + 32 * jb) * CM + 4 * hl;
+#pragma unroll
+        for (int blk = 0; blk < 8; blk++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = alpha * acc[blk][jb][4 * g + e];
+                *reinterpret_cast<f32x4*>(row + 32 * blk + 8 * g) = v;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    }
+}
+
+// panels -> LDS image (image row j = this lane's column)
+__device__ __forceinline__ void image_from_panel(char* img, const bf16x8 (&p)[16][NJ], int j0, int hl) {
+    asm volatile("" : "+v"(j0));   // keep the swizzled addresses out of loop-invariant hoisting (they would be spilled)
+    const int s = swz(j0);         // bits 0..3 of the column only: the same for both column blocks
+#pragma unroll
+    for (int jb = 0; jb < NJ; jb++) {
+        char* row = img + (j0 + 32 * jb) * 512;
+#pragma unroll
+        for (int T = 0; T < 16; T++) {
+            const u32x4 v = __builtin_bit_cast(u32x4, p[T][jb]);
+            *reinterpret_cast<u32x2*>(row + (((4 * T + hl) ^ s) << 3)) = u32x2{v[0], v[1]};
+            *reinterpret_cast<u32x2*>(row + (((4 * T + 2 + hl) ^ s) << 3)) = u32x2{v[2], v[3]};
+        }
+    }
+}
+// panel-native HBM matrix -> LDS image, BATCH 16-byte items in flight per thread (fewer while an accumulator tile is
+// live).  Item it = tid + 256 n is lane (tid & 63) of k-step wave + 4 (n & 3) of column block n >> 2.
+template <int BATCH>
+__device__ __forceinline__ void image_from_global(char* img, const bf16_t* __restrict__ G, int tid) {
+    asm volatile("" : "+v"(tid));   // recompute the addresses at every call instead of hoisting + spilling them
+    const int lane = tid & 63, c = lane & 31, hl = lane >> 5, s = swz(c), tw = tid >> 6;
+#pragma unroll
+    for (int n0 = 0; n0 < 32; n0 += BATCH) {
+        u32x4 r[BATCH];
+#pragma unroll
+        for (int n = 0; n < BATCH; n++) r[n] = *reinterpret_cast<const u32x4*>(G + ((long)(tid + CT * (n0 + n)) << 3));
+#pragma unroll
+        for (int n = 0; n < BATCH; n++) {
+            const int jblk = (n0 + n) >> 2, T = tw + 4 * ((n0 + n) & 3);
+            char* row = img + (32 * jblk + c) * 512;
+            *reinterpret_cast<u32x2*>(row + (((4 * T + hl) ^ s) << 3)) = u32x2{r[n][0], r[n][1]};
+            *reinterpret_cast<u32x2*>(row + (((4 * T + 2 + hl) ^ s) << 3)) = u32x2{r[n][2], r[n][3]};
+        }
+    }
+}
+// LDS image -> column-major HBM matrix G[j][i] (row copy, coalesced): the form the caller's GEMMs read
+__device__ __forceinline__ void image_to_global(const char* img, bf16_t* __restrict__ G, int tid) {
+#pragma unroll
+    for (int n = 0; n < NCH; n++) {
+        const int cid = tid + CT * n, k = cid >> 5, c16 = cid & 31, s = swz(k);
+        u32x4 v = *reinterpret_cast<const u32x4*>(img + k * 512 + ((c16 ^ (s >> 1)) << 4));
+        if (s & 1) v = u32x4{v[2], v[3], v[0], v[1]};
+        *reinterpret_cast<u32x4*>(G + (long)cid * 8) = v;
+    }
+}
+// make this workgroup's global stores visible to its other waves, and wait until nobody reads the LDS image any more
+__device__ __forceinline__ void publish() {
+    // workgroup scope only (all waves share this CU's L1, stores are write-through, and every line is written before
+    // its first read): an agent-scope fence writes back and invalidates the whole L2 every time
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// ---------------------------------------------------------------------------------------------------------- forward
+// XP = PN(X); saved[k] = PN{z_k, P_k, T2_k, T3_k}, z_0 pre-filled; zfT[j][i] = z_iters[i][j] (column-major)
+__global__ __launch_bounds__(CT) void pinv_panel_fwd_kernel(const bf16_t* __restrict__ XT, bf16_t* __restrict__ saved,
+                                                            bf16_t* __restrict__ zfT, int BH, int iters) {
+    __shared__ __attribute__((aligned(16))) char img[IMG];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 5, j = 64 * wave + (lane & 31);
+    const int bh = blockIdx.x;
+    const int dreg = (hl == ((lane >> 2) & 1)) ? ((((lane & 31) >> 3) << 2) | (lane & 3)) : -1;
+    unsigned rlo[2][4], rhi[2][4];
+    read_bases(rlo, rhi, lane);
+    const bf16_t* Xb = XT + bh * MAT;
+    f32x16 acc[8][NJ];
+    bf16x8 pa[16][NJ], pb[16][NJ];
+    load_panel(pa, saved + bh * MAT, wave, lane);                              // z_0
+    image_from_global<16>(img, Xb, tid);
+    __syncthreads();
+#pragma unroll 1
+    for (int k = 0; k < iters; k++) {
+        bf16_t* base = saved + ((long)k * 4 * BH + bh) * MAT;              // [iters][4][BH][m][m]
+        bf16_t* P = base + (long)BH * MAT;
+        bf16_t* T2 = base + 2L * BH * MAT;
+        bf16_t* T3 = base + 3L * BH * MAT;
+        zero_acc(acc);
+        panel_gemm(acc, img, rlo, rhi, pa);                               // P = X z
+        finish<false>(acc, 1.f, 0.f, pa, 0.f, pb, wave, dreg);
+        store_panel(P, pb, wave, lane);
+        __syncthreads();
+        image_from_panel(img, pb, j, hl);
+        __syncthreads();
+        zero_acc(acc);
+        panel_gemm(acc, img, rlo, rhi, pb);                               // T2 = 15I - 7P + P P
+        finish<true>(acc, 1.f, 15.f, pb, -7.f, pa, wave, dreg);
+        store_panel(T2, pa, wave, lane);
+        zero_acc(acc);
+        panel_gemm(acc, img, rlo, rhi, pa);                               // T3 = 13I - P T2
+        finish<false>(acc, -1.f, 13.f, pa, 0.f, pb, wave, dreg);
+        store_panel(T3, pb, wave, lane);
+        publish();
+        image_from_global<16>(img, base, tid);                            // z_k (written by this workgroup one step ago)
+        __syncthreads();
+        zero_acc(acc);
+        panel_gemm(acc, img, rlo, rhi, pb);                               // z' = 1/4 z T3
+        finish<false>(acc, 0.25f, 0.f, pb, 0.f, pa, wave, dreg);
+        if (k + 1 < iters) {
+            store_panel(saved + ((long)(k + 1) * 4 * BH + bh) * MAT, pa, wave, lane);
+            publish();
+            image_from_global<16>(img, Xb, tid);
+            __syncthreads();
+        } else {                                                           // z_iters leaves column-major, via the image
+            __syncthreads();
+            image_from_panel(img, pa, j, hl);
+            __syncthreads();
+            image_to_global(img, zfT + bh * MAT, tid);
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------------- backward
+// dzf = PN(U), U = (d z_iters)^T;  work[k] = PN{V3, V2, W, U_k};
+// dX (f32, row-major) = sum_k dP_k z_k^T;  dz0 (f32, row-major) = d z_0
+__global__ __launch_bounds__(CT) void pinv_panel_bwd_kernel(const bf16_t* __restrict__ XT, const bf16_t* __restrict__ saved,
+                                                            const bf16_t* __restrict__ dzf, bf16_t* __restrict__ work,
+                                                            float* __restrict__ dX, float* __restrict__ dz0, int BH, int iters) {
+    __shared__ __attribute__((aligned(16))) char img[IMG];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 5, j = 64 * wave + (lane & 31);
+    const int bh = blockIdx.x;
+    const int dreg = (hl == ((lane >> 2) & 1)) ? ((((lane & 31) >> 3) << 2) | (lane & 3)) : -1;
+    unsigned rlo[2][4], rhi[2][4];
+    read_bases(rlo, rhi, lane);
+    const bf16_t* Xb = XT + bh * MAT;
+    f32x16 acc[8][NJ];
+    bf16x8 pa[16][NJ], pb[16][NJ];
+    const bf16_t* U = dzf + bh * MAT;
+    image_from_global<16>(img, U, tid);
+    __syncthreads();
+#pragma unroll 1
+    for (int k = iters - 1; k >= 0; k--) {
+        const bf16_t* sb = saved + ((long)k * 4 * BH + bh) * MAT;
+        const bf16_t* Z = sb;
+        const bf16_t* P = sb + (long)BH * MAT;
+        const bf16_t* T2 = sb + 2L * BH * MAT;
+        const bf16_t* T3 = sb + 3L * BH * MAT;
+        bf16_t* wb = work + ((long)k * 4 * BH + bh) * MAT;
+        bf16_t* V3 = wb;
+        bf16_t* V2 = wb + (long)BH * MAT;
+        bf16_t* W = wb + 2L * BH * MAT;
+        bf16_t* Un = wb + 3L * BH * MAT;
+        // V3 = 1/4 U Z                                                   (image: U)
+        load_panel(pa, Z, wave, lane);
+        zero_acc(acc);
+        panel_gemm(acc, img, rlo, rhi, pa);
+        finish<false>(acc, 0.25f, 0.f, pa, 0.f, pb, wave, dreg);
+        store_panel(V3, pb, wave, lane);
+        __syncthreads();
+        image_from_panel(img, pb, j, hl);
+        __syncthreads();
+        // V2 = -V3 P                                                     (image: V3)
+        load_panel(pa, P, wave, lane);
+        zero_acc(acc);
+        panel_gemm(acc, img, rlo, rhi, pa);
+        finish<false>(acc, -1.f, 0.f, pa, 0.f, pb, wave, dreg);
+        store_panel(V2, pb, wave, lane);
+        __syncthreads();
+        image_from_panel(img, pb, j, hl);
+        __syncthreads();
+        // W = V2 P - 7 V2 + P V2 - T2 V3      (one panel besides the accumulators at any time: reload, do not hold)
+        zero_acc(acc);
+        panel_gemm(acc, img, rlo, rhi, pa);                               // V2 P   (image: V2, panel: P)
+        publish();                                                         // V3 / V2 stores of this step are visible
+        image_from_global<8>(img, P, tid);
+        load_panel(pb, V2, wave, lane);
+#pragma unroll
+        for (int blk = 0; blk < 8; blk++)
+#pragma unroll
+            for (int jb = 0; jb < NJ; jb++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[blk][jb][r] -= 7.f * (float)pb[2 * blk + (r >> 3)][jb][r & 7];
+        __syncthreads();
+        panel_gemm(acc, img, rlo, rhi, pb);                               // + P V2 (image: P, panel: V2)
+        __syncthreads();
+        image_from_global<8>(img, T2, tid);
+        load_panel(pa, V3, wave, lane);
+        negate_panel(pa);
+        __syncthreads();
+        panel_gemm(acc, img, rlo, rhi, pa);                               // - T2 V3
+        finish<false>(acc, 1.f, 0.f, pa, 0.f, pb, wave, dreg);
+        store_panel(W, pb, wave, lane);
+        __syncthreads();
+        image_from_panel(img, pb, j, hl);
+        __syncthreads();
+        // U' = W X + 1/4 T3 U  =  1/4 (4 W X + T3 U)
+        load_panel(pa, Xb, wave, lane);
+        zero_acc(acc);
+        panel_gemm(acc, img, rlo, rhi, pa);                               // W X    (image: W, panel: X)
+        scale_acc(acc, 4.f);
+        publish();                                                         // U stores of the previous step are visible
+        image_from_global<8>(img, T3, tid);
+        load_panel(pa, U, wave, lane);
+        __syncthreads();
+        panel_gemm(acc, img, rlo, rhi, pa);                               // + T3 U
+        finish<false>(acc, 0.25f, 0.f, pa, 0.f, pb, wave, dreg);
+        store_panel(Un, pb, wave, lane);
+        if (k == 0) store_f32(dz0 + bh * MAT, acc, 0.25f, j, hl);
+        __syncthreads();
+        image_from_panel(img, pb, j, hl);                                 // next step's U
+        __syncthreads();
+        U = Un;
+    }
+    // dX^T = sum_k Z_k W_k
+    publish();
+    zero_acc(acc);
+#pragma unroll 1
+    for (int k = 0; k < iters; k++) {
+        const bf16_t* Z = saved + ((long)k * 4 * BH + bh) * MAT;
+        const bf16_t* W = work + ((long)k * 4 * BH + bh) * MAT + 2L * BH * MAT;
+        __syncthreads();
+        image_from_global<8>(img, Z, tid);
+        load_panel(pa, W, wave, lane);
+        __syncthreads();
+        panel_gemm(acc, img, rlo, rhi, pa);
+    }
+    store_f32(dX + bh * MAT, acc, 1.f, j, hl);
+}
+
+// One thread per panel-native item (bh, jblk, T, lane): i_e = 16T + 4hl + (e & 3) + 8 (e >> 2), j = 32 jblk + c.
+__device__ __forceinline__ void pn_item(int it, int& j, int& i0) {
+    const int lane = it & 63, T = (it >> 6) & 15, jblk = it >> 10;
+    j = 32 * jblk + (lane & 31);
+    i0 = 16 * T + 4 * (lane >> 5);
+}
+__device__ __forceinline__ u32x4 pack_bf16x8(const float (&v)[8]) {
+    u32x4 o;
+#pragma unroll
+    for (int w = 0; w < 4; w++) o[w] = (unsigned)f2bf(v[2 * w]) | ((unsigned)f2bf(v[2 * w + 1]) << 16);
+    return o;
+}
+
+// x = attn2 (f32 row-major) -> xp = PN(x), z0p = PN(z0), z0 = x^T / (c r) in f32 row-major (for mh_pinv_z0_bwd)
+__global__ __launch_bounds__(256) void pinv_chain_prep_kernel(const float* __restrict__ x, const unsigned long long* __restrict__ st,
+                                                              float* __restrict__ z0, bf16_t* __restrict__ xp,
+                                                              bf16_t* __restrict__ z0p) {
+    const float c = __uint_as_float((unsigned)(st[0] >> 32)), r = __uint_as_float((unsigned)(st[1] >> 32));
+    const float inv = 1.f / (c * r);
+    const int it = blockIdx.x * 256 + threadIdx.x;          // 8192 items per matrix
+    const long base = (long)blockIdx.y * MAT;
+    int j, i0;
+    pn_item(it, j, i0);
+    float xv[8], zv[8];
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x + base + (long)j * CM + i0);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(x + base + (long)j * CM + i0 + 8);
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int i = i0 + (e & 3) + 8 * (e >> 2);
+        xv[e] = x[base + (long)i * CM + j];                   // X[i][j]
+        zv[e] = (e < 4 ? a[e] : b[e - 4]) * inv;              // z0[i][j] = x[j][i] / (c r)
+        z0[base + (long)i * CM + j] = zv[e];
+    }
+    *reinterpret_cast<u32x4*>(xp + base + (long)it * 8) = pack_bf16x8(xv);
+    *reinterpret_cast<u32x4*>(z0p + base + (long)it * 8) = pack_bf16x8(zv);
+}
+
+// dz (f32 row-major, d z_iters) -> PN(U), U = dz^T
+__global__ __launch_bounds__(256) void pinv_chain_pack_kernel(const float* __restrict__ dz, bf16_t* __restrict__ up) {
+    const int it = blockIdx.x * 256 + threadIdx.x;
+    const long base = (long)blockIdx.y * MAT;
+    int j, i0;
+    pn_item(it, j, i0);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(dz + base + (long)j * CM + i0);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(dz + base + (long)j * CM + i0 + 8);
+    const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};   // U[i][j] = dz[j][i]
+    *reinterpret_cast<u32x4*>(up + base + (long)it * 8) = pack_bf16x8(v);
+}
+
+}  // namespace
+
+extern "C" int mh_pinv_chain_prep(const float* x, const uint64_t* stats64, float* z0, void* xp, void* z0p, int BH, int m,
+                                  mh_stream s) {
+    MH_REQUIRE(m == CM, "mh_pinv_chain_prep: m=%d unsupported (the chain kernels are built for m = %d; other sizes use mh_gemm)", m, CM);
+    if (BH <= 0) return MH_OK;
+    hipLaunchKernelGGL(pinv_chain_prep_kernel, dim3(MAT / 8 / 256, BH), dim3(256), 0, (hipStream_t)s, x,
+                       (const unsigned long long*)stats64, z0, (bf16_t*)xp, (bf16_t*)z0p);
+    MH_LAUNCH_CHECK("mh_pinv_chain_prep");
+    return MH_OK;
+}
+
+extern "C" int mh_pinv_chain_pack(const float* dz, void* up, int BH, int m, mh_stream s) {
+    MH_REQUIRE(m == CM, "mh_pinv_chain_pack: m=%d unsupported (built for m = %d)", m, CM);
+    if (BH <= 0) return MH_OK;
+    hipLaunchKernelGGL(pinv_chain_pack_kernel, dim3(MAT / 8 / 256, BH), dim3(256), 0, (hipStream_t)s, dz, (bf16_t*)up);
+    MH_LAUNCH_CHECK("mh_pinv_chain_pack");
+    return MH_OK;
+}
+
+extern "C" int mh_pinv_chain_fwd(const void* XT, void* saved, void* zfT, int BH, int m, int iters, mh_stream s) {
+    MH_REQUIRE(m == CM, "mh_pinv_chain_fwd: m=%d unsupported (built for m = %d; other sizes use mh_gemm)", m, CM);
+    MH_REQUIRE(iters >= 1 && BH >= 0, "mh_pinv_chain_fwd: bad arguments");
+    if (BH == 0) return MH_OK;
+    hipLaunchKernelGGL(pinv_panel_fwd_kernel, dim3(BH), dim3(CT), 0, (hipStream_t)s, (const bf16_t*)XT, (bf16_t*)saved,
+                       (bf16_t*)zfT, BH, iters);
+    MH_LAUNCH_CHECK("mh_pinv_chain_fwd");
+    return MH_OK;
+}
+
+extern "C" int mh_pinv_chain_bwd(const void* XT, const void* saved, const void* dzf, void* work, float* dX, float* dz0, int BH,
+                                 int m, int iters, mh_stream s) {
+    MH_REQUIRE(m == CM, "mh_pinv_chain_bwd: m=%d unsupported (built for m = %d; other sizes use mh_gemm)", m, CM);
+    MH_REQUIRE(iters >= 1 && BH >= 0, "mh_pinv_chain_bwd: bad arguments");
+    if (BH == 0) return MH_OK;
+    hipLaunchKernelGGL(pinv_panel_bwd_kernel, dim3(BH), dim3(CT), 0, (hipStream_t)s, (const bf16_t*)XT, (const bf16_t*)saved,
+                       (const bf16_t*)dzf, (bf16_t*)work, dX, dz0, BH, iters);
+    MH_LAUNCH_CHECK("mh_pinv_chain_bwd");
+    return MH_OK;
+}

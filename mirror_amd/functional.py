@@ -494,23 +494,22 @@ class NystromCoreFn(Function):
         K.softmax_fwd(a2, a2)
         sd = f32 if pm == MH_F32 else bf16
         m_l = a2.shape[-1]
-        chain = pm == MH_BF16 and m_l in (128, 256)     # whole iteration in one launch (pinv_chain.hip)
+        chain = pm == MH_BF16 and m_l == K.PINV_CHAIN_M    # whole iteration in one launch (pinv_panel.hip)
         side = None
         if chain:
-            # B*h workgroups of 1024 threads / 144 KiB LDS: the chain owns B*h CUs and nothing else.  At B*h = 128 that
-            # is half of the chip, so it runs on a side stream while the other half computes the two big softmax
-            # kernels (sim1, sim3) and a3 @ v on the main stream; they meet again at w2 = pinv @ (a3 v).
+            # B*h workgroups with a 128 KiB LDS image each: the chain owns B*h CUs and nothing else.  At B*h = 128 that
+            # is half of the chip, so it runs on a side stream beside the attn3 side on the main stream; they meet
+            # again at w2 = pinv @ (a3 v).  Chain-private matrices are column-major (see mirror_hip.h).
             st = K.pinv_absmax(a2)
-            z0 = K.pinv_z0(a2, st)
-            xb = K.cast(a2, bf16)
             chain_saved = torch.empty((iters, 4, Bn * h, m_l, m_l), device=qkv.device, dtype=bf16)
-            K.cast(z0.reshape(Bn * h, m_l, m_l), bf16, out=chain_saved[0, 0])
-            zf = torch.empty((Bn, h, m_l, m_l), device=qkv.device, dtype=bf16)
+            z0, xt = K.pinv_chain_prep(a2, st, chain_saved[0, 0])
+            zfT = torch.empty((Bn, h, m_l, m_l), device=qkv.device, dtype=bf16)
+            zf = zfT.transpose(-1, -2)
             side = _side_stream(qkv.device)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                K.pinv_chain_fwd(xb, chain_saved, zf, iters)
-            saved = [(xb, chain_saved, z0)]
+                K.pinv_chain_fwd(xt, chain_saved, zfT, iters)
+            saved = [(xt, chain_saved, z0)]
         fused = K.nys_fused_ok(qkv, h, m_l) and lm.dtype == bf16      # nystrom_fused.hip: sim1 / sim3 never reach HBM
         lse1 = lse3 = a1 = a3 = None
         if fused:
@@ -536,7 +535,8 @@ class NystromCoreFn(Function):
             K.gemm(a1, w2, out=_heads(out, 0, 1, h), mma=mma)
         K.resconv(qkv[..., 2 * D:], res_w.detach().contiguous(), out, h, transpose=False, accumulate=True)
         stats = (lse1, lse3) if fused else (a1, a3)
-        ctx.save_for_backward(qkv, res_w, lm, stats[0], a2, stats[1], av, w2, st, zf, *[t for it in saved for t in it])
+        ctx.save_for_backward(qkv, res_w, lm, stats[0], a2, stats[1], av, w2, st, zfT if chain else zf,
+                              *[t for it in saved for t in it])
         ctx.cfg = (heads, l, prec)
         ctx.chain = (chain, iters, fused)
         return out
@@ -545,6 +545,8 @@ class NystromCoreFn(Function):
     def backward(ctx, dout):
         qkv, res_w, lm, a1, a2, a3, av, w2, st, zf, *flat = ctx.saved_tensors
         chain, iters, fused = ctx.chain
+        if chain:
+            zf = zf.transpose(-1, -2)       # saved as the column-major chain output
         saved = None if chain else [tuple(flat[i:i + 4]) for i in range(0, len(flat), 4)]
         heads, l, prec = ctx.cfg
         A, mma, pm = prec.act, prec.mma, prec.pinv_mma
@@ -584,7 +586,7 @@ class NystromCoreFn(Function):
             work = torch.empty_like(chain_saved)
             dS2 = torch.empty_like(a2)
             dz0 = torch.empty_like(a2)
-            dzb = K.cast(dZ, bf16)
+            dzb = K.pinv_chain_pack(dZ)
             side = _side_stream(qkv.device)      # half-chip chain again, beside the softmax backward / dq / dk work
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):

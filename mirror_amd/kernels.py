@@ -347,36 +347,68 @@ def pinv_z0_bwd(x, z0, dz0, stats, dx) -> None:
               x.numel() // (m * m), m, stream=_stream())
 
 
-def pinv_chain_fwd(Xb: torch.Tensor, saved: torch.Tensor, zf: torch.Tensor, iters: int) -> None:
-    _chk(Xb, saved, zf)
-    m = Xb.shape[-1]
-    BH = Xb.numel() // (m * m)
+PINV_CHAIN_M = 256
+
+
+def pinv_chain_prep(x: torch.Tensor, stats: torch.Tensor, z0cm_out: torch.Tensor):
+    """attn2 (f32 [.., m, m]) -> (z0 f32 = x^T/(c r) row-major, XP = panel-native bf16 x); writes the panel-native z_0 into
+    `z0cm_out` (normally saved[0, 0] of the chain).  Panel-native layout: include/mirror_hip.h."""
+    _chk(x, stats, z0cm_out)
+    _contig(x, "pinv_chain_prep input")
+    m = x.shape[-1]
+    BH = x.numel() // (m * m)
+    if x.dtype != torch.float32 or z0cm_out.dtype != torch.bfloat16 or not z0cm_out.is_contiguous() or z0cm_out.numel() != x.numel():
+        raise MirrorHipError("pinv_chain_prep: bad operands")
+    z0 = torch.empty_like(x)
+    xt = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    _lib.call("mh_pinv_chain_prep", _p(x), _p(stats), _p(z0), _p(xt), _p(z0cm_out), BH, m, stream=_stream())
+    return z0, xt
+
+
+def pinv_chain_pack(dz: torch.Tensor) -> torch.Tensor:
+    """d z_iters (f32 row-major [.., m, m]) -> the panel-native bf16 input of pinv_chain_bwd."""
+    _chk(dz)
+    _contig(dz, "pinv_chain_pack input")
+    m = dz.shape[-1]
+    if dz.dtype != torch.float32:
+        raise MirrorHipError("pinv_chain_pack: f32 input expected")
+    up = torch.empty(dz.shape, device=dz.device, dtype=torch.bfloat16)
+    _lib.call("mh_pinv_chain_pack", _p(dz), _p(up), dz.numel() // (m * m), m, stream=_stream())
+    return up
+
+
+def pinv_chain_fwd(XT: torch.Tensor, saved: torch.Tensor, zfT: torch.Tensor, iters: int) -> None:
+    """XT = panel-native x, saved[0, 0] = panel-native z_0; zfT receives the column-major z_iters (= pinv^T row-major)."""
+    _chk(XT, saved, zfT)
+    m = XT.shape[-1]
+    BH = XT.numel() // (m * m)
     bf = torch.bfloat16
-    if not (Xb.dtype == bf and saved.dtype == bf and zf.dtype == bf and Xb.is_contiguous() and saved.is_contiguous()
-            and zf.is_contiguous() and saved.numel() == iters * 4 * BH * m * m and zf.numel() == BH * m * m):
+    if not (XT.dtype == bf and saved.dtype == bf and zfT.dtype == bf and XT.is_contiguous() and saved.is_contiguous()
+            and zfT.is_contiguous() and saved.numel() == iters * 4 * BH * m * m and zfT.numel() == BH * m * m):
         raise MirrorHipError("pinv_chain_fwd: bad operands")
-    fn = lambda: _lib.call("mh_pinv_chain_fwd", _p(Xb), _p(saved), _p(zf), BH, m, iters, stream=_stream())  # noqa: E731
+    fn = lambda: _lib.call("mh_pinv_chain_fwd", _p(XT), _p(saved), _p(zfT), BH, m, iters, stream=_stream())  # noqa: E731
     if gemm_profiler is None:
         fn()
     else:
-        gemm_profiler.launch_named(f"pinv_chain_fwd_kernel<{m}>", iters * 4 * 2.0 * m ** 3 * BH, fn)
+        gemm_profiler.launch_named("pinv_panel_fwd_kernel", iters * 4 * 2.0 * m ** 3 * BH, fn)
 
 
-def pinv_chain_bwd(Xb, saved, dzf, work, dX, dz0, iters: int) -> None:
-    _chk(Xb, saved, dzf, work, dX, dz0)
-    m = Xb.shape[-1]
-    BH = Xb.numel() // (m * m)
+def pinv_chain_bwd(XT, saved, dzf, work, dX, dz0, iters: int) -> None:
+    """dzf = pinv_chain_pack(d z_iters).  dX / dz0: row-major f32 outputs."""
+    _chk(XT, saved, dzf, work, dX, dz0)
+    m = XT.shape[-1]
+    BH = XT.numel() // (m * m)
     bf = torch.bfloat16
-    if not (all(t.dtype == bf and t.is_contiguous() for t in (Xb, saved, dzf, work))
+    if not (all(t.dtype == bf and t.is_contiguous() for t in (XT, saved, dzf, work))
             and all(t.dtype == torch.float32 and t.is_contiguous() and t.numel() == BH * m * m for t in (dX, dz0))
             and saved.numel() == iters * 4 * BH * m * m and work.numel() == saved.numel() and dzf.numel() == BH * m * m):
         raise MirrorHipError("pinv_chain_bwd: bad operands")
-    fn = lambda: _lib.call("mh_pinv_chain_bwd", _p(Xb), _p(saved), _p(dzf), _p(work), _p(dX), _p(dz0), BH, m, iters,  # noqa: E731
+    fn = lambda: _lib.call("mh_pinv_chain_bwd", _p(XT), _p(saved), _p(dzf), _p(work), _p(dX), _p(dz0), BH, m, iters,  # noqa: E731
                            stream=_stream())
     if gemm_profiler is None:
         fn()
     else:
-        gemm_profiler.launch_named(f"pinv_chain_bwd_kernel<{m}>", iters * 8 * 2.0 * m ** 3 * BH, fn)
+        gemm_profiler.launch_named("pinv_panel_bwd_kernel", iters * 8 * 2.0 * m ** 3 * BH, fn)
 
 
 # ------------------------------------------------------------------ fused Nystrom attention sides (nystrom_fused.hip)

@@ -565,21 +565,33 @@ def test_skinny_fwd_wgrad_transpose(M, N, Kd):
 
 
 # --------------------------------------------------------------------------------------- fused pinv chain
-@pytest.mark.parametrize("m", [128, 256])
-def test_pinv_chain_matches_reference_iteration(m):
+@pytest.mark.parametrize("BH", [1, 3])
+def test_pinv_chain_matches_reference_iteration(BH):
     """One-launch Moore-Penrose chain (bf16 operands, f32 accumulate) vs the f64 iteration and its autograd."""
     from oracle import mirror_oracle as O
-    gen = g(m)
-    BH, iters = 3, 6
+    m = K.PINV_CHAIN_M
+    gen = g(m + BH)
+    iters = 6
     x = (torch.randn(1, BH, m, m, generator=gen) * 2).softmax(-1)
     xd = x.to(DEV)
     st = K.pinv_absmax(xd)
-    z0 = K.pinv_z0(xd, st)
     saved = torch.zeros((iters, 4, BH, m, m), device=DEV, dtype=torch.bfloat16)
-    K.cast(z0.reshape(BH, m, m), torch.bfloat16, out=saved[0, 0])
-    zf = torch.empty((BH, m, m), device=DEV, dtype=torch.bfloat16)
-    xb = K.cast(xd, torch.bfloat16)
-    K.pinv_chain_fwd(xb, saved, zf, iters)
+    z0, xb = K.pinv_chain_prep(xd, st, saved[0, 0])
+    close(z0, K.pinv_z0(xd, st).cpu(), 0, 1e-12, "prep z0")
+
+    def pn(M):      # panel-native layout of [BH, m, m] (include/mirror_hip.h)
+        it = torch.arange(m * m // 8)
+        lane, T, jblk = it & 63, (it >> 6) & 15, it >> 10
+        e = torch.arange(8)
+        i = (16 * T + 4 * (lane >> 5))[:, None] + (e & 3) + 8 * (e >> 2)
+        j = (32 * jblk + (lane & 31))[:, None].expand(-1, 8)
+        return M[:, i, j].reshape(M.shape[0], m, m)
+
+    close(xb.reshape(BH, m, m), pn(x[0].to(torch.bfloat16).float()), 0, 0, "prep PN(x)")
+    close(saved[0, 0], pn(z0.reshape(BH, m, m).cpu().to(torch.bfloat16).float()), 0, 0, "prep PN(z0)")
+    zfT = torch.empty((BH, m, m), device=DEV, dtype=torch.bfloat16)
+    K.pinv_chain_fwd(xb, saved, zfT, iters)
+    zf = zfT.transpose(-1, -2)
     xr = x.double().requires_grad_(True)
     ref = O.pinv_iter(xr, iters)
     scale = float(ref.abs().max())
@@ -591,7 +603,8 @@ def test_pinv_chain_matches_reference_iteration(m):
     work = torch.empty_like(saved)
     dX = torch.empty((BH, m, m), device=DEV)
     dz0 = torch.empty((BH, m, m), device=DEV)
-    K.pinv_chain_bwd(xb, saved, K.cast(G[0].float().to(DEV), torch.bfloat16), work, dX, dz0, iters)
+    K.pinv_chain_bwd(xb, saved, K.pinv_chain_pack(G[0].float().to(DEV)), work, dX, dz0, iters)
+    assert bool(torch.isfinite(dX).all()) and bool(torch.isfinite(dz0).all())
     K.pinv_z0_bwd(xd.reshape(BH, m, m), z0.reshape(BH, m, m), dz0, st, dX)
     got = dX.cpu().double()
     want = xr.grad[0]
