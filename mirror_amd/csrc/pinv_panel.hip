@@ -28,6 +28,10 @@
 //   stay 16-byte (the two halves swap when k1 = 1).
 #include "gemm_kernel.h"
 
+#ifndef EXP
+#define EXP 0
+#endif
+
 namespace {
 
 constexpr int CM = 256;        // matrix size
@@ -82,42 +86,71 @@ __device__ __forceinline__ void load_frags(bf16x8 (&af)[8], const char* img, con
     }
 }
 
-// acc[blk][jb] += A(rows 32 blk ..) . B panel (column block jb) over all 256 k.  The fragments of k-step T+1 are
-// requested before the 16 MFMAs of k-step T are issued (one wave per SIMD: nobody else hides the LDS latency).
-template <int T>
+// acc[blk][jb] (+)= A(rows 32 blk ..) . B panel (column block jb) over all 256 k.  The fragments of k-step T+1 are
+// requested ahead of the MFMAs of k-step T (one wave per SIMD: nobody else hides the LDS latency).
+// ZERO: the product starts a new sum (the first k-step takes a zero C instead of 256 accumulator writes).
+template <int T, bool ZERO>
 __device__ __forceinline__ void gemm_step(f32x16 (&acc)[8][NJ], bf16x8 (&cur)[8], bf16x8 (&nxt)[8], const char* img,
                                           const unsigned (&blo)[2][4], const unsigned (&bhi)[2][4], const bf16x8 (&pB)[16][NJ]) {
-    if constexpr (T + 1 < 16) load_frags<(T + 1) & 15>(nxt, img, blo, bhi);
-    __builtin_amdgcn_sched_barrier(0);
+    constexpr int TN = (T + 1) & 15, hs = TN >> 3;
+#ifndef GEMM_GROUP
+#define GEMM_GROUP 2      // row blocks whose next fragments are requested together (measured: 2 beats 1, 4 and 8)
+#endif
 #pragma unroll
-    for (int blk = 0; blk < 8; blk++)
+    for (int b0 = 0; b0 < 8; b0 += GEMM_GROUP) {
+        if constexpr (T + 1 < 16) {
 #pragma unroll
-        for (int jb = 0; jb < NJ; jb++) acc[blk][jb] = MFMA(cur[blk], pB[T][jb], acc[blk][jb]);
-    __builtin_amdgcn_sched_barrier(0);
+            for (int blk = b0; blk < b0 + GEMM_GROUP; blk++) {
+                const int off = (blk >> 2) * 256 + (TN & 7) * 8192;
+                s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + blo[hs][blk & 3] + off));
+                s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + bhi[hs][blk & 3] + off));
+                nxt[blk] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int blk = b0; blk < b0 + GEMM_GROUP; blk++)
+#pragma unroll
+            for (int jb = 0; jb < NJ; jb++) {
+                if (EXP == 1) { acc[blk][jb][0] += (float)cur[blk][0] + (float)pB[T][jb][0]; continue; }   // no MFMA, same data flow
+                if constexpr (ZERO && T == 0) {
+                    f32x16 z;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) z[r] = 0.f;
+                    acc[blk][jb] = MFMA(cur[blk], pB[T][jb], z);
+                } else {
+                    acc[blk][jb] = MFMA(cur[blk], pB[T][jb], acc[blk][jb]);
+                }
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
+template <bool ZERO>
 __device__ __forceinline__ void panel_gemm(f32x16 (&acc)[8][NJ], const char* img, const unsigned (&blo)[2][4],
                                            const unsigned (&bhi)[2][4], const bf16x8 (&pB)[16][NJ]) {
     bf16x8 f0[8], f1[8];
     load_frags<0>(f0, img, blo, bhi);
-    gemm_step<0>(acc, f0, f1, img, blo, bhi, pB);
-    gemm_step<1>(acc, f1, f0, img, blo, bhi, pB);
-    gemm_step<2>(acc, f0, f1, img, blo, bhi, pB);
-    gemm_step<3>(acc, f1, f0, img, blo, bhi, pB);
-    gemm_step<4>(acc, f0, f1, img, blo, bhi, pB);
-    gemm_step<5>(acc, f1, f0, img, blo, bhi, pB);
-    gemm_step<6>(acc, f0, f1, img, blo, bhi, pB);
-    gemm_step<7>(acc, f1, f0, img, blo, bhi, pB);
-    gemm_step<8>(acc, f0, f1, img, blo, bhi, pB);
-    gemm_step<9>(acc, f1, f0, img, blo, bhi, pB);
-    gemm_step<10>(acc, f0, f1, img, blo, bhi, pB);
-    gemm_step<11>(acc, f1, f0, img, blo, bhi, pB);
-    gemm_step<12>(acc, f0, f1, img, blo, bhi, pB);
-    gemm_step<13>(acc, f1, f0, img, blo, bhi, pB);
-    gemm_step<14>(acc, f0, f1, img, blo, bhi, pB);
-    gemm_step<15>(acc, f1, f0, img, blo, bhi, pB);
+    __builtin_amdgcn_sched_barrier(0);
+    gemm_step<0, ZERO>(acc, f0, f1, img, blo, bhi, pB);
+    gemm_step<1, ZERO>(acc, f1, f0, img, blo, bhi, pB);
+    gemm_step<2, ZERO>(acc, f0, f1, img, blo, bhi, pB);
+    gemm_step<3, ZERO>(acc, f1, f0, img, blo, bhi, pB);
+    gemm_step<4, ZERO>(acc, f0, f1, img, blo, bhi, pB);
+    gemm_step<5, ZERO>(acc, f1, f0, img, blo, bhi, pB);
+    gemm_step<6, ZERO>(acc, f0, f1, img, blo, bhi, pB);
+    gemm_step<7, ZERO>(acc, f1, f0, img, blo, bhi, pB);
+    gemm_step<8, ZERO>(acc, f0, f1, img, blo, bhi, pB);
+    gemm_step<9, ZERO>(acc, f1, f0, img, blo, bhi, pB);
+    gemm_step<10, ZERO>(acc, f0, f1, img, blo, bhi, pB);
+    gemm_step<11, ZERO>(acc, f1, f0, img, blo, bhi, pB);
+    gemm_step<12, ZERO>(acc, f0, f1, img, blo, bhi, pB);
+    gemm_step<13, ZERO>(acc, f1, f0, img, blo, bhi, pB);
+    gemm_step<14, ZERO>(acc, f0, f1, img, blo, bhi, pB);
+    gemm_step<15, ZERO>(acc, f1, f0, img, blo, bhi, pB);
 }
 
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[8][NJ]) {
+    if (EXP == 5) return;
 #pragma unroll
     for (int blk = 0; blk < 8; blk++)
 #pragma unroll
@@ -138,6 +171,17 @@ __device__ __forceinline__ void scale_acc(f32x16 (&acc)[8][NJ], float a) {
 template <bool HASR>
 __device__ __forceinline__ void finish(const f32x16 (&acc)[8][NJ], float alpha, float diag, const bf16x8 (&pR)[16][NJ],
                                        float rcoef, bf16x8 (&pO)[16][NJ], int wave, int dreg) {
+    if (EXP == 2) {   // experiment: no epilogue arithmetic
+#pragma unroll
+        for (int blk = 0; blk < 8; blk++)
+#pragma unroll
+            for (int jb = 0; jb < NJ; jb++) {
+                asm volatile("" ::"v"(acc[blk][jb][0]));
+                pO[2 * blk][jb] = pR[2 * blk][jb];
+                pO[2 * blk + 1][jb] = pR[2 * blk + 1][jb];
+            }
+        return;
+    }
 #pragma unroll
     for (int blk = 0; blk < 8; blk++)
 #pragma unroll
@@ -146,12 +190,15 @@ __device__ __forceinline__ void finish(const f32x16 (&acc)[8][NJ], float alpha, 
 #pragma unroll
             for (int t = 0; t < 2; t++) {
                 bf16x8 o;
+                u32x4 rw = __builtin_bit_cast(u32x4, pR[2 * blk + t][jb]);
+                // opaque: otherwise the f32 values are "remembered" from the epilogue that produced R and spilled
+                if constexpr (HASR) asm volatile("" : "+v"(rw));
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
                     const int r = 8 * t + e;
                     float v = alpha * acc[blk][jb][r];
                     if (r == dreg) v += dg;
-                    if constexpr (HASR) v += rcoef * (float)pR[2 * blk + t][jb][e];
+                    if constexpr (HASR) v += rcoef * __uint_as_float((e & 1) ? (rw[e >> 1] & 0xffff0000u) : (rw[e >> 1] << 16));
                     o[e] = (__bf16)v;
                 }
                 pO[2 * blk + t][jb] = o;
@@ -164,18 +211,21 @@ __device__ __forceinline__ void finish(const f32x16 (&acc)[8][NJ], float alpha, 
 // hl = lane >> 5) of column block jblk feeds to k-step T, i.e. M[16T + 4hl + {0..3}, 16T + 8 + 4hl + {0..3}][32 jblk + c]:
 // every panel load / store is one fully coalesced 16-byte access per lane.
 __device__ __forceinline__ void store_panel(bf16_t* __restrict__ G, const bf16x8 (&p)[16][NJ], int wave, int lane) {
+    if (EXP == 4) return;
+    asm volatile("" : "+v"(lane));
 #pragma unroll
     for (int jb = 0; jb < NJ; jb++)
 #pragma unroll
         for (int T = 0; T < 16; T++)
-            *reinterpret_cast<u32x4*>(G + ((((2 * wave + jb) * 16 + T) * 64 + lane) << 3)) = __builtin_bit_cast(u32x4, p[T][jb]);
+            *reinterpret_cast<u32x4*>(G + (((2 * wave + jb) * 16 + T) * 512) + (lane << 3)) = __builtin_bit_cast(u32x4, p[T][jb]);
 }
 __device__ __forceinline__ void load_panel(bf16x8 (&p)[16][NJ], const bf16_t* __restrict__ G, int wave, int lane) {
+    asm volatile("" : "+v"(lane));   // loop-invariant sources (X) would otherwise get 32 hoisted, spilled 64-bit pointers
 #pragma unroll
     for (int jb = 0; jb < NJ; jb++)
 #pragma unroll
         for (int T = 0; T < 16; T++)
-            p[T][jb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(G + ((((2 * wave + jb) * 16 + T) * 64 + lane) << 3)));
+            p[T][jb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(G + (((2 * wave + jb) * 16 + T) * 512) + (lane << 3)));
 }
 __device__ __forceinline__ void negate_panel(bf16x8 (&p)[16][NJ]) {
 #pragma unroll
@@ -189,6 +239,7 @@ __device__ __forceinline__ void negate_panel(bf16x8 (&p)[16][NJ]) {
 }
 // f32 column-major store of alpha * acc (i.e. row-major of the transposed matrix)
 __device__ __forceinline__ void store_f32(float* __restrict__ G, const f32x16 (&acc)[8][NJ], float alpha, int j0, int hl) {
+    asm volatile("" : "+v"(j0), "+v"(hl));
 #pragma unroll
     for (int jb = 0; jb < NJ; jb++) {
         float* row = G + (long)(j0 + 32 * jb) * CM + 4 * hl;
@@ -207,7 +258,7 @@ __device__ __forceinline__ void store_f32(float* __restrict__ G, const f32x16 (&
 
 // panels -> LDS image (image row j = this lane's column)
 __device__ __forceinline__ void image_from_panel(char* img, const bf16x8 (&p)[16][NJ], int j0, int hl) {
-    asm volatile("" : "+v"(j0));   // keep the swizzled addresses out of loop-invariant hoisting (they would be spilled)
+    asm volatile("" : "+v"(j0), "+v"(hl));   // keep the swizzled addresses out of loop-invariant hoisting (they would be spilled)
     const int s = swz(j0);         // bits 0..3 of the column only: the same for both column blocks
 #pragma unroll
     for (int jb = 0; jb < NJ; jb++) {
@@ -224,6 +275,7 @@ __device__ __forceinline__ void image_from_panel(char* img, const bf16x8 (&p)[16
 // live).  Item it = tid + 256 n is lane (tid & 63) of k-step wave + 4 (n & 3) of column block n >> 2.
 template <int BATCH>
 __device__ __forceinline__ void image_from_global(char* img, const bf16_t* __restrict__ G, int tid) {
+    if (EXP == 3) return;
     asm volatile("" : "+v"(tid));   // recompute the addresses at every call instead of hoisting + spilling them
     const int lane = tid & 63, c = lane & 31, hl = lane >> 5, s = swz(c), tw = tid >> 6;
 #pragma unroll
@@ -242,6 +294,7 @@ __device__ __forceinline__ void image_from_global(char* img, const bf16_t* __res
 }
 // LDS image -> column-major HBM matrix G[j][i] (row copy, coalesced): the form the caller's GEMMs read
 __device__ __forceinline__ void image_to_global(const char* img, bf16_t* __restrict__ G, int tid) {
+    asm volatile("" : "+v"(tid));
 #pragma unroll
     for (int n = 0; n < NCH; n++) {
         const int cid = tid + CT * n, k = cid >> 5, c16 = cid & 31, s = swz(k);
@@ -264,15 +317,17 @@ __device__ __forceinline__ void publish() {
 __global__ __launch_bounds__(CT) void pinv_panel_fwd_kernel(const bf16_t* __restrict__ XT, bf16_t* __restrict__ saved,
                                                             bf16_t* __restrict__ zfT, int BH, int iters) {
     __shared__ __attribute__((aligned(16))) char img[IMG];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 5, j = 64 * wave + (lane & 31);
+    const int tid = threadIdx.x, lane = tid & 63, hl = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: panel addresses become SGPR base + one VGPR
+    const int j = 64 * wave + (lane & 31);
     const int bh = blockIdx.x;
     const int dreg = (hl == ((lane >> 2) & 1)) ? ((((lane & 31) >> 3) << 2) | (lane & 3)) : -1;
     unsigned rlo[2][4], rhi[2][4];
     read_bases(rlo, rhi, lane);
     const bf16_t* Xb = XT + bh * MAT;
     f32x16 acc[8][NJ];
-    bf16x8 pa[16][NJ], pb[16][NJ];
-    load_panel(pa, saved + bh * MAT, wave, lane);                              // z_0
+    bf16x8 p[16][NJ];       // THE panel: B operand of the running product, then (in place) its result
+    load_panel(p, saved + bh * MAT, wave, lane);                           // z_0
     image_from_global<16>(img, Xb, tid);
     __syncthreads();
 #pragma unroll 1
@@ -281,39 +336,33 @@ __global__ __launch_bounds__(CT) void pinv_panel_fwd_kernel(const bf16_t* __rest
         bf16_t* P = base + (long)BH * MAT;
         bf16_t* T2 = base + 2L * BH * MAT;
         bf16_t* T3 = base + 3L * BH * MAT;
-        zero_acc(acc);
-        panel_gemm(acc, img, rlo, rhi, pa);                               // P = X z
-        finish<false>(acc, 1.f, 0.f, pa, 0.f, pb, wave, dreg);
-        store_panel(P, pb, wave, lane);
+        panel_gemm<true>(acc, img, rlo, rhi, p);                                // P = X z
+        finish<false>(acc, 1.f, 0.f, p, 0.f, p, wave, dreg);
+        store_panel(P, p, wave, lane);
         __syncthreads();
-        image_from_panel(img, pb, j, hl);
+        image_from_panel(img, p, j, hl);
         __syncthreads();
-        zero_acc(acc);
-        panel_gemm(acc, img, rlo, rhi, pb);                               // T2 = 15I - 7P + P P
-        finish<true>(acc, 1.f, 15.f, pb, -7.f, pa, wave, dreg);
-        store_panel(T2, pa, wave, lane);
-        zero_acc(acc);
-        panel_gemm(acc, img, rlo, rhi, pa);                               // T3 = 13I - P T2
-        finish<false>(acc, -1.f, 13.f, pa, 0.f, pb, wave, dreg);
-        store_panel(T3, pb, wave, lane);
+        panel_gemm<true>(acc, img, rlo, rhi, p);                                // T2 = 15I - 7P + P P
+        finish<true>(acc, 1.f, 15.f, p, -7.f, p, wave, dreg);
+        store_panel(T2, p, wave, lane);
+        panel_gemm<true>(acc, img, rlo, rhi, p);                                // T3 = 13I - P T2
+        finish<false>(acc, -1.f, 13.f, p, 0.f, p, wave, dreg);
+        store_panel(T3, p, wave, lane);
         publish();
         image_from_global<16>(img, base, tid);                            // z_k (written by this workgroup one step ago)
         __syncthreads();
-        zero_acc(acc);
-        panel_gemm(acc, img, rlo, rhi, pb);                               // z' = 1/4 z T3
-        finish<false>(acc, 0.25f, 0.f, pb, 0.f, pa, wave, dreg);
+        panel_gemm<true>(acc, img, rlo, rhi, p);                                // z' = 1/4 z T3
+        finish<false>(acc, 0.25f, 0.f, p, 0.f, p, wave, dreg);
         if (k + 1 < iters) {
-            store_panel(saved + ((long)(k + 1) * 4 * BH + bh) * MAT, pa, wave, lane);
+            store_panel(saved + ((long)(k + 1) * 4 * BH + bh) * MAT, p, wave, lane);
             publish();
             image_from_global<16>(img, Xb, tid);
-            __syncthreads();
-        } else {                                                           // z_iters leaves column-major, via the image
-            __syncthreads();
-            image_from_panel(img, pa, j, hl);
-            __syncthreads();
-            image_to_global(img, zfT + bh * MAT, tid);
         }
+        __syncthreads();
     }
+    image_from_panel(img, p, j, hl);                                      // z_iters leaves column-major, via the image
+    __syncthreads();
+    image_to_global(img, zfT + bh * MAT, tid);
 }
 
 // --------------------------------------------------------------------------------------------------------- backward
@@ -323,14 +372,16 @@ __global__ __launch_bounds__(CT) void pinv_panel_bwd_kernel(const bf16_t* __rest
                                                             const bf16_t* __restrict__ dzf, bf16_t* __restrict__ work,
                                                             float* __restrict__ dX, float* __restrict__ dz0, int BH, int iters) {
     __shared__ __attribute__((aligned(16))) char img[IMG];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 5, j = 64 * wave + (lane & 31);
+    const int tid = threadIdx.x, lane = tid & 63, hl = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: panel addresses become SGPR base + one VGPR
+    const int j = 64 * wave + (lane & 31);
     const int bh = blockIdx.x;
     const int dreg = (hl == ((lane >> 2) & 1)) ? ((((lane & 31) >> 3) << 2) | (lane & 3)) : -1;
     unsigned rlo[2][4], rhi[2][4];
     read_bases(rlo, rhi, lane);
     const bf16_t* Xb = XT + bh * MAT;
     f32x16 acc[8][NJ];
-    bf16x8 pa[16][NJ], pb[16][NJ];
+    bf16x8 p[16][NJ];       // one panel at a time besides the accumulators: reload from HBM (coalesced) rather than hold
     const bf16_t* U = dzf + bh * MAT;
     image_from_global<16>(img, U, tid);
     __syncthreads();
@@ -347,63 +398,67 @@ __global__ __launch_bounds__(CT) void pinv_panel_bwd_kernel(const bf16_t* __rest
         bf16_t* W = wb + 2L * BH * MAT;
         bf16_t* Un = wb + 3L * BH * MAT;
         // V3 = 1/4 U Z                                                   (image: U)
-        load_panel(pa, Z, wave, lane);
-        zero_acc(acc);
-        panel_gemm(acc, img, rlo, rhi, pa);
-        finish<false>(acc, 0.25f, 0.f, pa, 0.f, pb, wave, dreg);
-        store_panel(V3, pb, wave, lane);
+        load_panel(p, Z, wave, lane);
+        panel_gemm<true>(acc, img, rlo, rhi, p);
+        finish<false>(acc, 0.25f, 0.f, p, 0.f, p, wave, dreg);
+        store_panel(V3, p, wave, lane);
         __syncthreads();
-        image_from_panel(img, pb, j, hl);
+        image_from_panel(img, p, j, hl);
         __syncthreads();
         // V2 = -V3 P                                                     (image: V3)
-        load_panel(pa, P, wave, lane);
-        zero_acc(acc);
-        panel_gemm(acc, img, rlo, rhi, pa);
-        finish<false>(acc, -1.f, 0.f, pa, 0.f, pb, wave, dreg);
-        store_panel(V2, pb, wave, lane);
+        load_panel(p, P, wave, lane);
+        panel_gemm<true>(acc, img, rlo, rhi, p);
+        finish<false>(acc, -1.f, 0.f, p, 0.f, p, wave, dreg);
+        store_panel(V2, p, wave, lane);
         __syncthreads();
-        image_from_panel(img, pb, j, hl);
+        image_from_panel(img, p, j, hl);
         __syncthreads();
-        // W = V2 P - 7 V2 + P V2 - T2 V3      (one panel besides the accumulators at any time: reload, do not hold)
-        zero_acc(acc);
-        panel_gemm(acc, img, rlo, rhi, pa);                               // V2 P   (image: V2, panel: P)
+        // W = V2 P - 7 V2 + P V2 - T2 V3
+        load_panel(p, P, wave, lane);
+        panel_gemm<true>(acc, img, rlo, rhi, p);                                // V2 P   (image: V2, panel: P)
         publish();                                                         // V3 / V2 stores of this step are visible
         image_from_global<8>(img, P, tid);
-        load_panel(pb, V2, wave, lane);
+        load_panel(p, V2, wave, lane);
 #pragma unroll
         for (int blk = 0; blk < 8; blk++)
 #pragma unroll
-            for (int jb = 0; jb < NJ; jb++)
+            for (int jb = 0; jb < NJ; jb++) {
 #pragma unroll
-                for (int r = 0; r < 16; r++) acc[blk][jb][r] -= 7.f * (float)pb[2 * blk + (r >> 3)][jb][r & 7];
+                for (int t = 0; t < 2; t++) {
+                    u32x4 rw = __builtin_bit_cast(u32x4, p[2 * blk + t][jb]);
+#pragma unroll
+                    for (int e = 0; e < 8; e++)
+                        acc[blk][jb][8 * t + e] -= 7.f * __uint_as_float((e & 1) ? (rw[e >> 1] & 0xffff0000u) : (rw[e >> 1] << 16));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         __syncthreads();
-        panel_gemm(acc, img, rlo, rhi, pb);                               // + P V2 (image: P, panel: V2)
+        panel_gemm<false>(acc, img, rlo, rhi, p);                                // + P V2 (image: P, panel: V2)
         __syncthreads();
         image_from_global<8>(img, T2, tid);
-        load_panel(pa, V3, wave, lane);
-        negate_panel(pa);
+        load_panel(p, V3, wave, lane);
+        negate_panel(p);
         __syncthreads();
-        panel_gemm(acc, img, rlo, rhi, pa);                               // - T2 V3
-        finish<false>(acc, 1.f, 0.f, pa, 0.f, pb, wave, dreg);
-        store_panel(W, pb, wave, lane);
+        panel_gemm<false>(acc, img, rlo, rhi, p);                                // - T2 V3
+        finish<false>(acc, 1.f, 0.f, p, 0.f, p, wave, dreg);
+        store_panel(W, p, wave, lane);
         __syncthreads();
-        image_from_panel(img, pb, j, hl);
+        image_from_panel(img, p, j, hl);
         __syncthreads();
         // U' = W X + 1/4 T3 U  =  1/4 (4 W X + T3 U)
-        load_panel(pa, Xb, wave, lane);
-        zero_acc(acc);
-        panel_gemm(acc, img, rlo, rhi, pa);                               // W X    (image: W, panel: X)
+        load_panel(p, Xb, wave, lane);
+        panel_gemm<true>(acc, img, rlo, rhi, p);                                // W X    (image: W, panel: X)
         scale_acc(acc, 4.f);
         publish();                                                         // U stores of the previous step are visible
         image_from_global<8>(img, T3, tid);
-        load_panel(pa, U, wave, lane);
+        load_panel(p, U, wave, lane);
         __syncthreads();
-        panel_gemm(acc, img, rlo, rhi, pa);                               // + T3 U
-        finish<false>(acc, 0.25f, 0.f, pa, 0.f, pb, wave, dreg);
-        store_panel(Un, pb, wave, lane);
+        panel_gemm<false>(acc, img, rlo, rhi, p);                                // + T3 U
+        finish<false>(acc, 0.25f, 0.f, p, 0.f, p, wave, dreg);
+        store_panel(Un, p, wave, lane);
         if (k == 0) store_f32(dz0 + bh * MAT, acc, 0.25f, j, hl);
         __syncthreads();
-        image_from_panel(img, pb, j, hl);                                 // next step's U
+        image_from_panel(img, p, j, hl);                                  // next step's U
         __syncthreads();
         U = Un;
     }
@@ -416,9 +471,9 @@ __global__ __launch_bounds__(CT) void pinv_panel_bwd_kernel(const bf16_t* __rest
         const bf16_t* W = work + ((long)k * 4 * BH + bh) * MAT + 2L * BH * MAT;
         __syncthreads();
         image_from_global<8>(img, Z, tid);
-        load_panel(pa, W, wave, lane);
+        load_panel(p, W, wave, lane);
         __syncthreads();
-        panel_gemm(acc, img, rlo, rhi, pa);
+        panel_gemm<false>(acc, img, rlo, rhi, p);
     }
     store_f32(dX + bh * MAT, acc, 1.f, j, hl);
 }
