@@ -1,0 +1,183 @@
+// Large-tile variant of the bf16 MFMA GEMM: 256 x 256 x 64 block tile, 512 threads = 8 waves (2 x 4), wave tile
+// 128 x 64 (4 x 2 MFMA blocks, 128 accumulator registers), two waves per SIMD.
+//
+// Why: the projection / weight-gradient GEMMs of the step are long and thin (M = 69632, K = 512..1536).  With 128 x 128
+// tiles every MFMA flop pulls (BM + BN) / (BM BN) = 1/64 byte through L2 -> LDS, i.e. ~39 TB/s at the 2.5 PFLOP/s
+// peak — more than the fabric delivers; 256 x 256 tiles halve that, and halve the LDS fragment reads per MFMA as well
+// (6 fragment reads feed 8 MFMAs instead of 4 feeding 4).  Same staging scheme as gemm_kernel (global -> registers
+// one K-tile ahead -> double-buffered LDS, ds_read_b64_tr_b16 for K-strided operands), 144 KiB of LDS.
+// Used by gemm_launch_bf16 when M, N are multiples of 256, K of 64, and the operands are 16-byte aligned.
+#include "gemm_kernel.h"
+
+namespace {
+
+constexpr int BIG = 256, NTB = 512, BWM = 4, BWN = 2;
+
+// accumulators -> f32 LDS tile [128][260] (one half of the rows at a time) -> 16-byte row-contiguous stores
+template <typename TC, int MODE>
+__device__ __forceinline__ void epilogue_big(const GemmArgs& g, TC* C, f32x16 (&acc)[BWM][BWN], char* smem, int tile_row0,
+                                             int tile_col0, int wm, int wn, int lane, int tid, bool lead) {
+    constexpr int PITCH = BIG + 4, HALF = BIG / 2;
+    float* t = reinterpret_cast<float*>(smem);
+    const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        if (wm == half) {
+#pragma unroll
+            for (int j = 0; j < BWN; j++) {
+                const int lc = wn * BWN * 32 + j * 32 + r;
+                const float bias = (g.bias && lead) ? g.bias[tile_col0 + lc] : 0.f;
+#pragma unroll
+                for (int i = 0; i < BWM; i++) {
+                    const int lr0 = i * 32 + 4 * hh;
+#pragma unroll
+                    for (int reg = 0; reg < 16; reg++) {
+                        const int lr = lr0 + (reg & 3) + 8 * (reg >> 2);
+                        float v = g.alpha * acc[i][j][reg] + bias;
+                        if (g.act == MH_ACT_RELU) v = fmaxf(v, 0.f);
+                        t[lr * PITCH + lc] = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        constexpr int EPC = 16 / (int)sizeof(TC);
+        constexpr int CPR = BIG / EPC;
+        constexpr int NCH = HALF * CPR / NTB;
+#pragma unroll
+        for (int i = 0; i < NCH; i++) {
+            const int cid = tid + i * NTB;
+            const int lr = cid / CPR, c = cid % CPR;
+            const float* src = t + lr * PITCH + c * EPC;
+            TC* dst = C + (long)(tile_row0 + half * HALF + lr) * g.ldc + tile_col0 + c * EPC;
+            f32x4 x0 = *reinterpret_cast<const f32x4*>(src);
+            u32x4 o;
+            if constexpr (sizeof(TC) == 4) {
+                if constexpr (MODE == 1) x0 += *reinterpret_cast<const f32x4*>(dst);
+                o[0] = __float_as_uint(x0[0]); o[1] = __float_as_uint(x0[1]);
+                o[2] = __float_as_uint(x0[2]); o[3] = __float_as_uint(x0[3]);
+            } else {
+                f32x4 x1 = *reinterpret_cast<const f32x4*>(src + 4);
+                if constexpr (MODE == 1) {
+                    const u32x4 old = *reinterpret_cast<const u32x4*>(dst);
+                    x0[0] += __uint_as_float(old[0] << 16); x0[1] += __uint_as_float(old[0] & 0xffff0000u);
+                    x0[2] += __uint_as_float(old[1] << 16); x0[3] += __uint_as_float(old[1] & 0xffff0000u);
+                    x1[0] += __uint_as_float(old[2] << 16); x1[1] += __uint_as_float(old[2] & 0xffff0000u);
+                    x1[2] += __uint_as_float(old[3] << 16); x1[3] += __uint_as_float(old[3] & 0xffff0000u);
+                }
+                o[0] = (unsigned)f2bf(x0[0]) | ((unsigned)f2bf(x0[1]) << 16);
+                o[1] = (unsigned)f2bf(x0[2]) | ((unsigned)f2bf(x0[3]) << 16);
+                o[2] = (unsigned)f2bf(x1[0]) | ((unsigned)f2bf(x1[1]) << 16);
+                o[3] = (unsigned)f2bf(x1[2]) | ((unsigned)f2bf(x1[3]) << 16);
+            }
+            *reinterpret_cast<u32x4*>(dst) = o;
+        }
+        __syncthreads();
+    }
+}
+
+template <typename TC, bool AKC, bool BKC>
+__global__ __launch_bounds__(NTB) void gemm_big_kernel(GemmArgs g) {
+    using GA = TileGeom<1, AKC, BIG>;
+    using GB = TileGeom<1, BKC, BIG>;
+    constexpr int BK = 64;
+    constexpr int STAGE = GA::BYTES + GB::BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    static_assert((BIG / 2) * (BIG + 4) * 4 <= 2 * STAGE, "epilogue half tile must fit the staging LDS");
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nwg = gridDim.x;
+    const int xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    const int tile_m = wgid / g.tiles_n, tile_n = wgid % g.tiles_n;
+    const int z = blockIdx.z;
+    const int b1 = z / g.batch2, b2 = z % g.batch2;
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A) + b1 * g.sA1 + b2 * g.sA2;
+    const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B) + b1 * g.sB1 + b2 * g.sB2;
+    TC* C = reinterpret_cast<TC*>(g.C) + b1 * g.sC1 + b2 * g.sC2;
+    const int split = blockIdx.y;
+    const int kbeg = split * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+    const int nt = (kend - kbeg) / BK;
+
+    f32x16 acc[BWM][BWN];
+#pragma unroll
+    for (int i = 0; i < BWM; i++)
+#pragma unroll
+        for (int j = 0; j < BWN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    using SA = Stager<1, bf16_t, AKC, BIG, true, NTB>;
+    using SB = Stager<1, bf16_t, BKC, BIG, true, NTB>;
+    u32x4 ra[SA::NCH], rb[SB::NCH];
+    if (nt > 0) {
+        SA::load(ra, A, g.lda, tile_m * BIG, g.M, kbeg, kend, true, tid);
+        SB::load(rb, B, g.ldb, tile_n * BIG, g.N, kbeg, kend, true, tid);
+        SA::store(ra, smem, tid);
+        SB::store(rb, smem + GA::BYTES, tid);
+    }
+    __syncthreads();
+    for (int t = 0; t < nt; t++) {
+        const int cur = t & 1;
+        const bool more = (t + 1 < nt);
+        if (more) {
+            const int k0 = kbeg + (t + 1) * BK;
+            SA::load(ra, A, g.lda, tile_m * BIG, g.M, k0, kend, true, tid);
+            SB::load(rb, B, g.ldb, tile_n * BIG, g.N, k0, kend, true, tid);
+        }
+        const char* at = smem + cur * STAGE;
+        const char* bt = at + GA::BYTES;
+#pragma unroll
+        for (int ks = 0; ks < BK; ks += 16) {
+            bf16x8 af[BWM], bfr[BWN];
+#pragma unroll
+            for (int i = 0; i < BWM; i++) af[i] = frag_bf16<AKC, BIG>(at, wm * BWM * 32 + i * 32, ks, lane);
+#pragma unroll
+            for (int j = 0; j < BWN; j++) bfr[j] = frag_bf16<BKC, BIG>(bt, wn * BWN * 32 + j * 32, ks, lane);
+#pragma unroll
+            for (int i = 0; i < BWM; i++)
+#pragma unroll
+                for (int j = 0; j < BWN; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            SA::store(ra, smem + (cur ^ 1) * STAGE, tid);
+            SB::store(rb, smem + (cur ^ 1) * STAGE + GA::BYTES, tid);
+        }
+        __syncthreads();
+    }
+    const bool lead = (split == 0);
+    if (g.atomic) {
+        epilogue<TC, BWM, BWN, true, 2>(g, C, nullptr, acc, tile_m * BIG + wm * BWM * 32, tile_n * BIG + wn * BWN * 32, lane, lead);
+    } else if (g.accumulate) {
+        epilogue_big<TC, 1>(g, C, acc, smem, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, lead);
+    } else {
+        epilogue_big<TC, 0>(g, C, acc, smem, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, lead);
+    }
+}
+
+template <typename TC>
+void launch_big(GemmArgs& a, int akc, int bkc, int batch, hipStream_t s) {
+    a.tiles_m = a.M / BIG;
+    a.tiles_n = a.N / BIG;
+    dim3 grid(a.tiles_m * a.tiles_n, a.split_k, batch);
+    if (akc && bkc) hipLaunchKernelGGL((gemm_big_kernel<TC, true, true>), grid, dim3(NTB), 0, s, a);
+    else if (akc) hipLaunchKernelGGL((gemm_big_kernel<TC, true, false>), grid, dim3(NTB), 0, s, a);
+    else if (bkc) hipLaunchKernelGGL((gemm_big_kernel<TC, false, true>), grid, dim3(NTB), 0, s, a);
+    else hipLaunchKernelGGL((gemm_big_kernel<TC, false, false>), grid, dim3(NTB), 0, s, a);
+}
+
+}  // namespace
+
+// true when the large-tile kernel took the launch
+bool gemm_try_big_bf16(GemmArgs& a, int akc, int bkc, int dtC, int batch, hipStream_t s) {
+    const bool shape_ok = a.M % BIG == 0 && a.N % BIG == 0 && a.K % 64 == 0 && a.k_per_split % 64 == 0;
+    if (!shape_ok || !a.vecA || !a.vecB || !a.vecC || a.R || a.diag != 0.f) return false;
+    const long wgs = (long)(a.M / BIG) * (a.N / BIG) * a.split_k * batch;
+    if (wgs < 128) return false;            // too few workgroups for one per CU: the 128 x 128 kernel spreads better
+    if (dtC == MH_BF16) launch_big<bf16_t>(a, akc, bkc, batch, s);
+    else launch_big<float>(a, akc, bkc, batch, s);
+    return true;
+}

@@ -123,10 +123,11 @@ def _gret(param: torch.Tensor, buf: torch.Tensor, via_sink: bool):
     return buf
 
 
-def _split_k_for(rows: int, n: int, k: int) -> int:
-    """Weight-gradient GEMMs have a huge contraction (rows) and few output tiles: split K to fill 256 CUs."""
+def _split_k_for(rows: int, n: int, k: int, batch: int = 1) -> int:
+    """Weight-gradient GEMMs have a huge contraction (rows) and few output tiles: split K to fill 256 CUs.  A batch
+    that reduces into the same dW already multiplies the workgroups (and the f32 atomics: 64 KiB per tile each)."""
     tiles = ((n + 127) // 128) * ((k + 127) // 128)
-    want = max(1, 1024 // max(tiles, 1))
+    want = max(1, 1024 // max(tiles * batch, 1))
     return int(max(1, min(want, rows // 256)))
 
 
@@ -195,7 +196,7 @@ def _wgrad(dy: torch.Tensor, x: torch.Tensor, N: int, Kd: int, prec: Precision, 
         K.gemm(dy.t(), x, out=dw, accumulate=True, split_k=_split_k_for(dy.shape[0], N, Kd), mma=prec.mma)
     else:  # batched window: every batch reduces into the same dW (atomics)
         K.gemm(dy.transpose(-1, -2), x, out=dw.expand(*dy.shape[:-2], N, Kd), accumulate=True,
-               split_k=_split_k_for(dy.shape[-2], N, Kd), mma=prec.mma)
+               split_k=_split_k_for(dy.shape[-2], N, Kd, batch=dy.numel() // (dy.shape[-2] * N)), mma=prec.mma)
     return dw
 
 

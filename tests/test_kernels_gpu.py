@@ -70,6 +70,32 @@ def test_gemm_layouts_dtypes_tails(mma, dtype, out_dtype, a_rm, b_t, M, N, Kd):
         close(out, ref, 2e-5, 2e-5 * math.sqrt(Kd), "f32 gemm")
 
 
+@pytest.mark.parametrize("a_rm,b_t", LAYOUTS)
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+def test_gemm_large_tile_kernel(a_rm, b_t, out_dtype):
+    """256 x 256 tiles (gemm_big.hip) take bf16 problems with M, N % 256 == 0: all layouts, batch, bias + ReLU,
+    read-modify-write accumulate and split-K atomics, bit-exact on small integers."""
+    gen = g(77 + a_rm + 2 * b_t)
+    Bt, M, N, Kd = 3, 512, 768, 320
+    bf = torch.bfloat16
+    a_dev, a = _mk(a_rm, (Bt, M, Kd), gen, bf, True)
+    b_dev, b = _mk(not b_t, (Bt, Kd, N), gen, bf, True)
+    bias = ints((N,), gen)
+    ref = a.double() @ b.double()
+    out = K.gemm(a_dev, b_dev, mma=MH_BF16, out_dtype=out_dtype)
+    close(out, ref.float().to(out_dtype).double(), 0, 0, "large tile plain")
+    out = K.gemm(a_dev, b_dev, bias=bias.to(DEV), act=ACT_RELU, alpha=0.5, mma=MH_BF16, out_dtype=out_dtype)
+    close(out, torch.relu(0.5 * ref + bias.double()).float().to(out_dtype).double(), 0, 0, "large tile bias+relu")
+    base = ints((Bt, M, N), gen)
+    acc = base.to(DEV, out_dtype)
+    K.gemm(a_dev, b_dev, out=acc, accumulate=True, mma=MH_BF16)
+    close(acc, (ref + base.double()).float().to(out_dtype).double(), 0, 0, "large tile accumulate")
+    if out_dtype == torch.float32:
+        dw = base[0].to(DEV).contiguous()
+        K.gemm(a_dev, b_dev, out=dw.expand(Bt, M, N), accumulate=True, split_k=3, mma=MH_BF16)   # batch broadcast + split-K
+        close(dw, ref.sum(0) + base[0].double(), 0, 0, "large tile split-K atomics")
+
+
 @pytest.mark.parametrize("mma,dtype", [(MH_F32, torch.float32), (MH_BF16, torch.bfloat16)])
 def test_gemm_batched_strided_views(mma, dtype):
     """The Nystrom use: heads are column slices of a [B, n, 3D] buffer; output written into a [B, n, D] view."""
