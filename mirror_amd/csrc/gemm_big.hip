@@ -112,20 +112,30 @@ __global__ __launch_bounds__(NTB) void gemm_big_kernel(GemmArgs g) {
     using SA = Stager<1, bf16_t, AKC, BIG, true, NTB>;
     using SB = Stager<1, bf16_t, BKC, BIG, true, NTB>;
     u32x4 ra[SA::NCH], rb[SB::NCH];
+    // One register set, written to LDS right AFTER the barrier that frees the other stage and re-issued at once: the
+    // ds_write pass (~80 B/clk per CU, ~800 cycles per K-tile) then drains under the MFMAs of the current tile instead
+    // of sitting between the last MFMA and the barrier (8192^3: 732 -> 1094 TFLOP/s).
     if (nt > 0) {
         SA::load(ra, A, g.lda, tile_m * BIG, g.M, kbeg, kend, true, tid);
         SB::load(rb, B, g.ldb, tile_n * BIG, g.N, kbeg, kend, true, tid);
         SA::store(ra, smem, tid);
         SB::store(rb, smem + GA::BYTES, tid);
+        if (nt > 1) {
+            SA::load(ra, A, g.lda, tile_m * BIG, g.M, kbeg + BK, kend, true, tid);
+            SB::load(rb, B, g.ldb, tile_n * BIG, g.N, kbeg + BK, kend, true, tid);
+        }
     }
     __syncthreads();
     for (int t = 0; t < nt; t++) {
         const int cur = t & 1;
-        const bool more = (t + 1 < nt);
-        if (more) {
-            const int k0 = kbeg + (t + 1) * BK;
-            SA::load(ra, A, g.lda, tile_m * BIG, g.M, k0, kend, true, tid);
-            SB::load(rb, B, g.ldb, tile_n * BIG, g.N, k0, kend, true, tid);
+        if (t + 1 < nt) {
+            SA::store(ra, smem + (cur ^ 1) * STAGE, tid);
+            SB::store(rb, smem + (cur ^ 1) * STAGE + GA::BYTES, tid);
+            if (t + 2 < nt) {
+                const int k0 = kbeg + (t + 2) * BK;
+                SA::load(ra, A, g.lda, tile_m * BIG, g.M, k0, kend, true, tid);
+                SB::load(rb, B, g.ldb, tile_n * BIG, g.N, k0, kend, true, tid);
+            }
         }
         const char* at = smem + cur * STAGE;
         const char* bt = at + GA::BYTES;
@@ -141,10 +151,6 @@ __global__ __launch_bounds__(NTB) void gemm_big_kernel(GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < BWN; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        }
-        if (more) {
-            SA::store(ra, smem + (cur ^ 1) * STAGE, tid);
-            SB::store(rb, smem + (cur ^ 1) * STAGE + GA::BYTES, tid);
         }
         __syncthreads();
     }

@@ -300,21 +300,30 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     using SA = Stager<MMA, TA, AKC, BM, FULL>;
     using SB = Stager<MMA, TB, BKC, BN, FULL>;
     u32x4 ra[SA::NCH], rb[SB::NCH];
+    // One register set: K-tile t+1 is written to LDS right AFTER the barrier that frees its stage and tile t+2 is
+    // requested at once, so the ds_write pass drains under the MFMAs of tile t (not between the last MFMA and the barrier).
     if (nt > 0) {
         SA::load(ra, A, g.lda, tile_m * BM, g.M, kbeg, kend, g.vecA, tid);
         SB::load(rb, B, g.ldb, tile_n * BN, g.N, kbeg, kend, g.vecB, tid);
         SA::store(ra, smem, tid);
         SB::store(rb, smem + GA::BYTES, tid);
+        if (nt > 1) {
+            SA::load(ra, A, g.lda, tile_m * BM, g.M, kbeg + BK, kend, g.vecA, tid);
+            SB::load(rb, B, g.ldb, tile_n * BN, g.N, kbeg + BK, kend, g.vecB, tid);
+        }
     }
     __syncthreads();
 
     for (int t = 0; t < nt; t++) {
         const int cur = t & 1;
-        const bool more = (t + 1 < nt);
-        if (more) {
-            const int k0 = kbeg + (t + 1) * BK;
-            SA::load(ra, A, g.lda, tile_m * BM, g.M, k0, kend, g.vecA, tid);
-            SB::load(rb, B, g.ldb, tile_n * BN, g.N, k0, kend, g.vecB, tid);
+        if (t + 1 < nt) {
+            SA::store(ra, smem + (cur ^ 1) * STAGE, tid);
+            SB::store(rb, smem + (cur ^ 1) * STAGE + GA::BYTES, tid);
+            if (t + 2 < nt) {
+                const int k0 = kbeg + (t + 2) * BK;
+                SA::load(ra, A, g.lda, tile_m * BM, g.M, k0, kend, g.vecA, tid);
+                SB::load(rb, B, g.ldb, tile_n * BN, g.N, k0, kend, g.vecB, tid);
+            }
         }
         const char* at = smem + cur * STAGE;
         const char* bt = at + GA::BYTES;
@@ -345,10 +354,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
                     for (int j = 0; j < WN; j++)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bfr[j][s], acc[i][j], 0, 0, 0);
-        }
-        if (more) {
-            SA::store(ra, smem + (cur ^ 1) * STAGE, tid);
-            SB::store(rb, smem + (cur ^ 1) * STAGE + GA::BYTES, tid);
         }
         __syncthreads();
     }
