@@ -83,11 +83,13 @@ int mh_transpose_bf16_many(const void* src, void* dst, const int64_t* table, int
 int mh_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                      int batches, int rows_per_batch, int D, int64_t x_bs, int64_t y_bs, float eps,
                      int dt_x, int dt_y, mh_stream s);
-/* dx = d/dx, dgamma/dbeta accumulated with f32 atomics (caller zeroes them). dy uses y's addressing. */
+/* dx = d/dx, dgamma/dbeta accumulated (+=, f32; caller zeroes them). dy uses y's addressing.
+ * workspace (optional, f32, ws_floats >= 2*D): per-block dgamma/dbeta partials are written there and folded by a second
+ * small launch instead of thousands of same-address atomics; size it 2*D*min(rows/16, 1024) floats for full speed. */
 int mh_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                      void* dx, float* dgamma, float* dbeta,
                      int batches, int rows_per_batch, int D, int64_t x_bs, int64_t y_bs,
-                     int dt_x, int dt_dy, int dt_dx, int accumulate_dx, mh_stream s);
+                     int dt_x, int dt_dy, int dt_dx, int accumulate_dx, float* workspace, int64_t ws_floats, mh_stream s);
 
 /* ---------------------------------------------------------------- row softmax ([3P] sim.softmax(-1); Attention :95)
  * x/y: rows x cols, row stride ld (elements). In place allowed when dtypes match. */

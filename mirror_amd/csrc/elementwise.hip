@@ -232,6 +232,74 @@ __global__ __launch_bounds__(256) void mask_apply_bwd_kernel(T* dy, const float*
     }
 }
 
+// f32, D % 4 == 0: lane owns 4 columns (16-byte accesses), a wave owns one t at a time and has 8 batch rows in flight
+typedef float mb_f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void mask_apply_bwd_vec_kernel(float* dy, const float* __restrict__ mask, float* __restrict__ dtoken,
+                                                                 float* __restrict__ dpos, int B, int Tn, int D, int first,
+                                                                 int token_scalar, int band) {
+    __shared__ mb_f4 red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 256 + 4 * lane;
+    const int t0 = blockIdx.y * band, t1 = min(Tn, t0 + band);
+    mb_f4 st = {0.f, 0.f, 0.f, 0.f};
+    if (c < D) {
+        for (int t = t0 + wave; t < t1; t += 4) {
+            mb_f4 sp = {0.f, 0.f, 0.f, 0.f};
+            for (int b0 = 0; b0 < B; b0 += 8) {
+                mb_f4 g[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (b0 + u < B) g[u] = *reinterpret_cast<const mb_f4*>(dy + ((long)(b0 + u) * Tn + t) * D + c);
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    if (b0 + u >= B) break;
+                    sp += g[u];
+                    if (t >= first && mask[(long)(b0 + u) * (Tn - first) + (t - first)] != 0.f) {
+                        st += g[u];
+                        *reinterpret_cast<mb_f4*>(dy + ((long)(b0 + u) * Tn + t) * D + c) = (mb_f4){0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+            }
+            mb_f4* dp = reinterpret_cast<mb_f4*>(dpos + (long)t * D + c);
+            *dp = *dp + sp;
+        }
+    }
+    red[wave][lane] = st;
+    __syncthreads();
+    if (wave == 0 && c < D) {
+        const mb_f4 tot = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        if (token_scalar) {
+            const float v = tot[0] + tot[1] + tot[2] + tot[3];
+            if (v != 0.f) atomicAdd(dtoken, v);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (tot[e] != 0.f) atomicAdd(dtoken + c + e, tot[e]);
+        }
+    }
+}
+
+// D == 1 (the RNA channel axis is the masked axis): thread = position t, loop over the batch (coalesced across t)
+template <typename T>
+__global__ __launch_bounds__(256) void mask_apply_bwd_d1_kernel(T* dy, const float* __restrict__ mask, float* __restrict__ dtoken,
+                                                                float* __restrict__ dpos, int B, int Tn, int first) {
+    __shared__ float red[4];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    float st = 0.f;
+    if (t < Tn) {
+        float sp = 0.f;
+        for (int b = 0; b < B; b++) {
+            T* p = dy + (long)b * Tn + t;
+            const float g = ldf(p);
+            sp += g;
+            if (t >= first && mask[(long)b * (Tn - first) + (t - first)] != 0.f) { st += g; stf(p, 0.f); }
+        }
+        dpos[t] += sp;
+    }
+    st = block_sum256(st, red);
+    if (threadIdx.x == 0 && st != 0.f) atomicAdd(dtoken, st);
+}
+
 extern "C" int mh_mask_apply_fwd(void* x, const float* mask, const float* token, const float* pos, int B, int T, int D,
                                  int first, int token_scalar, int dt, mh_stream s) {
     const long total = (long)B * T * D;
@@ -244,6 +312,19 @@ extern "C" int mh_mask_apply_fwd(void* x, const float* mask, const float* token,
 extern "C" int mh_mask_apply_bwd(void* dy, const float* mask, float* dtoken, float* dpos, int B, int T, int D, int first,
                                  int token_scalar, int dt, mh_stream s) {
     if (T == 0 || D == 0 || B == 0) return MH_OK;
+    if (D == 1) {
+        MH_DISPATCH_DT(dt, TT, hipLaunchKernelGGL((mask_apply_bwd_d1_kernel<TT>), dim3(mh_cdiv(T, 256)), dim3(256), 0, (hipStream_t)s, (TT*)dy, mask, dtoken, dpos, B, T, first));
+        MH_LAUNCH_CHECK("mh_mask_apply_bwd");
+        return MH_OK;
+    }
+    if (dt == MH_F32 && D % 4 == 0 && D >= 256 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dpos & 15) == 0) {
+        const int band = 16;     // rows of t per block: T / 16 x D / 256 blocks, 4 waves x 8 rows of 1 KiB in flight each
+        dim3 gv(mh_cdiv(D, 256), mh_cdiv(T, band));
+        hipLaunchKernelGGL(mask_apply_bwd_vec_kernel, gv, dim3(256), 0, (hipStream_t)s, (float*)dy, mask, dtoken, dpos, B, T, D, first,
+                           token_scalar, band);
+        MH_LAUNCH_CHECK("mh_mask_apply_bwd");
+        return MH_OK;
+    }
     dim3 grid(mh_cdiv(D, 64), mh_cdiv(T, MB_BAND));
     MH_DISPATCH_DT(dt, TT, hipLaunchKernelGGL((mask_apply_bwd_kernel<TT>), grid, dim3(256), 0, (hipStream_t)s, (TT*)dy, mask, dtoken, dpos, B, T, D, first, token_scalar));
     MH_LAUNCH_CHECK("mh_mask_apply_bwd");

@@ -1,6 +1,7 @@
 // Row-wise kernels: LayerNorm fwd/bwd, softmax fwd/bwd, L2-normalise fwd/bwd.
 // One wave64 per row (shuffle reductions); long softmax rows use one 256-thread block per row.
 #include "common.h"
+#include <cstdlib>
 
 #define LN_MAXPL 32  // values per lane kept in registers -> D <= 2048
 
@@ -273,18 +274,155 @@ extern "C" int mh_layernorm_fwd(const void* x, const float* gamma, const float* 
     return MH_OK;
 }
 
+// LayerNorm backward, workspace form: dx as above, but (a) two rows per wave are in flight per iteration (the row loop
+// is a serial load -> reduce -> store chain: one row per wave left HBM at 1.8 TB/s), (b) 32-bit row arithmetic, and
+// (c) the per-block dgamma / dbeta partials go to ws[block][2][D] with plain stores — 2048 blocks adding into the same
+// 2 D addresses cost ~100 us of serialised atomics — and a second small kernel folds them.
+template <typename TX, typename TDY, int LNV_CH>
+__global__ __launch_bounds__(256) void layernorm_bwd_ws_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x,
+                                                               const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, TX* __restrict__ dx,
+                                                               float* __restrict__ ws, int rows, int rpb, int D, long x_bs,
+                                                               long y_bs, int acc_dx, int rows_per_block) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f4 pg[LNV_CH], pb[LNV_CH], gm[LNV_CH];
+#pragma unroll
+    for (int k = 0; k < LNV_CH; k++) {
+        pg[k] = (f4){0.f, 0.f, 0.f, 0.f};
+        pb[k] = pg[k];
+        const int c = 256 * k + 4 * lane;
+        gm[k] = (c < D) ? ld4(gamma + c) : pg[k];
+    }
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    for (int row = r0 + wave; row < r1; row += 8) {
+        f4 dv[2][LNV_CH], xv[2][LNV_CH], ov[2][LNV_CH];
+        float mu[2], rs[2];
+        long xo[2];
+        bool ok[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {               // issue both rows' loads before anything is reduced
+            const int rr = row + 4 * u;
+            ok[u] = rr < r1;
+            const int rc = ok[u] ? rr : row;
+            const int b = rc / rpb, i = rc - b * rpb;
+            xo[u] = b * x_bs + (long)i * D;
+            const TDY* dyr = dy + b * y_bs + (long)i * D;
+            mu[u] = mean[rc];
+            rs[u] = rstd[rc];
+#pragma unroll
+            for (int k = 0; k < LNV_CH; k++) {
+                const int c = 256 * k + 4 * lane;
+                if (c < D) {
+                    dv[u][k] = ld4(dyr + c);
+                    xv[u][k] = ld4(x + xo[u] + c);
+                    if (acc_dx) ov[u][k] = ld4(dx + xo[u] + c);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            if (!ok[u]) continue;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < LNV_CH; k++) {
+                const int c = 256 * k + 4 * lane;
+                if (c < D) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const float xh = (xv[u][k][e] - mu[u]) * rs[u];
+                        const float d = dv[u][k][e];
+                        const float gd = d * gm[k][e];
+                        pg[k][e] += d * xh;
+                        pb[k][e] += d;
+                        s1 += gd;
+                        s2 += gd * xh;
+                        xv[u][k][e] = xh;
+                        dv[u][k][e] = gd;
+                    }
+                }
+            }
+            s1 = wave_sum(s1) / D;
+            s2 = wave_sum(s2) / D;
+#pragma unroll
+            for (int k = 0; k < LNV_CH; k++) {
+                const int c = 256 * k + 4 * lane;
+                if (c < D) {
+                    f4 r;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) r[e] = rs[u] * (dv[u][k][e] - s1 - xv[u][k][e] * s2);
+                    if (acc_dx) r += ov[u][k];
+                    st4(dx + xo[u] + c, r);
+                }
+            }
+        }
+    }
+    __shared__ f4 red[2][4][64];
+    float* wsb = ws + (long)blockIdx.x * 2 * D;
+#pragma unroll
+    for (int k = 0; k < LNV_CH; k++) {
+        if (256 * k >= D) break;
+        __syncthreads();
+        red[0][wave][lane] = pg[k];
+        red[1][wave][lane] = pb[k];
+        __syncthreads();
+        if (wave == 0) {
+            const int c = 256 * k + 4 * lane;
+            if (c < D) {
+                *reinterpret_cast<f4*>(wsb + c) = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
+                *reinterpret_cast<f4*>(wsb + D + c) = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
+            }
+        }
+    }
+}
+
+// dgamma[c] += sum_b ws[b][0][c], dbeta[c] += sum_b ws[b][1][c]; grid (ceil(2D / 256), splits)
+__global__ __launch_bounds__(256) void layernorm_bwd_fold_kernel(const float* __restrict__ ws, int nb, int D, float* __restrict__ dgamma,
+                                                                 float* __restrict__ dbeta) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= 2 * D) return;
+    const int per = (nb + gridDim.y - 1) / gridDim.y;
+    const int b0 = blockIdx.y * per, b1 = min(nb, b0 + per);
+    float s = 0.f;
+    for (int b = b0; b < b1; b++) s += ws[(long)b * 2 * D + t];
+    atomicAdd(t < D ? dgamma + t : dbeta + (t - D), s);
+}
+
+static int ln_bwd_blocks() { static const int n = [] { const char* e = getenv("MH_LN_BWD_BLOCKS"); return e ? atoi(e) : 512; }(); return n; }
+
 extern "C" int mh_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                 void* dx, float* dgamma, float* dbeta, int batches, int rpb, int D, int64_t x_bs,
-                                int64_t y_bs, int dt_x, int dt_dy, int dt_dx, int acc_dx, mh_stream s) {
+                                int64_t y_bs, int dt_x, int dt_dy, int dt_dx, int acc_dx, float* workspace, int64_t ws_floats,
+                                mh_stream s) {
     MH_REQUIRE(D >= 1 && D <= 64 * LN_MAXPL, "mh_layernorm_bwd: D=%d unsupported", D);
     MH_REQUIRE(dt_dx == dt_x, "mh_layernorm_bwd: dx dtype must equal x dtype");
     const long rows = (long)batches * rpb;
     if (rows == 0) return MH_OK;
-    dim3 grid((unsigned)min((long)mh_cdiv(rows, 4), 2048L));
+    MH_REQUIRE(rows < (1L << 31), "mh_layernorm_bwd: too many rows");
+    dim3 grid((unsigned)min((long)mh_cdiv(rows, 4), (long)ln_bwd_blocks()));
     const bool vecok = D % 4 == 0 && x_bs % 4 == 0 && y_bs % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0 &&
                        ((uintptr_t)dx & 15) == 0 && ((uintptr_t)gamma & 15) == 0;
 #define LN_BV1(TX, TDY, NC) hipLaunchKernelGGL((layernorm_bwd_vec_kernel<TX, TDY, NC>), grid, dim3(256), 0, (hipStream_t)s, (const TDY*)dy, (const TX*)x, gamma, mean, rstd, (TX*)dx, dgamma, dbeta, rows, rpb, D, (long)x_bs, (long)y_bs, acc_dx)
 #define LN_BV(TX, TDY) do { if (D <= 512) LN_BV1(TX, TDY, 2); else if (D <= 1024) LN_BV1(TX, TDY, 4); else LN_BV1(TX, TDY, 8); } while (0)
+    // workspace form: rows_per_block rows per block (a multiple of 8: two rows per wave per iteration), nb <= ws capacity
+    if (vecok && workspace && ws_floats >= 2L * D && rows >= 64) {
+        const long cap = ws_floats / (2L * D);
+        long nb = min(cap, min((long)mh_cdiv(rows, 16), 1024L));
+        const int rows_per_block = (int)(mh_cdiv(mh_cdiv(rows, nb), 8) * 8);
+        nb = mh_cdiv(rows, rows_per_block);
+        dim3 g2((unsigned)nb);
+#define LN_BW1(TX, TDY, NC) hipLaunchKernelGGL((layernorm_bwd_ws_kernel<TX, TDY, NC>), g2, dim3(256), 0, (hipStream_t)s, (const TDY*)dy, (const TX*)x, gamma, mean, rstd, (TX*)dx, workspace, (int)rows, rpb, D, (long)x_bs, (long)y_bs, acc_dx, rows_per_block)
+#define LN_BW(TX, TDY) do { if (D <= 512) LN_BW1(TX, TDY, 2); else if (D <= 1024) LN_BW1(TX, TDY, 4); else LN_BW1(TX, TDY, 8); } while (0)
+        if (dt_x == MH_F32 && dt_dy == MH_F32) LN_BW(float, float);
+        else if (dt_x == MH_F32 && dt_dy == MH_BF16) LN_BW(float, bf16_t);
+        else if (dt_x == MH_BF16 && dt_dy == MH_BF16) LN_BW(bf16_t, bf16_t);
+        else LN_BW(bf16_t, float);
+#undef LN_BW
+#undef LN_BW1
+        hipLaunchKernelGGL(layernorm_bwd_fold_kernel, dim3(mh_cdiv(2 * D, 256), (unsigned)min(nb, 32L)), dim3(256), 0, (hipStream_t)s,
+                           (const float*)workspace, (int)nb, D, dgamma, dbeta);
+        MH_LAUNCH_CHECK("mh_layernorm_bwd");
+        return MH_OK;
+    }
     if (vecok) {
         if (dt_x == MH_F32 && dt_dy == MH_F32) LN_BV(float, float);
         else if (dt_x == MH_F32 && dt_dy == MH_BF16) LN_BV(float, bf16_t);

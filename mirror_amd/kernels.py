@@ -240,8 +240,13 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, batches, rpb, D, x_bs, y_bs, ep
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, batches, rpb, D, x_bs, y_bs, accumulate_dx=False):
     _chk(dy, x, gamma, mean, rstd, dx, dgamma, dbeta)
+    rows = batches * rpb
+    ws = None
+    if rows >= 64:      # per-block dgamma / dbeta partials (folded by a second launch) instead of same-address atomics
+        ws = torch.empty((2 * D * max(1, min(rows // 16, 1024)),), device=x.device, dtype=torch.float32)
     _lib.call("mh_layernorm_bwd", _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma), _p(dbeta),
-              batches, rpb, D, x_bs, y_bs, dt(x), dt(dy), dt(dx), int(accumulate_dx), stream=_stream())
+              batches, rpb, D, x_bs, y_bs, dt(x), dt(dy), dt(dx), int(accumulate_dx), _p(ws) if ws is not None else 0,
+              ws.numel() if ws is not None else 0, stream=_stream())
 
 
 def softmax_fwd(x: torch.Tensor, y: Optional[torch.Tensor] = None, out_dtype=None) -> torch.Tensor:

@@ -390,6 +390,17 @@ def test_mask_apply(dtype):
     close(dyd, dy * keep, 0, 0, "mask dx")
     close(dtok, (dy[:, 1:] * mask[..., None]).sum((0, 1)), 0, 0, "dtoken")
     close(dpos, dy.sum(0), 0, 0, "dpos")
+    if dtype == torch.float32:      # 16-byte path (D % 4 == 0, D >= 256), ragged band and a batch that is not a multiple of 8
+        Bv, Tv, Dv = 11, 37, 512
+        dyv = ints((Bv, Tv, Dv), gen)
+        mv = (torch.rand(Bv, Tv - 1, generator=gen) > 0.5).float()
+        dyvd = dyv.to(DEV)
+        dtv, dpv = torch.zeros(Dv, device=DEV), torch.zeros((Tv, Dv), device=DEV)
+        K.mask_apply_bwd(dyvd, mv.to(DEV), dtv, dpv, Bv, Tv, Dv, 1, False)
+        keepv = torch.cat([torch.ones(Bv, 1), 1 - mv], dim=1)[..., None]
+        close(dyvd, dyv * keepv, 0, 0, "mask dx (vec)")
+        close(dtv, (dyv[:, 1:] * mv[..., None]).sum((0, 1)), 0, 0, "dtoken (vec)")
+        close(dpv, dyv.sum(0), 0, 0, "dpos (vec)")
     # RNA form: channels masked with a scalar token -> B x (T=D) x 1
     xr = ints((B, D), gen)
     mr = (torch.rand(B, D, generator=gen) > 0.4).float()
