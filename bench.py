@@ -139,6 +139,16 @@ def main():
         is_f32 = dominant.startswith("gemm_kernel<0")
         peak = PEAK_F32_TFLOPS if is_f32 else PEAK_BF16_TFLOPS
         avg_ms = prof["total_ms"] / max(prof["launches"], 1)
+        # HBM-side bytes per launch of the dominant kernel: PMC passes (FETCH_SIZE, WRITE_SIZE in separate runs, gfx950
+        # correction applied) summarised by tools/pmc_summary.py into profiles/pmc_traffic.json; null when not collected
+        traffic = None
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as fh:
+                ent = json.load(fh)["kernels"].get(dominant.replace(" ", ""))
+            if ent:
+                traffic = ent["bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         ach = (prof["flops"] / max(prof["launches"], 1)) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         out = {
             "metric": "SSL samples/sec (slide+RNA pairs)", "value": round(value, 3), "unit": "samples/s",
@@ -154,7 +164,7 @@ def main():
             "model_flops_frac_of_bf16_peak": round(step_tflops / world / PEAK_BF16_TFLOPS, 4),
             "losses": [round(x, 5) for x in loss_vals],
             "roofline": {"bound": "mfma", "kernel": dominant, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(ach / peak, 4), "traffic": None, "launches_timed": prof["launches"],
+                         "frac": round(ach / peak, 4), "traffic": traffic, "launches_timed": prof["launches"],
                          "avg_launch_ms": round(avg_ms, 5),
                          "share_of_mfma_kernel_time_in_profiled_step": round(summ[dominant]["total_ms"] / max(sum(s["total_ms"] for s in summ.values()), 1e-9), 3),
                          "flops_per_launch": round(prof["flops"] / max(prof["launches"], 1) / 1e9, 3),
