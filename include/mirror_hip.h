@@ -198,9 +198,10 @@ int mh_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int dt_x, in
 /* dx = dy * (y > 0); `batches` blocks of n_per_batch contiguous elements at the given batch strides */
 int mh_relu_bwd(const void* y, const void* dy, void* dx, int64_t n_per_batch, int batches, int64_t y_bs, int64_t dy_bs,
                 int64_t dx_bs, int dt_y, int dt_dy, int dt_dx, mh_stream s);
-/* y = x * keep/(1-p); keep from Philox4x32-10(seed, offset + i)  ([3P] nn.Dropout in to_out; :75, :142) */
-int mh_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, uint64_t offset, int dt_x, int dt_y,
-               mh_stream s);
+/* y = x * keep/(1-p); keep from Philox4x32-10(seed, offset + *dev_base + i)  ([3P] nn.Dropout in to_out; :75, :142).
+ * dev_base (nullable, device memory): per-step base offset, so that a captured graph draws fresh masks at every replay */
+int mh_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, uint64_t offset, const uint64_t* dev_base,
+               int dt_x, int dt_y, mh_stream s);
 /* out[c] += sum_r x[r*ld + c]  (bias gradients; f32 atomics) */
 int mh_colsum(const void* x, float* out, int64_t rows, int cols, int64_t ld, int dt, mh_stream s);
 /* y[r] = x[r*x_rs .. +D] / max(||.||, eps) (F.normalize, models/mirror.py:540, :683); norm[r] saved */
@@ -240,9 +241,12 @@ int mh_symkl_bwd(const float* w, const float* r, const float* g, float* dw, floa
 /* ---------------------------------------------------------------- step glue (train_mirror.py:1133-1136, :1230, :1254-1255) */
 int mh_rownorm_(float* w, int rows, int D, float eps, mh_stream s);
 int mh_clamp_(float* x, int64_t n, float lo, float hi, mh_stream s);
-/* torch.optim.Adam (wd=0): flat f32 params/grads/moments; optional bf16 shadow copy of the params */
+/* torch.optim.Adam (wd=0): flat f32 params/grads/moments; optional bf16 shadow copy of the params.
+ * dev_state (nullable, 4 device floats {t, 1-b1^t, 1-b2^t, lr}): when given, t is advanced and the bias corrections are
+ * refreshed ON THE DEVICE before the update and lr / bias_c1 / bias_c2 arguments are ignored — nothing step-dependent
+ * is a launch argument, so the whole step can be captured in a HIP graph (train_mirror.py:1254 optimizer.step()) */
 int mh_adam(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr, float beta1,
-            float beta2, float eps, float bias_c1, float bias_c2, float grad_scale, mh_stream s);
+            float beta2, float eps, float bias_c1, float bias_c2, float grad_scale, float* dev_state, mh_stream s);
 
 #ifdef __cplusplus
 }

@@ -74,7 +74,7 @@ _SIGS = {
     "mh_gelu_fwd": [P, P, L, I, I],
     "mh_gelu_bwd": [P, P, P, L, I, I, I],
     "mh_relu_bwd": [P, P, P, L, I, L, L, L, I, I, I],
-    "mh_dropout": [P, P, L, F, U64, U64, I, I],
+    "mh_dropout": [P, P, L, F, U64, U64, P, I, I],
     "mh_colsum": [P, P, L, I, L, I],
     "mh_l2norm_fwd": [P, P, P, I, I, L, F, I, I],
     "mh_l2norm_bwd": [P, P, P, P, I, I, L, F, I, I, I, I],
@@ -90,7 +90,7 @@ _SIGS = {
     "mh_symkl_bwd": [P, P, P, P, P, I, I, F],
     "mh_rownorm_": [P, I, I, F],
     "mh_clamp_": [P, L, F, F],
-    "mh_adam": [P, P, P, P, P, L, F, F, F, F, F, F, F],
+    "mh_adam": [P, P, P, P, P, L, F, F, F, F, F, F, F, P],
 }
 EXPORTS = sorted(list(_SIGS) + ["mh_last_error", "mh_version", "mh_device_ok"])
 
@@ -123,8 +123,13 @@ def load() -> C.CDLL:
     return lib
 
 
+_fns: dict = {}
+
+
 def call(name: str, *args, stream: int = 0) -> None:
-    lib = load()
-    rc = getattr(lib, name)(*args, stream)
+    fn = _fns.get(name)
+    if fn is None:
+        fn = _fns[name] = getattr(load(), name)
+    rc = fn(*args, stream)
     if rc != 0:
-        raise MirrorHipError(f"{name} failed ({rc}): {lib.mh_last_error().decode()}")
+        raise MirrorHipError(f"{name} failed ({rc}): {load().mh_last_error().decode()}")

@@ -104,7 +104,9 @@ __device__ __forceinline__ void philox4x32_10(uint32_t (&ctr)[4], uint32_t k0, u
 // element i uses word (i & 3) of the Philox block with counter (offset + i) >> 2: the mask is a pure
 // function of (seed, offset, i), so the backward pass regenerates it instead of storing it.
 template <typename TX, typename TY>
-__global__ __launch_bounds__(256) void dropout_kernel(const TX* x, TY* y, long n, float p, uint64_t seed, uint64_t offset) {
+__global__ __launch_bounds__(256) void dropout_kernel(const TX* x, TY* y, long n, float p, uint64_t seed, uint64_t offset,
+                                                      const uint64_t* __restrict__ dev_base) {
+    if (dev_base) offset += *dev_base & ~3ull;     // per-step base kept on the device (graph replays draw fresh masks)
     const float scale = 1.f / (1.f - p);
     const uint32_t thr = (uint32_t)fminf(p * 4294967296.f, 4294967295.f);
     for (long q = (long)blockIdx.x * 256 + threadIdx.x; q * 4 < n; q += (long)gridDim.x * 256) {
@@ -119,12 +121,12 @@ __global__ __launch_bounds__(256) void dropout_kernel(const TX* x, TY* y, long n
     }
 }
 
-extern "C" int mh_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, uint64_t offset, int dt_x, int dt_y,
-                          mh_stream s) {
+extern "C" int mh_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, uint64_t offset, const uint64_t* dev_base,
+                          int dt_x, int dt_y, mh_stream s) {
     MH_REQUIRE(p >= 0.f && p < 1.f, "mh_dropout: p=%f out of range", (double)p);
     MH_REQUIRE((offset & 3) == 0, "mh_dropout: offset must be a multiple of 4");
     if (n == 0) return MH_OK;
-#define DROP_(TX, TY) hipLaunchKernelGGL((dropout_kernel<TX, TY>), EW_GRID((n + 3) / 4), dim3(256), 0, (hipStream_t)s, (const TX*)x, (TY*)y, (long)n, p, seed, offset)
+#define DROP_(TX, TY) hipLaunchKernelGGL((dropout_kernel<TX, TY>), EW_GRID((n + 3) / 4), dim3(256), 0, (hipStream_t)s, (const TX*)x, (TY*)y, (long)n, p, seed, offset, dev_base)
     DISPATCH2(dt_x, dt_y, DROP_)
 #undef DROP_
     MH_LAUNCH_CHECK("mh_dropout");

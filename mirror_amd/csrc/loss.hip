@@ -270,7 +270,13 @@ extern "C" int mh_clamp_(float* x, int64_t n, float lo, float hi, mh_stream s) {
 // torch.optim.Adam semantics (no weight decay, no amsgrad): 4 floats per thread, 16-B accesses (HBM-bound: 28 B/param)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, bf16_t* __restrict__ shadow, long n, float lr, float b1,
-                                                   float b2, float eps, float bc1, float bc2, float gscale) {
+                                                   float b2, float eps, float bc1, float bc2, float gscale,
+                                                   const float* __restrict__ state) {
+    if (state) {   // device-resident step state {t, 1 - b1^t, 1 - b2^t, lr}: nothing step-dependent is a launch argument
+        bc1 = state[1];
+        bc2 = state[2];
+        lr = state[3];
+    }
     const float step = lr / bc1;
     const float isq = rsqrtf(bc2);
     const long n4 = n / 4;
@@ -307,12 +313,22 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// state = {t, 1 - b1^t, 1 - b2^t, lr}: t += 1 and the bias corrections are refreshed on the device, so a captured
+// HIP graph of the whole step replays with the right Adam step every time
+__global__ void adam_tick_kernel(float* state, float b1, float b2) {
+    const float t = state[0] + 1.f;
+    state[0] = t;
+    state[1] = 1.f - powf(b1, t);
+    state[2] = 1.f - powf(b2, t);
+}
+
 extern "C" int mh_adam(float* p, const float* g, float* m, float* v, void* shadow, int64_t n, float lr, float b1, float b2,
-                       float eps, float bc1, float bc2, float gscale, mh_stream s) {
+                       float eps, float bc1, float bc2, float gscale, float* dev_state, mh_stream s) {
     if (n == 0) return MH_OK;
     MH_REQUIRE(((uintptr_t)p & 15) == 0 && ((uintptr_t)g & 15) == 0 && ((uintptr_t)m & 15) == 0 && ((uintptr_t)v & 15) == 0 &&
                    ((uintptr_t)shadow & 7) == 0, "mh_adam: buffers must be 16-byte aligned");
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)min((long)mh_cdiv(mh_cdiv(n, 4), 256), 8192L)), dim3(256), 0, (hipStream_t)s, p, g, m, v, (bf16_t*)shadow, (long)n, lr, b1, b2, eps, bc1, bc2, gscale);
+    if (dev_state) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, dev_state, b1, b2);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)min((long)mh_cdiv(mh_cdiv(n, 4), 256), 8192L)), dim3(256), 0, (hipStream_t)s, p, g, m, v, (bf16_t*)shadow, (long)n, lr, b1, b2, eps, bc1, bc2, gscale, (const float*)dev_state);
     MH_LAUNCH_CHECK("mh_adam");
     return MH_OK;
 }

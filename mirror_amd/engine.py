@@ -14,6 +14,7 @@
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -47,7 +48,7 @@ def plan_buckets(sizes: Sequence[int], cap_elems: int, align: int = _ALIGN):
 class TrainEngine:
     def __init__(self, model: torch.nn.Module, loss_fn, *, lr: float = 2e-5, betas=(0.9, 0.999), eps: float = 1e-8,
                  precision: str = "bf16", wsi_mask_ratio: float = 0.75, rna_mask_ratio: float = 0.75,
-                 bucket_mb: float = 25.0, process_group=None):
+                 bucket_mb: float = 25.0, process_group=None, graph: Optional[bool] = None):
         if precision not in POLICIES:
             raise ValueError(f"unknown precision {precision!r}")
         self.model, self.loss_fn = model, loss_fn
@@ -102,6 +103,18 @@ class TrainEngine:
         self._counting = True
         self._proto = getattr(model, "prototypes", None)
         self._logit = getattr(model, "logit_scale", None)
+        # step state on the device {t, 1 - b1^t, 1 - b2^t, lr}: advanced by mh_adam itself, so nothing that changes from
+        # step to step is a launch argument and the whole step can be replayed as one HIP graph
+        self._state = torch.tensor([0.0, 0.0, 0.0, float(lr)], device=self.device, dtype=f32)
+        self._state_lr = float(lr)
+        # HIP graph of the step (~700 launches: the host needs ~10 ms to enqueue what the GPU runs in ~14 ms).  Single-GPU
+        # only by default: with RCCL buckets in flight the eager path stays (MIRROR_GRAPH=1 forces, =0 disables).
+        env = os.environ.get("MIRROR_GRAPH")
+        self._use_graph = (self.world == 1 if graph is None else bool(graph)) if env is None else env not in ("0", "")
+        self._graph = None
+        self._graph_warm = 0
+        self._g_in = None
+        self._g_out = None
         if self.world > 1:
             dist.broadcast(self.master, src=0, group=self.pg)  # DDP's parameter broadcast at wrap time
             self.sync_shadows()
@@ -176,7 +189,43 @@ class TrainEngine:
     # ------------------------------------------------------------------ one optimizer step
     def step(self, wsi: torch.Tensor, rna: torch.Tensor, noise: Optional[dict] = None):
         """prototype renorm -> forward -> MIRRORLoss -> backward (+ overlapped all-reduce) -> Adam -> clamp.
-        Returns the 6 loss tensors (device scalars; nothing is synchronised here)."""
+        Returns the 6 loss tensors (device scalars; nothing is synchronised here).  Without injected `noise` the step is
+        captured into a HIP graph after two eager steps and replayed from then on (the returned tensors are then the
+        graph's static outputs: read them before the next step)."""
+        if self.lr != self._state_lr:                       # lr schedulers write engine.lr: publish it to the device state
+            self._state[3:4].fill_(float(self.lr))
+            self._state_lr = float(self.lr)
+        if not self._use_graph or noise is not None:
+            return self._step_eager(wsi, rna, noise)
+        if self._graph is not None:
+            if wsi.shape != self._g_in[0].shape or rna.shape != self._g_in[1].shape or wsi.dtype != self._g_in[0].dtype:
+                return self._step_eager(wsi, rna, None)     # a ragged last batch runs eagerly
+            self._g_in[0].copy_(wsi, non_blocking=True)
+            self._g_in[1].copy_(rna, non_blocking=True)
+            self._graph.replay()
+            self.step_count += 1
+            return self._g_out
+        if self._graph_warm < 2:                            # allocator, shadows, sink counts and lazy inits settle first
+            self._graph_warm += 1
+            return self._step_eager(wsi, rna, None)
+        self._g_in = (wsi.clone(), rna.clone())
+        g = torch.cuda.CUDAGraph()
+        count = self.step_count
+        try:
+            with torch.cuda.graph(g):
+                self._g_out = self._step_eager(self._g_in[0], self._g_in[1], None)
+        except Exception as e:                              # noqa: BLE001  (capture is an optimisation: fall back loudly)
+            import warnings
+            warnings.warn(f"mirror_amd: HIP graph capture of the training step failed ({e!r}); running eagerly")
+            self._use_graph, self._graph, self._g_in, self._g_out = False, None, None, None
+            torch.cuda.synchronize()
+            return self._step_eager(wsi, rna, None)
+        self.step_count = count                             # capture enqueues nothing: the step runs by replay
+        self._graph = g
+        return self.step(wsi, rna)
+
+    def _step_eager(self, wsi: torch.Tensor, rna: torch.Tensor, noise: Optional[dict]):
+        Fn.dropout_step_begin(self.device)
         if self._proto is not None:
             w = self._proto.weight
             K.rownorm_(w.data)
@@ -197,13 +246,14 @@ class TrainEngine:
         self._finish_reduce()
         self.step_count += 1
         b1, b2 = self.betas
-        K.adam(self.master, self.grad, self.m, self.v, self.shadow, self.lr, b1, b2, self.eps,
-               1.0 - b1 ** self.step_count, 1.0 - b2 ** self.step_count,
-               grad_scale=1.0 / self.world)   # buckets are SUM-reduced; the DDP average is folded into Adam
+        K.adam(self.master, self.grad, self.m, self.v, self.shadow, self.lr, b1, b2, self.eps, 1.0, 1.0,
+               grad_scale=1.0 / self.world,    # buckets are SUM-reduced; the DDP average is folded into Adam
+               dev_state=self._state)          # t, bias corrections and lr live on the device
         self._refresh_transposes()
         if self._logit is not None:
             K.clamp_(self._logit.data.reshape(1), 0.0, math.log(100.0))
             if self.shadow is not None:
                 K.cast(self._logit.data.reshape(1), bf16, out=Fn.shadow(self._logit, POLICIES[self.precision]).reshape(1))
         self.grad.zero_()
+        Fn.dropout_step_end()
         return tuple(x.detach() for x in losses)

@@ -318,26 +318,47 @@ class GeluFn(Function):
 
 gelu = GeluFn.apply
 
-_dropout_state = {"seed": 0x5EED, "offset": 0}
+_dropout_state = {"seed": 0x5EED, "offset": 0, "base": None}
 
 
 def manual_seed(seed: int) -> None:
     _dropout_state["seed"], _dropout_state["offset"] = int(seed) & ((1 << 63) - 1), 0
+    if _dropout_state["base"] is not None:
+        _dropout_state["base"].zero_()
+
+
+def dropout_step_begin(device) -> None:
+    """Engine protocol for graph-safe dropout: every step starts at host offset 0 (so the per-call offsets are the same
+    at every step and can be baked into a captured graph) on top of a per-step base that lives on the device."""
+    if _dropout_state["base"] is None or _dropout_state["base"].device != torch.device(device):
+        _dropout_state["base"] = torch.zeros(1, device=device, dtype=torch.int64)
+    _dropout_state["offset"] = 0
+
+
+def dropout_step_end() -> None:
+    """Advance the device base by what this step consumed (a device-side add: captured with the step)."""
+    base = _dropout_state["base"]
+    if base is not None and _dropout_state["offset"]:
+        base.add_(_dropout_state["offset"])
+    _dropout_state["offset"] = 0
+
+
+def dropout_device_base_off() -> None:
+    _dropout_state["base"] = None
 
 
 class DropoutFn(Function):
-    """nn.Dropout in training mode; the Philox mask is regenerated in backward from (seed, offset)."""
+    """nn.Dropout in training mode; the Philox mask is regenerated in backward from (seed, offset [+ device base])."""
 
     @staticmethod
     def forward(ctx, x, p):
-        x = x.contiguous()
-        ctx.p, ctx.seed, ctx.offset = p, _dropout_state["seed"], _dropout_state["offset"]
+        ctx.p, ctx.seed, ctx.offset, ctx.base = p, _dropout_state["seed"], _dropout_state["offset"], _dropout_state["base"]
         _dropout_state["offset"] += (x.numel() + 3) // 4 * 4
-        return K.dropout(x, p, ctx.seed, ctx.offset)
+        return K.dropout(x, p, ctx.seed, ctx.offset, dev_base=ctx.base)
 
     @staticmethod
     def backward(ctx, dy):
-        return K.dropout(dy.contiguous(), ctx.p, ctx.seed, ctx.offset), None
+        return K.dropout(dy.contiguous(), ctx.p, ctx.seed, ctx.offset, dev_base=ctx.base), None
 
 
 def dropout(x, p: float, training: bool):

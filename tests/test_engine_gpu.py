@@ -105,3 +105,42 @@ def test_two_ranks_match_single_process_on_concatenated_batch():
     rel = (eng.master.cpu() - torch.from_numpy(res[0][1])).norm() / eng.master.cpu().norm()
     assert rel < 5e-3, rel
     assert abs(float(losses[1]) - 0.5 * (res[0][2] + res[1][2])) < 5e-3 * abs(float(losses[1]))
+
+
+def test_graphed_step_replays_with_fresh_state():
+    """Without injected noise the step is captured into a HIP graph after two eager steps.  Everything that changes
+    from step to step must live on the device: Adam's t / bias corrections / lr, the dropout base offset, the
+    noise draws.  Checks that replays keep training, advance the device state and honour an lr change."""
+    import mirror_amd.models as M
+    from mirror_amd import functional as Fn
+    from mirror_amd.engine import TrainEngine
+    from mirror_amd.losses import MIRRORLoss
+    torch.manual_seed(3)
+    model = M.mirror(**CFG).cuda().train()
+    eng = TrainEngine(model, MIRRORLoss(), lr=1e-3, precision="bf16", graph=True)
+    Fn.manual_seed(7)
+    wsi, rna, _ = _batch(4, 5)
+    wsi = wsi.to(torch.bfloat16)
+    snaps, losses, bases = [], [], []
+    for step in range(6):
+        out = eng.step(wsi, rna)
+        losses.append(float(out[0]))
+        snaps.append(eng.master.clone())
+        bases.append(int(Fn._dropout_state["base"]))
+    assert eng._graph is not None, "the step was not captured"
+    assert all(torch.isfinite(torch.tensor(losses))), losses
+    assert float(eng._state[0]) == 6.0 and abs(float(eng._state[1]) - (1 - 0.9 ** 6)) < 1e-6, eng._state
+    for a, b in zip(snaps[:-1], snaps[1:]):
+        assert float((a - b).abs().max()) > 0, "a replay did not update the parameters"
+    assert bases[0] > 0 and all(b2 - b1 == bases[0] for b1, b2 in zip(bases[:-1], bases[1:])), bases
+    assert len(set(losses[2:])) > 1, "replays produced identical losses: noise / dropout are not redrawn"
+    eng.lr = 0.0                                   # an lr scheduler writes engine.lr between steps
+    before = eng.master.clone()
+    eng.step(wsi, rna)
+    proto = model.prototypes.weight                # re-normalised at every step (train_mirror.py:1133-1136), lr or not
+    for prm, off in zip(eng.params, eng.offsets):
+        if prm.data_ptr() == proto.data_ptr():
+            continue
+        sl = slice(off, off + prm.numel())
+        assert float((eng.master[sl] - before[sl]).abs().max()) == 0.0, "lr change was not published to the graphed step"
+    assert float(eng._state[0]) == 7.0
