@@ -2,6 +2,14 @@
 // TransMIL sequence glue (models/mirror.py:657-665): landmark means, 33-tap residual conv of V,
 // pseudo-inverse initial scaling (tensor-wide max) and its adjoint, d*I - P, cls/square-pad rows.
 #include "common.h"
+#include <cstdlib>
+
+// resconv_mfma.hip
+bool resconv_try_mfma(const void* v, long ldv, long v_bs, const float* w, void* out, long ldo, long o_bs, int B, int n_p, int heads,
+                      int dh, int taps, int transpose, int accumulate, int dt_v, int dt_o, hipStream_t s);
+bool resconv_wgrad_try_mfma(const void* v, long ldv, long v_bs, const void* dout, long ldo, long o_bs, float* dw, int B, int n_p,
+                            int heads, int dh, int taps, int dt_v, int dt_o, hipStream_t s);
+static bool resconv_mfma_on() { static const bool on = [] { const char* e = getenv("MH_RESCONV_MFMA"); return !(e && e[0] == '0'); }(); return on; }
 
 // ------------------------------------------------------------------ landmarks
 // lm[b, j, c] = (1/l) sum_t qkv[b, j*l + t, c], c < 2D (q and k column blocks)
@@ -232,6 +240,11 @@ extern "C" int mh_resconv_fwd(const void* v, int64_t ldv, int64_t v_bs, const fl
     const int C = heads * dh;
     MH_REQUIRE(heads <= 8 || 255 / dh + 2 <= 8, "mh_resconv_fwd: more than 8 heads per 256 columns (heads=%d dh=%d)", heads, dh);
     if (B == 0 || n_p == 0) return MH_OK;
+    if (resconv_mfma_on() && resconv_try_mfma(v, ldv, v_bs, w, out, ldo, o_bs, B, n_p, heads, dh, taps, transpose, accumulate, dt_v,
+                                              dt_o, (hipStream_t)s)) {   // bf16, dh = 64, 33 taps: banded Toeplitz product on MFMA
+        MH_LAUNCH_CHECK("mh_resconv_fwd");
+        return MH_OK;
+    }
     if (dh % 8 == 0 && ldv % 8 == 0 && v_bs % 8 == 0 && ldo % 8 == 0 && o_bs % 8 == 0 && ((uintptr_t)v & 15) == 0 &&
         ((uintptr_t)out & 15) == 0 && (heads <= 8 || 511 / dh + 2 <= 8)) {
         dim3 vgrid(mh_cdiv(C, 512), mh_cdiv(n_p, 4 * RV_RT), B);
@@ -337,6 +350,10 @@ extern "C" int mh_resconv_wgrad(const void* v, int64_t ldv, int64_t v_bs, const 
                                 float* dw, int B, int n_p, int heads, int dh, int taps, int dt_v, int dt_o, mh_stream s) {
     MH_REQUIRE(taps >= 1 && taps <= 63 && (taps & 1), "mh_resconv_wgrad: taps=%d unsupported", taps);
     if (B == 0 || n_p == 0) return MH_OK;
+    if (resconv_mfma_on() && resconv_wgrad_try_mfma(v, ldv, v_bs, dout, ldo, o_bs, dw, B, n_p, heads, dh, taps, dt_v, dt_o, (hipStream_t)s)) {
+        MH_LAUNCH_CHECK("mh_resconv_wgrad");
+        return MH_OK;
+    }
     dim3 grid(heads, mh_cdiv(n_p, RW_ROWS), B);
 #define RW(TV, TO) hipLaunchKernelGGL((resconv_wgrad_kernel<TV, TO>), grid, dim3(256), 0, (hipStream_t)s, (const TV*)v, (long)ldv, (long)v_bs, (const TO*)dout, (long)ldo, (long)o_bs, dw, n_p, dh, taps, vec8)
     const int vec8 = dh % 8 == 0 && ldv % 8 == 0 && v_bs % 8 == 0 && ldo % 8 == 0 && o_bs % 8 == 0 && ((uintptr_t)v & 15) == 0 && ((uintptr_t)dout & 15) == 0;

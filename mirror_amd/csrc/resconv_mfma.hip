@@ -1,0 +1,175 @@
+// [3P] NystromAttention.res_conv (33-tap depthwise conv along the sequence, one filter per head; called at
+// models/mirror.py:312) on the matrix cores — bf16 policy, dh = 64, taps = 33.
+//
+// As VALU code the conv is 33 MACs per element = 1.2 G FMA per call at c2: ~36 us of pure issue, 90 us measured.
+// As a banded Toeplitz product it is 8 MFMAs per 32 x 64 output block and purely memory bound:
+//     out[t0 + i, c] = sum_k A[i][k] v[t0 - 16 + k, c],     A[i][k] = w[k - i] for 0 <= k - i <= 32 (else 0),  k < 64
+// The accumulators hold out^T (c in registers, t in lanes) so a lane adds 4 consecutive channels of one row with an
+// 8-byte read-modify-write; the v tile (128 + 32 halo rows of one head) sits in LDS and is read with
+// ds_read_b64_tr_b16 in the accumulator's k order (see nystrom_fused.hip).
+// The weight gradient dw[j] = sum_{b,t,c} dout[t, c] v[t + j - 16, c] is the diagonal sums of
+//     S[i][k] = sum_c dout[t0 + i, c] v[t0 - 16 + k, c]
+// accumulated over every row block: both operands are channel-contiguous rows, read straight from HBM as fragments.
+#include "gemm_kernel.h"
+
+namespace {
+
+constexpr int RM_P = 72;       // LDS pitch (bf16) of the [rows][64] image
+constexpr int RM_T = 128;      // output rows per workgroup
+constexpr int RM_HALO = 16;    // taps / 2
+constexpr int RM_TAPS = 33;
+constexpr int RM_DH = 64;
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+// fragment with free index = image column (col0 + lane&31), contraction index = image rows kb + 4hl + {0..3}, kb + 8 + 4hl + {0..3}
+__device__ __forceinline__ bf16x8 rm_frag_tr(const bf16_t* img, int col0, int kb, int lane) {
+    const int g16 = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const bf16_t* a0 = img + (kb + 4 * (g16 >> 1) + q) * RM_P + col0 + 16 * (g16 & 1) + 4 * p;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 8 * RM_P));
+    s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// grid (n_p / 128, heads, B)
+__global__ __launch_bounds__(256) void resconv_mfma_kernel(const bf16_t* __restrict__ v, long ldv, long v_bs, const float* __restrict__ w,
+                                                           bf16_t* out, long ldo, long o_bs, int n_p, int transpose, int accumulate) {
+    __shared__ __attribute__((aligned(16))) bf16_t img[(RM_T + 2 * RM_HALO) * RM_P];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 5, r = lane & 31;
+    const int t0 = blockIdx.x * RM_T, h = blockIdx.y, b = blockIdx.z;
+    const bf16_t* vb = v + (long)b * v_bs + h * RM_DH;
+    // image row q <-> sequence position t0 - 16 + q, zero outside [0, n_p)
+#pragma unroll
+    for (int i = 0; i < (RM_T + 2 * RM_HALO) * 8 / 256; i++) {
+        const int cid = tid + i * 256, q = cid >> 3, c = cid & 7;
+        const int t = t0 - RM_HALO + q;
+        u32x4 val = {0u, 0u, 0u, 0u};
+        if (t >= 0 && t < n_p) val = *reinterpret_cast<const u32x4*>(vb + (long)t * ldv + c * 8);
+        *reinterpret_cast<u32x4*>(img + q * RM_P + c * 8) = val;
+    }
+    // Toeplitz operand W^T[k][t = r] = w[k - r], k in the accumulator order of k-step ks
+    const float* wh = w + h * RM_TAPS;
+    bf16x8 wf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int k = 16 * ks + (e < 4 ? 4 * hl + e : 8 + 4 * hl + (e - 4));
+            const int j = k - r;
+            const float x = (j >= 0 && j < RM_TAPS) ? wh[transpose ? RM_TAPS - 1 - j : j] : 0.f;
+            wf[ks][e] = (__bf16)x;
+        }
+    __syncthreads();
+    f32x16 acc[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; nb++) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[nb][e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) acc[nb] = MFMA(rm_frag_tr(img, 32 * nb, 32 * wave + 16 * ks, lane), wf[ks], acc[nb]);
+    }
+    const int t = t0 + 32 * wave + r;
+    if (t >= n_p) return;
+    bf16_t* orow = out + (long)b * o_bs + (long)t * ldo + h * RM_DH + 4 * hl;
+#pragma unroll
+    for (int nb = 0; nb < 2; nb++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            bf16_t* p = orow + 32 * nb + 8 * g;
+            float x[4] = {acc[nb][4 * g], acc[nb][4 * g + 1], acc[nb][4 * g + 2], acc[nb][4 * g + 3]};
+            if (accumulate) {
+                const u32x2 old = *reinterpret_cast<const u32x2*>(p);
+                x[0] += __uint_as_float(old[0] << 16); x[1] += __uint_as_float(old[0] & 0xffff0000u);
+                x[2] += __uint_as_float(old[1] << 16); x[3] += __uint_as_float(old[1] & 0xffff0000u);
+            }
+            u32x2 o;
+            o[0] = (unsigned)f2bf(x[0]) | ((unsigned)f2bf(x[1]) << 16);
+            o[1] = (unsigned)f2bf(x[2]) | ((unsigned)f2bf(x[3]) << 16);
+            *reinterpret_cast<u32x2*>(p) = o;
+        }
+}
+
+// grid (splits, heads, B); wave w of the block walks 32-row blocks blockIdx.x * 4 + w, + 4 gridDim.x, ...
+__global__ __launch_bounds__(256) void resconv_wgrad_mfma_kernel(const bf16_t* __restrict__ v, long ldv, long v_bs,
+                                                                 const bf16_t* __restrict__ dout, long ldo, long o_bs,
+                                                                 float* __restrict__ dw, int n_p) {
+    __shared__ float gsum[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 5, r = lane & 31;
+    const int h = blockIdx.y, b = blockIdx.z;
+    if (tid < 64) gsum[tid] = 0.f;
+    const bf16_t* vb = v + (long)b * v_bs + h * RM_DH + 8 * hl;
+    const bf16_t* gb = dout + (long)b * o_bs + h * RM_DH + 8 * hl;
+    f32x16 acc[2];     // S[i = output row (registers)][k = input row (lanes)], k block 0 / 1
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[kb][e] = 0.f;
+    const int nblk = (n_p + 31) / 32;
+    for (int tb = blockIdx.x * 4 + wave; tb < nblk; tb += 4 * gridDim.x) {
+        const int t = 32 * tb + r;
+        bf16x8 af[4], bf[2][4];
+        const bool tok = t < n_p;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            u32x4 a = {0u, 0u, 0u, 0u};
+            if (tok) a = *reinterpret_cast<const u32x4*>(gb + (long)t * ldo + 16 * ks);
+            af[ks] = __builtin_bit_cast(bf16x8, a);
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) {
+            const int q = 32 * tb - RM_HALO + 32 * kb + r;
+            const bool qok = q >= 0 && q < n_p;
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                u32x4 x = {0u, 0u, 0u, 0u};
+                if (qok) x = *reinterpret_cast<const u32x4*>(vb + (long)q * ldv + 16 * ks);
+                bf[kb][ks] = __builtin_bit_cast(bf16x8, x);
+            }
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) acc[kb] = MFMA(af[ks], bf[kb][ks], acc[kb]);
+    }
+    __syncthreads();
+    // diagonal sums: S[i][k] belongs to tap j = k - i
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int i = 8 * (e >> 2) + 4 * hl + (e & 3);
+            const int j = 32 * kb + r - i;
+            if (j >= 0 && j < RM_TAPS) atomicAdd(&gsum[j], acc[kb][e]);
+        }
+    __syncthreads();
+    if (tid < RM_TAPS) atomicAdd(dw + h * RM_TAPS + tid, gsum[tid]);
+}
+
+}  // namespace
+
+// true when the MFMA path took the launch (bf16 in / bf16 out, dh = 64, 33 taps, 16-byte aligned rows)
+bool resconv_try_mfma(const void* v, long ldv, long v_bs, const float* w, void* out, long ldo, long o_bs, int B, int n_p, int heads,
+                      int dh, int taps, int transpose, int accumulate, int dt_v, int dt_o, hipStream_t s) {
+    if (dt_v != MH_BF16 || dt_o != MH_BF16 || dh != RM_DH || taps != RM_TAPS) return false;
+    if (ldv % 8 || v_bs % 8 || ldo % 4 || o_bs % 4 || ((uintptr_t)v & 15) || ((uintptr_t)out & 7)) return false;
+    dim3 grid(mh_cdiv(n_p, RM_T), heads, B);
+    hipLaunchKernelGGL(resconv_mfma_kernel, grid, dim3(256), 0, s, (const bf16_t*)v, ldv, v_bs, w, (bf16_t*)out, ldo, o_bs, n_p,
+                       transpose, accumulate);
+    return true;
+}
+
+bool resconv_wgrad_try_mfma(const void* v, long ldv, long v_bs, const void* dout, long ldo, long o_bs, float* dw, int B, int n_p,
+                            int heads, int dh, int taps, int dt_v, int dt_o, hipStream_t s) {
+    if (dt_v != MH_BF16 || dt_o != MH_BF16 || dh != RM_DH || taps != RM_TAPS) return false;
+    if (ldv % 8 || v_bs % 8 || ldo % 8 || o_bs % 8 || ((uintptr_t)v & 15) || ((uintptr_t)dout & 15)) return false;
+    const int nblk = mh_cdiv(n_p, 32);
+    int splits = 1;
+    while (splits * 2 * heads * B <= 2048 && splits * 2 * 4 <= nblk) splits *= 2;
+    dim3 grid(splits, heads, B);
+    hipLaunchKernelGGL(resconv_wgrad_mfma_kernel, grid, dim3(256), 0, s, (const bf16_t*)v, ldv, v_bs, (const bf16_t*)dout, ldo, o_bs,
+                       dw, n_p);
+    return true;
+}

@@ -284,6 +284,43 @@ def test_resconv_fwd_adjoint_wgrad(dh, n_p):
     close(dw, wr.grad.reshape(h, taps), 1e-4, 1e-3, "resconv wgrad")
 
 
+@pytest.mark.parametrize("n_p", [256, 100, 4352])
+def test_resconv_mfma_path_bf16(n_p):
+    """bf16 / dh = 64 / 33 taps runs as a banded Toeplitz product on the matrix cores (resconv_mfma.hip): forward,
+    transposed (data-gradient) form and the weight gradient against conv2d autograd on the bf16-rounded operands."""
+    gen = g(n_p)
+    B, h, dh, taps = 2, 8, 64, 33
+    D = h * dh
+    bf = torch.bfloat16
+    qkv = torch.randn(B, n_p, 3 * D, generator=gen).to(bf)
+    w = (torch.randn(h, 1, taps, 1, generator=gen) * 0.2)
+    wq = w.to(bf).float()                                               # the kernel feeds bf16 weights to the MFMA
+    v = qkv[..., 2 * D:].float().reshape(B, n_p, h, dh).permute(0, 2, 1, 3).contiguous().requires_grad_(True)
+    wr = wq.clone().requires_grad_(True)
+    from oracle import mirror_oracle as O
+    with O.exact_cpu_convs():     # torch's oneDNN CPU conv2d weight gradient is wrong at n_p = 256 (DESIGN.md §2)
+        ref = F.conv2d(v, wr, padding=(taps // 2, 0), groups=h)
+    qkv_d = qkv.to(DEV)
+    base = torch.randn(B, n_p, D, generator=gen).to(bf)
+    out = base.to(DEV).clone()
+    K.resconv(qkv_d[..., 2 * D:], w.to(DEV), out, h, transpose=False, accumulate=True)
+    want = base.float() + ref.detach().permute(0, 2, 1, 3).reshape(B, n_p, D)
+    close(out, want, 1e-2, 2e-2, "resconv fwd (mfma, accumulate)")
+    out2 = torch.full((B, n_p, D), float("nan"), device=DEV, dtype=bf)
+    K.resconv(qkv_d[..., 2 * D:], w.to(DEV), out2, h, transpose=False, accumulate=False)
+    close(out2, ref.detach().permute(0, 2, 1, 3).reshape(B, n_p, D), 1e-2, 2e-2, "resconv fwd (mfma, store)")
+    dout = torch.randn(B, n_p, D, generator=gen).to(bf)
+    with O.exact_cpu_convs():
+        ref.backward(dout.float().reshape(B, n_p, h, dh).permute(0, 2, 1, 3))
+    dqkv = torch.zeros((B, n_p, 3 * D), device=DEV, dtype=bf)
+    K.resconv(dout.to(DEV), w.to(DEV), dqkv[..., 2 * D:], h, transpose=True, accumulate=True)
+    close(dqkv[..., 2 * D:], v.grad.permute(0, 2, 1, 3).reshape(B, n_p, D), 1e-2, 2e-2, "resconv adjoint (mfma)")
+    dw = torch.zeros((h, taps), device=DEV)
+    K.resconv_wgrad(qkv_d[..., 2 * D:], dout.to(DEV), dw, h)
+    gref = wr.grad.reshape(h, taps)
+    close(dw, gref, 2e-3, 2e-3 * float(gref.abs().max()), "resconv wgrad (mfma)")
+
+
 def test_pinv_init_and_adjoint():
     gen = g(2)
     BH, m = 6, 40
