@@ -147,15 +147,15 @@ int mh_pinv_chain_bwd(const void* XP, const void* saved, const void* dzf, void* 
  * attn1_fwd: out[:, :, head] = softmax_m(scale q k_l^T) w2 (overwrites), lse1 = row logsumexp.
  * attn3_fwd: av = softmax_n(scale q_l k^T) v, lse3.
  * attn1_bwd: writes the q block of dqkv and delta1; ADDS (f32 atomics) into dw2 and the k_l half of dlm.
- * attn3_bwd: writes the k and v blocks of dqkv; ADDS into the q_l half of dlm. */
+ * attn3_bwd: writes the k and v blocks of dqkv and delta3 [B,h,m] f32 (scratch); ADDS into the q_l half of dlm. */
 int mh_nys_attn1_fwd(const void* qkv, const void* lm, const void* w2, void* out, float* lse1, int B, int h, int n_p, int m,
                      int dh, float scale, mh_stream s);
 int mh_nys_attn3_fwd(const void* qkv, const void* lm, float* av, float* lse3, int B, int h, int n_p, int m, int dh, float scale,
                      mh_stream s);
 int mh_nys_attn1_bwd(const void* qkv, const void* lm, const void* w2, const void* dout, const float* lse1, float* delta1,
                      void* dqkv, float* dw2, float* dlm, int B, int h, int n_p, int m, int dh, float scale, mh_stream s);
-int mh_nys_attn3_bwd(const void* qkv, const void* lm, const float* av, const void* dav, const float* lse3, void* dqkv,
-                     float* dlm, int B, int h, int n_p, int m, int dh, float scale, mh_stream s);
+int mh_nys_attn3_bwd(const void* qkv, const void* lm, const float* av, const void* dav, const float* lse3, float* delta3,
+                     void* dqkv, float* dlm, int B, int h, int n_p, int m, int dh, float scale, mh_stream s);
 /* T = d*I - P  (batched [BH,m,m] f32) */
 int mh_eye_minus(const float* P, float* T, float d, int BH, int m, mh_stream s);
 

@@ -58,7 +58,7 @@ _SIGS = {
     "mh_nys_attn1_fwd": [P, P, P, P, P, I, I, I, I, I, F],
     "mh_nys_attn3_fwd": [P, P, P, P, I, I, I, I, I, F],
     "mh_nys_attn1_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, F],
-    "mh_nys_attn3_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, F],
+    "mh_nys_attn3_bwd": [P, P, P, P, P, P, P, P, I, I, I, I, I, F],
     "mh_seq_finish": [P, P, I, I, I, I, I],
     "mh_seq_finish_bwd": [P, P, I, I, I, I, I],
     "mh_ppeg_merge": [P, P, P, P, P, P, P, P, I],

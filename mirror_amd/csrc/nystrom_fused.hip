@@ -439,10 +439,31 @@ __global__ __launch_bounds__(NT) void nys_a3_fwd_kernel(const bf16_t* __restrict
     }
 }
 
+// delta3[bh, l] = sum_d dav[l, d] av[l, d]: once per (b, h) instead of once per 128-row tile (34x the reads)
+__global__ __launch_bounds__(256) void nys_delta3_kernel(const float* __restrict__ av, const bf16_t* __restrict__ dav,
+                                                         float* __restrict__ delta3) {
+    const long row = (long)blockIdx.x * NM + threadIdx.x;
+    const float* ar = av + row * ND;
+    const bf16_t* gr = dav + row * ND;
+    float d = 0.f;
+#pragma unroll
+    for (int e = 0; e < ND; e += 8) {
+        const u32x4 gv = *reinterpret_cast<const u32x4*>(gr + e);
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(ar + e), a1 = *reinterpret_cast<const f32x4*>(ar + e + 4);
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const float lo = __uint_as_float(gv[w] << 16), hi = __uint_as_float(gv[w] & 0xffff0000u);
+            const float x0 = w < 2 ? a0[2 * w] : a1[2 * w - 4], x1 = w < 2 ? a0[2 * w + 1] : a1[2 * w - 3];
+            d += lo * x0 + hi * x1;
+        }
+    }
+    delta3[row] = d;
+}
+
 // ============================================================================ attn3 backward, dk + dv (N kernel)
 // grid (n_p / 128, B h).  P3 = exp(scale q_l k^T - lse3), dv = P3^T dav, dS3 = P3 o (dav v^T - delta3) scale, dk = dS3^T q_l
 __global__ __launch_bounds__(NT) void nys_a3_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ lm,
-                                                            const float* __restrict__ av, const bf16_t* __restrict__ dav,
+                                                            const float* __restrict__ delta3, const bf16_t* __restrict__ dav,
                                                             const float* __restrict__ lse3, bf16_t* __restrict__ dqkv, Geo g) {
     __shared__ __attribute__((aligned(16))) bf16_t s_ql[NM * NP];
     __shared__ __attribute__((aligned(16))) bf16_t s_g[NM * NP];
@@ -452,24 +473,8 @@ __global__ __launch_bounds__(NT) void nys_a3_bwd_dkv_kernel(const bf16_t* __rest
     const int bh = blockIdx.y, b = bh / g.h, hd = bh % g.h, D = g.D;
     stage_rows<NM>(s_ql, lm + (long)b * NM * 2 * D + hd * ND, 2 * D, tid);
     stage_rows<NM>(s_g, dav + (long)bh * NM * ND, ND, tid);
-    {   // delta3[l] = sum_d dav[l, d] av[l, d]   (thread = landmark)
-        const float* ar = av + ((long)bh * NM + tid) * ND;
-        const bf16_t* gr = dav + ((long)bh * NM + tid) * ND;
-        float d = 0.f;
-#pragma unroll
-        for (int e = 0; e < ND; e += 8) {
-            const u32x4 gv = *reinterpret_cast<const u32x4*>(gr + e);
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(ar + e), a1 = *reinterpret_cast<const f32x4*>(ar + e + 4);
-#pragma unroll
-            for (int w = 0; w < 4; w++) {
-                const float lo = __uint_as_float(gv[w] << 16), hi = __uint_as_float(gv[w] & 0xffff0000u);
-                const float x0 = w < 2 ? a0[2 * w] : a1[2 * w - 4], x1 = w < 2 ? a0[2 * w + 1] : a1[2 * w - 3];
-                d += lo * x0 + hi * x1;
-            }
-        }
-        s_del[tid] = d;
-        s_lse[tid] = lse3[(long)bh * NM + tid];
-    }
+    s_del[tid] = delta3[(long)bh * NM + tid];       // thread = landmark
+    s_lse[tid] = lse3[(long)bh * NM + tid];
     const long row = (long)blockIdx.x * TR + wave * 32 + c;
     const bf16_t* krow = qkv + ((long)b * g.n_p + row) * 3 * D + D + hd * ND;
     bf16x8 kf[4], vf[4];
@@ -521,7 +526,7 @@ __global__ __launch_bounds__(NT) void nys_a3_bwd_dkv_kernel(const bf16_t* __rest
 // ============================================================================ attn3 backward, dq_l (L kernel)
 // grid (splits, B h).  dq_l[l, d] += sum_n dS3[l, n] k[n, d]   (f32 atomics into the q_l half of dlm)
 __global__ __launch_bounds__(NT) void nys_a3_bwd_dql_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ lm,
-                                                            const float* __restrict__ av, const bf16_t* __restrict__ dav,
+                                                            const float* __restrict__ delta3, const bf16_t* __restrict__ dav,
                                                             const float* __restrict__ lse3, float* __restrict__ dlm, Geo g,
                                                             int tiles_per_wg) {
     __shared__ __attribute__((aligned(16))) bf16_t s_k[TR * NP];
@@ -538,23 +543,17 @@ __global__ __launch_bounds__(NT) void nys_a3_bwd_dql_kernel(const bf16_t* __rest
     for (int j = 0; j < 2; j++) {
         const int lq = 64 * wave + 32 * j + c;
         const bf16_t* gr = dav + ((long)bh * NM + lq) * ND;
-        const float* ar = av + ((long)bh * NM + lq) * ND;
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) {
             qlf[j][ks] = frag_g(qlb + (long)lq * 2 * D, 16 * ks, lane);
             gf[j][ks] = frag_g(gr, 16 * ks, lane);
         }
-        float d = 0.f;   // this lane half covers d = 16 ks + 8 hl + {0..7}; the halves are joined by the shuffle
-#pragma unroll
-        for (int ks = 0; ks < 4; ks++)
-#pragma unroll
-            for (int e = 0; e < 8; e++) d += (float)gf[j][ks][e] * ar[16 * ks + 8 * hl + e];
-        delv[j] = d + __shfl_xor(d, 32, 64);
+        delv[j] = delta3[(long)bh * NM + lq];
         lsev[j] = lse3[(long)bh * NM + lq];
     }
     const bf16_t* kb = qkv + (long)b * g.n_p * 3 * D + D + hd * ND;
     const bf16_t* vb = kb + D;
-    f32x16 acc[2][2];   // dq_l^T[d (nb)][landmark (j)]
+    f32x16 acc[2][2];   // dq_l[landmark (j block, registers)][d (nb block, lanes)]
 #pragma unroll
     for (int nb = 0; nb < 2; nb++)
 #pragma unroll
@@ -584,23 +583,22 @@ __global__ __launch_bounds__(NT) void nys_a3_bwd_dql_kernel(const bf16_t* __rest
                 }
 #pragma unroll
                 for (int r = 0; r < 16; r++) dp[r] = __expf(s[r] * g.scale - lsev[j]) * (dp[r] - delv[j]) * g.scale;
+                // dS3^T in the accumulator layout IS dS3 as an A operand (row = landmark = lane, k = keys): the product
+                // comes out as dq_l[landmark (registers)][d (lanes)], so the final atomics are 128-byte coalesced
                 const bf16x8 d0 = pack8<0>(dp), d1 = pack8<1>(dp);
 #pragma unroll
                 for (int nb = 0; nb < 2; nb++) {
-                    acc[nb][j] = MFMA(frag_tr(s_k, 32 * nb, 32 * i, lane), d0, acc[nb][j]);
-                    acc[nb][j] = MFMA(frag_tr(s_k, 32 * nb, 32 * i + 16, lane), d1, acc[nb][j]);
+                    acc[nb][j] = MFMA(d0, frag_tr(s_k, 32 * nb, 32 * i, lane), acc[nb][j]);
+                    acc[nb][j] = MFMA(d1, frag_tr(s_k, 32 * nb, 32 * i + 16, lane), acc[nb][j]);
                 }
             }
     }
     float* dqb = dlm + (long)b * NM * 2 * D + hd * ND;
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-        float* drow = dqb + (long)(64 * wave + 32 * j + c) * 2 * D;
+    for (int j = 0; j < 2; j++)
 #pragma unroll
         for (int nb = 0; nb < 2; nb++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) atomicAdd(drow + 32 * nb + 8 * (r >> 2) + 4 * hl + (r & 3), acc[nb][j][r]);
-    }
+            atomic_tile(dqb + (long)(64 * wave + 32 * j) * 2 * D + 32 * nb, 2 * D, acc[nb][j], hl, c);
 }
 
 int check_geo(const char* fn, int B, int h, int n_p, int m, int dh) {
@@ -656,17 +654,18 @@ extern "C" int mh_nys_attn1_bwd(const void* qkv, const void* lm, const void* w2,
     return MH_OK;
 }
 
-extern "C" int mh_nys_attn3_bwd(const void* qkv, const void* lm, const float* av, const void* dav, const float* lse3, void* dqkv,
-                                float* dlm, int B, int h, int n_p, int m, int dh, float scale, mh_stream s) {
+extern "C" int mh_nys_attn3_bwd(const void* qkv, const void* lm, const float* av, const void* dav, const float* lse3, float* delta3,
+                                void* dqkv, float* dlm, int B, int h, int n_p, int m, int dh, float scale, mh_stream s) {
     if (int e = check_geo("mh_nys_attn3_bwd", B, h, n_p, m, dh)) return e;
     if (B == 0) return MH_OK;
     const Geo g{h, n_p, h * ND, scale};
+    hipLaunchKernelGGL(nys_delta3_kernel, dim3(B * h), dim3(NM), 0, (hipStream_t)s, av, (const bf16_t*)dav, delta3);
     hipLaunchKernelGGL(nys_a3_bwd_dkv_kernel, dim3(n_p / TR, B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv,
-                       (const bf16_t*)lm, av, (const bf16_t*)dav, lse3, (bf16_t*)dqkv, g);
+                       (const bf16_t*)lm, (const float*)delta3, (const bf16_t*)dav, lse3, (bf16_t*)dqkv, g);
     MH_LAUNCH_CHECK("mh_nys_attn3_bwd(dkv)");
     const int ntiles = n_p / TR, splits = pick_splits(B * h, ntiles), tpw = (ntiles + splits - 1) / splits;
     hipLaunchKernelGGL(nys_a3_bwd_dql_kernel, dim3(splits, B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv,
-                       (const bf16_t*)lm, av, (const bf16_t*)dav, lse3, dlm, g, tpw);
+                       (const bf16_t*)lm, (const float*)delta3, (const bf16_t*)dav, lse3, dlm, g, tpw);
     MH_LAUNCH_CHECK("mh_nys_attn3_bwd(dql)");
     return MH_OK;
 }

@@ -510,8 +510,9 @@ def nys_attn3_bwd(qkv, lm, av, dav, lse3, dqkv, dlm, heads: int, scale: float) -
     _chk(qkv, lm, av, dav, lse3, dqkv, dlm)
     B, n_p, _ = qkv.shape
     _nys_check("nys_attn3_bwd", B, heads, n_p, qkv=qkv, lm=lm, av=av, dav=dav, lse3=lse3, dqkv=dqkv, dlm=dlm)
+    delta3 = torch.empty_like(lse3)
     _nys_launch("nys_a3_bwd_kernels", 7 * 2.0 * n_p * NYS_FUSED_M * NYS_FUSED_DH * B * heads,
-                lambda: _lib.call("mh_nys_attn3_bwd", _p(qkv), _p(lm), _p(av), _p(dav), _p(lse3), _p(dqkv), _p(dlm), B, heads,
+                lambda: _lib.call("mh_nys_attn3_bwd", _p(qkv), _p(lm), _p(av), _p(dav), _p(lse3), _p(delta3), _p(dqkv), _p(dlm), B, heads,
                                   n_p, NYS_FUSED_M, NYS_FUSED_DH, scale, stream=_stream()))
 
 
