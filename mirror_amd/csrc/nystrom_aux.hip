@@ -516,6 +516,41 @@ __global__ __launch_bounds__(256) void pinv_z0_bwd_kernel(const float* __restric
     if (threadIdx.x == 0) atomicAdd(scratch, dot);
 }
 
+// m % 64 == 0: 64 x 64 tiles, 16-byte loads and stores (the 32 x 32 scalar tiles ran at 1.2 TB/s)
+__global__ __launch_bounds__(256) void pinv_z0_bwd_vec_kernel(const float* __restrict__ z0, const float* __restrict__ dz0,
+                                                              const unsigned long long* __restrict__ st, float* __restrict__ dx,
+                                                              float* __restrict__ scratch, int m) {
+    typedef float zf4 __attribute__((ext_vector_type(4)));
+    __shared__ float tile[64][65];
+    __shared__ float red[4];
+    const float inv = 1.f / (stat_val(st, 0) * stat_val(st, 1));
+    const long base = (long)blockIdx.z * m * m;
+    const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+    const int c4 = (threadIdx.x & 15) * 4, r = threadIdx.x >> 4;   // 16 float4 per row, 16 rows per pass
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int i = i0 + r + 16 * k;
+        const zf4 d = *reinterpret_cast<const zf4*>(dz0 + base + (long)i * m + j0 + c4);
+        const zf4 z = *reinterpret_cast<const zf4*>(z0 + base + (long)i * m + j0 + c4);
+        dot += d[0] * z[0] + d[1] * z[1] + d[2] * z[2] + d[3] * z[3];
+#pragma unroll
+        for (int e = 0; e < 4; e++) tile[r + 16 * k][c4 + e] = d[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int j = j0 + r + 16 * k;             // dx[j][i0 + c4 ..] += dz0[i0 + c4 ..][j] * inv
+        zf4* p = reinterpret_cast<zf4*>(dx + base + (long)j * m + i0 + c4);
+        zf4 o = *p;
+#pragma unroll
+        for (int e = 0; e < 4; e++) o[e] += tile[c4 + e][r + 16 * k] * inv;
+        *p = o;
+    }
+    dot = block_sum256(dot, red);
+    if (threadIdx.x == 0) atomicAdd(scratch, dot);
+}
+
 // sub-gradients through the two torch.max(): d(c r) = -S/(c r); dc = d(cr)*r -> row i*: dx += dc*sign(x);
 // dr = d(cr)*c -> column j*: dx += dr*sign(x)
 __global__ void pinv_max_bwd_kernel(const float* __restrict__ x, const unsigned long long* __restrict__ st,
@@ -538,8 +573,13 @@ extern "C" int mh_pinv_z0_bwd(const float* x, const float* z0, const float* dz0,
     if (BH == 0) return MH_OK;
     hipError_t e = hipMemsetAsync(scratch1, 0, sizeof(float), (hipStream_t)s);
     if (e != hipSuccess) { mh_set_error("mh_pinv_z0_bwd: memset failed"); return MH_EHIP; }
-    dim3 grid(mh_cdiv(m, 32), mh_cdiv(m, 32), BH);
-    hipLaunchKernelGGL(pinv_z0_bwd_kernel, grid, dim3(256), 0, (hipStream_t)s, z0, dz0, (const unsigned long long*)stats64, dx, scratch1, m);
+    if (m % 64 == 0 && (((uintptr_t)z0 | (uintptr_t)dz0 | (uintptr_t)dx) & 15) == 0) {
+        hipLaunchKernelGGL(pinv_z0_bwd_vec_kernel, dim3(m / 64, m / 64, BH), dim3(256), 0, (hipStream_t)s, z0, dz0,
+                           (const unsigned long long*)stats64, dx, scratch1, m);
+    } else {
+        dim3 grid(mh_cdiv(m, 32), mh_cdiv(m, 32), BH);
+        hipLaunchKernelGGL(pinv_z0_bwd_kernel, grid, dim3(256), 0, (hipStream_t)s, z0, dz0, (const unsigned long long*)stats64, dx, scratch1, m);
+    }
     hipLaunchKernelGGL(pinv_max_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, x, (const unsigned long long*)stats64, scratch1, dx, m);
     MH_LAUNCH_CHECK("mh_pinv_z0_bwd");
     return MH_OK;

@@ -74,3 +74,10 @@ if which in ("all", "ppeg"):
     dm = torch.zeros(D * 49, device=dev)
     dbs = torch.zeros(D, device=dev)
     timeit("ppeg_wgrad f32", lambda: K.ppeg_wgrad(x, dout, dm, dbs, S), x.numel() * 8)
+if which in ("all", "pinv"):
+    a2 = torch.randn(B, h, 256, 256, device=dev).softmax(-1)
+    stt = K.pinv_absmax(a2)
+    z0 = K.pinv_z0(a2, stt)
+    dz0 = torch.randn_like(a2)
+    dxx = torch.zeros_like(a2)
+    timeit("pinv_z0_bwd [128,256,256]", lambda: K.pinv_z0_bwd(a2, z0, dz0, stt, dxx), a2.numel() * 16)
