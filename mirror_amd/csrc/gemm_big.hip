@@ -6,7 +6,8 @@
 // peak — more than the fabric delivers; 256 x 256 tiles halve that, and halve the LDS fragment reads per MFMA as well
 // (6 fragment reads feed 8 MFMAs instead of 4 feeding 4).  Same staging scheme as gemm_kernel (global -> registers
 // one K-tile ahead -> double-buffered LDS, ds_read_b64_tr_b16 for K-strided operands), 144 KiB of LDS.
-// Used by gemm_launch_bf16 when M, N are multiples of 256, K of 64, and the operands are 16-byte aligned.
+// Used by gemm_launch_bf16 when N is a multiple of 256, K of 64, M a multiple of 256 (or ragged with K-contiguous A rows:
+// loads clamp to the last row, stores are guarded) and the operands are 16-byte aligned.
 #include "gemm_kernel.h"
 
 namespace {
@@ -49,6 +50,7 @@ __device__ __forceinline__ void epilogue_big(const GemmArgs& g, TC* C, f32x16 (&
             const int cid = tid + i * NTB;
             const int lr = cid / CPR, c = cid % CPR;
             const float* src = t + lr * PITCH + c * EPC;
+            if (tile_row0 + half * HALF + lr >= g.M) continue;      // ragged last row tile (K-contiguous A only)
             TC* dst = C + (long)(tile_row0 + half * HALF + lr) * g.ldc + tile_col0 + c * EPC;
             f32x4 x0 = *reinterpret_cast<const f32x4*>(src);
             u32x4 o;
@@ -156,7 +158,8 @@ __global__ __launch_bounds__(NTB) void gemm_big_kernel(GemmArgs g) {
     }
     const bool lead = (split == 0);
     if (g.atomic) {
-        epilogue<TC, BWM, BWN, true, 2>(g, C, nullptr, acc, tile_m * BIG + wm * BWM * 32, tile_n * BIG + wn * BWN * 32, lane, lead);
+        if (tile_m * BIG + BIG <= g.M) epilogue<TC, BWM, BWN, true, 2>(g, C, nullptr, acc, tile_m * BIG + wm * BWM * 32, tile_n * BIG + wn * BWN * 32, lane, lead);
+        else epilogue<TC, BWM, BWN, false, 2>(g, C, nullptr, acc, tile_m * BIG + wm * BWM * 32, tile_n * BIG + wn * BWN * 32, lane, lead);
     } else if (g.accumulate) {
         epilogue_big<TC, 1>(g, C, acc, smem, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, lead);
     } else {
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(NTB) void gemm_big_kernel(GemmArgs g) {
 
 template <typename TC>
 void launch_big(GemmArgs& a, int akc, int bkc, int batch, hipStream_t s) {
-    a.tiles_m = a.M / BIG;
+    a.tiles_m = (a.M + BIG - 1) / BIG;     // a ragged last row tile is allowed when A rows are K-contiguous
     a.tiles_n = a.N / BIG;
     dim3 grid(a.tiles_m * a.tiles_n, a.split_k, batch);
     if (akc && bkc) hipLaunchKernelGGL((gemm_big_kernel<TC, true, true>), grid, dim3(NTB), 0, s, a);
@@ -179,9 +182,9 @@ void launch_big(GemmArgs& a, int akc, int bkc, int batch, hipStream_t s) {
 
 // true when the large-tile kernel took the launch
 bool gemm_try_big_bf16(GemmArgs& a, int akc, int bkc, int dtC, int batch, hipStream_t s) {
-    const bool shape_ok = a.M % BIG == 0 && a.N % BIG == 0 && a.K % 64 == 0 && a.k_per_split % 64 == 0;
+    const bool shape_ok = (a.M % BIG == 0 || (akc && a.M > BIG)) && a.N % BIG == 0 && a.K % 64 == 0 && a.k_per_split % 64 == 0;
     if (!shape_ok || !a.vecA || !a.vecB || !a.vecC || a.R || a.diag != 0.f) return false;
-    const long wgs = (long)(a.M / BIG) * (a.N / BIG) * a.split_k * batch;
+    const long wgs = (long)((a.M + BIG - 1) / BIG) * (a.N / BIG) * a.split_k * batch;
     if (wgs < 128) return false;            // too few workgroups for one per CU: the 128 x 128 kernel spreads better
     if (dtC == MH_BF16) launch_big<bf16_t>(a, akc, bkc, batch, s);
     else launch_big<float>(a, akc, bkc, batch, s);

@@ -161,10 +161,11 @@ def gemm_variant(d: GemmDesc) -> str:
     okc = d.C % 16 == 0 and d.ldc % cvec == 0 and d.sC1 % cvec == 0 and d.sC2 % cvec == 0
     batch = d.batch1 * d.batch2
     atomic = split > 1 or (d.accumulate and batch > 1 and d.sC1 == 0 and d.sC2 == 0)
-    if (d.mma == MH_BF16 and d.dtA == MH_BF16 and d.dtB == MH_BF16 and d.M % 256 == 0 and d.N % 256 == 0 and kk % 64 == 0
+    if (d.mma == MH_BF16 and d.dtA == MH_BF16 and d.dtB == MH_BF16 and (d.M % 256 == 0 or (d.a_kc and d.M > 256))
+            and d.N % 256 == 0 and kk % 64 == 0
             and kps % 64 == 0 and oka and okb and okc and not d.R and d.diag == 0.0
             and not (atomic and (d.bias or d.act != 0 or d.dtC != MH_F32))
-            and (d.M // 256) * (d.N // 256) * -(-kk // kps) * batch >= 128 and os.environ.get("MH_GEMM_BIG", "1")[:1] != "0"):
+            and -(-d.M // 256) * (d.N // 256) * -(-kk // kps) * batch >= 128 and os.environ.get("MH_GEMM_BIG", "1")[:1] != "0"):
         return f"gemm_big_kernel<{_TN[d.dtC]},{'true' if d.a_kc else 'false'},{'true' if d.b_kc else 'false'}>"
     full = (oka and okb and (d.a_kc or d.M % 128 == 0)
             and d.N % (64 * wn) == 0 and kk % bk == 0 and kk % kps == 0)

@@ -94,6 +94,14 @@ def test_gemm_large_tile_kernel(a_rm, b_t, out_dtype):
         dw = base[0].to(DEV).contiguous()
         K.gemm(a_dev, b_dev, out=dw.expand(Bt, M, N), accumulate=True, split_k=3, mma=MH_BF16)   # batch broadcast + split-K
         close(dw, ref.sum(0) + base[0].double(), 0, 0, "large tile split-K atomics")
+    if a_rm:        # ragged M (K-contiguous A rows): the last row tile clamps its loads and guards its stores
+        Mr = 4 * 256 + 37
+        ar_dev, ar = _mk(True, (Bt, Mr, Kd), gen, bf, True)
+        assert K.gemm_variant is not None
+        outr = torch.full((Bt, Mr + 3, N), 7.0, device=DEV, dtype=out_dtype)
+        K.gemm(ar_dev, b_dev, out=outr[:, :Mr], mma=MH_BF16)
+        close(outr[:, :Mr], (ar.double() @ b.double()).float().to(out_dtype).double(), 0, 0, "large tile ragged M")
+        assert bool((outr[:, Mr:] == 7.0).all()), "rows past M were written"
 
 
 @pytest.mark.parametrize("mma,dtype", [(MH_F32, torch.float32), (MH_BF16, torch.bfloat16)])
