@@ -144,12 +144,13 @@ int mh_pinv_chain_bwd(const void* XP, const void* saved, const void* dzf, void* 
  *   qkv [B,n_p,3D] bf16 (D = 64 h, heads are 64-wide column slices), lm [B,m,2D] bf16 = q_l | k_l,
  *   w2 [B,h,m,64] bf16, out/dout [B,n_p,D] bf16, av [B,h,m,64] f32, dav [B,h,m,64] bf16,
  *   lse1/delta1 [B,h,n_p] f32, lse3 [B,h,m] f32, dqkv like qkv, dw2 [B,h,m,64] f32, dlm [B,m,2D] f32.
- * attn1_fwd: out[:, :, head] = softmax_m(scale q k_l^T) w2 (overwrites), lse1 = row logsumexp.
+ * attn1_fwd: out[:, :, head] (+)= softmax_m(scale q k_l^T) w2 (accumulate = 1 adds to what is there, e.g. the res_conv
+ *            term computed while the pinv chain was running), lse1 = row logsumexp.
  * attn3_fwd: av = softmax_n(scale q_l k^T) v, lse3.
  * attn1_bwd: writes the q block of dqkv and delta1; ADDS (f32 atomics) into dw2 and the k_l half of dlm.
  * attn3_bwd: writes the k and v blocks of dqkv and delta3 [B,h,m] f32 (scratch); ADDS into the q_l half of dlm. */
 int mh_nys_attn1_fwd(const void* qkv, const void* lm, const void* w2, void* out, float* lse1, int B, int h, int n_p, int m,
-                     int dh, float scale, mh_stream s);
+                     int dh, float scale, int accumulate, mh_stream s);
 int mh_nys_attn3_fwd(const void* qkv, const void* lm, float* av, float* lse3, int B, int h, int n_p, int m, int dh, float scale,
                      mh_stream s);
 int mh_nys_attn1_bwd(const void* qkv, const void* lm, const void* w2, const void* dout, const float* lse1, float* delta1,

@@ -55,7 +55,7 @@ _SIGS = {
     "mh_pinv_chain_pack": [P, P, I, I],
     "mh_pinv_chain_fwd": [P, P, P, I, I, I],
     "mh_pinv_chain_bwd": [P, P, P, P, P, P, I, I, I],
-    "mh_nys_attn1_fwd": [P, P, P, P, P, I, I, I, I, I, F],
+    "mh_nys_attn1_fwd": [P, P, P, P, P, I, I, I, I, I, F, I],
     "mh_nys_attn3_fwd": [P, P, P, P, I, I, I, I, I, F],
     "mh_nys_attn1_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, F],
     "mh_nys_attn3_bwd": [P, P, P, P, P, P, P, P, I, I, I, I, I, F],

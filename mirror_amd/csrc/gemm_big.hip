@@ -78,6 +78,84 @@ __device__ __forceinline__ void epilogue_big(const GemmArgs& g, TC* C, f32x16 (&
     }
 }
 
+// split-K / batch-broadcast: f32 atomicAdd straight from the accumulators (lanes = 32 consecutive columns: coalesced);
+// rows past M (ragged last tile) are skipped
+__device__ __forceinline__ void epilogue_atomic_big(const GemmArgs& g, float* C, f32x16 (&acc)[BWM][BWN], int row0, int col0, int lane) {
+    const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < BWM; i++) {
+        const int rb = row0 + 32 * i + 4 * hh;
+        float* base = C + (long)rb * g.ldc + col0 + r;
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) {
+            const int dr = (reg & 3) + 8 * (reg >> 2);
+            if (rb + dr >= g.M) continue;
+            float* p = base + (long)dr * g.ldc;
+#pragma unroll
+            for (int j = 0; j < BWN; j++) atomicAdd(p + 32 * j, g.alpha * acc[i][j][reg]);
+        }
+    }
+}
+
+// bf16 output: the accumulators hold C^T (the MFMA takes the B fragment as its A operand), so a lane owns 4 consecutive
+// columns of one row: the whole 256 x 256 tile goes to LDS as bf16 with 8-byte stores (one pass, half the bytes of the
+// f32 image and no 4-byte scatter) and leaves as 16-byte row-contiguous stores.  Pitch 260: 16 lanes (rows) x 2 dwords
+// cover the 32 banks exactly.
+template <int MODE>
+__device__ __forceinline__ void epilogue_big_t(const GemmArgs& g, bf16_t* C, f32x16 (&acc)[BWM][BWN], char* smem, int tile_row0,
+                                               int tile_col0, int wm, int wn, int lane, int tid, bool lead) {
+    constexpr int PITCH = BIG + 4;
+    static_assert(BIG * PITCH * 2 <= 2 * (TileGeom<1, true, BIG>::BYTES + TileGeom<1, true, BIG>::BYTES), "bf16 tile must fit");
+    bf16_t* t = reinterpret_cast<bf16_t*>(smem);
+    const int r = lane & 31, hh = lane >> 5;
+    const bool has_bias = g.bias && lead;
+#pragma unroll
+    for (int j = 0; j < BWN; j++)
+#pragma unroll
+        for (int gq = 0; gq < 4; gq++) {
+            const int lc = wn * BWN * 32 + 32 * j + 8 * gq + 4 * hh;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (has_bias) bv = *reinterpret_cast<const f32x4*>(g.bias + tile_col0 + lc);
+#pragma unroll
+            for (int i = 0; i < BWM; i++) {
+                const int lr = wm * BWM * 32 + 32 * i + r;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    v[e] = g.alpha * acc[i][j][4 * gq + e] + bv[e];
+                    if (g.act == MH_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+                }
+                u32x2 o;
+                o[0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+                o[1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                *reinterpret_cast<u32x2*>(t + lr * PITCH + lc) = o;
+            }
+        }
+    __syncthreads();
+    constexpr int CPR = BIG / 8;                 // 16-byte chunks per tile row
+    constexpr int NCH = BIG * CPR / NTB;
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+        const int cid = tid + i * NTB;
+        const int lr = cid / CPR, c = cid % CPR;
+        if (tile_row0 + lr >= g.M) continue;      // ragged last row tile (K-contiguous A only)
+        bf16_t* dst = C + (long)(tile_row0 + lr) * g.ldc + tile_col0 + c * 8;
+        u32x2 lo = *reinterpret_cast<const u32x2*>(t + lr * PITCH + c * 8);
+        u32x2 hi = *reinterpret_cast<const u32x2*>(t + lr * PITCH + c * 8 + 4);
+        u32x4 o = {lo[0], lo[1], hi[0], hi[1]};
+        if constexpr (MODE == 1) {
+            const u32x4 old = *reinterpret_cast<const u32x4*>(dst);
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const float a0 = __uint_as_float(o[w] << 16) + __uint_as_float(old[w] << 16);
+                const float a1 = __uint_as_float(o[w] & 0xffff0000u) + __uint_as_float(old[w] & 0xffff0000u);
+                o[w] = (unsigned)f2bf(a0) | ((unsigned)f2bf(a1) << 16);
+            }
+        }
+        *reinterpret_cast<u32x4*>(dst) = o;
+    }
+}
+
 template <typename TC, bool AKC, bool BKC>
 __global__ __launch_bounds__(NTB) void gemm_big_kernel(GemmArgs g) {
     using GA = TileGeom<1, AKC, BIG>;
@@ -151,15 +229,22 @@ __global__ __launch_bounds__(NTB) void gemm_big_kernel(GemmArgs g) {
 #pragma unroll
             for (int i = 0; i < BWM; i++)
 #pragma unroll
-                for (int j = 0; j < BWN; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < BWN; j++) {
+                    if constexpr (sizeof(TC) == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // C^T
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                }
         }
         __syncthreads();
     }
     const bool lead = (split == 0);
+    if constexpr (sizeof(TC) == 2) {      // bf16 C is never an atomic target (mh_gemm requires f32 for split-K)
+        if (g.accumulate) epilogue_big_t<1>(g, C, acc, smem, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, lead);
+        else epilogue_big_t<0>(g, C, acc, smem, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, lead);
+        return;
+    }
     if (g.atomic) {
-        if (tile_m * BIG + BIG <= g.M) epilogue<TC, BWM, BWN, true, 2>(g, C, nullptr, acc, tile_m * BIG + wm * BWM * 32, tile_n * BIG + wn * BWN * 32, lane, lead);
-        else epilogue<TC, BWM, BWN, false, 2>(g, C, nullptr, acc, tile_m * BIG + wm * BWM * 32, tile_n * BIG + wn * BWN * 32, lane, lead);
+        if constexpr (sizeof(TC) == 4)
+            epilogue_atomic_big(g, C, acc, tile_m * BIG + wm * BWM * 32, tile_n * BIG + wn * BWN * 32, lane);
     } else if (g.accumulate) {
         epilogue_big<TC, 1>(g, C, acc, smem, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, lead);
     } else {
@@ -184,6 +269,7 @@ void launch_big(GemmArgs& a, int akc, int bkc, int batch, hipStream_t s) {
 bool gemm_try_big_bf16(GemmArgs& a, int akc, int bkc, int dtC, int batch, hipStream_t s) {
     const bool shape_ok = (a.M % BIG == 0 || (akc && a.M > BIG)) && a.N % BIG == 0 && a.K % 64 == 0 && a.k_per_split % 64 == 0;
     if (!shape_ok || !a.vecA || !a.vecB || !a.vecC || a.R || a.diag != 0.f) return false;
+    if (a.atomic && (a.bias || a.act != MH_ACT_NONE || dtC != MH_F32)) return false;
     const long wgs = (long)((a.M + BIG - 1) / BIG) * (a.N / BIG) * a.split_k * batch;
     if (wgs < 128) return false;            // too few workgroups for one per CU: the 128 x 128 kernel spreads better
     if (dtC == MH_BF16) launch_big<bf16_t>(a, akc, bkc, batch, s);

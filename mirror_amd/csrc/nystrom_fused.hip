@@ -104,6 +104,7 @@ __device__ __forceinline__ void store_row4(bf16_t* p, const f32x16& a, int g) {
 struct Geo {
     int h, n_p, D;
     float scale;
+    int accumulate;     // attn1 forward: add to `out` (the res_conv term is already there) instead of overwriting it
 };
 
 // ============================================================================ attn1 forward (N kernel)
@@ -164,7 +165,17 @@ __global__ __launch_bounds__(NT) void nys_a1_fwd_kernel(const bf16_t* __restrict
     for (int nb = 0; nb < 2; nb++) {
         o[nb] *= inv;
 #pragma unroll
-        for (int gq = 0; gq < 4; gq++) store_row4(orow + 32 * nb + 8 * gq + 4 * hl, o[nb], gq);
+        for (int gq = 0; gq < 4; gq++) {
+            bf16_t* p = orow + 32 * nb + 8 * gq + 4 * hl;
+            if (g.accumulate) {
+                const u32x2 old = *reinterpret_cast<const u32x2*>(p);
+                o[nb][4 * gq + 0] += __uint_as_float(old[0] << 16);
+                o[nb][4 * gq + 1] += __uint_as_float(old[0] & 0xffff0000u);
+                o[nb][4 * gq + 2] += __uint_as_float(old[1] << 16);
+                o[nb][4 * gq + 3] += __uint_as_float(old[1] & 0xffff0000u);
+            }
+            store_row4(p, o[nb], gq);
+        }
     }
 }
 
@@ -611,10 +622,10 @@ int check_geo(const char* fn, int B, int h, int n_p, int m, int dh) {
 }  // namespace
 
 extern "C" int mh_nys_attn1_fwd(const void* qkv, const void* lm, const void* w2, void* out, float* lse1, int B, int h, int n_p,
-                                int m, int dh, float scale, mh_stream s) {
+                                int m, int dh, float scale, int accumulate, mh_stream s) {
     if (int e = check_geo("mh_nys_attn1_fwd", B, h, n_p, m, dh)) return e;
     if (B == 0) return MH_OK;
-    const Geo g{h, n_p, h * ND, scale};
+    const Geo g{h, n_p, h * ND, scale, accumulate};
     hipLaunchKernelGGL(nys_a1_fwd_kernel, dim3(n_p / TR, B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv, (const bf16_t*)lm,
                        (const bf16_t*)w2, (bf16_t*)out, lse1, g);
     MH_LAUNCH_CHECK("mh_nys_attn1_fwd");
@@ -625,7 +636,7 @@ extern "C" int mh_nys_attn3_fwd(const void* qkv, const void* lm, float* av, floa
                                 float scale, mh_stream s) {
     if (int e = check_geo("mh_nys_attn3_fwd", B, h, n_p, m, dh)) return e;
     if (B == 0) return MH_OK;
-    const Geo g{h, n_p, h * ND, scale};
+    const Geo g{h, n_p, h * ND, scale, 0};
     hipLaunchKernelGGL(nys_a3_fwd_kernel, dim3(B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv, (const bf16_t*)lm, av, lse3, g);
     MH_LAUNCH_CHECK("mh_nys_attn3_fwd");
     return MH_OK;
@@ -643,7 +654,7 @@ extern "C" int mh_nys_attn1_bwd(const void* qkv, const void* lm, const void* w2,
                                 float scale, mh_stream s) {
     if (int e = check_geo("mh_nys_attn1_bwd", B, h, n_p, m, dh)) return e;
     if (B == 0) return MH_OK;
-    const Geo g{h, n_p, h * ND, scale};
+    const Geo g{h, n_p, h * ND, scale, 0};
     hipLaunchKernelGGL(nys_a1_bwd_dq_kernel, dim3(n_p / TR, B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv,
                        (const bf16_t*)lm, (const bf16_t*)w2, (const bf16_t*)dout, lse1, delta1, (bf16_t*)dqkv, g);
     MH_LAUNCH_CHECK("mh_nys_attn1_bwd(dq)");
@@ -658,7 +669,7 @@ extern "C" int mh_nys_attn3_bwd(const void* qkv, const void* lm, const float* av
                                 void* dqkv, float* dlm, int B, int h, int n_p, int m, int dh, float scale, mh_stream s) {
     if (int e = check_geo("mh_nys_attn3_bwd", B, h, n_p, m, dh)) return e;
     if (B == 0) return MH_OK;
-    const Geo g{h, n_p, h * ND, scale};
+    const Geo g{h, n_p, h * ND, scale, 0};
     hipLaunchKernelGGL(nys_delta3_kernel, dim3(B * h), dim3(NM), 0, (hipStream_t)s, av, (const bf16_t*)dav, delta3);
     hipLaunchKernelGGL(nys_a3_bwd_dkv_kernel, dim3(n_p / TR, B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv,
                        (const bf16_t*)lm, (const float*)delta3, (const bf16_t*)dav, lse3, (bf16_t*)dqkv, g);

@@ -545,17 +545,19 @@ class NystromCoreFn(Function):
             zf, saved, st = pinv_forward(a2, iters, pm, sd)
         if not fused:
             av = K.gemm(a3, v, mma=mma, out_dtype=f32)                                   # [B,h,m,dh]
+        out = torch.empty((Bn, n_p, D), device=qkv.device, dtype=A)
+        if fused:   # res_conv(v) does not need the pseudo-inverse: it runs under the chain, attn1 then adds to it
+            K.resconv(qkv[..., 2 * D:], res_w.detach().contiguous(), out, h, transpose=False, accumulate=False)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
         # GEMMs that meet activation-dtype tensors cannot use the exact-f32 MFMA unless the activations are f32 too
         pio = pm if (pm == MH_BF16 or A == f32) else mma
         w2 = K.gemm(zf, av, mma=pio, out_dtype=A)
-        out = torch.empty((Bn, n_p, D), device=qkv.device, dtype=A)
         if fused:
-            lse1 = K.nys_attn1_fwd(qkv, lm, w2, out, h, scale)
+            lse1 = K.nys_attn1_fwd(qkv, lm, w2, out, h, scale, accumulate=True)
         else:
             K.gemm(a1, w2, out=_heads(out, 0, 1, h), mma=mma)
-        K.resconv(qkv[..., 2 * D:], res_w.detach().contiguous(), out, h, transpose=False, accumulate=True)
+            K.resconv(qkv[..., 2 * D:], res_w.detach().contiguous(), out, h, transpose=False, accumulate=True)
         stats = (lse1, lse3) if fused else (a1, a3)
         ctx.save_for_backward(qkv, res_w, lm, stats[0], a2, stats[1], av, w2, st, zfT if chain else zf,
                               *[t for it in saved for t in it])

@@ -470,15 +470,15 @@ def _nys_launch(name: str, flops: float, fn) -> None:
         gemm_profiler.launch_named(name, flops, fn)
 
 
-def nys_attn1_fwd(qkv, lm, w2, out, heads: int, scale: float) -> torch.Tensor:
-    """out[:, :, head] = softmax_m(scale q k_l^T) w2; returns the row logsumexp [B, h, n_p]."""
+def nys_attn1_fwd(qkv, lm, w2, out, heads: int, scale: float, accumulate: bool = False) -> torch.Tensor:
+    """out[:, :, head] (+)= softmax_m(scale q k_l^T) w2; returns the row logsumexp [B, h, n_p]."""
     _chk(qkv, lm, w2, out)
     B, n_p, _ = qkv.shape
     lse1 = torch.empty((B, heads, n_p), device=qkv.device, dtype=torch.float32)
     _nys_check("nys_attn1_fwd", B, heads, n_p, qkv=qkv, lm=lm, w2=w2, out=out)
     _nys_launch("nys_a1_fwd_kernel", 2 * 2.0 * n_p * NYS_FUSED_M * NYS_FUSED_DH * B * heads,
                 lambda: _lib.call("mh_nys_attn1_fwd", _p(qkv), _p(lm), _p(w2), _p(out), _p(lse1), B, heads, n_p, NYS_FUSED_M,
-                                  NYS_FUSED_DH, scale, stream=_stream()))
+                                  NYS_FUSED_DH, scale, int(accumulate), stream=_stream()))
     return lse1
 
 

@@ -728,6 +728,9 @@ def test_nys_fused_attention_sides(B, h, l):
     qkv_d, lm_d, w2_d, dout_d, dav_d = (t.to(DEV) for t in (qkv, lm, w2, dout, dav))
     out = torch.full((B, n_p, D), float("nan"), device=DEV, dtype=bf)
     lse1 = K.nys_attn1_fwd(qkv_d, lm_d, w2_d, out, h, scale)
+    out_acc = torch.ones((B, n_p, D), device=DEV, dtype=bf)
+    K.nys_attn1_fwd(qkv_d, lm_d, w2_d, out_acc, h, scale, accumulate=True)
+    close(out_acc, 1.0 + out.float().cpu(), 0.0, 2e-2 * float(out.float().abs().max()), "attn1 accumulate")
     av, lse3 = K.nys_attn3_fwd(qkv_d, lm_d, h, scale)
     out_ref, av_ref, s1, s3 = (t.detach() for t in (out_ref, av_ref, s1, s3))
     close(out, out_ref, 0.0, 2e-2 * float(out_ref.abs().max()), "attn1 out")
