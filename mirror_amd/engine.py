@@ -226,6 +226,7 @@ class TrainEngine:
 
     def _step_eager(self, wsi: torch.Tensor, rna: torch.Tensor, noise: Optional[dict]):
         Fn.dropout_step_begin(self.device)
+        Fn._res_grads.clear()
         if self._proto is not None:
             w = self._proto.weight
             K.rownorm_(w.data)

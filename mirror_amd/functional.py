@@ -268,9 +268,17 @@ class LayerNormFn(Function):
         rows, pad = ctx.rows, ctx.pad
         if not dy.is_contiguous():
             dy = dy.contiguous()
-        dx = torch.zeros_like(x) if rows < T else torch.empty_like(x)
         dg, sunk_g = _gbuf(gamma, (D,))
         db, sunk_b = _gbuf(beta, (D,))
+        # pre-norm residual block  x + f(LN(x)):  the residual add's backward ran first and left its gradient for x in
+        # _res_grads; LN adds its own dx INTO that tensor (mh_layernorm_bwd accumulate_dx) instead of handing autograd a
+        # second [B, T, D] f32 gradient to sum (a 400 MB elementwise pass per block)
+        G = _res_grads.pop(x.data_ptr(), None)
+        if G is not None and G.shape == x.shape and G.dtype == x.dtype and G.is_contiguous():
+            K.layernorm_bwd(dy[:, pad:], x, gamma.detach(), mean, rstd, G, dg, db, Bn, rows, D, T * D, (pad + rows) * D,
+                            accumulate_dx=True)
+            return None, _gret(gamma, dg, sunk_g), _gret(beta, db, sunk_b), None, None, None, None
+        dx = torch.zeros_like(x) if rows < T else torch.empty_like(x)
         K.layernorm_bwd(dy[:, pad:], x, gamma.detach(), mean, rstd, dx, dg, db, Bn, rows, D, T * D, (pad + rows) * D)
         return dx, _gret(gamma, dg, sunk_g), _gret(beta, db, sunk_b), None, None, None, None
 
@@ -284,22 +292,30 @@ def layer_norm(x, gamma, beta, eps, *, rows=None, pad=0, out_dtype=f32):
 
 
 # ------------------------------------------------------------------ elementwise with autograd
+_res_grads: dict = {}      # data_ptr of a residual-stream tensor -> the gradient tensor its LayerNorm should add into
+
+
 class AddFn(Function):
-    """a + b -> out_dtype (residual adds; a and b may differ in dtype)."""
+    """a + b -> out_dtype (residual adds; a and b may differ in dtype).  residual=True marks `a` as the input of a
+    pre-norm block x + f(LN(x)): the backward then publishes a's gradient for that LayerNorm to accumulate into."""
 
     @staticmethod
-    def forward(ctx, a, b, out_dtype):
+    def forward(ctx, a, b, out_dtype, residual):
         ctx.da, ctx.db = a.dtype, b.dtype
+        ctx.res_key = a.data_ptr() if (residual and a.is_contiguous()) else None
         return K.add(a.contiguous(), b.contiguous(), out_dtype=out_dtype)
 
     @staticmethod
     def backward(ctx, dy):
         dy = dy.contiguous()
-        return K.cast(dy, ctx.da), K.cast(dy, ctx.db), None
+        ga = K.cast(dy, ctx.da)
+        if ctx.res_key is not None and ga.dtype == f32:
+            _res_grads[ctx.res_key] = ga
+        return ga, K.cast(dy, ctx.db), None, None
 
 
-def add(a, b, out_dtype=f32):
-    return AddFn.apply(a, b, out_dtype)
+def add(a, b, out_dtype=f32, residual=False):
+    return AddFn.apply(a, b, out_dtype, residual)
 
 
 class GeluFn(Function):

@@ -105,9 +105,9 @@ class Block(nn.Module):
 
     def forward(self, x, prec: Precision):
         h = Fn.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, out_dtype=prec.act)
-        x = Fn.add(x, self.attn(h, prec), f32)
+        x = Fn.add(x, self.attn(h, prec), f32, residual=True)     # x feeds exactly norm1 and this add
         h = Fn.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, out_dtype=prec.act)
-        return Fn.add(x, self.mlp(h, prec), f32)
+        return Fn.add(x, self.mlp(h, prec), f32, residual=True)
 
 
 class TransFormer(nn.Module):
@@ -184,7 +184,7 @@ class TransLayer(nn.Module):
         core = Fn.NystromCoreFn.apply(qkv, a.res_conv.weight, a.heads, l, a.pinv_iterations, prec)
         y = Fn.LinearRowsFn.apply(core, a.to_out[0].weight, a.to_out[0].bias, pad, n, prec, prec.act)
         y = Fn.dropout(y, a.drop, self.training)
-        return Fn.add(x, y, f32)
+        return Fn.add(x, y, f32, residual=True)                     # x feeds exactly self.norm and this add
 
 
 class PPEG(nn.Module):
