@@ -179,10 +179,10 @@ int mh_ppeg_wgrad(const void* x, const void* dout, float* dmerged, float* dbsum,
  * mask[b,i] = 1 if rank(noise[b,i]) >= len_keep (rank by ascending noise, ties by index) */
 int mh_rank_mask(const float* noise, float* mask, int B, int N, int len_keep, mh_stream s);
 /* x [B, T, D] rows t>=first: x = mask[b,t-first] ? token : x ; then x += pos[t]  (pos [T,D]) */
-int mh_mask_apply_fwd(void* x, const float* mask, const float* token, const float* pos, int B, int T, int D,
-                      int first, int token_scalar, int dt, mh_stream s);
-/* dx = dy*(1-mask) (in place); dtoken += sum mask*dy ; dpos[t] += sum_b dy */
-int mh_mask_apply_bwd(void* dy, const float* mask, float* dtoken, float* dpos, int B, int T, int D,
+int mh_mask_apply_fwd(const void* x, void* y, const float* mask, const float* token, const float* pos, int B, int T, int D,
+                      int first, int token_scalar, int dt, mh_stream s);   /* y may be x (in place) */
+/* dx = dy*(1-mask) (dx may be dy); dtoken += sum mask*dy ; dpos[t] += sum_b dy */
+int mh_mask_apply_bwd(const void* dy, void* dx, const float* mask, float* dtoken, float* dpos, int B, int T, int D,
                       int first, int token_scalar, int dt, mh_stream s);
 
 /* ---------------------------------------------------------------- RNA encoder pieces (models/mirror.py:77-102)

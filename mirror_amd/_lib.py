@@ -65,8 +65,8 @@ _SIGS = {
     "mh_ppeg_fwd": [P, P, P, P, I, I, I, I, I, I],
     "mh_ppeg_wgrad": [P, P, P, P, I, I, I, I, I],
     "mh_rank_mask": [P, P, I, I, I],
-    "mh_mask_apply_fwd": [P, P, P, P, I, I, I, I, I, I],
-    "mh_mask_apply_bwd": [P, P, P, P, I, I, I, I, I, I],
+    "mh_mask_apply_fwd": [P, P, P, P, P, I, I, I, I, I, I],
+    "mh_mask_apply_bwd": [P, P, P, P, P, I, I, I, I, I, I],
     "mh_headattn_fwd": [P, P, P, I, I, I, I],
     "mh_headattn_bwd": [P, P, P, P, I, I, I, I],
     "mh_add": [P, P, P, L, I, I, I],

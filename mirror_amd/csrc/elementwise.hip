@@ -187,9 +187,9 @@ extern "C" int mh_rank_mask(const float* noise, float* mask, int B, int N, int l
 
 // x [B,T,D]: rows t >= first take the mask token where mask[b,t-first] != 0; every row gets + pos[t]
 template <typename T>
-__global__ __launch_bounds__(256) void mask_apply_fwd_kernel(T* x, const float* __restrict__ mask, const float* __restrict__ token,
-                                                             const float* __restrict__ pos, int B, int Tn, int D, int first,
-                                                             int token_scalar) {
+__global__ __launch_bounds__(256) void mask_apply_fwd_kernel(const T* x, T* y, const float* __restrict__ mask,
+                                                             const float* __restrict__ token, const float* __restrict__ pos, int B, int Tn,
+                                                             int D, int first, int token_scalar) {
     const long total = (long)B * Tn * D;
     EW_LOOP(idx, total) {
         const int c = idx % D;
@@ -198,7 +198,25 @@ __global__ __launch_bounds__(256) void mask_apply_fwd_kernel(T* x, const float* 
         const long b = bt / Tn;
         float v = ldf(x + idx);
         if (t >= first && mask[b * (Tn - first) + (t - first)] != 0.f) v = token[token_scalar ? 0 : c];
-        stf(x + idx, v + pos[(long)t * D + c]);
+        stf(y + idx, v + pos[(long)t * D + c]);
+    }
+}
+
+// f32, D % 4 == 0, per-channel token: one (b, t) row per wave iteration, 16-byte accesses, no per-element div / mod
+typedef float mf_f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void mask_apply_fwd_vec_kernel(const float* x, float* y, const float* __restrict__ mask,
+                                                                 const float* __restrict__ token, const float* __restrict__ pos, int B,
+                                                                 int Tn, int D, int first) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long rows = (long)B * Tn;
+    for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+        const int t = (int)(row % Tn);
+        const long b = row / Tn;
+        const bool masked = t >= first && mask[b * (Tn - first) + (t - first)] != 0.f;
+        for (int c = 4 * lane; c < D; c += 256) {
+            const mf_f4 v = masked ? *reinterpret_cast<const mf_f4*>(token + c) : *reinterpret_cast<const mf_f4*>(x + row * D + c);
+            *reinterpret_cast<mf_f4*>(y + row * D + c) = v + *reinterpret_cast<const mf_f4*>(pos + (long)t * D + c);
+        }
     }
 }
 
@@ -206,9 +224,9 @@ __global__ __launch_bounds__(256) void mask_apply_fwd_kernel(T* x, const float* 
 // atomics and the mask-token gradient costs one f32 atomic per column per block.
 #define MB_BAND 64
 template <typename T>
-__global__ __launch_bounds__(256) void mask_apply_bwd_kernel(T* dy, const float* __restrict__ mask, float* __restrict__ dtoken,
-                                                             float* __restrict__ dpos, int B, int Tn, int D, int first,
-                                                             int token_scalar) {
+__global__ __launch_bounds__(256) void mask_apply_bwd_kernel(const T* dy, T* dx, const float* __restrict__ mask,
+                                                             float* __restrict__ dtoken, float* __restrict__ dpos, int B, int Tn, int D,
+                                                             int first, int token_scalar) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
@@ -218,10 +236,12 @@ __global__ __launch_bounds__(256) void mask_apply_bwd_kernel(T* dy, const float*
         for (int t = t0 + slice; t < t1; t += 4) {
             float sp = 0.f;
             for (int b = 0; b < B; b++) {
-                T* p = dy + ((long)b * Tn + t) * D + c;
-                const float g = ldf(p);
+                const long at = ((long)b * Tn + t) * D + c;
+                const float g = ldf(dy + at);
                 sp += g;
-                if (t >= first && mask[(long)b * (Tn - first) + (t - first)] != 0.f) { st += g; stf(p, 0.f); }
+                const bool msk = t >= first && mask[(long)b * (Tn - first) + (t - first)] != 0.f;
+                if (msk) st += g;
+                stf(dx + at, msk ? 0.f : g);
             }
             dpos[(long)t * D + c] += sp;
         }
@@ -236,9 +256,9 @@ __global__ __launch_bounds__(256) void mask_apply_bwd_kernel(T* dy, const float*
 
 // f32, D % 4 == 0: lane owns 4 columns (16-byte accesses), a wave owns one t at a time and has 8 batch rows in flight
 typedef float mb_f4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void mask_apply_bwd_vec_kernel(float* dy, const float* __restrict__ mask, float* __restrict__ dtoken,
-                                                                 float* __restrict__ dpos, int B, int Tn, int D, int first,
-                                                                 int token_scalar, int band) {
+__global__ __launch_bounds__(256) void mask_apply_bwd_vec_kernel(const float* dy, float* dx, const float* __restrict__ mask,
+                                                                 float* __restrict__ dtoken, float* __restrict__ dpos, int B, int Tn, int D,
+                                                                 int first, int token_scalar, int band) {
     __shared__ mb_f4 red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 256 + 4 * lane;
@@ -256,10 +276,10 @@ __global__ __launch_bounds__(256) void mask_apply_bwd_vec_kernel(float* dy, cons
                 for (int u = 0; u < 8; u++) {
                     if (b0 + u >= B) break;
                     sp += g[u];
-                    if (t >= first && mask[(long)(b0 + u) * (Tn - first) + (t - first)] != 0.f) {
-                        st += g[u];
-                        *reinterpret_cast<mb_f4*>(dy + ((long)(b0 + u) * Tn + t) * D + c) = (mb_f4){0.f, 0.f, 0.f, 0.f};
-                    }
+                    const bool msk = t >= first && mask[(long)(b0 + u) * (Tn - first) + (t - first)] != 0.f;
+                    if (msk) st += g[u];
+                    if (msk || dx != dy)
+                        *reinterpret_cast<mb_f4*>(dx + ((long)(b0 + u) * Tn + t) * D + c) = msk ? (mb_f4){0.f, 0.f, 0.f, 0.f} : g[u];
                 }
             }
             mb_f4* dp = reinterpret_cast<mb_f4*>(dpos + (long)t * D + c);
@@ -283,18 +303,21 @@ __global__ __launch_bounds__(256) void mask_apply_bwd_vec_kernel(float* dy, cons
 
 // D == 1 (the RNA channel axis is the masked axis): thread = position t, loop over the batch (coalesced across t)
 template <typename T>
-__global__ __launch_bounds__(256) void mask_apply_bwd_d1_kernel(T* dy, const float* __restrict__ mask, float* __restrict__ dtoken,
-                                                                float* __restrict__ dpos, int B, int Tn, int first) {
+__global__ __launch_bounds__(256) void mask_apply_bwd_d1_kernel(const T* dy, T* dx, const float* __restrict__ mask,
+                                                                float* __restrict__ dtoken, float* __restrict__ dpos, int B, int Tn,
+                                                                int first) {
     __shared__ float red[4];
     const int t = blockIdx.x * 256 + threadIdx.x;
     float st = 0.f;
     if (t < Tn) {
         float sp = 0.f;
         for (int b = 0; b < B; b++) {
-            T* p = dy + (long)b * Tn + t;
-            const float g = ldf(p);
+            const long at = (long)b * Tn + t;
+            const float g = ldf(dy + at);
             sp += g;
-            if (t >= first && mask[(long)b * (Tn - first) + (t - first)] != 0.f) { st += g; stf(p, 0.f); }
+            const bool msk = t >= first && mask[(long)b * (Tn - first) + (t - first)] != 0.f;
+            if (msk) st += g;
+            stf(dx + at, msk ? 0.f : g);
         }
         dpos[t] += sp;
     }
@@ -302,33 +325,39 @@ __global__ __launch_bounds__(256) void mask_apply_bwd_d1_kernel(T* dy, const flo
     if (threadIdx.x == 0 && st != 0.f) atomicAdd(dtoken, st);
 }
 
-extern "C" int mh_mask_apply_fwd(void* x, const float* mask, const float* token, const float* pos, int B, int T, int D,
+extern "C" int mh_mask_apply_fwd(const void* x, void* y, const float* mask, const float* token, const float* pos, int B, int T, int D,
                                  int first, int token_scalar, int dt, mh_stream s) {
     const long total = (long)B * T * D;
     if (total == 0) return MH_OK;
-    MH_DISPATCH_DT(dt, TT, hipLaunchKernelGGL((mask_apply_fwd_kernel<TT>), EW_GRID(total), dim3(256), 0, (hipStream_t)s, (TT*)x, mask, token, pos, B, T, D, first, token_scalar));
+    if (dt == MH_F32 && D % 4 == 0 && !token_scalar && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)token | (uintptr_t)pos) & 15) == 0) {
+        hipLaunchKernelGGL(mask_apply_fwd_vec_kernel, dim3((unsigned)min((long)mh_cdiv((long)B * T, 4), 16384L)), dim3(256), 0,
+                           (hipStream_t)s, (const float*)x, (float*)y, mask, token, pos, B, T, D, first);
+        MH_LAUNCH_CHECK("mh_mask_apply_fwd");
+        return MH_OK;
+    }
+    MH_DISPATCH_DT(dt, TT, hipLaunchKernelGGL((mask_apply_fwd_kernel<TT>), EW_GRID(total), dim3(256), 0, (hipStream_t)s, (const TT*)x, (TT*)y, mask, token, pos, B, T, D, first, token_scalar));
     MH_LAUNCH_CHECK("mh_mask_apply_fwd");
     return MH_OK;
 }
 
-extern "C" int mh_mask_apply_bwd(void* dy, const float* mask, float* dtoken, float* dpos, int B, int T, int D, int first,
-                                 int token_scalar, int dt, mh_stream s) {
+extern "C" int mh_mask_apply_bwd(const void* dy, void* dx, const float* mask, float* dtoken, float* dpos, int B, int T, int D,
+                                 int first, int token_scalar, int dt, mh_stream s) {
     if (T == 0 || D == 0 || B == 0) return MH_OK;
     if (D == 1) {
-        MH_DISPATCH_DT(dt, TT, hipLaunchKernelGGL((mask_apply_bwd_d1_kernel<TT>), dim3(mh_cdiv(T, 256)), dim3(256), 0, (hipStream_t)s, (TT*)dy, mask, dtoken, dpos, B, T, first));
+        MH_DISPATCH_DT(dt, TT, hipLaunchKernelGGL((mask_apply_bwd_d1_kernel<TT>), dim3(mh_cdiv(T, 256)), dim3(256), 0, (hipStream_t)s, (const TT*)dy, (TT*)dx, mask, dtoken, dpos, B, T, first));
         MH_LAUNCH_CHECK("mh_mask_apply_bwd");
         return MH_OK;
     }
-    if (dt == MH_F32 && D % 4 == 0 && D >= 256 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dpos & 15) == 0) {
+    if (dt == MH_F32 && D % 4 == 0 && D >= 256 && (((uintptr_t)dy | (uintptr_t)dx | (uintptr_t)dpos) & 15) == 0) {
         const int band = 16;     // rows of t per block: T / 16 x D / 256 blocks, 4 waves x 8 rows of 1 KiB in flight each
         dim3 gv(mh_cdiv(D, 256), mh_cdiv(T, band));
-        hipLaunchKernelGGL(mask_apply_bwd_vec_kernel, gv, dim3(256), 0, (hipStream_t)s, (float*)dy, mask, dtoken, dpos, B, T, D, first,
+        hipLaunchKernelGGL(mask_apply_bwd_vec_kernel, gv, dim3(256), 0, (hipStream_t)s, (const float*)dy, (float*)dx, mask, dtoken, dpos, B, T, D, first,
                            token_scalar, band);
         MH_LAUNCH_CHECK("mh_mask_apply_bwd");
         return MH_OK;
     }
     dim3 grid(mh_cdiv(D, 64), mh_cdiv(T, MB_BAND));
-    MH_DISPATCH_DT(dt, TT, hipLaunchKernelGGL((mask_apply_bwd_kernel<TT>), grid, dim3(256), 0, (hipStream_t)s, (TT*)dy, mask, dtoken, dpos, B, T, D, first, token_scalar));
+    MH_DISPATCH_DT(dt, TT, hipLaunchKernelGGL((mask_apply_bwd_kernel<TT>), grid, dim3(256), 0, (hipStream_t)s, (const TT*)dy, (TT*)dx, mask, dtoken, dpos, B, T, D, first, token_scalar));
     MH_LAUNCH_CHECK("mh_mask_apply_bwd");
     return MH_OK;
 }

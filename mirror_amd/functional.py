@@ -671,26 +671,28 @@ class MaskApplyFn(Function):
 
     @staticmethod
     def forward(ctx, x, mask, token, pos, first, token_scalar):
-        x = x.contiguous().clone()
+        x = x.contiguous()
         if x.dim() == 2:           # RNA: channels are the masked axis -> [B, T=D, 1]
             Bn, T, D = x.shape[0], x.shape[1], 1
         else:
             Bn, T, D = x.shape
+        y = torch.empty_like(x)
         K.mask_apply_fwd(x, mask, token.detach().reshape(-1).contiguous(), pos.detach().reshape(-1).contiguous(),
-                         Bn, T, D, first, token_scalar)
+                         Bn, T, D, first, token_scalar, out=y)
         ctx.save_for_backward(mask)
         ctx.geom = (Bn, T, D, first, token_scalar, token.shape, pos.shape)
-        return x
+        return y
 
     @staticmethod
     def backward(ctx, dy):
         (mask,) = ctx.saved_tensors
         Bn, T, D, first, token_scalar, tshape, pshape = ctx.geom
-        dy = dy.contiguous().clone()
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
         dtok = torch.zeros((1 if token_scalar else D,), device=dy.device, dtype=f32)
         dpos = torch.zeros((T * D,), device=dy.device, dtype=f32)
-        K.mask_apply_bwd(dy, mask, dtok, dpos, Bn, T, D, first, token_scalar)
-        return dy, None, dtok.reshape(tshape), dpos.reshape(pshape), None, None
+        K.mask_apply_bwd(dy, mask, dtok, dpos, Bn, T, D, first, token_scalar, out=dx)
+        return dx, None, dtok.reshape(tshape), dpos.reshape(pshape), None, None
 
 
 # ------------------------------------------------------------------ small heads

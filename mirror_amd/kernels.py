@@ -576,17 +576,23 @@ def rank_mask(noise: torch.Tensor, len_keep: int) -> torch.Tensor:
     return mask
 
 
-def mask_apply_fwd(x, mask, token, pos, B, T, D, first, token_scalar) -> None:
-    _chk(x, mask, token, pos)
+def mask_apply_fwd(x, mask, token, pos, B, T, D, first, token_scalar, out=None) -> None:
+    """out (same shape / dtype as x) receives the result; in place when omitted."""
+    out = x if out is None else out
+    _chk(x, mask, token, pos, out)
     assert x.is_contiguous() and x.numel() == B * T * D and mask.numel() == B * (T - first) and pos.numel() == T * D
-    _lib.call("mh_mask_apply_fwd", _p(x), _p(mask), _p(token), _p(pos), B, T, D, first, int(token_scalar), dt(x),
+    assert out.is_contiguous() and out.numel() == x.numel() and out.dtype == x.dtype
+    _lib.call("mh_mask_apply_fwd", _p(x), _p(out), _p(mask), _p(token), _p(pos), B, T, D, first, int(token_scalar), dt(x),
               stream=_stream())
 
 
-def mask_apply_bwd(dy, mask, dtoken, dpos, B, T, D, first, token_scalar) -> None:
-    _chk(dy, mask, dtoken, dpos)
+def mask_apply_bwd(dy, mask, dtoken, dpos, B, T, D, first, token_scalar, out=None) -> None:
+    """out (same shape / dtype as dy) receives dx; in place when omitted."""
+    out = dy if out is None else out
+    _chk(dy, mask, dtoken, dpos, out)
     assert dy.is_contiguous() and dy.numel() == B * T * D and dpos.numel() == T * D
-    _lib.call("mh_mask_apply_bwd", _p(dy), _p(mask), _p(dtoken), _p(dpos), B, T, D, first, int(token_scalar), dt(dy),
+    assert out.is_contiguous() and out.numel() == dy.numel() and out.dtype == dy.dtype
+    _lib.call("mh_mask_apply_bwd", _p(dy), _p(out), _p(mask), _p(dtoken), _p(dpos), B, T, D, first, int(token_scalar), dt(dy),
               stream=_stream())
 
 
