@@ -74,12 +74,71 @@ __global__ __launch_bounds__(256) void ppeg_kernel(const TX* __restrict__ x, TY*
     }
 }
 
+// Column-strip variant: a thread owns one channel and PX_T pixels along x and walks DOWN the grid with a 7-row register
+// window (row r lives in slot r mod 7; the walk is unrolled by 7 so every slot index is a compile-time constant).  Each
+// input row is loaded once per strip: (PX_T + 6) / PX_T = 1.75 loads per output instead of 12.25.
+#define PY_T 16   // grid rows per block
+template <typename TX, typename TY>
+__global__ __launch_bounds__(256) void ppeg_strip_kernel(const TX* __restrict__ x, TY* __restrict__ y, const float* __restrict__ merged,
+                                                         const float* __restrict__ bsum, int S, int D, int flip) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= D) return;
+    const int tiles_x = (S + PX_T - 1) / PX_T;
+    const int y0 = (blockIdx.y / tiles_x) * PY_T, x0 = (blockIdx.y % tiles_x) * PX_T;
+    const long b = blockIdx.z;
+    const long n = 1 + (long)S * S;
+    const TX* xb = x + b * n * D + c;
+    TY* yb = y + b * n * D + c;
+    if (blockIdx.y == 0) stf(yb, ldf(xb));  // cls token passes through
+    float w[49];
+#pragma unroll
+    for (int t = 0; t < 49; t++) w[t] = merged[(flip ? 48 - t : t) * D + c];
+    const float bias = flip ? 0.f : bsum[c];
+    float win[7][PX_T + 6];
+    auto load_row = [&](float (&dst)[PX_T + 6], int sy) {
+        const bool rok = sy >= 0 && sy < S;
+        const TX* row = xb + (1 + (long)(rok ? sy : 0) * S) * D;
+#pragma unroll
+        for (int u = 0; u < PX_T + 6; u++) {
+            const int sx = x0 - 3 + u;
+            dst[u] = (rok && sx >= 0 && sx < S) ? ldf(row + (long)sx * D) : 0.f;
+        }
+    };
+    // rows y0-3 .. y0+2 -> slots 4, 5, 6, 0, 1, 2
+    load_row(win[4], y0 - 3); load_row(win[5], y0 - 2); load_row(win[6], y0 - 1);
+    load_row(win[0], y0); load_row(win[1], y0 + 1); load_row(win[2], y0 + 2);
+    for (int yb0 = y0; yb0 < y0 + PY_T && yb0 < S; yb0 += 7) {
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            const int yy = yb0 + j;
+            if (yy >= y0 + PY_T || yy >= S) break;
+            load_row(win[(j + 3) % 7], yy + 3);
+            float acc[PX_T];
+#pragma unroll
+            for (int i = 0; i < PX_T; i++) acc[i] = bias;
+#pragma unroll
+            for (int ky = 0; ky < 7; ky++)
+#pragma unroll
+                for (int kx = 0; kx < 7; kx++) {
+                    const float wv = w[ky * 7 + kx];
+#pragma unroll
+                    for (int i = 0; i < PX_T; i++) acc[i] += wv * win[(j + ky + 4) % 7][i + kx];
+                }
+#pragma unroll
+            for (int i = 0; i < PX_T; i++)
+                if (x0 + i < S) stf(yb + (1 + (long)yy * S + x0 + i) * D, acc[i]);
+        }
+    }
+}
+
 extern "C" int mh_ppeg_fwd(const void* x, void* y, const float* merged, const float* bsum, int B, int S, int D, int flip,
                            int dt_x, int dt_y, mh_stream s) {
     MH_REQUIRE(S >= 1 && D >= 1, "mh_ppeg_fwd: bad shape S=%d D=%d", S, D);
     if (B == 0) return MH_OK;
-    dim3 grid(mh_cdiv(D, 256), S * mh_cdiv(S, PX_T), B);
-#define PP(TX, TY) hipLaunchKernelGGL((ppeg_kernel<TX, TY>), grid, dim3(256), 0, (hipStream_t)s, (const TX*)x, (TY*)y, merged, bsum, S, D, flip)
+    // PY_T = 16 rows per strip is not a multiple of the unroll (7): the walk is 7 + 7 + 2 rows with the window slots
+    // following the row index, so a strip must start at a slot-0 row -> strips are re-based every PY_T rows
+    dim3 grid(mh_cdiv(D, 256), mh_cdiv(S, PY_T) * mh_cdiv(S, PX_T), B);
+#define PP(TX, TY) hipLaunchKernelGGL((ppeg_strip_kernel<TX, TY>), grid, dim3(256), 0, (hipStream_t)s, (const TX*)x, (TY*)y, merged, bsum, S, D, flip)
     if (dt_x == MH_F32 && dt_y == MH_F32) PP(float, float);
     else if (dt_x == MH_BF16 && dt_y == MH_BF16) PP(bf16_t, bf16_t);
     else if (dt_x == MH_F32 && dt_y == MH_BF16) PP(float, bf16_t);
@@ -151,11 +210,69 @@ __global__ __launch_bounds__(256) void ppeg_wgrad_kernel(const TX* __restrict__ 
     }
 }
 
+// Column-strip weight gradient: a thread owns one channel and PX_T pixels along x, walks down PW_ROWS grid rows with the
+// same 7-row register window as ppeg_strip_kernel: 8 + 14 loads feed 49 x 8 FMAs (the row-sweep kernel needs 64).
+#define PW_ROWS 32
+template <typename TX, typename TO>
+__global__ __launch_bounds__(256) void ppeg_wgrad_strip_kernel(const TX* __restrict__ x, const TO* __restrict__ dout,
+                                                               float* __restrict__ dmerged, float* __restrict__ dbsum, int S, int D) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= D) return;
+    const int tiles_x = (S + PX_T - 1) / PX_T;
+    const int y0 = (blockIdx.y / tiles_x) * PW_ROWS, x0 = (blockIdx.y % tiles_x) * PX_T;
+    const long b = blockIdx.z;
+    const long n = 1 + (long)S * S;
+    const TX* xb = x + b * n * D + c;
+    const TO* gb = dout + b * n * D + c;
+    float acc[49];
+#pragma unroll
+    for (int t = 0; t < 49; t++) acc[t] = 0.f;
+    float bacc = 0.f;
+    float win[7][PX_T + 6];
+    auto load_row = [&](float (&dst)[PX_T + 6], int sy) {
+        const bool rok = sy >= 0 && sy < S;
+        const TX* row = xb + (1 + (long)(rok ? sy : 0) * S) * D;
+#pragma unroll
+        for (int u = 0; u < PX_T + 6; u++) {
+            const int sx = x0 - 3 + u;
+            dst[u] = (rok && sx >= 0 && sx < S) ? ldf(row + (long)sx * D) : 0.f;
+        }
+    };
+    load_row(win[4], y0 - 3); load_row(win[5], y0 - 2); load_row(win[6], y0 - 1);
+    load_row(win[0], y0); load_row(win[1], y0 + 1); load_row(win[2], y0 + 2);
+    for (int yb0 = y0; yb0 < y0 + PW_ROWS && yb0 < S; yb0 += 7) {
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            const int yy = yb0 + j;
+            if (yy >= y0 + PW_ROWS || yy >= S) break;
+            load_row(win[(j + 3) % 7], yy + 3);
+            float g[PX_T];
+#pragma unroll
+            for (int i = 0; i < PX_T; i++) {
+                g[i] = (x0 + i < S) ? ldf(gb + (1 + (long)yy * S + x0 + i) * D) : 0.f;
+                bacc += g[i];
+            }
+#pragma unroll
+            for (int ky = 0; ky < 7; ky++)
+#pragma unroll
+                for (int kx = 0; kx < 7; kx++) {
+                    float a = acc[ky * 7 + kx];
+#pragma unroll
+                    for (int i = 0; i < PX_T; i++) a += g[i] * win[(j + ky + 4) % 7][i + kx];
+                    acc[ky * 7 + kx] = a;
+                }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 49; t++) atomicAdd(dmerged + t * D + c, acc[t]);
+    atomicAdd(dbsum + c, bacc);
+}
+
 extern "C" int mh_ppeg_wgrad(const void* x, const void* dout, float* dmerged, float* dbsum, int B, int S, int D, int dt_x,
                              int dt_o, mh_stream s) {
     if (B == 0) return MH_OK;
-    dim3 grid(mh_cdiv(D, 64), mh_cdiv(S, WG_ROWS), B);
-#define PW(TX, TO) hipLaunchKernelGGL((ppeg_wgrad_kernel<TX, TO>), grid, dim3(256), 0, (hipStream_t)s, (const TX*)x, (const TO*)dout, dmerged, dbsum, S, D)
+    dim3 grid(mh_cdiv(D, 256), mh_cdiv(S, PW_ROWS) * mh_cdiv(S, PX_T), B);
+#define PW(TX, TO) hipLaunchKernelGGL((ppeg_wgrad_strip_kernel<TX, TO>), grid, dim3(256), 0, (hipStream_t)s, (const TX*)x, (const TO*)dout, dmerged, dbsum, S, D)
     if (dt_x == MH_F32 && dt_o == MH_F32) PW(float, float);
     else if (dt_x == MH_BF16 && dt_o == MH_BF16) PW(bf16_t, bf16_t);
     else if (dt_x == MH_F32 && dt_o == MH_BF16) PW(float, bf16_t);

@@ -74,6 +74,9 @@ if which in ("all", "ppeg"):
     dm = torch.zeros(D * 49, device=dev)
     dbs = torch.zeros(D, device=dev)
     timeit("ppeg_wgrad f32", lambda: K.ppeg_wgrad(x, dout, dm, dbs, S), x.numel() * 8)
+    merged = torch.randn(49 * D, device=dev)
+    bsum = torch.randn(D, device=dev)
+    timeit("ppeg_fwd f32", lambda: K.ppeg(x, merged, bsum, S, False), x.numel() * 8)
 if which in ("all", "pinv"):
     a2 = torch.randn(B, h, 256, 256, device=dev).softmax(-1)
     stt = K.pinv_absmax(a2)
