@@ -124,42 +124,41 @@ __global__ __launch_bounds__(NT) void nys_a1_fwd_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) qf[ks] = frag_g(qrow, 16 * ks, lane);
     __syncthreads();
-    f32x16 s[8];   // S^T[landmark][q row]
-#pragma unroll
-    for (int blk = 0; blk < 8; blk++) {
-        s[blk] = zero16();
-#pragma unroll
-        for (int ks = 0; ks < 4; ks++) s[blk] = MFMA(frag_kc(s_kl, 32 * blk, 16 * ks, lane), qf[ks], s[blk]);
-    }
-    float mx = -INFINITY;
-#pragma unroll
-    for (int blk = 0; blk < 8; blk++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[blk][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float ms = mx * g.scale;
-    float sum = 0.f;
-#pragma unroll
-    for (int blk = 0; blk < 8; blk++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const float p = __expf(s[blk][r] * g.scale - ms);
-            s[blk][r] = p;
-            sum += p;
-        }
-    sum += __shfl_xor(sum, 32, 64);
-    if (hl == 0) lse1[(long)bh * g.n_p + row] = ms + __logf(sum);
-    const float inv = 1.f / sum;
+    // online softmax over the 8 landmark blocks: 16 logits live at a time instead of 128 (two waves per SIMD fit)
+    float mrun = -INFINITY, lrun = 0.f;
     f32x16 o[2] = {zero16(), zero16()};   // O^T[d][q row]
 #pragma unroll
     for (int blk = 0; blk < 8; blk++) {
-        const bf16x8 p0 = pack8<0>(s[blk]), p1 = pack8<1>(s[blk]);
+        f32x16 sb = zero16();             // S^T[landmark 32 blk ..][q row]
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) sb = MFMA(frag_kc(s_kl, 32 * blk, 16 * ks, lane), qf[ks], sb);
+        float mx = sb[0];
+#pragma unroll
+        for (int r = 1; r < 16; r++) mx = fmaxf(mx, sb[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(mrun, mx * g.scale);
+        const float alpha = __expf(mrun - mnew);
+        mrun = mnew;
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const float pv = __expf(sb[r] * g.scale - mnew);
+            sb[r] = pv;
+            sum += pv;
+        }
+        lrun = lrun * alpha + sum;        // per lane half; the halves are joined once at the end
+        o[0] *= alpha;
+        o[1] *= alpha;
+        const bf16x8 p0 = pack8<0>(sb), p1 = pack8<1>(sb);
 #pragma unroll
         for (int nb = 0; nb < 2; nb++) {
             o[nb] = MFMA(frag_tr(s_w2, 32 * nb, 32 * blk, lane), p0, o[nb]);
             o[nb] = MFMA(frag_tr(s_w2, 32 * nb, 32 * blk + 16, lane), p1, o[nb]);
         }
     }
+    const float sum = lrun + __shfl_xor(lrun, 32, 64);
+    if (hl == 0) lse1[(long)bh * g.n_p + row] = mrun + __logf(sum);
+    const float inv = 1.f / sum;
     bf16_t* orow = out + ((long)b * g.n_p + row) * D + hd * ND;
 #pragma unroll
     for (int nb = 0; nb < 2; nb++) {
