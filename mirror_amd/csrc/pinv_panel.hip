@@ -27,6 +27,7 @@
 //   banks, panel writes (16 lanes, one row each, same chunk) hit 16 distinct chunk slots, and 16-byte row copies
 //   stay 16-byte (the two halves swap when k1 = 1).
 #include "gemm_kernel.h"
+#include <cstdlib>
 
 #ifndef EXP
 #define EXP 0
@@ -40,6 +41,14 @@ constexpr int NJ = 2;          // 32-column blocks per wave
 constexpr int NCH = CM * CM / 8 / CT;   // 16-byte chunks per thread in a row copy
 constexpr long MAT = (long)CM * CM;
 constexpr int IMG = CM * CM * 2;
+// Optional (MH_CHAIN_CLAIM=1): claim the CU's whole 160 KiB of LDS so that no LDS-using workgroup of the main stream
+// shares the chain's SIMDs.  Measured neutral on the full step (the co-running kernels simply take twice as long on the
+// other half of the chip: what the chain costs is its CU-time), so it is off by default.
+constexpr int LDS_CLAIM = 160 * 1024;
+static int chain_claim_bytes() {
+    static const int n = [] { const char* e = getenv("MH_CHAIN_CLAIM"); return (e && e[0] == '1') ? LDS_CLAIM - IMG : 0; }();
+    return n;
+}
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -551,7 +560,7 @@ extern "C" int mh_pinv_chain_fwd(const void* XT, void* saved, void* zfT, int BH,
     MH_REQUIRE(m == CM, "mh_pinv_chain_fwd: m=%d unsupported (built for m = %d; other sizes use mh_gemm)", m, CM);
     MH_REQUIRE(iters >= 1 && BH >= 0, "mh_pinv_chain_fwd: bad arguments");
     if (BH == 0) return MH_OK;
-    hipLaunchKernelGGL(pinv_panel_fwd_kernel, dim3(BH), dim3(CT), 0, (hipStream_t)s, (const bf16_t*)XT, (bf16_t*)saved,
+    hipLaunchKernelGGL(pinv_panel_fwd_kernel, dim3(BH), dim3(CT), chain_claim_bytes(), (hipStream_t)s, (const bf16_t*)XT, (bf16_t*)saved,
                        (bf16_t*)zfT, BH, iters);
     MH_LAUNCH_CHECK("mh_pinv_chain_fwd");
     return MH_OK;
@@ -562,7 +571,7 @@ extern "C" int mh_pinv_chain_bwd(const void* XT, const void* saved, const void* 
     MH_REQUIRE(m == CM, "mh_pinv_chain_bwd: m=%d unsupported (built for m = %d; other sizes use mh_gemm)", m, CM);
     MH_REQUIRE(iters >= 1 && BH >= 0, "mh_pinv_chain_bwd: bad arguments");
     if (BH == 0) return MH_OK;
-    hipLaunchKernelGGL(pinv_panel_bwd_kernel, dim3(BH), dim3(CT), 0, (hipStream_t)s, (const bf16_t*)XT, (const bf16_t*)saved,
+    hipLaunchKernelGGL(pinv_panel_bwd_kernel, dim3(BH), dim3(CT), chain_claim_bytes(), (hipStream_t)s, (const bf16_t*)XT, (const bf16_t*)saved,
                        (const bf16_t*)dzf, (bf16_t*)work, dX, dz0, BH, iters);
     MH_LAUNCH_CHECK("mh_pinv_chain_bwd");
     return MH_OK;

@@ -15,6 +15,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -458,6 +460,8 @@ _side_streams: dict = {}
 
 def _side_stream(device, which: int = 0) -> torch.cuda.Stream:
     """Per-device helper streams: 0 = half-chip pinv chain, 1 = RNA encoder."""
+    if os.environ.get("MIRROR_EXP_NO_SIDE", "") and str(which) in os.environ["MIRROR_EXP_NO_SIDE"]:
+        return torch.cuda.current_stream()      # experiment: serialise this branch on the caller's stream
     key = (torch.device(device).index or 0, which)
     st = _side_streams.get(key)
     if st is None:
@@ -606,8 +610,8 @@ class NystromCoreFn(Function):
         dq, dk, dv = (_heads(dqkv, i, 3, h) for i in range(3))
         rw = res_w.detach().contiguous()
         dres = torch.zeros((rw.numel(),), device=qkv.device, dtype=f32)
-        K.resconv_wgrad(qkv[..., 2 * D:], dout, dres, h)
-        # out = a1 @ w2 ; w2 = Z @ av ; av = a3 @ v.  dZ first: it is all the pinv backward needs.
+        # out = a1 @ w2 ; w2 = Z @ av ; av = a3 @ v.  dZ first: it is all the pinv backward needs (the res_conv weight
+        # gradient does not depend on it and runs beside the chain, below).
         if fused:
             lse1, lse3 = a1, a3
             dW2 = torch.zeros((Bn, h, m, dh), device=qkv.device, dtype=f32)
@@ -633,6 +637,7 @@ class NystromCoreFn(Function):
                 K.pinv_chain_bwd(xb, chain_saved, dzb, work, dS2, dz0, iters)
                 K.pinv_z0_bwd(a2, z0, dz0, st, dS2)
                 K.softmax_bwd(a2, dS2)
+        K.resconv_wgrad(qkv[..., 2 * D:], dout, dres, h)
         dAV = K.gemm(tr(zf), dW2, mma=pio, out_dtype=A)                                  # [B,h,m,dh]
         if fused:
             K.nys_attn3_bwd(qkv, lm, av, dAV, lse3, dqkv, dlm, h, scale)                # dk, dv, dq_l

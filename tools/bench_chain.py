@@ -56,3 +56,44 @@ timeit("nys_attn1_fwd", lambda: K.nys_attn1_fwd(qkv, lm, w2, out, h, 0.125), 2 *
 timeit("nys_attn3_fwd", lambda: K.nys_attn3_fwd(qkv, lm, h, 0.125), 2 * fl)
 timeit("nys_attn1_bwd (2 kernels)", lambda: K.nys_attn1_bwd(qkv, lm, w2, dout, lse1, dqkv, dw2, dlm, h, 0.125), 7 * fl)
 timeit("nys_attn3_bwd (2 kernels)", lambda: K.nys_attn3_bwd(qkv, lm, av, dav, lse3, dqkv, dlm, h, 0.125), 7 * fl)
+
+# ---- does the chain really overlap with the attn3 side?  (side stream vs same stream)
+side = torch.cuda.Stream()
+w33 = torch.randn(h, 33, device=dev)
+outc = torch.zeros(B, n_p, D, device=dev, dtype=bf)
+
+
+def both(concurrent: bool):
+    main = torch.cuda.current_stream()
+    if concurrent:
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            K.pinv_chain_fwd(xp, saved, zfT, iters)
+    else:
+        K.pinv_chain_fwd(xp, saved, zfT, iters)
+    K.nys_attn3_fwd(qkv, lm, h, 0.125)
+    K.resconv(qkv[..., 2 * D:], w33, outc, h, transpose=False, accumulate=False)
+    if concurrent:
+        main.wait_stream(side)
+
+
+timeit("chain_fwd ; attn3_fwd ; resconv (serial)", lambda: both(False), 1.0)
+timeit("chain_fwd || attn3_fwd ; resconv", lambda: both(True), 1.0)
+
+
+def both_bwd(concurrent: bool):
+    main = torch.cuda.current_stream()
+    if concurrent:
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            K.pinv_chain_bwd(xp, saved, up, work, dX, dz0, iters)
+    else:
+        K.pinv_chain_bwd(xp, saved, up, work, dX, dz0, iters)
+    K.nys_attn3_bwd(qkv, lm, av, dav, lse3, dqkv, dlm, h, 0.125)
+    K.resconv(dout, w33, dqkv[..., 2 * D:], h, transpose=True, accumulate=True)
+    if concurrent:
+        main.wait_stream(side)
+
+
+timeit("chain_bwd ; attn3_bwd ; resconv^T (serial)", lambda: both_bwd(False), 1.0)
+timeit("chain_bwd || attn3_bwd ; resconv^T", lambda: both_bwd(True), 1.0)
