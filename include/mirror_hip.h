@@ -243,11 +243,16 @@ int mh_symkl_bwd(const float* w, const float* r, const float* g, float* dw, floa
 int mh_rownorm_(float* w, int rows, int D, float eps, mh_stream s);
 int mh_clamp_(float* x, int64_t n, float lo, float hi, mh_stream s);
 /* torch.optim.Adam (wd=0): flat f32 params/grads/moments; optional bf16 shadow copy of the params.
- * dev_state (nullable, 4 device floats {t, 1-b1^t, 1-b2^t, lr}): when given, t is advanced and the bias corrections are
- * refreshed ON THE DEVICE before the update and lr / bias_c1 / bias_c2 arguments are ignored — nothing step-dependent
+ * dev_state (nullable, 6 device floats {t, 1-b1^t, 1-b2^t, lr, clip, |g|}): when given, t is advanced and the bias
+ * corrections are refreshed ON THE DEVICE before the update, lr / bias_c1 / bias_c2 arguments are ignored and the
+ * gradient is additionally scaled by dev_state[4] (1, or the factor mh_grad_clip left there) — nothing step-dependent
  * is a launch argument, so the whole step can be captured in a HIP graph (train_mirror.py:1254 optimizer.step()) */
 int mh_adam(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr, float beta1,
             float beta2, float eps, float bias_c1, float bias_c2, float grad_scale, float* dev_state, mh_stream s);
+
+/* clip-grad "norm" mode (train_mirror.py:1206-1230): dev_state[5] = ||grad_scale * g||_2, dev_state[4] =
+ * min(1, max_norm / (norm + 1e-6)) (1 when max_norm <= 0); scratch1 = one device float. */
+int mh_grad_clip(const float* g, int64_t n, float grad_scale, float max_norm, float* scratch1, float* dev_state, mh_stream s);
 
 #ifdef __cplusplus
 }

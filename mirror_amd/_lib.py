@@ -91,6 +91,7 @@ _SIGS = {
     "mh_rownorm_": [P, I, I, F],
     "mh_clamp_": [P, L, F, F],
     "mh_adam": [P, P, P, P, P, L, F, F, F, F, F, F, F, P],
+    "mh_grad_clip": [P, L, F, F, P, P],
 }
 EXPORTS = sorted(list(_SIGS) + ["mh_last_error", "mh_version", "mh_device_ok"])
 

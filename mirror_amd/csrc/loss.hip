@@ -272,10 +272,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ v, bf16_t* __restrict__ shadow, long n, float lr, float b1,
                                                    float b2, float eps, float bc1, float bc2, float gscale,
                                                    const float* __restrict__ state) {
-    if (state) {   // device-resident step state {t, 1 - b1^t, 1 - b2^t, lr}: nothing step-dependent is a launch argument
+    if (state) {   // device-resident step state {t, 1 - b1^t, 1 - b2^t, lr, clip}: nothing step-dependent is a launch argument
         bc1 = state[1];
         bc2 = state[2];
         lr = state[3];
+        gscale *= state[4];     // gradient-clipping factor written by mh_grad_clip (1 when clipping is off)
     }
     const float step = lr / bc1;
     const float isq = rsqrtf(bc2);
@@ -313,13 +314,43 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
-// state = {t, 1 - b1^t, 1 - b2^t, lr}: t += 1 and the bias corrections are refreshed on the device, so a captured
-// HIP graph of the whole step replays with the right Adam step every time
+// state = {t, 1 - b1^t, 1 - b2^t, lr, clip, |g|}: t += 1 and the bias corrections are refreshed on the device, so a
+// captured HIP graph of the whole step replays with the right Adam step every time
 __global__ void adam_tick_kernel(float* state, float b1, float b2) {
     const float t = state[0] + 1.f;
     state[0] = t;
     state[1] = 1.f - powf(b1, t);
     state[2] = 1.f - powf(b2, t);
+}
+
+// ---- gradient clipping by global L2 norm (timm's clip_grad "norm" mode, train_mirror.py:1206-1230): the factor stays on
+// the device (state[4]) and mh_adam multiplies it into its gradient scale — no host round trip, graph-capturable
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ acc) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const long n4 = n / 4;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(g)[q];
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[n4 * 4 + threadIdx.x]; s += v * v; }
+    s = block_sum256(s, red);
+    if (threadIdx.x == 0) atomicAdd(acc, s);
+}
+__global__ void clip_factor_kernel(const float* acc, float gscale, float max_norm, float* state) {
+    const float norm = sqrtf(acc[0]) * gscale;
+    state[5] = norm;
+    state[4] = max_norm > 0.f ? fminf(1.f, max_norm / (norm + 1e-6f)) : 1.f;
+}
+
+extern "C" int mh_grad_clip(const float* g, int64_t n, float grad_scale, float max_norm, float* scratch1, float* dev_state,
+                            mh_stream s) {
+    MH_REQUIRE(((uintptr_t)g & 15) == 0 && dev_state && scratch1, "mh_grad_clip: bad arguments");
+    if (hipMemsetAsync(scratch1, 0, sizeof(float), (hipStream_t)s) != hipSuccess) { mh_set_error("mh_grad_clip: memset failed"); return MH_EHIP; }
+    if (n > 0) hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)min((long)mh_cdiv(mh_cdiv(n, 4), 256), 2048L)), dim3(256), 0, (hipStream_t)s, g, (long)n, scratch1);
+    hipLaunchKernelGGL(clip_factor_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, (const float*)scratch1, grad_scale, max_norm, dev_state);
+    MH_LAUNCH_CHECK("mh_grad_clip");
+    return MH_OK;
 }
 
 extern "C" int mh_adam(float* p, const float* g, float* m, float* v, void* shadow, int64_t n, float lr, float b1, float b2,

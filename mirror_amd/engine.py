@@ -48,7 +48,8 @@ def plan_buckets(sizes: Sequence[int], cap_elems: int, align: int = _ALIGN):
 class TrainEngine:
     def __init__(self, model: torch.nn.Module, loss_fn, *, lr: float = 2e-5, betas=(0.9, 0.999), eps: float = 1e-8,
                  precision: str = "bf16", wsi_mask_ratio: float = 0.75, rna_mask_ratio: float = 0.75,
-                 bucket_mb: float = 25.0, process_group=None, graph: Optional[bool] = None):
+                 bucket_mb: float = 25.0, process_group=None, graph: Optional[bool] = None,
+                 clip_grad: Optional[float] = None, accum_steps: int = 1):
         if precision not in POLICIES:
             raise ValueError(f"unknown precision {precision!r}")
         self.model, self.loss_fn = model, loss_fn
@@ -105,12 +106,18 @@ class TrainEngine:
         self._logit = getattr(model, "logit_scale", None)
         # step state on the device {t, 1 - b1^t, 1 - b2^t, lr}: advanced by mh_adam itself, so nothing that changes from
         # step to step is a launch argument and the whole step can be replayed as one HIP graph
-        self._state = torch.tensor([0.0, 0.0, 0.0, float(lr)], device=self.device, dtype=f32)
+        self._state = torch.tensor([0.0, 0.0, 0.0, float(lr), 1.0, 0.0], device=self.device, dtype=f32)
+        # timm's --clip-grad (mode "norm") and --grad-accum-steps (train_mirror.py:1192-1230): both stay on the device
+        self.clip_grad = clip_grad
+        self.accum_steps = max(1, int(accum_steps))
+        self._micro = 0
         self._state_lr = float(lr)
         # HIP graph of the step (~700 launches: the host needs ~10 ms to enqueue what the GPU runs in ~14 ms).  Single-GPU
         # only by default: with RCCL buckets in flight the eager path stays (MIRROR_GRAPH=1 forces, =0 disables).
         env = os.environ.get("MIRROR_GRAPH")
         self._use_graph = (self.world == 1 if graph is None else bool(graph)) if env is None else env not in ("0", "")
+        if self.accum_steps > 1:
+            self._use_graph = False      # micro-steps and update steps are different launch sequences
         self._graph = None
         self._graph_warm = 0
         self._g_in = None
@@ -161,6 +168,8 @@ class TrainEngine:
             p.register_post_accumulate_grad_hook(self._on_grad)
 
     def _on_grad(self, p: torch.Tensor) -> None:
+        if self._micro + 1 < self.accum_steps:      # accumulation micro-step: no reduction yet (DDP no_sync)
+            return
         b = self._bucket_of[id(p)]
         self._pending[b] -= 1
         if self._pending[b] == 0:
@@ -244,12 +253,20 @@ class TrainEngine:
             # reduces every bucket that is still pending)
             self._counting = False
         self._seen = [0] * len(self.params)
+        self._micro += 1
+        if self._micro < self.accum_steps:          # gradient accumulation: keep summing into the grad arena (the
+            Fn.dropout_step_end()                    # reference's no_sync micro-steps), no reduction, no update yet
+            return tuple(x.detach() for x in losses)
+        self._micro = 0
         self._finish_reduce()
         self.step_count += 1
         b1, b2 = self.betas
+        gs = 1.0 / (self.world * self.accum_steps)   # buckets are SUM-reduced, micro-batch losses are means
+        if self.clip_grad is not None:
+            K.grad_clip(self.grad, gs, float(self.clip_grad), self._state)
         K.adam(self.master, self.grad, self.m, self.v, self.shadow, self.lr, b1, b2, self.eps, 1.0, 1.0,
-               grad_scale=1.0 / self.world,    # buckets are SUM-reduced; the DDP average is folded into Adam
-               dev_state=self._state)          # t, bias corrections and lr live on the device
+               grad_scale=gs,                  # the DDP / accumulation average is folded into Adam
+               dev_state=self._state)          # t, bias corrections, lr and the clip factor live on the device
         self._refresh_transposes()
         if self._logit is not None:
             K.clamp_(self._logit.data.reshape(1), 0.0, math.log(100.0))

@@ -788,12 +788,21 @@ def clamp_(x: torch.Tensor, lo: float, hi: float) -> None:
     _lib.call("mh_clamp_", _p(x), x.numel(), lo, hi, stream=_stream())
 
 
+def grad_clip(g: torch.Tensor, grad_scale: float, max_norm: float, dev_state: torch.Tensor) -> None:
+    """Global-L2-norm clipping factor into dev_state[4] (and the norm into dev_state[5]); mh_adam applies it."""
+    _chk(g, dev_state)
+    assert g.dtype == torch.float32 and g.is_contiguous() and dev_state.numel() == 6
+    scratch = torch.empty(1, device=g.device, dtype=torch.float32)
+    _lib.call("mh_grad_clip", _p(g), g.numel(), grad_scale, max_norm, _p(scratch), _p(dev_state), stream=_stream())
+
+
 def adam(p, g, m, v, shadow, lr, b1, b2, eps, bc1, bc2, grad_scale=1.0, dev_state: Optional[torch.Tensor] = None) -> None:
-    """dev_state: optional f32[4] device tensor {t, 1-b1^t, 1-b2^t, lr}; when given the step count / bias corrections / lr
-    live on the device (advanced by the launch itself) and lr, bc1, bc2 are ignored."""
+    """dev_state: optional f32[6] device tensor {t, 1-b1^t, 1-b2^t, lr, clip, |g|}; when given the step count / bias
+    corrections / lr live on the device (advanced by the launch itself), lr, bc1, bc2 are ignored and the gradient is
+    also scaled by dev_state[4] (the factor grad_clip left there, else 1)."""
     _chk(p, g, m, v, shadow, dev_state)
     for t in (p, g, m, v):
         assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel()
-    assert dev_state is None or (dev_state.dtype == torch.float32 and dev_state.numel() == 4 and dev_state.is_contiguous())
+    assert dev_state is None or (dev_state.dtype == torch.float32 and dev_state.numel() == 6 and dev_state.is_contiguous())
     _lib.call("mh_adam", _p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), lr, b1, b2, eps, bc1, bc2, grad_scale,
               _p(dev_state), stream=_stream())

@@ -144,3 +144,35 @@ def test_graphed_step_replays_with_fresh_state():
         sl = slice(off, off + prm.numel())
         assert float((eng.master[sl] - before[sl]).abs().max()) == 0.0, "lr change was not published to the graphed step"
     assert float(eng._state[0]) == 7.0
+
+
+def test_grad_clip_and_accumulation_match_torch():
+    """clip_grad (global L2 norm, timm "norm" mode) and accum_steps against torch.optim.Adam + clip_grad_norm_ on the same
+    model: two micro-batches of 2 accumulate to the gradient of their mean loss, then one clipped update."""
+    from mirror_amd.engine import TrainEngine
+    from mirror_amd.losses import MIRRORLoss
+    ref = _make()
+    ref.precision = "fp32"
+    model = _make()
+    eng = TrainEngine(model, MIRRORLoss(), lr=1e-3, precision="fp32", clip_grad=0.05, accum_steps=2)
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-3)
+    init = {k: v.detach().clone() for k, v in _make().named_parameters()}
+    for upd in range(2):
+        with torch.no_grad():
+            ref.prototypes.weight.copy_(torch.nn.functional.normalize(ref.prototypes.weight, dim=1))
+        opt.zero_grad()
+        for micro in range(2):
+            wsi, rna, noise = _batch(2, 50 + 2 * upd + micro)
+            (MIRRORLoss()(*ref(wsi, rna, noise=noise))[0] / 2).backward()
+            eng.step(wsi, rna, noise=noise)
+        gn = torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.05)
+        assert abs(float(eng._state[5]) - float(gn)) < 2e-3 * float(gn), (float(eng._state[5]), float(gn))
+        opt.step()
+        with torch.no_grad():
+            ref.logit_scale.clamp_(0, 4.6052)
+    assert float(eng._state[0]) == 2.0
+    num = den = 0.0
+    for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        num += float((p.detach() - q.detach()).double().pow(2).sum())
+        den += float((p.detach() - init[k]).double().pow(2).sum())
+    assert num ** 0.5 < 0.05 * den ** 0.5, (num, den)
