@@ -1,9 +1,9 @@
 """Drop-in for the reference's `models` package (models/__init__.py:1-4) for the pre-training path."""
-from .mirror import MIRROR, mirror, set_precision, resolve_precision  # noqa: F401
+from .mirror import MIRROR, MIRRORClassifier, mirror, mirror_classifier, set_precision, resolve_precision  # noqa: F401
 
-__all__ = ["mirror"]
+__all__ = ["mirror", "mirror_classifier"]
 
-_REGISTRY = {"mirror": mirror}
+_REGISTRY = {"mirror": mirror, "mirror_classifier": mirror_classifier}
 
 
 def create_model(model_name: str, pretrained: bool = False, checkpoint_path: str = "", scriptable=None, **kwargs):
@@ -20,5 +20,6 @@ try:  # register with timm when it is installed so `timm.create_model("mirror")`
     from timm.models import register_model as _register_model
 
     _register_model(mirror)
+    _register_model(mirror_classifier)
 except Exception:  # timm absent: the local create_model above is the entry point
     pass

@@ -494,6 +494,53 @@ _ACCEPTED = {
 }
 
 
+# ===========================================
+#  Downstream classifier (inference / fine-tuning encoders)
+# ===========================================
+class MIRRORClassifier(nn.Module):
+    """models/mirror.py:921-1015: FeatureTransMIL (+ TransFormer) -> add / concat fusion -> linear head.  Same kwargs,
+    same state-dict keys (`wsi_encoder.*`, `rna_encoder.*`, `head.*`), so the checkpoints that tools/split_weights.py
+    cuts out of a pre-trained MIRROR load with strict=False exactly as in train_subtyping.py:740-763."""
+
+    def __init__(self, wsi_embed_dim: int, rna_embed_dim: int, embed_dim: int, num_classes: int, rna_encoder_depth: int = 2,
+                 rna_gene_embed: str = "learn", rna_mlp_ratio: float = 2.572, rna_pos_drop_rate: float = 0.0,
+                 rna_proj_drop_rate: float = 0.1, rna_attn_drop_rate: float = 0.0, rna_drop_path_rate: float = 0.0,
+                 rna_norm_layer=None, rna_act_layer=None, fusion: str = "concat", rna_num_heads: int = 12):
+        super().__init__()
+        assert fusion in ["add", "concat"], "Fusion must be either add or concat"
+        if rna_attn_drop_rate or rna_drop_path_rate:
+            raise NotImplementedError("attention dropout / stochastic depth are 0 in every reference config")
+        self.embed_dim, self.num_classes, self.fusion = embed_dim, num_classes, fusion
+        self.wsi_encoder = FeatureTransMIL(input_dim=wsi_embed_dim, embed_dim=embed_dim)
+        self.rna_encoder = TransFormer(input_dim=rna_embed_dim, embed_dim=embed_dim, depth=rna_encoder_depth,
+                                       num_heads=rna_num_heads, mlp_ratio=rna_mlp_ratio, gene_embed=rna_gene_embed,
+                                       pos_drop_rate=rna_pos_drop_rate, proj_drop_rate=rna_proj_drop_rate)
+        self.head = nn.Linear(embed_dim if fusion == "add" else embed_dim * 2, num_classes)
+        self.precision: Optional[str] = None
+
+    def forward(self, wsi_emb: torch.Tensor, rna_emb: Optional[torch.Tensor] = None) -> torch.Tensor:
+        prec = resolve_precision(self.precision)
+        self.wsi_encoder.precision = self.rna_encoder.precision = self.precision
+        w = self.wsi_encoder(wsi_emb)                                     # [B, D] f32
+        if rna_emb is None:
+            fused = w
+        else:
+            r = self.rna_encoder(rna_emb)
+            fused = Fn.add(w, r, f32) if self.fusion == "add" else torch.cat((w, r), dim=1)
+        return Fn.linear(fused.contiguous(), self.head.weight, self.head.bias, prec=prec, out_dtype=f32)
+
+
+def mirror_classifier(**kwargs) -> MIRRORClassifier:
+    """models/mirror.py:1056-1085 (kwarg filter with the same warning; `rna_num_heads` is a build-only extra)."""
+    accepted = {"wsi_embed_dim", "rna_embed_dim", "embed_dim", "rna_encoder_depth", "rna_gene_embed", "rna_mlp_ratio",
+                "rna_pos_drop_rate", "rna_proj_drop_rate", "rna_attn_drop_rate", "rna_drop_path_rate", "rna_norm_layer",
+                "rna_act_layer", "num_classes", "fusion", "rna_num_heads"}
+    dropped = [k for k in kwargs if k not in accepted]
+    if dropped:
+        _logger.warning("Filtered model kwargs: %s", ", ".join(dropped))
+    return MIRRORClassifier(**{k: v for k, v in kwargs.items() if k in accepted})
+
+
 def mirror(**kwargs) -> MIRROR:
     """Registry entry point (models/mirror.py:1018-1053): unknown kwargs (e.g. timm's pretrained*) are dropped with a warning."""
     kept = {k: v for k, v in kwargs.items() if k in _ACCEPTED}

@@ -263,6 +263,17 @@ LOSS_NAMES = ("total", "alignment", "wsi_retention", "rna_retention", "style", "
 
 
 # -------------------------------------------------------------------------------- losses
+def classifier_forward(sd: SD, cfg: Cfg, wsi: Tensor, rna: Optional[Tensor], fusion: str = "concat") -> Tensor:
+    """MIRRORClassifier.forward, models/mirror.py:998-1015: FeatureTransMIL (cls token of the normalised sequence,
+    :345-380) [+ TransFormer, :283-289] -> add / concat -> head."""
+    w = wsi_forward_encoder(wsi, sd, cfg)[:, 0]
+    if rna is None:
+        return _linear(w, sd, "head")
+    r = rna_forward_encoder(rna, sd, cfg)
+    fused = w + r if fusion == "add" else torch.cat([w, r], dim=1)
+    return _linear(fused, sd, "head")
+
+
 def clip_loss(w: Tensor, r: Tensor, scale: Tensor) -> Tensor:
     """ClipLoss.forward, losses/mirror_loss.py:37-52."""
     lab = torch.arange(w.shape[0])

@@ -86,6 +86,17 @@ def param_shapes(cfg: Cfg) -> List[Tuple[str, Tuple[int, ...]]]:
     return out
 
 
+def classifier_param_shapes(cfg: Cfg, num_classes: int, fusion: str = "concat") -> List[Tuple[str, Tuple[int, ...]]]:
+    """State-dict keys and shapes of `models.mirror.MIRRORClassifier` (models/mirror.py:921-996): the encoder keys of
+    MIRROR without the pre-training heads, plus `head`."""
+    drop = ("alignment_head", "retention_", "mask_token", "style_", "prototypes", "logit_scale")
+    out = [(k, sh) for k, sh in param_shapes(cfg) if not any(d in k for d in drop)]
+    d = cfg.embed_dim
+    out.append(("head.weight", (num_classes, 2 * d if fusion == "concat" else d)))
+    out.append(("head.bias", (num_classes,)))
+    return out
+
+
 def synth_state_dict(shapes: Sequence[Tuple[str, Tuple[int, ...]]], seed: int) -> Dict[str, torch.Tensor]:
     """Trained-like magnitudes: fan-in scaled matrices, LN gains near 1, small biases/tokens,
     unit-norm prototype rows (train_mirror.py:1133-1136), logit_scale = ln(1/0.07)."""

@@ -153,3 +153,36 @@ def test_model_refuses_cpu_tensors():
     from mirror_amd import MirrorHipError
     with pytest.raises(MirrorHipError):
         model(case.wsi, case.rna)
+
+
+@pytest.mark.parametrize("fusion", ["concat", "add"])
+def test_classifier_matches_reference_golden(fusion):
+    """MIRRORClassifier (downstream encoders), fp32 policy, eval mode: predictions and per-parameter
+    gradient norms of sum(pred^2) against the reference's recording; state-dict keys load strictly."""
+    import os
+    import numpy as np
+    import mirror_amd.models as M
+    from tools.make_golden import CLS_CFG as cfg
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_classifier.npz"))
+    keys = [str(k) for k in z[f"keys/{fusion}"]]
+    sd = {k: torch.from_numpy(z[f"sd/{fusion}/{k}" if f"sd/{fusion}/{k}" in z.files else f"sd/concat/{k}"]) for k in keys}
+    model = M.create_model("mirror_classifier", wsi_embed_dim=cfg.wsi_embed_dim, rna_embed_dim=cfg.rna_embed_dim,
+                           embed_dim=cfg.embed_dim, num_classes=5, rna_encoder_depth=cfg.rna_encoder_depth,
+                           rna_mlp_ratio=cfg.rna_mlp_ratio, rna_norm_layer="layernorm", rna_act_layer="gelu", fusion=fusion,
+                           an_unknown_kwarg=1)
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().eval()
+    model.precision = "fp32"
+    wsi, rna = torch.from_numpy(z["in/wsi"]).cuda(), torch.from_numpy(z["in/rna"]).cuda()
+    pred = model(wsi, rna)
+    want = z[f"pred/{fusion}"]
+    err = float(np.abs(pred.detach().cpu().numpy() - want).max()) / float(np.abs(want).max())
+    assert err <= 1e-4, err
+    if fusion == "add":
+        pw = model(wsi, None).detach().cpu().numpy()
+        assert float(np.abs(pw - z["pred/add_wsi_only"]).max()) <= 1e-4 * float(np.abs(z["pred/add_wsi_only"]).max())
+    pred.square().sum().backward()
+    params = dict(model.named_parameters())
+    for k, gn in zip(keys, z[f"grad_norm/{fusion}"]):
+        got = float(params[k].grad.double().norm())
+        assert abs(got - gn) <= 2e-3 * max(gn, 1e-3), (k, got, gn)

@@ -97,3 +97,23 @@ def test_nystrom_equals_softmax_attention_when_landmarks_are_tokens():
     a = (q @ k.transpose(-1, -2)).softmax(-1)
     approx = a @ O.pinv_iter(a, 30) @ a
     assert (approx - a).abs().max() < 1e-3
+
+
+def test_classifier_restatement_matches_reference():
+    """Downstream MIRRORClassifier: oracle vs the reference's recorded predictions."""
+    import os
+    import numpy as np
+    from oracle import synth
+    from oracle import mirror_oracle as O
+    from tools.make_golden import CLS_CFG
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_classifier.npz"))
+    wsi, rna = torch.from_numpy(z["in/wsi"]), torch.from_numpy(z["in/rna"])
+    for fusion in ("concat", "add"):
+        keys = [str(k) for k in z[f"keys/{fusion}"]]
+        assert keys == [k for k, _ in synth.classifier_param_shapes(CLS_CFG, 5, fusion)]
+        sd = {k: torch.from_numpy(z[f"sd/{fusion}/{k}" if f"sd/{fusion}/{k}" in z.files else f"sd/concat/{k}"]) for k in keys}
+        pred = O.classifier_forward(sd, CLS_CFG, wsi, rna, fusion)
+        np.testing.assert_allclose(pred.numpy(), z[f"pred/{fusion}"], rtol=1e-5, atol=1e-6)
+        if fusion == "add":
+            np.testing.assert_allclose(O.classifier_forward(sd, CLS_CFG, wsi, None, fusion).numpy(), z["pred/add_wsi_only"],
+                                       rtol=1e-5, atol=1e-6)

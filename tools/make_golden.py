@@ -171,6 +171,47 @@ def gen_model_case(mod, ref_losses, name, cfg: Cfg, batch, ratios, store_full, o
     print(f"{name}: losses(template)={rec['loss_template']}  -> {path} ({os.path.getsize(path)/1024:.0f} KiB)")
 
 
+CLS_CFG = Cfg(wsi_embed_dim=128, rna_embed_dim=96, embed_dim=96, wsi_num_tokens=50, rna_encoder_depth=2, rna_num_heads=12)
+
+
+def gen_classifier(mod, out_dir, used):
+    """Downstream model: MIRRORClassifier with both fusions and without RNA, eval mode."""
+    from oracle import mirror_oracle as O
+    rec = {"shim_timm": np.array(used["timm"]), "shim_nystrom": np.array(used["nystrom_attention"])}
+    cfg, ncls, batch = CLS_CFG, 5, 3
+    wsi, rna, _ = synth.synth_batch(cfg, batch, 4242)
+    rec["in/wsi"], rec["in/rna"] = wsi.numpy(), rna.numpy()
+    for fusion in ("concat", "add"):
+        torch.manual_seed(0)
+        model = mod.mirror_classifier(wsi_embed_dim=cfg.wsi_embed_dim, rna_embed_dim=cfg.rna_embed_dim, embed_dim=cfg.embed_dim,
+                                      num_classes=ncls, rna_encoder_depth=cfg.rna_encoder_depth, rna_mlp_ratio=cfg.rna_mlp_ratio,
+                                      rna_norm_layer="layernorm", rna_act_layer="gelu", fusion=fusion)
+        shapes = synth.classifier_param_shapes(cfg, ncls, fusion)
+        ref_shapes = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+        assert sorted(ref_shapes) == sorted(shapes), ("classifier state-dict mismatch", set(ref_shapes) ^ set(shapes))
+        sd = synth.synth_state_dict(shapes, 77)
+        model.load_state_dict(sd, strict=True)
+        model.eval()
+        pred = model(wsi, rna)
+        pred_w = model(wsi, None) if fusion == "add" else None
+        want = O.classifier_forward(sd, cfg, wsi, rna, fusion)
+        assert torch.allclose(pred, want, rtol=1e-5, atol=1e-6), "oracle restatement differs from the reference classifier"
+        rec[f"pred/{fusion}"] = pred.detach().numpy()
+        if pred_w is not None:
+            rec["pred/add_wsi_only"] = pred_w.detach().numpy()
+        model.zero_grad()
+        pred.square().sum().backward()
+        params = dict(model.named_parameters())
+        rec[f"keys/{fusion}"] = np.array([k for k, _ in shapes])
+        rec[f"grad_norm/{fusion}"] = np.array([float(params[k].grad.double().norm()) for k, _ in shapes], dtype=np.float64)
+        for k, _ in shapes:       # the generator seeds by key position: only the head differs between the two fusions
+            if fusion == "concat" or k.startswith("head."):
+                rec[f"sd/{fusion}/{k}"] = sd[k].numpy()
+    path = os.path.join(out_dir, "golden_classifier.npz")
+    np.savez_compressed(path, **rec)
+    print(f"classifier: pred(concat)[0]={rec['pred/concat'][0]} -> {path} ({os.path.getsize(path)/1024:.0f} KiB)")
+
+
 def gen_losses(ref_losses, ClipLoss, out_dir):
     g = torch.Generator().manual_seed(2024)
     b, n, d, p, lat = 8, 16, 32, 30, 12
@@ -237,6 +278,8 @@ def main():
         if a.only and name not in a.only.split(","):
             continue
         gen_model_case(mod, ref_losses, name, cfg, batch, ratios, full, a.out, used)
+    if not a.only or "cls" in a.only.split(","):
+        gen_classifier(mod, a.out, used)
 
 
 if __name__ == "__main__":
