@@ -73,9 +73,11 @@ int mh_skinny_fwd(const void* x, int64_t ldx, const void* w, int64_t ldw, const 
 /* dW[N,K] (+)= dy[M,N]^T x[M,K]  (f32, plain read-modify-write: one block owns each output tile) */
 int mh_skinny_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw, int64_t lddw, int M, int N,
                     int K, int accumulate, mh_stream s);
-/* bf16 [R,C] -> [C,R]; the batched form walks table[i] = {src_off, dst_off, R, C} (int64 element offsets) */
+/* bf16 [R,C] -> [C,R]; the batched form walks table[i] = {src_off, dst_off, R, C} (int64 element offsets).
+ * vec_ok != 0: every entry has R % 8 == 0, C % 8 == 0 and offsets that are multiples of 8 (16-byte accesses) */
 int mh_transpose_bf16(const void* in, void* out, int R, int C, mh_stream s);
-int mh_transpose_bf16_many(const void* src, void* dst, const int64_t* table, int n, int max_r, int max_c, mh_stream s);
+int mh_transpose_bf16_many(const void* src, void* dst, const int64_t* table, int n, int max_r, int max_c, int vec_ok,
+                           mh_stream s);
 
 /* ---------------------------------------------------------------- LayerNorm (models/mirror.py:298, :350, :604, :210)
  * rows are addressed as (b, i): x + b*x_bs + i*D, y + b*y_bs + i*D, i < rows_per_batch (lets the
@@ -178,12 +180,12 @@ int mh_ppeg_wgrad(const void* x, const void* dout, float* dmerged, float* dbsum,
 /* ---------------------------------------------------------------- masking (models/mirror.py:624-649, :510-533)
  * mask[b,i] = 1 if rank(noise[b,i]) >= len_keep (rank by ascending noise, ties by index) */
 int mh_rank_mask(const float* noise, float* mask, int B, int N, int len_keep, mh_stream s);
-/* x [B, T, D] rows t>=first: x = mask[b,t-first] ? token : x ; then x += pos[t]  (pos [T,D]) */
+/* y [B, T, D] (dt_y): rows t>=first take `token` where mask[b,t-first] != 0, else x (dt_x); then + pos[t]  (pos [T,D]) */
 int mh_mask_apply_fwd(const void* x, void* y, const float* mask, const float* token, const float* pos, int B, int T, int D,
-                      int first, int token_scalar, int dt, mh_stream s);   /* y may be x (in place) */
-/* dx = dy*(1-mask) (dx may be dy); dtoken += sum mask*dy ; dpos[t] += sum_b dy */
+                      int first, int token_scalar, int dt_x, int dt_y, mh_stream s);   /* y may be x (in place, same dtype) */
+/* dx (dt_dx) = dy*(1-mask) (dx may be dy when the dtypes agree); dtoken += sum mask*dy ; dpos[t] += sum_b dy */
 int mh_mask_apply_bwd(const void* dy, void* dx, const float* mask, float* dtoken, float* dpos, int B, int T, int D,
-                      int first, int token_scalar, int dt, mh_stream s);
+                      int first, int token_scalar, int dt_dy, int dt_dx, mh_stream s);
 
 /* ---------------------------------------------------------------- RNA encoder pieces (models/mirror.py:77-102)
  * qkv [B, 3D] -> softmax over the HEADS axis -> out[b, d*H + h]; attn [B,H,H] saved for backward */
@@ -224,12 +226,20 @@ int mh_ce_rows_fwd(const float* G, int64_t ldg, const float* scale, float scale_
 /* dG[r,c] = gcoef * g[0 or r] * scale * (softmax - onehot); dscale += sum dG_unscaled*G  */
 int mh_ce_rows_bwd(const float* G, int64_t ldg, const float* scale, float scale_mul, const float* lse, const float* g,
                    int g_per_row, float gcoef, float* dG, float* dscale, int R, int C, int label_off, mh_stream s);
-/* acc[0] += sum_r mask[r] * mean_D (p-t)^2 ; acc[1] += sum_r mask[r]   (losses/mirror_loss.py:98-103) */
+/* acc[0] += sum_r mask[r] * mean_D (p-t)^2 ; acc[1] += sum_r mask[r]   (losses/mirror_loss.py:98-103)
+ * pred [rows, D] contiguous; target row r at tgt + (r / rows_per_batch) * tgt_bs + (r % rows_per_batch) * D elements
+ * (a row window of a larger buffer: the WSI target is encoder_output[:, 1:], models/mirror.py:700) */
 int mh_mse_masked_fwd(const void* pred, const void* tgt, const float* mask, float* acc, int64_t rows, int D,
-                      int dt_p, int dt_t, mh_stream s);
-/* dpred = g * 2*mask*(p-t)/(D*acc[1]); dtgt = -dpred */
+                      int64_t rows_per_batch, int64_t tgt_bs, int dt_p, int dt_t, mh_stream s);
+/* dpred[rows, D] (dt_dp) = g * 2*mask*(p-t)/(D*acc[1]); dtgt[rows, D] (dt_t) = -dpred, not written when NULL */
 int mh_mse_masked_bwd(const void* pred, const void* tgt, const float* mask, const float* acc, const float* g,
-                      void* dpred, void* dtgt, int64_t rows, int D, int dt_p, int dt_t, int dt_d, mh_stream s);
+                      void* dpred, void* dtgt, int64_t rows, int D, int64_t rows_per_batch, int64_t tgt_bs, int dt_p, int dt_t,
+                      int dt_dp, mh_stream s);
+/* Gradient of the WSI encoder output E [B, T, D] (f32), which three consumers read (models/mirror.py:684, :690, :700, :833):
+ *   dE[b, t] = gfull[b, t] + alpha * x[b, t - 1] (t >= 1) + (t == 0 ? c[b] : 0)
+ * gfull f32 [B, T, D], x [B, T-1, D] in dt_x, c f32 [B, D]; each may be NULL (taken as zero). */
+int mh_fanout_bwd(const float* gfull, const void* x, float alpha, const float* c, float* dE, int B, int T, int D, int dt_x,
+                  mh_stream s);
 /* out[0] += coef * sum (exp(ls) + mu^2 - 1 - ls)   (losses/mirror_loss.py:105-112) */
 int mh_kl_fwd(const float* mu, const float* ls, float* out, int64_t n, float coef, mh_stream s);
 int mh_kl_bwd(const float* mu, const float* ls, const float* g, float* dmu, float* dls, int64_t n, float coef,

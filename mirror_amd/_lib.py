@@ -38,7 +38,7 @@ _SIGS = {
     "mh_skinny_fwd": [P, L, P, L, P, P, L, I, I, I, I, I],
     "mh_skinny_wgrad": [P, L, P, L, P, L, I, I, I, I],
     "mh_transpose_bf16": [P, P, I, I],
-    "mh_transpose_bf16_many": [P, P, P, I, I, I],
+    "mh_transpose_bf16_many": [P, P, P, I, I, I, I],
     "mh_layernorm_fwd": [P, P, P, P, P, P, I, I, I, L, L, F, I, I],
     "mh_layernorm_bwd": [P, P, P, P, P, P, P, P, I, I, I, L, L, I, I, I, I, P, L],
     "mh_softmax_fwd": [P, P, L, I, L, L, I, I],
@@ -65,8 +65,8 @@ _SIGS = {
     "mh_ppeg_fwd": [P, P, P, P, I, I, I, I, I, I],
     "mh_ppeg_wgrad": [P, P, P, P, I, I, I, I, I],
     "mh_rank_mask": [P, P, I, I, I],
-    "mh_mask_apply_fwd": [P, P, P, P, P, I, I, I, I, I, I],
-    "mh_mask_apply_bwd": [P, P, P, P, P, I, I, I, I, I, I],
+    "mh_mask_apply_fwd": [P, P, P, P, P, I, I, I, I, I, I, I],
+    "mh_mask_apply_bwd": [P, P, P, P, P, I, I, I, I, I, I, I],
     "mh_headattn_fwd": [P, P, P, I, I, I, I],
     "mh_headattn_bwd": [P, P, P, P, I, I, I, I],
     "mh_add": [P, P, P, L, I, I, I],
@@ -82,8 +82,9 @@ _SIGS = {
     "mh_reparam_bwd": [P, P, P, P, P, L],
     "mh_ce_rows_fwd": [P, L, P, F, I, I, I, F, P, P, P],
     "mh_ce_rows_bwd": [P, L, P, F, P, P, I, F, P, P, I, I, I],
-    "mh_mse_masked_fwd": [P, P, P, P, L, I, I, I],
-    "mh_mse_masked_bwd": [P, P, P, P, P, P, P, L, I, I, I, I],
+    "mh_mse_masked_fwd": [P, P, P, P, L, I, L, L, I, I],
+    "mh_mse_masked_bwd": [P, P, P, P, P, P, P, L, I, L, L, I, I, I],
+    "mh_fanout_bwd": [P, P, F, P, P, I, I, I, I],
     "mh_kl_fwd": [P, P, P, L, F],
     "mh_kl_bwd": [P, P, P, P, P, L, F],
     "mh_symkl_fwd": [P, P, P, I, I, F],

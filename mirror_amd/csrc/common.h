@@ -40,6 +40,26 @@ template <typename T> __device__ __forceinline__ void stf(T* p, float v);
 template <> __device__ __forceinline__ void stf<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
 
+// four consecutive elements as f32 (16-byte f32 / 8-byte bf16 accesses; the pointer must be aligned to that)
+typedef float f4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u2_t __attribute__((ext_vector_type(2)));
+template <typename T> __device__ __forceinline__ f4_t ld4(const T* p);
+template <> __device__ __forceinline__ f4_t ld4<float>(const float* p) { return *reinterpret_cast<const f4_t*>(p); }
+template <> __device__ __forceinline__ f4_t ld4<bf16_t>(const bf16_t* p) {
+    const u2_t u = *reinterpret_cast<const u2_t*>(p);
+    f4_t r = {__uint_as_float(u[0] << 16), __uint_as_float(u[0] & 0xffff0000u), __uint_as_float(u[1] << 16), __uint_as_float(u[1] & 0xffff0000u)};
+    return r;
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, f4_t v);
+template <> __device__ __forceinline__ void st4<float>(float* p, f4_t v) { *reinterpret_cast<f4_t*>(p) = v; }
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, f4_t v) {
+    u2_t u = {(uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16)};
+    *reinterpret_cast<u2_t*>(p) = u;
+}
+// host side: can `p` be accessed as quads of `esz`-byte elements?
+static inline bool mh_quad_ok(const void* p, int esz) { return ((uintptr_t)p % (4 * (uintptr_t)esz)) == 0; }
+static inline int mh_dt_size(int dt) { return dt == MH_F32 ? 4 : 2; }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -27,6 +27,26 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const TY* y, const TDY* d
     EW_LOOP(i, npb) stf(dx + b * dx_bs + i, ldf(y + b * y_bs + i) > 0.f ? ldf(dy + b * dy_bs + i) : 0.f);
 }
 
+// quad forms (n % 4 == 0, quad-aligned pointers): 16-byte f32 / 8-byte bf16 accesses
+#define EW4_LOOP(q, n4) for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < (n4); q += (long)gridDim.x * 256)
+template <typename TA, typename TB, typename TY>
+__global__ __launch_bounds__(256) void add4_kernel(const TA* a, const TB* b, TY* y, long n4) {
+    EW4_LOOP(q, n4) st4(y + 4 * q, ld4(a + 4 * q) + ld4(b + 4 * q));
+}
+template <typename TX, typename TY>
+__global__ __launch_bounds__(256) void cast4_kernel(const TX* x, TY* y, long n4) {
+    EW4_LOOP(q, n4) st4(y + 4 * q, ld4(x + 4 * q));
+}
+template <typename TY, typename TDY, typename TDX>
+__global__ __launch_bounds__(256) void relu_bwd4_kernel(const TY* y, const TDY* dy, TDX* dx, long npb4, long y_bs, long dy_bs, long dx_bs) {
+    const long b = blockIdx.y;
+    EW4_LOOP(q, npb4) {
+        const f4_t yv = ld4(y + b * y_bs + 4 * q), g = ld4(dy + b * dy_bs + 4 * q);
+        f4_t o = {yv[0] > 0.f ? g[0] : 0.f, yv[1] > 0.f ? g[1] : 0.f, yv[2] > 0.f ? g[2] : 0.f, yv[3] > 0.f ? g[3] : 0.f};
+        st4(dx + b * dx_bs + 4 * q, o);
+    }
+}
+
 #define DISPATCH2(dt0, dt1, MACRO)                                     \
     if ((dt0) == MH_F32 && (dt1) == MH_F32) { MACRO(float, float); }   \
     else if ((dt0) == MH_F32) { MACRO(float, bf16_t); }                \
@@ -35,6 +55,15 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const TY* y, const TDY* d
 
 extern "C" int mh_add(const void* a, const void* b, void* y, int64_t n, int dt_a, int dt_b, int dt_y, mh_stream s) {
     if (n == 0) return MH_OK;
+    if (n % 4 == 0 && mh_quad_ok(a, mh_dt_size(dt_a)) && mh_quad_ok(b, mh_dt_size(dt_b)) && mh_quad_ok(y, mh_dt_size(dt_y))) {
+#define ADD4_(TA, TB)                                                                                                    \
+    if (dt_y == MH_F32) hipLaunchKernelGGL((add4_kernel<TA, TB, float>), EW_GRID(n / 4), dim3(256), 0, (hipStream_t)s, (const TA*)a, (const TB*)b, (float*)y, (long)(n / 4)); \
+    else hipLaunchKernelGGL((add4_kernel<TA, TB, bf16_t>), EW_GRID(n / 4), dim3(256), 0, (hipStream_t)s, (const TA*)a, (const TB*)b, (bf16_t*)y, (long)(n / 4))
+        DISPATCH2(dt_a, dt_b, ADD4_)
+#undef ADD4_
+        MH_LAUNCH_CHECK("mh_add");
+        return MH_OK;
+    }
 #define ADD_(TA, TB)                                                                                                     \
     if (dt_y == MH_F32) hipLaunchKernelGGL((add_kernel<TA, TB, float>), EW_GRID(n), dim3(256), 0, (hipStream_t)s, (const TA*)a, (const TB*)b, (float*)y, (long)n); \
     else hipLaunchKernelGGL((add_kernel<TA, TB, bf16_t>), EW_GRID(n), dim3(256), 0, (hipStream_t)s, (const TA*)a, (const TB*)b, (bf16_t*)y, (long)n)
@@ -46,6 +75,13 @@ extern "C" int mh_add(const void* a, const void* b, void* y, int64_t n, int dt_a
 
 extern "C" int mh_cast(const void* x, void* y, int64_t n, int dt_x, int dt_y, mh_stream s) {
     if (n == 0) return MH_OK;
+    if (n % 4 == 0 && mh_quad_ok(x, mh_dt_size(dt_x)) && mh_quad_ok(y, mh_dt_size(dt_y))) {
+#define CAST4_(TX, TY) hipLaunchKernelGGL((cast4_kernel<TX, TY>), EW_GRID(n / 4), dim3(256), 0, (hipStream_t)s, (const TX*)x, (TY*)y, (long)(n / 4))
+        DISPATCH2(dt_x, dt_y, CAST4_)
+#undef CAST4_
+        MH_LAUNCH_CHECK("mh_cast");
+        return MH_OK;
+    }
 #define CAST_(TX, TY) hipLaunchKernelGGL((cast_kernel<TX, TY>), EW_GRID(n), dim3(256), 0, (hipStream_t)s, (const TX*)x, (TY*)y, (long)n)
     DISPATCH2(dt_x, dt_y, CAST_)
 #undef CAST_
@@ -76,6 +112,19 @@ extern "C" int mh_relu_bwd(const void* y, const void* dy, void* dx, int64_t n_pe
                            int64_t dy_bs, int64_t dx_bs, int dt_y, int dt_dy, int dt_dx, mh_stream s) {
     if (n_per_batch == 0 || batches == 0) return MH_OK;
     MH_REQUIRE(batches <= 65535, "mh_relu_bwd: too many batches");
+    if (n_per_batch % 4 == 0 && y_bs % 4 == 0 && dy_bs % 4 == 0 && dx_bs % 4 == 0 && mh_quad_ok(y, mh_dt_size(dt_y)) &&
+        mh_quad_ok(dy, mh_dt_size(dt_dy)) && mh_quad_ok(dx, mh_dt_size(dt_dx))) {
+        dim3 g4((unsigned)min((long)mh_cdiv(n_per_batch / 4, 256), 4096L), batches);
+#define RELUB42_(TY, TDY)                                                                                                  \
+    if (dt_dx == MH_F32) hipLaunchKernelGGL((relu_bwd4_kernel<TY, TDY, float>), g4, dim3(256), 0, (hipStream_t)s, (const TY*)y, (const TDY*)dy, (float*)dx, (long)(n_per_batch / 4), (long)y_bs, (long)dy_bs, (long)dx_bs); \
+    else hipLaunchKernelGGL((relu_bwd4_kernel<TY, TDY, bf16_t>), g4, dim3(256), 0, (hipStream_t)s, (const TY*)y, (const TDY*)dy, (bf16_t*)dx, (long)(n_per_batch / 4), (long)y_bs, (long)dy_bs, (long)dx_bs)
+#define RELUB4_(TY, TD) RELUB42_(TY, TD)
+        DISPATCH2(dt_y, dt_dy, RELUB4_)
+#undef RELUB42_
+#undef RELUB4_
+        MH_LAUNCH_CHECK("mh_relu_bwd");
+        return MH_OK;
+    }
     dim3 grid((unsigned)min((long)mh_cdiv(n_per_batch, 256), 4096L), batches);
 #define RELUB2_(TY, TDY)                                                                                                   \
     if (dt_dx == MH_F32) hipLaunchKernelGGL((relu_bwd_kernel<TY, TDY, float>), grid, dim3(256), 0, (hipStream_t)s, (const TY*)y, (const TDY*)dy, (float*)dx, (long)n_per_batch, (long)y_bs, (long)dy_bs, (long)dx_bs); \
@@ -186,8 +235,8 @@ extern "C" int mh_rank_mask(const float* noise, float* mask, int B, int N, int l
 }
 
 // x [B,T,D]: rows t >= first take the mask token where mask[b,t-first] != 0; every row gets + pos[t]
-template <typename T>
-__global__ __launch_bounds__(256) void mask_apply_fwd_kernel(const T* x, T* y, const float* __restrict__ mask,
+template <typename T, typename TY>
+__global__ __launch_bounds__(256) void mask_apply_fwd_kernel(const T* x, TY* y, const float* __restrict__ mask,
                                                              const float* __restrict__ token, const float* __restrict__ pos, int B, int Tn,
                                                              int D, int first, int token_scalar) {
     const long total = (long)B * Tn * D;
@@ -202,9 +251,10 @@ __global__ __launch_bounds__(256) void mask_apply_fwd_kernel(const T* x, T* y, c
     }
 }
 
-// f32, D % 4 == 0, per-channel token: one (b, t) row per wave iteration, 16-byte accesses, no per-element div / mod
+// f32 out, D % 4 == 0, per-channel token: one (b, t) row per wave iteration, quad accesses, no per-element div / mod
 typedef float mf_f4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void mask_apply_fwd_vec_kernel(const float* x, float* y, const float* __restrict__ mask,
+template <typename TX>
+__global__ __launch_bounds__(256) void mask_apply_fwd_vec_kernel(const TX* x, float* y, const float* __restrict__ mask,
                                                                  const float* __restrict__ token, const float* __restrict__ pos, int B,
                                                                  int Tn, int D, int first) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -214,7 +264,7 @@ __global__ __launch_bounds__(256) void mask_apply_fwd_vec_kernel(const float* x,
         const long b = row / Tn;
         const bool masked = t >= first && mask[b * (Tn - first) + (t - first)] != 0.f;
         for (int c = 4 * lane; c < D; c += 256) {
-            const mf_f4 v = masked ? *reinterpret_cast<const mf_f4*>(token + c) : *reinterpret_cast<const mf_f4*>(x + row * D + c);
+            const mf_f4 v = masked ? *reinterpret_cast<const mf_f4*>(token + c) : ld4(x + row * D + c);
             *reinterpret_cast<mf_f4*>(y + row * D + c) = v + *reinterpret_cast<const mf_f4*>(pos + (long)t * D + c);
         }
     }
@@ -223,8 +273,8 @@ __global__ __launch_bounds__(256) void mask_apply_fwd_vec_kernel(const float* x,
 // block = 64 columns x 4 row-slices over a band of MB_BAND rows t; each thread loops over b, so dpos needs no
 // atomics and the mask-token gradient costs one f32 atomic per column per block.
 #define MB_BAND 64
-template <typename T>
-__global__ __launch_bounds__(256) void mask_apply_bwd_kernel(const T* dy, T* dx, const float* __restrict__ mask,
+template <typename T, typename TDX>
+__global__ __launch_bounds__(256) void mask_apply_bwd_kernel(const T* dy, TDX* dx, const float* __restrict__ mask,
                                                              float* __restrict__ dtoken, float* __restrict__ dpos, int B, int Tn, int D,
                                                              int first, int token_scalar) {
     __shared__ float red[4][64];
@@ -254,9 +304,10 @@ __global__ __launch_bounds__(256) void mask_apply_bwd_kernel(const T* dy, T* dx,
     }
 }
 
-// f32, D % 4 == 0: lane owns 4 columns (16-byte accesses), a wave owns one t at a time and has 8 batch rows in flight
+// f32 in, D % 4 == 0: lane owns 4 columns (quad accesses), a wave owns one t at a time and has 8 batch rows in flight
 typedef float mb_f4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void mask_apply_bwd_vec_kernel(const float* dy, float* dx, const float* __restrict__ mask,
+template <typename TDX>
+__global__ __launch_bounds__(256) void mask_apply_bwd_vec_kernel(const float* dy, TDX* dx, const float* __restrict__ mask,
                                                                  float* __restrict__ dtoken, float* __restrict__ dpos, int B, int Tn, int D,
                                                                  int first, int token_scalar, int band) {
     __shared__ mb_f4 red[4][64];
@@ -278,8 +329,8 @@ __global__ __launch_bounds__(256) void mask_apply_bwd_vec_kernel(const float* dy
                     sp += g[u];
                     const bool msk = t >= first && mask[(long)(b0 + u) * (Tn - first) + (t - first)] != 0.f;
                     if (msk) st += g[u];
-                    if (msk || dx != dy)
-                        *reinterpret_cast<mb_f4*>(dx + ((long)(b0 + u) * Tn + t) * D + c) = msk ? (mb_f4){0.f, 0.f, 0.f, 0.f} : g[u];
+                    if (msk || (const void*)dx != (const void*)dy)
+                        st4(dx + ((long)(b0 + u) * Tn + t) * D + c, msk ? (mb_f4){0.f, 0.f, 0.f, 0.f} : g[u]);
                 }
             }
             mb_f4* dp = reinterpret_cast<mb_f4*>(dpos + (long)t * D + c);
@@ -302,8 +353,8 @@ __global__ __launch_bounds__(256) void mask_apply_bwd_vec_kernel(const float* dy
 }
 
 // D == 1 (the RNA channel axis is the masked axis): thread = position t, loop over the batch (coalesced across t)
-template <typename T>
-__global__ __launch_bounds__(256) void mask_apply_bwd_d1_kernel(const T* dy, T* dx, const float* __restrict__ mask,
+template <typename T, typename TDX>
+__global__ __launch_bounds__(256) void mask_apply_bwd_d1_kernel(const T* dy, TDX* dx, const float* __restrict__ mask,
                                                                 float* __restrict__ dtoken, float* __restrict__ dpos, int B, int Tn,
                                                                 int first) {
     __shared__ float red[4];
@@ -326,39 +377,93 @@ __global__ __launch_bounds__(256) void mask_apply_bwd_d1_kernel(const T* dy, T* 
 }
 
 extern "C" int mh_mask_apply_fwd(const void* x, void* y, const float* mask, const float* token, const float* pos, int B, int T, int D,
-                                 int first, int token_scalar, int dt, mh_stream s) {
+                                 int first, int token_scalar, int dt_x, int dt_y, mh_stream s) {
     const long total = (long)B * T * D;
     if (total == 0) return MH_OK;
-    if (dt == MH_F32 && D % 4 == 0 && !token_scalar && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)token | (uintptr_t)pos) & 15) == 0) {
-        hipLaunchKernelGGL(mask_apply_fwd_vec_kernel, dim3((unsigned)min((long)mh_cdiv((long)B * T, 4), 16384L)), dim3(256), 0,
-                           (hipStream_t)s, (const float*)x, (float*)y, mask, token, pos, B, T, D, first);
+    if (dt_y == MH_F32 && D % 4 == 0 && !token_scalar && mh_quad_ok(x, mh_dt_size(dt_x)) &&
+        (((uintptr_t)y | (uintptr_t)token | (uintptr_t)pos) & 15) == 0) {
+        dim3 gv((unsigned)min((long)mh_cdiv((long)B * T, 4), 16384L));
+        if (dt_x == MH_F32) hipLaunchKernelGGL((mask_apply_fwd_vec_kernel<float>), gv, dim3(256), 0, (hipStream_t)s, (const float*)x, (float*)y, mask, token, pos, B, T, D, first);
+        else hipLaunchKernelGGL((mask_apply_fwd_vec_kernel<bf16_t>), gv, dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (float*)y, mask, token, pos, B, T, D, first);
         MH_LAUNCH_CHECK("mh_mask_apply_fwd");
         return MH_OK;
     }
-    MH_DISPATCH_DT(dt, TT, hipLaunchKernelGGL((mask_apply_fwd_kernel<TT>), EW_GRID(total), dim3(256), 0, (hipStream_t)s, (const TT*)x, (TT*)y, mask, token, pos, B, T, D, first, token_scalar));
+#define MAF_(TX, TY) hipLaunchKernelGGL((mask_apply_fwd_kernel<TX, TY>), EW_GRID(total), dim3(256), 0, (hipStream_t)s, (const TX*)x, (TY*)y, mask, token, pos, B, T, D, first, token_scalar)
+    DISPATCH2(dt_x, dt_y, MAF_)
+#undef MAF_
     MH_LAUNCH_CHECK("mh_mask_apply_fwd");
     return MH_OK;
 }
 
 extern "C" int mh_mask_apply_bwd(const void* dy, void* dx, const float* mask, float* dtoken, float* dpos, int B, int T, int D,
-                                 int first, int token_scalar, int dt, mh_stream s) {
+                                 int first, int token_scalar, int dt_dy, int dt_dx, mh_stream s) {
     if (T == 0 || D == 0 || B == 0) return MH_OK;
     if (D == 1) {
-        MH_DISPATCH_DT(dt, TT, hipLaunchKernelGGL((mask_apply_bwd_d1_kernel<TT>), dim3(mh_cdiv(T, 256)), dim3(256), 0, (hipStream_t)s, (const TT*)dy, (TT*)dx, mask, dtoken, dpos, B, T, first));
+#define MAB1_(TDY, TDX) hipLaunchKernelGGL((mask_apply_bwd_d1_kernel<TDY, TDX>), dim3(mh_cdiv(T, 256)), dim3(256), 0, (hipStream_t)s, (const TDY*)dy, (TDX*)dx, mask, dtoken, dpos, B, T, first)
+        DISPATCH2(dt_dy, dt_dx, MAB1_)
+#undef MAB1_
         MH_LAUNCH_CHECK("mh_mask_apply_bwd");
         return MH_OK;
     }
-    if (dt == MH_F32 && D % 4 == 0 && D >= 256 && (((uintptr_t)dy | (uintptr_t)dx | (uintptr_t)dpos) & 15) == 0) {
+    if (dt_dy == MH_F32 && D % 4 == 0 && D >= 256 && mh_quad_ok(dx, mh_dt_size(dt_dx)) && (((uintptr_t)dy | (uintptr_t)dpos) & 15) == 0) {
         const int band = 16;     // rows of t per block: T / 16 x D / 256 blocks, 4 waves x 8 rows of 1 KiB in flight each
         dim3 gv(mh_cdiv(D, 256), mh_cdiv(T, band));
-        hipLaunchKernelGGL(mask_apply_bwd_vec_kernel, gv, dim3(256), 0, (hipStream_t)s, (const float*)dy, (float*)dx, mask, dtoken, dpos, B, T, D, first,
-                           token_scalar, band);
+        if (dt_dx == MH_F32) hipLaunchKernelGGL((mask_apply_bwd_vec_kernel<float>), gv, dim3(256), 0, (hipStream_t)s, (const float*)dy, (float*)dx, mask, dtoken, dpos, B, T, D, first, token_scalar, band);
+        else hipLaunchKernelGGL((mask_apply_bwd_vec_kernel<bf16_t>), gv, dim3(256), 0, (hipStream_t)s, (const float*)dy, (bf16_t*)dx, mask, dtoken, dpos, B, T, D, first, token_scalar, band);
         MH_LAUNCH_CHECK("mh_mask_apply_bwd");
         return MH_OK;
     }
     dim3 grid(mh_cdiv(D, 64), mh_cdiv(T, MB_BAND));
-    MH_DISPATCH_DT(dt, TT, hipLaunchKernelGGL((mask_apply_bwd_kernel<TT>), grid, dim3(256), 0, (hipStream_t)s, (const TT*)dy, (TT*)dx, mask, dtoken, dpos, B, T, D, first, token_scalar));
+#define MAB_(TDY, TDX) hipLaunchKernelGGL((mask_apply_bwd_kernel<TDY, TDX>), grid, dim3(256), 0, (hipStream_t)s, (const TDY*)dy, (TDX*)dx, mask, dtoken, dpos, B, T, D, first, token_scalar)
+    DISPATCH2(dt_dy, dt_dx, MAB_)
+#undef MAB_
     MH_LAUNCH_CHECK("mh_mask_apply_bwd");
+    return MH_OK;
+}
+
+// ------------------------------------------------------------------ encoder-output gradient fan-in
+// one wave per (b, t) row; VEC: D % 4 == 0 and quad-aligned pointers
+template <typename TX, bool VEC>
+__global__ __launch_bounds__(256) void fanout_bwd_kernel(const float* __restrict__ gfull, const TX* __restrict__ x, float alpha,
+                                                         const float* __restrict__ c, float* __restrict__ dE, int B, int Tn, int D) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long rows = (long)B * Tn;
+    for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+        const int t = (int)(row % Tn);
+        const long b = row / Tn;
+        const float* gr = gfull ? gfull + row * D : nullptr;
+        const TX* xr = (x && t >= 1) ? x + (b * (Tn - 1) + (t - 1)) * D : nullptr;
+        const float* cr = (c && t == 0) ? c + b * D : nullptr;
+        if (VEC) {
+            for (int k = 4 * lane; k < D; k += 256) {
+                f4_t v = {0.f, 0.f, 0.f, 0.f};
+                if (gr) v = ld4(gr + k);
+                if (xr) v += ld4(xr + k) * alpha;
+                if (cr) v += ld4(cr + k);
+                st4(dE + row * D + k, v);
+            }
+        } else {
+            for (int k = lane; k < D; k += 64) {
+                float v = gr ? gr[k] : 0.f;
+                if (xr) v += alpha * ldf(xr + k);
+                if (cr) v += cr[k];
+                dE[row * D + k] = v;
+            }
+        }
+    }
+}
+
+extern "C" int mh_fanout_bwd(const float* gfull, const void* x, float alpha, const float* c, float* dE, int B, int T, int D, int dt_x,
+                             mh_stream s) {
+    if (B == 0 || T == 0 || D == 0) return MH_OK;
+    const bool vec = D % 4 == 0 && mh_quad_ok(gfull, 4) && mh_quad_ok(x, mh_dt_size(dt_x)) && mh_quad_ok(c, 4) && mh_quad_ok(dE, 4);
+    dim3 grid((unsigned)min((long)mh_cdiv((long)B * T, 4), 16384L));
+#define FAN_(TX)                                                                                                                   \
+    if (vec) hipLaunchKernelGGL((fanout_bwd_kernel<TX, true>), grid, dim3(256), 0, (hipStream_t)s, gfull, (const TX*)x, alpha, c, dE, B, T, D); \
+    else hipLaunchKernelGGL((fanout_bwd_kernel<TX, false>), grid, dim3(256), 0, (hipStream_t)s, gfull, (const TX*)x, alpha, c, dE, B, T, D)
+    if (dt_x == MH_F32) { FAN_(float); } else { FAN_(bf16_t); }
+#undef FAN_
+    MH_LAUNCH_CHECK("mh_fanout_bwd");
     return MH_OK;
 }
 

@@ -72,10 +72,13 @@ extern "C" int mh_ce_rows_bwd(const float* G, int64_t ldg, const float* scale, f
 }
 
 // ------------------------------------------------------------------ masked MSE (retention losses)
-// acc[0] += sum_r mask[r] * (1/D) sum_d (p-t)^2 ; acc[1] += sum_r mask[r]; one wave per row, grid-stride
-template <typename TP, typename TT>
+// acc[0] += sum_r mask[r] * (1/D) sum_d (p-t)^2 ; acc[1] += sum_r mask[r]; one wave per row, grid-stride.
+// pred is [rows, D] contiguous; row r of the target sits at tgt + (r / rpb) * tgt_bs + (r % rpb) * D (a row window of a
+// larger [B, T, D] buffer: the WSI target is encoder_output[:, 1:], models/mirror.py:700).
+template <typename TP, typename TT, bool VEC>
 __global__ __launch_bounds__(256) void mse_masked_fwd_kernel(const TP* __restrict__ pred, const TT* __restrict__ tgt,
-                                                             const float* __restrict__ mask, float* __restrict__ acc, long rows, int D) {
+                                                             const float* __restrict__ mask, float* __restrict__ acc, long rows, int D,
+                                                             long rpb, long tgt_bs) {
     __shared__ float red[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float num = 0.f, den = 0.f;
@@ -83,10 +86,19 @@ __global__ __launch_bounds__(256) void mse_masked_fwd_kernel(const TP* __restric
         const float mk = mask[r];
         den += mk;  // every lane carries it; only lane 0's copy is used below
         if (mk != 0.f) {
+            const TP* pr = pred + r * D;
+            const TT* tr = tgt + (r / rpb) * tgt_bs + (r % rpb) * D;
             float s = 0.f;
-            for (int c = lane; c < D; c += 64) {
-                const float d = ldf(pred + r * D + c) - ldf(tgt + r * D + c);
-                s += d * d;
+            if (VEC) {
+                for (int c = 4 * lane; c < D; c += 256) {
+                    const f4_t d = ld4(pr + c) - ld4(tr + c);
+                    s += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+                }
+            } else {
+                for (int c = lane; c < D; c += 64) {
+                    const float d = ldf(pr + c) - ldf(tr + c);
+                    s += d * d;
+                }
             }
             num += mk * s / D;
         }
@@ -96,46 +108,83 @@ __global__ __launch_bounds__(256) void mse_masked_fwd_kernel(const TP* __restric
     if (threadIdx.x == 0) { atomicAdd(acc, num); atomicAdd(acc + 1, den); }
 }
 
+// dpred = k mask (p - t) in TD; dtgt = -dpred in TT when the caller wants it materialised (nullptr: not written)
 template <typename TP, typename TT, typename TD>
 __global__ __launch_bounds__(256) void mse_masked_bwd_kernel(const TP* __restrict__ pred, const TT* __restrict__ tgt,
                                                              const float* __restrict__ mask, const float* __restrict__ acc,
-                                                             const float* __restrict__ g, TD* __restrict__ dpred, TD* __restrict__ dtgt,
-                                                             long rows, int D) {
+                                                             const float* __restrict__ g, TD* __restrict__ dpred, TT* __restrict__ dtgt,
+                                                             long rows, int D, long rpb, long tgt_bs) {
     const float k = g[0] * 2.f / ((float)D * acc[1]);
     const long total = rows * D;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const float mk = mask[i / D];
-        const float d = mk != 0.f ? k * mk * (ldf(pred + i) - ldf(tgt + i)) : 0.f;
+        const long r = i / D;
+        const float mk = mask[r];
+        const float d = mk != 0.f ? k * mk * (ldf(pred + i) - ldf(tgt + (r / rpb) * tgt_bs + (r % rpb) * D + (i - r * D))) : 0.f;
         stf(dpred + i, d);
-        stf(dtgt + i, -d);
+        if (dtgt) stf(dtgt + i, -d);
+    }
+}
+
+// D % 4 == 0: one wave per row, quads; rows the mask drops are written as zeros without reading pred / tgt
+template <typename TP, typename TT, typename TD>
+__global__ __launch_bounds__(256) void mse_masked_bwd_vec_kernel(const TP* __restrict__ pred, const TT* __restrict__ tgt,
+                                                                 const float* __restrict__ mask, const float* __restrict__ acc,
+                                                                 const float* __restrict__ g, TD* __restrict__ dpred, TT* __restrict__ dtgt,
+                                                                 long rows, int D, long rpb, long tgt_bs) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float k = g[0] * 2.f / ((float)D * acc[1]);
+    for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
+        const float mk = mask[r];
+        const float km = k * mk;
+        const TP* pr = pred + r * D;
+        const TT* tr = tgt + (r / rpb) * tgt_bs + (r % rpb) * D;
+        for (int c = 4 * lane; c < D; c += 256) {
+            f4_t d = {0.f, 0.f, 0.f, 0.f};
+            if (mk != 0.f) d = (ld4(pr + c) - ld4(tr + c)) * km;
+            st4(dpred + r * D + c, d);
+            if (dtgt) st4(dtgt + r * D + c, -d);
+        }
     }
 }
 
 extern "C" int mh_mse_masked_fwd(const void* pred, const void* tgt, const float* mask, float* acc, int64_t rows, int D,
-                                 int dt_p, int dt_t, mh_stream s) {
+                                 int64_t rows_per_batch, int64_t tgt_bs, int dt_p, int dt_t, mh_stream s) {
     if (rows == 0) return MH_OK;
-    dim3 grid((unsigned)min((long)mh_cdiv(rows, 4), 2048L));
-#define MSEF(TP, TT) hipLaunchKernelGGL((mse_masked_fwd_kernel<TP, TT>), grid, dim3(256), 0, (hipStream_t)s, (const TP*)pred, (const TT*)tgt, mask, acc, (long)rows, D)
-    if (dt_p == MH_F32 && dt_t == MH_F32) MSEF(float, float);
-    else if (dt_p == MH_BF16 && dt_t == MH_BF16) MSEF(bf16_t, bf16_t);
-    else if (dt_p == MH_F32) MSEF(float, bf16_t);
-    else MSEF(bf16_t, float);
+    MH_REQUIRE(rows_per_batch > 0, "mh_mse_masked_fwd: rows_per_batch must be positive");
+    dim3 grid((unsigned)min((long)mh_cdiv(rows, 4), 4096L));
+    const bool vec = D % 4 == 0 && tgt_bs % 4 == 0 && mh_quad_ok(pred, mh_dt_size(dt_p)) && mh_quad_ok(tgt, mh_dt_size(dt_t));
+#define MSEF(TP, TT)                                                                                                              \
+    if (vec) hipLaunchKernelGGL((mse_masked_fwd_kernel<TP, TT, true>), grid, dim3(256), 0, (hipStream_t)s, (const TP*)pred, (const TT*)tgt, mask, acc, (long)rows, D, (long)rows_per_batch, (long)tgt_bs); \
+    else hipLaunchKernelGGL((mse_masked_fwd_kernel<TP, TT, false>), grid, dim3(256), 0, (hipStream_t)s, (const TP*)pred, (const TT*)tgt, mask, acc, (long)rows, D, (long)rows_per_batch, (long)tgt_bs)
+    if (dt_p == MH_F32 && dt_t == MH_F32) { MSEF(float, float); }
+    else if (dt_p == MH_BF16 && dt_t == MH_BF16) { MSEF(bf16_t, bf16_t); }
+    else if (dt_p == MH_F32) { MSEF(float, bf16_t); }
+    else { MSEF(bf16_t, float); }
 #undef MSEF
     MH_LAUNCH_CHECK("mh_mse_masked_fwd");
     return MH_OK;
 }
 
 extern "C" int mh_mse_masked_bwd(const void* pred, const void* tgt, const float* mask, const float* acc, const float* g,
-                                 void* dpred, void* dtgt, int64_t rows, int D, int dt_p, int dt_t, int dt_d, mh_stream s) {
+                                 void* dpred, void* dtgt, int64_t rows, int D, int64_t rows_per_batch, int64_t tgt_bs, int dt_p,
+                                 int dt_t, int dt_dp, mh_stream s) {
     if (rows == 0) return MH_OK;
-    MH_REQUIRE(dt_p == dt_t, "mh_mse_masked_bwd: pred/target dtype mismatch");
-    dim3 grid((unsigned)min((long)mh_cdiv(rows * D, 256), 16384L));
-#define MSEB(TP, TD) hipLaunchKernelGGL((mse_masked_bwd_kernel<TP, TP, TD>), grid, dim3(256), 0, (hipStream_t)s, (const TP*)pred, (const TP*)tgt, mask, acc, g, (TD*)dpred, (TD*)dtgt, (long)rows, D)
-    if (dt_p == MH_F32 && dt_d == MH_F32) MSEB(float, float);
-    else if (dt_p == MH_BF16 && dt_d == MH_BF16) MSEB(bf16_t, bf16_t);
-    else if (dt_p == MH_F32) MSEB(float, bf16_t);
-    else MSEB(bf16_t, float);
-#undef MSEB
+    MH_REQUIRE(rows_per_batch > 0, "mh_mse_masked_bwd: rows_per_batch must be positive");
+    const bool vec = D % 4 == 0 && tgt_bs % 4 == 0 && mh_quad_ok(pred, mh_dt_size(dt_p)) && mh_quad_ok(tgt, mh_dt_size(dt_t)) &&
+                     mh_quad_ok(dpred, mh_dt_size(dt_dp)) && (!dtgt || mh_quad_ok(dtgt, mh_dt_size(dt_t)));
+    dim3 grid((unsigned)min((long)mh_cdiv(rows * D, 256), 16384L)), gv((unsigned)min((long)mh_cdiv(rows, 4), 16384L));
+#define MSEB3(TP, TT, TD)                                                                                                         \
+    if (vec) hipLaunchKernelGGL((mse_masked_bwd_vec_kernel<TP, TT, TD>), gv, dim3(256), 0, (hipStream_t)s, (const TP*)pred, (const TT*)tgt, mask, acc, g, (TD*)dpred, (TT*)dtgt, (long)rows, D, (long)rows_per_batch, (long)tgt_bs); \
+    else hipLaunchKernelGGL((mse_masked_bwd_kernel<TP, TT, TD>), grid, dim3(256), 0, (hipStream_t)s, (const TP*)pred, (const TT*)tgt, mask, acc, g, (TD*)dpred, (TT*)dtgt, (long)rows, D, (long)rows_per_batch, (long)tgt_bs)
+#define MSEB2(TP, TT)                                 \
+    if (dt_dp == MH_F32) { MSEB3(TP, TT, float); }    \
+    else { MSEB3(TP, TT, bf16_t); }
+    if (dt_p == MH_F32 && dt_t == MH_F32) { MSEB2(float, float) }
+    else if (dt_p == MH_BF16 && dt_t == MH_BF16) { MSEB2(bf16_t, bf16_t) }
+    else if (dt_p == MH_F32) { MSEB2(float, bf16_t) }
+    else { MSEB2(bf16_t, float) }
+#undef MSEB2
+#undef MSEB3
     MH_LAUNCH_CHECK("mh_mse_masked_bwd");
     return MH_OK;
 }

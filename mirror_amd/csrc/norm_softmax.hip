@@ -104,26 +104,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restric
     }
 }
 
-// ------------------------------------------------------------------ 4-wide vector access (f32: 16 B, bf16: 8 B)
-typedef float f4 __attribute__((ext_vector_type(4)));
-typedef unsigned u2 __attribute__((ext_vector_type(2)));
-template <typename T> __device__ __forceinline__ f4 ld4(const T* p);
-template <> __device__ __forceinline__ f4 ld4<float>(const float* p) { return *reinterpret_cast<const f4*>(p); }
-template <> __device__ __forceinline__ f4 ld4<bf16_t>(const bf16_t* p) {
-    const u2 r = *reinterpret_cast<const u2*>(p);
-    f4 o;
-    o[0] = __uint_as_float(r[0] << 16); o[1] = __uint_as_float(r[0] & 0xffff0000u);
-    o[2] = __uint_as_float(r[1] << 16); o[3] = __uint_as_float(r[1] & 0xffff0000u);
-    return o;
-}
-template <typename T> __device__ __forceinline__ void st4(T* p, f4 v);
-template <> __device__ __forceinline__ void st4<float>(float* p, f4 v) { *reinterpret_cast<f4*>(p) = v; }
-template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, f4 v) {
-    u2 r;
-    r[0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-    r[1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-    *reinterpret_cast<u2*>(p) = r;
-}
+// 4-wide vector access: ld4 / st4 of common.h
+typedef f4_t f4;
 
 // Vectorised LayerNorm (D % 4 == 0): lane owns elements [256k + 4*lane, +4), k < LNV_CH (D <= 2048).
 template <typename TX, typename TY, int LNV_CH>

@@ -4,8 +4,9 @@
 // As VALU code the conv is 33 MACs per element = 1.2 G FMA per call at c2: ~36 us of pure issue, 90 us measured.
 // As a banded Toeplitz product it is 8 MFMAs per 32 x 64 output block and purely memory bound:
 //     out[t0 + i, c] = sum_k A[i][k] v[t0 - 16 + k, c],     A[i][k] = w[k - i] for 0 <= k - i <= 32 (else 0),  k < 64
-// The accumulators hold out^T (c in registers, t in lanes) so a lane adds 4 consecutive channels of one row with an
-// 8-byte read-modify-write; the v tile (128 + 32 halo rows of one head) sits in LDS and is read with
+// The accumulators hold out^T (c in registers, t in lanes); they pass through an f32 LDS image so that the read-modify-
+// write of `out` moves whole 128-byte rows in 16-byte pieces (per-lane 8-byte pieces of 32 different rows ran at a
+// quarter of the HBM rate); the v tile (128 + 32 halo rows of one head) sits in LDS and is read with
 // ds_read_b64_tr_b16 in the accumulator's k order (see nystrom_fused.hip).
 // The weight gradient dw[j] = sum_{b,t,c} dout[t, c] v[t + j - 16, c] is the diagonal sums of
 //     S[i][k] = sum_c dout[t0 + i, c] v[t0 - 16 + k, c]
@@ -19,6 +20,7 @@ constexpr int RM_T = 128;      // output rows per workgroup
 constexpr int RM_HALO = 16;    // taps / 2
 constexpr int RM_TAPS = 33;
 constexpr int RM_DH = 64;
+constexpr int RM_SP = 68;      // LDS pitch (f32) of the [128][64] output image
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -38,6 +40,7 @@ __device__ __forceinline__ bf16x8 rm_frag_tr(const bf16_t* img, int col0, int kb
 __global__ __launch_bounds__(256) void resconv_mfma_kernel(const bf16_t* __restrict__ v, long ldv, long v_bs, const float* __restrict__ w,
                                                            bf16_t* out, long ldo, long o_bs, int n_p, int transpose, int accumulate) {
     __shared__ __attribute__((aligned(16))) bf16_t img[(RM_T + 2 * RM_HALO) * RM_P];
+    __shared__ __attribute__((aligned(16))) float stage[RM_T * RM_SP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 5, r = lane & 31;
     const int t0 = blockIdx.x * RM_T, h = blockIdx.y, b = blockIdx.z;
     const bf16_t* vb = v + (long)b * v_bs + h * RM_DH;
@@ -71,25 +74,39 @@ __global__ __launch_bounds__(256) void resconv_mfma_kernel(const bf16_t* __restr
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) acc[nb] = MFMA(rm_frag_tr(img, 32 * nb, 32 * wave + 16 * ks, lane), wf[ks], acc[nb]);
     }
-    const int t = t0 + 32 * wave + r;
-    if (t >= n_p) return;
-    bf16_t* orow = out + (long)b * o_bs + (long)t * ldo + h * RM_DH + 4 * hl;
+    // out^T accumulators -> f32 [t][c] image, then whole 128-byte rows are read-modify-written with 16-byte accesses
+    float* srow = stage + (32 * wave + r) * RM_SP + 4 * hl;
 #pragma unroll
     for (int nb = 0; nb < 2; nb++)
 #pragma unroll
         for (int g = 0; g < 4; g++) {
-            bf16_t* p = orow + 32 * nb + 8 * g;
-            float x[4] = {acc[nb][4 * g], acc[nb][4 * g + 1], acc[nb][4 * g + 2], acc[nb][4 * g + 3]};
-            if (accumulate) {
-                const u32x2 old = *reinterpret_cast<const u32x2*>(p);
-                x[0] += __uint_as_float(old[0] << 16); x[1] += __uint_as_float(old[0] & 0xffff0000u);
-                x[2] += __uint_as_float(old[1] << 16); x[3] += __uint_as_float(old[1] & 0xffff0000u);
-            }
-            u32x2 o;
-            o[0] = (unsigned)f2bf(x[0]) | ((unsigned)f2bf(x[1]) << 16);
-            o[1] = (unsigned)f2bf(x[2]) | ((unsigned)f2bf(x[3]) << 16);
-            *reinterpret_cast<u32x2*>(p) = o;
+            f4_t x = {acc[nb][4 * g], acc[nb][4 * g + 1], acc[nb][4 * g + 2], acc[nb][4 * g + 3]};
+            *reinterpret_cast<f4_t*>(srow + 32 * nb + 8 * g) = x;
         }
+    __syncthreads();
+    bf16_t* ob = out + (long)b * o_bs + h * RM_DH;
+#pragma unroll
+    for (int i = 0; i < RM_T * 8 / 256; i++) {
+        const int cid = tid + i * 256, q = cid >> 3, c = cid & 7;
+        const int t = t0 + q;
+        if (t >= n_p) continue;
+        const float* sp = stage + q * RM_SP + 8 * c;
+        f4_t lo = *reinterpret_cast<const f4_t*>(sp), hi = *reinterpret_cast<const f4_t*>(sp + 4);
+        bf16_t* p = ob + (long)t * ldo + 8 * c;
+        if (accumulate) {
+            const u32x4 old = *reinterpret_cast<const u32x4*>(p);
+            lo[0] += __uint_as_float(old[0] << 16); lo[1] += __uint_as_float(old[0] & 0xffff0000u);
+            lo[2] += __uint_as_float(old[1] << 16); lo[3] += __uint_as_float(old[1] & 0xffff0000u);
+            hi[0] += __uint_as_float(old[2] << 16); hi[1] += __uint_as_float(old[2] & 0xffff0000u);
+            hi[2] += __uint_as_float(old[3] << 16); hi[3] += __uint_as_float(old[3] & 0xffff0000u);
+        }
+        u32x4 o;
+        o[0] = (unsigned)f2bf(lo[0]) | ((unsigned)f2bf(lo[1]) << 16);
+        o[1] = (unsigned)f2bf(lo[2]) | ((unsigned)f2bf(lo[3]) << 16);
+        o[2] = (unsigned)f2bf(hi[0]) | ((unsigned)f2bf(hi[1]) << 16);
+        o[3] = (unsigned)f2bf(hi[2]) | ((unsigned)f2bf(hi[3]) << 16);
+        *reinterpret_cast<u32x4*>(p) = o;
+    }
 }
 
 // grid (splits, heads, B); wave w of the block walks 32-row blocks blockIdx.x * 4 + w, + 4 gridDim.x, ...
@@ -154,7 +171,7 @@ __global__ __launch_bounds__(256) void resconv_wgrad_mfma_kernel(const bf16_t* _
 bool resconv_try_mfma(const void* v, long ldv, long v_bs, const float* w, void* out, long ldo, long o_bs, int B, int n_p, int heads,
                       int dh, int taps, int transpose, int accumulate, int dt_v, int dt_o, hipStream_t s) {
     if (dt_v != MH_BF16 || dt_o != MH_BF16 || dh != RM_DH || taps != RM_TAPS) return false;
-    if (ldv % 8 || v_bs % 8 || ldo % 4 || o_bs % 4 || ((uintptr_t)v & 15) || ((uintptr_t)out & 7)) return false;
+    if (ldv % 8 || v_bs % 8 || ldo % 8 || o_bs % 8 || ((uintptr_t)v & 15) || ((uintptr_t)out & 15)) return false;
     dim3 grid(mh_cdiv(n_p, RM_T), heads, B);
     hipLaunchKernelGGL(resconv_mfma_kernel, grid, dim3(256), 0, s, (const bf16_t*)v, ldv, v_bs, w, (bf16_t*)out, ldo, o_bs, n_p,
                        transpose, accumulate);

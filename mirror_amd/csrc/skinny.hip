@@ -167,15 +167,40 @@ extern "C" int mh_transpose_bf16(const void* in, void* out, int R, int Cc, mh_st
 
 // Batched form: table[i] = {src_off, dst_off, R, C} (element offsets into one bf16 arena each); one launch refreshes
 // every W^T shadow after the optimizer step.
+template <bool VEC>
 __global__ __launch_bounds__(256) void transpose_bf16_many_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
                                                                   const long* __restrict__ table) {
-    __shared__ bf16_t tile[64][66];
+    __shared__ __attribute__((aligned(16))) bf16_t tile[64][66];
     const long* e = table + 4 * blockIdx.z;
     const int R = (int)e[2], Cc = (int)e[3];
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     if (r0 >= R || c0 >= Cc) return;
     const bf16_t* in = src + e[0];
     bf16_t* out = dst + e[1];
+    if (VEC) {     // R % 8 == 0, Cc % 8 == 0, 16-byte aligned tensors: 16-byte global accesses both ways
+        typedef uint32_t tq __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int cid = threadIdx.x + 256 * i, r = cid >> 3, ch = cid & 7;
+            tq v = {0u, 0u, 0u, 0u};
+            if (r0 + r < R && c0 + 8 * ch < Cc) v = *reinterpret_cast<const tq*>(in + (long)(r0 + r) * Cc + c0 + 8 * ch);
+            uint32_t* t32 = reinterpret_cast<uint32_t*>(&tile[r][8 * ch]);     // pitch 132 B: 4-byte aligned only
+            t32[0] = v[0]; t32[1] = v[1]; t32[2] = v[2]; t32[3] = v[3];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int cid = threadIdx.x + 256 * i, c = cid >> 3, ch = cid & 7;
+            if (c0 + c < Cc && r0 + 8 * ch < R) {
+                tq v;
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    v[j] = (uint32_t)tile[8 * ch + 2 * j][c] | ((uint32_t)tile[8 * ch + 2 * j + 1][c] << 16);
+                *reinterpret_cast<tq*>(out + (long)(c0 + c) * R + r0 + 8 * ch) = v;
+            }
+        }
+        return;
+    }
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int i = ty; i < 64; i += 4) {
         const int r = r0 + i, c = c0 + tx;
@@ -188,11 +213,16 @@ __global__ __launch_bounds__(256) void transpose_bf16_many_kernel(const bf16_t* 
     }
 }
 
-extern "C" int mh_transpose_bf16_many(const void* src, void* dst, const int64_t* table, int n, int max_r, int max_c, mh_stream s) {
+extern "C" int mh_transpose_bf16_many(const void* src, void* dst, const int64_t* table, int n, int max_r, int max_c, int vec_ok,
+                                      mh_stream s) {
     if (n == 0) return MH_OK;
     MH_REQUIRE(n <= 65535, "mh_transpose_bf16_many: too many tensors");
-    hipLaunchKernelGGL(transpose_bf16_many_kernel, dim3(mh_cdiv(max_c, 64), mh_cdiv(max_r, 64), n), dim3(256), 0, (hipStream_t)s,
-                       (const bf16_t*)src, (bf16_t*)dst, (const long*)table);
+    dim3 grid(mh_cdiv(max_c, 64), mh_cdiv(max_r, 64), n);
+    // vec_ok: the caller vouches that every table entry has R % 8 == 0, C % 8 == 0 and offsets that are multiples of 8
+    if (vec_ok && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0)
+        hipLaunchKernelGGL((transpose_bf16_many_kernel<true>), grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)src, (bf16_t*)dst, (const long*)table);
+    else
+        hipLaunchKernelGGL((transpose_bf16_many_kernel<false>), grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)src, (bf16_t*)dst, (const long*)table);
     MH_LAUNCH_CHECK("mh_transpose_bf16_many");
     return MH_OK;
 }

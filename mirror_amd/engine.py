@@ -142,7 +142,8 @@ class TrainEngine:
 
     def _refresh_transposes(self) -> None:
         if self.shadow_t is not None:
-            K.transpose_bf16_many(self.shadow, self.shadow_t, self._t_table, self._t_n, self._t_max[0], self._t_max[1])
+            K.transpose_bf16_many(self.shadow, self.shadow_t, self._t_table, self._t_n, self._t_max[0], self._t_max[1],
+                                  vec_ok=True)   # 2-D weights with both dims % 32 == 0 at offsets that are multiples of _ALIGN = 8
 
     # ------------------------------------------------------------------ gradient sink protocol
     def slot(self, t: torch.Tensor):

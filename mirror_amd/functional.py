@@ -230,7 +230,11 @@ class LinearRowsFn(Function):
         N, Kd = wa.shape
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = torch.zeros_like(x)
+            dx = torch.empty_like(x)
+            if r0:
+                dx[:, :r0].zero_()
+            if r0 + R < x.shape[1]:
+                dx[:, r0 + R:].zero_()
             K.gemm(dy, wa, out=dx[:, r0:r0 + R], mma=prec.mma)
         if ctx.needs_input_grad[1]:
             dw, sunk = _gbuf(w, (N, Kd))
@@ -672,7 +676,8 @@ def rank_mask(noise: torch.Tensor, len_keep: int) -> torch.Tensor:
 
 
 class MaskApplyFn(Function):
-    """x[b,t] <- mask_token where mask[b,t-first]; x += pos  (models/mirror.py:636-643 + :693; :521-527 + :549)."""
+    """y[b,t] = mask_token where mask[b,t-first] else x[b,t];  y += pos  (models/mirror.py:636-643 + :693; :521-527 + :549).
+    y is f32 (it starts a residual stream); dx comes back in x's dtype."""
 
     @staticmethod
     def forward(ctx, x, mask, token, pos, first, token_scalar):
@@ -681,23 +686,73 @@ class MaskApplyFn(Function):
             Bn, T, D = x.shape[0], x.shape[1], 1
         else:
             Bn, T, D = x.shape
-        y = torch.empty_like(x)
+        y = torch.empty(x.shape, device=x.device, dtype=f32)
         K.mask_apply_fwd(x, mask, token.detach().reshape(-1).contiguous(), pos.detach().reshape(-1).contiguous(),
                          Bn, T, D, first, token_scalar, out=y)
         ctx.save_for_backward(mask)
-        ctx.geom = (Bn, T, D, first, token_scalar, token.shape, pos.shape)
+        ctx.geom = (Bn, T, D, first, token_scalar, token.shape, pos.shape, x.dtype)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         (mask,) = ctx.saved_tensors
-        Bn, T, D, first, token_scalar, tshape, pshape = ctx.geom
+        Bn, T, D, first, token_scalar, tshape, pshape, xdt = ctx.geom
         dy = dy.contiguous()
-        dx = torch.empty_like(dy)
+        dx = torch.empty(dy.shape, device=dy.device, dtype=xdt)
         dtok = torch.zeros((1 if token_scalar else D,), device=dy.device, dtype=f32)
         dpos = torch.zeros((T * D,), device=dy.device, dtype=f32)
         K.mask_apply_bwd(dy, mask, dtok, dpos, Bn, T, D, first, token_scalar, out=dx)
         return dx, None, dtok.reshape(tshape), dpos.reshape(pshape), None, None
+
+
+# ------------------------------------------------------------------ encoder-output fan-out
+class _FanToken:
+    """Hand-over slot between the consumer of E[:, 1:] (the masked MSE) and EncFanoutFn.backward."""
+    __slots__ = ("grad",)
+
+    def __init__(self):
+        self.grad = None       # (tensor [B, T-1, D], alpha): the target's gradient is alpha * tensor
+
+
+class EncFanoutFn(Function):
+    """The WSI encoder output E [B, T, D] feeds three consumers (models/mirror.py:684-700, :833): the retention decoder
+    (all of E), the retention target (rows 1..) and the cls row.  autograd would sum three [B, T, D] f32 gradients with
+    zero-filled slice backwards (~1.3 GB of traffic); this node builds dE in one pass (mh_fanout_bwd), and the masked
+    MSE hands its target gradient over as -dpred instead of materialising it."""
+
+    @staticmethod
+    def forward(ctx, E, tok):
+        ctx.set_materialize_grads(False)
+        ctx.tok, ctx.shape = tok, tuple(E.shape)
+        return E.view_as(E), E[:, 1:], E[:, 0]
+
+    @staticmethod
+    def backward(ctx, g_full, g_tgt, g_cls):
+        Bn, T, D = ctx.shape
+        x, alpha = (None, 0.0) if ctx.tok.grad is None else ctx.tok.grad
+        ctx.tok.grad = None
+        late = None
+        if g_tgt is not None:                  # a consumer that returned a materialised gradient for the target
+            if x is None:
+                x, alpha = g_tgt.contiguous(), 1.0
+            else:
+                late = g_tgt
+        gf = None if g_full is None else g_full.contiguous().float()
+        c = None if g_cls is None else g_cls.contiguous().float()
+        dE = K.fanout_bwd(gf, x, alpha, c, Bn, T, D)
+        if late is not None:
+            dE[:, 1:] += late
+        return dE, None
+
+
+def enc_fanout(E: torch.Tensor):
+    """(E, E[:, 1:], E[:, 0]) with the gradients of the three summed by one kernel."""
+    if not (torch.is_grad_enabled() and E.requires_grad and E.dim() == 3 and E.is_contiguous() and E.dtype == f32):
+        return E, E[:, 1:], E[:, 0]
+    tok = _FanToken()
+    full, tgt, cls = EncFanoutFn.apply(E, tok)
+    tgt._fan_token = tok
+    return full, tgt, cls
 
 
 # ------------------------------------------------------------------ small heads
@@ -790,28 +845,37 @@ class CERowsFn(Function):
 
 
 class MaskedMSEFn(Function):
-    """sum(mask * mean_D (p - t)^2) / sum(mask)  (losses/mirror_loss.py:98-103); gradients flow to BOTH p and t."""
+    """sum(mask * mean_D (p - t)^2) / sum(mask)  (losses/mirror_loss.py:98-103); gradients flow to BOTH p and t.
+    The target may be a row window of a larger buffer (encoder_output[:, 1:]) and is read in place."""
 
     @staticmethod
-    def forward(ctx, pred, tgt, mask, D):
-        pred, tgt = pred.contiguous(), tgt.contiguous()
-        if tgt.dtype != pred.dtype:
-            tgt = K.cast(tgt, pred.dtype)
+    def forward(ctx, pred, tgt, mask, D, tok=None):
+        pred = pred.contiguous()
+        if not (tgt.is_contiguous() or (tgt.dim() == 3 and tgt.stride(2) == 1 and tgt.stride(1) == D)):
+            tgt = tgt.contiguous()
         mask = mask.contiguous().float()
         rows = pred.numel() // D
         acc = torch.zeros((2,), device=pred.device, dtype=f32)
         K.mse_masked_fwd(pred, tgt, mask, acc, rows, D)
         ctx.save_for_backward(pred, tgt, mask, acc)
-        ctx.D = D
+        ctx.D, ctx.tok = D, tok
         return _div(acc)
 
     @staticmethod
     def backward(ctx, g):
         pred, tgt, mask, acc = ctx.saved_tensors
-        D = ctx.D
-        dp, dtg = torch.empty_like(pred), torch.empty_like(tgt)
+        D, tok = ctx.D, ctx.tok
+        dp = torch.empty_like(pred)
+        hand_over = tok is not None and ctx.needs_input_grad[1]
+        dtg = torch.empty(tgt.shape, device=tgt.device, dtype=tgt.dtype) if (ctx.needs_input_grad[1] and not hand_over) else None
         K.mse_masked_bwd(pred, tgt, mask, acc, g.contiguous().float().reshape(1), dp, dtg, pred.numel() // D, D)
-        return dp, dtg, None, None
+        if hand_over:
+            tok.grad = (dp, -1.0)          # EncFanoutFn.backward folds -dpred into the encoder-output gradient
+        return dp, dtg, None, None, None
+
+
+def masked_mse(pred, tgt, mask, D):
+    return MaskedMSEFn.apply(pred, tgt, mask, D, getattr(tgt, "_fan_token", None))
 
 
 def _div(acc: torch.Tensor) -> torch.Tensor:

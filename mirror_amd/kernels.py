@@ -246,10 +246,12 @@ def transpose_bf16(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch
     return y
 
 
-def transpose_bf16_many(src: torch.Tensor, dst: torch.Tensor, table: torch.Tensor, n: int, max_r: int, max_c: int) -> None:
+def transpose_bf16_many(src: torch.Tensor, dst: torch.Tensor, table: torch.Tensor, n: int, max_r: int, max_c: int,
+                        vec_ok: bool = False) -> None:
+    """vec_ok: the caller checked that every table entry has R % 8 == C % 8 == 0 and offsets that are multiples of 8."""
     _chk(src, dst, table)
     assert table.dtype == torch.int64 and table.is_contiguous() and table.numel() == 4 * n
-    _lib.call("mh_transpose_bf16_many", _p(src), _p(dst), _p(table), n, max_r, max_c, stream=_stream())
+    _lib.call("mh_transpose_bf16_many", _p(src), _p(dst), _p(table), n, max_r, max_c, int(vec_ok), stream=_stream())
 
 
 # ----------------------------------------------------------------------------- row kernels
@@ -577,23 +579,23 @@ def rank_mask(noise: torch.Tensor, len_keep: int) -> torch.Tensor:
 
 
 def mask_apply_fwd(x, mask, token, pos, B, T, D, first, token_scalar, out=None) -> None:
-    """out (same shape / dtype as x) receives the result; in place when omitted."""
+    """out (same shape as x, any dtype) receives the result; in place when omitted."""
     out = x if out is None else out
     _chk(x, mask, token, pos, out)
     assert x.is_contiguous() and x.numel() == B * T * D and mask.numel() == B * (T - first) and pos.numel() == T * D
-    assert out.is_contiguous() and out.numel() == x.numel() and out.dtype == x.dtype
-    _lib.call("mh_mask_apply_fwd", _p(x), _p(out), _p(mask), _p(token), _p(pos), B, T, D, first, int(token_scalar), dt(x),
+    assert out.is_contiguous() and out.numel() == x.numel()
+    _lib.call("mh_mask_apply_fwd", _p(x), _p(out), _p(mask), _p(token), _p(pos), B, T, D, first, int(token_scalar), dt(x), dt(out),
               stream=_stream())
 
 
 def mask_apply_bwd(dy, mask, dtoken, dpos, B, T, D, first, token_scalar, out=None) -> None:
-    """out (same shape / dtype as dy) receives dx; in place when omitted."""
+    """out (same shape as dy, any dtype) receives dx; in place when omitted."""
     out = dy if out is None else out
     _chk(dy, mask, dtoken, dpos, out)
     assert dy.is_contiguous() and dy.numel() == B * T * D and dpos.numel() == T * D
-    assert out.is_contiguous() and out.numel() == dy.numel() and out.dtype == dy.dtype
+    assert out.is_contiguous() and out.numel() == dy.numel()
     _lib.call("mh_mask_apply_bwd", _p(dy), _p(out), _p(mask), _p(dtoken), _p(dpos), B, T, D, first, int(token_scalar), dt(dy),
-              stream=_stream())
+              dt(out), stream=_stream())
 
 
 # ----------------------------------------------------------------------------- RNA attention
@@ -739,15 +741,42 @@ def ce_rows_bwd(G, scale, scale_mul, lse, g, g_per_row, gcoef, dscale, label_off
     return dG
 
 
+def _tgt_rows(tgt: torch.Tensor, rows: int, D: int):
+    """(rows_per_batch, batch stride in elements) of a target that is contiguous or a row window [B, R, D] of a larger buffer."""
+    if tgt.is_contiguous():
+        return rows, rows * D
+    if tgt.dim() == 3 and tgt.stride(2) == 1 and tgt.stride(1) == D and tgt.shape[2] == D:
+        return tgt.shape[1], tgt.stride(0)
+    raise MirrorHipError(f"masked-MSE target must be contiguous or a row window, got strides {tgt.stride()}")
+
+
 def mse_masked_fwd(pred, tgt, mask, acc, rows, D):
     _chk(pred, tgt, mask, acc)
-    _lib.call("mh_mse_masked_fwd", _p(pred), _p(tgt), _p(mask), _p(acc), rows, D, dt(pred), dt(tgt), stream=_stream())
+    assert pred.is_contiguous() and tgt.numel() == pred.numel()
+    rpb, tbs = _tgt_rows(tgt, rows, D)
+    _lib.call("mh_mse_masked_fwd", _p(pred), _p(tgt), _p(mask), _p(acc), rows, D, rpb, tbs, dt(pred), dt(tgt), stream=_stream())
 
 
 def mse_masked_bwd(pred, tgt, mask, acc, g, dpred, dtgt, rows, D):
-    _chk(pred, tgt, mask, acc, g, dpred, dtgt)
-    _lib.call("mh_mse_masked_bwd", _p(pred), _p(tgt), _p(mask), _p(acc), _p(g), _p(dpred), _p(dtgt), rows, D, dt(pred),
+    """dtgt None: the target's gradient (-dpred) is not materialised."""
+    _chk(pred, tgt, mask, acc, g, dpred, *([] if dtgt is None else [dtgt]))
+    assert pred.is_contiguous() and dpred.is_contiguous() and (dtgt is None or (dtgt.is_contiguous() and dtgt.dtype == tgt.dtype))
+    rpb, tbs = _tgt_rows(tgt, rows, D)
+    _lib.call("mh_mse_masked_bwd", _p(pred), _p(tgt), _p(mask), _p(acc), _p(g), _p(dpred), _p(dtgt), rows, D, rpb, tbs, dt(pred),
               dt(tgt), dt(dpred), stream=_stream())
+
+
+def fanout_bwd(gfull, x, alpha: float, c, B: int, T: int, D: int) -> torch.Tensor:
+    """dE[b,t] = gfull[b,t] + alpha * x[b,t-1] (t >= 1) + (t == 0 ? c[b] : 0); any of the three may be None."""
+    ref = next(t for t in (gfull, x, c) if t is not None)
+    _chk(*[t for t in (gfull, x, c) if t is not None])
+    assert gfull is None or (gfull.is_contiguous() and gfull.dtype == torch.float32 and gfull.numel() == B * T * D)
+    assert x is None or (x.is_contiguous() and x.numel() == B * (T - 1) * D)
+    assert c is None or (c.is_contiguous() and c.dtype == torch.float32 and c.numel() == B * D)
+    dE = torch.empty((B, T, D), device=ref.device, dtype=torch.float32)
+    _lib.call("mh_fanout_bwd", _p(gfull), _p(x), float(alpha), _p(c), _p(dE), B, T, D, dt(x) if x is not None else _lib.MH_F32,
+              stream=_stream())
+    return dE
 
 
 def kl_fwd(mu, ls, out, coef):

@@ -85,8 +85,8 @@ class MIRRORLoss(nn.Module):
                 rna_logstd, logit_scale):
         alignment_loss = self.clip_loss(wsi_alignment_emb, rna_alignment_emb, logit_scale)
         D = wsi_retention_emb.shape[-1]
-        wsi_retention_loss = Fn.MaskedMSEFn.apply(wsi_retention_emb, wsi_retention_target, wsi_mask, D)
-        rna_retention_loss = Fn.MaskedMSEFn.apply(rna_retention_emb, rna_retention_target, rna_mask, 1)
+        wsi_retention_loss = Fn.masked_mse(wsi_retention_emb, wsi_retention_target, wsi_mask, D)
+        rna_retention_loss = Fn.masked_mse(rna_retention_emb, rna_retention_target, rna_mask, 1)
         B = wsi_mu.shape[0]
         style_loss = (Fn.StyleKLFn.apply(wsi_mu, wsi_logstd, 0.5 / B)
                       + Fn.StyleKLFn.apply(rna_mu, rna_logstd, 0.5 / rna_mu.shape[0]))

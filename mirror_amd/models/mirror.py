@@ -347,19 +347,23 @@ class FeatureTransMILHybrid(FeatureTransMIL):
             noise = torch.rand(B, N, device=h.device)
         return Fn.rank_mask(noise, len_keep)
 
-    def forward_retention_head(self, h, mask_ratio: float, noise: Optional[torch.Tensor] = None):
+    def forward_retention_head(self, h, mask_ratio: float, noise: Optional[torch.Tensor] = None,
+                               mask: Optional[torch.Tensor] = None):
+        """`mask`: a mask already drawn for this batch (MIRROR.forward ranks the noise on a side stream up front)."""
         prec = resolve_precision(self.precision)
         if h.shape[1] != self.num_tokens + 1:
             raise ValueError(f"wsi_num_tokens={self.num_tokens} but the batch has {h.shape[1] - 1} tokens")
-        r = Fn.linear(h, self.retention_embed.weight, self.retention_embed.bias, prec=prec, out_dtype=f32)
-        mask = self.random_masking(r[:, 1:], mask_ratio, noise)
+        # activation dtype out (what autocast gives the reference); MaskApplyFn restarts the f32 residual stream
+        r = Fn.linear(h, self.retention_embed.weight, self.retention_embed.bias, prec=prec)
+        if mask is None:
+            mask = self.random_masking(r[:, 1:], mask_ratio, noise)
         r = Fn.MaskApplyFn.apply(r, mask, self.mask_token, self.retention_gene_embed, 1, False)
         for blk in self.retention_blocks:
             r = blk(r, prec)
         r = Fn.layer_norm(r, self.retention_norm.weight, self.retention_norm.bias, self.retention_norm.eps,
                           out_dtype=prec.act)
         # retention_head(...)[:, 1:]: the cls row is sliced away, so it is never computed
-        r = Fn.LinearRowsFn.apply(r, self.retention_head.weight, self.retention_head.bias, 1, r.shape[1] - 1, prec, f32)
+        r = Fn.LinearRowsFn.apply(r, self.retention_head.weight, self.retention_head.bias, 1, r.shape[1] - 1, prec, prec.act)
         return r, mask
 
     def forward_decoders(self, h, mask_ratio: float, noise: Optional[torch.Tensor] = None):
@@ -466,19 +470,27 @@ class MIRROR(nn.Module):
         side = Fn._side_stream(dev, 1)
         side.wait_stream(main)
         with torch.cuda.stream(side):
+            # the WSI token mask depends on the noise alone: rank it here, long before the retention decoder needs it
+            n_tok = wsi_emb.shape[1]
+            wsi_mask = Fn.rank_mask(noise["wsi_mask"], int(n_tok * (1 - wsi_mask_ratio)))
+            mask_ready = side.record_event()
             rna_emb = self.rna_encoder.forward_encoder(rna_emb)
             rna_alignment_emb, rna_retention_emb, rna_mask = self.rna_encoder.forward_decoders(
                 rna_emb, mask_ratio=rna_mask_ratio, noise=noise.get("rna_mask"))
         wsi_emb = self.wsi_encoder.forward_encoder(wsi_emb)
-        wsi_alignment_emb, wsi_retention_emb, wsi_mask = self.wsi_encoder.forward_decoders(
-            wsi_emb, mask_ratio=wsi_mask_ratio, noise=noise.get("wsi_mask"))
-        wsi_retention_target = wsi_emb[:, 1:, :]
+        # the encoder output has three consumers (decoder input, retention target, cls row): one node sums their gradients
+        wsi_full, wsi_retention_target, wsi_cls = Fn.enc_fanout(wsi_emb)
+        wsi_alignment_emb = self.wsi_encoder.forward_alignment_head(wsi_cls)
+        main.wait_event(mask_ready)
+        wsi_mask.record_stream(main)
+        wsi_retention_emb, wsi_mask = self.wsi_encoder.forward_retention_head(
+            wsi_full, mask_ratio=wsi_mask_ratio, mask=wsi_mask)
         main.wait_stream(side)
         for t in (rna_emb, rna_alignment_emb, rna_retention_emb, rna_mask):
             t.record_stream(main)       # allocated in the side stream's pool, consumed on the main stream
         rna_retention_target = rna_emb
         wsi_score, wsi_mu, wsi_logstd, rna_score, rna_mu, rna_logstd = self.forward_style_clustering(
-            wsi_emb[:, 0, :], rna_emb, noise.get("wsi_eps"), noise.get("rna_eps"))
+            wsi_cls, rna_emb, noise.get("wsi_eps"), noise.get("rna_eps"))
         return (wsi_alignment_emb, wsi_retention_emb, wsi_retention_target, wsi_mask, wsi_score, wsi_mu, wsi_logstd,
                 rna_alignment_emb, rna_retention_emb, rna_retention_target, rna_mask, rna_score, rna_mu, rna_logstd,
                 self.logit_scale.exp())

@@ -462,6 +462,104 @@ def test_mask_apply(dtype):
     close(dp1, dy.sum(0), 0, 0, "rna dpos")
 
 
+def test_mask_apply_mixed_dtypes():
+    """bf16 activations in -> f32 residual stream out, and an f32 gradient back to bf16 (the WSI retention decoder)."""
+    gen = g(61)
+    B, T, D = 5, 19, 512
+    x = ints((B, T, D), gen)
+    mask = (torch.rand(B, T - 1, generator=gen) > 0.5).float()
+    tok, pos = ints((D,), gen), ints((T, D), gen)
+    y = torch.empty(B, T, D, device=DEV)
+    K.mask_apply_fwd(x.to(DEV, torch.bfloat16), mask.to(DEV), tok.to(DEV), pos.to(DEV), B, T, D, 1, False, out=y)
+    ref = x.clone()
+    ref[:, 1:] = torch.where(mask[..., None] > 0, tok.expand(B, T - 1, D), x[:, 1:])
+    close(y, ref + pos, 0, 0, "mask fwd bf16 -> f32")
+    dy = ints((B, T, D), gen)
+    dx = torch.empty(B, T, D, device=DEV, dtype=torch.bfloat16)
+    dtok, dpos = torch.zeros(D, device=DEV), torch.zeros((T, D), device=DEV)
+    K.mask_apply_bwd(dy.to(DEV), mask.to(DEV), dtok, dpos, B, T, D, 1, False, out=dx)
+    keep = torch.cat([torch.ones(B, 1), 1 - mask], dim=1)[..., None]
+    close(dx, dy * keep, 0, 0, "mask dx f32 -> bf16")
+    close(dtok, (dy[:, 1:] * mask[..., None]).sum((0, 1)), 0, 0, "dtoken")
+    close(dpos, dy.sum(0), 0, 0, "dpos")
+
+
+@pytest.mark.parametrize("D", [512, 24])
+def test_masked_mse_row_window_target(D):
+    """The WSI retention target is encoder_output[:, 1:], read in place; dtgt may be left unmaterialised."""
+    gen = g(62)
+    B, N = 3, 37
+    pred = torch.randn(B, N, D, generator=gen)
+    E = torch.randn(B, N + 1, D, generator=gen)
+    mask = (torch.rand(B, N, generator=gen) > 0.4).float()
+    pr, er = pred.clone().requires_grad_(True), E.clone().requires_grad_(True)
+    ref = (((pr - er[:, 1:]) ** 2).mean(-1) * mask).sum() / mask.sum()
+    ref.backward()
+    Ed = E.to(DEV)
+    acc = torch.zeros(2, device=DEV)
+    K.mse_masked_fwd(pred.to(DEV), Ed[:, 1:], mask.to(DEV), acc, B * N, D)
+    close(acc[0] / acc[1], ref, 1e-5, 1e-6, "masked mse (window)")
+    dp, dtg = torch.empty(B, N, D, device=DEV), torch.empty(B, N, D, device=DEV)
+    K.mse_masked_bwd(pred.to(DEV), Ed[:, 1:], mask.to(DEV), acc, torch.ones(1, device=DEV), dp, dtg, B * N, D)
+    close(dp, pr.grad, 1e-5, 1e-7, "mse dpred (window)")
+    close(dtg, er.grad[:, 1:], 1e-5, 1e-7, "mse dtgt (window)")
+    # bf16 prediction / bf16 dpred, no dtgt
+    pb = pred.to(DEV, torch.bfloat16)
+    acc2 = torch.zeros(2, device=DEV)
+    K.mse_masked_fwd(pb, Ed[:, 1:], mask.to(DEV), acc2, B * N, D)
+    prb = pb.float().cpu().requires_grad_(True)
+    refb = (((prb - E[:, 1:]) ** 2).mean(-1) * mask).sum() / mask.sum()
+    refb.backward()
+    close(acc2[0] / acc2[1], refb, 1e-5, 1e-6, "masked mse (bf16 pred)")
+    dpb = torch.empty(B, N, D, device=DEV, dtype=torch.bfloat16)
+    K.mse_masked_bwd(pb, Ed[:, 1:], mask.to(DEV), acc2, torch.ones(1, device=DEV), dpb, None, B * N, D)
+    close(dpb, prb.grad.bfloat16().float(), 1e-2, 1e-6, "mse dpred (bf16)")
+
+
+@pytest.mark.parametrize("D", [512, 20])
+def test_fanout_bwd(D):
+    gen = g(63)
+    B, T = 3, 11
+    gf, c = torch.randn(B, T, D, generator=gen), torch.randn(B, D, generator=gen)
+    x = torch.randn(B, T - 1, D, generator=gen).bfloat16()
+    ref = gf.clone()
+    ref[:, 1:] += -1.0 * x.float()
+    ref[:, 0] += c
+    close(K.fanout_bwd(gf.to(DEV), x.to(DEV), -1.0, c.to(DEV), B, T, D), ref, 1e-6, 1e-6, "fanout all")
+    ref2 = torch.zeros(B, T, D)
+    ref2[:, 1:] = 0.5 * x.float()
+    close(K.fanout_bwd(None, x.to(DEV), 0.5, None, B, T, D), ref2, 1e-6, 1e-6, "fanout x only")
+    close(K.fanout_bwd(gf.to(DEV), None, 0.0, None, B, T, D), gf, 0, 0, "fanout gfull only")
+
+
+def test_enc_fanout_autograd():
+    """EncFanoutFn + masked_mse hand-over == plain autograd over the three consumers of the encoder output."""
+    from mirror_amd import functional as Fn
+    gen = g(64)
+    B, T, D = 2, 9, 64
+    E = torch.randn(B, T, D, generator=gen)
+    pred = torch.randn(B, T - 1, D, generator=gen)
+    mask = (torch.rand(B, T - 1, generator=gen) > 0.4).float()
+    wf, wc = torch.randn(B, T, D, generator=gen), torch.randn(B, D, generator=gen)
+    er, pr = E.clone().requires_grad_(True), pred.clone().requires_grad_(True)
+    ref = (((pr - er[:, 1:]) ** 2).mean(-1) * mask).sum() / mask.sum() + (er * wf).sum() + (er[:, 0] * wc).sum()
+    ref.backward()
+    Ed, pd = E.to(DEV).requires_grad_(True), pred.to(DEV).requires_grad_(True)
+    full, tgt, cls = Fn.enc_fanout(Ed * 1.0)
+    loss = Fn.masked_mse(pd, tgt, mask.to(DEV), D) + (full * wf.to(DEV)).sum() + (cls * wc.to(DEV)).sum()
+    loss.backward()
+    close(loss, ref, 1e-5, 1e-6, "fan-out loss")
+    close(Ed.grad, er.grad, 1e-5, 1e-6, "fan-out dE")
+    close(pd.grad, pr.grad, 1e-5, 1e-7, "fan-out dpred")
+    # a consumer that does not know the protocol still gets summed correctly
+    Ed2 = E.to(DEV).requires_grad_(True)
+    full, tgt, cls = Fn.enc_fanout(Ed2 * 1.0)
+    ((tgt * 2.0).sum() + full.sum()).backward()
+    ref2 = torch.ones(B, T, D)
+    ref2[:, 1:] += 2.0
+    close(Ed2.grad, ref2, 0, 0, "fan-out generic consumer")
+
+
 @pytest.mark.parametrize("H,hd", [(8, 4), (12, 8), (8, 64)])
 def test_headattn(H, hd):
     gen = g(H * hd)
@@ -644,6 +742,19 @@ def test_skinny_fwd_wgrad_transpose(M, N, Kd):
     K.transpose_bf16_many(src, dst, tab, 2, max(N, M), Kd)
     close(dst[:N * Kd].view(Kd, N), w.t(), 0, 0, "batched transpose 0")
     close(dst[N * Kd:].view(Kd, M), x.t(), 0, 0, "batched transpose 1")
+
+
+def test_transpose_many_vec():
+    """16-byte path of the batched transpose (every W^T shadow after the optimizer step): ragged 64-tiles, two shapes."""
+    gen = g(71)
+    a = torch.randint(-100, 100, (96, 200), generator=gen).float().bfloat16()
+    b = torch.randint(-100, 100, (1536, 512), generator=gen).float().bfloat16()
+    src = torch.cat([a.reshape(-1), b.reshape(-1)]).to(DEV)
+    dst = torch.zeros_like(src)
+    tab = torch.tensor([0, 0, 96, 200, a.numel(), a.numel(), 1536, 512], device=DEV, dtype=torch.int64)
+    K.transpose_bf16_many(src, dst, tab, 2, 1536, 512, vec_ok=True)
+    close(dst[:a.numel()].view(200, 96), a.float().t(), 0, 0, "vec transpose 0")
+    close(dst[a.numel():].view(512, 1536), b.float().t(), 0, 0, "vec transpose 1")
 
 
 # --------------------------------------------------------------------------------------- fused pinv chain
