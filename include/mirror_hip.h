@@ -153,8 +153,11 @@ int mh_pinv_chain_bwd(const void* XP, const void* saved, const void* dzf, void* 
  * attn3_bwd: writes the k and v blocks of dqkv and delta3 [B,h,m] f32 (scratch); ADDS into the q_l half of dlm. */
 int mh_nys_attn1_fwd(const void* qkv, const void* lm, const void* w2, void* out, float* lse1, int B, int h, int n_p, int m,
                      int dh, float scale, int accumulate, mh_stream s);
-int mh_nys_attn3_fwd(const void* qkv, const void* lm, float* av, float* lse3, int B, int h, int n_p, int m, int dh, float scale,
-                     mh_stream s);
+/* attn3_fwd cuts the sequence into ranges (one workgroup each) when B*h alone would not fill the chip; the partial results
+ * live in `workspace` (mh_nys_attn3_ws_floats(B, h, n_p) floats; NULL / too small: one workgroup per (b, h)). */
+int64_t mh_nys_attn3_ws_floats(int B, int h, int n_p);
+int mh_nys_attn3_fwd(const void* qkv, const void* lm, float* av, float* lse3, float* workspace, int64_t ws_floats, int B, int h,
+                     int n_p, int m, int dh, float scale, mh_stream s);
 int mh_nys_attn1_bwd(const void* qkv, const void* lm, const void* w2, const void* dout, const float* lse1, float* delta1,
                      void* dqkv, float* dw2, float* dlm, int B, int h, int n_p, int m, int dh, float scale, mh_stream s);
 int mh_nys_attn3_bwd(const void* qkv, const void* lm, const float* av, const void* dav, const float* lse3, float* delta3,

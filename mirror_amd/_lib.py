@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmirror_hip.so")
+# MIRROR_HIP_LIB: another build of the same ABI (A/B timing of kernel variants inside one process launch)
+LIB_PATH = os.environ.get("MIRROR_HIP_LIB") or os.path.join(_HERE, "lib", "libmirror_hip.so")
 
 MH_F32, MH_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
@@ -56,7 +57,7 @@ _SIGS = {
     "mh_pinv_chain_fwd": [P, P, P, I, I, I],
     "mh_pinv_chain_bwd": [P, P, P, P, P, P, I, I, I],
     "mh_nys_attn1_fwd": [P, P, P, P, P, I, I, I, I, I, F, I],
-    "mh_nys_attn3_fwd": [P, P, P, P, I, I, I, I, I, F],
+    "mh_nys_attn3_fwd": [P, P, P, P, P, L, I, I, I, I, I, F],
     "mh_nys_attn1_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, F],
     "mh_nys_attn3_bwd": [P, P, P, P, P, P, P, P, I, I, I, I, I, F],
     "mh_seq_finish": [P, P, I, I, I, I, I],
@@ -94,7 +95,7 @@ _SIGS = {
     "mh_adam": [P, P, P, P, P, L, F, F, F, F, F, F, F, P],
     "mh_grad_clip": [P, L, F, F, P, P],
 }
-EXPORTS = sorted(list(_SIGS) + ["mh_last_error", "mh_version", "mh_device_ok"])
+EXPORTS = sorted(list(_SIGS) + ["mh_last_error", "mh_version", "mh_device_ok", "mh_nys_attn3_ws_floats"])
 
 _lib = None
 
@@ -117,6 +118,8 @@ def load() -> C.CDLL:
     lib.mh_last_error.argtypes = []
     lib.mh_version.restype = C.c_int
     lib.mh_device_ok.restype = C.c_int
+    lib.mh_nys_attn3_ws_floats.restype = C.c_int64
+    lib.mh_nys_attn3_ws_floats.argtypes = [C.c_int, C.c_int, C.c_int]
     for name, sig in _SIGS.items():
         fn = getattr(lib, name)
         fn.argtypes = list(sig) + [C.c_void_p]

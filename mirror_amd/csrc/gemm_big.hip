@@ -208,11 +208,16 @@ __global__ __launch_bounds__(NTB) void gemm_big_kernel(GemmArgs g) {
     __syncthreads();
     for (int t = 0; t < nt; t++) {
         const int cur = t & 1;
+#ifndef GEMM_EXP
+#define GEMM_EXP 0
+#endif
         if (t + 1 < nt) {
-            SA::store(ra, smem + (cur ^ 1) * STAGE, tid);
-            SB::store(rb, smem + (cur ^ 1) * STAGE + GA::BYTES, tid);
-            if (t + 2 < nt) {
-                const int k0 = kbeg + (t + 2) * BK;
+            if (GEMM_EXP != 1 && GEMM_EXP != 3) {     // timing experiments (tools/exp/gemm_exp.cpp): 1 = no loads / stores, 3 = no LDS stores
+                SA::store(ra, smem + (cur ^ 1) * STAGE, tid);
+                SB::store(rb, smem + (cur ^ 1) * STAGE + GA::BYTES, tid);
+            }
+            if (t + 2 < nt && GEMM_EXP != 1) {
+                const int k0 = GEMM_EXP == 2 ? kbeg : kbeg + (t + 2) * BK;    // 2 = always the same K-tile (cache resident)
                 SA::load(ra, A, g.lda, tile_m * BIG, g.M, k0, kend, true, tid);
                 SB::load(rb, B, g.ldb, tile_n * BIG, g.N, k0, kend, true, tid);
             }

@@ -20,6 +20,7 @@
 //       attn3 fwd (online softmax), attn1 bwd dw2/dk_l, attn3 bwd dq_l
 // Layout (SURVEY.md §8 / DESIGN.md §4): qkv [B, n_p, 3D] bf16, heads are 64-wide column slices; landmarks lm
 // [B, m, 2D] = q_l | k_l; w2, av, dav [B, h, m, 64]; out / dout [B, n_p, D].
+#include <cstdlib>
 #include "gemm_kernel.h"
 
 namespace {
@@ -67,6 +68,54 @@ __device__ __forceinline__ f32x16 zero16() {
 }
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
+// The softmax arithmetic between the two products is what these kernels are bound by (the first version spent ~27 VALU
+// slots per MFMA): logits are scaled by scale * log2(e) so the exponential is a bare v_exp_f32, whole accumulator tiles
+// are processed as vectors so the compiler emits v_pk_fma / v_pk_mul / v_pk_add, and the file is built with
+// -mllvm -amdgpu-mfma-vgpr-form so accumulators stay in VGPRs instead of bouncing through v_accvgpr_read / write.
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+typedef float f32x8v __attribute__((ext_vector_type(8)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float vsum16(const f32x16& a) {
+    const f32x8v t8 = __builtin_shufflevector(a, a, 0, 1, 2, 3, 4, 5, 6, 7) + __builtin_shufflevector(a, a, 8, 9, 10, 11, 12, 13, 14, 15);
+    const f32x4 t4 = __builtin_shufflevector(t8, t8, 0, 1, 2, 3) + __builtin_shufflevector(t8, t8, 4, 5, 6, 7);
+    const f32x2v t2 = __builtin_shufflevector(t4, t4, 0, 1) + __builtin_shufflevector(t4, t4, 2, 3);
+    return t2[0] + t2[1];
+}
+__device__ __forceinline__ float vmax16(const f32x16& a) {
+    float m0 = fmaxf(fmaxf(a[0], a[1]), a[2]), m1 = fmaxf(fmaxf(a[3], a[4]), a[5]), m2 = fmaxf(fmaxf(a[6], a[7]), a[8]);
+    float m3 = fmaxf(fmaxf(a[9], a[10]), a[11]), m4 = fmaxf(fmaxf(a[12], a[13]), a[14]);
+    return fmaxf(fmaxf(fmaxf(m0, m1), fmaxf(m2, m3)), fmaxf(m4, a[15]));
+}
+__device__ __forceinline__ void exp2_16(f32x16& a) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) a[r] = __builtin_amdgcn_exp2f(a[r]);
+}
+// a * m + b with m, b the same for all 16 elements: pairs of elements, so the compiler emits 8 v_pk_fma_f32 (written as
+// `a * m - b` it first splats b into 16 registers and negates every one of them)
+__device__ __forceinline__ f32x16 fma_splat(const f32x16& a, float m, float b) {
+    const f32x2v mm = {m, m}, bb = {b, b};
+    f32x16 r;
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+        f32x2v x = {a[i], a[i + 1]};
+        x = __builtin_elementwise_fma(x, mm, bb);
+        r[i] = x[0];
+        r[i + 1] = x[1];
+    }
+    return r;
+}
+constexpr float NEG_BIG = -1e30f;   // "minus infinity" of the running maxima (the file is built with -fno-honor-nans)
+// accumulator registers <-> rows 8 (r >> 2) + 4 hl + (r & 3): the 16 per-row values of `src` (LDS, f32) for this lane
+__device__ __forceinline__ f32x16 rowvals16(const float* src, int hl) {
+    f32x16 v;
+#pragma unroll
+    for (int gq = 0; gq < 4; gq++) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(src + 8 * gq + 4 * hl);
+        v[4 * gq] = x[0]; v[4 * gq + 1] = x[1]; v[4 * gq + 2] = x[2]; v[4 * gq + 3] = x[3];
+    }
+    return v;
+}
+
 // ROWS x 64 bf16 (row stride ld) -> pitch-NP image
 template <int ROWS>
 __device__ __forceinline__ void stage_rows(bf16_t* img, const bf16_t* __restrict__ src, long ld, int tid) {
@@ -103,145 +152,193 @@ __device__ __forceinline__ void store_row4(bf16_t* p, const f32x16& a, int g) {
 
 struct Geo {
     int h, n_p, D;
-    float scale;
+    float scale, scale2;    // scale2 = scale * log2(e)
     int accumulate;     // attn1 forward: add to `out` (the res_conv term is already there) instead of overwriting it
 };
 
 // ============================================================================ attn1 forward (N kernel)
-// grid (n_p / 128, B h).  out[b, n, hd*64 + d] = sum_l softmax_l(scale q k_l^T)[n, l] w2[l, d];  lse1 = row logsumexp
+// grid (splits, B h).  out[b, n, hd*64 + d] = sum_l softmax_l(scale q k_l^T)[n, l] w2[l, d];  lse1 = row logsumexp.
+// The landmark images (k_l, w2: 64 KB) are staged ONCE per workgroup; after that every wave walks its own 32-row blocks
+// of the sequence (block = first + i * 4 * splits) with the q fragments read straight from HBM one block ahead — no
+// LDS writes and no barriers in the loop.  (One 128-row tile per workgroup spent 3x longer staging than computing.)
 __global__ __launch_bounds__(NT) void nys_a1_fwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ lm,
                                                         const bf16_t* __restrict__ w2, bf16_t* __restrict__ out,
                                                         float* __restrict__ lse1, Geo g) {
-    __shared__ __attribute__((aligned(16))) bf16_t s_kl[NM * NP];
-    __shared__ __attribute__((aligned(16))) bf16_t s_w2[NM * NP];
+    __shared__ __attribute__((aligned(16))) bf16_t s_kl_[NM * NP];
+    __shared__ __attribute__((aligned(16))) bf16_t s_w2_[NM * NP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hl = lane >> 5;
     const int bh = blockIdx.y, b = bh / g.h, hd = bh % g.h, D = g.D;
-    stage_rows<NM>(s_kl, lm + (long)b * NM * 2 * D + D + hd * ND, 2 * D, tid);
-    stage_rows<NM>(s_w2, w2 + (long)bh * NM * ND, ND, tid);
-    const long row = (long)blockIdx.x * TR + wave * 32 + c;
-    const bf16_t* qrow = qkv + ((long)b * g.n_p + row) * 3 * D + hd * ND;
-    bf16x8 qf[4];
+    stage_rows<NM>(s_kl_, lm + (long)b * NM * 2 * D + D + hd * ND, 2 * D, tid);
+    stage_rows<NM>(s_w2_, w2 + (long)bh * NM * ND, ND, tid);
+    const int nblk = g.n_p / 32, stride = 4 * gridDim.x;
+    int rb = 4 * blockIdx.x + wave;
+    const bf16_t* qb = qkv + (long)b * g.n_p * 3 * D + hd * ND;
+    bf16x8 qn[4];
+    if (rb < nblk) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++) qf[ks] = frag_g(qrow, 16 * ks, lane);
+        for (int ks = 0; ks < 4; ks++) qn[ks] = frag_g(qb + (long)(32 * rb + c) * 3 * D, 16 * ks, lane);
+    }
     __syncthreads();
-    // online softmax over the 8 landmark blocks: 16 logits live at a time instead of 128 (two waves per SIMD fit)
-    float mrun = -INFINITY, lrun = 0.f;
-    f32x16 o[2] = {zero16(), zero16()};   // O^T[d][q row]
+#pragma unroll 1
+    for (; rb < nblk; rb += stride) {
+        const long row = 32L * rb + c;
+        // the landmark fragments do not depend on the block: without an opaque base the compiler hoists all 64 LDS reads
+        // out of the loop and keeps them in 256 registers
+        int opq = 0;
+        asm volatile("" : "+v"(opq));
+        const bf16_t* s_kl = s_kl_ + opq;
+        const bf16_t* s_w2 = s_w2_ + opq;
+        bf16x8 qf[4];
 #pragma unroll
-    for (int blk = 0; blk < 8; blk++) {
-        f32x16 sb = zero16();             // S^T[landmark 32 blk ..][q row]
+        for (int ks = 0; ks < 4; ks++) qf[ks] = qn[ks];
+        if (rb + stride < nblk) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ks++) sb = MFMA(frag_kc(s_kl, 32 * blk, 16 * ks, lane), qf[ks], sb);
-        float mx = sb[0];
-#pragma unroll
-        for (int r = 1; r < 16; r++) mx = fmaxf(mx, sb[r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mnew = fmaxf(mrun, mx * g.scale);
-        const float alpha = __expf(mrun - mnew);
-        mrun = mnew;
-        float sum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const float pv = __expf(sb[r] * g.scale - mnew);
-            sb[r] = pv;
-            sum += pv;
+            for (int ks = 0; ks < 4; ks++) qn[ks] = frag_g(qb + (long)(32 * (rb + stride) + c) * 3 * D, 16 * ks, lane);
         }
-        lrun = lrun * alpha + sum;        // per lane half; the halves are joined once at the end
-        o[0] *= alpha;
-        o[1] *= alpha;
-        const bf16x8 p0 = pack8<0>(sb), p1 = pack8<1>(sb);
+        bf16_t* orow = out + ((long)b * g.n_p + row) * D + hd * ND;
+        u32x2 old[2][4];      // the res_conv term already in `out`: fetched now, needed at the end of the block
+        if (g.accumulate) {
+#pragma unroll
+            for (int nb = 0; nb < 2; nb++)
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++) old[nb][gq] = *reinterpret_cast<const u32x2*>(orow + 32 * nb + 8 * gq + 4 * hl);
+        }
+        // online softmax over the 8 landmark blocks: 16 logits live at a time instead of 128 (two waves per SIMD fit)
+        float mrun = NEG_BIG, lrun = 0.f;
+        f32x16 o[2] = {zero16(), zero16()};   // O^T[d][q row]
+#pragma unroll
+        for (int blk = 0; blk < 8; blk++) {
+            f32x16 sb = zero16();             // S^T[landmark 32 blk ..][q row]
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) sb = MFMA(frag_kc(s_kl, 32 * blk, 16 * ks, lane), qf[ks], sb);
+            float mx = vmax16(sb);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mnew = fmaxf(mrun, mx * g.scale2);         // running max in log2 units
+            if (__builtin_amdgcn_ballot_w64(mnew != mrun)) {       // rescale only when some row's max moved
+                const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+                lrun *= alpha;
+                o[0] *= alpha;
+                o[1] *= alpha;
+                mrun = mnew;
+            }
+            sb = fma_splat(sb, g.scale2, -mrun);
+            exp2_16(sb);
+            lrun += vsum16(sb);               // per lane half; the halves are joined once at the end
+            const bf16x8 p0 = pack8<0>(sb), p1 = pack8<1>(sb);
+#pragma unroll
+            for (int nb = 0; nb < 2; nb++) {
+                o[nb] = MFMA(frag_tr(s_w2, 32 * nb, 32 * blk, lane), p0, o[nb]);
+                o[nb] = MFMA(frag_tr(s_w2, 32 * nb, 32 * blk + 16, lane), p1, o[nb]);
+            }
+        }
+        const float sum = lrun + __shfl_xor(lrun, 32, 64);
+        if (hl == 0) lse1[(long)bh * g.n_p + row] = (mrun + __log2f(sum)) * LN2;
+        const float inv = 1.f / sum;
 #pragma unroll
         for (int nb = 0; nb < 2; nb++) {
-            o[nb] = MFMA(frag_tr(s_w2, 32 * nb, 32 * blk, lane), p0, o[nb]);
-            o[nb] = MFMA(frag_tr(s_w2, 32 * nb, 32 * blk + 16, lane), p1, o[nb]);
-        }
-    }
-    const float sum = lrun + __shfl_xor(lrun, 32, 64);
-    if (hl == 0) lse1[(long)bh * g.n_p + row] = mrun + __logf(sum);
-    const float inv = 1.f / sum;
-    bf16_t* orow = out + ((long)b * g.n_p + row) * D + hd * ND;
+            o[nb] *= inv;
 #pragma unroll
-    for (int nb = 0; nb < 2; nb++) {
-        o[nb] *= inv;
-#pragma unroll
-        for (int gq = 0; gq < 4; gq++) {
-            bf16_t* p = orow + 32 * nb + 8 * gq + 4 * hl;
-            if (g.accumulate) {
-                const u32x2 old = *reinterpret_cast<const u32x2*>(p);
-                o[nb][4 * gq + 0] += __uint_as_float(old[0] << 16);
-                o[nb][4 * gq + 1] += __uint_as_float(old[0] & 0xffff0000u);
-                o[nb][4 * gq + 2] += __uint_as_float(old[1] << 16);
-                o[nb][4 * gq + 3] += __uint_as_float(old[1] & 0xffff0000u);
+            for (int gq = 0; gq < 4; gq++) {
+                if (g.accumulate) {
+                    o[nb][4 * gq + 0] += __uint_as_float(old[nb][gq][0] << 16);
+                    o[nb][4 * gq + 1] += __uint_as_float(old[nb][gq][0] & 0xffff0000u);
+                    o[nb][4 * gq + 2] += __uint_as_float(old[nb][gq][1] << 16);
+                    o[nb][4 * gq + 3] += __uint_as_float(old[nb][gq][1] & 0xffff0000u);
+                }
+                store_row4(orow + 32 * nb + 8 * gq + 4 * hl, o[nb], gq);
             }
-            store_row4(p, o[nb], gq);
         }
     }
 }
 
 // ============================================================================ attn1 backward, dq + delta (N kernel)
-// dS1 = P1 o (dO w2^T - delta) scale, delta[n] = sum_l P1 dP1;  dq = dS1 k_l
-__global__ __launch_bounds__(NT) void nys_a1_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ lm,
+// grid (splits, B h), same walk as the forward.  dS1 = P1 o (dO w2^T - delta) scale, delta[n] = sum_l P1 dP1;  dq = dS1 k_l
+__global__ __launch_bounds__(NT, 2) void nys_a1_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ lm,
                                                            const bf16_t* __restrict__ w2, const bf16_t* __restrict__ dout,
                                                            const float* __restrict__ lse1, float* __restrict__ delta1,
                                                            bf16_t* __restrict__ dqkv, Geo g) {
-    __shared__ __attribute__((aligned(16))) bf16_t s_kl[NM * NP];
-    __shared__ __attribute__((aligned(16))) bf16_t s_w2[NM * NP];
+    __shared__ __attribute__((aligned(16))) bf16_t s_kl_[NM * NP];
+    __shared__ __attribute__((aligned(16))) bf16_t s_w2_[NM * NP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hl = lane >> 5;
     const int bh = blockIdx.y, b = bh / g.h, hd = bh % g.h, D = g.D;
-    stage_rows<NM>(s_kl, lm + (long)b * NM * 2 * D + D + hd * ND, 2 * D, tid);
-    stage_rows<NM>(s_w2, w2 + (long)bh * NM * ND, ND, tid);
-    const long row = (long)blockIdx.x * TR + wave * 32 + c;
-    const bf16_t* qrow = qkv + ((long)b * g.n_p + row) * 3 * D + hd * ND;
-    const bf16_t* grow = dout + ((long)b * g.n_p + row) * D + hd * ND;
-    bf16x8 qf[4], gf[4];
+    stage_rows<NM>(s_kl_, lm + (long)b * NM * 2 * D + D + hd * ND, 2 * D, tid);
+    stage_rows<NM>(s_w2_, w2 + (long)bh * NM * ND, ND, tid);
+    const int nblk = g.n_p / 32, stride = 4 * gridDim.x;
+    int rb = 4 * blockIdx.x + wave;
+    const bf16_t* qb = qkv + (long)b * g.n_p * 3 * D + hd * ND;
+    const bf16_t* gb = dout + (long)b * g.n_p * D + hd * ND;
+    bf16x8 qn[4], gn[4];
+    float lsen = 0.f;
+    if (rb < nblk) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++) {
-        qf[ks] = frag_g(qrow, 16 * ks, lane);
-        gf[ks] = frag_g(grow, 16 * ks, lane);
-    }
-    const float lse = lse1[(long)bh * g.n_p + row];
-    __syncthreads();
-    f32x16 s[8];   // P1^T[landmark][q row]
-#pragma unroll
-    for (int blk = 0; blk < 8; blk++) {
-        s[blk] = zero16();
-#pragma unroll
-        for (int ks = 0; ks < 4; ks++) s[blk] = MFMA(frag_kc(s_kl, 32 * blk, 16 * ks, lane), qf[ks], s[blk]);
-#pragma unroll
-        for (int r = 0; r < 16; r++) s[blk][r] = __expf(s[blk][r] * g.scale - lse);
-    }
-    // pass 1: delta = sum_l P dP   (dP^T[landmark][q row] = w2 dO^T, recomputed in pass 2 instead of held)
-    float del = 0.f;
-#pragma unroll
-    for (int blk = 0; blk < 8; blk++) {
-        f32x16 dp = zero16();
-#pragma unroll
-        for (int ks = 0; ks < 4; ks++) dp = MFMA(frag_kc(s_w2, 32 * blk, 16 * ks, lane), gf[ks], dp);
-#pragma unroll
-        for (int r = 0; r < 16; r++) del += s[blk][r] * dp[r];
-    }
-    del += __shfl_xor(del, 32, 64);
-    if (hl == 0) delta1[(long)bh * g.n_p + row] = del;
-    f32x16 dq[2] = {zero16(), zero16()};   // dq^T[d][q row]
-#pragma unroll
-    for (int blk = 0; blk < 8; blk++) {
-        f32x16 dp = zero16();
-#pragma unroll
-        for (int ks = 0; ks < 4; ks++) dp = MFMA(frag_kc(s_w2, 32 * blk, 16 * ks, lane), gf[ks], dp);
-#pragma unroll
-        for (int r = 0; r < 16; r++) dp[r] = s[blk][r] * (dp[r] - del) * g.scale;
-        const bf16x8 d0 = pack8<0>(dp), d1 = pack8<1>(dp);
-#pragma unroll
-        for (int nb = 0; nb < 2; nb++) {
-            dq[nb] = MFMA(frag_tr(s_kl, 32 * nb, 32 * blk, lane), d0, dq[nb]);
-            dq[nb] = MFMA(frag_tr(s_kl, 32 * nb, 32 * blk + 16, lane), d1, dq[nb]);
+        for (int ks = 0; ks < 4; ks++) {
+            qn[ks] = frag_g(qb + (long)(32 * rb + c) * 3 * D, 16 * ks, lane);
+            gn[ks] = frag_g(gb + (long)(32 * rb + c) * D, 16 * ks, lane);
         }
+        lsen = lse1[(long)bh * g.n_p + 32 * rb + c];
     }
-    bf16_t* drow = dqkv + ((long)b * g.n_p + row) * 3 * D + hd * ND;
+    __syncthreads();
+#pragma unroll 1
+    for (; rb < nblk; rb += stride) {
+        const long row = 32L * rb + c;
+        int opq = 0;                      // see nys_a1_fwd_kernel
+        asm volatile("" : "+v"(opq));
+        const bf16_t* s_kl = s_kl_ + opq;
+        const bf16_t* s_w2 = s_w2_ + opq;
+        bf16x8 qf[4], gf[4];
 #pragma unroll
-    for (int nb = 0; nb < 2; nb++)
+        for (int ks = 0; ks < 4; ks++) { qf[ks] = qn[ks]; gf[ks] = gn[ks]; }
+        const float lse2 = lsen * LOG2E;
+        if (rb + stride < nblk) {
+            const long nrow = 32L * (rb + stride) + c;
 #pragma unroll
-        for (int gq = 0; gq < 4; gq++) store_row4(drow + 32 * nb + 8 * gq + 4 * hl, dq[nb], gq);
+            for (int ks = 0; ks < 4; ks++) {
+                qn[ks] = frag_g(qb + nrow * 3 * D, 16 * ks, lane);
+                gn[ks] = frag_g(gb + nrow * D, 16 * ks, lane);
+            }
+            lsen = lse1[(long)bh * g.n_p + nrow];
+        }
+        f32x16 s[8];   // P1^T[landmark][q row]
+#pragma unroll
+        for (int blk = 0; blk < 8; blk++) {
+            s[blk] = zero16();
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) s[blk] = MFMA(frag_kc(s_kl, 32 * blk, 16 * ks, lane), qf[ks], s[blk]);
+            s[blk] = fma_splat(s[blk], g.scale2, -lse2);
+            exp2_16(s[blk]);
+        }
+        // pass 1: delta = sum_l P dP   (dP^T[landmark][q row] = w2 dO^T, recomputed in pass 2 instead of held)
+        f32x16 dacc = zero16();
+#pragma unroll
+        for (int blk = 0; blk < 8; blk++) {
+            f32x16 dp = zero16();
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) dp = MFMA(frag_kc(s_w2, 32 * blk, 16 * ks, lane), gf[ks], dp);
+            dacc += s[blk] * dp;
+        }
+        float del = vsum16(dacc);
+        del += __shfl_xor(del, 32, 64);
+        if (hl == 0) delta1[(long)bh * g.n_p + row] = del;
+        f32x16 dq[2] = {zero16(), zero16()};   // dq^T[d][q row]
+#pragma unroll
+        for (int blk = 0; blk < 8; blk++) {
+            f32x16 dp = zero16();
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) dp = MFMA(frag_kc(s_w2, 32 * blk, 16 * ks, lane), gf[ks], dp);
+            dp = s[blk] * fma_splat(dp, g.scale, -del * g.scale);
+            const bf16x8 d0 = pack8<0>(dp), d1 = pack8<1>(dp);
+#pragma unroll
+            for (int nb = 0; nb < 2; nb++) {
+                dq[nb] = MFMA(frag_tr(s_kl, 32 * nb, 32 * blk, lane), d0, dq[nb]);
+                dq[nb] = MFMA(frag_tr(s_kl, 32 * nb, 32 * blk + 16, lane), d1, dq[nb]);
+            }
+        }
+        bf16_t* drow = dqkv + ((long)b * g.n_p + row) * 3 * D + hd * ND;
+#pragma unroll
+        for (int nb = 0; nb < 2; nb++)
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) store_row4(drow + 32 * nb + 8 * gq + 4 * hl, dq[nb], gq);
+    }
 }
 
 // accumulator [rows in registers][cols in lanes] -> f32 atomics into dst[row * ld + col]
@@ -312,12 +409,7 @@ __global__ __launch_bounds__(NT) void nys_a1_bwd_dw_kernel(const bf16_t* __restr
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) {   // 32 q rows at a time
-            f32x4 lr[4], dr[4];
-#pragma unroll
-            for (int gq = 0; gq < 4; gq++) {
-                lr[gq] = *reinterpret_cast<const f32x4*>(s_lse + 32 * i + 8 * gq + 4 * hl);
-                dr[gq] = *reinterpret_cast<const f32x4*>(s_del + 32 * i + 8 * gq + 4 * hl);
-            }
+            const f32x16 lv = rowvals16(s_lse + 32 * i, hl) * LOG2E, dv = rowvals16(s_del + 32 * i, hl) * g.scale;
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 f32x16 s = zero16(), dp = zero16();   // S[q row][landmark], dP[q row][landmark]
@@ -326,12 +418,9 @@ __global__ __launch_bounds__(NT) void nys_a1_bwd_dw_kernel(const bf16_t* __restr
                     s = MFMA(frag_kc(s_q, 32 * i, 16 * ks, lane), klf[j][ks], s);
                     dp = MFMA(frag_kc(s_g, 32 * i, 16 * ks, lane), w2f[j][ks], dp);
                 }
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const float p = __expf(s[r] * g.scale - lr[r >> 2][r & 3]);
-                    s[r] = p;
-                    dp[r] = p * (dp[r] - dr[r >> 2][r & 3]) * g.scale;
-                }
+                s = s * g.scale2 - lv;
+                exp2_16(s);
+                dp = s * (dp * g.scale - dv);
                 const bf16x8 p0 = pack8<0>(s), p1 = pack8<1>(s), d0 = pack8<0>(dp), d1 = pack8<1>(dp);
 #pragma unroll
                 for (int nb = 0; nb < 2; nb++) {
@@ -356,14 +445,19 @@ __global__ __launch_bounds__(NT) void nys_a1_bwd_dw_kernel(const bf16_t* __restr
 }
 
 // ============================================================================ attn3 forward (L kernel, online softmax)
-// grid (B h).  av[bh, l, d] = sum_n softmax_n(scale q_l k^T)[l, n] v[n, d];  lse3[bh, l]
-__global__ __launch_bounds__(NT) void nys_a3_fwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ lm,
-                                                        float* __restrict__ av, float* __restrict__ lse3, Geo g) {
+// grid (splits, B h).  av[bh, l, d] = sum_n softmax_n(scale q_l k^T)[l, n] v[n, d];  lse3[bh, l].
+// One workgroup per (b, h) would leave half of the CUs idle (128 workgroups), so the sequence is cut into `splits`
+// ranges of tiles: each workgroup leaves its unnormalised O, running max and sum in `part` and nys_a3_combine_kernel
+// merges them (splits == 1: finished here, `part` unused).
+constexpr int A3_PART = NM * (ND + 2);     // floats per (b, h, split): O [256][64], m [256], l [256]
+__global__ __launch_bounds__(NT, 2) void nys_a3_fwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ lm,
+                                                        float* __restrict__ av, float* __restrict__ lse3, float* __restrict__ part,
+                                                        Geo g, int tiles_per_wg) {
     __shared__ __attribute__((aligned(16))) bf16_t s_k[TR * NP];
     __shared__ __attribute__((aligned(16))) bf16_t s_v[TR * NP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hl = lane >> 5;
-    const int bh = blockIdx.x, b = bh / g.h, hd = bh % g.h, D = g.D;
-    const int ntiles = g.n_p / TR;
+    const int bh = blockIdx.y, b = bh / g.h, hd = bh % g.h, D = g.D;
+    const int t0 = blockIdx.x * tiles_per_wg, t1 = min(t0 + tiles_per_wg, g.n_p / TR);
     const bf16_t* qlb = lm + (long)b * NM * 2 * D + hd * ND;
     bf16x8 qlf[2][4];
 #pragma unroll
@@ -372,71 +466,76 @@ __global__ __launch_bounds__(NT) void nys_a3_fwd_kernel(const bf16_t* __restrict
         for (int ks = 0; ks < 4; ks++) qlf[j][ks] = frag_g(qlb + (long)(64 * wave + 32 * j + c) * 2 * D, 16 * ks, lane);
     const bf16_t* kb = qkv + (long)b * g.n_p * 3 * D + D + hd * ND;
     const bf16_t* vb = kb + D;
-    float mrun[2] = {-INFINITY, -INFINITY}, lrun[2] = {0.f, 0.f};
+    float mrun[2] = {NEG_BIG, NEG_BIG}, lrun[2] = {0.f, 0.f};
     f32x16 o[2][2];   // O^T[d (nb)][landmark (j)]
 #pragma unroll
     for (int nb = 0; nb < 2; nb++)
 #pragma unroll
         for (int j = 0; j < 2; j++) o[nb][j] = zero16();
     u32x4 rk[TR * 8 / NT], rv[TR * 8 / NT];
-    tile_load<TR>(rk, kb, 3 * D, tid);
-    tile_load<TR>(rv, vb, 3 * D, tid);
+    tile_load<TR>(rk, kb + (long)t0 * TR * 3 * D, 3 * D, tid);
+    tile_load<TR>(rv, vb + (long)t0 * TR * 3 * D, 3 * D, tid);
 #pragma unroll 1
-    for (int t = 0; t < ntiles; t++) {
+    for (int t = t0; t < t1; t++) {
         __syncthreads();
         tile_store<TR>(rk, s_k, tid);
         tile_store<TR>(rv, s_v, tid);
         __syncthreads();
-        if (t + 1 < ntiles) {
+        if (t + 1 < t1) {
             tile_load<TR>(rk, kb + (long)(t + 1) * TR * 3 * D, 3 * D, tid);
             tile_load<TR>(rv, vb + (long)(t + 1) * TR * 3 * D, 3 * D, tid);
         }
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            f32x16 s[4];   // S3^T[key][landmark]
-            float mx = -INFINITY;
+        for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                s[i] = zero16();
+            for (int hf = 0; hf < 2; hf++) {      // 64 keys at a time: 32 logits live instead of 64 (two waves per SIMD)
+                f32x16 s[2];   // S3^T[key][landmark]
+                float mx = NEG_BIG;
 #pragma unroll
-                for (int ks = 0; ks < 4; ks++) s[i] = MFMA(frag_kc(s_k, 32 * i, 16 * ks, lane), qlf[j][ks], s[i]);
+                for (int i = 0; i < 2; i++) {
+                    s[i] = zero16();
 #pragma unroll
-                for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[i][r]);
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float mnew = fmaxf(mrun[j], mx * g.scale);
-            const float alpha = __expf(mrun[j] - mnew);
-            mrun[j] = mnew;
-            float sum = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const float p = __expf(s[i][r] * g.scale - mnew);
-                    s[i][r] = p;
-                    sum += p;
+                    for (int ks = 0; ks < 4; ks++) s[i] = MFMA(frag_kc(s_k, 64 * hf + 32 * i, 16 * ks, lane), qlf[j][ks], s[i]);
+                    mx = fmaxf(mx, vmax16(s[i]));
                 }
-            lrun[j] = lrun[j] * alpha + sum;   // per lane half; the halves are joined once at the end
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float mnew = fmaxf(mrun[j], mx * g.scale2);      // running max in log2 units
+                if (__builtin_amdgcn_ballot_w64(mnew != mrun[j])) {    // rescale only when some landmark's max moved
+                    const float alpha = __builtin_amdgcn_exp2f(mrun[j] - mnew);
+                    lrun[j] *= alpha;
 #pragma unroll
-            for (int nb = 0; nb < 2; nb++) o[nb][j] *= alpha;
+                    for (int nb = 0; nb < 2; nb++) o[nb][j] *= alpha;
+                    mrun[j] = mnew;
+                }
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const bf16x8 p0 = pack8<0>(s[i]), p1 = pack8<1>(s[i]);
+                for (int i = 0; i < 2; i++) {
+                    s[i] = fma_splat(s[i], g.scale2, -mrun[j]);
+                    exp2_16(s[i]);
+                }
+                lrun[j] += vsum16(s[0] + s[1]);    // per lane half; the halves are joined once at the end
 #pragma unroll
-                for (int nb = 0; nb < 2; nb++) {
-                    o[nb][j] = MFMA(frag_tr(s_v, 32 * nb, 32 * i, lane), p0, o[nb][j]);
-                    o[nb][j] = MFMA(frag_tr(s_v, 32 * nb, 32 * i + 16, lane), p1, o[nb][j]);
+                for (int i = 0; i < 2; i++) {
+                    const bf16x8 p0 = pack8<0>(s[i]), p1 = pack8<1>(s[i]);
+#pragma unroll
+                    for (int nb = 0; nb < 2; nb++) {
+                        o[nb][j] = MFMA(frag_tr(s_v, 32 * nb, 64 * hf + 32 * i, lane), p0, o[nb][j]);
+                        o[nb][j] = MFMA(frag_tr(s_v, 32 * nb, 64 * hf + 32 * i + 16, lane), p1, o[nb][j]);
+                    }
                 }
             }
-        }
     }
+    const bool whole = gridDim.x == 1;
+    float* pb = part + ((long)bh * gridDim.x + blockIdx.x) * A3_PART;
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const float l = lrun[j] + __shfl_xor(lrun[j], 32, 64);
-        const float inv = 1.f / l;
+        const float inv = whole ? 1.f / l : 1.f;
         const int lq = 64 * wave + 32 * j + c;
-        if (hl == 0) lse3[(long)bh * NM + lq] = mrun[j] + __logf(l);
-        float* arow = av + ((long)bh * NM + lq) * ND;
+        if (hl == 0) {
+            if (whole) lse3[(long)bh * NM + lq] = (mrun[j] + __log2f(l)) * LN2;
+            else { pb[NM * ND + lq] = mrun[j]; pb[NM * ND + NM + lq] = l; }
+        }
+        float* arow = whole ? av + ((long)bh * NM + lq) * ND : pb + (long)lq * ND;
 #pragma unroll
         for (int nb = 0; nb < 2; nb++)
 #pragma unroll
@@ -447,6 +546,28 @@ __global__ __launch_bounds__(NT) void nys_a3_fwd_kernel(const bf16_t* __restrict
                 *reinterpret_cast<f32x4*>(arow + 32 * nb + 8 * gq + 4 * hl) = w;
             }
     }
+}
+
+// grid (4, B h): thread = (landmark, 16-wide slice of d).  av = sum_s O_s 2^(m_s - M) / sum_s l_s 2^(m_s - M)
+__global__ __launch_bounds__(256) void nys_a3_combine_kernel(const float* __restrict__ part, float* __restrict__ av,
+                                                             float* __restrict__ lse3, int splits) {
+    const int bh = blockIdx.y, l = threadIdx.x, d0 = 16 * blockIdx.x;
+    const float* pb = part + (long)bh * splits * A3_PART;
+    float M = NEG_BIG;
+    for (int sp = 0; sp < splits; sp++) M = fmaxf(M, pb[(long)sp * A3_PART + NM * ND + l]);
+    float L = 0.f;
+    f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    for (int sp = 0; sp < splits; sp++) {
+        const float* ps = pb + (long)sp * A3_PART;
+        const float w = __builtin_amdgcn_exp2f(ps[NM * ND + l] - M);
+        L += ps[NM * ND + NM + l] * w;
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[q] += *reinterpret_cast<const f32x4*>(ps + (long)l * ND + d0 + 4 * q) * w;
+    }
+    const float inv = 1.f / L;
+    if (blockIdx.x == 0) lse3[(long)bh * NM + l] = (M + __log2f(L)) * LN2;
+#pragma unroll
+    for (int q = 0; q < 4; q++) *reinterpret_cast<f32x4*>(av + ((long)bh * NM + l) * ND + d0 + 4 * q) = acc[q] * inv;
 }
 
 // delta3[bh, l] = sum_d dav[l, d] av[l, d]: once per (b, h) instead of once per 128-row tile (34x the reads)
@@ -471,66 +592,83 @@ __global__ __launch_bounds__(256) void nys_delta3_kernel(const float* __restrict
 }
 
 // ============================================================================ attn3 backward, dk + dv (N kernel)
-// grid (n_p / 128, B h).  P3 = exp(scale q_l k^T - lse3), dv = P3^T dav, dS3 = P3 o (dav v^T - delta3) scale, dk = dS3^T q_l
-__global__ __launch_bounds__(NT) void nys_a3_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ lm,
+// grid (splits, B h), same walk as attn1.  P3 = exp(scale q_l k^T - lse3), dv = P3^T dav,
+// dS3 = P3 o (dav v^T - delta3) scale, dk = dS3^T q_l
+__global__ __launch_bounds__(NT, 2) void nys_a3_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ lm,
                                                             const float* __restrict__ delta3, const bf16_t* __restrict__ dav,
                                                             const float* __restrict__ lse3, bf16_t* __restrict__ dqkv, Geo g) {
-    __shared__ __attribute__((aligned(16))) bf16_t s_ql[NM * NP];
-    __shared__ __attribute__((aligned(16))) bf16_t s_g[NM * NP];
-    __shared__ __attribute__((aligned(16))) float s_lse[NM];
-    __shared__ __attribute__((aligned(16))) float s_del[NM];
+    __shared__ __attribute__((aligned(16))) bf16_t s_ql_[NM * NP];
+    __shared__ __attribute__((aligned(16))) bf16_t s_g_[NM * NP];
+    __shared__ __attribute__((aligned(16))) float s_lse_[NM];
+    __shared__ __attribute__((aligned(16))) float s_del_[NM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hl = lane >> 5;
     const int bh = blockIdx.y, b = bh / g.h, hd = bh % g.h, D = g.D;
-    stage_rows<NM>(s_ql, lm + (long)b * NM * 2 * D + hd * ND, 2 * D, tid);
-    stage_rows<NM>(s_g, dav + (long)bh * NM * ND, ND, tid);
-    s_del[tid] = delta3[(long)bh * NM + tid];       // thread = landmark
-    s_lse[tid] = lse3[(long)bh * NM + tid];
-    const long row = (long)blockIdx.x * TR + wave * 32 + c;
-    const bf16_t* krow = qkv + ((long)b * g.n_p + row) * 3 * D + D + hd * ND;
-    bf16x8 kf[4], vf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ks++) {
-        kf[ks] = frag_g(krow, 16 * ks, lane);
-        vf[ks] = frag_g(krow + D, 16 * ks, lane);
-    }
-    __syncthreads();
-    f32x16 adv[2] = {zero16(), zero16()}, adk[2] = {zero16(), zero16()};   // dv^T[d][key], dk^T[d][key]
-#pragma unroll
-    for (int blk = 0; blk < 8; blk++) {
-        f32x16 s = zero16(), dp = zero16();   // S3[landmark][key], dP3[landmark][key]
+    stage_rows<NM>(s_ql_, lm + (long)b * NM * 2 * D + hd * ND, 2 * D, tid);
+    stage_rows<NM>(s_g_, dav + (long)bh * NM * ND, ND, tid);
+    s_del_[tid] = delta3[(long)bh * NM + tid] * g.scale;       // thread = landmark
+    s_lse_[tid] = lse3[(long)bh * NM + tid] * LOG2E;
+    const int nblk = g.n_p / 32, stride = 4 * gridDim.x;
+    int rb = 4 * blockIdx.x + wave;
+    const bf16_t* kb = qkv + (long)b * g.n_p * 3 * D + D + hd * ND;
+    bf16x8 kn[4], vn[4];
+    if (rb < nblk) {
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) {
-            s = MFMA(frag_kc(s_ql, 32 * blk, 16 * ks, lane), kf[ks], s);
-            dp = MFMA(frag_kc(s_g, 32 * blk, 16 * ks, lane), vf[ks], dp);
-        }
-#pragma unroll
-        for (int gq = 0; gq < 4; gq++) {
-            const f32x4 lr = *reinterpret_cast<const f32x4*>(s_lse + 32 * blk + 8 * gq + 4 * hl);
-            const f32x4 dr = *reinterpret_cast<const f32x4*>(s_del + 32 * blk + 8 * gq + 4 * hl);
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const float p = __expf(s[4 * gq + e] * g.scale - lr[e]);
-                s[4 * gq + e] = p;
-                dp[4 * gq + e] = p * (dp[4 * gq + e] - dr[e]) * g.scale;
-            }
-        }
-        const bf16x8 p0 = pack8<0>(s), p1 = pack8<1>(s), d0 = pack8<0>(dp), d1 = pack8<1>(dp);
-#pragma unroll
-        for (int nb = 0; nb < 2; nb++) {
-            adv[nb] = MFMA(frag_tr(s_g, 32 * nb, 32 * blk, lane), p0, adv[nb]);
-            adv[nb] = MFMA(frag_tr(s_g, 32 * nb, 32 * blk + 16, lane), p1, adv[nb]);
-            adk[nb] = MFMA(frag_tr(s_ql, 32 * nb, 32 * blk, lane), d0, adk[nb]);
-            adk[nb] = MFMA(frag_tr(s_ql, 32 * nb, 32 * blk + 16, lane), d1, adk[nb]);
+            kn[ks] = frag_g(kb + (long)(32 * rb + c) * 3 * D, 16 * ks, lane);
+            vn[ks] = frag_g(kb + (long)(32 * rb + c) * 3 * D + D, 16 * ks, lane);
         }
     }
-    bf16_t* dkrow = dqkv + ((long)b * g.n_p + row) * 3 * D + D + hd * ND;
+    __syncthreads();
+#pragma unroll 1
+    for (; rb < nblk; rb += stride) {
+        const long row = 32L * rb + c;
+        int opq = 0;                      // see nys_a1_fwd_kernel
+        asm volatile("" : "+v"(opq));
+        const bf16_t* s_ql = s_ql_ + opq;
+        const bf16_t* s_g = s_g_ + opq;
+        const float* s_lse = s_lse_ + opq;
+        const float* s_del = s_del_ + opq;
+        bf16x8 kf[4], vf[4];
 #pragma unroll
-    for (int nb = 0; nb < 2; nb++)
+        for (int ks = 0; ks < 4; ks++) { kf[ks] = kn[ks]; vf[ks] = vn[ks]; }
+        if (rb + stride < nblk) {
+            const bf16_t* nr = kb + (32L * (rb + stride) + c) * 3 * D;
 #pragma unroll
-        for (int gq = 0; gq < 4; gq++) {
-            store_row4(dkrow + 32 * nb + 8 * gq + 4 * hl, adk[nb], gq);
-            store_row4(dkrow + D + 32 * nb + 8 * gq + 4 * hl, adv[nb], gq);
+            for (int ks = 0; ks < 4; ks++) {
+                kn[ks] = frag_g(nr, 16 * ks, lane);
+                vn[ks] = frag_g(nr + D, 16 * ks, lane);
+            }
         }
+        f32x16 adv[2] = {zero16(), zero16()}, adk[2] = {zero16(), zero16()};   // dv^T[d][key], dk^T[d][key]
+#pragma unroll
+        for (int blk = 0; blk < 8; blk++) {
+            f32x16 s = zero16(), dp = zero16();   // S3[landmark][key], dP3[landmark][key]
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                s = MFMA(frag_kc(s_ql, 32 * blk, 16 * ks, lane), kf[ks], s);
+                dp = MFMA(frag_kc(s_g, 32 * blk, 16 * ks, lane), vf[ks], dp);
+            }
+            s = s * g.scale2 - rowvals16(s_lse + 32 * blk, hl);      // staged as lse3 * log2(e)
+            exp2_16(s);
+            dp = s * (dp * g.scale - rowvals16(s_del + 32 * blk, hl));   // staged as delta3 * scale
+            const bf16x8 p0 = pack8<0>(s), p1 = pack8<1>(s), d0 = pack8<0>(dp), d1 = pack8<1>(dp);
+#pragma unroll
+            for (int nb = 0; nb < 2; nb++) {
+                adv[nb] = MFMA(frag_tr(s_g, 32 * nb, 32 * blk, lane), p0, adv[nb]);
+                adv[nb] = MFMA(frag_tr(s_g, 32 * nb, 32 * blk + 16, lane), p1, adv[nb]);
+                adk[nb] = MFMA(frag_tr(s_ql, 32 * nb, 32 * blk, lane), d0, adk[nb]);
+                adk[nb] = MFMA(frag_tr(s_ql, 32 * nb, 32 * blk + 16, lane), d1, adk[nb]);
+            }
+        }
+        bf16_t* dkrow = dqkv + ((long)b * g.n_p + row) * 3 * D + D + hd * ND;
+#pragma unroll
+        for (int nb = 0; nb < 2; nb++)
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                store_row4(dkrow + 32 * nb + 8 * gq + 4 * hl, adk[nb], gq);
+                store_row4(dkrow + D + 32 * nb + 8 * gq + 4 * hl, adv[nb], gq);
+            }
+    }
 }
 
 // ============================================================================ attn3 backward, dq_l (L kernel)
@@ -558,8 +696,8 @@ __global__ __launch_bounds__(NT) void nys_a3_bwd_dql_kernel(const bf16_t* __rest
             qlf[j][ks] = frag_g(qlb + (long)lq * 2 * D, 16 * ks, lane);
             gf[j][ks] = frag_g(gr, 16 * ks, lane);
         }
-        delv[j] = delta3[(long)bh * NM + lq];
-        lsev[j] = lse3[(long)bh * NM + lq];
+        delv[j] = delta3[(long)bh * NM + lq] * g.scale;
+        lsev[j] = lse3[(long)bh * NM + lq] * LOG2E;
     }
     const bf16_t* kb = qkv + (long)b * g.n_p * 3 * D + D + hd * ND;
     const bf16_t* vb = kb + D;
@@ -591,8 +729,9 @@ __global__ __launch_bounds__(NT) void nys_a3_bwd_dql_kernel(const bf16_t* __rest
                     s = MFMA(frag_kc(s_k, 32 * i, 16 * ks, lane), qlf[j][ks], s);
                     dp = MFMA(frag_kc(s_v, 32 * i, 16 * ks, lane), gf[j][ks], dp);
                 }
-#pragma unroll
-                for (int r = 0; r < 16; r++) dp[r] = __expf(s[r] * g.scale - lsev[j]) * (dp[r] - delv[j]) * g.scale;
+                s = fma_splat(s, g.scale2, -lsev[j]);
+                exp2_16(s);
+                dp = s * fma_splat(dp, g.scale, -delv[j]);
                 // dS3^T in the accumulator layout IS dS3 as an A operand (row = landmark = lane, k = keys): the product
                 // comes out as dq_l[landmark (registers)][d (lanes)], so the final atomics are 128-byte coalesced
                 const bf16x8 d0 = pack8<0>(dp), d1 = pack8<1>(dp);
@@ -611,6 +750,16 @@ __global__ __launch_bounds__(NT) void nys_a3_bwd_dql_kernel(const bf16_t* __rest
             atomic_tile(dqb + (long)(64 * wave + 32 * j) * 2 * D + 32 * nb, 2 * D, acc[nb][j], hl, c);
 }
 
+// workgroups per (b, h) of the sequence-walking N kernels: enough to put two workgroups on every CU (the landmark images
+// take 72 KB of LDS each), never more than one 32-row block per wave
+int pick_walkers(int BH, int n_p) {
+    static const char* env = getenv("MH_NYS_WALKERS");      // timing experiments: "max" = one 128-row tile per workgroup
+    if (env && env[0] == 'm') return n_p / TR;
+    int w = 1;
+    while (BH * w < 512 && 4 * w * 2 <= n_p / 32) w *= 2;
+    return w;
+}
+
 int check_geo(const char* fn, int B, int h, int n_p, int m, int dh) {
     MH_REQUIRE(m == NM && dh == ND, "%s: built for m = %d landmarks and dh = %d (got m=%d dh=%d); other shapes use mh_gemm + mh_softmax",
                fn, NM, ND, m, dh);
@@ -624,25 +773,46 @@ extern "C" int mh_nys_attn1_fwd(const void* qkv, const void* lm, const void* w2,
                                 int m, int dh, float scale, int accumulate, mh_stream s) {
     if (int e = check_geo("mh_nys_attn1_fwd", B, h, n_p, m, dh)) return e;
     if (B == 0) return MH_OK;
-    const Geo g{h, n_p, h * ND, scale, accumulate};
-    hipLaunchKernelGGL(nys_a1_fwd_kernel, dim3(n_p / TR, B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv, (const bf16_t*)lm,
+    const Geo g{h, n_p, h * ND, scale, scale * LOG2E, accumulate};
+    hipLaunchKernelGGL(nys_a1_fwd_kernel, dim3(pick_walkers(B * h, n_p), B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv, (const bf16_t*)lm,
                        (const bf16_t*)w2, (bf16_t*)out, lse1, g);
     MH_LAUNCH_CHECK("mh_nys_attn1_fwd");
     return MH_OK;
 }
 
-extern "C" int mh_nys_attn3_fwd(const void* qkv, const void* lm, float* av, float* lse3, int B, int h, int n_p, int m, int dh,
-                                float scale, mh_stream s) {
+int pick_splits(int BH, int ntiles);
+
+extern "C" int64_t mh_nys_attn3_ws_floats(int B, int h, int n_p) {
+    if (B <= 0 || h <= 0 || n_p < TR) return 0;
+    const int splits = pick_splits(B * h, n_p / TR);
+    return splits > 1 ? (int64_t)B * h * splits * A3_PART : 0;
+}
+
+extern "C" int mh_nys_attn3_fwd(const void* qkv, const void* lm, float* av, float* lse3, float* workspace, int64_t ws_floats, int B,
+                                int h, int n_p, int m, int dh, float scale, mh_stream s) {
     if (int e = check_geo("mh_nys_attn3_fwd", B, h, n_p, m, dh)) return e;
     if (B == 0) return MH_OK;
-    const Geo g{h, n_p, h * ND, scale, 0};
-    hipLaunchKernelGGL(nys_a3_fwd_kernel, dim3(B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv, (const bf16_t*)lm, av, lse3, g);
+    const Geo g{h, n_p, h * ND, scale, scale * LOG2E, 0};
+    const int ntiles = n_p / TR;
+    int splits = pick_splits(B * h, ntiles);
+    if (!workspace || ws_floats < (int64_t)B * h * splits * A3_PART) splits = 1;      // no room for partials: one workgroup per (b, h)
+    const int tpw = (ntiles + splits - 1) / splits;
+    splits = (ntiles + tpw - 1) / tpw;                                                 // no empty ranges
+    hipLaunchKernelGGL(nys_a3_fwd_kernel, dim3(splits, B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv, (const bf16_t*)lm, av,
+                       lse3, workspace, g, tpw);
     MH_LAUNCH_CHECK("mh_nys_attn3_fwd");
+    if (splits > 1) {
+        hipLaunchKernelGGL(nys_a3_combine_kernel, dim3(ND / 16, B * h), dim3(NM), 0, (hipStream_t)s, (const float*)workspace, av, lse3,
+                           splits);
+        MH_LAUNCH_CHECK("mh_nys_attn3_fwd(combine)");
+    }
     return MH_OK;
 }
 
-// splits: workgroups per (b, h) for the landmark-owner kernels (they flush with f32 atomics)
-static int pick_splits(int BH, int ntiles) {
+// splits: workgroups per (b, h) for the landmark-owner kernels (partials in a workspace, or f32 atomics)
+int pick_splits(int BH, int ntiles) {
+    static const char* env = getenv("MH_NYS_SPLITS");       // timing experiments: force the number of sequence ranges
+    if (env && atoi(env) > 0) return min(atoi(env), ntiles);
     int splits = 1;
     while (BH * splits < 512 && splits * 2 <= ntiles) splits *= 2;
     return splits;
@@ -653,8 +823,8 @@ extern "C" int mh_nys_attn1_bwd(const void* qkv, const void* lm, const void* w2,
                                 float scale, mh_stream s) {
     if (int e = check_geo("mh_nys_attn1_bwd", B, h, n_p, m, dh)) return e;
     if (B == 0) return MH_OK;
-    const Geo g{h, n_p, h * ND, scale, 0};
-    hipLaunchKernelGGL(nys_a1_bwd_dq_kernel, dim3(n_p / TR, B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv,
+    const Geo g{h, n_p, h * ND, scale, scale * LOG2E, 0};
+    hipLaunchKernelGGL(nys_a1_bwd_dq_kernel, dim3(pick_walkers(B * h, n_p), B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv,
                        (const bf16_t*)lm, (const bf16_t*)w2, (const bf16_t*)dout, lse1, delta1, (bf16_t*)dqkv, g);
     MH_LAUNCH_CHECK("mh_nys_attn1_bwd(dq)");
     const int ntiles = n_p / TR, splits = pick_splits(B * h, ntiles), tpw = (ntiles + splits - 1) / splits;
@@ -668,9 +838,9 @@ extern "C" int mh_nys_attn3_bwd(const void* qkv, const void* lm, const float* av
                                 void* dqkv, float* dlm, int B, int h, int n_p, int m, int dh, float scale, mh_stream s) {
     if (int e = check_geo("mh_nys_attn3_bwd", B, h, n_p, m, dh)) return e;
     if (B == 0) return MH_OK;
-    const Geo g{h, n_p, h * ND, scale, 0};
+    const Geo g{h, n_p, h * ND, scale, scale * LOG2E, 0};
     hipLaunchKernelGGL(nys_delta3_kernel, dim3(B * h), dim3(NM), 0, (hipStream_t)s, av, (const bf16_t*)dav, delta3);
-    hipLaunchKernelGGL(nys_a3_bwd_dkv_kernel, dim3(n_p / TR, B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv,
+    hipLaunchKernelGGL(nys_a3_bwd_dkv_kernel, dim3(pick_walkers(B * h, n_p), B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv,
                        (const bf16_t*)lm, (const float*)delta3, (const bf16_t*)dav, lse3, (bf16_t*)dqkv, g);
     MH_LAUNCH_CHECK("mh_nys_attn3_bwd(dkv)");
     const int ntiles = n_p / TR, splits = pick_splits(B * h, ntiles), tpw = (ntiles + splits - 1) / splits;

@@ -491,8 +491,10 @@ def nys_attn3_fwd(qkv, lm, heads: int, scale: float):
     av = torch.empty((B, heads, NYS_FUSED_M, NYS_FUSED_DH), device=qkv.device, dtype=torch.float32)
     lse3 = torch.empty((B, heads, NYS_FUSED_M), device=qkv.device, dtype=torch.float32)
     _nys_check("nys_attn3_fwd", B, heads, n_p, qkv=qkv, lm=lm)
+    nws = int(_lib.load().mh_nys_attn3_ws_floats(B, heads, n_p))     # partial results of the sequence ranges
+    ws = torch.empty((nws,), device=qkv.device, dtype=torch.float32) if nws else None
     _nys_launch("nys_a3_fwd_kernel", 2 * 2.0 * n_p * NYS_FUSED_M * NYS_FUSED_DH * B * heads,
-                lambda: _lib.call("mh_nys_attn3_fwd", _p(qkv), _p(lm), _p(av), _p(lse3), B, heads, n_p, NYS_FUSED_M,
+                lambda: _lib.call("mh_nys_attn3_fwd", _p(qkv), _p(lm), _p(av), _p(lse3), _p(ws), nws, B, heads, n_p, NYS_FUSED_M,
                                   NYS_FUSED_DH, scale, stream=_stream()))
     return av, lse3
 

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Fused Nystrom attention sides in isolation at the c2 geometry (B=16, h=8, n_p=4352, m=256, dh=64)."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mirror_amd import kernels as K
+dev, bf = "cuda", torch.bfloat16
+B, h, n_p, m, dh = 16, 8, 4352, 256, 64
+D = h * dh
+g = torch.Generator(device=dev).manual_seed(0)
+qkv = (torch.randn(B, n_p, 3 * D, device=dev, generator=g) * 0.5).to(bf)
+lm = (torch.randn(B, m, 2 * D, device=dev, generator=g) * 0.5).to(bf)
+w2 = (torch.randn(B, h, m, dh, device=dev, generator=g) * 0.1).to(bf)
+out = torch.zeros(B, n_p, D, device=dev, dtype=bf)
+dout = (torch.randn(B, n_p, D, device=dev, generator=g) * 0.1).to(bf)
+dav = (torch.randn(B, h, m, dh, device=dev, generator=g) * 0.1).to(bf)
+dqkv = torch.empty_like(qkv)
+dw2 = torch.zeros(B, h, m, dh, device=dev)
+dlm = torch.zeros(B, m, 2 * D, device=dev)
+scale = dh ** -0.5
+lse1 = K.nys_attn1_fwd(qkv, lm, w2, out, h, scale)
+av, lse3 = K.nys_attn3_fwd(qkv, lm, h, scale)
+unit = 2.0 * n_p * m * dh * B * h / 1e9     # one [n_p x m x dh] product over every (b, h), GFLOP
+
+
+def t(name, fn, products, reps=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    print(f"{name:28s} {ms * 1e3:8.1f} us   {products * unit / ms:7.1f} TF/s", flush=True)
+
+
+t("attn1 fwd", lambda: K.nys_attn1_fwd(qkv, lm, w2, out, h, scale), 2)
+t("attn1 fwd (accumulate)", lambda: K.nys_attn1_fwd(qkv, lm, w2, out, h, scale, accumulate=True), 2)
+t("attn3 fwd", lambda: K.nys_attn3_fwd(qkv, lm, h, scale), 2)
+t("attn1 bwd (dq + dw)", lambda: K.nys_attn1_bwd(qkv, lm, w2, dout, lse1, dqkv, dw2, dlm, h, scale), 7)
+t("attn3 bwd (delta+dkv+dql)", lambda: K.nys_attn3_bwd(qkv, lm, av, dav, lse3, dqkv, dlm, h, scale), 7)
