@@ -238,6 +238,10 @@ int mh_mse_masked_fwd(const void* pred, const void* tgt, const float* mask, floa
 int mh_mse_masked_bwd(const void* pred, const void* tgt, const float* mask, const float* acc, const float* g,
                       void* dpred, void* dtgt, int64_t rows, int D, int64_t rows_per_batch, int64_t tgt_bs, int dt_p, int dt_t,
                       int dt_dp, mh_stream s);
+/* Data feed (datasets/dataset_pretrain.py:150-167, `wsi_feature[sampled_indices]`): out[r, :] = src[row[r], :] for R rows of F
+ * elements; src is the bank of all slides' patch features back to back ([src_rows, F]); row holds GLOBAL row indices
+ * (slide offset + sampled index; clamped to the bank). */
+int mh_gather_rows(const void* src, const int64_t* row, void* out, int64_t R, int64_t F, int64_t src_rows, int dt, mh_stream s);
 /* Gradient of the WSI encoder output E [B, T, D] (f32), which three consumers read (models/mirror.py:684, :690, :700, :833):
  *   dE[b, t] = gfull[b, t] + alpha * x[b, t - 1] (t >= 1) + (t == 0 ? c[b] : 0)
  * gfull f32 [B, T, D], x [B, T-1, D] in dt_x, c f32 [B, D]; each may be NULL (taken as zero). */

@@ -421,6 +421,43 @@ extern "C" int mh_mask_apply_bwd(const void* dy, void* dx, const float* mask, fl
     return MH_OK;
 }
 
+// ------------------------------------------------------------------ data feed: fixed-N resampling (datasets/dataset_pretrain.py:150-167)
+// out[r, :] = src[row[r], :]: the gather behind `wsi_feature[sampled_indices]`, for a whole batch at once (row = global row
+// index into the bank of concatenated slides).  One wave per row, 16-byte pieces; rows are F * esz bytes.
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint4* __restrict__ src, const long* __restrict__ row, uint4* __restrict__ out,
+                                                          long R, int chunks, long src_rows) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long r = (long)blockIdx.x * 4 + wave; r < R; r += (long)gridDim.x * 4) {
+        long q = row[r];
+        q = q < 0 ? 0 : (q >= src_rows ? src_rows - 1 : q);       // never read outside the bank
+        for (int c = lane; c < chunks; c += 64) out[r * chunks + c] = src[q * chunks + c];
+    }
+}
+__global__ __launch_bounds__(256) void gather_rows_bytes_kernel(const unsigned char* __restrict__ src, const long* __restrict__ row,
+                                                                unsigned char* __restrict__ out, long R, long row_bytes, long src_rows) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long r = (long)blockIdx.x * 4 + wave; r < R; r += (long)gridDim.x * 4) {
+        long q = row[r];
+        q = q < 0 ? 0 : (q >= src_rows ? src_rows - 1 : q);
+        for (long c = lane; c < row_bytes; c += 64) out[r * row_bytes + c] = src[q * row_bytes + c];
+    }
+}
+
+extern "C" int mh_gather_rows(const void* src, const int64_t* row, void* out, int64_t R, int64_t F, int64_t src_rows, int dt, mh_stream s) {
+    if (R == 0 || F == 0) return MH_OK;
+    MH_REQUIRE(src_rows > 0, "mh_gather_rows: empty source bank");
+    const long row_bytes = F * mh_dt_size(dt);
+    dim3 grid((unsigned)min((long)mh_cdiv(R, 4), 16384L));
+    if (row_bytes % 16 == 0 && (((uintptr_t)src | (uintptr_t)out) & 15) == 0)
+        hipLaunchKernelGGL(gather_rows_kernel, grid, dim3(256), 0, (hipStream_t)s, (const uint4*)src, (const long*)row, (uint4*)out, (long)R,
+                           (int)(row_bytes / 16), (long)src_rows);
+    else
+        hipLaunchKernelGGL(gather_rows_bytes_kernel, grid, dim3(256), 0, (hipStream_t)s, (const unsigned char*)src, (const long*)row,
+                           (unsigned char*)out, (long)R, row_bytes, (long)src_rows);
+    MH_LAUNCH_CHECK("mh_gather_rows");
+    return MH_OK;
+}
+
 // ------------------------------------------------------------------ encoder-output gradient fan-in
 // one wave per (b, t) row; VEC: D % 4 == 0 and quad-aligned pointers
 template <typename TX, bool VEC>

@@ -15,7 +15,8 @@ from __future__ import annotations
 
 import math
 import os
-from typing import Dict, List, Optional, Sequence
+from collections import OrderedDict
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -276,3 +277,75 @@ class TrainEngine:
         self.grad.zero_()
         Fn.dropout_step_end()
         return tuple(x.detach() for x in losses)
+
+    # ------------------------------------------------------------------ validation (train_mirror.py:1382-1526)
+    LOSS_NAMES = ("loss", "alignment_loss", "wsi_retention_loss", "rna_retention_loss", "style_loss", "cluster_loss")
+
+    def validate(self, loader: Iterable[Tuple[torch.Tensor, torch.Tensor]], noise: Optional[Sequence[dict]] = None) -> "OrderedDict[str, float]":
+        """The reference's `validate()`: eval mode (dropout off, masking still on), no autograd, the six losses averaged
+        over the loader weighted by batch size (utils.AverageMeter.update(loss, B)) and, under DDP, averaged over ranks
+        (utils.reduce_tensor).  The running sums stay on the device: ONE host sync at the end instead of six `.item()`s
+        per batch.  `noise[i]` optionally pins the random draws of batch i (parity tests).  The module's train / eval
+        mode is restored on return (the reference leaves it in eval and flips it back in train_one_epoch)."""
+        was_training = self.model.training
+        self.model.eval()
+        acc = torch.zeros(7, device=self.device, dtype=torch.float64)        # 6 weighted sums + the sample count
+        try:
+            with torch.no_grad():
+                for i, (wsi, rna) in enumerate(loader):
+                    wsi = wsi.to(self.device, non_blocking=True)
+                    rna = rna.to(self.device, non_blocking=True)
+                    outs = self.model(wsi, rna, wsi_mask_ratio=self.wsi_mask_ratio, rna_mask_ratio=self.rna_mask_ratio,
+                                      noise=None if noise is None else noise[i])
+                    losses = self.loss_fn(*outs)
+                    b = float(wsi.shape[0])
+                    acc[:6] += torch.stack([x.detach().reshape(()) for x in losses]).double() * b
+                    acc[6] += b
+        finally:
+            self.model.train(was_training)
+        if self.world > 1:      # mean over ranks of every batch's loss == summed weighted sums / summed counts for equal batch sizes
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=self.pg)
+        vals = acc.cpu()
+        n = max(float(vals[6]), 1.0)
+        return OrderedDict((k, float(vals[j]) / n) for j, k in enumerate(self.LOSS_NAMES))
+
+    # ------------------------------------------------------------------ optimizer state (resume_checkpoint, train_mirror.py:772-780)
+    def _opt_order(self) -> List[Tuple[torch.nn.Parameter, int]]:
+        off = {id(p): o for p, o in zip(self.params, self.offsets)}
+        return [(p, off[id(p)]) for p in self.model.parameters() if id(p) in off]
+
+    def state_dict(self) -> dict:
+        """torch.optim.Adam-shaped state (what the reference checkpoints and `resume_checkpoint` reloads): per parameter, in
+        model.parameters() order, {step, exp_avg, exp_avg_sq} on the CPU."""
+        t = float(self._state[0].item())
+        state = {}
+        for i, (p, o) in enumerate(self._opt_order()):
+            n = p.numel()
+            state[i] = {"step": torch.tensor(t), "exp_avg": self.m[o:o + n].view(p.shape).cpu().clone(),
+                        "exp_avg_sq": self.v[o:o + n].view(p.shape).cpu().clone()}
+        group = {"lr": float(self.lr), "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "amsgrad": False,
+                 "params": list(range(len(state)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd: dict) -> None:
+        order = self._opt_order()
+        if len(sd["state"]) not in (0, len(order)):
+            raise ValueError(f"optimizer state has {len(sd['state'])} entries, the model has {len(order)} parameters")
+        t = 0.0
+        for i, (p, o) in enumerate(order):
+            st = sd["state"].get(i)
+            if st is None:
+                continue
+            n = p.numel()
+            self.m[o:o + n].copy_(st["exp_avg"].reshape(-1))
+            self.v[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+            t = float(st["step"])
+        if sd.get("param_groups"):
+            self.lr = float(sd["param_groups"][0].get("lr", self.lr))
+        b1, b2 = self.betas
+        self._state[:4].copy_(torch.tensor([t, 1.0 - b1 ** t, 1.0 - b2 ** t, float(self.lr)]))
+        self._state_lr = float(self.lr)
+        self.step_count = int(t)
+        self._graph, self._graph_warm = None, 0          # a captured step is still valid, but re-capture keeps this simple
+        self.sync_shadows()
+

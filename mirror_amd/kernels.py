@@ -570,6 +570,22 @@ def ppeg_wgrad(x, dout, dmerged, dbsum, S: int) -> None:
     _lib.call("mh_ppeg_wgrad", _p(x), _p(dout), _p(dmerged), _p(dbsum), B, S, D, dt(x), dt(dout), stream=_stream())
 
 
+# ----------------------------------------------------------------------------- data feed
+def gather_rows(src: torch.Tensor, rows: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[r] = src[rows[r]] for a [S, F] bank and int64 row indices of any shape (result: rows.shape + (F,))."""
+    _chk(src, rows)
+    if src.dim() != 2 or not src.is_contiguous():
+        raise MirrorHipError("gather_rows: the bank must be a contiguous [rows, F] tensor")
+    if rows.dtype != torch.int64 or not rows.is_contiguous():
+        raise MirrorHipError("gather_rows: row indices must be contiguous int64")
+    R, Fd = rows.numel(), src.shape[1]
+    if out is None:
+        out = torch.empty(tuple(rows.shape) + (Fd,), device=src.device, dtype=src.dtype)
+    assert out.is_contiguous() and out.numel() == R * Fd and out.dtype == src.dtype
+    _lib.call("mh_gather_rows", _p(src), _p(rows), _p(out), R, Fd, src.shape[0], dt(src), stream=_stream())
+    return out
+
+
 # ----------------------------------------------------------------------------- masking
 def rank_mask(noise: torch.Tensor, len_keep: int) -> torch.Tensor:
     _chk(noise)

@@ -274,6 +274,17 @@ def classifier_forward(sd: SD, cfg: Cfg, wsi: Tensor, rna: Optional[Tensor], fus
     return _linear(fused, sd, "head")
 
 
+def dataset_getitem(wsi_feature: Tensor, rna_row, num_tokens: int):
+    """TCGAWSIRNAPretrainDataset.__getitem__, datasets/dataset_pretrain.py:150-167: sample `num_tokens` patch rows with numpy's
+    GLOBAL RNG (`np.random.choice`, with replacement only when the slide is shorter than num_tokens), gather them, and
+    return the slide's RNA row as float32.  Also returns the drawn indices."""
+    import numpy as np
+    n = wsi_feature.shape[0]
+    is_replace = not n >= num_tokens
+    idx = np.random.choice(n, num_tokens, replace=is_replace)
+    return wsi_feature[idx], torch.tensor(np.asarray(rna_row), dtype=torch.float32), idx
+
+
 def clip_loss(w: Tensor, r: Tensor, scale: Tensor) -> Tensor:
     """ClipLoss.forward, losses/mirror_loss.py:37-52."""
     lab = torch.arange(w.shape[0])

@@ -176,3 +176,45 @@ def test_grad_clip_and_accumulation_match_torch():
         num += float((p.detach() - q.detach()).double().pow(2).sum())
         den += float((p.detach() - init[k]).double().pow(2).sum())
     assert num ** 0.5 < 0.05 * den ** 0.5, (num, den)
+
+
+def test_validate_matches_reference_loop_and_state_roundtrip(tmp_path):
+    """validate() == the reference loop (eval mode, no grad, batch-size-weighted means), and the
+    Adam state survives CheckpointSaver -> resume_checkpoint (train_mirror.py:772-780, :1053-1062)."""
+    from mirror_amd.checkpoint import CheckpointSaver, resume_checkpoint
+    from mirror_amd.engine import TrainEngine
+    from mirror_amd.losses import MIRRORLoss
+    model = _make().train()                      # train mode going in: validate() must switch to eval and switch back
+    eng = TrainEngine(model, MIRRORLoss(), lr=1e-3, precision="fp32", graph=False)
+    batches, noises = [], []
+    for i, b in enumerate((4, 4, 2)):           # ragged last batch: weights matter
+        wsi, rna, noise = _batch(b, 50 + i)
+        batches.append((wsi.cpu(), rna.cpu()))
+        noises.append(noise)
+    got = eng.validate(batches, noise=noises)
+    assert model.training                        # mode restored
+    model.eval()
+    want = torch.zeros(6, dtype=torch.float64)
+    with torch.no_grad():
+        for (wsi, rna), noise in zip(batches, noises):
+            ls = MIRRORLoss()(*model(wsi.cuda(), rna.cuda(), noise=noise))
+            want += torch.stack([x.double().cpu() for x in ls]) * wsi.shape[0]
+    want /= 10                                   # the model stays in eval from here on: dropout off keeps the two runs comparable
+    assert list(got) == ["loss", "alignment_loss", "wsi_retention_loss", "rna_retention_loss", "style_loss", "cluster_loss"]
+    assert torch.allclose(torch.tensor(list(got.values()), dtype=torch.float64), want, rtol=1e-6), (got, want)
+    # two steps, checkpoint, two more steps  ==  resume into a fresh engine and take the same two steps
+    for i in range(2):
+        eng.step(*_batch(4, 70 + i))
+    saver = CheckpointSaver(model, eng, checkpoint_dir=str(tmp_path), max_history=1)
+    saver.save_checkpoint(0, metric=float(got["loss"]))
+    tail = [_batch(4, 80 + i) for i in range(2)]
+    for b in tail:
+        eng.step(*b)
+    model2 = _make(seed=5)
+    eng2 = TrainEngine(model2, MIRRORLoss(), lr=1e-3, precision="fp32", graph=False)
+    assert resume_checkpoint(model2, os.path.join(tmp_path, "last.pth.tar"), eng2) == 1
+    assert eng2.step_count == 2
+    for b in tail:
+        eng2.step(*b)
+    for (k, p), (_, q) in zip(model.named_parameters(), model2.named_parameters()):
+        assert torch.allclose(p, q, rtol=1e-5, atol=1e-7), k

@@ -91,3 +91,38 @@ def test_bucket_plan_covers_arena_once():
     padded = sum((s + 7) // 8 * 8 for s in sizes)
     assert buckets[-1][1] == padded
     assert all(b[1] - b[0] >= 1024 for b in buckets[:-1])
+
+
+def test_checkpoint_saver_keeps_best_k(tmp_path):
+    """Best-k selection of train_mirror.py:1053-1062 (timm CheckpointSaver semantics, decreasing loss metric)."""
+    from mirror_amd.checkpoint import CheckpointSaver, resume_checkpoint
+    model = torch.nn.Linear(3, 2)
+    saver = CheckpointSaver(model, checkpoint_dir=str(tmp_path), decreasing=True, max_history=2)
+    seen = []
+    for epoch, metric in enumerate([5.0, 3.0, 4.0, 1.0, 2.0]):
+        with torch.no_grad():
+            model.weight.fill_(float(epoch))
+        seen.append(saver.save_checkpoint(epoch, metric))
+    assert seen == [(5.0, 0), (3.0, 1), (3.0, 1), (1.0, 3), (1.0, 3)]
+    kept = sorted(f for f in os.listdir(tmp_path) if f.startswith("checkpoint-"))
+    assert kept == ["checkpoint-3.pth.tar", "checkpoint-4.pth.tar"]             # the two lowest losses: epochs 3 and 4
+    assert [m for _, m in saver.files] == [1.0, 2.0]
+    other = torch.nn.Linear(3, 2)
+    assert resume_checkpoint(other, os.path.join(tmp_path, "model_best.pth.tar")) == 4
+    assert float(other.weight[0, 0]) == 3.0
+    assert resume_checkpoint(other, os.path.join(tmp_path, "last.pth.tar")) == 5
+    assert float(other.weight[0, 0]) == 4.0
+
+
+def test_sample_indices_follows_the_reference_replace_rule():
+    """datasets/dataset_pretrain.py:157-161: replace only when the slide is shorter than num_wsi_feature_tokens."""
+    from mirror_amd.data import sample_indices
+    g = torch.Generator().manual_seed(3)
+    long = sample_indices(50, 20, g)
+    assert long.shape == (20,) and len(set(long.tolist())) == 20 and int(long.max()) < 50 and int(long.min()) >= 0
+    exact = sample_indices(20, 20, g)
+    assert sorted(exact.tolist()) == list(range(20))
+    short = sample_indices(5, 20, g)
+    assert short.shape == (20,) and int(short.max()) < 5 and len(set(short.tolist())) <= 5
+    with pytest.raises(ValueError):
+        sample_indices(0, 4, g)

@@ -867,3 +867,40 @@ def test_nys_fused_rejects_other_geometry():
     assert not K.nys_fused_ok(qkv, 1, 128)
     with pytest.raises(MirrorHipError):
         K.nys_attn3_fwd(qkv, torch.zeros((1, 128, 64), device=DEV, dtype=bf), 1, 1.0)
+
+
+@pytest.mark.parametrize("dtype,Fd", [(torch.bfloat16, 1024), (torch.float32, 8), (torch.bfloat16, 7)])
+def test_gather_rows_and_device_feed(dtype, Fd):
+    """batched `wsi_feature[sampled_indices]` (datasets/dataset_pretrain.py:162) — bit-exact copies."""
+    gen = g(81)
+    bank = torch.randn(300, Fd, generator=gen).to(dtype)
+    rows = torch.randint(0, 300, (3, 41), generator=gen)
+    out = K.gather_rows(bank.to(DEV), rows.to(DEV))
+    assert out.shape == (3, 41, Fd) and torch.equal(out.cpu(), bank[rows])
+
+
+def test_device_slide_bank_matches_reference_items():
+    """The device feed reproduces the reference dataset's items when it is given the reference's own index draws
+    (tests/golden/golden_datafeed.npz), and draws by the same replace rule on its own."""
+    import numpy as np
+    import os
+    from mirror_amd.data import DeviceSlideBank
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_datafeed.npz"))
+    N = int(z["num_tokens"])
+    slides = [torch.from_numpy(z[f"slide/{k}"]) for k in range(3)]
+    bank = DeviceSlideBank(slides, torch.from_numpy(z["rna"]), N, device=DEV)
+    ids = [int(k) for k in z["order"]]
+    rows = torch.stack([torch.from_numpy(z[f"out/{j}/idx"]).long() + int(bank.offsets[k]) for j, k in enumerate(ids)])
+    wsi, rna = bank.batch(ids, rows=rows)
+    for j in range(len(ids)):
+        assert torch.equal(wsi[j].cpu(), torch.from_numpy(z[f"out/{j}/wsi"]))
+        assert torch.equal(rna[j].cpu(), torch.from_numpy(z[f"out/{j}/rna"]))
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    wsi2, _ = bank.batch([0, 1, 2], generator=gen)
+    drawn = bank.draw([0, 1, 2], generator=gen).cpu()
+    assert wsi2.shape == (3, N, slides[0].shape[1])
+    for j, k in enumerate([0, 1, 2]):
+        local = drawn[j] - int(bank.offsets[k])
+        assert int(local.min()) >= 0 and int(local.max()) < slides[k].shape[0]
+        if slides[k].shape[0] >= N:
+            assert len(set(local.tolist())) == N

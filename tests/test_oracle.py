@@ -117,3 +117,19 @@ def test_classifier_restatement_matches_reference():
         if fusion == "add":
             np.testing.assert_allclose(O.classifier_forward(sd, CLS_CFG, wsi, None, fusion).numpy(), z["pred/add_wsi_only"],
                                        rtol=1e-5, atol=1e-6)
+
+
+def test_dataset_getitem_restatement_matches_reference():
+    """the fixed-N resampling of TCGAWSIRNAPretrainDataset.__getitem__ recorded from the reference
+    (tools/make_golden.py gen_datafeed), numpy's global RNG seeded the same way."""
+    z = np.load(os.path.join(GOLDEN, "golden_datafeed.npz"))
+    N = int(z["num_tokens"])
+    slides = [torch.from_numpy(z[f"slide/{k}"]) for k in range(3)]
+    rna = z["rna"]
+    np.random.seed(int(z["seed"]))
+    for j, k in enumerate(z["order"]):
+        w, r, idx = O.dataset_getitem(slides[int(k)], rna[int(k)].astype(np.float64), N)
+        assert np.array_equal(idx, z[f"out/{j}/idx"])
+        assert np.array_equal(w.numpy(), z[f"out/{j}/wsi"]) and np.array_equal(r.numpy(), z[f"out/{j}/rna"])
+        n = slides[int(k)].shape[0]
+        assert (len(set(idx.tolist())) == N) == (n >= N) or n < N      # without replacement <=> no duplicates when long enough

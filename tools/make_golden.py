@@ -212,6 +212,48 @@ def gen_classifier(mod, out_dir, used):
     print(f"classifier: pred(concat)[0]={rec['pred/concat'][0]} -> {path} ({os.path.getsize(path)/1024:.0f} KiB)")
 
 
+def gen_datafeed(out_dir):
+    """Data feed: the reference dataset's __getitem__ (datasets/dataset_pretrain.py:150-167) on a tiny
+    on-disk bank: a long slide (sampled without replacement) and a short one (with replacement), numpy's global RNG seeded."""
+    import importlib.util
+    import tempfile
+    import pandas as pd
+    from oracle import mirror_oracle as O
+    spec = importlib.util.spec_from_file_location("ref_dataset_pretrain", os.path.join(REF, "datasets", "dataset_pretrain.py"))
+    dmod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dmod)
+    g = torch.Generator().manual_seed(99)
+    ids = ["TCGA-AA-0001-01Z-00-DX1", "TCGA-BB-0002-01Z-00-DX1", "TCGA-CC-0003-01Z-00-DX1"]
+    lens, Fd, G, N = [37, 5, 12], 8, 6, 12
+    slides = [torch.randn(n, Fd, generator=g) for n in lens]
+    rna = torch.randn(len(ids), G, generator=g)
+    rec = {"num_tokens": np.array(N), "seed": np.array(2024)}
+    with tempfile.TemporaryDirectory() as d:
+        fdir = os.path.join(d, "feat")
+        os.makedirs(fdir)
+        for sid, sl in zip(ids, slides):
+            torch.save(sl, os.path.join(fdir, sid + ".pt"))
+        pd.DataFrame(rna.numpy().astype(np.float64), index=[s[:15] for s in ids], columns=[f"g{j}" for j in range(G)]).to_csv(os.path.join(d, "rna.csv"))
+        ds = dmod.TCGAWSIRNAPretrainDataset(fdir, os.path.join(d, "rna.csv"), N)
+        order = list(ds.used_feature_ids)                 # os.listdir order
+        np.random.seed(2024)
+        items = [ds[i] for i in range(len(ds))] + [ds[0]]
+    by_id = dict(zip(ids, range(len(ids))))
+    rec["order"] = np.array([by_id[s] for s in order] + [by_id[order[0]]])
+    np.random.seed(2024)
+    for j, (w, r) in enumerate(items):
+        k = int(rec["order"][j])
+        ow, orr, idx = O.dataset_getitem(slides[k], rna[k].double().numpy(), N)
+        assert torch.equal(ow, w) and torch.equal(orr, r), "oracle restatement differs from the reference dataset"
+        rec[f"out/{j}/wsi"], rec[f"out/{j}/rna"], rec[f"out/{j}/idx"] = w.numpy(), r.numpy(), idx
+    for k, sl in enumerate(slides):
+        rec[f"slide/{k}"] = sl.numpy()
+    rec["rna"] = rna.numpy()
+    path = os.path.join(out_dir, "golden_datafeed.npz")
+    np.savez_compressed(path, **rec)
+    print(f"datafeed: {len(items)} items, lens {lens}, N={N} -> {path} ({os.path.getsize(path)/1024:.0f} KiB)")
+
+
 def gen_losses(ref_losses, ClipLoss, out_dir):
     g = torch.Generator().manual_seed(2024)
     b, n, d, p, lat = 8, 16, 32, 30, 12
@@ -270,6 +312,10 @@ def main():
     # res_conv at n_p=256: error O(10) vs an explicit sum; forward and input-gradient are fine).  Recording the
     # reference with oneDNN off uses ATen's native convolution, which agrees with the explicit sum.
     torch.backends.mkldnn.enabled = False
+    if not a.only or "datafeed" in a.only.split(","):
+        gen_datafeed(a.out)
+    if a.only == "datafeed":
+        return
     ref_losses, ClipLoss = load_reference_losses()
     gen_losses(ref_losses, ClipLoss, a.out)
     mod, used = load_reference_model_module(a.use_installed)
