@@ -101,6 +101,17 @@ int mh_softmax_fwd(const void* x, void* y, int64_t rows, int cols, int64_t ldx, 
 int mh_softmax_bwd(const void* y, const void* dy, void* dx, int64_t rows, int cols, int64_t ldy, int64_t lddy,
                    int64_t lddx, int dt_y, int dt_dy, int dt_dx, mh_stream s);
 
+/* Key-padding-mask variants ([3P] NystromAttention.forward(x, mask=...): `sim.masked_fill_(~(rowmask & colmask), -finfo.max)`
+ * before each of the three softmaxes; BASELINE config 4).  x, y: contiguous [batches, h, R, cols]; rowmask [batches, R] and
+ * colmask [batches, cols] hold 0 / 1 floats.  A fully masked row comes out uniform, as in the package.  bwd: dx = 0 at
+ * filled entries, y (dy - sum y dy) elsewhere; in place on dy allowed. */
+int mh_softmax_masked_fwd(const void* x, void* y, const float* rowmask, const float* colmask, int64_t batches, int h, int R,
+                          int cols, int dt_x, int dt_y, mh_stream s);
+int mh_softmax_masked_bwd(const void* y, const void* dy, void* dx, const float* rowmask, const float* colmask, int64_t batches,
+                          int h, int R, int cols, int dt_y, int dt_d, mh_stream s);
+/* y[r, :] = x[r, :] * scale[r] (masked rows zeroed before the bias-free to_qkv; masked-mean landmarks = sum / (count + 1e-8)) */
+int mh_row_scale(const void* x, const float* scale, void* y, int64_t rows, int D, int dt, mh_stream s);
+
 /* ---------------------------------------------------------------- Nystrom pieces ([3P], called at models/mirror.py:312)
  * qkv: [B, n_p, 3D] (q | k | v column blocks, heads are dh-wide column slices).
  * landmarks: lm[b, j, c] = mean_{t<l} qkv[b, j*l+t, c], c < 2D  -> lm [B, m, 2D]            */

@@ -87,6 +87,9 @@ _SIGS = {
     "mh_mse_masked_bwd": [P, P, P, P, P, P, P, L, I, L, L, I, I, I],
     "mh_fanout_bwd": [P, P, F, P, P, I, I, I, I],
     "mh_gather_rows": [P, P, P, L, L, L, I],
+    "mh_softmax_masked_fwd": [P, P, P, P, L, I, I, I, I, I],
+    "mh_softmax_masked_bwd": [P, P, P, P, P, L, I, I, I, I, I],
+    "mh_row_scale": [P, P, P, L, I, I],
     "mh_kl_fwd": [P, P, P, L, F],
     "mh_kl_bwd": [P, P, P, P, P, L, F],
     "mh_symkl_fwd": [P, P, P, I, I, F],

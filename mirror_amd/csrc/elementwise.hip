@@ -421,6 +421,33 @@ extern "C" int mh_mask_apply_bwd(const void* dy, void* dx, const float* mask, fl
     return MH_OK;
 }
 
+// ------------------------------------------------------------------ per-row scale (key-padding mask: zeroed rows, masked-mean landmarks)
+// y[r, :] = x[r, :] * s[r]; one wave per row
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void row_scale_kernel(const T* x, const float* __restrict__ sc, T* y, long rows, int D) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
+        const float f = sc[r];
+        if (VEC) {
+            for (int c = 4 * lane; c < D; c += 256) st4(y + r * D + c, ld4(x + r * D + c) * f);
+        } else {
+            for (int c = lane; c < D; c += 64) stf(y + r * D + c, ldf(x + r * D + c) * f);
+        }
+    }
+}
+extern "C" int mh_row_scale(const void* x, const float* scale, void* y, int64_t rows, int D, int dt, mh_stream s) {
+    if (rows == 0 || D == 0) return MH_OK;
+    dim3 grid((unsigned)min((long)mh_cdiv(rows, 4), 16384L));
+    const bool vec = D % 4 == 0 && mh_quad_ok(x, mh_dt_size(dt)) && mh_quad_ok(y, mh_dt_size(dt));
+#define RS_(T)                                                                                                                 \
+    if (vec) hipLaunchKernelGGL((row_scale_kernel<T, true>), grid, dim3(256), 0, (hipStream_t)s, (const T*)x, scale, (T*)y, (long)rows, D); \
+    else hipLaunchKernelGGL((row_scale_kernel<T, false>), grid, dim3(256), 0, (hipStream_t)s, (const T*)x, scale, (T*)y, (long)rows, D)
+    if (dt == MH_F32) { RS_(float); } else { RS_(bf16_t); }
+#undef RS_
+    MH_LAUNCH_CHECK("mh_row_scale");
+    return MH_OK;
+}
+
 // ------------------------------------------------------------------ data feed: fixed-N resampling (datasets/dataset_pretrain.py:150-167)
 // out[r, :] = src[row[r], :]: the gather behind `wsi_feature[sampled_indices]`, for a whole batch at once (row = global row
 // index into the bank of concatenated slides).  One wave per row, 16-byte pieces; rows are F * esz bytes.

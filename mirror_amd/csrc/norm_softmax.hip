@@ -532,6 +532,85 @@ __global__ __launch_bounds__(256) void softmax_bwd_vec_kernel(const TY* y, const
     }
 }
 
+// ---- key-padding-mask variants ([3P] NystromAttention.forward with `mask`: sim.masked_fill_(~(rowmask & colmask), -finfo.max)
+// before the softmax).  x is [batches, h, R, C]; rowmask [batches, R] and colmask [batches, C] hold 0 / 1 floats.  An entry whose
+// row or column is masked out is replaced by -FLT_MAX, so a fully masked row comes out uniform (1 / C), exactly like the
+// package.  One 256-thread block per row (c4 parity path: not tuned).
+template <typename TX, typename TY>
+__global__ __launch_bounds__(256) void softmax_masked_fwd_kernel(const TX* x, TY* y, const float* __restrict__ rowmask,
+                                                                 const float* __restrict__ colmask, long rows, int cols, long rows_per_batch,
+                                                                 int R) {
+    __shared__ float red[4];
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const long b = row / rows_per_batch;
+        const bool rv = rowmask[b * R + (row % R)] != 0.f;
+        const float* cm = colmask + b * cols;
+        const TX* xr = x + row * cols;
+        TY* yr = y + row * cols;
+        float mx = -3.402823466e38f;
+        for (int c = threadIdx.x; c < cols; c += 256) mx = fmaxf(mx, (rv && cm[c] != 0.f) ? ldf(xr + c) : -3.402823466e38f);
+        mx = block_max256(mx, red);
+        float sum = 0.f;
+        for (int c = threadIdx.x; c < cols; c += 256) sum += __expf(((rv && cm[c] != 0.f) ? ldf(xr + c) : -3.402823466e38f) - mx);
+        sum = block_sum256(sum, red);
+        const float inv = 1.f / sum;
+        __syncthreads();       // in place: every read of the row is done
+        for (int c = threadIdx.x; c < cols; c += 256) stf(yr + c, __expf(((rv && cm[c] != 0.f) ? ldf(xr + c) : -3.402823466e38f) - mx) * inv);
+    }
+}
+// dx = filled ? 0 : y (dy - sum_c y dy)   (softmax backward followed by masked_fill's backward)
+template <typename TY, typename TD>
+__global__ __launch_bounds__(256) void softmax_masked_bwd_kernel(const TY* y, const TD* dy, TD* dx, const float* __restrict__ rowmask,
+                                                                 const float* __restrict__ colmask, long rows, int cols, long rows_per_batch,
+                                                                 int R) {
+    __shared__ float red[4];
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const long b = row / rows_per_batch;
+        const bool rv = rowmask[b * R + (row % R)] != 0.f;
+        const float* cm = colmask + b * cols;
+        const TY* yr = y + row * cols;
+        const TD* gr = dy + row * cols;
+        TD* dr = dx + row * cols;
+        float dot = 0.f;
+        for (int c = threadIdx.x; c < cols; c += 256) dot += ldf(yr + c) * ldf(gr + c);
+        dot = block_sum256(dot, red);
+        __syncthreads();
+        for (int c = threadIdx.x; c < cols; c += 256) stf(dr + c, (rv && cm[c] != 0.f) ? ldf(yr + c) * (ldf(gr + c) - dot) : 0.f);
+    }
+}
+
+extern "C" int mh_softmax_masked_fwd(const void* x, void* y, const float* rowmask, const float* colmask, int64_t batches, int h, int R,
+                                     int cols, int dt_x, int dt_y, mh_stream s) {
+    MH_REQUIRE(cols >= 1 && R >= 1 && h >= 1, "mh_softmax_masked_fwd: bad shape");
+    const long rows = (long)batches * h * R;
+    if (rows == 0) return MH_OK;
+    dim3 grid((unsigned)min(rows, 65535L));
+#define SMF_(TX, TY) hipLaunchKernelGGL((softmax_masked_fwd_kernel<TX, TY>), grid, dim3(256), 0, (hipStream_t)s, (const TX*)x, (TY*)y, rowmask, colmask, rows, cols, (long)h * R, R)
+    if (dt_x == MH_F32 && dt_y == MH_F32) { SMF_(float, float); }
+    else if (dt_x == MH_F32) { SMF_(float, bf16_t); }
+    else if (dt_y == MH_F32) { SMF_(bf16_t, float); }
+    else { SMF_(bf16_t, bf16_t); }
+#undef SMF_
+    MH_LAUNCH_CHECK("mh_softmax_masked_fwd");
+    return MH_OK;
+}
+
+extern "C" int mh_softmax_masked_bwd(const void* y, const void* dy, void* dx, const float* rowmask, const float* colmask, int64_t batches,
+                                     int h, int R, int cols, int dt_y, int dt_d, mh_stream s) {
+    MH_REQUIRE(cols >= 1 && R >= 1 && h >= 1, "mh_softmax_masked_bwd: bad shape");
+    const long rows = (long)batches * h * R;
+    if (rows == 0) return MH_OK;
+    dim3 grid((unsigned)min(rows, 65535L));
+#define SMB_(TY, TD) hipLaunchKernelGGL((softmax_masked_bwd_kernel<TY, TD>), grid, dim3(256), 0, (hipStream_t)s, (const TY*)y, (const TD*)dy, (TD*)dx, rowmask, colmask, rows, cols, (long)h * R, R)
+    if (dt_y == MH_F32 && dt_d == MH_F32) { SMB_(float, float); }
+    else if (dt_y == MH_F32) { SMB_(float, bf16_t); }
+    else if (dt_d == MH_F32) { SMB_(bf16_t, float); }
+    else { SMB_(bf16_t, bf16_t); }
+#undef SMB_
+    MH_LAUNCH_CHECK("mh_softmax_masked_bwd");
+    return MH_OK;
+}
+
 extern "C" int mh_softmax_fwd(const void* x, void* y, int64_t rows, int cols, int64_t ldx, int64_t ldy, int dt_x,
                               int dt_y, mh_stream s) {
     MH_REQUIRE(cols >= 1, "mh_softmax_fwd: cols=%d", cols);

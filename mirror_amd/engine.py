@@ -198,7 +198,8 @@ class TrainEngine:
         self._pending = [b[2] for b in self.buckets]
 
     # ------------------------------------------------------------------ one optimizer step
-    def step(self, wsi: torch.Tensor, rna: torch.Tensor, noise: Optional[dict] = None):
+    def step(self, wsi: torch.Tensor, rna: torch.Tensor, noise: Optional[dict] = None,
+             wsi_key_padding_mask: Optional[torch.Tensor] = None):
         """prototype renorm -> forward -> MIRRORLoss -> backward (+ overlapped all-reduce) -> Adam -> clamp.
         Returns the 6 loss tensors (device scalars; nothing is synchronised here).  Without injected `noise` the step is
         captured into a HIP graph after two eager steps and replayed from then on (the returned tensors are then the
@@ -206,8 +207,8 @@ class TrainEngine:
         if self.lr != self._state_lr:                       # lr schedulers write engine.lr: publish it to the device state
             self._state[3:4].fill_(float(self.lr))
             self._state_lr = float(self.lr)
-        if not self._use_graph or noise is not None:
-            return self._step_eager(wsi, rna, noise)
+        if not self._use_graph or noise is not None or wsi_key_padding_mask is not None:
+            return self._step_eager(wsi, rna, noise, wsi_key_padding_mask)       # config-4 batches (padded slides + mask) run eagerly
         if self._graph is not None:
             if wsi.shape != self._g_in[0].shape or rna.shape != self._g_in[1].shape or wsi.dtype != self._g_in[0].dtype:
                 return self._step_eager(wsi, rna, None)     # a ragged last batch runs eagerly
@@ -235,7 +236,8 @@ class TrainEngine:
         self._graph = g
         return self.step(wsi, rna)
 
-    def _step_eager(self, wsi: torch.Tensor, rna: torch.Tensor, noise: Optional[dict]):
+    def _step_eager(self, wsi: torch.Tensor, rna: torch.Tensor, noise: Optional[dict],
+                    wsi_key_padding_mask: Optional[torch.Tensor] = None):
         Fn.dropout_step_begin(self.device)
         Fn._res_grads.clear()
         if self._proto is not None:
@@ -243,7 +245,8 @@ class TrainEngine:
             K.rownorm_(w.data)
             if self.shadow is not None:
                 K.cast(w.data, bf16, out=Fn.shadow(w, POLICIES[self.precision]))
-        outs = self.model(wsi, rna, wsi_mask_ratio=self.wsi_mask_ratio, rna_mask_ratio=self.rna_mask_ratio, noise=noise)
+        kw = {} if wsi_key_padding_mask is None else {"wsi_key_padding_mask": wsi_key_padding_mask}
+        outs = self.model(wsi, rna, wsi_mask_ratio=self.wsi_mask_ratio, rna_mask_ratio=self.rna_mask_ratio, noise=noise, **kw)
         losses = self.loss_fn(*outs)
         Fn.set_grad_sink(self)
         try:

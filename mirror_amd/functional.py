@@ -526,7 +526,11 @@ class NystromCoreFn(Function):
     (a1 @ a2inv) @ (a3 @ v), 2 m^2 D instead of 2 n_p m^2 h flops)."""
 
     @staticmethod
-    def forward(ctx, qkv, res_w, heads, l, iters, prec):
+    def forward(ctx, qkv, res_w, heads, l, iters, prec, kmask=None):
+        """kmask: None, or the package's key-padding mask prepared by TransLayer as (rows [B, n_p], landmarks [B, m],
+        landmark scale [B, m]) float tensors: rows of qkv that are masked out are already zero (the caller zeroes the
+        LayerNorm output in front of the bias-free to_qkv); here the landmark means become masked means and the three
+        similarity matrices are masked_fill'ed before their softmax."""
         qkv = qkv.contiguous()
         Bn, n_p, D3 = qkv.shape
         D, h = D3 // 3, heads
@@ -535,9 +539,15 @@ class NystromCoreFn(Function):
         scale = dh ** -0.5
         q, k, v = (_heads(qkv, i, 3, h) for i in range(3))
         lm = K.landmark_fwd(qkv, l)
+        if kmask is not None:
+            mrow, mlm, lscale = kmask
+            lm = K.row_scale(lm, lscale)                       # sum over the group / (valid count + 1e-8)
         ql, kl = _heads(lm, 0, 2, h), _heads(lm, 1, 2, h)
         a2 = K.gemm(ql, kl.transpose(-1, -2), alpha=scale, mma=mma, out_dtype=f32)      # [B,h,m,m]
-        K.softmax_fwd(a2, a2)
+        if kmask is None:
+            K.softmax_fwd(a2, a2)
+        else:
+            K.softmax_masked_fwd(a2, mlm, mlm, a2)
         sd = f32 if pm == MH_F32 else bf16
         m_l = a2.shape[-1]
         chain = pm == MH_BF16 and m_l == K.PINV_CHAIN_M    # whole iteration in one launch (pinv_panel.hip)
@@ -556,15 +566,19 @@ class NystromCoreFn(Function):
             with torch.cuda.stream(side):
                 K.pinv_chain_fwd(xt, chain_saved, zfT, iters)
             saved = [(xt, chain_saved, z0)]
-        fused = K.nys_fused_ok(qkv, h, m_l) and lm.dtype == bf16      # nystrom_fused.hip: sim1 / sim3 never reach HBM
+        fused = kmask is None and K.nys_fused_ok(qkv, h, m_l) and lm.dtype == bf16      # nystrom_fused.hip: sim1 / sim3 never reach HBM
         lse1 = lse3 = a1 = a3 = None
         if fused:
             av, lse3 = K.nys_attn3_fwd(qkv, lm, h, scale)                                # [B,h,m,dh] f32
         else:
             a1 = K.gemm(q, kl.transpose(-1, -2), alpha=scale, mma=mma, out_dtype=f32)   # [B,h,n_p,m]
-            a1 = K.softmax_fwd(a1, a1 if A == f32 else None, out_dtype=A)
             a3 = K.gemm(ql, k.transpose(-1, -2), alpha=scale, mma=mma, out_dtype=f32)   # [B,h,m,n_p]
-            a3 = K.softmax_fwd(a3, a3 if A == f32 else None, out_dtype=A)
+            if kmask is None:
+                a1 = K.softmax_fwd(a1, a1 if A == f32 else None, out_dtype=A)
+                a3 = K.softmax_fwd(a3, a3 if A == f32 else None, out_dtype=A)
+            else:
+                a1 = K.softmax_masked_fwd(a1, mrow, mlm, a1 if A == f32 else None, out_dtype=A)
+                a3 = K.softmax_masked_fwd(a3, mlm, mrow, a3 if A == f32 else None, out_dtype=A)
         if not chain:
             zf, saved, st = pinv_forward(a2, iters, pm, sd)
         if not fused:
@@ -587,12 +601,17 @@ class NystromCoreFn(Function):
                               *[t for it in saved for t in it])
         ctx.cfg = (heads, l, prec)
         ctx.chain = (chain, iters, fused)
+        ctx.kmask = kmask
         return out
 
     @staticmethod
     def backward(ctx, dout):
         qkv, res_w, lm, a1, a2, a3, av, w2, st, zf, *flat = ctx.saved_tensors
         chain, iters, fused = ctx.chain
+        kmask = ctx.kmask
+        if kmask is not None:
+            mrow, mlm, lscale = kmask
+        sm_bwd = (lambda y, dy, rm, cm: K.softmax_bwd(y, dy)) if kmask is None else K.softmax_masked_bwd
         if chain:
             zf = zf.transpose(-1, -2)       # saved as the column-major chain output
         saved = None if chain else [tuple(flat[i:i + 4]) for i in range(0, len(flat), 4)]
@@ -640,7 +659,7 @@ class NystromCoreFn(Function):
             with torch.cuda.stream(side):
                 K.pinv_chain_bwd(xb, chain_saved, dzb, work, dS2, dz0, iters)
                 K.pinv_z0_bwd(a2, z0, dz0, st, dS2)
-                K.softmax_bwd(a2, dS2)
+                sm_bwd(a2, dS2, mlm if kmask else None, mlm if kmask else None)
         K.resconv_wgrad(qkv[..., 2 * D:], dout, dres, h)
         dAV = K.gemm(tr(zf), dW2, mma=pio, out_dtype=A)                                  # [B,h,m,dh]
         if fused:
@@ -648,11 +667,11 @@ class NystromCoreFn(Function):
             K.resconv(dout, rw, dqkv[..., 2 * D:], h, transpose=True, accumulate=True)
         else:
             dS1 = K.gemm(dO, tr(w2), mma=mma, out_dtype=A)                               # [B,h,n_p,m]
-            K.softmax_bwd(a1, dS1)
+            sm_bwd(a1, dS1, mrow if kmask else None, mlm if kmask else None)
             dS3 = K.gemm(dAV, tr(v), mma=mma, out_dtype=A)                               # [B,h,m,n_p]
             K.gemm(tr(a3), dAV, out=dv, mma=mma)
             K.resconv(dout, rw, dqkv[..., 2 * D:], h, transpose=True, accumulate=True)
-            K.softmax_bwd(a3, dS3)
+            sm_bwd(a3, dS3, mlm if kmask else None, mrow if kmask else None)
             # similarities: s1 = scale q kl^T, s2 = scale ql kl^T, s3 = scale ql k^T
             K.gemm(dS1, kl, out=dq, alpha=scale, mma=mma)
             K.gemm(tr(dS3), ql, out=dk, alpha=scale, mma=mma)
@@ -663,11 +682,28 @@ class NystromCoreFn(Function):
             del work
         else:
             dS2 = pinv_backward(a2, saved, st, dZ, pm, sd)
-            K.softmax_bwd(a2, dS2)
+            sm_bwd(a2, dS2, mlm if kmask else None, mlm if kmask else None)
         K.gemm(tr(dS2), ql, out=dkl, alpha=scale, accumulate=True, mma=pio)
         K.gemm(dS2, kl, out=dql, alpha=scale, accumulate=True, mma=pio)
+        if kmask is not None:
+            dlm = K.row_scale(dlm, lscale)
         K.landmark_bwd(K.cast(dlm, A), dqkv, l)
-        return dqkv, dres.view_as(res_w), None, None, None, None
+        return dqkv, dres.view_as(res_w), None, None, None, None, None
+
+
+class RowScaleFn(Function):
+    """y[..., r, :] = x[..., r, :] * s[..., r] with a constant per-row factor (key-padding mask: rows zeroed in front of the
+    bias-free to_qkv, which is what the package's `q, k, v = map(lambda t: t * mask[..., None], (q, k, v))` amounts to)."""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        ctx.save_for_backward(s)
+        return K.row_scale(x.contiguous(), s)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (s,) = ctx.saved_tensors
+        return K.row_scale(dy.contiguous(), s), None
 
 
 # ------------------------------------------------------------------ masking

@@ -295,6 +295,44 @@ def softmax_bwd(y: torch.Tensor, dy: torch.Tensor, dx: Optional[torch.Tensor] = 
     return dx
 
 
+def softmax_masked_fwd(x: torch.Tensor, rowmask: torch.Tensor, colmask: torch.Tensor, y: Optional[torch.Tensor] = None,
+                       out_dtype=None) -> torch.Tensor:
+    """softmax(masked_fill(x, ~(rowmask[b, i] & colmask[b, j]), -max)) over the last dim of x [B, h, R, C]."""
+    _chk(x, y, rowmask, colmask)
+    _contig(x, "softmax input")
+    Bn, h, R, Cc = x.shape
+    assert rowmask.shape == (Bn, R) and colmask.shape == (Bn, Cc) and rowmask.dtype == colmask.dtype == torch.float32
+    if y is None:
+        y = torch.empty_like(x, dtype=out_dtype or x.dtype)
+    _contig(y, "softmax output")
+    _lib.call("mh_softmax_masked_fwd", _p(x), _p(y), _p(rowmask.contiguous()), _p(colmask.contiguous()), Bn, h, R, Cc, dt(x), dt(y),
+              stream=_stream())
+    return y
+
+
+def softmax_masked_bwd(y: torch.Tensor, dy: torch.Tensor, rowmask: torch.Tensor, colmask: torch.Tensor) -> torch.Tensor:
+    """In place on dy."""
+    _chk(y, dy, rowmask, colmask)
+    _contig(y, "softmax y"), _contig(dy, "softmax dy")
+    Bn, h, R, Cc = y.shape
+    _lib.call("mh_softmax_masked_bwd", _p(y), _p(dy), _p(dy), _p(rowmask.contiguous()), _p(colmask.contiguous()), Bn, h, R, Cc, dt(y),
+              dt(dy), stream=_stream())
+    return dy
+
+
+def row_scale(x: torch.Tensor, scale: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[..., r, :] = x[..., r, :] * scale[..., r] (x contiguous, scale f32 with one entry per row)."""
+    _chk(x, scale, out)
+    _contig(x, "row_scale input")
+    D = x.shape[-1]
+    rows = x.numel() // max(D, 1)
+    assert scale.numel() == rows and scale.dtype == torch.float32
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.call("mh_row_scale", _p(x), _p(scale.contiguous()), _p(out), rows, D, dt(x), stream=_stream())
+    return out
+
+
 def l2norm_fwd(x2d_rows: torch.Tensor, rows: int, D: int, x_rs: int, eps: float, out_dtype):
     _chk(x2d_rows)
     y = torch.empty((rows, D), device=x2d_rows.device, dtype=out_dtype)

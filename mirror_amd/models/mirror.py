@@ -172,16 +172,24 @@ class TransLayer(nn.Module):
                                      pinv_iterations=6, residual=True, dropout=0.1)
 
     def forward(self, x, prec: Precision, mask=None):
-        if mask is not None:
-            raise NotImplementedError("key-padding mask path (BASELINE config 4) is not built yet; "
-                                      "the reference never passes one (models/mirror.py:312)")
+        """mask: optional [B, n] bool key-padding mask (True = real token), the `mask` argument of [3P]
+        NystromAttention.forward that the reference never passes (models/mirror.py:312); BASELINE config 4 uses it for
+        variable-length slides.  It is front-padded with False like the sequence."""
         a = self.attn
         n, m = x.shape[1], a.num_landmarks
         pad = (m - n % m) % m
         l = math.ceil(n / m)  # noqa: E741
         xp = Fn.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps, pad=pad, out_dtype=prec.act)
+        kmask = None
+        if mask is not None:
+            if mask.shape != x.shape[:2]:
+                raise ValueError(f"key-padding mask must be {tuple(x.shape[:2])}, got {tuple(mask.shape)}")
+            mrow = torch.nn.functional.pad(mask.to(x.device, torch.float32), (pad, 0), value=0.0).contiguous()
+            cnt = mrow.reshape(mrow.shape[0], (n + pad) // l, l).sum(-1)
+            kmask = (mrow, (cnt > 0).float().contiguous(), (float(l) / (cnt + 1e-8)).contiguous())
+            xp = Fn.RowScaleFn.apply(xp, mrow)           # to_qkv has no bias: zero rows in, zero q / k / v rows out
         qkv = Fn.linear(xp, a.to_qkv.weight, None, prec=prec)
-        core = Fn.NystromCoreFn.apply(qkv, a.res_conv.weight, a.heads, l, a.pinv_iterations, prec)
+        core = Fn.NystromCoreFn.apply(qkv, a.res_conv.weight, a.heads, l, a.pinv_iterations, prec, kmask)
         y = Fn.LinearRowsFn.apply(core, a.to_out[0].weight, a.to_out[0].bias, pad, n, prec, prec.act)
         y = Fn.dropout(y, a.drop, self.training)
         return Fn.add(x, y, f32, residual=True)                     # x feeds exactly self.norm and this add
@@ -216,7 +224,9 @@ class FeatureTransMIL(nn.Module):
         self.norm = nn.LayerNorm(embed_dim)
         self.precision: Optional[str] = None
 
-    def _encode(self, h, keep_rows: Optional[int]):
+    def _encode(self, h, keep_rows: Optional[int], mask: Optional[torch.Tensor] = None):
+        """mask: optional [B, N] bool, True = real patch (BASELINE config 4; the reference has no such argument).  The
+        sequence [cls, x_0..x_{N-1}, x_0..x_{add-1}] carries [True, mask, mask[:, :add]]."""
         prec = resolve_precision(self.precision)
         if not h.is_cuda:
             raise MirrorHipError("mirror_amd models run on MI355X only (no CPU fallback): move the inputs to the GPU")
@@ -224,9 +234,13 @@ class FeatureTransMIL(nn.Module):
         side = int(np.ceil(np.sqrt(n_tok)))
         add = side * side - n_tok
         seq = Fn.Fc1SeqFn.apply(h, self._fc1[0].weight, self._fc1[0].bias, self.cls_token, add, prec)
-        seq = self.layer1(seq, prec)
+        smask = None
+        if mask is not None:
+            mask = mask.to(h.device, torch.bool)
+            smask = torch.cat([torch.ones_like(mask[:, :1]), mask, mask[:, :add]], dim=1)
+        seq = self.layer1(seq, prec, smask)
         seq = self.pos_layer(seq, side, side)
-        seq = self.layer2(seq, prec)
+        seq = self.layer2(seq, prec, smask)
         rows = seq.shape[1] - add if keep_rows is None else keep_rows
         return Fn.layer_norm(seq, self.norm.weight, self.norm.bias, self.norm.eps, rows=rows, out_dtype=f32)
 
@@ -332,8 +346,8 @@ class FeatureTransMILHybrid(FeatureTransMIL):
                 nn.init.constant_(m.bias, 0)
                 nn.init.constant_(m.weight, 1.0)
 
-    def forward_encoder(self, h):
-        return self._encode(h, keep_rows=None)
+    def forward_encoder(self, h, mask: Optional[torch.Tensor] = None):
+        return self._encode(h, keep_rows=None, mask=mask)
 
     def forward_alignment_head(self, h):
         prec = resolve_precision(self.precision)
@@ -348,8 +362,9 @@ class FeatureTransMILHybrid(FeatureTransMIL):
         return Fn.rank_mask(noise, len_keep)
 
     def forward_retention_head(self, h, mask_ratio: float, noise: Optional[torch.Tensor] = None,
-                               mask: Optional[torch.Tensor] = None):
-        """`mask`: a mask already drawn for this batch (MIRROR.forward ranks the noise on a side stream up front)."""
+                               mask: Optional[torch.Tensor] = None, key_padding_mask: Optional[torch.Tensor] = None):
+        """`mask`: a mask already drawn for this batch (MIRROR.forward ranks the noise on a side stream up front).
+        `key_padding_mask` [B, N] bool: attention mask of the decoder layers (config 4; cls is always attended)."""
         prec = resolve_precision(self.precision)
         if h.shape[1] != self.num_tokens + 1:
             raise ValueError(f"wsi_num_tokens={self.num_tokens} but the batch has {h.shape[1] - 1} tokens")
@@ -358,8 +373,12 @@ class FeatureTransMILHybrid(FeatureTransMIL):
         if mask is None:
             mask = self.random_masking(r[:, 1:], mask_ratio, noise)
         r = Fn.MaskApplyFn.apply(r, mask, self.mask_token, self.retention_gene_embed, 1, False)
+        kp = None
+        if key_padding_mask is not None:
+            kpm = key_padding_mask.to(h.device, torch.bool)
+            kp = torch.cat([torch.ones_like(kpm[:, :1]), kpm], dim=1)
         for blk in self.retention_blocks:
-            r = blk(r, prec)
+            r = blk(r, prec, kp)
         r = Fn.layer_norm(r, self.retention_norm.weight, self.retention_norm.bias, self.retention_norm.eps,
                           out_dtype=prec.act)
         # retention_head(...)[:, 1:]: the cls row is sliced away, so it is never computed
@@ -448,7 +467,10 @@ class MIRROR(nn.Module):
         return wsi_score, wsi_mu, wsi_logstd, rna_score, rna_mu, rna_logstd
 
     def forward(self, wsi_emb, rna_emb, wsi_mask_ratio: float = 0.75, rna_mask_ratio: float = 0.75,
-                noise: Optional[Dict[str, torch.Tensor]] = None):
+                noise: Optional[Dict[str, torch.Tensor]] = None, wsi_key_padding_mask: Optional[torch.Tensor] = None):
+        """`noise` (build-only) pins the random draws; `wsi_key_padding_mask` (build-only, BASELINE config 4): [B, N] bool,
+        True = real patch, False = padding of a slide shorter than N — handed to every Nystrom layer as the package's
+        key-padding `mask`."""
         noise = dict(noise or {})
         if not wsi_emb.is_cuda:
             raise MirrorHipError("mirror_amd models run on MI355X only (no CPU fallback): move the inputs to the GPU")
@@ -477,14 +499,14 @@ class MIRROR(nn.Module):
             rna_emb = self.rna_encoder.forward_encoder(rna_emb)
             rna_alignment_emb, rna_retention_emb, rna_mask = self.rna_encoder.forward_decoders(
                 rna_emb, mask_ratio=rna_mask_ratio, noise=noise.get("rna_mask"))
-        wsi_emb = self.wsi_encoder.forward_encoder(wsi_emb)
+        wsi_emb = self.wsi_encoder.forward_encoder(wsi_emb, wsi_key_padding_mask)
         # the encoder output has three consumers (decoder input, retention target, cls row): one node sums their gradients
         wsi_full, wsi_retention_target, wsi_cls = Fn.enc_fanout(wsi_emb)
         wsi_alignment_emb = self.wsi_encoder.forward_alignment_head(wsi_cls)
         main.wait_event(mask_ready)
         wsi_mask.record_stream(main)
         wsi_retention_emb, wsi_mask = self.wsi_encoder.forward_retention_head(
-            wsi_full, mask_ratio=wsi_mask_ratio, mask=wsi_mask)
+            wsi_full, mask_ratio=wsi_mask_ratio, mask=wsi_mask, key_padding_mask=wsi_key_padding_mask)
         main.wait_stream(side)
         for t in (rna_emb, rna_alignment_emb, rna_retention_emb, rna_mask):
             t.record_stream(main)       # allocated in the side stream's pool, consumed on the main stream

@@ -149,17 +149,20 @@ def ppeg(x: Tensor, sd: SD, p: str, hh: int, ww: int) -> Tensor:
 
 
 # ---------------------------------------------------------------------------- WSI side
-def wsi_forward_encoder(wsi: Tensor, sd: SD, cfg: Cfg, p: str = "wsi_encoder") -> Tensor:
-    """FeatureTransMILHybrid.forward_encoder, models/mirror.py:651-679."""
+def wsi_forward_encoder(wsi: Tensor, sd: SD, cfg: Cfg, p: str = "wsi_encoder", mask: Optional[Tensor] = None) -> Tensor:
+    """FeatureTransMILHybrid.forward_encoder, models/mirror.py:651-679.  `mask` ([B, N] bool, True = real patch) is the
+    BASELINE config-4 extension: the reference has no such argument; the sequence [cls, x, x[:add]] carries
+    [True, mask, mask[:, :add]] into the package's key-padding `mask` of both Nystrom layers."""
     h = F.relu(_linear(wsi.float(), sd, p + "._fc1.0"))
     n = h.shape[1]
     side = int(math.ceil(math.sqrt(n)))
     add = side * side - n
     h = torch.cat([h, h[:, :add]], dim=1)
     h = torch.cat([sd[p + ".cls_token"].expand(h.shape[0], -1, -1), h], dim=1)
-    h = trans_layer(h, sd, p + ".layer1", cfg)
+    smask = None if mask is None else torch.cat([torch.ones_like(mask[:, :1]), mask, mask[:, :add]], dim=1)
+    h = trans_layer(h, sd, p + ".layer1", cfg, smask)
     h = ppeg(h, sd, p + ".pos_layer", side, side)
-    h = trans_layer(h, sd, p + ".layer2", cfg)
+    h = trans_layer(h, sd, p + ".layer2", cfg, smask)
     h = _ln(h, sd, p + ".norm", 1e-5)
     return h[:, : h.shape[1] - add]
 
@@ -171,7 +174,7 @@ def rank_mask(noise: Tensor, len_keep: int) -> Tensor:
 
 
 def wsi_forward_decoders(h: Tensor, sd: SD, cfg: Cfg, ratio: float, noise: Tensor,
-                         p: str = "wsi_encoder") -> Tuple[Tensor, Tensor, Tensor]:
+                         p: str = "wsi_encoder", kp_mask: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
     """forward_decoders, models/mirror.py:701-706 (+ :681-699, :624-649)."""
     align = _linear(F.normalize(h, dim=-1, p=2, eps=1e-12)[:, 0], sd, p + ".alignment_head")
     r = _linear(h, sd, p + ".retention_embed")
@@ -179,8 +182,9 @@ def wsi_forward_decoders(h: Tensor, sd: SD, cfg: Cfg, ratio: float, noise: Tenso
     mask = rank_mask(noise, int(n * (1 - ratio)))
     tok = torch.where(mask[..., None] > 0, sd[p + ".mask_token"].expand(r.shape[0], n, -1), r[:, 1:])
     r = torch.cat([r[:, :1], tok], dim=1) + sd[p + ".retention_gene_embed"]
+    kp = None if kp_mask is None else torch.cat([torch.ones_like(kp_mask[:, :1]), kp_mask], dim=1)
     for i in range(cfg.wsi_retention_decoder_depth):
-        r = trans_layer(r, sd, f"{p}.retention_blocks.{i}", cfg)
+        r = trans_layer(r, sd, f"{p}.retention_blocks.{i}", cfg, kp)
     r = _linear(_ln(r, sd, p + ".retention_norm", 1e-5), sd, p + ".retention_head")
     return align, r[:, 1:], mask
 
@@ -242,11 +246,12 @@ def style_branch(x: Tensor, sd: SD, eps: Tensor) -> Tuple[Tensor, Tensor, Tensor
 
 
 def mirror_forward(sd: SD, cfg: Cfg, wsi: Tensor, rna: Tensor, noise: Dict[str, Tensor],
-                   wsi_mask_ratio: float = 0.75, rna_mask_ratio: float = 0.75):
+                   wsi_mask_ratio: float = 0.75, rna_mask_ratio: float = 0.75, wsi_key_padding_mask: Optional[Tensor] = None):
     """MIRROR.forward, models/mirror.py:860-915.  noise keys: wsi_mask [B,N], rna_mask [B,D],
-    wsi_eps [B,latent], rna_eps [B,latent] (the draw order of the reference)."""
-    w = wsi_forward_encoder(wsi, sd, cfg)
-    w_align, w_ret, w_mask = wsi_forward_decoders(w, sd, cfg, wsi_mask_ratio, noise["wsi_mask"])
+    wsi_eps [B,latent], rna_eps [B,latent] (the draw order of the reference).  `wsi_key_padding_mask` ([B, N] bool): the
+    BASELINE config-4 extension (variable-length slides), see wsi_forward_encoder."""
+    w = wsi_forward_encoder(wsi, sd, cfg, mask=wsi_key_padding_mask)
+    w_align, w_ret, w_mask = wsi_forward_decoders(w, sd, cfg, wsi_mask_ratio, noise["wsi_mask"], kp_mask=wsi_key_padding_mask)
     r = rna_forward_encoder(rna, sd, cfg)
     r_align, r_ret, r_mask = rna_forward_decoders(r, sd, cfg, rna_mask_ratio, noise["rna_mask"])
     w_score, w_mu, w_ls = style_branch(w[:, 0], sd, noise["wsi_eps"])

@@ -904,3 +904,27 @@ def test_device_slide_bank_matches_reference_items():
         assert int(local.min()) >= 0 and int(local.max()) < slides[k].shape[0]
         if slides[k].shape[0] >= N:
             assert len(set(local.tolist())) == N
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_softmax_masked_and_row_scale(dtype):
+    """Key-padding-mask pieces ([3P] masked_fill(-finfo.max) + softmax; zeroed rows / masked-mean scale)."""
+    gen = g(91)
+    B, h, R, Cc = 2, 3, 5, 300
+    x = torch.randn(B, h, R, Cc, generator=gen)
+    rm = (torch.rand(B, R, generator=gen) > 0.3).float()
+    cm = (torch.rand(B, Cc, generator=gen) > 0.4).float()
+    rm[0, 0] = 0.0                                           # a fully masked row -> uniform
+    xr = x.to(dtype).float().requires_grad_(True)
+    keep = (rm[:, None, :, None] > 0) & (cm[:, None, None, :] > 0)
+    ref = xr.masked_fill(~keep, -torch.finfo(torch.float32).max).softmax(-1)
+    dy = torch.randn(B, h, R, Cc, generator=gen)
+    ref.backward(dy)
+    y = K.softmax_masked_fwd(x.to(DEV, dtype), rm.to(DEV), cm.to(DEV), out_dtype=torch.float32)
+    close(y, ref.detach(), 1e-5, 1e-7, "masked softmax")
+    assert abs(float(y[0, 0, 0].sum()) - 1.0) < 1e-5 and float(y[0, 0, 0].max() - y[0, 0, 0].min()) < 1e-9
+    dx = K.softmax_masked_bwd(y, dy.to(DEV), rm.to(DEV), cm.to(DEV))
+    close(dx, xr.grad, 1e-4, 1e-6, "masked softmax bwd")
+    z = torch.randn(7, 9, 64, generator=gen).to(dtype)
+    sc = torch.rand(7, 9, generator=gen)
+    close(K.row_scale(z.to(DEV), sc.to(DEV)), (z.float() * sc[..., None]).to(dtype).float(), 0, 0, "row scale")

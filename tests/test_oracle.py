@@ -133,3 +133,25 @@ def test_dataset_getitem_restatement_matches_reference():
         assert np.array_equal(w.numpy(), z[f"out/{j}/wsi"]) and np.array_equal(r.numpy(), z[f"out/{j}/rna"])
         n = slides[int(k)].shape[0]
         assert (len(set(idx.tolist())) == N) == (n >= N) or n < N      # without replacement <=> no duplicates when long enough
+
+
+def test_masked_nystrom_restatement_matches_package_standin():
+    """BASELINE config 4 (variable-length slides): the package's key-padding `mask` path.  The oracle's restatement against
+    the literal stand-in of nystrom_attention 0.0.14 (tools/oracle_shims.py) — partially masked rows, a fully masked
+    landmark group, a fully masked query row (uniform attention), front padding."""
+    from tools.oracle_shims import NystromAttention
+    torch.manual_seed(3)
+    D, h, n = 32, 8, 37
+    cfg = O.Cfg(wsi_embed_dim=8, rna_embed_dim=8, embed_dim=D)
+    mod = NystromAttention(dim=D, dim_head=D // h, heads=h, num_landmarks=D // 2, pinv_iterations=6, residual=True, dropout=0.1).eval()
+    sd = {"attn." + k: v.detach() for k, v in mod.state_dict().items()}
+    x = torch.randn(3, n, D)
+    lens = [37, 20, 5]
+    mask = torch.stack([torch.arange(n) < L for L in lens])
+    with torch.no_grad():
+        want = mod(x, mask=mask)
+        got = O.nystrom_attention(x, sd, "attn", cfg, mask)
+        assert torch.allclose(got, want, rtol=1e-5, atol=1e-6), float((got - want).abs().max())
+        assert not torch.allclose(got, O.nystrom_attention(x, sd, "attn", cfg, None), atol=1e-3)      # the mask matters
+        # (an all-True mask is NOT the unmasked path: with a mask the front-padding rows are masked out of the landmark
+        #  means and the three softmaxes, without one they take part as zero rows — the package's quirk, kept)
