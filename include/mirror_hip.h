@@ -219,6 +219,10 @@ int mh_relu_bwd(const void* y, const void* dy, void* dx, int64_t n_per_batch, in
  * dev_base (nullable, device memory): per-step base offset, so that a captured graph draws fresh masks at every replay */
 int mh_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, uint64_t offset, const uint64_t* dev_base,
                int dt_x, int dt_y, mh_stream s);
+/* y = a + dropout(x): the residual add behind the Dropout of [3P] NystromAttention.to_out (models/mirror.py:312), one pass.
+ * Same mask as mh_dropout for the same (seed, offset [+ *dev_base]).  n % 4 == 0, quad-aligned buffers; a, y f32. */
+int mh_dropout_add(const float* a, const void* x, float* y, int64_t n, float p, uint64_t seed, uint64_t offset,
+                   const uint64_t* dev_base, int dt_x, mh_stream s);
 /* out[c] += sum_r x[r*ld + c]  (bias gradients; f32 atomics) */
 int mh_colsum(const void* x, float* out, int64_t rows, int cols, int64_t ld, int dt, mh_stream s);
 /* y[r] = x[r*x_rs .. +D] / max(||.||, eps) (F.normalize, models/mirror.py:540, :683); norm[r] saved */

@@ -170,15 +170,57 @@ __global__ __launch_bounds__(256) void dropout_kernel(const TX* x, TY* y, long n
     }
 }
 
+// quad form (n % 4 == 0, quad-aligned pointers): one Philox block per thread iteration = one 8 / 16-byte access per tensor;
+// ADD: y = a + dropout(x) (the residual add behind to_out's Dropout, models/mirror.py:312 + [3P] to_out[1])
+template <typename TX, typename TY, bool ADD>
+__global__ __launch_bounds__(256) void dropout4_kernel(const TX* x, const float* a, TY* y, long n4, float p, uint64_t seed, uint64_t offset,
+                                                       const uint64_t* __restrict__ dev_base) {
+    if (dev_base) offset += *dev_base & ~3ull;
+    const float scale = 1.f / (1.f - p);
+    const uint32_t thr = (uint32_t)fminf(p * 4294967296.f, 4294967295.f);
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long)gridDim.x * 256) {
+        const uint64_t blk = (offset >> 2) + (uint64_t)q;
+        uint32_t ctr[4] = {(uint32_t)blk, (uint32_t)(blk >> 32), 0u, 0u};
+        philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
+        const f4_t v = ld4(x + 4 * q);
+        f4_t o = {ctr[0] >= thr ? v[0] * scale : 0.f, ctr[1] >= thr ? v[1] * scale : 0.f, ctr[2] >= thr ? v[2] * scale : 0.f,
+                  ctr[3] >= thr ? v[3] * scale : 0.f};
+        if (ADD) o += ld4(a + 4 * q);
+        st4(y + 4 * q, o);
+    }
+}
+
 extern "C" int mh_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, uint64_t offset, const uint64_t* dev_base,
                           int dt_x, int dt_y, mh_stream s) {
     MH_REQUIRE(p >= 0.f && p < 1.f, "mh_dropout: p=%f out of range", (double)p);
     MH_REQUIRE((offset & 3) == 0, "mh_dropout: offset must be a multiple of 4");
     if (n == 0) return MH_OK;
+    if (n % 4 == 0 && mh_quad_ok(x, mh_dt_size(dt_x)) && mh_quad_ok(y, mh_dt_size(dt_y))) {
+#define DROP4_(TX, TY) hipLaunchKernelGGL((dropout4_kernel<TX, TY, false>), EW_GRID(n / 4), dim3(256), 0, (hipStream_t)s, (const TX*)x, (const float*)nullptr, (TY*)y, (long)(n / 4), p, seed, offset, dev_base)
+        DISPATCH2(dt_x, dt_y, DROP4_)
+#undef DROP4_
+        MH_LAUNCH_CHECK("mh_dropout");
+        return MH_OK;
+    }
 #define DROP_(TX, TY) hipLaunchKernelGGL((dropout_kernel<TX, TY>), EW_GRID((n + 3) / 4), dim3(256), 0, (hipStream_t)s, (const TX*)x, (TY*)y, (long)n, p, seed, offset, dev_base)
     DISPATCH2(dt_x, dt_y, DROP_)
 #undef DROP_
     MH_LAUNCH_CHECK("mh_dropout");
+    return MH_OK;
+}
+
+extern "C" int mh_dropout_add(const float* a, const void* x, float* y, int64_t n, float p, uint64_t seed, uint64_t offset,
+                              const uint64_t* dev_base, int dt_x, mh_stream s) {
+    MH_REQUIRE(p >= 0.f && p < 1.f, "mh_dropout_add: p=%f out of range", (double)p);
+    MH_REQUIRE((offset & 3) == 0, "mh_dropout_add: offset must be a multiple of 4");
+    MH_REQUIRE(n % 4 == 0 && mh_quad_ok(x, mh_dt_size(dt_x)) && mh_quad_ok(a, 4) && mh_quad_ok(y, 4),
+               "mh_dropout_add: n must be a multiple of 4 and the buffers quad-aligned");
+    if (n == 0) return MH_OK;
+    if (dt_x == MH_F32)
+        hipLaunchKernelGGL((dropout4_kernel<float, float, true>), EW_GRID(n / 4), dim3(256), 0, (hipStream_t)s, (const float*)x, a, y, (long)(n / 4), p, seed, offset, dev_base);
+    else
+        hipLaunchKernelGGL((dropout4_kernel<bf16_t, float, true>), EW_GRID(n / 4), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, a, y, (long)(n / 4), p, seed, offset, dev_base);
+    MH_LAUNCH_CHECK("mh_dropout_add");
     return MH_OK;
 }
 

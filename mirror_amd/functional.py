@@ -389,6 +389,36 @@ def dropout(x, p: float, training: bool):
     return DropoutFn.apply(x, p)
 
 
+class DropoutAddFn(Function):
+    """a + dropout(b) -> f32 in one pass (pre-norm block x + Dropout(to_out(...)), models/mirror.py:312): saves the
+    dropped copy of b in the forward and, in the backward, the cast of dy in front of the dropout (the kernel reads the
+    f32 gradient and writes the masked, scaled activation-dtype gradient).  `a`'s gradient is dy itself and is published
+    for the block's LayerNorm to accumulate into (see AddFn)."""
+
+    @staticmethod
+    def forward(ctx, a, b, p):
+        a, b = a.contiguous(), b.contiguous()
+        ctx.p, ctx.seed, ctx.offset, ctx.base = p, _dropout_state["seed"], _dropout_state["offset"], _dropout_state["base"]
+        _dropout_state["offset"] += (b.numel() + 3) // 4 * 4
+        ctx.res_key, ctx.db = a.data_ptr(), b.dtype
+        return K.dropout_add(a, b, p, ctx.seed, ctx.offset, dev_base=ctx.base)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        gb = torch.empty(dy.shape, device=dy.device, dtype=ctx.db)
+        K.dropout(dy, ctx.p, ctx.seed, ctx.offset, out=gb, dev_base=ctx.base)
+        _res_grads[ctx.res_key] = dy
+        return dy, gb, None
+
+
+def dropout_add(a, b, p: float, training: bool):
+    """a + dropout(b) with `a` the f32 residual stream of a pre-norm block (falls back to the two-op form otherwise)."""
+    if training and p > 0.0 and a.dtype == f32 and a.shape == b.shape and b.numel() % 4 == 0:
+        return DropoutAddFn.apply(a, b, p)
+    return add(a, dropout(b, p, training), f32, residual=True)
+
+
 # ------------------------------------------------------------------ TransMIL sequence assembly
 class Fc1SeqFn(Function):
     """seq = [cls | relu(wsi @ W^T + b) | first `add` tokens again]  (models/mirror.py:652-665).

@@ -752,6 +752,16 @@ def dropout(x: torch.Tensor, p: float, seed: int, offset: int, out: Optional[tor
     return y
 
 
+def dropout_add(a: torch.Tensor, x: torch.Tensor, p: float, seed: int, offset: int, dev_base: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """a + dropout(x) as f32 (a f32, x f32 / bf16, same shape, numel % 4 == 0)."""
+    _chk(a, x, dev_base)
+    _contig(a, "dropout_add a"), _contig(x, "dropout_add x")
+    assert a.dtype == torch.float32 and a.shape == x.shape and x.numel() % 4 == 0
+    y = torch.empty_like(a)
+    _lib.call("mh_dropout_add", _p(a), _p(x), _p(y), x.numel(), p, seed, offset, _p(dev_base), dt(x), stream=_stream())
+    return y
+
+
 def colsum(x2d: torch.Tensor, out: torch.Tensor) -> None:
     """out[c] += sum_r x2d[r, c]; x2d may be row-strided."""
     _chk(x2d, out)

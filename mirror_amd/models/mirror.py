@@ -191,8 +191,7 @@ class TransLayer(nn.Module):
         qkv = Fn.linear(xp, a.to_qkv.weight, None, prec=prec)
         core = Fn.NystromCoreFn.apply(qkv, a.res_conv.weight, a.heads, l, a.pinv_iterations, prec, kmask)
         y = Fn.LinearRowsFn.apply(core, a.to_out[0].weight, a.to_out[0].bias, pad, n, prec, prec.act)
-        y = Fn.dropout(y, a.drop, self.training)
-        return Fn.add(x, y, f32, residual=True)                     # x feeds exactly self.norm and this add
+        return Fn.dropout_add(x, y, a.drop, self.training)           # x feeds exactly self.norm and this add
 
 
 class PPEG(nn.Module):

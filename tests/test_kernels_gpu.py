@@ -928,3 +928,30 @@ def test_softmax_masked_and_row_scale(dtype):
     z = torch.randn(7, 9, 64, generator=gen).to(dtype)
     sc = torch.rand(7, 9, generator=gen)
     close(K.row_scale(z.to(DEV), sc.to(DEV)), (z.float() * sc[..., None]).to(dtype).float(), 0, 0, "row scale")
+
+
+def test_dropout_add_equals_dropout_then_add():
+    """Fused a + dropout(b) and the fused cast + dropout backward draw the very masks of the two-op form."""
+    from mirror_amd import functional as Fn
+    gen = g(95)
+    a = torch.randn(3, 50, 64, generator=gen).to(DEV)
+    b = torch.randn(3, 50, 64, generator=gen).to(DEV, torch.bfloat16)
+    dy = torch.randn(3, 50, 64, generator=gen).to(DEV)
+    Fn.manual_seed(77)
+    a1, b1 = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y1 = Fn.add(a1, Fn.dropout(b1, 0.25, True), torch.float32)
+    y1.backward(dy)
+    Fn.manual_seed(77)
+    a2, b2 = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y2 = Fn.dropout_add(a2, b2, 0.25, True)
+    y2.backward(dy.clone())
+    # same masks; the fused form skips two bf16 roundings (the dropped copy of b, the cast of dy), so values agree to bf16 eps
+    assert torch.equal(y1 == a, y2 == a) and torch.equal(b1.grad == 0, b2.grad == 0)
+    close(y2, y1.cpu(), 1e-2, 1e-2, "dropout_add forward")
+    close(b2.grad, b1.grad.float().cpu(), 2e-2, 1e-3, "dropout_add db")
+    assert torch.equal(a1.grad, a2.grad)
+    ref = a.cpu() + torch.where(y2.cpu() != a.cpu(), b.float().cpu() / 0.75, torch.zeros(()))
+    close(y2, ref, 1e-6, 1e-6, "dropout_add exact")
+    kept = float((y2 != a).float().mean())
+    assert 0.70 < kept < 0.80
+    Fn._res_grads.clear()
