@@ -81,30 +81,62 @@ __global__ __launch_bounds__(256) void mse_masked_fwd_kernel(const TP* __restric
                                                              long rpb, long tgt_bs) {
     __shared__ float red[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long nw = (long)gridDim.x * 4;
     float num = 0.f, den = 0.f;
-    for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
-        const float mk = mask[r];
-        den += mk;  // every lane carries it; only lane 0's copy is used below
-        if (mk != 0.f) {
-            const TP* pr = pred + r * D;
-            const TT* tr = tgt + (r / rpb) * tgt_bs + (r % rpb) * D;
-            float s = 0.f;
-            if (VEC) {
-                for (int c = 4 * lane; c < D; c += 256) {
-                    const f4_t d = ld4(pr + c) - ld4(tr + c);
-                    s += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
-                }
-            } else {
-                for (int c = lane; c < D; c += 64) {
-                    const float d = ldf(pr + c) - ldf(tr + c);
-                    s += d * d;
-                }
-            }
-            num += mk * s / D;
+    // four rows in flight per wave (rows r, r + nw, r + 2 nw, r + 3 nw): the mask -> data dependency of one row at a time
+    // left the kernel latency bound (1.3 TB/s); few blocks, so the two same-address atomics per block stay cheap
+    for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += 4 * nw) {
+        float mk[4], s[4] = {0.f, 0.f, 0.f, 0.f};
+        const TP* pr[4];
+        const TT* tr[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const long ru = r + u * nw;
+            mk[u] = ru < rows ? mask[ru] : 0.f;
+            pr[u] = pred + ru * D;
+            tr[u] = tgt + (ru / rpb) * tgt_bs + (ru % rpb) * D;
+            den += mk[u];   // every lane carries it; only lane 0's copy is used below
         }
+        if (VEC) {
+            for (int c = 4 * lane; c < D; c += 256) {
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (mk[u] != 0.f) {
+                        const f4_t d = ld4(pr[u] + c) - ld4(tr[u] + c);
+                        s[u] += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+                    }
+            }
+        } else {
+            for (int c = lane; c < D; c += 64) {
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (mk[u] != 0.f) {
+                        const float d = ldf(pr[u] + c) - ldf(tr[u] + c);
+                        s[u] += d * d;
+                    }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) num += mk[u] * s[u] / D;
     }
     num = block_sum256(num, red);
     den = block_sum256(lane == 0 ? den : 0.f, red);
+    if (threadIdx.x == 0) { atomicAdd(acc, num); atomicAdd(acc + 1, den); }
+}
+
+// D == 1 (RNA retention loss: the channel axis is the masked axis): a flat reduction, one element per thread iteration
+template <typename TP, typename TT>
+__global__ __launch_bounds__(256) void mse_masked_fwd_flat_kernel(const TP* __restrict__ pred, const TT* __restrict__ tgt,
+                                                                  const float* __restrict__ mask, float* __restrict__ acc, long n) {
+    __shared__ float red[4];
+    float num = 0.f, den = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float mk = mask[i], d = ldf(pred + i) - ldf(tgt + i);
+        num += mk * d * d;
+        den += mk;
+    }
+    num = block_sum256(num, red);
+    den = block_sum256(den, red);
     if (threadIdx.x == 0) { atomicAdd(acc, num); atomicAdd(acc + 1, den); }
 }
 
@@ -151,7 +183,18 @@ extern "C" int mh_mse_masked_fwd(const void* pred, const void* tgt, const float*
                                  int64_t rows_per_batch, int64_t tgt_bs, int dt_p, int dt_t, mh_stream s) {
     if (rows == 0) return MH_OK;
     MH_REQUIRE(rows_per_batch > 0, "mh_mse_masked_fwd: rows_per_batch must be positive");
-    dim3 grid((unsigned)min((long)mh_cdiv(rows, 4), 4096L));
+    if (D == 1 && tgt_bs == rows_per_batch) {       // contiguous [rows] vectors
+        dim3 gf((unsigned)min((long)mh_cdiv(rows, 256), 64L));
+#define MSEFL(TP, TT) hipLaunchKernelGGL((mse_masked_fwd_flat_kernel<TP, TT>), gf, dim3(256), 0, (hipStream_t)s, (const TP*)pred, (const TT*)tgt, mask, acc, (long)rows)
+        if (dt_p == MH_F32 && dt_t == MH_F32) { MSEFL(float, float); }
+        else if (dt_p == MH_BF16 && dt_t == MH_BF16) { MSEFL(bf16_t, bf16_t); }
+        else if (dt_p == MH_F32) { MSEFL(float, bf16_t); }
+        else { MSEFL(bf16_t, float); }
+#undef MSEFL
+        MH_LAUNCH_CHECK("mh_mse_masked_fwd");
+        return MH_OK;
+    }
+    dim3 grid((unsigned)min((long)mh_cdiv(rows, 16), 1024L));
     const bool vec = D % 4 == 0 && tgt_bs % 4 == 0 && mh_quad_ok(pred, mh_dt_size(dt_p)) && mh_quad_ok(tgt, mh_dt_size(dt_t));
 #define MSEF(TP, TT)                                                                                                              \
     if (vec) hipLaunchKernelGGL((mse_masked_fwd_kernel<TP, TT, true>), grid, dim3(256), 0, (hipStream_t)s, (const TP*)pred, (const TT*)tgt, mask, acc, (long)rows, D, (long)rows_per_batch, (long)tgt_bs); \

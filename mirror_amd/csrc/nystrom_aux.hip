@@ -31,6 +31,31 @@ __global__ __launch_bounds__(256) void landmark_fwd_kernel(const T* __restrict__
     }
 }
 
+// quad form (D % 4 == 0, quad-aligned): a thread owns 4 consecutive columns of one landmark; same summation order
+template <typename T>
+__global__ __launch_bounds__(256) void landmark_fwd_vec_kernel(const T* __restrict__ qkv, T* __restrict__ lm, int B, int n_p,
+                                                               int D, int l) {
+    const int m = n_p / l, q2 = 2 * D / 4;
+    const long total = (long)B * m * q2;
+    const float inv = 1.f / l;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % q2) * 4;
+        const long bj = idx / q2;
+        const int j = bj % m;
+        const long b = bj / m;
+        const T* src = qkv + (b * n_p + (long)j * l) * 3 * D + c;
+        f4_t s = {0.f, 0.f, 0.f, 0.f};
+        int t = 0;
+        for (; t + 4 <= l; t += 4) {      // four rows in flight
+            const f4_t a0 = ld4(src + (long)t * 3 * D), a1 = ld4(src + (long)(t + 1) * 3 * D), a2 = ld4(src + (long)(t + 2) * 3 * D),
+                       a3 = ld4(src + (long)(t + 3) * 3 * D);
+            s += a0; s += a1; s += a2; s += a3;
+        }
+        for (; t < l; t++) s += ld4(src + (long)t * 3 * D);
+        st4(lm + bj * 2 * D + c, s * inv);
+    }
+}
+
 // dqkv[b, r, c] += dlm[b, r / l, c] / l, c < 2D
 template <typename T>
 __global__ __launch_bounds__(256) void landmark_bwd_kernel(const T* __restrict__ dlm, T* __restrict__ dqkv, int B, int n_p,
@@ -57,6 +82,12 @@ extern "C" int mh_landmark_fwd(const void* qkv, void* lm, int B, int n_p, int D,
     MH_REQUIRE(l >= 1 && n_p % l == 0, "mh_landmark_fwd: n_p=%d not a multiple of l=%d", n_p, l);
     const long total = (long)B * (n_p / l) * 2 * D;
     if (total == 0) return MH_OK;
+    if (D % 4 == 0 && mh_quad_ok(qkv, mh_dt_size(dt)) && mh_quad_ok(lm, mh_dt_size(dt))) {
+        dim3 gv((unsigned)min((long)mh_cdiv(total / 4, 256), 16384L));
+        MH_DISPATCH_DT(dt, T, hipLaunchKernelGGL((landmark_fwd_vec_kernel<T>), gv, dim3(256), 0, (hipStream_t)s, (const T*)qkv, (T*)lm, B, n_p, D, l));
+        MH_LAUNCH_CHECK("mh_landmark_fwd");
+        return MH_OK;
+    }
     dim3 grid((unsigned)min((long)mh_cdiv(total, 256), 8192L));
     MH_DISPATCH_DT(dt, T, hipLaunchKernelGGL((landmark_fwd_kernel<T>), grid, dim3(256), 0, (hipStream_t)s, (const T*)qkv, (T*)lm, B, n_p, D, l));
     MH_LAUNCH_CHECK("mh_landmark_fwd");
