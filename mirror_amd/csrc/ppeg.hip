@@ -131,10 +131,72 @@ __global__ __launch_bounds__(256) void ppeg_strip_kernel(const TX* __restrict__ 
     }
 }
 
+// Channel-pair form of the strip kernel (f32 in / out, D even): a thread owns TWO adjacent channels, so window, weights and
+// accumulators are float2 and every multiply-add is a v_pk_fma_f32 — the depthwise 7 x 7 filter is 49 FMAs per output
+// element (1.6 G per launch at c2: 42 us of plain v_fma issue, 21 us packed) and nothing else in the kernel is close.
+#define P2_T 4    // pixels along x per thread (the 7 x (P2_T + 6) float2 window is 140 registers)
+typedef float pp2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void ppeg_strip2_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ merged,
+                                                          const float* __restrict__ bsum, int S, int D, int flip) {
+    const int c = 2 * (blockIdx.x * 256 + threadIdx.x);
+    if (c >= D) return;
+    const int tiles_x = (S + P2_T - 1) / P2_T;
+    const int y0 = (blockIdx.y / tiles_x) * PY_T, x0 = (blockIdx.y % tiles_x) * P2_T;
+    const long b = blockIdx.z;
+    const long n = 1 + (long)S * S;
+    const float* xb = x + b * n * D + c;
+    float* yb = y + b * n * D + c;
+    if (blockIdx.y == 0) *reinterpret_cast<pp2*>(yb) = *reinterpret_cast<const pp2*>(xb);  // cls token passes through
+    pp2 w[49];
+#pragma unroll
+    for (int t = 0; t < 49; t++) w[t] = *reinterpret_cast<const pp2*>(merged + (flip ? 48 - t : t) * D + c);
+    const pp2 bias = flip ? (pp2){0.f, 0.f} : *reinterpret_cast<const pp2*>(bsum + c);
+    pp2 win[7][P2_T + 6];
+    auto load_row = [&](pp2 (&dst)[P2_T + 6], int sy) {
+        const bool rok = sy >= 0 && sy < S;
+        const float* row = xb + (1 + (long)(rok ? sy : 0) * S) * D;
+#pragma unroll
+        for (int u = 0; u < P2_T + 6; u++) {
+            const int sx = x0 - 3 + u;
+            dst[u] = (rok && sx >= 0 && sx < S) ? *reinterpret_cast<const pp2*>(row + (long)sx * D) : (pp2){0.f, 0.f};
+        }
+    };
+    load_row(win[4], y0 - 3); load_row(win[5], y0 - 2); load_row(win[6], y0 - 1);
+    load_row(win[0], y0); load_row(win[1], y0 + 1); load_row(win[2], y0 + 2);
+    for (int yb0 = y0; yb0 < y0 + PY_T && yb0 < S; yb0 += 7) {
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            const int yy = yb0 + j;
+            if (yy >= y0 + PY_T || yy >= S) break;
+            load_row(win[(j + 3) % 7], yy + 3);
+            pp2 acc[P2_T];
+#pragma unroll
+            for (int i = 0; i < P2_T; i++) acc[i] = bias;
+#pragma unroll
+            for (int ky = 0; ky < 7; ky++)
+#pragma unroll
+                for (int kx = 0; kx < 7; kx++) {
+                    const pp2 wv = w[ky * 7 + kx];
+#pragma unroll
+                    for (int i = 0; i < P2_T; i++) acc[i] = __builtin_elementwise_fma(wv, win[(j + ky + 4) % 7][i + kx], acc[i]);
+                }
+#pragma unroll
+            for (int i = 0; i < P2_T; i++)
+                if (x0 + i < S) *reinterpret_cast<pp2*>(yb + (1 + (long)yy * S + x0 + i) * D) = acc[i];
+        }
+    }
+}
+
 extern "C" int mh_ppeg_fwd(const void* x, void* y, const float* merged, const float* bsum, int B, int S, int D, int flip,
                            int dt_x, int dt_y, mh_stream s) {
     MH_REQUIRE(S >= 1 && D >= 1, "mh_ppeg_fwd: bad shape S=%d D=%d", S, D);
     if (B == 0) return MH_OK;
+    if (dt_x == MH_F32 && dt_y == MH_F32 && D % 2 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)merged | (uintptr_t)bsum) & 7) == 0) {
+        dim3 g2(mh_cdiv(D / 2, 256), mh_cdiv(S, PY_T) * mh_cdiv(S, P2_T), B);
+        hipLaunchKernelGGL(ppeg_strip2_kernel, g2, dim3(256), 0, (hipStream_t)s, (const float*)x, (float*)y, merged, bsum, S, D, flip);
+        MH_LAUNCH_CHECK("mh_ppeg_fwd");
+        return MH_OK;
+    }
     // PY_T = 16 rows per strip is not a multiple of the unroll (7): the walk is 7 + 7 + 2 rows with the window slots
     // following the row index, so a strip must start at a slot-0 row -> strips are re-based every PY_T rows
     dim3 grid(mh_cdiv(D, 256), mh_cdiv(S, PY_T) * mh_cdiv(S, PX_T), B);
@@ -212,6 +274,8 @@ __global__ __launch_bounds__(256) void ppeg_wgrad_kernel(const TX* __restrict__ 
 
 // Column-strip weight gradient: a thread owns one channel and PX_T pixels along x, walks down PW_ROWS grid rows with the
 // same 7-row register window as ppeg_strip_kernel: 8 + 14 loads feed 49 x 8 FMAs (the row-sweep kernel needs 64).
+// (A channel-pair v_pk_fma form like ppeg_strip2_kernel was slower here: 98 accumulator + 140 window registers leave one
+// wave per SIMD and nothing to hide the row loads behind.)
 #define PW_ROWS 32
 template <typename TX, typename TO>
 __global__ __launch_bounds__(256) void ppeg_wgrad_strip_kernel(const TX* __restrict__ x, const TO* __restrict__ dout,
