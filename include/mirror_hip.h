@@ -262,6 +262,11 @@ int mh_gather_rows(const void* src, const int64_t* row, void* out, int64_t R, in
  * gfull f32 [B, T, D], x [B, T-1, D] in dt_x, c f32 [B, D]; each may be NULL (taken as zero). */
 int mh_fanout_bwd(const float* gfull, const void* x, float alpha, const float* c, float* dE, int B, int T, int D, int dt_x,
                   mh_stream s);
+/* total = sum_i w_i * term_i over up to 6 separate f32 scalars (losses/mirror_loss.py:121-127); bwd: dterms[i] = w_i * g[0] */
+int mh_weighted_sum(const float* t0, const float* t1, const float* t2, const float* t3, const float* t4, const float* t5,
+                    float w0, float w1, float w2, float w3, float w4, float w5, int n, float* out, mh_stream s);
+int mh_weighted_sum_bwd(const float* g, float w0, float w1, float w2, float w3, float w4, float w5, int n, float* dterms,
+                        mh_stream s);
 /* out[0] += coef * sum (exp(ls) + mu^2 - 1 - ls)   (losses/mirror_loss.py:105-112) */
 int mh_kl_fwd(const float* mu, const float* ls, float* out, int64_t n, float coef, mh_stream s);
 int mh_kl_bwd(const float* mu, const float* ls, const float* g, float* dmu, float* dls, int64_t n, float coef,

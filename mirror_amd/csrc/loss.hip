@@ -232,6 +232,35 @@ extern "C" int mh_mse_masked_bwd(const void* pred, const void* tgt, const float*
     return MH_OK;
 }
 
+// ------------------------------------------------------------------ weighted sum of the loss terms (losses/mirror_loss.py:121-127)
+// out[0] = sum_i w[i] * t_i[0] over up to 6 separate 0-d tensors; the backward is dt[i] = w[i] * g[0].  One launch each
+// instead of ~10 scalar torch kernels forward and ~10 backward.
+struct WSum6 { const float* t[6]; float w[6]; int n; };
+__global__ void wsum6_kernel(WSum6 a, float* out) {
+    float s = 0.f;
+    for (int i = 0; i < a.n; i++) s += a.w[i] * a.t[i][0];
+    out[0] = s;
+}
+__global__ void wscale6_kernel(const float* g, WSum6 a, float* out) {
+    if ((int)threadIdx.x < a.n) out[threadIdx.x] = a.w[threadIdx.x] * g[0];
+}
+extern "C" int mh_weighted_sum(const float* t0, const float* t1, const float* t2, const float* t3, const float* t4, const float* t5,
+                               float w0, float w1, float w2, float w3, float w4, float w5, int n, float* out, mh_stream s) {
+    MH_REQUIRE(n >= 1 && n <= 6, "mh_weighted_sum: n=%d (1..6 terms)", n);
+    WSum6 a = {{t0, t1, t2, t3, t4, t5}, {w0, w1, w2, w3, w4, w5}, n};
+    hipLaunchKernelGGL(wsum6_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, a, out);
+    MH_LAUNCH_CHECK("mh_weighted_sum");
+    return MH_OK;
+}
+extern "C" int mh_weighted_sum_bwd(const float* g, float w0, float w1, float w2, float w3, float w4, float w5, int n, float* dterms,
+                                   mh_stream s) {
+    MH_REQUIRE(n >= 1 && n <= 6, "mh_weighted_sum_bwd: n=%d (1..6 terms)", n);
+    WSum6 a = {{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, {w0, w1, w2, w3, w4, w5}, n};
+    hipLaunchKernelGGL(wscale6_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, g, a, dterms);
+    MH_LAUNCH_CHECK("mh_weighted_sum_bwd");
+    return MH_OK;
+}
+
 // ------------------------------------------------------------------ style KL to N(0, I)
 __global__ __launch_bounds__(256) void kl_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ ls, float* __restrict__ out,
                                                      long n, float coef) {

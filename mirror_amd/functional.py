@@ -977,6 +977,20 @@ def _div(acc: torch.Tensor) -> torch.Tensor:
     return (acc[0] / acc[1]).reshape(())
 
 
+class WeightedSumFn(Function):
+    """total = sum_i w_i * term_i (losses/mirror_loss.py:121-127) in one launch; the backward hands w_i * g to every term."""
+
+    @staticmethod
+    def forward(ctx, weights, *terms):
+        ctx.weights, ctx.shapes = tuple(float(w) for w in weights), [t.shape for t in terms]
+        return K.weighted_sum([t.detach().float().contiguous() for t in terms], ctx.weights)
+
+    @staticmethod
+    def backward(ctx, g):
+        d = K.weighted_sum_bwd(g.contiguous().float().reshape(1), ctx.weights)
+        return (None,) + tuple(d[i].reshape(sh) for i, sh in enumerate(ctx.shapes))
+
+
 class StyleKLFn(Function):
     """coef * sum(exp(ls) + mu^2 - 1 - ls)  (losses/mirror_loss.py:105-112)."""
 

@@ -845,6 +845,30 @@ def fanout_bwd(gfull, x, alpha: float, c, B: int, T: int, D: int) -> torch.Tenso
     return dE
 
 
+def weighted_sum(terms, weights) -> torch.Tensor:
+    """sum_i weights[i] * terms[i] for up to 6 f32 scalars living in separate tensors -> 0-d tensor."""
+    n = len(terms)
+    assert 1 <= n <= 6 and len(weights) == n
+    _chk(*terms)
+    ts = [t.reshape(1) for t in terms]
+    for t in ts:
+        assert t.dtype == torch.float32
+    out = torch.empty((1,), device=ts[0].device, dtype=torch.float32)
+    ptrs = [_p(t) for t in ts] + [None] * (6 - n)
+    ws = [float(w) for w in weights] + [0.0] * (6 - n)
+    _lib.call("mh_weighted_sum", *ptrs, *ws, n, _p(out), stream=_stream())
+    return out.reshape(())
+
+
+def weighted_sum_bwd(g: torch.Tensor, weights) -> torch.Tensor:
+    n = len(weights)
+    _chk(g)
+    out = torch.empty((n,), device=g.device, dtype=torch.float32)
+    ws = [float(w) for w in weights] + [0.0] * (6 - n)
+    _lib.call("mh_weighted_sum_bwd", _p(g), *ws, n, _p(out), stream=_stream())
+    return out
+
+
 def kl_fwd(mu, ls, out, coef):
     _chk(mu, ls, out)
     _lib.call("mh_kl_fwd", _p(mu), _p(ls), _p(out), mu.numel(), coef, stream=_stream())

@@ -88,12 +88,15 @@ class MIRRORLoss(nn.Module):
         wsi_retention_loss = Fn.masked_mse(wsi_retention_emb, wsi_retention_target, wsi_mask, D)
         rna_retention_loss = Fn.masked_mse(rna_retention_emb, rna_retention_target, rna_mask, 1)
         B = wsi_mu.shape[0]
-        style_loss = (Fn.StyleKLFn.apply(wsi_mu, wsi_logstd, 0.5 / B)
-                      + Fn.StyleKLFn.apply(rna_mu, rna_logstd, 0.5 / rna_mu.shape[0]))
+        style_w = Fn.StyleKLFn.apply(wsi_mu, wsi_logstd, 0.5 / B)
+        style_r = Fn.StyleKLFn.apply(rna_mu, rna_logstd, 0.5 / rna_mu.shape[0])
         cluster_loss = Fn.SymKLFn.apply(wsi_score, rna_score, 0.5 / wsi_score.shape[0])
-        total_loss = (self.alignment_loss_weight * alignment_loss
-                      + self.wsi_retention_loss_weight * wsi_retention_loss
-                      + self.rna_retention_loss_weight * rna_retention_loss
-                      + self.style_loss_weight * style_loss
-                      + self.cluster_loss_weight * cluster_loss)
-        return total_loss, alignment_loss, wsi_retention_loss, rna_retention_loss, style_loss, cluster_loss
+        # losses/mirror_loss.py:121-127 as ONE kernel (and one in the backward) instead of ~20 scalar torch launches
+        sw = self.style_loss_weight
+        total_loss = Fn.WeightedSumFn.apply(
+            (self.alignment_loss_weight, self.wsi_retention_loss_weight, self.rna_retention_loss_weight, sw, sw, self.cluster_loss_weight),
+            alignment_loss.reshape(()), wsi_retention_loss, rna_retention_loss, style_w.reshape(()), style_r.reshape(()),
+            cluster_loss.reshape(()))
+        style_loss = (style_w.detach() + style_r.detach()).reshape(())
+        return (total_loss, alignment_loss.reshape(()), wsi_retention_loss, rna_retention_loss, style_loss,
+                cluster_loss.reshape(()))
