@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (weak scaling)")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16_pinv32", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16_pinv32", "fp32", "fp8"])
     ap.add_argument("--config", default="c2", choices=["c1", "c2"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="rank-local InfoNCE even when N>1 (reference behaviour)")
@@ -162,7 +162,7 @@ def main():
             "metric": "SSL samples/sec (slide+RNA pairs)", "value": round(value, 3), "unit": "samples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"bf16": "bf16", "bf16_pinv32": "bf16", "fp32": "f32"}[a.precision], "data": "synthetic",
+            "dtype": {"bf16": "bf16", "bf16_pinv32": "bf16", "fp32": "f32", "fp8": "fp8-fwd/bf16"}[a.precision], "data": "synthetic",
             "config": {"workload": f"BASELINE {a.config}: B={a.batch}/GPU x [{shp['N']} patch tokens x {shp['F']}-d] + "
                                    f"[{shp['G']} genes], D={shp['D']}, RNA depth {shp['L']}, train mode, "
                                    f"{'global' if (world > 1 and not a.no_gather) else 'local'}-batch InfoNCE",

@@ -93,6 +93,17 @@ int mh_layernorm_bwd(const void* dy, const void* x, const float* gamma, const fl
                      int batches, int rows_per_batch, int D, int64_t x_bs, int64_t y_bs,
                      int dt_x, int dt_dy, int dt_dx, int accumulate_dx, float* workspace, int64_t ws_floats, mh_stream s);
 
+/* ---------------------------------------------------------------- fp8 forward projections (BASELINE config 5)
+ * mh_quant_fp8: q[i] = e4m3(x[i] * 448 / max|x|) for a whole tensor (x f32 / bf16, n % 4 == 0), scale[0] = max|x| / 448
+ *               (amax_scratch: one uint32 of device scratch).
+ * mh_gemm_fp8 : C[z] = act(scale_a * scale_b * A[z] B^T + bias), v_mfma_f32_32x32x16_fp8_fp8, f32 accumulate.  A [batch][M, K] and
+ *               B [N, K] are e4m3 bytes with K contiguous (lda, ldb, a_bs in bytes); C f32 / bf16 (ldc, c_bs in elements);
+ *               K % 64 == 0, N % 128 == 0, M ragged.  Replaces the forward of nn.Linear at models/mirror.py:346 (`_fc1`), [3P]
+ *               to_qkv / to_out and the retention embed / head (:595-607) under the `fp8` precision policy. */
+int mh_quant_fp8(const void* x, int64_t n, void* q, float* scale, unsigned* amax_scratch, int dt, mh_stream s);
+int mh_gemm_fp8(const void* A, int64_t lda, int64_t a_bs, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t c_bs, int batch,
+                const float* scale_a, const float* scale_b, const float* bias, int act, int M, int N, int K, int dt_c, mh_stream s);
+
 /* ---------------------------------------------------------------- row softmax ([3P] sim.softmax(-1); Attention :95)
  * x/y: rows x cols, row stride ld (elements). In place allowed when dtypes match. */
 int mh_softmax_fwd(const void* x, void* y, int64_t rows, int cols, int64_t ldx, int64_t ldy,

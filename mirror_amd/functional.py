@@ -32,12 +32,14 @@ class Precision:
     mma: int
     act: torch.dtype
     pinv_mma: int
+    fp8_fwd: bool = False       # forward of the big WSI projections with e4m3 MFMA operands (BASELINE config 5)
 
 
 FP32 = Precision("fp32", MH_F32, f32, MH_F32)
 BF16 = Precision("bf16", MH_BF16, bf16, MH_BF16)
 BF16_PINV32 = Precision("bf16_pinv32", MH_BF16, bf16, MH_F32)
-POLICIES = {p.name: p for p in (FP32, BF16, BF16_PINV32)}
+FP8 = Precision("fp8", MH_BF16, bf16, MH_BF16, True)      # bf16 policy + fp8 forward projections; backward stays bf16
+POLICIES = {p.name: p for p in (FP32, BF16, BF16_PINV32, FP8)}
 
 # ------------------------------------------------------------------ bf16 shadows of f32 master weights
 _shadow_cache: dict = {}
@@ -161,6 +163,26 @@ def _gemm_rows(a, b, *, bias=None, act=ACT_NONE, mma, out_dtype):
     return K.gemm(a, b, bias=bias, act=act, mma=mma, out_dtype=out_dtype)
 
 
+def _fp8_linear(xa, wa, bias, act, out):
+    """out = act(xa @ wa^T + bias) with per-tensor-scaled e4m3 operands (config 5).  xa [.., R, K] bf16 (a row window of a
+    contiguous parent is quantised through the parent), wa [N, K] bf16 contiguous.  Returns False when the shape does not
+    qualify (the caller then runs the bf16 product)."""
+    N = wa.shape[0]
+    rows = xa.numel() // xa.shape[-1]
+    if rows < 1024 or not wa.is_contiguous() or wa.numel() % 4:
+        return False
+    base = xa if xa.is_contiguous() else xa._base
+    if base is None or not base.is_contiguous() or base.numel() % 4 or base.dtype != bf16:
+        return False
+    qb, sx = K.quant_fp8(base)
+    xq = qb if base is xa else qb.as_strided(xa.shape, xa.stride(), xa.storage_offset() - base.storage_offset())
+    if not K.gemm_fp8_ok(xq, N):
+        return False
+    wq, sw = K.quant_fp8(wa)
+    K.gemm_fp8(xq, sx, wq, sw, out, bias=bias, act=act)
+    return True
+
+
 # ------------------------------------------------------------------ Linear (+ReLU)
 class LinearFn(Function):
     """y = act(x @ W^T + b).  x: [R, K] or [B, R, K] (a row window of a larger buffer is fine);
@@ -172,9 +194,14 @@ class LinearFn(Function):
         wa = shadow(w, prec)
         bd = None if b is None else b.detach()
         ctx.skinny = prec.act == bf16 and K.skinny_ok(xa, wa)      # [B, D] activations: weight-streaming kernels
+        y = None
         if ctx.skinny:
             y = K.skinny_fwd(xa, wa, bd, act, out_dtype or prec.act)
-        else:
+        elif prec.fp8_fwd:
+            y = torch.empty(tuple(xa.shape[:-1]) + (wa.shape[0],), device=xa.device, dtype=out_dtype or prec.act)
+            if not _fp8_linear(xa, wa, bd, act, y):
+                y = None
+        if y is None:
             y = _gemm_rows(xa, wa.t(), bias=bd, act=act, mma=prec.mma, out_dtype=out_dtype or prec.act)
         ctx.save_for_backward(xa, wa, y if act == ACT_RELU else None, w, b)
         ctx.act, ctx.prec, ctx.has_b, ctx.x_dtype = act, prec, b is not None, x.dtype
@@ -242,7 +269,13 @@ class LinearRowsFn(Function):
     def forward(ctx, x, w, b, r0, R, prec, out_dtype):
         wa = shadow(w, prec)
         xv = x[:, r0:r0 + R]
-        y = K.gemm(xv, wa.t(), bias=None if b is None else b.detach(), mma=prec.mma, out_dtype=out_dtype or prec.act)
+        y = None
+        if prec.fp8_fwd and x.dtype == bf16:
+            y = torch.empty((x.shape[0], R, wa.shape[0]), device=x.device, dtype=out_dtype or prec.act)
+            if not _fp8_linear(xv, wa, None if b is None else b.detach(), ACT_NONE, y):
+                y = None
+        if y is None:
+            y = K.gemm(xv, wa.t(), bias=None if b is None else b.detach(), mma=prec.mma, out_dtype=out_dtype or prec.act)
         ctx.save_for_backward(x, wa, w, b)
         ctx.r0, ctx.R, ctx.prec, ctx.has_b = r0, R, prec, b is not None
         return y
@@ -459,7 +492,8 @@ class Fc1SeqFn(Function):
         xa = wsi if wsi.dtype == prec.act else K.cast(wsi.contiguous(), prec.act)
         wa = shadow(w, prec)
         seq = torch.empty((Bn, 1 + N + add_len, D), device=wsi.device, dtype=f32)
-        K.gemm(xa, wa.t(), out=seq[:, 1:1 + N], bias=b.detach(), act=ACT_RELU, mma=prec.mma)
+        if not (prec.fp8_fwd and xa.dtype == bf16 and _fp8_linear(xa, wa, b.detach(), ACT_RELU, seq[:, 1:1 + N])):
+            K.gemm(xa, wa.t(), out=seq[:, 1:1 + N], bias=b.detach(), act=ACT_RELU, mma=prec.mma)
         K.seq_finish(seq, cls.detach().reshape(-1).contiguous(), N, add_len)
         ctx.save_for_backward(xa, wa, seq, w, b)
         ctx.add_len, ctx.prec = add_len, prec

@@ -208,6 +208,45 @@ class GemmProfiler:
 gemm_profiler: Optional[GemmProfiler] = None
 
 
+# ----------------------------------------------------------------------------- fp8 forward projections (config 5)
+def quant_fp8(x: torch.Tensor):
+    """Per-tensor e4m3 quantisation: (q uint8 like x, scale f32[1]) with x ~= q * scale."""
+    _chk(x)
+    _contig(x, "quant_fp8 input")
+    if x.numel() % 4:
+        raise MirrorHipError("quant_fp8: numel must be a multiple of 4")
+    q = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+    scale = torch.empty((1,), device=x.device, dtype=torch.float32)
+    scratch = torch.empty((1,), device=x.device, dtype=torch.int32)
+    _lib.call("mh_quant_fp8", _p(x), x.numel(), _p(q), _p(scale), _p(scratch), dt(x), stream=_stream())
+    return q, scale
+
+
+def gemm_fp8_ok(a: torch.Tensor, n_out: int) -> bool:
+    """a [..., R, K] as e4m3 bytes: K % 64 == 0, N % 128 == 0, rows K-contiguous, <= one batch dim with 16-byte strides."""
+    Kd = a.shape[-1]
+    if Kd % 64 or n_out % 128 or a.stride(-1) != 1 or a.dim() not in (2, 3) or a.stride(-2) % 16:
+        return False
+    return a.dim() == 2 or a.stride(0) % 16 == 0
+
+
+def gemm_fp8(aq: torch.Tensor, sa: torch.Tensor, wq: torch.Tensor, sw: torch.Tensor, out: torch.Tensor,
+             bias: Optional[torch.Tensor] = None, act: int = ACT_NONE) -> torch.Tensor:
+    """out[..., R, N] = act(sa * sw * aq @ wq^T + bias); aq uint8 [R, K] or [B, R, K] (a row window is fine), wq uint8 [N, K]
+    contiguous, out f32 / bf16 with unit column stride (a row window of a larger buffer is fine)."""
+    _chk(aq, wq, out, sa, sw, bias)
+    N, Kd = wq.shape
+    assert aq.dtype == torch.uint8 and wq.dtype == torch.uint8 and wq.is_contiguous() and aq.shape[-1] == Kd
+    assert out.stride(-1) == 1 and out.shape[-1] == N and out.shape[:-1] == aq.shape[:-1]
+    if aq.dim() == 3:
+        batch, M, a_bs, c_bs = aq.shape[0], aq.shape[1], aq.stride(0), out.stride(0)
+    else:
+        batch, M, a_bs, c_bs = 1, aq.shape[0], 0, 0
+    _lib.call("mh_gemm_fp8", _p(aq), aq.stride(-2), a_bs, _p(wq), Kd, _p(out), out.stride(-2), c_bs, batch, _p(sa), _p(sw), _p(bias),
+              act, M, N, Kd, dt(out), stream=_stream())
+    return out
+
+
 # ----------------------------------------------------------------------------- skinny-M linears
 def skinny_ok(x2d: torch.Tensor, w: torch.Tensor) -> bool:
     """bf16 x [M<=32, K] (row-strided ok) against bf16 W [N, K] contiguous, K % 32 == 0, 16-B aligned rows."""

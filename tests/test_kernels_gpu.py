@@ -955,3 +955,33 @@ def test_dropout_add_equals_dropout_then_add():
     kept = float((y2 != a).float().mean())
     assert 0.70 < kept < 0.80
     Fn._res_grads.clear()
+
+
+@pytest.mark.parametrize("M,N,Kd,batch", [(300, 256, 128, 1), (1100, 128, 64, 1), (137, 384, 192, 3)])
+def test_fp8_quant_and_gemm(M, N, Kd, batch):
+    """BASELINE config 5 pieces: per-tensor e4m3 quantisation (bit-exact against torch.float8_e4m3fn) and the fp8 MFMA product
+    (f32 accumulate) with bias / ReLU, ragged M, a batch of row windows of a larger buffer."""
+    gen = g(101)
+    e4 = torch.float8_e4m3fn
+    x = (torch.randn(batch, M + 5, Kd, generator=gen) * 3).bfloat16()
+    w = torch.randn(N, Kd, generator=gen).bfloat16()
+    bias = torch.randn(N, generator=gen)
+    xq, sx = K.quant_fp8(x.to(DEV))
+    wq, sw = K.quant_fp8(w.to(DEV))
+    for t, q, sc in ((x, xq, sx), (w, wq, sw)):
+        amax = t.float().abs().max()
+        qr = (t.float() * (448.0 / amax)).clamp(-448, 448).to(e4)
+        assert torch.equal(q.cpu().view(e4).float(), qr.float()), "quantised bytes differ"
+        close(sc, (amax / 448.0).reshape(1), 1e-7, 0, "scale")
+    xr = xq.cpu().view(e4).float()[:, 2:2 + M]            # a row window, like to_out(x)[:, -n:]
+    ref = torch.relu(xr.double() @ wq.cpu().view(e4).float().double().t() * float(sx) * float(sw) + bias.double())
+    out = torch.full((batch, M + 1, N), -7.0, device=DEV)
+    K.gemm_fp8(xq[:, 2:2 + M], sx, wq, sw, out[:, 1:], bias=bias.to(DEV), act=1)
+    # products of e4m3 values are exact in f32, but the MFMA's 16-term dot product is not accumulated at full f32 precision
+    # (measured: ~1e-4 relative to the row / column norms), hence the tolerance
+    close(out[:, 1:], ref, 1e-3, 2e-2, "fp8 gemm")
+    assert float(out[:, 0].max()) == -7.0                 # nothing written outside the window
+    ob = torch.empty((batch, M, N), device=DEV, dtype=torch.bfloat16)
+    K.gemm_fp8(xq[:, 2:2 + M], sx, wq, sw, ob)
+    ref2 = xr.double() @ wq.cpu().view(e4).float().double().t() * float(sx) * float(sw)
+    close(ob, ref2.float().bfloat16().double(), 2e-2, 2e-2, "fp8 gemm bf16 out")      # within one bf16 ulp

@@ -244,3 +244,28 @@ def test_key_padding_mask_bf16_policy_runs_and_is_close():
     got = [float(x.detach()) for x in MIRRORLoss()(*outs)]
     np.testing.assert_allclose(got, ref, rtol=5e-2)
     MIRRORLoss()(*outs)[0].backward()
+
+
+def test_fp8_forward_policy_is_close_and_trains():
+    """BASELINE config 5: e4m3 MFMA operands for the forward WSI projections, bf16 backward.  Loss terms stay near the
+    oracle (reported, not the parity gate) and a training step runs."""
+    from mirror_amd.engine import TrainEngine
+    case = ModelCase("c1")
+    outs_ref = O.mirror_forward(case.sd, case.cfg, case.wsi, case.rna, case.noise, *case.ratios)
+    ref = np.array([float(x) for x in O.mirror_loss(outs_ref, DEFAULT_W)])
+    model = build(case, "fp8")
+    noise = {k: v.to(DEV) for k, v in case.noise.items()}
+    used = []
+    orig = M.mirror.__globals__["Fn"].K.gemm_fp8
+    M.mirror.__globals__["Fn"].K.gemm_fp8 = lambda *a, **k: (used.append(1), orig(*a, **k))[1]
+    try:
+        outs = model(case.wsi.to(DEV).bfloat16(), case.rna.to(DEV), wsi_mask_ratio=case.ratios[0], rna_mask_ratio=case.ratios[1],
+                     noise=noise)
+    finally:
+        M.mirror.__globals__["Fn"].K.gemm_fp8 = orig
+    assert len(used) >= 6, f"fp8 products launched: {len(used)}"       # _fc1, 3 x to_qkv, 3 x to_out, retention embed / head
+    got = np.array([float(x.detach()) for x in MIRRORLoss()(*outs)])
+    np.testing.assert_allclose(got, ref, rtol=8e-2)
+    eng = TrainEngine(model.train(), MIRRORLoss(), lr=1e-4, precision="fp8", graph=False)
+    l0 = eng.step(case.wsi.to(DEV).bfloat16(), case.rna.to(DEV))
+    assert all(torch.isfinite(x) for x in l0)
