@@ -62,6 +62,10 @@ typedef struct {
                                      A batch whose sC1 = sC2 = 0 with accumulate=1 also reduces into C with atomics. */
     const void* R; float rcoef;   /* optional addend: C (+)= ... + rcoef * R; R has C's dtype, ldc and batch strides
                                      (lets the pinv polynomial 15I - 7P + P.P come out of one launch) */
+    float* workspace;             /* optional scratch for reductions into one C (split-K, batch broadcast): with at least
+                                     parts * M * N floats (parts = splits * batch) the large-tile kernel writes plain
+                                     partial tiles there and a fold pass adds them to C; NULL / too small: f32 atomics */
+    int64_t workspace_floats;
 } mh_gemm_desc;
 int mh_gemm(const mh_gemm_desc* d, mh_stream s);
 

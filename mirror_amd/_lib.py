@@ -28,6 +28,7 @@ class GemmDesc(C.Structure):
         ("alpha", C.c_float), ("diag", C.c_float),
         ("act", C.c_int32), ("accumulate", C.c_int32), ("split_k", C.c_int32),
         ("R", C.c_void_p), ("rcoef", C.c_float),
+        ("workspace", C.c_void_p), ("workspace_floats", C.c_int64),
     ]
 
 

@@ -13,6 +13,7 @@ static int launch_one(const mh_gemm_desc* d, hipStream_t s) {
     a.batch2 = d->batch2;
     a.alpha = d->alpha; a.diag = d->diag; a.act = d->act; a.accumulate = d->accumulate;
     a.R = d->R; a.rcoef = d->rcoef;
+    a.ws = d->workspace; a.ws_floats = d->workspace_floats;
     const int BK = d->mma == MH_BF16 ? 64 : 16;
     const int kps = mh_cdiv(mh_cdiv(d->K, split), BK) * BK;
     a.k_per_split = kps;

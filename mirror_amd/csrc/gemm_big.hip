@@ -248,12 +248,42 @@ __global__ __launch_bounds__(NTB) void gemm_big_kernel(GemmArgs g) {
         return;
     }
     if (g.atomic) {
-        if constexpr (sizeof(TC) == 4)
-            epilogue_atomic_big(g, C, acc, tile_m * BIG + wm * BWM * 32, tile_n * BIG + wn * BWN * 32, lane);
+        if constexpr (sizeof(TC) == 4) {
+            if (g.ws) {
+                // partial tile -> workspace [part][M][N] with plain 16-byte stores (part = z * splits + split); 16.7 M same-
+                // matrix f32 atomics of a 64-way split cost more than the whole K loop, a fold pass over the partials does not
+                GemmArgs gp = g;
+                gp.ldc = g.N;
+                gp.alpha = g.alpha;
+                float* P = g.ws + ((long)z * gridDim.y + split) * (long)g.M * g.N;
+                epilogue_big<float, 0>(gp, P, acc, smem, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, false);
+            } else {
+                epilogue_atomic_big(g, C, acc, tile_m * BIG + wm * BWM * 32, tile_n * BIG + wn * BWN * 32, lane);
+            }
+        }
     } else if (g.accumulate) {
         epilogue_big<TC, 1>(g, C, acc, smem, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, lead);
     } else {
         epilogue_big<TC, 0>(g, C, acc, smem, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, lead);
+    }
+}
+
+// C[r][c] += sum_p P[p][r][c]: quads, 8 partials in flight
+__global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restrict__ P, int parts, long mn, float* __restrict__ C, long ldc,
+                                                            int N) {
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q * 4 < mn; q += (long)gridDim.x * 256) {
+        const long i = q * 4, r = i / N, c = i % N;
+        f32x4 s = *reinterpret_cast<const f32x4*>(C + r * ldc + c);
+        int p = 0;
+        for (; p + 8 <= parts; p += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const f32x4*>(P + (long)(p + u) * mn + i);
+#pragma unroll
+            for (int u = 0; u < 8; u++) s += v[u];
+        }
+        for (; p < parts; p++) s += *reinterpret_cast<const f32x4*>(P + (long)p * mn + i);
+        *reinterpret_cast<f32x4*>(C + r * ldc + c) = s;
     }
 }
 
@@ -262,10 +292,18 @@ void launch_big(GemmArgs& a, int akc, int bkc, int batch, hipStream_t s) {
     a.tiles_m = (a.M + BIG - 1) / BIG;     // a ragged last row tile is allowed when A rows are K-contiguous
     a.tiles_n = a.N / BIG;
     dim3 grid(a.tiles_m * a.tiles_n, a.split_k, batch);
+    // reduction into one C: partial tiles in the caller's workspace when it is large enough, f32 atomics otherwise
+    const long parts = (long)a.split_k * batch, mn = (long)a.M * a.N;
+    const bool partial = a.atomic && a.ws && a.M % BIG == 0 && a.ws_floats >= parts * mn && ((uintptr_t)a.ws & 15) == 0 && a.vecC &&
+                         a.sC1 == 0 && a.sC2 == 0 && parts >= 8;
+    if (!partial) a.ws = nullptr;
     if (akc && bkc) hipLaunchKernelGGL((gemm_big_kernel<TC, true, true>), grid, dim3(NTB), 0, s, a);
     else if (akc) hipLaunchKernelGGL((gemm_big_kernel<TC, true, false>), grid, dim3(NTB), 0, s, a);
     else if (bkc) hipLaunchKernelGGL((gemm_big_kernel<TC, false, true>), grid, dim3(NTB), 0, s, a);
     else hipLaunchKernelGGL((gemm_big_kernel<TC, false, false>), grid, dim3(NTB), 0, s, a);
+    if (partial)
+        hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)min((long)mh_cdiv(mn / 4, 256), 2048L)), dim3(256), 0, s, (const float*)a.ws,
+                           (int)parts, mn, (float*)a.C, (long)a.ldc, a.N);
 }
 
 }  // namespace

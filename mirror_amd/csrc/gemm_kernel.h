@@ -35,6 +35,7 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int vecC;    // C rows are 16-B aligned (LDS-staged wide-store epilogue allowed)
     const void* R; float rcoef;   // optional addend rcoef * R, R laid out exactly like C (same dtype and strides)
+    float* ws; long ws_floats;    // split-K partial tiles go here instead of f32 atomics (gemm_big.hip), then a fold pass
 };
 
 template <int MMA, bool KC, int ROWS>

@@ -126,6 +126,14 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *
         if R.dtype != o4.dtype or R.numel() != o4.numel() or tuple(R.stride()) != tuple(out.stride()):
             raise MirrorHipError("gemm: R must have the output's dtype, shape and strides")
         d.R, d.rcoef = R.data_ptr(), rcoef
+    # reductions into one f32 C (split-K / a batch that broadcasts into C) on the large-tile kernel: give it room for plain
+    # partial tiles + a fold pass (f32 atomics of a 64-way split cost more than the K loop).  `ws` stays alive until the call
+    # is enqueued; the caching allocator keeps the block valid for stream-ordered use.
+    parts = d.split_k * B1 * B2 if (so[0] == 0 or B1 == 1) and (so[1] == 0 or B2 == 1) else d.split_k
+    if (accumulate and parts >= 8 and o4.dtype == torch.float32 and mma == MH_BF16 and M % 256 == 0 and N % 256 == 0
+            and a4.dtype == torch.bfloat16 and b4.dtype == torch.bfloat16 and parts * M * N <= (1 << 27) and _GEMM_WS):
+        ws = torch.empty((parts * M * N,), device=a.device, dtype=torch.float32)
+        d.workspace, d.workspace_floats = ws.data_ptr(), ws.numel()
     prof = gemm_profiler
     if prof is None:
         _lib.call("mh_gemm", C.byref(d), stream=_stream())
@@ -134,6 +142,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *
     return out
 
 
+_GEMM_WS = os.environ.get("MH_GEMM_WS", "1") != "0"      # A/B switch: split-K partials in a workspace vs f32 atomics
 _TN = {MH_F32: "float", MH_BF16: "bf16"}
 
 
