@@ -177,17 +177,22 @@ int mh_pinv_chain_bwd(const void* XP, const void* saved, const void* dzf, void* 
  * attn3_fwd: av = softmax_n(scale q_l k^T) v, lse3.
  * attn1_bwd: writes the q block of dqkv and delta1; ADDS (f32 atomics) into dw2 and the k_l half of dlm.
  * attn3_bwd: writes the k and v blocks of dqkv and delta3 [B,h,m] f32 (scratch); ADDS into the q_l half of dlm. */
-int mh_nys_attn1_fwd(const void* qkv, const void* lm, const void* w2, void* out, float* lse1, int B, int h, int n_p, int m,
-                     int dh, float scale, int accumulate, mh_stream s);
+/* mrow [B, n_p] / mlm [B, m] (f32 0 / 1, both or neither): the package's key-padding mask — valid sequence rows and landmark
+ * groups that contain a valid row.  A logit whose row or landmark is invalid is masked_fill'ed before the softmax (a fully
+ * masked row comes out uniform, as in the package) and gets no gradient.  NULL: no mask. */
+int mh_nys_attn1_fwd(const void* qkv, const void* lm, const void* w2, void* out, float* lse1, const float* mrow, const float* mlm,
+                     int B, int h, int n_p, int m, int dh, float scale, int accumulate, mh_stream s);
 /* attn3_fwd cuts the sequence into ranges (one workgroup each) when B*h alone would not fill the chip; the partial results
  * live in `workspace` (mh_nys_attn3_ws_floats(B, h, n_p) floats; NULL / too small: one workgroup per (b, h)). */
 int64_t mh_nys_attn3_ws_floats(int B, int h, int n_p);
-int mh_nys_attn3_fwd(const void* qkv, const void* lm, float* av, float* lse3, float* workspace, int64_t ws_floats, int B, int h,
-                     int n_p, int m, int dh, float scale, mh_stream s);
+int mh_nys_attn3_fwd(const void* qkv, const void* lm, float* av, float* lse3, float* workspace, int64_t ws_floats,
+                     const float* mrow, const float* mlm, int B, int h, int n_p, int m, int dh, float scale, mh_stream s);
 int mh_nys_attn1_bwd(const void* qkv, const void* lm, const void* w2, const void* dout, const float* lse1, float* delta1,
-                     void* dqkv, float* dw2, float* dlm, int B, int h, int n_p, int m, int dh, float scale, mh_stream s);
+                     void* dqkv, float* dw2, float* dlm, const float* mrow, const float* mlm, int B, int h, int n_p, int m, int dh,
+                     float scale, mh_stream s);
 int mh_nys_attn3_bwd(const void* qkv, const void* lm, const float* av, const void* dav, const float* lse3, float* delta3,
-                     void* dqkv, float* dlm, int B, int h, int n_p, int m, int dh, float scale, mh_stream s);
+                     void* dqkv, float* dlm, const float* mrow, const float* mlm, int B, int h, int n_p, int m, int dh, float scale,
+                     mh_stream s);
 /* T = d*I - P  (batched [BH,m,m] f32) */
 int mh_eye_minus(const float* P, float* T, float d, int BH, int m, mh_stream s);
 

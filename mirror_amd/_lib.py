@@ -57,10 +57,10 @@ _SIGS = {
     "mh_pinv_chain_pack": [P, P, I, I],
     "mh_pinv_chain_fwd": [P, P, P, I, I, I],
     "mh_pinv_chain_bwd": [P, P, P, P, P, P, I, I, I],
-    "mh_nys_attn1_fwd": [P, P, P, P, P, I, I, I, I, I, F, I],
-    "mh_nys_attn3_fwd": [P, P, P, P, P, L, I, I, I, I, I, F],
-    "mh_nys_attn1_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, F],
-    "mh_nys_attn3_bwd": [P, P, P, P, P, P, P, P, I, I, I, I, I, F],
+    "mh_nys_attn1_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, F, I],
+    "mh_nys_attn3_fwd": [P, P, P, P, P, L, P, P, I, I, I, I, I, F],
+    "mh_nys_attn1_bwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F],
+    "mh_nys_attn3_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F],
     "mh_seq_finish": [P, P, I, I, I, I, I],
     "mh_seq_finish_bwd": [P, P, I, I, I, I, I],
     "mh_ppeg_merge": [P, P, P, P, P, P, P, P, I],

@@ -150,9 +150,26 @@ __device__ __forceinline__ void store_row4(bf16_t* p, const f32x16& a, int g) {
     *reinterpret_cast<u32x2*>(p) = w;
 }
 
+// Key-padding mask ([3P] NystromAttention.forward(x, mask=...), BASELINE config 4): mrow [B, n_p] and mlm [B, m] hold 0 / 1
+// floats (valid sequence rows / landmark groups with at least one valid row); an entry of sim1 (row n, landmark l) or
+// sim3 (landmark l, key n) is valid iff mrow[n] and mlm[l].  Invalid logits take NEG_FILL — the package's
+// masked_fill_(-finfo.max) in log2 units, small enough in magnitude that `fill + log2(row sum)` stays exact, so the
+// backward's exp2(fill - lse) reproduces the uniform row of a fully masked query — and their gradient is zero.
+constexpr float NEG_FILL = -1.0e6f;
+__device__ __forceinline__ void mask_fill16(f32x16& l2, const f32x16& vr, float vl) {
+#pragma unroll
+    for (int e = 0; e < 16; e++) l2[e] = (vr[e] * vl != 0.f) ? l2[e] : NEG_FILL;
+}
+__device__ __forceinline__ void mask_zero16(f32x16& d, const f32x16& vr, float vl) {
+#pragma unroll
+    for (int e = 0; e < 16; e++) d[e] = (vr[e] * vl != 0.f) ? d[e] : 0.f;
+}
+
 struct Geo {
     int h, n_p, D;
     float scale, scale2;    // scale2 = scale * log2(e)
+    const float* mrow;      // key-padding mask rows [B, n_p] (NULL: no mask)
+    const float* mlm;       // valid landmarks [B, m]
     int accumulate;     // attn1 forward: add to `out` (the res_conv term is already there) instead of overwriting it
 };
 
@@ -161,15 +178,19 @@ struct Geo {
 // The landmark images (k_l, w2: 64 KB) are staged ONCE per workgroup; after that every wave walks its own 32-row blocks
 // of the sequence (block = first + i * 4 * splits) with the q fragments read straight from HBM one block ahead — no
 // LDS writes and no barriers in the loop.  (One 128-row tile per workgroup spent 3x longer staging than computing.)
+template <bool MASKED>
 __global__ __launch_bounds__(NT) void nys_a1_fwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ lm,
                                                         const bf16_t* __restrict__ w2, bf16_t* __restrict__ out,
                                                         float* __restrict__ lse1, Geo g) {
     __shared__ __attribute__((aligned(16))) bf16_t s_kl_[NM * NP];
     __shared__ __attribute__((aligned(16))) bf16_t s_w2_[NM * NP];
+    __shared__ __attribute__((aligned(16))) float s_mlm_[NM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hl = lane >> 5;
     const int bh = blockIdx.y, b = bh / g.h, hd = bh % g.h, D = g.D;
     stage_rows<NM>(s_kl_, lm + (long)b * NM * 2 * D + D + hd * ND, 2 * D, tid);
     stage_rows<NM>(s_w2_, w2 + (long)bh * NM * ND, ND, tid);
+    constexpr bool masked = MASKED;
+    s_mlm_[tid] = masked ? g.mlm[(long)b * NM + tid] : 1.f;
     const int nblk = g.n_p / 32, stride = 4 * gridDim.x;
     int rb = 4 * blockIdx.x + wave;
     const bf16_t* qb = qkv + (long)b * g.n_p * 3 * D + hd * ND;
@@ -188,6 +209,8 @@ __global__ __launch_bounds__(NT) void nys_a1_fwd_kernel(const bf16_t* __restrict
         asm volatile("" : "+v"(opq));
         const bf16_t* s_kl = s_kl_ + opq;
         const bf16_t* s_w2 = s_w2_ + opq;
+        const float* s_mlm = s_mlm_ + opq;
+        const float mr = masked ? g.mrow[(long)b * g.n_p + row] : 1.f;
         bf16x8 qf[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) qf[ks] = qn[ks];
@@ -211,9 +234,15 @@ __global__ __launch_bounds__(NT) void nys_a1_fwd_kernel(const bf16_t* __restrict
             f32x16 sb = zero16();             // S^T[landmark 32 blk ..][q row]
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) sb = MFMA(frag_kc(s_kl, 32 * blk, 16 * ks, lane), qf[ks], sb);
+            float sc2 = g.scale2;
+            if (masked) {                                          // logits to log2 units first, invalid ones to NEG_FILL
+                sb = sb * g.scale2;
+                mask_fill16(sb, rowvals16(s_mlm + 32 * blk, hl), mr);
+                sc2 = 1.f;
+            }
             float mx = vmax16(sb);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float mnew = fmaxf(mrun, mx * g.scale2);         // running max in log2 units
+            const float mnew = fmaxf(mrun, mx * sc2);              // running max in log2 units
             if (__builtin_amdgcn_ballot_w64(mnew != mrun)) {       // rescale only when some row's max moved
                 const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
                 lrun *= alpha;
@@ -221,7 +250,7 @@ __global__ __launch_bounds__(NT) void nys_a1_fwd_kernel(const bf16_t* __restrict
                 o[1] *= alpha;
                 mrun = mnew;
             }
-            sb = fma_splat(sb, g.scale2, -mrun);
+            sb = fma_splat(sb, sc2, -mrun);
             exp2_16(sb);
             lrun += vsum16(sb);               // per lane half; the halves are joined once at the end
             const bf16x8 p0 = pack8<0>(sb), p1 = pack8<1>(sb);
@@ -253,16 +282,20 @@ __global__ __launch_bounds__(NT) void nys_a1_fwd_kernel(const bf16_t* __restrict
 
 // ============================================================================ attn1 backward, dq + delta (N kernel)
 // grid (splits, B h), same walk as the forward.  dS1 = P1 o (dO w2^T - delta) scale, delta[n] = sum_l P1 dP1;  dq = dS1 k_l
+template <bool MASKED>
 __global__ __launch_bounds__(NT, 2) void nys_a1_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ lm,
                                                            const bf16_t* __restrict__ w2, const bf16_t* __restrict__ dout,
                                                            const float* __restrict__ lse1, float* __restrict__ delta1,
                                                            bf16_t* __restrict__ dqkv, Geo g) {
     __shared__ __attribute__((aligned(16))) bf16_t s_kl_[NM * NP];
     __shared__ __attribute__((aligned(16))) bf16_t s_w2_[NM * NP];
+    __shared__ __attribute__((aligned(16))) float s_mlm_[NM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hl = lane >> 5;
     const int bh = blockIdx.y, b = bh / g.h, hd = bh % g.h, D = g.D;
     stage_rows<NM>(s_kl_, lm + (long)b * NM * 2 * D + D + hd * ND, 2 * D, tid);
     stage_rows<NM>(s_w2_, w2 + (long)bh * NM * ND, ND, tid);
+    constexpr bool masked = MASKED;
+    s_mlm_[tid] = masked ? g.mlm[(long)b * NM + tid] : 1.f;
     const int nblk = g.n_p / 32, stride = 4 * gridDim.x;
     int rb = 4 * blockIdx.x + wave;
     const bf16_t* qb = qkv + (long)b * g.n_p * 3 * D + hd * ND;
@@ -285,6 +318,8 @@ __global__ __launch_bounds__(NT, 2) void nys_a1_bwd_dq_kernel(const bf16_t* __re
         asm volatile("" : "+v"(opq));
         const bf16_t* s_kl = s_kl_ + opq;
         const bf16_t* s_w2 = s_w2_ + opq;
+        const float* s_mlm = s_mlm_ + opq;
+        const float mr = masked ? g.mrow[(long)b * g.n_p + row] : 1.f;
         bf16x8 qf[4], gf[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) { qf[ks] = qn[ks]; gf[ks] = gn[ks]; }
@@ -304,7 +339,13 @@ __global__ __launch_bounds__(NT, 2) void nys_a1_bwd_dq_kernel(const bf16_t* __re
             s[blk] = zero16();
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) s[blk] = MFMA(frag_kc(s_kl, 32 * blk, 16 * ks, lane), qf[ks], s[blk]);
-            s[blk] = fma_splat(s[blk], g.scale2, -lse2);
+            if (masked) {
+                s[blk] = s[blk] * g.scale2;
+                mask_fill16(s[blk], rowvals16(s_mlm + 32 * blk, hl), mr);
+                s[blk] = fma_splat(s[blk], 1.f, -lse2);
+            } else {
+                s[blk] = fma_splat(s[blk], g.scale2, -lse2);
+            }
             exp2_16(s[blk]);
         }
         // pass 1: delta = sum_l P dP   (dP^T[landmark][q row] = w2 dO^T, recomputed in pass 2 instead of held)
@@ -326,6 +367,7 @@ __global__ __launch_bounds__(NT, 2) void nys_a1_bwd_dq_kernel(const bf16_t* __re
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) dp = MFMA(frag_kc(s_w2, 32 * blk, 16 * ks, lane), gf[ks], dp);
             dp = s[blk] * fma_splat(dp, g.scale, -del * g.scale);
+            if (masked) mask_zero16(dp, rowvals16(s_mlm + 32 * blk, hl), mr);
             const bf16x8 d0 = pack8<0>(dp), d1 = pack8<1>(dp);
 #pragma unroll
             for (int nb = 0; nb < 2; nb++) {
@@ -349,6 +391,7 @@ __device__ __forceinline__ void atomic_tile(float* dst, long ld, const f32x16& a
 
 // ============================================================================ attn1 backward, dw2 + dk_l (L kernel)
 // grid (splits, B h); wave w owns landmarks [64 w, 64 w + 64).  dw2 = P1^T dO,  dk_l = dS1^T q  (f32 atomics)
+template <bool MASKED>
 __global__ __launch_bounds__(NT) void nys_a1_bwd_dw_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ lm,
                                                            const bf16_t* __restrict__ w2, const bf16_t* __restrict__ dout,
                                                            const float* __restrict__ lse1, const float* __restrict__ delta1,
@@ -358,11 +401,15 @@ __global__ __launch_bounds__(NT) void nys_a1_bwd_dw_kernel(const bf16_t* __restr
     __shared__ __attribute__((aligned(16))) bf16_t s_g[TR * NP];
     __shared__ __attribute__((aligned(16))) float s_lse[TR];
     __shared__ __attribute__((aligned(16))) float s_del[TR];
+    __shared__ __attribute__((aligned(16))) float s_mr[TR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hl = lane >> 5;
     const int bh = blockIdx.y, b = bh / g.h, hd = bh % g.h, D = g.D;
     const int ntiles = g.n_p / TR;
     const int t0 = blockIdx.x * tiles_per_wg, t1 = min(t0 + tiles_per_wg, ntiles);
     if (t0 >= t1) return;
+    constexpr bool masked = MASKED;
+    float ml[2] = {1.f, 1.f};
+    if (masked) { ml[0] = g.mlm[(long)b * NM + 64 * wave + c]; ml[1] = g.mlm[(long)b * NM + 64 * wave + 32 + c]; }
     const bf16_t* klb = lm + (long)b * NM * 2 * D + D + hd * ND;
     const bf16_t* w2b = w2 + (long)bh * NM * ND;
     bf16x8 klf[2][4], w2f[2][4];
@@ -397,6 +444,7 @@ __global__ __launch_bounds__(NT) void nys_a1_bwd_dw_kernel(const bf16_t* __restr
         if (tid < TR) {
             s_lse[tid] = rl;
             s_del[tid] = rd;
+            s_mr[tid] = masked ? g.mrow[(long)b * g.n_p + (long)t * TR + tid] : 1.f;
         }
         __syncthreads();
         if (t + 1 < t1) {
@@ -418,9 +466,19 @@ __global__ __launch_bounds__(NT) void nys_a1_bwd_dw_kernel(const bf16_t* __restr
                     s = MFMA(frag_kc(s_q, 32 * i, 16 * ks, lane), klf[j][ks], s);
                     dp = MFMA(frag_kc(s_g, 32 * i, 16 * ks, lane), w2f[j][ks], dp);
                 }
-                s = s * g.scale2 - lv;
-                exp2_16(s);
-                dp = s * (dp * g.scale - dv);
+                if (masked) {
+                    const f32x16 vr = rowvals16(s_mr + 32 * i, hl);
+                    s = s * g.scale2;
+                    mask_fill16(s, vr, ml[j]);
+                    s = s - lv;
+                    exp2_16(s);
+                    dp = s * (dp * g.scale - dv);
+                    mask_zero16(dp, vr, ml[j]);
+                } else {
+                    s = s * g.scale2 - lv;
+                    exp2_16(s);
+                    dp = s * (dp * g.scale - dv);
+                }
                 const bf16x8 p0 = pack8<0>(s), p1 = pack8<1>(s), d0 = pack8<0>(dp), d1 = pack8<1>(dp);
 #pragma unroll
                 for (int nb = 0; nb < 2; nb++) {
@@ -450,14 +508,19 @@ __global__ __launch_bounds__(NT) void nys_a1_bwd_dw_kernel(const bf16_t* __restr
 // ranges of tiles: each workgroup leaves its unnormalised O, running max and sum in `part` and nys_a3_combine_kernel
 // merges them (splits == 1: finished here, `part` unused).
 constexpr int A3_PART = NM * (ND + 2);     // floats per (b, h, split): O [256][64], m [256], l [256]
+template <bool MASKED>
 __global__ __launch_bounds__(NT, 2) void nys_a3_fwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ lm,
                                                         float* __restrict__ av, float* __restrict__ lse3, float* __restrict__ part,
                                                         Geo g, int tiles_per_wg) {
     __shared__ __attribute__((aligned(16))) bf16_t s_k[TR * NP];
     __shared__ __attribute__((aligned(16))) bf16_t s_v[TR * NP];
+    __shared__ __attribute__((aligned(16))) float s_mr[TR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hl = lane >> 5;
     const int bh = blockIdx.y, b = bh / g.h, hd = bh % g.h, D = g.D;
     const int t0 = blockIdx.x * tiles_per_wg, t1 = min(t0 + tiles_per_wg, g.n_p / TR);
+    constexpr bool masked = MASKED;
+    float ml[2] = {1.f, 1.f};
+    if (masked) { ml[0] = g.mlm[(long)b * NM + 64 * wave + c]; ml[1] = g.mlm[(long)b * NM + 64 * wave + 32 + c]; }
     const bf16_t* qlb = lm + (long)b * NM * 2 * D + hd * ND;
     bf16x8 qlf[2][4];
 #pragma unroll
@@ -480,6 +543,7 @@ __global__ __launch_bounds__(NT, 2) void nys_a3_fwd_kernel(const bf16_t* __restr
         __syncthreads();
         tile_store<TR>(rk, s_k, tid);
         tile_store<TR>(rv, s_v, tid);
+        if (tid < TR) s_mr[tid] = masked ? g.mrow[(long)b * g.n_p + (long)t * TR + tid] : 1.f;
         __syncthreads();
         if (t + 1 < t1) {
             tile_load<TR>(rk, kb + (long)(t + 1) * TR * 3 * D, 3 * D, tid);
@@ -496,10 +560,15 @@ __global__ __launch_bounds__(NT, 2) void nys_a3_fwd_kernel(const bf16_t* __restr
                     s[i] = zero16();
 #pragma unroll
                     for (int ks = 0; ks < 4; ks++) s[i] = MFMA(frag_kc(s_k, 64 * hf + 32 * i, 16 * ks, lane), qlf[j][ks], s[i]);
+                    if (masked) {
+                        s[i] = s[i] * g.scale2;
+                        mask_fill16(s[i], rowvals16(s_mr + 64 * hf + 32 * i, hl), ml[j]);
+                    }
                     mx = fmaxf(mx, vmax16(s[i]));
                 }
+                const float sc2 = masked ? 1.f : g.scale2;
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                const float mnew = fmaxf(mrun[j], mx * g.scale2);      // running max in log2 units
+                const float mnew = fmaxf(mrun[j], mx * sc2);           // running max in log2 units
                 if (__builtin_amdgcn_ballot_w64(mnew != mrun[j])) {    // rescale only when some landmark's max moved
                     const float alpha = __builtin_amdgcn_exp2f(mrun[j] - mnew);
                     lrun[j] *= alpha;
@@ -509,7 +578,7 @@ __global__ __launch_bounds__(NT, 2) void nys_a3_fwd_kernel(const bf16_t* __restr
                 }
 #pragma unroll
                 for (int i = 0; i < 2; i++) {
-                    s[i] = fma_splat(s[i], g.scale2, -mrun[j]);
+                    s[i] = fma_splat(s[i], sc2, -mrun[j]);
                     exp2_16(s[i]);
                 }
                 lrun[j] += vsum16(s[0] + s[1]);    // per lane half; the halves are joined once at the end
@@ -594,6 +663,7 @@ __global__ __launch_bounds__(256) void nys_delta3_kernel(const float* __restrict
 // ============================================================================ attn3 backward, dk + dv (N kernel)
 // grid (splits, B h), same walk as attn1.  P3 = exp(scale q_l k^T - lse3), dv = P3^T dav,
 // dS3 = P3 o (dav v^T - delta3) scale, dk = dS3^T q_l
+template <bool MASKED>
 __global__ __launch_bounds__(NT, 2) void nys_a3_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ lm,
                                                             const float* __restrict__ delta3, const bf16_t* __restrict__ dav,
                                                             const float* __restrict__ lse3, bf16_t* __restrict__ dqkv, Geo g) {
@@ -601,12 +671,15 @@ __global__ __launch_bounds__(NT, 2) void nys_a3_bwd_dkv_kernel(const bf16_t* __r
     __shared__ __attribute__((aligned(16))) bf16_t s_g_[NM * NP];
     __shared__ __attribute__((aligned(16))) float s_lse_[NM];
     __shared__ __attribute__((aligned(16))) float s_del_[NM];
+    __shared__ __attribute__((aligned(16))) float s_mlm_[NM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hl = lane >> 5;
     const int bh = blockIdx.y, b = bh / g.h, hd = bh % g.h, D = g.D;
     stage_rows<NM>(s_ql_, lm + (long)b * NM * 2 * D + hd * ND, 2 * D, tid);
     stage_rows<NM>(s_g_, dav + (long)bh * NM * ND, ND, tid);
     s_del_[tid] = delta3[(long)bh * NM + tid] * g.scale;       // thread = landmark
     s_lse_[tid] = lse3[(long)bh * NM + tid] * LOG2E;
+    constexpr bool masked = MASKED;
+    s_mlm_[tid] = masked ? g.mlm[(long)b * NM + tid] : 1.f;
     const int nblk = g.n_p / 32, stride = 4 * gridDim.x;
     int rb = 4 * blockIdx.x + wave;
     const bf16_t* kb = qkv + (long)b * g.n_p * 3 * D + D + hd * ND;
@@ -628,6 +701,8 @@ __global__ __launch_bounds__(NT, 2) void nys_a3_bwd_dkv_kernel(const bf16_t* __r
         const bf16_t* s_g = s_g_ + opq;
         const float* s_lse = s_lse_ + opq;
         const float* s_del = s_del_ + opq;
+        const float* s_mlm = s_mlm_ + opq;
+        const float mr = masked ? g.mrow[(long)b * g.n_p + row] : 1.f;
         bf16x8 kf[4], vf[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) { kf[ks] = kn[ks]; vf[ks] = vn[ks]; }
@@ -648,9 +723,19 @@ __global__ __launch_bounds__(NT, 2) void nys_a3_bwd_dkv_kernel(const bf16_t* __r
                 s = MFMA(frag_kc(s_ql, 32 * blk, 16 * ks, lane), kf[ks], s);
                 dp = MFMA(frag_kc(s_g, 32 * blk, 16 * ks, lane), vf[ks], dp);
             }
-            s = s * g.scale2 - rowvals16(s_lse + 32 * blk, hl);      // staged as lse3 * log2(e)
-            exp2_16(s);
-            dp = s * (dp * g.scale - rowvals16(s_del + 32 * blk, hl));   // staged as delta3 * scale
+            if (masked) {
+                const f32x16 vr = rowvals16(s_mlm + 32 * blk, hl);
+                s = s * g.scale2;
+                mask_fill16(s, vr, mr);
+                s = s - rowvals16(s_lse + 32 * blk, hl);
+                exp2_16(s);
+                dp = s * (dp * g.scale - rowvals16(s_del + 32 * blk, hl));
+                mask_zero16(dp, vr, mr);
+            } else {
+                s = s * g.scale2 - rowvals16(s_lse + 32 * blk, hl);      // staged as lse3 * log2(e)
+                exp2_16(s);
+                dp = s * (dp * g.scale - rowvals16(s_del + 32 * blk, hl));   // staged as delta3 * scale
+            }
             const bf16x8 p0 = pack8<0>(s), p1 = pack8<1>(s), d0 = pack8<0>(dp), d1 = pack8<1>(dp);
 #pragma unroll
             for (int nb = 0; nb < 2; nb++) {
@@ -673,17 +758,22 @@ __global__ __launch_bounds__(NT, 2) void nys_a3_bwd_dkv_kernel(const bf16_t* __r
 
 // ============================================================================ attn3 backward, dq_l (L kernel)
 // grid (splits, B h).  dq_l[l, d] += sum_n dS3[l, n] k[n, d]   (f32 atomics into the q_l half of dlm)
+template <bool MASKED>
 __global__ __launch_bounds__(NT) void nys_a3_bwd_dql_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ lm,
                                                             const float* __restrict__ delta3, const bf16_t* __restrict__ dav,
                                                             const float* __restrict__ lse3, float* __restrict__ dlm, Geo g,
                                                             int tiles_per_wg) {
     __shared__ __attribute__((aligned(16))) bf16_t s_k[TR * NP];
     __shared__ __attribute__((aligned(16))) bf16_t s_v[TR * NP];
+    __shared__ __attribute__((aligned(16))) float s_mr[TR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hl = lane >> 5;
     const int bh = blockIdx.y, b = bh / g.h, hd = bh % g.h, D = g.D;
     const int ntiles = g.n_p / TR;
     const int t0 = blockIdx.x * tiles_per_wg, t1 = min(t0 + tiles_per_wg, ntiles);
     if (t0 >= t1) return;
+    constexpr bool masked = MASKED;
+    float ml[2] = {1.f, 1.f};
+    if (masked) { ml[0] = g.mlm[(long)b * NM + 64 * wave + c]; ml[1] = g.mlm[(long)b * NM + 64 * wave + 32 + c]; }
     const bf16_t* qlb = lm + (long)b * NM * 2 * D + hd * ND;
     bf16x8 qlf[2][4], gf[2][4];
     float lsev[2], delv[2];
@@ -714,6 +804,7 @@ __global__ __launch_bounds__(NT) void nys_a3_bwd_dql_kernel(const bf16_t* __rest
         __syncthreads();
         tile_store<TR>(rk, s_k, tid);
         tile_store<TR>(rv, s_v, tid);
+        if (tid < TR) s_mr[tid] = masked ? g.mrow[(long)b * g.n_p + (long)t * TR + tid] : 1.f;
         __syncthreads();
         if (t + 1 < t1) {
             tile_load<TR>(rk, kb + (long)(t + 1) * TR * 3 * D, 3 * D, tid);
@@ -729,9 +820,19 @@ __global__ __launch_bounds__(NT) void nys_a3_bwd_dql_kernel(const bf16_t* __rest
                     s = MFMA(frag_kc(s_k, 32 * i, 16 * ks, lane), qlf[j][ks], s);
                     dp = MFMA(frag_kc(s_v, 32 * i, 16 * ks, lane), gf[j][ks], dp);
                 }
-                s = fma_splat(s, g.scale2, -lsev[j]);
-                exp2_16(s);
-                dp = s * fma_splat(dp, g.scale, -delv[j]);
+                if (masked) {
+                    const f32x16 vr = rowvals16(s_mr + 32 * i, hl);
+                    s = s * g.scale2;
+                    mask_fill16(s, vr, ml[j]);
+                    s = fma_splat(s, 1.f, -lsev[j]);
+                    exp2_16(s);
+                    dp = s * fma_splat(dp, g.scale, -delv[j]);
+                    mask_zero16(dp, vr, ml[j]);
+                } else {
+                    s = fma_splat(s, g.scale2, -lsev[j]);
+                    exp2_16(s);
+                    dp = s * fma_splat(dp, g.scale, -delv[j]);
+                }
                 // dS3^T in the accumulator layout IS dS3 as an A operand (row = landmark = lane, k = keys): the product
                 // comes out as dq_l[landmark (registers)][d (lanes)], so the final atomics are 128-byte coalesced
                 const bf16x8 d0 = pack8<0>(dp), d1 = pack8<1>(dp);
@@ -760,6 +861,13 @@ int pick_walkers(int BH, int n_p) {
     return w;
 }
 
+// the mask-aware instantiation only when a mask is given: the unmasked kernels keep their register budget
+#define NYS_LAUNCH(kern, grid, block, shm, stream, ...)                                              \
+    do {                                                                                             \
+        if (g.mrow) hipLaunchKernelGGL((kern<true>), grid, block, shm, stream, __VA_ARGS__);        \
+        else hipLaunchKernelGGL((kern<false>), grid, block, shm, stream, __VA_ARGS__);              \
+    } while (0)
+
 int check_geo(const char* fn, int B, int h, int n_p, int m, int dh) {
     MH_REQUIRE(m == NM && dh == ND, "%s: built for m = %d landmarks and dh = %d (got m=%d dh=%d); other shapes use mh_gemm + mh_softmax",
                fn, NM, ND, m, dh);
@@ -769,12 +877,13 @@ int check_geo(const char* fn, int B, int h, int n_p, int m, int dh) {
 
 }  // namespace
 
-extern "C" int mh_nys_attn1_fwd(const void* qkv, const void* lm, const void* w2, void* out, float* lse1, int B, int h, int n_p,
-                                int m, int dh, float scale, int accumulate, mh_stream s) {
+extern "C" int mh_nys_attn1_fwd(const void* qkv, const void* lm, const void* w2, void* out, float* lse1, const float* mrow,
+                                const float* mlm, int B, int h, int n_p, int m, int dh, float scale, int accumulate, mh_stream s) {
     if (int e = check_geo("mh_nys_attn1_fwd", B, h, n_p, m, dh)) return e;
     if (B == 0) return MH_OK;
-    const Geo g{h, n_p, h * ND, scale, scale * LOG2E, accumulate};
-    hipLaunchKernelGGL(nys_a1_fwd_kernel, dim3(pick_walkers(B * h, n_p), B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv, (const bf16_t*)lm,
+    MH_REQUIRE((mrow == nullptr) == (mlm == nullptr), "mh_nys_attn1_fwd: mrow and mlm go together");
+    const Geo g{h, n_p, h * ND, scale, scale * LOG2E, mrow, mlm, accumulate};
+    NYS_LAUNCH(nys_a1_fwd_kernel, dim3(pick_walkers(B * h, n_p), B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv, (const bf16_t*)lm,
                        (const bf16_t*)w2, (bf16_t*)out, lse1, g);
     MH_LAUNCH_CHECK("mh_nys_attn1_fwd");
     return MH_OK;
@@ -788,17 +897,17 @@ extern "C" int64_t mh_nys_attn3_ws_floats(int B, int h, int n_p) {
     return splits > 1 ? (int64_t)B * h * splits * A3_PART : 0;
 }
 
-extern "C" int mh_nys_attn3_fwd(const void* qkv, const void* lm, float* av, float* lse3, float* workspace, int64_t ws_floats, int B,
-                                int h, int n_p, int m, int dh, float scale, mh_stream s) {
+extern "C" int mh_nys_attn3_fwd(const void* qkv, const void* lm, float* av, float* lse3, float* workspace, int64_t ws_floats,
+                                const float* mrow, const float* mlm, int B, int h, int n_p, int m, int dh, float scale, mh_stream s) {
     if (int e = check_geo("mh_nys_attn3_fwd", B, h, n_p, m, dh)) return e;
     if (B == 0) return MH_OK;
-    const Geo g{h, n_p, h * ND, scale, scale * LOG2E, 0};
+    const Geo g{h, n_p, h * ND, scale, scale * LOG2E, mrow, mlm, 0};
     const int ntiles = n_p / TR;
     int splits = pick_splits(B * h, ntiles);
     if (!workspace || ws_floats < (int64_t)B * h * splits * A3_PART) splits = 1;      // no room for partials: one workgroup per (b, h)
     const int tpw = (ntiles + splits - 1) / splits;
     splits = (ntiles + tpw - 1) / tpw;                                                 // no empty ranges
-    hipLaunchKernelGGL(nys_a3_fwd_kernel, dim3(splits, B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv, (const bf16_t*)lm, av,
+    NYS_LAUNCH(nys_a3_fwd_kernel, dim3(splits, B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv, (const bf16_t*)lm, av,
                        lse3, workspace, g, tpw);
     MH_LAUNCH_CHECK("mh_nys_attn3_fwd");
     if (splits > 1) {
@@ -819,32 +928,33 @@ int pick_splits(int BH, int ntiles) {
 }
 
 extern "C" int mh_nys_attn1_bwd(const void* qkv, const void* lm, const void* w2, const void* dout, const float* lse1,
-                                float* delta1, void* dqkv, float* dw2, float* dlm, int B, int h, int n_p, int m, int dh,
-                                float scale, mh_stream s) {
+                                float* delta1, void* dqkv, float* dw2, float* dlm, const float* mrow, const float* mlm, int B, int h,
+                                int n_p, int m, int dh, float scale, mh_stream s) {
     if (int e = check_geo("mh_nys_attn1_bwd", B, h, n_p, m, dh)) return e;
     if (B == 0) return MH_OK;
-    const Geo g{h, n_p, h * ND, scale, scale * LOG2E, 0};
-    hipLaunchKernelGGL(nys_a1_bwd_dq_kernel, dim3(pick_walkers(B * h, n_p), B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv,
+    const Geo g{h, n_p, h * ND, scale, scale * LOG2E, mrow, mlm, 0};
+    NYS_LAUNCH(nys_a1_bwd_dq_kernel, dim3(pick_walkers(B * h, n_p), B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv,
                        (const bf16_t*)lm, (const bf16_t*)w2, (const bf16_t*)dout, lse1, delta1, (bf16_t*)dqkv, g);
     MH_LAUNCH_CHECK("mh_nys_attn1_bwd(dq)");
     const int ntiles = n_p / TR, splits = pick_splits(B * h, ntiles), tpw = (ntiles + splits - 1) / splits;
-    hipLaunchKernelGGL(nys_a1_bwd_dw_kernel, dim3(splits, B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv,
+    NYS_LAUNCH(nys_a1_bwd_dw_kernel, dim3(splits, B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv,
                        (const bf16_t*)lm, (const bf16_t*)w2, (const bf16_t*)dout, lse1, (const float*)delta1, dw2, dlm, g, tpw);
     MH_LAUNCH_CHECK("mh_nys_attn1_bwd(dw)");
     return MH_OK;
 }
 
 extern "C" int mh_nys_attn3_bwd(const void* qkv, const void* lm, const float* av, const void* dav, const float* lse3, float* delta3,
-                                void* dqkv, float* dlm, int B, int h, int n_p, int m, int dh, float scale, mh_stream s) {
+                                void* dqkv, float* dlm, const float* mrow, const float* mlm, int B, int h, int n_p, int m, int dh,
+                                float scale, mh_stream s) {
     if (int e = check_geo("mh_nys_attn3_bwd", B, h, n_p, m, dh)) return e;
     if (B == 0) return MH_OK;
-    const Geo g{h, n_p, h * ND, scale, scale * LOG2E, 0};
+    const Geo g{h, n_p, h * ND, scale, scale * LOG2E, mrow, mlm, 0};
     hipLaunchKernelGGL(nys_delta3_kernel, dim3(B * h), dim3(NM), 0, (hipStream_t)s, av, (const bf16_t*)dav, delta3);
-    hipLaunchKernelGGL(nys_a3_bwd_dkv_kernel, dim3(pick_walkers(B * h, n_p), B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv,
+    NYS_LAUNCH(nys_a3_bwd_dkv_kernel, dim3(pick_walkers(B * h, n_p), B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv,
                        (const bf16_t*)lm, (const float*)delta3, (const bf16_t*)dav, lse3, (bf16_t*)dqkv, g);
     MH_LAUNCH_CHECK("mh_nys_attn3_bwd(dkv)");
     const int ntiles = n_p / TR, splits = pick_splits(B * h, ntiles), tpw = (ntiles + splits - 1) / splits;
-    hipLaunchKernelGGL(nys_a3_bwd_dql_kernel, dim3(splits, B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv,
+    NYS_LAUNCH(nys_a3_bwd_dql_kernel, dim3(splits, B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv,
                        (const bf16_t*)lm, (const float*)delta3, (const bf16_t*)dav, lse3, dlm, g, tpw);
     MH_LAUNCH_CHECK("mh_nys_attn3_bwd(dql)");
     return MH_OK;

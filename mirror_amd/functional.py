@@ -658,10 +658,10 @@ class NystromCoreFn(Function):
             with torch.cuda.stream(side):
                 K.pinv_chain_fwd(xt, chain_saved, zfT, iters)
             saved = [(xt, chain_saved, z0)]
-        fused = kmask is None and K.nys_fused_ok(qkv, h, m_l) and lm.dtype == bf16      # nystrom_fused.hip: sim1 / sim3 never reach HBM
+        fused = K.nys_fused_ok(qkv, h, m_l) and lm.dtype == bf16      # nystrom_fused.hip: sim1 / sim3 never reach HBM (mask-aware)
         lse1 = lse3 = a1 = a3 = None
         if fused:
-            av, lse3 = K.nys_attn3_fwd(qkv, lm, h, scale)                                # [B,h,m,dh] f32
+            av, lse3 = K.nys_attn3_fwd(qkv, lm, h, scale, kmask)                         # [B,h,m,dh] f32
         else:
             a1 = K.gemm(q, kl.transpose(-1, -2), alpha=scale, mma=mma, out_dtype=f32)   # [B,h,n_p,m]
             a3 = K.gemm(ql, k.transpose(-1, -2), alpha=scale, mma=mma, out_dtype=f32)   # [B,h,m,n_p]
@@ -684,7 +684,7 @@ class NystromCoreFn(Function):
         pio = pm if (pm == MH_BF16 or A == f32) else mma
         w2 = K.gemm(zf, av, mma=pio, out_dtype=A)
         if fused:
-            lse1 = K.nys_attn1_fwd(qkv, lm, w2, out, h, scale, accumulate=True)
+            lse1 = K.nys_attn1_fwd(qkv, lm, w2, out, h, scale, accumulate=True, kmask=kmask)
         else:
             K.gemm(a1, w2, out=_heads(out, 0, 1, h), mma=mma)
             K.resconv(qkv[..., 2 * D:], res_w.detach().contiguous(), out, h, transpose=False, accumulate=True)
@@ -731,7 +731,7 @@ class NystromCoreFn(Function):
             lse1, lse3 = a1, a3
             dW2 = torch.zeros((Bn, h, m, dh), device=qkv.device, dtype=f32)
             dlm = torch.zeros((Bn, m, 2 * D), device=qkv.device, dtype=f32)
-            K.nys_attn1_bwd(qkv, lm, w2, dout, lse1, dqkv, dW2, dlm, h, scale)          # dq, dW2, dk_l
+            K.nys_attn1_bwd(qkv, lm, w2, dout, lse1, dqkv, dW2, dlm, h, scale, kmask)   # dq, dW2, dk_l
         else:
             dW2 = K.gemm(tr(a1), dO, mma=mma, out_dtype=f32)                             # [B,h,m,dh]
             dlm = torch.empty((Bn, m, 2 * D), device=qkv.device, dtype=f32)
@@ -755,7 +755,7 @@ class NystromCoreFn(Function):
         K.resconv_wgrad(qkv[..., 2 * D:], dout, dres, h)
         dAV = K.gemm(tr(zf), dW2, mma=pio, out_dtype=A)                                  # [B,h,m,dh]
         if fused:
-            K.nys_attn3_bwd(qkv, lm, av, dAV, lse3, dqkv, dlm, h, scale)                # dk, dv, dq_l
+            K.nys_attn3_bwd(qkv, lm, av, dAV, lse3, dqkv, dlm, h, scale, kmask)         # dk, dv, dq_l
             K.resconv(dout, rw, dqkv[..., 2 * D:], h, transpose=True, accumulate=True)
         else:
             dS1 = K.gemm(dO, tr(w2), mma=mma, out_dtype=A)                               # [B,h,n_p,m]

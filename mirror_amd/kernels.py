@@ -558,19 +558,30 @@ def _nys_launch(name: str, flops: float, fn) -> None:
         gemm_profiler.launch_named(name, flops, fn)
 
 
-def nys_attn1_fwd(qkv, lm, w2, out, heads: int, scale: float, accumulate: bool = False) -> torch.Tensor:
-    """out[:, :, head] (+)= softmax_m(scale q k_l^T) w2; returns the row logsumexp [B, h, n_p]."""
+def _nys_masks(kmask, B: int, n_p: int):
+    """(mrow ptr, mlm ptr) of the key-padding mask pair prepared by TransLayer, or (None, None)."""
+    if kmask is None:
+        return None, None
+    mrow, mlm = kmask[0], kmask[1]
+    _chk(mrow, mlm)
+    assert mrow.shape == (B, n_p) and mlm.shape == (B, NYS_FUSED_M) and mrow.dtype == mlm.dtype == torch.float32
+    assert mrow.is_contiguous() and mlm.is_contiguous()
+    return _p(mrow), _p(mlm)
+
+
+def nys_attn1_fwd(qkv, lm, w2, out, heads: int, scale: float, accumulate: bool = False, kmask=None) -> torch.Tensor:
+    """out[:, :, head] (+)= softmax_m(scale q k_l^T) w2; returns the row logsumexp [B, h, n_p].  kmask: key-padding mask."""
     _chk(qkv, lm, w2, out)
     B, n_p, _ = qkv.shape
     lse1 = torch.empty((B, heads, n_p), device=qkv.device, dtype=torch.float32)
     _nys_check("nys_attn1_fwd", B, heads, n_p, qkv=qkv, lm=lm, w2=w2, out=out)
     _nys_launch("nys_a1_fwd_kernel", 2 * 2.0 * n_p * NYS_FUSED_M * NYS_FUSED_DH * B * heads,
-                lambda: _lib.call("mh_nys_attn1_fwd", _p(qkv), _p(lm), _p(w2), _p(out), _p(lse1), B, heads, n_p, NYS_FUSED_M,
-                                  NYS_FUSED_DH, scale, int(accumulate), stream=_stream()))
+                lambda: _lib.call("mh_nys_attn1_fwd", _p(qkv), _p(lm), _p(w2), _p(out), _p(lse1), *_nys_masks(kmask, B, n_p), B, heads,
+                                  n_p, NYS_FUSED_M, NYS_FUSED_DH, scale, int(accumulate), stream=_stream()))
     return lse1
 
 
-def nys_attn3_fwd(qkv, lm, heads: int, scale: float):
+def nys_attn3_fwd(qkv, lm, heads: int, scale: float, kmask=None):
     """av = softmax_n(scale q_l k^T) v as [B, h, m, dh] f32, and the row logsumexp [B, h, m]."""
     _chk(qkv, lm)
     B, n_p, _ = qkv.shape
@@ -580,12 +591,12 @@ def nys_attn3_fwd(qkv, lm, heads: int, scale: float):
     nws = int(_lib.load().mh_nys_attn3_ws_floats(B, heads, n_p))     # partial results of the sequence ranges
     ws = torch.empty((nws,), device=qkv.device, dtype=torch.float32) if nws else None
     _nys_launch("nys_a3_fwd_kernel", 2 * 2.0 * n_p * NYS_FUSED_M * NYS_FUSED_DH * B * heads,
-                lambda: _lib.call("mh_nys_attn3_fwd", _p(qkv), _p(lm), _p(av), _p(lse3), _p(ws), nws, B, heads, n_p, NYS_FUSED_M,
-                                  NYS_FUSED_DH, scale, stream=_stream()))
+                lambda: _lib.call("mh_nys_attn3_fwd", _p(qkv), _p(lm), _p(av), _p(lse3), _p(ws), nws, *_nys_masks(kmask, B, n_p), B,
+                                  heads, n_p, NYS_FUSED_M, NYS_FUSED_DH, scale, stream=_stream()))
     return av, lse3
 
 
-def nys_attn1_bwd(qkv, lm, w2, dout, lse1, dqkv, dw2, dlm, heads: int, scale: float) -> None:
+def nys_attn1_bwd(qkv, lm, w2, dout, lse1, dqkv, dw2, dlm, heads: int, scale: float, kmask=None) -> None:
     """Writes the q block of dqkv; ADDS into dw2 and into the k_l half of dlm (both f32, zeroed by the caller)."""
     _chk(qkv, lm, w2, dout, lse1, dqkv, dw2, dlm)
     B, n_p, _ = qkv.shape
@@ -593,18 +604,19 @@ def nys_attn1_bwd(qkv, lm, w2, dout, lse1, dqkv, dw2, dlm, heads: int, scale: fl
     delta1 = torch.empty_like(lse1)
     _nys_launch("nys_a1_bwd_kernels", 7 * 2.0 * n_p * NYS_FUSED_M * NYS_FUSED_DH * B * heads,
                 lambda: _lib.call("mh_nys_attn1_bwd", _p(qkv), _p(lm), _p(w2), _p(dout), _p(lse1), _p(delta1), _p(dqkv),
-                                  _p(dw2), _p(dlm), B, heads, n_p, NYS_FUSED_M, NYS_FUSED_DH, scale, stream=_stream()))
+                                  _p(dw2), _p(dlm), *_nys_masks(kmask, B, n_p), B, heads, n_p, NYS_FUSED_M, NYS_FUSED_DH, scale,
+                                  stream=_stream()))
 
 
-def nys_attn3_bwd(qkv, lm, av, dav, lse3, dqkv, dlm, heads: int, scale: float) -> None:
+def nys_attn3_bwd(qkv, lm, av, dav, lse3, dqkv, dlm, heads: int, scale: float, kmask=None) -> None:
     """Writes the k and v blocks of dqkv; ADDS into the q_l half of dlm."""
     _chk(qkv, lm, av, dav, lse3, dqkv, dlm)
     B, n_p, _ = qkv.shape
     _nys_check("nys_attn3_bwd", B, heads, n_p, qkv=qkv, lm=lm, av=av, dav=dav, lse3=lse3, dqkv=dqkv, dlm=dlm)
     delta3 = torch.empty_like(lse3)
     _nys_launch("nys_a3_bwd_kernels", 7 * 2.0 * n_p * NYS_FUSED_M * NYS_FUSED_DH * B * heads,
-                lambda: _lib.call("mh_nys_attn3_bwd", _p(qkv), _p(lm), _p(av), _p(dav), _p(lse3), _p(delta3), _p(dqkv), _p(dlm), B, heads,
-                                  n_p, NYS_FUSED_M, NYS_FUSED_DH, scale, stream=_stream()))
+                lambda: _lib.call("mh_nys_attn3_bwd", _p(qkv), _p(lm), _p(av), _p(dav), _p(lse3), _p(delta3), _p(dqkv), _p(dlm),
+                                  *_nys_masks(kmask, B, n_p), B, heads, n_p, NYS_FUSED_M, NYS_FUSED_DH, scale, stream=_stream()))
 
 
 def eye_minus(P: torch.Tensor, d: float) -> torch.Tensor:

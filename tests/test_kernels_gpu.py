@@ -985,3 +985,64 @@ def test_fp8_quant_and_gemm(M, N, Kd, batch):
     K.gemm_fp8(xq[:, 2:2 + M], sx, wq, sw, ob)
     ref2 = xr.double() @ wq.cpu().view(e4).float().double().t() * float(sx) * float(sw)
     close(ob, ref2.float().bfloat16().double(), 2e-2, 2e-2, "fp8 gemm bf16 out")      # within one bf16 ulp
+
+
+@pytest.mark.parametrize("B,h,l", [(2, 2, 2), (1, 8, 3)])
+def test_nys_fused_attention_sides_with_key_padding_mask(B, h, l):
+    """The fused attention kernels with the package's key-padding mask (BASELINE config 4: 'fused attention mask path'):
+    masked_fill(-finfo.max) on sim1 / sim3, uniform rows for fully masked queries / landmarks, zero gradient at filled logits —
+    against f64 autograd through the plain masked products."""
+    gen = g(300 * B + 10 * h + l)
+    m, dh = 256, 64
+    D, n_p, scale = h * dh, m * l, dh ** -0.5
+    bf = torch.bfloat16
+    qkv = (torch.randn((B, n_p, 3 * D), generator=gen) * 1.5).to(bf)
+    lm = (torch.randn((B, m, 2 * D), generator=gen) * 1.5).to(bf)
+    w2 = torch.randn((B, h, m, dh), generator=gen).to(bf)
+    dout = torch.randn((B, n_p, D), generator=gen).to(bf)
+    dav = torch.randn((B, h, m, dh), generator=gen).to(bf)
+    # front padding + a ragged valid length per sample; landmark group j covers rows [j l, (j + 1) l)
+    mrow = torch.zeros(B, n_p)
+    for b in range(B):
+        lo = 5 + 40 * b
+        hi = n_p - (17 + 100 * b)
+        mrow[b, lo:hi] = 1.0
+    mlm = (mrow.reshape(B, m, l).sum(-1) > 0).float()
+    assert float(mlm.min()) == 0.0 and float(mrow.min()) == 0.0
+
+    def heads(t, which, parts):
+        return t.double().view(B, t.shape[1], parts, h, dh)[:, :, which].permute(0, 2, 1, 3)
+
+    qkv_r, lm_r, w2_r = (t.double().requires_grad_() for t in (qkv, lm, w2))
+    q, k, v = (heads(qkv_r, i, 3) for i in range(3))
+    ql, kl = heads(lm_r, 0, 2), heads(lm_r, 1, 2)
+    neg = -torch.finfo(torch.float32).max
+    mb, ml = mrow.bool()[:, None, :], mlm.bool()[:, None, :]
+    s1 = (scale * q @ kl.transpose(-1, -2)).masked_fill(~(mb[..., None] & ml[..., None, :]), neg)
+    out_ref = (torch.softmax(s1, -1) @ w2_r).permute(0, 2, 1, 3).reshape(B, n_p, D)
+    s3 = (scale * ql @ k.transpose(-1, -2)).masked_fill(~(ml[..., None] & mb[..., None, :]), neg)
+    av_ref = torch.softmax(s3, -1) @ v
+    ((out_ref * dout.double()).sum() + (av_ref * dav.double()).sum()).backward()
+
+    kmask = (mrow.to(DEV), mlm.to(DEV))
+    qkv_d, lm_d, w2_d, dout_d, dav_d = (t.to(DEV) for t in (qkv, lm, w2, dout, dav))
+    out = torch.full((B, n_p, D), float("nan"), device=DEV, dtype=bf)
+    lse1 = K.nys_attn1_fwd(qkv_d, lm_d, w2_d, out, h, scale, kmask=kmask)
+    av, lse3 = K.nys_attn3_fwd(qkv_d, lm_d, h, scale, kmask=kmask)
+    out_ref, av_ref = out_ref.detach(), av_ref.detach()
+    close(out, out_ref, 0.0, 2e-2 * float(out_ref.abs().max()), "masked attn1 out")
+    close(av, av_ref, 0.0, 1e-2 * float(av_ref.abs().max()), "masked attn3 av")
+    # a fully masked query row attends uniformly over the landmarks
+    close(out[0, 0, :dh], w2[0, 0].double().mean(0), 0.0, 2e-2 * float(out_ref.abs().max()), "uniform row")
+
+    dqkv = torch.full_like(qkv_d, float("nan"))
+    dw2 = torch.zeros((B, h, m, dh), device=DEV)
+    dlm = torch.zeros((B, m, 2 * D), device=DEV)
+    K.nys_attn1_bwd(qkv_d, lm_d, w2_d, dout_d, lse1, dqkv, dw2, dlm, h, scale, kmask=kmask)
+    K.nys_attn3_bwd(qkv_d, lm_d, av, dav_d, lse3, dqkv, dlm, h, scale, kmask=kmask)
+    for name, got, ref in (("dqkv", dqkv, qkv_r.grad), ("dw2", dw2, w2_r.grad), ("dlm", dlm, lm_r.grad)):
+        close(got, ref, 0.0, 2e-2 * float(ref.abs().max()), "masked " + name)
+        rel = float((got.float().cpu().double() - ref).norm() / ref.norm())
+        assert rel < 1e-2, (name, rel)
+    # q / k rows that are masked out get no gradient through the similarities (v rows still do, through attn3 only if valid)
+    assert float(dqkv[0, 0, :2 * D].abs().max()) == 0.0
