@@ -14,10 +14,13 @@
 // is i, so a tile of probabilities is fed straight back as an operand: registers 8t..8t+7 form the bf16x8 fragment of
 // k-step t, and the other operand is read from LDS in the same permuted k order (rows kb + 4 hl + {0..3} and
 // kb + 8 + 4 hl + {0..3}) with ds_read_b64_tr_b16.  Which index must be contracted decides the orientation:
-//   N kernels (one 128-row tile of the sequence per workgroup, n in lanes, all 256 landmarks in registers):
-//       attn1 fwd, attn1 bwd dq (+ delta), attn3 bwd dk/dv
-//   L kernels (wave owns 64 landmark columns in lanes and walks the sequence, n in registers):
-//       attn3 fwd (online softmax), attn1 bwd dw2/dk_l, attn3 bwd dq_l
+//   N kernels (the landmark images are staged once per workgroup, then every wave walks its own 32-row blocks of the
+//   sequence: n in lanes, the 256 landmarks pass through registers 32 at a time):
+//       attn1 fwd (online softmax over landmark blocks), attn1 bwd dq (+ delta), attn3 bwd dk/dv
+//   L kernels (wave owns 64 landmark columns in lanes and walks 128-row tiles of the sequence, n in registers; the
+//   sequence is cut into ranges over several workgroups per (b, h)):
+//       attn3 fwd (online softmax + nys_a3_combine), attn1 bwd dw2/dk_l, attn3 bwd dq_l
+// Every kernel has a MASKED instance for the package's key-padding mask (BASELINE config 4), see Geo.
 // Layout (SURVEY.md §8 / DESIGN.md §4): qkv [B, n_p, 3D] bf16, heads are 64-wide column slices; landmarks lm
 // [B, m, 2D] = q_l | k_l; w2, av, dav [B, h, m, 64]; out / dout [B, n_p, D].
 #include <cstdlib>
