@@ -17,7 +17,7 @@ constexpr int BIG = 256, NTB = 512, BWM = 4, BWN = 2;
 // accumulators -> f32 LDS tile [128][260] (one half of the rows at a time) -> 16-byte row-contiguous stores
 template <typename TC, int MODE>
 __device__ __forceinline__ void epilogue_big(const GemmArgs& g, TC* C, f32x16 (&acc)[BWM][BWN], char* smem, int tile_row0,
-                                             int tile_col0, int wm, int wn, int lane, int tid, bool lead) {
+                                             int tile_col0, int wm, int wn, int lane, int tid, bool lead, long ldc, float alpha) {
     constexpr int PITCH = BIG + 4, HALF = BIG / 2;
     float* t = reinterpret_cast<float*>(smem);
     const int r = lane & 31, hh = lane >> 5;
@@ -34,7 +34,7 @@ __device__ __forceinline__ void epilogue_big(const GemmArgs& g, TC* C, f32x16 (&
 #pragma unroll
                     for (int reg = 0; reg < 16; reg++) {
                         const int lr = lr0 + (reg & 3) + 8 * (reg >> 2);
-                        float v = g.alpha * acc[i][j][reg] + bias;
+                        float v = alpha * acc[i][j][reg] + bias;
                         if (g.act == MH_ACT_RELU) v = fmaxf(v, 0.f);
                         t[lr * PITCH + lc] = v;
                     }
@@ -51,7 +51,7 @@ __device__ __forceinline__ void epilogue_big(const GemmArgs& g, TC* C, f32x16 (&
             const int lr = cid / CPR, c = cid % CPR;
             const float* src = t + lr * PITCH + c * EPC;
             if (tile_row0 + half * HALF + lr >= g.M) continue;      // ragged last row tile (K-contiguous A only)
-            TC* dst = C + (long)(tile_row0 + half * HALF + lr) * g.ldc + tile_col0 + c * EPC;
+            TC* dst = C + (long)(tile_row0 + half * HALF + lr) * ldc + tile_col0 + c * EPC;
             f32x4 x0 = *reinterpret_cast<const f32x4*>(src);
             u32x4 o;
             if constexpr (sizeof(TC) == 4) {
@@ -103,7 +103,7 @@ __device__ __forceinline__ void epilogue_atomic_big(const GemmArgs& g, float* C,
 // cover the 32 banks exactly.
 template <int MODE>
 __device__ __forceinline__ void epilogue_big_t(const GemmArgs& g, bf16_t* C, f32x16 (&acc)[BWM][BWN], char* smem, int tile_row0,
-                                               int tile_col0, int wm, int wn, int lane, int tid, bool lead) {
+                                               int tile_col0, int wm, int wn, int lane, int tid, bool lead, float alpha) {
     constexpr int PITCH = BIG + 4;
     static_assert(BIG * PITCH * 2 <= 2 * (TileGeom<1, true, BIG>::BYTES + TileGeom<1, true, BIG>::BYTES), "bf16 tile must fit");
     bf16_t* t = reinterpret_cast<bf16_t*>(smem);
@@ -122,7 +122,7 @@ __device__ __forceinline__ void epilogue_big_t(const GemmArgs& g, bf16_t* C, f32
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    v[e] = g.alpha * acc[i][j][4 * gq + e] + bv[e];
+                    v[e] = alpha * acc[i][j][4 * gq + e] + bv[e];
                     if (g.act == MH_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
                 }
                 u32x2 o;
@@ -156,8 +156,19 @@ __device__ __forceinline__ void epilogue_big_t(const GemmArgs& g, bf16_t* C, f32
     }
 }
 
-template <typename TC, bool AKC, bool BKC>
+// FP8 instance (BASELINE config 5): the operands are e4m3 bytes with K contiguous, described to the staging code as bf16 rows
+// of half the length (same 128-byte K-tile rows, same LDS image); a lane then owns 32 consecutive bytes of a 64-byte k-step
+// and the product is v_mfma_scale_f32_32x32x64_f8f6f4 (unit scales) — 16 instead of 32 MFMAs per K-tile at twice the K each.
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x8 f8_pair(bf16x8 lo, bf16x8 hi) {
+    const i32x4f a = __builtin_bit_cast(i32x4f, lo), b = __builtin_bit_cast(i32x4f, hi);
+    return i32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+
+template <typename TC, bool AKC, bool BKC, bool FP8 = false, bool PART = false>
 __global__ __launch_bounds__(NTB) void gemm_big_kernel(GemmArgs g) {
+    static_assert(!FP8 || (AKC && BKC), "fp8 operands are K-contiguous");
     using GA = TileGeom<1, AKC, BIG>;
     using GB = TileGeom<1, BKC, BIG>;
     constexpr int BK = 64;
@@ -224,6 +235,26 @@ __global__ __launch_bounds__(NTB) void gemm_big_kernel(GemmArgs g) {
         }
         const char* at = smem + cur * STAGE;
         const char* bt = at + GA::BYTES;
+        if constexpr (FP8) {
+#pragma unroll
+            for (int s8 = 0; s8 < 2; s8++) {      // two 64-byte k-steps per 128-byte tile row; lane half hl owns bytes [32 hl, 32 hl + 32)
+                const int ks = 32 * s8 + 8 * (lane >> 5);      // in 2-byte units; frag_bf16 adds another 8 (lane >> 5)
+                i32x8 af[BWM], bfr[BWN];
+#pragma unroll
+                for (int i = 0; i < BWM; i++)
+                    af[i] = f8_pair(frag_bf16<true, BIG>(at, wm * BWM * 32 + i * 32, ks, lane), frag_bf16<true, BIG>(at, wm * BWM * 32 + i * 32, ks + 8, lane));
+#pragma unroll
+                for (int j = 0; j < BWN; j++)
+                    bfr[j] = f8_pair(frag_bf16<true, BIG>(bt, wn * BWN * 32 + j * 32, ks, lane), frag_bf16<true, BIG>(bt, wn * BWN * 32 + j * 32, ks + 8, lane));
+#pragma unroll
+                for (int i = 0; i < BWM; i++)
+#pragma unroll
+                    for (int j = 0; j < BWN; j++) {
+                        if constexpr (sizeof(TC) == 2) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bfr[j], af[i], acc[i][j], 0, 0, 0, 127, 0, 127);   // C^T
+                        else acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[i], bfr[j], acc[i][j], 0, 0, 0, 127, 0, 127);
+                    }
+            }
+        } else {
 #pragma unroll
         for (int ks = 0; ks < BK; ks += 16) {
             bf16x8 af[BWM], bfr[BWN];
@@ -239,32 +270,38 @@ __global__ __launch_bounds__(NTB) void gemm_big_kernel(GemmArgs g) {
                     else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
                 }
         }
+        }
         __syncthreads();
+    }
+    if constexpr (FP8) {      // per-tensor dequantisation factors live on the device: fold them into alpha
+        const float a8 = g.alpha * g.scale_a[0] * g.scale_b[0];
+        if constexpr (sizeof(TC) == 2) epilogue_big_t<0>(g, C, acc, smem, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, true, a8);
+        else epilogue_big<TC, 0>(g, C, acc, smem, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, true, g.ldc, a8);
+        return;
     }
     const bool lead = (split == 0);
     if constexpr (sizeof(TC) == 2) {      // bf16 C is never an atomic target (mh_gemm requires f32 for split-K)
-        if (g.accumulate) epilogue_big_t<1>(g, C, acc, smem, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, lead);
-        else epilogue_big_t<0>(g, C, acc, smem, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, lead);
+        if (g.accumulate) epilogue_big_t<1>(g, C, acc, smem, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, lead, g.alpha);
+        else epilogue_big_t<0>(g, C, acc, smem, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, lead, g.alpha);
+        return;
+    }
+    if constexpr (PART) {
+        // partial tile -> workspace [part][M][N] with plain 16-byte stores (part = z * splits + split); 16.7 M same-matrix
+        // f32 atomics of a 64-way split cost more than the whole K loop, a fold pass over the partials does not.  (Its own
+        // instance: with three epilogues inlined into one kernel the compiler spilled in the f32 instances.)
+        if constexpr (sizeof(TC) == 4) {
+            float* P = g.ws + ((long)z * gridDim.y + split) * (long)g.M * g.N;
+            epilogue_big<float, 0>(g, P, acc, smem, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, false, (long)g.N, g.alpha);
+        }
         return;
     }
     if (g.atomic) {
-        if constexpr (sizeof(TC) == 4) {
-            if (g.ws) {
-                // partial tile -> workspace [part][M][N] with plain 16-byte stores (part = z * splits + split); 16.7 M same-
-                // matrix f32 atomics of a 64-way split cost more than the whole K loop, a fold pass over the partials does not
-                GemmArgs gp = g;
-                gp.ldc = g.N;
-                gp.alpha = g.alpha;
-                float* P = g.ws + ((long)z * gridDim.y + split) * (long)g.M * g.N;
-                epilogue_big<float, 0>(gp, P, acc, smem, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, false);
-            } else {
-                epilogue_atomic_big(g, C, acc, tile_m * BIG + wm * BWM * 32, tile_n * BIG + wn * BWN * 32, lane);
-            }
-        }
+        if constexpr (sizeof(TC) == 4)
+            epilogue_atomic_big(g, C, acc, tile_m * BIG + wm * BWM * 32, tile_n * BIG + wn * BWN * 32, lane);
     } else if (g.accumulate) {
-        epilogue_big<TC, 1>(g, C, acc, smem, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, lead);
+        epilogue_big<TC, 1>(g, C, acc, smem, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, lead, g.ldc, g.alpha);
     } else {
-        epilogue_big<TC, 0>(g, C, acc, smem, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, lead);
+        epilogue_big<TC, 0>(g, C, acc, smem, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, lead, g.ldc, g.alpha);
     }
 }
 
@@ -297,16 +334,37 @@ void launch_big(GemmArgs& a, int akc, int bkc, int batch, hipStream_t s) {
     const bool partial = a.atomic && a.ws && a.M % BIG == 0 && a.ws_floats >= parts * mn && ((uintptr_t)a.ws & 15) == 0 && a.vecC &&
                          a.sC1 == 0 && a.sC2 == 0 && parts >= 8;
     if (!partial) a.ws = nullptr;
+    if constexpr (sizeof(TC) == 4) {
+        if (partial) {
+            if (akc && bkc) hipLaunchKernelGGL((gemm_big_kernel<TC, true, true, false, true>), grid, dim3(NTB), 0, s, a);
+            else if (akc) hipLaunchKernelGGL((gemm_big_kernel<TC, true, false, false, true>), grid, dim3(NTB), 0, s, a);
+            else if (bkc) hipLaunchKernelGGL((gemm_big_kernel<TC, false, true, false, true>), grid, dim3(NTB), 0, s, a);
+            else hipLaunchKernelGGL((gemm_big_kernel<TC, false, false, false, true>), grid, dim3(NTB), 0, s, a);
+            hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)min((long)mh_cdiv(mn / 4, 256), 2048L)), dim3(256), 0, s, (const float*)a.ws,
+                               (int)parts, mn, (float*)a.C, (long)a.ldc, a.N);
+            return;
+        }
+    }
     if (akc && bkc) hipLaunchKernelGGL((gemm_big_kernel<TC, true, true>), grid, dim3(NTB), 0, s, a);
     else if (akc) hipLaunchKernelGGL((gemm_big_kernel<TC, true, false>), grid, dim3(NTB), 0, s, a);
     else if (bkc) hipLaunchKernelGGL((gemm_big_kernel<TC, false, true>), grid, dim3(NTB), 0, s, a);
     else hipLaunchKernelGGL((gemm_big_kernel<TC, false, false>), grid, dim3(NTB), 0, s, a);
-    if (partial)
-        hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)min((long)mh_cdiv(mn / 4, 256), 2048L)), dim3(256), 0, s, (const float*)a.ws,
-                           (int)parts, mn, (float*)a.C, (long)a.ldc, a.N);
 }
 
 }  // namespace
+
+// e4m3 operands (K contiguous, described in 2-byte units: K, lda, ldb, strides are HALF the byte counts): true when taken
+bool gemm_try_big_fp8(GemmArgs& a, int dtC, int batch, hipStream_t s) {
+    const bool ok = a.M > BIG && a.N % BIG == 0 && a.K % 64 == 0 && a.k_per_split == a.K && a.split_k == 1 && !a.atomic && !a.accumulate &&
+                    a.vecA && a.vecB && a.vecC && !a.R && a.diag == 0.f && a.scale_a && a.scale_b;
+    if (!ok || (long)((a.M + BIG - 1) / BIG) * (a.N / BIG) * batch < 128) return false;
+    a.tiles_m = (a.M + BIG - 1) / BIG;
+    a.tiles_n = a.N / BIG;
+    dim3 grid(a.tiles_m * a.tiles_n, 1, batch);
+    if (dtC == MH_BF16) hipLaunchKernelGGL((gemm_big_kernel<bf16_t, true, true, true>), grid, dim3(NTB), 0, s, a);
+    else hipLaunchKernelGGL((gemm_big_kernel<float, true, true, true>), grid, dim3(NTB), 0, s, a);
+    return true;
+}
 
 // true when the large-tile kernel took the launch
 bool gemm_try_big_bf16(GemmArgs& a, int akc, int bkc, int dtC, int batch, hipStream_t s) {

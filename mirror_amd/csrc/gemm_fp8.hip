@@ -9,7 +9,10 @@
 // instead of halfwords — so the tile images are [rows][64 bytes of k] with an 80-byte pitch.  This first version uses a
 // 128 x 128 x 64 tile with 4 waves (wave tile 64 x 64); it is the parity / plumbing implementation of config 5, not yet
 // a tuned kernel (the 2x MFMA rate of CDNA4 for fp8 needs the 32x32x64 f8f6f4 instruction and the 256-tile pipeline).
-#include "common.h"
+#include <cstdlib>
+#include "gemm_kernel.h"
+
+bool gemm_try_big_fp8(GemmArgs& a, int dtC, int batch, hipStream_t s);   // gemm_big.hip: 256-tile pipeline, f8f6f4 MFMA
 
 namespace {
 
@@ -161,6 +164,23 @@ extern "C" int mh_gemm_fp8(const void* A, int64_t lda, int64_t a_bs, const void*
     MH_REQUIRE(K >= F8_BK && K % F8_BK == 0 && N % F8_T == 0, "mh_gemm_fp8: needs K %% 64 == 0 and N %% 128 == 0 (got N=%d K=%d)", N, K);
     MH_REQUIRE(lda % 16 == 0 && ldb % 16 == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0, "mh_gemm_fp8: operands must be 16-byte aligned");
     MH_REQUIRE(act == MH_ACT_NONE || act == MH_ACT_RELU, "mh_gemm_fp8: activation %d unsupported", act);
+    // the large-tile pipeline (v_mfma_scale_f32_32x32x64_f8f6f4: twice the bf16 MFMA rate) when the shape fits it
+    if (K % 128 == 0 && N % 256 == 0 && lda % 2 == 0 && ldb % 2 == 0 && a_bs % 2 == 0 && getenv("MH_FP8_SMALL") == nullptr) {
+        GemmArgs a = {};
+        a.A = A; a.B = B; a.C = C; a.bias = bias;
+        a.M = M; a.N = N; a.K = K / 2;
+        a.lda = lda / 2; a.ldb = ldb / 2; a.ldc = ldc;
+        a.sA1 = a_bs / 2; a.sC1 = c_bs; a.batch2 = 1;
+        a.alpha = 1.f; a.act = act; a.split_k = 1; a.k_per_split = K / 2;
+        a.vecA = a.vecB = 1;
+        const int cvec = dt_c == MH_F32 ? 4 : 8;
+        a.vecC = (((uintptr_t)C & 15) == 0) && ldc % cvec == 0 && c_bs % cvec == 0;
+        a.scale_a = scale_a; a.scale_b = scale_b;
+        if (gemm_try_big_fp8(a, dt_c, batch, (hipStream_t)s)) {
+            MH_LAUNCH_CHECK("mh_gemm_fp8");
+            return MH_OK;
+        }
+    }
     dim3 grid(N / F8_T, mh_cdiv(M, F8_T), batch);
     if (dt_c == MH_F32)
         hipLaunchKernelGGL((gemm_fp8_kernel<float>), grid, dim3(256), 0, (hipStream_t)s, (const unsigned char*)A, (long)lda, (long)a_bs,

@@ -36,6 +36,7 @@ struct GemmArgs {
     int vecC;    // C rows are 16-B aligned (LDS-staged wide-store epilogue allowed)
     const void* R; float rcoef;   // optional addend rcoef * R, R laid out exactly like C (same dtype and strides)
     float* ws; long ws_floats;    // split-K partial tiles go here instead of f32 atomics (gemm_big.hip), then a fold pass
+    const float* scale_a; const float* scale_b;   // fp8 operands (gemm_big.hip FP8 instance): alpha *= scale_a[0] * scale_b[0]
 };
 
 template <int MMA, bool KC, int ROWS>

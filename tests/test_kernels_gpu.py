@@ -957,10 +957,11 @@ def test_dropout_add_equals_dropout_then_add():
     Fn._res_grads.clear()
 
 
-@pytest.mark.parametrize("M,N,Kd,batch", [(300, 256, 128, 1), (1100, 128, 64, 1), (137, 384, 192, 3)])
+@pytest.mark.parametrize("M,N,Kd,batch", [(300, 256, 128, 1), (1100, 128, 64, 1), (137, 384, 192, 3), (4100, 512, 256, 4)])
 def test_fp8_quant_and_gemm(M, N, Kd, batch):
     """BASELINE config 5 pieces: per-tensor e4m3 quantisation (bit-exact against torch.float8_e4m3fn) and the fp8 MFMA product
-    (f32 accumulate) with bias / ReLU, ragged M, a batch of row windows of a larger buffer."""
+    (f32 accumulate) with bias / ReLU, ragged M, a batch of row windows of a larger buffer.  The last shape is large enough for
+    the 256-tile pipeline with the 32x32x64 f8f6f4 MFMA; the others run on the 128-tile kernel."""
     gen = g(101)
     e4 = torch.float8_e4m3fn
     x = (torch.randn(batch, M + 5, Kd, generator=gen) * 3).bfloat16()
