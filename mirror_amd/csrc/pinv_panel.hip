@@ -375,7 +375,7 @@ __global__ __launch_bounds__(CT) void pinv_panel_fwd_kernel(const bf16_t* __rest
 }
 
 // --------------------------------------------------------------------------------------------------------- backward
-// dzf = PN(U), U = (d z_iters)^T;  work[k] = PN{V3, V2, W, U_k};
+// dzf = PN(U), U = (d z_iters)^T;  work[k] = PN{V3, V2, 4 W, U_k};
 // dX (f32, row-major) = sum_k dP_k z_k^T;  dz0 (f32, row-major) = d z_0
 __global__ __launch_bounds__(CT) void pinv_panel_bwd_kernel(const bf16_t* __restrict__ XT, const bf16_t* __restrict__ saved,
                                                             const bf16_t* __restrict__ dzf, bf16_t* __restrict__ work,
@@ -428,19 +428,6 @@ __global__ __launch_bounds__(CT) void pinv_panel_bwd_kernel(const bf16_t* __rest
         publish();                                                         // V3 / V2 stores of this step are visible
         image_from_global<8>(img, P, tid);
         load_panel(p, V2, wave, lane);
-#pragma unroll
-        for (int blk = 0; blk < 8; blk++)
-#pragma unroll
-            for (int jb = 0; jb < NJ; jb++) {
-#pragma unroll
-                for (int t = 0; t < 2; t++) {
-                    u32x4 rw = __builtin_bit_cast(u32x4, p[2 * blk + t][jb]);
-#pragma unroll
-                    for (int e = 0; e < 8; e++)
-                        acc[blk][jb][8 * t + e] -= 7.f * __uint_as_float((e & 1) ? (rw[e >> 1] & 0xffff0000u) : (rw[e >> 1] << 16));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
         __syncthreads();
         panel_gemm<false>(acc, img, rlo, rhi, p);                                // + P V2 (image: P, panel: V2)
         __syncthreads();
@@ -449,15 +436,19 @@ __global__ __launch_bounds__(CT) void pinv_panel_bwd_kernel(const bf16_t* __rest
         negate_panel(p);
         __syncthreads();
         panel_gemm<false>(acc, img, rlo, rhi, p);                                // - T2 V3
-        finish<false>(acc, 1.f, 0.f, p, 0.f, p, wave, dreg);
+        // the - 7 V2 term rides on the epilogue (V2's panel comes back from L2: 64 KB per workgroup) instead of a VALU
+        // pass over the 256 accumulator registers in the middle of the phase, which also kept V2 alive across an image fill
+        // ... and W is kept as 4 W (exact in bf16): U' = W X + 1/4 T3 U = 1/4 (4W X + T3 U) then needs no rescaling of the 256
+        // accumulators between its two products, and dX = sum Z (4W) takes its 1/4 at the final store
+        load_panel(p, V2, wave, lane);
+        finish<true>(acc, 4.f, 0.f, p, -28.f, p, wave, dreg);
         store_panel(W, p, wave, lane);
         __syncthreads();
         image_from_panel(img, p, j, hl);
         __syncthreads();
         // U' = W X + 1/4 T3 U  =  1/4 (4 W X + T3 U)
         load_panel(p, Xb, wave, lane);
-        panel_gemm<true>(acc, img, rlo, rhi, p);                                // W X    (image: W, panel: X)
-        scale_acc(acc, 4.f);
+        panel_gemm<true>(acc, img, rlo, rhi, p);                                // 4W X   (image: 4W, panel: X)
         publish();                                                         // U stores of the previous step are visible
         image_from_global<8>(img, T3, tid);
         load_panel(p, U, wave, lane);
@@ -484,7 +475,7 @@ __global__ __launch_bounds__(CT) void pinv_panel_bwd_kernel(const bf16_t* __rest
         __syncthreads();
         panel_gemm<false>(acc, img, rlo, rhi, p);
     }
-    store_f32(dX + bh * MAT, acc, 1.f, j, hl);
+    store_f32(dX + bh * MAT, acc, 0.25f, j, hl);      // the panels hold 4 W
 }
 
 // One thread per panel-native item (bh, jblk, T, lane): i_e = 16T + 4hl + (e & 3) + 8 (e >> 2), j = 32 jblk + c.
