@@ -39,8 +39,8 @@ __device__ __forceinline__ bf16x8 rm_frag_tr(const bf16_t* img, int col0, int kb
 // grid (n_p / 128, heads, B)
 __global__ __launch_bounds__(256) void resconv_mfma_kernel(const bf16_t* __restrict__ v, long ldv, long v_bs, const float* __restrict__ w,
                                                            bf16_t* out, long ldo, long o_bs, int n_p, int transpose, int accumulate) {
+    static_assert(64 * RM_SP * 4 <= (RM_T + 2 * RM_HALO) * RM_P * 2, "half of the f32 output image must fit the v tile");
     __shared__ __attribute__((aligned(16))) bf16_t img[(RM_T + 2 * RM_HALO) * RM_P];
-    __shared__ __attribute__((aligned(16))) float stage[RM_T * RM_SP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 5, r = lane & 31;
     const int t0 = blockIdx.x * RM_T, h = blockIdx.y, b = blockIdx.z;
     const bf16_t* vb = v + (long)b * v_bs + h * RM_DH;
@@ -74,38 +74,48 @@ __global__ __launch_bounds__(256) void resconv_mfma_kernel(const bf16_t* __restr
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) acc[nb] = MFMA(rm_frag_tr(img, 32 * nb, 32 * wave + 16 * ks, lane), wf[ks], acc[nb]);
     }
-    // out^T accumulators -> f32 [t][c] image, then whole 128-byte rows are read-modify-written with 16-byte accesses
-    float* srow = stage + (32 * wave + r) * RM_SP + 4 * hl;
-#pragma unroll
-    for (int nb = 0; nb < 2; nb++)
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            f4_t x = {acc[nb][4 * g], acc[nb][4 * g + 1], acc[nb][4 * g + 2], acc[nb][4 * g + 3]};
-            *reinterpret_cast<f4_t*>(srow + 32 * nb + 8 * g) = x;
-        }
-    __syncthreads();
+    // out^T accumulators -> f32 [t][c] image -> whole 128-byte rows read-modify-written with 16-byte accesses.  The image
+    // reuses the v tile's LDS (64 rows at a time: 17 KB inside the 23 KB tile) so that 6 workgroups fit a CU: the kernel is a
+    // chain of dependent memory round trips per workgroup and lives on occupancy.
+    float* stage = reinterpret_cast<float*>(img);
     bf16_t* ob = out + (long)b * o_bs + h * RM_DH;
+    __syncthreads();                                  // every wave is done reading the v tile
 #pragma unroll
-    for (int i = 0; i < RM_T * 8 / 256; i++) {
-        const int cid = tid + i * 256, q = cid >> 3, c = cid & 7;
-        const int t = t0 + q;
-        if (t >= n_p) continue;
-        const float* sp = stage + q * RM_SP + 8 * c;
-        f4_t lo = *reinterpret_cast<const f4_t*>(sp), hi = *reinterpret_cast<const f4_t*>(sp + 4);
-        bf16_t* p = ob + (long)t * ldo + 8 * c;
-        if (accumulate) {
-            const u32x4 old = *reinterpret_cast<const u32x4*>(p);
-            lo[0] += __uint_as_float(old[0] << 16); lo[1] += __uint_as_float(old[0] & 0xffff0000u);
-            lo[2] += __uint_as_float(old[1] << 16); lo[3] += __uint_as_float(old[1] & 0xffff0000u);
-            hi[0] += __uint_as_float(old[2] << 16); hi[1] += __uint_as_float(old[2] & 0xffff0000u);
-            hi[2] += __uint_as_float(old[3] << 16); hi[3] += __uint_as_float(old[3] & 0xffff0000u);
+    for (int half = 0; half < 2; half++) {
+        if ((wave >> 1) == half) {
+            float* srow = stage + (32 * (wave & 1) + r) * RM_SP + 4 * hl;
+#pragma unroll
+            for (int nb = 0; nb < 2; nb++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    f4_t x = {acc[nb][4 * g], acc[nb][4 * g + 1], acc[nb][4 * g + 2], acc[nb][4 * g + 3]};
+                    *reinterpret_cast<f4_t*>(srow + 32 * nb + 8 * g) = x;
+                }
         }
-        u32x4 o;
-        o[0] = (unsigned)f2bf(lo[0]) | ((unsigned)f2bf(lo[1]) << 16);
-        o[1] = (unsigned)f2bf(lo[2]) | ((unsigned)f2bf(lo[3]) << 16);
-        o[2] = (unsigned)f2bf(hi[0]) | ((unsigned)f2bf(hi[1]) << 16);
-        o[3] = (unsigned)f2bf(hi[2]) | ((unsigned)f2bf(hi[3]) << 16);
-        *reinterpret_cast<u32x4*>(p) = o;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 64 * 8 / 256; i++) {
+            const int cid = tid + i * 256, q = cid >> 3, c = cid & 7;
+            const int t = t0 + 64 * half + q;
+            if (t >= n_p) continue;
+            const float* sp = stage + q * RM_SP + 8 * c;
+            f4_t lo = *reinterpret_cast<const f4_t*>(sp), hi = *reinterpret_cast<const f4_t*>(sp + 4);
+            bf16_t* p = ob + (long)t * ldo + 8 * c;
+            if (accumulate) {
+                const u32x4 old = *reinterpret_cast<const u32x4*>(p);
+                lo[0] += __uint_as_float(old[0] << 16); lo[1] += __uint_as_float(old[0] & 0xffff0000u);
+                lo[2] += __uint_as_float(old[1] << 16); lo[3] += __uint_as_float(old[1] & 0xffff0000u);
+                hi[0] += __uint_as_float(old[2] << 16); hi[1] += __uint_as_float(old[2] & 0xffff0000u);
+                hi[2] += __uint_as_float(old[3] << 16); hi[3] += __uint_as_float(old[3] & 0xffff0000u);
+            }
+            u32x4 o;
+            o[0] = (unsigned)f2bf(lo[0]) | ((unsigned)f2bf(lo[1]) << 16);
+            o[1] = (unsigned)f2bf(lo[2]) | ((unsigned)f2bf(lo[3]) << 16);
+            o[2] = (unsigned)f2bf(hi[0]) | ((unsigned)f2bf(hi[1]) << 16);
+            o[3] = (unsigned)f2bf(hi[2]) | ((unsigned)f2bf(hi[3]) << 16);
+            *reinterpret_cast<u32x4*>(p) = o;
+        }
+        if (half == 0) __syncthreads();               // the first half is consumed before the second overwrites it
     }
 }
 
@@ -184,7 +194,8 @@ bool resconv_wgrad_try_mfma(const void* v, long ldv, long v_bs, const void* dout
     if (ldv % 8 || v_bs % 8 || ldo % 8 || o_bs % 8 || ((uintptr_t)v & 15) || ((uintptr_t)dout & 15)) return false;
     const int nblk = mh_cdiv(n_p, 32);
     int splits = 1;
-    while (splits * 2 * heads * B <= 2048 && splits * 2 * 4 <= nblk) splits *= 2;
+    // ~one workgroup per CU: every extra split adds a round of LDS + global atomics (16 splits: 64 us, 2: 37 us at c2)
+    while (splits * 2 * heads * B <= 256 && splits * 2 * 4 <= nblk) splits *= 2;
     dim3 grid(splits, heads, B);
     hipLaunchKernelGGL(resconv_wgrad_mfma_kernel, grid, dim3(256), 0, s, (const bf16_t*)v, ldv, v_bs, (const bf16_t*)dout, ldo, o_bs,
                        dw, n_p);
