@@ -426,12 +426,12 @@ __global__ __launch_bounds__(CT) void pinv_panel_bwd_kernel(const bf16_t* __rest
         load_panel(p, P, wave, lane);
         panel_gemm<true>(acc, img, rlo, rhi, p);                                // V2 P   (image: V2, panel: P)
         publish();                                                         // V3 / V2 stores of this step are visible
-        image_from_global<8>(img, P, tid);
+        image_from_global<16>(img, P, tid);
         load_panel(p, V2, wave, lane);
         __syncthreads();
         panel_gemm<false>(acc, img, rlo, rhi, p);                                // + P V2 (image: P, panel: V2)
         __syncthreads();
-        image_from_global<8>(img, T2, tid);
+        image_from_global<16>(img, T2, tid);
         load_panel(p, V3, wave, lane);
         negate_panel(p);
         __syncthreads();
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(CT) void pinv_panel_bwd_kernel(const bf16_t* __rest
         load_panel(p, Xb, wave, lane);
         panel_gemm<true>(acc, img, rlo, rhi, p);                                // 4W X   (image: 4W, panel: X)
         publish();                                                         // U stores of the previous step are visible
-        image_from_global<8>(img, T3, tid);
+        image_from_global<16>(img, T3, tid);
         load_panel(p, U, wave, lane);
         __syncthreads();
         panel_gemm<false>(acc, img, rlo, rhi, p);                                // + T3 U
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(CT) void pinv_panel_bwd_kernel(const bf16_t* __rest
         const bf16_t* Z = saved + ((long)k * 4 * BH + bh) * MAT;
         const bf16_t* W = work + ((long)k * 4 * BH + bh) * MAT + 2L * BH * MAT;
         __syncthreads();
-        image_from_global<8>(img, Z, tid);
+        image_from_global<16>(img, Z, tid);
         load_panel(p, W, wave, lane);
         __syncthreads();
         panel_gemm<false>(acc, img, rlo, rhi, p);
