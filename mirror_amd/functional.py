@@ -42,23 +42,35 @@ FP8 = Precision("fp8", MH_BF16, bf16, MH_BF16, True)      # bf16 policy + fp8 fo
 POLICIES = {p.name: p for p in (FP32, BF16, BF16_PINV32, FP8)}
 
 # ------------------------------------------------------------------ bf16 shadows of f32 master weights
+# Entries are keyed by (address, shape) and carry a weak reference to the tensor they were made for: an entry is valid only
+# while that tensor is alive — then nothing else can own the address.  (Without it a model built after another one was freed
+# could land on the same addresses and silently pick up the old model's bf16 weights.)
+import weakref
+
 _shadow_cache: dict = {}
 
 
+def _alive(ref) -> bool:
+    return ref is not None and ref() is not None
+
+
 def shadow(w: torch.Tensor, prec: Precision) -> torch.Tensor:
-    """The weight in the policy's GEMM operand dtype; bf16 copies are cached per (storage, version)."""
+    """The weight in the policy's GEMM operand dtype; bf16 copies are cached per (tensor, version)."""
     wd = w.detach()
     if wd.dtype == prec.act:
         return wd
     key = (wd.data_ptr(), tuple(wd.shape))
     man = _managed_shadows.get(key)
-    if man is not None and man.dtype == prec.act:
-        return man
+    if man is not None:
+        if _alive(man[1]) and man[0].dtype == prec.act:
+            return man[0]
+        if not _alive(man[1]):
+            _managed_shadows.pop(key, None)
     hit = _shadow_cache.get(key)
-    if hit is not None and hit[0] == w._version and hit[1].dtype == prec.act:
+    if hit is not None and _alive(hit[2]) and hit[0] == w._version and hit[1].dtype == prec.act:
         return hit[1]
     s = K.cast(wd.contiguous(), prec.act)
-    _shadow_cache[key] = (w._version, s)
+    _shadow_cache[key] = (w._version, s, weakref.ref(w))
     return s
 
 
@@ -72,12 +84,14 @@ def shadow_t(w: torch.Tensor, prec: Precision) -> torch.Tensor:
     key = (w.data_ptr(), tuple(w.shape))
     man = _managed_shadows_t.get(key)
     if man is not None:
-        return man
+        if _alive(man[1]):
+            return man[0]
+        _managed_shadows_t.pop(key, None)
     hit = _shadow_t_cache.get(key)
-    if hit is not None and hit[0] == w._version:
+    if hit is not None and _alive(hit[2]) and hit[0] == w._version:
         return hit[1]
     t = K.transpose_bf16(shadow(w, prec).contiguous())
-    _shadow_t_cache[key] = (w._version, t)
+    _shadow_t_cache[key] = (w._version, t, weakref.ref(w))
     return t
 
 
@@ -86,17 +100,18 @@ def register_shadow_t(w: torch.Tensor, t: Optional[torch.Tensor]) -> None:
     if t is None:
         _managed_shadows_t.pop(key, None)
     else:
-        _managed_shadows_t[key] = t
+        _managed_shadows_t[key] = (t, weakref.ref(w))
 
 
 def register_shadow(w: torch.Tensor, s: Optional[torch.Tensor]) -> None:
     """An optimizer that maintains the bf16 copy itself (mh_adam writes master + shadow in one pass) publishes it
-    here; whoever rewrites the master outside that optimizer must refresh the shadow (TrainEngine.sync_shadows)."""
+    here; whoever rewrites the master outside that optimizer must refresh the shadow (TrainEngine.sync_shadows).
+    `w` must be the long-lived parameter object: the entry dies with it."""
     key = (w.data_ptr(), tuple(w.shape))
     if s is None:
         _managed_shadows.pop(key, None)
     else:
-        _managed_shadows[key] = s
+        _managed_shadows[key] = (s, weakref.ref(w))
 
 
 # ------------------------------------------------------------------ gradient sink (TrainEngine's flat grad arena)
@@ -224,7 +239,15 @@ class LinearFn(Function):
             if ctx.skinny and N % 32 == 0:
                 dx = K.skinny_fwd(dy, shadow_t(w, prec), None, ACT_NONE, ctx.x_dtype)
             else:
-                dx = _gemm_rows(dy, wa, mma=prec.mma, out_dtype=ctx.x_dtype)
+                rows = dy.numel() // N
+                if rows <= 128 and N >= 1024 and dy.dim() == 2 and dy.is_contiguous():
+                    # few rows, long contraction (the prototype scores: [B, 3000] @ [3000, D]): Kd / 128 workgroups would walk
+                    # all of N each (50 us); split the contraction instead and round once at the end
+                    dx32 = torch.zeros((rows, Kd), device=dy.device, dtype=f32)
+                    K.gemm(dy, wa, out=dx32, accumulate=True, split_k=max(2, min(32, N // 128)), mma=prec.mma)
+                    dx = dx32 if ctx.x_dtype == f32 else K.cast(dx32, ctx.x_dtype)
+                else:
+                    dx = _gemm_rows(dy, wa, mma=prec.mma, out_dtype=ctx.x_dtype)
         if ctx.needs_input_grad[1]:
             dw, sunk = _gbuf(w, (N, Kd))
             if ctx.skinny:
@@ -1070,6 +1093,11 @@ class MatmulNTFn(Function):
     def forward(ctx, a, b):
         a, b = a.contiguous().float(), b.contiguous().float()
         ctx.save_for_backward(a, b)
+        Kd = a.shape[1]
+        if a.shape[0] <= 128 and b.shape[0] <= 128 and Kd >= 256:
+            # a [B, D] x [D, B] product is ONE workgroup walking D in exact-f32 steps of 16 (30 us at D = 512): split K
+            out = torch.zeros((a.shape[0], b.shape[0]), device=a.device, dtype=f32)
+            return K.gemm(a, b.t(), out=out, accumulate=True, split_k=max(2, min(16, Kd // 64)), mma=MH_F32)
         return K.gemm(a, b.t(), mma=MH_F32)
 
     @staticmethod

@@ -49,7 +49,8 @@ def clip_loss_terms(wsi, rna, logit_scale, gather: bool = False):
         w_all, r_all = both[:, :D], both[:, D:]
         off = dist.get_rank() * B
     g_img = Fn.MatmulNTFn.apply(w, r_all)                            # [B, P*B]
-    g_txt = Fn.MatmulNTFn.apply(r, w_all)
+    # rank-local loss: R W^T is the transpose of W R^T — one product (and one pair of gradient products) instead of two
+    g_txt = g_img.t().contiguous() if w_all is w else Fn.MatmulNTFn.apply(r, w_all)
     li = Fn.CERowsFn.apply(g_img, logit_scale, 1.0, off, 0.5 / B, False)
     lt = Fn.CERowsFn.apply(g_txt, logit_scale, 1.0, off, 0.5 / B, False)
     return (li + lt).reshape(())

@@ -1047,3 +1047,25 @@ def test_nys_fused_attention_sides_with_key_padding_mask(B, h, l):
         assert rel < 1e-2, (name, rel)
     # q / k rows that are masked out get no gradient through the similarities (v rows still do, through attn3 only if valid)
     assert float(dqkv[0, 0, :2 * D].abs().max()) == 0.0
+
+
+def test_shadow_cache_does_not_outlive_its_tensor():
+    """A weight allocated at the address of a freed one (same shape, same version counter) must not inherit its cached bf16
+    copy: the shadow caches are tied to the lifetime of the tensor they were made for."""
+    from mirror_amd import functional as Fn
+    w1 = torch.full((64, 128), 1.5, device=DEV)
+    s1 = Fn.shadow(w1, Fn.BF16)
+    assert float(s1.float().mean()) == 1.5
+    ptr = w1.data_ptr()
+    del w1, s1
+    w2 = torch.full((64, 128), -2.0, device=DEV)
+    if w2.data_ptr() != ptr:
+        pytest.skip("the allocator did not reuse the block")
+    assert float(Fn.shadow(w2, Fn.BF16).float().mean()) == -2.0
+    p = torch.nn.Parameter(torch.full((64, 128), 3.0, device=DEV))
+    Fn.register_shadow(p, torch.full((64, 128), 3.0, device=DEV, dtype=torch.bfloat16))
+    pp = p.data_ptr()
+    del p
+    w3 = torch.full((64, 128), 0.5, device=DEV)
+    if w3.data_ptr() == pp:
+        assert float(Fn.shadow(w3, Fn.BF16).float().mean()) == 0.5
