@@ -36,6 +36,37 @@ static int launch_one(const mh_gemm_desc* d, hipStream_t s) {
     return MH_OK;
 }
 
+// The K % 64 remainder of a weight gradient over B * 4097 rows is ONE row per slide: as a second tiled launch it cost 30 us
+// (256 workgroups of f32 atomics for a rank-16 update).  C[m][n] += alpha * sum_z sum_{k < KT} A_z[k][m] B_z[k][n], both operands
+// with the contraction index as their row (M- / N-contiguous rows), every batch reducing into the same C.  Runs after the
+// main launch in stream order, so a plain read-modify-write is enough.
+template <typename TA, typename TB>
+__global__ __launch_bounds__(256) void rank_update_kernel(const TA* __restrict__ A, long lda, long sA, const TB* __restrict__ B, long ldb,
+                                                          long sB, float* __restrict__ C, long ldc, int M, int N, int KT, int batch,
+                                                          float alpha) {
+    const int n = blockIdx.x * 256 + threadIdx.x, m = blockIdx.y;
+    if (n >= N) return;
+    float acc = 0.f;
+    for (int z = 0; z < batch; z++)
+        for (int k = 0; k < KT; k++) acc += ldf(A + z * sA + (long)k * lda + m) * ldf(B + z * sB + (long)k * ldb + n);
+    C[(long)m * ldc + n] += alpha * acc;
+}
+
+static bool try_rank_update(const mh_gemm_desc* t, hipStream_t s) {
+    const int batch = t->batch1 * t->batch2;
+    if (t->K > 8 || t->a_kc || t->b_kc || t->dtC != MH_F32 || !t->accumulate || t->bias || t->R || t->diag != 0.f || t->act != MH_ACT_NONE)
+        return false;
+    if (t->batch2 != 1 || (batch > 1 && (t->sC1 != 0 || t->sC2 != 0)) || t->M > 65535) return false;
+    dim3 grid(mh_cdiv(t->N, 256), t->M);
+#define RU_(TA, TB) hipLaunchKernelGGL((rank_update_kernel<TA, TB>), grid, dim3(256), 0, s, (const TA*)t->A, (long)t->lda, (long)t->sA1, (const TB*)t->B, (long)t->ldb, (long)t->sB1, (float*)t->C, (long)t->ldc, t->M, t->N, t->K, batch, t->alpha)
+    if (t->dtA == MH_BF16 && t->dtB == MH_BF16) RU_(bf16_t, bf16_t);
+    else if (t->dtA == MH_F32 && t->dtB == MH_F32) RU_(float, float);
+    else if (t->dtA == MH_F32) RU_(float, bf16_t);
+    else RU_(bf16_t, float);
+#undef RU_
+    return true;
+}
+
 extern "C" int mh_gemm(const mh_gemm_desc* d, mh_stream stream) {
     MH_REQUIRE(d && d->A && d->B && d->C, "mh_gemm: null pointer");
     MH_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "mh_gemm: empty problem M=%d N=%d K=%d", d->M, d->N, d->K);
@@ -67,6 +98,10 @@ extern "C" int mh_gemm(const mh_gemm_desc* d, mh_stream stream) {
         t.split_k = 1;
         const int rc = launch_one(&m, s);
         if (rc != MH_OK) return rc;
+        if (m.accumulate && try_rank_update(&t, s)) {
+            MH_LAUNCH_CHECK("mh_gemm(tail)");
+            return MH_OK;
+        }
         return launch_one(&t, s);
     }
     return launch_one(d, s);
