@@ -75,8 +75,8 @@ int mh_gemm(const mh_gemm_desc* d, mh_stream s);
 int mh_skinny_fwd(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, void* y, int64_t ldy,
                   int M, int N, int K, int act, int dt_y, mh_stream s);
 /* dW[N,K] (+)= dy[M,N]^T x[M,K]  (f32, plain read-modify-write: one block owns each output tile) */
-int mh_skinny_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw, int64_t lddw, int M, int N,
-                    int K, int accumulate, mh_stream s);
+int mh_skinny_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw, int64_t lddw, float* db, int M, int N,
+                    int K, int accumulate, mh_stream s);   /* db (optional, [N] f32): db += column sums of dy (the bias gradient) */
 /* bf16 [R,C] -> [C,R]; the batched form walks table[i] = {src_off, dst_off, R, C} (int64 element offsets).
  * vec_ok != 0: every entry has R % 8 == 0, C % 8 == 0 and offsets that are multiples of 8 (16-byte accesses) */
 int mh_transpose_bf16(const void* in, void* out, int R, int C, mh_stream s);

@@ -38,7 +38,7 @@ P, I, L, F, U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 _SIGS = {
     "mh_gemm": [C.POINTER(GemmDesc)],
     "mh_skinny_fwd": [P, L, P, L, P, P, L, I, I, I, I, I],
-    "mh_skinny_wgrad": [P, L, P, L, P, L, I, I, I, I],
+    "mh_skinny_wgrad": [P, L, P, L, P, L, P, I, I, I, I],
     "mh_transpose_bf16": [P, P, I, I],
     "mh_transpose_bf16_many": [P, P, P, I, I, I, I],
     "mh_layernorm_fwd": [P, P, P, P, P, P, I, I, I, L, L, F, I, I],

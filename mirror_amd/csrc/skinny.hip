@@ -80,8 +80,8 @@ extern "C" int mh_skinny_fwd(const void* x, int64_t ldx, const void* w, int64_t 
 #define SW_TN 64
 #define SW_TK 256
 __global__ __launch_bounds__(256) void skinny_wgrad_kernel(const bf16_t* __restrict__ dy, long lddy, const bf16_t* __restrict__ x,
-                                                           long ldx, float* __restrict__ dw, long lddw, int M, int N, int K,
-                                                           int accumulate) {
+                                                           long ldx, float* __restrict__ dw, long lddw, float* __restrict__ db, int M,
+                                                           int N, int K, int accumulate) {
     __shared__ __attribute__((aligned(16))) float sdy[32][SW_TN];
     __shared__ __attribute__((aligned(16))) float sx[32][SW_TK];
     const int n0 = blockIdx.x * SW_TN, k0 = blockIdx.y * SW_TK;
@@ -94,6 +94,12 @@ __global__ __launch_bounds__(256) void skinny_wgrad_kernel(const bf16_t* __restr
         sx[m][c] = (k0 + c < K) ? bf2f(x[(long)m * ldx + k0 + c]) : 0.f;
     }
     __syncthreads();
+    // bias gradient db[n] += sum_m dy[m][n] rides along (the k = 0 column of blocks owns it): one launch less per Linear
+    if (db && blockIdx.y == 0 && threadIdx.x < SW_TN && n0 + threadIdx.x < N) {
+        float t = 0.f;
+        for (int m = 0; m < M; m++) t += sdy[m][threadIdx.x];
+        db[n0 + threadIdx.x] += t;
+    }
     const int tn = threadIdx.x >> 5, tk = threadIdx.x & 31;
     float acc[8][8];
 #pragma unroll
@@ -129,14 +135,14 @@ __global__ __launch_bounds__(256) void skinny_wgrad_kernel(const bf16_t* __restr
     }
 }
 
-extern "C" int mh_skinny_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw, int64_t lddw, int M, int N,
-                               int K, int accumulate, mh_stream s) {
+extern "C" int mh_skinny_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw, int64_t lddw, float* db, int M,
+                               int N, int K, int accumulate, mh_stream s) {
     MH_REQUIRE(M >= 1 && M <= 32, "mh_skinny_wgrad: M=%d (needs 1..32)", M);
     MH_REQUIRE(((uintptr_t)dw & 15) == 0, "mh_skinny_wgrad: dW must be 16-byte aligned");
     if (N == 0 || K == 0) return MH_OK;
     dim3 grid(mh_cdiv(N, SW_TN), mh_cdiv(K, SW_TK));
     hipLaunchKernelGGL(skinny_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)dy, (long)lddy, (const bf16_t*)x,
-                       (long)ldx, dw, (long)lddw, M, N, K, accumulate);
+                       (long)ldx, dw, (long)lddw, db, M, N, K, accumulate);
     MH_LAUNCH_CHECK("mh_skinny_wgrad");
     return MH_OK;
 }

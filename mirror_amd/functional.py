@@ -248,14 +248,22 @@ class LinearFn(Function):
                     dx = dx32 if ctx.x_dtype == f32 else K.cast(dx32, ctx.x_dtype)
                 else:
                     dx = _gemm_rows(dy, wa, mma=prec.mma, out_dtype=ctx.x_dtype)
+        want_db = ctx.has_b and ctx.needs_input_grad[2]
+        fused_db = False
         if ctx.needs_input_grad[1]:
             dw, sunk = _gbuf(w, (N, Kd))
             if ctx.skinny:
-                K.skinny_wgrad(dy, xa, dw, accumulate=True)
+                dbuf = sunk_b = None
+                if want_db:                      # the bias gradient rides on the weight-gradient launch
+                    dbuf, sunk_b = _gbuf(b, (N,))
+                    fused_db = True
+                K.skinny_wgrad(dy, xa, dw, accumulate=True, db=dbuf)
+                if fused_db:
+                    db = _gret(b, dbuf, sunk_b)
             else:
                 _wgrad(dy, xa, N, Kd, prec, dw)
             dw = _gret(w, dw, sunk)
-        if ctx.has_b and ctx.needs_input_grad[2]:
+        if want_db and not fused_db:
             db, sunk = _gbuf(b, (N,))
             K.colsum(dy.reshape(-1, N), db)
             db = _gret(b, db, sunk)

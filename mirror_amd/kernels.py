@@ -274,14 +274,16 @@ def skinny_fwd(x2d: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],
     return y
 
 
-def skinny_wgrad(dy2d: torch.Tensor, x2d: torch.Tensor, dw: torch.Tensor, accumulate: bool) -> None:
-    _chk(dy2d, x2d, dw)
+def skinny_wgrad(dy2d: torch.Tensor, x2d: torch.Tensor, dw: torch.Tensor, accumulate: bool, db: Optional[torch.Tensor] = None) -> None:
+    """dW (+)= dy^T x; with `db` ([N] f32) also db += column sums of dy (the bias gradient) in the same launch."""
+    _chk(dy2d, x2d, dw, db)
+    assert db is None or (db.dtype == torch.float32 and db.numel() == dy2d.shape[1] and db.is_contiguous())
     M, N = dy2d.shape
     Kd = x2d.shape[1]
     if (dy2d.dtype != torch.bfloat16 or x2d.dtype != torch.bfloat16 or dw.dtype != torch.float32 or x2d.shape[0] != M
             or tuple(dw.shape) != (N, Kd) or dy2d.stride(1) != 1 or x2d.stride(1) != 1 or dw.stride(1) != 1):
         raise MirrorHipError("skinny_wgrad: bad operands")
-    _lib.call("mh_skinny_wgrad", _p(dy2d), dy2d.stride(0), _p(x2d), x2d.stride(0), _p(dw), dw.stride(0), M, N, Kd,
+    _lib.call("mh_skinny_wgrad", _p(dy2d), dy2d.stride(0), _p(x2d), x2d.stride(0), _p(dw), dw.stride(0), _p(db), M, N, Kd,
               int(accumulate), stream=_stream())
 
 

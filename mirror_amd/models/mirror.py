@@ -60,13 +60,16 @@ class _Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden_features, out_features)
         self.drop = drop
 
-    def forward(self, x, prec: Precision, extra_bias: Optional[torch.Tensor] = None, out_dtype=None):
+    def forward(self, x, prec: Precision, extra_bias: Optional[torch.Tensor] = None, out_dtype=None, residual=None):
+        """residual: the pre-norm block's stream; `residual + drop2(fc2(...))` then comes back as one fused op."""
         h = Fn.gelu(Fn.linear(x, self.fc1.weight, self.fc1.bias, prec=prec))
         h = Fn.dropout(h, self.drop, self.training)
         if isinstance(self.norm, nn.LayerNorm):
             h = Fn.layer_norm(h, self.norm.weight, self.norm.bias, self.norm.eps, out_dtype=prec.act)
         b2 = self.fc2.bias if extra_bias is None else Fn.add(self.fc2.bias, extra_bias.reshape(-1), f32)
         y = Fn.linear(h, self.fc2.weight, b2, prec=prec, out_dtype=out_dtype)
+        if residual is not None:
+            return Fn.dropout_add(residual, y, self.drop, self.training)
         return Fn.dropout(y, self.drop, self.training)
 
 
@@ -85,10 +88,12 @@ class Attention(nn.Module):
         self.proj = nn.Linear(dim, dim)
         self.proj_drop = proj_drop
 
-    def forward(self, x, prec: Precision):
+    def forward(self, x, prec: Precision, residual=None):
         qkv = Fn.linear(x, self.qkv.weight, self.qkv.bias, prec=prec)
         o = Fn.HeadAttnFn.apply(qkv, self.num_heads)
         y = Fn.linear(o, self.proj.weight, self.proj.bias, prec=prec)
+        if residual is not None:
+            return Fn.dropout_add(residual, y, self.proj_drop, self.training)
         return Fn.dropout(y, self.proj_drop, self.training)
 
 
@@ -105,9 +110,9 @@ class Block(nn.Module):
 
     def forward(self, x, prec: Precision):
         h = Fn.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, out_dtype=prec.act)
-        x = Fn.add(x, self.attn(h, prec), f32, residual=True)     # x feeds exactly norm1 and this add
+        x = self.attn(h, prec, residual=x)                          # x + drop(proj(...)); x feeds exactly norm1 and this add
         h = Fn.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, out_dtype=prec.act)
-        return Fn.add(x, self.mlp(h, prec), f32, residual=True)
+        return self.mlp(h, prec, residual=x)
 
 
 class TransFormer(nn.Module):

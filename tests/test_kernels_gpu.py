@@ -735,6 +735,10 @@ def test_skinny_fwd_wgrad_transpose(M, N, Kd):
     close(dw, 2 + dy.double().t() @ x.double(), 0, 0, "skinny wgrad accumulate")
     K.skinny_wgrad(dyd, xd, dw, accumulate=False)
     close(dw, dy.double().t() @ x.double(), 0, 0, "skinny wgrad")
+    dbv = torch.full((N,), 1.0, device=DEV)
+    K.skinny_wgrad(dyd, xd, dw, accumulate=False, db=dbv)                  # bias gradient in the same launch
+    close(dbv, 1 + dy.double().sum(0), 0, 0, "skinny wgrad db")
+    close(dw, dy.double().t() @ x.double(), 0, 0, "skinny wgrad (with db)")
     # batched transpose table
     src = torch.cat([wd.reshape(-1), xd.reshape(-1)])
     dst = torch.zeros_like(src)
