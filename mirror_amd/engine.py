@@ -238,6 +238,14 @@ class TrainEngine:
 
     def _step_eager(self, wsi: torch.Tensor, rna: torch.Tensor, noise: Optional[dict],
                     wsi_key_padding_mask: Optional[torch.Tensor] = None):
+        Fn.zero_arena_begin(self.device)
+        try:
+            return self._step_body(wsi, rna, noise, wsi_key_padding_mask)
+        finally:
+            Fn.zero_arena_end()      # also after an exception: nothing outside a step may carve from an arena that is not re-zeroed
+
+    def _step_body(self, wsi: torch.Tensor, rna: torch.Tensor, noise: Optional[dict],
+                   wsi_key_padding_mask: Optional[torch.Tensor] = None):
         Fn.dropout_step_begin(self.device)
         Fn._res_grads.clear()
         if self._proto is not None:

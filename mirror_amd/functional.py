@@ -114,6 +114,47 @@ def register_shadow(w: torch.Tensor, s: Optional[torch.Tensor]) -> None:
         _managed_shadows[key] = (s, weakref.ref(w))
 
 
+# ------------------------------------------------------------------ per-step zero arena
+# ~30 small / medium f32 buffers per step start as zeros (atomic targets, loss accumulators, zero-initialised gradients): inside
+# a TrainEngine step they are carved from ONE buffer that is cleared by a single memset at the start of the step (30 fill
+# launches less; the eager multi-GPU step is host-bound).  Outside a step `zeros` is plain torch.zeros.
+_zero_arena = {"buf": None, "off": 0, "active": False, "demand": 0, "peak": 0}
+
+
+def zero_arena_begin(device) -> None:
+    st = _zero_arena
+    want = int(st["peak"] * 1.25) + 4096
+    if st["peak"] > 0 and (st["buf"] is None or st["buf"].numel() < want or st["buf"].device != torch.device(device)):
+        st["buf"] = torch.empty((want,), device=device, dtype=f32)
+    if st["buf"] is not None:
+        st["buf"].zero_()
+    st["off"], st["demand"], st["active"] = 0, 0, True
+
+
+def zero_arena_end() -> None:
+    st = _zero_arena
+    st["peak"] = max(st["peak"], st["demand"])
+    st["active"] = False
+
+
+def zeros(shape, device) -> torch.Tensor:
+    """f32 zeros of `shape`: a slice of the step's zero arena when one is active and has room, torch.zeros otherwise."""
+    shape = (shape,) if isinstance(shape, int) else tuple(shape)
+    n = 1
+    for d in shape:
+        n *= int(d)
+    st = _zero_arena
+    if st["active"]:
+        pad = (n + 63) // 64 * 64
+        st["demand"] += pad
+        buf = st["buf"]
+        if buf is not None and st["off"] + pad <= buf.numel() and buf.device == torch.device(device):
+            out = buf[st["off"]:st["off"] + n].view(shape)
+            st["off"] += pad
+            return out
+    return torch.zeros(shape, device=device, dtype=f32)
+
+
 # ------------------------------------------------------------------ gradient sink (TrainEngine's flat grad arena)
 # With a sink installed, weight/bias/LayerNorm gradients are accumulated straight into the arena view of the parameter
 # (no zeros() + autograd "grad += new" pass per parameter) and the Function returns None for them; the sink is told
@@ -243,7 +284,7 @@ class LinearFn(Function):
                 if rows <= 128 and N >= 1024 and dy.dim() == 2 and dy.is_contiguous():
                     # few rows, long contraction (the prototype scores: [B, 3000] @ [3000, D]): Kd / 128 workgroups would walk
                     # all of N each (50 us); split the contraction instead and round once at the end
-                    dx32 = torch.zeros((rows, Kd), device=dy.device, dtype=f32)
+                    dx32 = zeros((rows, Kd), dy.device)
                     K.gemm(dy, wa, out=dx32, accumulate=True, split_k=max(2, min(32, N // 128)), mma=prec.mma)
                     dx = dx32 if ctx.x_dtype == f32 else K.cast(dx32, ctx.x_dtype)
                 else:
@@ -539,7 +580,7 @@ class Fc1SeqFn(Function):
         dseq = dseq.contiguous()
         if add_len:
             dseq = dseq.clone()  # the fold below is in place; autograd owns the incoming buffer
-        dcls = torch.zeros((D,), device=dseq.device, dtype=f32)
+        dcls = zeros((D,), dseq.device)
         K.seq_finish_bwd(dseq, dcls, N, add_len)
         dh = K.relu_bwd(seq[:, 1:1 + N], dseq[:, 1:1 + N], out_dtype=prec.act)   # [B,N,D] contiguous
         dw, sunk_w = _gbuf(w, (D, Fd))
@@ -755,13 +796,13 @@ class NystromCoreFn(Function):
         dqkv = torch.empty_like(qkv)
         dq, dk, dv = (_heads(dqkv, i, 3, h) for i in range(3))
         rw = res_w.detach().contiguous()
-        dres = torch.zeros((rw.numel(),), device=qkv.device, dtype=f32)
+        dres = zeros((rw.numel(),), qkv.device)
         # out = a1 @ w2 ; w2 = Z @ av ; av = a3 @ v.  dZ first: it is all the pinv backward needs (the res_conv weight
         # gradient does not depend on it and runs beside the chain, below).
         if fused:
             lse1, lse3 = a1, a3
-            dW2 = torch.zeros((Bn, h, m, dh), device=qkv.device, dtype=f32)
-            dlm = torch.zeros((Bn, m, 2 * D), device=qkv.device, dtype=f32)
+            dW2 = zeros((Bn, h, m, dh), qkv.device)
+            dlm = zeros((Bn, m, 2 * D), qkv.device)
             K.nys_attn1_bwd(qkv, lm, w2, dout, lse1, dqkv, dW2, dlm, h, scale, kmask)   # dq, dW2, dk_l
         else:
             dW2 = K.gemm(tr(a1), dO, mma=mma, out_dtype=f32)                             # [B,h,m,dh]
@@ -858,8 +899,8 @@ class MaskApplyFn(Function):
         Bn, T, D, first, token_scalar, tshape, pshape, xdt = ctx.geom
         dy = dy.contiguous()
         dx = torch.empty(dy.shape, device=dy.device, dtype=xdt)
-        dtok = torch.zeros((1 if token_scalar else D,), device=dy.device, dtype=f32)
-        dpos = torch.zeros((T * D,), device=dy.device, dtype=f32)
+        dtok = zeros((1 if token_scalar else D,), dy.device)
+        dpos = zeros((T * D,), dy.device)
         K.mask_apply_bwd(dy, mask, dtok, dpos, Bn, T, D, first, token_scalar, out=dx)
         return dx, None, dtok.reshape(tshape), dpos.reshape(pshape), None, None
 
@@ -985,7 +1026,7 @@ class CERowsFn(Function):
     def forward(ctx, G, scale, scale_mul, label_off, coef, per_row):
         G = G.contiguous()
         R = G.shape[0]
-        out = torch.zeros((1,), device=G.device, dtype=f32)
+        out = zeros((1,), G.device)
         rows = torch.empty((R,), device=G.device, dtype=f32) if per_row else None
         sc = None if scale is None else scale.detach().reshape(1)
         lse = K.ce_rows_fwd(G, sc, scale_mul, label_off, coef, out, rows)
@@ -998,7 +1039,7 @@ class CERowsFn(Function):
         G, sc, lse = ctx.saved_tensors
         scale_mul, label_off, coef, per_row, want_ds, sshape = ctx.cfg
         g = g.contiguous().float()
-        ds = torch.zeros((1,), device=G.device, dtype=f32) if sc is not None else None
+        ds = zeros((1,), G.device) if sc is not None else None
         dG = K.ce_rows_bwd(G, sc, scale_mul, lse, g, per_row, coef, ds, label_off)
         return dG, (ds.reshape(sshape) if want_ds else None), None, None, None, None
 
@@ -1014,7 +1055,7 @@ class MaskedMSEFn(Function):
             tgt = tgt.contiguous()
         mask = mask.contiguous().float()
         rows = pred.numel() // D
-        acc = torch.zeros((2,), device=pred.device, dtype=f32)
+        acc = zeros((2,), pred.device)
         K.mse_masked_fwd(pred, tgt, mask, acc, rows, D)
         ctx.save_for_backward(pred, tgt, mask, acc)
         ctx.D, ctx.tok = D, tok
@@ -1062,7 +1103,7 @@ class StyleKLFn(Function):
     @staticmethod
     def forward(ctx, mu, ls, coef):
         mu, ls = mu.contiguous().float(), ls.contiguous().float()
-        out = torch.zeros((1,), device=mu.device, dtype=f32)
+        out = zeros((1,), mu.device)
         K.kl_fwd(mu, ls, out, coef)
         ctx.save_for_backward(mu, ls)
         ctx.coef = coef
@@ -1081,7 +1122,7 @@ class SymKLFn(Function):
     @staticmethod
     def forward(ctx, w, r, coef):
         w, r = w.contiguous().float(), r.contiguous().float()
-        out = torch.zeros((1,), device=w.device, dtype=f32)
+        out = zeros((1,), w.device)
         K.symkl_fwd(w, r, out, coef)
         ctx.save_for_backward(w, r)
         ctx.coef = coef
@@ -1104,7 +1145,7 @@ class MatmulNTFn(Function):
         Kd = a.shape[1]
         if a.shape[0] <= 128 and b.shape[0] <= 128 and Kd >= 256:
             # a [B, D] x [D, B] product is ONE workgroup walking D in exact-f32 steps of 16 (30 us at D = 512): split K
-            out = torch.zeros((a.shape[0], b.shape[0]), device=a.device, dtype=f32)
+            out = zeros((a.shape[0], b.shape[0]), a.device)
             return K.gemm(a, b.t(), out=out, accumulate=True, split_k=max(2, min(16, Kd // 64)), mma=MH_F32)
         return K.gemm(a, b.t(), mma=MH_F32)
 
