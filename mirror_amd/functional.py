@@ -413,7 +413,8 @@ class LayerNormFn(Function):
         # _res_grads; LN adds its own dx INTO that tensor (mh_layernorm_bwd accumulate_dx) instead of handing autograd a
         # second [B, T, D] f32 gradient to sum (a 400 MB elementwise pass per block)
         G = _res_grads.pop(x.data_ptr(), None)
-        if G is not None and G.shape == x.shape and G.dtype == x.dtype and G.is_contiguous():
+        if G is not None and G.numel() == x.numel() and G.dtype == x.dtype and G.is_contiguous():
+            G = G.view(x.shape)          # the RNA blocks run on [B, D]: layer_norm() added a leading 1
             K.layernorm_bwd(dy[:, pad:], x, gamma.detach(), mean, rstd, G, dg, db, Bn, rows, D, T * D, (pad + rows) * D,
                             accumulate_dx=True)
             return None, _gret(gamma, dg, sunk_g), _gret(beta, db, sunk_b), None, None, None, None
