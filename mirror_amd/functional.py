@@ -173,7 +173,7 @@ def _gbuf(param: torch.Tensor, shape):
         v = _sink.slot(param)
         if v is not None:
             return v.view(shape), True
-    return torch.zeros(shape, device=param.device, dtype=f32), False
+    return zeros(shape, param.device), False
 
 
 def _gret(param: torch.Tensor, buf: torch.Tensor, via_sink: bool):
@@ -797,7 +797,7 @@ class NystromCoreFn(Function):
         dqkv = torch.empty_like(qkv)
         dq, dk, dv = (_heads(dqkv, i, 3, h) for i in range(3))
         rw = res_w.detach().contiguous()
-        dres = zeros((rw.numel(),), qkv.device)
+        dres, dres_sunk = _gbuf(res_w, (rw.numel(),))     # the 33-tap filters' gradient goes straight into the grad arena
         # out = a1 @ w2 ; w2 = Z @ av ; av = a3 @ v.  dZ first: it is all the pinv backward needs (the res_conv weight
         # gradient does not depend on it and runs beside the chain, below).
         if fused:
@@ -853,7 +853,8 @@ class NystromCoreFn(Function):
         if kmask is not None:
             dlm = K.row_scale(dlm, lscale)
         K.landmark_bwd(K.cast(dlm, A), dqkv, l)
-        return dqkv, dres.view_as(res_w), None, None, None, None, None
+        dres = _gret(res_w, dres, dres_sunk)
+        return dqkv, (None if dres is None else dres.view_as(res_w)), None, None, None, None, None
 
 
 class RowScaleFn(Function):
