@@ -219,6 +219,24 @@ def _gemm_rows(a, b, *, bias=None, act=ACT_NONE, mma, out_dtype):
     return K.gemm(a, b, bias=bias, act=act, mma=mma, out_dtype=out_dtype)
 
 
+_GEMM_WINDOW = os.environ.get("MIRROR_GEMM_WINDOW", "1") != "0"     # A/B switch
+
+
+def _gemm_window(a3, b2, out3, *, bias=None, mma):
+    """out3[b] = a3[b] @ b2 (+ bias) for a row window a3 [B, R, K] of a larger buffer.  Nystrom's `to_out(out)[:, -n:]`
+    has R = n = 4097 rows (cls + 4096 patches): 17 row tiles of the 256 x 256 kernel per slide, the 17th holding ONE row,
+    and 16 x 17 x 2 = 544 workgroups = a third round on 256 CUs for 32 almost empty tiles.  The few ragged rows go to their
+    own small launch instead and the rest is whole tiles (512 workgroups, two full rounds)."""
+    R = a3.shape[1]
+    hr = R % 256
+    if a3.dim() == 3 and R > 256 and 0 < hr <= 32 and mma == MH_BF16 and _GEMM_WINDOW:
+        K.gemm(a3[:, hr:], b2, out=out3[:, hr:], bias=bias, mma=mma)
+        K.gemm(a3[:, :hr], b2, out=out3[:, :hr], bias=bias, mma=mma)
+    else:
+        K.gemm(a3, b2, out=out3, bias=bias, mma=mma)
+    return out3
+
+
 def _fp8_linear(xa, wa, bias, act, out):
     """out = act(xa @ wa^T + bias) with per-tensor-scaled e4m3 operands (config 5).  xa [.., R, K] bf16 (a row window of a
     contiguous parent is quantised through the parent), wa [N, K] bf16 contiguous.  Returns False when the shape does not
@@ -347,7 +365,8 @@ class LinearRowsFn(Function):
             if not _fp8_linear(xv, wa, None if b is None else b.detach(), ACT_NONE, y):
                 y = None
         if y is None:
-            y = K.gemm(xv, wa.t(), bias=None if b is None else b.detach(), mma=prec.mma, out_dtype=out_dtype or prec.act)
+            y = torch.empty((x.shape[0], R, wa.shape[0]), device=x.device, dtype=out_dtype or prec.act)
+            _gemm_window(xv, wa.t(), y, bias=None if b is None else b.detach(), mma=prec.mma)
         ctx.save_for_backward(x, wa, w, b)
         ctx.r0, ctx.R, ctx.prec, ctx.has_b = r0, R, prec, b is not None
         return y
@@ -368,7 +387,7 @@ class LinearRowsFn(Function):
                 dx[:, :r0].zero_()
             if r0 + R < x.shape[1]:
                 dx[:, r0 + R:].zero_()
-            K.gemm(dy, wa, out=dx[:, r0:r0 + R], mma=prec.mma)
+            _gemm_window(dy, wa, dx[:, r0:r0 + R], mma=prec.mma)
         if ctx.needs_input_grad[1]:
             dw, sunk = _gbuf(w, (N, Kd))
             _wgrad(dy, x[:, r0:r0 + R], N, Kd, prec, dw)
