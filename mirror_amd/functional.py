@@ -195,14 +195,16 @@ _GEMM_SPLIT = os.environ.get("MIRROR_GEMM_SPLIT", "1") != "0"     # A/B switch f
 _CUS = 256       # MI355X compute units = workgroup slots of the one-workgroup-per-CU 256 x 256 GEMM tile
 
 
-def _gemm_rows(a, b, *, bias=None, act=ACT_NONE, mma, out_dtype):
+def _gemm_rows(a, b, *, bias=None, act=ACT_NONE, mma, out_dtype, out=None):
     """a @ b for activations a [..., R, K] against a 2-D weight view b [K, N].  The 256 x 256-tile kernel runs one
     workgroup per CU, so a launch costs ceil(tiles / 256) rounds: the to_qkv data gradient (544 tiles) pays 3 rounds for
     2.1 rounds of work.  When the last round would be less than half full, the rows that fill whole rounds go to one
     launch and the remaining rows to a second one, which is too small for the big tile and runs on the 128 x 128 kernel
     (4x smaller tiles, 2 workgroups per CU): 2.1 rounds cost ~2.3 instead of 3."""
     if (a.dim() >= 2 and a.is_contiguous() and b.dim() == 2 and a.dtype == bf16 and b.dtype == bf16 and mma == MH_BF16
-            and (out_dtype or a.dtype) in (bf16, f32) and _GEMM_SPLIT):
+            and (out_dtype or a.dtype) in (bf16, f32) and _GEMM_SPLIT
+            and (out is None or (out.dim() == a.dim() and out.stride(-1) == 1 and all(
+                out.stride(i) == out.shape[i + 1] * out.stride(i + 1) for i in range(out.dim() - 2))))):
         R, Kd, N = a.numel() // a.shape[-1], a.shape[-1], b.shape[1]
         if R % 256 == 0 and N % 256 == 0 and Kd % 64 == 0:
             tn = N // 256
@@ -212,11 +214,11 @@ def _gemm_rows(a, b, *, bias=None, act=ACT_NONE, mma, out_dtype):
                 rows_main = (full * _CUS // tn) * 256
                 if 0 < rows_main < R:
                     a2 = a.reshape(R, Kd)
-                    out = torch.empty((R, N), device=a.device, dtype=out_dtype or a.dtype)
-                    K.gemm(a2[:rows_main], b, out=out[:rows_main], bias=bias, act=act, mma=mma)
-                    K.gemm(a2[rows_main:], b, out=out[rows_main:], bias=bias, act=act, mma=mma)
-                    return out.reshape(*a.shape[:-1], N)
-    return K.gemm(a, b, bias=bias, act=act, mma=mma, out_dtype=out_dtype)
+                    o2 = torch.empty((R, N), device=a.device, dtype=out_dtype or a.dtype) if out is None else out.view(R, N)
+                    K.gemm(a2[:rows_main], b, out=o2[:rows_main], bias=bias, act=act, mma=mma)
+                    K.gemm(a2[rows_main:], b, out=o2[rows_main:], bias=bias, act=act, mma=mma)
+                    return o2.reshape(*a.shape[:-1], N) if out is None else out
+    return K.gemm(a, b, out=out, bias=bias, act=act, mma=mma, out_dtype=out_dtype)
 
 
 _GEMM_WINDOW = os.environ.get("MIRROR_GEMM_WINDOW", "1") != "0"     # A/B switch
@@ -263,12 +265,19 @@ class LinearFn(Function):
     W: [N, K] f32 master.  Replaces nn.Linear (+ nn.ReLU for _fc1, models/mirror.py:346)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, act, prec, out_dtype):
+    def forward(ctx, x, w, b, act, prec, out_dtype, defer_from=None):
         xa = x if x.dtype == prec.act else K.cast(x.contiguous(), prec.act)
         wa = shadow(w, prec)
         bd = None if b is None else b.detach()
         ctx.skinny = prec.act == bf16 and K.skinny_ok(xa, wa)      # [B, D] activations: weight-streaming kernels
         y = None
+        if (defer_from and _DEFER_V and not ctx.skinny and not prec.fp8_fwd and b is None and act == ACT_NONE
+                and xa.is_contiguous() and 0 < defer_from < wa.shape[0]):
+            # to_qkv: the q | k columns now, the v columns when NystromCoreFn asks for them (under the pinv chain)
+            y = torch.empty(tuple(xa.shape[:-1]) + (wa.shape[0],), device=xa.device, dtype=out_dtype or prec.act)
+            c0, od = defer_from, out_dtype or prec.act
+            _gemm_rows(xa, wa[:c0].t(), mma=prec.mma, out_dtype=od, out=y[..., :c0])
+            _deferred[y.data_ptr()] = lambda: _gemm_rows(xa, wa[c0:].t(), mma=prec.mma, out_dtype=od, out=y[..., c0:])
         if ctx.skinny:
             y = K.skinny_fwd(xa, wa, bd, act, out_dtype or prec.act)
         elif prec.fp8_fwd:
@@ -326,7 +335,7 @@ class LinearFn(Function):
             db, sunk = _gbuf(b, (N,))
             K.colsum(dy.reshape(-1, N), db)
             db = _gret(b, db, sunk)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
 def _blk_ok(t: torch.Tensor) -> bool:
@@ -347,8 +356,20 @@ def _wgrad(dy: torch.Tensor, x: torch.Tensor, N: int, Kd: int, prec: Precision, 
     return dw
 
 
-def linear(x, w, b=None, *, act=ACT_NONE, prec: Precision, out_dtype=None):
-    return LinearFn.apply(x, w, b, act, prec, out_dtype)
+def linear(x, w, b=None, *, act=ACT_NONE, prec: Precision, out_dtype=None, defer_from=None):
+    """defer_from = c: only output columns [0, c) are computed here; the rest is a pending launch that the consumer runs
+    with run_deferred(y) (NystromCoreFn does, right after it has forked the pinv chain)."""
+    return LinearFn.apply(x, w, b, act, prec, out_dtype, defer_from)
+
+
+_DEFER_V = os.environ.get("MIRROR_DEFER_V", "1") != "0"       # A/B switch
+_deferred: dict = {}        # data_ptr of a partly computed linear output -> the launch that completes it
+
+
+def run_deferred(y: torch.Tensor) -> None:
+    t = _deferred.pop(y.data_ptr(), None)
+    if t is not None:
+        t()
 
 
 class LinearRowsFn(Function):
@@ -750,6 +771,7 @@ class NystromCoreFn(Function):
             with torch.cuda.stream(side):
                 K.pinv_chain_fwd(xt, chain_saved, zfT, iters)
             saved = [(xt, chain_saved, z0)]
+        run_deferred(qkv)        # the v columns of to_qkv: nothing above reads them (landmarks are means of q and k)
         fused = K.nys_fused_ok(qkv, h, m_l) and lm.dtype == bf16      # nystrom_fused.hip: sim1 / sim3 never reach HBM (mask-aware)
         lse1 = lse3 = a1 = a3 = None
         if fused:

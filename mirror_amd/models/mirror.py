@@ -193,7 +193,7 @@ class TransLayer(nn.Module):
             cnt = mrow.reshape(mrow.shape[0], (n + pad) // l, l).sum(-1)
             kmask = (mrow, (cnt > 0).float().contiguous(), (float(l) / (cnt + 1e-8)).contiguous())
             xp = Fn.RowScaleFn.apply(xp, mrow)           # to_qkv has no bias: zero rows in, zero q / k / v rows out
-        qkv = Fn.linear(xp, a.to_qkv.weight, None, prec=prec)
+        qkv = Fn.linear(xp, a.to_qkv.weight, None, prec=prec, defer_from=2 * a.to_qkv.weight.shape[1])
         core = Fn.NystromCoreFn.apply(qkv, a.res_conv.weight, a.heads, l, a.pinv_iterations, prec, kmask)
         y = Fn.LinearRowsFn.apply(core, a.to_out[0].weight, a.to_out[0].bias, pad, n, prec, prec.act)
         return Fn.dropout_add(x, y, a.drop, self.training)           # x feeds exactly self.norm and this add
@@ -478,7 +478,8 @@ class MIRROR(nn.Module):
         noise = dict(noise or {})
         if not wsi_emb.is_cuda:
             raise MirrorHipError("mirror_amd models run on MI355X only (no CPU fallback): move the inputs to the GPU")
-        Fn._res_grads.clear()       # hand-over slots of a backward that never completed must not meet this step's tensors
+        Fn._res_grads.clear()
+        Fn._deferred.clear()       # hand-over slots of a backward that never completed must not meet this step's tensors
         # the reference draws: rand(B,N) -> rand(B,D) -> eps_wsi -> eps_rna (models/mirror.py:630, :516, :832-833);
         # draw them up front in that order so the two encoders can then run on different streams
         B, dev = wsi_emb.shape[0], wsi_emb.device
