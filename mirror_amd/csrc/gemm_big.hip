@@ -9,6 +9,9 @@
 // Used by gemm_launch_bf16 when N is a multiple of 256, K of 64, M a multiple of 256 (or ragged with K-contiguous A rows:
 // loads clamp to the last row, stores are guarded) and the operands are 16-byte aligned.
 #include "gemm_kernel.h"
+#ifndef GEMM_EXP
+#define GEMM_EXP 0
+#endif
 
 namespace {
 
@@ -152,6 +155,7 @@ __device__ __forceinline__ void epilogue_big_t(const GemmArgs& g, bf16_t* C, f32
                 o[w] = (unsigned)f2bf(a0) | ((unsigned)f2bf(a1) << 16);
             }
         }
+        if (GEMM_EXP == 5) { if (o[0] == 0x12345678u) *reinterpret_cast<u32x4*>(dst) = o; continue; }
         *reinterpret_cast<u32x4*>(dst) = o;
     }
 }
@@ -277,6 +281,17 @@ __global__ __launch_bounds__(NTB) void gemm_big_kernel(GemmArgs g) {
         const float a8 = g.alpha * g.scale_a[0] * g.scale_b[0];
         if constexpr (sizeof(TC) == 2) epilogue_big_t<0>(g, C, acc, smem, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, true, a8);
         else epilogue_big<TC, 0>(g, C, acc, smem, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, true, g.ldc, a8);
+        return;
+    }
+    if (GEMM_EXP == 4) {
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < BWM; i++)
+#pragma unroll
+            for (int j = 0; j < BWN; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) ss += acc[i][j][r];
+        if (ss == 123.456f) C[0] = (TC)0;
         return;
     }
     const bool lead = (split == 0);
