@@ -18,5 +18,5 @@ rm -rf /tmp/p3; rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/p3 -o f -
 rm -rf /tmp/p4; rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/p4 -o w -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 ff=$(find /tmp/p3 -name "*counter_collection.csv" | head -1); fw=$(find /tmp/p4 -name "*counter_collection.csv" | head -1)
 [ -n "$ff" ] && [ -n "$fw" ] && python3 $R/tools/pmc_summary.py $ff $fw > $OUT/pmc_traffic.json
-python3 $R/tools/run_c4.py --batch 8 --steps 5 2>/dev/null | tail -1 > $OUT/${TAG}_c4_run.json
+python3 $R/tools/run_c4.py --batch 8 --steps 12 2>/dev/null | tail -1 > $OUT/${TAG}_c4_run.json
 ls -la $OUT
