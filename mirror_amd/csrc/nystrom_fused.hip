@@ -232,11 +232,20 @@ __global__ __launch_bounds__(NT) void nys_a1_fwd_kernel(const bf16_t* __restrict
         // online softmax over the 8 landmark blocks: 16 logits live at a time instead of 128 (two waves per SIMD fit)
         float mrun = NEG_BIG, lrun = 0.f;
         f32x16 o[2] = {zero16(), zero16()};   // O^T[d][q row]
+        // the logits of block blk + 1 are issued before the softmax arithmetic of block blk: the MFMA pipe works on them
+        // while the VALU does max / exp2 / sum / pack (a wave is otherwise strictly MFMA -> VALU -> MFMA, and only one
+        // other wave shares the SIMD)
+        f32x16 snext = zero16();              // S^T[landmark 32 blk ..][q row]
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) snext = MFMA(frag_kc(s_kl, 0, 16 * ks, lane), qf[ks], snext);
 #pragma unroll
         for (int blk = 0; blk < 8; blk++) {
-            f32x16 sb = zero16();             // S^T[landmark 32 blk ..][q row]
+            f32x16 sb = snext;
+            if (blk + 1 < 8) {
+                snext = zero16();
 #pragma unroll
-            for (int ks = 0; ks < 4; ks++) sb = MFMA(frag_kc(s_kl, 32 * blk, 16 * ks, lane), qf[ks], sb);
+                for (int ks = 0; ks < 4; ks++) snext = MFMA(frag_kc(s_kl, 32 * (blk + 1), 16 * ks, lane), qf[ks], snext);
+            }
             float sc2 = g.scale2;
             if (masked) {                                          // logits to log2 units first, invalid ones to NEG_FILL
                 sb = sb * g.scale2;
