@@ -103,6 +103,8 @@ class TrainEngine:
         self._uses = [0] * len(order)        # sink writes per parameter per step, learnt during the first step
         self._seen = [0] * len(order)
         self._counting = True
+        self._capturing = None               # list of parameter indices while graphed.GraphedBranch records a backward
+        self._index_of = {id(p): i for i, p in enumerate(order)}
         self._proto = getattr(model, "prototypes", None)
         self._logit = getattr(model, "logit_scale", None)
         # step state on the device {t, 1 - b1^t, 1 - b2^t, lr}: advanced by mh_adam itself, so nothing that changes from
@@ -121,6 +123,9 @@ class TrainEngine:
             self._use_graph = False      # micro-steps and update steps are different launch sequences
         self._graph = None
         self._graph_warm = 0
+        # eager launch mode: the launch-bound RNA branch is replayed from two HIP graphs (MIRROR_RNA_GRAPH=0 disables)
+        self._rna_branch_state = "pending" if os.environ.get("MIRROR_RNA_GRAPH", "1") not in ("0", "") else "off"
+        self._rna_warm = 0
         self._g_in = None
         self._g_out = None
         if self.world > 1:
@@ -153,30 +158,77 @@ class TrainEngine:
 
     def done(self, t: torch.Tensor) -> None:
         i = self._slot_of[t.data_ptr()]
+        if self._capturing is not None:          # dry run that records a branch's backward graph (graphed.py)
+            self._capturing.append(i)
+            return
         self._seen[i] += 1
         if self._counting:
             self._uses[i] += 1
         elif self.world > 1 and self._seen[i] == self._uses[i]:
             self._on_grad(self.params[i])
 
+    def _branch_done(self, idx) -> None:
+        """A replayed backward graph has finished these parameters' gradients (they never pass done() / autograd hooks)."""
+        if self.world > 1:
+            for i in idx:
+                self._on_grad(self.params[i])
+
+    # ------------------------------------------------------------------ graphed RNA branch of the eager step
+    def _maybe_graph_rna(self, rna: torch.Tensor) -> None:
+        """Eager launch mode only (N > 1, masks, accumulation): after two warm steps record the RNA branch's forward and
+        backward as HIP graphs (graphed.py) and let the model replay them.  Any failure keeps the eager branch."""
+        if self._rna_branch_state != "pending" or self._rna_warm < 2:
+            self._rna_warm += 1
+            return
+        self._rna_branch_state = "off"
+        m = self.model
+        if not hasattr(m, "rna_branch") or not m.training or self.precision == "fp32":
+            return
+        try:
+            from .graphed import GraphedBranch
+            noise = torch.rand(rna.shape[0], m.embed_dim, device=rna.device)
+            ratio = self.rna_mask_ratio
+            br = GraphedBranch(lambda x, nz: m.rna_branch(x, nz, ratio), (rna, noise),
+                               next(m.rna_encoder.parameters()), self)
+            m._rna_graph = (br, ratio)
+            self._rna_branch_state = "on"
+        except Exception as e:                               # noqa: BLE001  (an optimisation: fall back loudly)
+            import warnings
+            warnings.warn(f"mirror_amd: HIP graph capture of the RNA branch failed ({e!r}); it stays eager")
+            m._rna_graph = None
+            self._capturing = None
+            Fn.set_grad_sink(None)
+            torch.cuda.synchronize()
+
     # ------------------------------------------------------------------ gradient buckets (data parallel)
     def _build_buckets(self, bucket_mb: float) -> None:
         self.buckets, owner = plan_buckets([p.numel() for p in self.params], int(bucket_mb * (1 << 20) / 4))
         self._bucket_of: Dict[int, int] = {id(p): b for p, b in zip(self.params, owner)}
         self._pending = [b[2] for b in self.buckets]
+        self._reported = [False] * len(self.params)
         self._works = []
         self.comm_stream = torch.cuda.Stream(device=self.device)
         for p in self.params:
             p.register_post_accumulate_grad_hook(self._on_grad)
 
     def _on_grad(self, p: torch.Tensor) -> None:
+        if self._capturing is not None:             # autograd-accumulated parameter inside a branch capture
+            self._capturing.append(self._index_of[id(p)])
+            return
         if self._micro + 1 < self.accum_steps:      # accumulation micro-step: no reduction yet (DDP no_sync)
             return
+        i = self._index_of[id(p)]
+        if self._reported[i]:       # a parameter reports ONCE per step: autograd still runs the AccumulateGrad node (and its
+            return                  # post hook) of a parameter whose Functions returned None because they used the sink
+        self._reported[i] = True
         b = self._bucket_of[id(p)]
         self._pending[b] -= 1
         if self._pending[b] == 0:
             s, e, _ = self.buckets[b]
+            # a bucket mixes parameters whose gradient kernels were queued on different streams (main, RNA side stream):
+            # the reduction has to wait for all of them, not only for the stream of the parameter that completed it
             self.comm_stream.wait_stream(torch.cuda.current_stream())
+            Fn.join_side_streams(self.device, self.comm_stream)
             with torch.cuda.stream(self.comm_stream):
                 w = dist.all_reduce(self.grad[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
             self._works.append(w)
@@ -189,6 +241,7 @@ class TrainEngine:
                 if c != 0:
                     s, e, _ = self.buckets[b]
                     self.comm_stream.wait_stream(torch.cuda.current_stream())
+                    Fn.join_side_streams(self.device, self.comm_stream)
                     with torch.cuda.stream(self.comm_stream):
                         self._works.append(dist.all_reduce(self.grad[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         for w in self._works:
@@ -196,6 +249,7 @@ class TrainEngine:
         torch.cuda.current_stream().wait_stream(self.comm_stream)
         self._works = []
         self._pending = [b[2] for b in self.buckets]
+        self._reported = [False] * len(self.params)
 
     # ------------------------------------------------------------------ one optimizer step
     def step(self, wsi: torch.Tensor, rna: torch.Tensor, noise: Optional[dict] = None,
@@ -238,6 +292,8 @@ class TrainEngine:
 
     def _step_eager(self, wsi: torch.Tensor, rna: torch.Tensor, noise: Optional[dict],
                     wsi_key_padding_mask: Optional[torch.Tensor] = None):
+        if not torch.cuda.is_current_stream_capturing() and (not self._use_graph or wsi_key_padding_mask is not None):
+            self._maybe_graph_rna(rna)       # steps that are not replayed as one graph: N > 1, padded slides + mask
         Fn.zero_arena_begin(self.device)
         try:
             return self._step_body(wsi, rna, noise, wsi_key_padding_mask)
@@ -261,6 +317,7 @@ class TrainEngine:
             losses[0].backward()
         finally:
             Fn.set_grad_sink(None)
+        Fn.join_side_streams(self.device)       # sink-written gradients of the side-stream branches (see join_side_streams)
         if self._counting:
             # first step: sink-written parameters were only counted; their buckets are reduced below (_finish_reduce
             # reduces every bucket that is still pending)

@@ -687,6 +687,18 @@ def _side_stream(device, which: int = 0) -> torch.cuda.Stream:
     return st
 
 
+def join_side_streams(device, stream=None) -> None:
+    """`stream` (default: the current one) waits for everything queued on the helper streams of `device`.  Autograd's end-of-backward
+    synchronisation only covers streams on which an AccumulateGrad node ran; with the gradient sink the weight gradients are
+    written by kernels launched inside Function.backward (or by a replayed HIP graph, graphed.py) on the branch's stream, so
+    whoever reads the gradient arena next (all-reduce, clip, Adam) has to join those streams itself."""
+    idx = torch.device(device).index or 0
+    cur = stream if stream is not None else torch.cuda.current_stream()
+    for (d, _), st in _side_streams.items():
+        if d == idx and st != cur:
+            cur.wait_stream(st)
+
+
 def _heads(t3: torch.Tensor, which: int, parts: int, h: int) -> torch.Tensor:
     """[B, T, parts*D] buffer -> [B, h, T, dh] view of column block `which` (heads are dh-wide column slices)."""
     Bn, T, Dt = t3.shape

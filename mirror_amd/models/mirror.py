@@ -470,6 +470,12 @@ class MIRROR(nn.Module):
         rna_score, rna_mu, rna_logstd = self._style_branch(rna_emb, rna_eps, prec)
         return wsi_score, wsi_mu, wsi_logstd, rna_score, rna_mu, rna_logstd
 
+    def rna_branch(self, rna_emb, rna_noise, rna_mask_ratio: float):
+        """The RNA side of forward() up to the loss inputs: encoder output, alignment / retention heads, token mask."""
+        rna_emb = self.rna_encoder.forward_encoder(rna_emb)
+        a, r, mask = self.rna_encoder.forward_decoders(rna_emb, mask_ratio=rna_mask_ratio, noise=rna_noise)
+        return rna_emb, a, r, mask
+
     def forward(self, wsi_emb, rna_emb, wsi_mask_ratio: float = 0.75, rna_mask_ratio: float = 0.75,
                 noise: Optional[Dict[str, torch.Tensor]] = None, wsi_key_padding_mask: Optional[torch.Tensor] = None):
         """`noise` (build-only) pins the random draws; `wsi_key_padding_mask` (build-only, BASELINE config 4): [B, N] bool,
@@ -502,9 +508,13 @@ class MIRROR(nn.Module):
             n_tok = wsi_emb.shape[1]
             wsi_mask = Fn.rank_mask(noise["wsi_mask"], int(n_tok * (1 - wsi_mask_ratio)))
             mask_ready = side.record_event()
-            rna_emb = self.rna_encoder.forward_encoder(rna_emb)
-            rna_alignment_emb, rna_retention_emb, rna_mask = self.rna_encoder.forward_decoders(
-                rna_emb, mask_ratio=rna_mask_ratio, noise=noise.get("rna_mask"))
+            g = getattr(self, "_rna_graph", None)      # TrainEngine's HIP-graph replay of this branch (graphed.py)
+            if (g is not None and g[1] == rna_mask_ratio and self.training and torch.is_grad_enabled()
+                    and not torch.cuda.is_current_stream_capturing() and g[0].matches((rna_emb, noise["rna_mask"]))):
+                rna_emb, rna_alignment_emb, rna_retention_emb, rna_mask = g[0](rna_emb, noise["rna_mask"])
+            else:
+                rna_emb, rna_alignment_emb, rna_retention_emb, rna_mask = self.rna_branch(
+                    rna_emb, noise["rna_mask"], rna_mask_ratio)
         wsi_emb = self.wsi_encoder.forward_encoder(wsi_emb, wsi_key_padding_mask)
         # the encoder output has three consumers (decoder input, retention target, cls row): one node sums their gradients
         wsi_full, wsi_retention_target, wsi_cls = Fn.enc_fanout(wsi_emb)
