@@ -1,3 +1,4 @@
+"""Two gloo ranks on one GPU: how often does each parameter report to its gradient bucket per step, which buckets are\nleft for _finish_reduce, which went negative (each parameter must report exactly once)."""
 import sys, os, collections
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import torch, torch.distributed as dist, torch.multiprocessing as mp

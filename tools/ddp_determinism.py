@@ -1,3 +1,4 @@
+"""Two gloo ranks on one GPU run the eager bucketed step twice (second engine optionally with the graphed RNA branch):\nper-parameter differences of the reduced gradients and checksums — they must agree from run to run (SECOND_ON=0/1, GATHER=0/1)."""
 import sys, os
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import torch, torch.distributed as dist, torch.multiprocessing as mp
