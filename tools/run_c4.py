@@ -26,7 +26,7 @@ rna = torch.randn(a.batch, G, device=dev, generator=g)
 lens = torch.randint(2048, N + 1, (a.batch,), device=dev, generator=g)
 mask = torch.arange(N, device=dev)[None, :] < lens[:, None]
 wsi = wsi * mask[..., None]                                   # padded rows are zeros, as a collate function would leave them
-for _ in range(2):
+for _ in range(4):      # two warm steps, the step that records the RNA-branch graphs, one replayed step
     losses = eng.step(wsi, rna, wsi_key_padding_mask=mask)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
