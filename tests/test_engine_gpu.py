@@ -144,6 +144,14 @@ def test_graphed_step_replays_with_fresh_state():
         sl = slice(off, off + prm.numel())
         assert float((eng.master[sl] - before[sl]).abs().max()) == 0.0, "lr change was not published to the graphed step"
     assert float(eng._state[0]) == 7.0
+    # static inputs: the same, unmodified batch tensor is not copied again; a refilled one (version bump) or a new tensor is
+    assert eng._g_src[0] is wsi and torch.equal(eng._g_in[0], wsi)
+    wsi.mul_(0.5)
+    eng.step(wsi, rna)
+    assert torch.equal(eng._g_in[0], wsi), "an in-place refill of the batch tensor did not reach the graph's static input"
+    wsi2 = wsi.clone() + 1
+    eng.step(wsi2, rna)
+    assert torch.equal(eng._g_in[0], wsi2) and eng._g_src[0] is wsi2
 
 
 def test_grad_clip_and_accumulation_match_torch():
