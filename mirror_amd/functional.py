@@ -87,11 +87,16 @@ def shadow_t(w: torch.Tensor, prec: Precision) -> torch.Tensor:
         if _alive(man[1]):
             return man[0]
         _managed_shadows_t.pop(key, None)
+    # An optimizer that rewrites the master through raw kernels (TrainEngine: mh_adam) does not bump the version counter:
+    # for a weight whose bf16 shadow it manages but whose transpose it does not (a dimension that is not a multiple of 32),
+    # the cached W^T would be the first step's for ever — transpose the live shadow on every call instead (small weights).
+    engine_managed = key in _managed_shadows
     hit = _shadow_t_cache.get(key)
-    if hit is not None and _alive(hit[2]) and hit[0] == w._version:
+    if not engine_managed and hit is not None and _alive(hit[2]) and hit[0] == w._version:
         return hit[1]
     t = K.transpose_bf16(shadow(w, prec).contiguous())
-    _shadow_t_cache[key] = (w._version, t, weakref.ref(w))
+    if not engine_managed:
+        _shadow_t_cache[key] = (w._version, t, weakref.ref(w))
     return t
 
 

@@ -320,3 +320,24 @@ def test_rna_branch_graph_under_bucketed_all_reduce_world2():
     assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2]), "ranks diverged"
     _traj_close(torch.from_numpy(res[0][1]), torch.from_numpy(res[0][2]), torch.from_numpy(res[0][3]))
     assert abs(res[0][5] - res[0][6]) < 5e-3 * abs(res[0][5])
+
+
+def test_transposed_shadow_follows_the_optimizer_for_unmanaged_shapes():
+    """The engine keeps W^T shadows only for weights whose dims are multiples of 32; for the others (here the style decoder
+    with a 16-wide latent) functional.shadow_t must transpose the LIVE bf16 shadow: mh_adam rewrites the master through a raw
+    pointer, so a version-keyed cache would serve the first step's W^T for ever."""
+    import mirror_amd.models as M
+    from mirror_amd import functional as Fn
+    from mirror_amd.engine import TrainEngine
+    from mirror_amd.losses import MIRRORLoss
+    torch.manual_seed(5)
+    model = M.mirror(**CFG).cuda().train()
+    eng = TrainEngine(model, MIRRORLoss(), lr=1e-2, precision="bf16", graph=False)
+    prec = Fn.POLICIES["bf16"]
+    odd = [p for p in eng.params if p.dim() == 2 and (p.shape[0] % 32 or p.shape[1] % 32) and p.shape[0] % 32 == 0]
+    assert odd, "the test configuration lost its non-multiple-of-32 weight"
+    for s in range(3):
+        wsi, rna, noise = _batch(4, 40 + s)
+        eng.step(wsi.to(torch.bfloat16), rna, noise=noise)
+        for w in odd:
+            assert torch.equal(Fn.shadow_t(w, prec), Fn.shadow(w, prec).t().contiguous()), (s, tuple(w.shape))
