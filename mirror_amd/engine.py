@@ -189,8 +189,10 @@ class TrainEngine:
             from .graphed import GraphedBranch
             noise = torch.rand(rna.shape[0], m.embed_dim, device=rna.device)
             ratio = self.rna_mask_ratio
-            br = GraphedBranch(lambda x, nz: m.rna_branch(x, nz, ratio), (rna, noise),
-                               next(m.rna_encoder.parameters()), self)
+            anchor = next((p for p in m.rna_encoder.parameters() if p.requires_grad), None)
+            if anchor is None:                               # a frozen RNA encoder has no backward to replay
+                return
+            br = GraphedBranch(lambda x, nz: m.rna_branch(x, nz, ratio), (rna, noise), anchor, self)
             m._rna_graph = (br, ratio)
             self._rna_branch_state = "on"
         except Exception as e:                               # noqa: BLE001  (an optimisation: fall back loudly)
