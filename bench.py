@@ -58,10 +58,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # MIRROR_BENCH_DIST=gloo:shared runs the N > 1 code path with every rank on GPU 0 over gloo: a dry run of this file's
+    # multi-rank branch on a one-GPU box (tools/bench_world2_dryrun.sh); the driver's runs use RCCL, one GPU per rank.
+    dry = os.environ.get("MIRROR_BENCH_DIST", "") == "gloo:shared"
+    if dry:
+        local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
