@@ -510,7 +510,8 @@ class MIRROR(nn.Module):
             mask_ready = side.record_event()
             g = getattr(self, "_rna_graph", None)      # TrainEngine's HIP-graph replay of this branch (graphed.py)
             if (g is not None and g[1] == rna_mask_ratio and self.training and torch.is_grad_enabled()
-                    and not torch.cuda.is_current_stream_capturing() and g[0].matches((rna_emb, noise["rna_mask"]))):
+                    and not torch.cuda.is_current_stream_capturing() and Fn._dropout_state["offset"] == 0   # offsets baked at 0
+                    and g[0].matches((rna_emb, noise["rna_mask"]))):
                 rna_emb, rna_alignment_emb, rna_retention_emb, rna_mask = g[0](rna_emb, noise["rna_mask"])
             else:
                 rna_emb, rna_alignment_emb, rna_retention_emb, rna_mask = self.rna_branch(
