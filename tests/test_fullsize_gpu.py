@@ -49,6 +49,12 @@ def test_c2_shapes_fp32_policy_matches_live_oracle():
         assert err <= EMB_TOL, f"{nm}: {err:.3e}"
     got = [float(x.detach()) for x in MIRRORLoss()(*outs)]
     np.testing.assert_allclose(got, ref_loss, rtol=LOSS_RTOL)
+    # the policies the bench runs in (bf16 MFMA; fp8 forward projections): reported accuracy band, not the parity gate
+    for pol, band in (("bf16", 3e-2), ("fp8", 8e-2)):
+        o = _model(C2, sd, pol)(wsi.to(DEV).to(torch.bfloat16), rna.to(DEV), wsi_mask_ratio=0.75, rna_mask_ratio=0.75,
+                                noise={k: v.to(DEV) for k, v in noise.items()})
+        rel = np.abs(np.array([float(x.detach()) for x in MIRRORLoss()(*o)]) - np.array(ref_loss)) / np.abs(np.array(ref_loss))
+        assert (rel < band).all(), f"{pol}: loss rel err {rel}"
 
 
 def test_c2_shapes_fp32_backward_matches_live_oracle():
