@@ -272,70 +272,121 @@ __global__ __launch_bounds__(256) void ppeg_wgrad_kernel(const TX* __restrict__ 
     }
 }
 
-// Column-strip weight gradient: a thread owns one channel and PX_T pixels along x, walks down PW_ROWS grid rows with the
-// same 7-row register window as ppeg_strip_kernel: 8 + 14 loads feed 49 x 8 FMAs (the row-sweep kernel needs 64).
+// Column-strip weight gradient: a thread owns one channel and PX_T pixels along x, walks down PW_ROWS grid rows with a
+// register window of input rows: 8 + 14 loads feed 49 x 8 FMAs (the row-sweep kernel needs 64).
+// The window is a ring of EIGHT rows and the gradient row is double-buffered: row yy + 4 and the gradients of row yy + 1
+// are requested while row yy is accumulated, so no FMA waits for a load issued in its own iteration (with the 7-row
+// window every row step began with a full memory latency, at two waves per SIMD: 173 us for 268 MB).
 // (A channel-pair v_pk_fma form like ppeg_strip2_kernel was slower here: 98 accumulator + 140 window registers leave one
 // wave per SIMD and nothing to hide the row loads behind.)
-#define PW_ROWS 32
+#ifndef PW_ROWS
+#define PW_ROWS 64   // multiple of 8 (the ring is unrolled by its length)
+#endif
+#ifndef PW_X
+#define PW_X 4       // pixels along x per thread
+#endif
+#ifndef PW_RED
+#define PW_RED 1     // 1: workgroup = 64 channels x 4 strips with an LDS reduction, 0: 256 channels x 1 strip
+#endif
 template <typename TX, typename TO>
 __global__ __launch_bounds__(256) void ppeg_wgrad_strip_kernel(const TX* __restrict__ x, const TO* __restrict__ dout,
                                                                float* __restrict__ dmerged, float* __restrict__ dbsum, int S, int D) {
+    const int tiles_x = (S + PW_X - 1) / PW_X;
+#if PW_RED
+    // a workgroup = 64 channels x 4 strips (one per wave); the four partial filters are summed through LDS, so a
+    // workgroup issues 50 x 64 atomics instead of 50 x 256
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: addresses stay scalar
+    const int c = blockIdx.x * 64 + lane;
+    const int strip = blockIdx.y * 4 + wave;
+    const bool live = c < D && strip < tiles_x * ((S + PW_ROWS - 1) / PW_ROWS);
+#else
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= D) return;
-    const int tiles_x = (S + PX_T - 1) / PX_T;
-    const int y0 = (blockIdx.y / tiles_x) * PW_ROWS, x0 = (blockIdx.y % tiles_x) * PX_T;
+    const int strip = blockIdx.y;
+    const bool live = true;
+#endif
+    const int y0 = (strip / tiles_x) * PW_ROWS, x0 = (strip % tiles_x) * PW_X;
+    const int y1 = live ? min(y0 + PW_ROWS, S) : y0;      // one past the last row of this strip
     const long b = blockIdx.z;
     const long n = 1 + (long)S * S;
-    const TX* xb = x + b * n * D + c;
-    const TO* gb = dout + b * n * D + c;
+    const TX* xb = x + b * n * D + (live ? c : 0);
+    const TO* gb = dout + b * n * D + (live ? c : 0);
     float acc[49];
 #pragma unroll
     for (int t = 0; t < 49; t++) acc[t] = 0.f;
     float bacc = 0.f;
-    float win[7][PX_T + 6];
-    auto load_row = [&](float (&dst)[PX_T + 6], int sy) {
+    float win[8][PW_X + 6];      // row r of the grid lives in slot (r - y0 + 3) & 7
+    float g[2][PW_X];
+    auto load_row = [&](float (&dst)[PW_X + 6], int sy) {
         const bool rok = sy >= 0 && sy < S;
         const TX* row = xb + (1 + (long)(rok ? sy : 0) * S) * D;
 #pragma unroll
-        for (int u = 0; u < PX_T + 6; u++) {
+        for (int u = 0; u < PW_X + 6; u++) {
             const int sx = x0 - 3 + u;
             dst[u] = (rok && sx >= 0 && sx < S) ? ldf(row + (long)sx * D) : 0.f;
         }
     };
-    load_row(win[4], y0 - 3); load_row(win[5], y0 - 2); load_row(win[6], y0 - 1);
-    load_row(win[0], y0); load_row(win[1], y0 + 1); load_row(win[2], y0 + 2);
-    for (int yb0 = y0; yb0 < y0 + PW_ROWS && yb0 < S; yb0 += 7) {
+    auto load_g = [&](float (&dst)[PW_X], int yy) {
+        const bool rok = yy < y1;
+        const TO* row = gb + (1 + (long)(rok ? yy : 0) * S) * D;
 #pragma unroll
-        for (int j = 0; j < 7; j++) {
+        for (int i = 0; i < PW_X; i++) dst[i] = (rok && x0 + i < S) ? ldf(row + (long)(x0 + i) * D) : 0.f;
+    };
+    if (live) {
+#pragma unroll
+        for (int r = 0; r < 7; r++) load_row(win[r], y0 - 3 + r);
+        load_g(g[0], y0);
+    }
+    for (int yb0 = y0; yb0 < y1; yb0 += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
             const int yy = yb0 + j;
-            if (yy >= y0 + PW_ROWS || yy >= S) break;
-            load_row(win[(j + 3) % 7], yy + 3);
-            float g[PX_T];
-#pragma unroll
-            for (int i = 0; i < PX_T; i++) {
-                g[i] = (x0 + i < S) ? ldf(gb + (1 + (long)yy * S + x0 + i) * D) : 0.f;
-                bacc += g[i];
+            if (yy >= y1) break;
+            if (yy + 1 < y1) {                      // the next row step exists: its newest window row and its gradients
+                load_row(win[(j + 7) & 7], yy + 4);
+                load_g(g[(j + 1) & 1], yy + 1);
             }
+#pragma unroll
+            for (int i = 0; i < PW_X; i++) bacc += g[j & 1][i];
 #pragma unroll
             for (int ky = 0; ky < 7; ky++)
 #pragma unroll
                 for (int kx = 0; kx < 7; kx++) {
                     float a = acc[ky * 7 + kx];
 #pragma unroll
-                    for (int i = 0; i < PX_T; i++) a += g[i] * win[(j + ky + 4) % 7][i + kx];
+                    for (int i = 0; i < PW_X; i++) a += g[j & 1][i] * win[(j + ky) & 7][i + kx];
                     acc[ky * 7 + kx] = a;
                 }
         }
     }
+#if PW_RED
+    __shared__ float red[3][50][64];
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < 49; t++) red[wave - 1][t][lane] = acc[t];
+        red[wave - 1][49][lane] = bacc;
+    }
+    __syncthreads();
+    if (wave == 0 && c < D) {
+#pragma unroll
+        for (int t = 0; t < 49; t++) atomicAdd(dmerged + t * D + c, acc[t] + red[0][t][lane] + red[1][t][lane] + red[2][t][lane]);
+        atomicAdd(dbsum + c, bacc + red[0][49][lane] + red[1][49][lane] + red[2][49][lane]);
+    }
+#else
 #pragma unroll
     for (int t = 0; t < 49; t++) atomicAdd(dmerged + t * D + c, acc[t]);
     atomicAdd(dbsum + c, bacc);
+#endif
 }
 
 extern "C" int mh_ppeg_wgrad(const void* x, const void* dout, float* dmerged, float* dbsum, int B, int S, int D, int dt_x,
                              int dt_o, mh_stream s) {
     if (B == 0) return MH_OK;
-    dim3 grid(mh_cdiv(D, 256), mh_cdiv(S, PW_ROWS) * mh_cdiv(S, PX_T), B);
+#if PW_RED
+    dim3 grid(mh_cdiv(D, 64), mh_cdiv(mh_cdiv(S, PW_ROWS) * mh_cdiv(S, PW_X), 4), B);
+#else
+    dim3 grid(mh_cdiv(D, 256), mh_cdiv(S, PW_ROWS) * mh_cdiv(S, PW_X), B);
+#endif
 #define PW(TX, TO) hipLaunchKernelGGL((ppeg_wgrad_strip_kernel<TX, TO>), grid, dim3(256), 0, (hipStream_t)s, (const TX*)x, (const TO*)dout, dmerged, dbsum, S, D)
     if (dt_x == MH_F32 && dt_o == MH_F32) PW(float, float);
     else if (dt_x == MH_BF16 && dt_o == MH_BF16) PW(bf16_t, bf16_t);

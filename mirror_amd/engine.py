@@ -202,6 +202,14 @@ class TrainEngine:
             self._capturing = None
             Fn.set_grad_sink(None)
             torch.cuda.synchronize()
+        if self.world > 1:
+            # the graphed branch reports its parameters to the buckets at another point of the backward than the eager
+            # one: every rank has to run the same variant or their bucket all-reduces pair up in different orders
+            ok = torch.tensor([1 if self._rna_branch_state == "on" else 0], device=rna.device, dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.pg)
+            if int(ok) == 0 and self._rna_branch_state == "on":
+                m._rna_graph = None
+                self._rna_branch_state = "off"
 
     # ------------------------------------------------------------------ gradient buckets (data parallel)
     def _build_buckets(self, bucket_mb: float) -> None:
