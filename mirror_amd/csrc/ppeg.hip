@@ -187,13 +187,93 @@ __global__ __launch_bounds__(256) void ppeg_strip2_kernel(const float* __restric
     }
 }
 
+// Input-stationary form of the channel-pair kernel: instead of a 7-row input window (140 registers, the newest row loaded
+// and consumed in the same row step) a thread keeps SEVEN partial output rows (56 registers) and two input rows: input row
+// sy adds its seven filter rows into output rows sy - 3 .. sy + 3, output row sy - 3 is then complete and stored, and row
+// sy + 1 was requested a whole row step earlier.  Rows outside the strip are skipped by uniform branches.
+#ifndef P2_FORM
+#define P2_FORM 1     // 1: input-stationary rows (ppeg_rows2_kernel), 0: 7-row input window (ppeg_strip2_kernel)
+#endif
+#ifndef PR_T
+#define PR_T 32       // grid rows per strip of ppeg_rows2_kernel
+#endif
+__global__ __launch_bounds__(256) void ppeg_rows2_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ merged,
+                                                         const float* __restrict__ bsum, int S, int D, int flip) {
+    const int c = 2 * (blockIdx.x * 256 + threadIdx.x);
+    if (c >= D) return;
+    const int tiles_x = (S + P2_T - 1) / P2_T;
+    const int y0 = (blockIdx.y / tiles_x) * PR_T, x0 = (blockIdx.y % tiles_x) * P2_T;
+    const int rows = min(PR_T, S - y0);
+    const long b = blockIdx.z;
+    const long n = 1 + (long)S * S;
+    const float* xb = x + b * n * D + c;
+    float* yb = y + b * n * D + c;
+    if (blockIdx.y == 0) *reinterpret_cast<pp2*>(yb) = *reinterpret_cast<const pp2*>(xb);  // cls token passes through
+    pp2 w[49];
+#pragma unroll
+    for (int t = 0; t < 49; t++) w[t] = *reinterpret_cast<const pp2*>(merged + (flip ? 48 - t : t) * D + c);
+    const pp2 bias = flip ? (pp2){0.f, 0.f} : *reinterpret_cast<const pp2*>(bsum + c);
+    pp2 in[2][P2_T + 6];
+    auto load_row = [&](pp2 (&dst)[P2_T + 6], int sy) {
+        const bool rok = sy >= 0 && sy < S;
+        const float* row = xb + (1 + (long)(rok ? sy : 0) * S) * D;
+#pragma unroll
+        for (int u = 0; u < P2_T + 6; u++) {
+            const int sx = x0 - 3 + u;
+            dst[u] = (rok && sx >= 0 && sx < S) ? *reinterpret_cast<const pp2*>(row + (long)sx * D) : (pp2){0.f, 0.f};
+        }
+    };
+    pp2 acc[7][P2_T];          // output row y0 + o lives in slot o % 7
+#pragma unroll
+    for (int i = 0; i < P2_T; i++) acc[0][i] = bias;
+    const int steps = rows + 6;   // input rows y0 - 3 .. y0 + rows + 2
+    load_row(in[0], y0 - 3);
+    for (int kb = 0; kb < steps; kb += 14) {
+#pragma unroll
+        for (int j = 0; j < 14; j++) {
+            const int k = kb + j;
+            if (k >= steps) break;
+            const int sy = y0 - 3 + k;
+            if (k + 1 < steps) load_row(in[(j + 1) & 1], sy + 1);
+            if (sy >= 0 && sy < S) {      // a row of zero padding adds nothing
+#pragma unroll
+                for (int ky = 0; ky < 7; ky++) {
+                    const int o = k - ky;
+                    if (o >= 0 && o < rows) {
+#pragma unroll
+                        for (int kx = 0; kx < 7; kx++) {
+                            const pp2 wv = w[ky * 7 + kx];
+#pragma unroll
+                            for (int i = 0; i < P2_T; i++)
+                                acc[(j - ky + 14) % 7][i] = __builtin_elementwise_fma(wv, in[j & 1][i + kx], acc[(j - ky + 14) % 7][i]);
+                        }
+                    }
+                }
+            }
+            const int od = k - 6;         // this output row has seen all seven input rows
+            if (od >= 0) {
+#pragma unroll
+                for (int i = 0; i < P2_T; i++)
+                    if (x0 + i < S) *reinterpret_cast<pp2*>(yb + (1 + (long)(y0 + od) * S + x0 + i) * D) = acc[(j + 1) % 7][i];
+            }
+#pragma unroll
+            for (int i = 0; i < P2_T; i++) acc[(j + 1) % 7][i] = bias;      // slot of output row k + 1
+        }
+    }
+}
+
 extern "C" int mh_ppeg_fwd(const void* x, void* y, const float* merged, const float* bsum, int B, int S, int D, int flip,
                            int dt_x, int dt_y, mh_stream s) {
     MH_REQUIRE(S >= 1 && D >= 1, "mh_ppeg_fwd: bad shape S=%d D=%d", S, D);
     if (B == 0) return MH_OK;
     if (dt_x == MH_F32 && dt_y == MH_F32 && D % 2 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)merged | (uintptr_t)bsum) & 7) == 0) {
+#if P2_FORM
+        dim3 g2(mh_cdiv(D / 2, 256), mh_cdiv(S, PR_T) * mh_cdiv(S, P2_T), B);
+        hipLaunchKernelGGL(ppeg_rows2_kernel, g2, dim3(256), 0, (hipStream_t)s, (const float*)x, (float*)y, merged, bsum, S, D, flip);
+#else
         dim3 g2(mh_cdiv(D / 2, 256), mh_cdiv(S, PY_T) * mh_cdiv(S, P2_T), B);
         hipLaunchKernelGGL(ppeg_strip2_kernel, g2, dim3(256), 0, (hipStream_t)s, (const float*)x, (float*)y, merged, bsum, S, D, flip);
+#endif
         MH_LAUNCH_CHECK("mh_ppeg_fwd");
         return MH_OK;
     }
