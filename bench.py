@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """MIRROR pre-training step benchmark on MI355X (BASELINE.json metric: SSL samples/s, slide+RNA pairs).
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL.  Under an external launcher (`python -m torch.distributed.run --nproc-per-node N ...
+bench.py --gpus N`, the reference's scripts/run_train_mirror.sh:62-71) the ranks read RANK / LOCAL_RANK / WORLD_SIZE from
+the environment; without one (`python bench.py --gpus N` on its own) this process starts that launcher itself as a child
+BEFORE it touches the GPU and exits with its code.
 
 A step = prototype renorm -> forward -> MIRRORLoss -> backward (+ RCCL gradient all-reduce) -> Adam -> logit clamp
 on one synthetic batch per GPU (BASELINE config 2: B x [4096 patch tokens x 1024-d] + [B x 2048 genes], D=512,
@@ -43,6 +48,46 @@ def model_flops_fwd(N, F, D, G, L, P=3000, mlp_ratio=4.0, style=(512, 256, 128))
     return 2 * N * F * D + 2 * layer(n) + 166 * nsq * D + 4 * (N + 1) * D * D + layer(nr) + 2 * D * D + rna + sty
 
 
+def csrc_digest() -> str:
+    """sha256 over the kernel sources: the key that ties profiles/pmc_traffic.json to the code it was measured on."""
+    import hashlib
+    d = os.path.join(ROOT, "mirror_amd", "csrc")
+    h = hashlib.sha256()
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".h", ".cpp")):
+            h.update(fn.encode())
+            h.update(open(os.path.join(d, fn), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: run N ranks through torch.distributed.run as a CHILD process (this
+    process has made no GPU call yet and makes none: device_count() does not initialise HIP)."""
+    import socket
+    import subprocess
+    dry = os.environ.get("MIRROR_BENCH_DIST", "") == "gloo:shared"
+    have = torch.cuda.device_count()
+    if have < (1 if dry else n):
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1")).returncode
+
+
+CONFIGS = {
+    # BASELINE.json configs[1] (the metric's config) and configs[0]; "template" = the reference's own operating point,
+    # configs/pretrain/mirror.template.yaml:16-46 (2048 Phikon tokens x 768-d, 10234 genes, D = 768 -> dh = 96, m = 384,
+    # RNA depth 2 / 12 heads / mlp_ratio 2.572): a second bench line, not the headline
+    "c2": dict(N=4096, F=1024, G=2048, D=512, L=6, heads=8, mlp=4.0),
+    "c1": dict(N=256, F=1024, G=512, D=256, L=2, heads=8, mlp=4.0),
+    "template": dict(N=2048, F=768, G=10234, D=768, L=2, heads=12, mlp=2.572),
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -50,12 +95,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (weak scaling)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16_pinv32", "fp32", "fp8"])
-    ap.add_argument("--config", default="c2", choices=["c1", "c2"])
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="rank-local InfoNCE even when N>1 (reference behaviour)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(a.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # MIRROR_BENCH_DIST=gloo:shared runs the N > 1 code path with every rank on GPU 0 over gloo: a dry run of this file's
@@ -83,14 +132,11 @@ def main():
     if lib.mh_device_ok() <= 0:
         raise SystemExit("bench.py needs an MI355X: " + lib.mh_last_error().decode())
 
-    if a.config == "c2":
-        shp = dict(N=4096, F=1024, G=2048, D=512, L=6)
-    else:
-        shp = dict(N=256, F=1024, G=512, D=256, L=2)
+    shp = CONFIGS[a.config]
     torch.manual_seed(42)   # configs/pretrain/mirror.template.yaml:123
     model = M.mirror(wsi_embed_dim=shp["F"], rna_embed_dim=shp["G"], embed_dim=shp["D"], wsi_num_tokens=shp["N"],
-                     rna_encoder_depth=shp["L"], rna_mlp_ratio=4.0, rna_norm_layer="layernorm", rna_act_layer="gelu",
-                     rna_num_heads=8).to(dev).train()
+                     rna_encoder_depth=shp["L"], rna_mlp_ratio=shp["mlp"], rna_norm_layer="layernorm", rna_act_layer="gelu",
+                     rna_num_heads=shp["heads"]).to(dev).train()
     loss_fn = MIRRORLoss(alignment_loss_weight=0.5, wsi_retention_loss_weight=0.15, rna_retention_loss_weight=0.15,
                          style_loss_weight=0.1, cluster_loss_weight=0.1,
                          gather_distributed=(world > 1 and not a.no_gather))
@@ -153,29 +199,34 @@ def main():
     if rank == 0:
         samples = a.batch * world * a.steps
         value = samples / dt
-        fl_fwd = model_flops_fwd(shp["N"], shp["F"], shp["D"], shp["G"], shp["L"])
+        fl_fwd = model_flops_fwd(shp["N"], shp["F"], shp["D"], shp["G"], shp["L"], mlp_ratio=shp["mlp"])
         step_tflops = 3 * fl_fwd * a.batch * world * a.steps / dt / 1e12
         is_f32 = dominant.startswith("gemm_kernel<0")
         peak = PEAK_F32_TFLOPS if is_f32 else PEAK_BF16_TFLOPS
         avg_ms = prof["total_ms"] / max(prof["launches"], 1)
         # HBM-side bytes per launch of the dominant kernel: PMC passes (FETCH_SIZE, WRITE_SIZE in separate runs, gfx950
         # correction applied) summarised by tools/pmc_summary.py into profiles/pmc_traffic.json; null when not collected
-        traffic = None
+        # the file records the digest of the kernel sources it was measured on: an entry from other code is refused (null)
+        traffic, traffic_note = None, "no profiles/pmc_traffic.json entry for this kernel"
         try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as fh:
-                ent = json.load(fh)["kernels"].get(dominant.replace(" ", ""))
-            if ent:
-                traffic = ent["bytes_per_launch"]
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+                pm = json.load(fh)
+            ent = pm["kernels"].get(dominant.replace(" ", ""))
+            if ent and pm.get("csrc_sha256") == csrc_digest() and pm.get("config", "c2") == a.config:
+                traffic, traffic_note = ent["bytes_per_launch"], f"PMC passes on csrc {pm['csrc_sha256']} (tools/collect_profiles.sh)"
+            elif ent:
+                traffic_note = (f"stale: profiles/pmc_traffic.json was measured on csrc {pm.get('csrc_sha256')}, "
+                                f"this run is {csrc_digest()} / config {a.config}")
         except (OSError, ValueError, KeyError):
             pass
         ach = (prof["flops"] / max(prof["launches"], 1)) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         out = {
             "metric": "SSL samples/sec (slide+RNA pairs)", "value": round(value, 3), "unit": "samples/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "n_gpus": world, "world_size_reported": (dist.get_world_size() if world > 1 else 1), "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"bf16": "bf16", "bf16_pinv32": "bf16", "fp32": "f32", "fp8": "fp8-fwd/bf16"}[a.precision], "data": "synthetic",
-            "config": {"workload": f"BASELINE {a.config}: B={a.batch}/GPU x [{shp['N']} patch tokens x {shp['F']}-d] + "
-                                   f"[{shp['G']} genes], D={shp['D']}, RNA depth {shp['L']}, train mode, "
+            "config": {"workload": f"{'reference template' if a.config == 'template' else 'BASELINE ' + a.config}: B={a.batch}/GPU x [{shp['N']} patch tokens x {shp['F']}-d] + "
+                                   f"[{shp['G']} genes], D={shp['D']}, RNA depth {shp['L']} / {shp['heads']} heads, train mode, "
                                    f"{'global' if (world > 1 and not a.no_gather) else 'local'}-batch InfoNCE",
                        "precision_policy": a.precision, "per_gpu_batch": a.batch, "global_batch": a.batch * world,
                        "parallelism": f"dp{world}", "untimed_steps": nwarm,
@@ -185,7 +236,8 @@ def main():
             "model_flops_frac_of_bf16_peak": round(step_tflops / world / PEAK_BF16_TFLOPS, 4),
             "losses": [round(x, 5) for x in loss_vals],
             "roofline": {"bound": "mfma", "kernel": dominant, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(ach / peak, 4), "traffic": traffic, "launches_timed": prof["launches"],
+                         "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_note,
+                         "launches_timed": prof["launches"],
                          "timed_in": ("eager re-run of min(K,5) steps right after the timed region (the timed region "
                                       "replays one HIP graph per step)") if graphed else "the timed region",
                          "avg_launch_ms": round(avg_ms, 5),
@@ -198,8 +250,8 @@ def main():
             from oracle import mirror_oracle as O
             from oracle.cpu_step import time_cpu_steps
             cfg = O.Cfg(wsi_embed_dim=shp["F"], rna_embed_dim=shp["G"], embed_dim=shp["D"], wsi_num_tokens=shp["N"],
-                        rna_encoder_depth=shp["L"], rna_mlp_ratio=4.0, rna_num_heads=8)
-            cb = 2 if a.config == "c2" else 8
+                        rna_encoder_depth=shp["L"], rna_mlp_ratio=shp["mlp"], rna_num_heads=shp["heads"])
+            cb = 8 if a.config == "c1" else 2
             r = time_cpu_steps(cfg, batch=cb, budget_s=25.0)
             out["cpu_baseline"] = {"value": round(r["samples_per_s"], 4), "unit": "samples/s", "cores": r["cores"],
                                    "kind": "port",

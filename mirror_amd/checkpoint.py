@@ -34,7 +34,9 @@ class CheckpointSaver:
         if self.engine is not None:
             state["optimizer"] = self.engine.state_dict()
         if self.args is not None:
-            state["args"] = self.args
+            # timm pickles the argparse.Namespace itself (train_mirror.py:920-930); a plain dict holds the same information and
+            # opens under torch.load's default weights_only=True
+            state["args"] = dict(vars(self.args)) if hasattr(self.args, "__dict__") else self.args
         if metric is not None:
             state["metric"] = metric
         return state
@@ -68,10 +70,22 @@ class CheckpointSaver:
         self.files = self.files[:keep]
 
 
-def resume_checkpoint(model: torch.nn.Module, path: str, engine=None) -> Optional[int]:
+def load_checkpoint_file(path: str, trusted: bool = False):
+    """torch.load for a training checkpoint.  Files written by this package hold tensors and plain containers only; the
+    reference's (timm CheckpointSaver) also pickle `args` as an argparse.Namespace, which torch >= 2.6 refuses under the
+    default weights_only=True — it is allow-listed here.  `trusted=True` is the explicit opt-in to full unpickling
+    (weights_only=False) for files that carry other Python objects: only for files you wrote yourself."""
+    if trusted:
+        return torch.load(path, map_location="cpu", weights_only=False)
+    import argparse
+    with torch.serialization.safe_globals([argparse.Namespace]):
+        return torch.load(path, map_location="cpu", weights_only=True)
+
+
+def resume_checkpoint(model: torch.nn.Module, path: str, engine=None, trusted: bool = False) -> Optional[int]:
     """timm.models.resume_checkpoint as used at train_mirror.py:772-780: weights (+ optimizer state) back in, returns the
     epoch to resume from (saved epoch + 1) or None for a bare state_dict file."""
-    ckpt = torch.load(path, map_location="cpu")
+    ckpt = load_checkpoint_file(path, trusted)
     if isinstance(ckpt, dict) and "state_dict" in ckpt:
         sd = {k[7:] if k.startswith("module.") else k: v for k, v in ckpt["state_dict"].items()}
         model.load_state_dict(sd)

@@ -50,7 +50,12 @@ class TrainEngine:
     def __init__(self, model: torch.nn.Module, loss_fn, *, lr: float = 2e-5, betas=(0.9, 0.999), eps: float = 1e-8,
                  precision: str = "bf16", wsi_mask_ratio: float = 0.75, rna_mask_ratio: float = 0.75,
                  bucket_mb: float = 25.0, process_group=None, graph: Optional[bool] = None,
-                 clip_grad: Optional[float] = None, accum_steps: int = 1):
+                 clip_grad: Optional[float] = None, accum_steps: int = 1, seed: Optional[int] = None,
+                 snapshot_grads: bool = False):
+        """seed: dropout (Philox) seed of this process; rank is added to it, as the reference's
+        `utils.random_seed(args.seed, args.rank)` does (train_mirror.py:682).  Without it, a multi-rank engine folds its rank
+        into whatever seed `Fn.manual_seed` last set, so that ranks never draw identical dropout masks.
+        snapshot_grads: keep a copy of the (reduced) gradient arena of the last update in `self.grad_snap` (tests)."""
         if precision not in POLICIES:
             raise ValueError(f"unknown precision {precision!r}")
         self.model, self.loss_fn = model, loss_fn
@@ -61,6 +66,14 @@ class TrainEngine:
         model.precision = precision
         self.pg = process_group
         self.world = dist.get_world_size(self.pg) if (dist.is_available() and dist.is_initialized()) else 1
+        self.rank = dist.get_rank(self.pg) if self.world > 1 else 0
+        if seed is not None:
+            Fn.manual_seed(int(seed) + self.rank)
+        elif self.world > 1:
+            Fn.manual_seed(Fn._dropout_state["seed"] + self.rank)
+        clip = getattr(loss_fn, "clip_loss", None)
+        if process_group is not None and clip is not None and hasattr(clip, "process_group"):
+            clip.process_group = process_group       # gather size / label offset / reduce-scatter follow the gradient group
         params = [p for p in model.parameters() if p.requires_grad]
         if not params or not params[0].is_cuda:
             raise Fn.K.MirrorHipError("TrainEngine needs the model on an MI355X device (model.to('cuda') first)")
@@ -114,7 +127,10 @@ class TrainEngine:
         self.clip_grad = clip_grad
         self.accum_steps = max(1, int(accum_steps))
         self._micro = 0
+        self._force = False
         self._state_lr = float(lr)
+        self._snapshot_grads = bool(snapshot_grads)
+        self.grad_snap = torch.empty_like(self.grad) if snapshot_grads else None
         # HIP graph of the step (~700 launches: the host needs ~10 ms to enqueue what the GPU runs in ~14 ms).  Single-GPU
         # only by default: with RCCL buckets in flight the eager path stays (MIRROR_GRAPH=1 forces, =0 disables).
         env = os.environ.get("MIRROR_GRAPH")
@@ -123,6 +139,7 @@ class TrainEngine:
             self._use_graph = False      # micro-steps and update steps are different launch sequences
         self._graph = None
         self._graph_warm = 0
+        self._zarena = Fn.ZeroArena()          # per engine; frozen once a captured step holds its address
         # eager launch mode: the launch-bound RNA branch is replayed from two HIP graphs (MIRROR_RNA_GRAPH=0 disables)
         self._rna_branch_state = "pending" if os.environ.get("MIRROR_RNA_GRAPH", "1") not in ("0", "") else "off"
         self._rna_warm = 0
@@ -226,7 +243,7 @@ class TrainEngine:
         if self._capturing is not None:             # autograd-accumulated parameter inside a branch capture
             self._capturing.append(self._index_of[id(p)])
             return
-        if self._micro + 1 < self.accum_steps:      # accumulation micro-step: no reduction yet (DDP no_sync)
+        if self._micro + 1 < self.accum_steps and not self._force:   # accumulation micro-step: no reduction yet (DDP no_sync)
             return
         i = self._index_of[id(p)]
         if self._reported[i]:       # a parameter reports ONCE per step: autograd still runs the AccumulateGrad node (and its
@@ -264,9 +281,13 @@ class TrainEngine:
 
     # ------------------------------------------------------------------ one optimizer step
     def step(self, wsi: torch.Tensor, rna: torch.Tensor, noise: Optional[dict] = None,
-             wsi_key_padding_mask: Optional[torch.Tensor] = None):
+             wsi_key_padding_mask: Optional[torch.Tensor] = None, force_update: bool = False):
         """prototype renorm -> forward -> MIRRORLoss -> backward (+ overlapped all-reduce) -> Adam -> clamp.
-        Returns the 6 loss tensors (device scalars; nothing is synchronised here).  Without injected `noise` the step is
+        force_update: with accum_steps > 1, make this micro-step the last of its window whatever its index (the reference's
+        `need_update = last_batch or (batch_idx + 1) % accum_steps == 0`, train_mirror.py:1128-1131): the gradients summed so
+        far are reduced and applied instead of leaking into the next epoch's first update.
+        Returns the 6 loss tensors (device scalars; nothing is synchronised here; in the eager path they are copies that
+        stay valid across later steps).  Without injected `noise` the step is
         captured into a HIP graph after two eager steps and replayed from then on (the returned tensors are then the
         graph's static outputs: read them before the next step).  A batch tensor that is the same object, with the same
         version counter, as the one passed last time is taken to hold the same data (its copy into the graph's static input
@@ -274,6 +295,7 @@ class TrainEngine:
         if self.lr != self._state_lr:                       # lr schedulers write engine.lr: publish it to the device state
             self._state[3:4].fill_(float(self.lr))
             self._state_lr = float(self.lr)
+        self._force = bool(force_update) and self.accum_steps > 1
         if not self._use_graph or noise is not None or wsi_key_padding_mask is not None:
             return self._step_eager(wsi, rna, noise, wsi_key_padding_mask)       # config-4 batches (padded slides + mask) run eagerly
         if self._graph is not None:
@@ -295,6 +317,7 @@ class TrainEngine:
         self._g_src, self._g_ver = [wsi, rna], [wsi._version, rna._version]
         g = torch.cuda.CUDAGraph()
         count = self.step_count
+        self._zarena.freeze()       # the captured memset and every carved slice hold this buffer's address from here on
         try:
             with torch.cuda.graph(g):
                 self._g_out = self._step_eager(self._g_in[0], self._g_in[1], None)
@@ -313,7 +336,7 @@ class TrainEngine:
                     wsi_key_padding_mask: Optional[torch.Tensor] = None):
         if not torch.cuda.is_current_stream_capturing() and (not self._use_graph or wsi_key_padding_mask is not None):
             self._maybe_graph_rna(rna)       # steps that are not replayed as one graph: N > 1, padded slides + mask
-        Fn.zero_arena_begin(self.device)
+        Fn.zero_arena_begin(self.device, self._zarena)
         try:
             return self._step_body(wsi, rna, noise, wsi_key_padding_mask)
         finally:
@@ -343,11 +366,14 @@ class TrainEngine:
             self._counting = False
         self._seen = [0] * len(self.params)
         self._micro += 1
-        if self._micro < self.accum_steps:          # gradient accumulation: keep summing into the grad arena (the
+        if self._micro < self.accum_steps and not self._force:   # gradient accumulation: keep summing into the grad arena (the
             Fn.dropout_step_end()                    # reference's no_sync micro-steps), no reduction, no update yet
-            return tuple(x.detach() for x in losses)
+            return self._loss_out(losses)
         self._micro = 0
+        self._force = False
         self._finish_reduce()
+        if self._snapshot_grads:
+            self.grad_snap.copy_(self.grad)
         self.step_count += 1
         b1, b2 = self.betas
         gs = 1.0 / (self.world * self.accum_steps)   # buckets are SUM-reduced, micro-batch losses are means
@@ -363,7 +389,13 @@ class TrainEngine:
                 K.cast(self._logit.data.reshape(1), bf16, out=Fn.shadow(self._logit, POLICIES[self.precision]).reshape(1))
         self.grad.zero_()
         Fn.dropout_step_end()
-        return tuple(x.detach() for x in losses)
+        return self._loss_out(losses)
+
+    @staticmethod
+    def _loss_out(losses):
+        """The six scalars as views of ONE freshly allocated tensor: some loss terms are slices of the step's zero arena,
+        which the next step's memset clears — a caller that keeps them (deferred logging) must not read zeros later."""
+        return tuple(torch.stack([x.detach().reshape(()).float() for x in losses]).unbind(0))
 
     # ------------------------------------------------------------------ validation (train_mirror.py:1382-1526)
     LOSS_NAMES = ("loss", "alignment_loss", "wsi_retention_loss", "rna_retention_loss", "style_loss", "cluster_loss")

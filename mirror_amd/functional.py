@@ -123,23 +123,42 @@ def register_shadow(w: torch.Tensor, s: Optional[torch.Tensor]) -> None:
 # ~30 small / medium f32 buffers per step start as zeros (atomic targets, loss accumulators, zero-initialised gradients): inside
 # a TrainEngine step they are carved from ONE buffer that is cleared by a single memset at the start of the step (30 fill
 # launches less; the eager multi-GPU step is host-bound).  Outside a step `zeros` is plain torch.zeros.
-_zero_arena = {"buf": None, "off": 0, "active": False, "demand": 0, "peak": 0}
+# Every engine owns its arena (ZeroArena).  A captured HIP graph bakes the buffer's address into its memset and into every
+# carved slice, so a buffer that a graph has seen is never handed back to the allocator: the arena is FROZEN once its engine
+# captures a step that carves from it (no regrowth — a later step that needs more falls back to torch.zeros for the excess).
+class ZeroArena:
+    __slots__ = ("buf", "off", "demand", "peak", "frozen")
+
+    def __init__(self):
+        self.buf, self.off, self.demand, self.peak, self.frozen = None, 0, 0, 0, False
+
+    def freeze(self) -> None:
+        """Called by the owner right before it captures a graph that carves from this arena."""
+        self.frozen = True
 
 
-def zero_arena_begin(device) -> None:
-    st = _zero_arena
-    want = int(st["peak"] * 1.25) + 4096
-    if st["peak"] > 0 and (st["buf"] is None or st["buf"].numel() < want or st["buf"].device != torch.device(device)):
-        st["buf"] = torch.empty((want,), device=device, dtype=f32)
-    if st["buf"] is not None:
-        st["buf"].zero_()
-    st["off"], st["demand"], st["active"] = 0, 0, True
+_default_arena = ZeroArena()
+_active_arena: Optional[ZeroArena] = None
+
+
+def zero_arena_begin(device, arena: Optional[ZeroArena] = None) -> None:
+    global _active_arena
+    st = arena if arena is not None else _default_arena
+    want = int(st.peak * 1.25) + 4096
+    if not st.frozen and st.peak > 0 and (st.buf is None or st.buf.numel() < want or st.buf.device != torch.device(device)):
+        st.buf = torch.empty((want,), device=device, dtype=f32)
+    if st.buf is not None:
+        st.buf.zero_()
+    st.off, st.demand = 0, 0
+    _active_arena = st
 
 
 def zero_arena_end() -> None:
-    st = _zero_arena
-    st["peak"] = max(st["peak"], st["demand"])
-    st["active"] = False
+    global _active_arena
+    st = _active_arena
+    if st is not None:
+        st.peak = max(st.peak, st.demand)
+    _active_arena = None
 
 
 def zeros(shape, device) -> torch.Tensor:
@@ -148,14 +167,14 @@ def zeros(shape, device) -> torch.Tensor:
     n = 1
     for d in shape:
         n *= int(d)
-    st = _zero_arena
-    if st["active"]:
+    st = _active_arena
+    if st is not None:
         pad = (n + 63) // 64 * 64
-        st["demand"] += pad
-        buf = st["buf"]
-        if buf is not None and st["off"] + pad <= buf.numel() and buf.device == torch.device(device):
-            out = buf[st["off"]:st["off"] + n].view(shape)
-            st["off"] += pad
+        st.demand += pad
+        buf = st.buf
+        if buf is not None and st.off + pad <= buf.numel() and buf.device == torch.device(device):
+            out = buf[st.off:st.off + n].view(shape)
+            st.off += pad
             return out
     return torch.zeros(shape, device=device, dtype=f32)
 
@@ -788,8 +807,8 @@ class NystromCoreFn(Function):
             # is half of the chip, so it runs on a side stream beside the attn3 side on the main stream; they meet
             # again at w2 = pinv @ (a3 v).  Chain-private matrices are column-major (see mirror_hip.h).
             st = K.pinv_absmax(a2)
-            chain_saved = torch.empty((iters, 4, Bn * h, m_l, m_l), device=qkv.device, dtype=bf16)
-            z0, xt = K.pinv_chain_prep(a2, st, chain_saved[0, 0])
+            chain_saved = K.pinv_chain_saved_alloc(iters, Bn * h, m_l, qkv.device)
+            z0, xt = K.pinv_chain_prep(a2, st, K.pinv_chain_z0_slot(chain_saved))
             zfT = torch.empty((Bn, h, m_l, m_l), device=qkv.device, dtype=bf16)
             zf = zfT.transpose(-1, -2)
             side = _side_stream(qkv.device)

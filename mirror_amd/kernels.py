@@ -466,6 +466,17 @@ def pinv_z0_bwd(x, z0, dz0, stats, dx) -> None:
 PINV_CHAIN_M = 256
 
 
+def pinv_chain_saved_alloc(iters: int, BH: int, m: int, device) -> torch.Tensor:
+    """The chain's saved-iterate buffer (what mh_pinv_chain_fwd writes for mh_pinv_chain_bwd): [iters, 4, BH, m, m] bf16,
+    slot k = (z_k, P_k, T2_k, T3_k), panel native."""
+    return torch.empty((iters, 4, BH, m, m), device=device, dtype=torch.bfloat16)
+
+
+def pinv_chain_z0_slot(saved: torch.Tensor) -> torch.Tensor:
+    """Where mh_pinv_chain_prep has to put the panel-native z_0."""
+    return saved[0, 0]
+
+
 def pinv_chain_prep(x: torch.Tensor, stats: torch.Tensor, z0cm_out: torch.Tensor):
     """attn2 (f32 [.., m, m]) -> (z0 f32 = x^T/(c r) row-major, XP = panel-native bf16 x); writes the panel-native z_0 into
     `z0cm_out` (normally saved[0, 0] of the chain).  Panel-native layout: include/mirror_hip.h."""

@@ -21,33 +21,36 @@ class _AllGatherCat(torch.autograd.Function):
     """all_gather along dim 0 with a gradient: backward reduce-scatters (sums) the slices back to their owners."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, group=None):
         x = x.contiguous()
-        world = dist.get_world_size()
+        ctx.group = group
+        world = dist.get_world_size(group)
         out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)
-        dist.all_gather_into_tensor(out, x)
+        dist.all_gather_into_tensor(out, x, group=group)
         return out
 
     @staticmethod
     def backward(ctx, g):
         g = g.contiguous()
-        world = dist.get_world_size()
+        world = dist.get_world_size(ctx.group)
         out = torch.empty((g.shape[0] // world,) + tuple(g.shape[1:]), device=g.device, dtype=g.dtype)
-        dist.reduce_scatter_tensor(out, g, op=dist.ReduceOp.SUM)
-        return out
+        dist.reduce_scatter_tensor(out, g, op=dist.ReduceOp.SUM, group=ctx.group)
+        return out, None
 
 
-def clip_loss_terms(wsi, rna, logit_scale, gather: bool = False):
-    """0.5 * (CE(s W R^T) + CE(s R W^T)) with labels on the (rank-shifted) diagonal; returns a 0-d tensor."""
+def clip_loss_terms(wsi, rna, logit_scale, gather: bool = False, group=None):
+    """0.5 * (CE(s W R^T) + CE(s R W^T)) with labels on the (rank-shifted) diagonal; returns a 0-d tensor.
+    `group`: the process group whose ranks are contrasted (None = the default group); gather size, label offset and the
+    backward reduce-scatter all use it, so it must be the group the gradients are averaged over."""
     w, r = wsi.float(), rna.float()
     B = w.shape[0]
     off = 0
     w_all, r_all = w, r
-    if gather and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        both = _AllGatherCat.apply(torch.cat([w, r], dim=1))          # one message: [P*B, 2D]
+    if gather and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        both = _AllGatherCat.apply(torch.cat([w, r], dim=1), group)   # one message: [P*B, 2D]
         D = w.shape[1]
         w_all, r_all = both[:, :D], both[:, D:]
-        off = dist.get_rank() * B
+        off = dist.get_rank(group) * B
     g_img = Fn.MatmulNTFn.apply(w, r_all)                            # [B, P*B]
     # rank-local loss: R W^T is the transpose of W R^T — one product (and one pair of gradient products) instead of two
     g_txt = g_img.t().contiguous() if w_all is w else Fn.MatmulNTFn.apply(r, w_all)
@@ -59,22 +62,24 @@ def clip_loss_terms(wsi, rna, logit_scale, gather: bool = False):
 class ClipLoss(nn.Module):
     """losses/mirror_loss.py:16-52 (labels are implicit: the kernel indexes the diagonal, nothing to cache)."""
 
-    def __init__(self, cache_labels: bool = False, gather_distributed: bool = False):
+    def __init__(self, cache_labels: bool = False, gather_distributed: bool = False, process_group=None):
         super().__init__()
         self.cache_labels = cache_labels
         self.gather_distributed = gather_distributed
+        self.process_group = process_group        # TrainEngine(process_group=...) sets it to its own group
 
     def forward(self, wsi_features, rna_features, logit_scale, output_dict: bool = False):
-        total = clip_loss_terms(wsi_features, rna_features, logit_scale, self.gather_distributed)
+        total = clip_loss_terms(wsi_features, rna_features, logit_scale, self.gather_distributed, self.process_group)
         return {"contrastive_loss": total} if output_dict else total
 
 
 class MIRRORLoss(nn.Module):
     def __init__(self, clip_loss_cache_labels=True, alignment_loss_weight=0.5, wsi_retention_loss_weight=0.1,
                  rna_retention_loss_weight=0.1, style_loss_weight=0.1, cluster_loss_weight=0.2,
-                 gather_distributed: bool = False):
+                 gather_distributed: bool = False, process_group=None):
         super().__init__()
-        self.clip_loss = ClipLoss(cache_labels=clip_loss_cache_labels, gather_distributed=gather_distributed)
+        self.clip_loss = ClipLoss(cache_labels=clip_loss_cache_labels, gather_distributed=gather_distributed,
+                                  process_group=process_group)
         self.alignment_loss_weight = alignment_loss_weight
         self.wsi_retention_loss_weight = wsi_retention_loss_weight
         self.rna_retention_loss_weight = rna_retention_loss_weight

@@ -8,10 +8,10 @@ _REGISTRY = {"mirror": mirror, "mirror_classifier": mirror_classifier}
 
 def create_model(model_name: str, pretrained: bool = False, checkpoint_path: str = "", scriptable=None, **kwargs):
     """Minimal stand-in for timm.models.create_model as called at train_mirror.py:689-694 (timm is optional)."""
-    import torch
     model = _REGISTRY[model_name](**kwargs)
     if checkpoint_path:
-        state = torch.load(checkpoint_path, map_location="cpu")
+        from ..checkpoint import load_checkpoint_file
+        state = load_checkpoint_file(checkpoint_path)
         model.load_state_dict(state.get("state_dict", state))
     return model
 

@@ -290,18 +290,24 @@ class TransFormerHybrid(TransFormer):
         y = Fn.L2NormRowFn.apply(x, 1e-12, f32)
         return Fn.linear(y, self.alignment_head.weight, self.alignment_head.bias, prec=prec, out_dtype=f32)
 
-    def random_masking(self, x, mask_ratio: float, noise: Optional[torch.Tensor] = None):
+    def _draw_mask(self, x, mask_ratio: float, noise: Optional[torch.Tensor] = None):
         B, N = x.shape  # noqa: N806
         len_keep = int(N * (1 - mask_ratio))
         if noise is None:
             noise = torch.rand(B, N, device=x.device)
-        mask = Fn.rank_mask(noise, len_keep)
-        return mask
+        return Fn.rank_mask(noise, len_keep)
+
+    def random_masking(self, x, mask_ratio: float, noise: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """models/mirror.py:510-533: (x with the masked CHANNELS replaced by the scalar mask token, mask [B, D]).  The
+        retention head below fuses the same select with the `+ retention_gene_embed` that follows it."""
+        mask = self._draw_mask(x, mask_ratio, noise)
+        zero_pos = torch.zeros(x.shape[1], device=x.device, dtype=f32)
+        return Fn.MaskApplyFn.apply(x, mask, self.mask_token, zero_pos, 0, True), mask
 
     def forward_retention_head(self, x, mask_ratio: float, noise: Optional[torch.Tensor] = None):
         prec = resolve_precision(self.precision)
         r = Fn.linear(x, self.retention_embed.weight, self.retention_embed.bias, prec=prec, out_dtype=f32)
-        mask = self.random_masking(r, mask_ratio, noise)
+        mask = self._draw_mask(r, mask_ratio, noise)
         r = Fn.MaskApplyFn.apply(r, mask, self.mask_token, self.retention_gene_embed, 0, True)
         for blk in self.retention_blocks:
             r = blk(r, prec)
@@ -358,12 +364,19 @@ class FeatureTransMILHybrid(FeatureTransMIL):
         y = Fn.L2NormRowFn.apply(h, 1e-12, f32)         # only the cls row is consumed (models/mirror.py:684)
         return Fn.linear(y, self.alignment_head.weight, self.alignment_head.bias, prec=prec, out_dtype=f32)
 
-    def random_masking(self, h, mask_ratio: float, noise: Optional[torch.Tensor] = None):
+    def _draw_mask(self, h, mask_ratio: float, noise: Optional[torch.Tensor] = None):
         B, N = h.shape[0], h.shape[1]  # noqa: N806
         len_keep = int(N * (1 - mask_ratio))
         if noise is None:
             noise = torch.rand(B, N, device=h.device)
         return Fn.rank_mask(noise, len_keep)
+
+    def random_masking(self, h, mask_ratio: float, noise: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """models/mirror.py:624-649: (h [B, N, C] with the masked TOKENS replaced by mask_token, mask [B, N]).  The
+        retention head below fuses the same select with the cls concat and the `+ retention_gene_embed` that follow it."""
+        mask = self._draw_mask(h, mask_ratio, noise)
+        zero_pos = torch.zeros(h.shape[1] * h.shape[2], device=h.device, dtype=f32)
+        return Fn.MaskApplyFn.apply(h, mask, self.mask_token, zero_pos, 0, False), mask
 
     def forward_retention_head(self, h, mask_ratio: float, noise: Optional[torch.Tensor] = None,
                                mask: Optional[torch.Tensor] = None, key_padding_mask: Optional[torch.Tensor] = None):
@@ -375,7 +388,7 @@ class FeatureTransMILHybrid(FeatureTransMIL):
         # activation dtype out (what autocast gives the reference); MaskApplyFn restarts the f32 residual stream
         r = Fn.linear(h, self.retention_embed.weight, self.retention_embed.bias, prec=prec)
         if mask is None:
-            mask = self.random_masking(r[:, 1:], mask_ratio, noise)
+            mask = self._draw_mask(r[:, 1:], mask_ratio, noise)
         r = Fn.MaskApplyFn.apply(r, mask, self.mask_token, self.retention_gene_embed, 1, False)
         kp = None
         if key_padding_mask is not None:

@@ -1,0 +1,386 @@
+"""GPU: the path `bench.py` times — bf16 policy at D = 512 (fused Nystrom kernels, one-launch pinv chain, 256-tile GEMMs,
+gradient sink, whole-step HIP graph) — under the oracle, plus oracle-free properties of the HIP Nystrom path itself
+(VERDICT r1 items 1, 6, 10).
+
+  * parameter gradients of the bf16 policy at configs[1]'s shapes against torch-CPU autograd through the oracle;
+  * a HIP-graph REPLAY of training step k equals the eagerly launched step k (same device RNG state), losses and the
+    gradient arena, at B = 16;
+  * the whole-model configs[3] step (8192 x 768-d, key-padding mask) against a live oracle run;
+  * the reference's step sequence (train_mirror.py:1133-1136, :1162-1191, :1254-1255) under torch.autocast(bfloat16);
+  * properties that need no oracle: Nystrom -> exact softmax attention when every token is a landmark, a2 . pinv(a2) -> I on
+    the one-launch chain, and the kernel-side front padding equals an explicitly zero-padded sequence.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+import mirror_amd.models as M  # noqa: E402
+from mirror_amd import functional as Fn, kernels as K  # noqa: E402
+from mirror_amd.losses import MIRRORLoss  # noqa: E402
+from oracle import mirror_oracle as O, synth  # noqa: E402
+from tests.golden_util import DEFAULT_W  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+C2 = O.Cfg(wsi_embed_dim=1024, rna_embed_dim=2048, embed_dim=512, wsi_num_tokens=4096, rna_encoder_depth=6,
+           rna_mlp_ratio=4.0, rna_num_heads=8)
+C4 = O.Cfg(wsi_embed_dim=768, rna_embed_dim=2048, embed_dim=512, wsi_num_tokens=8192, rna_encoder_depth=6,
+           rna_mlp_ratio=4.0, rna_num_heads=8)
+f32, bf16 = torch.float32, torch.bfloat16
+
+
+def _model(cfg, sd, precision, train=False):
+    m = M.mirror(wsi_embed_dim=cfg.wsi_embed_dim, rna_embed_dim=cfg.rna_embed_dim, embed_dim=cfg.embed_dim,
+                 wsi_num_tokens=cfg.wsi_num_tokens, rna_encoder_depth=cfg.rna_encoder_depth, rna_mlp_ratio=cfg.rna_mlp_ratio,
+                 rna_norm_layer="layernorm", rna_act_layer="gelu", rna_num_heads=cfg.rna_num_heads)
+    m.load_state_dict(sd, strict=True)
+    m.precision = precision
+    return m.to(DEV).train(train)
+
+
+def _report(name, payload):
+    """Measured bands go to gpurun_out/ (scratch, merged back by gpurun) so that DESIGN.md can quote them."""
+    d = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, name), "w") as fh:
+            json.dump(payload, fh, indent=1)
+    except OSError:
+        pass
+
+
+# ------------------------------------------------------------------------------------------------ (a) bf16 gradients
+# Bands of the bf16 policy against the f32 oracle (per parameter, gradient of the TOTAL loss): stated here, measured values
+# are written to gpurun_out/r02_bf16_grad_band.json and quoted in DESIGN.md §2.
+BF16_COS_MIN = 0.99
+BF16_RATIO = (0.95, 1.05)
+BF16_TINY = 1e-4          # parameters whose oracle gradient norm is below this fraction of the largest one: bounded, not banded
+
+
+def test_c2_bf16_policy_parameter_gradients_match_oracle():
+    """configs[1] shapes, B = 2, eval mode, injected noise, the policy the bench runs (bf16 MFMA, fused attention kernels,
+    one-launch pinv chain, bf16 activations between GEMMs): d total_loss / d parameter for EVERY parameter against
+    torch-CPU autograd through the f32 oracle — cosine >= 0.99 and norm ratio within [0.95, 1.05]."""
+    sd = synth.synth_state_dict(synth.param_shapes(C2), 99)
+    wsi, rna, noise = synth.synth_batch(C2, 2, 100)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    with O.exact_cpu_convs():
+        ref = O.mirror_forward(leaf, C2, wsi, rna, noise, 0.75, 0.75)
+        ref_loss = O.mirror_loss(ref, DEFAULT_W)
+        ref_loss[0].backward()
+    m = _model(C2, sd, "bf16")
+    outs = m(wsi.to(DEV).to(bf16), rna.to(DEV), wsi_mask_ratio=0.75, rna_mask_ratio=0.75,
+             noise={k: v.to(DEV) for k, v in noise.items()})
+    loss = MIRRORLoss()(*outs)
+    loss[0].backward()
+    gmax = max(float(v.grad.norm()) for v in leaf.values() if v.grad is not None)
+    rows, bad = [], []
+    for k, p in m.named_parameters():
+        r = leaf[k].grad
+        assert r is not None and p.grad is not None, k
+        r64, g64 = r.double().reshape(-1), p.grad.detach().cpu().double().reshape(-1)
+        rn, gn = float(r64.norm()), float(g64.norm())
+        if rn < BF16_TINY * gmax:
+            ok = gn <= 3.0 * rn + BF16_TINY * 1e-2 * gmax
+            rows.append((k, rn, gn, None, None))
+        else:
+            cos = float(torch.dot(r64, g64) / (rn * gn + 1e-300))
+            ratio = gn / rn
+            ok = cos >= BF16_COS_MIN and BF16_RATIO[0] <= ratio <= BF16_RATIO[1]
+            rows.append((k, rn, gn, cos, ratio))
+        if not ok:
+            bad.append(rows[-1])
+    banded = [r for r in rows if r[3] is not None]
+    lrel = [abs(float(a.detach()) - float(b)) / abs(float(b)) for a, b in zip(loss, ref_loss)]
+    _report("r02_bf16_grad_band.json", {
+        "config": "c2 shapes, B=2, eval, bf16 policy vs f32 oracle", "n_params": len(rows), "n_banded": len(banded),
+        "cos_min": min(r[3] for r in banded), "cos_median": float(np.median([r[3] for r in banded])),
+        "ratio_min": min(r[4] for r in banded), "ratio_max": max(r[4] for r in banded),
+        "worst_cos": sorted(((r[3], r[0]) for r in banded))[:8],
+        "worst_ratio": sorted(((abs(r[4] - 1), r[0], r[4]) for r in banded), reverse=True)[:8],
+        "loss_rel_err": lrel})
+    assert len(banded) > 100
+    assert not bad, "; ".join(f"{k}: |ref| {rn:.3g} |got| {gn:.3g} cos {c} ratio {q}" for k, rn, gn, c, q in bad[:10])
+
+
+# ------------------------------------------------------------------------------------------------ (b) replay == eager
+def _c2_engine(graph: bool, steps: int, snap_at):
+    from mirror_amd.engine import TrainEngine
+    torch.manual_seed(42)
+    m = M.mirror(wsi_embed_dim=1024, rna_embed_dim=2048, embed_dim=512, wsi_num_tokens=4096, rna_encoder_depth=6,
+                 rna_mlp_ratio=4.0, rna_norm_layer="layernorm", rna_act_layer="gelu", rna_num_heads=8).to(DEV).train()
+    eng = TrainEngine(m, MIRRORLoss(), lr=2e-5, precision="bf16", graph=graph, seed=1234, snapshot_grads=True)
+    if not graph:
+        eng._rna_branch_state = "off"            # all-eager: every launch issued from Python
+    g = torch.Generator(device=DEV).manual_seed(1)
+    wsi = torch.randn(16, 4096, 1024, device=DEV, generator=g).to(bf16)
+    rna = torch.randn(16, 2048, device=DEV, generator=g)
+    torch.manual_seed(99)                        # the four noise draws of every step come from the default CUDA generator
+    losses, snaps = [], {}
+    for s in range(steps):
+        losses.append([float(x) for x in eng.step(wsi, rna)])
+        if s in snap_at:
+            snaps[s] = eng.grad_snap.cpu()
+    layout = [(n, o, p.numel()) for (n, p), o in zip(
+        [(name_of(m, p), p) for p in eng.params], eng.offsets)]
+    replayed = eng._graph is not None
+    del eng, m
+    torch.cuda.empty_cache()
+    return np.array(losses), snaps, layout, replayed
+
+
+def name_of(model, p):
+    for n, q in model.named_parameters():
+        if q is p:
+            return n
+    return "?"
+
+
+def test_c2_graph_replay_equals_eager_step():
+    """The bench configuration (c2, B = 16, bf16 policy, train mode with dropout): engine A replays the whole step as ONE HIP
+    graph from its third step on, engine B launches every step eagerly.  Same seeds -> the torch generator (noise draws),
+    the Philox dropout base and Adam's device state advance identically, so step k of A must equal step k of B up to the
+    order of f32 atomics: the six losses of every step, and the gradient arena of the first two replayed steps."""
+    la, sa, layout, replayed = _c2_engine(True, 6, (2, 3))
+    lb, sb, _, _ = _c2_engine(False, 6, (2, 3))
+    assert replayed
+    assert np.isfinite(la).all() and np.isfinite(lb).all()
+    rel = np.abs(la - lb) / np.maximum(np.abs(lb), 1e-3)
+    worst = []
+    for s in (2, 3):
+        ga, gb = sa[s].double(), sb[s].double()
+        for n, o, cnt in layout:
+            a, b = ga[o:o + cnt], gb[o:o + cnt]
+            d = float((a - b).norm()) / max(float(b.norm()), 1e-30)
+            worst.append((d, s, n))
+    worst.sort(reverse=True)
+    _report("r02_replay_vs_eager.json", {"loss_rel_diff_per_step": rel.tolist(), "worst_param_grad_rel_diff": worst[:10]})
+    assert rel.max() < 2e-3, rel                                   # measured ~1e-5 (gpurun_out/r02_replay_vs_eager.json)
+    assert worst[0][0] < 2e-2, worst[:5]
+    total = sum(float((sa[2][o:o + c].double() - sb[2][o:o + c].double()).pow(2).sum()) for _, o, c in layout) ** 0.5
+    assert total < 2e-3 * float(sb[2].double().norm())
+
+
+# ------------------------------------------------------------------------------------------------ (c) whole-model c4
+def test_c4_whole_model_with_key_padding_mask_matches_live_oracle():
+    """configs[3]: 8192 patch tokens x 768-d per slide, valid lengths 5000 and 2048 + 77, padded + bool key-padding mask
+    through all three Nystrom layers, B = 2.  fp32 policy: the 15 outputs, six losses and every parameter gradient norm
+    against a live oracle run with the same mask; bf16 policy (mask-aware fused kernels): loss band."""
+    sd = synth.synth_state_dict(synth.param_shapes(C4), 31)
+    wsi, rna, noise = synth.synth_batch(C4, 2, 32)
+    lens = torch.tensor([5000, 2048 + 77])
+    mask = torch.arange(8192)[None, :] < lens[:, None]
+    wsi = wsi * mask[..., None]
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    with O.exact_cpu_convs():
+        ref = O.mirror_forward(leaf, C4, wsi, rna, noise, 0.75, 0.75, wsi_key_padding_mask=mask)
+        ref_loss = O.mirror_loss(ref, DEFAULT_W)
+        ref_loss[0].backward()
+    nz = {k: v.to(DEV) for k, v in noise.items()}
+    m = _model(C4, sd, "fp32")
+    outs = m(wsi.to(DEV), rna.to(DEV), wsi_mask_ratio=0.75, rna_mask_ratio=0.75, noise=nz, wsi_key_padding_mask=mask.to(DEV))
+    for nm, a, b in zip(O.OUTPUT_NAMES, outs, ref):
+        scale = max(float(b.abs().max()), 1e-6)
+        err = float((a.detach().float().cpu() - b.detach().float()).abs().max()) / scale
+        assert err <= 2e-4, f"{nm}: {err:.3e}"
+    loss = MIRRORLoss()(*outs)
+    np.testing.assert_allclose([float(x.detach()) for x in loss], [float(x) for x in ref_loss], rtol=1e-4)
+    loss[0].backward()
+    gmax = max(float(v.grad.norm()) for v in leaf.values() if v.grad is not None)
+    bad = []
+    for k, p in m.named_parameters():
+        rn, gn = float(leaf[k].grad.double().norm()), float(p.grad.double().norm())
+        if abs(gn - rn) > 2e-3 * rn + 1e-6 * gmax:
+            bad.append(f"{k}: {gn:.6g} vs {rn:.6g}")
+    assert not bad, "; ".join(bad[:10])
+    del m, outs, loss
+    mb = _model(C4, sd, "bf16")
+    ob = mb(wsi.to(DEV).to(bf16), rna.to(DEV), wsi_mask_ratio=0.75, rna_mask_ratio=0.75, noise=nz,
+            wsi_key_padding_mask=mask.to(DEV))
+    got = np.array([float(x.detach()) for x in MIRRORLoss()(*ob)])
+    want = np.array([float(x) for x in ref_loss])
+    rel = np.abs(got - want) / np.abs(want)
+    _report("r02_c4_bf16_loss_band.json", {"loss_rel_err": rel.tolist()})
+    assert (rel < 3e-2).all(), rel
+
+
+# ------------------------------------------------------------------------------------------------ reference step order
+def test_reference_step_sequence_under_autocast_selects_bf16_policy(monkeypatch):
+    """What train_mirror.py does with `--amp --amp-dtype bfloat16` and this build behind `models` / `losses`
+    (INTEGRATION.md §1): prototype renorm (:1133-1136), forward + loss under torch.autocast (:1144-1191), backward +
+    optimizer step (:1206-1230), logit_scale clamp (:1254-1255).  No `.precision` is set anywhere: the modules must pick
+    the bf16 MFMA policy from the autocast state, and the f32 policy outside of it."""
+    import mirror_amd
+    import sys
+    saved = {k: sys.modules.get(k) for k in ("models", "models.mirror", "losses", "losses.mirror_loss", "losses.info_nce")}
+    mirror_amd.install_aliases()
+    try:
+        import models
+        from losses import MIRRORLoss as RefNameLoss
+        from mirror_amd.models import mirror as mm
+        picked = []
+        real = mm.resolve_precision
+
+        def spy(pref):
+            p = real(pref)
+            picked.append(p.name)
+            return p
+        monkeypatch.setattr(mm, "resolve_precision", spy)
+        torch.manual_seed(0)
+        model = models.create_model("mirror", wsi_embed_dim=256, rna_embed_dim=128, embed_dim=512, wsi_num_tokens=700,
+                                    rna_encoder_depth=2, rna_num_heads=8, num_prototypes=200, pretrained_cfg=None).to(DEV).train()
+        loss_fn = RefNameLoss(alignment_loss_weight=0.5, wsi_retention_loss_weight=0.15, rna_retention_loss_weight=0.15,
+                              style_loss_weight=0.1, cluster_loss_weight=0.1).to(DEV)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        g = torch.Generator(device=DEV).manual_seed(3)
+        wsi = torch.randn(4, 700, 256, device=DEV, generator=g)
+        rna = torch.randn(4, 128, device=DEV, generator=g)
+        before = {k: v.detach().clone() for k, v in model.named_parameters()}
+        hist = []
+        for _ in range(4):
+            with torch.no_grad():
+                w = model.prototypes.weight.data.clone()
+                w = torch.nn.functional.normalize(w, dim=1, p=2)
+                model.prototypes.weight.copy_(w)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = model(wsi, rna, wsi_mask_ratio=0.75, rna_mask_ratio=0.75)
+                losses = loss_fn(*out)
+            opt.zero_grad()
+            losses[0].backward()
+            opt.step()
+            with torch.no_grad():
+                model.logit_scale.clamp_(0, math.log(100))
+            hist.append(float(losses[0]))
+        assert picked and set(picked) == {"bf16"}, set(picked)
+        assert all(math.isfinite(x) for x in hist) and hist[-1] < hist[0], hist
+        moved = [k for k, v in model.named_parameters() if not torch.equal(v.detach(), before[k])]
+        assert len(moved) == len(before), sorted(set(before) - set(moved))
+        picked.clear()
+        model.eval()
+        with torch.no_grad():
+            model(wsi, rna)
+        assert set(picked) == {"fp32"}
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+def test_random_masking_returns_the_reference_pair():
+    """models/mirror.py:624-649 / :510-533: random_masking returns (masked tensor, mask) — tokens for the WSI encoder,
+    channels for the RNA encoder — with the double-argsort ranking of the reference."""
+    torch.manual_seed(1)
+    m = M.mirror(wsi_embed_dim=32, rna_embed_dim=24, embed_dim=64, wsi_num_tokens=50, rna_num_heads=8, num_prototypes=10).to(DEV)
+    g = torch.Generator().manual_seed(2)
+    h = torch.randn(3, 50, 64, generator=g)
+    noise = torch.rand(3, 50, generator=g)
+    keep = int(50 * (1 - 0.75))
+    rank = torch.argsort(torch.argsort(noise, dim=1), dim=1)
+    want_mask = (rank >= keep).float()
+    tok = m.wsi_encoder.mask_token.detach().cpu().reshape(1, 1, 64)
+    want = torch.where(want_mask[..., None] > 0, tok.expand(3, 50, 64), h)
+    got, mask = m.wsi_encoder.random_masking(h.to(DEV), 0.75, noise=noise.to(DEV))
+    assert torch.equal(mask.cpu(), want_mask) and torch.allclose(got.cpu(), want, atol=0, rtol=0)
+    x = torch.randn(3, 64, generator=g)
+    nz = torch.rand(3, 64, generator=g)
+    keep = int(64 * (1 - 0.6))
+    want_mask = (torch.argsort(torch.argsort(nz, dim=1), dim=1) >= keep).float()
+    want = torch.where(want_mask > 0, m.rna_encoder.mask_token.detach().cpu().reshape(1, 1).expand(3, 64), x)
+    got, mask = m.rna_encoder.random_masking(x.to(DEV), 0.6, noise=nz.to(DEV))
+    assert torch.equal(mask.cpu(), want_mask) and torch.equal(got.cpu(), want)
+    got2, mask2 = m.wsi_encoder.random_masking(h.to(DEV), 0.75)          # own noise draw: exactly N - len_keep masked
+    assert got2.shape == h.shape and float(mask2.sum()) == 3 * (50 - int(50 * 0.25))
+
+
+# ------------------------------------------------------------------------------------------------ oracle-free properties
+def _qkv_for(B, n, D, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(B, n, 3 * D, generator=g) * scale).to(DEV)
+
+
+@pytest.mark.parametrize("policy,floor", [("fp32", 2e-4), ("bf16", 4e-2)])
+def test_nystrom_with_every_token_a_landmark_converges_to_softmax_attention(policy, floor):
+    """[3P] NystromAttention with m = n landmarks (l = 1): landmarks are the tokens themselves, so a1 = a2 = a3 =
+    A = softmax(q k^T / sqrt(dh)) and out = A . pinv(A) . A v + res_conv(v) -> A v + res_conv(v), exact softmax attention,
+    as the Moore-Penrose iteration converges (A Z A -> A for every A, singular or not).  D = 512, n = m = 256, dh = 64: the
+    geometry of the fused kernels and the one-launch chain in the bf16 policy; the composed path in fp32.  No oracle: the
+    target is formed from the same q, k, v by plain softmax attention in f64."""
+    B, n, D, h = 2, 256, 512, 8
+    dh = D // h
+    prec = Fn.POLICIES[policy]
+    qkv = _qkv_for(B, n, D, 5, scale=1.5).to(prec.act)
+    res_w = (torch.randn(h, 1, 33, 1, generator=torch.Generator().manual_seed(6)) * 0.1).to(DEV)
+    x64 = qkv.double().view(B, n, 3, h, dh).permute(2, 0, 3, 1, 4)                  # [3, B, h, n, dh]
+    q, k, v = x64[0] * dh ** -0.5, x64[1], x64[2]
+    A = torch.softmax(q @ k.transpose(-1, -2), dim=-1)
+    conv = torch.nn.functional.conv2d(v, res_w.double(), padding=(16, 0), groups=h)
+    want = (A @ v + conv).permute(0, 2, 1, 3).reshape(B, n, D)
+    errs = []
+    for iters in (2, 6, 12, 24):
+        out = Fn.NystromCoreFn.apply(qkv, res_w, h, 1, iters, prec, None)
+        errs.append(float((out.double() - want).norm() / want.norm()))
+    _report(f"r02_nystrom_m_eq_n_{policy}.json", {"iters": [2, 6, 12, 24], "rel_err": errs})
+    assert errs[1] < errs[0] and errs[2] < max(errs[1], floor) and errs[3] <= max(errs[2], floor), errs
+    assert errs[3] < floor, errs
+
+
+def test_pinv_chain_times_a2_converges_to_identity():
+    """The one-launch Newton-Schulz chain of the bf16 policy (pinv_panel.hip) on a well-conditioned row-stochastic matrix
+    (softmax of a diagonally dominant logit matrix): || a2 . Z_k - I || falls with the iteration count and reaches the
+    bf16 floor — the property tests/test_oracle.py checks on the CPU restatement, here on the HIP kernel itself."""
+    BH, m = 16, 256
+    g = torch.Generator().manual_seed(9)
+    logits = torch.randn(2, 8, m, m, generator=g) + 6.0 * torch.eye(m)
+    a2 = torch.softmax(logits, dim=-1).to(DEV)
+    eye = torch.eye(m, device=DEV, dtype=torch.float64)
+    errs = []
+    for iters in (1, 3, 6, 9):
+        st = K.pinv_absmax(a2)
+        saved = K.pinv_chain_saved_alloc(iters, BH, m, DEV)
+        z0, xt = K.pinv_chain_prep(a2, st, K.pinv_chain_z0_slot(saved))
+        zfT = torch.empty((2, 8, m, m), device=DEV, dtype=bf16)
+        K.pinv_chain_fwd(xt, saved, zfT, iters)
+        Z = zfT.transpose(-1, -2).double()
+        errs.append(float((a2.double() @ Z - eye).norm(dim=(-1, -2)).max()) / m ** 0.5)
+    _report("r02_pinv_chain_identity.json", {"iters": [1, 3, 6, 9], "rms_residual": errs})
+    assert errs[0] > errs[1] > errs[2], errs
+    assert errs[2] < 2e-2 and errs[3] < 2e-2, errs
+
+
+@pytest.mark.parametrize("policy,tol", [("fp32", 1e-5), ("bf16", 2.0 ** -7)])
+def test_kernel_side_front_padding_equals_explicit_zero_rows(policy, tol):
+    """[3P] NystromAttention zero-pads the sequence at the FRONT to a multiple of the landmark count.  The HIP path never
+    builds that tensor: LayerNorm writes behind `pad` zero rows, to_out computes only the rows that survive `[:, -n:]`.
+    Same layer, same input, but with the padded sequence built explicitly (torch.cat of zero rows, every row of to_out
+    computed, then sliced): the surviving rows must agree — to f32 rounding in the fp32 policy, to one bf16 rounding of the
+    attention branch in the bf16 policy (the two forms tile the same products differently).  Two lengths: pad = 255 rows
+    (n = 1025) and pad = 0 (n = 1024)."""
+    torch.manual_seed(4)
+    prec = Fn.POLICIES[policy]
+    layer = M.mirror(wsi_embed_dim=32, rna_embed_dim=24, embed_dim=512, wsi_num_tokens=16, rna_num_heads=8,
+                     num_prototypes=10).wsi_encoder.layer1.to(DEV).eval()
+    a = layer.attn
+    for n in (1025, 1024):
+        x = torch.randn(2, n, 512, device=DEV, generator=torch.Generator(device=DEV).manual_seed(n))
+        with torch.no_grad():
+            got = layer(x, prec)
+            m_l = a.num_landmarks
+            pad = (m_l - n % m_l) % m_l
+            l = math.ceil(n / m_l)  # noqa: E741
+            xn = Fn.layer_norm(x, layer.norm.weight, layer.norm.bias, layer.norm.eps, out_dtype=prec.act)
+            xp = torch.cat([torch.zeros(2, pad, 512, device=DEV, dtype=prec.act), xn], dim=1).contiguous()
+            qkv = Fn.linear(xp, a.to_qkv.weight, None, prec=prec)
+            core = Fn.NystromCoreFn.apply(qkv, a.res_conv.weight, a.heads, l, a.pinv_iterations, prec, None)
+            y = Fn.linear(core, a.to_out[0].weight, a.to_out[0].bias, prec=prec)
+            want = x + y[:, -n:].float()
+        assert got.shape == want.shape == (2, n, 512)
+        branch = float(y[:, -n:].float().abs().max())
+        assert float((got - want).abs().max()) <= tol * branch, (float((got - want).abs().max()), branch)

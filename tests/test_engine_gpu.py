@@ -15,17 +15,24 @@ CFG = dict(wsi_embed_dim=64, rna_embed_dim=48, embed_dim=64, wsi_num_tokens=60, 
            style_mlp_hidden_dim=64, style_mlp_out_dim=32, style_latent_dim=16, num_prototypes=50)
 
 
-def _make(seed=0):
+# D = 512: dh = 64, m = 256 landmarks -> the geometry of the fused Nystrom kernels and the one-launch pinv chain of the bf16
+# policy (what bench.py times); 1000 tokens -> n = 1025 (cls + 1000 + 24 wrap-around), n_p = 1280, l = 5
+CFG512 = dict(wsi_embed_dim=128, rna_embed_dim=96, embed_dim=512, wsi_num_tokens=1000, rna_encoder_depth=2, rna_num_heads=8,
+              rna_mlp_ratio=4.0, style_mlp_hidden_dim=128, style_mlp_out_dim=64, style_latent_dim=32, num_prototypes=300)
+
+
+def _make(seed=0, cfg=CFG):
     import mirror_amd.models as M
     torch.manual_seed(seed)
-    return M.mirror(**CFG).cuda().eval()       # eval: dropout off so runs are comparable
+    return M.mirror(**cfg).cuda().eval()       # eval: dropout off so runs are comparable
 
 
-def _batch(b, seed):
+def _batch(b, seed, cfg=CFG):
     g = torch.Generator().manual_seed(seed)
-    wsi, rna = torch.randn(b, 60, 64, generator=g), torch.randn(b, 48, generator=g)
-    noise = {"wsi_mask": torch.rand(b, 60, generator=g), "rna_mask": torch.rand(b, 64, generator=g),
-             "wsi_eps": torch.randn(b, 16, generator=g), "rna_eps": torch.randn(b, 16, generator=g)}
+    n, f, gd, d, lat = cfg["wsi_num_tokens"], cfg["wsi_embed_dim"], cfg["rna_embed_dim"], cfg["embed_dim"], cfg["style_latent_dim"]
+    wsi, rna = torch.randn(b, n, f, generator=g), torch.randn(b, gd, generator=g)
+    noise = {"wsi_mask": torch.rand(b, n, generator=g), "rna_mask": torch.rand(b, d, generator=g),
+             "wsi_eps": torch.randn(b, lat, generator=g), "rna_eps": torch.randn(b, lat, generator=g)}
     return wsi.cuda(), rna.cuda(), {k: v.cuda() for k, v in noise.items()}
 
 
@@ -229,17 +236,17 @@ def test_validate_matches_reference_loop_and_state_roundtrip(tmp_path):
 
 
 # ---------------------------------------------------------------- graphed RNA branch of the eager step (mirror_amd/graphed.py)
-def _run_eager(rna_graph: bool, steps: int, gather: bool = False):
+def _run_eager(rna_graph: bool, steps: int, gather: bool = False, cfg=CFG, batch: int = 4, bucket_mb: float = 0.05):
     import mirror_amd.models as M
     from mirror_amd import functional as Fn
     from mirror_amd.engine import TrainEngine
     from mirror_amd.losses import MIRRORLoss
     torch.manual_seed(11)
-    model = M.mirror(**CFG, rna_proj_drop_rate=0.1).cuda().train()
-    eng = TrainEngine(model, MIRRORLoss(gather_distributed=gather), lr=1e-3, precision="bf16", graph=False, bucket_mb=0.05)
+    model = M.mirror(**cfg, rna_proj_drop_rate=0.1).cuda().train()
+    eng = TrainEngine(model, MIRRORLoss(gather_distributed=gather), lr=1e-3, precision="bf16", graph=False, bucket_mb=bucket_mb)
     if not rna_graph:
         eng._rna_branch_state = "off"
-    Fn.manual_seed(5)
+    Fn.manual_seed(5)                  # the same dropout stream on every rank and in every variant: runs stay comparable
     init = eng.master.clone()
     losses = []
     eng.grad_snaps = []
@@ -251,7 +258,7 @@ def _run_eager(rna_graph: bool, steps: int, gather: bool = False):
     eng._finish_reduce = snap
     rank = dist.get_rank() if dist.is_initialized() else 0
     for s in range(steps):
-        wsi, rna, noise = _batch(4, 100 + 10 * s + rank)
+        wsi, rna, noise = _batch(batch, 100 + 10 * s + rank, cfg)
         losses.append([float(x) for x in eng.step(wsi.to(torch.bfloat16), rna, noise=noise)])
     return eng, init, losses
 
@@ -341,3 +348,70 @@ def test_transposed_shadow_follows_the_optimizer_for_unmanaged_shapes():
         eng.step(wsi.to(torch.bfloat16), rna, noise=noise)
         for w in odd:
             assert torch.equal(Fn.shadow_t(w, prec), Fn.shadow(w, prec).t().contiguous()), (s, tuple(w.shape))
+
+
+# ---------------------------------------------------------------- the same engine paths at D = 512 (fused kernels + pinv chain)
+def test_d512_graph_replay_matches_eager_launch():
+    """Whole-step HIP graph vs eager launch at D = 512 (bf16 policy, train mode): the fused Nystrom kernels, the one-launch
+    pinv chain on its side stream, the deferred v columns and the gradient sink all sit inside the captured step.  Same
+    seeds: losses of every step and the final parameters agree to f32-atomics noise."""
+    import mirror_amd.models as M
+    from mirror_amd.engine import TrainEngine
+    from mirror_amd.losses import MIRRORLoss
+    runs = []
+    for graph in (True, False):
+        torch.manual_seed(21)
+        model = M.mirror(**CFG512, rna_proj_drop_rate=0.1).cuda().train()
+        eng = TrainEngine(model, MIRRORLoss(), lr=1e-4, precision="bf16", graph=graph, seed=77, snapshot_grads=True)
+        if not graph:
+            eng._rna_branch_state = "off"
+        init = eng.master.clone()
+        wsi, rna, _ = _batch(4, 5, CFG512)
+        wsi = wsi.to(torch.bfloat16)
+        torch.manual_seed(123)
+        losses = [[float(x) for x in eng.step(wsi, rna)] for _ in range(6)]
+        assert (eng._graph is not None) == graph
+        runs.append((losses, eng.master.clone(), eng.grad_snap.clone(), init))
+    (la, pa, ga, init), (lb, pb, gb, _) = runs
+    for a, b in zip(la, lb):
+        for x, y in zip(a, b):
+            assert abs(x - y) <= 2e-3 * max(1.0, abs(y)), (la, lb)
+    assert float((ga - gb).norm()) <= 2e-2 * float(gb.norm())
+    _traj_close(pa, pb, init)
+
+
+def _worker_d512(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        eng_off, init, l_off = _run_eager(False, 4, gather=True, cfg=CFG512, batch=2, bucket_mb=1.0)
+        eng_on, _, l_on = _run_eager(True, 4, gather=True, cfg=CFG512, batch=2, bucket_mb=1.0)
+        a, b = eng_off.grad_snaps[1], eng_on.grad_snaps[1]        # step 1: eager + bucketed in both -> reproducible
+        rerun = float((a - b).norm() / a.norm())
+        q.put((rank, eng_off.master.cpu().numpy(), eng_on.master.cpu().numpy(), init.cpu().numpy(), eng_on._rna_branch_state,
+               l_off[-1][0], l_on[-1][0], rerun, len(eng_on.buckets)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_d512_bucketed_all_reduce_and_rna_graph_world2():
+    """Two gloo ranks on the one GPU at D = 512, bf16 policy, global-batch InfoNCE: the pinv chain's side stream, the fused
+    attention backward and the graphed RNA branch all feed the bucketed all-reduce; ranks must stay bit-identical, the
+    reduced gradients reproducible, and the graphed-branch trajectory must match the all-eager one."""
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 90)
+    procs = [ctx.Process(target=_worker_d512, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=900) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0][8] > 2, "the test needs several buckets"
+    assert res[0][4] == "on" and res[1][4] == "on"
+    assert res[0][7] < 1e-3 and res[1][7] < 1e-3, (res[0][7], res[1][7])
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2]), "ranks diverged"
+    _traj_close(torch.from_numpy(res[0][1]), torch.from_numpy(res[0][2]), torch.from_numpy(res[0][3]))
+    assert abs(res[0][5] - res[0][6]) < 1e-2 * abs(res[0][5])

@@ -126,3 +126,68 @@ def test_sample_indices_follows_the_reference_replace_rule():
     assert short.shape == (20,) and int(short.max()) < 5 and len(set(short.tolist())) <= 5
     with pytest.raises(ValueError):
         sample_indices(0, 4, g)
+
+
+def test_reference_import_names_resolve_through_the_alias():
+    """INTEGRATION.md §1: after install_aliases() the reference trainers' own imports (`import models`, train_mirror.py:43;
+    `from losses import MIRRORLoss`, :889-891; `from losses import InfoNCE`, train_pretrain.py:43) land in this build."""
+    import importlib
+    import sys
+    saved = {k: sys.modules.get(k) for k in ("models", "models.mirror", "losses", "losses.mirror_loss", "losses.info_nce")}
+    try:
+        mirror_amd.install_aliases()
+        models = importlib.import_module("models")
+        from models import mirror, mirror_classifier  # noqa: F401
+        from models.mirror import MIRROR, FeatureTransMILHybrid, TransFormerHybrid  # noqa: F401
+        from losses import CrossEntropySurvLoss, InfoNCE, MIRRORLoss, NLLSurvLoss  # noqa: F401
+        from losses.mirror_loss import ClipLoss  # noqa: F401
+        from losses.info_nce import InfoNCE as I2
+        import mirror_amd.models as M
+        import mirror_amd.losses as L
+        assert models is M and mirror is M.mirror and MIRRORLoss is L.MIRRORLoss and I2 is InfoNCE is L.InfoNCE
+        assert sorted(importlib.import_module("losses").__all__) == ["CrossEntropySurvLoss", "InfoNCE", "MIRRORLoss", "NLLSurvLoss"]
+        m = models.create_model("mirror", wsi_embed_dim=16, rna_embed_dim=8, embed_dim=96, wsi_num_tokens=4, num_prototypes=5,
+                                pretrained_cfg=None)                 # timm injects pretrained*: filtered with a warning
+        assert isinstance(m, MIRROR) and m.rna_encoder.num_heads == 12
+        assert MIRRORLoss(alignment_loss_weight=0.5, cluster_loss_weight=0.1).cluster_loss_weight == 0.1
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+def test_checkpoint_with_args_round_trips_and_reference_namespace_opens(tmp_path):
+    """The reference always checkpoints `args` (train_mirror.py:920-930, an argparse.Namespace).  This build stores it as a
+    plain dict (opens under torch.load's weights_only default), and a reference-style file that pickles the Namespace itself
+    opens through the allow-list in load_checkpoint_file."""
+    import argparse
+    from mirror_amd.checkpoint import CheckpointSaver, load_checkpoint_file, resume_checkpoint
+    model = torch.nn.Linear(3, 2)
+    args = argparse.Namespace(model="mirror", lr=2e-5, model_kwargs={"embed_dim": 512}, amp=True)
+    saver = CheckpointSaver(model, args=args, checkpoint_dir=str(tmp_path), max_history=1)
+    saver.save_checkpoint(3, metric=1.5)
+    other = torch.nn.Linear(3, 2)
+    assert resume_checkpoint(other, os.path.join(tmp_path, "last.pth.tar")) == 4
+    assert torch.equal(other.weight, model.weight)
+    ck = load_checkpoint_file(os.path.join(tmp_path, "last.pth.tar"))
+    assert ck["args"] == vars(args) and ck["metric"] == 1.5
+    ref_style = os.path.join(tmp_path, "ref.pth.tar")
+    torch.save({"epoch": 7, "arch": "mirror", "state_dict": model.state_dict(), "args": args, "version": 2}, ref_style)
+    assert resume_checkpoint(other, ref_style) == 8
+    assert load_checkpoint_file(ref_style)["args"].lr == 2e-5
+
+
+def test_bench_gpus_n_without_launcher_refuses_when_devices_are_missing():
+    """`python bench.py --gpus N` launches its N ranks itself; with fewer than N visible GPUs it must exit non-zero instead
+    of silently benchmarking one rank (--gpus was parsed and never read).  No GPU here: 0 devices < 2."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MIRROR_BENCH_DIST")}
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than 2 GPUs")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 2 but only" in r.stderr, (r.returncode, r.stderr[-300:])
+    assert '"n_gpus"' not in r.stdout

@@ -33,5 +33,9 @@ for k in sorted(set(ft) | set(wt)):
     w = wt[k] / max(wc[k], 1)
     out[k] = {"fetch_kib_raw": round(f, 1), "write_kib": round(w, 1), "bytes_per_launch": int((2 * f + w) * 1024),
               "launches": int(max(fc[k], wc[k]))}
-json.dump({"note": "bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB, averaged over the launches of each kernel in a "
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import csrc_digest  # noqa: E402
+
+json.dump({"csrc_sha256": csrc_digest(), "config": "c2", "note": "bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB, averaged over the launches of each kernel in a "
                    "3-step bench run; see tools/pmc_summary.py", "kernels": out}, sys.stdout, indent=1)
