@@ -110,12 +110,12 @@ def test_c2_bf16_policy_parameter_gradients_match_oracle():
 
 
 # ------------------------------------------------------------------------------------------------ (b) replay == eager
-def _c2_engine(graph: bool, steps: int, snap_at):
+def _c2_engine(graph: bool, steps: int, snap_at, lr: float = 2e-5):
     from mirror_amd.engine import TrainEngine
     torch.manual_seed(42)
     m = M.mirror(wsi_embed_dim=1024, rna_embed_dim=2048, embed_dim=512, wsi_num_tokens=4096, rna_encoder_depth=6,
                  rna_mlp_ratio=4.0, rna_norm_layer="layernorm", rna_act_layer="gelu", rna_num_heads=8).to(DEV).train()
-    eng = TrainEngine(m, MIRRORLoss(), lr=2e-5, precision="bf16", graph=graph, seed=1234, snapshot_grads=True)
+    eng = TrainEngine(m, MIRRORLoss(), lr=lr, precision="bf16", graph=graph, seed=1234, snapshot_grads=True)
     if not graph:
         eng._rna_branch_state = "off"            # all-eager: every launch issued from Python
     g = torch.Generator(device=DEV).manual_seed(1)
@@ -146,25 +146,39 @@ def test_c2_graph_replay_equals_eager_step():
     """The bench configuration (c2, B = 16, bf16 policy, train mode with dropout): engine A replays the whole step as ONE HIP
     graph from its third step on, engine B launches every step eagerly.  Same seeds -> the torch generator (noise draws),
     the Philox dropout base and Adam's device state advance identically, so step k of A must equal step k of B up to the
-    order of f32 atomics: the six losses of every step, and the gradient arena of the first two replayed steps."""
-    la, sa, layout, replayed = _c2_engine(True, 6, (2, 3))
-    lb, sb, _, _ = _c2_engine(False, 6, (2, 3))
-    assert replayed
-    assert np.isfinite(la).all() and np.isfinite(lb).all()
-    rel = np.abs(la - lb) / np.maximum(np.abs(lb), 1e-3)
-    worst = []
+    order of the f32 atomics.
+      * lr = 0 (parameters frozen, noise / dropout still redrawn every step): the gradient arena of the first two REPLAYED
+        steps equals the eager one per parameter — nothing but atomics order can differ;
+      * lr = 2e-5 (the bench): the six losses of all six steps agree (Adam turns rounding-level gradient noise into +-lr
+        moves of near-zero-gradient elements, so the trajectories drift apart at the 1e-4 level: measured <= 6e-4)."""
+    la, sa, layout, replayed = _c2_engine(True, 4, (2, 3), lr=0.0)
+    lb, sb, _, _ = _c2_engine(False, 4, (2, 3), lr=0.0)
+    le, se, _, _ = _c2_engine(False, 4, (2, 3), lr=0.0)       # a second eager run: the noise floor of the comparison
+    assert replayed and np.isfinite(la).all() and np.isfinite(lb).all()
+    rel0 = np.abs(la - lb) / np.maximum(np.abs(lb), 1e-3)
+    assert len({tuple(r) for r in la[2:].round(6).tolist()}) > 1, "replays produced identical losses: noise is not redrawn"
+    worst, totals = [], []
     for s in (2, 3):
-        ga, gb = sa[s].double(), sb[s].double()
+        ga, gb, ge = sa[s].double(), sb[s].double(), se[s].double()
+        gtot = float(gb.norm())
         for n, o, cnt in layout:
             a, b = ga[o:o + cnt], gb[o:o + cnt]
-            d = float((a - b).norm()) / max(float(b.norm()), 1e-30)
-            worst.append((d, s, n))
+            worst.append((float((a - b).norm()) / (float(b.norm()) + 1e-3 * gtot), s, n))
+        d_replay, d_floor = float((ga - gb).norm()) / gtot, float((ge - gb).norm()) / gtot
+        totals.append((s, d_replay, d_floor))
+        # bf16 activations turn a different f32 summation order into 1-ulp flips here and there: eager vs eager is not
+        # bit-equal either.  The replay must sit at that floor, not merely be "close".
+        assert d_replay < 3.0 * d_floor + 1e-5 and d_replay < 2e-3, totals
     worst.sort(reverse=True)
-    _report("r02_replay_vs_eager.json", {"loss_rel_diff_per_step": rel.tolist(), "worst_param_grad_rel_diff": worst[:10]})
-    assert rel.max() < 2e-3, rel                                   # measured ~1e-5 (gpurun_out/r02_replay_vs_eager.json)
+    lc, _, _, _ = _c2_engine(True, 6, ())
+    ld, _, _, _ = _c2_engine(False, 6, ())
+    rel = np.abs(lc - ld) / np.maximum(np.abs(ld), 1e-3)
+    _report("r02_replay_vs_eager.json", {"lr0_loss_rel_diff_per_step": rel0.tolist(), "lr0_worst_param_grad_rel_diff": worst[:10],
+                                         "lr0_total_grad_rel_diff (step, replay-vs-eager, eager-vs-eager)": totals,
+                                         "lr2e-5_loss_rel_diff_per_step": rel.tolist()})
+    assert rel0.max() < 2e-4, rel0
     assert worst[0][0] < 2e-2, worst[:5]
-    total = sum(float((sa[2][o:o + c].double() - sb[2][o:o + c].double()).pow(2).sum()) for _, o, c in layout) ** 0.5
-    assert total < 2e-3 * float(sb[2].double().norm())
+    assert rel.max() < 2e-3, rel
 
 
 # ------------------------------------------------------------------------------------------------ (c) whole-model c4
@@ -223,7 +237,8 @@ def test_reference_step_sequence_under_autocast_selects_bf16_policy(monkeypatch)
     try:
         import models
         from losses import MIRRORLoss as RefNameLoss
-        from mirror_amd.models import mirror as mm
+        import importlib
+        mm = importlib.import_module("mirror_amd.models.mirror")
         picked = []
         real = mm.resolve_precision
 
@@ -323,11 +338,14 @@ def test_nystrom_with_every_token_a_landmark_converges_to_softmax_attention(poli
     A = torch.softmax(q @ k.transpose(-1, -2), dim=-1)
     conv = torch.nn.functional.conv2d(v, res_w.double(), padding=(16, 0), groups=h)
     want = (A @ v + conv).permute(0, 2, 1, 3).reshape(B, n, D)
+    # bf16 iterates stop at 12: far past convergence the cubic iteration amplifies rounding noise in the directions of A's
+    # tiny singular values by 13/4 per step (z there grows like 1/sigma), which bf16 cannot hold — the reference runs 6
+    schedule = (2, 6, 12, 24) if policy == "fp32" else (2, 4, 6, 12)
     errs = []
-    for iters in (2, 6, 12, 24):
+    for iters in schedule:
         out = Fn.NystromCoreFn.apply(qkv, res_w, h, 1, iters, prec, None)
         errs.append(float((out.double() - want).norm() / want.norm()))
-    _report(f"r02_nystrom_m_eq_n_{policy}.json", {"iters": [2, 6, 12, 24], "rel_err": errs})
+    _report(f"r02_nystrom_m_eq_n_{policy}.json", {"iters": list(schedule), "rel_err": errs})
     assert errs[1] < errs[0] and errs[2] < max(errs[1], floor) and errs[3] <= max(errs[2], floor), errs
     assert errs[3] < floor, errs
 
@@ -342,7 +360,7 @@ def test_pinv_chain_times_a2_converges_to_identity():
     a2 = torch.softmax(logits, dim=-1).to(DEV)
     eye = torch.eye(m, device=DEV, dtype=torch.float64)
     errs = []
-    for iters in (1, 3, 6, 9):
+    for iters in (1, 3, 6, 9, 12):
         st = K.pinv_absmax(a2)
         saved = K.pinv_chain_saved_alloc(iters, BH, m, DEV)
         z0, xt = K.pinv_chain_prep(a2, st, K.pinv_chain_z0_slot(saved))
@@ -350,9 +368,9 @@ def test_pinv_chain_times_a2_converges_to_identity():
         K.pinv_chain_fwd(xt, saved, zfT, iters)
         Z = zfT.transpose(-1, -2).double()
         errs.append(float((a2.double() @ Z - eye).norm(dim=(-1, -2)).max()) / m ** 0.5)
-    _report("r02_pinv_chain_identity.json", {"iters": [1, 3, 6, 9], "rms_residual": errs})
-    assert errs[0] > errs[1] > errs[2], errs
-    assert errs[2] < 2e-2 and errs[3] < 2e-2, errs
+    _report("r02_pinv_chain_identity.json", {"iters": [1, 3, 6, 9, 12], "rms_residual": errs})
+    assert errs[0] > errs[1] > errs[2] > errs[3], errs
+    assert errs[2] < 0.1 and errs[3] < 1e-2 and errs[4] < 1e-2, errs
 
 
 @pytest.mark.parametrize("policy,tol", [("fp32", 1e-5), ("bf16", 2.0 ** -7)])
