@@ -223,6 +223,41 @@ int mh_mask_apply_bwd(const void* dy, void* dx, const float* mask, float* dtoken
 
 /* ---------------------------------------------------------------- RNA encoder pieces (models/mirror.py:77-102)
  * qkv [B, 3D] -> softmax over the HEADS axis -> out[b, d*H + h]; attn [B,H,H] saved for backward */
+/* One pre-norm Block of the RNA transformer (reference: Block.forward models/mirror.py:149-152, Attention.forward :77-102,
+ * [3P] timm Mlp fc1 -> GELU -> drop -> fc2 -> drop) on [B <= 32, D] rows, forward and backward, ONE call per direction:
+ *   x1 = x + drop(proj(headattn(qkv(LN1(x)))));  y = x1 + drop(fc2(drop(gelu(fc1(LN2(x1))))))
+ * LayerNorm, bias, GELU, the three dropouts (Philox, regenerated in the backward) and the residual adds ride in the
+ * prologues / epilogues of the weight-streaming GEMM kernels (5 launches forward, 6 backward; csrc/rna_block.hip).
+ * Needs D % 32 == 0, Hh % 32 == 0, D % H == 0.  Weights are bf16 [N, K] row-major; wt_* are their transposes [K, N] (the
+ * data gradients stream them like forward weights).  Saved tensors are caller-allocated in the forward and handed back
+ * unchanged in the backward; gradients ACCUMULATE into the f32 d* buffers. */
+typedef struct {
+    int32_t B, D, Hh, H;          /* rows, model width, MLP hidden width, attention heads */
+    float eps, p_drop;            /* LayerNorm eps; dropout probability (0 = eval mode) */
+    uint64_t seed, offset;        /* Philox streams: proj output at `offset`, fc1 activation at + q4(B D), fc2 output at + q4(B Hh) more (q4 = round up to 4) */
+    const uint64_t* dev_base;     /* optional device-side base added to `offset` (per-step base of a replayed HIP graph) */
+    const void *w_qkv, *w_proj, *w_fc1, *w_fc2;         /* bf16 [3D, D], [D, D], [Hh, D], [D, Hh] */
+    const void *wt_qkv, *wt_proj, *wt_fc1, *wt_fc2;     /* bf16 transposes (backward only) */
+    const float *b_qkv, *b_proj, *b_fc1, *b_fc2;        /* biases (b_qkv may be NULL) */
+    const float *g1, *be1, *g2, *be2;                   /* LayerNorm 1 / 2 weight and bias */
+    const float* x;               /* [B, D] f32 block input */
+    float* y;                     /* [B, D] f32 block output (forward) */
+    float* stats;                 /* saved: [4, B] mean1, rstd1, mean2, rstd2 */
+    void* qkv;                    /* saved: bf16 [B, 3D] */
+    float* attn;                  /* saved: f32 [B, H, H] attention probabilities */
+    void* o;                      /* saved: bf16 [B, D] attention output */
+    float* x1;                    /* saved: f32 [B, D] stream after the attention half */
+    void* u;                      /* saved: bf16 [B, Hh] fc1 output before GELU */
+    void* f;                      /* saved: bf16 [B, Hh] fc2 input */
+    const float* dy;              /* backward: [B, D] f32 gradient of y */
+    float* dx;                    /* backward: [B, D] f32 gradient of x (written) */
+    float *dw_qkv, *dw_proj, *dw_fc1, *dw_fc2, *db_qkv, *db_proj, *db_fc1, *db_fc2, *dg1, *dbe1, *dg2, *dbe2;
+    void* scratch;                /* backward: mh_rna_block_workspace_bytes(B, D, Hh) bytes */
+} mh_rna_block;
+int mh_rna_block_fwd(const mh_rna_block* blk, mh_stream s);
+int mh_rna_block_bwd(const mh_rna_block* blk, mh_stream s);
+int64_t mh_rna_block_workspace_bytes(int B, int D, int Hh);
+
 int mh_headattn_fwd(const void* qkv, void* out, float* attn, int B, int H, int hd, int dt, mh_stream s);
 int mh_headattn_bwd(const void* qkv, const float* attn, const void* dout, void* dqkv, int B, int H, int hd,
                     int dt, mh_stream s);

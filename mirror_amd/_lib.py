@@ -34,6 +34,20 @@ class GemmDesc(C.Structure):
 
 P, I, L, F, U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 
+
+class RnaBlockDesc(C.Structure):
+    """mh_rna_block of include/mirror_hip.h (field order = the header's)."""
+    _fields_ = (
+        [("B", C.c_int32), ("D", C.c_int32), ("Hh", C.c_int32), ("H", C.c_int32), ("eps", C.c_float), ("p_drop", C.c_float),
+         ("seed", C.c_uint64), ("offset", C.c_uint64), ("dev_base", C.c_void_p)]
+        + [(n, C.c_void_p) for n in (
+            "w_qkv", "w_proj", "w_fc1", "w_fc2", "wt_qkv", "wt_proj", "wt_fc1", "wt_fc2",
+            "b_qkv", "b_proj", "b_fc1", "b_fc2", "g1", "be1", "g2", "be2",
+            "x", "y", "stats", "qkv", "attn", "o", "x1", "u", "f", "dy", "dx",
+            "dw_qkv", "dw_proj", "dw_fc1", "dw_fc2", "db_qkv", "db_proj", "db_fc1", "db_fc2", "dg1", "dbe1", "dg2", "dbe2",
+            "scratch")])
+
+
 # name -> argtypes (the trailing stream argument is appended automatically)
 _SIGS = {
     "mh_gemm": [C.POINTER(GemmDesc)],
@@ -104,8 +118,10 @@ _SIGS = {
     "mh_clamp_": [P, L, F, F],
     "mh_adam": [P, P, P, P, P, L, F, F, F, F, F, F, F, P],
     "mh_grad_clip": [P, L, F, F, P, P],
+    "mh_rna_block_fwd": [C.POINTER(RnaBlockDesc)],
+    "mh_rna_block_bwd": [C.POINTER(RnaBlockDesc)],
 }
-EXPORTS = sorted(list(_SIGS) + ["mh_last_error", "mh_version", "mh_device_ok", "mh_nys_attn3_ws_floats"])
+EXPORTS = sorted(list(_SIGS) + ["mh_last_error", "mh_version", "mh_device_ok", "mh_nys_attn3_ws_floats", "mh_rna_block_workspace_bytes"])
 
 _lib = None
 
@@ -130,6 +146,8 @@ def load() -> C.CDLL:
     lib.mh_device_ok.restype = C.c_int
     lib.mh_nys_attn3_ws_floats.restype = C.c_int64
     lib.mh_nys_attn3_ws_floats.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.mh_rna_block_workspace_bytes.restype = C.c_int64
+    lib.mh_rna_block_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
     for name, sig in _SIGS.items():
         fn = getattr(lib, name)
         fn.argtypes = list(sig) + [C.c_void_p]

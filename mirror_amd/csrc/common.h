@@ -94,6 +94,19 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return cdf + x * pdf;
 }
 
+// Philox4x32-10 (dropout masks): element i of a tensor uses word (i & 3) of the block with counter (offset + i) >> 2
+__device__ __forceinline__ void philox4x32_10(uint32_t (&ctr)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * ctr[0];
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * ctr[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ ctr[1] ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ ctr[3] ^ k1;
+        ctr[0] = n0; ctr[1] = (uint32_t)p1; ctr[2] = n2; ctr[3] = (uint32_t)p0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
 static inline int mh_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // Dispatch a functor-style macro over one runtime dtype.

@@ -1,0 +1,539 @@
+// One pre-norm Block of the RNA transformer (models/mirror.py:105-152 with Attention :50-102 and [3P] timm Mlp) behind ONE
+// C-ABI call per direction: mh_rna_block_fwd / mh_rna_block_bwd.
+//
+//   x1 = x  + drop(proj(headattn(qkv(LN1(x)))))        x2 = x1 + drop(fc2(drop(gelu(fc1(LN2(x1))))))
+//
+// Every tensor is [B, D] with B = the per-GPU batch (<= 32): the four Linears are weight-streaming problems (6.3 MB of
+// bf16 weights per block at D = 512, Hh = 2048) and everything between them is B x D elementwise work.  The un-fused
+// path ran a block as ~12 forward and ~20 backward launches (LayerNorm, GELU, three dropouts, residual adds, casts, one
+// launch per bias / weight gradient).  Here the elementwise work rides in the prologues / epilogues of the GEMM kernels:
+//
+//   forward  (5 launches)  [LN1 -> qkv + bias]  [heads attention]  [proj + bias + dropout + residual]
+//                          [LN2 -> fc1 + bias -> GELU -> dropout]  [fc2 + bias + dropout + residual]
+//   backward (6 launches)  [dropout' -> fc2 dgrad -> GELU' dropout'  |  fc2 wgrad + bias grad]
+//                          [fc1 dgrad                                |  fc1 wgrad (LN2 recomputed) + bias grad]
+//                          [LN2' + residual -> dropout' -> proj dgrad |  proj wgrad + bias grad | LN2 gamma / beta grads]
+//                          [heads attention']  [qkv dgrad | qkv wgrad (LN1 recomputed) + bias grad]  [LN1' + residual, LN1 grads]
+//
+// A data-gradient launch and the weight-gradient launch of the same Linear are ONE grid (role by blockIdx): both read the
+// same B x N gradient matrix, which every workgroup rebuilds from its source (incoming gradient, dropout mask regenerated
+// from Philox, LayerNorm backward) in its prologue instead of a separate kernel materialising it.
+// Stage boundaries are kernel boundaries on purpose: every stage needs ALL columns of the previous one, and a dependent
+// launch costs ~1.5-1.9 us on this chip against 4-7 us for an in-kernel grid barrier (MI355X_MICROARCH.md price list).
+//
+// GEMM core: v_mfma_f32_16x16x32_bf16, the B x K operand staged once in LDS (bf16), weights HBM -> VGPR in B-fragment layout
+// (one 16-byte load of a weight row per lane and k-step), one workgroup per 16 output columns, the 4 waves split K.
+#include "common.h"
+
+typedef __bf16 rb_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float rb_f4 __attribute__((ext_vector_type(4)));
+typedef unsigned rb_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned rb_u2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int PADK = 8;       // bf16 elements of padding per LDS operand row (16 bytes: rows land on different banks)
+
+struct Drop {                  // one Philox dropout stream: element i -> word (i & 3) of block (offset + i) >> 2
+    float p;
+    unsigned long long seed, offset;
+};
+
+// keep-scale factors of the four elements i .. i + 3 (i % 4 == 0) of stream d
+__device__ __forceinline__ rb_f4 drop4(const Drop& d, long i) {
+    if (d.p <= 0.f) return rb_f4{1.f, 1.f, 1.f, 1.f};
+    const float scale = 1.f / (1.f - d.p);
+    const uint32_t thr = (uint32_t)fminf(d.p * 4294967296.f, 4294967295.f);
+    const uint64_t blk = (d.offset + (uint64_t)i) >> 2;
+    uint32_t ctr[4] = {(uint32_t)blk, (uint32_t)(blk >> 32), 0u, 0u};
+    philox4x32_10(ctr, (uint32_t)d.seed, (uint32_t)(d.seed >> 32));
+    return rb_f4{ctr[0] >= thr ? scale : 0.f, ctr[1] >= thr ? scale : 0.f, ctr[2] >= thr ? scale : 0.f, ctr[3] >= thr ? scale : 0.f};
+}
+
+__device__ __forceinline__ rb_u2 pack4(rb_f4 v) {
+    return rb_u2{(unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16)};
+}
+__device__ __forceinline__ rb_f4 unpack4(rb_u2 u) {
+    return rb_f4{__uint_as_float(u[0] << 16), __uint_as_float(u[0] & 0xffff0000u), __uint_as_float(u[1] << 16), __uint_as_float(u[1] & 0xffff0000u)};
+}
+
+// ------------------------------------------------------------------------------------------------------ GEMM core
+// acc[t] (16 x 16 per 16-row tile t) = sA[16 t .., :] . W[n0 .., :]^T over K, K split over the 4 waves, reduced into
+// red[4][MT][16][17].  sA: bf16 [MT * 16][K + PADK] in LDS.
+template <int MT>
+__device__ __forceinline__ void skinny_core(const bf16_t* sA, int K, const bf16_t* __restrict__ w, long ldw, int n0, int N, float* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, kq = lane >> 4;
+    const int pitch = K + PADK;
+    const bf16_t* wp = w + (long)min(n0 + col, N - 1) * ldw + 8 * kq;      // ragged last column group: re-read row N-1, never stored
+    rb_f4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; t++) acc[t] = rb_f4{0.f, 0.f, 0.f, 0.f};
+    const int steps = K / 32;
+#pragma unroll 4
+    for (int s = wave; s < steps; s += 4) {
+        const rb_bf16x8 b = *reinterpret_cast<const rb_bf16x8*>(wp + 32 * s);
+#pragma unroll
+        for (int t = 0; t < MT; t++) {
+            const rb_bf16x8 a = *reinterpret_cast<const rb_bf16x8*>(sA + (16 * t + col) * pitch + 32 * s + 8 * kq);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) red[((wave * MT + t) * 16 + kq * 4 + r) * 17 + col] = acc[t][r];   // C/D map: row = 4 kq + r, col
+}
+template <int MT>
+__device__ __forceinline__ rb_f4 red_quad(const float* red, int t, int rr, int c4) {
+    rb_f4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < 4; w++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] += red[((w * MT + t) * 16 + rr) * 17 + c4 + e];
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------------ forward
+struct FwdArgs {
+    const void* a;            // operand rows [B, K]: f32 when a_f32 (LayerNorm input or plain cast), else bf16
+    int a_f32, ln;
+    const float *gamma, *beta;
+    float eps;
+    float* stats;             // ln: mean [B], rstd [B] written by workgroup 0 (saved for the backward)
+    const bf16_t* w;          // [N, K]
+    const float* bias;
+    void* out;                // [B, N]
+    int out_f32;
+    bf16_t* preact;           // optional: bf16 copy of the result before the activation
+    const float* res;         // optional f32 [B, N] residual: out = res + dropout(act(...))
+    int act;
+    Drop drop;
+    const unsigned long long* dev_base;     // optional per-step base offset kept on the device (graph replays)
+    int B, N, K;
+};
+
+template <int MT>
+__global__ __launch_bounds__(256) void rna_fwd_kernel(FwdArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* sA = reinterpret_cast<bf16_t*>(smem);
+    if (g.dev_base) g.drop.offset += *g.dev_base & ~3ull;
+    const int K = g.K, pitch = K + PADK;
+    float* red = reinterpret_cast<float*>(smem + (size_t)MT * 16 * pitch * 2);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // ---- operand image: (LayerNorm of) the B input rows as bf16; rows past B are zero
+    for (int m = wave; m < MT * 16; m += 4) {
+        bf16_t* row = sA + m * pitch;
+        if (m >= g.B) {
+            for (int k = 4 * lane; k < K; k += 256) *reinterpret_cast<rb_u2*>(row + k) = rb_u2{0u, 0u};
+            continue;
+        }
+        if (!g.a_f32) {
+            const bf16_t* src = reinterpret_cast<const bf16_t*>(g.a) + (long)m * K;
+            for (int k = 4 * lane; k < K; k += 256) *reinterpret_cast<rb_u2*>(row + k) = *reinterpret_cast<const rb_u2*>(src + k);
+            continue;
+        }
+        const float* src = reinterpret_cast<const float*>(g.a) + (long)m * K;
+        float mean = 0.f, rstd = 1.f;
+        if (g.ln) {
+            float s = 0.f;
+            for (int k = 4 * lane; k < K; k += 256) { const rb_f4 v = *reinterpret_cast<const rb_f4*>(src + k); s += v[0] + v[1] + v[2] + v[3]; }
+            mean = wave_sum(s) / (float)K;
+            float q = 0.f;
+            for (int k = 4 * lane; k < K; k += 256) {
+                const rb_f4 v = *reinterpret_cast<const rb_f4*>(src + k) - mean;
+                q += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+            }
+            rstd = rsqrtf(wave_sum(q) / (float)K + g.eps);
+            if (blockIdx.x == 0 && lane == 0 && g.stats) { g.stats[m] = mean; g.stats[g.B + m] = rstd; }
+        }
+        for (int k = 4 * lane; k < K; k += 256) {
+            rb_f4 v = *reinterpret_cast<const rb_f4*>(src + k);
+            if (g.ln) v = (v - mean) * rstd * *reinterpret_cast<const rb_f4*>(g.gamma + k) + *reinterpret_cast<const rb_f4*>(g.beta + k);
+            *reinterpret_cast<rb_u2*>(row + k) = pack4(v);
+        }
+    }
+    __syncthreads();
+    const int n0 = blockIdx.x * 16;
+    skinny_core<MT>(sA, K, g.w, K, n0, g.N, red);
+    __syncthreads();
+    // ---- epilogue: one quad of columns per thread
+    for (int i = threadIdx.x; i < MT * 64; i += 256) {
+        const int t = i >> 6, rr = (i >> 2) & 15, c4 = 4 * (i & 3);
+        const int m = 16 * t + rr, n = n0 + c4;
+        if (m >= g.B || n >= g.N) continue;
+        rb_f4 v = red_quad<MT>(red, t, rr, c4);
+        if (g.bias) v += *reinterpret_cast<const rb_f4*>(g.bias + n);
+        const long idx = (long)m * g.N + n;
+        if (g.preact) *reinterpret_cast<rb_u2*>(g.preact + idx) = pack4(v);
+        if (g.act == MH_ACT_GELU) v = rb_f4{gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])};
+        else if (g.act == MH_ACT_RELU) v = rb_f4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+        v *= drop4(g.drop, idx);
+        if (g.res) v += *reinterpret_cast<const rb_f4*>(g.res + idx);
+        if (g.out_f32) *reinterpret_cast<rb_f4*>(reinterpret_cast<float*>(g.out) + idx) = v;
+        else *reinterpret_cast<rb_u2*>(reinterpret_cast<bf16_t*>(g.out) + idx) = pack4(v);
+    }
+}
+
+size_t fwd_lds(int MT, int K) { return (size_t)MT * 16 * (K + PADK) * 2 + (size_t)4 * MT * 16 * 17 * 4; }
+
+int launch_fwd(const FwdArgs& a, hipStream_t s) {
+    const int MT = a.B <= 16 ? 1 : 2;
+    const size_t lds = fwd_lds(MT, a.K);
+    dim3 grid(mh_cdiv(a.N, 16));
+    static const bool attr = [] {       // operand images above 64 KiB (K = 2048 at B = 16) need the opt-in
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rna_fwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rna_fwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+        return true;
+    }();
+    (void)attr;
+    if (lds > 158 * 1024) { mh_set_error("rna block: operand image of %zu bytes exceeds the 160 KiB of LDS", lds); return MH_EINVAL; }
+    if (MT == 1) hipLaunchKernelGGL((rna_fwd_kernel<1>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((rna_fwd_kernel<2>), grid, dim3(256), lds, s, a);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------ backward
+// One Linear y = x W^T + b of the block, both gradients in one grid.  The gradient matrix G [B, M] (M = the Linear's output
+// width) is rebuilt by every workgroup from its source:
+//   src 0: G = g_in (bf16)                                   src 1: G = r * dropmask                 (r f32 [B, M])
+//   src 2: G = (r + LayerNorm'(dh; xs, stats, gamma)) * dropmask — the pre-norm residual join; workgroup 0 also writes the
+//          joined f32 gradient to r_out and accumulates the LayerNorm's gamma / beta gradients
+// dgrad role (blockIdx < n_dgrad): dx[:, k0 .. k0 + 16) = G . W over M, via W^T [Kin, M]; epilogue 0: f32, 1: * GELU'(u) *
+//          dropmask2 -> bf16, 2: bf16
+// wgrad role: dW[n0 .. n0 + 64, k0 .. k0 + 256) += G^T X, db += column sums of G; X = x_in (bf16) or LayerNorm(xl) recomputed
+struct BwdArgs {
+    int src;
+    const bf16_t* g_in;
+    const float *r, *dh, *xs, *stats, *gamma;
+    float *r_out, *dgamma, *dbeta;
+    Drop drop;
+    int B, M;
+    const bf16_t* wt;         // [Kin, M]
+    int Kin, epi;
+    void* dx;
+    const bf16_t* u;
+    Drop drop2;
+    int xsrc;
+    const bf16_t* x_in;
+    const float *xl, *stats_l, *gamma_l, *beta_l;
+    float *dw, *db;
+    const unsigned long long* dev_base;
+    int n_dgrad;
+};
+
+// four consecutive elements (n % 4 == 0) of row m of G; c12: LDS [2][32] row constants of the LayerNorm backward (src 2)
+__device__ __forceinline__ rb_f4 gval4(const BwdArgs& g, const float* c12, int m, int n) {
+    const long idx = (long)m * g.M + n;
+    if (g.src == 0) return unpack4(*reinterpret_cast<const rb_u2*>(g.g_in + idx));
+    rb_f4 v = *reinterpret_cast<const rb_f4*>(g.r + idx);
+    if (g.src == 2) {
+        const float mean = g.stats[m], rstd = g.stats[g.B + m];
+        const rb_f4 xh = (*reinterpret_cast<const rb_f4*>(g.xs + idx) - mean) * rstd;
+        const rb_f4 a = *reinterpret_cast<const rb_f4*>(g.dh + idx) * *reinterpret_cast<const rb_f4*>(g.gamma + n);
+        v += rstd * (a - c12[m] - xh * c12[32 + m]);
+    }
+    return v;
+}
+
+template <int MT>
+__global__ __launch_bounds__(256) void rna_bwd_kernel(BwdArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float c12[64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int M = g.M;
+    if (g.dev_base) {
+        const unsigned long long base = *g.dev_base & ~3ull;
+        g.drop.offset += base;
+        g.drop2.offset += base;
+    }
+    if (g.src == 2) {        // row constants of LayerNorm': c1 = mean(dh gamma), c2 = mean(dh gamma xhat)
+        for (int m = wave; m < g.B; m += 4) {
+            const float mean = g.stats[m], rstd = g.stats[g.B + m];
+            float s1 = 0.f, s2 = 0.f;
+            for (int n = 4 * lane; n < M; n += 256) {
+                const long idx = (long)m * M + n;
+                const rb_f4 xh = (*reinterpret_cast<const rb_f4*>(g.xs + idx) - mean) * rstd;
+                const rb_f4 a = *reinterpret_cast<const rb_f4*>(g.dh + idx) * *reinterpret_cast<const rb_f4*>(g.gamma + n);
+                s1 += a[0] + a[1] + a[2] + a[3];
+                s2 += a[0] * xh[0] + a[1] * xh[1] + a[2] * xh[2] + a[3] * xh[3];
+            }
+            s1 = wave_sum(s1) / (float)M;
+            s2 = wave_sum(s2) / (float)M;
+            if (lane == 0) { c12[m] = s1; c12[32 + m] = s2; }
+        }
+        __syncthreads();
+        if (blockIdx.x == 0) {       // joined gradient out, LayerNorm parameter gradients (columns over threads)
+            for (int n = threadIdx.x; n < M; n += 256) {
+                float dg = 0.f, dbt = 0.f;
+                for (int m = 0; m < g.B; m++) {
+                    const long idx = (long)m * M + n;
+                    const float xh = (g.xs[idx] - g.stats[m]) * g.stats[g.B + m], d = g.dh[idx];
+                    dg += d * xh;
+                    dbt += d;
+                }
+                g.dgamma[n] += dg;
+                g.dbeta[n] += dbt;
+            }
+            if (g.r_out)
+                for (int i = threadIdx.x; i < g.B * (M / 4); i += 256) {
+                    const int m = i / (M / 4), n = 4 * (i % (M / 4));
+                    *reinterpret_cast<rb_f4*>(g.r_out + (long)m * M + n) = gval4(g, c12, m, n);
+                }
+        }
+    }
+    if ((int)blockIdx.x < g.n_dgrad) {
+        // ------------------------------------------------ data gradient: G (bf16 image) . W^T rows
+        bf16_t* sG = reinterpret_cast<bf16_t*>(smem);
+        const int pitch = M + PADK;
+        float* red = reinterpret_cast<float*>(smem + (size_t)MT * 16 * pitch * 2);
+        for (int m = wave; m < MT * 16; m += 4) {
+            bf16_t* row = sG + m * pitch;
+            for (int n = 4 * lane; n < M; n += 256) {
+                rb_f4 v = {0.f, 0.f, 0.f, 0.f};
+                if (m < g.B) v = gval4(g, c12, m, n) * drop4(g.drop, (long)m * M + n);
+                *reinterpret_cast<rb_u2*>(row + n) = pack4(v);
+            }
+        }
+        __syncthreads();
+        const int k0 = blockIdx.x * 16;
+        skinny_core<MT>(sG, M, g.wt, M, k0, g.Kin, red);
+        __syncthreads();
+        for (int i = threadIdx.x; i < MT * 64; i += 256) {
+            const int t = i >> 6, rr = (i >> 2) & 15, c4 = 4 * (i & 3);
+            const int m = 16 * t + rr, k = k0 + c4;
+            if (m >= g.B || k >= g.Kin) continue;
+            rb_f4 v = red_quad<MT>(red, t, rr, c4);
+            const long idx = (long)m * g.Kin + k;
+            if (g.epi == 1) {
+                const rb_f4 uu = unpack4(*reinterpret_cast<const rb_u2*>(g.u + idx));
+                v *= drop4(g.drop2, idx) * rb_f4{gelu_grad_f(uu[0]), gelu_grad_f(uu[1]), gelu_grad_f(uu[2]), gelu_grad_f(uu[3])};
+            }
+            if (g.epi == 0) *reinterpret_cast<rb_f4*>(reinterpret_cast<float*>(g.dx) + idx) = v;
+            else *reinterpret_cast<rb_u2*>(reinterpret_cast<bf16_t*>(g.dx) + idx) = pack4(v);
+        }
+        return;
+    }
+    // ---------------------------------------------------- weight gradient tile: 64 (n) x 256 (k), rank-B outer products
+    float (*sdy)[64] = reinterpret_cast<float (*)[64]>(smem);
+    float (*sx)[256] = reinterpret_cast<float (*)[256]>(smem + 32 * 64 * 4);
+    const int tiles_n = (M + 63) / 64;
+    const int t = blockIdx.x - g.n_dgrad;
+    const int n0 = (t % tiles_n) * 64, k0 = (t / tiles_n) * 256;
+    const int Bn = g.B;
+    for (int i = threadIdx.x; i < Bn * 16; i += 256) {
+        const int m = i >> 4, c = 4 * (i & 15);
+        rb_f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (n0 + c < M) {      // M % 4 == 0: a quad is inside or outside as a whole
+            v = gval4(g, c12, m, n0 + c) * drop4(g.drop, (long)m * M + n0 + c);
+            v = unpack4(pack4(v));                           // the data gradient consumes G rounded to bf16: same operand here
+        }
+        *reinterpret_cast<rb_f4*>(&sdy[m][c]) = v;
+    }
+    for (int i = threadIdx.x; i < Bn * 64; i += 256) {
+        const int m = i >> 6, c = 4 * (i & 63), k = k0 + c;
+        rb_f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k < g.Kin) {
+            if (g.xsrc == 0) v = unpack4(*reinterpret_cast<const rb_u2*>(g.x_in + (long)m * g.Kin + k));
+            else {
+                const float mean = g.stats_l[m], rstd = g.stats_l[Bn + m];
+                v = (*reinterpret_cast<const rb_f4*>(g.xl + (long)m * g.Kin + k) - mean) * rstd * *reinterpret_cast<const rb_f4*>(g.gamma_l + k) +
+                    *reinterpret_cast<const rb_f4*>(g.beta_l + k);
+                v = unpack4(pack4(v));                       // what the forward GEMM multiplied by
+            }
+        }
+        *reinterpret_cast<rb_f4*>(&sx[m][c]) = v;
+    }
+    __syncthreads();
+    if (g.db && k0 == 0 && threadIdx.x < 64 && n0 + (int)threadIdx.x < M) {
+        float sacc = 0.f;
+        for (int m = 0; m < Bn; m++) sacc += sdy[m][threadIdx.x];
+        g.db[n0 + threadIdx.x] += sacc;
+    }
+    const int tn = threadIdx.x >> 5, tk = threadIdx.x & 31;
+    float acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[i][j] = 0.f;
+    for (int m = 0; m < Bn; m++) {
+        const rb_f4 a0 = *reinterpret_cast<const rb_f4*>(&sdy[m][8 * tn]), a1 = *reinterpret_cast<const rb_f4*>(&sdy[m][8 * tn + 4]);
+        const rb_f4 b0 = *reinterpret_cast<const rb_f4*>(&sx[m][8 * tk]), b1 = *reinterpret_cast<const rb_f4*>(&sx[m][8 * tk + 4]);
+        const float a[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        const float b[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc[i][j] += a[i] * b[j];
+    }
+    if (k0 + 8 * tk >= g.Kin) return;         // Kin % 8 == 0: an 8-wide strip is inside or outside as a whole
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int n = n0 + 8 * tn + i;
+        if (n >= M) continue;
+        float* dst = g.dw + (long)n * g.Kin + k0 + 8 * tk;
+        rb_f4 o0 = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]}, o1 = {acc[i][4], acc[i][5], acc[i][6], acc[i][7]};
+        o0 += *reinterpret_cast<const rb_f4*>(dst);
+        o1 += *reinterpret_cast<const rb_f4*>(dst + 4);
+        *reinterpret_cast<rb_f4*>(dst) = o0;
+        *reinterpret_cast<rb_f4*>(dst + 4) = o1;
+    }
+}
+
+int launch_bwd(BwdArgs a, hipStream_t s) {
+    const int MT = a.B <= 16 ? 1 : 2;
+    a.n_dgrad = a.dx ? mh_cdiv(a.Kin, 16) : 0;
+    const int n_wgrad = a.dw ? mh_cdiv(a.M, 64) * mh_cdiv(a.Kin, 256) : 0;
+    const size_t lds_d = (size_t)MT * 16 * (a.M + PADK) * 2 + (size_t)4 * MT * 16 * 17 * 4, lds_w = 32 * 64 * 4 + 32 * 256 * 4;
+    const size_t lds = lds_d > lds_w ? lds_d : lds_w;
+    dim3 grid(a.n_dgrad + n_wgrad);
+    if (grid.x == 0) return 0;
+    static const bool attr = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rna_bwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rna_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+        return true;
+    }();
+    (void)attr;
+    if (lds > 158 * 1024) { mh_set_error("rna block: operand image of %zu bytes exceeds the 160 KiB of LDS", lds); return MH_EINVAL; }
+    if (MT == 1) hipLaunchKernelGGL((rna_bwd_kernel<1>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((rna_bwd_kernel<2>), grid, dim3(256), lds, s, a);
+    return 0;
+}
+
+// dx = r + LayerNorm'(dh; x, stats, gamma); dgamma += sum_m dh xhat; dbeta += sum_m dh.  One workgroup (B x D elements).
+__global__ __launch_bounds__(256) void rna_ln_bwd_res_kernel(const float* __restrict__ r, const float* __restrict__ dh, const float* __restrict__ x,
+                                                             const float* __restrict__ stats, const float* __restrict__ gamma, float* __restrict__ dx,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int D) {
+    __shared__ float c12[64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int m = wave; m < B; m += 4) {
+        const float mean = stats[m], rstd = stats[B + m];
+        float s1 = 0.f, s2 = 0.f;
+        for (int n = lane; n < D; n += 64) {
+            const float a = dh[(long)m * D + n] * gamma[n], xh = (x[(long)m * D + n] - mean) * rstd;
+            s1 += a;
+            s2 += a * xh;
+        }
+        s1 = wave_sum(s1) / (float)D;
+        s2 = wave_sum(s2) / (float)D;
+        if (lane == 0) { c12[m] = s1; c12[32 + m] = s2; }
+    }
+    __syncthreads();
+    for (int n = threadIdx.x; n < D; n += 256) {
+        float dg = 0.f, dbt = 0.f;
+        const float gm = gamma[n];
+        for (int m = 0; m < B; m++) {
+            const long idx = (long)m * D + n;
+            const float rstd = stats[B + m], xh = (x[idx] - stats[m]) * rstd, d = dh[idx];
+            dg += d * xh;
+            dbt += d;
+            dx[idx] = (r ? r[idx] : 0.f) + rstd * (d * gm - c12[m] - xh * c12[32 + m]);
+        }
+        dgamma[n] += dg;
+        dbeta[n] += dbt;
+    }
+}
+
+inline long q4(long n) { return (n + 3) / 4 * 4; }
+
+}  // namespace
+
+extern "C" int64_t mh_rna_block_workspace_bytes(int B, int D, int Hh) {
+    // dg bf16 [B, Hh] | dh2 f32 [B, D] | dx1 f32 [B, D] | do bf16 [B, D] | dqkv bf16 [B, 3D] | dh1 f32 [B, D]; each 256-byte aligned
+    auto al = [](long n) { return (n + 255) / 256 * 256; };
+    return al(2L * B * Hh) + 3 * al(4L * B * D) + al(2L * B * D) + al(6L * B * D);
+}
+
+static int rna_check(const mh_rna_block* b, const char* who) {
+    MH_REQUIRE(b, "%s: null descriptor", who);
+    MH_REQUIRE(b->B >= 1 && b->B <= 32, "%s: B=%d (needs 1..32 rows)", who, b->B);
+    MH_REQUIRE(b->D % 32 == 0 && b->Hh % 32 == 0 && b->D > 0 && b->Hh > 0, "%s: D=%d, Hh=%d must be multiples of 32", who, b->D, b->Hh);
+    MH_REQUIRE(b->H >= 1 && b->H <= 64 && b->D % b->H == 0 && b->D <= 4096, "%s: H=%d does not divide D=%d", who, b->H, b->D);
+    MH_REQUIRE(b->Hh <= 8192, "%s: Hh=%d too wide for the LDS operand image", who, b->Hh);
+    MH_REQUIRE(b->p_drop >= 0.f && b->p_drop < 1.f && (b->offset & 3) == 0, "%s: bad dropout arguments", who);
+    return MH_OK;
+}
+
+extern "C" int mh_rna_block_fwd(const mh_rna_block* b, mh_stream s) {
+    if (int rc = rna_check(b, "mh_rna_block_fwd")) return rc;
+    hipStream_t st = (hipStream_t)s;
+    const int B = b->B, D = b->D, Hh = b->Hh;
+    const unsigned long long base = b->offset;      // a device-side per-step base (dev_base) is added by the kernels themselves
+    const Drop none{0.f, 0ull, 0ull};
+    // dropout streams in the order of the un-fused path: proj output, fc1 activation, fc2 output
+    Drop d1{b->p_drop, b->seed, base}, d2{b->p_drop, b->seed, base + q4((long)B * D)}, d3{b->p_drop, b->seed, base + q4((long)B * D) + q4((long)B * Hh)};
+    FwdArgs a{};
+    a.B = B;
+    a.dev_base = (const unsigned long long*)b->dev_base;
+    // [LN1 -> qkv]
+    a.a = b->x; a.a_f32 = 1; a.ln = 1; a.gamma = b->g1; a.beta = b->be1; a.eps = b->eps; a.stats = b->stats;
+    a.w = (const bf16_t*)b->w_qkv; a.bias = b->b_qkv; a.out = b->qkv; a.out_f32 = 0; a.preact = nullptr; a.res = nullptr; a.act = MH_ACT_NONE;
+    a.drop = none; a.N = 3 * D; a.K = D;
+    if (int rc = launch_fwd(a, st)) return rc;
+    if (int rc = mh_headattn_fwd(b->qkv, b->o, b->attn, B, b->H, D / b->H, MH_BF16, s)) return rc;
+    // [proj + dropout + residual]
+    a.a = b->o; a.a_f32 = 0; a.ln = 0; a.stats = nullptr; a.w = (const bf16_t*)b->w_proj; a.bias = b->b_proj; a.out = b->x1; a.out_f32 = 1;
+    a.res = b->x; a.drop = d1; a.N = D; a.K = D;
+    if (int rc = launch_fwd(a, st)) return rc;
+    // [LN2 -> fc1 -> GELU -> dropout]
+    a.a = b->x1; a.a_f32 = 1; a.ln = 1; a.gamma = b->g2; a.beta = b->be2; a.stats = b->stats + 2 * B;
+    a.w = (const bf16_t*)b->w_fc1; a.bias = b->b_fc1; a.out = b->f; a.out_f32 = 0; a.preact = (bf16_t*)b->u; a.res = nullptr; a.act = MH_ACT_GELU;
+    a.drop = d2; a.N = Hh; a.K = D;
+    if (int rc = launch_fwd(a, st)) return rc;
+    // [fc2 + dropout + residual]
+    a.a = b->f; a.a_f32 = 0; a.ln = 0; a.stats = nullptr; a.w = (const bf16_t*)b->w_fc2; a.bias = b->b_fc2; a.out = b->y; a.out_f32 = 1;
+    a.preact = nullptr; a.res = b->x1; a.act = MH_ACT_NONE; a.drop = d3; a.N = D; a.K = Hh;
+    if (int rc = launch_fwd(a, st)) return rc;
+    MH_LAUNCH_CHECK("mh_rna_block_fwd");
+    return MH_OK;
+}
+
+extern "C" int mh_rna_block_bwd(const mh_rna_block* b, mh_stream s) {
+    if (int rc = rna_check(b, "mh_rna_block_bwd")) return rc;
+    MH_REQUIRE(b->scratch && b->dy && b->dx, "mh_rna_block_bwd: dy, dx and scratch are required");
+    hipStream_t st = (hipStream_t)s;
+    const int B = b->B, D = b->D, Hh = b->Hh;
+    auto al = [](long n) { return (n + 255) / 256 * 256; };
+    char* ws = (char*)b->scratch;
+    bf16_t* dg = (bf16_t*)ws; ws += al(2L * B * Hh);
+    float* dh2 = (float*)ws; ws += al(4L * B * D);
+    float* dx1 = (float*)ws; ws += al(4L * B * D);
+    bf16_t* dO = (bf16_t*)ws; ws += al(2L * B * D);
+    bf16_t* dqkv = (bf16_t*)ws; ws += al(6L * B * D);
+    float* dh1 = (float*)ws;
+    const Drop none{0.f, 0ull, 0ull};
+    Drop d1{b->p_drop, b->seed, b->offset}, d2{b->p_drop, b->seed, b->offset + q4((long)B * D)},
+        d3{b->p_drop, b->seed, b->offset + q4((long)B * D) + q4((long)B * Hh)};
+    BwdArgs a{};
+    a.dev_base = (const unsigned long long*)b->dev_base;
+    a.B = B;
+    // fc2: G = dy * mask3 [B, D];  dg = (G . W2) * mask2 * GELU'(u);  dW2 += G^T f
+    a.src = 1; a.r = b->dy; a.drop = d3; a.M = D; a.wt = (const bf16_t*)b->wt_fc2; a.Kin = Hh; a.epi = 1; a.dx = dg; a.u = (const bf16_t*)b->u; a.drop2 = d2;
+    a.xsrc = 0; a.x_in = (const bf16_t*)b->f; a.dw = b->dw_fc2; a.db = b->db_fc2;
+    if (int rc = launch_bwd(a, st)) return rc;
+    // fc1: G = dg [B, Hh];  dh2 = G . W1 (f32);  dW1 += G^T LN2(x1)
+    a = BwdArgs{};
+    a.dev_base = (const unsigned long long*)b->dev_base;
+    a.B = B; a.src = 0; a.g_in = dg; a.drop = none; a.M = Hh; a.wt = (const bf16_t*)b->wt_fc1; a.Kin = D; a.epi = 0; a.dx = dh2; a.drop2 = none;
+    a.xsrc = 1; a.xl = b->x1; a.stats_l = b->stats + 2 * B; a.gamma_l = b->g2; a.beta_l = b->be2; a.dw = b->dw_fc1; a.db = b->db_fc1;
+    if (int rc = launch_bwd(a, st)) return rc;
+    // proj: dx1 = dy + LN2'(dh2);  G = dx1 * mask1;  do = G . Wproj (bf16);  dWproj += G^T o
+    a = BwdArgs{};
+    a.dev_base = (const unsigned long long*)b->dev_base;
+    a.B = B; a.src = 2; a.r = b->dy; a.dh = dh2; a.xs = b->x1; a.stats = b->stats + 2 * B; a.gamma = b->g2; a.r_out = dx1; a.dgamma = b->dg2; a.dbeta = b->dbe2;
+    a.drop = d1; a.M = D; a.wt = (const bf16_t*)b->wt_proj; a.Kin = D; a.epi = 2; a.dx = dO; a.drop2 = none;
+    a.xsrc = 0; a.x_in = (const bf16_t*)b->o; a.dw = b->dw_proj; a.db = b->db_proj;
+    if (int rc = launch_bwd(a, st)) return rc;
+    if (int rc = mh_headattn_bwd(b->qkv, b->attn, dO, dqkv, B, b->H, D / b->H, MH_BF16, s)) return rc;
+    // qkv: G = dqkv [B, 3D];  dh1 = G . Wqkv (f32);  dWqkv += G^T LN1(x)
+    a = BwdArgs{};
+    a.dev_base = (const unsigned long long*)b->dev_base;
+    a.B = B; a.src = 0; a.g_in = dqkv; a.drop = none; a.M = 3 * D; a.wt = (const bf16_t*)b->wt_qkv; a.Kin = D; a.epi = 0; a.dx = dh1; a.drop2 = none;
+    a.xsrc = 1; a.xl = b->x; a.stats_l = b->stats; a.gamma_l = b->g1; a.beta_l = b->be1; a.dw = b->dw_qkv; a.db = b->db_qkv;
+    if (int rc = launch_bwd(a, st)) return rc;
+    // dx = dx1 + LN1'(dh1)
+    hipLaunchKernelGGL(rna_ln_bwd_res_kernel, dim3(1), dim3(256), 0, st, (const float*)dx1, (const float*)dh1, b->x, (const float*)b->stats, b->g1, b->dx, b->dg1,
+                       b->dbe1, B, D);
+    MH_LAUNCH_CHECK("mh_rna_block_bwd");
+    return MH_OK;
+}

@@ -1092,6 +1092,82 @@ class HeadAttnFn(Function):
         return K.headattn_bwd(qkv, attn, dout, ctx.H), None
 
 
+_RNA_FUSED = os.environ.get("MIRROR_RNA_FUSED", "1") != "0"      # A/B switch: 0 = the composed Block
+
+
+class RnaBlockFn(Function):
+    """Block.forward (models/mirror.py:149-152) on [B, D] rows as ONE C-ABI call per direction (mh_rna_block_fwd / _bwd):
+    LayerNorm, bias, GELU, the three dropouts and both residual adds ride in the GEMM kernels' prologues / epilogues."""
+
+    NAMES = ("g1", "be1", "w_qkv", "b_qkv", "w_proj", "b_proj", "g2", "be2", "w_fc1", "b_fc1", "w_fc2", "b_fc2")
+
+    @staticmethod
+    def forward(ctx, x, g1, be1, wqkv, bqkv, wproj, bproj, g2, be2, w1, b1, w2, b2, H, eps, p, prec):
+        masters = dict(zip(RnaBlockFn.NAMES, (g1, be1, wqkv, bqkv, wproj, bproj, g2, be2, w1, b1, w2, b2)))
+        params = {}
+        for k, v in masters.items():
+            if v is None:
+                params[k] = None
+            elif k.startswith("w_"):
+                params[k] = shadow(v, prec).contiguous()
+            else:
+                params[k] = v.detach().reshape(-1)
+        B, D = x.shape
+        Hh = w1.shape[0]
+        st = _dropout_state
+        ctx.drop = (float(p), st["seed"], st["offset"], st["base"]) if p > 0.0 else (0.0, 0, 0, None)
+        if p > 0.0:
+            q4 = lambda n: (n + 3) // 4 * 4  # noqa: E731
+            st["offset"] += 2 * q4(B * D) + q4(B * Hh)
+        y, saved = K.rna_block_fwd(x, params, H, eps, *ctx.drop)
+        ctx.masters, ctx.saved, ctx.cfg = masters, saved, (H, eps, prec)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        H, eps, prec = ctx.cfg
+        masters = ctx.masters
+        params, params_t, grads, rets = {}, {}, {}, {}
+        for k, v in masters.items():
+            if v is None:
+                params[k] = None
+                continue
+            if k.startswith("w_"):
+                params[k] = shadow(v, prec).contiguous()
+                params_t["wt_" + k[2:]] = shadow_t(v, prec)
+                gk = "dw_" + k[2:]
+            else:
+                params[k] = v.detach().reshape(-1)
+                gk = {"g1": "dg1", "be1": "dbe1", "g2": "dg2", "be2": "dbe2"}.get(k, "d" + k)
+            buf, sunk = _gbuf(v, tuple(v.shape))
+            grads[gk] = buf
+            rets[k] = (v, buf, sunk)
+        dx = K.rna_block_bwd(x, dy.contiguous().float(), params, params_t, grads, ctx.saved, H, eps, *ctx.drop)
+        out = [dx]
+        for k in RnaBlockFn.NAMES:
+            if k in rets:
+                v, buf, sunk = rets[k]
+                out.append(_gret(v, buf, sunk))
+            else:
+                out.append(None)
+        return tuple(out) + (None, None, None, None)
+
+
+def rna_block(x, blk, prec: Precision, training: bool):
+    """x [B, D] f32 through `blk` (a models.mirror.Block): fused when the geometry fits, None otherwise (the caller then
+    runs the composed ops)."""
+    a, m = blk.attn, blk.mlp
+    p = float(a.proj_drop) if training else 0.0
+    if not (_RNA_FUSED and prec.act == bf16 and x.dtype == f32 and K.rna_block_ok(x, x.shape[-1], m.fc1.weight.shape[0], a.num_heads)
+            and float(m.drop) == float(a.proj_drop) and blk.norm1.eps == blk.norm2.eps):
+        return None
+    return RnaBlockFn.apply(x.contiguous(), blk.norm1.weight, blk.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
+                            blk.norm2.weight, blk.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias,
+                            a.num_heads, float(blk.norm1.eps), p, prec)
+
+
 class ReparamFn(Function):
     @staticmethod
     def forward(ctx, mu, logstd, eps):

@@ -750,6 +750,62 @@ def headattn_bwd(qkv, attn, dout, H: int) -> torch.Tensor:
     return dqkv
 
 
+# ----------------------------------------------------------------------------- fused RNA Block (csrc/rna_block.hip)
+def rna_block_ok(x: torch.Tensor, D: int, Hh: int, H: int) -> bool:
+    """The fused Block covers [B <= 32, D] f32 rows with D, Hh multiples of 32 and H | D (c2: D = 512, Hh = 2048, H = 8)."""
+    return (x.dim() == 2 and x.dtype == torch.float32 and x.is_contiguous() and 1 <= x.shape[0] <= 32 and x.shape[1] == D
+            and D % 32 == 0 and Hh % 32 == 0 and D % H == 0 and D <= 4096 and Hh <= 4096 and H <= 64)
+
+
+def rna_block_workspace_bytes(B: int, D: int, Hh: int) -> int:
+    return int(_lib.load().mh_rna_block_workspace_bytes(B, D, Hh))
+
+
+def _rna_desc(B, D, Hh, H, eps, p, seed, offset, dev_base, **ptrs) -> "_lib.RnaBlockDesc":
+    d = _lib.RnaBlockDesc()
+    d.B, d.D, d.Hh, d.H, d.eps, d.p_drop, d.seed, d.offset = B, D, Hh, H, eps, p, seed, offset
+    d.dev_base = _p(dev_base)
+    for k, v in ptrs.items():
+        _chk(v)
+        setattr(d, k, _p(v))
+    return d
+
+
+def rna_block_fwd(x, params: dict, H: int, eps: float, p: float, seed: int, offset: int, dev_base):
+    """params: bf16 weights w_qkv [3D, D], w_proj [D, D], w_fc1 [Hh, D], w_fc2 [D, Hh]; f32 b_qkv (or None), b_proj, b_fc1,
+    b_fc2, g1, be1, g2, be2.  Returns (y, saved) with saved = the tensors mh_rna_block_bwd reads."""
+    import ctypes
+    B, D = x.shape
+    Hh = params["w_fc1"].shape[0]
+    dev, bf, f = x.device, torch.bfloat16, torch.float32
+    for k in ("w_qkv", "w_proj", "w_fc1", "w_fc2"):
+        if params[k].dtype != bf or not params[k].is_contiguous():
+            raise MirrorHipError(f"rna_block_fwd: {k} must be a contiguous bf16 matrix")
+    saved = {"stats": torch.empty((4, B), device=dev, dtype=f), "qkv": torch.empty((B, 3 * D), device=dev, dtype=bf),
+             "attn": torch.empty((B, H, H), device=dev, dtype=f), "o": torch.empty((B, D), device=dev, dtype=bf),
+             "x1": torch.empty((B, D), device=dev, dtype=f), "u": torch.empty((B, Hh), device=dev, dtype=bf),
+             "f": torch.empty((B, Hh), device=dev, dtype=bf)}
+    y = torch.empty((B, D), device=dev, dtype=f)
+    d = _rna_desc(B, D, Hh, H, eps, p, seed, offset, dev_base, x=x, y=y, **params, **saved)
+    _lib.call("mh_rna_block_fwd", ctypes.byref(d), stream=_stream())
+    return y, saved
+
+
+def rna_block_bwd(x, dy, params: dict, params_t: dict, grads: dict, saved: dict, H: int, eps: float, p: float, seed: int, offset: int,
+                  dev_base) -> torch.Tensor:
+    """params_t: wt_qkv ... (bf16 transposes); grads: f32 accumulation buffers dw_* / db_* / dg1 / dbe1 / dg2 / dbe2."""
+    import ctypes
+    B, D = x.shape
+    Hh = params["w_fc1"].shape[0]
+    if dy.dtype != torch.float32 or not dy.is_contiguous() or dy.shape != x.shape:
+        raise MirrorHipError("rna_block_bwd: dy must be a contiguous f32 [B, D] tensor")
+    dx = torch.empty_like(x)
+    scratch = torch.empty((rna_block_workspace_bytes(B, D, Hh),), device=x.device, dtype=torch.uint8)
+    d = _rna_desc(B, D, Hh, H, eps, p, seed, offset, dev_base, x=x, dy=dy, dx=dx, scratch=scratch, **params, **params_t, **grads, **saved)
+    _lib.call("mh_rna_block_bwd", ctypes.byref(d), stream=_stream())
+    return dx
+
+
 # ----------------------------------------------------------------------------- elementwise
 def add(a: torch.Tensor, b: torch.Tensor, out_dtype=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _chk(a, b, out)

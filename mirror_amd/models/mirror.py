@@ -109,6 +109,9 @@ class Block(nn.Module):
         self.mlp = _Mlp(dim, int(dim * mlp_ratio), dim, None, proj_drop)
 
     def forward(self, x, prec: Precision):
+        y = Fn.rna_block(x, self, prec, self.training)          # one fused call per direction (csrc/rna_block.hip) when it fits
+        if y is not None:
+            return y
         h = Fn.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, out_dtype=prec.act)
         x = self.attn(h, prec, residual=x)                          # x + drop(proj(...)); x feeds exactly norm1 and this add
         h = Fn.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, out_dtype=prec.act)
