@@ -60,23 +60,42 @@ __device__ __forceinline__ rb_f4 unpack4(rb_u2 u) {
 // ------------------------------------------------------------------------------------------------------ GEMM core
 // acc[t] (16 x 16 per 16-row tile t) = sA[16 t .., :] . W[n0 .., :]^T over K, K split over the 4 waves, reduced into
 // red[4][MT][16][17].  sA: bf16 [MT * 16][K + PADK] in LDS.
+// The first eight weight fragments of a wave (k-steps wave, wave + 4, ...): issued at the very top of a kernel, before its
+// prologue, so that the weight stream's first HBM round trip overlaps the prologue's instead of following it.
+struct WPre {
+    rb_bf16x8 b[8];
+};
+__device__ __forceinline__ void wfrag_batch(WPre& p, const bf16_t* wp, int steps, int s) {
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int su = s + 4 * u;
+        p.b[u] = *reinterpret_cast<const rb_bf16x8*>(wp + 32 * min(su, steps - 1));
+        if (su >= steps) p.b[u] = __builtin_bit_cast(rb_bf16x8, rb_u4{0u, 0u, 0u, 0u});      // k-steps past the end multiply by zero
+    }
+}
+__device__ __forceinline__ const bf16_t* wfrag_ptr(const bf16_t* __restrict__ w, long ldw, int n0, int N) {
+    const int lane = threadIdx.x & 63;
+    return w + (long)min(n0 + (lane & 15), N - 1) * ldw + 8 * (lane >> 4);      // ragged last column group: re-read row N-1, never stored
+}
 template <int MT>
-__device__ __forceinline__ void skinny_core(const bf16_t* sA, int K, const bf16_t* __restrict__ w, long ldw, int n0, int N, float* red) {
+__device__ __forceinline__ void skinny_core(const bf16_t* sA, int K, const bf16_t* wp, WPre& pre, float* red) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, kq = lane >> 4;
     const int pitch = K + PADK;
-    const bf16_t* wp = w + (long)min(n0 + col, N - 1) * ldw + 8 * kq;      // ragged last column group: re-read row N-1, never stored
     rb_f4 acc[MT];
 #pragma unroll
     for (int t = 0; t < MT; t++) acc[t] = rb_f4{0.f, 0.f, 0.f, 0.f};
     const int steps = K / 32;
-#pragma unroll 4
-    for (int s = wave; s < steps; s += 4) {
-        const rb_bf16x8 b = *reinterpret_cast<const rb_bf16x8*>(wp + 32 * s);
+    for (int s = wave; s < steps; s += 32) {
+        if (s != wave) wfrag_batch(pre, wp, steps, s);
 #pragma unroll
-        for (int t = 0; t < MT; t++) {
-            const rb_bf16x8 a = *reinterpret_cast<const rb_bf16x8*>(sA + (16 * t + col) * pitch + 32 * s + 8 * kq);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[t], 0, 0, 0);
+        for (int u = 0; u < 8; u++) {
+            const int su = min(s + 4 * u, steps - 1);
+#pragma unroll
+            for (int t = 0; t < MT; t++) {
+                const rb_bf16x8 a = *reinterpret_cast<const rb_bf16x8*>(sA + (16 * t + col) * pitch + 32 * su + 8 * kq);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pre.b[u], acc[t], 0, 0, 0);
+            }
         }
     }
 #pragma unroll
@@ -121,41 +140,80 @@ __global__ __launch_bounds__(256) void rna_fwd_kernel(FwdArgs g) {
     const int K = g.K, pitch = K + PADK;
     float* red = reinterpret_cast<float*>(smem + (size_t)MT * 16 * pitch * 2);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // ---- operand image: (LayerNorm of) the B input rows as bf16; rows past B are zero
-    for (int m = wave; m < MT * 16; m += 4) {
-        bf16_t* row = sA + m * pitch;
-        if (m >= g.B) {
-            for (int k = 4 * lane; k < K; k += 256) *reinterpret_cast<rb_u2*>(row + k) = rb_u2{0u, 0u};
-            continue;
-        }
-        if (!g.a_f32) {
-            const bf16_t* src = reinterpret_cast<const bf16_t*>(g.a) + (long)m * K;
-            for (int k = 4 * lane; k < K; k += 256) *reinterpret_cast<rb_u2*>(row + k) = *reinterpret_cast<const rb_u2*>(src + k);
-            continue;
-        }
-        const float* src = reinterpret_cast<const float*>(g.a) + (long)m * K;
-        float mean = 0.f, rstd = 1.f;
-        if (g.ln) {
-            float s = 0.f;
-            for (int k = 4 * lane; k < K; k += 256) { const rb_f4 v = *reinterpret_cast<const rb_f4*>(src + k); s += v[0] + v[1] + v[2] + v[3]; }
-            mean = wave_sum(s) / (float)K;
-            float q = 0.f;
-            for (int k = 4 * lane; k < K; k += 256) {
-                const rb_f4 v = *reinterpret_cast<const rb_f4*>(src + k) - mean;
-                q += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    const int n0 = blockIdx.x * 16;
+    const bf16_t* wp = wfrag_ptr(g.w, K, n0, g.N);
+    WPre pre;
+    wfrag_batch(pre, wp, K / 32, wave);
+    // ---- operand image: (LayerNorm of) the B input rows as bf16; rows past B are zero.  A wave owns rows wave, wave + 4, ...;
+    //      all loads of four rows (8 quads per lane and row: a 2048-column chunk) are issued before anything waits on them —
+    //      a row-by-row loop is a chain of dependent L2 round trips (~1 us each) in front of a ~2 us GEMM
+    const int nchunk = (K + 2047) / 2048;       // LayerNorm rows fit one chunk (host check: K <= 2048 when ln)
+    for (int i0 = 0; i0 < MT * 4; i0 += 4) {
+        for (int c = 0; c < nchunk; c++) {
+            if (g.a_f32) {
+                rb_f4 v[4][8], gm[8], bt[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int k = min(2048 * c + 4 * (lane + 64 * j), K - 4);
+                    if (g.ln) { gm[j] = *reinterpret_cast<const rb_f4*>(g.gamma + k); bt[j] = *reinterpret_cast<const rb_f4*>(g.beta + k); }
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        v[i][j] = *reinterpret_cast<const rb_f4*>(reinterpret_cast<const float*>(g.a) + (long)min(wave + 4 * (i0 + i), g.B - 1) * K + k);
+                }
+                float mean[4] = {0.f, 0.f, 0.f, 0.f}, rstd[4] = {1.f, 1.f, 1.f, 1.f};
+                if (g.ln) {          // two passes over the registers: mean, then sum (x - mean)^2 (what mh_layernorm_fwd computes)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        float s1 = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 8; j++)
+                            if (4 * (lane + 64 * j) < K) s1 += v[i][j][0] + v[i][j][1] + v[i][j][2] + v[i][j][3];
+                        mean[i] = wave_sum(s1) / (float)K;
+                        float s2 = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 8; j++)
+                            if (4 * (lane + 64 * j) < K) {
+                                const rb_f4 d = v[i][j] - mean[i];
+                                s2 += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+                            }
+                        rstd[i] = rsqrtf(wave_sum(s2) / (float)K + g.eps);
+                        const int m = wave + 4 * (i0 + i);
+                        if (blockIdx.x == 0 && lane == 0 && g.stats && m < g.B) { g.stats[m] = mean[i]; g.stats[g.B + m] = rstd[i]; }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const int m = wave + 4 * (i0 + i), k = 2048 * c + 4 * (lane + 64 * j);
+                        if (k >= K) continue;
+                        rb_f4 o = v[i][j];
+                        if (g.ln) o = (o - mean[i]) * rstd[i] * gm[j] + bt[j];
+                        if (m >= g.B) o = rb_f4{0.f, 0.f, 0.f, 0.f};
+                        *reinterpret_cast<rb_u2*>(sA + m * pitch + k) = pack4(o);
+                    }
+            } else {
+                rb_u2 v[4][8];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const int m = min(wave + 4 * (i0 + i), g.B - 1), k = min(2048 * c + 4 * (lane + 64 * j), K - 4);
+                        v[i][j] = *reinterpret_cast<const rb_u2*>(reinterpret_cast<const bf16_t*>(g.a) + (long)m * K + k);
+                    }
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const int m = wave + 4 * (i0 + i), k = 2048 * c + 4 * (lane + 64 * j);
+                        if (k >= K) continue;
+                        *reinterpret_cast<rb_u2*>(sA + m * pitch + k) = m < g.B ? v[i][j] : rb_u2{0u, 0u};
+                    }
             }
-            rstd = rsqrtf(wave_sum(q) / (float)K + g.eps);
-            if (blockIdx.x == 0 && lane == 0 && g.stats) { g.stats[m] = mean; g.stats[g.B + m] = rstd; }
-        }
-        for (int k = 4 * lane; k < K; k += 256) {
-            rb_f4 v = *reinterpret_cast<const rb_f4*>(src + k);
-            if (g.ln) v = (v - mean) * rstd * *reinterpret_cast<const rb_f4*>(g.gamma + k) + *reinterpret_cast<const rb_f4*>(g.beta + k);
-            *reinterpret_cast<rb_u2*>(row + k) = pack4(v);
         }
     }
     __syncthreads();
-    const int n0 = blockIdx.x * 16;
-    skinny_core<MT>(sA, K, g.w, K, n0, g.N, red);
+    skinny_core<MT>(sA, K, wp, pre, red);
     __syncthreads();
     // ---- epilogue: one quad of columns per thread
     for (int i = threadIdx.x; i < MT * 64; i += 256) {
@@ -219,7 +277,7 @@ struct BwdArgs {
     const float *xl, *stats_l, *gamma_l, *beta_l;
     float *dw, *db;
     const unsigned long long* dev_base;
-    int n_dgrad;
+    int n_dgrad, n_wgrad;     // + one more workgroup when src == 2: the LayerNorm's gamma / beta gradients
 };
 
 // four consecutive elements (n % 4 == 0) of row m of G; c12: LDS [2][32] row constants of the LayerNorm backward (src 2)
@@ -247,57 +305,102 @@ __global__ __launch_bounds__(256) void rna_bwd_kernel(BwdArgs g) {
         g.drop.offset += base;
         g.drop2.offset += base;
     }
-    if (g.src == 2) {        // row constants of LayerNorm': c1 = mean(dh gamma), c2 = mean(dh gamma xhat)
-        for (int m = wave; m < g.B; m += 4) {
-            const float mean = g.stats[m], rstd = g.stats[g.B + m];
-            float s1 = 0.f, s2 = 0.f;
-            for (int n = 4 * lane; n < M; n += 256) {
-                const long idx = (long)m * M + n;
-                const rb_f4 xh = (*reinterpret_cast<const rb_f4*>(g.xs + idx) - mean) * rstd;
-                const rb_f4 a = *reinterpret_cast<const rb_f4*>(g.dh + idx) * *reinterpret_cast<const rb_f4*>(g.gamma + n);
-                s1 += a[0] + a[1] + a[2] + a[3];
-                s2 += a[0] * xh[0] + a[1] * xh[1] + a[2] * xh[2] + a[3] * xh[3];
+    const int role = (int)blockIdx.x < g.n_dgrad ? 0 : ((int)blockIdx.x < g.n_dgrad + g.n_wgrad ? 1 : 2);
+    if (role == 2) {         // src 2 only: dgamma[n] += sum_m dh xhat, dbeta[n] += sum_m dh — columns over threads, 16 rows in flight
+        for (int n = threadIdx.x; n < M; n += 256) {
+            float dg = 0.f, dbt = 0.f;
+            for (int m0 = 0; m0 < g.B; m0 += 16) {
+                float xv[16], dv[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const long idx = (long)min(m0 + i, g.B - 1) * M + n;
+                    xv[i] = g.xs[idx];
+                    dv[i] = g.dh[idx];
+                }
+#pragma unroll
+                for (int i = 0; i < 16; i++)
+                    if (m0 + i < g.B) {
+                        dg += dv[i] * (xv[i] - g.stats[m0 + i]) * g.stats[g.B + m0 + i];
+                        dbt += dv[i];
+                    }
             }
-            s1 = wave_sum(s1) / (float)M;
-            s2 = wave_sum(s2) / (float)M;
-            if (lane == 0) { c12[m] = s1; c12[32 + m] = s2; }
+            g.dgamma[n] += dg;
+            g.dbeta[n] += dbt;
+        }
+        return;
+    }
+    const int k0 = blockIdx.x * 16;
+    const bf16_t* wp = nullptr;
+    WPre pre;
+    if (role == 0) {         // the weight stream's first round trip overlaps the prologue's
+        wp = wfrag_ptr(g.wt, M, k0, g.Kin);
+        wfrag_batch(pre, wp, M / 32, wave);
+    }
+    if (g.src == 2) {        // row constants of LayerNorm': c1 = mean(dh gamma), c2 = mean(dh gamma xhat); M <= 2048 (host check)
+        for (int i0 = 0; i0 < MT * 4; i0 += 4) {
+            rb_f4 xv[4][8], dv[4][8], gm[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int n = min(4 * (lane + 64 * j), M - 4);
+                gm[j] = *reinterpret_cast<const rb_f4*>(g.gamma + n);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const long idx = (long)min(wave + 4 * (i0 + i), g.B - 1) * M + n;
+                    xv[i][j] = *reinterpret_cast<const rb_f4*>(g.xs + idx);
+                    dv[i][j] = *reinterpret_cast<const rb_f4*>(g.dh + idx);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int m = min(wave + 4 * (i0 + i), g.B - 1);
+                const float mean = g.stats[m], rstd = g.stats[g.B + m];
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    if (4 * (lane + 64 * j) < M) {
+                        const rb_f4 xh = (xv[i][j] - mean) * rstd, a = dv[i][j] * gm[j];
+                        s1 += a[0] + a[1] + a[2] + a[3];
+                        s2 += a[0] * xh[0] + a[1] * xh[1] + a[2] * xh[2] + a[3] * xh[3];
+                    }
+                s1 = wave_sum(s1) / (float)M;
+                s2 = wave_sum(s2) / (float)M;
+                if (lane == 0 && wave + 4 * (i0 + i) < g.B) { c12[m] = s1; c12[32 + m] = s2; }
+            }
         }
         __syncthreads();
-        if (blockIdx.x == 0) {       // joined gradient out, LayerNorm parameter gradients (columns over threads)
-            for (int n = threadIdx.x; n < M; n += 256) {
-                float dg = 0.f, dbt = 0.f;
-                for (int m = 0; m < g.B; m++) {
-                    const long idx = (long)m * M + n;
-                    const float xh = (g.xs[idx] - g.stats[m]) * g.stats[g.B + m], d = g.dh[idx];
-                    dg += d * xh;
-                    dbt += d;
-                }
-                g.dgamma[n] += dg;
-                g.dbeta[n] += dbt;
-            }
-            if (g.r_out)
-                for (int i = threadIdx.x; i < g.B * (M / 4); i += 256) {
-                    const int m = i / (M / 4), n = 4 * (i % (M / 4));
-                    *reinterpret_cast<rb_f4*>(g.r_out + (long)m * M + n) = gval4(g, c12, m, n);
-                }
-        }
     }
-    if ((int)blockIdx.x < g.n_dgrad) {
+    if (role == 0) {
         // ------------------------------------------------ data gradient: G (bf16 image) . W^T rows
         bf16_t* sG = reinterpret_cast<bf16_t*>(smem);
         const int pitch = M + PADK;
         float* red = reinterpret_cast<float*>(smem + (size_t)MT * 16 * pitch * 2);
-        for (int m = wave; m < MT * 16; m += 4) {
-            bf16_t* row = sG + m * pitch;
-            for (int n = 4 * lane; n < M; n += 256) {
-                rb_f4 v = {0.f, 0.f, 0.f, 0.f};
-                if (m < g.B) v = gval4(g, c12, m, n) * drop4(g.drop, (long)m * M + n);
-                *reinterpret_cast<rb_u2*>(row + n) = pack4(v);
+        // four rows x 8 quads per lane in flight (a 2048-column chunk), as in the forward prologue
+        const int nchunk = (M + 2047) / 2048;
+        for (int i0 = 0; i0 < MT * 4; i0 += 4)
+            for (int c = 0; c < nchunk; c++) {
+                rb_f4 v[4][8];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const int m = min(wave + 4 * (i0 + i), g.B - 1), n = min(2048 * c + 4 * (lane + 64 * j), M - 4);
+                        v[i][j] = gval4(g, c12, m, n);
+                    }
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const int m = wave + 4 * (i0 + i), n = 2048 * c + 4 * (lane + 64 * j);
+                        if (n >= M) continue;
+                        rb_f4 o = {0.f, 0.f, 0.f, 0.f};
+                        if (m < g.B) o = v[i][j] * drop4(g.drop, (long)m * M + n);
+                        *reinterpret_cast<rb_u2*>(sG + m * pitch + n) = pack4(o);
+                        // src 2: the joined f32 gradient r + LayerNorm'(dh) leaves through the workgroups that own its columns
+                        if (g.src == 2 && g.r_out && m < g.B && (n >> 4) == (int)blockIdx.x) *reinterpret_cast<rb_f4*>(g.r_out + (long)m * M + n) = v[i][j];
+                    }
             }
-        }
         __syncthreads();
-        const int k0 = blockIdx.x * 16;
-        skinny_core<MT>(sG, M, g.wt, M, k0, g.Kin, red);
+        skinny_core<MT>(sG, M, wp, pre, red);
         __syncthreads();
         for (int i = threadIdx.x; i < MT * 64; i += 256) {
             const int t = i >> 6, rr = (i >> 2) & 15, c4 = 4 * (i & 3);
@@ -319,33 +422,48 @@ __global__ __launch_bounds__(256) void rna_bwd_kernel(BwdArgs g) {
     float (*sx)[256] = reinterpret_cast<float (*)[256]>(smem + 32 * 64 * 4);
     const int tiles_n = (M + 63) / 64;
     const int t = blockIdx.x - g.n_dgrad;
-    const int n0 = (t % tiles_n) * 64, k0 = (t / tiles_n) * 256;
+    const int n0 = (t % tiles_n) * 64, kt0 = (t / tiles_n) * 256;
     const int Bn = g.B;
-    for (int i = threadIdx.x; i < Bn * 16; i += 256) {
-        const int m = i >> 4, c = 4 * (i & 15);
-        rb_f4 v = {0.f, 0.f, 0.f, 0.f};
-        if (n0 + c < M) {      // M % 4 == 0: a quad is inside or outside as a whole
-            v = gval4(g, c12, m, n0 + c) * drop4(g.drop, (long)m * M + n0 + c);
-            v = unpack4(pack4(v));                           // the data gradient consumes G rounded to bf16: same operand here
+    {   // G tile [B][64] and X tile [B][256] as f32: all loads issued before the first use
+        rb_f4 gv[MT], xv[MT * 4];
+#pragma unroll
+        for (int u = 0; u < MT; u++) {              // MT * 16 rows x 16 quads = MT * 256 items
+            const int i = threadIdx.x + 256 * u, m = min(i >> 4, Bn - 1), c = 4 * (i & 15);
+            gv[u] = gval4(g, c12, m, min(n0 + c, M - 4));
         }
-        *reinterpret_cast<rb_f4*>(&sdy[m][c]) = v;
-    }
-    for (int i = threadIdx.x; i < Bn * 64; i += 256) {
-        const int m = i >> 6, c = 4 * (i & 63), k = k0 + c;
-        rb_f4 v = {0.f, 0.f, 0.f, 0.f};
-        if (k < g.Kin) {
-            if (g.xsrc == 0) v = unpack4(*reinterpret_cast<const rb_u2*>(g.x_in + (long)m * g.Kin + k));
-            else {
-                const float mean = g.stats_l[m], rstd = g.stats_l[Bn + m];
-                v = (*reinterpret_cast<const rb_f4*>(g.xl + (long)m * g.Kin + k) - mean) * rstd * *reinterpret_cast<const rb_f4*>(g.gamma_l + k) +
-                    *reinterpret_cast<const rb_f4*>(g.beta_l + k);
-                v = unpack4(pack4(v));                       // what the forward GEMM multiplied by
+#pragma unroll
+        for (int u = 0; u < MT * 4; u++) {
+            const int i = threadIdx.x + 256 * u, m = min(i >> 6, Bn - 1), k = min(kt0 + 4 * (i & 63), g.Kin - 4);
+            if (g.xsrc == 0) xv[u] = unpack4(*reinterpret_cast<const rb_u2*>(g.x_in + (long)m * g.Kin + k));
+            else xv[u] = *reinterpret_cast<const rb_f4*>(g.xl + (long)m * g.Kin + k);
+        }
+#pragma unroll
+        for (int u = 0; u < MT; u++) {
+            const int i = threadIdx.x + 256 * u, m = i >> 4, c = 4 * (i & 15);
+            rb_f4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < Bn && n0 + c < M) {      // M % 4 == 0: a quad is inside or outside as a whole
+                v = gv[u] * drop4(g.drop, (long)m * M + n0 + c);
+                v = unpack4(pack4(v));                       // the data gradient consumes G rounded to bf16: same operand here
             }
+            *reinterpret_cast<rb_f4*>(&sdy[m][c]) = v;
         }
-        *reinterpret_cast<rb_f4*>(&sx[m][c]) = v;
+#pragma unroll
+        for (int u = 0; u < MT * 4; u++) {
+            const int i = threadIdx.x + 256 * u, m = i >> 6, c = 4 * (i & 63), k = kt0 + c;
+            rb_f4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < Bn && k < g.Kin) {
+                v = xv[u];
+                if (g.xsrc != 0) {
+                    const float mean = g.stats_l[m], rstd = g.stats_l[Bn + m];
+                    v = (v - mean) * rstd * *reinterpret_cast<const rb_f4*>(g.gamma_l + k) + *reinterpret_cast<const rb_f4*>(g.beta_l + k);
+                    v = unpack4(pack4(v));                   // what the forward GEMM multiplied by
+                }
+            }
+            *reinterpret_cast<rb_f4*>(&sx[m][c]) = v;
+        }
     }
     __syncthreads();
-    if (g.db && k0 == 0 && threadIdx.x < 64 && n0 + (int)threadIdx.x < M) {
+    if (g.db && kt0 == 0 && threadIdx.x < 64 && n0 + (int)threadIdx.x < M) {
         float sacc = 0.f;
         for (int m = 0; m < Bn; m++) sacc += sdy[m][threadIdx.x];
         g.db[n0 + threadIdx.x] += sacc;
@@ -366,12 +484,12 @@ __global__ __launch_bounds__(256) void rna_bwd_kernel(BwdArgs g) {
 #pragma unroll
             for (int j = 0; j < 8; j++) acc[i][j] += a[i] * b[j];
     }
-    if (k0 + 8 * tk >= g.Kin) return;         // Kin % 8 == 0: an 8-wide strip is inside or outside as a whole
+    if (kt0 + 8 * tk >= g.Kin) return;         // Kin % 8 == 0: an 8-wide strip is inside or outside as a whole
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const int n = n0 + 8 * tn + i;
         if (n >= M) continue;
-        float* dst = g.dw + (long)n * g.Kin + k0 + 8 * tk;
+        float* dst = g.dw + (long)n * g.Kin + kt0 + 8 * tk;
         rb_f4 o0 = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]}, o1 = {acc[i][4], acc[i][5], acc[i][6], acc[i][7]};
         o0 += *reinterpret_cast<const rb_f4*>(dst);
         o1 += *reinterpret_cast<const rb_f4*>(dst + 4);
@@ -383,7 +501,8 @@ __global__ __launch_bounds__(256) void rna_bwd_kernel(BwdArgs g) {
 int launch_bwd(BwdArgs a, hipStream_t s) {
     const int MT = a.B <= 16 ? 1 : 2;
     a.n_dgrad = a.dx ? mh_cdiv(a.Kin, 16) : 0;
-    const int n_wgrad = a.dw ? mh_cdiv(a.M, 64) * mh_cdiv(a.Kin, 256) : 0;
+    a.n_wgrad = a.dw ? mh_cdiv(a.M, 64) * mh_cdiv(a.Kin, 256) : 0;
+    const int n_wgrad = a.n_wgrad + (a.src == 2 ? 1 : 0);
     const size_t lds_d = (size_t)MT * 16 * (a.M + PADK) * 2 + (size_t)4 * MT * 16 * 17 * 4, lds_w = 32 * 64 * 4 + 32 * 256 * 4;
     const size_t lds = lds_d > lds_w ? lds_d : lds_w;
     dim3 grid(a.n_dgrad + n_wgrad);
@@ -400,37 +519,66 @@ int launch_bwd(BwdArgs a, hipStream_t s) {
     return 0;
 }
 
-// dx = r + LayerNorm'(dh; x, stats, gamma); dgamma += sum_m dh xhat; dbeta += sum_m dh.  One workgroup (B x D elements).
+// dx = r + LayerNorm'(dh; x, stats, gamma); dgamma += sum_m dh xhat; dbeta += sum_m dh.  One workgroup per 64-column slab;
+// every workgroup recomputes the 2 B row constants from the whole [B, D] operands (all loads of four rows in flight).
 __global__ __launch_bounds__(256) void rna_ln_bwd_res_kernel(const float* __restrict__ r, const float* __restrict__ dh, const float* __restrict__ x,
                                                              const float* __restrict__ stats, const float* __restrict__ gamma, float* __restrict__ dx,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int D) {
     __shared__ float c12[64];
+    __shared__ float part[2][4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int m = wave; m < B; m += 4) {
-        const float mean = stats[m], rstd = stats[B + m];
-        float s1 = 0.f, s2 = 0.f;
-        for (int n = lane; n < D; n += 64) {
-            const float a = dh[(long)m * D + n] * gamma[n], xh = (x[(long)m * D + n] - mean) * rstd;
-            s1 += a;
-            s2 += a * xh;
+    for (int i0 = 0; i0 < 8; i0 += 4) {
+        if (wave + 4 * i0 >= B) break;
+        rb_f4 xv[4][8], dv[4][8], gm[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int n = min(4 * (lane + 64 * j), D - 4);
+            gm[j] = *reinterpret_cast<const rb_f4*>(gamma + n);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const long idx = (long)min(wave + 4 * (i0 + i), B - 1) * D + n;
+                xv[i][j] = *reinterpret_cast<const rb_f4*>(x + idx);
+                dv[i][j] = *reinterpret_cast<const rb_f4*>(dh + idx);
+            }
         }
-        s1 = wave_sum(s1) / (float)D;
-        s2 = wave_sum(s2) / (float)D;
-        if (lane == 0) { c12[m] = s1; c12[32 + m] = s2; }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int m = min(wave + 4 * (i0 + i), B - 1);
+            const float mean = stats[m], rstd = stats[B + m];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (4 * (lane + 64 * j) < D) {
+                    const rb_f4 xh = (xv[i][j] - mean) * rstd, a = dv[i][j] * gm[j];
+                    s1 += a[0] + a[1] + a[2] + a[3];
+                    s2 += a[0] * xh[0] + a[1] * xh[1] + a[2] * xh[2] + a[3] * xh[3];
+                }
+            s1 = wave_sum(s1) / (float)D;
+            s2 = wave_sum(s2) / (float)D;
+            if (lane == 0 && wave + 4 * (i0 + i) < B) { c12[m] = s1; c12[32 + m] = s2; }
+        }
     }
     __syncthreads();
-    for (int n = threadIdx.x; n < D; n += 256) {
-        float dg = 0.f, dbt = 0.f;
-        const float gm = gamma[n];
-        for (int m = 0; m < B; m++) {
+    // slab: column n = 64 blockIdx + lane, rows wave, wave + 4, ...: partial column sums per wave, folded through LDS
+    const int n = 64 * blockIdx.x + lane;
+    float dg = 0.f, dbt = 0.f;
+    if (n < D) {
+        const float gmn = gamma[n];
+#pragma unroll 8
+        for (int m = wave; m < B; m += 4) {
             const long idx = (long)m * D + n;
             const float rstd = stats[B + m], xh = (x[idx] - stats[m]) * rstd, d = dh[idx];
             dg += d * xh;
             dbt += d;
-            dx[idx] = (r ? r[idx] : 0.f) + rstd * (d * gm - c12[m] - xh * c12[32 + m]);
+            dx[idx] = (r ? r[idx] : 0.f) + rstd * (d * gmn - c12[m] - xh * c12[32 + m]);
         }
-        dgamma[n] += dg;
-        dbeta[n] += dbt;
+    }
+    part[0][wave][lane] = dg;
+    part[1][wave][lane] = dbt;
+    __syncthreads();
+    if (wave == 0 && n < D) {
+        dgamma[n] += part[0][0][lane] + part[0][1][lane] + part[0][2][lane] + part[0][3][lane];
+        dbeta[n] += part[1][0][lane] + part[1][1][lane] + part[1][2][lane] + part[1][3][lane];
     }
 }
 
@@ -449,7 +597,7 @@ static int rna_check(const mh_rna_block* b, const char* who) {
     MH_REQUIRE(b->B >= 1 && b->B <= 32, "%s: B=%d (needs 1..32 rows)", who, b->B);
     MH_REQUIRE(b->D % 32 == 0 && b->Hh % 32 == 0 && b->D > 0 && b->Hh > 0, "%s: D=%d, Hh=%d must be multiples of 32", who, b->D, b->Hh);
     MH_REQUIRE(b->H >= 1 && b->H <= 64 && b->D % b->H == 0 && b->D <= 4096, "%s: H=%d does not divide D=%d", who, b->H, b->D);
-    MH_REQUIRE(b->Hh <= 8192, "%s: Hh=%d too wide for the LDS operand image", who, b->Hh);
+    MH_REQUIRE(b->Hh <= 4096 && b->D <= 2048, "%s: D=%d, Hh=%d exceed the batched prologues (D <= 2048, Hh <= 4096)", who, b->D, b->Hh);
     MH_REQUIRE(b->p_drop >= 0.f && b->p_drop < 1.f && (b->offset & 3) == 0, "%s: bad dropout arguments", who);
     return MH_OK;
 }
@@ -532,7 +680,7 @@ extern "C" int mh_rna_block_bwd(const mh_rna_block* b, mh_stream s) {
     a.xsrc = 1; a.xl = b->x; a.stats_l = b->stats; a.gamma_l = b->g1; a.beta_l = b->be1; a.dw = b->dw_qkv; a.db = b->db_qkv;
     if (int rc = launch_bwd(a, st)) return rc;
     // dx = dx1 + LN1'(dh1)
-    hipLaunchKernelGGL(rna_ln_bwd_res_kernel, dim3(1), dim3(256), 0, st, (const float*)dx1, (const float*)dh1, b->x, (const float*)b->stats, b->g1, b->dx, b->dg1,
+    hipLaunchKernelGGL(rna_ln_bwd_res_kernel, dim3(mh_cdiv(D, 64)), dim3(256), 0, st, (const float*)dx1, (const float*)dh1, b->x, (const float*)b->stats, b->g1, b->dx, b->dg1,
                        b->dbe1, B, D);
     MH_LAUNCH_CHECK("mh_rna_block_bwd");
     return MH_OK;
