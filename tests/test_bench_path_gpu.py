@@ -403,3 +403,48 @@ def test_kernel_side_front_padding_equals_explicit_zero_rows(policy, tol):
         assert got.shape == want.shape == (2, n, 512)
         branch = float(y[:, -n:].float().abs().max())
         assert float((got - want).abs().max()) <= tol * branch, (float((got - want).abs().max()), branch)
+
+
+# ------------------------------------------------------------------------------------------------ the reference's own config
+TEMPLATE = O.Cfg(wsi_embed_dim=768, rna_embed_dim=10234, embed_dim=768, wsi_num_tokens=2048, rna_encoder_depth=2,
+                 rna_mlp_ratio=2.572, rna_num_heads=12)
+
+
+def test_template_config_matches_live_oracle():
+    """configs/pretrain/mirror.template.yaml:16-46 — the reference's real operating point: 2048 Phikon tokens x 768-d, 10234
+    genes, embed_dim 768 (dh = 96, m = 384 landmarks, n = 2117 -> n_p = 2304, l = 6), RNA depth 2 with the UNPATCHED 12
+    heads and mlp_ratio 2.572 (hidden width int(768 * 2.572) = 1975: no multiple of anything), B = 2.  fp32 policy: 15 outputs,
+    six losses, every parameter gradient norm against a live oracle run; bf16 policy: loss band."""
+    sd = synth.synth_state_dict(synth.param_shapes(TEMPLATE), 17)
+    wsi, rna, noise = synth.synth_batch(TEMPLATE, 2, 18)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    with O.exact_cpu_convs():
+        ref = O.mirror_forward(leaf, TEMPLATE, wsi, rna, noise, 0.75, 0.75)
+        ref_loss = O.mirror_loss(ref, DEFAULT_W)
+        ref_loss[0].backward()
+    nz = {k: v.to(DEV) for k, v in noise.items()}
+    m = _model(TEMPLATE, sd, "fp32")
+    assert m.rna_encoder.blocks[0].mlp.fc1.weight.shape[0] == 1975 and m.wsi_encoder.layer1.attn.num_landmarks == 384
+    outs = m(wsi.to(DEV), rna.to(DEV), wsi_mask_ratio=0.75, rna_mask_ratio=0.75, noise=nz)
+    for nm, a, b in zip(O.OUTPUT_NAMES, outs, ref):
+        scale = max(float(b.abs().max()), 1e-6)
+        err = float((a.detach().float().cpu() - b.detach().float()).abs().max()) / scale
+        assert err <= 2e-4, f"{nm}: {err:.3e}"
+    loss = MIRRORLoss()(*outs)
+    np.testing.assert_allclose([float(x.detach()) for x in loss], [float(x) for x in ref_loss], rtol=1e-4)
+    loss[0].backward()
+    gmax = max(float(v.grad.norm()) for v in leaf.values() if v.grad is not None)
+    bad = []
+    for k, p in m.named_parameters():
+        rn, gn = float(leaf[k].grad.double().norm()), float(p.grad.double().norm())
+        if abs(gn - rn) > 2e-3 * rn + 1e-6 * gmax:
+            bad.append(f"{k}: {gn:.6g} vs {rn:.6g}")
+    assert not bad, "; ".join(bad[:10])
+    del m, outs, loss
+    mb = _model(TEMPLATE, sd, "bf16")
+    ob = mb(wsi.to(DEV).to(bf16), rna.to(DEV), wsi_mask_ratio=0.75, rna_mask_ratio=0.75, noise=nz)
+    got = np.array([float(x.detach()) for x in MIRRORLoss()(*ob)])
+    want = np.array([float(x) for x in ref_loss])
+    rel = np.abs(got - want) / np.abs(want)
+    _report("r02_template_bf16_loss_band.json", {"loss_rel_err": rel.tolist()})
+    assert (rel < 3e-2).all(), rel
