@@ -66,6 +66,10 @@ typedef struct {
                                      parts * M * N floats (parts = splits * batch) the large-tile kernel writes plain
                                      partial tiles there and a fold pass adds them to C; NULL / too small: f32 atomics */
     int64_t workspace_floats;
+    void* C2;                     /* optional bf16 copy of the final C (C's ldc and batch strides), written by the same epilogue:
+                                     the next product's operand without a cast launch.  192 x 384 tile kernel only (bf16
+                                     operands, M % 192 == 0, N % 384 == 0, K % 64 == 0, no bias / activation / split-K) */
+    int32_t r_bf16;               /* 1: R is bf16 although C is f32 (same tile kernel only) */
 } mh_gemm_desc;
 int mh_gemm(const mh_gemm_desc* d, mh_stream s);
 

@@ -29,6 +29,7 @@ class GemmDesc(C.Structure):
         ("act", C.c_int32), ("accumulate", C.c_int32), ("split_k", C.c_int32),
         ("R", C.c_void_p), ("rcoef", C.c_float),
         ("workspace", C.c_void_p), ("workspace_floats", C.c_int64),
+        ("C2", C.c_void_p), ("r_bf16", C.c_int32),
     ]
 
 

@@ -2,6 +2,7 @@
 #include "gemm_kernel.h"
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+bool gemm_try_tile384(GemmArgs& a, int akc, int bkc, int dtC, int batch, void* c2, int r_bf16, hipStream_t s);   // gemm_tile.hip
 
 static int launch_one(const mh_gemm_desc* d, hipStream_t s) {
     const int split = d->split_k < 1 ? 1 : d->split_k;
@@ -27,6 +28,12 @@ static int launch_one(const mh_gemm_desc* d, hipStream_t s) {
     a.atomic = (a.split_k > 1) || (d->accumulate && batch > 1 && d->sC1 == 0 && d->sC2 == 0);
     MH_REQUIRE(!a.atomic || (d->dtC == MH_F32 && d->act == MH_ACT_NONE && d->accumulate),
                "mh_gemm: atomic accumulation (split-K / batch broadcast into C) needs f32 C, accumulate=1, no activation");
+    const bool want_tile = d->C2 || d->r_bf16;
+    if (d->mma == MH_BF16 && d->dtA == MH_BF16 && d->dtB == MH_BF16 && gemm_try_tile384(a, d->a_kc, d->b_kc, d->dtC, batch, d->C2, d->r_bf16, s)) {
+        MH_LAUNCH_CHECK("mh_gemm(tile)");
+        return MH_OK;
+    }
+    MH_REQUIRE(!want_tile, "mh_gemm: C2 / r_bf16 need the 192 x 384 tile kernel (bf16 operands, M %% 192 == 0, N %% 384 == 0, K %% 64 == 0, no bias / split-K)");
     if (d->mma == MH_F32) gemm_launch_f32(a, d->a_kc, d->b_kc, batch, s);
     else if (d->dtA == MH_BF16 && d->dtB == MH_BF16) gemm_launch_bf16(a, d->a_kc, d->b_kc, d->dtC, batch, s);
     else if (d->dtA == MH_F32 && d->dtB == MH_F32) gemm_launch_mixed_ff(a, d->a_kc, d->b_kc, d->dtC, batch, s);

@@ -408,63 +408,60 @@ __global__ __launch_bounds__(256) void pinv_absmax_kernel(const float* __restric
     unsigned long long best_r = 0, best_c = 0;
     __shared__ unsigned long long sr[256], sc[256];
     __shared__ __attribute__((aligned(16))) float colp[4 * 512];   // [4 waves][m] partial column sums
-    if ((m & 255) == 0 && m <= 512) {
-        // one pass, 16-byte loads, 8 rows in flight per wave: lane owns columns [256 q + 4 lane, +4) of the rows its wave
-        // walks; row sums close with a wave reduction, column sums stay per lane and are folded over the 4 waves in LDS
-        // (one scalar-load pass per sum took 106 us for 33 MB)
+    if ((m & 3) == 0 && m <= 512) {
+        // one pass, 16-byte loads, 8 rows in flight per wave: lane owns columns [256 c + 4 lane, +4), c = 0, 1, of the rows its
+        // wave walks; row sums close with a wave reduction, column sums stay per lane and are folded over the 4 waves in LDS
+        // (one scalar-load pass per sum took 106 us for 33 MB at m = 256 and 450 us at m = 384, the template's landmarks)
         typedef float f4 __attribute__((ext_vector_type(4)));
-        for (int q = 0; q < m; q += 256) {
-            f4 cs = {0.f, 0.f, 0.f, 0.f};
-            for (int i0 = wave; i0 < m; i0 += 32) {
-                f4 v[8];
+        f4 cs[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        const bool two = m > 256;
+        const int c0 = 4 * lane, c1 = 256 + 4 * lane;
+        for (int i0 = wave; i0 < m; i0 += 32) {
+            f4 v[8][2];
 #pragma unroll
-                for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const f4*>(xb + (long)(i0 + 4 * u) * m + q + 4 * lane);
+            for (int u = 0; u < 8; u++) {
+                const int i = min(i0 + 4 * u, m - 1);
+                v[u][0] = *reinterpret_cast<const f4*>(xb + (long)i * m + min(c0, m - 4));
+                v[u][1] = two ? *reinterpret_cast<const f4*>(xb + (long)i * m + min(c1, m - 4)) : f4{0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const f4 a = {fabsf(v[u][0]), fabsf(v[u][1]), fabsf(v[u][2]), fabsf(v[u][3])};
-                    cs += a;
-                    v[u] = a;
-                }
-                if (m == 256) {
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const float s = wave_sum(v[u][0] + v[u][1] + v[u][2] + v[u][3]);
-                        const unsigned long long p = ((unsigned long long)__float_as_uint(s) << 32) | (unsigned)(bh * m + i0 + 4 * u);
-                        best_r = p > best_r ? p : best_r;
-                    }
+            for (int u = 0; u < 8; u++) {
+                const bool row_ok = i0 + 4 * u < m;
+                f4 a = {fabsf(v[u][0][0]), fabsf(v[u][0][1]), fabsf(v[u][0][2]), fabsf(v[u][0][3])};
+                f4 b = {fabsf(v[u][1][0]), fabsf(v[u][1][1]), fabsf(v[u][1][2]), fabsf(v[u][1][3])};
+                if (!row_ok || c0 >= m) a = f4{0.f, 0.f, 0.f, 0.f};
+                if (!row_ok || c1 >= m) b = f4{0.f, 0.f, 0.f, 0.f};
+                cs[0] += a;
+                cs[1] += b;
+                const float sv = wave_sum(a[0] + a[1] + a[2] + a[3] + b[0] + b[1] + b[2] + b[3]);
+                if (row_ok) {
+                    const unsigned long long p = ((unsigned long long)__float_as_uint(sv) << 32) | (unsigned)(bh * m + i0 + 4 * u);
+                    best_r = p > best_r ? p : best_r;
                 }
             }
-            *reinterpret_cast<f4*>(colp + wave * m + q + 4 * lane) = cs;
         }
+        if (c0 < m) *reinterpret_cast<f4*>(colp + wave * 512 + c0) = cs[0];
+        if (c1 < m) *reinterpret_cast<f4*>(colp + wave * 512 + c1) = cs[1];
         __syncthreads();
         for (int j = threadIdx.x; j < m; j += 256) {
-            const float s = colp[j] + colp[m + j] + colp[2 * m + j] + colp[3 * m + j];
-            const unsigned long long p = ((unsigned long long)__float_as_uint(s) << 32) | (unsigned)(bh * m + j);
+            const float sv = colp[j] + colp[512 + j] + colp[1024 + j] + colp[1536 + j];
+            const unsigned long long p = ((unsigned long long)__float_as_uint(sv) << 32) | (unsigned)(bh * m + j);
             best_c = p > best_c ? p : best_c;
-        }
-        if (m != 256) {   // wider rows: separate row pass (not a TransMIL shape)
-            for (int i = wave; i < m; i += 4) {
-                float s = 0.f;
-                for (int j = lane; j < m; j += 64) s += fabsf(xb[(long)i * m + j]);
-                s = wave_sum(s);
-                const unsigned long long p = ((unsigned long long)__float_as_uint(s) << 32) | (unsigned)(bh * m + i);
-                best_r = p > best_r ? p : best_r;
-            }
         }
     } else {
         // row sums: one wave per row
         for (int i = wave; i < m; i += 4) {
-            float s = 0.f;
-            for (int j = lane; j < m; j += 64) s += fabsf(xb[(long)i * m + j]);
-            s = wave_sum(s);
-            const unsigned long long p = ((unsigned long long)__float_as_uint(s) << 32) | (unsigned)(bh * m + i);
+            float sv = 0.f;
+            for (int j = lane; j < m; j += 64) sv += fabsf(xb[(long)i * m + j]);
+            sv = wave_sum(sv);
+            const unsigned long long p = ((unsigned long long)__float_as_uint(sv) << 32) | (unsigned)(bh * m + i);
             best_r = p > best_r ? p : best_r;
         }
         // column sums: one thread per column (coalesced across threads)
         for (int j = threadIdx.x; j < m; j += 256) {
-            float s = 0.f;
-            for (int i = 0; i < m; i++) s += fabsf(xb[(long)i * m + j]);
-            const unsigned long long p = ((unsigned long long)__float_as_uint(s) << 32) | (unsigned)(bh * m + j);
+            float sv = 0.f;
+            for (int i = 0; i < m; i++) sv += fabsf(xb[(long)i * m + j]);
+            const unsigned long long p = ((unsigned long long)__float_as_uint(sv) << 32) | (unsigned)(bh * m + j);
             best_c = p > best_c ? p : best_c;
         }
     }

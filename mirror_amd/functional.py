@@ -769,6 +769,46 @@ def pinv_backward(a2, saved, st, dZ, pm, sd):
     return dX
 
 
+def pinv_forward_tile(a2: torch.Tensor, iters: int):
+    """pinv_forward for landmark counts the 192 x 384 tile kernel takes (the template's m = 384): every operand bf16, f32
+    accumulation inside a product, one launch per product at one workgroup per CU (csrc/gemm_tile.hip)."""
+    st = K.pinv_absmax(a2)
+    z = K.cast(K.pinv_z0(a2, st), bf16)
+    a2b = K.cast(a2, bf16)
+    saved = []
+    for _ in range(iters):
+        P = K.gemm(a2b, z, mma=MH_BF16)
+        T2 = K.gemm(P, P, diag=15.0, R=P, rcoef=-7.0, mma=MH_BF16)
+        T3 = K.gemm(P, T2, alpha=-1.0, diag=13.0, mma=MH_BF16)
+        zn = K.gemm(z, T3, alpha=0.25, mma=MH_BF16)
+        saved.append((z, P, T2, T3))
+        z = zn
+    return z, saved, st
+
+
+def pinv_backward_tile(a2, saved, st, dZ):
+    """Reverse mode of pinv_forward_tile: 8 products per iteration, operands bf16; sums of several products accumulate in
+    f32 C and the launch that completes one writes its bf16 copy (the next operand) in the same epilogue."""
+    tr = lambda t: t.transpose(-1, -2)  # noqa: E731
+    a2b = K.cast(a2, bf16)
+    dX = torch.zeros_like(a2)
+    dz = K.cast(dZ, bf16) if dZ.dtype != bf16 else dZ
+    dzn = dZ
+    for z, P, T2, T3 in reversed(saved):
+        dT3 = K.gemm(tr(z), dz, alpha=0.25, mma=MH_BF16)                               # z' = 1/4 z T3
+        dzn = K.gemm(dz, tr(T3), alpha=0.25, mma=MH_BF16, out_dtype=f32)
+        dT2 = K.gemm(tr(P), dT3, alpha=-1.0, mma=MH_BF16)                              # T3 = 13I - P T2
+        dP = K.gemm(dT3, tr(T2), alpha=-1.0, mma=MH_BF16, out_dtype=f32)
+        K.gemm(dT2, tr(P), out=dP, accumulate=True, R=dT2, rcoef=-7.0, mma=MH_BF16)    # T2 = 15I - 7P + P P
+        dPb = torch.empty(dP.shape, device=dP.device, dtype=bf16)
+        K.gemm(tr(P), dT2, out=dP, accumulate=True, mma=MH_BF16, c2=dPb)
+        K.gemm(dPb, tr(z), out=dX, accumulate=True, mma=MH_BF16)                       # P = a2 z
+        dz = torch.empty(dzn.shape, device=dzn.device, dtype=bf16)
+        K.gemm(tr(a2b), dPb, out=dzn, accumulate=True, mma=MH_BF16, c2=dz)
+    K.pinv_z0_bwd(a2, K.cast(saved[0][0], f32), dzn, st, dX)
+    return dX
+
+
 class NystromCoreFn(Function):
     """[3P] NystromAttention between to_qkv and to_out (called at models/mirror.py:312):
     qkv [B, n_p, 3D] -> out [B, n_p, D] = softmax(q k_l^T) . pinv(softmax(q_l k_l^T)) . softmax(q_l k^T) v + res_conv(v).
@@ -830,7 +870,10 @@ class NystromCoreFn(Function):
             else:
                 a1 = K.softmax_masked_fwd(a1, mrow, mlm, a1 if A == f32 else None, out_dtype=A)
                 a3 = K.softmax_masked_fwd(a3, mlm, mrow, a3 if A == f32 else None, out_dtype=A)
-        if not chain:
+        tile = (not chain) and pm == MH_BF16 and K.gemm_tile_ok(m_l, m_l, m_l)
+        if tile:
+            zf, saved, st = pinv_forward_tile(a2, iters)
+        elif not chain:
             zf, saved, st = pinv_forward(a2, iters, pm, sd)
         if not fused:
             av = K.gemm(a3, v, mma=mma, out_dtype=f32)                                   # [B,h,m,dh]
@@ -852,6 +895,7 @@ class NystromCoreFn(Function):
                               *[t for it in saved for t in it])
         ctx.cfg = (heads, l, prec)
         ctx.chain = (chain, iters, fused)
+        ctx.tile = tile
         ctx.kmask = kmask
         return out
 
@@ -932,7 +976,7 @@ class NystromCoreFn(Function):
             torch.cuda.current_stream().wait_stream(side)
             del work
         else:
-            dS2 = pinv_backward(a2, saved, st, dZ, pm, sd)
+            dS2 = pinv_backward_tile(a2, saved, st, dZ) if ctx.tile else pinv_backward(a2, saved, st, dZ, pm, sd)
             sm_bwd(a2, dS2, mlm if kmask else None, mlm if kmask else None)
         K.gemm(tr(dS2), ql, out=dkl, alpha=scale, accumulate=True, mma=pio)
         K.gemm(dS2, kl, out=dql, alpha=scale, accumulate=True, mma=pio)

@@ -73,9 +73,10 @@ def _mat(t: torch.Tensor):
 def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *, alpha: float = 1.0,
          diag: float = 0.0, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, accumulate: bool = False,
          split_k: int = 1, mma: int = MH_F32, out_dtype: Optional[torch.dtype] = None,
-         R: Optional[torch.Tensor] = None, rcoef: float = 0.0) -> torch.Tensor:
+         R: Optional[torch.Tensor] = None, rcoef: float = 0.0, c2: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[..] (+)= act(alpha * a @ b + diag*I + bias + rcoef*R) with a [..,M,K], b [..,K,N] given as (possibly
-    transposed / strided / broadcast) views; <= 2 leading batch dims."""
+    transposed / strided / broadcast) views; <= 2 leading batch dims.  c2: optional bf16 tensor shaped and strided like `out`
+    that receives a copy of the final result (192 x 384 tile kernel only, see gemm_tile_ok)."""
     _chk(a, b, out, bias)
     nd = max(a.dim(), b.dim())
     a4, a_rm, lda, sa1, sa2 = _mat(a)
@@ -123,9 +124,17 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *
     d.alpha, d.diag, d.act, d.accumulate, d.split_k = alpha, diag, act, int(accumulate), max(1, int(split_k))
     if R is not None:
         _chk(R)
-        if R.dtype != o4.dtype or R.numel() != o4.numel() or tuple(R.stride()) != tuple(out.stride()):
-            raise MirrorHipError("gemm: R must have the output's dtype, shape and strides")
+        tile = gemm_tile_ok(M, N, K, a4.dtype, b4.dtype) and bias is None and act == ACT_NONE and d.split_k == 1
+        if R.numel() != o4.numel() or tuple(R.stride()) != tuple(out.stride()) or not (
+                R.dtype == o4.dtype or (tile and R.dtype == torch.bfloat16)):
+            raise MirrorHipError("gemm: R must have the output's dtype (or bf16 on the 192 x 384 tile kernel), shape and strides")
         d.R, d.rcoef = R.data_ptr(), rcoef
+        d.r_bf16 = int(R.dtype == torch.bfloat16 and o4.dtype != torch.bfloat16)
+    if c2 is not None:
+        _chk(c2)
+        if c2.dtype != torch.bfloat16 or c2.numel() != o4.numel() or tuple(c2.stride()) != tuple(out.stride()):
+            raise MirrorHipError("gemm: c2 must be a bf16 tensor with the output's shape and strides")
+        d.C2 = c2.data_ptr()
     # reductions into one f32 C (split-K / a batch that broadcasts into C) on the large-tile kernel: give it room for plain
     # partial tiles + a fold pass (f32 atomics of a 64-way split cost more than the K loop).  `ws` stays alive until the call
     # is enqueued; the caching allocator keeps the block valid for stream-ordered use.
@@ -140,6 +149,12 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *
     else:
         prof.launch(d, lambda: _lib.call("mh_gemm", C.byref(d), stream=_stream()))
     return out
+
+
+def gemm_tile_ok(M: int, N: int, Kd: int, dta=torch.bfloat16, dtb=torch.bfloat16) -> bool:
+    """Shapes the 192 x 384 tile kernel (csrc/gemm_tile.hip) takes: the batched 384-cubed products of the template's pinv."""
+    return (M % 192 == 0 and N % 384 == 0 and Kd % 64 == 0 and dta == torch.bfloat16 and dtb == torch.bfloat16
+            and os.environ.get("MH_GEMM_TILE384", "1")[:1] != "0")
 
 
 _GEMM_WS = os.environ.get("MH_GEMM_WS", "1") != "0"      # A/B switch: split-K partials in a workspace vs f32 atomics
@@ -170,6 +185,10 @@ def gemm_variant(d: GemmDesc) -> str:
     okc = d.C % 16 == 0 and d.ldc % cvec == 0 and d.sC1 % cvec == 0 and d.sC2 % cvec == 0
     batch = d.batch1 * d.batch2
     atomic = split > 1 or (d.accumulate and batch > 1 and d.sC1 == 0 and d.sC2 == 0)
+    if (d.mma == MH_BF16 and d.dtA == MH_BF16 and d.dtB == MH_BF16 and d.M % 192 == 0 and d.N % 384 == 0 and kk == d.K and d.K % 64 == 0
+            and split == 1 and not atomic and not d.bias and d.act == 0 and oka and okb and okc and not (not d.a_kc and d.b_kc)
+            and ((d.M // 192) * (d.N // 384) * batch >= 64 or d.C2 or d.r_bf16) and os.environ.get("MH_GEMM_TILE384", "1")[:1] != "0"):
+        return f"gemm_tile_kernel<{_TN[d.dtC]},{'true' if d.a_kc else 'false'},{'true' if d.b_kc else 'false'}>"
     if (d.mma == MH_BF16 and d.dtA == MH_BF16 and d.dtB == MH_BF16 and (d.M % 256 == 0 or (d.a_kc and d.M > 256))
             and d.N % 256 == 0 and kk % 64 == 0
             and kps % 64 == 0 and oka and okb and okc and not d.R and d.diag == 0.0
@@ -194,8 +213,8 @@ class GemmProfiler:
         self.launch_named(gemm_variant(d), 2.0 * d.M * d.N * d.K * d.batch1 * d.batch2, fn)
 
     def launch_named(self, v: str, flops: float, fn) -> None:
-        if self.only is not None and v != self.only:
-            fn()
+        if (self.only is not None and v != self.only) or torch.cuda.is_current_stream_capturing():
+            fn()                 # events recorded inside a capture (the RNA branch graph) are not timing events
             return
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()          # recorded on the stream the kernel is launched on (torch's current stream)

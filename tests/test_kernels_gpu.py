@@ -104,6 +104,70 @@ def test_gemm_large_tile_kernel(a_rm, b_t, out_dtype):
         assert bool((outr[:, Mr:] == 7.0).all()), "rows past M were written"
 
 
+@pytest.mark.parametrize("a_rm,b_t", [(True, False), (False, False), (True, True)])
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+def test_gemm_tile384_kernel(a_rm, b_t, out_dtype):
+    """192 x 384 tiles (gemm_tile.hip: the batched 384-cubed products of the template's Moore-Penrose iteration): the three
+    operand layouts the iteration uses, batch, alpha / diag / R addend (bf16 R beside an f32 C), read-modify-write
+    accumulate and the bf16 copy of the final C — bit-exact on small integers."""
+    gen = g(91 + a_rm + 2 * b_t)
+    Bt, M, N, Kd = 5, 384, 768, 192
+    bf = torch.bfloat16
+    a_dev, a = _mk(a_rm, (Bt, M, Kd), gen, bf, True)
+    b_dev, b = _mk(not b_t, (Bt, Kd, N), gen, bf, True)
+    ref = a.double() @ b.double()
+    out = K.gemm(a_dev, b_dev, mma=MH_BF16, out_dtype=out_dtype)
+    close(out, ref.float().to(out_dtype).double(), 0, 0, "tile plain")
+    assert K.gemm_tile_ok(M, N, Kd)
+    Rm = ints((Bt, M, N), gen)
+    eye = torch.zeros(M, N, dtype=torch.float64)
+    eye[torch.arange(M), torch.arange(M)] = 1.0
+    out = K.gemm(a_dev, b_dev, alpha=-1.0, diag=13.0, R=Rm.to(DEV, out_dtype), rcoef=2.0, mma=MH_BF16, out_dtype=out_dtype)
+    close(out, (-ref + 13.0 * eye + 2.0 * Rm.double()).float().to(out_dtype).double(), 0, 0, "tile alpha + diag + R")
+    base = ints((Bt, M, N), gen)
+    acc = base.to(DEV, out_dtype)
+    c2 = torch.zeros((Bt, M, N), device=DEV, dtype=bf)
+    K.gemm(a_dev, b_dev, out=acc, accumulate=True, R=Rm.to(DEV, bf), rcoef=-7.0, mma=MH_BF16, c2=c2)   # bf16 R beside any C
+    want = (ref + base.double() - 7.0 * Rm.double()).float()
+    close(acc, want.to(out_dtype).double(), 0, 0, "tile accumulate + bf16 R")
+    close(c2, want.to(bf).double(), 0, 0, "tile bf16 copy")
+
+
+def test_pinv_tile_path_matches_generic_path():
+    """m = 384 (the template's landmark count): pinv_forward_tile / pinv_backward_tile (one 192 x 384-tile launch per product)
+    against the generic bf16 path they replace and, loosely, against f64 autograd through the same iteration."""
+    from mirror_amd import functional as Fn
+    gen = g(5)
+    m, BH, iters = 384, 6, 6
+    logits = torch.randn(BH, m, m, generator=gen) + 4.0 * torch.eye(m)
+    a2 = torch.softmax(logits, dim=-1).to(DEV).contiguous()
+    dZ = (torch.randn(BH, m, m, generator=gen) * 0.1).to(DEV)
+    z_t, saved_t, st_t = Fn.pinv_forward_tile(a2, iters)
+    z_g, saved_g, st_g = Fn.pinv_forward(a2, iters, MH_BF16, torch.bfloat16)
+    assert torch.equal(st_t, st_g)
+    close(z_t.float(), z_g.double().cpu(), 3e-2, 3e-2 * float(z_g.float().abs().max()), "pinv tile forward")
+    dX_t = Fn.pinv_backward_tile(a2, saved_t, st_t, dZ)
+    dX_g = Fn.pinv_backward(a2, saved_g, st_g, dZ, MH_BF16, torch.bfloat16)
+    x64 = a2.double().cpu().requires_grad_(True)
+    ax = x64.abs()
+    z = x64.transpose(-1, -2) / (ax.sum(-1).max() * ax.sum(-2).max())
+    eye = torch.eye(m, dtype=torch.float64)
+    for _ in range(iters):
+        xz = x64 @ z
+        z = 0.25 * z @ (13 * eye - xz @ (15 * eye - xz @ (7 * eye - xz)))
+    z.backward(dZ.double().cpu())
+    ref = x64.grad
+
+    def cos(a, b):
+        a, b = a.double().cpu().reshape(-1), b.double().cpu().reshape(-1)
+        return float(torch.dot(a, b) / (a.norm() * b.norm())), float(a.norm() / b.norm())
+    c_t, r_t = cos(dX_t, ref)
+    c_g, r_g = cos(dX_g, ref)
+    assert c_t > 0.995 and 0.97 < r_t < 1.03, (c_t, r_t)
+    assert c_t > c_g - 2e-3, (c_t, c_g)          # no worse than the path it replaces
+    close(z_t.float(), z.detach(), 3e-2, 3e-2 * float(z.detach().abs().max()), "pinv tile forward vs f64")
+
+
 @pytest.mark.parametrize("mma,dtype", [(MH_F32, torch.float32), (MH_BF16, torch.bfloat16)])
 def test_gemm_batched_strided_views(mma, dtype):
     """The Nystrom use: heads are column slices of a [B, n, 3D] buffer; output written into a [B, n, D] view."""
