@@ -72,6 +72,9 @@ typedef struct {
     int32_t r_bf16;               /* 1: R is bf16 although C is f32 (same tile kernel only) */
 } mh_gemm_desc;
 int mh_gemm(const mh_gemm_desc* d, mh_stream s);
+/* Bytes of `workspace` with which this call reduces through plain partial tiles + a fold pass instead of f32 atomics
+ * (0: the call has no use for one — no split-K / batch broadcast, or the shape is not on the large-tile kernel). */
+int64_t mh_gemm_workspace_bytes(const mh_gemm_desc* d);
 
 /* ---------------------------------------------------------------- skinny-M linears (RNA encoder / style heads: every
  * tensor is [B, D], models/mirror.py:77-102, :217-224, :845-857): weight-streaming kernels, bf16 operands.
@@ -96,6 +99,7 @@ int mh_layernorm_fwd(const void* x, const float* gamma, const float* beta, void*
 /* dx = d/dx, dgamma/dbeta accumulated (+=, f32; caller zeroes them). dy uses y's addressing.
  * workspace (optional, f32, ws_floats >= 2*D): per-block dgamma/dbeta partials are written there and folded by a second
  * small launch instead of thousands of same-address atomics; size it 2*D*min(rows/16, 1024) floats for full speed. */
+int64_t mh_layernorm_bwd_workspace_bytes(int64_t rows, int D);      /* full-speed size of `workspace` below */
 int mh_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                      void* dx, float* dgamma, float* dbeta,
                      int batches, int rows_per_batch, int D, int64_t x_bs, int64_t y_bs,
@@ -169,6 +173,9 @@ int mh_pinv_chain_pack(const float* dz, void* up, int BH, int m, mh_stream s);
 int mh_pinv_chain_fwd(const void* XP, void* saved, void* zfT, int BH, int m, int iters, mh_stream s);
 int mh_pinv_chain_bwd(const void* XP, const void* saved, const void* dzf, void* work, float* dX, float* dz0, int BH, int m,
                       int iters, mh_stream s);
+/* Bytes of the chain's caller-allocated buffers: which = 0: `saved` (forward output, backward input: [iters, 4, BH, m, m]
+ * bf16 = the iterates z_k, P_k, T2_k, T3_k); which = 1: `work` (backward scratch, same size). */
+int64_t mh_pinv_chain_workspace_bytes(int BH, int m, int iters, int which);
 /* Fused attention sides of the Nystrom core (bf16 policy, dh = 64, m = 256 landmarks; anything else returns
  * MH_EINVAL and the caller composes mh_gemm + mh_softmax).  The [n_p x m] / [m x n_p] similarity matrices stay in MFMA
  * accumulators; only row statistics reach HBM.  Replaces, in [3P] NystromAttention.forward (called at
@@ -189,6 +196,7 @@ int mh_nys_attn1_fwd(const void* qkv, const void* lm, const void* w2, void* out,
 /* attn3_fwd cuts the sequence into ranges (one workgroup each) when B*h alone would not fill the chip; the partial results
  * live in `workspace` (mh_nys_attn3_ws_floats(B, h, n_p) floats; NULL / too small: one workgroup per (b, h)). */
 int64_t mh_nys_attn3_ws_floats(int B, int h, int n_p);
+int64_t mh_nys_attn3_workspace_bytes(int B, int h, int n_p);         /* the same in bytes */
 int mh_nys_attn3_fwd(const void* qkv, const void* lm, float* av, float* lse3, float* workspace, int64_t ws_floats,
                      const float* mrow, const float* mlm, int B, int h, int n_p, int m, int dh, float scale, mh_stream s);
 int mh_nys_attn1_bwd(const void* qkv, const void* lm, const void* w2, const void* dout, const float* lse1, float* delta1,

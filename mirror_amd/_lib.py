@@ -122,7 +122,9 @@ _SIGS = {
     "mh_rna_block_fwd": [C.POINTER(RnaBlockDesc)],
     "mh_rna_block_bwd": [C.POINTER(RnaBlockDesc)],
 }
-EXPORTS = sorted(list(_SIGS) + ["mh_last_error", "mh_version", "mh_device_ok", "mh_nys_attn3_ws_floats", "mh_rna_block_workspace_bytes"])
+EXPORTS = sorted(list(_SIGS) + ["mh_last_error", "mh_version", "mh_device_ok", "mh_nys_attn3_ws_floats", "mh_rna_block_workspace_bytes",
+                                 "mh_gemm_workspace_bytes", "mh_layernorm_bwd_workspace_bytes", "mh_nys_attn3_workspace_bytes",
+                                 "mh_pinv_chain_workspace_bytes"])
 
 _lib = None
 
@@ -147,6 +149,14 @@ def load() -> C.CDLL:
     lib.mh_device_ok.restype = C.c_int
     lib.mh_nys_attn3_ws_floats.restype = C.c_int64
     lib.mh_nys_attn3_ws_floats.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.mh_gemm_workspace_bytes.restype = C.c_int64
+    lib.mh_gemm_workspace_bytes.argtypes = [C.POINTER(GemmDesc)]
+    lib.mh_layernorm_bwd_workspace_bytes.restype = C.c_int64
+    lib.mh_layernorm_bwd_workspace_bytes.argtypes = [C.c_int64, C.c_int]
+    lib.mh_nys_attn3_workspace_bytes.restype = C.c_int64
+    lib.mh_nys_attn3_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.mh_pinv_chain_workspace_bytes.restype = C.c_int64
+    lib.mh_pinv_chain_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     lib.mh_rna_block_workspace_bytes.restype = C.c_int64
     lib.mh_rna_block_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
     for name, sig in _SIGS.items():

@@ -74,6 +74,16 @@ static bool try_rank_update(const mh_gemm_desc* t, hipStream_t s) {
     return true;
 }
 
+extern "C" int64_t mh_gemm_workspace_bytes(const mh_gemm_desc* d) {
+    if (!d || d->mma != MH_BF16 || d->dtA != MH_BF16 || d->dtB != MH_BF16 || d->dtC != MH_F32 || !d->accumulate) return 0;
+    if (d->M % 256 || d->N % 256 || d->M <= 0) return 0;
+    const int split = d->split_k < 1 ? 1 : d->split_k;
+    const bool bcast = (d->sC1 == 0 || d->batch1 == 1) && (d->sC2 == 0 || d->batch2 == 1);
+    const int64_t parts = (int64_t)split * (bcast ? (int64_t)d->batch1 * d->batch2 : 1);
+    if (parts < 8) return 0;
+    return parts * d->M * d->N * 4;
+}
+
 extern "C" int mh_gemm(const mh_gemm_desc* d, mh_stream stream) {
     MH_REQUIRE(d && d->A && d->B && d->C, "mh_gemm: null pointer");
     MH_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "mh_gemm: empty problem M=%d N=%d K=%d", d->M, d->N, d->K);

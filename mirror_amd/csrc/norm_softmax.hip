@@ -371,6 +371,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_fold_kernel(const float* __
 
 static int ln_bwd_blocks() { static const int n = [] { const char* e = getenv("MH_LN_BWD_BLOCKS"); return e ? atoi(e) : 512; }(); return n; }
 
+extern "C" int64_t mh_layernorm_bwd_workspace_bytes(int64_t rows, int D) {
+    if (rows < 64 || D <= 0) return 0;
+    const int64_t nb = rows / 16 < 1024 ? (rows / 16 < 1 ? 1 : rows / 16) : 1024;
+    return 2 * (int64_t)D * nb * 4;
+}
+
 extern "C" int mh_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                 void* dx, float* dgamma, float* dbeta, int batches, int rpb, int D, int64_t x_bs,
                                 int64_t y_bs, int dt_x, int dt_dy, int dt_dx, int acc_dx, float* workspace, int64_t ws_floats,

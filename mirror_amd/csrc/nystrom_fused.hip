@@ -909,6 +909,8 @@ extern "C" int64_t mh_nys_attn3_ws_floats(int B, int h, int n_p) {
     return splits > 1 ? (int64_t)B * h * splits * A3_PART : 0;
 }
 
+extern "C" int64_t mh_nys_attn3_workspace_bytes(int B, int h, int n_p) { return 4 * mh_nys_attn3_ws_floats(B, h, n_p); }
+
 extern "C" int mh_nys_attn3_fwd(const void* qkv, const void* lm, float* av, float* lse3, float* workspace, int64_t ws_floats,
                                 const float* mrow, const float* mlm, int B, int h, int n_p, int m, int dh, float scale, mh_stream s) {
     if (int e = check_geo("mh_nys_attn3_fwd", B, h, n_p, m, dh)) return e;

@@ -569,3 +569,8 @@ extern "C" int mh_pinv_chain_bwd(const void* XT, const void* saved, const void* 
     MH_LAUNCH_CHECK("mh_pinv_chain_bwd");
     return MH_OK;
 }
+
+extern "C" int64_t mh_pinv_chain_workspace_bytes(int BH, int m, int iters, int which) {
+    if (BH <= 0 || m != CM || iters < 1 || which < 0 || which > 1) return 0;
+    return (int64_t)iters * 4 * BH * MAT * 2;
+}

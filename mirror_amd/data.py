@@ -67,3 +67,82 @@ class DeviceSlideBank:
         wsi = K.gather_rows(self.bank, rows)
         idx = torch.as_tensor(list(ids), device=self.device, dtype=torch.int64)
         return wsi, K.gather_rows(self.rna, idx)
+
+
+class HostFeeder:
+    """Pipelined host -> HBM hand-off of DataLoader batches: what `train_mirror.py:1138-1139` does synchronously
+    (`wsi_features.to(device)`, `rna_features.to(device)` at the top of every step) moved onto a copy stream, double
+    buffered, so that batch k + 1 crosses PCIe (B * N * F * 4 bytes as f32: 268 MB at c2, ~5 ms at PCIe Gen5 rates; half that
+    when the loader already holds bf16) while the GPU runs step k.
+
+        feeder = HostFeeder(loader, device, wsi_dtype=torch.bfloat16)
+        for wsi, rna in feeder:          # device tensors; valid until the NEXT iteration step
+            engine.step(wsi, rna)
+
+    Host batches are staged in pinned buffers (allocated once, sized by the first batch); the f32 -> bf16 cast, when asked for,
+    happens on the device on the copy stream (a host-side cast would cost more CPU time than the copy saves).  The consumer
+    stream waits on an event, never on the host."""
+
+    def __init__(self, loader, device, wsi_dtype: Optional[torch.dtype] = None, depth: int = 2):
+        self.loader, self.device, self.wsi_dtype = loader, torch.device(device), wsi_dtype
+        if self.device.type != "cuda":
+            raise MirrorHipError("HostFeeder feeds an MI355X device")
+        self.depth = max(2, int(depth))
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._slots = []          # per slot: (pinned wsi, pinned rna, device wsi raw, device wsi, device rna, ready event, free event)
+
+    def _slot(self, k: int, wsi: torch.Tensor, rna: torch.Tensor):
+        while len(self._slots) <= k:
+            self._slots.append(None)
+        sl = self._slots[k]
+        if sl is None or sl[0].shape != wsi.shape or sl[0].dtype != wsi.dtype or sl[1].shape != rna.shape:
+            pw = torch.empty(wsi.shape, dtype=wsi.dtype, pin_memory=True)
+            pr = torch.empty(rna.shape, dtype=torch.float32, pin_memory=True)
+            dw_raw = torch.empty(wsi.shape, dtype=wsi.dtype, device=self.device)
+            dw = dw_raw if self.wsi_dtype in (None, wsi.dtype) else torch.empty(wsi.shape, dtype=self.wsi_dtype, device=self.device)
+            dr = torch.empty(rna.shape, dtype=torch.float32, device=self.device)
+            sl = self._slots[k] = [pw, pr, dw_raw, dw, dr, torch.cuda.Event(), None, False]
+        return sl
+
+    def _issue(self, k: int, batch):
+        wsi, rna = batch[0], batch[1]
+        sl = self._slot(k, wsi, rna)
+        pw, pr, dw_raw, dw, dr, ready, free, used = sl
+        if used:
+            ready.synchronize()                   # the slot's previous host -> device copy has left the pinned buffer (depth steps ago)
+        if free is not None:
+            self.stream.wait_event(free)          # the step that consumed this slot's device tensors has been queued and finished
+        sl[7] = True
+        pw.copy_(wsi)                             # host memcpy into the pinned staging buffer (the loader's tensor may be pageable)
+        pr.copy_(rna)
+        with torch.cuda.stream(self.stream):
+            dw_raw.copy_(pw, non_blocking=True)
+            dr.copy_(pr, non_blocking=True)
+            if dw is not dw_raw:
+                K.cast(dw_raw, self.wsi_dtype, out=dw)
+            ready.record(self.stream)
+        return sl
+
+    def __iter__(self):
+        it = iter(self.loader)
+        pending = []
+        k = 0
+        for _ in range(self.depth - 1):
+            try:
+                pending.append(self._issue(k % self.depth, next(it)))
+                k += 1
+            except StopIteration:
+                break
+        while pending:
+            sl = pending.pop(0)
+            try:                                   # request batch k + 1 before handing batch k to the consumer
+                pending.append(self._issue(k % self.depth, next(it)))
+                k += 1
+            except StopIteration:
+                pass
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(sl[5])
+            yield sl[3], sl[4]
+            ev = torch.cuda.Event()
+            ev.record(cur)                         # everything the consumer queued on this batch so far
+            sl[6] = ev

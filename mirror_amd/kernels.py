@@ -138,10 +138,9 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *
     # reductions into one f32 C (split-K / a batch that broadcasts into C) on the large-tile kernel: give it room for plain
     # partial tiles + a fold pass (f32 atomics of a 64-way split cost more than the K loop).  `ws` stays alive until the call
     # is enqueued; the caching allocator keeps the block valid for stream-ordered use.
-    parts = d.split_k * B1 * B2 if (so[0] == 0 or B1 == 1) and (so[1] == 0 or B2 == 1) else d.split_k
-    if (accumulate and parts >= 8 and o4.dtype == torch.float32 and mma == MH_BF16 and M % 256 == 0 and N % 256 == 0
-            and a4.dtype == torch.bfloat16 and b4.dtype == torch.bfloat16 and parts * M * N <= (1 << 27) and _GEMM_WS):
-        ws = torch.empty((parts * M * N,), device=a.device, dtype=torch.float32)
+    wsb = int(_lib.load().mh_gemm_workspace_bytes(C.byref(d))) if (accumulate and _GEMM_WS) else 0
+    if 0 < wsb <= (1 << 29):
+        ws = torch.empty((wsb // 4,), device=a.device, dtype=torch.float32)
         d.workspace, d.workspace_floats = ws.data_ptr(), ws.numel()
     prof = gemm_profiler
     if prof is None:
@@ -334,8 +333,9 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, batches, rpb, D, 
     _chk(dy, x, gamma, mean, rstd, dx, dgamma, dbeta)
     rows = batches * rpb
     ws = None
-    if rows >= 64:      # per-block dgamma / dbeta partials (folded by a second launch) instead of same-address atomics
-        ws = torch.empty((2 * D * max(1, min(rows // 16, 1024)),), device=x.device, dtype=torch.float32)
+    nbytes = int(_lib.load().mh_layernorm_bwd_workspace_bytes(rows, D))
+    if nbytes:          # per-block dgamma / dbeta partials (folded by a second launch) instead of same-address atomics
+        ws = torch.empty((nbytes // 4,), device=x.device, dtype=torch.float32)
     _lib.call("mh_layernorm_bwd", _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma), _p(dbeta),
               batches, rpb, D, x_bs, y_bs, dt(x), dt(dy), dt(dx), int(accumulate_dx), _p(ws) if ws is not None else 0,
               ws.numel() if ws is not None else 0, stream=_stream())
@@ -488,6 +488,9 @@ PINV_CHAIN_M = 256
 def pinv_chain_saved_alloc(iters: int, BH: int, m: int, device) -> torch.Tensor:
     """The chain's saved-iterate buffer (what mh_pinv_chain_fwd writes for mh_pinv_chain_bwd): [iters, 4, BH, m, m] bf16,
     slot k = (z_k, P_k, T2_k, T3_k), panel native."""
+    nbytes = int(_lib.load().mh_pinv_chain_workspace_bytes(BH, m, iters, 0))
+    if nbytes != iters * 4 * BH * m * m * 2:
+        raise MirrorHipError(f"pinv chain: m={m} unsupported (mh_pinv_chain_workspace_bytes says {nbytes})")
     return torch.empty((iters, 4, BH, m, m), device=device, dtype=torch.bfloat16)
 
 
