@@ -181,7 +181,8 @@ def main():
     if a.feed != "resident":
         from mirror_amd.data import HostFeeder
         hdt = torch.float32 if a.feed == "host" else torch.bfloat16
-        host = [(wsi.float().cpu().to(hdt).roll(i, 0), rna.cpu().roll(i, 0)) for i in range(2)]     # two distinct host batches, alternated
+        # two distinct host batches, alternated, in pinned memory as a DataLoader(pin_memory=True) hands them over
+        host = [(wsi.float().cpu().to(hdt).roll(i, 0).pin_memory(), rna.cpu().roll(i, 0).pin_memory()) for i in range(2)]
         feed = HostFeeder((host[i % 2] for i in range(a.steps + 2)), dev, wsi_dtype=in_dtype)
         it = iter(feed)
         for _ in range(2):                        # untimed: pinned buffers allocated, pipeline primed

@@ -113,11 +113,14 @@ class HostFeeder:
         if free is not None:
             self.stream.wait_event(free)          # the step that consumed this slot's device tensors has been queued and finished
         sl[7] = True
-        pw.copy_(wsi)                             # host memcpy into the pinned staging buffer (the loader's tensor may be pageable)
-        pr.copy_(rna)
+        # a pinned batch (DataLoader(pin_memory=True), what train_mirror.py builds with --pin-mem) goes to the device as it is;
+        # a pageable one is staged through the slot's pinned buffer first (one host memcpy: ~10 GB/s on one core, i.e. the
+        # bottleneck for 268 MB batches — pin in the loader's workers)
+        src_w = wsi if wsi.is_pinned() else pw.copy_(wsi)
+        src_r = rna if (rna.is_pinned() and rna.dtype == torch.float32) else pr.copy_(rna)
         with torch.cuda.stream(self.stream):
-            dw_raw.copy_(pw, non_blocking=True)
-            dr.copy_(pr, non_blocking=True)
+            dw_raw.copy_(src_w, non_blocking=True)
+            dr.copy_(src_r, non_blocking=True)
             if dw is not dw_raw:
                 K.cast(dw_raw, self.wsi_dtype, out=dw)
             ready.record(self.stream)
