@@ -6,7 +6,7 @@ bool gemm_try_tile384(GemmArgs& a, int akc, int bkc, int dtC, int batch, void* c
 
 static int launch_one(const mh_gemm_desc* d, hipStream_t s) {
     const int split = d->split_k < 1 ? 1 : d->split_k;
-    GemmArgs a;
+    GemmArgs a{};
     a.A = d->A; a.B = d->B; a.C = d->C; a.bias = d->bias;
     a.M = d->M; a.N = d->N; a.K = d->K;
     a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc;

@@ -54,7 +54,8 @@ struct TileGeom {
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-template <int MMA, typename TG, bool KC, int ROWS, bool FULL, int NT = 256>
+// FULL: 0 = guarded loads, 1 = whole tiles everywhere, 2 = whole tiles in M / N with a ragged last K-tile (K % VEC == 0)
+template <int MMA, typename TG, bool KC, int ROWS, int FULL, int NT = 256>
 struct Stager {
     using G = TileGeom<MMA, KC, ROWS>;
     static constexpr int VEC = 16 / (int)sizeof(TG);
@@ -74,8 +75,17 @@ struct Stager {
             // FULL + K-contiguous rows: a ragged last row-tile re-reads row dim-1 (its results are never stored)
             if (KC) { gm = FULL ? min(tile0 + r, dim - 1) : tile0 + r; gk = k0 + c * VEC; off = (long)gm * ld + gk; }
             else    { gk = k0 + r; gm = tile0 + c * VEC; off = (long)gk * ld + gm; }
-            if constexpr (FULL) {
+            if constexpr (FULL == 1) {
                 regs[i] = *reinterpret_cast<const u32x4*>(base + off);
+            } else if constexpr (FULL == 2) {
+                // ragged K only (the 96-wide heads of the template geometry: K = 96 = 1.5 K-tiles): a 16-byte chunk is inside or
+                // outside K as a whole -> clamped address + select, no branches (the guarded path costs a divergent branch and
+                // an early wait per chunk: 2.3x on those products)
+                const bool in = KC ? (gk + VEC <= kend) : (gk < kend);
+                const long o2 = KC ? (long)gm * ld + min(gk, kend - VEC) : (long)min(gk, kend - 1) * ld + gm;
+                u32x4 v = *reinterpret_cast<const u32x4*>(base + o2);
+                if (!in) v = u32x4{0u, 0u, 0u, 0u};
+                regs[i] = v;
             } else {
                 const bool row_ok = KC ? (gm < dim) : (gk < kend);
                 const int cstart = KC ? gk : gm;
@@ -263,7 +273,7 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& g, TC* C, const TC*
     }
 }
 
-template <int MMA, typename TA, typename TB, typename TC, bool AKC, bool BKC, int WM, int WN, bool FULL>
+template <int MMA, typename TA, typename TB, typename TC, bool AKC, bool BKC, int WM, int WN, int FULL>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     using GA = TileGeom<MMA, AKC, BM>;
@@ -390,15 +400,22 @@ static void launch_w(GemmArgs& a, int batch, hipStream_t s) {
     a.tiles_m = mh_cdiv(a.M, 128);
     a.tiles_n = mh_cdiv(a.N, BN);
     // a ragged M is fine when A's rows are K-contiguous (loads clamp to the last row, stores are guarded)
-    const bool full = a.vecA && a.vecB && (AKC || a.M % 128 == 0) && a.N % BN == 0 && a.K % BK == 0 &&
-                      a.k_per_split % BK == 0 && a.K % a.k_per_split == 0;
+    const bool mn_ok = a.vecA && a.vecB && (AKC || a.M % 128 == 0) && a.N % BN == 0;
+    const bool full = mn_ok && a.K % BK == 0 && a.k_per_split % BK == 0 && a.K % a.k_per_split == 0;
+    // whole tiles in M and N, one ragged K-tile at the end (no split-K): the FULL == 2 instances (bf16 MMA only: the batched
+    // dh = 96 products of the template geometry)
+    constexpr int VMAX = (sizeof(TA) == 2 || sizeof(TB) == 2) ? 8 : 4;
+    const bool ktail = MMA == 1 && mn_ok && !full && a.split_k == 1 && a.K % VMAX == 0 && a.K > BK && a.M % 128 == 0;
     dim3 grid(a.tiles_m * a.tiles_n, a.split_k, batch);
     if (narrow) {
-        if (full) hipLaunchKernelGGL((gemm_kernel<MMA, TA, TB, TC, AKC, BKC, 2, 1, true>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((gemm_kernel<MMA, TA, TB, TC, AKC, BKC, 2, 1, false>), grid, dim3(256), 0, s, a);
+        if (full) hipLaunchKernelGGL((gemm_kernel<MMA, TA, TB, TC, AKC, BKC, 2, 1, 1>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((gemm_kernel<MMA, TA, TB, TC, AKC, BKC, 2, 1, 0>), grid, dim3(256), 0, s, a);
     } else {
-        if (full) hipLaunchKernelGGL((gemm_kernel<MMA, TA, TB, TC, AKC, BKC, 2, 2, true>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((gemm_kernel<MMA, TA, TB, TC, AKC, BKC, 2, 2, false>), grid, dim3(256), 0, s, a);
+        if (full) hipLaunchKernelGGL((gemm_kernel<MMA, TA, TB, TC, AKC, BKC, 2, 2, 1>), grid, dim3(256), 0, s, a);
+        else if constexpr (MMA == 1 && sizeof(TA) == 2 && sizeof(TB) == 2) {
+            if (ktail) hipLaunchKernelGGL((gemm_kernel<MMA, TA, TB, TC, AKC, BKC, 2, 2, 2>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((gemm_kernel<MMA, TA, TB, TC, AKC, BKC, 2, 2, 0>), grid, dim3(256), 0, s, a);
+        } else hipLaunchKernelGGL((gemm_kernel<MMA, TA, TB, TC, AKC, BKC, 2, 2, 0>), grid, dim3(256), 0, s, a);
     }
 }
 

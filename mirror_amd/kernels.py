@@ -194,10 +194,12 @@ def gemm_variant(d: GemmDesc) -> str:
             and not (atomic and (d.bias or d.act != 0 or d.dtC != MH_F32))
             and -(-d.M // 256) * (d.N // 256) * -(-kk // kps) * batch >= 128 and os.environ.get("MH_GEMM_BIG", "1")[:1] != "0"):
         return f"gemm_big_kernel<{_TN[d.dtC]},{'true' if d.a_kc else 'false'},{'true' if d.b_kc else 'false'}>"
-    full = (oka and okb and (d.a_kc or d.M % 128 == 0)
-            and d.N % (64 * wn) == 0 and kk % bk == 0 and kk % kps == 0)
+    mn_ok = oka and okb and (d.a_kc or d.M % 128 == 0) and d.N % (64 * wn) == 0
+    full = mn_ok and kk % bk == 0 and kk % kps == 0
+    ktail = (d.mma == MH_BF16 and d.dtA == MH_BF16 and d.dtB == MH_BF16 and wn == 2 and mn_ok and not full and split == 1
+             and kk % 8 == 0 and kk > bk and d.M % 128 == 0)
     return (f"gemm_kernel<{d.mma},{_TN[d.dtA]},{_TN[d.dtB]},{tc},{'true' if d.a_kc else 'false'},"
-            f"{'true' if d.b_kc else 'false'},2,{wn},{'true' if full else 'false'}>")
+            f"{'true' if d.b_kc else 'false'},2,{wn},{1 if full else (2 if ktail else 0)}>")
 
 
 class GemmProfiler:
