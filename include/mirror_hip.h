@@ -113,6 +113,12 @@ int mh_layernorm_bwd(const void* dy, const void* x, const float* gamma, const fl
  *               K % 64 == 0, N % 128 == 0, M ragged.  Replaces the forward of nn.Linear at models/mirror.py:346 (`_fc1`), [3P]
  *               to_qkv / to_out and the retention embed / head (:595-607) under the `fp8` precision policy. */
 int mh_quant_fp8(const void* x, int64_t n, void* q, float* scale, unsigned* amax_scratch, int dt, mh_stream s);
+/* Delayed scaling, ONE pass: the scale is `margin` x this tensor's max |x| of the PREVIOUS step (ring: 3 uint32 of device state
+ * per call site, zero-initialised; tick: device f32 holding the step counter, e.g. TrainEngine's Adam state), this step's
+ * max is gathered for the next step.  Values past the e4m3 range saturate.  The first two steps of a call site (ring still
+ * empty) must go through mh_quant_fp8. */
+int mh_quant_fp8_delayed(const void* x, int64_t n, void* q, float* scale, unsigned* ring, const float* tick, float margin,
+                         int dt, mh_stream s);
 int mh_gemm_fp8(const void* A, int64_t lda, int64_t a_bs, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t c_bs, int batch,
                 const float* scale_a, const float* scale_b, const float* bias, int act, int M, int N, int K, int dt_c, mh_stream s);
 

@@ -105,6 +105,7 @@ _SIGS = {
     "mh_fanout_bwd": [P, P, F, P, P, I, I, I, I],
     "mh_gather_rows": [P, P, P, L, L, L, I],
     "mh_quant_fp8": [P, L, P, P, P, I],
+    "mh_quant_fp8_delayed": [P, L, P, P, P, P, F, I],
     "mh_gemm_fp8": [P, L, L, P, L, P, L, L, I, P, P, P, I, I, I, I, I],
     "mh_weighted_sum": [P, P, P, P, P, P, F, F, F, F, F, F, I, P],
     "mh_weighted_sum_bwd": [P, F, F, F, F, F, F, I, P],

@@ -54,6 +54,40 @@ __global__ __launch_bounds__(256) void quant_fp8_kernel(const T* __restrict__ x,
     }
 }
 
+// Delayed scaling: ONE pass.  q = e4m3(clamp(x * 448 / amax_prev)) with amax_prev = this tensor's max |x| of the previous step,
+// while this step's max is gathered for the next one.  `ring` is 3 uint32 per call site: slot t % 3 collects step t, slot
+// (t - 1) % 3 is read, slot (t + 1) % 3 is cleared by one thread (nobody else touches it during step t) — no pass over the
+// tensor just to learn its scale, no grid-wide ordering inside the kernel.  t comes from DEVICE memory (`tick`, the optimizer's
+// step counter), so a replayed HIP graph rotates the ring by itself.  margin > 1 leaves headroom for growth from step to
+// step; values past +-448 saturate.
+template <typename T>
+__global__ __launch_bounds__(256) void quant_fp8_delayed_kernel(const T* __restrict__ x, long n, unsigned* __restrict__ ring,
+                                                                const float* __restrict__ tick, float margin,
+                                                                unsigned char* __restrict__ q, float* __restrict__ scale) {
+    __shared__ float red[4];
+    const int t = (int)tick[0];
+    const int cur = t % 3, prev = (t + 2) % 3, nxt = (t + 1) % 3;
+    const float amax = __uint_as_float(ring[prev]) * margin;
+    const float mul = amax > 0.f ? F8_MAX / amax : 1.f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        scale[0] = amax > 0.f ? amax / F8_MAX : 1.f;
+        ring[nxt] = 0u;
+    }
+    float m = 0.f;
+    const long n4 = n / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f4_t raw = ld4(x + 4 * i);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(raw[0]), fabsf(raw[1]))), fmaxf(fabsf(raw[2]), fabsf(raw[3])));
+        const f4_t v = raw * mul;
+        unsigned w = 0;
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(v[0], -F8_MAX), F8_MAX), fminf(fmaxf(v[1], -F8_MAX), F8_MAX), w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(v[2], -F8_MAX), F8_MAX), fminf(fmaxf(v[3], -F8_MAX), F8_MAX), w, true);
+        reinterpret_cast<unsigned*>(q)[i] = w;
+    }
+    m = block_max256(m, red);
+    if (threadIdx.x == 0) atomicMax(ring + cur, __float_as_uint(m));
+}
+
 // C[M, N] = act(sa * sb * A[M, K] B[N, K]^T + bias); A, B fp8 with K contiguous (lda, ldb bytes), K % 64 == 0, N % 128 == 0
 template <typename TC>
 __global__ __launch_bounds__(256) void gemm_fp8_kernel(const unsigned char* __restrict__ A, long lda, long a_bs,
@@ -153,6 +187,20 @@ extern "C" int mh_quant_fp8(const void* x, int64_t n, void* q, float* scale, uns
         hipLaunchKernelGGL((quant_fp8_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (long)n, amax_scratch, (unsigned char*)q, scale);
     }
     MH_LAUNCH_CHECK("mh_quant_fp8");
+    return MH_OK;
+}
+
+extern "C" int mh_quant_fp8_delayed(const void* x, int64_t n, void* q, float* scale, unsigned* ring, const float* tick, float margin,
+                                    int dt, mh_stream s) {
+    if (n == 0) return MH_OK;
+    MH_REQUIRE(n % 4 == 0 && mh_quad_ok(x, mh_dt_size(dt)) && ((uintptr_t)q & 3) == 0, "mh_quant_fp8_delayed: n must be a multiple of 4, buffers quad-aligned");
+    MH_REQUIRE(ring && tick && margin >= 1.f, "mh_quant_fp8_delayed: ring, tick and margin >= 1 are required");
+    dim3 grid((unsigned)min((long)mh_cdiv(n / 4, 256), 4096L));
+    if (dt == MH_F32)
+        hipLaunchKernelGGL((quant_fp8_delayed_kernel<float>), grid, dim3(256), 0, (hipStream_t)s, (const float*)x, (long)n, ring, tick, margin, (unsigned char*)q, scale);
+    else
+        hipLaunchKernelGGL((quant_fp8_delayed_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (long)n, ring, tick, margin, (unsigned char*)q, scale);
+    MH_LAUNCH_CHECK("mh_quant_fp8_delayed");
     return MH_OK;
 }
 

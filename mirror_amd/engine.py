@@ -341,11 +341,14 @@ class TrainEngine:
             return self._step_body(wsi, rna, noise, wsi_key_padding_mask)
         finally:
             Fn.zero_arena_end()      # also after an exception: nothing outside a step may carve from an arena that is not re-zeroed
+            Fn.fp8_delayed_scaling(None)      # delayed fp8 scaling belongs to training steps only
 
     def _step_body(self, wsi: torch.Tensor, rna: torch.Tensor, noise: Optional[dict],
                    wsi_key_padding_mask: Optional[torch.Tensor] = None):
         Fn.dropout_step_begin(self.device)
         Fn._res_grads.clear()
+        if POLICIES[self.precision].fp8_fwd:       # delayed fp8 scaling keys its amax rings on the device-side step counter
+            Fn.fp8_delayed_scaling(self._state[0:1], self.step_count)
         if self._proto is not None:
             w = self._proto.weight
             K.rownorm_(w.data)

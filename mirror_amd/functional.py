@@ -272,6 +272,36 @@ def _gemm_window(a3, b2, out3, *, bias=None, mma):
     return out3
 
 
+# Delayed scaling for the fp8 forward (BASELINE config 5): per call site (keyed by the weight's address + the operand role) a
+# 3-slot amax ring on the device; the engine publishes its device-side step counter here.  Without a counter (no engine,
+# evaluation) or during a site's first two steps the exact two-pass quantisation runs.
+_fp8_state = {"tick": None, "sites": {}, "host_step": 0}
+
+
+def fp8_delayed_scaling(tick: Optional[torch.Tensor], host_step: int = 0) -> None:
+    """tick: device f32[1] step counter (TrainEngine._state[0:1]) for the duration of a training step; None: back to the exact
+    two-pass quantisation (evaluation, module use without an engine).  The per-site amax rings survive a None."""
+    _fp8_state["tick"] = tick
+    _fp8_state["host_step"] = int(host_step)
+
+
+def _quant_site(t: torch.Tensor, key):
+    st = _fp8_state
+    if st["tick"] is None:
+        return K.quant_fp8(t)
+    site = st["sites"].get(key)
+    if site is None:
+        site = st["sites"][key] = [torch.zeros(3, device=t.device, dtype=torch.int32), st["host_step"]]
+    ring, born = site
+    if st["host_step"] - born < 2:
+        # the ring is still empty: exact scale now, and seed this step's slot so that the next step finds a history
+        q, sc = K.quant_fp8(t)
+        slot = st["host_step"] % 3
+        ring[slot:slot + 1].copy_((sc * 448.0).view(torch.int32))
+        return q, sc
+    return K.quant_fp8_delayed(t, ring, st["tick"])
+
+
 def _fp8_linear(xa, wa, bias, act, out):
     """out = act(xa @ wa^T + bias) with per-tensor-scaled e4m3 operands (config 5).  xa [.., R, K] bf16 (a row window of a
     contiguous parent is quantised through the parent), wa [N, K] bf16 contiguous.  Returns False when the shape does not
@@ -283,11 +313,11 @@ def _fp8_linear(xa, wa, bias, act, out):
     base = xa if xa.is_contiguous() else xa._base
     if base is None or not base.is_contiguous() or base.numel() % 4 or base.dtype != bf16:
         return False
-    qb, sx = K.quant_fp8(base)
+    qb, sx = _quant_site(base, (wa.data_ptr(), "x"))
     xq = qb if base is xa else qb.as_strided(xa.shape, xa.stride(), xa.storage_offset() - base.storage_offset())
     if not K.gemm_fp8_ok(xq, N):
         return False
-    wq, sw = K.quant_fp8(wa)
+    wq, sw = _quant_site(wa, (wa.data_ptr(), "w"))
     K.gemm_fp8(xq, sx, wq, sw, out, bias=bias, act=act)
     return True
 

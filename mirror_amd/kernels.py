@@ -251,6 +251,19 @@ def quant_fp8(x: torch.Tensor):
     return q, scale
 
 
+def quant_fp8_delayed(x: torch.Tensor, ring: torch.Tensor, tick: torch.Tensor, margin: float = 1.25):
+    """One-pass e4m3 quantisation with the previous step's scale (ring: int32[3] device state of this call site, tick: device f32
+    step counter).  Returns (q, scale) like quant_fp8."""
+    _chk(x, ring, tick)
+    _contig(x, "quant_fp8_delayed input")
+    if x.numel() % 4 or ring.numel() != 3 or ring.dtype != torch.int32 or tick.dtype != torch.float32:
+        raise MirrorHipError("quant_fp8_delayed: bad operands")
+    q = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+    scale = torch.empty((1,), device=x.device, dtype=torch.float32)
+    _lib.call("mh_quant_fp8_delayed", _p(x), x.numel(), _p(q), _p(scale), _p(ring), _p(tick), float(margin), dt(x), stream=_stream())
+    return q, scale
+
+
 def gemm_fp8_ok(a: torch.Tensor, n_out: int) -> bool:
     """a [..., R, K] as e4m3 bytes: K % 64 == 0, N % 128 == 0, rows K-contiguous, <= one batch dim with 16-byte strides."""
     Kd = a.shape[-1]

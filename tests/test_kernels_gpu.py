@@ -1137,3 +1137,28 @@ def test_shadow_cache_does_not_outlive_its_tensor():
     w3 = torch.full((64, 128), 0.5, device=DEV)
     if w3.data_ptr() == pp:
         assert float(Fn.shadow(w3, Fn.BF16).float().mean()) == 0.5
+
+
+def test_fp8_delayed_scaling_quantisation_uses_last_steps_amax_and_rotates_its_ring():
+    """mh_quant_fp8_delayed: scale = margin x amax of the PREVIOUS step (3-slot ring keyed by a device-side step counter), this
+    step's amax lands in its own slot, the slot after it is cleared; values are bit-exact against torch.float8_e4m3fn at that
+    scale, and values beyond the scale's range saturate at +-448."""
+    gen = g(123)
+    x1 = torch.randn(64, 512, generator=gen).to(DEV, torch.bfloat16)
+    x2 = (torch.randn(64, 512, generator=gen) * 3).to(DEV, torch.bfloat16)
+    ring = torch.zeros(3, device=DEV, dtype=torch.int32)
+    tick = torch.zeros(1, device=DEV)
+    a1 = float(x1.float().abs().max())
+    ring[0] = torch.tensor([a1], device=DEV).view(torch.int32)[0]        # step 0 seeded by the exact path
+    ring[2] = 12345                                                      # stale content of the slot step 1 must clear
+    tick.fill_(1.0)
+    q, sc = K.quant_fp8_delayed(x2, ring, tick, margin=1.25)
+    assert abs(float(sc) - 1.25 * a1 / 448.0) <= 1e-6 * a1
+    want = (x2.float() / sc).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert torch.equal(q, want)
+    got_amax = float(ring[1:2].view(torch.float32))
+    assert got_amax == float(x2.float().abs().max()) and int(ring[2]) == 0 and float(ring[0:1].view(torch.float32)) == a1
+    assert int((q.view(torch.float8_e4m3fn).float().abs() == 448).sum()) > 0     # 3x larger values at 1.25x headroom: some saturate
+    tick.fill_(2.0)
+    q3, sc3 = K.quant_fp8_delayed(x1, ring, tick, margin=1.0)
+    assert abs(float(sc3) - got_amax / 448.0) <= 1e-6 * got_amax and int(ring[0]) == 0
