@@ -421,3 +421,37 @@ def test_d512_bucketed_all_reduce_and_rna_graph_world2():
     assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2]), "ranks diverged"
     _traj_close(torch.from_numpy(res[0][1]), torch.from_numpy(res[0][2]), torch.from_numpy(res[0][3]), tol=0.1)
     assert abs(res[0][5] - res[0][6]) < 1e-2 * abs(res[0][5])
+
+
+def test_force_update_flushes_a_partial_accumulation_window_and_ranks_seed_dropout_differently():
+    """(1) train_mirror.py:1128-1131: `need_update = last_batch or (batch_idx + 1) % accum_steps == 0` — the last, partial
+    window of an epoch still updates (loss scaled by 1 / accum_steps as in the reference, :1192-1196).  With accum_steps = 3, two
+    micro-steps and force_update on the second: one optimizer step, gradients = (g1 + g2) / 3, nothing left for the next window.
+    (2) `seed=` folds the rank in (utils.random_seed(args.seed, args.rank), :682): two engines built with ranks' seeds draw
+    different dropout masks, the same seed reproduces."""
+    from mirror_amd import functional as Fn
+    from mirror_amd.engine import TrainEngine
+    from mirror_amd.losses import MIRRORLoss
+    ref = _make()
+    ref.precision = "fp32"
+    model = _make()
+    eng = TrainEngine(model, MIRRORLoss(), lr=1e-3, precision="fp32", accum_steps=3, snapshot_grads=True)
+    with torch.no_grad():
+        ref.prototypes.weight.copy_(torch.nn.functional.normalize(ref.prototypes.weight, dim=1))
+    for micro in range(2):
+        wsi, rna, noise = _batch(2, 300 + micro)
+        (MIRRORLoss()(*ref(wsi, rna, noise=noise))[0] / 3).backward()
+        eng.step(wsi, rna, noise=noise, force_update=(micro == 1))
+    assert float(eng._state[0]) == 1.0 and eng._micro == 0
+    want = torch.cat([p.grad.reshape(-1) for p in reversed(list(ref.parameters()))])
+    got = torch.cat([eng.grad_snap[o:o + p.numel()] for p, o in zip(eng.params, eng.offsets)]) / 3.0     # Adam folds 1 / accum_steps in
+    assert float((got - want).norm()) < 2e-3 * float(want.norm())
+    assert float(eng.grad.abs().max()) == 0.0          # nothing leaks into the next window
+
+    def masks(seed):
+        m = _make().train()
+        TrainEngine(m, MIRRORLoss(), precision="bf16", seed=seed, graph=False)
+        x = torch.ones(4, 4096, device="cuda")
+        return Fn.dropout(x, 0.5, True)
+    a, b, c = masks(10), masks(11), masks(10)
+    assert torch.equal(a, c) and not torch.equal(a, b)
