@@ -132,7 +132,7 @@ struct FwdArgs {
     int B, N, K;
 };
 
-template <int MT>
+template <int MT, int QPL>      // QPL: 16-byte quads per lane and row in one pass of the prologue (256 QPL columns)
 __global__ __launch_bounds__(256) void rna_fwd_kernel(FwdArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* sA = reinterpret_cast<bf16_t*>(smem);
@@ -147,14 +147,14 @@ __global__ __launch_bounds__(256) void rna_fwd_kernel(FwdArgs g) {
     // ---- operand image: (LayerNorm of) the B input rows as bf16; rows past B are zero.  A wave owns rows wave, wave + 4, ...;
     //      all loads of four rows (8 quads per lane and row: a 2048-column chunk) are issued before anything waits on them —
     //      a row-by-row loop is a chain of dependent L2 round trips (~1 us each) in front of a ~2 us GEMM
-    const int nchunk = (K + 2047) / 2048;       // LayerNorm rows fit one chunk (host check: K <= 2048 when ln)
+    const int nchunk = (K + 256 * QPL - 1) / (256 * QPL);       // LayerNorm rows fit one chunk (host check: K <= 2048 when ln)
     for (int i0 = 0; i0 < MT * 4; i0 += 4) {
         for (int c = 0; c < nchunk; c++) {
             if (g.a_f32) {
-                rb_f4 v[4][8], gm[8], bt[8];
+                rb_f4 v[4][QPL], gm[QPL], bt[QPL];
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const int k = min(2048 * c + 4 * (lane + 64 * j), K - 4);
+                for (int j = 0; j < QPL; j++) {
+                    const int k = min(256 * QPL * c + 4 * (lane + 64 * j), K - 4);
                     if (g.ln) { gm[j] = *reinterpret_cast<const rb_f4*>(g.gamma + k); bt[j] = *reinterpret_cast<const rb_f4*>(g.beta + k); }
 #pragma unroll
                     for (int i = 0; i < 4; i++)
@@ -166,12 +166,12 @@ __global__ __launch_bounds__(256) void rna_fwd_kernel(FwdArgs g) {
                     for (int i = 0; i < 4; i++) {
                         float s1 = 0.f;
 #pragma unroll
-                        for (int j = 0; j < 8; j++)
+                        for (int j = 0; j < QPL; j++)
                             if (4 * (lane + 64 * j) < K) s1 += v[i][j][0] + v[i][j][1] + v[i][j][2] + v[i][j][3];
                         mean[i] = wave_sum(s1) / (float)K;
                         float s2 = 0.f;
 #pragma unroll
-                        for (int j = 0; j < 8; j++)
+                        for (int j = 0; j < QPL; j++)
                             if (4 * (lane + 64 * j) < K) {
                                 const rb_f4 d = v[i][j] - mean[i];
                                 s2 += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
@@ -184,8 +184,8 @@ __global__ __launch_bounds__(256) void rna_fwd_kernel(FwdArgs g) {
 #pragma unroll
                 for (int i = 0; i < 4; i++)
 #pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        const int m = wave + 4 * (i0 + i), k = 2048 * c + 4 * (lane + 64 * j);
+                    for (int j = 0; j < QPL; j++) {
+                        const int m = wave + 4 * (i0 + i), k = 256 * QPL * c + 4 * (lane + 64 * j);
                         if (k >= K) continue;
                         rb_f4 o = v[i][j];
                         if (g.ln) o = (o - mean[i]) * rstd[i] * gm[j] + bt[j];
@@ -193,19 +193,19 @@ __global__ __launch_bounds__(256) void rna_fwd_kernel(FwdArgs g) {
                         *reinterpret_cast<rb_u2*>(sA + m * pitch + k) = pack4(o);
                     }
             } else {
-                rb_u2 v[4][8];
+                rb_u2 v[4][QPL];
 #pragma unroll
                 for (int i = 0; i < 4; i++)
 #pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        const int m = min(wave + 4 * (i0 + i), g.B - 1), k = min(2048 * c + 4 * (lane + 64 * j), K - 4);
+                    for (int j = 0; j < QPL; j++) {
+                        const int m = min(wave + 4 * (i0 + i), g.B - 1), k = min(256 * QPL * c + 4 * (lane + 64 * j), K - 4);
                         v[i][j] = *reinterpret_cast<const rb_u2*>(reinterpret_cast<const bf16_t*>(g.a) + (long)m * K + k);
                     }
 #pragma unroll
                 for (int i = 0; i < 4; i++)
 #pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        const int m = wave + 4 * (i0 + i), k = 2048 * c + 4 * (lane + 64 * j);
+                    for (int j = 0; j < QPL; j++) {
+                        const int m = wave + 4 * (i0 + i), k = 256 * QPL * c + 4 * (lane + 64 * j);
                         if (k >= K) continue;
                         *reinterpret_cast<rb_u2*>(sA + m * pitch + k) = m < g.B ? v[i][j] : rb_u2{0u, 0u};
                     }
@@ -240,14 +240,20 @@ int launch_fwd(const FwdArgs& a, hipStream_t s) {
     const size_t lds = fwd_lds(MT, a.K);
     dim3 grid(mh_cdiv(a.N, 16));
     static const bool attr = [] {       // operand images above 64 KiB (K = 2048 at B = 16) need the opt-in
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rna_fwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rna_fwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+#define RNA_A(MT_, Q_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rna_fwd_kernel<MT_, Q_>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024)
+        RNA_A(1, 2); RNA_A(1, 4); RNA_A(1, 8); RNA_A(2, 2); RNA_A(2, 4); RNA_A(2, 8);
+#undef RNA_A
         return true;
     }();
     (void)attr;
     if (lds > 158 * 1024) { mh_set_error("rna block: operand image of %zu bytes exceeds the 160 KiB of LDS", lds); return MH_EINVAL; }
-    if (MT == 1) hipLaunchKernelGGL((rna_fwd_kernel<1>), grid, dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((rna_fwd_kernel<2>), grid, dim3(256), lds, s, a);
+    // the prologue handles 256 QPL columns per pass: pick the smallest instance that covers K in one pass (compact code,
+    // no predicated-off loads), 8 (2048 columns per pass) beyond
+#define RNA_F(MT_, Q_) hipLaunchKernelGGL((rna_fwd_kernel<MT_, Q_>), grid, dim3(256), lds, s, a)
+    const int q = a.K <= 512 ? 2 : (a.K <= 1024 ? 4 : 8);
+    if (MT == 1) { if (q == 2) RNA_F(1, 2); else if (q == 4) RNA_F(1, 4); else RNA_F(1, 8); }
+    else { if (q == 2) RNA_F(2, 2); else if (q == 4) RNA_F(2, 4); else RNA_F(2, 8); }
+#undef RNA_F
     return 0;
 }
 
@@ -294,7 +300,7 @@ __device__ __forceinline__ rb_f4 gval4(const BwdArgs& g, const float* c12, int m
     return v;
 }
 
-template <int MT>
+template <int MT, int QPL>
 __global__ __launch_bounds__(256) void rna_bwd_kernel(BwdArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ float c12[64];
@@ -338,9 +344,9 @@ __global__ __launch_bounds__(256) void rna_bwd_kernel(BwdArgs g) {
     }
     if (g.src == 2) {        // row constants of LayerNorm': c1 = mean(dh gamma), c2 = mean(dh gamma xhat); M <= 2048 (host check)
         for (int i0 = 0; i0 < MT * 4; i0 += 4) {
-            rb_f4 xv[4][8], dv[4][8], gm[8];
+            rb_f4 xv[4][QPL], dv[4][QPL], gm[QPL];
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
+            for (int j = 0; j < QPL; j++) {
                 const int n = min(4 * (lane + 64 * j), M - 4);
                 gm[j] = *reinterpret_cast<const rb_f4*>(g.gamma + n);
 #pragma unroll
@@ -356,7 +362,7 @@ __global__ __launch_bounds__(256) void rna_bwd_kernel(BwdArgs g) {
                 const float mean = g.stats[m], rstd = g.stats[g.B + m];
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                for (int j = 0; j < 8; j++)
+                for (int j = 0; j < QPL; j++)
                     if (4 * (lane + 64 * j) < M) {
                         const rb_f4 xh = (xv[i][j] - mean) * rstd, a = dv[i][j] * gm[j];
                         s1 += a[0] + a[1] + a[2] + a[3];
@@ -375,22 +381,22 @@ __global__ __launch_bounds__(256) void rna_bwd_kernel(BwdArgs g) {
         const int pitch = M + PADK;
         float* red = reinterpret_cast<float*>(smem + (size_t)MT * 16 * pitch * 2);
         // four rows x 8 quads per lane in flight (a 2048-column chunk), as in the forward prologue
-        const int nchunk = (M + 2047) / 2048;
+        const int nchunk = (M + 256 * QPL - 1) / (256 * QPL);
         for (int i0 = 0; i0 < MT * 4; i0 += 4)
             for (int c = 0; c < nchunk; c++) {
-                rb_f4 v[4][8];
+                rb_f4 v[4][QPL];
 #pragma unroll
                 for (int i = 0; i < 4; i++)
 #pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        const int m = min(wave + 4 * (i0 + i), g.B - 1), n = min(2048 * c + 4 * (lane + 64 * j), M - 4);
+                    for (int j = 0; j < QPL; j++) {
+                        const int m = min(wave + 4 * (i0 + i), g.B - 1), n = min(256 * QPL * c + 4 * (lane + 64 * j), M - 4);
                         v[i][j] = gval4(g, c12, m, n);
                     }
 #pragma unroll
                 for (int i = 0; i < 4; i++)
 #pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        const int m = wave + 4 * (i0 + i), n = 2048 * c + 4 * (lane + 64 * j);
+                    for (int j = 0; j < QPL; j++) {
+                        const int m = wave + 4 * (i0 + i), n = 256 * QPL * c + 4 * (lane + 64 * j);
                         if (n >= M) continue;
                         rb_f4 o = {0.f, 0.f, 0.f, 0.f};
                         if (m < g.B) o = v[i][j] * drop4(g.drop, (long)m * M + n);
@@ -508,19 +514,24 @@ int launch_bwd(BwdArgs a, hipStream_t s) {
     dim3 grid(a.n_dgrad + n_wgrad);
     if (grid.x == 0) return 0;
     static const bool attr = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rna_bwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rna_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+#define RNA_A(MT_, Q_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rna_bwd_kernel<MT_, Q_>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024)
+        RNA_A(1, 2); RNA_A(1, 4); RNA_A(1, 8); RNA_A(2, 2); RNA_A(2, 4); RNA_A(2, 8);
+#undef RNA_A
         return true;
     }();
     (void)attr;
     if (lds > 158 * 1024) { mh_set_error("rna block: operand image of %zu bytes exceeds the 160 KiB of LDS", lds); return MH_EINVAL; }
-    if (MT == 1) hipLaunchKernelGGL((rna_bwd_kernel<1>), grid, dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((rna_bwd_kernel<2>), grid, dim3(256), lds, s, a);
+#define RNA_B(MT_, Q_) hipLaunchKernelGGL((rna_bwd_kernel<MT_, Q_>), grid, dim3(256), lds, s, a)
+    const int q = a.M <= 512 ? 2 : (a.M <= 1024 ? 4 : 8);
+    if (MT == 1) { if (q == 2) RNA_B(1, 2); else if (q == 4) RNA_B(1, 4); else RNA_B(1, 8); }
+    else { if (q == 2) RNA_B(2, 2); else if (q == 4) RNA_B(2, 4); else RNA_B(2, 8); }
+#undef RNA_B
     return 0;
 }
 
 // dx = r + LayerNorm'(dh; x, stats, gamma); dgamma += sum_m dh xhat; dbeta += sum_m dh.  One workgroup per 64-column slab;
 // every workgroup recomputes the 2 B row constants from the whole [B, D] operands (all loads of four rows in flight).
+template <int QPL>
 __global__ __launch_bounds__(256) void rna_ln_bwd_res_kernel(const float* __restrict__ r, const float* __restrict__ dh, const float* __restrict__ x,
                                                              const float* __restrict__ stats, const float* __restrict__ gamma, float* __restrict__ dx,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int D) {
@@ -529,9 +540,9 @@ __global__ __launch_bounds__(256) void rna_ln_bwd_res_kernel(const float* __rest
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i0 = 0; i0 < 8; i0 += 4) {
         if (wave + 4 * i0 >= B) break;
-        rb_f4 xv[4][8], dv[4][8], gm[8];
+        rb_f4 xv[4][QPL], dv[4][QPL], gm[QPL];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
+        for (int j = 0; j < QPL; j++) {
             const int n = min(4 * (lane + 64 * j), D - 4);
             gm[j] = *reinterpret_cast<const rb_f4*>(gamma + n);
 #pragma unroll
@@ -547,7 +558,7 @@ __global__ __launch_bounds__(256) void rna_ln_bwd_res_kernel(const float* __rest
             const float mean = stats[m], rstd = stats[B + m];
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; j++)
+            for (int j = 0; j < QPL; j++)
                 if (4 * (lane + 64 * j) < D) {
                     const rb_f4 xh = (xv[i][j] - mean) * rstd, a = dv[i][j] * gm[j];
                     s1 += a[0] + a[1] + a[2] + a[3];
@@ -680,8 +691,9 @@ extern "C" int mh_rna_block_bwd(const mh_rna_block* b, mh_stream s) {
     a.xsrc = 1; a.xl = b->x; a.stats_l = b->stats; a.gamma_l = b->g1; a.beta_l = b->be1; a.dw = b->dw_qkv; a.db = b->db_qkv;
     if (int rc = launch_bwd(a, st)) return rc;
     // dx = dx1 + LN1'(dh1)
-    hipLaunchKernelGGL(rna_ln_bwd_res_kernel, dim3(mh_cdiv(D, 64)), dim3(256), 0, st, (const float*)dx1, (const float*)dh1, b->x, (const float*)b->stats, b->g1, b->dx, b->dg1,
-                       b->dbe1, B, D);
+#define RNA_L(Q_) hipLaunchKernelGGL((rna_ln_bwd_res_kernel<Q_>), dim3(mh_cdiv(D, 64)), dim3(256), 0, st, (const float*)dx1, (const float*)dh1, b->x, (const float*)b->stats, b->g1, b->dx, b->dg1, b->dbe1, B, D)
+    if (D <= 512) RNA_L(2); else if (D <= 1024) RNA_L(4); else RNA_L(8);
+#undef RNA_L
     MH_LAUNCH_CHECK("mh_rna_block_bwd");
     return MH_OK;
 }
