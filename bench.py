@@ -190,14 +190,19 @@ def main():
             eng.step(w_, r_)
     sync_all()
     t0 = time.perf_counter()
+    host_us = []                                  # host time inside each step() call (MIRROR_BENCH_HOSTTIME=1 prints it to stderr)
     if feed is None:
         for _ in range(a.steps):
+            h0 = time.perf_counter()
             losses = eng.step(wsi, rna)
+            host_us.append((time.perf_counter() - h0) * 1e6)
     else:
         for w_, r_ in it:
             losses = eng.step(w_, r_)
     sync_all()
     dt = time.perf_counter() - t0
+    if os.environ.get("MIRROR_BENCH_HOSTTIME") and rank == 0 and host_us:
+        print("host us per step() call: " + " ".join(f"{u:.0f}" for u in host_us), file=sys.stderr)
     loss_vals = [float(x) for x in losses]
     # ---- roofline leg: the dominant kernel's launches carry HIP event pairs on their launch stream.  Events cannot be
     #      recorded inside a graph replay, so the same steps are run once more eagerly right here (same process, same

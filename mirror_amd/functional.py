@@ -731,7 +731,7 @@ _side_streams: dict = {}
 
 
 def _side_stream(device, which: int = 0) -> torch.cuda.Stream:
-    """Per-device helper streams: 0 = half-chip pinv chain, 1 = RNA encoder."""
+    """Per-device helper streams: 0 = half-chip pinv chain, 1 = RNA encoder + alignment / style heads."""
     if os.environ.get("MIRROR_EXP_NO_SIDE", "") and str(which) in os.environ["MIRROR_EXP_NO_SIDE"]:
         return torch.cuda.current_stream()      # experiment: serialise this branch on the caller's stream
     key = (torch.device(device).index or 0, which)

@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import logging
 import math
+import os
 from typing import Dict, Optional, Tuple
 
 import numpy as np
@@ -27,6 +28,11 @@ _logger = logging.getLogger(__name__)
 f32 = torch.float32
 
 _DEFAULT_PRECISION: Optional[str] = None
+
+# program order of the two encoder branches in MIRROR.forward (see there): 1 = WSI encoder launches first (default)
+_RNA_LATE = os.environ.get("MIRROR_RNA_LATE", "1") != "0"
+# 1 (default) = the alignment / style heads run on the RNA branch's helper stream, 0 = on the caller's stream (A/B switch)
+_HEADS_SIDE = os.environ.get("MIRROR_HEADS_SIDE", "1") != "0"
 
 
 def set_precision(name: Optional[str]) -> None:
@@ -453,6 +459,7 @@ class MIRROR(nn.Module):
         self.prototypes = nn.Linear(embed_dim, num_prototypes, bias=False)
         nn.init.orthogonal_(self.prototypes.weight)
         self._precision: Optional[str] = None
+        self._rna_drop_n: Dict[tuple, int] = {}      # dropout offsets the RNA branch consumes, per (shape, mode): see forward()
 
     @property
     def precision(self) -> Optional[str]:
@@ -518,34 +525,72 @@ class MIRROR(nn.Module):
         # backward overlaps the WSI backward as well.
         main = torch.cuda.current_stream()
         side = Fn._side_stream(dev, 1)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            # the WSI token mask depends on the noise alone: rank it here, long before the retention decoder needs it
-            n_tok = wsi_emb.shape[1]
-            wsi_mask = Fn.rank_mask(noise["wsi_mask"], int(n_tok * (1 - wsi_mask_ratio)))
-            mask_ready = side.record_event()
-            g = getattr(self, "_rna_graph", None)      # TrainEngine's HIP-graph replay of this branch (graphed.py)
-            if (g is not None and g[1] == rna_mask_ratio and self.training and torch.is_grad_enabled()
-                    and not torch.cuda.is_current_stream_capturing() and Fn._dropout_state["offset"] == 0   # offsets baked at 0
-                    and g[0].matches((rna_emb, noise["rna_mask"]))):
-                rna_emb, rna_alignment_emb, rna_retention_emb, rna_mask = g[0](rna_emb, noise["rna_mask"])
-            else:
-                rna_emb, rna_alignment_emb, rna_retention_emb, rna_mask = self.rna_branch(
-                    rna_emb, noise["rna_mask"], rna_mask_ratio)
-        wsi_emb = self.wsi_encoder.forward_encoder(wsi_emb, wsi_key_padding_mask)
+        fork = main.record_event()
+        wsi_in, rna_in = wsi_emb, rna_emb
+
+        def run_side():
+            side.wait_event(fork)
+            with torch.cuda.stream(side):
+                # the WSI token mask depends on the noise alone: rank it here, long before the retention decoder needs it
+                n_tok = wsi_in.shape[1]
+                mask_ = Fn.rank_mask(noise["wsi_mask"], int(n_tok * (1 - wsi_mask_ratio)))
+                ready_ = side.record_event()
+                g = getattr(self, "_rna_graph", None)      # TrainEngine's HIP-graph replay of this branch (graphed.py)
+                if (g is not None and g[1] == rna_mask_ratio and self.training and torch.is_grad_enabled()
+                        and not torch.cuda.is_current_stream_capturing() and Fn._dropout_state["offset"] == 0   # offsets baked at 0
+                        and g[0].matches((rna_in, noise["rna_mask"]))):
+                    outs_ = g[0](rna_in, noise["rna_mask"])
+                else:
+                    outs_ = self.rna_branch(rna_in, noise["rna_mask"], rna_mask_ratio)
+            return mask_, ready_, outs_
+
+        # Launch ORDER matters even though the two branches are independent: launches (and the nodes of a captured graph) reach
+        # the GPU in program order at a few microseconds each, so ~70 tiny RNA kernels issued first keep the first WSI GEMM
+        # waiting for ~0.5 ms, while issued after the WSI encoder's launches they run underneath its long kernels.  Autograd
+        # replays later-created nodes first, so the RNA backward is then issued before the WSI backward and overlaps it
+        # instead of trailing it.
+        # The dropout offsets stay those of the RNA-first order (the RNA branch's HIP-graph replay has them baked in, and the
+        # masks do not depend on the launch order): the RNA range is reserved up front once its length is known.
+        st = Fn._dropout_state
+        key = (tuple(rna_emb.shape), self.training, torch.is_grad_enabled(), rna_mask_ratio)
+        n_rna = self._rna_drop_n.get(key) if _RNA_LATE else None
+        if n_rna is not None:
+            off0 = st["offset"]
+            st["offset"] = off0 + n_rna
+            wsi_emb = self.wsi_encoder.forward_encoder(wsi_in, wsi_key_padding_mask)
+            off_w, st["offset"] = st["offset"], off0
+            wsi_mask, mask_ready, (rna_emb, rna_alignment_emb, rna_retention_emb, rna_mask) = run_side()
+            if st["offset"] != off0 + n_rna:
+                raise MirrorHipError("the RNA branch consumed a different number of dropout offsets than on its first run")
+            st["offset"] = off_w
+        else:
+            off0 = st["offset"]
+            wsi_mask, mask_ready, (rna_emb, rna_alignment_emb, rna_retention_emb, rna_mask) = run_side()
+            self._rna_drop_n[key] = st["offset"] - off0
+            wsi_emb = self.wsi_encoder.forward_encoder(wsi_in, wsi_key_padding_mask)
         # the encoder output has three consumers (decoder input, retention target, cls row): one node sums their gradients
         wsi_full, wsi_retention_target, wsi_cls = Fn.enc_fanout(wsi_emb)
-        wsi_alignment_emb = self.wsi_encoder.forward_alignment_head(wsi_cls)
+        # The alignment head of the cls row and the two style / prototype branches are ~25 forward and ~50 backward launches on
+        # [B, D] rows (they share their weights, so they stay on ONE stream: their weight gradients accumulate in place): on the
+        # RNA branch's stream they run beside the retention decoder (a whole TransLayer) instead of in front of its backward.
+        # (A third helper stream that waits for both the main and the RNA stream before its first kernel makes
+        # hipStreamEndCapture of the whole-step graph segfault on ROCm 7.2.)
+        heads = side if _HEADS_SIDE else main
+        heads.wait_event(main.record_event())
+        wsi_cls.record_stream(heads)
+        with torch.cuda.stream(heads):
+            wsi_alignment_emb = self.wsi_encoder.forward_alignment_head(wsi_cls)
+            wsi_score, wsi_mu, wsi_logstd, rna_score, rna_mu, rna_logstd = self.forward_style_clustering(
+                wsi_cls, rna_emb, noise.get("wsi_eps"), noise.get("rna_eps"))
         main.wait_event(mask_ready)
         wsi_mask.record_stream(main)
         wsi_retention_emb, wsi_mask = self.wsi_encoder.forward_retention_head(
             wsi_full, mask_ratio=wsi_mask_ratio, mask=wsi_mask, key_padding_mask=wsi_key_padding_mask)
         main.wait_stream(side)
-        for t in (rna_emb, rna_alignment_emb, rna_retention_emb, rna_mask):
-            t.record_stream(main)       # allocated in the side stream's pool, consumed on the main stream
+        for t in (rna_emb, rna_alignment_emb, rna_retention_emb, rna_mask, wsi_alignment_emb, wsi_score, wsi_mu, wsi_logstd,
+                  rna_score, rna_mu, rna_logstd):
+            t.record_stream(main)       # allocated in a helper stream's pool, consumed on the main stream
         rna_retention_target = rna_emb
-        wsi_score, wsi_mu, wsi_logstd, rna_score, rna_mu, rna_logstd = self.forward_style_clustering(
-            wsi_cls, rna_emb, noise.get("wsi_eps"), noise.get("rna_eps"))
         return (wsi_alignment_emb, wsi_retention_emb, wsi_retention_target, wsi_mask, wsi_score, wsi_mu, wsi_logstd,
                 rna_alignment_emb, rna_retention_emb, rna_retention_target, rna_mask, rna_score, rna_mu, rna_logstd,
                 self.logit_scale.exp())

@@ -290,5 +290,8 @@ def test_fp8_forward_policy_is_close_and_trains():
     t_exact, n_exact = run(False)
     assert n_exact == 0 and n_del >= 3 * 8 * 2, (n_exact, n_del)       # steps 3..5 x >= 8 sites x (activation + weight)
     assert np.isfinite(t_del).all()
-    np.testing.assert_allclose(t_del[:2], t_exact[:2], rtol=1e-5)      # the first two steps ARE the exact path
-    np.testing.assert_allclose(t_del[2:], t_exact[2:], rtol=5e-2)
+    # the first two steps ARE the exact path: step 1 agrees to rounding; step 2 sits behind one Adam update, whose first step
+    # moves every weight by lr * sign(g), so parameters whose gradient is f32-atomics noise around zero make it run-to-run
+    # bimodal (3e-3 here, with or without delayed scaling)
+    np.testing.assert_allclose(t_del[0], t_exact[0], rtol=1e-5)
+    np.testing.assert_allclose(t_del[1:], t_exact[1:], rtol=5e-2)
