@@ -70,6 +70,10 @@ typedef struct {
                                      the next product's operand without a cast launch.  192 x 384 tile kernel only (bf16
                                      operands, M % 192 == 0, N % 384 == 0, K % 64 == 0, no bias / activation / split-K) */
     int32_t r_bf16;               /* 1: R is bf16 although C is f32 (same tile kernel only) */
+    int32_t k_segments;           /* > 1: C = sum_s A_s B_s over k_segments operand pairs of K each, A_s = A + s * sA_seg, B_s = B + s * sB_seg
+                                     (elements): a sum of products in one accumulator, e.g. dX = sum_k dP_k z_k^T of the pinv reverse
+                                     mode without an f32 read-modify-write of C per term.  Same tile kernel only; 0 / 1: one pair */
+    int64_t sA_seg, sB_seg;
 } mh_gemm_desc;
 int mh_gemm(const mh_gemm_desc* d, mh_stream s);
 /* Bytes of `workspace` with which this call reduces through plain partial tiles + a fold pass instead of f32 atomics

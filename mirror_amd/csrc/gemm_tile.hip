@@ -82,7 +82,10 @@ __global__ __launch_bounds__(NTT) void gemm_tile_kernel(GemmArgs g, bf16_t* __re
     const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A) + b1 * g.sA1 + b2 * g.sA2;
     const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B) + b1 * g.sB1 + b2 * g.sB2;
     const long coff = b1 * g.sC1 + b2 * g.sC2;
-    const int nt = g.K / TBK;
+    // K loop over kseg operand pairs of K each (a sum of products in ONE accumulator: the f32 C never goes through HBM in between)
+    const int nts = g.K / TBK, nt = nts * max(g.kseg, 1);
+    auto a_of = [&](int t) { return A + (long)(t / nts) * g.sAk; };
+    auto b_of = [&](int t) { return B + (long)(t / nts) * g.sBk; };
 
     f32x16 acc[TWM][TWN];
 #pragma unroll
@@ -98,8 +101,8 @@ __global__ __launch_bounds__(NTT) void gemm_tile_kernel(GemmArgs g, bf16_t* __re
     t_store<AKC, TM>(ra, smem, tid);
     t_store<BKC, TN>(rb, smem + GA::BYTES, tid);
     if (nt > 1) {
-        t_load<AKC, TM>(ra, A, g.lda, tile_m * TM, TBK, tid);
-        t_load<BKC, TN>(rb, B, g.ldb, tile_n * TN, TBK, tid);
+        t_load<AKC, TM>(ra, a_of(1), g.lda, tile_m * TM, (1 % nts) * TBK, tid);
+        t_load<BKC, TN>(rb, b_of(1), g.ldb, tile_n * TN, (1 % nts) * TBK, tid);
     }
     __syncthreads();
     for (int t = 0; t < nt; t++) {
@@ -108,8 +111,8 @@ __global__ __launch_bounds__(NTT) void gemm_tile_kernel(GemmArgs g, bf16_t* __re
             t_store<AKC, TM>(ra, smem + (cur ^ 1) * STAGE, tid);
             t_store<BKC, TN>(rb, smem + (cur ^ 1) * STAGE + GA::BYTES, tid);
             if (t + 2 < nt) {
-                t_load<AKC, TM>(ra, A, g.lda, tile_m * TM, (t + 2) * TBK, tid);
-                t_load<BKC, TN>(rb, B, g.ldb, tile_n * TN, (t + 2) * TBK, tid);
+                t_load<AKC, TM>(ra, a_of(t + 2), g.lda, tile_m * TM, ((t + 2) % nts) * TBK, tid);
+                t_load<BKC, TN>(rb, b_of(t + 2), g.ldb, tile_n * TN, ((t + 2) % nts) * TBK, tid);
             }
         }
         const char* at = smem + cur * STAGE;
@@ -177,7 +180,7 @@ bool gemm_try_tile384(GemmArgs& a, int akc, int bkc, int dtC, int batch, void* c
                     a.act == MH_ACT_NONE && a.vecA && a.vecB && a.vecC && !(akc == 0 && bkc == 1);
     if (!ok) return false;
     const long wgs = (long)(a.M / TM) * (a.N / TN) * batch;
-    if (wgs < 64 && !c2 && !r_bf16) return false;      // a few tiles: the 128 x 128 kernel spreads better
+    if (wgs < 64 && !c2 && !r_bf16 && a.kseg <= 1) return false;      // a few tiles: the 128 x 128 kernel spreads better
     a.tiles_m = a.M / TM;
     a.tiles_n = a.N / TN;
     dim3 grid(a.tiles_m * a.tiles_n, 1, batch);

@@ -801,42 +801,68 @@ def pinv_backward(a2, saved, st, dZ, pm, sd):
 
 def pinv_forward_tile(a2: torch.Tensor, iters: int):
     """pinv_forward for landmark counts the 192 x 384 tile kernel takes (the template's m = 384): every operand bf16, f32
-    accumulation inside a product, one launch per product at one workgroup per CU (csrc/gemm_tile.hip)."""
+    accumulation inside a product, one launch per product at one workgroup per CU (csrc/gemm_tile.hip).  The iterates are
+    written into stacks (zs[k] = z_k; pt[k] = (T2_k, P_k)) so that the backward pass can sum products over an iteration's or
+    the whole chain's operand pairs in one launch (K.gemm_ksum)."""
     st = K.pinv_absmax(a2)
-    z = K.cast(K.pinv_z0(a2, st), bf16)
     a2b = K.cast(a2, bf16)
+    zs = torch.empty((iters + 1,) + tuple(a2.shape), device=a2.device, dtype=bf16)
+    pt = torch.empty((iters, 2) + tuple(a2.shape), device=a2.device, dtype=bf16)
+    K.cast(K.pinv_z0(a2, st), bf16, out=zs[0])
     saved = []
-    for _ in range(iters):
-        P = K.gemm(a2b, z, mma=MH_BF16)
-        T2 = K.gemm(P, P, diag=15.0, R=P, rcoef=-7.0, mma=MH_BF16)
+    for k in range(iters):
+        z, P, T2 = zs[k], pt[k, 1], pt[k, 0]
+        K.gemm(a2b, z, P, mma=MH_BF16)
+        K.gemm(P, P, T2, diag=15.0, R=P, rcoef=-7.0, mma=MH_BF16)
         T3 = K.gemm(P, T2, alpha=-1.0, diag=13.0, mma=MH_BF16)
-        zn = K.gemm(z, T3, alpha=0.25, mma=MH_BF16)
+        K.gemm(z, T3, zs[k + 1], alpha=0.25, mma=MH_BF16)
         saved.append((z, P, T2, T3))
-        z = zn
-    return z, saved, st
+    return zs[iters], saved, st
 
 
 def pinv_backward_tile(a2, saved, st, dZ):
-    """Reverse mode of pinv_forward_tile: 8 products per iteration, operands bf16; sums of several products accumulate in
-    f32 C and the launch that completes one writes its bf16 copy (the next operand) in the same epilogue."""
+    """Reverse mode of pinv_forward_tile, operands bf16.  Sums of products that share an operand layout run as ONE launch over
+    several operand pairs (K.gemm_ksum: the f32 sum stays in the accumulators): dP's two `x @ y^T` terms per iteration, and
+    dX = sum_k dP_k z_k^T over the whole chain at the end; the launch that completes a sum writes its bf16 copy (the next
+    operand) in the same epilogue."""
     tr = lambda t: t.transpose(-1, -2)  # noqa: E731
+    iters = len(saved)
     a2b = K.cast(a2, bf16)
-    dX = torch.zeros_like(a2)
     dz = K.cast(dZ, bf16) if dZ.dtype != bf16 else dZ
     dzn = dZ
-    for z, P, T2, T3 in reversed(saved):
-        dT3 = K.gemm(tr(z), dz, alpha=0.25, mma=MH_BF16)                               # z' = 1/4 z T3
+    z0 = saved[0][0]
+    stacked = (iters > 1 and saved[1][0].data_ptr() - z0.data_ptr() == z0.numel() * 2
+               and saved[0][1].data_ptr() - saved[0][2].data_ptr() == z0.numel() * 2)     # pinv_forward_tile's stacks
+    dPs = torch.empty((iters,) + tuple(a2.shape), device=a2.device, dtype=bf16)
+    dd = torch.empty((2,) + tuple(a2.shape), device=a2.device, dtype=bf16)
+    for k in range(iters - 1, -1, -1):
+        z, P, T2, T3 = saved[k]
+        nT3, dT2, dPb = dd[0], dd[1], dPs[k]
+        K.gemm(tr(z), dz, nT3, alpha=-0.25, mma=MH_BF16)                               # z' = 1/4 z T3:  nT3 = -dT3
         dzn = K.gemm(dz, tr(T3), alpha=0.25, mma=MH_BF16, out_dtype=f32)
-        dT2 = K.gemm(tr(P), dT3, alpha=-1.0, mma=MH_BF16)                              # T3 = 13I - P T2
-        dP = K.gemm(dT3, tr(T2), alpha=-1.0, mma=MH_BF16, out_dtype=f32)
-        K.gemm(dT2, tr(P), out=dP, accumulate=True, R=dT2, rcoef=-7.0, mma=MH_BF16)    # T2 = 15I - 7P + P P
-        dPb = torch.empty(dP.shape, device=dP.device, dtype=bf16)
+        K.gemm(tr(P), nT3, dT2, mma=MH_BF16)                                           # T3 = 13I - P T2: dT2 = -P^T dT3
+        if stacked:     # dP = -dT3 T2^T + dT2 P^T - 7 dT2 (T2 = 15I - 7P + P P) in one launch over the pairs (nT3, T2), (dT2, P)
+            dP = K.gemm_ksum(dd, tr(_pair(T2, P)), R=dT2, rcoef=-7.0, mma=MH_BF16, out_dtype=f32)
+        else:
+            dP = K.gemm(nT3, tr(T2), mma=MH_BF16, out_dtype=f32)
+            K.gemm(dT2, tr(P), out=dP, accumulate=True, R=dT2, rcoef=-7.0, mma=MH_BF16)
         K.gemm(tr(P), dT2, out=dP, accumulate=True, mma=MH_BF16, c2=dPb)
-        K.gemm(dPb, tr(z), out=dX, accumulate=True, mma=MH_BF16)                       # P = a2 z
         dz = torch.empty(dzn.shape, device=dzn.device, dtype=bf16)
-        K.gemm(tr(a2b), dPb, out=dzn, accumulate=True, mma=MH_BF16, c2=dz)
-    K.pinv_z0_bwd(a2, K.cast(saved[0][0], f32), dzn, st, dX)
+        K.gemm(tr(a2b), dPb, out=dzn, accumulate=True, mma=MH_BF16, c2=dz)             # P = a2 z
+    if stacked:
+        zst = torch.as_strided(z0, (iters,) + tuple(z0.shape), (z0.numel(),) + tuple(z0.stride()))
+        dX = K.gemm_ksum(dPs, tr(zst), mma=MH_BF16, out_dtype=f32)
+    else:
+        dX = torch.zeros_like(a2)
+        for k in range(iters):
+            K.gemm(dPs[k], tr(saved[k][0]), out=dX, accumulate=True, mma=MH_BF16)
+    K.pinv_z0_bwd(a2, K.cast(z0, f32), dzn, st, dX)
     return dX
+
+
+def _pair(first: torch.Tensor, second: torch.Tensor) -> torch.Tensor:
+    """[2, ...] view of two equally shaped tensors that sit one tensor apart in memory (first, then second)."""
+    return torch.as_strided(first, (2,) + tuple(first.shape), (first.numel(),) + tuple(first.stride()))
 
 
 class NystromCoreFn(Function):

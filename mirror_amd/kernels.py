@@ -73,10 +73,12 @@ def _mat(t: torch.Tensor):
 def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *, alpha: float = 1.0,
          diag: float = 0.0, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, accumulate: bool = False,
          split_k: int = 1, mma: int = MH_F32, out_dtype: Optional[torch.dtype] = None,
-         R: Optional[torch.Tensor] = None, rcoef: float = 0.0, c2: Optional[torch.Tensor] = None) -> torch.Tensor:
+         R: Optional[torch.Tensor] = None, rcoef: float = 0.0, c2: Optional[torch.Tensor] = None,
+         kseg: Optional[tuple] = None) -> torch.Tensor:
     """out[..] (+)= act(alpha * a @ b + diag*I + bias + rcoef*R) with a [..,M,K], b [..,K,N] given as (possibly
     transposed / strided / broadcast) views; <= 2 leading batch dims.  c2: optional bf16 tensor shaped and strided like `out`
-    that receives a copy of the final result (192 x 384 tile kernel only, see gemm_tile_ok)."""
+    that receives a copy of the final result (192 x 384 tile kernel only, see gemm_tile_ok).  kseg = (S, a_stride, b_stride):
+    the product becomes sum_s a_s @ b_s over S operand pairs that start a_stride / b_stride elements apart (gemm_ksum)."""
     _chk(a, b, out, bias)
     nd = max(a.dim(), b.dim())
     a4, a_rm, lda, sa1, sa2 = _mat(a)
@@ -135,6 +137,10 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *
         if c2.dtype != torch.bfloat16 or c2.numel() != o4.numel() or tuple(c2.stride()) != tuple(out.stride()):
             raise MirrorHipError("gemm: c2 must be a bf16 tensor with the output's shape and strides")
         d.C2 = c2.data_ptr()
+    if kseg is not None and int(kseg[0]) > 1:
+        if not (gemm_tile_ok(M, N, K, a4.dtype, b4.dtype) and bias is None and act == ACT_NONE and d.split_k == 1):
+            raise MirrorHipError("gemm: a sum over operand pairs (kseg) needs the 192 x 384 tile kernel (see gemm_tile_ok)")
+        d.k_segments, d.sA_seg, d.sB_seg = int(kseg[0]), int(kseg[1]), int(kseg[2])
     # reductions into one f32 C (split-K / a batch that broadcasts into C) on the large-tile kernel: give it room for plain
     # partial tiles + a fold pass (f32 atomics of a 64-way split cost more than the K loop).  `ws` stays alive until the call
     # is enqueued; the caching allocator keeps the block valid for stream-ordered use.
@@ -148,6 +154,15 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *
     else:
         prof.launch(d, lambda: _lib.call("mh_gemm", C.byref(d), stream=_stream()))
     return out
+
+
+def gemm_ksum(a_stack: torch.Tensor, b_stack: torch.Tensor, out: Optional[torch.Tensor] = None, **kw) -> torch.Tensor:
+    """sum_s a_stack[s] @ b_stack[s] in ONE launch and one accumulator (192 x 384 tile kernel): the operand pairs sit a constant
+    stride apart (the leading dim of the two stacks; a transpose of the trailing dims or a strided slice of a longer stack
+    is fine), so the K loop simply walks from one pair to the next and the f32 sum never takes a read-modify-write through HBM."""
+    if a_stack.shape[0] != b_stack.shape[0] or a_stack.shape[0] < 1:
+        raise MirrorHipError("gemm_ksum: the stacks need the same, non-zero leading length")
+    return gemm(a_stack[0], b_stack[0], out, kseg=(a_stack.shape[0], a_stack.stride(0), b_stack.stride(0)), **kw)
 
 
 def gemm_tile_ok(M: int, N: int, Kd: int, dta=torch.bfloat16, dtb=torch.bfloat16) -> bool:

@@ -133,6 +133,31 @@ def test_gemm_tile384_kernel(a_rm, b_t, out_dtype):
     close(c2, want.to(bf).double(), 0, 0, "tile bf16 copy")
 
 
+@pytest.mark.parametrize("a_rm,b_t", [(True, True), (True, False), (False, False)])
+def test_gemm_ksum_sums_operand_pairs_in_one_launch(a_rm, b_t):
+    """K.gemm_ksum (k_segments of mh_gemm_desc): sum_s A_s B_s over operand pairs a constant stride apart, one launch, one
+    accumulator — bit-exact on small integers, with an R addend, the bf16 copy and a strided stack."""
+    gen = g(131 + a_rm + 2 * b_t)
+    S, Bt, M, N, Kd = 3, 4, 384, 384, 128
+    bf = torch.bfloat16
+    a = ints((S, Bt, M, Kd), gen)
+    b = ints((S, Bt, Kd, N), gen)
+    a_dev = a.to(DEV, bf) if a_rm else a.transpose(-1, -2).contiguous().to(DEV, bf).transpose(-1, -2)
+    b_dev = b.to(DEV, bf) if not b_t else b.transpose(-1, -2).contiguous().to(DEV, bf).transpose(-1, -2)
+    ref = (a.double() @ b.double()).sum(0)
+    out = K.gemm_ksum(a_dev, b_dev, mma=MH_BF16, out_dtype=torch.float32)
+    close(out, ref, 0, 0, "ksum plain")
+    Rm = ints((Bt, M, N), gen)
+    c2 = torch.zeros((Bt, M, N), device=DEV, dtype=bf)
+    out = K.gemm_ksum(a_dev, b_dev, alpha=-1.0, R=Rm.to(DEV, bf), rcoef=-7.0, mma=MH_BF16, out_dtype=torch.float32, c2=c2)
+    want = (-ref - 7.0 * Rm.double()).float()
+    close(out, want.double(), 0, 0, "ksum alpha + bf16 R")
+    close(c2, want.to(bf).double(), 0, 0, "ksum bf16 copy")
+    # every second pair of a longer stack (pair stride = two matrices)
+    out = K.gemm_ksum(a_dev[::2], b_dev[::2], mma=MH_BF16, out_dtype=torch.float32)
+    close(out, (a[::2].double() @ b[::2].double()).sum(0), 0, 0, "ksum strided stack")
+
+
 def test_pinv_tile_path_matches_generic_path():
     """m = 384 (the template's landmark count): pinv_forward_tile / pinv_backward_tile (one 192 x 384-tile launch per product)
     against the generic bf16 path they replace and, loosely, against f64 autograd through the same iteration."""
