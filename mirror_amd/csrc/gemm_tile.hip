@@ -31,16 +31,19 @@ struct TGeo {
 
 template <int ROWS> using TRegs = u32x4[ROWS * 8 / NTT];
 
+// kend: the operand's K extent.  A K that is not a multiple of 64 (the 96-wide heads of the template geometry) ends in a partly
+// empty K-tile: chunks at k >= kend read as zeros (K % 8 == 0, so a 16-byte chunk is all in or all out).
 template <bool KC, int ROWS>
-__device__ __forceinline__ void t_load(TRegs<ROWS>& regs, const bf16_t* __restrict__ base, long ld, int tile0, int k0, int tid) {
+__device__ __forceinline__ void t_load(TRegs<ROWS>& regs, const bf16_t* __restrict__ base, long ld, int tile0, int k0, int kend, int tid) {
     constexpr int NCH = TGeo<KC, ROWS>::NCH;
 #pragma unroll
     for (int i = 0; i < NCH; i++) {
         const int cid = tid + i * NTT;
         long off;
-        if (KC) { const int r = cid >> 3, c = cid & 7; off = (long)(tile0 + r) * ld + k0 + 8 * c; }
-        else { constexpr int CPR = ROWS / 8; const int r = cid / CPR, c = cid % CPR; off = (long)(k0 + r) * ld + tile0 + 8 * c; }
-        regs[i] = *reinterpret_cast<const u32x4*>(base + off);
+        bool in;
+        if (KC) { const int r = cid >> 3, c = cid & 7; off = (long)(tile0 + r) * ld + k0 + 8 * c; in = k0 + 8 * c < kend; }
+        else { constexpr int CPR = ROWS / 8; const int r = cid / CPR, c = cid % CPR; off = (long)(k0 + r) * ld + tile0 + 8 * c; in = k0 + r < kend; }
+        regs[i] = in ? *reinterpret_cast<const u32x4*>(base + off) : u32x4{0u, 0u, 0u, 0u};
     }
 }
 template <bool KC, int ROWS>
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(NTT) void gemm_tile_kernel(GemmArgs g, bf16_t* __re
     const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B) + b1 * g.sB1 + b2 * g.sB2;
     const long coff = b1 * g.sC1 + b2 * g.sC2;
     // K loop over kseg operand pairs of K each (a sum of products in ONE accumulator: the f32 C never goes through HBM in between)
-    const int nts = g.K / TBK, nt = nts * max(g.kseg, 1);
+    const int nts = (g.K + TBK - 1) / TBK, nt = nts * max(g.kseg, 1);
     auto a_of = [&](int t) { return A + (long)(t / nts) * g.sAk; };
     auto b_of = [&](int t) { return B + (long)(t / nts) * g.sBk; };
 
@@ -96,13 +99,13 @@ __global__ __launch_bounds__(NTT) void gemm_tile_kernel(GemmArgs g, bf16_t* __re
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
     u32x4 ra[GA::NCH], rb[GB::NCH];
-    t_load<AKC, TM>(ra, A, g.lda, tile_m * TM, 0, tid);
-    t_load<BKC, TN>(rb, B, g.ldb, tile_n * TN, 0, tid);
+    t_load<AKC, TM>(ra, A, g.lda, tile_m * TM, 0, g.K, tid);
+    t_load<BKC, TN>(rb, B, g.ldb, tile_n * TN, 0, g.K, tid);
     t_store<AKC, TM>(ra, smem, tid);
     t_store<BKC, TN>(rb, smem + GA::BYTES, tid);
     if (nt > 1) {
-        t_load<AKC, TM>(ra, a_of(1), g.lda, tile_m * TM, (1 % nts) * TBK, tid);
-        t_load<BKC, TN>(rb, b_of(1), g.ldb, tile_n * TN, (1 % nts) * TBK, tid);
+        t_load<AKC, TM>(ra, a_of(1), g.lda, tile_m * TM, (1 % nts) * TBK, g.K, tid);
+        t_load<BKC, TN>(rb, b_of(1), g.ldb, tile_n * TN, (1 % nts) * TBK, g.K, tid);
     }
     __syncthreads();
     for (int t = 0; t < nt; t++) {
@@ -111,8 +114,8 @@ __global__ __launch_bounds__(NTT) void gemm_tile_kernel(GemmArgs g, bf16_t* __re
             t_store<AKC, TM>(ra, smem + (cur ^ 1) * STAGE, tid);
             t_store<BKC, TN>(rb, smem + (cur ^ 1) * STAGE + GA::BYTES, tid);
             if (t + 2 < nt) {
-                t_load<AKC, TM>(ra, a_of(t + 2), g.lda, tile_m * TM, ((t + 2) % nts) * TBK, tid);
-                t_load<BKC, TN>(rb, b_of(t + 2), g.ldb, tile_n * TN, ((t + 2) % nts) * TBK, tid);
+                t_load<AKC, TM>(ra, a_of(t + 2), g.lda, tile_m * TM, ((t + 2) % nts) * TBK, g.K, tid);
+                t_load<BKC, TN>(rb, b_of(t + 2), g.ldb, tile_n * TN, ((t + 2) % nts) * TBK, g.K, tid);
             }
         }
         const char* at = smem + cur * STAGE;
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(NTT) void gemm_tile_kernel(GemmArgs g, bf16_t* __re
 // true when the tile kernel took the launch (bf16 operands only; no bias / activation / split-K)
 bool gemm_try_tile384(GemmArgs& a, int akc, int bkc, int dtC, int batch, void* c2, int r_bf16, hipStream_t s) {
     static const bool on = [] { const char* e = getenv("MH_GEMM_TILE384"); return !(e && e[0] == '0'); }();
-    const bool ok = on && a.M % TM == 0 && a.N % TN == 0 && a.K % TBK == 0 && a.k_per_split == a.K && a.split_k == 1 && !a.atomic && !a.bias &&
+    const bool ok = on && a.M % TM == 0 && a.N % TN == 0 && a.K % 8 == 0 && a.split_k == 1 && !a.atomic && !a.bias &&
                     a.act == MH_ACT_NONE && a.vecA && a.vecB && a.vecC && !(akc == 0 && bkc == 1);
     if (!ok) return false;
     const long wgs = (long)(a.M / TM) * (a.N / TN) * batch;

@@ -199,7 +199,7 @@ def gemm_variant(d: GemmDesc) -> str:
     okc = d.C % 16 == 0 and d.ldc % cvec == 0 and d.sC1 % cvec == 0 and d.sC2 % cvec == 0
     batch = d.batch1 * d.batch2
     atomic = split > 1 or (d.accumulate and batch > 1 and d.sC1 == 0 and d.sC2 == 0)
-    if (d.mma == MH_BF16 and d.dtA == MH_BF16 and d.dtB == MH_BF16 and d.M % 192 == 0 and d.N % 384 == 0 and kk == d.K and d.K % 64 == 0
+    if (d.mma == MH_BF16 and d.dtA == MH_BF16 and d.dtB == MH_BF16 and d.M % 192 == 0 and d.N % 384 == 0 and d.K % 8 == 0
             and split == 1 and not atomic and not d.bias and d.act == 0 and oka and okb and okc and not (not d.a_kc and d.b_kc)
             and ((d.M // 192) * (d.N // 384) * batch >= 64 or d.C2 or d.r_bf16) and os.environ.get("MH_GEMM_TILE384", "1")[:1] != "0"):
         return f"gemm_tile_kernel<{_TN[d.dtC]},{'true' if d.a_kc else 'false'},{'true' if d.b_kc else 'false'}>"

@@ -131,6 +131,11 @@ def test_gemm_tile384_kernel(a_rm, b_t, out_dtype):
     want = (ref + base.double() - 7.0 * Rm.double()).float()
     close(acc, want.to(out_dtype).double(), 0, 0, "tile accumulate + bf16 R")
     close(c2, want.to(bf).double(), 0, 0, "tile bf16 copy")
+    # K = 96 (the 96-wide heads of the template geometry): the second K-tile is half empty and reads as zeros
+    a_dev, a = _mk(a_rm, (Bt, M, 96), gen, bf, True)
+    b_dev, b = _mk(not b_t, (Bt, 96, N), gen, bf, True)
+    out = K.gemm(a_dev, b_dev, alpha=0.5, mma=MH_BF16, out_dtype=out_dtype)
+    close(out, (0.5 * (a.double() @ b.double())).float().to(out_dtype).double(), 0, 0, "tile ragged K")
 
 
 @pytest.mark.parametrize("a_rm,b_t", [(True, True), (True, False), (False, False)])
