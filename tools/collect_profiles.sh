@@ -4,7 +4,7 @@
 # template config line + kernel stats, host-feed (PCIe-inclusive) lines, B = 32 line.
 set -u
 TAG=${1:-r02_x}; R=$PWD; OUT=$R/gpurun_out/prof_$TAG; mkdir -p $OUT
-cd /tmp; export TMPDIR=/tmp
+cd /tmp; export TMPDIR=/tmp; export PYTHONPATH=$R
 python3 $R/bench.py > $OUT/${TAG}_c2_bench.json 2> $OUT/bench.err
 echo "[collect] bench done"; 
 rm -rf /tmp/p1; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -o r -- python3 $R/bench.py --no-cpu-baseline > $OUT/${TAG}_c2_bench_under_rocprof.json 2>/dev/null
@@ -34,4 +34,9 @@ MIRROR_GRAPH=0 python3 $R/bench.py --no-cpu-baseline > $OUT/${TAG}_c2_bench_eage
 python3 $R/tools/run_c4.py --batch 8 --steps 12 2>/dev/null | tail -1 > $OUT/${TAG}_c4_run.json
 (cd $R && bash tools/bench_world2_dryrun.sh) > $OUT/${TAG}_world2_gloo_dryrun.txt 2>&1
 python3 $R/tools/bench_rna.py 2>/dev/null | tail -3 > $OUT/${TAG}_rna_branch_alone.txt
+python3 $R/bench.py --precision fp8 --no-cpu-baseline > $OUT/${TAG}_c5_fp8_bench.json 2>/dev/null
+python3 $R/tools/bench_chain.py 2>/dev/null | grep -v amdgpu > $OUT/${TAG}_chain_and_attention_isolated.txt
+python3 $R/tools/trace_gemms.py template 2>/dev/null | grep -v amdgpu > $OUT/${TAG}_template_gemm_calls.txt
+python3 $R/tools/trace_gemms.py c2 2>/dev/null | grep -v amdgpu > $OUT/${TAG}_c2_gemm_calls.txt
+(cd $R && bash tools/trace_step_raw.sh ${TAG}_graph > /dev/null 2>&1 && python3 tools/prof_step_listing.py gpurun_out/${TAG}_graph_kernel_trace.csv > $OUT/${TAG}_c2_step_listing_graph_replay_traced.txt && rm -f gpurun_out/${TAG}_graph_kernel_trace.csv)
 ls -la $OUT
