@@ -55,7 +55,8 @@ struct TileGeom {
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-// FULL: 0 = guarded loads, 1 = whole tiles everywhere, 2 = whole tiles in M / N with a ragged last K-tile (K % VEC == 0)
+// FULL: 0 = guarded loads, 1 = whole tiles everywhere, 2 = whole tiles in M / N with a ragged last K-tile (K % VEC == 0),
+//       3 = this operand's free dimension ends inside the tile (dim % VEC == 0): clamped address + select, K whole
 template <int MMA, typename TG, bool KC, int ROWS, int FULL, int NT = 256>
 struct Stager {
     using G = TileGeom<MMA, KC, ROWS>;
@@ -87,6 +88,17 @@ struct Stager {
                 u32x4 v = *reinterpret_cast<const u32x4*>(base + o2);
                 if (!in) v = u32x4{0u, 0u, 0u, 0u};
                 regs[i] = v;
+            } else if constexpr (FULL == 3) {
+                // ragged free dimension only (N = 96 of the template's attention products): rows past the end re-read the last
+                // row (K-contiguous form, gm is clamped above: those results are never stored), chunks past the end read as zeros
+                if (KC) {
+                    regs[i] = *reinterpret_cast<const u32x4*>(base + off);
+                } else {
+                    const bool in = gm + VEC <= dim;
+                    u32x4 v = *reinterpret_cast<const u32x4*>(base + (long)gk * ld + min(gm, dim - VEC));
+                    if (!in) v = u32x4{0u, 0u, 0u, 0u};
+                    regs[i] = v;
+                }
             } else {
                 const bool row_ok = KC ? (gm < dim) : (gk < kend);
                 const int cstart = KC ? gk : gm;
@@ -310,7 +322,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    using SA = Stager<MMA, TA, AKC, BM, FULL>;
+    // FULL == 3: whole tiles in M and K, N ends inside the (single) column tile: only B's loads and the stores know about it
+    constexpr bool WHOLE = FULL == 1 || FULL == 2;
+    using SA = Stager<MMA, TA, AKC, BM, FULL == 3 ? 1 : FULL>;
     using SB = Stager<MMA, TB, BKC, BN, FULL>;
     u32x4 ra[SA::NCH], rb[SB::NCH];
     // One register set: K-tile t+1 is written to LDS right AFTER the barrier that frees its stage and tile t+2 is
@@ -373,7 +387,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
     const int row_base = tile_m * BM + wm * WM * 32, col_base = tile_n * BN + wn * WN * 32;
     const bool lead = (split == 0);
-    if constexpr (FULL && MMA == 1) {
+    if constexpr (WHOLE && MMA == 1) {
         static_assert(BM * (BN + 4) * 4 <= 2 * STAGE, "epilogue tile must fit the staging LDS");
         if (g.vecC && !g.atomic) {
             if (g.accumulate) epilogue_lds<TC, WM, WN, 1>(g, C, R, acc, smem, tile_m * BM, tile_n * BN, wm, wn, lane, tid, lead);
@@ -381,7 +395,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
             return;
         }
     }
-    if (FULL && tile_m * BM + BM <= g.M) {   // interior tile: unguarded stores
+    if (WHOLE && tile_m * BM + BM <= g.M) {   // interior tile: unguarded stores
         if (g.atomic) epilogue<TC, WM, WN, true, 2>(g, C, R, acc, row_base, col_base, lane, lead);
         else if (g.accumulate) epilogue<TC, WM, WN, true, 1>(g, C, R, acc, row_base, col_base, lane, lead);
         else epilogue<TC, WM, WN, true, 0>(g, C, R, acc, row_base, col_base, lane, lead);
@@ -407,6 +421,9 @@ static void launch_w(GemmArgs& a, int batch, hipStream_t s) {
     // dh = 96 products of the template geometry)
     constexpr int VMAX = (sizeof(TA) == 2 || sizeof(TB) == 2) ? 8 : 4;
     const bool ktail = MMA == 1 && mn_ok && !full && a.split_k == 1 && a.K % VMAX == 0 && a.K > BK && a.M % 128 == 0;
+    // N ends inside the one column tile (64 < N < 128, N % 8 == 0), everything else whole: FULL == 3
+    const bool ntail = MMA == 1 && !narrow && a.vecA && a.vecB && a.M % 128 == 0 && a.N % BN != 0 && a.N < BN && a.N % VMAX == 0 &&
+                       a.K % BK == 0 && a.k_per_split % BK == 0 && a.K % a.k_per_split == 0;
     dim3 grid(a.tiles_m * a.tiles_n, a.split_k, batch);
     if (narrow) {
         if (full) hipLaunchKernelGGL((gemm_kernel<MMA, TA, TB, TC, AKC, BKC, 2, 1, 1>), grid, dim3(256), 0, s, a);
@@ -415,6 +432,7 @@ static void launch_w(GemmArgs& a, int batch, hipStream_t s) {
         if (full) hipLaunchKernelGGL((gemm_kernel<MMA, TA, TB, TC, AKC, BKC, 2, 2, 1>), grid, dim3(256), 0, s, a);
         else if constexpr (MMA == 1 && sizeof(TA) == 2 && sizeof(TB) == 2) {
             if (ktail) hipLaunchKernelGGL((gemm_kernel<MMA, TA, TB, TC, AKC, BKC, 2, 2, 2>), grid, dim3(256), 0, s, a);
+            else if (ntail) hipLaunchKernelGGL((gemm_kernel<MMA, TA, TB, TC, AKC, BKC, 2, 2, 3>), grid, dim3(256), 0, s, a);
             else hipLaunchKernelGGL((gemm_kernel<MMA, TA, TB, TC, AKC, BKC, 2, 2, 0>), grid, dim3(256), 0, s, a);
         } else hipLaunchKernelGGL((gemm_kernel<MMA, TA, TB, TC, AKC, BKC, 2, 2, 0>), grid, dim3(256), 0, s, a);
     }

@@ -213,8 +213,10 @@ def gemm_variant(d: GemmDesc) -> str:
     full = mn_ok and kk % bk == 0 and kk % kps == 0
     ktail = (d.mma == MH_BF16 and d.dtA == MH_BF16 and d.dtB == MH_BF16 and wn == 2 and mn_ok and not full and split == 1
              and kk % 8 == 0 and kk > bk and d.M % 128 == 0)
+    ntail = (d.mma == MH_BF16 and d.dtA == MH_BF16 and d.dtB == MH_BF16 and wn == 2 and oka and okb and d.M % 128 == 0
+             and d.N % 128 != 0 and d.N < 128 and d.N % 8 == 0 and kk % bk == 0 and kk % kps == 0)
     return (f"gemm_kernel<{d.mma},{_TN[d.dtA]},{_TN[d.dtB]},{tc},{'true' if d.a_kc else 'false'},"
-            f"{'true' if d.b_kc else 'false'},2,{wn},{1 if full else (2 if ktail else 0)}>")
+            f"{'true' if d.b_kc else 'false'},2,{wn},{1 if full else (2 if ktail else (3 if ntail else 0))}>")
 
 
 class GemmProfiler:

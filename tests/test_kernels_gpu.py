@@ -138,6 +138,28 @@ def test_gemm_tile384_kernel(a_rm, b_t, out_dtype):
     close(out, (0.5 * (a.double() @ b.double())).float().to(out_dtype).double(), 0, 0, "tile ragged K")
 
 
+@pytest.mark.parametrize("a_rm,b_t", [(True, False), (False, False), (True, True)])
+def test_gemm_ragged_n_instances(a_rm, b_t):
+    """N = 96 (one column tile that ends inside: the attn·v / dS·k products of the template's 96-wide heads) with M and K whole
+    tiles: FULL == 3 instances of the 128 x 128 kernel (only B's loads and the stores are guarded) — bit-exact on small integers,
+    bf16 and f32 C, accumulate."""
+    gen = g(171 + a_rm + 2 * b_t)
+    bf = torch.bfloat16
+    Bt, M, N, Kd = 3, 384, 96, 192
+    a_dev, a = _mk(a_rm, (Bt, M, Kd), gen, bf, True)
+    b_dev, b = _mk(not b_t, (Bt, Kd, N), gen, bf, True)
+    ref = a.double() @ b.double()
+    for od in (bf, torch.float32):
+        out = torch.full((Bt, M, N + 8), 5.0, device=DEV, dtype=od)        # columns behind N must stay untouched
+        K.gemm(a_dev, b_dev, out=out[..., :N], alpha=0.5, mma=MH_BF16)
+        close(out[..., :N], (0.5 * ref).float().to(od).double(), 0, 0, "ragged N")
+        assert bool((out[..., N:] == 5.0).all())
+    base = ints((Bt, M, N), gen)
+    acc = base.to(DEV)
+    K.gemm(a_dev, b_dev, out=acc, accumulate=True, mma=MH_BF16)
+    close(acc, ref + base.double(), 0, 0, "ragged N accumulate")
+
+
 @pytest.mark.parametrize("a_rm,b_t", [(True, True), (True, False), (False, False)])
 def test_gemm_ksum_sums_operand_pairs_in_one_launch(a_rm, b_t):
     """K.gemm_ksum (k_segments of mh_gemm_desc): sum_s A_s B_s over operand pairs a constant stride apart, one launch, one
