@@ -74,6 +74,9 @@ typedef struct {
                                      (elements): a sum of products in one accumulator, e.g. dX = sum_k dP_k z_k^T of the pinv reverse
                                      mode without an f32 read-modify-write of C per term.  Same tile kernel only; 0 / 1: one pair */
     int64_t sA_seg, sB_seg;
+    int32_t row_softmax;          /* 1: C = softmax over each row of alpha * A B, written as bf16 (N == 384 = one tile row of the same
+                                     tile kernel; no R / accumulate / diag / C2): sim1 = q k_l^T of the template geometry (m = 384
+                                     landmarks, models/mirror.py:312 [3P] `attn1 = sim1.softmax(dim=-1)`) without the f32 logits round trip */
 } mh_gemm_desc;
 int mh_gemm(const mh_gemm_desc* d, mh_stream s);
 /* Bytes of `workspace` with which this call reduces through plain partial tiles + a fold pass instead of f32 atomics

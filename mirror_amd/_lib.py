@@ -31,6 +31,7 @@ class GemmDesc(C.Structure):
         ("workspace", C.c_void_p), ("workspace_floats", C.c_int64),
         ("C2", C.c_void_p), ("r_bf16", C.c_int32),
         ("k_segments", C.c_int32), ("sA_seg", C.c_int64), ("sB_seg", C.c_int64),
+        ("row_softmax", C.c_int32),
     ]
 
 

@@ -16,6 +16,7 @@ static int launch_one(const mh_gemm_desc* d, hipStream_t s) {
     a.R = d->R; a.rcoef = d->rcoef;
     a.ws = d->workspace; a.ws_floats = d->workspace_floats;
     a.kseg = d->k_segments; a.sAk = d->sA_seg; a.sBk = d->sB_seg;
+    a.row_softmax = d->row_softmax;
     const int BK = d->mma == MH_BF16 ? 64 : 16;
     const int kps = mh_cdiv(mh_cdiv(d->K, split), BK) * BK;
     a.k_per_split = kps;
@@ -29,12 +30,12 @@ static int launch_one(const mh_gemm_desc* d, hipStream_t s) {
     a.atomic = (a.split_k > 1) || (d->accumulate && batch > 1 && d->sC1 == 0 && d->sC2 == 0);
     MH_REQUIRE(!a.atomic || (d->dtC == MH_F32 && d->act == MH_ACT_NONE && d->accumulate),
                "mh_gemm: atomic accumulation (split-K / batch broadcast into C) needs f32 C, accumulate=1, no activation");
-    const bool want_tile = d->C2 || d->r_bf16 || d->k_segments > 1;
+    const bool want_tile = d->C2 || d->r_bf16 || d->k_segments > 1 || d->row_softmax;
     if (d->mma == MH_BF16 && d->dtA == MH_BF16 && d->dtB == MH_BF16 && gemm_try_tile384(a, d->a_kc, d->b_kc, d->dtC, batch, d->C2, d->r_bf16, s)) {
         MH_LAUNCH_CHECK("mh_gemm(tile)");
         return MH_OK;
     }
-    MH_REQUIRE(!want_tile, "mh_gemm: C2 / r_bf16 / k_segments need the 192 x 384 tile kernel (bf16 operands, M %% 192 == 0, N %% 384 == 0, K %% 64 == 0, no bias / split-K)");
+    MH_REQUIRE(!want_tile, "mh_gemm: C2 / r_bf16 / k_segments / row_softmax need the 192 x 384 tile kernel (bf16 operands, M %% 192 == 0, N %% 384 == 0, K %% 64 == 0, no bias / split-K)");
     if (d->mma == MH_F32) gemm_launch_f32(a, d->a_kc, d->b_kc, batch, s);
     else if (d->dtA == MH_BF16 && d->dtB == MH_BF16) gemm_launch_bf16(a, d->a_kc, d->b_kc, d->dtC, batch, s);
     else if (d->dtA == MH_F32 && d->dtB == MH_F32) gemm_launch_mixed_ff(a, d->a_kc, d->b_kc, d->dtC, batch, s);

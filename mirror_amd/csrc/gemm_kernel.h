@@ -37,6 +37,7 @@ struct GemmArgs {
     const void* R; float rcoef;   // optional addend rcoef * R, R laid out exactly like C (same dtype and strides)
     float* ws; long ws_floats;    // split-K partial tiles go here instead of f32 atomics (gemm_big.hip), then a fold pass
     const float* scale_a; const float* scale_b;   // fp8 operands (gemm_big.hip FP8 instance): alpha *= scale_a[0] * scale_b[0]
+    int row_softmax;              // gemm_tile.hip, N == 384, bf16 C: C = softmax over each row of alpha * A B (the whole row is in one tile)
     int kseg; long sAk, sBk;      // C = sum over kseg operand pairs (A + s sAk, B + s sBk), K each (gemm_tile.hip only; 0 / 1: one pair)
 };
 

@@ -154,6 +154,41 @@ __global__ __launch_bounds__(NTT) void gemm_tile_kernel(GemmArgs g, bf16_t* __re
         }
         __syncthreads();
         const int row0 = tile_m * TM + h * (TWM * 32) + i * 32;
+        if (g.row_softmax) {
+            // N == TN: the f32 tile holds 32 whole rows.  24 threads per row, 16 columns each; row maxima and sums meet in a
+            // [32][24] scratch behind the tile.  The probabilities leave as bf16 (what the softmax launch behind an f32 logits
+            // GEMM wrote): the 453 MB f32 round trip of the template's sim1 never happens.
+            float* red = tl + 32 * PITCH;
+            const int lr = tid / 24, part = tid % 24;
+            f32x4 v[4];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                v[u] = g.alpha * *reinterpret_cast<const f32x4*>(tl + lr * PITCH + 16 * part + 4 * u);
+                mx = fmaxf(fmaxf(fmaxf(mx, v[u][0]), fmaxf(v[u][1], v[u][2])), v[u][3]);
+            }
+            red[lr * 24 + part] = mx;
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 24; u++) mx = fmaxf(mx, red[lr * 24 + u]);
+            float sum = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) { v[u][e] = __expf(v[u][e] - mx); sum += v[u][e]; }
+            __syncthreads();
+            red[lr * 24 + part] = sum;
+            __syncthreads();
+            sum = 0.f;
+#pragma unroll
+            for (int u = 0; u < 24; u++) sum += red[lr * 24 + u];
+            const float inv = 1.f / sum;
+            bf16_t* crow = reinterpret_cast<bf16_t*>(g.C) + coff + (long)(row0 + lr) * g.ldc + 16 * part;
+#pragma unroll
+            for (int u = 0; u < 4; u++) st4(crow + 4 * u, v[u] * inv);
+            __syncthreads();
+            continue;
+        }
         constexpr int QPR = TN / 4;                       // quads per tile row
 #pragma unroll
         for (int u = 0; u < 32 * QPR / NTT; u++) {
@@ -182,8 +217,9 @@ bool gemm_try_tile384(GemmArgs& a, int akc, int bkc, int dtC, int batch, void* c
     const bool ok = on && a.M % TM == 0 && a.N % TN == 0 && a.K % 8 == 0 && a.split_k == 1 && !a.atomic && !a.bias &&
                     a.act == MH_ACT_NONE && a.vecA && a.vecB && a.vecC && !(akc == 0 && bkc == 1);
     if (!ok) return false;
+    if (a.row_softmax && !(a.N == TN && dtC == MH_BF16 && !a.R && !a.accumulate && a.diag == 0.f && !c2)) return false;
     const long wgs = (long)(a.M / TM) * (a.N / TN) * batch;
-    if (wgs < 64 && !c2 && !r_bf16 && a.kseg <= 1) return false;      // a few tiles: the 128 x 128 kernel spreads better
+    if (wgs < 64 && !c2 && !r_bf16 && a.kseg <= 1 && !a.row_softmax) return false;      // a few tiles: the 128 x 128 kernel spreads better
     a.tiles_m = a.M / TM;
     a.tiles_n = a.N / TN;
     dim3 grid(a.tiles_m * a.tiles_n, 1, batch);

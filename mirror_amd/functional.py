@@ -918,10 +918,17 @@ class NystromCoreFn(Function):
         if fused:
             av, lse3 = K.nys_attn3_fwd(qkv, lm, h, scale, kmask)                         # [B,h,m,dh] f32
         else:
-            a1 = K.gemm(q, kl.transpose(-1, -2), alpha=scale, mma=mma, out_dtype=f32)   # [B,h,n_p,m]
+            # sim1's rows (length m) fit one 192 x 384 tile at the template's m = 384: the softmax runs in that GEMM's epilogue
+            sm1 = (kmask is None and A == bf16 and mma == MH_BF16 and q.dtype == bf16
+                   and K.gemm_softmax_ok(n_p, lm.shape[1], dh, q.dtype, kl.dtype))
+            if sm1:
+                a1 = K.gemm(q, kl.transpose(-1, -2), alpha=scale, mma=mma, out_dtype=bf16, softmax=True)   # [B,h,n_p,m]
+            else:
+                a1 = K.gemm(q, kl.transpose(-1, -2), alpha=scale, mma=mma, out_dtype=f32)
             a3 = K.gemm(ql, k.transpose(-1, -2), alpha=scale, mma=mma, out_dtype=f32)   # [B,h,m,n_p]
             if kmask is None:
-                a1 = K.softmax_fwd(a1, a1 if A == f32 else None, out_dtype=A)
+                if not sm1:
+                    a1 = K.softmax_fwd(a1, a1 if A == f32 else None, out_dtype=A)
                 a3 = K.softmax_fwd(a3, a3 if A == f32 else None, out_dtype=A)
             else:
                 a1 = K.softmax_masked_fwd(a1, mrow, mlm, a1 if A == f32 else None, out_dtype=A)

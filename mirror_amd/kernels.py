@@ -74,11 +74,12 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *
          diag: float = 0.0, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, accumulate: bool = False,
          split_k: int = 1, mma: int = MH_F32, out_dtype: Optional[torch.dtype] = None,
          R: Optional[torch.Tensor] = None, rcoef: float = 0.0, c2: Optional[torch.Tensor] = None,
-         kseg: Optional[tuple] = None) -> torch.Tensor:
+         kseg: Optional[tuple] = None, softmax: bool = False) -> torch.Tensor:
     """out[..] (+)= act(alpha * a @ b + diag*I + bias + rcoef*R) with a [..,M,K], b [..,K,N] given as (possibly
     transposed / strided / broadcast) views; <= 2 leading batch dims.  c2: optional bf16 tensor shaped and strided like `out`
     that receives a copy of the final result (192 x 384 tile kernel only, see gemm_tile_ok).  kseg = (S, a_stride, b_stride):
-    the product becomes sum_s a_s @ b_s over S operand pairs that start a_stride / b_stride elements apart (gemm_ksum)."""
+    the product becomes sum_s a_s @ b_s over S operand pairs that start a_stride / b_stride elements apart (gemm_ksum).
+    softmax=True: out = softmax(alpha * a @ b, dim=-1) as bf16, the rows normalised in the epilogue (gemm_softmax_ok shapes)."""
     _chk(a, b, out, bias)
     nd = max(a.dim(), b.dim())
     a4, a_rm, lda, sa1, sa2 = _mat(a)
@@ -137,6 +138,11 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *
         if c2.dtype != torch.bfloat16 or c2.numel() != o4.numel() or tuple(c2.stride()) != tuple(out.stride()):
             raise MirrorHipError("gemm: c2 must be a bf16 tensor with the output's shape and strides")
         d.C2 = c2.data_ptr()
+    if softmax:
+        if not (gemm_softmax_ok(M, N, K, a4.dtype, b4.dtype) and o4.dtype == torch.bfloat16 and bias is None and act == ACT_NONE
+                and d.split_k == 1 and not accumulate and R is None and c2 is None and diag == 0.0):
+            raise MirrorHipError("gemm: softmax=True needs bf16 operands and output, M % 192 == 0, N == 384, K % 8 == 0 and a plain product")
+        d.row_softmax = 1
     if kseg is not None and int(kseg[0]) > 1:
         if not (gemm_tile_ok(M, N, K, a4.dtype, b4.dtype) and bias is None and act == ACT_NONE and d.split_k == 1):
             raise MirrorHipError("gemm: a sum over operand pairs (kseg) needs the 192 x 384 tile kernel (see gemm_tile_ok)")
@@ -154,6 +160,12 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *
     else:
         prof.launch(d, lambda: _lib.call("mh_gemm", C.byref(d), stream=_stream()))
     return out
+
+
+def gemm_softmax_ok(M: int, N: int, Kd: int, dta=torch.bfloat16, dtb=torch.bfloat16) -> bool:
+    """Shapes whose row softmax the 192 x 384 tile kernel computes in its epilogue (a whole row of length N = 384 in one tile)."""
+    return (M % 192 == 0 and N == 384 and Kd % 8 == 0 and dta == torch.bfloat16 and dtb == torch.bfloat16
+            and os.environ.get("MH_GEMM_TILE384", "1")[:1] != "0" and os.environ.get("MH_GEMM_SOFTMAX", "1")[:1] != "0")
 
 
 def gemm_ksum(a_stack: torch.Tensor, b_stack: torch.Tensor, out: Optional[torch.Tensor] = None, **kw) -> torch.Tensor:

@@ -138,6 +138,27 @@ def test_gemm_tile384_kernel(a_rm, b_t, out_dtype):
     close(out, (0.5 * (a.double() @ b.double())).float().to(out_dtype).double(), 0, 0, "tile ragged K")
 
 
+@pytest.mark.parametrize("Kd", [96, 128])
+def test_gemm_row_softmax_epilogue(Kd):
+    """softmax=True on the 192 x 384 tile kernel (sim1 of the template geometry: rows of length m = 384): equals the f32 logits
+    GEMM followed by mh_softmax_fwd -> bf16 to one bf16 ulp, and torch.softmax of the f64 product to bf16 rounding."""
+    gen = g(211 + Kd)
+    bf = torch.bfloat16
+    Bt, M, N = 3, 576, 384
+    a = (torch.randn(Bt, M, Kd, generator=gen)).to(bf)
+    b = (torch.randn(Bt, N, Kd, generator=gen)).to(bf)
+    a_dev, bT = a.to(DEV), b.to(DEV).transpose(-1, -2)
+    scale = Kd ** -0.5
+    assert K.gemm_softmax_ok(M, N, Kd)
+    got = K.gemm(a_dev, bT, alpha=scale, mma=MH_BF16, out_dtype=bf, softmax=True)
+    ref = torch.softmax(scale * (a.double() @ b.double().transpose(-1, -2)), dim=-1)
+    two = K.softmax_fwd(K.gemm(a_dev, bT, alpha=scale, mma=MH_BF16, out_dtype=torch.float32), None, out_dtype=bf)
+    assert float((got.float() - two.float()).abs().max()) <= 2.0 ** -8 * float(two.float().abs().max())
+    err = (got.float().cpu().double() - ref).abs().max() / ref.abs().max()
+    assert float(err) < 2.0 ** -7, float(err)
+    assert float((got.float().sum(-1) - 1).abs().max()) < 2e-2
+
+
 @pytest.mark.parametrize("a_rm,b_t", [(True, False), (False, False), (True, True)])
 def test_gemm_ragged_n_instances(a_rm, b_t):
     """N = 96 (one column tile that ends inside: the attn·v / dS·k products of the template's 96-wide heads) with M and K whole
