@@ -76,7 +76,8 @@ typedef struct {
     int64_t sA_seg, sB_seg;
     int32_t row_softmax;          /* 1: C = softmax over each row of alpha * A B, written as bf16 (N == 384 = one tile row of the same
                                      tile kernel; no R / accumulate / diag / C2): sim1 = q k_l^T of the template geometry (m = 384
-                                     landmarks, models/mirror.py:312 [3P] `attn1 = sim1.softmax(dim=-1)`) without the f32 logits round trip */
+                                     landmarks, models/mirror.py:312 [3P] `attn1 = sim1.softmax(dim=-1)`) without the f32 logits round trip;
+                                     2: its backward, C = P o (alpha A B - rowsum(P o alpha A B)) with the probabilities P given as R (bf16) */
 } mh_gemm_desc;
 int mh_gemm(const mh_gemm_desc* d, mh_stream s);
 /* Bytes of `workspace` with which this call reduces through plain partial tiles + a fold pass instead of f32 atomics

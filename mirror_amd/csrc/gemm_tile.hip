@@ -167,6 +167,27 @@ __global__ __launch_bounds__(NTT) void gemm_tile_kernel(GemmArgs g, bf16_t* __re
                 v[u] = g.alpha * *reinterpret_cast<const f32x4*>(tl + lr * PITCH + 16 * part + 4 * u);
                 mx = fmaxf(fmaxf(fmaxf(mx, v[u][0]), fmaxf(v[u][1], v[u][2])), v[u][3]);
             }
+            if (g.row_softmax == 2) {
+                // softmax BACKWARD: the product is dP, R holds the probabilities P (bf16, laid out like C): dS = P o (dP - sum_row P dP)
+                const bf16_t* prow = reinterpret_cast<const bf16_t*>(g.R) + coff + (long)(row0 + lr) * g.ldc + 16 * part;
+                f32x4 y[4];
+                float dot = 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    y[u] = ld4(prow + 4 * u);
+                    dot += y[u][0] * v[u][0] + y[u][1] * v[u][1] + y[u][2] * v[u][2] + y[u][3] * v[u][3];
+                }
+                red[lr * 24 + part] = dot;
+                __syncthreads();
+                dot = 0.f;
+#pragma unroll
+                for (int u = 0; u < 24; u++) dot += red[lr * 24 + u];
+                bf16_t* drow = reinterpret_cast<bf16_t*>(g.C) + coff + (long)(row0 + lr) * g.ldc + 16 * part;
+#pragma unroll
+                for (int u = 0; u < 4; u++) st4(drow + 4 * u, y[u] * (v[u] - dot));
+                __syncthreads();
+                continue;
+            }
             red[lr * 24 + part] = mx;
             __syncthreads();
 #pragma unroll
@@ -217,7 +238,7 @@ bool gemm_try_tile384(GemmArgs& a, int akc, int bkc, int dtC, int batch, void* c
     const bool ok = on && a.M % TM == 0 && a.N % TN == 0 && a.K % 8 == 0 && a.split_k == 1 && !a.atomic && !a.bias &&
                     a.act == MH_ACT_NONE && a.vecA && a.vecB && a.vecC && !(akc == 0 && bkc == 1);
     if (!ok) return false;
-    if (a.row_softmax && !(a.N == TN && dtC == MH_BF16 && !a.R && !a.accumulate && a.diag == 0.f && !c2)) return false;
+    if (a.row_softmax && !(a.N == TN && dtC == MH_BF16 && (a.row_softmax == 2) == (a.R != nullptr) && !a.accumulate && a.diag == 0.f && !c2)) return false;
     const long wgs = (long)(a.M / TM) * (a.N / TN) * batch;
     if (wgs < 64 && !c2 && !r_bf16 && a.kseg <= 1 && !a.row_softmax) return false;      // a few tiles: the 128 x 128 kernel spreads better
     a.tiles_m = a.M / TM;

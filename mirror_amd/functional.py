@@ -1024,8 +1024,12 @@ class NystromCoreFn(Function):
             K.nys_attn3_bwd(qkv, lm, av, dAV, lse3, dqkv, dlm, h, scale, kmask)         # dk, dv, dq_l
             K.resconv(dout, rw, dqkv[..., 2 * D:], h, transpose=True, accumulate=True)
         else:
-            dS1 = K.gemm(dO, tr(w2), mma=mma, out_dtype=A)                               # [B,h,n_p,m]
-            sm_bwd(a1, dS1, mrow if kmask else None, mlm if kmask else None)
+            if (kmask is None and A == bf16 and mma == MH_BF16 and a1.dtype == bf16 and a1.is_contiguous()
+                    and K.gemm_softmax_ok(n_p, m, dh, dO.dtype, w2.dtype)):
+                dS1 = K.gemm(dO, tr(w2), mma=mma, out_dtype=bf16, softmax_bwd_of=a1)    # softmax backward in the epilogue
+            else:
+                dS1 = K.gemm(dO, tr(w2), mma=mma, out_dtype=A)                           # [B,h,n_p,m]
+                sm_bwd(a1, dS1, mrow if kmask else None, mlm if kmask else None)
             dS3 = K.gemm(dAV, tr(v), mma=mma, out_dtype=A)                               # [B,h,m,n_p]
             K.gemm(tr(a3), dAV, out=dv, mma=mma)
             K.resconv(dout, rw, dqkv[..., 2 * D:], h, transpose=True, accumulate=True)

@@ -74,12 +74,14 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *
          diag: float = 0.0, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, accumulate: bool = False,
          split_k: int = 1, mma: int = MH_F32, out_dtype: Optional[torch.dtype] = None,
          R: Optional[torch.Tensor] = None, rcoef: float = 0.0, c2: Optional[torch.Tensor] = None,
-         kseg: Optional[tuple] = None, softmax: bool = False) -> torch.Tensor:
+         kseg: Optional[tuple] = None, softmax: bool = False,
+         softmax_bwd_of: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[..] (+)= act(alpha * a @ b + diag*I + bias + rcoef*R) with a [..,M,K], b [..,K,N] given as (possibly
     transposed / strided / broadcast) views; <= 2 leading batch dims.  c2: optional bf16 tensor shaped and strided like `out`
     that receives a copy of the final result (192 x 384 tile kernel only, see gemm_tile_ok).  kseg = (S, a_stride, b_stride):
     the product becomes sum_s a_s @ b_s over S operand pairs that start a_stride / b_stride elements apart (gemm_ksum).
-    softmax=True: out = softmax(alpha * a @ b, dim=-1) as bf16, the rows normalised in the epilogue (gemm_softmax_ok shapes)."""
+    softmax=True: out = softmax(alpha * a @ b, dim=-1) as bf16, the rows normalised in the epilogue (gemm_softmax_ok shapes);
+    softmax_bwd_of=P (bf16 probabilities, shaped and strided like out): out = P * (dP - sum(P * dP, -1)) with dP = alpha * a @ b."""
     _chk(a, b, out, bias)
     nd = max(a.dim(), b.dim())
     a4, a_rm, lda, sa1, sa2 = _mat(a)
@@ -143,6 +145,14 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *
                 and d.split_k == 1 and not accumulate and R is None and c2 is None and diag == 0.0):
             raise MirrorHipError("gemm: softmax=True needs bf16 operands and output, M % 192 == 0, N == 384, K % 8 == 0 and a plain product")
         d.row_softmax = 1
+    if softmax_bwd_of is not None:
+        P_ = softmax_bwd_of
+        _chk(P_)
+        if not (gemm_softmax_ok(M, N, K, a4.dtype, b4.dtype) and o4.dtype == torch.bfloat16 and P_.dtype == torch.bfloat16 and bias is None
+                and act == ACT_NONE and d.split_k == 1 and not accumulate and R is None and c2 is None and diag == 0.0 and not softmax
+                and P_.numel() == o4.numel() and tuple(P_.stride()) == tuple(out.stride())):
+            raise MirrorHipError("gemm: softmax_bwd_of needs bf16 operands / output / probabilities (same layout as out), M % 192 == 0, N == 384")
+        d.row_softmax, d.R = 2, P_.data_ptr()
     if kseg is not None and int(kseg[0]) > 1:
         if not (gemm_tile_ok(M, N, K, a4.dtype, b4.dtype) and bias is None and act == ACT_NONE and d.split_k == 1):
             raise MirrorHipError("gemm: a sum over operand pairs (kseg) needs the 192 x 384 tile kernel (see gemm_tile_ok)")

@@ -157,6 +157,14 @@ def test_gemm_row_softmax_epilogue(Kd):
     err = (got.float().cpu().double() - ref).abs().max() / ref.abs().max()
     assert float(err) < 2.0 ** -7, float(err)
     assert float((got.float().sum(-1) - 1).abs().max()) < 2e-2
+    # backward form: dS = P o (dP - rowsum(P o dP)), dP = alpha a b^T, P given in bf16
+    P = got
+    want = K.softmax_bwd(P, K.gemm(a_dev, bT, alpha=scale, mma=MH_BF16, out_dtype=bf))       # the two-launch path, in place on dP
+    dS = K.gemm(a_dev, bT, alpha=scale, mma=MH_BF16, out_dtype=bf, softmax_bwd_of=P)
+    ref_d = P.float().cpu().double() * ((scale * (a.double() @ b.double().transpose(-1, -2)))
+                                        - (P.float().cpu().double() * (scale * (a.double() @ b.double().transpose(-1, -2)))).sum(-1, keepdim=True))
+    assert float((dS.float().cpu().double() - ref_d).abs().max()) < 2.0 ** -6 * float(ref_d.abs().max())
+    assert float((dS.float() - want.float()).abs().max()) < 2.0 ** -5 * float(want.float().abs().max())
 
 
 @pytest.mark.parametrize("a_rm,b_t", [(True, False), (False, False), (True, True)])
