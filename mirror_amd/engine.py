@@ -46,6 +46,10 @@ def plan_buckets(sizes: Sequence[int], cap_elems: int, align: int = _ALIGN):
     return buckets, owner
 
 
+# A/B switch: 1 (default) = the transposed weight copies are rebuilt at the start of a step on the RNA stream, 0 = behind Adam
+_TRANSPOSE_AT_START = os.environ.get("MIRROR_TRANSPOSE_AT_START", "1") != "0"
+
+
 class TrainEngine:
     def __init__(self, model: torch.nn.Module, loss_fn, *, lr: float = 2e-5, betas=(0.9, 0.999), eps: float = 1e-8,
                  precision: str = "bf16", wsi_mask_ratio: float = 0.75, rna_mask_ratio: float = 0.75,
@@ -354,9 +358,21 @@ class TrainEngine:
             K.rownorm_(w.data)
             if self.shadow is not None:
                 K.cast(w.data, bf16, out=Fn.shadow(w, POLICIES[self.precision]))
+        t_done = None
+        if _TRANSPOSE_AT_START and self.shadow_t is not None:
+            # The transposed bf16 weight copies are read by BACKWARD kernels only (data gradients of the [B, D]-row linears): instead
+            # of 50 us behind Adam at the end of every step they are rebuilt at the start of the next one, on the RNA branch's
+            # stream, beside the WSI forward; the backward below waits for them.
+            main, side = torch.cuda.current_stream(), Fn._side_stream(self.device, 1)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._refresh_transposes()
+                t_done = side.record_event()
         kw = {} if wsi_key_padding_mask is None else {"wsi_key_padding_mask": wsi_key_padding_mask}
         outs = self.model(wsi, rna, wsi_mask_ratio=self.wsi_mask_ratio, rna_mask_ratio=self.rna_mask_ratio, noise=noise, **kw)
         losses = self.loss_fn(*outs)
+        if t_done is not None:
+            torch.cuda.current_stream().wait_event(t_done)
         Fn.set_grad_sink(self)
         try:
             losses[0].backward()
@@ -385,7 +401,8 @@ class TrainEngine:
         K.adam(self.master, self.grad, self.m, self.v, self.shadow, self.lr, b1, b2, self.eps, 1.0, 1.0,
                grad_scale=gs,                  # the DDP / accumulation average is folded into Adam
                dev_state=self._state)          # t, bias corrections, lr and the clip factor live on the device
-        self._refresh_transposes()
+        if not _TRANSPOSE_AT_START:
+            self._refresh_transposes()
         if self._logit is not None:
             K.clamp_(self._logit.data.reshape(1), 0.0, math.log(100.0))
             if self.shadow is not None:
