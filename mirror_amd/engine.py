@@ -103,6 +103,7 @@ class TrainEngine:
                 p.grad = self.grad[o:o + n].view(p.shape)
         # W^T shadows of the 2-D weights (skinny data-gradient kernels stream them like forward weights)
         self.shadow_t = None
+        self._zero_pending = False
         if self.shadow is not None:
             two_d = [(p, o) for p, o in zip(order, offs) if p.dim() == 2 and p.shape[1] % 32 == 0 and p.shape[0] % 32 == 0]
             if two_d:
@@ -359,7 +360,7 @@ class TrainEngine:
             if self.shadow is not None:
                 K.cast(w.data, bf16, out=Fn.shadow(w, POLICIES[self.precision]))
         t_done = None
-        if _TRANSPOSE_AT_START and self.shadow_t is not None:
+        if _TRANSPOSE_AT_START:
             # The transposed bf16 weight copies are read by BACKWARD kernels only (data gradients of the [B, D]-row linears): instead
             # of 50 us behind Adam at the end of every step they are rebuilt at the start of the next one, on the RNA branch's
             # stream, beside the WSI forward; the backward below waits for them.
@@ -367,6 +368,9 @@ class TrainEngine:
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 self._refresh_transposes()
+                if self._zero_pending:           # the gradient arena of the update that ended the previous step
+                    self.grad.zero_()
+                    self._zero_pending = False
                 t_done = side.record_event()
         kw = {} if wsi_key_padding_mask is None else {"wsi_key_padding_mask": wsi_key_padding_mask}
         outs = self.model(wsi, rna, wsi_mask_ratio=self.wsi_mask_ratio, rna_mask_ratio=self.rna_mask_ratio, noise=noise, **kw)
@@ -407,7 +411,10 @@ class TrainEngine:
             K.clamp_(self._logit.data.reshape(1), 0.0, math.log(100.0))
             if self.shadow is not None:
                 K.cast(self._logit.data.reshape(1), bf16, out=Fn.shadow(self._logit, POLICIES[self.precision]).reshape(1))
-        self.grad.zero_()
+        if _TRANSPOSE_AT_START:
+            self._zero_pending = True        # cleared by the next step, beside its forward (nobody reads the arena in between)
+        else:
+            self.grad.zero_()
         Fn.dropout_step_end()
         return self._loss_out(losses)
 

@@ -448,7 +448,20 @@ def test_force_update_flushes_a_partial_accumulation_window_and_ranks_seed_dropo
     want = torch.cat([p.grad.reshape(-1) for p in reversed(list(ref.parameters()))])
     got = torch.cat([eng.grad_snap[o:o + p.numel()] for p, o in zip(eng.params, eng.offsets)]) / 3.0     # Adam folds 1 / accum_steps in
     assert float((got - want).norm()) < 2e-3 * float(want.norm())
-    assert float(eng.grad.abs().max()) == 0.0          # nothing leaks into the next window
+    # nothing leaks into the next window: the arena is cleared behind the update, or (default) beside the next step's forward —
+    # then the first micro-step of the next window must leave exactly its own gradient there
+    assert eng._zero_pending or float(eng.grad.abs().max()) == 0.0
+    for p in ref.parameters():
+        p.grad = None
+    wsi, rna, noise = _batch(2, 302)
+    eng.step(wsi, rna, noise=noise)
+    torch.cuda.synchronize()
+    assert eng._micro == 1 and float(eng._state[0]) == 1.0
+    ref.load_state_dict(model.state_dict())            # the engine's weights after its one update
+    (MIRRORLoss()(*ref(wsi, rna, noise=noise))[0]).backward()
+    want = torch.cat([p.grad.reshape(-1) for p in reversed(list(ref.parameters()))])
+    got = torch.cat([eng.grad[o:o + p.numel()] for p, o in zip(eng.params, eng.offsets)])
+    assert float((got - want).norm()) < 2e-3 * float(want.norm()), (float((got - want).norm()), float(want.norm()))
 
     def masks(seed):
         m = _make().train()
