@@ -104,6 +104,7 @@ class TrainEngine:
         # W^T shadows of the 2-D weights (skinny data-gradient kernels stream them like forward weights)
         self.shadow_t = None
         self._zero_pending = False
+        self._t_stale = False
         if self.shadow is not None:
             two_d = [(p, o) for p, o in zip(order, offs) if p.dim() == 2 and p.shape[1] % 32 == 0 and p.shape[0] % 32 == 0]
             if two_d:
@@ -167,9 +168,15 @@ class TrainEngine:
         self._refresh_transposes()
         if self.shadow_t is not None:
             for p, o in self._t_params:
-                Fn.register_shadow_t(p, self.shadow_t[o:o + p.numel()].view(p.shape[1], p.shape[0]))
+                Fn.register_shadow_t(p, self.shadow_t[o:o + p.numel()].view(p.shape[1], p.shape[0]), owner=self)
+
+    def refresh_transposes_now(self) -> None:
+        """The transposed copies trail an update until the next step starts (see _step_body); anything that differentiates
+        through the model outside step() gets them rebuilt on its own stream first (functional.shadow_t calls this)."""
+        self._refresh_transposes()
 
     def _refresh_transposes(self) -> None:
+        self._t_stale = False
         if self.shadow_t is not None:
             K.transpose_bf16_many(self.shadow, self.shadow_t, self._t_table, self._t_n, self._t_max[0], self._t_max[1],
                                   vec_ok=True)   # 2-D weights with both dims % 32 == 0 at offsets that are multiples of _ALIGN = 8
@@ -405,7 +412,9 @@ class TrainEngine:
         K.adam(self.master, self.grad, self.m, self.v, self.shadow, self.lr, b1, b2, self.eps, 1.0, 1.0,
                grad_scale=gs,                  # the DDP / accumulation average is folded into Adam
                dev_state=self._state)          # t, bias corrections, lr and the clip factor live on the device
-        if not _TRANSPOSE_AT_START:
+        if _TRANSPOSE_AT_START:
+            self._t_stale = self.shadow_t is not None
+        else:
             self._refresh_transposes()
         if self._logit is not None:
             K.clamp_(self._logit.data.reshape(1), 0.0, math.log(100.0))

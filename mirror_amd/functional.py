@@ -85,6 +85,9 @@ def shadow_t(w: torch.Tensor, prec: Precision) -> torch.Tensor:
     man = _managed_shadows_t.get(key)
     if man is not None:
         if _alive(man[1]):
+            owner = man[2]() if len(man) > 2 and man[2] is not None else None
+            if owner is not None and getattr(owner, "_t_stale", False):
+                owner.refresh_transposes_now()      # a backward pass outside TrainEngine.step(): its transposes trail the update
             return man[0]
         _managed_shadows_t.pop(key, None)
     # An optimizer that rewrites the master through raw kernels (TrainEngine: mh_adam) does not bump the version counter:
@@ -100,12 +103,14 @@ def shadow_t(w: torch.Tensor, prec: Precision) -> torch.Tensor:
     return t
 
 
-def register_shadow_t(w: torch.Tensor, t: Optional[torch.Tensor]) -> None:
+def register_shadow_t(w: torch.Tensor, t: Optional[torch.Tensor], owner=None) -> None:
+    """owner: the engine that keeps `t` current.  It may rebuild the transposes lazily (TrainEngine does it at the start of its
+    next step); while its `_t_stale` is set, a lookup from outside one of its steps triggers `owner.refresh_transposes_now()`."""
     key = (w.data_ptr(), tuple(w.shape))
     if t is None:
         _managed_shadows_t.pop(key, None)
     else:
-        _managed_shadows_t[key] = (t, weakref.ref(w))
+        _managed_shadows_t[key] = (t, weakref.ref(w), None if owner is None else weakref.ref(owner))
 
 
 def register_shadow(w: torch.Tensor, s: Optional[torch.Tensor]) -> None:

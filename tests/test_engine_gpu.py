@@ -425,6 +425,28 @@ def test_d512_bucketed_all_reduce_and_rna_graph_world2():
     assert abs(res[0][5] - res[0][6]) < 1e-2 * abs(res[0][5])
 
 
+def test_transposed_shadows_are_current_for_a_backward_outside_the_engine():
+    """TrainEngine rebuilds the transposed bf16 weight copies at the START of its next step (beside the forward) instead of
+    behind Adam.  Code that differentiates through the model between two steps must still see the weights of the last update:
+    functional.shadow_t asks the engine to catch up first."""
+    from mirror_amd import functional as Fn
+    from mirror_amd.engine import TrainEngine
+    from mirror_amd.losses import MIRRORLoss
+    model = _make().train()
+    eng = TrainEngine(model, MIRRORLoss(), lr=1e-2, precision="bf16", graph=False)
+    for s in range(2):
+        wsi, rna, noise = _batch(2, 700 + s)
+        eng.step(wsi.to(torch.bfloat16), rna, noise=noise)
+    assert eng.shadow_t is not None and eng._t_stale
+    prec = Fn.POLICIES["bf16"]
+    checked = 0
+    for p, _ in eng._t_params[:6]:
+        wt = Fn.shadow_t(p, prec)                       # the lookup a Linear backward does
+        assert torch.equal(wt, Fn.shadow(p, prec).t().contiguous()), "stale transposed copy"
+        checked += 1
+    assert checked > 0 and not eng._t_stale
+
+
 def test_force_update_flushes_a_partial_accumulation_window_and_ranks_seed_dropout_differently():
     """(1) train_mirror.py:1128-1131: `need_update = last_batch or (batch_idx + 1) % accum_steps == 0` — the last, partial
     window of an epoch still updates (loss scaled by 1 / accum_steps as in the reference, :1192-1196).  With accum_steps = 3, two
