@@ -104,6 +104,12 @@ int mh_transpose_bf16_many(const void* src, void* dst, const int64_t* table, int
 int mh_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                      int batches, int rows_per_batch, int D, int64_t x_bs, int64_t y_bs, float eps,
                      int dt_x, int dt_y, mh_stream s);
+/* the same with an e4m3 copy of the output beside the bf16 one (x f32, y bf16; q8 has y's row addressing, one byte per element):
+ * delayed per-tensor scaling as in mh_quant_fp8_delayed (ring: 3 uint32 of this call site, tick: device step counter), scale[0] =
+ * the dequantisation factor.  Config 5: the fp8 forward of [3P] to_qkv reads q8, its weight gradient the bf16 copy. */
+int mh_layernorm_fwd_q8(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                        int batches, int rows_per_batch, int D, int64_t x_bs, int64_t y_bs, float eps, void* q8, unsigned* ring,
+                        const float* tick, float margin, float* scale, mh_stream s);
 /* dx = d/dx, dgamma/dbeta accumulated (+=, f32; caller zeroes them). dy uses y's addressing.
  * workspace (optional, f32, ws_floats >= 2*D): per-block dgamma/dbeta partials are written there and folded by a second
  * small launch instead of thousands of same-address atomics; size it 2*D*min(rows/16, 1024) floats for full speed. */

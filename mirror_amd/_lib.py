@@ -59,6 +59,7 @@ _SIGS = {
     "mh_transpose_bf16": [P, P, I, I],
     "mh_transpose_bf16_many": [P, P, P, I, I, I, I],
     "mh_layernorm_fwd": [P, P, P, P, P, P, I, I, I, L, L, F, I, I],
+    "mh_layernorm_fwd_q8": [P, P, P, P, P, P, I, I, I, L, L, F, P, P, P, F, P],
     "mh_layernorm_bwd": [P, P, P, P, P, P, P, P, I, I, I, L, L, I, I, I, I, P, L],
     "mh_softmax_fwd": [P, P, L, I, L, L, I, I],
     "mh_softmax_bwd": [P, P, P, L, I, L, L, L, I, I, I],

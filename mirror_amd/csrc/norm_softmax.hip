@@ -152,6 +152,79 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const TX* __rest
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
+// LayerNorm forward that ALSO leaves an e4m3 copy of its output (BASELINE config 5: the fp8 forward of to_qkv reads it; the
+// bf16 copy is still needed by the weight gradient): delayed scaling exactly as mh_quant_fp8_delayed (ring of three per-site
+// maxima rotated by the device-side step counter), so the projection's input needs no quantisation pass of its own.
+// q has y's row addressing in bytes (q_bs bytes per batch).
+template <int LNV_CH>
+__global__ __launch_bounds__(256) void layernorm_fwd_q8_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                               float* __restrict__ mean, float* __restrict__ rstd,
+                                                               long rows, int rpb, int D, long x_bs, long y_bs, float eps,
+                                                               unsigned char* __restrict__ q, unsigned* __restrict__ ring,
+                                                               const float* __restrict__ tick, float margin, float* __restrict__ scale) {
+    constexpr float F8M = 448.f;
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63;
+    const int t = (int)tick[0];
+    const int cur = t % 3, prev = (t + 2) % 3, nxt = (t + 1) % 3;
+    const float amax = __uint_as_float(ring[prev]) * margin;
+    const float mul = amax > 0.f ? F8M / amax : 1.f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        scale[0] = amax > 0.f ? amax / F8M : 1.f;
+        ring[nxt] = 0u;
+    }
+    float m = 0.f;
+    // a wave walks rows (grid-stride) and keeps the running maximum: ONE atomic per workgroup at the end, not one per row
+    for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
+        const long b = row / rpb, i = row % rpb;
+        const float* xr = x + b * x_bs + i * D;
+        bf16_t* yr = y + b * y_bs + i * D;
+        unsigned char* qr = q + b * y_bs + i * D;
+        f4 v[LNV_CH];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < LNV_CH; k++) {
+            const int c = 256 * k + 4 * lane;
+            if (c < D) { v[k] = ld4(xr + c); s += v[k][0] + v[k][1] + v[k][2] + v[k][3]; }
+            else v[k] = (f4){0.f, 0.f, 0.f, 0.f};
+        }
+        const float mu = wave_sum(s) / D;
+        float qq = 0.f;
+#pragma unroll
+        for (int k = 0; k < LNV_CH; k++) {
+            const int c = 256 * k + 4 * lane;
+            if (c < D) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) { const float d = v[k][e] - mu; qq += d * d; }
+            }
+        }
+        const float rs = rsqrtf(wave_sum(qq) / D + eps);
+#pragma unroll
+        for (int k = 0; k < LNV_CH; k++) {
+            const int c = 256 * k + 4 * lane;
+            if (c < D) {
+                const f4 g = ld4(gamma + c), bt = ld4(beta + c);
+                f4 o;
+#pragma unroll
+                for (int e = 0; e < 4; e++) o[e] = (v[k][e] - mu) * rs * g[e] + bt[e];
+                st4(yr + c, o);
+                // quantise what the bf16 copy holds (the same operand values as the separate quantisation pass would read)
+#pragma unroll
+                for (int e = 0; e < 4; e++) { o[e] = bf2f(f2bf(o[e])); m = fmaxf(m, fabsf(o[e])); }
+                const f4 w4 = o * mul;
+                unsigned w = 0;
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(w4[0], -F8M), F8M), fminf(fmaxf(w4[1], -F8M), F8M), w, false);
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(w4[2], -F8M), F8M), fminf(fmaxf(w4[3], -F8M), F8M), w, true);
+                *reinterpret_cast<unsigned*>(qr + c) = w;
+            }
+        }
+        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    }
+    m = block_max256(m, red);
+    if (threadIdx.x == 0) atomicMax(ring + cur, __float_as_uint(m));
+}
+
 template <typename TX, typename TDY, int LNV_CH>
 __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x,
                                                                 const float* __restrict__ gamma, const float* __restrict__ mean,
@@ -253,6 +326,23 @@ extern "C" int mh_layernorm_fwd(const void* x, const float* gamma, const float* 
     else LN_F(bf16_t, float);
 #undef LN_F
     MH_LAUNCH_CHECK("mh_layernorm_fwd");
+    return MH_OK;
+}
+
+extern "C" int mh_layernorm_fwd_q8(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                   int batches, int rows_per_batch, int D, int64_t x_bs, int64_t y_bs, float eps, void* q8, unsigned* ring,
+                                   const float* tick, float margin, float* scale, mh_stream s) {
+    const long rows = (long)batches * rows_per_batch;
+    if (rows == 0) return MH_OK;
+    MH_REQUIRE(D % 4 == 0 && D <= 2048 && x_bs % 4 == 0 && y_bs % 4 == 0 && (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0 &&
+                   ((uintptr_t)y & 7) == 0 && ((uintptr_t)q8 & 3) == 0,
+               "mh_layernorm_fwd_q8: D %% 4 == 0, D <= 2048 and aligned buffers (D=%d)", D);
+    MH_REQUIRE(ring && tick && scale && margin >= 1.f, "mh_layernorm_fwd_q8: ring, tick, scale and margin >= 1 are required");
+    dim3 grid((unsigned)min((long)mh_cdiv(rows, 4), 4096L));
+#define LNQ(NC) hipLaunchKernelGGL((layernorm_fwd_q8_kernel<NC>), grid, dim3(256), 0, (hipStream_t)s, x, gamma, beta, (bf16_t*)y, mean, rstd, rows, rows_per_batch, D, (long)x_bs, (long)y_bs, eps, (unsigned char*)q8, ring, tick, margin, scale)
+    if (D <= 512) LNQ(2); else if (D <= 1024) LNQ(4); else LNQ(8);
+#undef LNQ
+    MH_LAUNCH_CHECK("mh_layernorm_fwd_q8");
     return MH_OK;
 }
 

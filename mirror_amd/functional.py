@@ -283,17 +283,24 @@ def _gemm_window(a3, b2, out3, *, bias=None, mma):
 _fp8_state = {"tick": None, "sites": {}, "host_step": 0}
 
 
+_prequant: dict = {}        # data_ptr of a producer's bf16 output -> (e4m3 copy, scale) the producer wrote in the same pass
+
+
 def fp8_delayed_scaling(tick: Optional[torch.Tensor], host_step: int = 0) -> None:
     """tick: device f32[1] step counter (TrainEngine._state[0:1]) for the duration of a training step; None: back to the exact
     two-pass quantisation (evaluation, module use without an engine).  The per-site amax rings survive a None."""
     _fp8_state["tick"] = tick
     _fp8_state["host_step"] = int(host_step)
+    _prequant.clear()
 
 
 def _quant_site(t: torch.Tensor, key):
     st = _fp8_state
     if st["tick"] is None:
         return K.quant_fp8(t)
+    pq = _prequant.get(t.data_ptr())
+    if pq is not None and pq[0].shape == t.shape:
+        return pq                       # the LayerNorm that produced `t` already wrote its e4m3 copy (layernorm_fwd_q8)
     site = st["sites"].get(key)
     if site is None:
         site = st["sites"][key] = [torch.zeros(3, device=t.device, dtype=torch.int32), st["host_step"]]
@@ -495,7 +502,7 @@ class LayerNormFn(Function):
     [3P] NystromAttention).  Output [B, pad + rows, D] in `out_dtype`."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, rows, pad, out_dtype):
+    def forward(ctx, x, gamma, beta, eps, rows, pad, out_dtype, q8_key=None):
         x = x.contiguous()
         Bn, T, D = x.shape
         y = torch.empty((Bn, pad + rows, D), device=x.device, dtype=out_dtype)
@@ -503,7 +510,20 @@ class LayerNormFn(Function):
             y[:, :pad].zero_()
         mean = torch.empty((Bn * rows,), device=x.device, dtype=f32)
         rstd = torch.empty_like(mean)
-        K.layernorm_fwd(x, gamma.detach(), beta.detach(), y[:, pad:], mean, rstd, Bn, rows, D, T * D, (pad + rows) * D, eps)
+        # fp8 forward policy: once the consumer's call site has a scale history (two exact steps), this launch also writes the
+        # e4m3 copy the projection reads, with that site's delayed scale — no quantisation pass over the LayerNorm output
+        st = _fp8_state
+        site = st["sites"].get(q8_key) if (q8_key is not None and st["tick"] is not None) else None
+        if (site is not None and st["host_step"] - site[1] >= 2 and x.dtype == f32 and out_dtype == bf16 and D % 4 == 0 and D <= 2048
+                and _LN_Q8):
+            q = torch.empty((Bn, pad + rows, D), device=x.device, dtype=torch.uint8)
+            if pad:
+                q[:, :pad].zero_()
+            sc = K.layernorm_fwd_q8(x, gamma.detach(), beta.detach(), y[:, pad:], mean, rstd, Bn, rows, D, T * D, (pad + rows) * D, eps,
+                                    q[:, pad:], site[0], st["tick"])
+            _prequant[y.data_ptr()] = (q, sc)
+        else:
+            K.layernorm_fwd(x, gamma.detach(), beta.detach(), y[:, pad:], mean, rstd, Bn, rows, D, T * D, (pad + rows) * D, eps)
         ctx.save_for_backward(x, gamma, mean, rstd, beta)
         ctx.rows, ctx.pad = rows, pad
         return y
@@ -525,17 +545,26 @@ class LayerNormFn(Function):
             G = G.view(x.shape)          # the RNA blocks run on [B, D]: layer_norm() added a leading 1
             K.layernorm_bwd(dy[:, pad:], x, gamma.detach(), mean, rstd, G, dg, db, Bn, rows, D, T * D, (pad + rows) * D,
                             accumulate_dx=True)
-            return None, _gret(gamma, dg, sunk_g), _gret(beta, db, sunk_b), None, None, None, None
+            return None, _gret(gamma, dg, sunk_g), _gret(beta, db, sunk_b), None, None, None, None, None
         dx = torch.zeros_like(x) if rows < T else torch.empty_like(x)
         K.layernorm_bwd(dy[:, pad:], x, gamma.detach(), mean, rstd, dx, dg, db, Bn, rows, D, T * D, (pad + rows) * D)
-        return dx, _gret(gamma, dg, sunk_g), _gret(beta, db, sunk_b), None, None, None, None
+        return dx, _gret(gamma, dg, sunk_g), _gret(beta, db, sunk_b), None, None, None, None, None
 
 
-def layer_norm(x, gamma, beta, eps, *, rows=None, pad=0, out_dtype=f32):
+_LN_Q8 = os.environ.get("MIRROR_LN_Q8", "1") != "0"      # A/B switch: LayerNorm writes the e4m3 copy of its output (fp8 policy)
+
+
+def fp8_site_key(w: torch.Tensor, prec: "Precision"):
+    """The key under which `linear(x, w)` keeps the delayed-scaling state of its activation operand (for a producer that
+    quantises on its behalf: layer_norm(..., q8_key=))."""
+    return (shadow(w, prec).data_ptr(), "x")
+
+
+def layer_norm(x, gamma, beta, eps, *, rows=None, pad=0, out_dtype=f32, q8_key=None):
     squeeze = x.dim() == 2
     if squeeze:
         x = x.unsqueeze(0)
-    y = LayerNormFn.apply(x, gamma, beta, eps, x.shape[1] if rows is None else rows, pad, out_dtype)
+    y = LayerNormFn.apply(x, gamma, beta, eps, x.shape[1] if rows is None else rows, pad, out_dtype, q8_key)
     return y.squeeze(0) if squeeze else y
 
 

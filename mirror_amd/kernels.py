@@ -383,6 +383,19 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, batches, rpb, D, x_bs, y_bs, ep
               eps, dt(x), dt(y), stream=_stream())
 
 
+def layernorm_fwd_q8(x, gamma, beta, y, mean, rstd, batches, rpb, D, x_bs, y_bs, eps, q8, ring, tick, margin: float = 1.25):
+    """layernorm_fwd (f32 in, bf16 out) that also writes the e4m3 copy q8 (uint8, y's row addressing) with the delayed scale of
+    `ring` (int32[3] device state of the call site) / `tick`; returns the dequantisation factor (f32[1])."""
+    _chk(x, gamma, beta, y, mean, rstd, q8, ring, tick)
+    if not (x.dtype == torch.float32 and y.dtype == torch.bfloat16 and q8.dtype == torch.uint8 and ring.numel() == 3
+            and ring.dtype == torch.int32 and tick.dtype == torch.float32):
+        raise MirrorHipError("layernorm_fwd_q8: f32 input, bf16 + uint8 outputs, int32[3] ring, f32 tick")
+    scale = torch.empty((1,), device=x.device, dtype=torch.float32)
+    _lib.call("mh_layernorm_fwd_q8", _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), batches, rpb, D, x_bs, y_bs, eps,
+              _p(q8), _p(ring), _p(tick), float(margin), _p(scale), stream=_stream())
+    return scale
+
+
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, batches, rpb, D, x_bs, y_bs, accumulate_dx=False):
     _chk(dy, x, gamma, mean, rstd, dx, dgamma, dbeta)
     rows = batches * rpb

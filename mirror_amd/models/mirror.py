@@ -193,7 +193,8 @@ class TransLayer(nn.Module):
         n, m = x.shape[1], a.num_landmarks
         pad = (m - n % m) % m
         l = math.ceil(n / m)  # noqa: E741
-        xp = Fn.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps, pad=pad, out_dtype=prec.act)
+        xp = Fn.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps, pad=pad, out_dtype=prec.act,
+                           q8_key=Fn.fp8_site_key(a.to_qkv.weight, prec) if prec.fp8_fwd else None)
         kmask = None
         if mask is not None:
             if mask.shape != x.shape[:2]:

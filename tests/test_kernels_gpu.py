@@ -1220,6 +1220,35 @@ def test_shadow_cache_does_not_outlive_its_tensor():
         assert float(Fn.shadow(w3, Fn.BF16).float().mean()) == 0.5
 
 
+def test_layernorm_writes_the_e4m3_copy_of_its_output_with_the_delayed_scale():
+    """mh_layernorm_fwd_q8 == mh_layernorm_fwd followed by mh_quant_fp8_delayed on its bf16 output: same bf16 rows, mean / rstd,
+    the same bytes, scale and ring update (behind `pad` front rows, as the Nystrom layers call it)."""
+    gen = g(321)
+    Bn, T, D, pad = 3, 70, 512, 6
+    x = (torch.randn(Bn, T, D, generator=gen) * 2 + 0.3).to(DEV)
+    gamma = (1 + 0.1 * torch.randn(D, generator=gen)).to(DEV)
+    beta = (0.1 * torch.randn(D, generator=gen)).to(DEV)
+    tick = torch.full((1,), 4.0, device=DEV)
+    ring_a = torch.zeros(3, device=DEV, dtype=torch.int32)
+    ring_a[0] = torch.tensor([2.5], device=DEV).view(torch.int32)[0]       # step 3's maximum (slot (4 + 2) % 3 = 0)
+    ring_a[2] = 999                                                        # slot (4 + 1) % 3 = 2 must be cleared
+    ring_b = ring_a.clone()
+    bf = torch.bfloat16
+
+    def bufs():
+        y = torch.zeros((Bn, pad + T, D), device=DEV, dtype=bf)
+        return y, torch.empty(Bn * T, device=DEV), torch.empty(Bn * T, device=DEV)
+    y1, m1, r1 = bufs()
+    K.layernorm_fwd(x, gamma, beta, y1[:, pad:], m1, r1, Bn, T, D, T * D, (pad + T) * D, 1e-5)
+    q1, s1 = K.quant_fp8_delayed(y1[:, pad:].contiguous(), ring_a, tick)
+    y2, m2, r2 = bufs()
+    q2 = torch.zeros((Bn, pad + T, D), device=DEV, dtype=torch.uint8)
+    s2 = K.layernorm_fwd_q8(x, gamma, beta, y2[:, pad:], m2, r2, Bn, T, D, T * D, (pad + T) * D, 1e-5, q2[:, pad:], ring_b, tick)
+    assert torch.equal(y1, y2) and torch.equal(m1, m2) and torch.equal(r1, r2)
+    assert torch.equal(q1, q2[:, pad:]) and float(s1) == float(s2) and int(q2[:, :pad].abs().max()) == 0
+    assert torch.equal(ring_a, ring_b) and int(ring_b[2]) == 0
+
+
 def test_fp8_delayed_scaling_quantisation_uses_last_steps_amax_and_rotates_its_ring():
     """mh_quant_fp8_delayed: scale = margin x amax of the PREVIOUS step (3-slot ring keyed by a device-side step counter), this
     step's amax lands in its own slot, the slot after it is cleared; values are bit-exact against torch.float8_e4m3fn at that
