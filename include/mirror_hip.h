@@ -213,6 +213,10 @@ int64_t mh_pinv_chain_workspace_bytes(int BH, int m, int iters, int which);
  * masked row comes out uniform, as in the package) and gets no gradient.  NULL: no mask. */
 int mh_nys_attn1_fwd(const void* qkv, const void* lm, const void* w2, void* out, float* lse1, const float* mrow, const float* mlm,
                      int B, int h, int n_p, int m, int dh, float scale, int accumulate, mh_stream s);
+/* unmasked mh_nys_attn1_fwd that also writes the e4m3 copy q8 [B, n_p, D] bytes of `out` (delayed scaling: ring / tick / margin as
+ * in mh_quant_fp8_delayed, q8_scale[0] = dequantisation factor): the fp8 forward of [3P] to_out needs no quantisation pass */
+int mh_nys_attn1_fwd_q8(const void* qkv, const void* lm, const void* w2, void* out, float* lse1, int B, int h, int n_p, int m, int dh,
+                        float scale, int accumulate, void* q8, unsigned* ring, const float* tick, float margin, float* q8_scale, mh_stream s);
 /* attn3_fwd cuts the sequence into ranges (one workgroup each) when B*h alone would not fill the chip; the partial results
  * live in `workspace` (mh_nys_attn3_ws_floats(B, h, n_p) floats; NULL / too small: one workgroup per (b, h)). */
 int64_t mh_nys_attn3_ws_floats(int B, int h, int n_p);

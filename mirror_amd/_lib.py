@@ -76,6 +76,7 @@ _SIGS = {
     "mh_pinv_chain_fwd": [P, P, P, I, I, I],
     "mh_pinv_chain_bwd": [P, P, P, P, P, P, I, I, I],
     "mh_nys_attn1_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, F, I],
+    "mh_nys_attn1_fwd_q8": [P, P, P, P, P, I, I, I, I, I, F, I, P, P, P, F, P],
     "mh_nys_attn3_fwd": [P, P, P, P, P, L, P, P, I, I, I, I, I, F],
     "mh_nys_attn1_bwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F],
     "mh_nys_attn3_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F],

@@ -168,6 +168,16 @@ __device__ __forceinline__ void mask_zero16(f32x16& d, const f32x16& vr, float v
     for (int e = 0; e < 16; e++) d[e] = (vr[e] * vl != 0.f) ? d[e] : 0.f;
 }
 
+// e4m3 copy of attn1's output for the fp8 forward of to_out (BASELINE config 5): delayed per-tensor scaling as in
+// mh_quant_fp8_delayed (ring of three per-site maxima rotated by the device-side step counter)
+struct Q8Out {
+    unsigned char* q;
+    unsigned* ring;
+    const float* tick;
+    float margin;
+    float* scale;
+};
+
 struct Geo {
     int h, n_p, D;
     float scale, scale2;    // scale2 = scale * log2(e)
@@ -181,15 +191,27 @@ struct Geo {
 // The landmark images (k_l, w2: 64 KB) are staged ONCE per workgroup; after that every wave walks its own 32-row blocks
 // of the sequence (block = first + i * 4 * splits) with the q fragments read straight from HBM one block ahead — no
 // LDS writes and no barriers in the loop.  (One 128-row tile per workgroup spent 3x longer staging than computing.)
-template <bool MASKED>
+template <bool MASKED, bool Q8 = false>
 __global__ __launch_bounds__(NT) void nys_a1_fwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ lm,
                                                         const bf16_t* __restrict__ w2, bf16_t* __restrict__ out,
-                                                        float* __restrict__ lse1, Geo g) {
+                                                        float* __restrict__ lse1, Geo g, Q8Out q8 = Q8Out{}) {
     __shared__ __attribute__((aligned(16))) bf16_t s_kl_[NM * NP];
     __shared__ __attribute__((aligned(16))) bf16_t s_w2_[NM * NP];
     __shared__ __attribute__((aligned(16))) float s_mlm_[NM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hl = lane >> 5;
     const int bh = blockIdx.y, b = bh / g.h, hd = bh % g.h, D = g.D;
+    float q8mul = 1.f, q8max = 0.f;
+    int q8cur = 0;
+    if constexpr (Q8) {
+        const int t = (int)q8.tick[0];
+        q8cur = t % 3;
+        const float amax = __uint_as_float(q8.ring[(t + 2) % 3]) * q8.margin;
+        q8mul = amax > 0.f ? 448.f / amax : 1.f;
+        if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+            q8.scale[0] = amax > 0.f ? amax / 448.f : 1.f;
+            q8.ring[(t + 1) % 3] = 0u;
+        }
+    }
     stage_rows<NM>(s_kl_, lm + (long)b * NM * 2 * D + D + hd * ND, 2 * D, tid);
     stage_rows<NM>(s_w2_, w2 + (long)bh * NM * ND, ND, tid);
     constexpr bool masked = MASKED;
@@ -287,8 +309,27 @@ __global__ __launch_bounds__(NT) void nys_a1_fwd_kernel(const bf16_t* __restrict
                     o[nb][4 * gq + 3] += __uint_as_float(old[nb][gq][1] & 0xffff0000u);
                 }
                 store_row4(orow + 32 * nb + 8 * gq + 4 * hl, o[nb], gq);
+                if constexpr (Q8) {       // the e4m3 copy of exactly the bf16 values just stored
+                    float v4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        v4[e] = bf2f(f2bf(o[nb][4 * gq + e]));
+                        q8max = fmaxf(q8max, fabsf(v4[e]));
+                        v4[e] = fminf(fmaxf(v4[e] * q8mul, -448.f), 448.f);
+                    }
+                    unsigned w = 0;
+                    w = __builtin_amdgcn_cvt_pk_fp8_f32(v4[0], v4[1], w, false);
+                    w = __builtin_amdgcn_cvt_pk_fp8_f32(v4[2], v4[3], w, true);
+                    *reinterpret_cast<unsigned*>(q8.q + ((long)b * g.n_p + row) * D + hd * ND + 32 * nb + 8 * gq + 4 * hl) = w;
+                }
             }
         }
+    }
+    if constexpr (Q8) {       // one atomic per wave that raises the step's maximum
+        float m = q8max;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (lane == 0 && m > 0.f) atomicMax(q8.ring + q8cur, __float_as_uint(m));
     }
 }
 
@@ -896,8 +937,22 @@ extern "C" int mh_nys_attn1_fwd(const void* qkv, const void* lm, const void* w2,
     MH_REQUIRE((mrow == nullptr) == (mlm == nullptr), "mh_nys_attn1_fwd: mrow and mlm go together");
     const Geo g{h, n_p, h * ND, scale, scale * LOG2E, mrow, mlm, accumulate};
     NYS_LAUNCH(nys_a1_fwd_kernel, dim3(pick_walkers(B * h, n_p), B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv, (const bf16_t*)lm,
-                       (const bf16_t*)w2, (bf16_t*)out, lse1, g);
+                       (const bf16_t*)w2, (bf16_t*)out, lse1, g, Q8Out{});
     MH_LAUNCH_CHECK("mh_nys_attn1_fwd");
+    return MH_OK;
+}
+
+extern "C" int mh_nys_attn1_fwd_q8(const void* qkv, const void* lm, const void* w2, void* out, float* lse1, int B, int h, int n_p, int m,
+                                   int dh, float scale, int accumulate, void* q8, unsigned* ring, const float* tick, float margin,
+                                   float* q8_scale, mh_stream s) {
+    if (int e = check_geo("mh_nys_attn1_fwd_q8", B, h, n_p, m, dh)) return e;
+    if (B == 0) return MH_OK;
+    MH_REQUIRE(q8 && ring && tick && q8_scale && margin >= 1.f && ((uintptr_t)q8 & 3) == 0, "mh_nys_attn1_fwd_q8: q8, ring, tick, scale and margin >= 1");
+    const Geo g{h, n_p, h * ND, scale, scale * LOG2E, nullptr, nullptr, accumulate};
+    const Q8Out o{(unsigned char*)q8, ring, tick, margin, q8_scale};
+    hipLaunchKernelGGL((nys_a1_fwd_kernel<false, true>), dim3(pick_walkers(B * h, n_p), B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv,
+                       (const bf16_t*)lm, (const bf16_t*)w2, (bf16_t*)out, lse1, g, o);
+    MH_LAUNCH_CHECK("mh_nys_attn1_fwd_q8");
     return MH_OK;
 }
 

@@ -906,7 +906,7 @@ class NystromCoreFn(Function):
     (a1 @ a2inv) @ (a3 @ v), 2 m^2 D instead of 2 n_p m^2 h flops)."""
 
     @staticmethod
-    def forward(ctx, qkv, res_w, heads, l, iters, prec, kmask=None):
+    def forward(ctx, qkv, res_w, heads, l, iters, prec, kmask=None, q8_key=None):
         """kmask: None, or the package's key-padding mask prepared by TransLayer as (rows [B, n_p], landmarks [B, m],
         landmark scale [B, m]) float tensors: rows of qkv that are masked out are already zero (the caller zeroes the
         LayerNorm output in front of the bias-free to_qkv); here the landmark means become masked means and the three
@@ -983,7 +983,15 @@ class NystromCoreFn(Function):
         pio = pm if (pm == MH_BF16 or A == f32) else mma
         w2 = K.gemm(zf, av, mma=pio, out_dtype=A)
         if fused:
-            lse1 = K.nys_attn1_fwd(qkv, lm, w2, out, h, scale, accumulate=True, kmask=kmask)
+            # fp8 forward policy: once to_out's call site has a scale history, attn1 also writes the e4m3 copy that projection reads
+            st8 = _fp8_state
+            site = st8["sites"].get(q8_key) if (q8_key is not None and st8["tick"] is not None and kmask is None) else None
+            if site is not None and st8["host_step"] - site[1] >= 2 and _LN_Q8:
+                q8 = torch.empty(out.shape, device=out.device, dtype=torch.uint8)
+                lse1, sc8 = K.nys_attn1_fwd_q8(qkv, lm, w2, out, h, scale, True, q8, site[0], st8["tick"])
+                _prequant[out.data_ptr()] = (q8, sc8)
+            else:
+                lse1 = K.nys_attn1_fwd(qkv, lm, w2, out, h, scale, accumulate=True, kmask=kmask)
         else:
             K.gemm(a1, w2, out=_heads(out, 0, 1, h), mma=mma)
             K.resconv(qkv[..., 2 * D:], res_w.detach().contiguous(), out, h, transpose=False, accumulate=True)
@@ -1085,7 +1093,7 @@ class NystromCoreFn(Function):
             dlm = K.row_scale(dlm, lscale)
         K.landmark_bwd(K.cast(dlm, A), dqkv, l)
         dres = _gret(res_w, dres, dres_sunk)
-        return dqkv, (None if dres is None else dres.view_as(res_w)), None, None, None, None, None
+        return dqkv, (None if dres is None else dres.view_as(res_w)), None, None, None, None, None, None
 
 
 class RowScaleFn(Function):

@@ -683,6 +683,23 @@ def nys_attn1_fwd(qkv, lm, w2, out, heads: int, scale: float, accumulate: bool =
     return lse1
 
 
+def nys_attn1_fwd_q8(qkv, lm, w2, out, heads: int, scale: float, accumulate: bool, q8, ring, tick, margin: float = 1.25):
+    """nys_attn1_fwd (no mask) that also writes the e4m3 copy of `out` into q8 (uint8, out's shape) with the delayed scale of
+    `ring` / `tick`; returns (lse1, dequantisation factor)."""
+    _chk(qkv, lm, w2, out, q8, ring, tick)
+    B, n_p, _ = qkv.shape
+    if not (q8.dtype == torch.uint8 and q8.shape == out.shape and q8.is_contiguous() and ring.dtype == torch.int32 and ring.numel() == 3
+            and tick.dtype == torch.float32):
+        raise MirrorHipError("nys_attn1_fwd_q8: q8 uint8 shaped like out, int32[3] ring, f32 tick")
+    lse1 = torch.empty((B, heads, n_p), device=qkv.device, dtype=torch.float32)
+    sc = torch.empty((1,), device=qkv.device, dtype=torch.float32)
+    _nys_check("nys_attn1_fwd", B, heads, n_p, qkv=qkv, lm=lm, w2=w2, out=out)
+    _nys_launch("nys_a1_fwd_kernel", 2 * 2.0 * n_p * NYS_FUSED_M * NYS_FUSED_DH * B * heads,
+                lambda: _lib.call("mh_nys_attn1_fwd_q8", _p(qkv), _p(lm), _p(w2), _p(out), _p(lse1), B, heads, n_p, NYS_FUSED_M,
+                                  NYS_FUSED_DH, scale, int(accumulate), _p(q8), _p(ring), _p(tick), float(margin), _p(sc), stream=_stream()))
+    return lse1, sc
+
+
 def nys_attn3_fwd(qkv, lm, heads: int, scale: float, kmask=None):
     """av = softmax_n(scale q_l k^T) v as [B, h, m, dh] f32, and the row logsumexp [B, h, m]."""
     _chk(qkv, lm)

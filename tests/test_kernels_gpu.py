@@ -1220,6 +1220,32 @@ def test_shadow_cache_does_not_outlive_its_tensor():
         assert float(Fn.shadow(w3, Fn.BF16).float().mean()) == 0.5
 
 
+def test_attn1_forward_writes_the_e4m3_copy_of_its_output_with_the_delayed_scale():
+    """mh_nys_attn1_fwd_q8 == mh_nys_attn1_fwd followed by mh_quant_fp8_delayed on `out` (accumulate mode, as the model calls it):
+    same bf16 output and lse, same bytes, scale and ring update."""
+    gen = g(654)
+    B, h, n_p, m, dh = 2, 2, 512, 256, 64
+    D = h * dh
+    bf = torch.bfloat16
+    qkv = torch.randn(B, n_p, 3 * D, generator=gen).to(DEV, bf)
+    lm = torch.randn(B, m, 2 * D, generator=gen).to(DEV, bf)
+    w2 = torch.randn(B, h, m, dh, generator=gen).to(DEV, bf)
+    base = torch.randn(B, n_p, D, generator=gen).to(DEV, bf)
+    tick = torch.full((1,), 7.0, device=DEV)
+    ring_a = torch.zeros(3, device=DEV, dtype=torch.int32)
+    ring_a[0] = torch.tensor([3.0], device=DEV).view(torch.int32)[0]       # (7 + 2) % 3 = 0: the previous step's maximum
+    ring_a[2] = 77                                                         # (7 + 1) % 3 = 2: cleared
+    ring_b = ring_a.clone()
+    o1 = base.clone()
+    l1 = K.nys_attn1_fwd(qkv, lm, w2, o1, h, dh ** -0.5, accumulate=True)
+    q1, s1 = K.quant_fp8_delayed(o1, ring_a, tick)
+    o2 = base.clone()
+    q2 = torch.empty((B, n_p, D), device=DEV, dtype=torch.uint8)
+    l2, s2 = K.nys_attn1_fwd_q8(qkv, lm, w2, o2, h, dh ** -0.5, True, q2, ring_b, tick)
+    assert torch.equal(o1, o2) and torch.equal(l1, l2)
+    assert torch.equal(q1, q2) and float(s1) == float(s2) and torch.equal(ring_a, ring_b)
+
+
 def test_layernorm_writes_the_e4m3_copy_of_its_output_with_the_delayed_scale():
     """mh_layernorm_fwd_q8 == mh_layernorm_fwd followed by mh_quant_fp8_delayed on its bf16 output: same bf16 rows, mean / rstd,
     the same bytes, scale and ring update (behind `pad` front rows, as the Nystrom layers call it)."""

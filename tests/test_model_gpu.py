@@ -289,9 +289,9 @@ def test_fp8_forward_policy_is_close_and_trains():
         return np.array(traj), len(launches), len(fused)
     t_del, n_del, n_ln = run(True)
     t_exact, n_exact, n_ln_exact = run(False)
-    # steps 3..5: the three LayerNorms in front of to_qkv write the e4m3 copy themselves; the other >= 5 activation sites and the
-    # weights take the one-pass quantisation launch
-    assert n_exact == 0 and n_ln_exact == 0 and n_ln == 3 * 3 and n_del >= 3 * (5 + 8), (n_exact, n_del, n_ln)
+    # steps 3..5: the three LayerNorms in front of to_qkv write the e4m3 copy themselves (and, where the fused attention kernels
+    # run, attn1 does for to_out); the other activation sites and the weights take the one-pass quantisation launch
+    assert n_exact == 0 and n_ln_exact == 0 and n_ln == 3 * 3 and n_del >= 3 * (2 + 8), (n_exact, n_del, n_ln)
     assert np.isfinite(t_del).all()
     # the first two steps ARE the exact path: step 1 agrees to rounding; step 2 sits behind one Adam update, whose first step
     # moves every weight by lr * sign(g), so parameters whose gradient is f32-atomics noise around zero make it run-to-run
