@@ -24,6 +24,7 @@
 // Layout (SURVEY.md §8 / DESIGN.md §4): qkv [B, n_p, 3D] bf16, heads are 64-wide column slices; landmarks lm
 // [B, m, 2D] = q_l | k_l; w2, av, dav [B, h, m, 64]; out / dout [B, n_p, D].
 #include <cstdlib>
+#include <cstring>
 #include "gemm_kernel.h"
 
 namespace {
@@ -909,6 +910,7 @@ __global__ __launch_bounds__(NT) void nys_a3_bwd_dql_kernel(const bf16_t* __rest
 int pick_walkers(int BH, int n_p) {
     static const char* env = getenv("MH_NYS_WALKERS");      // timing experiments: "max" = one 128-row tile per workgroup
     if (env && env[0] == 'm') return n_p / TR;
+    if (env && atoi(env) > 0) return min(atoi(env), max(1, n_p / 128));
     int w = 1;
     while (BH * w < 512 && 4 * w * 2 <= n_p / 32) w *= 2;
     return w;
@@ -956,11 +958,11 @@ extern "C" int mh_nys_attn1_fwd_q8(const void* qkv, const void* lm, const void* 
     return MH_OK;
 }
 
-int pick_splits(int BH, int ntiles);
+int pick_splits(int BH, int ntiles, int which);
 
 extern "C" int64_t mh_nys_attn3_ws_floats(int B, int h, int n_p) {
     if (B <= 0 || h <= 0 || n_p < TR) return 0;
-    const int splits = pick_splits(B * h, n_p / TR);
+    const int splits = pick_splits(B * h, n_p / TR, 0);
     return splits > 1 ? (int64_t)B * h * splits * A3_PART : 0;
 }
 
@@ -972,7 +974,7 @@ extern "C" int mh_nys_attn3_fwd(const void* qkv, const void* lm, float* av, floa
     if (B == 0) return MH_OK;
     const Geo g{h, n_p, h * ND, scale, scale * LOG2E, mrow, mlm, 0};
     const int ntiles = n_p / TR;
-    int splits = pick_splits(B * h, ntiles);
+    int splits = pick_splits(B * h, ntiles, 0);
     if (!workspace || ws_floats < (int64_t)B * h * splits * A3_PART) splits = 1;      // no room for partials: one workgroup per (b, h)
     const int tpw = (ntiles + splits - 1) / splits;
     splits = (ntiles + tpw - 1) / tpw;                                                 // no empty ranges
@@ -988,11 +990,20 @@ extern "C" int mh_nys_attn3_fwd(const void* qkv, const void* lm, float* av, floa
 }
 
 // splits: workgroups per (b, h) for the landmark-owner kernels (partials in a workspace, or f32 atomics)
-int pick_splits(int BH, int ntiles) {
-    static const char* env = getenv("MH_NYS_SPLITS");       // timing experiments: force the number of sequence ranges
-    if (env && atoi(env) > 0) return min(atoi(env), ntiles);
+// which: 0 = attn3 forward (+ combine pass), 1 = attn1 backward dw2 / dk_l, 2 = attn3 backward dq_l (f32 atomics).
+// One workgroup per CU in all (B h x splits ~ 256): measured in the step at B h = 128, 2 ranges per (b, h) beat 4 by 1.7 %
+// (half the partial tiles / atomics, and these launches run beside the half-chip chain) and 1 by 1.2 %.
+int pick_splits(int BH, int ntiles, int which) {
+    static const char* env = getenv("MH_NYS_SPLITS");       // timing experiments: force the number of sequence ranges ("a,b,c" per kernel)
+    if (env && atoi(env) > 0) {
+        int v[3] = {atoi(env), 0, 0};
+        const char* p = env;
+        for (int i = 1; i < 3; i++) { p = strchr(p, ','); if (!p) break; v[i] = atoi(++p); }
+        const int f = v[which] > 0 ? v[which] : v[0];
+        return min(f, ntiles);
+    }
     int splits = 1;
-    while (BH * splits < 512 && splits * 2 <= ntiles) splits *= 2;
+    while (BH * splits < 256 && splits * 2 <= ntiles) splits *= 2;
     return splits;
 }
 
@@ -1005,7 +1016,7 @@ extern "C" int mh_nys_attn1_bwd(const void* qkv, const void* lm, const void* w2,
     NYS_LAUNCH(nys_a1_bwd_dq_kernel, dim3(pick_walkers(B * h, n_p), B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv,
                        (const bf16_t*)lm, (const bf16_t*)w2, (const bf16_t*)dout, lse1, delta1, (bf16_t*)dqkv, g);
     MH_LAUNCH_CHECK("mh_nys_attn1_bwd(dq)");
-    const int ntiles = n_p / TR, splits = pick_splits(B * h, ntiles), tpw = (ntiles + splits - 1) / splits;
+    const int ntiles = n_p / TR, splits = pick_splits(B * h, ntiles, 1), tpw = (ntiles + splits - 1) / splits;
     NYS_LAUNCH(nys_a1_bwd_dw_kernel, dim3(splits, B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv,
                        (const bf16_t*)lm, (const bf16_t*)w2, (const bf16_t*)dout, lse1, (const float*)delta1, dw2, dlm, g, tpw);
     MH_LAUNCH_CHECK("mh_nys_attn1_bwd(dw)");
@@ -1022,7 +1033,7 @@ extern "C" int mh_nys_attn3_bwd(const void* qkv, const void* lm, const float* av
     NYS_LAUNCH(nys_a3_bwd_dkv_kernel, dim3(pick_walkers(B * h, n_p), B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv,
                        (const bf16_t*)lm, (const float*)delta3, (const bf16_t*)dav, lse3, (bf16_t*)dqkv, g);
     MH_LAUNCH_CHECK("mh_nys_attn3_bwd(dkv)");
-    const int ntiles = n_p / TR, splits = pick_splits(B * h, ntiles), tpw = (ntiles + splits - 1) / splits;
+    const int ntiles = n_p / TR, splits = pick_splits(B * h, ntiles, 2), tpw = (ntiles + splits - 1) / splits;
     NYS_LAUNCH(nys_a3_bwd_dql_kernel, dim3(splits, B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv,
                        (const bf16_t*)lm, (const float*)delta3, (const bf16_t*)dav, lse3, dlm, g, tpw);
     MH_LAUNCH_CHECK("mh_nys_attn3_bwd(dql)");
