@@ -340,8 +340,8 @@ int mh_ce_rows_bwd(const float* G, int64_t ldg, const float* scale, float scale_
  * (a row window of a larger buffer: the WSI target is encoder_output[:, 1:], models/mirror.py:700) */
 int mh_mse_masked_fwd(const void* pred, const void* tgt, const float* mask, float* acc, int64_t rows, int D,
                       int64_t rows_per_batch, int64_t tgt_bs, int dt_p, int dt_t, mh_stream s);
-/* dpred[rows, D] (dt_dp) = g * 2*mask*(p-t)/(D*acc[1]); dtgt[rows, D] (dt_t) = -dpred, not written when NULL */
-int mh_mse_masked_bwd(const void* pred, const void* tgt, const float* mask, const float* acc, const float* g,
+/* dpred[rows, D] (dt_dp) = g[0] * gmul * 2*mask*(p-t)/(D*acc[1]) (gmul: the term's loss weight, host constant); dtgt[rows, D] (dt_t) = -dpred, not written when NULL */
+int mh_mse_masked_bwd(const void* pred, const void* tgt, const float* mask, const float* acc, const float* g, float gmul,
                       void* dpred, void* dtgt, int64_t rows, int D, int64_t rows_per_batch, int64_t tgt_bs, int dt_p, int dt_t,
                       int dt_dp, mh_stream s);
 /* Data feed (datasets/dataset_pretrain.py:150-167, `wsi_feature[sampled_indices]`): out[r, :] = src[row[r], :] for R rows of F
@@ -366,6 +366,61 @@ int mh_kl_bwd(const float* mu, const float* ls, const float* g, float* dmu, floa
 int mh_symkl_fwd(const float* w, const float* r, float* out, int B, int P, float coef, mh_stream s);
 int mh_symkl_bwd(const float* w, const float* r, const float* g, float* dw, float* dr, int B, int P, float coef,
                  mh_stream s);
+
+/* MIRRORLoss's small terms in one launch each way (losses/mirror_loss.py:74-135, everything but the WSI retention MSE):
+ * the rank-local CLIP alignment term (:37-52: logits s W R^T, both cross-entropies, and in the backward the gradient
+ * products d W = P R, d R = P^T W and d s), the RNA retention MSE (:98-103), both style KLs (:105-112), the cluster KL
+ * (:114-119) and the weighted total (:121-127).  All tensors f32, contiguous.  weight[] = {alignment, wsi retention,
+ * rna retention, style (wsi), style (rna), cluster}.
+ *   forward : out[8] = {total, alignment, wsi retention, rna retention, style_w + style_r, cluster, style_w, style_r};
+ *             wsi_acc = the {num, den} pair mh_mse_masked_fwd accumulated on the same stream BEFORE this call (NULL: 0);
+ *             scratch = 8 floats zeroed by the caller (kept for the backward), save = B*B + 2B floats (kept as well).
+ *   backward: the upstream of term i is weight[i] * g_total[0] + (g_terms ? g_terms[i] : 0); every d_* of a term that is
+ *             present is overwritten.  The WSI retention gradient stays mh_mse_masked_bwd(g = g_total, gmul = weight[1]).
+ * has_align = 0: the alignment term was computed by the caller over the gathered batch (align_ext, one float, may be
+ * NULL = 0) and the backward writes its upstream to d_align_ext.  Alignment in here needs B <= 32 and
+ * 2 B (D + 1) + B (B + 1) floats of LDS <= 150 KiB. */
+typedef struct {
+    const float* wsi_emb;      /* [B, D] L2-normalised alignment embeddings */
+    const float* rna_emb;      /* [B, D] */
+    const float* logit_scale;  /* one float: exp(logit_scale parameter) */
+    const float* align_ext;
+    int32_t B, D, has_align;
+    const float* rna_pred;     /* [n_rna] reconstructed expression, target, mask (1 = masked gene) */
+    const float* rna_tgt;
+    const float* rna_mask;
+    int64_t n_rna;
+    const float* w_mu;         /* style posteriors: [rows, latent] each */
+    const float* w_logstd;
+    const float* r_mu;
+    const float* r_logstd;
+    int64_t n_wstyle, n_rstyle;
+    int32_t rows_wstyle, rows_rstyle;
+    const float* w_score;      /* prototype scores [Bc, P] (logits; the kernel takes the softmax) */
+    const float* r_score;
+    int32_t Bc, P;
+    const float* wsi_acc;
+    float weight[6];
+    float* scratch;
+    float* save;
+    float* out;
+    const float* g_total;      /* backward only from here */
+    const float* g_terms;
+    float* d_wsi_emb;
+    float* d_rna_emb;
+    float* d_logit_scale;
+    float* d_align_ext;
+    float* d_rna_pred;
+    float* d_rna_tgt;          /* = -d_rna_pred; NULL: not written (the target is data) */
+    float* d_w_mu;
+    float* d_w_logstd;
+    float* d_r_mu;
+    float* d_r_logstd;
+    float* d_w_score;
+    float* d_r_score;
+} mh_loss_terms;
+int mh_loss_terms_fwd(const mh_loss_terms* d, mh_stream s);
+int mh_loss_terms_bwd(const mh_loss_terms* d, mh_stream s);
 
 /* ---------------------------------------------------------------- step glue (train_mirror.py:1133-1136, :1230, :1254-1255) */
 int mh_rownorm_(float* w, int rows, int D, float eps, mh_stream s);

@@ -38,6 +38,24 @@ class GemmDesc(C.Structure):
 P, I, L, F, U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 
 
+class LossTermsDesc(C.Structure):
+    """mh_loss_terms of include/mirror_hip.h (field order = the header's)."""
+    _fields_ = [
+        ("wsi_emb", C.c_void_p), ("rna_emb", C.c_void_p), ("logit_scale", C.c_void_p), ("align_ext", C.c_void_p),
+        ("B", C.c_int32), ("D", C.c_int32), ("has_align", C.c_int32),
+        ("rna_pred", C.c_void_p), ("rna_tgt", C.c_void_p), ("rna_mask", C.c_void_p), ("n_rna", C.c_int64),
+        ("w_mu", C.c_void_p), ("w_logstd", C.c_void_p), ("r_mu", C.c_void_p), ("r_logstd", C.c_void_p),
+        ("n_wstyle", C.c_int64), ("n_rstyle", C.c_int64), ("rows_wstyle", C.c_int32), ("rows_rstyle", C.c_int32),
+        ("w_score", C.c_void_p), ("r_score", C.c_void_p), ("Bc", C.c_int32), ("P", C.c_int32),
+        ("wsi_acc", C.c_void_p), ("weight", C.c_float * 6),
+        ("scratch", C.c_void_p), ("save", C.c_void_p), ("out", C.c_void_p),
+        ("g_total", C.c_void_p), ("g_terms", C.c_void_p),
+        ("d_wsi_emb", C.c_void_p), ("d_rna_emb", C.c_void_p), ("d_logit_scale", C.c_void_p), ("d_align_ext", C.c_void_p),
+        ("d_rna_pred", C.c_void_p), ("d_rna_tgt", C.c_void_p), ("d_w_mu", C.c_void_p), ("d_w_logstd", C.c_void_p), ("d_r_mu", C.c_void_p),
+        ("d_r_logstd", C.c_void_p), ("d_w_score", C.c_void_p), ("d_r_score", C.c_void_p),
+    ]
+
+
 class RnaBlockDesc(C.Structure):
     """mh_rna_block of include/mirror_hip.h (field order = the header's)."""
     _fields_ = (
@@ -105,7 +123,7 @@ _SIGS = {
     "mh_ce_rows_fwd": [P, L, P, F, I, I, I, F, P, P, P],
     "mh_ce_rows_bwd": [P, L, P, F, P, P, I, F, P, P, I, I, I],
     "mh_mse_masked_fwd": [P, P, P, P, L, I, L, L, I, I],
-    "mh_mse_masked_bwd": [P, P, P, P, P, P, P, L, I, L, L, I, I, I],
+    "mh_mse_masked_bwd": [P, P, P, P, P, F, P, P, L, I, L, L, I, I, I],
     "mh_fanout_bwd": [P, P, F, P, P, I, I, I, I],
     "mh_gather_rows": [P, P, P, L, L, L, I],
     "mh_quant_fp8": [P, L, P, P, P, I],
@@ -126,6 +144,8 @@ _SIGS = {
     "mh_grad_clip": [P, L, F, F, P, P],
     "mh_rna_block_fwd": [C.POINTER(RnaBlockDesc)],
     "mh_rna_block_bwd": [C.POINTER(RnaBlockDesc)],
+    "mh_loss_terms_fwd": [C.POINTER(LossTermsDesc)],
+    "mh_loss_terms_bwd": [C.POINTER(LossTermsDesc)],
 }
 EXPORTS = sorted(list(_SIGS) + ["mh_last_error", "mh_version", "mh_device_ok", "mh_nys_attn3_ws_floats", "mh_rna_block_workspace_bytes",
                                  "mh_gemm_workspace_bytes", "mh_layernorm_bwd_workspace_bytes", "mh_nys_attn3_workspace_bytes",

@@ -14,7 +14,7 @@ void mh_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* mh_last_error(void) { return g_err; }
-extern "C" int mh_version(void) { return 102; }   // 102: mh_gemm_desc.k_segments, mh_rna_block, *_workspace_bytes queries
+extern "C" int mh_version(void) { return 103; }   // 103: mh_loss_terms_fwd / _bwd, mh_mse_masked_bwd(gmul)
 
 extern "C" int mh_device_ok(void) {
     int n = 0;

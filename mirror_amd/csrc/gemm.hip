@@ -56,18 +56,35 @@ __global__ __launch_bounds__(256) void rank_update_kernel(const TA* __restrict__
     const int n = blockIdx.x * 256 + threadIdx.x, m = blockIdx.y;
     if (n >= N) return;
     float acc = 0.f;
-    for (int z = 0; z < batch; z++)
-        for (int k = 0; k < KT; k++) acc += ldf(A + z * sA + (long)k * lda + m) * ldf(B + z * sB + (long)k * ldb + n);
+    // batch * KT (<= 16 * 16) independent products: eight loads of each operand in flight, not one dependent pair at a time
+    const int total = batch * KT;
+    int i = 0;
+    for (; i + 8 <= total; i += 8) {
+        float a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int z = (i + u) / KT, k = (i + u) - z * KT;
+            a[u] = ldf(A + z * sA + (long)k * lda + m);
+            b[u] = ldf(B + z * sB + (long)k * ldb + n);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc += a[u] * b[u];
+    }
+    for (; i < total; i++) {
+        const int z = i / KT, k = i - z * KT;
+        acc += ldf(A + z * sA + (long)k * lda + m) * ldf(B + z * sB + (long)k * ldb + n);
+    }
     C[(long)m * ldc + n] += alpha * acc;
 }
 
 static bool try_rank_update(const mh_gemm_desc* t, hipStream_t s) {
     const int batch = t->batch1 * t->batch2;
-    if (t->K > 8 || t->a_kc || t->b_kc || t->dtC != MH_F32 || !t->accumulate || t->bias || t->R || t->diag != 0.f || t->act != MH_ACT_NONE)
+    if (t->K > 16 || t->a_kc || t->b_kc || t->dtC != MH_F32 || !t->accumulate || t->bias || t->R || t->diag != 0.f || t->act != MH_ACT_NONE)
         return false;
-    if (t->batch2 != 1 || (batch > 1 && (t->sC1 != 0 || t->sC2 != 0)) || t->M > 65535) return false;
+    if ((t->batch1 != 1 && t->batch2 != 1) || (batch > 1 && (t->sC1 != 0 || t->sC2 != 0)) || t->M > 65535 || batch * t->K > 256) return false;
+    const long sA = t->batch1 > 1 ? t->sA1 : t->sA2, sB = t->batch1 > 1 ? t->sB1 : t->sB2;     // the one batch axis in use
     dim3 grid(mh_cdiv(t->N, 256), t->M);
-#define RU_(TA, TB) hipLaunchKernelGGL((rank_update_kernel<TA, TB>), grid, dim3(256), 0, s, (const TA*)t->A, (long)t->lda, (long)t->sA1, (const TB*)t->B, (long)t->ldb, (long)t->sB1, (float*)t->C, (long)t->ldc, t->M, t->N, t->K, batch, t->alpha)
+#define RU_(TA, TB) hipLaunchKernelGGL((rank_update_kernel<TA, TB>), grid, dim3(256), 0, s, (const TA*)t->A, (long)t->lda, sA, (const TB*)t->B, (long)t->ldb, sB, (float*)t->C, (long)t->ldc, t->M, t->N, t->K, batch, t->alpha)
     if (t->dtA == MH_BF16 && t->dtB == MH_BF16) RU_(bf16_t, bf16_t);
     else if (t->dtA == MH_F32 && t->dtB == MH_F32) RU_(float, float);
     else if (t->dtA == MH_F32) RU_(float, bf16_t);

@@ -145,8 +145,8 @@ template <typename TP, typename TT, typename TD>
 __global__ __launch_bounds__(256) void mse_masked_bwd_kernel(const TP* __restrict__ pred, const TT* __restrict__ tgt,
                                                              const float* __restrict__ mask, const float* __restrict__ acc,
                                                              const float* __restrict__ g, TD* __restrict__ dpred, TT* __restrict__ dtgt,
-                                                             long rows, int D, long rpb, long tgt_bs) {
-    const float k = g[0] * 2.f / ((float)D * acc[1]);
+                                                             long rows, int D, long rpb, long tgt_bs, float gmul) {
+    const float k = g[0] * gmul * 2.f / ((float)D * acc[1]);
     const long total = rows * D;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long r = i / D;
@@ -162,9 +162,9 @@ template <typename TP, typename TT, typename TD>
 __global__ __launch_bounds__(256) void mse_masked_bwd_vec_kernel(const TP* __restrict__ pred, const TT* __restrict__ tgt,
                                                                  const float* __restrict__ mask, const float* __restrict__ acc,
                                                                  const float* __restrict__ g, TD* __restrict__ dpred, TT* __restrict__ dtgt,
-                                                                 long rows, int D, long rpb, long tgt_bs) {
+                                                                 long rows, int D, long rpb, long tgt_bs, float gmul) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float k = g[0] * 2.f / ((float)D * acc[1]);
+    const float k = g[0] * gmul * 2.f / ((float)D * acc[1]);
     for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
         const float mk = mask[r];
         const float km = k * mk;
@@ -209,16 +209,16 @@ extern "C" int mh_mse_masked_fwd(const void* pred, const void* tgt, const float*
 }
 
 extern "C" int mh_mse_masked_bwd(const void* pred, const void* tgt, const float* mask, const float* acc, const float* g,
-                                 void* dpred, void* dtgt, int64_t rows, int D, int64_t rows_per_batch, int64_t tgt_bs, int dt_p,
-                                 int dt_t, int dt_dp, mh_stream s) {
+                                 float gmul, void* dpred, void* dtgt, int64_t rows, int D, int64_t rows_per_batch, int64_t tgt_bs,
+                                 int dt_p, int dt_t, int dt_dp, mh_stream s) {
     if (rows == 0) return MH_OK;
     MH_REQUIRE(rows_per_batch > 0, "mh_mse_masked_bwd: rows_per_batch must be positive");
     const bool vec = D % 4 == 0 && tgt_bs % 4 == 0 && mh_quad_ok(pred, mh_dt_size(dt_p)) && mh_quad_ok(tgt, mh_dt_size(dt_t)) &&
                      mh_quad_ok(dpred, mh_dt_size(dt_dp)) && (!dtgt || mh_quad_ok(dtgt, mh_dt_size(dt_t)));
     dim3 grid((unsigned)min((long)mh_cdiv(rows * D, 256), 16384L)), gv((unsigned)min((long)mh_cdiv(rows, 4), 16384L));
 #define MSEB3(TP, TT, TD)                                                                                                         \
-    if (vec) hipLaunchKernelGGL((mse_masked_bwd_vec_kernel<TP, TT, TD>), gv, dim3(256), 0, (hipStream_t)s, (const TP*)pred, (const TT*)tgt, mask, acc, g, (TD*)dpred, (TT*)dtgt, (long)rows, D, (long)rows_per_batch, (long)tgt_bs); \
-    else hipLaunchKernelGGL((mse_masked_bwd_kernel<TP, TT, TD>), grid, dim3(256), 0, (hipStream_t)s, (const TP*)pred, (const TT*)tgt, mask, acc, g, (TD*)dpred, (TT*)dtgt, (long)rows, D, (long)rows_per_batch, (long)tgt_bs)
+    if (vec) hipLaunchKernelGGL((mse_masked_bwd_vec_kernel<TP, TT, TD>), gv, dim3(256), 0, (hipStream_t)s, (const TP*)pred, (const TT*)tgt, mask, acc, g, (TD*)dpred, (TT*)dtgt, (long)rows, D, (long)rows_per_batch, (long)tgt_bs, gmul); \
+    else hipLaunchKernelGGL((mse_masked_bwd_kernel<TP, TT, TD>), grid, dim3(256), 0, (hipStream_t)s, (const TP*)pred, (const TT*)tgt, mask, acc, g, (TD*)dpred, (TT*)dtgt, (long)rows, D, (long)rows_per_batch, (long)tgt_bs, gmul)
 #define MSEB2(TP, TT)                                 \
     if (dt_dp == MH_F32) { MSEB3(TP, TT, float); }    \
     else { MSEB3(TP, TT, bf16_t); }

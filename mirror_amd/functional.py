@@ -1452,6 +1452,101 @@ class SymKLFn(Function):
         return dw, dr, None
 
 
+_LOSS_FUSED = os.environ.get("MIRROR_LOSS_FUSED", "1") != "0"      # A/B switch: MIRRORLoss as two launches + the WSI MSE
+
+
+def loss_terms_fusable(align, rna, style, scores) -> bool:
+    """MIRRORLoss's small terms run as mh_loss_terms_fwd / _bwd when every operand is an f32 device tensor, the RNA
+    mask is data and, for a rank-local alignment term (align = (wsi, rna, scale); None = computed by the caller
+    over the gathered batch), the batch fits the kernel's alignment block."""
+    rp, rt, rm = rna
+    ts = (rp, rt) + tuple(style) + tuple(scores) + (tuple(align) if align is not None else ())
+    if not _LOSS_FUSED or any((not t.is_cuda) or t.dtype != f32 for t in ts) or not rm.is_cuda:
+        return False
+    if rm.requires_grad or rp.numel() == 0 or rp.shape != rt.shape or rm.numel() != rp.numel():
+        return False
+    wmu, wls, rmu, rls = style
+    if wmu.dim() != 2 or rmu.dim() != 2 or wmu.shape != wls.shape or rmu.shape != rls.shape or wmu.numel() == 0 or rmu.numel() == 0:
+        return False
+    if scores[0].dim() != 2 or scores[0].shape != scores[1].shape or scores[0].numel() == 0:
+        return False
+    if align is not None:
+        wa, ra, sc = align
+        if wa.dim() != 2 or wa.shape != ra.shape or sc.numel() != 1 or not K.loss_terms_ok(wa.shape[0], wa.shape[1]):
+            return False
+    return True
+
+
+class MirrorLossTermsFn(Function):
+    """MIRRORLoss (losses/mirror_loss.py:74-135) as the WSI retention MSE + ONE launch for everything else, each way.
+    Returns (total, alignment, wsi retention, rna retention, style, cluster); the usual backward arrives through `total`
+    alone (gradients of single terms are honoured too, through a small torch-side vector).  wa / ra / scale None: the
+    alignment term is `align_ext`, computed by the caller over the gathered batch."""
+
+    @staticmethod
+    def forward(ctx, weights, wa, ra, scale, align_ext, wpred, wtgt, wmask, Dw, tok, rp, rt, rm, wmu, wls, rmu, rls, wsc, rsc):
+        ctx.set_materialize_grads(False)
+        dev = rp.device
+        wpred = wpred.contiguous()
+        if not (wtgt.is_contiguous() or (wtgt.dim() == 3 and wtgt.stride(2) == 1 and wtgt.stride(1) == Dw)):
+            wtgt = wtgt.contiguous()
+        wmask = wmask.contiguous().float()
+        acc = zeros((2,), dev)
+        K.mse_masked_fwd(wpred, wtgt, wmask, acc, wpred.numel() // Dw, Dw)
+        local = wa is not None
+        t = dict(rna_pred=rp.contiguous(), rna_tgt=rt.contiguous(), rna_mask=rm.contiguous().float(), w_mu=wmu.contiguous(),
+                 w_logstd=wls.contiguous(), r_mu=rmu.contiguous(), r_logstd=rls.contiguous(), w_score=wsc.contiguous(),
+                 r_score=rsc.contiguous(), wsi_acc=acc, scratch=zeros((8,), dev), out=torch.empty((8,), device=dev, dtype=f32))
+        if local:
+            Bq = wa.shape[0]
+            t.update(wsi_emb=wa.contiguous(), rna_emb=ra.contiguous(), logit_scale=scale.detach().reshape(1).contiguous(),
+                     save=torch.empty((Bq * Bq + 2 * Bq,), device=dev, dtype=f32))
+        elif align_ext is not None:
+            t["align_ext"] = align_ext.detach().float().reshape(1).contiguous()
+        K.loss_terms_fwd(weights, t)
+        ctx.t, ctx.weights, ctx.big = t, tuple(float(w) for w in weights), (wpred, wtgt, wmask, acc, Dw, tok)
+        ctx.shapes = (None if scale is None else scale.shape, None if align_ext is None else align_ext.shape)
+        out = t["out"]
+        return tuple(out[i].reshape(()) for i in range(6))
+
+    @staticmethod
+    def backward(ctx, g_total, g_align, g_wsi, g_rna, g_style, g_clu):
+        t, weights = dict(ctx.t), ctx.weights
+        wpred, wtgt, wmask, acc, Dw, tok = ctx.big
+        dev = wpred.device
+        extra = (g_align, g_wsi, g_rna, g_style, g_style, g_clu)
+        if any(g is not None for g in extra):        # a single term was backpropagated through as well: rare, torch-side glue
+            t["g_terms"] = torch.stack([torch.zeros((), device=dev) if g is None else g.float().reshape(()) for g in extra]).contiguous()
+        if g_total is not None:
+            t["g_total"] = g_total.contiguous().float().reshape(1)
+        local = "wsi_emb" in t
+        names = ["rna_pred", "w_mu", "w_logstd", "r_mu", "r_logstd", "w_score", "r_score"] + (["wsi_emb", "rna_emb"] if local else [])
+        for n in names:
+            t["d_" + n] = torch.empty_like(t[n])
+        if ctx.needs_input_grad[11]:
+            t["d_rna_tgt"] = torch.empty_like(t["rna_tgt"])
+        if local:
+            t["d_logit_scale"] = torch.empty((1,), device=dev, dtype=f32)
+        else:
+            t["d_align_ext"] = torch.empty((1,), device=dev, dtype=f32)
+        K.loss_terms_bwd(weights, t)
+        # WSI retention: its own HBM-bound kernel; upstream = weight * g_total (+ the single-term gradient)
+        dp = torch.empty_like(wpred)
+        hand_over = tok is not None and ctx.needs_input_grad[6]
+        dtg = torch.empty(wtgt.shape, device=dev, dtype=wtgt.dtype) if (ctx.needs_input_grad[6] and not hand_over) else None
+        if "g_terms" in t or g_total is None:
+            gb = t["g_terms"][1:2] + (weights[1] * t["g_total"] if g_total is not None else 0.0)
+            K.mse_masked_bwd(wpred, wtgt, wmask, acc, gb.contiguous(), dp, dtg, wpred.numel() // Dw, Dw)
+        else:
+            K.mse_masked_bwd(wpred, wtgt, wmask, acc, t["g_total"], dp, dtg, wpred.numel() // Dw, Dw, gmul=weights[1])
+        if hand_over:
+            tok.grad = (dp, -1.0)          # EncFanoutFn.backward folds -dpred into the encoder-output gradient
+        ssh, ash = ctx.shapes
+        return (None, t.get("d_wsi_emb"), t.get("d_rna_emb"), t["d_logit_scale"].reshape(ssh) if local else None,
+                t["d_align_ext"].reshape(ash) if (not local and ash is not None) else None, dp, dtg, None, None, None,
+                t["d_rna_pred"], t.get("d_rna_tgt"), None, t["d_w_mu"], t["d_w_logstd"], t["d_r_mu"], t["d_r_logstd"], t["d_w_score"], t["d_r_score"])
+
+
 class MatmulNTFn(Function):
     """G = a @ b^T in f32 (similarity logits of ClipLoss / InfoNCE, losses/mirror_loss.py:39-40)."""
 

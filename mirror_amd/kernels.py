@@ -1058,13 +1058,58 @@ def mse_masked_fwd(pred, tgt, mask, acc, rows, D):
     _lib.call("mh_mse_masked_fwd", _p(pred), _p(tgt), _p(mask), _p(acc), rows, D, rpb, tbs, dt(pred), dt(tgt), stream=_stream())
 
 
-def mse_masked_bwd(pred, tgt, mask, acc, g, dpred, dtgt, rows, D):
-    """dtgt None: the target's gradient (-dpred) is not materialised."""
+def mse_masked_bwd(pred, tgt, mask, acc, g, dpred, dtgt, rows, D, gmul: float = 1.0):
+    """dtgt None: the target's gradient (-dpred) is not materialised.  The upstream is g[0] * gmul."""
     _chk(pred, tgt, mask, acc, g, dpred, *([] if dtgt is None else [dtgt]))
     assert pred.is_contiguous() and dpred.is_contiguous() and (dtgt is None or (dtgt.is_contiguous() and dtgt.dtype == tgt.dtype))
     rpb, tbs = _tgt_rows(tgt, rows, D)
-    _lib.call("mh_mse_masked_bwd", _p(pred), _p(tgt), _p(mask), _p(acc), _p(g), _p(dpred), _p(dtgt), rows, D, rpb, tbs, dt(pred),
+    _lib.call("mh_mse_masked_bwd", _p(pred), _p(tgt), _p(mask), _p(acc), _p(g), float(gmul), _p(dpred), _p(dtgt), rows, D, rpb, tbs, dt(pred),
               dt(tgt), dt(dpred), stream=_stream())
+
+
+LOSS_TERMS_BMAX = 32          # alignment block of mh_loss_terms: B <= 32 and 2 B (D + 1) + B (B + 1) floats <= 150 KiB of LDS
+
+
+def loss_terms_ok(B: int, D: int) -> bool:
+    return 1 <= B <= LOSS_TERMS_BMAX and 4 * (2 * B * (D + 1) + B * (B + 1)) <= 150 * 1024
+
+
+def _loss_terms_desc(weights, t: dict) -> "_lib.LossTermsDesc":
+    """t: name -> f32 contiguous device tensor (or None) for the fields of mh_loss_terms; shapes are read off the operands."""
+    d = _lib.LossTermsDesc()
+    for k, v in t.items():
+        if v is not None:
+            if not (v.is_cuda and v.dtype == torch.float32 and v.is_contiguous()):
+                raise MirrorHipError(f"loss_terms: {k} must be a contiguous f32 device tensor")
+            setattr(d, k, v.data_ptr())
+    d.has_align = int(t.get("wsi_emb") is not None)
+    if d.has_align:
+        d.B, d.D = t["wsi_emb"].shape
+        if tuple(t["rna_emb"].shape) != (d.B, d.D) or not loss_terms_ok(d.B, d.D):
+            raise MirrorHipError(f"loss_terms: alignment embeddings {tuple(t['wsi_emb'].shape)} / {tuple(t['rna_emb'].shape)} not supported")
+    d.n_rna = t["rna_pred"].numel()
+    if t["rna_tgt"].numel() != d.n_rna or t["rna_mask"].numel() != d.n_rna:
+        raise MirrorHipError("loss_terms: rna prediction / target / mask sizes differ")
+    d.n_wstyle, d.n_rstyle = t["w_mu"].numel(), t["r_mu"].numel()
+    d.rows_wstyle, d.rows_rstyle = t["w_mu"].shape[0], t["r_mu"].shape[0]
+    if t["w_logstd"].numel() != d.n_wstyle or t["r_logstd"].numel() != d.n_rstyle:
+        raise MirrorHipError("loss_terms: mu / logstd sizes differ")
+    d.Bc, d.P = t["w_score"].shape
+    if tuple(t["r_score"].shape) != (d.Bc, d.P):
+        raise MirrorHipError("loss_terms: prototype score shapes differ")
+    for i, w in enumerate(weights):
+        d.weight[i] = float(w)
+    return d
+
+
+def loss_terms_fwd(weights, t: dict) -> None:
+    """mh_loss_terms_fwd: t carries the operands plus scratch [8] (zeroed), save [B*B + 2B], out [8], wsi_acc (or None)."""
+    _lib.call("mh_loss_terms_fwd", C.byref(_loss_terms_desc(weights, t)), stream=_stream())
+
+
+def loss_terms_bwd(weights, t: dict) -> None:
+    """mh_loss_terms_bwd: t additionally carries g_total (and g_terms) and the d_* outputs."""
+    _lib.call("mh_loss_terms_bwd", C.byref(_loss_terms_desc(weights, t)), stream=_stream())
 
 
 def fanout_bwd(gfull, x, alpha: float, c, B: int, T: int, D: int) -> torch.Tensor:

@@ -89,8 +89,25 @@ class MIRRORLoss(nn.Module):
     def forward(self, wsi_alignment_emb, wsi_retention_emb, wsi_retention_target, wsi_mask, wsi_score, wsi_mu,
                 wsi_logstd, rna_alignment_emb, rna_retention_emb, rna_retention_target, rna_mask, rna_score, rna_mu,
                 rna_logstd, logit_scale):
-        alignment_loss = self.clip_loss(wsi_alignment_emb, rna_alignment_emb, logit_scale)
         D = wsi_retention_emb.shape[-1]
+        sw = self.style_loss_weight
+        weights = (self.alignment_loss_weight, self.wsi_retention_loss_weight, self.rna_retention_loss_weight, sw, sw,
+                   self.cluster_loss_weight)
+        cl = self.clip_loss
+        gathered = (cl.gather_distributed and dist.is_available() and dist.is_initialized()
+                    and dist.get_world_size(cl.process_group) > 1)
+        align = None if gathered else (wsi_alignment_emb, rna_alignment_emb, logit_scale)
+        if Fn.loss_terms_fusable(align, (rna_retention_emb, rna_retention_target, rna_mask), (wsi_mu, wsi_logstd, rna_mu, rna_logstd),
+                                 (wsi_score, rna_score)):
+            # every term but the WSI retention MSE in one launch (and one in the backward): the ~28 tiny launches of the
+            # composed form below sit back to back on the critical path between the forward and the backward of the step
+            ext = cl(wsi_alignment_emb, rna_alignment_emb, logit_scale).reshape(()) if gathered else None
+            wa, ra, sc = align if align is not None else (None, None, None)
+            return Fn.MirrorLossTermsFn.apply(weights, wa, ra, sc, ext, wsi_retention_emb, wsi_retention_target, wsi_mask, D,
+                                              getattr(wsi_retention_target, "_fan_token", None), rna_retention_emb,
+                                              rna_retention_target, rna_mask, wsi_mu, wsi_logstd, rna_mu, rna_logstd,
+                                              wsi_score, rna_score)
+        alignment_loss = self.clip_loss(wsi_alignment_emb, rna_alignment_emb, logit_scale)
         wsi_retention_loss = Fn.masked_mse(wsi_retention_emb, wsi_retention_target, wsi_mask, D)
         rna_retention_loss = Fn.masked_mse(rna_retention_emb, rna_retention_target, rna_mask, 1)
         B = wsi_mu.shape[0]
@@ -98,10 +115,8 @@ class MIRRORLoss(nn.Module):
         style_r = Fn.StyleKLFn.apply(rna_mu, rna_logstd, 0.5 / rna_mu.shape[0])
         cluster_loss = Fn.SymKLFn.apply(wsi_score, rna_score, 0.5 / wsi_score.shape[0])
         # losses/mirror_loss.py:121-127 as ONE kernel (and one in the backward) instead of ~20 scalar torch launches
-        sw = self.style_loss_weight
         total_loss = Fn.WeightedSumFn.apply(
-            (self.alignment_loss_weight, self.wsi_retention_loss_weight, self.rna_retention_loss_weight, sw, sw, self.cluster_loss_weight),
-            alignment_loss.reshape(()), wsi_retention_loss, rna_retention_loss, style_w.reshape(()), style_r.reshape(()),
+            weights, alignment_loss.reshape(()), wsi_retention_loss, rna_retention_loss, style_w.reshape(()), style_r.reshape(()),
             cluster_loss.reshape(()))
         style_loss = (style_w.detach() + style_r.detach()).reshape(())
         return (total_loss, alignment_loss.reshape(()), wsi_retention_loss, rna_retention_loss, style_loss,

@@ -106,6 +106,67 @@ def test_mirror_loss_module_matches_reference_golden():
     np.testing.assert_allclose(float(cl), float(z["clip_loss"]), rtol=LOSS_RTOL)
 
 
+def _loss_inputs(B, N, F, G, D, P, S, seed, pred_dtype=torch.float32):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    r = lambda *sh: torch.randn(*sh, device=DEV, generator=g)
+    nrm = lambda t: t / t.norm(dim=-1, keepdim=True)
+    ins = [nrm(r(B, D)), r(B, N, F).to(pred_dtype), r(B, N, F), (torch.rand(B, N, device=DEV, generator=g) < 0.75).float(), r(B, P),
+           r(B, S), 0.3 * r(B, S), nrm(r(B, D)), r(B, G), r(B, G), (torch.rand(B, G, device=DEV, generator=g) < 0.75).float(), r(B, P),
+           r(B, S), 0.3 * r(B, S), torch.tensor(14.3, device=DEV)]
+    grad = (0, 1, 2, 4, 5, 6, 7, 8, 9, 11, 12, 13, 14)        # everything but the masks
+    return [t.requires_grad_(i in grad) for i, t in enumerate(ins)], grad
+
+
+@pytest.mark.parametrize("shape", [(16, 64, 32, 2048, 512, 3000, 128), (5, 7, 12, 77, 33, 70, 9), (32, 3, 8, 300, 256, 257, 16),
+                                   (1, 4, 4, 5, 8, 3, 2)])
+def test_one_launch_loss_terms_match_the_composed_terms(shape, monkeypatch):
+    """mh_loss_terms_fwd / _bwd (alignment + RNA retention + style + cluster + total in one launch each way) against the
+    per-term kernels that the golden-vector and oracle tests pin: all six results and every input gradient."""
+    from mirror_amd import functional as Fn
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(Fn, "_LOSS_FUSED", fused)
+        ins, grad = _loss_inputs(*shape, seed=3, pred_dtype=torch.bfloat16 if shape[0] == 16 else torch.float32)
+        out = MIRRORLoss(**dict(zip(W_KW, TEMPLATE_W)))(*ins)
+        assert (out[0].grad_fn.name().startswith("MirrorLossTermsFn")) == fused
+        (out[0] * 0.5).backward()
+        res[fused] = ([float(x.detach()) for x in out], [ins[i].grad.float().cpu().numpy() for i in grad])
+    np.testing.assert_allclose(res[True][0], res[False][0], rtol=2e-6, atol=1e-7)
+    for i, a, b in zip(grad, res[True][1], res[False][1]):
+        np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-6 * max(float(np.abs(b).max()), 1e-30), err_msg=O.OUTPUT_NAMES[i])
+
+
+def test_one_launch_loss_terms_single_term_and_external_alignment(monkeypatch):
+    """The two side doors of the fused loss: a backward through ONE returned term (the reference returns attached terms,
+    losses/mirror_loss.py:129-135), and the gathered-batch form where the caller supplies the alignment term."""
+    from mirror_amd import functional as Fn
+    shape = (6, 5, 8, 40, 64, 50, 8)
+    got = {}
+    for fused in (True, False):
+        monkeypatch.setattr(Fn, "_LOSS_FUSED", fused)
+        ins, grad = _loss_inputs(*shape, seed=11)
+        out = MIRRORLoss()(*ins)
+        (out[0] + 3.0 * out[1] + 0.5 * out[3] + 2.0 * out[5] + 0.25 * out[2]).backward()
+        got[fused] = [ins[i].grad.cpu().numpy() for i in grad]
+    for i, a, b in zip(grad, got[True], got[False]):
+        np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-6 * max(float(np.abs(b).max()), 1e-30), err_msg=O.OUTPUT_NAMES[i])
+    # external alignment term: total and gradients equal the local form when the caller's term IS the local ClipLoss
+    monkeypatch.setattr(Fn, "_LOSS_FUSED", True)
+    ins, grad = _loss_inputs(*shape, seed=11)
+    w = (0.5, 0.1, 0.1, 0.1, 0.1, 0.2)
+    ext = ClipLoss()(ins[0], ins[7], ins[14]).reshape(())
+    out = Fn.MirrorLossTermsFn.apply(w, None, None, None, ext, ins[1], ins[2], ins[3], ins[1].shape[-1], None, ins[8], ins[9], ins[10],
+                                     ins[5], ins[6], ins[12], ins[13], ins[4], ins[11])
+    ins2, _ = _loss_inputs(*shape, seed=11)
+    ref = MIRRORLoss()(*ins2)
+    np.testing.assert_allclose([float(x.detach()) for x in out], [float(x.detach()) for x in ref], rtol=2e-6)
+    out[0].backward()
+    ref[0].backward()
+    for i in grad:
+        np.testing.assert_allclose(ins[i].grad.cpu().numpy(), ins2[i].grad.cpu().numpy(), rtol=2e-5,
+                                   atol=2e-6 * max(float(ins2[i].grad.abs().max()), 1e-30), err_msg=O.OUTPUT_NAMES[i])
+
+
 def test_info_nce_module_matches_reference_golden():
     z = np.load(os.path.join(GOLDEN, "golden_infonce.npz"))
     q0, k0 = torch.from_numpy(z["q"]).to(DEV), torch.from_numpy(z["k"]).to(DEV)
