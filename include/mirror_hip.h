@@ -246,6 +246,11 @@ int mh_ppeg_fwd(const void* x, void* y, const float* merged, const float* bsum, 
 /* dmerged[tap][c] += sum dout*x(shifted); dbsum[c] += sum dout  (f32 atomics) */
 int mh_ppeg_wgrad(const void* x, const void* dout, float* dmerged, float* dbsum, int B, int S, int D,
                   int dt_x, int dt_o, mh_stream s);
+/* dw7 [D,1,7,7] += dmerged^T, dw5 [D,1,5,5] += its centre 5x5, dw3 [D,1,3,3] += its centre 3x3, db7 / db5 / db3 [D] += dbsum:
+ * the gradients of the three depthwise kernels PPEG sums (models/mirror.py:324-331) from the merged kernel's gradient
+ * (dmerged is tap-major [49, D] as mh_ppeg_wgrad writes it).  Accumulates: the caller owns the zeroing. */
+int mh_ppeg_grad_scatter(const float* dmerged, const float* dbsum, float* dw7, float* dw5, float* dw3, float* db7,
+                         float* db5, float* db3, int D, mh_stream s);
 
 /* ---------------------------------------------------------------- masking (models/mirror.py:624-649, :510-533)
  * mask[b,i] = 1 if rank(noise[b,i]) >= len_keep (rank by ascending noise, ties by index) */

@@ -103,6 +103,7 @@ _SIGS = {
     "mh_ppeg_merge": [P, P, P, P, P, P, P, P, I],
     "mh_ppeg_fwd": [P, P, P, P, I, I, I, I, I, I],
     "mh_ppeg_wgrad": [P, P, P, P, I, I, I, I, I],
+    "mh_ppeg_grad_scatter": [P, P, P, P, P, P, P, P, I],
     "mh_rank_mask": [P, P, I, I, I],
     "mh_mask_apply_fwd": [P, P, P, P, P, I, I, I, I, I, I, I],
     "mh_mask_apply_bwd": [P, P, P, P, P, I, I, I, I, I, I, I],

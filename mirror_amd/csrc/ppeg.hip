@@ -476,3 +476,36 @@ extern "C" int mh_ppeg_wgrad(const void* x, const void* dout, float* dmerged, fl
     MH_LAUNCH_CHECK("mh_ppeg_wgrad");
     return MH_OK;
 }
+
+// ------------------------------------------------------------------ merged gradient -> the six parameter gradients
+// The forward folds the 7x7, 5x5 and 3x3 depthwise kernels (and their biases) into one 7x7 (mh_ppeg_merge), so the gradient
+// of the merged kernel IS the 7x7's, its centre 5x5 the 5x5's, its centre 3x3 the 3x3's, and all three biases get dbsum
+// (models/mirror.py:324-331).  One launch that ACCUMULATES into the six buffers (the training engine's gradient arena)
+// instead of two zero fills, a transposing copy, two window copies, two clones and six `grad += new` launches of autograd.
+__global__ __launch_bounds__(256) void ppeg_grad_scatter_kernel(const float* __restrict__ dm, const float* __restrict__ dbs,
+                                                                float* __restrict__ dw7, float* __restrict__ dw5, float* __restrict__ dw3,
+                                                                float* __restrict__ db7, float* __restrict__ db5, float* __restrict__ db3, int D) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < D * 49) {
+        const int c = i / 49, t = i - c * 49, ky = t / 7, kx = t - ky * 7;
+        const float v = dm[(long)t * D + c];          // dmerged is tap-major [49, D]
+        dw7[i] += v;
+        if (ky >= 1 && ky <= 5 && kx >= 1 && kx <= 5) dw5[c * 25 + (ky - 1) * 5 + (kx - 1)] += v;
+        if (ky >= 2 && ky <= 4 && kx >= 2 && kx <= 4) dw3[c * 9 + (ky - 2) * 3 + (kx - 2)] += v;
+    }
+    if (i < D) {
+        const float b = dbs[i];
+        db7[i] += b;
+        db5[i] += b;
+        db3[i] += b;
+    }
+}
+
+extern "C" int mh_ppeg_grad_scatter(const float* dmerged, const float* dbsum, float* dw7, float* dw5, float* dw3, float* db7,
+                                    float* db5, float* db3, int D, mh_stream s) {
+    MH_REQUIRE(dmerged && dbsum && dw7 && dw5 && dw3 && db7 && db5 && db3, "mh_ppeg_grad_scatter: null pointer");
+    if (D == 0) return MH_OK;
+    hipLaunchKernelGGL(ppeg_grad_scatter_kernel, dim3(mh_cdiv(D * 49, 256)), dim3(256), 0, (hipStream_t)s, dmerged, dbsum, dw7, dw5, dw3, db7, db5, db3, D);
+    MH_LAUNCH_CHECK("mh_ppeg_grad_scatter");
+    return MH_OK;
+}

@@ -734,6 +734,9 @@ class Fc1SeqFn(Function):
         return dx, dw, db, dcls.reshape(1, 1, D), None, None
 
 
+_PPEG_SCATTER = os.environ.get("MIRROR_PPEG_SCATTER", "1") != "0"
+
+
 class PPEGFn(Function):
     """PPEG.forward (models/mirror.py:324-331) as one merged depthwise 7x7 on the token-major sequence."""
 
@@ -742,7 +745,7 @@ class PPEGFn(Function):
         x = x.contiguous()
         merged, bsum = K.ppeg_merge(w7.detach(), w5.detach(), w3.detach(), b7.detach(), b5.detach(), b3.detach())
         ctx.save_for_backward(x, merged, bsum)
-        ctx.S = S
+        ctx.S, ctx.params = S, (w7, b7, w5, b5, w3, b3)
         return K.ppeg(x, merged, bsum, S, flip=False)
 
     @staticmethod
@@ -752,12 +755,17 @@ class PPEGFn(Function):
         D = x.shape[-1]
         dy = dy.contiguous()
         dx = K.ppeg(dy, merged, bsum, S, flip=True)
-        dm = torch.zeros_like(merged)
-        dbs = torch.zeros_like(bsum)
+        dm = zeros(tuple(merged.shape), merged.device)
+        dbs = zeros(tuple(bsum.shape), bsum.device)
         K.ppeg_wgrad(x, dy, dm, dbs, S)
-        dm = dm.t().reshape(D, 1, 7, 7)
-        return (dx, dm.contiguous(), dbs, dm[:, :, 1:6, 1:6].contiguous(), dbs.clone(),
-                dm[:, :, 2:5, 2:5].contiguous(), dbs.clone(), None)
+        if not _PPEG_SCATTER:       # A/B: the torch-side split (13 tiny launches with autograd's accumulation)
+            dm = dm.t().reshape(D, 1, 7, 7)
+            return (dx, dm.contiguous(), dbs, dm[:, :, 1:6, 1:6].contiguous(), dbs.clone(), dm[:, :, 2:5, 2:5].contiguous(), dbs.clone(), None)
+        # merged gradient -> the six parameter gradients in one accumulating launch (straight into the engine's arena)
+        bufs = [_gbuf(p, tuple(p.shape)) for p in ctx.params]
+        K.ppeg_grad_scatter(dm, dbs, *[bufs[i][0] for i in (0, 2, 4, 1, 3, 5)])
+        g = [_gret(p, b, sunk) for p, (b, sunk) in zip(ctx.params, bufs)]
+        return (dx, g[0], g[1], g[2], g[3], g[4], g[5], None)
 
 
 # ------------------------------------------------------------------ Nystrom attention core

@@ -787,6 +787,17 @@ def ppeg_wgrad(x, dout, dmerged, dbsum, S: int) -> None:
     _lib.call("mh_ppeg_wgrad", _p(x), _p(dout), _p(dmerged), _p(dbsum), B, S, D, dt(x), dt(dout), stream=_stream())
 
 
+def ppeg_grad_scatter(dmerged, dbsum, dw7, dw5, dw3, db7, db5, db3) -> None:
+    """The six PPEG parameter gradients += their share of the merged kernel's gradient (dmerged [49, D], dbsum [D])."""
+    D = dbsum.numel()
+    outs = (dw7, dw5, dw3, db7, db5, db3)
+    _chk(dmerged, dbsum, *outs)
+    for t, n in zip((dmerged,) + outs, (49 * D, 49 * D, 25 * D, 9 * D, D, D, D)):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n:
+            raise MirrorHipError(f"ppeg_grad_scatter: expected a contiguous f32 tensor of {n} elements, got {tuple(t.shape)} {t.dtype}")
+    _lib.call("mh_ppeg_grad_scatter", _p(dmerged), _p(dbsum), *[_p(t) for t in outs], D, stream=_stream())
+
+
 # ----------------------------------------------------------------------------- data feed
 def gather_rows(src: torch.Tensor, rows: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[r] = src[rows[r]] for a [S, F] bank and int64 row indices of any shape (result: rows.shape + (F,))."""
