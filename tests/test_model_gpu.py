@@ -118,7 +118,7 @@ def _loss_inputs(B, N, F, G, D, P, S, seed, pred_dtype=torch.float32):
 
 
 @pytest.mark.parametrize("shape", [(16, 64, 32, 2048, 512, 3000, 128), (5, 7, 12, 77, 33, 70, 9), (32, 3, 8, 300, 256, 257, 16),
-                                   (1, 4, 4, 5, 8, 3, 2)])
+                                   (1, 4, 4, 5, 8, 3, 2), (3, 2, 4, 9, 16, 4200, 4)])
 def test_one_launch_loss_terms_match_the_composed_terms(shape, monkeypatch):
     """mh_loss_terms_fwd / _bwd (alignment + RNA retention + style + cluster + total in one launch each way) against the
     per-term kernels that the golden-vector and oracle tests pin: all six results and every input gradient."""
