@@ -132,6 +132,7 @@ class TrainEngine:
         # timm's --clip-grad (mode "norm") and --grad-accum-steps (train_mirror.py:1192-1230): both stay on the device
         self.clip_grad = clip_grad
         self.accum_steps = max(1, int(accum_steps))
+        self._one: Optional[torch.Tensor] = None      # root gradient of loss.backward()
         self._micro = 0
         self._force = False
         self._state_lr = float(lr)
@@ -386,7 +387,9 @@ class TrainEngine:
             torch.cuda.current_stream().wait_event(t_done)
         Fn.set_grad_sink(self)
         try:
-            losses[0].backward()
+            if self._one is None or self._one.device != losses[0].device:
+                self._one = torch.ones((), device=losses[0].device, dtype=losses[0].dtype)
+            losses[0].backward(self._one)        # a persistent root gradient: no ones_like fill launch per step
         finally:
             Fn.set_grad_sink(None)
         Fn.join_side_streams(self.device)       # sink-written gradients of the side-stream branches (see join_side_streams)

@@ -808,7 +808,7 @@ def pinv_forward(a2: torch.Tensor, iters: int, pm: int, sd: torch.dtype):
     step is one GEMM with an epilogue (diag / R addend) and nothing else is launched.  Iterates and intermediates
     are stored in `sd` (f32, or bf16 when the GEMMs round their operands to bf16 anyway) and KEPT for the backward.
     Returns (z_final, [(z_k, P_k, T2_k, T3_k)], stats)."""
-    st = K.pinv_absmax(a2)
+    st = K.pinv_absmax(a2, zeros((4,), a2.device).view(torch.int64))
     z = K.cast(K.pinv_z0(a2, st), sd)
     saved = []
     for _ in range(iters):
@@ -846,7 +846,7 @@ def pinv_forward_tile(a2: torch.Tensor, iters: int):
     accumulation inside a product, one launch per product at one workgroup per CU (csrc/gemm_tile.hip).  The iterates are
     written into stacks (zs[k] = z_k; pt[k] = (T2_k, P_k)) so that the backward pass can sum products over an iteration's or
     the whole chain's operand pairs in one launch (K.gemm_ksum)."""
-    st = K.pinv_absmax(a2)
+    st = K.pinv_absmax(a2, zeros((4,), a2.device).view(torch.int64))
     a2b = K.cast(a2, bf16)
     zs = torch.empty((iters + 1,) + tuple(a2.shape), device=a2.device, dtype=bf16)
     pt = torch.empty((iters, 2) + tuple(a2.shape), device=a2.device, dtype=bf16)
@@ -944,7 +944,7 @@ class NystromCoreFn(Function):
             # B*h workgroups with a 128 KiB LDS image each: the chain owns B*h CUs and nothing else.  At B*h = 128 that
             # is half of the chip, so it runs on a side stream beside the attn3 side on the main stream; they meet
             # again at w2 = pinv @ (a3 v).  Chain-private matrices are column-major (see mirror_hip.h).
-            st = K.pinv_absmax(a2)
+            st = K.pinv_absmax(a2, zeros((4,), a2.device).view(torch.int64))
             chain_saved = K.pinv_chain_saved_alloc(iters, Bn * h, m_l, qkv.device)
             z0, xt = K.pinv_chain_prep(a2, st, K.pinv_chain_z0_slot(chain_saved))
             zfT = torch.empty((Bn, h, m_l, m_l), device=qkv.device, dtype=bf16)

@@ -525,11 +525,13 @@ def resconv_wgrad(v_src: torch.Tensor, dout: torch.Tensor, dw: torch.Tensor, hea
               _p(dw), B, n_p, heads, Cc // heads, taps, dt(v_src), dt(dout), stream=_stream())
 
 
-def pinv_absmax(x: torch.Tensor) -> torch.Tensor:
+def pinv_absmax(x: torch.Tensor, stats: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """stats: optional zeroed int64[2] (the caller's pre-zeroed arena saves the fill launch)."""
     _chk(x)
     _contig(x, "pinv input")
     m = x.shape[-1]
-    stats = torch.zeros(2, device=x.device, dtype=torch.int64)
+    if stats is None:
+        stats = torch.zeros(2, device=x.device, dtype=torch.int64)
     _lib.call("mh_pinv_absmax", _p(x), _p(stats), x.numel() // (m * m), m, stream=_stream())
     return stats
 
