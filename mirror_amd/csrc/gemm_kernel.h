@@ -16,6 +16,7 @@
 //   Workgroup ids are remapped so that each XCD (private L2) walks a contiguous range of tiles.
 #pragma once
 #include "common.h"
+#include <cstdlib>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -411,7 +412,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 template <int MMA, typename TA, typename TB, typename TC, bool AKC, bool BKC>
 static void launch_w(GemmArgs& a, int batch, hipStream_t s) {
     constexpr int BK = MMA ? 64 : 16;
-    const bool narrow = a.N <= 64;
+    // 128 x 64 tiles for N <= 64 -- and for launches that would leave more than a third of the CUs without a 128 x 128 tile
+    // (the row remainders of the big-tile split: 4096 x 512 is 128 tiles, 256 half tiles finish in ~60 % of the time)
+    static const bool fill = [] { const char* e = getenv("MH_GEMM_HALF_TILES"); return !(e && e[0] == '0'); }();   // A/B switch
+    const long wide_wgs = (long)mh_cdiv(a.M, 128) * mh_cdiv(a.N, 128) * a.split_k * batch;
+    const bool narrow = a.N <= 64 || (fill && MMA == 1 && wide_wgs <= 160 && a.N % 64 == 0 && a.M >= 1024);
     const int BN = narrow ? 64 : 128;
     a.tiles_m = mh_cdiv(a.M, 128);
     a.tiles_n = mh_cdiv(a.N, BN);

@@ -199,7 +199,9 @@ _TN = {MH_F32: "float", MH_BF16: "bf16"}
 
 def gemm_variant(d: GemmDesc) -> str:
     """The template instance mh_gemm dispatches to (matches the kernel symbol rocprofv3 reports)."""
-    wn = 1 if d.N <= 64 else 2
+    wide = -(-d.M // 128) * -(-d.N // 128) * max(1, d.split_k) * d.batch1 * d.batch2
+    half = (d.mma == MH_BF16 and wide <= 160 and d.N % 64 == 0 and d.M >= 1024 and os.environ.get("MH_GEMM_HALF_TILES", "1")[:1] != "0")
+    wn = 1 if (d.N <= 64 or half) else 2
     tc = "float" if d.mma == MH_F32 else _TN[d.dtC]
     bk = 64 if d.mma == MH_BF16 else 16
     vec = 4 if d.dtA == MH_F32 else 8
