@@ -402,14 +402,18 @@ __global__ __launch_bounds__(256) void mask_apply_bwd_vec_kernel(const float* dy
             mb_f4 sp = {0.f, 0.f, 0.f, 0.f};
             for (int b0 = 0; b0 < B; b0 += 8) {
                 mb_f4 g[8];
+                float mk[8];       // requested with the gradient rows: eight dependent mask loads per step were a latency chain
 #pragma unroll
                 for (int u = 0; u < 8; u++)
-                    if (b0 + u < B) g[u] = *reinterpret_cast<const mb_f4*>(dy + ((long)(b0 + u) * Tn + t) * D + c);
+                    if (b0 + u < B) {
+                        g[u] = *reinterpret_cast<const mb_f4*>(dy + ((long)(b0 + u) * Tn + t) * D + c);
+                        mk[u] = t >= first ? mask[(long)(b0 + u) * (Tn - first) + (t - first)] : 0.f;
+                    }
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     if (b0 + u >= B) break;
                     sp += g[u];
-                    const bool msk = t >= first && mask[(long)(b0 + u) * (Tn - first) + (t - first)] != 0.f;
+                    const bool msk = mk[u] != 0.f;
                     if (msk) st += g[u];
                     if (msk || (const void*)dx != (const void*)dy)
                         st4(dx + ((long)(b0 + u) * Tn + t) * D + c, msk ? (mb_f4){0.f, 0.f, 0.f, 0.f} : g[u]);

@@ -565,15 +565,16 @@ __global__ __launch_bounds__(256) void pinv_z0_bwd_vec_kernel(const float* __res
 #pragma unroll
         for (int e = 0; e < 4; e++) tile[r + 16 * k][c4 + e] = d[e];
     }
+    zf4 o[4];                                      // the dx tile is requested before the barrier, beside the two input tiles
+#pragma unroll
+    for (int k = 0; k < 4; k++) o[k] = *reinterpret_cast<const zf4*>(dx + base + (long)(j0 + r + 16 * k) * m + i0 + c4);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int j = j0 + r + 16 * k;             // dx[j][i0 + c4 ..] += dz0[i0 + c4 ..][j] * inv
-        zf4* p = reinterpret_cast<zf4*>(dx + base + (long)j * m + i0 + c4);
-        zf4 o = *p;
 #pragma unroll
-        for (int e = 0; e < 4; e++) o[e] += tile[c4 + e][r + 16 * k] * inv;
-        *p = o;
+        for (int e = 0; e < 4; e++) o[k][e] += tile[c4 + e][r + 16 * k] * inv;
+        *reinterpret_cast<zf4*>(dx + base + (long)j * m + i0 + c4) = o[k];
     }
     dot = block_sum256(dot, red);
     if (threadIdx.x == 0) atomicAdd(scratch, dot);
