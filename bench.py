@@ -104,6 +104,12 @@ def main():
                          "copied on a side stream under the previous step — the PCIe-inclusive rate, reported as a separate line")
     a = ap.parse_args()
 
+    # a timing tool must not be one environment variable away from a fake number: the MH_EXP_* switches make entry points
+    # return without launching (results garbage) and only exist in `make EXP=1` builds of the library
+    bad = sorted(k for k in os.environ if k.startswith("MH_EXP_"))
+    if bad:
+        raise SystemExit(f"bench.py: refusing to run with timing-experiment switches set: {', '.join(bad)}")
+
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(a.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))

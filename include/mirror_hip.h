@@ -34,6 +34,7 @@ typedef void* mh_stream; /* hipStream_t */
 
 const char* mh_last_error(void);
 int mh_version(void);
+int mh_exp_build(void);      /* 1: built with -DMH_EXP (timing-experiment switches compiled in); the shipped build returns 0 */
 /* number of visible HIP devices whose arch is gfx950; <=0 means the library cannot run here */
 int mh_device_ok(void);
 

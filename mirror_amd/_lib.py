@@ -148,7 +148,7 @@ _SIGS = {
     "mh_loss_terms_fwd": [C.POINTER(LossTermsDesc)],
     "mh_loss_terms_bwd": [C.POINTER(LossTermsDesc)],
 }
-EXPORTS = sorted(list(_SIGS) + ["mh_last_error", "mh_version", "mh_device_ok", "mh_nys_attn3_ws_floats", "mh_rna_block_workspace_bytes",
+EXPORTS = sorted(list(_SIGS) + ["mh_last_error", "mh_version", "mh_exp_build", "mh_device_ok", "mh_nys_attn3_ws_floats", "mh_rna_block_workspace_bytes",
                                  "mh_gemm_workspace_bytes", "mh_layernorm_bwd_workspace_bytes", "mh_nys_attn3_workspace_bytes",
                                  "mh_pinv_chain_workspace_bytes"])
 
@@ -172,6 +172,7 @@ def load() -> C.CDLL:
     lib.mh_last_error.restype = C.c_char_p
     lib.mh_last_error.argtypes = []
     lib.mh_version.restype = C.c_int
+    lib.mh_exp_build.restype = C.c_int
     lib.mh_device_ok.restype = C.c_int
     lib.mh_nys_attn3_ws_floats.restype = C.c_int64
     lib.mh_nys_attn3_ws_floats.argtypes = [C.c_int, C.c_int, C.c_int]
@@ -198,11 +199,30 @@ _fns: dict = {}
 
 # timing experiment (tools/exp/skip_cost.sh): entry points named in MH_EXP_SKIP return at once — the results are garbage, the
 # step time shows what each of them costs INSIDE the step (on its stream, beside whatever it overlaps) rather than alone
-_SKIP = frozenset(x for x in os.environ.get("MH_EXP_SKIP", "").split(",") if x)
+# Both this switch and MH_EXP_CHAIN_SKIP only exist in a library built with `make EXP=1` (mh_exp_build() == 1); with the
+# shipped build a set MH_EXP_* variable is an error, not a silent fake number.
+_SKIP = None
+
+
+def _exp_skip() -> frozenset:
+    global _SKIP
+    if _SKIP is None:
+        names = [k for k in os.environ if k.startswith("MH_EXP_")]
+        lib = load()
+        exp_build = bool(lib.mh_exp_build())
+        if names and not exp_build:
+            raise MirrorHipError(f"{', '.join(sorted(names))} set, but libmirror_hip.so is not a timing-experiment build "
+                                 "(make -C mirror_amd/csrc EXP=1): refusing to run with result-corrupting switches")
+        if names:
+            import warnings
+            warnings.warn(f"mirror_amd: timing-experiment switches active ({', '.join(sorted(names))}): RESULTS ARE GARBAGE")
+        _SKIP = frozenset(x for x in os.environ.get("MH_EXP_SKIP", "").split(",") if x)
+    return _SKIP
 
 
 def call(name: str, *args, stream: int = 0) -> None:
-    if _SKIP and name in _SKIP:
+    skip = _SKIP if _SKIP is not None else _exp_skip()
+    if skip and name in skip:
         return
     fn = _fns.get(name)
     if fn is None:

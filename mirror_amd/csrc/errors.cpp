@@ -16,6 +16,16 @@ void mh_set_error(const char* fmt, ...) {
 extern "C" const char* mh_last_error(void) { return g_err; }
 extern "C" int mh_version(void) { return 103; }   // 103: mh_loss_terms_fwd / _bwd, mh_mse_masked_bwd(gmul)
 
+// 1 when the library was built with -DMH_EXP (make EXP=1): the timing-experiment switches (MH_EXP_CHAIN_SKIP, and MH_EXP_SKIP
+// in the Python host) only exist in such a build; the default build answers 0 and the host refuses the variables.
+extern "C" int mh_exp_build(void) {
+#ifdef MH_EXP
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 extern "C" int mh_device_ok(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {

@@ -551,7 +551,9 @@ extern "C" int mh_pinv_chain_fwd(const void* XT, void* saved, void* zfT, int BH,
     MH_REQUIRE(m == CM, "mh_pinv_chain_fwd: m=%d unsupported (built for m = %d; other sizes use mh_gemm)", m, CM);
     MH_REQUIRE(iters >= 1 && BH >= 0, "mh_pinv_chain_fwd: bad arguments");
     if (BH == 0) return MH_OK;
-    if (getenv("MH_EXP_CHAIN_SKIP")) return MH_OK;        // timing experiment: what the step costs without the chain (results are garbage)
+#ifdef MH_EXP       // timing-experiment builds only (make EXP=1): what the step costs without the chain; results are garbage
+    if (getenv("MH_EXP_CHAIN_SKIP")) return MH_OK;
+#endif
     hipLaunchKernelGGL(pinv_panel_fwd_kernel, dim3(BH), dim3(CT), chain_claim_bytes(), (hipStream_t)s, (const bf16_t*)XT, (bf16_t*)saved,
                        (bf16_t*)zfT, BH, iters);
     MH_LAUNCH_CHECK("mh_pinv_chain_fwd");
@@ -563,7 +565,9 @@ extern "C" int mh_pinv_chain_bwd(const void* XT, const void* saved, const void* 
     MH_REQUIRE(m == CM, "mh_pinv_chain_bwd: m=%d unsupported (built for m = %d; other sizes use mh_gemm)", m, CM);
     MH_REQUIRE(iters >= 1 && BH >= 0, "mh_pinv_chain_bwd: bad arguments");
     if (BH == 0) return MH_OK;
+#ifdef MH_EXP
     if (getenv("MH_EXP_CHAIN_SKIP")) return MH_OK;
+#endif
     hipLaunchKernelGGL(pinv_panel_bwd_kernel, dim3(BH), dim3(CT), chain_claim_bytes(), (hipStream_t)s, (const bf16_t*)XT, (const bf16_t*)saved,
                        (const bf16_t*)dzf, (bf16_t*)work, dX, dz0, BH, iters);
     MH_LAUNCH_CHECK("mh_pinv_chain_bwd");

@@ -90,6 +90,7 @@ class HostFeeder:
         self.depth = max(2, int(depth))
         self.stream = torch.cuda.Stream(device=self.device)
         self._slots = []          # per slot: (pinned wsi, pinned rna, device wsi raw, device wsi, device rna, ready event, free event)
+        self._k = 0               # running slot counter: NOT reset per epoch, so two consecutive batches never share a slot
 
     def _slot(self, k: int, wsi: torch.Tensor, rna: torch.Tensor):
         while len(self._slots) <= k:
@@ -98,9 +99,14 @@ class HostFeeder:
         if sl is None or sl[0].shape != wsi.shape or sl[0].dtype != wsi.dtype or sl[1].shape != rna.shape:
             pw = torch.empty(wsi.shape, dtype=wsi.dtype, pin_memory=True)
             pr = torch.empty(rna.shape, dtype=torch.float32, pin_memory=True)
-            dw_raw = torch.empty(wsi.shape, dtype=wsi.dtype, device=self.device)
-            dw = dw_raw if self.wsi_dtype in (None, wsi.dtype) else torch.empty(wsi.shape, dtype=self.wsi_dtype, device=self.device)
-            dr = torch.empty(rna.shape, dtype=torch.float32, device=self.device)
+            # the slot's device buffers are first written on the copy stream: allocate them there (after the copy stream has
+            # caught up with the consumer's stream), so that a block the caching allocator just took back from the consumer's
+            # stream with kernels still pending cannot be handed out and overwritten
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self.stream):
+                dw_raw = torch.empty(wsi.shape, dtype=wsi.dtype, device=self.device)
+                dw = dw_raw if self.wsi_dtype in (None, wsi.dtype) else torch.empty(wsi.shape, dtype=self.wsi_dtype, device=self.device)
+                dr = torch.empty(rna.shape, dtype=torch.float32, device=self.device)
             sl = self._slots[k] = [pw, pr, dw_raw, dw, dr, torch.cuda.Event(), None, False]
         return sl
 
@@ -123,13 +129,16 @@ class HostFeeder:
             dr.copy_(src_r, non_blocking=True)
             if dw is not dw_raw:
                 K.cast(dw_raw, self.wsi_dtype, out=dw)
+                # the raw kernel wrote through a pointer: tell torch the tensor changed (TrainEngine.step's graph replay skips the
+                # copy into its static input when it sees the same tensor object at the same version)
+                torch.autograd.graph.increment_version(dw)
             ready.record(self.stream)
         return sl
 
     def __iter__(self):
         it = iter(self.loader)
         pending = []
-        k = 0
+        k = self._k
         for _ in range(self.depth - 1):
             try:
                 pending.append(self._issue(k % self.depth, next(it)))
@@ -149,3 +158,4 @@ class HostFeeder:
             ev = torch.cuda.Event()
             ev.record(cur)                         # everything the consumer queued on this batch so far
             sl[6] = ev
+            self._k = k

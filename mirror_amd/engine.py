@@ -175,6 +175,9 @@ class TrainEngine:
         """The transposed copies trail an update until the next step starts (see _step_body); anything that differentiates
         through the model outside step() gets them rebuilt on its own stream first (functional.shadow_t calls this)."""
         self._refresh_transposes()
+        if self._zero_pending and not torch.cuda.is_current_stream_capturing():
+            self.grad.zero_()                 # an out-of-step backward accumulates into p.grad = arena views: start from zero
+            self._zero_pending = False
 
     def _refresh_transposes(self) -> None:
         self._t_stale = False
@@ -322,6 +325,10 @@ class TrainEngine:
                     self._g_src[k], self._g_ver[k] = t, t._version
             self._graph.replay()
             self.step_count += 1
+            # the replay ran Adam: the transposed copies trail it and the arena holds this step's gradients until the next
+            # step's start — the Python flags of _step_body have to say so after a replay too (out-of-step backward)
+            self._t_stale = self.shadow_t is not None and _TRANSPOSE_AT_START
+            self._zero_pending = self._zero_pending or _TRANSPOSE_AT_START
             return self._g_out
         if self._graph_warm < 2:                            # allocator, shadows, sink counts and lazy inits settle first
             self._graph_warm += 1
@@ -402,6 +409,7 @@ class TrainEngine:
         if self._micro < self.accum_steps and not self._force:   # gradient accumulation: keep summing into the grad arena (the
             Fn.dropout_step_end()                    # reference's no_sync micro-steps), no reduction, no update yet
             return self._loss_out(losses)
+        n_micro = self._micro            # micro-steps actually summed in this window (< accum_steps when force_update closed it)
         self._micro = 0
         self._force = False
         self._finish_reduce()
@@ -409,7 +417,11 @@ class TrainEngine:
             self.grad_snap.copy_(self.grad)
         self.step_count += 1
         b1, b2 = self.betas
-        gs = 1.0 / (self.world * self.accum_steps)   # buckets are SUM-reduced, micro-batch losses are means
+        # buckets are SUM-reduced, micro-batch losses are means.  A window that force_update closed early is averaged over the
+        # micro-steps it holds: the reference switches its divisor to `last_accum_steps` for the tail batches of an epoch
+        # (train_mirror.py:1117-1131, :1192)
+        gs = 1.0 / (self.world * n_micro)
+        self.last_grad_scale = gs
         if self.clip_grad is not None:
             K.grad_clip(self.grad, gs, float(self.clip_grad), self._state)
         K.adam(self.master, self.grad, self.m, self.v, self.shadow, self.lr, b1, b2, self.eps, 1.0, 1.0,

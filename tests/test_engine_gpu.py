@@ -449,8 +449,9 @@ def test_transposed_shadows_are_current_for_a_backward_outside_the_engine():
 
 def test_force_update_flushes_a_partial_accumulation_window_and_ranks_seed_dropout_differently():
     """(1) train_mirror.py:1128-1131: `need_update = last_batch or (batch_idx + 1) % accum_steps == 0` — the last, partial
-    window of an epoch still updates (loss scaled by 1 / accum_steps as in the reference, :1192-1196).  With accum_steps = 3, two
-    micro-steps and force_update on the second: one optimizer step, gradients = (g1 + g2) / 3, nothing left for the next window.
+    window of an epoch still updates, and the reference divides its tail batches by `last_accum_steps`, the number of batches
+    in that window (:1117-1131, :1192-1196).  With accum_steps = 3, two micro-steps and force_update on the second: one
+    optimizer step, gradients = (g1 + g2) / 2, nothing left for the next window.
     (2) `seed=` folds the rank in (utils.random_seed(args.seed, args.rank), :682): two engines built with ranks' seeds draw
     different dropout masks, the same seed reproduces."""
     from mirror_amd import functional as Fn
@@ -464,11 +465,12 @@ def test_force_update_flushes_a_partial_accumulation_window_and_ranks_seed_dropo
         ref.prototypes.weight.copy_(torch.nn.functional.normalize(ref.prototypes.weight, dim=1))
     for micro in range(2):
         wsi, rna, noise = _batch(2, 300 + micro)
-        (MIRRORLoss()(*ref(wsi, rna, noise=noise))[0] / 3).backward()
+        (MIRRORLoss()(*ref(wsi, rna, noise=noise))[0] / 2).backward()
         eng.step(wsi, rna, noise=noise, force_update=(micro == 1))
     assert float(eng._state[0]) == 1.0 and eng._micro == 0
     want = torch.cat([p.grad.reshape(-1) for p in reversed(list(ref.parameters()))])
-    got = torch.cat([eng.grad_snap[o:o + p.numel()] for p, o in zip(eng.params, eng.offsets)]) / 3.0     # Adam folds 1 / accum_steps in
+    assert eng.last_grad_scale == 0.5          # what mh_adam / mh_grad_clip were handed: 1 / (world * micro-steps in the window)
+    got = torch.cat([eng.grad_snap[o:o + p.numel()] for p, o in zip(eng.params, eng.offsets)]) * eng.last_grad_scale
     assert float((got - want).norm()) < 2e-3 * float(want.norm())
     # nothing leaks into the next window: the arena is cleared behind the update, or (default) beside the next step's forward —
     # then the first micro-step of the next window must leave exactly its own gradient there
@@ -492,3 +494,49 @@ def test_force_update_flushes_a_partial_accumulation_window_and_ranks_seed_dropo
         return Fn.dropout(x, 0.5, True)
     a, b, c = masks(10), masks(11), masks(10)
     assert torch.equal(a, c) and not torch.equal(a, b)
+
+
+def test_host_feeder_graph_replay_trains_on_every_batch_across_epochs():
+    """HostFeeder (train_mirror.py:1138-1139 made asynchronous) in front of the graph-replayed step: host f32 batches are cast
+    to bf16 on the device by a raw kernel into per-slot buffers.  With an odd number of batches per epoch the last batch of
+    epoch e and the first of epoch e + 1 used to land in the same slot tensor at the same torch version, so the replay skipped
+    its copy into the static input and trained on the previous batch's slide features.  Two epochs of three batches: after
+    every step the graph's static input must hold exactly the batch that was fed, and the losses must equal a run that is
+    handed resident device tensors."""
+    from mirror_amd import functional as Fn
+    from mirror_amd.data import HostFeeder
+    from mirror_amd.engine import TrainEngine
+    from mirror_amd.losses import MIRRORLoss
+    host = []
+    for i in range(3):
+        w, r, _ = _batch(2, 900 + i)
+        host.append((w.cpu().float() * (1.0 + i), r.cpu().float()))
+
+    def run(use_feeder):
+        torch.manual_seed(11)
+        Fn.manual_seed(13)
+        model = _make(seed=4)
+        eng = TrainEngine(model, MIRRORLoss(), lr=1e-3, precision="bf16", graph=True)
+        out, seen = [], []
+        for _epoch in range(2):
+            if use_feeder:
+                src = HostFeeder(host, "cuda", wsi_dtype=torch.bfloat16) if _epoch == 0 else src
+                it = iter(src)
+            else:
+                it = iter([(w.cuda().to(torch.bfloat16), r.cuda()) for w, r in host])
+            for i, (w, r) in enumerate(it):
+                assert w.dtype == torch.bfloat16 and w.is_cuda
+                losses = eng.step(w, r)
+                out.append([float(x) for x in losses])
+                if eng._graph is not None:
+                    seen.append(bool(torch.equal(eng._g_in[0], host[i][0].cuda().to(torch.bfloat16))))
+        torch.cuda.synchronize()
+        return out, seen, eng
+
+    got, seen, eng = run(True)
+    assert eng._graph is not None, "the step was not captured: this test has to exercise the replay path"
+    assert seen and all(seen), seen
+    want, _, _ = run(False)
+    for a, b in zip(got, want):
+        for x, y in zip(a, b):
+            assert abs(x - y) <= 2e-3 * max(abs(y), 1e-3), (got, want)
