@@ -63,6 +63,9 @@ class TrainEngine:
         if precision not in POLICIES:
             raise ValueError(f"unknown precision {precision!r}")
         self.model, self.loss_fn = model, loss_fn
+        # the fp8 delayed-scaling sites are keyed by weight-shadow addresses: a new engine's shadows may land where a freed
+        # engine's lived, and must not inherit its amax rings
+        Fn._fp8_state["sites"].clear()
         self.lr, self.betas, self.eps = lr, betas, eps
         self.precision = precision
         self.wsi_mask_ratio, self.rna_mask_ratio = wsi_mask_ratio, rna_mask_ratio
@@ -517,5 +520,6 @@ class TrainEngine:
         self._state_lr = float(self.lr)
         self.step_count = int(t)
         self._graph, self._graph_warm = None, 0          # a captured step is still valid, but re-capture keeps this simple
+        Fn._fp8_state["sites"].clear()
         self.sync_shadows()
 

@@ -874,8 +874,13 @@ def headattn_bwd(qkv, attn, dout, H: int) -> torch.Tensor:
 # ----------------------------------------------------------------------------- fused RNA Block (csrc/rna_block.hip)
 def rna_block_ok(x: torch.Tensor, D: int, Hh: int, H: int) -> bool:
     """The fused Block covers [B <= 32, D] f32 rows with D, Hh multiples of 32 and H | D (c2: D = 512, Hh = 2048, H = 8)."""
-    return (x.dim() == 2 and x.dtype == torch.float32 and x.is_contiguous() and 1 <= x.shape[0] <= 32 and x.shape[1] == D
-            and D % 32 == 0 and Hh % 32 == 0 and D % H == 0 and D <= 4096 and Hh <= 4096 and H <= 64)
+    if not (x.dim() == 2 and x.dtype == torch.float32 and x.is_contiguous() and 1 <= x.shape[0] <= 32 and x.shape[1] == D
+            and D % 32 == 0 and Hh % 32 == 0 and D % H == 0 and D <= 2048 and Hh <= 4096 and H <= 64):
+        return False
+    # the kernels stage the [B x K] operand of every Linear in LDS (csrc/rna_block.hip fwd_lds / launch_bwd): MT * 16 rows of
+    # K + 8 bf16 plus the cross-wave reduction scratch must fit 158 KiB, K = the longest contraction = max(D, Hh)
+    mt = 1 if x.shape[0] <= 16 else 2
+    return mt * 16 * (max(D, Hh) + 8) * 2 + 4 * mt * 16 * 17 * 4 <= 158 * 1024
 
 
 def rna_block_workspace_bytes(B: int, D: int, Hh: int) -> int:

@@ -191,3 +191,15 @@ def test_bench_gpus_n_without_launcher_refuses_when_devices_are_missing():
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "--gpus 2 but only" in r.stderr, (r.returncode, r.stderr[-300:])
     assert '"n_gpus"' not in r.stdout
+
+
+def test_rna_block_ok_mirrors_the_kernel_limits():
+    """mh_rna_block_fwd rejects D > 2048 and operand images above 158 KiB (csrc/rna_block.hip): the host-side admission test
+    must say no to the same shapes so that Block.forward falls back to the composed ops instead of raising."""
+    import torch
+    from mirror_amd import kernels as K
+    assert K.rna_block_ok(torch.zeros(16, 512), 512, 2048, 8)            # c2
+    assert K.rna_block_ok(torch.zeros(16, 768), 768, 1984, 12)
+    assert not K.rna_block_ok(torch.zeros(32, 1024), 1024, 4096, 8)     # 2 x 16 x 4104 x 2 B = 262 KiB operand image
+    assert not K.rna_block_ok(torch.zeros(8, 4096), 4096, 4096, 8)      # D > 2048
+    assert K.rna_block_ok(torch.zeros(16, 1024), 1024, 4096, 8)         # one row tile: 131 KiB
