@@ -47,6 +47,36 @@ int mh_device_ok(void);
  * Replaces: nn.Linear fwd/bwd (models/mirror.py:346, :70-74, :470-495, :594-605, :823-827),
  * [3P] NystromAttention's to_qkv / einsum similarities / attn@v / pinv matmuls / to_out
  * (models/mirror.py:312), ClipLoss logits (losses/mirror_loss.py:39-40).                      */
+/* Fused epilogues of the 256 x 256-tile projection GEMM (mh_gemm_desc.epi; NULL = none).  Each replaces an elementwise pass
+ * (and its HBM round trip) that the reference runs as a separate op behind an nn.Linear; the call fails with MH_EINVAL when
+ * the shape is not on that kernel (bf16 operands, N % 256 == 0, K % 64 == 0, M > 256, no split-K / accumulate / R / diag), and
+ * the host then runs the composed ops.  The Linear's result is rounded to bf16 (the activation dtype autocast gives it)
+ * before the fused op, so fused == composed bit for bit.
+ *   MH_EPI_DROPADD: C[f32] = resid + Dropout_p(A W^T + bias)         [3P] to_out = Sequential(Linear, Dropout) and the residual
+ *                   add of TransLayer.forward, models/mirror.py:312-313.  Philox4x32-10 exactly as mh_dropout: element i of C
+ *                   (flat, C contiguous: ldc == N) uses word i & 3 of the block with counter (offset + i) >> 2.
+ *   MH_EPI_MASKPOS: C[f32] = (t >= first && mask[b, t - first] ? token : A W^T + bias) + pos[t]      retention_embed followed by
+ *                   random_masking's mask-token select and `+ retention_gene_embed`, models/mirror.py:636-643, :691-693;
+ *                   flat row r of C is (b, t) = (r / rows_per_batch, r % rows_per_batch).
+ *   MH_EPI_SQERR:   C[bf16] = A W^T + bias as usual, and sq[0] += sum over rows with mask[b, t] != 0 of (C - tgt)^2,
+ *                   sq[1] += D * (number of such rows)   (tgt f32 at tgt + b * tgt_bs + t * D + col; rows_per_batch % 256 == 0)
+ *                   retention_head + the masked MSE of MIRRORLoss.forward, losses/mirror_loss.py:98-103. */
+#define MH_EPI_NONE 0
+#define MH_EPI_DROPADD 1
+#define MH_EPI_MASKPOS 2
+#define MH_EPI_SQERR 3
+typedef struct {
+    int32_t kind;
+    const float* resid;           /* DROPADD: residual stream, C's shape and layout */
+    float p; uint64_t seed, offset; const uint64_t* dev_base;      /* DROPADD: as mh_dropout */
+    const float* mask;            /* MASKPOS: [batches, rows_per_batch - first]; SQERR: [batches, rows_per_batch] (f32, != 0 = masked) */
+    const float* token;           /* MASKPOS: [N] */
+    const float* pos;             /* MASKPOS: [rows_per_batch, N] */
+    int32_t rows_per_batch, first;
+    const float* tgt; int64_t tgt_bs;      /* SQERR */
+    float* sq;                    /* SQERR: 2 f32, accumulated with atomics (caller zeroes) */
+} mh_gemm_epi;
+
 typedef struct {
     const void* A; const void* B; void* C;
     const float* bias;            /* [N] f32 or NULL */
@@ -79,6 +109,10 @@ typedef struct {
                                      tile kernel; no R / accumulate / diag / C2): sim1 = q k_l^T of the template geometry (m = 384
                                      landmarks, models/mirror.py:312 [3P] `attn1 = sim1.softmax(dim=-1)`) without the f32 logits round trip;
                                      2: its backward, C = P o (alpha A B - rowsum(P o alpha A B)) with the probabilities P given as R (bf16) */
+    const mh_gemm_epi* epi;       /* optional fused epilogue (above); NULL: none */
+    int32_t a_rows_per_batch, a_row_skip;   /* > 0: A's M rows are `a_rows_per_batch`-row windows of larger batches: flat row r lives at
+                                     A row r + (r / a_rows_per_batch) * a_row_skip (a_kc = 1 only).  Lets `to_out(out)[:, -n:]` and
+                                     `retention_head(x)[:, 1:]` run as ONE flat problem instead of a batched one with a ragged tile per slide */
 } mh_gemm_desc;
 int mh_gemm(const mh_gemm_desc* d, mh_stream s);
 /* Bytes of `workspace` with which this call reduces through plain partial tiles + a fold pass instead of f32 atomics
@@ -105,6 +139,10 @@ int mh_transpose_bf16_many(const void* src, void* dst, const int64_t* table, int
 int mh_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                      int batches, int rows_per_batch, int D, int64_t x_bs, int64_t y_bs, float eps,
                      int dt_x, int dt_y, mh_stream s);
+/* f32 output y plus a bf16 copy y_bf16 (same row addressing) in one pass: the encoder's final norm (models/mirror.py:679) feeds
+ * f32 consumers (retention target :699, cls row :684) and the bf16 operand of retention_embed (:690).  D % 4 == 0, D <= 2048. */
+int mh_layernorm_fwd_dual(const float* x, const float* gamma, const float* beta, float* y, void* y_bf16, float* mean, float* rstd,
+                          int batches, int rows_per_batch, int D, int64_t x_bs, int64_t y_bs, float eps, mh_stream s);
 /* the same with an e4m3 copy of the output beside the bf16 one (x f32, y bf16; q8 has y's row addressing, one byte per element):
  * delayed per-tensor scaling as in mh_quant_fp8_delayed (ring: 3 uint32 of this call site, tick: device step counter), scale[0] =
  * the dequantisation factor.  Config 5: the fp8 forward of [3P] to_qkv reads q8, its weight gradient the bf16 copy. */

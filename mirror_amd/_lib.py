@@ -15,6 +15,17 @@ MH_F32, MH_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 
 
+class GemmEpi(C.Structure):
+    """mh_gemm_epi of include/mirror_hip.h (field order = the header's)."""
+    _fields_ = [
+        ("kind", C.c_int32), ("resid", C.c_void_p),
+        ("p", C.c_float), ("seed", C.c_uint64), ("offset", C.c_uint64), ("dev_base", C.c_void_p),
+        ("mask", C.c_void_p), ("token", C.c_void_p), ("pos", C.c_void_p),
+        ("rows_per_batch", C.c_int32), ("first", C.c_int32),
+        ("tgt", C.c_void_p), ("tgt_bs", C.c_int64), ("sq", C.c_void_p),
+    ]
+
+
 class GemmDesc(C.Structure):
     _fields_ = [
         ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p),
@@ -32,6 +43,7 @@ class GemmDesc(C.Structure):
         ("C2", C.c_void_p), ("r_bf16", C.c_int32),
         ("k_segments", C.c_int32), ("sA_seg", C.c_int64), ("sB_seg", C.c_int64),
         ("row_softmax", C.c_int32),
+        ("epi", C.POINTER(GemmEpi)), ("a_rows_per_batch", C.c_int32), ("a_row_skip", C.c_int32),
     ]
 
 
@@ -77,6 +89,7 @@ _SIGS = {
     "mh_transpose_bf16": [P, P, I, I],
     "mh_transpose_bf16_many": [P, P, P, I, I, I, I],
     "mh_layernorm_fwd": [P, P, P, P, P, P, I, I, I, L, L, F, I, I],
+    "mh_layernorm_fwd_dual": [P, P, P, P, P, P, P, I, I, I, L, L, F],
     "mh_layernorm_fwd_q8": [P, P, P, P, P, P, I, I, I, L, L, F, P, P, P, F, P],
     "mh_layernorm_bwd": [P, P, P, P, P, P, P, P, I, I, I, L, L, I, I, I, I, P, L],
     "mh_softmax_fwd": [P, P, L, I, L, L, I, I],

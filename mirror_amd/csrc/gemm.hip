@@ -3,6 +3,7 @@
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 bool gemm_try_tile384(GemmArgs& a, int akc, int bkc, int dtC, int batch, void* c2, int r_bf16, hipStream_t s);   // gemm_tile.hip
+const char* gemm_big_epi(GemmArgs& a, int akc, int bkc, int dtC, int batch, hipStream_t s);                     // gemm_big.hip
 
 static int launch_one(const mh_gemm_desc* d, hipStream_t s) {
     const int split = d->split_k < 1 ? 1 : d->split_k;
@@ -30,6 +31,17 @@ static int launch_one(const mh_gemm_desc* d, hipStream_t s) {
     a.atomic = (a.split_k > 1) || (d->accumulate && batch > 1 && d->sC1 == 0 && d->sC2 == 0);
     MH_REQUIRE(!a.atomic || (d->dtC == MH_F32 && d->act == MH_ACT_NONE && d->accumulate),
                "mh_gemm: atomic accumulation (split-K / batch broadcast into C) needs f32 C, accumulate=1, no activation");
+    if (d->epi && d->epi->kind != MH_EPI_NONE) {
+        MH_REQUIRE(d->mma == MH_BF16 && d->dtA == MH_BF16 && d->dtB == MH_BF16 && !d->C2 && !d->r_bf16 && d->k_segments <= 1 && !d->row_softmax,
+                   "mh_gemm: a fused epilogue needs plain bf16 operands");
+        a.epi = *d->epi;
+        a.a_rpb = d->a_rows_per_batch; a.a_skip = d->a_row_skip;
+        const char* why = gemm_big_epi(a, d->a_kc, d->b_kc, d->dtC, batch, s);
+        MH_REQUIRE(!why, "mh_gemm(epi %d): %s", d->epi->kind, why);
+        MH_LAUNCH_CHECK("mh_gemm(epi)");
+        return MH_OK;
+    }
+    MH_REQUIRE(d->a_rows_per_batch == 0, "mh_gemm: a_rows_per_batch is part of the fused-epilogue path (epi)");
     const bool want_tile = d->C2 || d->r_bf16 || d->k_segments > 1 || d->row_softmax;
     if (d->mma == MH_BF16 && d->dtA == MH_BF16 && d->dtB == MH_BF16 && gemm_try_tile384(a, d->a_kc, d->b_kc, d->dtC, batch, d->C2, d->r_bf16, s)) {
         MH_LAUNCH_CHECK("mh_gemm(tile)");

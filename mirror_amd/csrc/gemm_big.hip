@@ -17,10 +17,49 @@ namespace {
 
 constexpr int BIG = 256, NTB = 512, BWM = 4, BWN = 2;
 
+// Fused epilogues (mh_gemm_epi, include/mirror_hip.h) on one quad of a row: x = the Linear's result for columns gcol .. gcol + 3
+// of flat row grow.  The result is rounded to bf16 first: that is what the composed path hands the elementwise op.
+__device__ __forceinline__ f32x4 round_bf16_4(f32x4 x) {
+    return f32x4{bf2f(f2bf(x[0])), bf2f(f2bf(x[1])), bf2f(f2bf(x[2])), bf2f(f2bf(x[3]))};
+}
+template <int EPI>
+__device__ __forceinline__ f32x4 epi_quad(const GemmArgs& g, f32x4 x, long grow, int gcol, uint64_t drop_blk0, uint32_t thr, float dscale) {
+    if constexpr (EPI == MH_EPI_DROPADD) {
+        // [3P] to_out[1] = Dropout, then TransLayer's residual add (models/mirror.py:312-313); Philox exactly as mh_dropout
+        x = round_bf16_4(x);
+        const uint64_t blk = drop_blk0 + (((uint64_t)grow * (uint64_t)g.N + (uint64_t)gcol) >> 2);
+        uint32_t ctr[4] = {(uint32_t)blk, (uint32_t)(blk >> 32), 0u, 0u};
+        philox4x32_10(ctr, (uint32_t)g.epi.seed, (uint32_t)(g.epi.seed >> 32));
+        const f32x4 res = *reinterpret_cast<const f32x4*>(g.epi.resid + grow * (long)g.N + gcol);
+        return f32x4{res[0] + (ctr[0] >= thr ? x[0] * dscale : 0.f), res[1] + (ctr[1] >= thr ? x[1] * dscale : 0.f),
+                     res[2] + (ctr[2] >= thr ? x[2] * dscale : 0.f), res[3] + (ctr[3] >= thr ? x[3] * dscale : 0.f)};
+    } else if constexpr (EPI == MH_EPI_MASKPOS) {
+        // random_masking's token select + `+ retention_gene_embed` (models/mirror.py:636-643, :691-693)
+        x = round_bf16_4(x);
+        const int rpb = g.epi.rows_per_batch, first = g.epi.first;
+        const long b = grow / rpb;
+        const int t = (int)(grow - b * rpb);
+        if (t >= first && g.epi.mask[b * (rpb - first) + (t - first)] != 0.f) x = *reinterpret_cast<const f32x4*>(g.epi.token + gcol);
+        return x + *reinterpret_cast<const f32x4*>(g.epi.pos + (long)t * g.N + gcol);
+    } else {
+        return x;
+    }
+}
+
 // accumulators -> f32 LDS tile [128][260] (one half of the rows at a time) -> 16-byte row-contiguous stores
-template <typename TC, int MODE>
+template <typename TC, int MODE, int EPI = 0>
 __device__ __forceinline__ void epilogue_big(const GemmArgs& g, TC* C, f32x16 (&acc)[BWM][BWN], char* smem, int tile_row0,
                                              int tile_col0, int wm, int wn, int lane, int tid, bool lead, long ldc, float alpha) {
+    uint64_t drop_blk0 = 0;
+    uint32_t thr = 0;
+    float dscale = 1.f;
+    if constexpr (EPI == MH_EPI_DROPADD) {
+        uint64_t off = g.epi.offset;
+        if (g.epi.dev_base) off += *g.epi.dev_base & ~3ull;
+        drop_blk0 = off >> 2;
+        thr = (uint32_t)fminf(g.epi.p * 4294967296.f, 4294967295.f);
+        dscale = 1.f / (1.f - g.epi.p);
+    }
     constexpr int PITCH = BIG + 4, HALF = BIG / 2;
     float* t = reinterpret_cast<float*>(smem);
     const int r = lane & 31, hh = lane >> 5;
@@ -58,6 +97,7 @@ __device__ __forceinline__ void epilogue_big(const GemmArgs& g, TC* C, f32x16 (&
             f32x4 x0 = *reinterpret_cast<const f32x4*>(src);
             u32x4 o;
             if constexpr (sizeof(TC) == 4) {
+                if constexpr (EPI != 0) x0 = epi_quad<EPI>(g, x0, (long)(tile_row0 + half * HALF + lr), tile_col0 + c * EPC, drop_blk0, thr, dscale);
                 if constexpr (MODE == 1) x0 += *reinterpret_cast<const f32x4*>(dst);
                 o[0] = __float_as_uint(x0[0]); o[1] = __float_as_uint(x0[1]);
                 o[2] = __float_as_uint(x0[2]); o[3] = __float_as_uint(x0[3]);
@@ -104,10 +144,11 @@ __device__ __forceinline__ void epilogue_atomic_big(const GemmArgs& g, float* C,
 // columns of one row: the whole 256 x 256 tile goes to LDS as bf16 with 8-byte stores (one pass, half the bytes of the
 // f32 image and no 4-byte scatter) and leaves as 16-byte row-contiguous stores.  Pitch 260: 16 lanes (rows) x 2 dwords
 // cover the 32 banks exactly.
-template <int MODE>
+template <int MODE, int EPI = 0>
 __device__ __forceinline__ void epilogue_big_t(const GemmArgs& g, bf16_t* C, f32x16 (&acc)[BWM][BWN], char* smem, int tile_row0,
                                                int tile_col0, int wm, int wn, int lane, int tid, bool lead, float alpha) {
     constexpr int PITCH = BIG + 4;
+    float sq_sum = 0.f, sq_cnt = 0.f;          // MH_EPI_SQERR partials of this thread
     static_assert(BIG * PITCH * 2 <= 2 * (TileGeom<1, true, BIG>::BYTES + TileGeom<1, true, BIG>::BYTES), "bf16 tile must fit");
     bf16_t* t = reinterpret_cast<bf16_t*>(smem);
     const int r = lane & 31, hh = lane >> 5;
@@ -157,6 +198,37 @@ __device__ __forceinline__ void epilogue_big_t(const GemmArgs& g, bf16_t* C, f32
         }
         if (GEMM_EXP == 5) { if (o[0] == 0x12345678u) *reinterpret_cast<u32x4*>(dst) = o; continue; }
         *reinterpret_cast<u32x4*>(dst) = o;
+        if constexpr (EPI == MH_EPI_SQERR) {
+            // masked squared error against the f32 target rows (losses/mirror_loss.py:98-103) on the bf16-rounded prediction
+            const int rpb = g.epi.rows_per_batch;             // % 256 == 0: a tile lies inside one batch
+            const long b = tile_row0 / rpb;
+            const int t = tile_row0 - (int)(b * rpb) + lr;
+            if (g.epi.mask[b * rpb + t] != 0.f) {
+                const float* tg = g.epi.tgt + b * g.epi.tgt_bs + (long)t * g.N + tile_col0 + c * 8;
+                const f32x4 t0 = *reinterpret_cast<const f32x4*>(tg), t1 = *reinterpret_cast<const f32x4*>(tg + 4);
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    const float d0 = __uint_as_float(o[w] << 16) - (w < 2 ? t0[2 * w] : t1[2 * w - 4]);
+                    const float d1 = __uint_as_float(o[w] & 0xffff0000u) - (w < 2 ? t0[2 * w + 1] : t1[2 * w - 3]);
+                    sq_sum += d0 * d0 + d1 * d1;
+                }
+                sq_cnt += 8.f;
+            }
+        }
+    }
+    if constexpr (EPI == MH_EPI_SQERR) {
+        float* red = reinterpret_cast<float*>(smem + BIG * PITCH * 2);     // behind the bf16 tile image (133120 of 147456 bytes)
+        sq_sum = wave_sum(sq_sum);
+        sq_cnt = wave_sum(sq_cnt);
+        if (lane == 0) { red[2 * (tid >> 6)] = sq_sum; red[2 * (tid >> 6) + 1] = sq_cnt; }
+        __syncthreads();
+        if (tid == 0) {
+            float a = 0.f, n = 0.f;
+#pragma unroll
+            for (int w = 0; w < NTB / 64; w++) { a += red[2 * w]; n += red[2 * w + 1]; }
+            atomicAdd(g.epi.sq, a);
+            atomicAdd(g.epi.sq + 1, n);
+        }
     }
 }
 
@@ -170,9 +242,25 @@ __device__ __forceinline__ i32x8 f8_pair(bf16x8 lo, bf16x8 hi) {
     return i32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
 
-template <typename TC, bool AKC, bool BKC, bool FP8 = false, bool PART = false>
+// A tile load for the fused-epilogue instances: K-contiguous A whose M rows are row windows of larger batches (GemmArgs.a_rpb /
+// a_skip: `to_out(out)[:, -n:]`, `retention_head(x)[:, 1:]`): a 256-row tile crosses at most one batch boundary (a_rpb >= 256),
+// at local row `bnd`; rows past M re-read row M - 1 (their results are never stored).
+template <int NCH>
+__device__ __forceinline__ void load_a_window(u32x4 (&regs)[NCH], const bf16_t* __restrict__ base, long ld, int tile0, int dim, int k0,
+                                              int tid, int adj0, int bnd, int skip) {
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+        const int cid = tid + i * NTB;
+        const int rl = min(tile0 + (cid >> 3), dim - 1) - tile0, c = cid & 7;
+        const int row = tile0 + rl + adj0 + (rl >= bnd ? skip : 0);
+        regs[i] = *reinterpret_cast<const u32x4*>(base + (long)row * ld + k0 + c * 8);
+    }
+}
+
+template <typename TC, bool AKC, bool BKC, bool FP8 = false, bool PART = false, int EPI = 0>
 __global__ __launch_bounds__(NTB) void gemm_big_kernel(GemmArgs g) {
     static_assert(!FP8 || (AKC && BKC), "fp8 operands are K-contiguous");
+    static_assert(EPI == 0 || (AKC && !FP8 && !PART), "fused epilogues: K-contiguous A, plain bf16 operands, no split-K");
     using GA = TileGeom<1, AKC, BIG>;
     using GB = TileGeom<1, BKC, BIG>;
     constexpr int BK = 64;
@@ -210,13 +298,26 @@ __global__ __launch_bounds__(NTB) void gemm_big_kernel(GemmArgs g) {
     // One register set, written to LDS right AFTER the barrier that frees the other stage and re-issued at once: the
     // ds_write pass (~80 B/clk per CU, ~800 cycles per K-tile) then drains under the MFMAs of the current tile instead
     // of sitting between the last MFMA and the barrier (8192^3: 732 -> 1094 TFLOP/s).
+    int adj0 = 0, bnd = 1 << 30;
+    if constexpr (EPI != 0) {
+        if (g.a_rpb > 0) {
+            const int b0 = (tile_m * BIG) / g.a_rpb;
+            adj0 = b0 * g.a_skip;
+            bnd = (b0 + 1) * g.a_rpb - tile_m * BIG;
+        }
+    }
+#define LOAD_A_(K0_)                                                                                         \
+    do {                                                                                                     \
+        if constexpr (EPI != 0) load_a_window<SA::NCH>(ra, A, g.lda, tile_m * BIG, g.M, K0_, tid, adj0, bnd, g.a_skip); \
+        else SA::load(ra, A, g.lda, tile_m * BIG, g.M, K0_, kend, true, tid);                                \
+    } while (0)
     if (nt > 0) {
-        SA::load(ra, A, g.lda, tile_m * BIG, g.M, kbeg, kend, true, tid);
+        LOAD_A_(kbeg);
         SB::load(rb, B, g.ldb, tile_n * BIG, g.N, kbeg, kend, true, tid);
         SA::store(ra, smem, tid);
         SB::store(rb, smem + GA::BYTES, tid);
         if (nt > 1) {
-            SA::load(ra, A, g.lda, tile_m * BIG, g.M, kbeg + BK, kend, true, tid);
+            LOAD_A_(kbeg + BK);
             SB::load(rb, B, g.ldb, tile_n * BIG, g.N, kbeg + BK, kend, true, tid);
         }
     }
@@ -233,7 +334,7 @@ __global__ __launch_bounds__(NTB) void gemm_big_kernel(GemmArgs g) {
             }
             if (t + 2 < nt && GEMM_EXP != 1) {
                 const int k0 = GEMM_EXP == 2 ? kbeg : kbeg + (t + 2) * BK;    // 2 = always the same K-tile (cache resident)
-                SA::load(ra, A, g.lda, tile_m * BIG, g.M, k0, kend, true, tid);
+                LOAD_A_(k0);
                 SB::load(rb, B, g.ldb, tile_n * BIG, g.N, k0, kend, true, tid);
             }
         }
@@ -276,6 +377,12 @@ __global__ __launch_bounds__(NTB) void gemm_big_kernel(GemmArgs g) {
         }
         }
         __syncthreads();
+    }
+#undef LOAD_A_
+    if constexpr (EPI != 0) {
+        if constexpr (sizeof(TC) == 2) epilogue_big_t<0, EPI>(g, C, acc, smem, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, true, g.alpha);
+        else epilogue_big<TC, 0, EPI>(g, C, acc, smem, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, true, g.ldc, g.alpha);
+        return;
     }
     if constexpr (FP8) {      // per-tensor dequantisation factors live on the device: fold them into alpha
         const float a8 = g.alpha * g.scale_a[0] * g.scale_b[0];
@@ -379,6 +486,41 @@ bool gemm_try_big_fp8(GemmArgs& a, int dtC, int batch, hipStream_t s) {
     if (dtC == MH_BF16) hipLaunchKernelGGL((gemm_big_kernel<bf16_t, true, true, true>), grid, dim3(NTB), 0, s, a);
     else hipLaunchKernelGGL((gemm_big_kernel<float, true, true, true>), grid, dim3(NTB), 0, s, a);
     return true;
+}
+
+// fused-epilogue launch (mh_gemm_desc.epi): 0 = launched, otherwise why not (the caller reports MH_EINVAL)
+const char* gemm_big_epi(GemmArgs& a, int akc, int bkc, int dtC, int batch, hipStream_t s) {
+    if (!(akc && a.M > BIG && a.N % BIG == 0 && a.K % 64 == 0 && a.split_k == 1 && a.k_per_split == a.K && !a.atomic && !a.accumulate && !a.R &&
+          a.diag == 0.f && a.vecA && a.vecB && a.vecC && batch == 1))
+        return "shape is not on the 256 x 256 kernel (K-contiguous bf16 A, M > 256, N % 256 == 0, K % 64 == 0, one batch, no split-K / accumulate / R / diag)";
+    if (a.a_rpb != 0 && a.a_rpb < BIG) return "a_rows_per_batch must be >= 256";
+    if (a.ldc != a.N) return "C must be contiguous (ldc == N)";
+    const mh_gemm_epi& e = a.epi;
+    a.tiles_m = (a.M + BIG - 1) / BIG;
+    a.tiles_n = a.N / BIG;
+    dim3 grid(a.tiles_m * a.tiles_n, 1, 1);
+#define EPI_LAUNCH_(TC, EPI) \
+    do { if (bkc) hipLaunchKernelGGL((gemm_big_kernel<TC, true, true, false, false, EPI>), grid, dim3(NTB), 0, s, a); \
+         else hipLaunchKernelGGL((gemm_big_kernel<TC, true, false, false, false, EPI>), grid, dim3(NTB), 0, s, a); } while (0)
+    switch (e.kind) {
+    case MH_EPI_DROPADD:
+        if (dtC != MH_F32 || !e.resid || !(e.p >= 0.f && e.p < 1.f) || (e.offset & 3) || ((uintptr_t)e.resid & 15)) return "DROPADD: f32 C, a 16-byte aligned residual, 0 <= p < 1, offset % 4 == 0";
+        EPI_LAUNCH_(float, MH_EPI_DROPADD);
+        return nullptr;
+    case MH_EPI_MASKPOS:
+        if (dtC != MH_F32 || !e.mask || !e.token || !e.pos || e.rows_per_batch <= 0 || e.first < 0 || a.M % e.rows_per_batch) return "MASKPOS: f32 C, mask / token / pos, M a multiple of rows_per_batch";
+        if (((uintptr_t)e.token & 15) || ((uintptr_t)e.pos & 15)) return "MASKPOS: token / pos must be 16-byte aligned";
+        EPI_LAUNCH_(float, MH_EPI_MASKPOS);
+        return nullptr;
+    case MH_EPI_SQERR:
+        if (dtC != MH_BF16 || !e.mask || !e.tgt || !e.sq || e.rows_per_batch <= 0 || e.rows_per_batch % BIG || a.M % e.rows_per_batch || a.act != MH_ACT_NONE) return "SQERR: bf16 C, mask / tgt / sq, rows_per_batch % 256 == 0";
+        if (((uintptr_t)e.tgt & 15) || e.tgt_bs % 4) return "SQERR: tgt must be 16-byte aligned";
+        EPI_LAUNCH_(bf16_t, MH_EPI_SQERR);
+        return nullptr;
+    default:
+        return "unknown epilogue kind";
+    }
+#undef EPI_LAUNCH_
 }
 
 // true when the large-tile kernel took the launch

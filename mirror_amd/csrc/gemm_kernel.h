@@ -40,6 +40,8 @@ struct GemmArgs {
     const float* scale_a; const float* scale_b;   // fp8 operands (gemm_big.hip FP8 instance): alpha *= scale_a[0] * scale_b[0]
     int row_softmax;              // gemm_tile.hip, N == 384, bf16 C: C = softmax over each row of alpha * A B (the whole row is in one tile)
     int kseg; long sAk, sBk;      // C = sum over kseg operand pairs (A + s sAk, B + s sBk), K each (gemm_tile.hip only; 0 / 1: one pair)
+    mh_gemm_epi epi;              // fused epilogue (gemm_big.hip only; kind 0: none)
+    int a_rpb, a_skip;            // row-window remap of A (gemm_big.hip, K-contiguous A): flat row r -> r + (r / a_rpb) * a_skip
 };
 
 template <int MMA, bool KC, int ROWS>

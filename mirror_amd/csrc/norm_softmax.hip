@@ -112,13 +112,15 @@ template <typename TX, typename TY, int LNV_CH>
 __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const TX* __restrict__ x, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, TY* __restrict__ y,
                                                                 float* __restrict__ mean, float* __restrict__ rstd,
-                                                                long rows, int rpb, int D, long x_bs, long y_bs, float eps) {
+                                                                long rows, int rpb, int D, long x_bs, long y_bs, float eps,
+                                                                bf16_t* __restrict__ y2 = nullptr) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const long b = row / rpb, i = row % rpb;
     const TX* xr = x + b * x_bs + i * D;
     TY* yr = y + b * y_bs + i * D;
+    bf16_t* y2r = y2 ? y2 + b * y_bs + i * D : nullptr;      // mh_layernorm_fwd_dual: a bf16 copy beside the f32 output
     f4 v[LNV_CH];
     float s = 0.f;
 #pragma unroll
@@ -147,6 +149,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const TX* __rest
 #pragma unroll
             for (int e = 0; e < 4; e++) o[e] = (v[k][e] - mu) * rs * g[e] + bt[e];
             st4(yr + c, o);
+            if (y2r) st4(y2r + c, o);
         }
     }
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
@@ -326,6 +329,24 @@ extern "C" int mh_layernorm_fwd(const void* x, const float* gamma, const float* 
     else LN_F(bf16_t, float);
 #undef LN_F
     MH_LAUNCH_CHECK("mh_layernorm_fwd");
+    return MH_OK;
+}
+
+// f32 output + a bf16 copy with the same row addressing, one pass: the encoder's final norm feeds an f32 consumer (retention
+// target, cls row: models/mirror.py:699, :684) and a projection that takes bf16 operands (retention_embed, :690) — without the
+// copy the projection's input costs a separate 214 MB cast pass.
+extern "C" int mh_layernorm_fwd_dual(const float* x, const float* gamma, const float* beta, float* y, void* y_bf16, float* mean, float* rstd,
+                                     int batches, int rpb, int D, int64_t x_bs, int64_t y_bs, float eps, mh_stream s) {
+    const long rows = (long)batches * rpb;
+    if (rows == 0) return MH_OK;
+    MH_REQUIRE(y_bf16 && D % 4 == 0 && D <= 2048 && x_bs % 4 == 0 && y_bs % 4 == 0 &&
+                   (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0 && ((uintptr_t)y_bf16 & 7) == 0,
+               "mh_layernorm_fwd_dual: D %% 4 == 0, D <= 2048 and aligned buffers (D=%d)", D);
+    dim3 grid(mh_cdiv(rows, 4));
+#define LND(NC) hipLaunchKernelGGL((layernorm_fwd_vec_kernel<float, float, NC>), grid, dim3(256), 0, (hipStream_t)s, x, gamma, beta, y, mean, rstd, rows, rpb, D, (long)x_bs, (long)y_bs, eps, (bf16_t*)y_bf16)
+    if (D <= 512) LND(2); else if (D <= 1024) LND(4); else LND(8);
+#undef LND
+    MH_LAUNCH_CHECK("mh_layernorm_fwd_dual");
     return MH_OK;
 }
 

@@ -495,6 +495,115 @@ class LinearRowsFn(Function):
         return dx, dw, db, None, None, None, None
 
 
+def _linear_rows_bwd(ctx_needs, x, wa, w, b, r0, R, prec, dy, dx_dtype=None):
+    """Backward of y = x[:, r0:r0+R] @ W^T + b given dy [B, R, N] in the activation dtype: (dx over all of x's rows, dW, db)."""
+    N, Kd = wa.shape
+    dx = dw = db = None
+    if ctx_needs[0]:
+        dx = torch.empty(x.shape, device=x.device, dtype=dx_dtype or x.dtype)
+        if r0:
+            dx[:, :r0].zero_()
+        if r0 + R < x.shape[1]:
+            dx[:, r0 + R:].zero_()
+        _gemm_window(dy, wa, dx[:, r0:r0 + R], mma=prec.mma)
+    if ctx_needs[1]:
+        dw, sunk = _gbuf(w, (N, Kd))
+        _wgrad(dy, x[:, r0:r0 + R], N, Kd, prec, dw)
+        dw = _gret(w, dw, sunk)
+    if b is not None and ctx_needs[2]:
+        db, sunk = _gbuf(b, (N,))
+        K.colsum(dy.reshape(-1, N), db)
+        db = _gret(b, db, sunk)
+    return dx, dw, db
+
+
+class ToOutDropAddFn(Function):
+    """resid + Dropout_p(core[:, r0:r0+R] @ W^T + b) -> f32 in ONE launch: [3P] to_out = Sequential(Linear, Dropout), the `[:, -n:]`
+    slice and TransLayer's residual add (models/mirror.py:312-313) ride in the projection's epilogue (mh_gemm_epi DROPADD): the
+    bf16 projection output never goes through HBM and the separate dropout + add pass is gone.  Bit-identical to
+    dropout_add(resid, LinearRowsFn(core, ...)) (the Linear's result is rounded to bf16 in the epilogue, the Philox mask is the
+    one mh_dropout draws for the same (seed, offset, element))."""
+
+    @staticmethod
+    def forward(ctx, resid, core, w, b, r0, R, p, prec):
+        wa = shadow(w, prec)
+        Bn, _, Kd = core.shape
+        N = wa.shape[0]
+        out = torch.empty((Bn, R, N), device=core.device, dtype=f32)
+        ctx.p, ctx.seed, ctx.offset, ctx.base = p, _dropout_state["seed"], _dropout_state["offset"], _dropout_state["base"]
+        _dropout_state["offset"] += (out.numel() + 3) // 4 * 4
+        K.linear_fused(core, wa, None if b is None else b.detach(), out,
+                       K.epi_dropadd(resid, p, ctx.seed, ctx.offset, ctx.base), window=(r0, R))
+        ctx.save_for_backward(core, wa, w, b)
+        ctx.r0, ctx.R, ctx.prec, ctx.res_key = r0, R, prec, resid.data_ptr()
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        core, wa, w, b = ctx.saved_tensors
+        dy = dy.contiguous()
+        gb = torch.empty(dy.shape, device=dy.device, dtype=ctx.prec.act)
+        K.dropout(dy, ctx.p, ctx.seed, ctx.offset, out=gb, dev_base=ctx.base)      # masked, scaled gradient of the projection output
+        _res_grads[ctx.res_key] = dy         # the block's LayerNorm accumulates its dx into the residual gradient (see AddFn)
+        dcore, dw, db = _linear_rows_bwd(ctx.needs_input_grad[1:4], core, wa, w, b, ctx.r0, ctx.R, ctx.prec, gb)
+        return dy, dcore, dw, db, None, None, None, None
+
+
+def to_out_dropout_add(resid, core, w, b, r0: int, R: int, p: float, training: bool, prec: Precision):
+    """x + Dropout(to_out(core)[:, r0:r0+R]): fused when the shapes are on the 256 x 256-tile kernel (bf16 policy, training)."""
+    if (training and p > 0.0 and prec.act == bf16 and not prec.fp8_fwd and resid.dtype == f32 and resid.is_contiguous()
+            and core.dtype == bf16 and tuple(resid.shape) == (core.shape[0], R, w.shape[0]) and (core.shape[0] * R * w.shape[0]) % 4 == 0
+            and K.linear_fused_ok(core, shadow(w, prec), (r0, R))):
+        return ToOutDropAddFn.apply(resid, core, w, b, r0, R, p, prec)
+    y = LinearRowsFn.apply(core, w, b, r0, R, prec, prec.act)
+    return dropout_add(resid, y, p, training)
+
+
+class EmbedMaskPosFn(Function):
+    """(mask ? mask_token : h @ W^T + b) + pos -> f32 residual stream in ONE launch: retention_embed, random_masking's token select
+    and `+ retention_gene_embed` (models/mirror.py:636-643, :691-693) as the projection's epilogue (mh_gemm_epi MASKPOS).
+    h [B, T, K] bf16; mask [B, T - first] (1 = masked); token [D]; pos [T, D]."""
+
+    @staticmethod
+    def forward(ctx, h32, h, w, b, mask, token, pos, first, prec):
+        """h32: the tensor autograd tracks (its gradient is returned in f32); h: its bf16 copy, the operand."""
+        wa = shadow(w, prec)
+        Bn, T, Kd = h.shape
+        N = wa.shape[0]
+        out = torch.empty((Bn, T, N), device=h.device, dtype=f32)
+        K.linear_fused(h, wa, None if b is None else b.detach(), out,
+                       K.epi_maskpos(mask, token.detach().reshape(-1).contiguous(), pos.detach().reshape(-1).contiguous(), T, first))
+        ctx.save_for_backward(h, wa, w, b, mask)
+        ctx.geom = (Bn, T, N, first, token.shape, pos.shape, prec)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, wa, w, b, mask = ctx.saved_tensors
+        Bn, T, N, first, tshape, pshape, prec = ctx.geom
+        dy = dy.contiguous()
+        dr = torch.empty(dy.shape, device=dy.device, dtype=prec.act)          # gradient of the projection output (zero at masked rows)
+        dtok = zeros((N,), dy.device)
+        dpos = zeros((T * N,), dy.device)
+        K.mask_apply_bwd(dy, mask, dtok, dpos, Bn, T, N, first, False, out=dr)
+        # f32 data gradient: EncFanoutFn sums it with the target / cls gradients in one pass (mh_fanout_bwd reads f32)
+        needs = (ctx.needs_input_grad[0], ctx.needs_input_grad[2], ctx.needs_input_grad[3])
+        dh, dw, db = _linear_rows_bwd(needs, h, wa, w, b, 0, T, prec, dr, dx_dtype=f32)
+        return dh, None, dw, db, None, dtok.reshape(tshape), dpos.reshape(pshape), None, None
+
+
+def embed_mask_pos(h, w, b, mask, token, pos, first: int, prec: Precision):
+    """MaskApplyFn(linear(h, w, b), mask, token, pos, first): one launch when h has a bf16 copy (layer_norm(bf16_copy=True)) or is
+    bf16 itself and the shapes are on the 256 x 256-tile kernel; the composed ops otherwise."""
+    hb = h if h.dtype == bf16 else getattr(h, "_bf16", None)
+    if (hb is not None and prec.act == bf16 and not prec.fp8_fwd and hb.is_contiguous() and tuple(hb.shape) == tuple(h.shape)
+            and mask.dtype == f32 and mask.is_contiguous() and K.linear_fused_ok(hb, shadow(w, prec))
+            and token.numel() == w.shape[0] and pos.numel() == h.shape[1] * w.shape[0]):
+        return EmbedMaskPosFn.apply(h, hb, w, b, mask, token, pos, first, prec)
+    r = linear(h, w, b, prec=prec)
+    return MaskApplyFn.apply(r, mask, token, pos, first, False)
+
+
 # ------------------------------------------------------------------ LayerNorm
 class LayerNormFn(Function):
     """LayerNorm over the last dim of x [B, T, D] (f32 residual stream) using only the first `rows` rows
@@ -502,10 +611,21 @@ class LayerNormFn(Function):
     [3P] NystromAttention).  Output [B, pad + rows, D] in `out_dtype`."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, rows, pad, out_dtype, q8_key=None):
+    def forward(ctx, x, gamma, beta, eps, rows, pad, out_dtype, q8_key=None, dual=None):
         x = x.contiguous()
         Bn, T, D = x.shape
         y = torch.empty((Bn, pad + rows, D), device=x.device, dtype=out_dtype)
+        if dual is not None:
+            # f32 output + its bf16 copy in one pass (mh_layernorm_fwd_dual); the copy is handed over through `dual` (a
+            # one-element list): it carries no gradient of its own, its consumers' gradients arrive through the f32 output
+            mean = torch.empty((Bn * rows,), device=x.device, dtype=f32)
+            rstd = torch.empty_like(mean)
+            y16 = torch.empty((Bn, rows, D), device=x.device, dtype=bf16)
+            K.layernorm_fwd_dual(x, gamma.detach(), beta.detach(), y, y16, mean, rstd, Bn, rows, D, T * D, rows * D, eps)
+            dual.append(y16)
+            ctx.save_for_backward(x, gamma, mean, rstd, beta)
+            ctx.rows, ctx.pad = rows, pad
+            return y
         if pad:
             y[:, :pad].zero_()
         mean = torch.empty((Bn * rows,), device=x.device, dtype=f32)
@@ -545,10 +665,10 @@ class LayerNormFn(Function):
             G = G.view(x.shape)          # the RNA blocks run on [B, D]: layer_norm() added a leading 1
             K.layernorm_bwd(dy[:, pad:], x, gamma.detach(), mean, rstd, G, dg, db, Bn, rows, D, T * D, (pad + rows) * D,
                             accumulate_dx=True)
-            return None, _gret(gamma, dg, sunk_g), _gret(beta, db, sunk_b), None, None, None, None, None
+            return None, _gret(gamma, dg, sunk_g), _gret(beta, db, sunk_b), None, None, None, None, None, None
         dx = torch.zeros_like(x) if rows < T else torch.empty_like(x)
         K.layernorm_bwd(dy[:, pad:], x, gamma.detach(), mean, rstd, dx, dg, db, Bn, rows, D, T * D, (pad + rows) * D)
-        return dx, _gret(gamma, dg, sunk_g), _gret(beta, db, sunk_b), None, None, None, None, None
+        return dx, _gret(gamma, dg, sunk_g), _gret(beta, db, sunk_b), None, None, None, None, None, None
 
 
 _LN_Q8 = os.environ.get("MIRROR_LN_Q8", "1") != "0"      # A/B switch: LayerNorm writes the e4m3 copy of its output (fp8 policy)
@@ -560,11 +680,23 @@ def fp8_site_key(w: torch.Tensor, prec: "Precision"):
     return (shadow(w, prec).data_ptr(), "x")
 
 
-def layer_norm(x, gamma, beta, eps, *, rows=None, pad=0, out_dtype=f32, q8_key=None):
+_LN_DUAL = os.environ.get("MIRROR_LN_DUAL", "1") != "0"      # A/B switch
+
+
+def layer_norm(x, gamma, beta, eps, *, rows=None, pad=0, out_dtype=f32, q8_key=None, bf16_copy=False):
+    """bf16_copy=True (f32 in / f32 out, no padding): the same launch also writes a bf16 copy of the output, attached to the
+    result as `y._bf16` for a consumer that takes bf16 operands (the retention_embed projection) — no cast pass."""
     squeeze = x.dim() == 2
     if squeeze:
         x = x.unsqueeze(0)
-    y = LayerNormFn.apply(x, gamma, beta, eps, x.shape[1] if rows is None else rows, pad, out_dtype, q8_key)
+    r = x.shape[1] if rows is None else rows
+    dual = None
+    if (bf16_copy and _LN_DUAL and not squeeze and x.dtype == f32 and out_dtype == f32 and pad == 0 and x.shape[-1] % 4 == 0
+            and x.shape[-1] <= 2048 and q8_key is None):
+        dual = []
+    y = LayerNormFn.apply(x, gamma, beta, eps, r, pad, out_dtype, q8_key, dual)
+    if dual:
+        y._bf16 = dual[0]
     return y.squeeze(0) if squeeze else y
 
 
@@ -1201,6 +1333,8 @@ def enc_fanout(E: torch.Tensor):
     tok = _FanToken()
     full, tgt, cls = EncFanoutFn.apply(E, tok)
     tgt._fan_token = tok
+    if getattr(E, "_bf16", None) is not None:
+        full._bf16 = E._bf16          # layer_norm(..., bf16_copy=True): the decoder's projection reads this copy
     return full, tgt, cls
 
 

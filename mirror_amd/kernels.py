@@ -172,6 +172,75 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *
     return out
 
 
+EPI_DROPADD, EPI_MASKPOS, EPI_SQERR = 1, 2, 3
+_EPI_ON = os.environ.get("MIRROR_GEMM_EPI", "1") != "0"       # A/B switch: the fused projection epilogues (mh_gemm_epi)
+
+
+def linear_fused_ok(x: torch.Tensor, w: torch.Tensor, window: Optional[tuple] = None) -> bool:
+    """Shapes mh_gemm's fused epilogues take: bf16 activations x [B, T, K] (contiguous; optionally the row window
+    [r0, r0 + R) of every batch), bf16 weight [N, K] contiguous, N % 256 == 0, K % 64 == 0, more than 256 rows in all."""
+    if not (_EPI_ON and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.dim() == 3 and x.is_contiguous() and w.dim() == 2
+            and w.is_contiguous() and x.is_cuda):
+        return False
+    Bn, T, Kd = x.shape
+    R = T if window is None else window[1]
+    return (w.shape[1] == Kd and Kd % 64 == 0 and w.shape[0] % 256 == 0 and Bn * R > 256 and (window is None or R >= 256 or Bn == 1)
+            and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0)
+
+
+def linear_fused(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, epi: "_lib.GemmEpi",
+                 window: Optional[tuple] = None) -> torch.Tensor:
+    """out [B * R, N] (flat rows, contiguous) = epilogue(x[:, r0:r0 + R] @ w^T + bias) on the 256 x 256-tile kernel with one of the
+    fused epilogues of include/mirror_hip.h (mh_gemm_epi).  window = (r0, R) or None (all T rows).  The row windows of all batches
+    are ONE flat problem (mh_gemm_desc.a_rows_per_batch): no ragged tile per slide, no tail launch."""
+    _chk(x, w, out, bias)
+    Bn, T, Kd = x.shape
+    r0, R = (0, T) if window is None else window
+    N = w.shape[0]
+    if not out.is_contiguous() or out.numel() != Bn * R * N:
+        raise MirrorHipError("linear_fused: out must be contiguous [B * R, N]")
+    d = GemmDesc()
+    d.A, d.B, d.C, d.bias = x.data_ptr() + r0 * Kd * 2, w.data_ptr(), out.data_ptr(), _p(bias)
+    d.M, d.N, d.K = Bn * R, N, Kd
+    d.lda, d.ldb, d.ldc = Kd, Kd, N
+    d.a_kc, d.b_kc = 1, 1
+    d.dtA, d.dtB, d.dtC, d.mma = MH_BF16, MH_BF16, dt(out), MH_BF16
+    d.batch1 = d.batch2 = 1
+    d.alpha, d.split_k = 1.0, 1
+    if R != T and Bn > 1:
+        d.a_rows_per_batch, d.a_row_skip = R, T - R
+    d.epi = C.pointer(epi)
+    prof = gemm_profiler
+    if prof is None:
+        _lib.call("mh_gemm", C.byref(d), stream=_stream())
+    else:
+        tc = "float" if out.dtype == torch.float32 else "bf16"
+        prof.launch_named(f"gemm_big_kernel<{tc},true,true,epi{epi.kind}>", 2.0 * d.M * d.N * d.K,
+                          lambda: _lib.call("mh_gemm", C.byref(d), stream=_stream()))
+    return out
+
+
+def epi_dropadd(resid: torch.Tensor, p: float, seed: int, offset: int, dev_base) -> "_lib.GemmEpi":
+    _chk(resid)
+    e = _lib.GemmEpi()
+    e.kind, e.resid, e.p, e.seed, e.offset, e.dev_base = EPI_DROPADD, resid.data_ptr(), float(p), int(seed), int(offset), _p(dev_base)
+    return e
+
+
+def epi_maskpos(mask: torch.Tensor, token: torch.Tensor, pos: torch.Tensor, rows_per_batch: int, first: int) -> "_lib.GemmEpi":
+    _chk(mask, token, pos)
+    e = _lib.GemmEpi()
+    e.kind, e.mask, e.token, e.pos, e.rows_per_batch, e.first = EPI_MASKPOS, mask.data_ptr(), token.data_ptr(), pos.data_ptr(), int(rows_per_batch), int(first)
+    return e
+
+
+def epi_sqerr(mask: torch.Tensor, tgt: torch.Tensor, tgt_bs: int, sq: torch.Tensor, rows_per_batch: int) -> "_lib.GemmEpi":
+    _chk(mask, tgt, sq)
+    e = _lib.GemmEpi()
+    e.kind, e.mask, e.tgt, e.tgt_bs, e.sq, e.rows_per_batch = EPI_SQERR, mask.data_ptr(), tgt.data_ptr(), int(tgt_bs), sq.data_ptr(), int(rows_per_batch)
+    return e
+
+
 def gemm_softmax_ok(M: int, N: int, Kd: int, dta=torch.bfloat16, dtb=torch.bfloat16) -> bool:
     """Shapes whose row softmax the 192 x 384 tile kernel computes in its epilogue (a whole row of length N = 384 in one tile)."""
     return (M % 192 == 0 and N == 384 and Kd % 8 == 0 and dta == torch.bfloat16 and dtb == torch.bfloat16
@@ -383,6 +452,15 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, batches, rpb, D, x_bs, y_bs, ep
     _chk(x, gamma, beta, y, mean, rstd)
     _lib.call("mh_layernorm_fwd", _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), batches, rpb, D, x_bs, y_bs,
               eps, dt(x), dt(y), stream=_stream())
+
+
+def layernorm_fwd_dual(x, gamma, beta, y, y16, mean, rstd, batches, rpb, D, x_bs, y_bs, eps):
+    """layernorm_fwd (f32 in, f32 out) that also writes the bf16 copy y16 (same row addressing as y)."""
+    _chk(x, gamma, beta, y, y16, mean, rstd)
+    if not (x.dtype == torch.float32 and y.dtype == torch.float32 and y16.dtype == torch.bfloat16):
+        raise MirrorHipError("layernorm_fwd_dual: f32 input, f32 + bf16 outputs")
+    _lib.call("mh_layernorm_fwd_dual", _p(x), _p(gamma), _p(beta), _p(y), _p(y16), _p(mean), _p(rstd), batches, rpb, D, x_bs, y_bs,
+              eps, stream=_stream())
 
 
 def layernorm_fwd_q8(x, gamma, beta, y, mean, rstd, batches, rpb, D, x_bs, y_bs, eps, q8, ring, tick, margin: float = 1.25):

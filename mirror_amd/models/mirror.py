@@ -206,8 +206,9 @@ class TransLayer(nn.Module):
         qkv = Fn.linear(xp, a.to_qkv.weight, None, prec=prec, defer_from=2 * a.to_qkv.weight.shape[1])
         core = Fn.NystromCoreFn.apply(qkv, a.res_conv.weight, a.heads, l, a.pinv_iterations, prec, kmask,
                                       Fn.fp8_site_key(a.to_out[0].weight, prec) if prec.fp8_fwd else None)
-        y = Fn.LinearRowsFn.apply(core, a.to_out[0].weight, a.to_out[0].bias, pad, n, prec, prec.act)
-        return Fn.dropout_add(x, y, a.drop, self.training)           # x feeds exactly self.norm and this add
+        # to_out(...)[:, -n:], its Dropout and the residual add: one launch when the shapes allow (Fn.to_out_dropout_add).
+        # x feeds exactly self.norm and this add
+        return Fn.to_out_dropout_add(x, core, a.to_out[0].weight, a.to_out[0].bias, pad, n, a.drop, self.training, prec)
 
 
 class PPEG(nn.Module):
@@ -257,7 +258,9 @@ class FeatureTransMIL(nn.Module):
         seq = self.pos_layer(seq, side, side)
         seq = self.layer2(seq, prec, smask)
         rows = seq.shape[1] - add if keep_rows is None else keep_rows
-        return Fn.layer_norm(seq, self.norm.weight, self.norm.bias, self.norm.eps, rows=rows, out_dtype=f32)
+        # the pre-training encoder output also feeds the retention decoder's bf16 projection: the norm writes that copy itself
+        return Fn.layer_norm(seq, self.norm.weight, self.norm.bias, self.norm.eps, rows=rows, out_dtype=f32,
+                             bf16_copy=(keep_rows is None and prec.act == torch.bfloat16 and torch.is_grad_enabled()))
 
     def forward(self, h):
         return self._encode(h, keep_rows=1)[:, 0]
@@ -397,10 +400,11 @@ class FeatureTransMILHybrid(FeatureTransMIL):
         if h.shape[1] != self.num_tokens + 1:
             raise ValueError(f"wsi_num_tokens={self.num_tokens} but the batch has {h.shape[1] - 1} tokens")
         # activation dtype out (what autocast gives the reference); MaskApplyFn restarts the f32 residual stream
-        r = Fn.linear(h, self.retention_embed.weight, self.retention_embed.bias, prec=prec)
         if mask is None:
-            mask = self._draw_mask(r[:, 1:], mask_ratio, noise)
-        r = Fn.MaskApplyFn.apply(r, mask, self.mask_token, self.retention_gene_embed, 1, False)
+            mask = self._draw_mask(h[:, 1:], mask_ratio, noise)
+        # retention_embed, the mask-token select and `+ retention_gene_embed` (models/mirror.py:690-693): one launch when possible
+        r = Fn.embed_mask_pos(h, self.retention_embed.weight, self.retention_embed.bias, mask, self.mask_token,
+                              self.retention_gene_embed, 1, prec)
         kp = None
         if key_padding_mask is not None:
             kpm = key_padding_mask.to(h.device, torch.bool)

@@ -1,0 +1,100 @@
+"""GPU: the fused projection epilogues (mh_gemm_epi, include/mirror_hip.h) against the composed ops they replace.
+
+Each fused launch must be BIT-IDENTICAL to the composed HIP path — the Linear's result is rounded to bf16 in the epilogue exactly
+where the composed path stores it as bf16, and the dropout mask is the one mh_dropout draws for the same (seed, offset, element)
+— and the composed path is what the oracle parity tests (test_model_gpu.py, test_bench_path_gpu.py) pin.  Shapes cover a ragged
+last row tile, row windows that cross batch boundaries inside a tile, and both weight layouts the step uses.
+Reference: [3P] to_out + Dropout + the residual add (models/mirror.py:312-313); retention_embed + random_masking + the
+position embedding (:636-643, :690-693); retention_head + the masked MSE (losses/mirror_loss.py:98-103)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+bf16, f32 = torch.bfloat16, torch.float32
+
+
+def _w(n, k, seed):
+    g = torch.Generator().manual_seed(seed)
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).cuda().requires_grad_(True)
+    b = (torch.randn(n, generator=g) * 0.1).cuda().requires_grad_(True)
+    return w, b
+
+
+@pytest.mark.parametrize("Bn,T,r0,R,Kd,N", [(3, 600, 88, 512, 512, 512), (2, 700, 1, 699, 256, 256), (4, 300, 0, 300, 512, 256)])
+def test_to_out_dropout_residual_epilogue_equals_composed(Bn, T, r0, R, Kd, N):
+    from mirror_amd import functional as Fn
+    prec = Fn.POLICIES["bf16"]
+    g = torch.Generator().manual_seed(1)
+    core0 = torch.randn(Bn, T, Kd, generator=g).cuda().to(bf16)
+    resid0 = torch.randn(Bn, R, N, generator=g).cuda()
+    up = torch.randn(Bn, R, N, generator=g).cuda()
+    w, b = _w(N, Kd, 2)
+    res = []
+    for fused in (True, False):
+        Fn.manual_seed(77)
+        Fn._dropout_state["offset"] = 4096          # a non-zero call offset
+        core, resid = core0.clone().requires_grad_(True), resid0.clone().requires_grad_(True)
+        w.grad = b.grad = None
+        Fn._res_grads.clear()
+        if fused:
+            assert Fn.K.linear_fused_ok(core, Fn.shadow(w, prec), (r0, R))
+            y = Fn.ToOutDropAddFn.apply(resid, core, w, b, r0, R, 0.1, prec)
+        else:
+            y = Fn.dropout_add(resid, Fn.LinearRowsFn.apply(core, w, b, r0, R, prec, bf16), 0.1, True)
+        y.backward(up)
+        res.append((y.detach().clone(), core.grad.clone(), resid.grad.clone(), w.grad.clone(), b.grad.clone(), Fn._dropout_state["offset"]))
+    torch.cuda.synchronize()
+    (y1, dc1, dr1, dw1, db1, o1), (y2, dc2, dr2, dw2, db2, o2) = res
+    assert o1 == o2, "both forms consume the same dropout offsets"
+    assert torch.equal(y1, y2), float((y1 - y2).abs().max())
+    assert float((y1 == resid0).float().mean()) > 0.05, "dropout zeroes ~10 % of the projection"
+    assert torch.equal(dc1, dc2) and torch.equal(dr1, dr2) and torch.equal(db1, db2)
+    assert float((dw1 - dw2).abs().max()) <= 1e-5 * float(dw2.abs().max())        # split-K f32 sums: order may differ
+
+
+@pytest.mark.parametrize("Bn,T,Kd,N", [(3, 257, 512, 512), (2, 1025, 256, 256)])
+def test_retention_embed_mask_pos_epilogue_equals_composed(Bn, T, Kd, N):
+    from mirror_amd import functional as Fn
+    prec = Fn.POLICIES["bf16"]
+    g = torch.Generator().manual_seed(3)
+    h32 = torch.randn(Bn, T, Kd, generator=g).cuda()
+    mask = (torch.rand(Bn, T - 1, generator=g) < 0.75).float().cuda()
+    token = (torch.randn(1, 1, N, generator=g) * 0.02).cuda().requires_grad_(True)
+    pos = (torch.randn(1, T, N, generator=g) * 0.02).cuda().requires_grad_(True)
+    up = torch.randn(Bn, T, N, generator=g).cuda()
+    w, b = _w(N, Kd, 4)
+    res = []
+    for fused in (True, False):
+        h = h32.clone().requires_grad_(True)
+        for p in (w, b, token, pos):
+            p.grad = None
+        if fused:
+            h._bf16 = h32.to(bf16)
+            y = Fn.embed_mask_pos(h, w, b, mask, token, pos, 1, prec)
+            assert y.grad_fn.__class__.__name__.startswith("EmbedMaskPosFn")
+        else:
+            y = Fn.MaskApplyFn.apply(Fn.linear(h, w, b, prec=prec), mask, token, pos, 1, False)
+        y.backward(up)
+        res.append([y.detach().clone()] + [t.grad.clone() for t in (h, w, b, token, pos)])
+    torch.cuda.synchronize()
+    for i, (a, c) in enumerate(zip(*res)):
+        if i == 2:       # dW: split-K f32 sums
+            assert float((a - c).abs().max()) <= 1e-5 * float(c.abs().max())
+        else:
+            assert torch.equal(a, c), (i, float((a.float() - c.float()).abs().max()))
+
+
+def test_layernorm_dual_writes_the_bf16_copy():
+    from mirror_amd import functional as Fn
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 70, 512, generator=g).cuda().requires_grad_(True)
+    gm, bt = torch.randn(512, generator=g).cuda().requires_grad_(True), torch.randn(512, generator=g).cuda().requires_grad_(True)
+    y = Fn.layer_norm(x, gm, bt, 1e-5, rows=66, out_dtype=f32, bf16_copy=True)
+    y0 = Fn.layer_norm(x, gm, bt, 1e-5, rows=66, out_dtype=f32)
+    assert torch.equal(y, y0) and hasattr(y, "_bf16") and not hasattr(y0, "_bf16")
+    assert torch.equal(y._bf16, y0.to(bf16)) and not y._bf16.requires_grad
+    full, tgt, cls = Fn.enc_fanout(y)
+    assert full._bf16 is y._bf16
+    (full.sum() + 2 * tgt.sum() + 3 * cls.sum()).backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all()
