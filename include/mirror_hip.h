@@ -58,8 +58,9 @@ int mh_device_ok(void);
  *   MH_EPI_MASKPOS: C[f32] = (t >= first && mask[b, t - first] ? token : A W^T + bias) + pos[t]      retention_embed followed by
  *                   random_masking's mask-token select and `+ retention_gene_embed`, models/mirror.py:636-643, :691-693;
  *                   flat row r of C is (b, t) = (r / rows_per_batch, r % rows_per_batch).
- *   MH_EPI_SQERR:   C[bf16] = A W^T + bias as usual, and sq[0] += sum over rows with mask[b, t] != 0 of (C - tgt)^2,
- *                   sq[1] += D * (number of such rows)   (tgt f32 at tgt + b * tgt_bs + t * D + col; rows_per_batch % 256 == 0)
+ *   MH_EPI_SQERR:   C[bf16] = A W^T + bias as usual, and sq[0] += sum over rows with mask[b, t] != 0 of mean_D (C - tgt)^2,
+ *                   sq[1] += the number of such rows: mh_mse_masked_fwd's accumulator, filled by the projection that produces the
+ *                   prediction (tgt f32 at tgt + b * tgt_bs + t * D + col; rows_per_batch % 256 == 0)
  *                   retention_head + the masked MSE of MIRRORLoss.forward, losses/mirror_loss.py:98-103. */
 #define MH_EPI_NONE 0
 #define MH_EPI_DROPADD 1

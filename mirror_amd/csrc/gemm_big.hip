@@ -226,8 +226,9 @@ __device__ __forceinline__ void epilogue_big_t(const GemmArgs& g, bf16_t* C, f32
             float a = 0.f, n = 0.f;
 #pragma unroll
             for (int w = 0; w < NTB / 64; w++) { a += red[2 * w]; n += red[2 * w + 1]; }
-            atomicAdd(g.epi.sq, a);
-            atomicAdd(g.epi.sq + 1, n);
+            const float inv = 1.f / (float)g.N;          // mh_mse_masked_fwd's convention: row means over D, rows counted once
+            atomicAdd(g.epi.sq, a * inv);
+            atomicAdd(g.epi.sq + 1, n * inv);
         }
     }
 }

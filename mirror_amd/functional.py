@@ -559,6 +559,64 @@ def to_out_dropout_add(resid, core, w, b, r0: int, R: int, p: float, training: b
     return dropout_add(resid, y, p, training)
 
 
+class HeadSqErrFn(Function):
+    """pred = x[:, r0:r0+R] @ W^T + b (bf16) with the masked squared error against `tgt` accumulated by the same launch
+    (mh_gemm_epi SQERR): retention_head + the WSI retention MSE of MIRRORLoss.forward (models/mirror.py:698-699,
+    losses/mirror_loss.py:98-103).  The accumulator (mh_mse_masked_fwd's [sum of row means, masked rows]) rides on the
+    returned prediction as `pred._sq = (acc, tgt, mask)`; MaskedMSEFn / MirrorLossTermsFn use it instead of their forward
+    pass when they are handed the same target and mask.  The backward is LinearRowsFn's."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, r0, R, prec, tgt, mask, acc):
+        wa = shadow(w, prec)
+        Bn, T, Kd = x.shape
+        N = wa.shape[0]
+        y = torch.empty((Bn, R, N), device=x.device, dtype=bf16)
+        K.linear_fused(x, wa, None if b is None else b.detach(), y,
+                       K.epi_sqerr(mask, tgt, tgt.stride(0), acc, R), window=(r0, R))
+        ctx.save_for_backward(x, wa, w, b)
+        ctx.r0, ctx.R, ctx.prec = r0, R, prec
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wa, w, b = ctx.saved_tensors
+        prec = ctx.prec
+        if not dy.is_contiguous():
+            dy = dy.contiguous()
+        if dy.dtype != prec.act:
+            dy = K.cast(dy, prec.act)
+        dx, dw, db = _linear_rows_bwd(ctx.needs_input_grad[0:3], x, wa, w, b, ctx.r0, ctx.R, prec, dy)
+        return dx, dw, db, None, None, None, None, None, None
+
+
+def head_sqerr(x, w, b, r0: int, R: int, prec: Precision, tgt, mask):
+    """LinearRowsFn(x, w, b, r0, R) whose launch also fills the masked-MSE accumulator against tgt [B, R, N] (f32 rows, possibly a
+    row window of a larger buffer) when the shapes are on the 256 x 256-tile kernel."""
+    N = w.shape[0]
+    if (tgt is not None and mask is not None and prec.act == bf16 and not prec.fp8_fwd and x.dtype == bf16 and tgt.dtype == f32
+            and tgt.dim() == 3 and tuple(tgt.shape) == (x.shape[0], R, N) and tgt.stride(2) == 1 and tgt.stride(1) == N
+            and mask.dtype == f32 and mask.is_contiguous() and tuple(mask.shape) == (x.shape[0], R) and R % 256 == 0
+            and torch.is_grad_enabled() and K.linear_fused_ok(x, shadow(w, prec), (r0, R))):
+        acc = zeros((2,), x.device)
+        y = HeadSqErrFn.apply(x, w, b, r0, R, prec, tgt, mask, acc)
+        y._sq = (acc, tgt, mask)
+        return y
+    return LinearRowsFn.apply(x, w, b, r0, R, prec, prec.act)
+
+
+def _sq_of(pred, tgt, mask):
+    """The accumulator a HeadSqErrFn launch left for exactly this (prediction, target, mask) triple, or None."""
+    sq = getattr(pred, "_sq", None)
+    if sq is None:
+        return None
+    acc, t0, m0 = sq
+    if (t0.data_ptr() == tgt.data_ptr() and tuple(t0.shape) == tuple(tgt.shape) and t0.stride() == tgt.stride()
+            and m0.data_ptr() == mask.data_ptr() and tuple(m0.shape) == tuple(mask.shape)):
+        return acc
+    return None
+
+
 class EmbedMaskPosFn(Function):
     """(mask ? mask_token : h @ W^T + b) + pos -> f32 residual stream in ONE launch: retention_embed, random_masking's token select
     and `+ retention_gene_embed` (models/mirror.py:636-643, :691-693) as the projection's epilogue (mh_gemm_epi MASKPOS).
@@ -1512,10 +1570,12 @@ class MaskedMSEFn(Function):
         pred = pred.contiguous()
         if not (tgt.is_contiguous() or (tgt.dim() == 3 and tgt.stride(2) == 1 and tgt.stride(1) == D)):
             tgt = tgt.contiguous()
+        acc = _sq_of(pred, tgt, mask)        # filled by the projection that produced pred (HeadSqErrFn)
         mask = mask.contiguous().float()
         rows = pred.numel() // D
-        acc = zeros((2,), pred.device)
-        K.mse_masked_fwd(pred, tgt, mask, acc, rows, D)
+        if acc is None:
+            acc = zeros((2,), pred.device)
+            K.mse_masked_fwd(pred, tgt, mask, acc, rows, D)
         ctx.save_for_backward(pred, tgt, mask, acc)
         ctx.D, ctx.tok = D, tok
         return _div(acc)
@@ -1629,12 +1689,14 @@ class MirrorLossTermsFn(Function):
     def forward(ctx, weights, wa, ra, scale, align_ext, wpred, wtgt, wmask, Dw, tok, rp, rt, rm, wmu, wls, rmu, rls, wsc, rsc):
         ctx.set_materialize_grads(False)
         dev = rp.device
+        acc = _sq_of(wpred, wtgt, wmask)     # filled by the projection that produced wpred (HeadSqErrFn)
         wpred = wpred.contiguous()
         if not (wtgt.is_contiguous() or (wtgt.dim() == 3 and wtgt.stride(2) == 1 and wtgt.stride(1) == Dw)):
             wtgt = wtgt.contiguous()
         wmask = wmask.contiguous().float()
-        acc = zeros((2,), dev)
-        K.mse_masked_fwd(wpred, wtgt, wmask, acc, wpred.numel() // Dw, Dw)
+        if acc is None:
+            acc = zeros((2,), dev)
+            K.mse_masked_fwd(wpred, wtgt, wmask, acc, wpred.numel() // Dw, Dw)
         local = wa is not None
         t = dict(rna_pred=rp.contiguous(), rna_tgt=rt.contiguous(), rna_mask=rm.contiguous().float(), w_mu=wmu.contiguous(),
                  w_logstd=wls.contiguous(), r_mu=rmu.contiguous(), r_logstd=rls.contiguous(), w_score=wsc.contiguous(),

@@ -393,7 +393,8 @@ class FeatureTransMILHybrid(FeatureTransMIL):
         return Fn.MaskApplyFn.apply(h, mask, self.mask_token, zero_pos, 0, False), mask
 
     def forward_retention_head(self, h, mask_ratio: float, noise: Optional[torch.Tensor] = None,
-                               mask: Optional[torch.Tensor] = None, key_padding_mask: Optional[torch.Tensor] = None):
+                               mask: Optional[torch.Tensor] = None, key_padding_mask: Optional[torch.Tensor] = None,
+                               target: Optional[torch.Tensor] = None):
         """`mask`: a mask already drawn for this batch (MIRROR.forward ranks the noise on a side stream up front).
         `key_padding_mask` [B, N] bool: attention mask of the decoder layers (config 4; cls is always attended)."""
         prec = resolve_precision(self.precision)
@@ -413,8 +414,9 @@ class FeatureTransMILHybrid(FeatureTransMIL):
             r = blk(r, prec, kp)
         r = Fn.layer_norm(r, self.retention_norm.weight, self.retention_norm.bias, self.retention_norm.eps,
                           out_dtype=prec.act)
-        # retention_head(...)[:, 1:]: the cls row is sliced away, so it is never computed
-        r = Fn.LinearRowsFn.apply(r, self.retention_head.weight, self.retention_head.bias, 1, r.shape[1] - 1, prec, prec.act)
+        # retention_head(...)[:, 1:]: the cls row is sliced away, so it is never computed.  When the caller names the retention
+        # target (MIRROR.forward does), the same launch accumulates the masked squared error MIRRORLoss needs (Fn.head_sqerr)
+        r = Fn.head_sqerr(r, self.retention_head.weight, self.retention_head.bias, 1, r.shape[1] - 1, prec, target, mask)
         return r, mask
 
     def forward_decoders(self, h, mask_ratio: float, noise: Optional[torch.Tensor] = None):
@@ -591,7 +593,8 @@ class MIRROR(nn.Module):
         main.wait_event(mask_ready)
         wsi_mask.record_stream(main)
         wsi_retention_emb, wsi_mask = self.wsi_encoder.forward_retention_head(
-            wsi_full, mask_ratio=wsi_mask_ratio, mask=wsi_mask, key_padding_mask=wsi_key_padding_mask)
+            wsi_full, mask_ratio=wsi_mask_ratio, mask=wsi_mask, key_padding_mask=wsi_key_padding_mask,
+            target=wsi_retention_target if self.training else None)
         main.wait_stream(side)
         for t in (rna_emb, rna_alignment_emb, rna_retention_emb, rna_mask, wsi_alignment_emb, wsi_score, wsi_mu, wsi_logstd,
                   rna_score, rna_mu, rna_logstd):

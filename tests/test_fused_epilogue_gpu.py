@@ -98,3 +98,83 @@ def test_layernorm_dual_writes_the_bf16_copy():
     assert full._bf16 is y._bf16
     (full.sum() + 2 * tgt.sum() + 3 * cls.sum()).backward()
     assert x.grad is not None and torch.isfinite(x.grad).all()
+
+
+@pytest.mark.parametrize("Bn,T,Kd,N", [(3, 513, 512, 512), (2, 257, 256, 768)])
+def test_retention_head_squared_error_epilogue_equals_mse_kernel(Bn, T, Kd, N):
+    """HeadSqErrFn: the prediction is LinearRowsFn's bit for bit, the accumulator is mh_mse_masked_fwd's up to f32 summation order,
+    and both loss Functions pick it up only for the very (target, mask) it was computed against."""
+    from mirror_amd import functional as Fn
+    prec = Fn.POLICIES["bf16"]
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(Bn, T, Kd, generator=g).cuda().to(bf16).requires_grad_(True)
+    E = torch.randn(Bn, T, N, generator=g).cuda()
+    tgt = E[:, 1:]
+    mask = (torch.rand(Bn, T - 1, generator=g) < 0.75).float().cuda()
+    w, b = _w(N, Kd, 7)
+    y = Fn.head_sqerr(x, w, b, 1, T - 1, prec, tgt, mask)
+    assert hasattr(y, "_sq"), "the fused path was not taken"
+    y0 = Fn.LinearRowsFn.apply(x, w, b, 1, T - 1, prec, bf16)
+    assert torch.equal(y, y0)
+    acc0 = torch.zeros(2, device="cuda")
+    Fn.K.mse_masked_fwd(y0.detach(), tgt, mask, acc0, Bn * (T - 1), N)
+    acc = y._sq[0]
+    torch.cuda.synchronize()
+    assert abs(float(acc[1]) - float(acc0[1])) <= 1e-3 and float(acc0[1]) == float(mask.sum())
+    assert abs(float(acc[0]) - float(acc0[0])) <= 2e-5 * float(acc0[0]), (float(acc[0]), float(acc0[0]))
+    assert Fn._sq_of(y, tgt, mask) is acc
+    assert Fn._sq_of(y, tgt.clone(), mask) is None and Fn._sq_of(y, tgt, mask.clone()) is None and Fn._sq_of(y0, tgt, mask) is None
+    loss = Fn.masked_mse(y, tgt, mask, N)
+    loss0 = Fn.masked_mse(y0, tgt, mask, N)
+    assert abs(float(loss) - float(loss0)) <= 2e-5 * float(loss0)
+    gx = torch.autograd.grad(loss, x, retain_graph=True)[0]
+    gx0 = torch.autograd.grad(loss0, x)[0]
+    assert float((gx.float() - gx0.float()).abs().max()) <= 1e-2 * float(gx0.float().abs().max())
+
+
+def test_whole_model_train_step_fused_epilogues_equal_composed():
+    """MIRROR forward + MIRRORLoss + backward in TRAIN mode (dropout on, bf16 policy) with the fused projection epilogues on and
+    off (mirror_amd.kernels._EPI_ON): same dropout masks, same losses up to f32 summation order, same gradients up to the
+    split-K / atomics order.  D = 512, 1024 tokens: every fused epilogue (DROPADD x 3 layers, MASKPOS, SQERR) is on its path."""
+    import mirror_amd.models as M
+    from mirror_amd import functional as Fn
+    from mirror_amd import kernels as K
+    from mirror_amd.losses import MIRRORLoss
+    cfg = dict(wsi_embed_dim=128, rna_embed_dim=96, embed_dim=512, wsi_num_tokens=1024, rna_encoder_depth=1, rna_num_heads=8,
+               rna_mlp_ratio=4.0, style_mlp_hidden_dim=128, style_mlp_out_dim=64, style_latent_dim=32, num_prototypes=300)
+    g = torch.Generator().manual_seed(8)
+    wsi = torch.randn(2, 1024, 128, generator=g).cuda().to(bf16)
+    rna = torch.randn(2, 96, generator=g).cuda()
+    noise = {"wsi_mask": torch.rand(2, 1024, generator=g).cuda(), "rna_mask": torch.rand(2, 512, generator=g).cuda(),
+             "wsi_eps": torch.randn(2, 32, generator=g).cuda(), "rna_eps": torch.randn(2, 32, generator=g).cuda()}
+    out = []
+    was = K._EPI_ON
+    try:
+        for on in (True, False):
+            K._EPI_ON = on
+            torch.manual_seed(0)
+            model = M.mirror(**cfg).cuda().train()
+            model.precision = "bf16"
+            Fn.manual_seed(99)
+            launched = []
+            orig = K.linear_fused
+            K.linear_fused = lambda *a, **k: (launched.append(a[4].kind), orig(*a, **k))[1]
+            try:
+                losses = MIRRORLoss()(*model(wsi, rna, noise=noise))
+                losses[0].backward()
+            finally:
+                K.linear_fused = orig
+            torch.cuda.synchronize()
+            assert sorted(launched) == ([1, 1, 1, 2, 3] if on else []), launched
+            out.append(([float(x) for x in losses], {k: p.grad.detach().clone() for k, p in model.named_parameters()}))
+    finally:
+        K._EPI_ON = was
+    (l1, g1), (l2, g2) = out
+    for a, c in zip(l1, l2):
+        assert abs(a - c) <= 1e-4 * max(abs(c), 1e-3), (l1, l2)
+    worst = 0.0
+    for k in g1:
+        d = float((g1[k] - g2[k]).norm()) / max(float(g2[k].norm()), 1e-12)
+        worst = max(worst, d)
+        assert d <= 2e-2, (k, d)          # bf16 activations turn a different f32 summation order into 1-ulp flips downstream
+    print("fused vs composed: losses", l1, l2, "worst relative gradient difference", worst)
