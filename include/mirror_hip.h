@@ -159,6 +159,18 @@ int mh_layernorm_bwd(const void* dy, const void* x, const float* gamma, const fl
                      int batches, int rows_per_batch, int D, int64_t x_bs, int64_t y_bs,
                      int dt_x, int dt_dy, int dt_dx, int accumulate_dx, float* workspace, int64_t ws_floats, mh_stream s);
 
+/* LayerNorm of a Nystrom layer that also leaves the landmark means of its output (models/mirror.py:298 + [3P] NystromAttention's
+ * front padding and `q_landmarks = reduce(q, '... (n l) d -> ... n d', 'sum') / l`): x f32 [batches, >= rows, D] (x_bs elements per
+ * batch) -> y bf16 [batches, pad + rows, D] (pad zero rows first, written here) and xpm bf16 [batches, (pad + rows) / l, D] =
+ * the mean of each group of l consecutive rows of y.  to_qkv is linear and bias-free, so the landmarks are to_qkv(xpm)[:, :2D].
+ * mh_layernorm_bwd_lm: mh_layernorm_bwd whose dy rows also receive gadd[b, (i + pad) / l] / l (gadd f32 = d loss / d xpm). */
+int mh_layernorm_fwd_lm(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, void* xpm,
+                        int batches, int rows, int D, int64_t x_bs, int pad, int l, float eps, mh_stream s);
+int mh_layernorm_bwd_lm(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                        void* dx, float* dgamma, float* dbeta, int batches, int rows_per_batch, int D, int64_t x_bs, int64_t y_bs,
+                        int dt_x, int dt_dy, int dt_dx, int accumulate_dx, float* workspace, int64_t ws_floats,
+                        const float* gadd, int pad, int l, mh_stream s);
+
 /* ---------------------------------------------------------------- fp8 forward projections (BASELINE config 5)
  * mh_quant_fp8: q[i] = e4m3(x[i] * 448 / max|x|) for a whole tensor (x f32 / bf16, n % 4 == 0), scale[0] = max|x| / 448
  *               (amax_scratch: one uint32 of device scratch).

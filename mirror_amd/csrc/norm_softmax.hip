@@ -155,6 +155,95 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const TX* __rest
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
+// LayerNorm forward of a Nystrom layer (models/mirror.py:298 + the front zero padding of [3P] NystromAttention) that ALSO
+// leaves the landmark means of its OUTPUT: xpm[b, g] = mean over the l consecutive padded positions g l .. g l + l - 1 of the
+// (bf16-rounded) normalised rows, zero rows for the pad.  to_qkv is linear and bias-free, so the package's landmarks
+// q_landmarks = reduce(q, '... (n l) d -> ... n d', 'sum') / l equal to_qkv(xpm)[:, :2D]: a [B m, D] x [D, 2D] product instead of
+// a pass over the [B, n_p, 2D] q | k columns, and in the backward the landmark gradient reaches the rows through this
+// LayerNorm's backward (mh_layernorm_bwd gadd) instead of a read-modify-write of dqkv.
+// One wave per (batch, group): its l rows in chunks of LMU rows in flight; pad rows are written as zeros here.
+#define LMU 4
+template <int LNV_CH>
+__global__ __launch_bounds__(256) void layernorm_fwd_lm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                               float* __restrict__ mean, float* __restrict__ rstd,
+                                                               bf16_t* __restrict__ xpm, int groups, int m, int rows, int D, long x_bs,
+                                                               int pad, int l, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int grp = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (grp >= groups) return;
+    const int b = grp / m, g = grp - b * m;
+    const long n_p = (long)pad + rows;
+    f4 gm[LNV_CH], bt[LNV_CH], acc[LNV_CH];
+#pragma unroll
+    for (int k = 0; k < LNV_CH; k++) {
+        const int c = 256 * k + 4 * lane;
+        acc[k] = (f4){0.f, 0.f, 0.f, 0.f};
+        gm[k] = c < D ? ld4(gamma + c) : acc[k];
+        bt[k] = c < D ? ld4(beta + c) : acc[k];
+    }
+    for (int j0 = g * l; j0 < (g + 1) * l; j0 += LMU) {
+        f4 v[LMU][LNV_CH];
+#pragma unroll
+        for (int u = 0; u < LMU; u++) {               // all loads of the chunk before any reduction
+            const int j = j0 + u;
+            const bool live = j < (g + 1) * l && j >= pad;
+            const float* xr = x + b * x_bs + (long)(live ? j - pad : 0) * D;
+#pragma unroll
+            for (int k = 0; k < LNV_CH; k++) {
+                const int c = 256 * k + 4 * lane;
+                v[u][k] = (live && c < D) ? ld4(xr + c) : (f4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < LMU; u++) {
+            const int j = j0 + u;
+            if (j >= (g + 1) * l) break;               // wave-uniform
+            bf16_t* yr = y + (b * n_p + j) * D;
+            if (j < pad) {                            // front padding: zero rows, no statistics
+#pragma unroll
+                for (int k = 0; k < LNV_CH; k++) {
+                    const int c = 256 * k + 4 * lane;
+                    if (c < D) st4(yr + c, (f4){0.f, 0.f, 0.f, 0.f});
+                }
+                continue;
+            }
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < LNV_CH; k++) s += v[u][k][0] + v[u][k][1] + v[u][k][2] + v[u][k][3];
+            const float mu = wave_sum(s) / D;
+            float q = 0.f;
+#pragma unroll
+            for (int k = 0; k < LNV_CH; k++) {
+                const int c = 256 * k + 4 * lane;
+                if (c < D) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { const float d = v[u][k][e] - mu; q += d * d; }
+                }
+            }
+            const float rs = rsqrtf(wave_sum(q) / D + eps);
+#pragma unroll
+            for (int k = 0; k < LNV_CH; k++) {
+                const int c = 256 * k + 4 * lane;
+                if (c < D) {
+                    f4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) o[e] = bf2f(f2bf((v[u][k][e] - mu) * rs * gm[k][e] + bt[k][e]));   // what the projection reads
+                    st4(yr + c, o);
+                    acc[k] += o;
+                }
+            }
+            if (lane == 0) { const long row = (long)b * rows + (j - pad); mean[row] = mu; rstd[row] = rs; }
+        }
+    }
+    const float inv = 1.f / (float)l;
+#pragma unroll
+    for (int k = 0; k < LNV_CH; k++) {
+        const int c = 256 * k + 4 * lane;
+        if (c < D) st4(xpm + ((long)b * m + g) * D + c, acc[k] * inv);
+    }
+}
+
 // LayerNorm forward that ALSO leaves an e4m3 copy of its output (BASELINE config 5: the fp8 forward of to_qkv reads it; the
 // bf16 copy is still needed by the weight gradient): delayed scaling exactly as mh_quant_fp8_delayed (ring of three per-site
 // maxima rotated by the device-side step counter), so the projection's input needs no quantisation pass of its own.
@@ -332,6 +421,22 @@ extern "C" int mh_layernorm_fwd(const void* x, const float* gamma, const float* 
     return MH_OK;
 }
 
+extern "C" int mh_layernorm_fwd_lm(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, void* xpm,
+                                   int batches, int rows, int D, int64_t x_bs, int pad, int l, float eps, mh_stream s) {
+    MH_REQUIRE(l >= 1 && pad >= 0 && rows >= 1 && (pad + rows) % l == 0, "mh_layernorm_fwd_lm: pad + rows = %d must be a multiple of l = %d", pad + rows, l);
+    MH_REQUIRE(D % 4 == 0 && D <= 2048 && x_bs % 4 == 0 && (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0 &&
+                   (((uintptr_t)y | (uintptr_t)xpm) & 7) == 0,
+               "mh_layernorm_fwd_lm: D %% 4 == 0, D <= 2048 and aligned buffers (D=%d)", D);
+    if (batches == 0) return MH_OK;
+    const int m = (pad + rows) / l, groups = batches * m;
+    dim3 grid(mh_cdiv(groups, 4));
+#define LNL(NC) hipLaunchKernelGGL((layernorm_fwd_lm_kernel<NC>), grid, dim3(256), 0, (hipStream_t)s, x, gamma, beta, (bf16_t*)y, mean, rstd, (bf16_t*)xpm, groups, m, rows, D, (long)x_bs, pad, l, eps)
+    if (D <= 512) LNL(2); else if (D <= 1024) LNL(4); else LNL(8);
+#undef LNL
+    MH_LAUNCH_CHECK("mh_layernorm_fwd_lm");
+    return MH_OK;
+}
+
 // f32 output + a bf16 copy with the same row addressing, one pass: the encoder's final norm feeds an f32 consumer (retention
 // target, cls row: models/mirror.py:699, :684) and a projection that takes bf16 operands (retention_embed, :690) — without the
 // copy the projection's input costs a separate 214 MB cast pass.
@@ -376,7 +481,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_ws_kernel(const TDY* __rest
                                                                const float* __restrict__ gamma, const float* __restrict__ mean,
                                                                const float* __restrict__ rstd, TX* __restrict__ dx,
                                                                float* __restrict__ ws, int rows, int rpb, int D, long x_bs,
-                                                               long y_bs, int acc_dx, int rows_per_block) {
+                                                               long y_bs, int acc_dx, int rows_per_block,
+                                                               const float* __restrict__ gadd = nullptr, int ga_pad = 0, int ga_l = 1,
+                                                               int ga_m = 0, float ga_scale = 0.f) {
+    // gadd [batches, ga_m, D] f32: dy of row i of batch b is dy + ga_scale * gadd[b, (i + ga_pad) / ga_l] (the gradient of the
+    // landmark means mh_layernorm_fwd_lm produced beside the rows)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f4 pg[LNV_CH], pb[LNV_CH], gm[LNV_CH];
 #pragma unroll
@@ -409,6 +518,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_ws_kernel(const TDY* __rest
                     dv[u][k] = ld4(dyr + c);
                     xv[u][k] = ld4(x + xo[u] + c);
                     if (acc_dx) ov[u][k] = ld4(dx + xo[u] + c);
+                    if (gadd) dv[u][k] += ld4(gadd + ((long)b * ga_m + (i + ga_pad) / ga_l) * D + c) * ga_scale;
                 }
             }
         }
@@ -488,10 +598,34 @@ extern "C" int64_t mh_layernorm_bwd_workspace_bytes(int64_t rows, int D) {
     return 2 * (int64_t)D * nb * 4;
 }
 
+static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                       void* dx, float* dgamma, float* dbeta, int batches, int rpb, int D, int64_t x_bs,
+                       int64_t y_bs, int dt_x, int dt_dy, int dt_dx, int acc_dx, float* workspace, int64_t ws_floats,
+                       const float* gadd, int ga_pad, int ga_l, mh_stream s);
+
 extern "C" int mh_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                 void* dx, float* dgamma, float* dbeta, int batches, int rpb, int D, int64_t x_bs,
                                 int64_t y_bs, int dt_x, int dt_dy, int dt_dx, int acc_dx, float* workspace, int64_t ws_floats,
                                 mh_stream s) {
+    return ln_bwd_impl(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, batches, rpb, D, x_bs, y_bs, dt_x, dt_dy, dt_dx, acc_dx, workspace,
+                       ws_floats, nullptr, 0, 1, s);
+}
+
+// the backward of mh_layernorm_fwd_lm: dy of row i of batch b is dy[b, i] + gadd[b, (i + pad) / l] / l, gadd [batches, (pad + rpb) / l, D]
+// f32 = the gradient of the landmark means (needs the workspace form: D % 4 == 0, aligned buffers, a workspace)
+extern "C" int mh_layernorm_bwd_lm(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                   void* dx, float* dgamma, float* dbeta, int batches, int rpb, int D, int64_t x_bs,
+                                   int64_t y_bs, int dt_x, int dt_dy, int dt_dx, int acc_dx, float* workspace, int64_t ws_floats,
+                                   const float* gadd, int pad, int l, mh_stream s) {
+    MH_REQUIRE(gadd && l >= 1 && pad >= 0 && (pad + rpb) % l == 0 && ((uintptr_t)gadd & 15) == 0, "mh_layernorm_bwd_lm: gadd, l >= 1, (pad + rows) %% l == 0");
+    return ln_bwd_impl(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, batches, rpb, D, x_bs, y_bs, dt_x, dt_dy, dt_dx, acc_dx, workspace,
+                       ws_floats, gadd, pad, l, s);
+}
+
+static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                       void* dx, float* dgamma, float* dbeta, int batches, int rpb, int D, int64_t x_bs,
+                       int64_t y_bs, int dt_x, int dt_dy, int dt_dx, int acc_dx, float* workspace, int64_t ws_floats,
+                       const float* gadd, int ga_pad, int ga_l, mh_stream s) {
     MH_REQUIRE(D >= 1 && D <= 64 * LN_MAXPL, "mh_layernorm_bwd: D=%d unsupported", D);
     MH_REQUIRE(dt_dx == dt_x, "mh_layernorm_bwd: dx dtype must equal x dtype");
     const long rows = (long)batches * rpb;
@@ -509,7 +643,7 @@ extern "C" int mh_layernorm_bwd(const void* dy, const void* x, const float* gamm
         const int rows_per_block = (int)(mh_cdiv(mh_cdiv(rows, nb), 8) * 8);
         nb = mh_cdiv(rows, rows_per_block);
         dim3 g2((unsigned)nb);
-#define LN_BW1(TX, TDY, NC) hipLaunchKernelGGL((layernorm_bwd_ws_kernel<TX, TDY, NC>), g2, dim3(256), 0, (hipStream_t)s, (const TDY*)dy, (const TX*)x, gamma, mean, rstd, (TX*)dx, workspace, (int)rows, rpb, D, (long)x_bs, (long)y_bs, acc_dx, rows_per_block)
+#define LN_BW1(TX, TDY, NC) hipLaunchKernelGGL((layernorm_bwd_ws_kernel<TX, TDY, NC>), g2, dim3(256), 0, (hipStream_t)s, (const TDY*)dy, (const TX*)x, gamma, mean, rstd, (TX*)dx, workspace, (int)rows, rpb, D, (long)x_bs, (long)y_bs, acc_dx, rows_per_block, gadd, ga_pad, ga_l, (ga_pad + rpb) / ga_l, 1.f / (float)ga_l)
 #define LN_BW(TX, TDY) do { if (D <= 512) LN_BW1(TX, TDY, 2); else if (D <= 1024) LN_BW1(TX, TDY, 4); else LN_BW1(TX, TDY, 8); } while (0)
         if (dt_x == MH_F32 && dt_dy == MH_F32) LN_BW(float, float);
         else if (dt_x == MH_F32 && dt_dy == MH_BF16) LN_BW(float, bf16_t);
@@ -522,6 +656,7 @@ extern "C" int mh_layernorm_bwd(const void* dy, const void* x, const float* gamm
         MH_LAUNCH_CHECK("mh_layernorm_bwd");
         return MH_OK;
     }
+    MH_REQUIRE(!gadd, "mh_layernorm_bwd_lm: needs the workspace form (D %% 4 == 0, 16-byte aligned buffers, a workspace of >= 2 D floats, >= 64 rows)");
     if (vecok) {
         if (dt_x == MH_F32 && dt_dy == MH_F32) LN_BV(float, float);
         else if (dt_x == MH_F32 && dt_dy == MH_BF16) LN_BV(float, bf16_t);

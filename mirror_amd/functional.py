@@ -729,6 +729,91 @@ class LayerNormFn(Function):
         return dx, _gret(gamma, dg, sunk_g), _gret(beta, db, sunk_b), None, None, None, None, None, None
 
 
+class LayerNormLmFn(Function):
+    """LayerNormFn for a Nystrom layer that also returns the landmark means of its output (mh_layernorm_fwd_lm): (xp bf16
+    [B, pad + rows, D] behind `pad` zero rows, xpm bf16 [B, m, D] = the mean of each group of l consecutive rows of xp).
+    [3P] NystromAttention's landmarks are means over l consecutive positions of q and k; to_qkv is linear and bias-free, so they
+    are to_qkv(xpm)[:, :2D] (LandmarkProjFn) — no pass over the q | k columns, and in the backward the landmark gradient reaches
+    the rows through THIS node (mh_layernorm_bwd_lm) instead of a read-modify-write of dqkv."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, rows, pad, l):
+        x = x.contiguous()
+        Bn, T, D = x.shape
+        n_p = pad + rows
+        y = torch.empty((Bn, n_p, D), device=x.device, dtype=bf16)
+        xpm = torch.empty((Bn, n_p // l, D), device=x.device, dtype=bf16)
+        mean = torch.empty((Bn * rows,), device=x.device, dtype=f32)
+        rstd = torch.empty_like(mean)
+        K.layernorm_fwd_lm(x, gamma.detach(), beta.detach(), y, mean, rstd, xpm, Bn, rows, D, T * D, pad, l, eps)
+        ctx.save_for_backward(x, gamma, mean, rstd, beta)
+        ctx.rows, ctx.pad, ctx.l = rows, pad, l
+        return y, xpm
+
+    @staticmethod
+    def backward(ctx, dy, dxpm):
+        x, gamma, mean, rstd, beta = ctx.saved_tensors
+        Bn, T, D = x.shape
+        rows, pad, l = ctx.rows, ctx.pad, ctx.l
+        if not dy.is_contiguous():
+            dy = dy.contiguous()
+        if dxpm is not None:
+            dxpm = dxpm.contiguous()
+            if dxpm.dtype != f32:
+                dxpm = K.cast(dxpm, f32)
+        dg, sunk_g = _gbuf(gamma, (D,))
+        db, sunk_b = _gbuf(beta, (D,))
+        G = _res_grads.pop(x.data_ptr(), None)
+        if G is not None and G.numel() == x.numel() and G.dtype == x.dtype and G.is_contiguous():
+            K.layernorm_bwd(dy[:, pad:], x, gamma.detach(), mean, rstd, G.view(x.shape), dg, db, Bn, rows, D, T * D, (pad + rows) * D,
+                            accumulate_dx=True, gadd=dxpm, pad=pad, l=l)
+            return None, _gret(gamma, dg, sunk_g), _gret(beta, db, sunk_b), None, None, None, None
+        dx = torch.zeros_like(x) if rows < T else torch.empty_like(x)
+        K.layernorm_bwd(dy[:, pad:], x, gamma.detach(), mean, rstd, dx, dg, db, Bn, rows, D, T * D, (pad + rows) * D, gadd=dxpm, pad=pad, l=l)
+        return dx, _gret(gamma, dg, sunk_g), _gret(beta, db, sunk_b), None, None, None, None
+
+
+class LandmarkProjFn(Function):
+    """lm [B, m, 2D] = xpm @ W[:2D]^T: the q | k landmarks of [3P] NystromAttention from the landmark means of the LayerNorm output
+    (LayerNormLmFn); W is to_qkv.weight [3D, D] (rows 0..2D-1 = the q and k projections).  A [B m, D] x [D, 2D] product."""
+
+    @staticmethod
+    def forward(ctx, xpm, w, prec):
+        wa = shadow(w, prec)
+        n2 = 2 * wa.shape[1]
+        lm = K.gemm(xpm, wa[:n2].t(), mma=prec.mma, out_dtype=prec.act)
+        ctx.save_for_backward(xpm, wa, w)
+        ctx.prec, ctx.n2 = prec, n2
+        return lm
+
+    @staticmethod
+    def backward(ctx, dlm):
+        xpm, wa, w = ctx.saved_tensors
+        prec, n2 = ctx.prec, ctx.n2
+        dlm = dlm.contiguous()
+        if dlm.dtype != prec.act:
+            dlm = K.cast(dlm, prec.act)
+        Dm = wa.shape[1]
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = K.gemm(dlm, wa[:n2], mma=prec.mma, out_dtype=f32)          # f32: mh_layernorm_bwd_lm's addend
+        if ctx.needs_input_grad[1]:
+            full, sunk = _gbuf(w, tuple(wa.shape))
+            rows = dlm.numel() // n2
+            K.gemm(dlm.reshape(rows, n2).t(), xpm.reshape(rows, Dm), out=full[:n2], accumulate=True,
+                   split_k=_split_k_for(rows, n2, Dm), mma=prec.mma)
+            dw = _gret(w, full, sunk)
+        return dx, dw, None
+
+
+_LM_ALGEBRA = os.environ.get("MIRROR_LM_ALGEBRA", "1") != "0"     # A/B switch: landmarks from the LayerNorm's group means
+
+
+def layer_norm_landmarks_ok(x, rows: int, pad: int, l: int, prec: Precision) -> bool:
+    return (_LM_ALGEBRA and prec.act == bf16 and not prec.fp8_fwd and x.dim() == 3 and x.dtype == f32 and x.shape[-1] % 4 == 0
+            and x.shape[-1] <= 2048 and (pad + rows) % l == 0 and x.shape[0] * rows >= 64)
+
+
 _LN_Q8 = os.environ.get("MIRROR_LN_Q8", "1") != "0"      # A/B switch: LayerNorm writes the e4m3 copy of its output (fp8 policy)
 
 
@@ -1104,8 +1189,10 @@ class NystromCoreFn(Function):
     (a1 @ a2inv) @ (a3 @ v), 2 m^2 D instead of 2 n_p m^2 h flops)."""
 
     @staticmethod
-    def forward(ctx, qkv, res_w, heads, l, iters, prec, kmask=None, q8_key=None):
-        """kmask: None, or the package's key-padding mask prepared by TransLayer as (rows [B, n_p], landmarks [B, m],
+    def forward(ctx, qkv, res_w, heads, l, iters, prec, kmask=None, q8_key=None, lm_ext=None):
+        """lm_ext: the q | k landmarks [B, m, 2D] computed by the caller (LandmarkProjFn on the LayerNorm's group means); their
+        gradient is returned instead of being scattered into dqkv.
+        kmask: None, or the package's key-padding mask prepared by TransLayer as (rows [B, n_p], landmarks [B, m],
         landmark scale [B, m]) float tensors: rows of qkv that are masked out are already zero (the caller zeroes the
         LayerNorm output in front of the bias-free to_qkv); here the landmark means become masked means and the three
         similarity matrices are masked_fill'ed before their softmax."""
@@ -1116,7 +1203,8 @@ class NystromCoreFn(Function):
         A, mma, pm = prec.act, prec.mma, prec.pinv_mma
         scale = dh ** -0.5
         q, k, v = (_heads(qkv, i, 3, h) for i in range(3))
-        lm = K.landmark_fwd(qkv, l)
+        lm = lm_ext.contiguous() if lm_ext is not None else K.landmark_fwd(qkv, l)
+        ctx.lm_ext = lm_ext is not None
         if kmask is not None:
             mrow, mlm, lscale = kmask
             lm = K.row_scale(lm, lscale)                       # sum over the group / (valid count + 1e-8)
@@ -1289,9 +1377,11 @@ class NystromCoreFn(Function):
         K.gemm(dS2, kl, out=dql, alpha=scale, accumulate=True, mma=pio)
         if kmask is not None:
             dlm = K.row_scale(dlm, lscale)
-        K.landmark_bwd(K.cast(dlm, A), dqkv, l)
         dres = _gret(res_w, dres, dres_sunk)
-        return dqkv, (None if dres is None else dres.view_as(res_w)), None, None, None, None, None, None
+        if ctx.lm_ext:         # the landmarks came from the caller: their gradient goes back to it (no scatter into dqkv)
+            return dqkv, (None if dres is None else dres.view_as(res_w)), None, None, None, None, None, None, dlm
+        K.landmark_bwd(K.cast(dlm, A), dqkv, l)
+        return dqkv, (None if dres is None else dres.view_as(res_w)), None, None, None, None, None, None, None
 
 
 class RowScaleFn(Function):

@@ -476,16 +476,37 @@ def layernorm_fwd_q8(x, gamma, beta, y, mean, rstd, batches, rpb, D, x_bs, y_bs,
     return scale
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, batches, rpb, D, x_bs, y_bs, accumulate_dx=False):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, batches, rpb, D, x_bs, y_bs, accumulate_dx=False, gadd=None,
+                  pad: int = 0, l: int = 1):
+    """gadd (f32 [batches, (pad + rpb) / l, D]): the gradient of the landmark means layernorm_fwd_lm produced; every dy row also
+    receives gadd[b, (i + pad) / l] / l (mh_layernorm_bwd_lm)."""
     _chk(dy, x, gamma, mean, rstd, dx, dgamma, dbeta)
     rows = batches * rpb
     ws = None
     nbytes = int(_lib.load().mh_layernorm_bwd_workspace_bytes(rows, D))
     if nbytes:          # per-block dgamma / dbeta partials (folded by a second launch) instead of same-address atomics
         ws = torch.empty((nbytes // 4,), device=x.device, dtype=torch.float32)
+    if gadd is not None:
+        _chk(gadd)
+        if gadd.dtype != torch.float32 or not gadd.is_contiguous() or gadd.numel() != batches * ((pad + rpb) // l) * D:
+            raise MirrorHipError("layernorm_bwd: gadd must be contiguous f32 [batches, (pad + rows) / l, D]")
+        _lib.call("mh_layernorm_bwd_lm", _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma), _p(dbeta),
+                  batches, rpb, D, x_bs, y_bs, dt(x), dt(dy), dt(dx), int(accumulate_dx), _p(ws) if ws is not None else 0,
+                  ws.numel() if ws is not None else 0, _p(gadd), int(pad), int(l), stream=_stream())
+        return
     _lib.call("mh_layernorm_bwd", _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma), _p(dbeta),
               batches, rpb, D, x_bs, y_bs, dt(x), dt(dy), dt(dx), int(accumulate_dx), _p(ws) if ws is not None else 0,
               ws.numel() if ws is not None else 0, stream=_stream())
+
+
+def layernorm_fwd_lm(x, gamma, beta, y, mean, rstd, xpm, batches, rows, D, x_bs, pad, l, eps):
+    """LayerNorm (f32 in, bf16 out behind `pad` zero rows, which this launch writes) + the landmark means xpm [batches, (pad + rows) / l, D]
+    (bf16) of its output rows (mh_layernorm_fwd_lm)."""
+    _chk(x, gamma, beta, y, mean, rstd, xpm)
+    if not (x.dtype == torch.float32 and y.dtype == torch.bfloat16 and xpm.dtype == torch.bfloat16 and y.is_contiguous() and xpm.is_contiguous()):
+        raise MirrorHipError("layernorm_fwd_lm: f32 input, contiguous bf16 outputs")
+    _lib.call("mh_layernorm_fwd_lm", _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), _p(xpm), batches, rows, D, x_bs, int(pad),
+              int(l), eps, stream=_stream())
 
 
 def softmax_fwd(x: torch.Tensor, y: Optional[torch.Tensor] = None, out_dtype=None) -> torch.Tensor:

@@ -193,8 +193,15 @@ class TransLayer(nn.Module):
         n, m = x.shape[1], a.num_landmarks
         pad = (m - n % m) % m
         l = math.ceil(n / m)  # noqa: E741
-        xp = Fn.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps, pad=pad, out_dtype=prec.act,
-                           q8_key=Fn.fp8_site_key(a.to_qkv.weight, prec) if prec.fp8_fwd else None)
+        lm = None
+        if mask is None and Fn.layer_norm_landmarks_ok(x, n, pad, l, prec):
+            # the norm also leaves the landmark means of its output; to_qkv is linear and bias-free, so the q | k landmarks of
+            # [3P] NystromAttention are a [B m, D] x [D, 2D] product on them (Fn.LayerNormLmFn / Fn.LandmarkProjFn)
+            xp, xpm = Fn.LayerNormLmFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps, n, pad, l)
+            lm = Fn.LandmarkProjFn.apply(xpm, a.to_qkv.weight, prec)
+        else:
+            xp = Fn.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps, pad=pad, out_dtype=prec.act,
+                               q8_key=Fn.fp8_site_key(a.to_qkv.weight, prec) if prec.fp8_fwd else None)
         kmask = None
         if mask is not None:
             if mask.shape != x.shape[:2]:
@@ -205,7 +212,7 @@ class TransLayer(nn.Module):
             xp = Fn.RowScaleFn.apply(xp, mrow)           # to_qkv has no bias: zero rows in, zero q / k / v rows out
         qkv = Fn.linear(xp, a.to_qkv.weight, None, prec=prec, defer_from=2 * a.to_qkv.weight.shape[1])
         core = Fn.NystromCoreFn.apply(qkv, a.res_conv.weight, a.heads, l, a.pinv_iterations, prec, kmask,
-                                      Fn.fp8_site_key(a.to_out[0].weight, prec) if prec.fp8_fwd else None)
+                                      Fn.fp8_site_key(a.to_out[0].weight, prec) if prec.fp8_fwd else None, lm)
         # to_out(...)[:, -n:], its Dropout and the residual add: one launch when the shapes allow (Fn.to_out_dropout_add).
         # x feeds exactly self.norm and this add
         return Fn.to_out_dropout_add(x, core, a.to_out[0].weight, a.to_out[0].bias, pad, n, a.drop, self.training, prec)

@@ -178,3 +178,82 @@ def test_whole_model_train_step_fused_epilogues_equal_composed():
         worst = max(worst, d)
         assert d <= 2e-2, (k, d)          # bf16 activations turn a different f32 summation order into 1-ulp flips downstream
     print("fused vs composed: losses", l1, l2, "worst relative gradient difference", worst)
+
+
+@pytest.mark.parametrize("Bn,n,D,m", [(3, 1025, 512, 256), (2, 300, 256, 128)])
+def test_layernorm_landmark_means_and_their_backward(Bn, n, D, m):
+    """mh_layernorm_fwd_lm / mh_layernorm_bwd_lm against LayerNormFn + explicit group means through torch autograd."""
+    import math
+    from mirror_amd import functional as Fn
+    g = torch.Generator().manual_seed(9)
+    pad = (m - n % m) % m
+    l = math.ceil(n / m)
+    assert (pad + n) == m * l
+    x0 = torch.randn(Bn, n, D, generator=g).cuda()
+    gm0, bt0 = (1 + 0.1 * torch.randn(D, generator=g)).cuda(), (0.1 * torch.randn(D, generator=g)).cuda()
+    up_y = torch.randn(Bn, pad + n, D, generator=g).cuda().to(bf16)
+    up_m = torch.randn(Bn, m, D, generator=g).cuda()
+    res = []
+    for fused in (True, False):
+        x, gm, bt = x0.clone().requires_grad_(True), gm0.clone().requires_grad_(True), bt0.clone().requires_grad_(True)
+        if fused:
+            y, xpm = Fn.LayerNormLmFn.apply(x, gm, bt, 1e-5, n, pad, l)
+            xpm32 = xpm.float()
+        else:
+            y = Fn.layer_norm(x, gm, bt, 1e-5, pad=pad, out_dtype=bf16)
+            xpm32 = y.float().reshape(Bn, m, l, D).mean(2)
+        (y.float() * up_y.float()).sum().backward(retain_graph=True)
+        if fused:
+            xpm.backward(up_m.to(bf16))
+        else:
+            (xpm32 * up_m.to(bf16).float()).sum().backward()
+        res.append((y.detach().clone(), xpm32.detach().clone(), x.grad.clone(), gm.grad.clone(), bt.grad.clone()))
+    torch.cuda.synchronize()
+    (y1, m1, dx1, dg1, db1), (y2, m2, dx2, dg2, db2) = res
+    assert torch.equal(y1, y2) and float(y1[:, :pad].abs().max() if pad else 0.0) == 0.0
+    assert float((m1 - m2).abs().max()) <= 2 ** -8 * float(m2.abs().max())          # bf16 rounding of the mean
+    for a, c, tol in ((dx1, dx2, 3e-3), (dg1, dg2, 3e-3), (db1, db2, 3e-3)):
+        assert float((a - c).norm()) <= tol * float(c.norm()), (float((a - c).norm()), float(c.norm()))
+
+
+def test_whole_model_landmarks_from_layernorm_means_equal_the_landmark_kernels():
+    """bf16 policy, train mode, D = 512: landmarks as to_qkv(group means of the LayerNorm output) (Fn._LM_ALGEBRA) against
+    the landmark kernels on q | k.  Algebraically identical ([3P] to_qkv is linear and bias-free); numerically the mean is
+    rounded to bf16 before the projection instead of after it: losses within 2e-3, parameter gradients cosine >= 0.999."""
+    import mirror_amd.models as M
+    from mirror_amd import functional as Fn
+    from mirror_amd.losses import MIRRORLoss
+    cfg = dict(wsi_embed_dim=128, rna_embed_dim=96, embed_dim=512, wsi_num_tokens=1024, rna_encoder_depth=1, rna_num_heads=8,
+               rna_mlp_ratio=4.0, style_mlp_hidden_dim=128, style_mlp_out_dim=64, style_latent_dim=32, num_prototypes=300)
+    g = torch.Generator().manual_seed(10)
+    wsi = torch.randn(2, 1024, 128, generator=g).cuda().to(bf16)
+    rna = torch.randn(2, 96, generator=g).cuda()
+    noise = {"wsi_mask": torch.rand(2, 1024, generator=g).cuda(), "rna_mask": torch.rand(2, 512, generator=g).cuda(),
+             "wsi_eps": torch.randn(2, 32, generator=g).cuda(), "rna_eps": torch.randn(2, 32, generator=g).cuda()}
+    out = []
+    was = Fn._LM_ALGEBRA
+    try:
+        for on in (True, False):
+            Fn._LM_ALGEBRA = on
+            torch.manual_seed(0)
+            model = M.mirror(**cfg).cuda().train()
+            model.precision = "bf16"
+            Fn.manual_seed(99)
+            losses = MIRRORLoss()(*model(wsi, rna, noise=noise))
+            losses[0].backward()
+            torch.cuda.synchronize()
+            out.append(([float(x) for x in losses], {k: p.grad.detach().clone() for k, p in model.named_parameters()}))
+    finally:
+        Fn._LM_ALGEBRA = was
+    (l1, g1), (l2, g2) = out
+    for a, c in zip(l1, l2):
+        assert abs(a - c) <= 2e-3 * max(abs(c), 1e-3), (l1, l2)
+    worst = 1.0
+    for k in g1:
+        a, c = g1[k].flatten().double(), g2[k].flatten().double()
+        if float(c.norm()) < 1e-10:
+            continue
+        cos = float(a @ c / (a.norm() * c.norm()))
+        worst = min(worst, cos)
+        assert cos >= 0.999, (k, cos)
+    print("landmark algebra vs kernels: losses", l1, l2, "worst gradient cosine", worst)

@@ -27,19 +27,25 @@ def test_library_exports_every_declared_symbol():
     assert lib.mh_version() >= 100
 
 
-def test_gemm_desc_matches_header_field_order():
-    header = open(os.path.join(ROOT, "include", "mirror_hip.h")).read()
-    body = header[header.index("typedef struct {"):header.index("} mh_gemm_desc;")]
+def _struct_fields(header: str, name: str):
+    """Field names of `typedef struct { ... } name;` in declaration order."""
+    end = header.index("} %s;" % name)
+    body = header[header.rindex("typedef struct {", 0, end):end]
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     names = []
     for decl in body.split(";"):
         decl = decl.replace("typedef struct {", "").strip()
         if not decl:
             continue
-        decl = re.sub(r"^(const\s+)?(void|float|int32_t|int64_t)\s*\*?", "", decl)
+        decl = re.sub(r"^(const\s+)?[A-Za-z_][A-Za-z0-9_]*\s*\*?\s*", "", decl)          # the declaration's type
         names += [n.strip().lstrip("*").strip() for n in decl.split(",")]
-    names = [re.sub(r"^(const\s+)?(void|float)\s*\*\s*", "", n) for n in names]
-    assert names == [f[0] for f in _lib.GemmDesc._fields_], names
+    return names
+
+
+def test_gemm_desc_matches_header_field_order():
+    header = open(os.path.join(ROOT, "include", "mirror_hip.h")).read()
+    assert _struct_fields(header, "mh_gemm_desc") == [f[0] for f in _lib.GemmDesc._fields_]
+    assert _struct_fields(header, "mh_gemm_epi") == [f[0] for f in _lib.GemmEpi._fields_]
 
 
 def test_state_dict_contract_matches_reference_keys():
