@@ -49,7 +49,8 @@ def test_to_out_dropout_residual_epilogue_equals_composed(Bn, T, r0, R, Kd, N):
     assert o1 == o2, "both forms consume the same dropout offsets"
     assert torch.equal(y1, y2), float((y1 - y2).abs().max())
     assert float((y1 == resid0).float().mean()) > 0.05, "dropout zeroes ~10 % of the projection"
-    assert torch.equal(dc1, dc2) and torch.equal(dr1, dr2) and torch.equal(db1, db2)
+    assert torch.equal(dc1, dc2) and torch.equal(dr1, dr2)
+    assert float((db1 - db2).abs().max()) <= 1e-5 * float(db2.abs().max())        # column sums: f32 atomics, order may differ
     assert float((dw1 - dw2).abs().max()) <= 1e-5 * float(dw2.abs().max())        # split-K f32 sums: order may differ
 
 
@@ -79,7 +80,7 @@ def test_retention_embed_mask_pos_epilogue_equals_composed(Bn, T, Kd, N):
         res.append([y.detach().clone()] + [t.grad.clone() for t in (h, w, b, token, pos)])
     torch.cuda.synchronize()
     for i, (a, c) in enumerate(zip(*res)):
-        if i == 2:       # dW: split-K f32 sums
+        if i in (2, 3, 4, 5):       # dW, db, dtoken, dpos: f32 sums whose order may differ (split-K, atomics)
             assert float((a - c).abs().max()) <= 1e-5 * float(c.abs().max())
         else:
             assert torch.equal(a, c), (i, float((a.float() - c.float()).abs().max()))
