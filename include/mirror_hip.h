@@ -53,8 +53,8 @@ int mh_device_ok(void);
  * the host then runs the composed ops.  The Linear's result is rounded to bf16 (the activation dtype autocast gives it)
  * before the fused op, so fused == composed bit for bit.
  *   MH_EPI_DROPADD: C[f32] = resid + Dropout_p(A W^T + bias)         [3P] to_out = Sequential(Linear, Dropout) and the residual
- *                   add of TransLayer.forward, models/mirror.py:312-313.  Philox4x32-10 exactly as mh_dropout: element i of C
- *                   (flat, C contiguous: ldc == N) uses word i & 3 of the block with counter (offset + i) >> 2.
+ *                   add of TransLayer.forward, models/mirror.py:312-313.  The mask is mh_dropout_lite's: element i of C (flat,
+ *                   C contiguous: ldc == N) uses 16-bit field i & 7 of the Philox4x32-7 block with counter (offset + i) >> 3.
  *   MH_EPI_MASKPOS: C[f32] = (t >= first && mask[b, t - first] ? token : A W^T + bias) + pos[t]      retention_embed followed by
  *                   random_masking's mask-token select and `+ retention_gene_embed`, models/mirror.py:636-643, :691-693;
  *                   flat row r of C is (b, t) = (r / rows_per_batch, r % rows_per_batch).
@@ -69,7 +69,7 @@ int mh_device_ok(void);
 typedef struct {
     int32_t kind;
     const float* resid;           /* DROPADD: residual stream, C's shape and layout */
-    float p; uint64_t seed, offset; const uint64_t* dev_base;      /* DROPADD: as mh_dropout */
+    float p; uint64_t seed, offset; const uint64_t* dev_base;      /* DROPADD: as mh_dropout_lite */
     const float* mask;            /* MASKPOS: [batches, rows_per_batch - first]; SQERR: [batches, rows_per_batch] (f32, != 0 = masked) */
     const float* token;           /* MASKPOS: [N] */
     const float* pos;             /* MASKPOS: [rows_per_batch, N] */
@@ -371,6 +371,12 @@ int mh_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, uint64
  * Same mask as mh_dropout for the same (seed, offset [+ *dev_base]).  n % 4 == 0, quad-aligned buffers; a, y f32. */
 int mh_dropout_add(const float* a, const void* x, float* y, int64_t n, float p, uint64_t seed, uint64_t offset,
                    const uint64_t* dev_base, int dt_x, mh_stream s);
+/* The "lite" dropout stream of the [B, n, D]-sized WSI dropouts ([3P] to_out[1], models/mirror.py:312): Philox4x32-7, 16 random
+ * bits per element (8 elements per block: element i = 16-bit field i & 7 of the block with counter (offset + i) >> 3), kept when
+ * field >= round(p * 65536), scaled by the exact 1 / P(keep).  y = dropout(x) (a NULL) or a + dropout(x) (y f32);
+ * n % 8 == 0, offset % 8 == 0.  The DROPADD projection epilogue (mh_gemm_epi) draws the same stream. */
+int mh_dropout_lite(const float* a, const void* x, void* y, int64_t n, float p, uint64_t seed, uint64_t offset,
+                    const uint64_t* dev_base, int dt_x, int dt_y, mh_stream s);
 /* out[c] += sum_r x[r*ld + c]  (bias gradients; f32 atomics) */
 int mh_colsum(const void* x, float* out, int64_t rows, int cols, int64_t ld, int dt, mh_stream s);
 /* y[r] = x[r*x_rs .. +D] / max(||.||, eps) (F.normalize, models/mirror.py:540, :683); norm[r] saved */

@@ -131,6 +131,7 @@ _SIGS = {
     "mh_relu_bwd": [P, P, P, L, I, L, L, L, I, I, I],
     "mh_dropout": [P, P, L, F, U64, U64, P, I, I],
     "mh_dropout_add": [P, P, P, L, F, U64, U64, P, I],
+    "mh_dropout_lite": [P, P, P, L, F, U64, U64, P, I, I],
     "mh_colsum": [P, P, L, I, L, I],
     "mh_l2norm_fwd": [P, P, P, I, I, L, F, I, I],
     "mh_l2norm_bwd": [P, P, P, P, I, I, L, F, I, I, I, I],

@@ -180,6 +180,43 @@ __global__ __launch_bounds__(256) void dropout4_kernel(const TX* x, const float*
     }
 }
 
+// the lite stream (common.h drop16_*): 8 elements per Philox block, n % 8 == 0, 16 / 32-byte accesses per tensor
+template <typename TX, typename TY, bool ADD>
+__global__ __launch_bounds__(256) void dropout8_kernel(const TX* x, const float* a, TY* y, long n8, float p, uint64_t seed, uint64_t offset,
+                                                       const uint64_t* __restrict__ dev_base) {
+    if (dev_base) offset += *dev_base & ~7ull;
+    const uint32_t thr = drop16_thr(p);
+    const float scale = drop16_scale(thr);
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < n8; q += (long)gridDim.x * 256) {
+        const uint32_t keep = drop16_keep8((offset >> 3) + (uint64_t)q, seed, thr);
+        const f4_t v0 = ld4(x + 8 * q), v1 = ld4(x + 8 * q + 4);
+        f4_t o0 = {keep & 1u ? v0[0] * scale : 0.f, keep & 2u ? v0[1] * scale : 0.f, keep & 4u ? v0[2] * scale : 0.f, keep & 8u ? v0[3] * scale : 0.f};
+        f4_t o1 = {keep & 16u ? v1[0] * scale : 0.f, keep & 32u ? v1[1] * scale : 0.f, keep & 64u ? v1[2] * scale : 0.f, keep & 128u ? v1[3] * scale : 0.f};
+        if (ADD) { o0 += ld4(a + 8 * q); o1 += ld4(a + 8 * q + 4); }
+        st4(y + 8 * q, o0);
+        st4(y + 8 * q + 4, o1);
+    }
+}
+
+// y = dropout(x) (a == NULL) or y = a + dropout(x) on the lite stream; n % 8 == 0, offset % 8 == 0, 16-byte aligned buffers
+extern "C" int mh_dropout_lite(const float* a, const void* x, void* y, int64_t n, float p, uint64_t seed, uint64_t offset,
+                               const uint64_t* dev_base, int dt_x, int dt_y, mh_stream s) {
+    MH_REQUIRE(p >= 0.f && p < 1.f, "mh_dropout_lite: p=%f out of range", (double)p);
+    MH_REQUIRE((offset & 7) == 0 && n % 8 == 0, "mh_dropout_lite: offset and n must be multiples of 8");
+    MH_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)a) & 15) == 0, "mh_dropout_lite: buffers must be 16-byte aligned");
+    MH_REQUIRE(!a || dt_y == MH_F32, "mh_dropout_lite: the residual form writes f32");
+    if (n == 0) return MH_OK;
+#define DROP8_(TX, TY, ADD) hipLaunchKernelGGL((dropout8_kernel<TX, TY, ADD>), EW_GRID(n / 8), dim3(256), 0, (hipStream_t)s, (const TX*)x, a, (TY*)y, (long)(n / 8), p, seed, offset, dev_base)
+    if (a) { if (dt_x == MH_F32) DROP8_(float, float, true); else DROP8_(bf16_t, float, true); }
+    else if (dt_x == MH_F32 && dt_y == MH_F32) DROP8_(float, float, false);
+    else if (dt_x == MH_F32) DROP8_(float, bf16_t, false);
+    else if (dt_y == MH_F32) DROP8_(bf16_t, float, false);
+    else DROP8_(bf16_t, bf16_t, false);
+#undef DROP8_
+    MH_LAUNCH_CHECK("mh_dropout_lite");
+    return MH_OK;
+}
+
 extern "C" int mh_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, uint64_t offset, const uint64_t* dev_base,
                           int dt_x, int dt_y, mh_stream s) {
     MH_REQUIRE(p >= 0.f && p < 1.f, "mh_dropout: p=%f out of range", (double)p);

@@ -23,23 +23,15 @@ __device__ __forceinline__ f32x4 round_bf16_4(f32x4 x) {
     return f32x4{bf2f(f2bf(x[0])), bf2f(f2bf(x[1])), bf2f(f2bf(x[2])), bf2f(f2bf(x[3]))};
 }
 template <int EPI>
-__device__ __forceinline__ f32x4 epi_quad(const GemmArgs& g, f32x4 x, long grow, int gcol, uint64_t drop_blk0, uint32_t thr, float dscale) {
-    if constexpr (EPI == MH_EPI_DROPADD) {
-        // [3P] to_out[1] = Dropout, then TransLayer's residual add (models/mirror.py:312-313); Philox exactly as mh_dropout
-        x = round_bf16_4(x);
-        const uint64_t blk = drop_blk0 + (((uint64_t)grow * (uint64_t)g.N + (uint64_t)gcol) >> 2);
-        uint32_t ctr[4] = {(uint32_t)blk, (uint32_t)(blk >> 32), 0u, 0u};
-        philox4x32_10(ctr, (uint32_t)g.epi.seed, (uint32_t)(g.epi.seed >> 32));
-        const f32x4 res = *reinterpret_cast<const f32x4*>(g.epi.resid + grow * (long)g.N + gcol);
-        return f32x4{res[0] + (ctr[0] >= thr ? x[0] * dscale : 0.f), res[1] + (ctr[1] >= thr ? x[1] * dscale : 0.f),
-                     res[2] + (ctr[2] >= thr ? x[2] * dscale : 0.f), res[3] + (ctr[3] >= thr ? x[3] * dscale : 0.f)};
-    } else if constexpr (EPI == MH_EPI_MASKPOS) {
-        // random_masking's token select + `+ retention_gene_embed` (models/mirror.py:636-643, :691-693)
+__device__ __forceinline__ f32x4 epi_quad(const GemmArgs& g, f32x4 x, int grow, int gcol) {
+    if constexpr (EPI == MH_EPI_MASKPOS) {
+        // random_masking's token select + `+ retention_gene_embed` (models/mirror.py:636-643, :691-693); 32-bit row arithmetic
+        // (a 64-bit division per quad made this epilogue longer than the pass it replaces)
         x = round_bf16_4(x);
         const int rpb = g.epi.rows_per_batch, first = g.epi.first;
-        const long b = grow / rpb;
-        const int t = (int)(grow - b * rpb);
-        if (t >= first && g.epi.mask[b * (rpb - first) + (t - first)] != 0.f) x = *reinterpret_cast<const f32x4*>(g.epi.token + gcol);
+        const int b = grow / rpb;
+        const int t = grow - b * rpb;
+        if (t >= first && g.epi.mask[(long)b * (rpb - first) + (t - first)] != 0.f) x = *reinterpret_cast<const f32x4*>(g.epi.token + gcol);
         return x + *reinterpret_cast<const f32x4*>(g.epi.pos + (long)t * g.N + gcol);
     } else {
         return x;
@@ -55,10 +47,10 @@ __device__ __forceinline__ void epilogue_big(const GemmArgs& g, TC* C, f32x16 (&
     float dscale = 1.f;
     if constexpr (EPI == MH_EPI_DROPADD) {
         uint64_t off = g.epi.offset;
-        if (g.epi.dev_base) off += *g.epi.dev_base & ~3ull;
-        drop_blk0 = off >> 2;
-        thr = (uint32_t)fminf(g.epi.p * 4294967296.f, 4294967295.f);
-        dscale = 1.f / (1.f - g.epi.p);
+        if (g.epi.dev_base) off += *g.epi.dev_base & ~7ull;
+        drop_blk0 = off >> 3;
+        thr = drop16_thr(g.epi.p);
+        dscale = drop16_scale(thr);
     }
     constexpr int PITCH = BIG + 4, HALF = BIG / 2;
     float* t = reinterpret_cast<float*>(smem);
@@ -87,6 +79,33 @@ __device__ __forceinline__ void epilogue_big(const GemmArgs& g, TC* C, f32x16 (&
         constexpr int EPC = 16 / (int)sizeof(TC);
         constexpr int CPR = BIG / EPC;
         constexpr int NCH = HALF * CPR / NTB;
+        if constexpr (EPI == MH_EPI_DROPADD) {
+            // [3P] to_out[1] = Dropout, then TransLayer's residual add (models/mirror.py:312-313): 8 columns per thread = one block
+            // of the lite dropout stream (common.h), the mask mh_dropout_lite draws for the same (seed, offset, element)
+            constexpr int CPR8 = BIG / 8, NCH8 = HALF * CPR8 / NTB;
+#pragma unroll 2
+            for (int i = 0; i < NCH8; i++) {
+                const int cid = tid + i * NTB;
+                const int lr = cid / CPR8, c = cid % CPR8;
+                const int grow = tile_row0 + half * HALF + lr, gcol = tile_col0 + c * 8;
+                if (grow >= g.M) continue;
+                const float* src = t + lr * PITCH + c * 8;
+                const float* rp = g.epi.resid + (long)grow * g.N + gcol;
+                f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+                const f32x4 x0 = round_bf16_4(*reinterpret_cast<const f32x4*>(src)), x1 = round_bf16_4(*reinterpret_cast<const f32x4*>(src + 4));
+                const uint32_t keep = drop16_keep8(drop_blk0 + (((uint64_t)grow * (uint64_t)g.N + (uint64_t)gcol) >> 3), g.epi.seed, thr);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    if (keep & (1u << e)) r0[e] += x0[e] * dscale;
+                    if (keep & (16u << e)) r1[e] += x1[e] * dscale;
+                }
+                float* dst = reinterpret_cast<float*>(C) + (long)grow * ldc + gcol;
+                *reinterpret_cast<f32x4*>(dst) = r0;
+                *reinterpret_cast<f32x4*>(dst + 4) = r1;
+            }
+            __syncthreads();
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < NCH; i++) {
             const int cid = tid + i * NTB;
@@ -97,7 +116,7 @@ __device__ __forceinline__ void epilogue_big(const GemmArgs& g, TC* C, f32x16 (&
             f32x4 x0 = *reinterpret_cast<const f32x4*>(src);
             u32x4 o;
             if constexpr (sizeof(TC) == 4) {
-                if constexpr (EPI != 0) x0 = epi_quad<EPI>(g, x0, (long)(tile_row0 + half * HALF + lr), tile_col0 + c * EPC, drop_blk0, thr, dscale);
+                if constexpr (EPI != 0) x0 = epi_quad<EPI>(g, x0, tile_row0 + half * HALF + lr, tile_col0 + c * EPC);
                 if constexpr (MODE == 1) x0 += *reinterpret_cast<const f32x4*>(dst);
                 o[0] = __float_as_uint(x0[0]); o[1] = __float_as_uint(x0[1]);
                 o[2] = __float_as_uint(x0[2]); o[3] = __float_as_uint(x0[3]);
@@ -512,7 +531,7 @@ const char* gemm_big_epi(GemmArgs& a, int akc, int bkc, int dtC, int batch, hipS
          else hipLaunchKernelGGL((gemm_big_kernel<TC, true, false, false, false, EPI>), grid, dim3(NTB), 0, s, a); } while (0)
     switch (e.kind) {
     case MH_EPI_DROPADD:
-        if (dtC != MH_F32 || !e.resid || !(e.p >= 0.f && e.p < 1.f) || (e.offset & 3) || ((uintptr_t)e.resid & 15)) return "DROPADD: f32 C, a 16-byte aligned residual, 0 <= p < 1, offset % 4 == 0";
+        if (dtC != MH_F32 || !e.resid || !(e.p >= 0.f && e.p < 1.f) || (e.offset & 7) || ((uintptr_t)e.resid & 15)) return "DROPADD: f32 C, a 16-byte aligned residual, 0 <= p < 1, offset % 8 == 0";
         EPI_LAUNCH_(float, MH_EPI_DROPADD);
         return nullptr;
     case MH_EPI_MASKPOS:

@@ -530,8 +530,8 @@ class ToOutDropAddFn(Function):
         Bn, _, Kd = core.shape
         N = wa.shape[0]
         out = torch.empty((Bn, R, N), device=core.device, dtype=f32)
-        ctx.p, ctx.seed, ctx.offset, ctx.base = p, _dropout_state["seed"], _dropout_state["offset"], _dropout_state["base"]
-        _dropout_state["offset"] += (out.numel() + 3) // 4 * 4
+        ctx.p, ctx.seed, ctx.offset, ctx.base = p, _dropout_state["seed"], _lite_offset(), _dropout_state["base"]
+        _dropout_state["offset"] = ctx.offset + out.numel()
         K.linear_fused(core, wa, None if b is None else b.detach(), out,
                        K.epi_dropadd(resid, p, ctx.seed, ctx.offset, ctx.base), window=(r0, R))
         ctx.save_for_backward(core, wa, w, b)
@@ -543,7 +543,7 @@ class ToOutDropAddFn(Function):
         core, wa, w, b = ctx.saved_tensors
         dy = dy.contiguous()
         gb = torch.empty(dy.shape, device=dy.device, dtype=ctx.prec.act)
-        K.dropout(dy, ctx.p, ctx.seed, ctx.offset, out=gb, dev_base=ctx.base)      # masked, scaled gradient of the projection output
+        K.dropout_lite(dy, ctx.p, ctx.seed, ctx.offset, ctx.base, out=gb)           # masked, scaled gradient of the projection output
         _res_grads[ctx.res_key] = dy         # the block's LayerNorm accumulates its dx into the residual gradient (see AddFn)
         dcore, dw, db = _linear_rows_bwd(ctx.needs_input_grad[1:4], core, wa, w, b, ctx.r0, ctx.R, ctx.prec, gb)
         return dy, dcore, dw, db, None, None, None, None
@@ -552,11 +552,11 @@ class ToOutDropAddFn(Function):
 def to_out_dropout_add(resid, core, w, b, r0: int, R: int, p: float, training: bool, prec: Precision):
     """x + Dropout(to_out(core)[:, r0:r0+R]): fused when the shapes are on the 256 x 256-tile kernel (bf16 policy, training)."""
     if (training and p > 0.0 and prec.act == bf16 and not prec.fp8_fwd and resid.dtype == f32 and resid.is_contiguous()
-            and core.dtype == bf16 and tuple(resid.shape) == (core.shape[0], R, w.shape[0]) and (core.shape[0] * R * w.shape[0]) % 4 == 0
+            and core.dtype == bf16 and tuple(resid.shape) == (core.shape[0], R, w.shape[0]) and (core.shape[0] * R * w.shape[0]) % 8 == 0
             and K.linear_fused_ok(core, shadow(w, prec), (r0, R))):
         return ToOutDropAddFn.apply(resid, core, w, b, r0, R, p, prec)
     y = LinearRowsFn.apply(core, w, b, r0, R, prec, prec.act)
-    return dropout_add(resid, y, p, training)
+    return dropout_add(resid, y, p, training, lite=True)
 
 
 class HeadSqErrFn(Function):
@@ -915,6 +915,11 @@ def dropout_device_base_off() -> None:
     _dropout_state["base"] = None
 
 
+def _lite_offset() -> int:
+    """The next offset of the lite dropout stream (8 elements per Philox block): the running offset rounded up to 8."""
+    return (_dropout_state["offset"] + 7) // 8 * 8
+
+
 class DropoutFn(Function):
     """nn.Dropout in training mode; the Philox mask is regenerated in backward from (seed, offset [+ device base])."""
 
@@ -942,26 +947,36 @@ class DropoutAddFn(Function):
     for the block's LayerNorm to accumulate into (see AddFn)."""
 
     @staticmethod
-    def forward(ctx, a, b, p):
+    def forward(ctx, a, b, p, lite=False):
         a, b = a.contiguous(), b.contiguous()
-        ctx.p, ctx.seed, ctx.offset, ctx.base = p, _dropout_state["seed"], _dropout_state["offset"], _dropout_state["base"]
-        _dropout_state["offset"] += (b.numel() + 3) // 4 * 4
+        ctx.lite = bool(lite) and b.numel() % 8 == 0        # the lite stream (mh_dropout_lite), the one ToOutDropAddFn's epilogue draws
+        ctx.p, ctx.seed, ctx.base = p, _dropout_state["seed"], _dropout_state["base"]
         ctx.res_key, ctx.db = a.data_ptr(), b.dtype
+        if ctx.lite:
+            ctx.offset = _lite_offset()
+            _dropout_state["offset"] = ctx.offset + b.numel()
+            return K.dropout_lite(b, p, ctx.seed, ctx.offset, ctx.base, add_to=a)
+        ctx.offset = _dropout_state["offset"]
+        _dropout_state["offset"] += (b.numel() + 3) // 4 * 4
         return K.dropout_add(a, b, p, ctx.seed, ctx.offset, dev_base=ctx.base)
 
     @staticmethod
     def backward(ctx, dy):
         dy = dy.contiguous()
         gb = torch.empty(dy.shape, device=dy.device, dtype=ctx.db)
-        K.dropout(dy, ctx.p, ctx.seed, ctx.offset, out=gb, dev_base=ctx.base)
+        if ctx.lite:
+            K.dropout_lite(dy, ctx.p, ctx.seed, ctx.offset, ctx.base, out=gb)
+        else:
+            K.dropout(dy, ctx.p, ctx.seed, ctx.offset, out=gb, dev_base=ctx.base)
         _res_grads[ctx.res_key] = dy
-        return dy, gb, None
+        return dy, gb, None, None
 
 
-def dropout_add(a, b, p: float, training: bool):
-    """a + dropout(b) with `a` the f32 residual stream of a pre-norm block (falls back to the two-op form otherwise)."""
+def dropout_add(a, b, p: float, training: bool, lite: bool = False):
+    """a + dropout(b) with `a` the f32 residual stream of a pre-norm block (falls back to the two-op form otherwise).
+    lite=True: the masks of the lite stream (mh_dropout_lite) — the WSI layers, whose fused projection epilogue draws them too."""
     if training and p > 0.0 and a.dtype == f32 and a.shape == b.shape and b.numel() % 4 == 0:
-        return DropoutAddFn.apply(a, b, p)
+        return DropoutAddFn.apply(a, b, p, lite)
     return add(a, dropout(b, p, training), f32, residual=True)
 
 

@@ -1116,6 +1116,25 @@ def dropout_add(a: torch.Tensor, x: torch.Tensor, p: float, seed: int, offset: i
     return y
 
 
+def dropout_lite(x: torch.Tensor, p: float, seed: int, offset: int, dev_base: Optional[torch.Tensor] = None, *, add_to: Optional[torch.Tensor] = None,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dropout(x) (or add_to + dropout(x) as f32) on the lite stream (mh_dropout_lite: Philox4x32-7, 16 bits per element);
+    numel % 8 == 0, offset % 8 == 0.  The DROPADD projection epilogue draws the same masks."""
+    _chk(x, dev_base, add_to, out)
+    _contig(x, "dropout_lite x")
+    if x.numel() % 8 or offset % 8:
+        raise MirrorHipError("dropout_lite: numel and offset must be multiples of 8")
+    if add_to is not None:
+        _contig(add_to, "dropout_lite add_to")
+        assert add_to.dtype == torch.float32 and add_to.shape == x.shape
+        out = torch.empty_like(add_to) if out is None else out
+    elif out is None:
+        out = torch.empty_like(x)
+    assert out.is_contiguous() and out.numel() == x.numel()
+    _lib.call("mh_dropout_lite", _p(add_to), _p(x), _p(out), x.numel(), p, seed, offset, _p(dev_base), dt(x), dt(out), stream=_stream())
+    return out
+
+
 def colsum(x2d: torch.Tensor, out: torch.Tensor) -> None:
     """out[c] += sum_r x2d[r, c]; x2d may be row-strided."""
     _chk(x2d, out)

@@ -41,7 +41,7 @@ def test_to_out_dropout_residual_epilogue_equals_composed(Bn, T, r0, R, Kd, N):
             assert Fn.K.linear_fused_ok(core, Fn.shadow(w, prec), (r0, R))
             y = Fn.ToOutDropAddFn.apply(resid, core, w, b, r0, R, 0.1, prec)
         else:
-            y = Fn.dropout_add(resid, Fn.LinearRowsFn.apply(core, w, b, r0, R, prec, bf16), 0.1, True)
+            y = Fn.dropout_add(resid, Fn.LinearRowsFn.apply(core, w, b, r0, R, prec, bf16), 0.1, True, lite=True)
         y.backward(up)
         res.append((y.detach().clone(), core.grad.clone(), resid.grad.clone(), w.grad.clone(), b.grad.clone(), Fn._dropout_state["offset"]))
     torch.cuda.synchronize()
@@ -258,3 +258,25 @@ def test_whole_model_landmarks_from_layernorm_means_equal_the_landmark_kernels()
         worst = min(worst, cos)
         assert cos >= 0.999, (k, cos)
     print("landmark algebra vs kernels: losses", l1, l2, "worst gradient cosine", worst)
+
+
+def test_lite_dropout_stream_statistics_and_backward_mask():
+    """mh_dropout_lite: keep rate 1 - round(p * 65536) / 65536, unbiased scaling, the same mask for the same (seed, offset) — the
+    backward regenerates it — and a different one for a different offset or seed."""
+    from mirror_amd import kernels as K
+    x = torch.ones(1 << 22, device="cuda")
+    y = K.dropout_lite(x, 0.1, 1234, 64)
+    y2 = K.dropout_lite(x.to(bf16), 0.1, 1234, 64)
+    torch.cuda.synchronize()
+    keep = float((y != 0).float().mean())
+    assert abs(keep - (1 - 6554 / 65536)) < 1e-3, keep
+    assert abs(float(y.mean()) - 1.0) < 2e-3
+    assert torch.equal(y != 0, y2 != 0)
+    assert not torch.equal(y != 0, K.dropout_lite(x, 0.1, 1234, 72) != 0)
+    assert not torch.equal(y != 0, K.dropout_lite(x, 0.1, 1235, 64) != 0)
+    a = torch.randn(1 << 22, device="cuda")
+    z = K.dropout_lite(x, 0.1, 1234, 64, add_to=a)
+    assert torch.equal(z, a + y)
+    # neighbouring elements are independent: P(both kept) = keep^2
+    both = float(((y[:-1] != 0) & (y[1:] != 0)).float().mean())
+    assert abs(both - keep * keep) < 2e-3, (both, keep)
