@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const TX* __rest
 // a pass over the [B, n_p, 2D] q | k columns, and in the backward the landmark gradient reaches the rows through this
 // LayerNorm's backward (mh_layernorm_bwd gadd) instead of a read-modify-write of dqkv.
 // One wave per (batch, group): its l rows in chunks of LMU rows in flight; pad rows are written as zeros here.
-#define LMU 4
+#define LMU 2
 template <int LNV_CH>
 __global__ __launch_bounds__(256) void layernorm_fwd_lm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, bf16_t* __restrict__ y,
@@ -182,12 +182,14 @@ __global__ __launch_bounds__(256) void layernorm_fwd_lm_kernel(const float* __re
         gm[k] = c < D ? ld4(gamma + c) : acc[k];
         bt[k] = c < D ? ld4(beta + c) : acc[k];
     }
-    for (int j0 = g * l; j0 < (g + 1) * l; j0 += LMU) {
-        f4 v[LMU][LNV_CH];
+    // the rows of chunk c + 1 are requested before chunk c is reduced and stored: with one chunk in flight the kernel alternated
+    // between a load phase and a compute / store phase (4.5 TB/s)
+    const int jend = (g + 1) * l;
+    auto load_chunk = [&](f4 (&v)[LMU][LNV_CH], int j0) {
 #pragma unroll
-        for (int u = 0; u < LMU; u++) {               // all loads of the chunk before any reduction
+        for (int u = 0; u < LMU; u++) {
             const int j = j0 + u;
-            const bool live = j < (g + 1) * l && j >= pad;
+            const bool live = j < jend && j >= pad;
             const float* xr = x + b * x_bs + (long)(live ? j - pad : 0) * D;
 #pragma unroll
             for (int k = 0; k < LNV_CH; k++) {
@@ -195,10 +197,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_lm_kernel(const float* __re
                 v[u][k] = (live && c < D) ? ld4(xr + c) : (f4){0.f, 0.f, 0.f, 0.f};
             }
         }
+    };
+    auto do_chunk = [&](f4 (&v)[LMU][LNV_CH], int j0) {
 #pragma unroll
         for (int u = 0; u < LMU; u++) {
             const int j = j0 + u;
-            if (j >= (g + 1) * l) break;               // wave-uniform
+            if (j >= jend) break;                     // wave-uniform
             bf16_t* yr = y + (b * n_p + j) * D;
             if (j < pad) {                            // front padding: zero rows, no statistics
 #pragma unroll
@@ -235,6 +239,15 @@ __global__ __launch_bounds__(256) void layernorm_fwd_lm_kernel(const float* __re
             }
             if (lane == 0) { const long row = (long)b * rows + (j - pad); mean[row] = mu; rstd[row] = rs; }
         }
+    };
+    f4 va[LMU][LNV_CH], vb[LMU][LNV_CH];
+    load_chunk(va, g * l);
+    for (int j0 = g * l; j0 < jend; j0 += 2 * LMU) {
+        if (j0 + LMU < jend) load_chunk(vb, j0 + LMU);
+        do_chunk(va, j0);
+        if (j0 + LMU >= jend) break;
+        if (j0 + 2 * LMU < jend) load_chunk(va, j0 + 2 * LMU);
+        do_chunk(vb, j0 + LMU);
     }
     const float inv = 1.f / (float)l;
 #pragma unroll
