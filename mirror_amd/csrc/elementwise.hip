@@ -190,9 +190,17 @@ __global__ __launch_bounds__(256) void dropout8_kernel(const TX* x, const float*
     for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < n8; q += (long)gridDim.x * 256) {
         const uint32_t keep = drop16_keep8((offset >> 3) + (uint64_t)q, seed, thr);
         const f4_t v0 = ld4(x + 8 * q), v1 = ld4(x + 8 * q + 4);
-        f4_t o0 = {keep & 1u ? v0[0] * scale : 0.f, keep & 2u ? v0[1] * scale : 0.f, keep & 4u ? v0[2] * scale : 0.f, keep & 8u ? v0[3] * scale : 0.f};
-        f4_t o1 = {keep & 16u ? v1[0] * scale : 0.f, keep & 32u ? v1[1] * scale : 0.f, keep & 64u ? v1[2] * scale : 0.f, keep & 128u ? v1[3] * scale : 0.f};
-        if (ADD) { o0 += ld4(a + 8 * q); o1 += ld4(a + 8 * q + 4); }
+        f4_t o0, o1;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {           // __fmul_rn / __fadd_rn: scale and residual add round separately (never an fma), so the
+            o0[e] = (keep & (1u << e)) ? __fmul_rn(v0[e], scale) : 0.f;      // DROPADD projection epilogue reproduces this bit for bit
+            o1[e] = (keep & (16u << e)) ? __fmul_rn(v1[e], scale) : 0.f;
+        }
+        if (ADD) {
+            const f4_t a0 = ld4(a + 8 * q), a1 = ld4(a + 8 * q + 4);
+#pragma unroll
+            for (int e = 0; e < 4; e++) { o0[e] = __fadd_rn(a0[e], o0[e]); o1[e] = __fadd_rn(a1[e], o1[e]); }
+        }
         st4(y + 8 * q, o0);
         st4(y + 8 * q + 4, o1);
     }

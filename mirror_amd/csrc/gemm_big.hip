@@ -95,9 +95,9 @@ __device__ __forceinline__ void epilogue_big(const GemmArgs& g, TC* C, f32x16 (&
                 const f32x4 x0 = round_bf16_4(*reinterpret_cast<const f32x4*>(src)), x1 = round_bf16_4(*reinterpret_cast<const f32x4*>(src + 4));
                 const uint32_t keep = drop16_keep8(drop_blk0 + (((uint64_t)grow * (uint64_t)g.N + (uint64_t)gcol) >> 3), g.epi.seed, thr);
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    if (keep & (1u << e)) r0[e] += x0[e] * dscale;
-                    if (keep & (16u << e)) r1[e] += x1[e] * dscale;
+                for (int e = 0; e < 4; e++) {      // two roundings (scale, then add), as mh_dropout_lite: no fused multiply-add
+                    r0[e] = __fadd_rn(r0[e], (keep & (1u << e)) ? __fmul_rn(x0[e], dscale) : 0.f);
+                    r1[e] = __fadd_rn(r1[e], (keep & (16u << e)) ? __fmul_rn(x1[e], dscale) : 0.f);
                 }
                 float* dst = reinterpret_cast<float*>(C) + (long)grow * ldc + gcol;
                 *reinterpret_cast<f32x4*>(dst) = r0;

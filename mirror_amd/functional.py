@@ -532,8 +532,14 @@ class ToOutDropAddFn(Function):
         out = torch.empty((Bn, R, N), device=core.device, dtype=f32)
         ctx.p, ctx.seed, ctx.offset, ctx.base = p, _dropout_state["seed"], _lite_offset(), _dropout_state["base"]
         _dropout_state["offset"] = ctx.offset + out.numel()
-        K.linear_fused(core, wa, None if b is None else b.detach(), out,
-                       K.epi_dropadd(resid, p, ctx.seed, ctx.offset, ctx.base), window=(r0, R))
+        M = Bn * R
+        tail = K.linear_fused_tail(M)
+        bd = None if b is None else b.detach()
+        K.linear_fused(core, wa, bd, out, K.epi_dropadd(resid, p, ctx.seed, ctx.offset, ctx.base), window=(r0, R), m_rows=M - tail)
+        if tail:     # the last rows of the last slide: composed ops on [tail, K] (same stream, same masks: the offsets are per element)
+            yt = K.gemm(core[Bn - 1, r0 + R - tail:r0 + R], wa.t(), bias=bd, mma=prec.mma, out_dtype=bf16)
+            K.dropout_lite(yt, p, ctx.seed, ctx.offset + (M - tail) * N, ctx.base, add_to=resid.view(M, N)[M - tail:],
+                           out=out.view(M, N)[M - tail:])
         ctx.save_for_backward(core, wa, w, b)
         ctx.r0, ctx.R, ctx.prec, ctx.res_key = r0, R, prec, resid.data_ptr()
         return out
@@ -629,8 +635,17 @@ class EmbedMaskPosFn(Function):
         Bn, T, Kd = h.shape
         N = wa.shape[0]
         out = torch.empty((Bn, T, N), device=h.device, dtype=f32)
-        K.linear_fused(h, wa, None if b is None else b.detach(), out,
-                       K.epi_maskpos(mask, token.detach().reshape(-1).contiguous(), pos.detach().reshape(-1).contiguous(), T, first))
+        M = Bn * T
+        tail = K.linear_fused_tail(M)
+        bd = None if b is None else b.detach()
+        tok, ps = token.detach().reshape(-1).contiguous(), pos.detach().reshape(T, N).contiguous()
+        K.linear_fused(h, wa, bd, out, K.epi_maskpos(mask, tok, ps, T, first), m_rows=M - tail)
+        if tail and T - tail >= first:       # the last rows of the last slide through the composed ops
+            rt = K.gemm(h[Bn - 1, T - tail:], wa.t(), bias=bd, mma=prec.mma, out_dtype=bf16)
+            K.mask_apply_fwd(rt.view(1, tail, N), mask[Bn - 1, T - tail - first:].contiguous(), tok, ps[T - tail:].reshape(-1), 1, tail, N, 0, False,
+                             out=out[Bn - 1:, T - tail:])
+        elif tail:
+            raise K.MirrorHipError("EmbedMaskPosFn: the tail rows cross the unmasked prefix")
         ctx.save_for_backward(h, wa, w, b, mask)
         ctx.geom = (Bn, T, N, first, token.shape, pos.shape, prec)
         return out

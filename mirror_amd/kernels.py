@@ -188,8 +188,16 @@ def linear_fused_ok(x: torch.Tensor, w: torch.Tensor, window: Optional[tuple] = 
             and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0)
 
 
+def linear_fused_tail(rows: int) -> int:
+    """Flat rows that a fused launch leaves to the caller: a few rows past whole 256-row tiles (B x 4097 = 256 tiles + 16 rows) would
+    cost every launch a third round of workgroups on 256 CUs for two almost empty tiles; the caller runs them through the composed
+    ops (a [16, K] product and a 16-row elementwise launch)."""
+    rem = rows % 256
+    return rem if (rows > 512 and 0 < rem <= 64) else 0
+
+
 def linear_fused(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, epi: "_lib.GemmEpi",
-                 window: Optional[tuple] = None) -> torch.Tensor:
+                 window: Optional[tuple] = None, m_rows: Optional[int] = None) -> torch.Tensor:
     """out [B * R, N] (flat rows, contiguous) = epilogue(x[:, r0:r0 + R] @ w^T + bias) on the 256 x 256-tile kernel with one of the
     fused epilogues of include/mirror_hip.h (mh_gemm_epi).  window = (r0, R) or None (all T rows).  The row windows of all batches
     are ONE flat problem (mh_gemm_desc.a_rows_per_batch): no ragged tile per slide, no tail launch."""
@@ -201,7 +209,7 @@ def linear_fused(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],
         raise MirrorHipError("linear_fused: out must be contiguous [B * R, N]")
     d = GemmDesc()
     d.A, d.B, d.C, d.bias = x.data_ptr() + r0 * Kd * 2, w.data_ptr(), out.data_ptr(), _p(bias)
-    d.M, d.N, d.K = Bn * R, N, Kd
+    d.M, d.N, d.K = (Bn * R if m_rows is None else int(m_rows)), N, Kd      # m_rows: only the first m_rows flat rows (see linear_fused_tail)
     d.lda, d.ldb, d.ldc = Kd, Kd, N
     d.a_kc, d.b_kc = 1, 1
     d.dtA, d.dtB, d.dtC, d.mma = MH_BF16, MH_BF16, dt(out), MH_BF16
