@@ -454,6 +454,246 @@ __global__ __launch_bounds__(NTB) void gemm_big_kernel(GemmArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// gemm_pp_kernel: the same 256 x 256 x 64 tile and wave grid, a different main loop (cdna_hip_programming.md §5: direct-to-LDS
+// staging, counted waits, raw barriers, the two wave rows in ping-pong).
+//   * staging: global_load_lds_dwordx4 (1 KiB per wave instruction, no staging registers, no ds_write pass).  The LDS images are
+//     lane-linear, the bank swizzle sits in the per-lane SOURCE address and in the fragment reads (rule 21):
+//       K-contiguous operand: [256 rows][128 B], 16-byte chunk c of row r stored at chunk c ^ ((r >> 1) & 7)  -> ds_read_b128 conflict free
+//       K-strided operand   : [64 k][512 B], byte offset o of row k stored at o ^ ((k & 3) << 6)             -> ds_read_b64_tr_b16 conflict free
+//   * two LDS stages; tile t + 1 is requested during k-steps 0 and 1 of tile t (4 pieces per wave each) and waited for with
+//     vmcnt(0) at the end of k-step 3, when nothing younger is in flight: >= 2 k-steps (~1000 cycles) of MFMA time cover the latency.
+//   * a k-step = LOAD segment (6 fragment reads, the stage requests) | barrier | COMPUTE segment (8 MFMAs) | barrier; waves 4-7 run
+//     one barrier behind waves 0-3, so on every SIMD one wave computes while its partner loads (the matrix pipe is never left idle
+//     by the fragment reads, and the two groups' LDS bursts do not collide).
+// Epilogues, XCD order, split-K partials and the fused epilogues are gemm_big_kernel's.
+constexpr int PP_OP = BIG * 64 * 2;          // bytes of one operand tile image
+constexpr int PP_STAGE = 2 * PP_OP;
+constexpr int PP_LDS = 136 * 1024;           // 2 stages (128 KiB); the epilogue images (133120 B + reduction scratch) reuse them
+typedef __attribute__((address_space(3))) void pp_lds_t;
+typedef __attribute__((address_space(1))) const void pp_glb_t;
+
+#define PP_GLDS(gp, lp, off) __builtin_amdgcn_global_load_lds((pp_glb_t*)(gp), (pp_lds_t*)(lp), 16, (off), 0)
+
+// one operand tile = 32 pieces of 1 KiB; wave w requests pieces 4 w .. 4 w + 3
+template <bool KC>
+struct PPStage {
+    const bf16_t* p0;      // this lane's source address for piece 0 of its wave at k0 = kbeg (even-piece swizzle)
+    const bf16_t* p1;      // ... with the odd-piece swizzle
+    long step;             // elements between two pieces of this wave
+    long kadv;             // elements per K-tile
+    // rows: tile rows for KC (clamped to dim - 1, optional batch-window remap), k rows for KS
+    __device__ __forceinline__ void init(const bf16_t* base, long ld, int tile0, int dim, int kbeg, int wave, int lane, int adj0, int bnd, int skip) {
+        if constexpr (KC) {
+            // piece i of wave w = rows 32 w + 8 i + (lane >> 3); LDS chunk lane & 7 holds source chunk (lane & 7) ^ ((row >> 1) & 7),
+            // (row >> 1) & 7 = (4 i + (lane >> 4)) & 7: two variants (i even / odd)
+            const int r = 32 * wave + (lane >> 3);
+            const int c0 = (lane & 7) ^ ((lane >> 4) & 7), c1 = c0 ^ 4;
+            // rows are clamped / remapped per piece below: keep the row-independent part here
+            p0 = base + kbeg + c0 * 8;
+            p1 = base + kbeg + c1 * 8;
+            step = ld;
+            kadv = 64;
+            row0_ = r; tile0_ = tile0; dim_ = dim; adj0_ = adj0; bnd_ = bnd; skip_ = skip;
+        } else {
+            // piece i of wave w = k rows 8 w + 2 i + (lane >> 5); LDS 16-byte chunk lane & 31 holds source chunk (lane & 31) ^ ((k & 3) << 2),
+            // k & 3 = (2 i + (lane >> 5)) & 3: two variants (i even / odd)
+            const int k = 8 * wave + (lane >> 5);
+            const int c0 = (lane & 31) ^ (((lane >> 5) & 3) << 2), c1 = (lane & 31) ^ (((2 + (lane >> 5)) & 3) << 2);
+            p0 = base + (long)(kbeg + k) * ld + tile0 + c0 * 8;
+            p1 = base + (long)(kbeg + k) * ld + tile0 + c1 * 8;
+            step = 2 * ld;
+            kadv = 64 * ld;
+            row0_ = 0; tile0_ = 0; dim_ = 0; adj0_ = 0; bnd_ = 0; skip_ = 0;
+        }
+    }
+    int row0_, tile0_, dim_, adj0_, bnd_, skip_;
+    // request K-tile t of this operand into the LDS image `img` (this wave's four pieces)
+    __device__ __forceinline__ void issue(char* img, int wave, int t) const {
+        char* dst = img + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const bf16_t* src;
+            if constexpr (KC) {
+                const int rl = min(tile0_ + row0_ + 8 * i, dim_ - 1) - tile0_;
+                const long row = tile0_ + rl + adj0_ + (rl >= bnd_ ? skip_ : 0);
+                src = ((i & 1) ? p1 : p0) + row * step + (long)t * kadv;
+            } else {
+                src = ((i & 1) ? p1 : p0) + (long)i * step + (long)t * kadv;
+            }
+            PP_GLDS(src, dst + i * 1024, 0);
+        }
+    }
+};
+
+// fragment of row block `rb` (32 rows) at k-step s of a K-contiguous image: lane offset table off[s], block stride 4096 B
+__device__ __forceinline__ bf16x8 pp_frag_kc(const char* img, const unsigned (&off)[4], int rb, int s) {
+    return *reinterpret_cast<const bf16x8*>(img + off[s] + rb * 4096);
+}
+// ... of a K-strided image: `off` = the lane's offset for this 32-column block (pp_ks_off), k-step stride 8192 B, second 4-row group + 2048 B
+__device__ __forceinline__ bf16x8 pp_frag_ks(const char* img, unsigned off, int s) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const char* a0 = img + off + s * 8192;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 2048));
+    s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+// ds_read_b64_tr_b16 address of this lane for 32-column block cb (0..7) of a K-strided image at k-step 0: lane 4 q + p of a 16-lane
+// group supplies k row q (+ 8 for the upper lane half), columns 4 p .. 4 p + 3 of the group's 16 columns; the 64-byte column group
+// index is XORed with the k row (k & 3 = q)
+__device__ __forceinline__ unsigned pp_ks_off(int cb, int lane) {
+    const int g16 = lane >> 4, q = (lane & 15) >> 2, p4 = lane & 3;
+    return (8 * (g16 >> 1) + q) * 512 + (cb >> 2) * 256 + (((cb & 3) ^ q) << 6) + 32 * (g16 & 1) + 8 * p4;
+}
+
+template <typename TC, bool AKC, bool BKC, bool PART = false, int EPI = 0>
+__global__ __launch_bounds__(NTB) void gemm_pp_kernel(GemmArgs g) {
+    static_assert(EPI == 0 || (AKC && !PART), "fused epilogues: K-contiguous A, no split-K");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int tiles = gridDim.x, nwg = tiles * gridDim.y * gridDim.z;
+    const int lin = blockIdx.x + tiles * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int xcd = lin & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int unit = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
+    const int wgid = unit % tiles, slice = unit / tiles;
+    const int tile_m = wgid / g.tiles_n, tile_n = wgid % g.tiles_n;
+    const int z = slice / (int)gridDim.y;
+    const int b1 = z / g.batch2, b2 = z % g.batch2;
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A) + b1 * g.sA1 + b2 * g.sA2;
+    const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B) + b1 * g.sB1 + b2 * g.sB2;
+    TC* C = reinterpret_cast<TC*>(g.C) + b1 * g.sC1 + b2 * g.sC2;
+    const int split = slice % (int)gridDim.y;
+    const int kbeg = split * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+    const int nt = (kend - kbeg) / 64;
+
+    int adj0 = 0, bnd = 1 << 30;
+    if constexpr (EPI != 0) {
+        if (g.a_rpb > 0) {
+            const int bq = (tile_m * BIG) / g.a_rpb;
+            adj0 = bq * g.a_skip;
+            bnd = (bq + 1) * g.a_rpb - tile_m * BIG;
+        }
+    }
+    PPStage<AKC> sa;
+    PPStage<BKC> sb;
+    sa.init(A, g.lda, tile_m * BIG, g.M, kbeg, wave, lane, adj0, bnd, g.a_skip);
+    sb.init(B, g.ldb, tile_n * BIG, g.N, kbeg, wave, lane, 0, 1 << 30, 0);
+
+    // fragment read offsets (lane-dependent part; see the image layouts above): K-contiguous: one per k-step, the row block is an
+    // immediate; K-strided: one per 32-column block of this wave, the k-step is an immediate
+    unsigned offa[4], offb[4];
+    if constexpr (AKC) {
+        const int r = lane & 31, h = lane >> 5, f = (r >> 1) & 7;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) offa[s4] = wm * 4 * 4096 + r * 128 + (((2 * s4 + h) ^ f) << 4);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) offa[i] = pp_ks_off(wm * 4 + i, lane);
+    }
+    if constexpr (BKC) {
+        const int r = lane & 31, h = lane >> 5, f = (r >> 1) & 7;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) offb[s4] = wn * 2 * 4096 + r * 128 + (((2 * s4 + h) ^ f) << 4);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 2; j++) offb[j] = pp_ks_off(wn * 2 + j, lane);
+        offb[2] = offb[3] = 0;
+    }
+
+    f32x16 acc[BWM][BWN];
+#pragma unroll
+    for (int i = 0; i < BWM; i++)
+#pragma unroll
+        for (int j = 0; j < BWN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    if (nt > 0) {
+        sa.issue(smem, wave, 0);
+        sb.issue(smem + PP_OP, wave, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();          // waves 4-7 run one barrier behind waves 0-3
+#pragma unroll 1
+    for (int t = 0; t < nt; t++) {
+        const char* at = smem + (t & 1) * PP_STAGE;
+        const char* bt = at + PP_OP;
+        char* an = smem + ((t + 1) & 1) * PP_STAGE;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            // ---- LOAD segment
+            bf16x8 af[BWM], bfr[BWN];
+#pragma unroll
+            for (int j = 0; j < BWN; j++) {
+                if constexpr (BKC) bfr[j] = pp_frag_kc(bt, offb, j, s);
+                else bfr[j] = pp_frag_ks(bt, offb[j], s);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < BWM; i++) {
+                if constexpr (AKC) af[i] = pp_frag_kc(at, offa, i, s);
+                else af[i] = pp_frag_ks(at, offa[i], s);
+            }
+            if (t + 1 < nt) {
+                if (s == 0) sa.issue(an, wave, t + 1);
+                if (s == 1) sb.issue(an + PP_OP, wave, t + 1);
+            }
+            if (s == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile t + 1 (requested two k-steps ago) has landed
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- COMPUTE segment
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < BWM; i++)
+#pragma unroll
+                for (int j = 0; j < BWN; j++) {
+                    if constexpr (sizeof(TC) == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // C^T
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    if constexpr (EPI != 0) {
+        if constexpr (sizeof(TC) == 2) epilogue_big_t<0, EPI>(g, C, acc, smem, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, true, g.alpha);
+        else epilogue_big<TC, 0, EPI>(g, C, acc, smem, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, true, g.ldc, g.alpha);
+        return;
+    }
+    const bool lead = (split == 0);
+    if constexpr (sizeof(TC) == 2) {
+        if (g.accumulate) epilogue_big_t<1>(g, C, acc, smem, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, lead, g.alpha);
+        else epilogue_big_t<0>(g, C, acc, smem, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, lead, g.alpha);
+        return;
+    }
+    if constexpr (PART) {
+        if constexpr (sizeof(TC) == 4) {
+            float* P = g.ws + ((long)z * gridDim.y + split) * (long)g.M * g.N;
+            epilogue_big<float, 0>(g, P, acc, smem, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, false, (long)g.N, g.alpha);
+        }
+        return;
+    }
+    if (g.atomic) {
+        if constexpr (sizeof(TC) == 4)
+            epilogue_atomic_big(g, C, acc, tile_m * BIG + wm * BWM * 32, tile_n * BIG + wn * BWN * 32, lane);
+    } else if (g.accumulate) {
+        epilogue_big<TC, 1>(g, C, acc, smem, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, lead, g.ldc, g.alpha);
+    } else {
+        epilogue_big<TC, 0>(g, C, acc, smem, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, lead, g.ldc, g.alpha);
+    }
+}
+
 // C[r][c] += sum_p P[p][r][c]: quads, 8 partials in flight
 __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restrict__ P, int parts, long mn, float* __restrict__ C, long ldc,
                                                             int N) {
@@ -473,11 +713,52 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restr
     }
 }
 
+// MH_GEMM_PP=0 keeps every launch on gemm_big_kernel (A/B switch; default: the ping-pong kernel)
+static int g_pp = -1;
+static bool pp_enabled() {
+    if (g_pp < 0) { const char* e = getenv("MH_GEMM_PP"); g_pp = !(e && e[0] == '0'); }
+    return g_pp != 0;
+}
+template <typename K>
+static void pp_attr(K kern) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+}
+#define PP_LAUNCH_(TC, AKC, BKC, PART, EPI, grid, s, a)                                              \
+    do {                                                                                             \
+        static const bool attr_ = (pp_attr(gemm_pp_kernel<TC, AKC, BKC, PART, EPI>), true);          \
+        (void)attr_;                                                                                 \
+        hipLaunchKernelGGL((gemm_pp_kernel<TC, AKC, BKC, PART, EPI>), grid, dim3(NTB), PP_LDS, s, a); \
+    } while (0)
+
 template <typename TC>
 void launch_big(GemmArgs& a, int akc, int bkc, int batch, hipStream_t s) {
     a.tiles_m = (a.M + BIG - 1) / BIG;     // a ragged last row tile is allowed when A rows are K-contiguous
     a.tiles_n = a.N / BIG;
     dim3 grid(a.tiles_m * a.tiles_n, a.split_k, batch);
+    if (pp_enabled()) {
+        const long parts_ = (long)a.split_k * batch, mn_ = (long)a.M * a.N;
+        const bool partial_ = a.atomic && a.ws && a.M % BIG == 0 && a.ws_floats >= parts_ * mn_ && ((uintptr_t)a.ws & 15) == 0 && a.vecC &&
+                              a.sC1 == 0 && a.sC2 == 0 && parts_ >= 8;
+        if (!partial_) a.ws = nullptr;
+#define PP_DISPATCH_(PART)                                                                 \
+        do {                                                                               \
+            if (akc && bkc) PP_LAUNCH_(TC, true, true, PART, 0, grid, s, a);               \
+            else if (akc) PP_LAUNCH_(TC, true, false, PART, 0, grid, s, a);                \
+            else if (bkc) PP_LAUNCH_(TC, false, true, PART, 0, grid, s, a);                \
+            else PP_LAUNCH_(TC, false, false, PART, 0, grid, s, a);                        \
+        } while (0)
+        if constexpr (sizeof(TC) == 4) {
+            if (partial_) {
+                PP_DISPATCH_(true);
+                hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)min((long)mh_cdiv(mn_ / 4, 256), 2048L)), dim3(256), 0, s, (const float*)a.ws,
+                                   (int)parts_, mn_, (float*)a.C, (long)a.ldc, a.N);
+                return;
+            }
+        }
+        PP_DISPATCH_(false);
+#undef PP_DISPATCH_
+        return;
+    }
     // reduction into one C: partial tiles in the caller's workspace when it is large enough, f32 atomics otherwise
     const long parts = (long)a.split_k * batch, mn = (long)a.M * a.N;
     const bool partial = a.atomic && a.ws && a.M % BIG == 0 && a.ws_floats >= parts * mn && ((uintptr_t)a.ws & 15) == 0 && a.vecC &&
@@ -501,6 +782,13 @@ void launch_big(GemmArgs& a, int akc, int bkc, int batch, hipStream_t s) {
 }
 
 }  // namespace
+
+// tuning switch (tools/bench_gemm_pp.py A/B in one process): 1 = ping-pong kernel (default), 0 = gemm_big_kernel; returns the old value
+extern "C" int mh_gemm_select_pp(int on) {
+    const int old = pp_enabled() ? 1 : 0;
+    g_pp = on ? 1 : 0;
+    return old;
+}
 
 // e4m3 operands (K contiguous, described in 2-byte units: K, lda, ldb, strides are HALF the byte counts): true when taken
 bool gemm_try_big_fp8(GemmArgs& a, int dtC, int batch, hipStream_t s) {
@@ -527,7 +815,8 @@ const char* gemm_big_epi(GemmArgs& a, int akc, int bkc, int dtC, int batch, hipS
     a.tiles_n = a.N / BIG;
     dim3 grid(a.tiles_m * a.tiles_n, 1, 1);
 #define EPI_LAUNCH_(TC, EPI) \
-    do { if (bkc) hipLaunchKernelGGL((gemm_big_kernel<TC, true, true, false, false, EPI>), grid, dim3(NTB), 0, s, a); \
+    do { if (pp_enabled()) { if (bkc) PP_LAUNCH_(TC, true, true, false, EPI, grid, s, a); else PP_LAUNCH_(TC, true, false, false, EPI, grid, s, a); } \
+         else if (bkc) hipLaunchKernelGGL((gemm_big_kernel<TC, true, true, false, false, EPI>), grid, dim3(NTB), 0, s, a); \
          else hipLaunchKernelGGL((gemm_big_kernel<TC, true, false, false, false, EPI>), grid, dim3(NTB), 0, s, a); } while (0)
     switch (e.kind) {
     case MH_EPI_DROPADD:
@@ -535,7 +824,7 @@ const char* gemm_big_epi(GemmArgs& a, int akc, int bkc, int dtC, int batch, hipS
         EPI_LAUNCH_(float, MH_EPI_DROPADD);
         return nullptr;
     case MH_EPI_MASKPOS:
-        if (dtC != MH_F32 || !e.mask || !e.token || !e.pos || e.rows_per_batch <= 0 || e.first < 0 || a.M % e.rows_per_batch) return "MASKPOS: f32 C, mask / token / pos, M a multiple of rows_per_batch";
+        if (dtC != MH_F32 || !e.mask || !e.token || !e.pos || e.rows_per_batch <= 0 || e.first < 0) return "MASKPOS: f32 C, mask / token / pos, rows_per_batch > 0";
         if (((uintptr_t)e.token & 15) || ((uintptr_t)e.pos & 15)) return "MASKPOS: token / pos must be 16-byte aligned";
         EPI_LAUNCH_(float, MH_EPI_MASKPOS);
         return nullptr;
