@@ -116,9 +116,10 @@ typedef struct {
                                      `retention_head(x)[:, 1:]` run as ONE flat problem instead of a batched one with a ragged tile per slide */
 } mh_gemm_desc;
 int mh_gemm(const mh_gemm_desc* d, mh_stream s);
-/* Tuning switch for A/B timing in one process: which main loop the 256 x 256-tile launches use (1 = direct-to-LDS ping-pong kernel,
- * the default; 0 = register-staged kernel; env MH_GEMM_PP=0 selects 0 at start).  Results are identical.  Returns the previous value. */
-int mh_gemm_select_pp(int on);
+/* Tuning switch for A/B timing in one process: which main loop the 256 x 256-tile launches use (2 = persistent direct-to-LDS
+ * ping-pong kernel, the default; 1 = the same, one workgroup per tile; 0 = register-staged kernel; env MH_GEMM_PP selects one
+ * at start).  Results are identical up to the f32 summation order of split-K.  Returns the previous value. */
+int mh_gemm_select_pp(int mode);
 /* Bytes of `workspace` with which this call reduces through plain partial tiles + a fold pass instead of f32 atomics
  * (0: the call has no use for one — no split-K / batch broadcast, or the shape is not on the large-tile kernel). */
 int64_t mh_gemm_workspace_bytes(const mh_gemm_desc* d);

@@ -694,6 +694,348 @@ __global__ __launch_bounds__(NTB) void gemm_pp_kernel(GemmArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// gemm_pq_kernel: gemm_pp_kernel made PERSISTENT — one workgroup per CU walks its share of the (tile, K-slice) units.
+// The projection / gradient GEMMs of the step have K = 512 ... 1536: 8 ... 24 K-tiles per output tile, so with one launch-scheduled
+// workgroup per tile a third of the time went to per-tile fixed costs with the matrix pipe idle — the first K-tile's load latency,
+// and an epilogue whose 128 KiB of C stores had to drain before the CU could take its next tile, with all 256 CUs in that phase
+// at the same moment (an HBM write burst, then an HBM-idle K loop).  Here
+//   * the stage pipeline runs ACROSS units: the next unit's first K-tile is requested during the last K-tile of the current one;
+//   * the epilogue stages C through the LDS stage it has just consumed (half a tile at a time for bf16, a quarter for f32: 66.5 KiB
+//     in a 68 KiB slot) while the other stage already holds the next unit's first K-tile;
+//   * the C stores are only ISSUED in the epilogue: they drain underneath the next unit's K loop.
+// vmcnt counts stores and loads together, in order: the first wait of a unit's K loop (end of K-tile 0) also waits for the
+// stores issued ~1 us earlier; what is left of their drain time is the only exposed part of the epilogue's memory traffic.
+constexpr int PQ_SLOT = 68 * 1024;            // LDS stage slot: A image 32 KiB | B image 32 KiB | 4 KiB that only the C staging uses
+constexpr int PQ_LDS = 2 * PQ_SLOT;
+
+// bf16 C (accumulators hold C^T: a lane owns 4 consecutive columns of a row): rows [128 half, +128) of the tile through `t`
+template <int MODE, int EPI>
+__device__ __forceinline__ void pq_epilogue_bf16(const GemmArgs& g, bf16_t* C, f32x16 (&acc)[BWM][BWN], char* smem_c, int tile_row0, int tile_col0,
+                                                 int wm, int wn, int lane, int tid, bool lead, float alpha) {
+    constexpr int PITCH = BIG + 4, HALF = BIG / 2;
+    bf16_t* t = reinterpret_cast<bf16_t*>(smem_c);
+    const int r = lane & 31, hh = lane >> 5;
+    const bool has_bias = g.bias && lead;
+    float sq_sum = 0.f, sq_cnt = 0.f;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        if (wm == half) {
+#pragma unroll
+            for (int j = 0; j < BWN; j++)
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++) {
+                    const int lc = wn * BWN * 32 + 32 * j + 8 * gq + 4 * hh;
+                    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                    if (has_bias) bv = *reinterpret_cast<const f32x4*>(g.bias + tile_col0 + lc);
+#pragma unroll
+                    for (int i = 0; i < BWM; i++) {
+                        const int lr = 32 * i + r;
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            v[e] = alpha * acc[i][j][4 * gq + e] + bv[e];
+                            if (g.act == MH_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+                        }
+                        u32x2 o;
+                        o[0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+                        o[1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                        *reinterpret_cast<u32x2*>(t + lr * PITCH + lc) = o;
+                    }
+                }
+        }
+        __syncthreads();
+        constexpr int CPR = BIG / 8;                 // 16-byte chunks per tile row
+        constexpr int NCH = HALF * CPR / NTB;
+#pragma unroll
+        for (int i = 0; i < NCH; i++) {
+            const int cid = tid + i * NTB;
+            const int lr = cid / CPR, c = cid % CPR;
+            const int grow = tile_row0 + half * HALF + lr;
+            if (grow >= g.M) continue;               // ragged last row tile (K-contiguous A only)
+            bf16_t* dst = C + (long)grow * g.ldc + tile_col0 + c * 8;
+            u32x2 lo = *reinterpret_cast<const u32x2*>(t + lr * PITCH + c * 8);
+            u32x2 hi = *reinterpret_cast<const u32x2*>(t + lr * PITCH + c * 8 + 4);
+            u32x4 o = {lo[0], lo[1], hi[0], hi[1]};
+            if constexpr (MODE == 1) {
+                const u32x4 old = *reinterpret_cast<const u32x4*>(dst);
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    const float a0 = __uint_as_float(o[w] << 16) + __uint_as_float(old[w] << 16);
+                    const float a1 = __uint_as_float(o[w] & 0xffff0000u) + __uint_as_float(old[w] & 0xffff0000u);
+                    o[w] = (unsigned)f2bf(a0) | ((unsigned)f2bf(a1) << 16);
+                }
+            }
+            *reinterpret_cast<u32x4*>(dst) = o;
+            if constexpr (EPI == MH_EPI_SQERR) {
+                const int rpb = g.epi.rows_per_batch;             // % 256 == 0: a tile lies inside one batch
+                const long b = tile_row0 / rpb;
+                const int tt = grow - (int)(b * rpb);
+                if (g.epi.mask[b * rpb + tt] != 0.f) {
+                    const float* tg = g.epi.tgt + b * g.epi.tgt_bs + (long)tt * g.N + tile_col0 + c * 8;
+                    const f32x4 t0 = *reinterpret_cast<const f32x4*>(tg), t1 = *reinterpret_cast<const f32x4*>(tg + 4);
+#pragma unroll
+                    for (int w = 0; w < 4; w++) {
+                        const float d0 = __uint_as_float(o[w] << 16) - (w < 2 ? t0[2 * w] : t1[2 * w - 4]);
+                        const float d1 = __uint_as_float(o[w] & 0xffff0000u) - (w < 2 ? t0[2 * w + 1] : t1[2 * w - 3]);
+                        sq_sum += d0 * d0 + d1 * d1;
+                    }
+                    sq_cnt += 8.f;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if constexpr (EPI == MH_EPI_SQERR) {
+        float* red = reinterpret_cast<float*>(smem_c + HALF * PITCH * 2);     // behind the half-tile image (66560 of 69632 bytes)
+        sq_sum = wave_sum(sq_sum);
+        sq_cnt = wave_sum(sq_cnt);
+        if (lane == 0) { red[2 * (tid >> 6)] = sq_sum; red[2 * (tid >> 6) + 1] = sq_cnt; }
+        __syncthreads();
+        if (tid == 0) {
+            float a = 0.f, n = 0.f;
+#pragma unroll
+            for (int w = 0; w < NTB / 64; w++) { a += red[2 * w]; n += red[2 * w + 1]; }
+            const float inv = 1.f / (float)g.N;
+            atomicAdd(g.epi.sq, a * inv);
+            atomicAdd(g.epi.sq + 1, n * inv);
+        }
+        __syncthreads();
+    }
+}
+
+// f32 C (a lane owns a column, its registers the rows): rows [64 q, +64) of the tile through `t`, q = 0 .. 3
+template <int MODE, int EPI>
+__device__ __forceinline__ void pq_epilogue_f32(const GemmArgs& g, float* C, f32x16 (&acc)[BWM][BWN], char* smem_c, int tile_row0, int tile_col0,
+                                                int wm, int wn, int lane, int tid, bool lead, long ldc, float alpha) {
+    constexpr int PITCH = BIG + 4, QR = BIG / 4;
+    float* t = reinterpret_cast<float*>(smem_c);
+    const int r = lane & 31, hh = lane >> 5;
+    uint64_t drop_blk0 = 0;
+    uint32_t thr = 0;
+    float dscale = 1.f;
+    if constexpr (EPI == MH_EPI_DROPADD) {
+        uint64_t off = g.epi.offset;
+        if (g.epi.dev_base) off += *g.epi.dev_base & ~7ull;
+        drop_blk0 = off >> 3;
+        thr = drop16_thr(g.epi.p);
+        dscale = drop16_scale(thr);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        if (wm == (q >> 1)) {
+#pragma unroll
+            for (int j = 0; j < BWN; j++) {
+                const int lc = wn * BWN * 32 + j * 32 + r;
+                const float bias = (g.bias && lead) ? g.bias[tile_col0 + lc] : 0.f;
+#pragma unroll
+                for (int i2 = 0; i2 < 2; i2++) {
+                    const int lr0 = i2 * 32 + 4 * hh;
+#pragma unroll
+                    for (int reg = 0; reg < 16; reg++) {
+                        const int lr = lr0 + (reg & 3) + 8 * (reg >> 2);
+                        float v = alpha * acc[2 * (q & 1) + i2][j][reg] + bias;
+                        if (g.act == MH_ACT_RELU) v = fmaxf(v, 0.f);
+                        t[lr * PITCH + lc] = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if constexpr (EPI == MH_EPI_DROPADD) {
+            constexpr int CPR8 = BIG / 8, NCH8 = QR * CPR8 / NTB;
+#pragma unroll
+            for (int i = 0; i < NCH8; i++) {
+                const int cid = tid + i * NTB;
+                const int lr = cid / CPR8, c = cid % CPR8;
+                const int grow = tile_row0 + q * QR + lr, gcol = tile_col0 + c * 8;
+                if (grow >= g.M) continue;
+                const float* src = t + lr * PITCH + c * 8;
+                const float* rp = g.epi.resid + (long)grow * g.N + gcol;
+                f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+                const f32x4 x0 = round_bf16_4(*reinterpret_cast<const f32x4*>(src)), x1 = round_bf16_4(*reinterpret_cast<const f32x4*>(src + 4));
+                const uint32_t keep = drop16_keep8(drop_blk0 + (((uint64_t)grow * (uint64_t)g.N + (uint64_t)gcol) >> 3), g.epi.seed, thr);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    r0[e] = __fadd_rn(r0[e], (keep & (1u << e)) ? __fmul_rn(x0[e], dscale) : 0.f);
+                    r1[e] = __fadd_rn(r1[e], (keep & (16u << e)) ? __fmul_rn(x1[e], dscale) : 0.f);
+                }
+                float* dst = C + (long)grow * ldc + gcol;
+                *reinterpret_cast<f32x4*>(dst) = r0;
+                *reinterpret_cast<f32x4*>(dst + 4) = r1;
+            }
+        } else {
+            constexpr int CPR = BIG / 4, NCH = QR * CPR / NTB;
+#pragma unroll
+            for (int i = 0; i < NCH; i++) {
+                const int cid = tid + i * NTB;
+                const int lr = cid / CPR, c = cid % CPR;
+                const int grow = tile_row0 + q * QR + lr;
+                if (grow >= g.M) continue;
+                float* dst = C + (long)grow * ldc + tile_col0 + c * 4;
+                f32x4 x0 = *reinterpret_cast<const f32x4*>(t + lr * PITCH + c * 4);
+                if constexpr (EPI != 0) x0 = epi_quad<EPI>(g, x0, grow, tile_col0 + c * 4);
+                if constexpr (MODE == 1) x0 += *reinterpret_cast<const f32x4*>(dst);
+                *reinterpret_cast<f32x4*>(dst) = x0;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <typename TC, bool AKC, bool BKC, bool PART = false, int EPI = 0>
+__global__ __launch_bounds__(NTB) void gemm_pq_kernel(GemmArgs g, int units, int tiles, int splits) {
+    static_assert(EPI == 0 || (AKC && !PART), "fused epilogues: K-contiguous A, no split-K");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int q8 = units >> 3, r8 = units & 7;
+
+    // fragment read offsets within a stage slot (as gemm_pp_kernel)
+    unsigned offa[4], offb[4];
+    if constexpr (AKC) {
+        const int r = lane & 31, h = lane >> 5, f = (r >> 1) & 7;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) offa[s4] = wm * 4 * 4096 + r * 128 + (((2 * s4 + h) ^ f) << 4);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) offa[i] = pp_ks_off(wm * 4 + i, lane);
+    }
+    if constexpr (BKC) {
+        const int r = lane & 31, h = lane >> 5, f = (r >> 1) & 7;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) offb[s4] = wn * 2 * 4096 + r * 128 + (((2 * s4 + h) ^ f) << 4);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 2; j++) offb[j] = pp_ks_off(wn * 2 + j, lane);
+        offb[2] = offb[3] = 0;
+    }
+
+    // unit v of this workgroup -> (tile_m, tile_n, batch z, K-slice): XCD-aware order over all units (see gemm_big_kernel); the
+    // workgroups of one launch run on XCD blockIdx.x % 8, and v = blockIdx.x + k gridDim.x keeps that residue when gridDim.x % 8 == 0
+    PPStage<AKC> sa, sa_n;
+    PPStage<BKC> sb, sb_n;
+    int tile_m = 0, tile_n = 0, z = 0, split = 0, nt = 0;
+    int n_tile_m = 0, n_tile_n = 0, n_z = 0, n_split = 0, n_nt = 0;
+    auto decode = [&](int v, int& tm, int& tn, int& zz, int& sp, int& ntl, PPStage<AKC>& pa, PPStage<BKC>& pb) {
+        const int xcd = v & 7;
+        const int unit = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (v >> 3);
+        const int wgid = unit % tiles, slice = unit / tiles;
+        tm = wgid / g.tiles_n; tn = wgid % g.tiles_n;
+        zz = slice / splits; sp = slice % splits;
+        const int b1 = zz / g.batch2, b2 = zz % g.batch2;
+        const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A) + b1 * g.sA1 + b2 * g.sA2;
+        const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B) + b1 * g.sB1 + b2 * g.sB2;
+        const int kbeg = sp * g.k_per_split;
+        ntl = (min(g.K, kbeg + g.k_per_split) - kbeg) / 64;
+        int adj0 = 0, bnd = 1 << 30;
+        if constexpr (EPI != 0) {
+            if (g.a_rpb > 0) {
+                const int bq = (tm * BIG) / g.a_rpb;
+                adj0 = bq * g.a_skip;
+                bnd = (bq + 1) * g.a_rpb - tm * BIG;
+            }
+        }
+        pa.init(A, g.lda, tm * BIG, g.M, kbeg, wave, lane, adj0, bnd, g.a_skip);
+        pb.init(B, g.ldb, tn * BIG, g.N, kbeg, wave, lane, 0, 1 << 30, 0);
+    };
+
+    int v = blockIdx.x;
+    if (v >= units) return;
+    decode(v, tile_m, tile_n, z, split, nt, sa, sb);
+    int ctr = 0;                                   // K-tiles consumed so far: stage = ctr & 1
+    if (nt > 0) {
+        sa.issue(smem, wave, 0);
+        sb.issue(smem + PP_OP, wave, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+    for (; v < units; v += gridDim.x) {
+        const int vn = v + gridDim.x;
+        const bool has_next = vn < units;
+        if (has_next) decode(vn, n_tile_m, n_tile_n, n_z, n_split, n_nt, sa_n, sb_n);
+        f32x16 acc[BWM][BWN];
+#pragma unroll
+        for (int i = 0; i < BWM; i++)
+#pragma unroll
+            for (int j = 0; j < BWN; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+        if (wm == 1) __builtin_amdgcn_s_barrier();          // waves 4-7 run one barrier behind waves 0-3 inside the K loop
+#pragma unroll 1
+        for (int t = 0; t < nt; t++, ctr++) {
+            const char* at = smem + (ctr & 1) * PQ_SLOT;
+            const char* bt = at + PP_OP;
+            char* an = smem + ((ctr + 1) & 1) * PQ_SLOT;
+            const bool last = t + 1 == nt;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                bf16x8 af[BWM], bfr[BWN];
+#pragma unroll
+                for (int j = 0; j < BWN; j++) {
+                    if constexpr (BKC) bfr[j] = pp_frag_kc(bt, offb, j, s);
+                    else bfr[j] = pp_frag_ks(bt, offb[j], s);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < BWM; i++) {
+                    if constexpr (AKC) af[i] = pp_frag_kc(at, offa, i, s);
+                    else af[i] = pp_frag_ks(at, offa[i], s);
+                }
+                if (!last) {
+                    if (s == 0) sa.issue(an, wave, t + 1);
+                    if (s == 1) sb.issue(an + PP_OP, wave, t + 1);
+                } else if (has_next && n_nt > 0) {          // the next unit's first K-tile: the pipeline runs across units
+                    if (s == 0) sa_n.issue(an, wave, 0);
+                    if (s == 1) sb_n.issue(an + PP_OP, wave, 0);
+                }
+                if (s == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < BWM; i++)
+#pragma unroll
+                    for (int j = 0; j < BWN; j++) {
+                        if constexpr (sizeof(TC) == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // C^T
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    }
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (wm == 0) __builtin_amdgcn_s_barrier();          // both wave rows level again
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- epilogue through the stage just consumed; the other one holds the next unit's first K-tile
+        char* cst = smem + ((ctr + 1) & 1) * PQ_SLOT;
+        const int b1 = z / g.batch2, b2 = z % g.batch2;
+        TC* C = reinterpret_cast<TC*>(g.C) + b1 * g.sC1 + b2 * g.sC2;
+        const bool lead = (split == 0);
+        if constexpr (EPI != 0) {
+            if constexpr (sizeof(TC) == 2) pq_epilogue_bf16<0, EPI>(g, C, acc, cst, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, true, g.alpha);
+            else pq_epilogue_f32<0, EPI>(g, C, acc, cst, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, true, g.ldc, g.alpha);
+        } else if constexpr (sizeof(TC) == 2) {
+            if (g.accumulate) pq_epilogue_bf16<1, 0>(g, C, acc, cst, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, lead, g.alpha);
+            else pq_epilogue_bf16<0, 0>(g, C, acc, cst, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, lead, g.alpha);
+        } else if constexpr (PART) {
+            float* P = g.ws + ((long)z * splits + split) * (long)g.M * g.N;
+            pq_epilogue_f32<0, 0>(g, P, acc, cst, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, false, (long)g.N, g.alpha);
+        } else {
+            if (g.atomic) epilogue_atomic_big(g, reinterpret_cast<float*>(C), acc, tile_m * BIG + wm * BWM * 32, tile_n * BIG + wn * BWN * 32, lane);
+            else if (g.accumulate) pq_epilogue_f32<1, 0>(g, reinterpret_cast<float*>(C), acc, cst, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, lead, g.ldc, g.alpha);
+            else pq_epilogue_f32<0, 0>(g, reinterpret_cast<float*>(C), acc, cst, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, lead, g.ldc, g.alpha);
+        }
+        __syncthreads();
+        tile_m = n_tile_m; tile_n = n_tile_n; z = n_z; split = n_split; nt = n_nt;
+        sa = sa_n; sb = sb_n;
+    }
+}
+
 // C[r][c] += sum_p P[p][r][c]: quads, 8 partials in flight
 __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restrict__ P, int parts, long mn, float* __restrict__ C, long ldc,
                                                             int N) {
@@ -714,10 +1056,17 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restr
 }
 
 // MH_GEMM_PP=0 keeps every launch on gemm_big_kernel (A/B switch; default: the ping-pong kernel)
+// which main loop the 256 x 256-tile launches use: 0 = gemm_big_kernel (register staging), 1 = gemm_pp_kernel (direct-to-LDS,
+// ping-pong), 2 = gemm_pq_kernel (the same, persistent: default).  env MH_GEMM_PP = 0 / 1 / 2, or mh_gemm_select_pp().
 static int g_pp = -1;
-static bool pp_enabled() {
-    if (g_pp < 0) { const char* e = getenv("MH_GEMM_PP"); g_pp = !(e && e[0] == '0'); }
-    return g_pp != 0;
+static int pp_mode() {
+    if (g_pp < 0) { const char* e = getenv("MH_GEMM_PP"); g_pp = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2; }
+    return g_pp;
+}
+static bool pp_enabled() { return pp_mode() != 0; }
+static int pq_grid(long units) {
+    static const int cus = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
+    return (int)(units < cus ? units : cus);
 }
 template <typename K>
 static void pp_attr(K kern) {
@@ -725,9 +1074,17 @@ static void pp_attr(K kern) {
 }
 #define PP_LAUNCH_(TC, AKC, BKC, PART, EPI, grid, s, a)                                              \
     do {                                                                                             \
-        static const bool attr_ = (pp_attr(gemm_pp_kernel<TC, AKC, BKC, PART, EPI>), true);          \
-        (void)attr_;                                                                                 \
-        hipLaunchKernelGGL((gemm_pp_kernel<TC, AKC, BKC, PART, EPI>), grid, dim3(NTB), PP_LDS, s, a); \
+        if (pp_mode() == 2) {                                                                        \
+            static const bool attrq_ = (pp_attr(gemm_pq_kernel<TC, AKC, BKC, PART, EPI>), true);     \
+            (void)attrq_;                                                                            \
+            const long units_ = (long)(grid).x * (grid).y * (grid).z;                                \
+            hipLaunchKernelGGL((gemm_pq_kernel<TC, AKC, BKC, PART, EPI>), dim3(pq_grid(units_)), dim3(NTB), PQ_LDS, s, a, (int)units_, \
+                               (int)(grid).x, (int)(grid).y);                                        \
+        } else {                                                                                     \
+            static const bool attr_ = (pp_attr(gemm_pp_kernel<TC, AKC, BKC, PART, EPI>), true);      \
+            (void)attr_;                                                                             \
+            hipLaunchKernelGGL((gemm_pp_kernel<TC, AKC, BKC, PART, EPI>), grid, dim3(NTB), PP_LDS, s, a); \
+        }                                                                                            \
     } while (0)
 
 template <typename TC>
@@ -783,10 +1140,11 @@ void launch_big(GemmArgs& a, int akc, int bkc, int batch, hipStream_t s) {
 
 }  // namespace
 
-// tuning switch (tools/bench_gemm_pp.py A/B in one process): 1 = ping-pong kernel (default), 0 = gemm_big_kernel; returns the old value
-extern "C" int mh_gemm_select_pp(int on) {
-    const int old = pp_enabled() ? 1 : 0;
-    g_pp = on ? 1 : 0;
+// tuning switch (tools/bench_gemm_pp.py A/B in one process): 2 = persistent ping-pong kernel (default), 1 = ping-pong kernel,
+// 0 = gemm_big_kernel; returns the old value
+extern "C" int mh_gemm_select_pp(int mode) {
+    const int old = pp_mode();
+    g_pp = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
     return old;
 }
 

@@ -38,22 +38,27 @@ def timeit(fn, reps=20):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
+MODES = ((2, "pq"), (1, "pp"), (0, "reg"))
+
+
 def run(name, make, flops, ref=None):
     res = {}
     for rnd in range(2):
-        for pp in (1, 0):
-            lib.mh_gemm_select_pp(pp)
+        for mode, _ in MODES:
+            lib.mh_gemm_select_pp(mode)
             fn = make()
             out = fn()
             torch.cuda.synchronize()
             err = ref(out) if (ref is not None and rnd == 0) else None
             us = timeit(fn)
-            res.setdefault(pp, []).append((us, err))
-    lib.mh_gemm_select_pp(1)
-    a, b = min(u for u, _ in res[1]), min(u for u, _ in res[0])
-    e1, e0 = res[1][0][1], res[0][0][1]
-    print(f"{name:58s} pp {a:7.1f} us {flops / a / 1e6:7.0f} TF/s | reg {b:7.1f} us {flops / b / 1e6:7.0f} TF/s | x{b / a:5.2f}"
-          + (f" | err pp {e1:.1e} reg {e0:.1e}" if e1 is not None else ""))
+            res.setdefault(mode, []).append((us, err))
+    lib.mh_gemm_select_pp(2)
+    best = {m: min(u for u, _ in res[m]) for m, _ in MODES}
+    line = f"{name:58s}"
+    for m, nm in MODES:
+        line += f" {nm} {best[m]:7.1f} us {flops / best[m] / 1e6:5.0f} TF/s |"
+    line += f" pq/reg x{best[0] / best[2]:4.2f} | err " + " ".join(f"{res[m][0][1]:.1e}" for m, _ in MODES)
+    print(line, flush=True)
 
 
 M, D = 69632, 512
