@@ -706,6 +706,53 @@ __global__ __launch_bounds__(NTB) void gemm_pp_kernel(GemmArgs g) {
 //   * the C stores are only ISSUED in the epilogue: they drain underneath the next unit's K loop.
 // vmcnt counts stores and loads together, in order: the first wait of a unit's K loop (end of K-tile 0) also waits for the
 // stores issued ~1 us earlier; what is left of their drain time is the only exposed part of the epilogue's memory traffic.
+// ---- stage layout of gemm_pq_kernel: every operand tile is TWO k-half sub-images of 16 KiB (k in [0, 32) and [32, 64) of the K-tile),
+// so that a segment of two k-steps reads one sub-image per operand and the other half can be in flight:
+//   K-contiguous: [256 rows][64 B], 16-byte chunk c of row r stored at chunk c ^ ((r >> 2) & 3)      (ds_read_b128 conflict free)
+//   K-strided   : [32 k][512 B], byte offset o of row k stored at o ^ ((k & 3) << 6)                 (ds_read_b64_tr_b16 conflict free)
+// slot = A_k0 | A_k1 | B_k0 | B_k1 (16 KiB each) | 4 KiB that only the C staging uses.  A sub-image = 16 pieces of 1 KiB: 2 per wave.
+constexpr int P2_SUB = 16 * 1024;
+template <bool KC>
+struct P2Stage {
+    const bf16_t* p0;      // this lane's source address of its wave's piece 0 of sub-image k0 at K-tile 0 (KS: the even-piece swizzle)
+    const bf16_t* p1;      // KS: the odd-piece swizzle; KC: piece 1 (row clamp / window remap applied per piece)
+    long kadv, hadv, step; // elements per K-tile, per k-half, (KS) per piece
+    __device__ __forceinline__ void init(const bf16_t* base, long ld, int tile0, int dim, int kbeg, int wave, int lane, int adj0, int bnd, int skip) {
+        if constexpr (KC) {
+            // piece i of wave w = rows 32 w + 16 i + (lane >> 2); LDS chunk lane & 3 holds source chunk (lane & 3) ^ ((row >> 2) & 3),
+            // (row >> 2) & 3 = (lane >> 4) & 3 for every piece
+            const int c = (lane & 3) ^ ((lane >> 4) & 3);
+            const bf16_t* b0 = base + kbeg + c * 8;
+            const int r0 = 32 * wave + (lane >> 2), r1 = r0 + 16;
+            const int l0 = min(tile0 + r0, dim - 1) - tile0, l1 = min(tile0 + r1, dim - 1) - tile0;
+            p0 = b0 + (long)(tile0 + l0 + adj0 + (l0 >= bnd ? skip : 0)) * ld;
+            p1 = b0 + (long)(tile0 + l1 + adj0 + (l1 >= bnd ? skip : 0)) * ld;
+            kadv = 64; hadv = 32; step = 0;
+        } else {
+            // piece i of wave w = k rows 4 w + 2 i + (lane >> 5) of the sub-image; LDS 16-byte chunk lane & 31 holds source chunk
+            // (lane & 31) ^ ((k & 3) << 2), k & 3 = (2 i + (lane >> 5)) & 3
+            const int k = 4 * wave + (lane >> 5);
+            const int c0 = (lane & 31) ^ (((lane >> 5) & 3) << 2), c1 = (lane & 31) ^ (((2 + (lane >> 5)) & 3) << 2);
+            p0 = base + (long)(kbeg + k) * ld + tile0 + c0 * 8;
+            p1 = base + (long)(kbeg + k + 2) * ld + tile0 + c1 * 8;
+            kadv = 64 * ld; hadv = 32 * ld; step = 0;
+        }
+    }
+    // request k-half kh of K-tile t into the sub-image at `sub` (this wave's two pieces)
+    __device__ __forceinline__ void issue(char* sub, int wave, int t, int kh) const {
+        char* dst = sub + wave * 2048;
+        const long o = (long)t * kadv + (long)kh * hadv;
+        PP_GLDS(p0 + o, dst, 0);
+        PP_GLDS(p1 + o, dst + 1024, 0);
+    }
+};
+// K-contiguous sub-image: fragment of row block rb (32 rows) at k-step ks (0 / 1) of the half: lane offset off[ks], block stride 2048 B
+__device__ __forceinline__ bf16x8 p2_frag_kc(const char* sub, const unsigned (&off)[2], int rb, int ks) {
+    return *reinterpret_cast<const bf16x8*>(sub + off[ks] + rb * 2048);
+}
+// K-strided sub-image: `off` = pp_ks_off of the 32-column block, k-step stride 8192 B, second 4-row group + 2048 B
+__device__ __forceinline__ bf16x8 p2_frag_ks(const char* sub, unsigned off, int ks) { return pp_frag_ks(sub, off, ks); }
+
 constexpr int PQ_SLOT = 68 * 1024;            // LDS stage slot: A image 32 KiB | B image 32 KiB | 4 KiB that only the C staging uses
 constexpr int PQ_LDS = 2 * PQ_SLOT;
 
@@ -892,33 +939,38 @@ __global__ __launch_bounds__(NTB) void gemm_pq_kernel(GemmArgs g, int units, int
     const int wm = wave >> 2, wn = wave & 3;
     const int q8 = units >> 3, r8 = units & 7;
 
-    // fragment read offsets within a stage slot (as gemm_pp_kernel)
+    // fragment read offsets within a sub-image: K-contiguous: one per k-step of the half (row block = immediate); K-strided: one per
+    // 32-column block of this wave (k-step = immediate)
     unsigned offa[4], offb[4];
     if constexpr (AKC) {
-        const int r = lane & 31, h = lane >> 5, f = (r >> 1) & 7;
-#pragma unroll
-        for (int s4 = 0; s4 < 4; s4++) offa[s4] = wm * 4 * 4096 + r * 128 + (((2 * s4 + h) ^ f) << 4);
+        const int r = lane & 31, h = lane >> 5, f = (r >> 2) & 3;
+        offa[0] = wm * 4 * 2048 + r * 64 + (((0 + h) ^ f) << 4);
+        offa[1] = wm * 4 * 2048 + r * 64 + (((2 + h) ^ f) << 4);
+        offa[2] = offa[3] = 0;
     } else {
 #pragma unroll
         for (int i = 0; i < 4; i++) offa[i] = pp_ks_off(wm * 4 + i, lane);
     }
     if constexpr (BKC) {
-        const int r = lane & 31, h = lane >> 5, f = (r >> 1) & 7;
-#pragma unroll
-        for (int s4 = 0; s4 < 4; s4++) offb[s4] = wn * 2 * 4096 + r * 128 + (((2 * s4 + h) ^ f) << 4);
+        const int r = lane & 31, h = lane >> 5, f = (r >> 2) & 3;
+        offb[0] = wn * 2 * 2048 + r * 64 + (((0 + h) ^ f) << 4);
+        offb[1] = wn * 2 * 2048 + r * 64 + (((2 + h) ^ f) << 4);
+        offb[2] = offb[3] = 0;
     } else {
 #pragma unroll
         for (int j = 0; j < 2; j++) offb[j] = pp_ks_off(wn * 2 + j, lane);
         offb[2] = offb[3] = 0;
     }
+    const unsigned (&offa2)[2] = reinterpret_cast<const unsigned (&)[2]>(offa);
+    const unsigned (&offb2)[2] = reinterpret_cast<const unsigned (&)[2]>(offb);
 
     // unit v of this workgroup -> (tile_m, tile_n, batch z, K-slice): XCD-aware order over all units (see gemm_big_kernel); the
     // workgroups of one launch run on XCD blockIdx.x % 8, and v = blockIdx.x + k gridDim.x keeps that residue when gridDim.x % 8 == 0
-    PPStage<AKC> sa, sa_n;
-    PPStage<BKC> sb, sb_n;
+    P2Stage<AKC> sa, sa_n;
+    P2Stage<BKC> sb, sb_n;
     int tile_m = 0, tile_n = 0, z = 0, split = 0, nt = 0;
     int n_tile_m = 0, n_tile_n = 0, n_z = 0, n_split = 0, n_nt = 0;
-    auto decode = [&](int v, int& tm, int& tn, int& zz, int& sp, int& ntl, PPStage<AKC>& pa, PPStage<BKC>& pb) {
+    auto decode = [&](int v, int& tm, int& tn, int& zz, int& sp, int& ntl, P2Stage<AKC>& pa, P2Stage<BKC>& pb) {
         const int xcd = v & 7;
         const int unit = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (v >> 3);
         const int wgid = unit % tiles, slice = unit / tiles;
@@ -946,8 +998,10 @@ __global__ __launch_bounds__(NTB) void gemm_pq_kernel(GemmArgs g, int units, int
     decode(v, tile_m, tile_n, z, split, nt, sa, sb);
     int ctr = 0;                                   // K-tiles consumed so far: stage = ctr & 1
     if (nt > 0) {
-        sa.issue(smem, wave, 0);
-        sb.issue(smem + PP_OP, wave, 0);
+        sa.issue(smem, wave, 0, 0);
+        sb.issue(smem + 2 * P2_SUB, wave, 0, 0);
+        sa.issue(smem + P2_SUB, wave, 0, 1);
+        sb.issue(smem + 3 * P2_SUB, wave, 0, 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -966,43 +1020,58 @@ __global__ __launch_bounds__(NTB) void gemm_pq_kernel(GemmArgs g, int units, int
         if (wm == 1) __builtin_amdgcn_s_barrier();          // waves 4-7 run one barrier behind waves 0-3 inside the K loop
 #pragma unroll 1
         for (int t = 0; t < nt; t++, ctr++) {
-            const char* at = smem + (ctr & 1) * PQ_SLOT;
-            const char* bt = at + PP_OP;
-            char* an = smem + ((ctr + 1) & 1) * PQ_SLOT;
+            const char* cur = smem + (ctr & 1) * PQ_SLOT;
+            char* nxt = smem + ((ctr + 1) & 1) * PQ_SLOT;
             const bool last = t + 1 == nt;
+            const bool feed = !last || (has_next && n_nt > 0);       // something to request during this K-tile
 #pragma unroll
-            for (int s = 0; s < 4; s++) {
-                bf16x8 af[BWM], bfr[BWN];
+            for (int kh = 0; kh < 2; kh++) {
+                // ---- LOAD segment: the fragments of both k-steps of this k-half, then the next K-tile's (or unit's) same k-half
+                const char* asub = cur + kh * P2_SUB;
+                const char* bsub = cur + (2 + kh) * P2_SUB;
+                bf16x8 af[2][BWM], bfr[2][BWN];
 #pragma unroll
-                for (int j = 0; j < BWN; j++) {
-                    if constexpr (BKC) bfr[j] = pp_frag_kc(bt, offb, j, s);
-                    else bfr[j] = pp_frag_ks(bt, offb[j], s);
-                }
+                for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+                    for (int j = 0; j < BWN; j++) {
+                        if constexpr (BKC) bfr[ks][j] = p2_frag_kc(bsub, offb2, j, ks);
+                        else bfr[ks][j] = p2_frag_ks(bsub, offb[j], ks);
+                    }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < BWM; i++) {
-                    if constexpr (AKC) af[i] = pp_frag_kc(at, offa, i, s);
-                    else af[i] = pp_frag_ks(at, offa[i], s);
+                for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+                    for (int i = 0; i < BWM; i++) {
+                        if constexpr (AKC) af[ks][i] = p2_frag_kc(asub, offa2, i, ks);
+                        else af[ks][i] = p2_frag_ks(asub, offa[i], ks);
+                    }
+                if (feed) {
+                    if (!last) {
+                        sa.issue(nxt + kh * P2_SUB, wave, t + 1, kh);
+                        sb.issue(nxt + (2 + kh) * P2_SUB, wave, t + 1, kh);
+                    } else {                                   // the next unit's first K-tile: the pipeline runs across units
+                        sa_n.issue(nxt + kh * P2_SUB, wave, 0, kh);
+                        sb_n.issue(nxt + (2 + kh) * P2_SUB, wave, 0, kh);
+                    }
+                    // the sub-images the NEXT segment reads (requested one segment ago) have landed; the four just requested stay in flight
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
-                if (!last) {
-                    if (s == 0) sa.issue(an, wave, t + 1);
-                    if (s == 1) sb.issue(an + PP_OP, wave, t + 1);
-                } else if (has_next && n_nt > 0) {          // the next unit's first K-tile: the pipeline runs across units
-                    if (s == 0) sa_n.issue(an, wave, 0);
-                    if (s == 1) sb_n.issue(an + PP_OP, wave, 0);
-                }
-                if (s == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
+                // ---- COMPUTE segment: 16 MFMAs
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int i = 0; i < BWM; i++)
+                for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-                    for (int j = 0; j < BWN; j++) {
-                        if constexpr (sizeof(TC) == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // C^T
-                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-                    }
+                    for (int i = 0; i < BWM; i++)
+#pragma unroll
+                        for (int j = 0; j < BWN; j++) {
+                            if constexpr (sizeof(TC) == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);   // C^T
+                            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+                        }
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
@@ -1011,7 +1080,7 @@ __global__ __launch_bounds__(NTB) void gemm_pq_kernel(GemmArgs g, int units, int
         }
         if (wm == 0) __builtin_amdgcn_s_barrier();          // both wave rows level again
         __builtin_amdgcn_sched_barrier(0);
-        // ---- epilogue through the stage just consumed; the other one holds the next unit's first K-tile
+        // ---- epilogue through the stage just consumed; the other one holds (or is receiving) the next unit's first K-tile
         char* cst = smem + ((ctr + 1) & 1) * PQ_SLOT;
         const int b1 = z / g.batch2, b2 = z % g.batch2;
         TC* C = reinterpret_cast<TC*>(g.C) + b1 * g.sC1 + b2 * g.sC2;
