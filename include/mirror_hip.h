@@ -114,11 +114,14 @@ typedef struct {
     int32_t a_rows_per_batch, a_row_skip;   /* > 0: A's M rows are `a_rows_per_batch`-row windows of larger batches: flat row r lives at
                                      A row r + (r / a_rows_per_batch) * a_row_skip (a_kc = 1 only).  Lets `to_out(out)[:, -n:]` and
                                      `retention_head(x)[:, 1:]` run as ONE flat problem instead of a batched one with a ragged tile per slide */
+    int32_t shared_chip;          /* hint: != 0 when another stream's kernel shares the chip with this launch (the half-chip pinv chain):
+                                     the persistent kernel (one workgroup per CU for the whole launch) would keep the other kernel's
+                                     workgroups from being scheduled until it ends, so the one-workgroup-per-tile kernel is used */
 } mh_gemm_desc;
 int mh_gemm(const mh_gemm_desc* d, mh_stream s);
 /* Tuning switch for A/B timing in one process: which main loop the 256 x 256-tile launches use (2 = persistent direct-to-LDS
  * ping-pong kernel, the default; 1 = the same, one workgroup per tile; 0 = register-staged kernel; env MH_GEMM_PP selects one
- * at start).  Results are identical up to the f32 summation order of split-K.  Returns the previous value. */
+ * at start; mode < 0 only queries).  Results are identical up to the f32 summation order of split-K.  Returns the previous value. */
 int mh_gemm_select_pp(int mode);
 /* Bytes of `workspace` with which this call reduces through plain partial tiles + a fold pass instead of f32 atomics
  * (0: the call has no use for one — no split-K / batch broadcast, or the shape is not on the large-tile kernel). */

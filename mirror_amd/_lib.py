@@ -44,6 +44,7 @@ class GemmDesc(C.Structure):
         ("k_segments", C.c_int32), ("sA_seg", C.c_int64), ("sB_seg", C.c_int64),
         ("row_softmax", C.c_int32),
         ("epi", C.POINTER(GemmEpi)), ("a_rows_per_batch", C.c_int32), ("a_row_skip", C.c_int32),
+        ("shared_chip", C.c_int32),
     ]
 
 

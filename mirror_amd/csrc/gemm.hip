@@ -18,6 +18,7 @@ static int launch_one(const mh_gemm_desc* d, hipStream_t s) {
     a.ws = d->workspace; a.ws_floats = d->workspace_floats;
     a.kseg = d->k_segments; a.sAk = d->sA_seg; a.sBk = d->sB_seg;
     a.row_softmax = d->row_softmax;
+    a.shared_chip = d->shared_chip;
     const int BK = d->mma == MH_BF16 ? 64 : 16;
     const int kps = mh_cdiv(mh_cdiv(d->K, split), BK) * BK;
     a.k_per_split = kps;

@@ -1143,7 +1143,7 @@ static void pp_attr(K kern) {
 }
 #define PP_LAUNCH_(TC, AKC, BKC, PART, EPI, grid, s, a)                                              \
     do {                                                                                             \
-        if (pp_mode() == 2) {                                                                        \
+        if (pp_mode() == 2 && !(a).shared_chip) {                                                    \
             static const bool attrq_ = (pp_attr(gemm_pq_kernel<TC, AKC, BKC, PART, EPI>), true);     \
             (void)attrq_;                                                                            \
             const long units_ = (long)(grid).x * (grid).y * (grid).z;                                \
@@ -1213,7 +1213,7 @@ void launch_big(GemmArgs& a, int akc, int bkc, int batch, hipStream_t s) {
 // 0 = gemm_big_kernel; returns the old value
 extern "C" int mh_gemm_select_pp(int mode) {
     const int old = pp_mode();
-    g_pp = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
+    if (mode >= 0) g_pp = mode > 2 ? 2 : mode;          // mode < 0: query only
     return old;
 }
 

@@ -42,6 +42,7 @@ struct GemmArgs {
     int kseg; long sAk, sBk;      // C = sum over kseg operand pairs (A + s sAk, B + s sBk), K each (gemm_tile.hip only; 0 / 1: one pair)
     mh_gemm_epi epi;              // fused epilogue (gemm_big.hip only; kind 0: none)
     int a_rpb, a_skip;            // row-window remap of A (gemm_big.hip, K-contiguous A): flat row r -> r + (r / a_rpb) * a_skip
+    int shared_chip;              // mh_gemm_desc.shared_chip: no persistent kernel
 };
 
 template <int MMA, bool KC, int ROWS>

@@ -1262,6 +1262,7 @@ class NystromCoreFn(Function):
             with torch.cuda.stream(side):
                 K.pinv_chain_fwd(xt, chain_saved, zfT, iters)
             saved = [(xt, chain_saved, z0)]
+            K.shared_chip = True         # until the join below: no persistent GEMM kernel beside the half-chip chain
         run_deferred(qkv)        # the v columns of to_qkv: nothing above reads them (landmarks are means of q and k)
         fused = K.nys_fused_ok(qkv, h, m_l) and lm.dtype == bf16      # nystrom_fused.hip: sim1 / sim3 never reach HBM (mask-aware)
         lse1 = lse3 = a1 = a3 = None
@@ -1295,6 +1296,7 @@ class NystromCoreFn(Function):
             K.resconv(qkv[..., 2 * D:], res_w.detach().contiguous(), out, h, transpose=False, accumulate=False)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
+            K.shared_chip = False
         # GEMMs that meet activation-dtype tensors cannot use the exact-f32 MFMA unless the activations are f32 too
         pio = pm if (pm == MH_BF16 or A == f32) else mma
         w2 = K.gemm(zf, av, mma=pio, out_dtype=A)
@@ -1376,6 +1378,7 @@ class NystromCoreFn(Function):
                 K.pinv_chain_bwd(xb, chain_saved, dzb, work, dS2, dz0, iters)
                 K.pinv_z0_bwd(a2, z0, dz0, st, dS2)
                 sm_bwd(a2, dS2, mlm if kmask else None, mlm if kmask else None)
+            K.shared_chip = True         # until the join below
         K.resconv_wgrad(qkv[..., 2 * D:], dout, dres, h)
         dAV = K.gemm(tr(zf), dW2, mma=pio, out_dtype=A)                                  # [B,h,m,dh]
         if fused:
@@ -1399,6 +1402,7 @@ class NystromCoreFn(Function):
             K.gemm(dS3, k, out=dql, alpha=scale, mma=mma)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
+            K.shared_chip = False
             del work
         else:
             dS2 = pinv_backward_tile(a2, saved, st, dZ) if ctx.tile else pinv_backward(a2, saved, st, dZ, pm, sd)

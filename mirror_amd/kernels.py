@@ -164,12 +164,18 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *
     if 0 < wsb <= (1 << 29):
         ws = torch.empty((wsb // 4,), device=a.device, dtype=torch.float32)
         d.workspace, d.workspace_floats = ws.data_ptr(), ws.numel()
+    d.shared_chip = int(shared_chip)
     prof = gemm_profiler
     if prof is None:
         _lib.call("mh_gemm", C.byref(d), stream=_stream())
     else:
         prof.launch(d, lambda: _lib.call("mh_gemm", C.byref(d), stream=_stream()))
     return out
+
+
+# set (by functional.NystromCoreFn) while the half-chip pinv chain runs on its side stream: launches issued meanwhile must not
+# use the persistent GEMM kernel (mh_gemm_desc.shared_chip)
+shared_chip = False
 
 
 EPI_DROPADD, EPI_MASKPOS, EPI_SQERR = 1, 2, 3
@@ -223,7 +229,8 @@ def linear_fused(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],
         _lib.call("mh_gemm", C.byref(d), stream=_stream())
     else:
         tc = "float" if out.dtype == torch.float32 else "bf16"
-        prof.launch_named(f"gemm_big_kernel<{tc},true,true,epi{epi.kind}>", 2.0 * d.M * d.N * d.K,
+        kern = ("gemm_big_kernel", "gemm_pp_kernel", "gemm_pq_kernel")[int(_lib.load().mh_gemm_select_pp(-1))]
+        prof.launch_named(f"{kern}<{tc},true,true,epi{epi.kind}>", 2.0 * d.M * d.N * d.K,
                           lambda: _lib.call("mh_gemm", C.byref(d), stream=_stream()))
     return out
 
@@ -309,7 +316,11 @@ def gemm_variant(d: GemmDesc) -> str:
             and kps % 64 == 0 and oka and okb and okc and not d.R and d.diag == 0.0
             and not (atomic and (d.bias or d.act != 0 or d.dtC != MH_F32))
             and -(-d.M // 256) * (d.N // 256) * -(-kk // kps) * batch >= 128 and os.environ.get("MH_GEMM_BIG", "1")[:1] != "0"):
-        return f"gemm_big_kernel<{_TN[d.dtC]},{'true' if d.a_kc else 'false'},{'true' if d.b_kc else 'false'}>"
+        mode = int(_lib.load().mh_gemm_select_pp(-1))
+        if mode == 2 and d.shared_chip:
+            mode = 1
+        kern = ("gemm_big_kernel", "gemm_pp_kernel", "gemm_pq_kernel")[mode]
+        return f"{kern}<{_TN[d.dtC]},{'true' if d.a_kc else 'false'},{'true' if d.b_kc else 'false'}>"
     mn_ok = oka and okb and (d.a_kc or d.M % 128 == 0) and d.N % (64 * wn) == 0
     full = mn_ok and kk % bk == 0 and kk % kps == 0
     ktail = (d.mma == MH_BF16 and d.dtA == MH_BF16 and d.dtB == MH_BF16 and wn == 2 and mn_ok and not full and split == 1

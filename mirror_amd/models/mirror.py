@@ -523,6 +523,7 @@ class MIRROR(nn.Module):
         if not wsi_emb.is_cuda:
             raise MirrorHipError("mirror_amd models run on MI355X only (no CPU fallback): move the inputs to the GPU")
         Fn._res_grads.clear()
+        Fn.K.shared_chip = False   # a forward that raised between a chain fork and its join must not leave the hint set
         Fn._deferred.clear()       # hand-over slots of a backward that never completed must not meet this step's tensors
         # the reference draws: rand(B,N) -> rand(B,D) -> eps_wsi -> eps_rna (models/mirror.py:630, :516, :832-833);
         # draw them up front in that order so the two encoders can then run on different streams
