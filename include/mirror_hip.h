@@ -135,6 +135,17 @@ int mh_skinny_fwd(const void* x, int64_t ldx, const void* w, int64_t ldw, const 
 /* dW[N,K] (+)= dy[M,N]^T x[M,K]  (f32, plain read-modify-write: one block owns each output tile) */
 int mh_skinny_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw, int64_t lddw, float* db, int M, int N,
                     int K, int accumulate, mh_stream s);   /* db (optional, [N] f32): db += column sums of dy (the bias gradient) */
+/* Up to MH_SKINNY_MANY_MAX of those weight gradients in ONE launch (always accumulating: dW += dy^T x, db += column sums of dy):
+ * the backward of the [B, D]-row linears queues its (dy, x) pairs and one grid covers the tiles of all of them. */
+#define MH_SKINNY_MANY_MAX 32
+typedef struct {
+    const void* dy; int64_t lddy;     /* [M, N] bf16 */
+    const void* x; int64_t ldx;       /* [M, K] bf16 */
+    float* dw; int64_t lddw;          /* [N, K] f32, 16-byte aligned */
+    float* db;                        /* [N] f32 or NULL */
+    int32_t M, N, K;
+} mh_skinny_wgrad_item;
+int mh_skinny_wgrad_many(const mh_skinny_wgrad_item* items, int n, mh_stream s);
 /* bf16 [R,C] -> [C,R]; the batched form walks table[i] = {src_off, dst_off, R, C} (int64 element offsets).
  * vec_ok != 0: every entry has R % 8 == 0, C % 8 == 0 and offsets that are multiples of 8 (16-byte accesses) */
 int mh_transpose_bf16(const void* in, void* out, int R, int C, mh_stream s);

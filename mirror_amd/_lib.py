@@ -26,6 +26,12 @@ class GemmEpi(C.Structure):
     ]
 
 
+class SkinnyWgradItem(C.Structure):
+    """mh_skinny_wgrad_item of include/mirror_hip.h."""
+    _fields_ = [("dy", C.c_void_p), ("lddy", C.c_int64), ("x", C.c_void_p), ("ldx", C.c_int64), ("dw", C.c_void_p), ("lddw", C.c_int64),
+                ("db", C.c_void_p), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32)]
+
+
 class GemmDesc(C.Structure):
     _fields_ = [
         ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p),
@@ -87,6 +93,7 @@ _SIGS = {
     "mh_gemm": [C.POINTER(GemmDesc)],
     "mh_skinny_fwd": [P, L, P, L, P, P, L, I, I, I, I, I],
     "mh_skinny_wgrad": [P, L, P, L, P, L, P, I, I, I, I],
+    "mh_skinny_wgrad_many": [C.POINTER(SkinnyWgradItem), I],
     "mh_transpose_bf16": [P, P, I, I],
     "mh_transpose_bf16_many": [P, P, P, I, I, I, I],
     "mh_layernorm_fwd": [P, P, P, P, P, P, I, I, I, L, L, F, I, I],

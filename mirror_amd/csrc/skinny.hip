@@ -79,12 +79,12 @@ extern "C" int mh_skinny_fwd(const void* x, int64_t ldx, const void* w, int64_t 
 // dW tile = 64 (n) x 256 (k) per block; thread (tn = tid>>5, tk = tid&31) owns n = 8*tn.., k = 8*tk..
 #define SW_TN 64
 #define SW_TK 256
-__global__ __launch_bounds__(256) void skinny_wgrad_kernel(const bf16_t* __restrict__ dy, long lddy, const bf16_t* __restrict__ x,
-                                                           long ldx, float* __restrict__ dw, long lddw, float* __restrict__ db, int M,
-                                                           int N, int K, int accumulate) {
+__device__ __forceinline__ void skinny_wgrad_tile(const bf16_t* __restrict__ dy, long lddy, const bf16_t* __restrict__ x,
+                                                  long ldx, float* __restrict__ dw, long lddw, float* __restrict__ db, int M,
+                                                  int N, int K, int accumulate, int bx, int by) {
     __shared__ __attribute__((aligned(16))) float sdy[32][SW_TN];
     __shared__ __attribute__((aligned(16))) float sx[32][SW_TK];
-    const int n0 = blockIdx.x * SW_TN, k0 = blockIdx.y * SW_TK;
+    const int n0 = bx * SW_TN, k0 = by * SW_TK;
     for (int i = threadIdx.x; i < M * SW_TN; i += 256) {
         const int m = i / SW_TN, c = i % SW_TN;
         sdy[m][c] = (n0 + c < N) ? bf2f(dy[(long)m * lddy + n0 + c]) : 0.f;
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void skinny_wgrad_kernel(const bf16_t* __restr
     }
     __syncthreads();
     // bias gradient db[n] += sum_m dy[m][n] rides along (the k = 0 column of blocks owns it): one launch less per Linear
-    if (db && blockIdx.y == 0 && threadIdx.x < SW_TN && n0 + threadIdx.x < N) {
+    if (db && by == 0 && threadIdx.x < SW_TN && n0 + threadIdx.x < N) {
         float t = 0.f;
         for (int m = 0; m < M; m++) t += sdy[m][threadIdx.x];
         db[n0 + threadIdx.x] += t;
@@ -133,6 +133,49 @@ __global__ __launch_bounds__(256) void skinny_wgrad_kernel(const bf16_t* __restr
                 if (k0 + 8 * tk + j < K) dst[j] = (accumulate ? dst[j] : 0.f) + acc[i][j];
         }
     }
+}
+
+__global__ __launch_bounds__(256) void skinny_wgrad_kernel(const bf16_t* __restrict__ dy, long lddy, const bf16_t* __restrict__ x,
+                                                           long ldx, float* __restrict__ dw, long lddw, float* __restrict__ db, int M,
+                                                           int N, int K, int accumulate) {
+    skinny_wgrad_tile(dy, lddy, x, ldx, dw, lddw, db, M, N, K, accumulate, blockIdx.x, blockIdx.y);
+}
+
+// Many weight gradients in ONE launch: the [B, D]-row linears of the RNA branch and the heads (models/mirror.py:70-100, :217-224,
+// :845-857) each had its own 8-32-workgroup launch (18 per step, ~22 us each on the side stream for 35 MB of f32 read-modify-write
+// in all); their (dy, x) pairs are queued during the backward and the tiles of all of them form one grid.  The items travel in
+// the kernel arguments (no device table: nothing to copy per step, capturable into a HIP graph as it is).
+struct SkinnyMany {
+    mh_skinny_wgrad_item it[MH_SKINNY_MANY_MAX];
+    int tile0[MH_SKINNY_MANY_MAX + 1];      // first flat tile of each item
+    int n;
+};
+__global__ __launch_bounds__(256) void skinny_wgrad_many_kernel(SkinnyMany a) {
+    int i = 0;
+    while (i + 1 < a.n && (int)blockIdx.x >= a.tile0[i + 1]) i++;        // uniform scan over <= 32 entries
+    const mh_skinny_wgrad_item& e = a.it[i];
+    const int t = blockIdx.x - a.tile0[i], tn = (e.N + SW_TN - 1) / SW_TN;
+    skinny_wgrad_tile((const bf16_t*)e.dy, (long)e.lddy, (const bf16_t*)e.x, (long)e.ldx, e.dw, (long)e.lddw, e.db, e.M, e.N, e.K, 1, t % tn, t / tn);
+}
+
+extern "C" int mh_skinny_wgrad_many(const mh_skinny_wgrad_item* items, int n, mh_stream s) {
+    MH_REQUIRE(n >= 0 && n <= MH_SKINNY_MANY_MAX && (items || n == 0), "mh_skinny_wgrad_many: n=%d (at most %d items per call)", n, MH_SKINNY_MANY_MAX);
+    if (n == 0) return MH_OK;
+    SkinnyMany a;
+    int tiles = 0;
+    for (int i = 0; i < n; i++) {
+        const mh_skinny_wgrad_item& e = items[i];
+        MH_REQUIRE(e.dy && e.x && e.dw && e.M >= 1 && e.M <= 32 && e.N >= 1 && e.K >= 1 && ((uintptr_t)e.dw & 15) == 0,
+                   "mh_skinny_wgrad_many: item %d: M=%d (needs 1..32), N=%d, K=%d, 16-byte aligned dW", i, e.M, e.N, e.K);
+        a.it[i] = e;
+        a.tile0[i] = tiles;
+        tiles += mh_cdiv(e.N, SW_TN) * mh_cdiv(e.K, SW_TK);
+    }
+    a.tile0[n] = tiles;
+    a.n = n;
+    hipLaunchKernelGGL(skinny_wgrad_many_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)s, a);
+    MH_LAUNCH_CHECK("mh_skinny_wgrad_many");
+    return MH_OK;
 }
 
 extern "C" int mh_skinny_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw, int64_t lddw, float* db, int M,

@@ -47,6 +47,7 @@ def plan_buckets(sizes: Sequence[int], cap_elems: int, align: int = _ALIGN):
 
 
 # A/B switch: 1 (default) = the transposed weight copies are rebuilt at the start of a step on the RNA stream, 0 = behind Adam
+_DEFER_SKINNY = os.environ.get("MIRROR_DEFER_SKINNY", "1") != "0"     # A/B switch: one multi-tensor launch for the skinny weight gradients
 _TRANSPOSE_AT_START = os.environ.get("MIRROR_TRANSPOSE_AT_START", "1") != "0"
 
 
@@ -396,11 +397,21 @@ class TrainEngine:
         if t_done is not None:
             torch.cuda.current_stream().wait_event(t_done)
         Fn.set_grad_sink(self)
+        # one process, no graphed RNA branch: the ~18 weight gradients of the [B, D]-row linears (RNA branch, heads) are queued during
+        # the backward and run as ONE launch on the branch's stream behind it (with data parallelism they stay where they are: their
+        # buckets should be reduced as early as possible)
+        defer = _DEFER_SKINNY and self.world == 1 and self._rna_branch_state != "on" and self.shadow is not None
+        if defer:
+            Fn.skinny_wgrads_begin()
         try:
             if self._one is None or self._one.device != losses[0].device:
                 self._one = torch.ones((), device=losses[0].device, dtype=losses[0].dtype)
             losses[0].backward(self._one)        # a persistent root gradient: no ones_like fill launch per step
+            if defer:
+                with torch.cuda.stream(Fn._side_stream(self.device, 1)):
+                    Fn.flush_skinny_wgrads()
         finally:
+            Fn._wgrad_queue = None
             Fn.set_grad_sink(None)
         Fn.join_side_streams(self.device)       # sink-written gradients of the side-stream branches (see join_side_streams)
         if self._counting:

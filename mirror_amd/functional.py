@@ -400,6 +400,10 @@ class LinearFn(Function):
                 if want_db:                      # the bias gradient rides on the weight-gradient launch
                     dbuf, sunk_b = _gbuf(b, (N,))
                     fused_db = True
+                if _wgrad_queue is not None and sunk and (dbuf is None or sunk_b) and dy.dim() == 2:
+                    # engine step: every [B, D]-row weight gradient of the backward goes into ONE launch at its end (flush_skinny_wgrads)
+                    _wgrad_queue.append((dy, xa, dw, dbuf, w, b if fused_db else None, torch.cuda.current_stream()))
+                    return dx, None, None, None, None, None, None
                 K.skinny_wgrad(dy, xa, dw, accumulate=True, db=dbuf)
                 if fused_db:
                     db = _gret(b, dbuf, sunk_b)
@@ -411,6 +415,32 @@ class LinearFn(Function):
             K.colsum(dy.reshape(-1, N), db)
             db = _gret(b, db, sunk)
         return dx, dw, db, None, None, None, None
+
+
+# deferred weight gradients of the skinny linears: a list while an engine step's backward runs (TrainEngine sets it), else None
+_wgrad_queue = None
+
+
+def skinny_wgrads_begin() -> None:
+    global _wgrad_queue
+    _wgrad_queue = []
+
+
+def flush_skinny_wgrads() -> None:
+    """One launch for everything the backward queued (mh_skinny_wgrad_many), then the parameters report their gradients done."""
+    global _wgrad_queue
+    q, _wgrad_queue = _wgrad_queue, None
+    if not q:
+        return
+    cur = torch.cuda.current_stream()
+    for st in {e[6] for e in q}:            # operands queued from another stream than the one this launch goes to
+        if st != cur:
+            cur.wait_stream(st)
+    K.skinny_wgrad_many([e[:4] for e in q])
+    for _, _, _, _, w, b, _ in q:
+        _sink.done(w)
+        if b is not None:
+            _sink.done(b)
 
 
 def _blk_ok(t: torch.Tensor) -> bool:

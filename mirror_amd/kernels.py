@@ -449,6 +449,27 @@ def skinny_wgrad(dy2d: torch.Tensor, x2d: torch.Tensor, dw: torch.Tensor, accumu
               int(accumulate), stream=_stream())
 
 
+SKINNY_MANY_MAX = 32
+
+
+def skinny_wgrad_many(items) -> None:
+    """items: list of (dy2d, x2d, dw, db or None) as skinny_wgrad takes them (always accumulating); ONE launch per 32 items."""
+    for i0 in range(0, len(items), SKINNY_MANY_MAX):
+        chunk = items[i0:i0 + SKINNY_MANY_MAX]
+        arr = (_lib.SkinnyWgradItem * len(chunk))()
+        for e, (dy2d, x2d, dw, db) in zip(arr, chunk):
+            _chk(dy2d, x2d, dw, db)
+            M, N = dy2d.shape
+            Kd = x2d.shape[1]
+            if (dy2d.dtype != torch.bfloat16 or x2d.dtype != torch.bfloat16 or dw.dtype != torch.float32 or x2d.shape[0] != M
+                    or tuple(dw.shape) != (N, Kd) or dy2d.stride(1) != 1 or x2d.stride(1) != 1 or dw.stride(1) != 1
+                    or (db is not None and (db.dtype != torch.float32 or db.numel() != N or not db.is_contiguous()))):
+                raise MirrorHipError("skinny_wgrad_many: bad operands")
+            e.dy, e.lddy, e.x, e.ldx, e.dw, e.lddw, e.db = dy2d.data_ptr(), dy2d.stride(0), x2d.data_ptr(), x2d.stride(0), dw.data_ptr(), dw.stride(0), _p(db)
+            e.M, e.N, e.K = M, N, Kd
+        _lib.call("mh_skinny_wgrad_many", arr, len(chunk), stream=_stream())
+
+
 def transpose_bf16(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _chk(x, out)
     _contig(x, "transpose input")

@@ -281,3 +281,31 @@ def test_lite_dropout_stream_statistics_and_backward_mask():
     # neighbouring elements are independent: P(both kept) = keep^2
     both = float(((y[:-1] != 0) & (y[1:] != 0)).float().mean())
     assert abs(both - keep * keep) < 2e-3, (both, keep)
+
+
+def test_skinny_wgrad_many_equals_single_launches():
+    """mh_skinny_wgrad_many (one grid over the tiles of many [B, D]-row weight gradients) against mh_skinny_wgrad per item,
+    bit for bit (same tile code, same accumulation order), ragged N / K included."""
+    from mirror_amd import kernels as K
+    g = torch.Generator().manual_seed(12)
+    shapes = [(16, 512, 512), (16, 3000, 512), (7, 100, 72), (32, 256, 128), (16, 512, 2048), (1, 64, 64)]
+    items, ref = [], []
+    for M, N, Kd in shapes:
+        dy = torch.randn(M, N, generator=g).cuda().to(bf16)
+        x = torch.randn(M, Kd, generator=g).cuda().to(bf16)
+        dw0 = torch.randn(N, Kd, generator=g).cuda()
+        db0 = torch.randn(N, generator=g).cuda()
+        dw1, db1 = dw0.clone(), db0.clone()
+        K.skinny_wgrad(dy, x, dw1, accumulate=True, db=db1)
+        dw2, db2 = dw0.clone(), db0.clone()
+        items.append((dy, x, dw2, db2 if N != 100 else None))
+        ref.append((dw1, db1 if N != 100 else None))
+    K.skinny_wgrad_many(items * 6)            # 36 items: two launches; every gradient accumulated six times
+    for (dy, x, dw2, db2), (dw1, db1) in zip(items, ref):
+        want = dw1
+        for _ in range(5):
+            K.skinny_wgrad(dy, x, want, accumulate=True, db=db1)
+        torch.cuda.synchronize()
+        assert torch.equal(dw2, want)
+        if db2 is not None:
+            assert torch.equal(db2, db1)
