@@ -300,12 +300,20 @@ def test_skinny_wgrad_many_equals_single_launches():
         dw2, db2 = dw0.clone(), db0.clone()
         items.append((dy, x, dw2, db2 if N != 100 else None))
         ref.append((dw1, db1 if N != 100 else None))
-    K.skinny_wgrad_many(items * 6)            # 36 items: two launches; every gradient accumulated six times
+    K.skinny_wgrad_many(items)                # one launch (items must not share a destination: they run concurrently)
+    K.skinny_wgrad_many(items)                # and once more: accumulation
     for (dy, x, dw2, db2), (dw1, db1) in zip(items, ref):
-        want = dw1
-        for _ in range(5):
-            K.skinny_wgrad(dy, x, want, accumulate=True, db=db1)
+        K.skinny_wgrad(dy, x, dw1, accumulate=True, db=db1)
         torch.cuda.synchronize()
-        assert torch.equal(dw2, want)
+        assert torch.equal(dw2, dw1)
         if db2 is not None:
             assert torch.equal(db2, db1)
+    many = []
+    for i in range(40):                       # more than one launch's worth of items
+        dy = torch.randn(16, 64, generator=g).cuda().to(bf16)
+        x = torch.randn(16, 96, generator=g).cuda().to(bf16)
+        many.append((dy, x, torch.zeros(64, 96, device="cuda"), None))
+    K.skinny_wgrad_many(many)
+    torch.cuda.synchronize()
+    for dy, x, dw, _ in many:
+        assert float((dw - dy.float().t() @ x.float()).abs().max()) < 1e-3
