@@ -131,19 +131,20 @@ int64_t mh_gemm_workspace_bytes(const mh_gemm_desc* d);
  * tensor is [B, D], models/mirror.py:77-102, :217-224, :845-857): weight-streaming kernels, bf16 operands.
  * y[M<=32, N] = act(x[M,K] W[N,K]^T + bias); K % 32 == 0; the data gradient is the same call on the W^T shadow. */
 int mh_skinny_fwd(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, void* y, int64_t ldy,
-                  int M, int N, int K, int act, int dt_y, mh_stream s);
+                  int M, int N, int K, int act, int dt_x, int dt_y, mh_stream s);      /* x bf16, or f32 rounded to bf16 on load */
 /* dW[N,K] (+)= dy[M,N]^T x[M,K]  (f32, plain read-modify-write: one block owns each output tile) */
 int mh_skinny_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw, int64_t lddw, float* db, int M, int N,
-                    int K, int accumulate, mh_stream s);   /* db (optional, [N] f32): db += column sums of dy (the bias gradient) */
+                    int K, int accumulate, int dt_dy, int dt_x, mh_stream s);   /* db (optional, [N] f32): db += column sums of dy (the bias gradient) */
 /* Up to MH_SKINNY_MANY_MAX of those weight gradients in ONE launch (always accumulating: dW += dy^T x, db += column sums of dy):
  * the backward of the [B, D]-row linears queues its (dy, x) pairs and one grid covers the tiles of all of them. */
 #define MH_SKINNY_MANY_MAX 32
 typedef struct {
-    const void* dy; int64_t lddy;     /* [M, N] bf16 */
-    const void* x; int64_t ldx;       /* [M, K] bf16 */
+    const void* dy; int64_t lddy;     /* [M, N] bf16 (or f32, rounded to bf16 on load: dt_dy) */
+    const void* x; int64_t ldx;       /* [M, K] bf16 (or f32: dt_x) */
     float* dw; int64_t lddw;          /* [N, K] f32, 16-byte aligned */
     float* db;                        /* [N] f32 or NULL */
     int32_t M, N, K;
+    int32_t dt_dy, dt_x;              /* MH_BF16 / MH_F32 */
 } mh_skinny_wgrad_item;
 int mh_skinny_wgrad_many(const mh_skinny_wgrad_item* items, int n, mh_stream s);
 /* bf16 [R,C] -> [C,R]; the batched form walks table[i] = {src_off, dst_off, R, C} (int64 element offsets).

@@ -29,7 +29,7 @@ class GemmEpi(C.Structure):
 class SkinnyWgradItem(C.Structure):
     """mh_skinny_wgrad_item of include/mirror_hip.h."""
     _fields_ = [("dy", C.c_void_p), ("lddy", C.c_int64), ("x", C.c_void_p), ("ldx", C.c_int64), ("dw", C.c_void_p), ("lddw", C.c_int64),
-                ("db", C.c_void_p), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32)]
+                ("db", C.c_void_p), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("dt_dy", C.c_int32), ("dt_x", C.c_int32)]
 
 
 class GemmDesc(C.Structure):
@@ -91,8 +91,8 @@ class RnaBlockDesc(C.Structure):
 # name -> argtypes (the trailing stream argument is appended automatically)
 _SIGS = {
     "mh_gemm": [C.POINTER(GemmDesc)],
-    "mh_skinny_fwd": [P, L, P, L, P, P, L, I, I, I, I, I],
-    "mh_skinny_wgrad": [P, L, P, L, P, L, P, I, I, I, I],
+    "mh_skinny_fwd": [P, L, P, L, P, P, L, I, I, I, I, I, I],
+    "mh_skinny_wgrad": [P, L, P, L, P, L, P, I, I, I, I, I, I],
     "mh_skinny_wgrad_many": [C.POINTER(SkinnyWgradItem), I],
     "mh_transpose_bf16": [P, P, I, I],
     "mh_transpose_bf16_many": [P, P, P, I, I, I, I],

@@ -15,8 +15,17 @@ typedef __bf16 sk_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float sk_f4 __attribute__((ext_vector_type(4)));
 typedef unsigned sk_u4 __attribute__((ext_vector_type(4)));
 
-template <typename TY, int MT>   // MT = number of 16-row tiles of x (1 or 2)
-__global__ __launch_bounds__(256) void skinny_fwd_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ w,
+// 8 consecutive k of an x row as the MFMA A fragment: bf16 as stored, f32 rounded to bf16 here (what a separate cast launch in
+// front of every [B, D]-row Linear with an f32 input — residual streams, LayerNorm / style outputs — used to do)
+template <typename TX> __device__ __forceinline__ sk_bf16x8 sk_load8(const TX* p);
+template <> __device__ __forceinline__ sk_bf16x8 sk_load8<bf16_t>(const bf16_t* p) { return *reinterpret_cast<const sk_bf16x8*>(p); }
+template <> __device__ __forceinline__ sk_bf16x8 sk_load8<float>(const float* p) {
+    const sk_f4 a = *reinterpret_cast<const sk_f4*>(p), b = *reinterpret_cast<const sk_f4*>(p + 4);
+    return sk_bf16x8{(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3], (__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
+}
+
+template <typename TX, typename TY, int MT>   // MT = number of 16-row tiles of x (1 or 2)
+__global__ __launch_bounds__(256) void skinny_fwd_kernel(const TX* __restrict__ x, long ldx, const bf16_t* __restrict__ w,
                                                          long ldw, const float* __restrict__ bias, TY* __restrict__ y, long ldy,
                                                          int M, int N, int K, int act) {
     __shared__ float red[4][MT][16][17];
@@ -25,7 +34,7 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const bf16_t* __restric
     const int col = lane & 15, kq = lane >> 4;
     const int nrow = min(n0 + col, N - 1);                 // ragged last column group: re-read row N-1, never stored
     const bf16_t* wp = w + (long)nrow * ldw + 8 * kq;
-    const bf16_t* xp[MT];
+    const TX* xp[MT];
 #pragma unroll
     for (int t = 0; t < MT; t++) xp[t] = x + (long)min(16 * t + col, M - 1) * ldx + 8 * kq;
     sk_f4 acc[MT];
@@ -38,7 +47,7 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const bf16_t* __restric
         const sk_bf16x8 b = *reinterpret_cast<const sk_bf16x8*>(wp + 32 * s);
 #pragma unroll
         for (int t = 0; t < MT; t++) {
-            const sk_bf16x8 a = *reinterpret_cast<const sk_bf16x8*>(xp[t] + 32 * s);
+            const sk_bf16x8 a = sk_load8<TX>(xp[t] + 32 * s);
             acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[t], 0, 0, 0);
         }
     }
@@ -62,15 +71,16 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const bf16_t* __restric
 }
 
 extern "C" int mh_skinny_fwd(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, void* y, int64_t ldy,
-                             int M, int N, int K, int act, int dt_y, mh_stream s) {
+                             int M, int N, int K, int act, int dt_x, int dt_y, mh_stream s) {
     MH_REQUIRE(M >= 1 && M <= 32, "mh_skinny_fwd: M=%d (needs 1..32)", M);
     MH_REQUIRE(K % 32 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0,
                "mh_skinny_fwd: K %% 32 == 0 and 16-byte aligned rows required (K=%d ldx=%ld ldw=%ld)", K, (long)ldx, (long)ldw);
     if (N == 0) return MH_OK;
     dim3 grid(mh_cdiv(N, 16));
-#define SKF(TY, MT) hipLaunchKernelGGL((skinny_fwd_kernel<TY, MT>), grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (long)ldx, (const bf16_t*)w, (long)ldw, bias, (TY*)y, (long)ldy, M, N, K, act)
-    if (dt_y == MH_F32) { if (M <= 16) SKF(float, 1); else SKF(float, 2); }
-    else { if (M <= 16) SKF(bf16_t, 1); else SKF(bf16_t, 2); }
+#define SKF(TX, TY, MT) hipLaunchKernelGGL((skinny_fwd_kernel<TX, TY, MT>), grid, dim3(256), 0, (hipStream_t)s, (const TX*)x, (long)ldx, (const bf16_t*)w, (long)ldw, bias, (TY*)y, (long)ldy, M, N, K, act)
+#define SKF2(TX) do { if (dt_y == MH_F32) { if (M <= 16) SKF(TX, float, 1); else SKF(TX, float, 2); } else { if (M <= 16) SKF(TX, bf16_t, 1); else SKF(TX, bf16_t, 2); } } while (0)
+    if (dt_x == MH_F32) SKF2(float); else SKF2(bf16_t);
+#undef SKF2
 #undef SKF
     MH_LAUNCH_CHECK("mh_skinny_fwd");
     return MH_OK;
@@ -79,19 +89,23 @@ extern "C" int mh_skinny_fwd(const void* x, int64_t ldx, const void* w, int64_t 
 // dW tile = 64 (n) x 256 (k) per block; thread (tn = tid>>5, tk = tid&31) owns n = 8*tn.., k = 8*tk..
 #define SW_TN 64
 #define SW_TK 256
-__device__ __forceinline__ void skinny_wgrad_tile(const bf16_t* __restrict__ dy, long lddy, const bf16_t* __restrict__ x,
+// operand element as the bf16 MFMA path sees it: f32 sources are rounded to bf16 (no cast launch in front of the gradient)
+__device__ __forceinline__ float sk_ld(const void* p, long i, int f32) {
+    return f32 ? bf2f(f2bf(reinterpret_cast<const float*>(p)[i])) : bf2f(reinterpret_cast<const bf16_t*>(p)[i]);
+}
+__device__ __forceinline__ void skinny_wgrad_tile(const void* __restrict__ dy, long lddy, const void* __restrict__ x,
                                                   long ldx, float* __restrict__ dw, long lddw, float* __restrict__ db, int M,
-                                                  int N, int K, int accumulate, int bx, int by) {
+                                                  int N, int K, int accumulate, int bx, int by, int dy_f32, int x_f32) {
     __shared__ __attribute__((aligned(16))) float sdy[32][SW_TN];
     __shared__ __attribute__((aligned(16))) float sx[32][SW_TK];
     const int n0 = bx * SW_TN, k0 = by * SW_TK;
     for (int i = threadIdx.x; i < M * SW_TN; i += 256) {
         const int m = i / SW_TN, c = i % SW_TN;
-        sdy[m][c] = (n0 + c < N) ? bf2f(dy[(long)m * lddy + n0 + c]) : 0.f;
+        sdy[m][c] = (n0 + c < N) ? sk_ld(dy, (long)m * lddy + n0 + c, dy_f32) : 0.f;
     }
     for (int i = threadIdx.x; i < M * SW_TK; i += 256) {
         const int m = i / SW_TK, c = i % SW_TK;
-        sx[m][c] = (k0 + c < K) ? bf2f(x[(long)m * ldx + k0 + c]) : 0.f;
+        sx[m][c] = (k0 + c < K) ? sk_ld(x, (long)m * ldx + k0 + c, x_f32) : 0.f;
     }
     __syncthreads();
     // bias gradient db[n] += sum_m dy[m][n] rides along (the k = 0 column of blocks owns it): one launch less per Linear
@@ -135,10 +149,10 @@ __device__ __forceinline__ void skinny_wgrad_tile(const bf16_t* __restrict__ dy,
     }
 }
 
-__global__ __launch_bounds__(256) void skinny_wgrad_kernel(const bf16_t* __restrict__ dy, long lddy, const bf16_t* __restrict__ x,
+__global__ __launch_bounds__(256) void skinny_wgrad_kernel(const void* __restrict__ dy, long lddy, const void* __restrict__ x,
                                                            long ldx, float* __restrict__ dw, long lddw, float* __restrict__ db, int M,
-                                                           int N, int K, int accumulate) {
-    skinny_wgrad_tile(dy, lddy, x, ldx, dw, lddw, db, M, N, K, accumulate, blockIdx.x, blockIdx.y);
+                                                           int N, int K, int accumulate, int dy_f32, int x_f32) {
+    skinny_wgrad_tile(dy, lddy, x, ldx, dw, lddw, db, M, N, K, accumulate, blockIdx.x, blockIdx.y, dy_f32, x_f32);
 }
 
 // Many weight gradients in ONE launch: the [B, D]-row linears of the RNA branch and the heads (models/mirror.py:70-100, :217-224,
@@ -155,7 +169,7 @@ __global__ __launch_bounds__(256) void skinny_wgrad_many_kernel(SkinnyMany a) {
     while (i + 1 < a.n && (int)blockIdx.x >= a.tile0[i + 1]) i++;        // uniform scan over <= 32 entries
     const mh_skinny_wgrad_item& e = a.it[i];
     const int t = blockIdx.x - a.tile0[i], tn = (e.N + SW_TN - 1) / SW_TN;
-    skinny_wgrad_tile((const bf16_t*)e.dy, (long)e.lddy, (const bf16_t*)e.x, (long)e.ldx, e.dw, (long)e.lddw, e.db, e.M, e.N, e.K, 1, t % tn, t / tn);
+    skinny_wgrad_tile(e.dy, (long)e.lddy, e.x, (long)e.ldx, e.dw, (long)e.lddw, e.db, e.M, e.N, e.K, 1, t % tn, t / tn, e.dt_dy == MH_F32, e.dt_x == MH_F32);
 }
 
 extern "C" int mh_skinny_wgrad_many(const mh_skinny_wgrad_item* items, int n, mh_stream s) {
@@ -179,13 +193,13 @@ extern "C" int mh_skinny_wgrad_many(const mh_skinny_wgrad_item* items, int n, mh
 }
 
 extern "C" int mh_skinny_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw, int64_t lddw, float* db, int M,
-                               int N, int K, int accumulate, mh_stream s) {
+                               int N, int K, int accumulate, int dt_dy, int dt_x, mh_stream s) {
     MH_REQUIRE(M >= 1 && M <= 32, "mh_skinny_wgrad: M=%d (needs 1..32)", M);
     MH_REQUIRE(((uintptr_t)dw & 15) == 0, "mh_skinny_wgrad: dW must be 16-byte aligned");
     if (N == 0 || K == 0) return MH_OK;
     dim3 grid(mh_cdiv(N, SW_TN), mh_cdiv(K, SW_TK));
-    hipLaunchKernelGGL(skinny_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)dy, (long)lddy, (const bf16_t*)x,
-                       (long)ldx, dw, (long)lddw, db, M, N, K, accumulate);
+    hipLaunchKernelGGL(skinny_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)s, dy, (long)lddy, x,
+                       (long)ldx, dw, (long)lddw, db, M, N, K, accumulate, (int)(dt_dy == MH_F32), (int)(dt_x == MH_F32));
     MH_LAUNCH_CHECK("mh_skinny_wgrad");
     return MH_OK;
 }

@@ -341,10 +341,12 @@ class LinearFn(Function):
 
     @staticmethod
     def forward(ctx, x, w, b, act, prec, out_dtype, defer_from=None):
-        xa = x if x.dtype == prec.act else K.cast(x.contiguous(), prec.act)
         wa = shadow(w, prec)
+        # [B, D] activations: weight-streaming kernels, which take an f32 operand as it is (rounded to bf16 on load: no cast launch)
+        ctx.skinny = prec.act == bf16 and _SKINNY_F32 and x.dtype == f32 and K.skinny_ok(x, wa)
+        xa = x if (x.dtype == prec.act or ctx.skinny) else K.cast(x.contiguous(), prec.act)
         bd = None if b is None else b.detach()
-        ctx.skinny = prec.act == bf16 and K.skinny_ok(xa, wa)      # [B, D] activations: weight-streaming kernels
+        ctx.skinny = ctx.skinny or (prec.act == bf16 and K.skinny_ok(xa, wa))
         y = None
         if (defer_from and _DEFER_V and not ctx.skinny and not prec.fp8_fwd and b is None and act == ACT_NONE
                 and xa.is_contiguous() and 0 < defer_from < wa.shape[0]):
@@ -374,8 +376,8 @@ class LinearFn(Function):
         else:
             if not dy.is_contiguous():
                 dy = dy.contiguous()
-            if dy.dtype != prec.act:
-                dy = K.cast(dy, prec.act)
+            if dy.dtype != prec.act and not (ctx.skinny and _SKINNY_F32 and dy.dtype == f32 and dy.dim() == 2):
+                dy = K.cast(dy, prec.act)          # (the skinny kernels round an f32 gradient on load)
         N, Kd = wa.shape
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
@@ -468,6 +470,7 @@ def linear(x, w, b=None, *, act=ACT_NONE, prec: Precision, out_dtype=None, defer
 
 
 _DEFER_V = os.environ.get("MIRROR_DEFER_V", "1") != "0"       # A/B switch
+_SKINNY_F32 = os.environ.get("MIRROR_SKINNY_F32", "1") != "0"     # A/B switch: f32 operands straight into the skinny kernels
 _deferred: dict = {}        # data_ptr of a partly computed linear output -> the launch that completes it
 
 

@@ -420,8 +420,9 @@ def gemm_fp8(aq: torch.Tensor, sa: torch.Tensor, wq: torch.Tensor, sw: torch.Ten
 
 # ----------------------------------------------------------------------------- skinny-M linears
 def skinny_ok(x2d: torch.Tensor, w: torch.Tensor) -> bool:
-    """bf16 x [M<=32, K] (row-strided ok) against bf16 W [N, K] contiguous, K % 32 == 0, 16-B aligned rows."""
-    return (x2d.dim() == 2 and w.dim() == 2 and x2d.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
+    """bf16 or f32 x [M<=32, K] (row-strided ok; f32 is rounded to bf16 on load: no cast launch) against bf16 W [N, K] contiguous,
+    K % 32 == 0, 16-B aligned rows."""
+    return (x2d.dim() == 2 and w.dim() == 2 and x2d.dtype in (torch.bfloat16, torch.float32) and w.dtype == torch.bfloat16
             and 1 <= x2d.shape[0] <= 32 and x2d.shape[1] == w.shape[1] and w.shape[1] % 32 == 0 and w.is_contiguous()
             and (x2d.stride(1) == 1) and x2d.stride(0) % 8 == 0 and x2d.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0)
 
@@ -431,7 +432,7 @@ def skinny_fwd(x2d: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],
     M, Kd = x2d.shape
     N = w.shape[0]
     y = torch.empty((M, N), device=x2d.device, dtype=out_dtype)
-    _lib.call("mh_skinny_fwd", _p(x2d), x2d.stride(0), _p(w), w.stride(0), _p(bias), _p(y), N, M, N, Kd, act, dt(y),
+    _lib.call("mh_skinny_fwd", _p(x2d), x2d.stride(0), _p(w), w.stride(0), _p(bias), _p(y), N, M, N, Kd, act, dt(x2d), dt(y),
               stream=_stream())
     return y
 
@@ -442,11 +443,12 @@ def skinny_wgrad(dy2d: torch.Tensor, x2d: torch.Tensor, dw: torch.Tensor, accumu
     assert db is None or (db.dtype == torch.float32 and db.numel() == dy2d.shape[1] and db.is_contiguous())
     M, N = dy2d.shape
     Kd = x2d.shape[1]
-    if (dy2d.dtype != torch.bfloat16 or x2d.dtype != torch.bfloat16 or dw.dtype != torch.float32 or x2d.shape[0] != M
+    ok_dt = (torch.bfloat16, torch.float32)
+    if (dy2d.dtype not in ok_dt or x2d.dtype not in ok_dt or dw.dtype != torch.float32 or x2d.shape[0] != M
             or tuple(dw.shape) != (N, Kd) or dy2d.stride(1) != 1 or x2d.stride(1) != 1 or dw.stride(1) != 1):
         raise MirrorHipError("skinny_wgrad: bad operands")
     _lib.call("mh_skinny_wgrad", _p(dy2d), dy2d.stride(0), _p(x2d), x2d.stride(0), _p(dw), dw.stride(0), _p(db), M, N, Kd,
-              int(accumulate), stream=_stream())
+              int(accumulate), dt(dy2d), dt(x2d), stream=_stream())
 
 
 SKINNY_MANY_MAX = 32
@@ -461,12 +463,12 @@ def skinny_wgrad_many(items) -> None:
             _chk(dy2d, x2d, dw, db)
             M, N = dy2d.shape
             Kd = x2d.shape[1]
-            if (dy2d.dtype != torch.bfloat16 or x2d.dtype != torch.bfloat16 or dw.dtype != torch.float32 or x2d.shape[0] != M
+            if (dy2d.dtype not in (torch.bfloat16, torch.float32) or x2d.dtype not in (torch.bfloat16, torch.float32) or dw.dtype != torch.float32 or x2d.shape[0] != M
                     or tuple(dw.shape) != (N, Kd) or dy2d.stride(1) != 1 or x2d.stride(1) != 1 or dw.stride(1) != 1
                     or (db is not None and (db.dtype != torch.float32 or db.numel() != N or not db.is_contiguous()))):
                 raise MirrorHipError("skinny_wgrad_many: bad operands")
             e.dy, e.lddy, e.x, e.ldx, e.dw, e.lddw, e.db = dy2d.data_ptr(), dy2d.stride(0), x2d.data_ptr(), x2d.stride(0), dw.data_ptr(), dw.stride(0), _p(db)
-            e.M, e.N, e.K = M, N, Kd
+            e.M, e.N, e.K, e.dt_dy, e.dt_x = M, N, Kd, dt(dy2d), dt(x2d)
         _lib.call("mh_skinny_wgrad_many", arr, len(chunk), stream=_stream())
 
 
