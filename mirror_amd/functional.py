@@ -438,7 +438,20 @@ def flush_skinny_wgrads() -> None:
     for st in {e[6] for e in q}:            # operands queued from another stream than the one this launch goes to
         if st != cur:
             cur.wait_stream(st)
-    K.skinny_wgrad_many([e[:4] for e in q])
+    # items of one launch run concurrently and read-modify-write their destination: a weight used twice in the step (the style /
+    # prototype branch runs on both modalities) goes to a later launch
+    rounds = []
+    for e in q:
+        for r in rounds:
+            if e[2].data_ptr() not in r[0]:
+                break
+        else:
+            r = (set(), [])
+            rounds.append(r)
+        r[0].add(e[2].data_ptr())
+        r[1].append(e[:4])
+    for _, items in rounds:
+        K.skinny_wgrad_many(items)
     for _, _, _, _, w, b, _ in q:
         _sink.done(w)
         if b is not None:
