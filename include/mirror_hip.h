@@ -245,7 +245,7 @@ int mh_resconv_wgrad(const void* v, int64_t ldv, int64_t v_bs, const void* dout,
 int mh_pinv_absmax(const float* x, uint64_t* stats64, int BH, int m, mh_stream s);
 /* z0[bh,i,j] = x[bh,j,i] / (c*r) */
 int mh_pinv_z0(const float* x, const uint64_t* stats64, float* z0, int BH, int m, mh_stream s);
-/* dx += dz0^T/(c r) + sub-gradients through the two max() */
+/* dx += dz0^T/(c r) + sub-gradients through the two max(); z0 may be NULL (m % 64 == 0): z0 = x^T / (c r) is then formed on the fly */
 int mh_pinv_z0_bwd(const float* x, const float* z0, const float* dz0, const uint64_t* stats64, float* dx,
                    float* scratch1, int BH, int m, mh_stream s);
 /* The whole iteration as ONE launch per pass (bf16 policy, m = 256; other sizes return MH_EINVAL and the caller
@@ -261,7 +261,16 @@ int mh_pinv_z0_bwd(const float* x, const float* z0, const float* dz0, const uint
  *   bwd  : dzf = up; work like saved (scratch); dX (f32, row-major) = sum_k dP_k z_k^T, dz0 (f32, row-major) = d z_0 */
 int mh_pinv_chain_prep(const float* x, const uint64_t* stats64, float* z0, void* xp, void* z0p, int BH, int m, mh_stream s);
 int mh_pinv_chain_pack(const float* dz, void* up, int BH, int m, mh_stream s);
-int mh_pinv_chain_fwd(const void* XP, void* saved, void* zfT, int BH, int m, int iters, mh_stream s);
+int mh_pinv_chain_fwd(const void* XP, void* saved, void* zfT, int BH, int m, int iters, const float* z0f, const uint64_t* stats64,
+                      mh_stream s);     /* z0f != NULL: z_0 = z0f / (c r) (mh_nys_sim2's unscaled panel-native attn2^T, stats64 = its maxima),
+                                           rounded to bf16 and written to saved[0] here; NULL: saved[0] is pre-filled (mh_pinv_chain_prep) */
+/* attn2 = softmax(scale q_l k_l^T) of [3P] NystromAttention (m = 256 landmarks, dh = 64) and what moore_penrose_iter_pinv's start
+ * needs from it, one launch: lm bf16 [B, m, 2 D] (q | k landmarks) -> a2 f32 [B h, m, m] row-major, xp = panel-native bf16 a2 (the
+ * chain's X), z0f = panel-native f32 a2^T (unscaled z_0), stats64[0 / 1] = packed (value << 32 | flat index) maxima of the row /
+ * column abs sums as mh_pinv_absmax leaves them (caller zeroes stats64).  Replaces mh_gemm + mh_softmax_fwd + mh_pinv_absmax +
+ * mh_pinv_chain_prep on the fused path. */
+int mh_nys_sim2(const void* lm, float* a2, void* xp, float* z0f, uint64_t* stats64, int B, int m, int D, int heads, float scale,
+                mh_stream s);
 int mh_pinv_chain_bwd(const void* XP, const void* saved, const void* dzf, void* work, float* dX, float* dz0, int BH, int m,
                       int iters, mh_stream s);
 /* Bytes of the chain's caller-allocated buffers: which = 0: `saved` (forward output, backward input: [iters, 4, BH, m, m]

@@ -547,7 +547,7 @@ __global__ __launch_bounds__(256) void pinv_z0_bwd_kernel(const float* __restric
 // m % 64 == 0: 64 x 64 tiles, 16-byte loads and stores (the 32 x 32 scalar tiles ran at 1.2 TB/s)
 __global__ __launch_bounds__(256) void pinv_z0_bwd_vec_kernel(const float* __restrict__ z0, const float* __restrict__ dz0,
                                                               const unsigned long long* __restrict__ st, float* __restrict__ dx,
-                                                              float* __restrict__ scratch, int m) {
+                                                              float* __restrict__ scratch, int m, const float* __restrict__ x) {
     typedef float zf4 __attribute__((ext_vector_type(4)));
     __shared__ float tile[64][65];
     __shared__ float red[4];
@@ -560,20 +560,29 @@ __global__ __launch_bounds__(256) void pinv_z0_bwd_vec_kernel(const float* __res
     for (int k = 0; k < 4; k++) {
         const int i = i0 + r + 16 * k;
         const zf4 d = *reinterpret_cast<const zf4*>(dz0 + base + (long)i * m + j0 + c4);
-        const zf4 z = *reinterpret_cast<const zf4*>(z0 + base + (long)i * m + j0 + c4);
-        dot += d[0] * z[0] + d[1] * z[1] + d[2] * z[2] + d[3] * z[3];
+        if (z0) {
+            const zf4 z = *reinterpret_cast<const zf4*>(z0 + base + (long)i * m + j0 + c4);
+            dot += d[0] * z[0] + d[1] * z[1] + d[2] * z[2] + d[3] * z[3];
+        }
 #pragma unroll
         for (int e = 0; e < 4; e++) tile[r + 16 * k][c4 + e] = d[e];
     }
-    zf4 o[4];                                      // the dx tile is requested before the barrier, beside the two input tiles
+    zf4 o[4], xs[4];                               // the dx (and x) tiles are requested before the barrier, beside the input tiles
 #pragma unroll
-    for (int k = 0; k < 4; k++) o[k] = *reinterpret_cast<const zf4*>(dx + base + (long)(j0 + r + 16 * k) * m + i0 + c4);
+    for (int k = 0; k < 4; k++) {
+        o[k] = *reinterpret_cast<const zf4*>(dx + base + (long)(j0 + r + 16 * k) * m + i0 + c4);
+        if (!z0) xs[k] = *reinterpret_cast<const zf4*>(x + base + (long)(j0 + r + 16 * k) * m + i0 + c4);
+    }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int j = j0 + r + 16 * k;             // dx[j][i0 + c4 ..] += dz0[i0 + c4 ..][j] * inv
 #pragma unroll
-        for (int e = 0; e < 4; e++) o[k][e] += tile[c4 + e][r + 16 * k] * inv;
+        for (int e = 0; e < 4; e++) {
+            const float d = tile[c4 + e][r + 16 * k];
+            o[k][e] += d * inv;
+            if (!z0) dot += d * (xs[k][e] * inv);  // z0[i][j] = x[j][i] / (c r): no stored z0 needed (mh_nys_sim2 path)
+        }
         *reinterpret_cast<zf4*>(dx + base + (long)j * m + i0 + c4) = o[k];
     }
     dot = block_sum256(dot, red);
@@ -602,9 +611,10 @@ extern "C" int mh_pinv_z0_bwd(const float* x, const float* z0, const float* dz0,
     if (BH == 0) return MH_OK;
     hipError_t e = hipMemsetAsync(scratch1, 0, sizeof(float), (hipStream_t)s);
     if (e != hipSuccess) { mh_set_error("mh_pinv_z0_bwd: memset failed"); return MH_EHIP; }
-    if (m % 64 == 0 && (((uintptr_t)z0 | (uintptr_t)dz0 | (uintptr_t)dx) & 15) == 0) {
+    MH_REQUIRE(z0 || (m % 64 == 0 && (((uintptr_t)x | (uintptr_t)dz0 | (uintptr_t)dx) & 15) == 0), "mh_pinv_z0_bwd: z0 == NULL needs m %% 64 == 0 and aligned buffers");
+    if (m % 64 == 0 && (((uintptr_t)z0 | (uintptr_t)dz0 | (uintptr_t)dx | (uintptr_t)x) & 15) == 0) {
         hipLaunchKernelGGL(pinv_z0_bwd_vec_kernel, dim3(m / 64, m / 64, BH), dim3(256), 0, (hipStream_t)s, z0, dz0,
-                           (const unsigned long long*)stats64, dx, scratch1, m);
+                           (const unsigned long long*)stats64, dx, scratch1, m, x);
     } else {
         dim3 grid(mh_cdiv(m, 32), mh_cdiv(m, 32), BH);
         hipLaunchKernelGGL(pinv_z0_bwd_kernel, grid, dim3(256), 0, (hipStream_t)s, z0, dz0, (const unsigned long long*)stats64, dx, scratch1, m);

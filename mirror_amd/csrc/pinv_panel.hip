@@ -324,7 +324,8 @@ __device__ __forceinline__ void publish() {
 // ---------------------------------------------------------------------------------------------------------- forward
 // XP = PN(X); saved[k] = PN{z_k, P_k, T2_k, T3_k}, z_0 pre-filled; zfT[j][i] = z_iters[i][j] (column-major)
 __global__ __launch_bounds__(CT) void pinv_panel_fwd_kernel(const bf16_t* __restrict__ XT, bf16_t* __restrict__ saved,
-                                                            bf16_t* __restrict__ zfT, int BH, int iters) {
+                                                            bf16_t* __restrict__ zfT, int BH, int iters,
+                                                            const float* __restrict__ z0f, const unsigned long long* __restrict__ st) {
     __shared__ __attribute__((aligned(16))) char img[IMG];
     const int tid = threadIdx.x, lane = tid & 63, hl = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: panel addresses become SGPR base + one VGPR
@@ -336,7 +337,26 @@ __global__ __launch_bounds__(CT) void pinv_panel_fwd_kernel(const bf16_t* __rest
     const bf16_t* Xb = XT + bh * MAT;
     f32x16 acc[8][NJ];
     bf16x8 p[16][NJ];       // THE panel: B operand of the running product, then (in place) its result
-    load_panel(p, saved + bh * MAT, wave, lane);                           // z_0
+    if (z0f) {
+        // z_0 = attn2^T / (c r) from mh_nys_sim2's unscaled f32 panel-native attn2^T and the tensor-wide maxima (complete only now,
+        // after that launch); rounded to bf16 once, and left in saved[0] for the backward
+        const float inv = 1.f / (__uint_as_float((unsigned)(st[0] >> 32)) * __uint_as_float((unsigned)(st[1] >> 32)));
+        const float* zb = z0f + bh * MAT;
+#pragma unroll
+        for (int jb = 0; jb < NJ; jb++)
+#pragma unroll
+            for (int T = 0; T < 16; T++) {
+                const float* src = zb + (((2 * wave + jb) * 16 + T) * 512) + (lane << 3);
+                const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 4; e++) { o[e] = (__bf16)(a[e] * inv); o[4 + e] = (__bf16)(b[e] * inv); }
+                p[T][jb] = o;
+            }
+        store_panel(saved + bh * MAT, p, wave, lane);
+    } else {
+        load_panel(p, saved + bh * MAT, wave, lane);                       // z_0
+    }
     image_from_global<16>(img, Xb, tid);
     __syncthreads();
 #pragma unroll 1
@@ -547,15 +567,17 @@ extern "C" int mh_pinv_chain_pack(const float* dz, void* up, int BH, int m, mh_s
     return MH_OK;
 }
 
-extern "C" int mh_pinv_chain_fwd(const void* XT, void* saved, void* zfT, int BH, int m, int iters, mh_stream s) {
+extern "C" int mh_pinv_chain_fwd(const void* XT, void* saved, void* zfT, int BH, int m, int iters, const float* z0f, const uint64_t* stats64,
+                                 mh_stream s) {
     MH_REQUIRE(m == CM, "mh_pinv_chain_fwd: m=%d unsupported (built for m = %d; other sizes use mh_gemm)", m, CM);
     MH_REQUIRE(iters >= 1 && BH >= 0, "mh_pinv_chain_fwd: bad arguments");
     if (BH == 0) return MH_OK;
 #ifdef MH_EXP       // timing-experiment builds only (make EXP=1): what the step costs without the chain; results are garbage
     if (getenv("MH_EXP_CHAIN_SKIP")) return MH_OK;
 #endif
+    MH_REQUIRE(!z0f || (stats64 && ((uintptr_t)z0f & 15) == 0), "mh_pinv_chain_fwd: z0f needs the maxima and 16-byte alignment");
     hipLaunchKernelGGL(pinv_panel_fwd_kernel, dim3(BH), dim3(CT), chain_claim_bytes(), (hipStream_t)s, (const bf16_t*)XT, (bf16_t*)saved,
-                       (bf16_t*)zfT, BH, iters);
+                       (bf16_t*)zfT, BH, iters, z0f, (const unsigned long long*)stats64);
     MH_LAUNCH_CHECK("mh_pinv_chain_fwd");
     return MH_OK;
 }

@@ -1285,29 +1285,38 @@ class NystromCoreFn(Function):
             mrow, mlm, lscale = kmask
             lm = K.row_scale(lm, lscale)                       # sum over the group / (valid count + 1e-8)
         ql, kl = _heads(lm, 0, 2, h), _heads(lm, 1, 2, h)
-        a2 = K.gemm(ql, kl.transpose(-1, -2), alpha=scale, mma=mma, out_dtype=f32)      # [B,h,m,m]
-        if kmask is None:
-            K.softmax_fwd(a2, a2)
-        else:
-            K.softmax_masked_fwd(a2, mlm, mlm, a2)
-        sd = f32 if pm == MH_F32 else bf16
-        m_l = a2.shape[-1]
+        m_l = lm.shape[1]
         chain = pm == MH_BF16 and m_l == K.PINV_CHAIN_M    # whole iteration in one launch (pinv_panel.hip)
+        # sim2, its softmax, the tensor-wide abs-sum maxima and the chain's operand packing in ONE launch (nystrom_sim2.hip)
+        one = chain and kmask is None and dh == 64 and K.nys_sim2_ok(lm, h)
+        z0f = None
+        if one:
+            a2, xt, z0f, st = K.nys_sim2(lm, h, scale, zeros((4,), qkv.device).view(torch.int64))
+        else:
+            a2 = K.gemm(ql, kl.transpose(-1, -2), alpha=scale, mma=mma, out_dtype=f32)      # [B,h,m,m]
+            if kmask is None:
+                K.softmax_fwd(a2, a2)
+            else:
+                K.softmax_masked_fwd(a2, mlm, mlm, a2)
+        sd = f32 if pm == MH_F32 else bf16
         side = None
         if chain:
             # B*h workgroups with a 128 KiB LDS image each: the chain owns B*h CUs and nothing else.  At B*h = 128 that
             # is half of the chip, so it runs on a side stream beside the attn3 side on the main stream; they meet
             # again at w2 = pinv @ (a3 v).  Chain-private matrices are column-major (see mirror_hip.h).
-            st = K.pinv_absmax(a2, zeros((4,), a2.device).view(torch.int64))
             chain_saved = K.pinv_chain_saved_alloc(iters, Bn * h, m_l, qkv.device)
-            z0, xt = K.pinv_chain_prep(a2, st, K.pinv_chain_z0_slot(chain_saved))
+            z0 = None
+            if not one:
+                st = K.pinv_absmax(a2, zeros((4,), a2.device).view(torch.int64))
+                z0, xt = K.pinv_chain_prep(a2, st, K.pinv_chain_z0_slot(chain_saved))
             zfT = torch.empty((Bn, h, m_l, m_l), device=qkv.device, dtype=bf16)
             zf = zfT.transpose(-1, -2)
             side = _side_stream(qkv.device)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                K.pinv_chain_fwd(xt, chain_saved, zfT, iters)
-            saved = [(xt, chain_saved, z0)]
+                K.pinv_chain_fwd(xt, chain_saved, zfT, iters, z0f=z0f, stats=st if one else None)
+            saved = [(xt, chain_saved, z0 if z0 is not None else st)]      # (no stored f32 z_0 on the one-launch path: a placeholder)
+            ctx.z0_stored = z0 is not None
             K.shared_chip = True         # until the join below: no persistent GEMM kernel beside the half-chip chain
         run_deferred(qkv)        # the v columns of to_qkv: nothing above reads them (landmarks are means of q and k)
         fused = K.nys_fused_ok(qkv, h, m_l) and lm.dtype == bf16      # nystrom_fused.hip: sim1 / sim3 never reach HBM (mask-aware)
@@ -1422,7 +1431,7 @@ class NystromCoreFn(Function):
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 K.pinv_chain_bwd(xb, chain_saved, dzb, work, dS2, dz0, iters)
-                K.pinv_z0_bwd(a2, z0, dz0, st, dS2)
+                K.pinv_z0_bwd(a2, z0 if ctx.z0_stored else None, dz0, st, dS2)
                 sm_bwd(a2, dS2, mlm if kmask else None, mlm if kmask else None)
             K.shared_chip = True         # until the join below
         K.resconv_wgrad(qkv[..., 2 * D:], dout, dres, h)

@@ -687,6 +687,7 @@ def pinv_z0(x: torch.Tensor, stats: torch.Tensor) -> torch.Tensor:
 
 
 def pinv_z0_bwd(x, z0, dz0, stats, dx) -> None:
+    """z0 None: formed on the fly from x and the maxima (nys_sim2 path: no stored f32 z_0)."""
     _chk(x, z0, dz0, stats, dx)
     m = x.shape[-1]
     scratch = torch.empty(1, device=x.device, dtype=torch.float32)
@@ -738,16 +739,40 @@ def pinv_chain_pack(dz: torch.Tensor) -> torch.Tensor:
     return up
 
 
-def pinv_chain_fwd(XT: torch.Tensor, saved: torch.Tensor, zfT: torch.Tensor, iters: int) -> None:
-    """XT = panel-native x, saved[0, 0] = panel-native z_0; zfT receives the column-major z_iters (= pinv^T row-major)."""
-    _chk(XT, saved, zfT)
+def nys_sim2_ok(lm: torch.Tensor, heads: int) -> bool:
+    """mh_nys_sim2's geometry: bf16 landmarks [B, 256, 2 D] with D = heads * 64."""
+    return (lm.dim() == 3 and lm.dtype == torch.bfloat16 and lm.is_contiguous() and lm.shape[1] == PINV_CHAIN_M
+            and lm.shape[2] == 2 * heads * 64 and os.environ.get("MIRROR_NYS_SIM2", "1") != "0")
+
+
+def nys_sim2(lm: torch.Tensor, heads: int, scale: float, stats: Optional[torch.Tensor] = None):
+    """(attn2 f32 [B, h, m, m], xt = panel-native bf16 attn2, z0f = panel-native f32 attn2^T (unscaled z_0), stats) in one launch."""
+    _chk(lm, stats)
+    Bn, m, D2 = lm.shape
+    D = D2 // 2
+    if stats is None:
+        stats = torch.zeros(2, device=lm.device, dtype=torch.int64)
+    a2 = torch.empty((Bn, heads, m, m), device=lm.device, dtype=torch.float32)
+    xt = torch.empty((Bn, heads, m, m), device=lm.device, dtype=torch.bfloat16)
+    z0f = torch.empty((Bn, heads, m, m), device=lm.device, dtype=torch.float32)
+    _lib.call("mh_nys_sim2", _p(lm), _p(a2), _p(xt), _p(z0f), _p(stats), Bn, m, D, heads, float(scale), stream=_stream())
+    return a2, xt, z0f, stats
+
+
+def pinv_chain_fwd(XT: torch.Tensor, saved: torch.Tensor, zfT: torch.Tensor, iters: int, z0f: Optional[torch.Tensor] = None,
+                   stats: Optional[torch.Tensor] = None) -> None:
+    """XT = panel-native x, saved[0, 0] = panel-native z_0 (or z0f / stats from nys_sim2: the kernel then forms z_0 itself and
+    writes saved[0, 0]); zfT receives the column-major z_iters (= pinv^T row-major)."""
+    _chk(XT, saved, zfT, z0f, stats)
     m = XT.shape[-1]
     BH = XT.numel() // (m * m)
     bf = torch.bfloat16
     if not (XT.dtype == bf and saved.dtype == bf and zfT.dtype == bf and XT.is_contiguous() and saved.is_contiguous()
             and zfT.is_contiguous() and saved.numel() == iters * 4 * BH * m * m and zfT.numel() == BH * m * m):
         raise MirrorHipError("pinv_chain_fwd: bad operands")
-    fn = lambda: _lib.call("mh_pinv_chain_fwd", _p(XT), _p(saved), _p(zfT), BH, m, iters, stream=_stream())  # noqa: E731
+    if z0f is not None and not (z0f.dtype == torch.float32 and z0f.is_contiguous() and z0f.numel() == BH * m * m and stats is not None):
+        raise MirrorHipError("pinv_chain_fwd: bad z0f / stats")
+    fn = lambda: _lib.call("mh_pinv_chain_fwd", _p(XT), _p(saved), _p(zfT), BH, m, iters, _p(z0f), _p(stats), stream=_stream())  # noqa: E731
     if gemm_profiler is None:
         fn()
     else:

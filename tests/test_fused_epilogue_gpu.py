@@ -317,3 +317,81 @@ def test_skinny_wgrad_many_equals_single_launches():
     torch.cuda.synchronize()
     for dy, x, dw, _ in many:
         assert float((dw - dy.float().t() @ x.float()).abs().max()) < 1e-3
+
+
+def test_nys_sim2_one_launch_equals_composed_chain_inputs():
+    """mh_nys_sim2 (sim2 + softmax + tensor-wide abs-sum maxima + chain operand packing, one launch) against the composed
+    mh_gemm / mh_softmax_fwd / mh_pinv_absmax / mh_pinv_chain_prep sequence, and the chain forward fed either way."""
+    from mirror_amd import kernels as K
+    from mirror_amd._lib import MH_BF16
+    g = torch.Generator().manual_seed(13)
+    Bn, h, m, dh = 3, 8, 256, 64
+    D = h * dh
+    lm = (torch.randn(Bn, m, 2 * D, generator=g) * 0.7).cuda().to(bf16)
+    scale = dh ** -0.5
+    a2, xt, z0f, st = K.nys_sim2(lm, h, scale)
+    ql = lm.view(Bn, m, 2, h, dh)[:, :, 0].permute(0, 2, 1, 3)
+    kl = lm.view(Bn, m, 2, h, dh)[:, :, 1].permute(0, 2, 1, 3)
+    ref = K.gemm(ql, kl.transpose(-1, -2), alpha=scale, mma=MH_BF16, out_dtype=f32)
+    K.softmax_fwd(ref, ref)
+    st0 = K.pinv_absmax(ref)
+    saved0 = K.pinv_chain_saved_alloc(6, Bn * h, m, "cuda")
+    z0_ref, xt_ref = K.pinv_chain_prep(ref, st0, K.pinv_chain_z0_slot(saved0))
+    torch.cuda.synchronize()
+    assert float((a2 - ref).abs().max()) <= 2e-6, float((a2 - ref).abs().max())
+    assert float((a2.sum(-1) - 1).abs().max()) < 1e-5
+    v = lambda s: s.view(torch.int32).view(-1)[1::2].view(torch.float32)          # the float halves of the packed maxima  # noqa: E731
+    assert torch.allclose(v(st)[:2], v(st0)[:2], rtol=1e-5), (v(st), v(st0))
+    assert float((xt.float() - xt_ref.float()).abs().max()) <= 2 ** -8 * float(ref.max())       # bf16 ulp flips of ~1e-7 differences
+    inv = 1.0 / float(v(st0)[0] * v(st0)[1])
+    # z0f is panel native; scale it and compare through the chain's own saved[0] slot
+    saved1 = K.pinv_chain_saved_alloc(6, Bn * h, m, "cuda")
+    zf0 = torch.empty(Bn, h, m, m, device="cuda", dtype=bf16)
+    zf1 = torch.empty_like(zf0)
+    K.pinv_chain_fwd(xt_ref, saved0, zf0, 6)
+    K.pinv_chain_fwd(xt, saved1, zf1, 6, z0f=z0f, stats=st)
+    torch.cuda.synchronize()
+    assert float((saved1[0, 0].float() - saved0[0, 0].float()).abs().max()) <= 2 ** -7 * float(saved0[0, 0].float().abs().max())
+    assert abs(float(z0f.sum()) * inv - float(z0_ref.sum())) <= 1e-3 * abs(float(z0_ref.sum()))
+    d = float((zf1.float() - zf0.float()).norm()) / float(zf0.float().norm())
+    assert d < 2e-2, d
+    # the backward's z0 adjoint without a stored z0
+    dz0 = torch.randn(Bn, h, m, m, generator=g).cuda()
+    dx_a, dx_b = torch.zeros_like(ref), torch.zeros_like(ref)
+    K.pinv_z0_bwd(ref, z0_ref, dz0, st0, dx_a)
+    K.pinv_z0_bwd(ref, None, dz0, st0, dx_b)
+    torch.cuda.synchronize()
+    assert float((dx_a - dx_b).norm()) <= 1e-5 * float(dx_a.norm())
+
+
+def test_whole_model_nys_sim2_on_off(monkeypatch):
+    """Whole model, bf16, train mode: the one-launch sim2 path against the composed one (losses within 1e-3, gradient cosine >= 0.99)."""
+    import mirror_amd.models as M
+    from mirror_amd import functional as Fn
+    from mirror_amd.losses import MIRRORLoss
+    cfg = dict(wsi_embed_dim=128, rna_embed_dim=96, embed_dim=512, wsi_num_tokens=1024, rna_encoder_depth=1, rna_num_heads=8,
+               rna_mlp_ratio=4.0, style_mlp_hidden_dim=128, style_mlp_out_dim=64, style_latent_dim=32, num_prototypes=300)
+    g = torch.Generator().manual_seed(14)
+    wsi = torch.randn(2, 1024, 128, generator=g).cuda().to(bf16)
+    rna = torch.randn(2, 96, generator=g).cuda()
+    noise = {"wsi_mask": torch.rand(2, 1024, generator=g).cuda(), "rna_mask": torch.rand(2, 512, generator=g).cuda(),
+             "wsi_eps": torch.randn(2, 32, generator=g).cuda(), "rna_eps": torch.randn(2, 32, generator=g).cuda()}
+    out = []
+    for on in ("1", "0"):
+        monkeypatch.setenv("MIRROR_NYS_SIM2", on)
+        torch.manual_seed(0)
+        model = M.mirror(**cfg).cuda().train()
+        model.precision = "bf16"
+        Fn.manual_seed(99)
+        losses = MIRRORLoss()(*model(wsi, rna, noise=noise))
+        losses[0].backward()
+        torch.cuda.synchronize()
+        out.append(([float(x) for x in losses], {k: p.grad.detach().clone() for k, p in model.named_parameters()}))
+    (l1, g1), (l2, g2) = out
+    for a, c in zip(l1, l2):
+        assert abs(a - c) <= 1e-3 * max(abs(c), 1e-3), (l1, l2)
+    for k in g1:
+        a, c = g1[k].flatten().double(), g2[k].flatten().double()
+        if float(c.norm()) < 1e-10:
+            continue
+        assert float(a @ c / (a.norm() * c.norm())) >= 0.99, k
