@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="rank-local InfoNCE even when N>1 (reference behaviour)")
+    ap.add_argument("--grad-dtype", default="f32", choices=["f32", "bf16"], help="wire format of the gradient buckets at N > 1 (config 5: bf16)")
     ap.add_argument("--feed", default="resident", choices=["resident", "host", "host-bf16"],
                     help="resident (default, the metric): the batch is in HBM when the timed region starts; host / host-bf16: every "
                          "step's batch comes from pinned host memory (f32 / bf16 patch features) through mirror_amd.data.HostFeeder, "
@@ -150,7 +151,7 @@ def main():
     loss_fn = MIRRORLoss(alignment_loss_weight=0.5, wsi_retention_loss_weight=0.15, rna_retention_loss_weight=0.15,
                          style_loss_weight=0.1, cluster_loss_weight=0.1,
                          gather_distributed=(world > 1 and not a.no_gather))
-    eng = TrainEngine(model, loss_fn, lr=2e-5, precision=a.precision)
+    eng = TrainEngine(model, loss_fn, lr=2e-5, precision=a.precision, grad_reduce_dtype=a.grad_dtype)
     Fn.manual_seed(1234 + rank)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     in_dtype = torch.float32 if a.precision == "fp32" else torch.bfloat16
@@ -249,6 +250,26 @@ def main():
                                 f"this run is {csrc_digest()} / config {a.config}")
         except (OSError, ValueError, KeyError):
             pass
+        # step-level HBM traffic (sum over every kernel of the same PMC passes) and the dominant kernel's MFMA-pipe utilisation
+        # (profiles/pmc_mfma_busy.json, its own PMC pass): both only when measured on exactly these kernel sources
+        step_bytes, mfma_busy, mfma_note = None, None, "no profiles/pmc_mfma_busy.json entry for this kernel"
+        try:
+            if pm.get("csrc_sha256") == csrc_digest() and pm.get("config", "c2") == a.config:
+                steps_prof = float(pm.get("steps", 9))
+                step_bytes = sum(v["bytes_per_launch"] * v["launches"] for v in pm["kernels"].values()) / steps_prof
+        except (NameError, KeyError, TypeError):
+            pass
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_mfma_busy.json")) as fh:
+                mb = json.load(fh)
+            key = {k.replace(" ", "").replace("unsignedshort", "bf16"): v for k, v in mb["kernels"].items()}
+            ent = key.get(dominant.replace(" ", ""))
+            if ent and mb.get("csrc_sha256") == csrc_digest():
+                mfma_busy, mfma_note = ent["mfma_pipe_utilisation_of_chip"], f"SQ_VALU_MFMA_BUSY_CYCLES pass on csrc {mb['csrc_sha256']} (tools/pmc_mfma.sh)"
+            elif ent:
+                mfma_note = f"stale: measured on csrc {mb.get('csrc_sha256')}, this run is {csrc_digest()}"
+        except (OSError, ValueError, KeyError):
+            pass
         ach = (prof["flops"] / max(prof["launches"], 1)) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         out = {
             "metric": "SSL samples/sec (slide+RNA pairs)", "value": round(value, 3), "unit": "samples/s",
@@ -259,7 +280,7 @@ def main():
                                    f"[{shp['G']} genes], D={shp['D']}, RNA depth {shp['L']} / {shp['heads']} heads, train mode, "
                                    f"{'global' if (world > 1 and not a.no_gather) else 'local'}-batch InfoNCE",
                        "precision_policy": a.precision, "per_gpu_batch": a.batch, "global_batch": a.batch * world,
-                       "parallelism": f"dp{world}", "untimed_steps": nwarm,
+                       "parallelism": f"dp{world}", "untimed_steps": nwarm, "grad_bucket_dtype": a.grad_dtype,
                        "step_launch": "hip_graph" if graphed else (
                            "eager + graphed RNA branch" if getattr(eng, "_rna_branch_state", "") == "on" else "eager")},
             "model_tflops_per_s": round(step_tflops, 2),
@@ -267,6 +288,12 @@ def main():
             "losses": [round(x, 5) for x in loss_vals],
             "roofline": {"bound": "mfma", "kernel": dominant, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_note,
+                         "bound_note": ("`bound` names what limits the DOMINANT KERNEL (a chain of dependent 256^3 products on half of the "
+                                        "CUs: MFMA latency, not throughput); the STEP as a whole moves step_hbm_bytes through HBM and "
+                                        "is closer to the HBM roof than to the MFMA roof, see step_hbm_frac_of_6.3TBps"),
+                         "mfma_busy_frac": mfma_busy, "mfma_busy_source": mfma_note,
+                         "step_hbm_bytes": None if step_bytes is None else int(step_bytes),
+                         "step_hbm_frac_of_6.3TBps": None if step_bytes is None else round(step_bytes / (dt / a.steps) / 6.3e12, 4),
                          "launches_timed": prof["launches"],
                          "timed_in": ("eager re-run of min(K,5) steps right after the timed region (the timed region "
                                       "replays one HIP graph per step)") if graphed else "the timed region",

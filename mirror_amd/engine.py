@@ -47,6 +47,7 @@ def plan_buckets(sizes: Sequence[int], cap_elems: int, align: int = _ALIGN):
 
 
 # A/B switch: 1 (default) = the transposed weight copies are rebuilt at the start of a step on the RNA stream, 0 = behind Adam
+_ASYNC_GATHER = os.environ.get("MIRROR_ASYNC_GATHER", "1") != "0"      # A/B switch: alignment all-gather issued behind the heads
 _DEFER_SKINNY = os.environ.get("MIRROR_DEFER_SKINNY", "1") != "0"     # A/B switch: one multi-tensor launch for the skinny weight gradients
 _TRANSPOSE_AT_START = os.environ.get("MIRROR_TRANSPOSE_AT_START", "1") != "0"
 
@@ -56,13 +57,19 @@ class TrainEngine:
                  precision: str = "bf16", wsi_mask_ratio: float = 0.75, rna_mask_ratio: float = 0.75,
                  bucket_mb: float = 25.0, process_group=None, graph: Optional[bool] = None,
                  clip_grad: Optional[float] = None, accum_steps: int = 1, seed: Optional[int] = None,
-                 snapshot_grads: bool = False):
-        """seed: dropout (Philox) seed of this process; rank is added to it, as the reference's
+                 snapshot_grads: bool = False, grad_reduce_dtype: str = "f32"):
+        """grad_reduce_dtype: "f32" (default: the f32 arena slices are all-reduced in place) or "bf16" (BASELINE config 5 /
+        SURVEY.md §8e "bf16 grads optional": each bucket is rounded to bf16 for the wire — half the xGMI bytes — summed by
+        RCCL in bf16 and widened back into the f32 arena; Adam still reads f32).
+        seed: dropout (Philox) seed of this process; rank is added to it, as the reference's
         `utils.random_seed(args.seed, args.rank)` does (train_mirror.py:682).  Without it, a multi-rank engine folds its rank
         into whatever seed `Fn.manual_seed` last set, so that ranks never draw identical dropout masks.
         snapshot_grads: keep a copy of the (reduced) gradient arena of the last update in `self.grad_snap` (tests)."""
         if precision not in POLICIES:
             raise ValueError(f"unknown precision {precision!r}")
+        if grad_reduce_dtype not in ("f32", "bf16"):
+            raise ValueError(f"grad_reduce_dtype must be 'f32' or 'bf16', got {grad_reduce_dtype!r}")
+        self.grad_reduce_dtype = grad_reduce_dtype
         self.model, self.loss_fn = model, loss_fn
         # the fp8 delayed-scaling sites are keyed by weight-shadow addresses: a new engine's shadows may land where a freed
         # engine's lived, and must not inherit its amax rings
@@ -82,6 +89,10 @@ class TrainEngine:
         clip = getattr(loss_fn, "clip_loss", None)
         if process_group is not None and clip is not None and hasattr(clip, "process_group"):
             clip.process_group = process_group       # gather size / label offset / reduce-scatter follow the gradient group
+        # global-batch InfoNCE: the model issues the alignment all-gather itself, right behind the heads (asynchronous, on a
+        # communication stream: losses.mirror_loss.prefetch_alignment_gather); the loss only awaits it
+        model._align_gather = ((clip.process_group,) if (clip is not None and getattr(clip, "gather_distributed", False) and self.world > 1
+                                                         and _ASYNC_GATHER) else None)
         params = [p for p in model.parameters() if p.requires_grad]
         if not params or not params[0].is_cuda:
             raise Fn.K.MirrorHipError("TrainEngine needs the model on an MI355X device (model.to('cuda') first)")
@@ -255,6 +266,7 @@ class TrainEngine:
         self._pending = [b[2] for b in self.buckets]
         self._reported = [False] * len(self.params)
         self._works = []
+        self._widen = []
         self.comm_stream = torch.cuda.Stream(device=self.device)
         for p in self.params:
             p.register_post_accumulate_grad_hook(self._on_grad)
@@ -278,8 +290,15 @@ class TrainEngine:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             Fn.join_side_streams(self.device, self.comm_stream)
             with torch.cuda.stream(self.comm_stream):
-                w = dist.all_reduce(self.grad[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-            self._works.append(w)
+                self._works.append(self._reduce_slice(s, e))
+
+    def _reduce_slice(self, s: int, e: int):
+        """SUM all-reduce of arena slice [s, e) (called on the communication stream); returns the work handle."""
+        if self.grad_reduce_dtype == "bf16":
+            tmp = self.grad[s:e].to(bf16)
+            self._widen.append((s, e, tmp))
+            return dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        return dist.all_reduce(self.grad[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
     def _finish_reduce(self) -> None:
         if self.world == 1:
@@ -291,9 +310,15 @@ class TrainEngine:
                     self.comm_stream.wait_stream(torch.cuda.current_stream())
                     Fn.join_side_streams(self.device, self.comm_stream)
                     with torch.cuda.stream(self.comm_stream):
-                        self._works.append(dist.all_reduce(self.grad[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                        self._works.append(self._reduce_slice(s, e))
         for w in self._works:
             w.wait()
+        if self._widen:            # bf16 wire format: widen the summed buckets back into the f32 arena (on the comm stream, in order)
+            with torch.cuda.stream(self.comm_stream):
+                for w, (s, e, tmp) in zip(self._works, self._widen):
+                    w.wait()
+                    self.grad[s:e].copy_(tmp)
+            self._widen = []
         torch.cuda.current_stream().wait_stream(self.comm_stream)
         self._works = []
         self._pending = [b[2] for b in self.buckets]

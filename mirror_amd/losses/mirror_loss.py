@@ -17,14 +17,56 @@ from .. import functional as Fn
 f32 = torch.float32
 
 
+# Alignment embeddings whose all-gather is already in flight (prefetch_alignment_gather): (w ptr, r ptr) -> (gathered, work, keep)
+_gather_inflight: dict = {}
+_comm_streams: dict = {}
+
+
+def _comm_stream(device) -> "torch.cuda.Stream":
+    key = torch.device(device).index or 0
+    st = _comm_streams.get(key)
+    if st is None:
+        st = _comm_streams[key] = torch.cuda.Stream(device=device)
+    return st
+
+
+def prefetch_alignment_gather(wsi_emb: torch.Tensor, rna_emb: torch.Tensor, group=None) -> None:
+    """Issue the global-batch InfoNCE all-gather of [wsi_alignment_emb | rna_alignment_emb] NOW, on a communication stream,
+    instead of synchronously inside the loss (north_star: "the all-gather of projected embeddings ... overlapped ... on a side
+    HIP stream").  MIRROR.forward calls this right after the two alignment heads; the retention decoder (a
+    whole TransLayer) and the style head then run while the [B, 2D] message crosses xGMI.  clip_loss_terms picks the result up
+    by the embeddings' storage; if nobody does (no gather configured), the entry is dropped at the next forward."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return
+    x = torch.cat([wsi_emb.detach().float(), rna_emb.detach().float()], dim=1).contiguous()
+    world = dist.get_world_size(group)
+    out = torch.empty((world * x.shape[0], x.shape[1]), device=x.device, dtype=x.dtype)
+    if x.is_cuda:
+        comm = _comm_stream(x.device)
+        comm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(comm):
+            work = dist.all_gather_into_tensor(out, x, group=group, async_op=True)
+        x.record_stream(comm)
+        out.record_stream(comm)
+    else:
+        work = dist.all_gather_into_tensor(out, x, group=group, async_op=True)
+    _gather_inflight.clear()                # one pair per forward
+    _gather_inflight[(wsi_emb.data_ptr(), rna_emb.data_ptr())] = (out, work, x)
+
+
 class _AllGatherCat(torch.autograd.Function):
-    """all_gather along dim 0 with a gradient: backward reduce-scatters (sums) the slices back to their owners."""
+    """all_gather along dim 0 with a gradient: backward reduce-scatters (sums) the slices back to their owners.
+    pre = (gathered, work, _): the gather was issued earlier (prefetch_alignment_gather); only its completion is awaited here."""
 
     @staticmethod
-    def forward(ctx, x, group=None):
+    def forward(ctx, x, group=None, pre=None):
         x = x.contiguous()
         ctx.group = group
         world = dist.get_world_size(group)
+        if pre is not None and tuple(pre[0].shape) == (world * x.shape[0],) + tuple(x.shape[1:]):
+            out, work, _ = pre
+            work.wait()                     # RCCL: the current stream waits for the collective; gloo: the host does
+            return out
         out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)
         dist.all_gather_into_tensor(out, x, group=group)
         return out
@@ -35,7 +77,7 @@ class _AllGatherCat(torch.autograd.Function):
         world = dist.get_world_size(ctx.group)
         out = torch.empty((g.shape[0] // world,) + tuple(g.shape[1:]), device=g.device, dtype=g.dtype)
         dist.reduce_scatter_tensor(out, g, op=dist.ReduceOp.SUM, group=ctx.group)
-        return out, None
+        return out, None, None
 
 
 def clip_loss_terms(wsi, rna, logit_scale, gather: bool = False, group=None):
@@ -47,7 +89,8 @@ def clip_loss_terms(wsi, rna, logit_scale, gather: bool = False, group=None):
     off = 0
     w_all, r_all = w, r
     if gather and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        both = _AllGatherCat.apply(torch.cat([w, r], dim=1), group)   # one message: [P*B, 2D]
+        pre = _gather_inflight.pop((wsi.data_ptr(), rna.data_ptr()), None)     # issued by MIRROR.forward right after the heads
+        both = _AllGatherCat.apply(torch.cat([w, r], dim=1), group, pre)       # one message: [P*B, 2D]
         D = w.shape[1]
         w_all, r_all = both[:, :D], both[:, D:]
         off = dist.get_rank(group) * B

@@ -598,6 +598,12 @@ class MIRROR(nn.Module):
             wsi_alignment_emb = self.wsi_encoder.forward_alignment_head(wsi_cls)
             wsi_score, wsi_mu, wsi_logstd, rna_score, rna_mu, rna_logstd = self.forward_style_clustering(
                 wsi_cls, rna_emb, noise.get("wsi_eps"), noise.get("rna_eps"))
+        ag = getattr(self, "_align_gather", None)      # TrainEngine: the loss contrasts against all ranks (gather_distributed)
+        if ag is not None:
+            # the [B, 2D] all-gather of the global-batch InfoNCE starts now, on a communication stream, under the retention decoder
+            from ..losses.mirror_loss import prefetch_alignment_gather
+            with torch.cuda.stream(heads):
+                prefetch_alignment_gather(wsi_alignment_emb, rna_alignment_emb, ag[0])
         main.wait_event(mask_ready)
         wsi_mask.record_stream(main)
         wsi_retention_emb, wsi_mask = self.wsi_encoder.forward_retention_head(

@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 import torch.nn.functional as F
 
 from mirror_amd.engine import plan_buckets
-from mirror_amd.losses.mirror_loss import _AllGatherCat
+from mirror_amd.losses.mirror_loss import _AllGatherCat, _gather_inflight, prefetch_alignment_gather
 from oracle import mirror_oracle as O
 
 WORLD, B, D = 2, 5, 16
@@ -51,7 +51,17 @@ def _worker(rank, port, q):
             dist.all_reduce(flat[s:e])
             flat[s:e] /= WORLD
         ok4 = torch.allclose(flat, expect)
-        q.put((rank, ok1, ok2, ok3, ok4))
+        # (3) the same gather issued ahead of the loss (prefetch_alignment_gather, what MIRROR.forward does right behind the heads):
+        # the loss-side node only awaits it; values and gradients are those of the synchronous gather
+        w2, r2 = w.detach().clone().requires_grad_(True), r.detach().clone().requires_grad_(True)
+        prefetch_alignment_gather(w2, r2)
+        pre = _gather_inflight.pop((w2.data_ptr(), r2.data_ptr()))
+        both2 = _AllGatherCat.apply(torch.cat([w2, r2], dim=1), None, pre)
+        ok5 = torch.equal(both2, both.detach())
+        wa2, ra2 = both2[:, :D], both2[:, D:]
+        (0.5 * (F.cross_entropy(scale * w2 @ ra2.T, lab) + F.cross_entropy(scale * r2 @ wa2.T, lab))).backward()
+        ok5 = ok5 and torch.allclose(w2.grad, w.grad) and torch.allclose(r2.grad, r.grad)
+        q.put((rank, ok1, ok2, ok3, ok4, ok5))
     finally:
         dist.destroy_process_group()
 

@@ -81,7 +81,20 @@ def _worker(rank, world, port, q):
         for _ in range(2):
             losses = eng.step(wsi[sl], rna[sl], noise={k: v[sl] for k, v in noise.items()})
         flat = eng.master.detach().cpu().numpy()      # numpy: no tensor-sharing handshake with an exiting process
-        q.put((rank, flat, float(losses[1])))
+        # the same two ranks with bf16 gradient buckets on the wire (BASELINE config 5, grad_reduce_dtype="bf16"): the reduced
+        # arena is the f32 one rounded per bucket — ranks stay identical, gradients within bf16 rounding of the f32 reduction
+        m32, m16 = _make(seed=5), _make(seed=5)
+        e32 = TrainEngine(m32, MIRRORLoss(gather_distributed=True), lr=1e-3, precision="fp32", bucket_mb=0.05, snapshot_grads=True)
+        e16 = TrainEngine(m16, MIRRORLoss(gather_distributed=True), lr=1e-3, precision="fp32", bucket_mb=0.05, snapshot_grads=True,
+                          grad_reduce_dtype="bf16")
+        nz = {k: v[sl] for k, v in noise.items()}
+        e32.step(wsi[sl], rna[sl], noise=nz)
+        e16.step(wsi[sl], rna[sl], noise=nz)
+        g32, g16 = e32.grad_snap, e16.grad_snap
+        bf_rel = float((g16 - g32).norm() / g32.norm())
+        bf_same = float((g16 - g16.to(torch.bfloat16).float()).abs().max())     # every reduced value is a bf16 number
+        g16c = g16.cpu().numpy()
+        q.put((rank, flat, float(losses[1]), bf_rel, bf_same, g16c))
     finally:
         dist.destroy_process_group()
 
@@ -101,6 +114,9 @@ def test_two_ranks_match_single_process_on_concatenated_batch():
         assert p.exitcode == 0
     import numpy as np
     assert np.array_equal(res[0][1], res[1][1]), "ranks diverged"
+    for r in res:
+        assert r[3] < 6e-3 and r[4] == 0.0, (r[3], r[4])        # bf16 wire format: 2^-8 relative rounding per element
+    assert np.array_equal(res[0][5], res[1][5]), "ranks diverged under bf16 gradient buckets"
     # single process, whole batch.  The cluster/style/retention terms are batch means, so their gradients agree with
     # the average of the two half-batch gradients; the pinv initial scaling couples samples inside a rank's batch
     # (tensor-wide max), so agreement is to ~1e-3, not bitwise.

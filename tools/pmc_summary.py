@@ -37,5 +37,5 @@ import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import csrc_digest  # noqa: E402
 
-json.dump({"csrc_sha256": csrc_digest(), "config": "c2", "note": "bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB, averaged over the launches of each kernel in a "
-                   "3-step bench run; see tools/pmc_summary.py", "kernels": out}, sys.stdout, indent=1)
+json.dump({"csrc_sha256": csrc_digest(), "config": "c2", "steps": 9, "note": "bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB, averaged over the launches of each kernel in a "
+                   "`bench.py --steps 3 --warmup 1` run = 9 steps (3 untimed, 3 timed, 3 eager re-run); see tools/pmc_summary.py", "kernels": out}, sys.stdout, indent=1)
