@@ -180,7 +180,7 @@ int mh_layernorm_bwd(const void* dy, const void* x, const float* gamma, const fl
 
 /* LayerNorm of a Nystrom layer that also leaves the landmark means of its output (models/mirror.py:298 + [3P] NystromAttention's
  * front padding and `q_landmarks = reduce(q, '... (n l) d -> ... n d', 'sum') / l`): x f32 [batches, >= rows, D] (x_bs elements per
- * batch) -> y bf16 [batches, pad + rows, D] (pad zero rows first, written here) and xpm bf16 [batches, (pad + rows) / l, D] =
+ * batch) -> y bf16 [batches, pad + rows, D] (pad zero rows first, written here) and xpm f32 [batches, (pad + rows) / l, D] =
  * the mean of each group of l consecutive rows of y.  to_qkv is linear and bias-free, so the landmarks are to_qkv(xpm)[:, :2D].
  * mh_layernorm_bwd_lm: mh_layernorm_bwd whose dy rows also receive gadd[b, (i + pad) / l] / l (gadd f32 = d loss / d xpm). */
 int mh_layernorm_fwd_lm(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, void* xpm,

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const TX* __rest
 }
 
 // LayerNorm forward of a Nystrom layer (models/mirror.py:298 + the front zero padding of [3P] NystromAttention) that ALSO
-// leaves the landmark means of its OUTPUT: xpm[b, g] = mean over the l consecutive padded positions g l .. g l + l - 1 of the
+// leaves the landmark means of its OUTPUT: xpm[b, g] (f32) = mean over the l consecutive padded positions g l .. g l + l - 1 of the
 // (bf16-rounded) normalised rows, zero rows for the pad.  to_qkv is linear and bias-free, so the package's landmarks
 // q_landmarks = reduce(q, '... (n l) d -> ... n d', 'sum') / l equal to_qkv(xpm)[:, :2D]: a [B m, D] x [D, 2D] product instead of
 // a pass over the [B, n_p, 2D] q | k columns, and in the backward the landmark gradient reaches the rows through this
@@ -167,7 +167,7 @@ template <int LNV_CH>
 __global__ __launch_bounds__(256) void layernorm_fwd_lm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                                float* __restrict__ mean, float* __restrict__ rstd,
-                                                               bf16_t* __restrict__ xpm, int groups, int m, int rows, int D, long x_bs,
+                                                               float* __restrict__ xpm, int groups, int m, int rows, int D, long x_bs,
                                                                int pad, int l, float eps) {
     const int lane = threadIdx.x & 63;
     const int grp = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -438,12 +438,12 @@ extern "C" int mh_layernorm_fwd_lm(const float* x, const float* gamma, const flo
                                    int batches, int rows, int D, int64_t x_bs, int pad, int l, float eps, mh_stream s) {
     MH_REQUIRE(l >= 1 && pad >= 0 && rows >= 1 && (pad + rows) % l == 0, "mh_layernorm_fwd_lm: pad + rows = %d must be a multiple of l = %d", pad + rows, l);
     MH_REQUIRE(D % 4 == 0 && D <= 2048 && x_bs % 4 == 0 && (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0 &&
-                   (((uintptr_t)y | (uintptr_t)xpm) & 7) == 0,
+                   ((uintptr_t)y & 7) == 0 && ((uintptr_t)xpm & 15) == 0,
                "mh_layernorm_fwd_lm: D %% 4 == 0, D <= 2048 and aligned buffers (D=%d)", D);
     if (batches == 0) return MH_OK;
     const int m = (pad + rows) / l, groups = batches * m;
     dim3 grid(mh_cdiv(groups, 4));
-#define LNL(NC) hipLaunchKernelGGL((layernorm_fwd_lm_kernel<NC>), grid, dim3(256), 0, (hipStream_t)s, x, gamma, beta, (bf16_t*)y, mean, rstd, (bf16_t*)xpm, groups, m, rows, D, (long)x_bs, pad, l, eps)
+#define LNL(NC) hipLaunchKernelGGL((layernorm_fwd_lm_kernel<NC>), grid, dim3(256), 0, (hipStream_t)s, x, gamma, beta, (bf16_t*)y, mean, rstd, (float*)xpm, groups, m, rows, D, (long)x_bs, pad, l, eps)
     if (D <= 512) LNL(2); else if (D <= 1024) LNL(4); else LNL(8);
 #undef LNL
     MH_LAUNCH_CHECK("mh_layernorm_fwd_lm");

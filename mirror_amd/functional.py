@@ -792,7 +792,7 @@ class LayerNormFn(Function):
 
 class LayerNormLmFn(Function):
     """LayerNormFn for a Nystrom layer that also returns the landmark means of its output (mh_layernorm_fwd_lm): (xp bf16
-    [B, pad + rows, D] behind `pad` zero rows, xpm bf16 [B, m, D] = the mean of each group of l consecutive rows of xp).
+    [B, pad + rows, D] behind `pad` zero rows, xpm f32 [B, m, D] = the mean of each group of l consecutive rows of xp).
     [3P] NystromAttention's landmarks are means over l consecutive positions of q and k; to_qkv is linear and bias-free, so they
     are to_qkv(xpm)[:, :2D] (LandmarkProjFn) — no pass over the q | k columns, and in the backward the landmark gradient reaches
     the rows through THIS node (mh_layernorm_bwd_lm) instead of a read-modify-write of dqkv."""
@@ -803,7 +803,7 @@ class LayerNormLmFn(Function):
         Bn, T, D = x.shape
         n_p = pad + rows
         y = torch.empty((Bn, n_p, D), device=x.device, dtype=bf16)
-        xpm = torch.empty((Bn, n_p // l, D), device=x.device, dtype=bf16)
+        xpm = torch.empty((Bn, n_p // l, D), device=x.device, dtype=f32)      # f32: its gradient arrives in f32, no cast launches
         mean = torch.empty((Bn * rows,), device=x.device, dtype=f32)
         rstd = torch.empty_like(mean)
         K.layernorm_fwd_lm(x, gamma.detach(), beta.detach(), y, mean, rstd, xpm, Bn, rows, D, T * D, pad, l, eps)

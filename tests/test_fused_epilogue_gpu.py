@@ -205,7 +205,7 @@ def test_layernorm_landmark_means_and_their_backward(Bn, n, D, m):
             xpm32 = y.float().reshape(Bn, m, l, D).mean(2)
         (y.float() * up_y.float()).sum().backward(retain_graph=True)
         if fused:
-            xpm.backward(up_m.to(bf16))
+            xpm.backward(up_m.to(bf16).float())
         else:
             (xpm32 * up_m.to(bf16).float()).sum().backward()
         res.append((y.detach().clone(), xpm32.detach().clone(), x.grad.clone(), gm.grad.clone(), bt.grad.clone()))
