@@ -398,11 +398,18 @@ class TrainEngine:
         Fn._res_grads.clear()
         if POLICIES[self.precision].fp8_fwd:       # delayed fp8 scaling keys its amax rings on the device-side step counter
             Fn.fp8_delayed_scaling(self._state[0:1], self.step_count)
-        if self._proto is not None:
-            w = self._proto.weight
-            K.rownorm_(w.data)
-            if self.shadow is not None:
-                K.cast(w.data, bf16, out=Fn.shadow(w, POLICIES[self.precision]))
+        def renorm_prototypes():
+            if self._proto is not None:
+                w = self._proto.weight
+                K.rownorm_(w.data)
+                if self.shadow is not None:
+                    K.cast(w.data, bf16, out=Fn.shadow(w, POLICIES[self.precision]))
+        # the prototypes are read by the style / cluster heads, which run on the RNA branch's stream: renormalise them there (beside
+        # the WSI encoder's first GEMM) unless the heads were told to stay on the main stream
+        proto_on_side = (_TRANSPOSE_AT_START and os.environ.get("MIRROR_HEADS_SIDE", "1") != "0"
+                         and os.environ.get("MIRROR_DRAW_SIDE", "1") != "0")
+        if not proto_on_side:
+            renorm_prototypes()
         t_done = None
         if _TRANSPOSE_AT_START:
             # The transposed bf16 weight copies are read by BACKWARD kernels only (data gradients of the [B, D]-row linears): instead
@@ -411,6 +418,8 @@ class TrainEngine:
             main, side = torch.cuda.current_stream(), Fn._side_stream(self.device, 1)
             side.wait_stream(main)
             with torch.cuda.stream(side):
+                if proto_on_side:
+                    renorm_prototypes()
                 self._refresh_transposes()
                 if self._zero_pending:           # the gradient arena of the update that ended the previous step
                     self.grad.zero_()

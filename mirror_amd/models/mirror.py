@@ -33,6 +33,7 @@ _DEFAULT_PRECISION: Optional[str] = None
 _RNA_LATE = os.environ.get("MIRROR_RNA_LATE", "1") != "0"
 # 1 (default) = the alignment / style heads run on the RNA branch's helper stream, 0 = on the caller's stream (A/B switch)
 _HEADS_SIDE = os.environ.get("MIRROR_HEADS_SIDE", "1") != "0"
+_DRAW_SIDE = os.environ.get("MIRROR_DRAW_SIDE", "1") != "0"      # A/B switch: the four noise draws on the RNA stream
 
 
 def set_precision(name: Optional[str]) -> None:
@@ -528,14 +529,6 @@ class MIRROR(nn.Module):
         # the reference draws: rand(B,N) -> rand(B,D) -> eps_wsi -> eps_rna (models/mirror.py:630, :516, :832-833);
         # draw them up front in that order so the two encoders can then run on different streams
         B, dev = wsi_emb.shape[0], wsi_emb.device
-        if "wsi_mask" not in noise:
-            noise["wsi_mask"] = torch.rand(B, wsi_emb.shape[1], device=dev)
-        if "rna_mask" not in noise:
-            noise["rna_mask"] = torch.rand(B, self.embed_dim, device=dev)
-        if "wsi_eps" not in noise:
-            noise["wsi_eps"] = torch.randn(B, self.style_latent_dim, device=dev)
-        if "rna_eps" not in noise:
-            noise["rna_eps"] = torch.randn(B, self.style_latent_dim, device=dev)
         # The RNA encoder is ~100 launch-bound [B, D] kernels (0.06 % of the FLOPs): it runs on a side stream
         # underneath the WSI encoder; autograd replays each backward node on its forward stream, so the RNA
         # backward overlaps the WSI backward as well.
@@ -543,6 +536,21 @@ class MIRROR(nn.Module):
         side = Fn._side_stream(dev, 1)
         fork = main.record_event()
         wsi_in, rna_in = wsi_emb, rna_emb
+        # The four draws are consumed on the side stream only (token ranking, RNA channel mask, the two style samples): they are
+        # launched THERE, in the reference's order, so that the main stream opens with _fc1's GEMM instead of four tiny launches
+        # (the generator hands out its offsets in host program order whatever the stream).
+        draw_stream = side if (_HEADS_SIDE and _DRAW_SIDE and dev.type == "cuda") else main
+        if draw_stream is not main:
+            draw_stream.wait_event(fork)
+        with torch.cuda.stream(draw_stream):
+            if "wsi_mask" not in noise:
+                noise["wsi_mask"] = torch.rand(B, wsi_emb.shape[1], device=dev)
+            if "rna_mask" not in noise:
+                noise["rna_mask"] = torch.rand(B, self.embed_dim, device=dev)
+            if "wsi_eps" not in noise:
+                noise["wsi_eps"] = torch.randn(B, self.style_latent_dim, device=dev)
+            if "rna_eps" not in noise:
+                noise["rna_eps"] = torch.randn(B, self.style_latent_dim, device=dev)
 
         def run_side():
             side.wait_event(fork)

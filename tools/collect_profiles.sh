@@ -22,6 +22,7 @@ rm -rf /tmp/p3; rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/p3 -o f -
 rm -rf /tmp/p4; rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/p4 -o w -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 ff=$(find /tmp/p3 -name "*counter_collection.csv" | head -1); fw=$(find /tmp/p4 -name "*counter_collection.csv" | head -1)
 [ -n "$ff" ] && [ -n "$fw" ] && python3 $R/tools/pmc_summary.py $ff $fw > $OUT/pmc_traffic.json
+(cd $R && bash tools/pmc_mfma.sh > $OUT/pmc_mfma_busy.json 2>/dev/null)      # SQ_VALU_MFMA_BUSY_CYCLES per kernel, its own PMC pass, keyed by the csrc digest
 echo "[collect] pmc done"
 python3 $R/bench.py --config template --no-cpu-baseline > $OUT/${TAG}_template_bench.json 2>/dev/null
 rm -rf /tmp/p5; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p5 -o r -- python3 $R/bench.py --config template --steps 5 --no-cpu-baseline > /dev/null 2>&1
