@@ -407,7 +407,7 @@ class TrainEngine:
         # the prototypes are read by the style / cluster heads, which run on the RNA branch's stream: renormalise them there (beside
         # the WSI encoder's first GEMM) unless the heads were told to stay on the main stream
         proto_on_side = (_TRANSPOSE_AT_START and os.environ.get("MIRROR_HEADS_SIDE", "1") != "0"
-                         and os.environ.get("MIRROR_DRAW_SIDE", "1") != "0")
+                         and os.environ.get("MIRROR_DRAW_SIDE", "0") != "0")
         if not proto_on_side:
             renorm_prototypes()
         t_done = None

@@ -33,7 +33,10 @@ _DEFAULT_PRECISION: Optional[str] = None
 _RNA_LATE = os.environ.get("MIRROR_RNA_LATE", "1") != "0"
 # 1 (default) = the alignment / style heads run on the RNA branch's helper stream, 0 = on the caller's stream (A/B switch)
 _HEADS_SIDE = os.environ.get("MIRROR_HEADS_SIDE", "1") != "0"
-_DRAW_SIDE = os.environ.get("MIRROR_DRAW_SIDE", "1") != "0"      # A/B switch: the four noise draws on the RNA stream
+# A/B switch (default off): the four noise draws + the prototype renorm on the RNA stream, so that the main stream opens with _fc1's
+# GEMM.  Measured on one box, interleaved: 1695 / 1692 / 1693 samples/s with it, 1701 / 1708 / 1704 without — six more launches at
+# the head of the RNA stream cost more than the ~60 us of tiny launches they take off the main stream's start.
+_DRAW_SIDE = os.environ.get("MIRROR_DRAW_SIDE", "0") != "0"
 
 
 def set_precision(name: Optional[str]) -> None:
