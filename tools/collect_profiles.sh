@@ -3,8 +3,9 @@
 # bench line, rocprofv3 kernel stats of the same command, eager-mode per-stream / top-launch views, PMC HBM traffic,
 # template config line + kernel stats, host-feed (PCIe-inclusive) lines, B = 32 line.
 set -u
-TAG=${1:-r02_x}; R=$PWD; OUT=$R/gpurun_out/prof_$TAG; mkdir -p $OUT
+TAG=${1:-r03_x}; PART=${2:-all}; R=$PWD; OUT=$R/gpurun_out/prof_$TAG; mkdir -p $OUT      # PART: core | rest | all (two calls fit gpurun's 20-minute limit)
 cd /tmp; export TMPDIR=/tmp; export PYTHONPATH=$R
+if [ "$PART" != "rest" ]; then
 python3 $R/bench.py > $OUT/${TAG}_c2_bench.json 2> $OUT/bench.err
 echo "[collect] bench done"; 
 rm -rf /tmp/p1; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -o r -- python3 $R/bench.py --no-cpu-baseline > $OUT/${TAG}_c2_bench_under_rocprof.json 2>/dev/null
@@ -24,6 +25,8 @@ ff=$(find /tmp/p3 -name "*counter_collection.csv" | head -1); fw=$(find /tmp/p4 
 [ -n "$ff" ] && [ -n "$fw" ] && python3 $R/tools/pmc_summary.py $ff $fw > $OUT/pmc_traffic.json
 (cd $R && bash tools/pmc_mfma.sh > $OUT/pmc_mfma_busy.json 2>/dev/null)      # SQ_VALU_MFMA_BUSY_CYCLES per kernel, its own PMC pass, keyed by the csrc digest
 echo "[collect] pmc done"
+fi
+if [ "$PART" = "core" ]; then ls -la $OUT; exit 0; fi
 python3 $R/bench.py --config template --no-cpu-baseline > $OUT/${TAG}_template_bench.json 2>/dev/null
 rm -rf /tmp/p5; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p5 -o r -- python3 $R/bench.py --config template --steps 5 --no-cpu-baseline > /dev/null 2>&1
 f=$(find /tmp/p5 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_template_kernel_stats.csv
