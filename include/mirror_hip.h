@@ -405,6 +405,10 @@ int mh_dropout_add(const float* a, const void* x, float* y, int64_t n, float p, 
  * n % 8 == 0, offset % 8 == 0.  The DROPADD projection epilogue (mh_gemm_epi) draws the same stream. */
 int mh_dropout_lite(const float* a, const void* x, void* y, int64_t n, float p, uint64_t seed, uint64_t offset,
                     const uint64_t* dev_base, int dt_x, int dt_y, mh_stream s);
+/* Timeline probe: *dst = the device's constant-rate wall clock (100 MHz ticks) when this one-thread launch runs on stream s.
+ * Profiling aid (tools/exp/probe_timeline.py: where the branches of a replayed step really start and end, without a tracer
+ * attached); nothing on the product path calls it. */
+int mh_timestamp(uint64_t* dst, mh_stream s);
 /* out[c] += sum_r x[r*ld + c]  (bias gradients; f32 atomics) */
 int mh_colsum(const void* x, float* out, int64_t rows, int cols, int64_t ld, int dt, mh_stream s);
 /* y[r] = x[r*x_rs .. +D] / max(||.||, eps) (F.normalize, models/mirror.py:540, :683); norm[r] saved */

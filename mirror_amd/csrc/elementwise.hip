@@ -795,3 +795,12 @@ extern "C" int mh_headattn_bwd(const void* qkv, const float* attn, const void* d
     MH_LAUNCH_CHECK("mh_headattn_bwd");
     return MH_OK;
 }
+
+__global__ void timestamp_kernel(unsigned long long* dst) { *dst = wall_clock64(); }
+
+extern "C" int mh_timestamp(uint64_t* dst, mh_stream s) {
+    MH_REQUIRE(dst != nullptr, "mh_timestamp: null destination");
+    hipLaunchKernelGGL(timestamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, (unsigned long long*)dst);
+    MH_LAUNCH_CHECK("mh_timestamp");
+    return MH_OK;
+}

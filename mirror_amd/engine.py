@@ -396,6 +396,7 @@ class TrainEngine:
                    wsi_key_padding_mask: Optional[torch.Tensor] = None):
         Fn.dropout_step_begin(self.device)
         Fn._res_grads.clear()
+        Fn.probe("step_start")
         if POLICIES[self.precision].fp8_fwd:       # delayed fp8 scaling keys its amax rings on the device-side step counter
             Fn.fp8_delayed_scaling(self._state[0:1], self.step_count)
         def renorm_prototypes():
@@ -440,10 +441,13 @@ class TrainEngine:
         try:
             if self._one is None or self._one.device != losses[0].device:
                 self._one = torch.ones((), device=losses[0].device, dtype=losses[0].dtype)
+            Fn.probe("loss_done")
             losses[0].backward(self._one)        # a persistent root gradient: no ones_like fill launch per step
             if defer:
                 with torch.cuda.stream(Fn._side_stream(self.device, 1)):
+                    Fn.probe("side_bwd_end")
                     Fn.flush_skinny_wgrads()
+                    Fn.probe("flush_end")
         finally:
             Fn._wgrad_queue = None
             Fn.set_grad_sink(None)
@@ -472,6 +476,7 @@ class TrainEngine:
         self.last_grad_scale = gs
         if self.clip_grad is not None:
             K.grad_clip(self.grad, gs, float(self.clip_grad), self._state)
+        Fn.probe("adam_start")
         K.adam(self.master, self.grad, self.m, self.v, self.shadow, self.lr, b1, b2, self.eps, 1.0, 1.0,
                grad_scale=gs,                  # the DDP / accumulation average is folded into Adam
                dev_state=self._state)          # t, bias corrections, lr and the clip factor live on the device

@@ -13,7 +13,7 @@ Precision policies
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Optional, Tuple
+from typing import List, Optional, Tuple
 
 import os
 
@@ -1486,6 +1486,55 @@ class RowScaleFn(Function):
     def backward(ctx, dy):
         (s,) = ctx.saved_tensors
         return K.row_scale(dy.contiguous(), s), None
+
+
+# ------------------------------------------------------------------ timeline probes (profiling aid, MIRROR_PROBE=1)
+# Where the branches of a step really start and end on the device, without a tracer attached (a tracer re-times the queues):
+# one-thread launches that store the device wall clock, named by call site; tools/exp/probe_timeline.py prints them.
+_PROBE = os.environ.get("MIRROR_PROBE", "0") != "0"
+_probe_names: List[str] = []
+_probe_buf: Optional[torch.Tensor] = None
+
+
+def probe(name: str) -> None:
+    global _probe_buf
+    if not _PROBE:
+        return
+    if _probe_buf is None:
+        _probe_buf = torch.zeros(256, dtype=torch.int64, device="cuda")
+    if name not in _probe_names:
+        _probe_names.append(name)
+    K.timestamp(_probe_buf[_probe_names.index(name):_probe_names.index(name) + 1])
+
+
+def probe_read() -> dict:
+    torch.cuda.synchronize()
+    v = _probe_buf[:len(_probe_names)].tolist()
+    return dict(zip(_probe_names, v))
+
+
+class ProbeFn(Function):
+    """identity; stamps `name`.fwd in the forward and `name`.bwd when the gradient of this point is complete"""
+
+    @staticmethod
+    def forward(ctx, x, name):
+        ctx.name = name
+        probe(name + ".fwd")
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        probe(ctx.name + ".bwd")
+        return g, None
+
+
+def probe_point(x: torch.Tensor, name: str) -> torch.Tensor:
+    if not (_PROBE and x.requires_grad):
+        return x
+    y = ProbeFn.apply(x, name)
+    if getattr(x, "_bf16", None) is not None:
+        y._bf16 = x._bf16
+    return y
 
 
 # ------------------------------------------------------------------ masking

@@ -1183,6 +1183,12 @@ def dropout_add(a: torch.Tensor, x: torch.Tensor, p: float, seed: int, offset: i
     return y
 
 
+def timestamp(slot: torch.Tensor) -> None:
+    """*slot (int64, one element) = the device wall clock when the current stream reaches this point (mh_timestamp: profiling aid)."""
+    assert slot.dtype == torch.int64 and slot.numel() == 1 and slot.is_cuda
+    _lib.call("mh_timestamp", _p(slot), stream=_stream())
+
+
 def dropout_lite(x: torch.Tensor, p: float, seed: int, offset: int, dev_base: Optional[torch.Tensor] = None, *, add_to: Optional[torch.Tensor] = None,
                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dropout(x) (or add_to + dropout(x) as f32) on the lite stream (mh_dropout_lite: Philox4x32-7, 16 bits per element);

@@ -260,7 +260,7 @@ class FeatureTransMIL(nn.Module):
         n_tok = h.shape[1]
         side = int(np.ceil(np.sqrt(n_tok)))
         add = side * side - n_tok
-        seq = Fn.Fc1SeqFn.apply(h, self._fc1[0].weight, self._fc1[0].bias, self.cls_token, add, prec)
+        seq = Fn.probe_point(Fn.Fc1SeqFn.apply(h, self._fc1[0].weight, self._fc1[0].bias, self.cls_token, add, prec), "wsi_fc1_out")
         smask = None
         if mask is not None:
             mask = mask.to(h.device, torch.bool)
@@ -514,8 +514,10 @@ class MIRROR(nn.Module):
 
     def rna_branch(self, rna_emb, rna_noise, rna_mask_ratio: float):
         """The RNA side of forward() up to the loss inputs: encoder output, alignment / retention heads, token mask."""
-        rna_emb = self.rna_encoder.forward_encoder(rna_emb)
+        Fn.probe("rna_enc_start")
+        rna_emb = Fn.probe_point(self.rna_encoder.forward_encoder(rna_emb), "rna_enc_out")
         a, r, mask = self.rna_encoder.forward_decoders(rna_emb, mask_ratio=rna_mask_ratio, noise=rna_noise)
+        Fn.probe("rna_branch_end")
         return rna_emb, a, r, mask
 
     def forward(self, wsi_emb, rna_emb, wsi_mask_ratio: float = 0.75, rna_mask_ratio: float = 0.75,
@@ -537,7 +539,7 @@ class MIRROR(nn.Module):
         # backward overlaps the WSI backward as well.
         main = torch.cuda.current_stream()
         side = Fn._side_stream(dev, 1)
-        fork = main.record_event()
+        fork = main.record_event()       # (re-recorded behind the draws below when they stay on the main stream)
         wsi_in, rna_in = wsi_emb, rna_emb
         # The four draws are consumed on the side stream only (token ranking, RNA channel mask, the two style samples): they are
         # launched THERE, in the reference's order, so that the main stream opens with _fc1's GEMM instead of four tiny launches
@@ -554,6 +556,8 @@ class MIRROR(nn.Module):
                 noise["wsi_eps"] = torch.randn(B, self.style_latent_dim, device=dev)
             if "rna_eps" not in noise:
                 noise["rna_eps"] = torch.randn(B, self.style_latent_dim, device=dev)
+        if draw_stream is main:
+            fork = main.record_event()   # the side stream ranks / applies these draws: it has to start behind them
 
         def run_side():
             side.wait_event(fork)
@@ -584,7 +588,8 @@ class MIRROR(nn.Module):
         if n_rna is not None:
             off0 = st["offset"]
             st["offset"] = off0 + n_rna
-            wsi_emb = self.wsi_encoder.forward_encoder(wsi_in, wsi_key_padding_mask)
+            Fn.probe("wsi_enc_start")
+            wsi_emb = Fn.probe_point(self.wsi_encoder.forward_encoder(wsi_in, wsi_key_padding_mask), "wsi_enc_out")
             off_w, st["offset"] = st["offset"], off0
             wsi_mask, mask_ready, (rna_emb, rna_alignment_emb, rna_retention_emb, rna_mask) = run_side()
             if st["offset"] != off0 + n_rna:
@@ -606,9 +611,11 @@ class MIRROR(nn.Module):
         heads.wait_event(main.record_event())
         wsi_cls.record_stream(heads)
         with torch.cuda.stream(heads):
+            Fn.probe("heads_start")
             wsi_alignment_emb = self.wsi_encoder.forward_alignment_head(wsi_cls)
             wsi_score, wsi_mu, wsi_logstd, rna_score, rna_mu, rna_logstd = self.forward_style_clustering(
                 wsi_cls, rna_emb, noise.get("wsi_eps"), noise.get("rna_eps"))
+            Fn.probe("heads_end")
         ag = getattr(self, "_align_gather", None)      # TrainEngine: the loss contrasts against all ranks (gather_distributed)
         if ag is not None:
             # the [B, 2D] all-gather of the global-batch InfoNCE starts now, on a communication stream, under the retention decoder
@@ -617,10 +624,13 @@ class MIRROR(nn.Module):
                 prefetch_alignment_gather(wsi_alignment_emb, rna_alignment_emb, ag[0])
         main.wait_event(mask_ready)
         wsi_mask.record_stream(main)
+        Fn.probe("decoder_start")
         wsi_retention_emb, wsi_mask = self.wsi_encoder.forward_retention_head(
             wsi_full, mask_ratio=wsi_mask_ratio, mask=wsi_mask, key_padding_mask=wsi_key_padding_mask,
             target=wsi_retention_target if self.training else None)
+        Fn.probe("decoder_end")
         main.wait_stream(side)
+        Fn.probe("fwd_joined")
         for t in (rna_emb, rna_alignment_emb, rna_retention_emb, rna_mask, wsi_alignment_emb, wsi_score, wsi_mu, wsi_logstd,
                   rna_score, rna_mu, rna_logstd):
             t.record_stream(main)       # allocated in a helper stream's pool, consumed on the main stream
