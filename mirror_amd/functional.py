@@ -224,7 +224,22 @@ _GEMM_SPLIT = os.environ.get("MIRROR_GEMM_SPLIT", "1") != "0"     # A/B switch f
 _CUS = 256       # MI355X compute units = workgroup slots of the one-workgroup-per-CU 256 x 256 GEMM tile
 
 
-def _gemm_rows(a, b, *, bias=None, act=ACT_NONE, mma, out_dtype, out=None):
+_TAIL_SKINNY = os.environ.get("MIRROR_TAIL_SKINNY", "1") != "0"     # A/B switch
+
+
+def _tail_rows(a2, b, out2, *, bias=None, act=ACT_NONE, mma, wt=None):
+    """out2 [m, N] = act(a2 [m, K] @ b [K, N] + bias) for the few ragged rows a tiled launch leaves over (16 of B x 4097).  A 16-row
+    product is the [B, D]-row shape of the RNA linears: the weight-streaming kernel (mh_skinny_fwd, ~6 us) instead of a tiled GEMM
+    launch (13-22 us for one MFMA row block per workgroup).  b is a weight VIEW: W^T of a forward ([N, K] row-major underneath),
+    or the weight itself in a data gradient, where `wt` is its transposed bf16 shadow."""
+    if _TAIL_SKINNY and mma == MH_BF16 and a2.dim() == 2:
+        W = b.t() if b.stride(0) == 1 else wt
+        if W is not None and W.shape[0] == b.shape[1] and K.skinny_rows_ok(a2, W, out2):
+            return K.skinny_fwd(a2, W, bias, act, out2.dtype, out=out2)
+    return K.gemm(a2, b, out=out2, bias=bias, act=act, mma=mma)
+
+
+def _gemm_rows(a, b, *, bias=None, act=ACT_NONE, mma, out_dtype, out=None, wt=None):
     """a @ b for activations a [..., R, K] against a 2-D weight view b [K, N].  The 256 x 256-tile kernel runs one
     workgroup per CU, so a launch costs ceil(tiles / 256) rounds: the to_qkv data gradient (544 tiles) pays 3 rounds for
     2.1 rounds of work.  When the last round would be less than half full, the rows that fill whole rounds go to one
@@ -242,7 +257,7 @@ def _gemm_rows(a, b, *, bias=None, act=ACT_NONE, mma, out_dtype, out=None):
             a2 = a.reshape(R, Kd)
             o2 = torch.empty((R, N), device=a.device, dtype=out_dtype or a.dtype) if out is None else out.view(R, N)
             _gemm_rows(a2[:R - rem], b, bias=bias, act=act, mma=mma, out_dtype=out_dtype, out=o2[:R - rem])
-            K.gemm(a2[R - rem:], b, out=o2[R - rem:], bias=bias, act=act, mma=mma)
+            _tail_rows(a2[R - rem:], b, o2[R - rem:], bias=bias, act=act, mma=mma, wt=wt)
             return o2.reshape(*a.shape[:-1], N) if out is None else out
         if R % 256 == 0 and N % 256 == 0 and Kd % 64 == 0:
             tn = N // 256
@@ -262,7 +277,18 @@ def _gemm_rows(a, b, *, bias=None, act=ACT_NONE, mma, out_dtype, out=None):
 _GEMM_WINDOW = os.environ.get("MIRROR_GEMM_WINDOW", "1") != "0"     # A/B switch
 
 
-def _gemm_window(a3, b2, out3, *, bias=None, mma):
+def _wt_of(w, prec, dy):
+    """the transposed bf16 shadow of `w` when the rows of `dy` leave a ragged tail for _tail_rows (else None: nothing to look up)"""
+    if not _TAIL_SKINNY or prec.mma != MH_BF16 or w is None or w.dim() != 2:
+        return None
+    rows = dy.shape[-2] if dy.dim() == 3 else dy.numel() // dy.shape[-1]
+    flat = dy.numel() // dy.shape[-1]
+    if not (0 < rows % 256 <= 32 or 0 < flat % 256 <= 32):
+        return None
+    return shadow_t(w, prec)
+
+
+def _gemm_window(a3, b2, out3, *, bias=None, mma, wt=None):
     """out3[b] = a3[b] @ b2 (+ bias) for a row window a3 [B, R, K] of a larger buffer.  Nystrom's `to_out(out)[:, -n:]`
     has R = n = 4097 rows (cls + 4096 patches): 17 row tiles of the 256 x 256 kernel per slide, the 17th holding ONE row,
     and 16 x 17 x 2 = 544 workgroups = a third round on 256 CUs for 32 almost empty tiles.  The few ragged rows go to their
@@ -271,7 +297,10 @@ def _gemm_window(a3, b2, out3, *, bias=None, mma):
     hr = R % 256
     if a3.dim() == 3 and R > 256 and 0 < hr <= 32 and mma == MH_BF16 and _GEMM_WINDOW:
         K.gemm(a3[:, hr:], b2, out=out3[:, hr:], bias=bias, mma=mma)
-        K.gemm(a3[:, :hr], b2, out=out3[:, :hr], bias=bias, mma=mma)
+        if hr == 1:      # one row per slide: [B, K] rows a batch stride apart
+            _tail_rows(a3[:, 0], b2, out3[:, 0], bias=bias, mma=mma, wt=wt)
+        else:
+            K.gemm(a3[:, :hr], b2, out=out3[:, :hr], bias=bias, mma=mma)
     else:
         K.gemm(a3, b2, out=out3, bias=bias, mma=mma)
     return out3
@@ -392,7 +421,7 @@ class LinearFn(Function):
                     K.gemm(dy, wa, out=dx32, accumulate=True, split_k=max(2, min(32, N // 128)), mma=prec.mma)
                     dx = dx32 if ctx.x_dtype == f32 else K.cast(dx32, ctx.x_dtype)
                 else:
-                    dx = _gemm_rows(dy, wa, mma=prec.mma, out_dtype=ctx.x_dtype)
+                    dx = _gemm_rows(dy, wa, mma=prec.mma, out_dtype=ctx.x_dtype, wt=_wt_of(w, prec, dy))
         want_db = ctx.has_b and ctx.needs_input_grad[2]
         fused_db = False
         if ctx.needs_input_grad[1]:
@@ -529,7 +558,7 @@ class LinearRowsFn(Function):
                 dx[:, :r0].zero_()
             if r0 + R < x.shape[1]:
                 dx[:, r0 + R:].zero_()
-            _gemm_window(dy, wa, dx[:, r0:r0 + R], mma=prec.mma)
+            _gemm_window(dy, wa, dx[:, r0:r0 + R], mma=prec.mma, wt=_wt_of(w, prec, dy))
         if ctx.needs_input_grad[1]:
             dw, sunk = _gbuf(w, (N, Kd))
             _wgrad(dy, x[:, r0:r0 + R], N, Kd, prec, dw)
@@ -551,7 +580,7 @@ def _linear_rows_bwd(ctx_needs, x, wa, w, b, r0, R, prec, dy, dx_dtype=None):
             dx[:, :r0].zero_()
         if r0 + R < x.shape[1]:
             dx[:, r0 + R:].zero_()
-        _gemm_window(dy, wa, dx[:, r0:r0 + R], mma=prec.mma)
+        _gemm_window(dy, wa, dx[:, r0:r0 + R], mma=prec.mma, wt=_wt_of(w, prec, dy))
     if ctx_needs[1]:
         dw, sunk = _gbuf(w, (N, Kd))
         _wgrad(dy, x[:, r0:r0 + R], N, Kd, prec, dw)
@@ -583,7 +612,7 @@ class ToOutDropAddFn(Function):
         bd = None if b is None else b.detach()
         K.linear_fused(core, wa, bd, out, K.epi_dropadd(resid, p, ctx.seed, ctx.offset, ctx.base), window=(r0, R), m_rows=M - tail)
         if tail:     # the last rows of the last slide: composed ops on [tail, K] (same stream, same masks: the offsets are per element)
-            yt = K.gemm(core[Bn - 1, r0 + R - tail:r0 + R], wa.t(), bias=bd, mma=prec.mma, out_dtype=bf16)
+            yt = _tail_rows(core[Bn - 1, r0 + R - tail:r0 + R], wa.t(), torch.empty((tail, N), device=core.device, dtype=bf16), bias=bd, mma=prec.mma)
             K.dropout_lite(yt, p, ctx.seed, ctx.offset + (M - tail) * N, ctx.base, add_to=resid.view(M, N)[M - tail:],
                            out=out.view(M, N)[M - tail:])
         ctx.save_for_backward(core, wa, w, b)
@@ -687,7 +716,7 @@ class EmbedMaskPosFn(Function):
         tok, ps = token.detach().reshape(-1).contiguous(), pos.detach().reshape(T, N).contiguous()
         K.linear_fused(h, wa, bd, out, K.epi_maskpos(mask, tok, ps, T, first), m_rows=M - tail)
         if tail and T - tail >= first:       # the last rows of the last slide through the composed ops
-            rt = K.gemm(h[Bn - 1, T - tail:], wa.t(), bias=bd, mma=prec.mma, out_dtype=bf16)
+            rt = _tail_rows(h[Bn - 1, T - tail:], wa.t(), torch.empty((tail, N), device=h.device, dtype=bf16), bias=bd, mma=prec.mma)
             K.mask_apply_fwd(rt.view(1, tail, N), mask[Bn - 1, T - tail - first:].contiguous(), tok, ps[T - tail:].reshape(-1), 1, tail, N, 0, False,
                              out=out[Bn - 1:, T - tail:])
         elif tail:

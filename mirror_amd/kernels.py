@@ -427,14 +427,28 @@ def skinny_ok(x2d: torch.Tensor, w: torch.Tensor) -> bool:
             and (x2d.stride(1) == 1) and x2d.stride(0) % 8 == 0 and x2d.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0)
 
 
-def skinny_fwd(x2d: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act: int, out_dtype) -> torch.Tensor:
-    _chk(x2d, w, bias)
+def skinny_fwd(x2d: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act: int, out_dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out: optional [M, N] destination rows (any row stride that keeps rows 16-byte aligned, e.g. rows of a larger buffer)."""
+    _chk(x2d, w, bias, out)
     M, Kd = x2d.shape
     N = w.shape[0]
-    y = torch.empty((M, N), device=x2d.device, dtype=out_dtype)
-    _lib.call("mh_skinny_fwd", _p(x2d), x2d.stride(0), _p(w), w.stride(0), _p(bias), _p(y), N, M, N, Kd, act, dt(x2d), dt(y),
+    y = torch.empty((M, N), device=x2d.device, dtype=out_dtype) if out is None else out
+    if tuple(y.shape) != (M, N) or y.stride(1) != 1 or x2d.stride(1) != 1 or w.stride(1) != 1:
+        raise MirrorHipError("skinny_fwd: bad operands")
+    _lib.call("mh_skinny_fwd", _p(x2d), x2d.stride(0), _p(w), w.stride(0), _p(bias), _p(y), y.stride(0), M, N, Kd, act, dt(x2d), dt(y),
               stream=_stream())
     return y
+
+
+def skinny_rows_ok(x2d: torch.Tensor, w: torch.Tensor, y2d: torch.Tensor) -> bool:
+    """mh_skinny_fwd's limits for rows of larger buffers (x2d [M <= 32, K], w [N, K], y2d [M, N]; unit inner strides)."""
+    ok_dt = (torch.bfloat16, torch.float32)
+    return (x2d.dim() == 2 and w.dim() == 2 and y2d.dim() == 2 and 1 <= x2d.shape[0] <= 32 and x2d.shape[1] % 32 == 0
+            and x2d.shape[1] == w.shape[1] and tuple(y2d.shape) == (x2d.shape[0], w.shape[0])
+            and x2d.stride(1) == 1 and w.stride(1) == 1 and y2d.stride(1) == 1
+            and x2d.stride(0) % 8 == 0 and w.stride(0) % 8 == 0 and y2d.stride(0) % 8 == 0
+            and x2d.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0 and y2d.data_ptr() % 16 == 0
+            and x2d.dtype in ok_dt and y2d.dtype in ok_dt and w.dtype == torch.bfloat16)
 
 
 def skinny_wgrad(dy2d: torch.Tensor, x2d: torch.Tensor, dw: torch.Tensor, accumulate: bool, db: Optional[torch.Tensor] = None) -> None:

@@ -80,8 +80,8 @@ def test_retention_embed_mask_pos_epilogue_equals_composed(Bn, T, Kd, N):
         res.append([y.detach().clone()] + [t.grad.clone() for t in (h, w, b, token, pos)])
     torch.cuda.synchronize()
     for i, (a, c) in enumerate(zip(*res)):
-        if i in (2, 3, 4, 5):       # dW, db, dtoken, dpos: f32 sums whose order may differ (split-K, atomics)
-            assert float((a - c).abs().max()) <= 1e-5 * float(c.abs().max())
+        if i in (1, 2, 3, 4, 5):    # dW, db, dtoken, dpos: f32 sums whose order may differ (split-K, atomics); dh: the ragged rows go
+            assert float((a - c).abs().max()) <= 1e-5 * float(c.abs().max())      # through the weight-streaming kernel (f32 FMA order)
         else:
             assert torch.equal(a, c), (i, float((a.float() - c.float()).abs().max()))
 
