@@ -184,7 +184,8 @@ int mh_layernorm_bwd(const void* dy, const void* x, const float* gamma, const fl
  * the mean of each group of l consecutive rows of y.  to_qkv is linear and bias-free, so the landmarks are to_qkv(xpm)[:, :2D].
  * mh_layernorm_bwd_lm: mh_layernorm_bwd whose dy rows also receive gadd[b, (i + pad) / l] / l (gadd f32 = d loss / d xpm). */
 int mh_layernorm_fwd_lm(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, void* xpm,
-                        int batches, int rows, int D, int64_t x_bs, int pad, int l, float eps, mh_stream s);
+                        void* xpm_bf16, int batches, int rows, int D, int64_t x_bs, int pad, int l, float eps, mh_stream s);
+                        /* xpm_bf16 (optional): the bf16 rounding of xpm, the B operand of the landmark projection's weight gradient */
 int mh_layernorm_bwd_lm(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                         void* dx, float* dgamma, float* dbeta, int batches, int rows_per_batch, int D, int64_t x_bs, int64_t y_bs,
                         int dt_x, int dt_dy, int dt_dx, int accumulate_dx, float* workspace, int64_t ws_floats,

@@ -167,8 +167,8 @@ template <int LNV_CH>
 __global__ __launch_bounds__(256) void layernorm_fwd_lm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                                float* __restrict__ mean, float* __restrict__ rstd,
-                                                               float* __restrict__ xpm, int groups, int m, int rows, int D, long x_bs,
-                                                               int pad, int l, float eps) {
+                                                               float* __restrict__ xpm, bf16_t* __restrict__ xpm16, int groups, int m, int rows,
+                                                               int D, long x_bs, int pad, int l, float eps) {
     const int lane = threadIdx.x & 63;
     const int grp = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (grp >= groups) return;
@@ -253,7 +253,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_lm_kernel(const float* __re
 #pragma unroll
     for (int k = 0; k < LNV_CH; k++) {
         const int c = 256 * k + 4 * lane;
-        if (c < D) st4(xpm + ((long)b * m + g) * D + c, acc[k] * inv);
+        if (c < D) {
+            st4(xpm + ((long)b * m + g) * D + c, acc[k] * inv);
+            if (xpm16) st4(xpm16 + ((long)b * m + g) * D + c, acc[k] * inv);      // what a bf16 MFMA operand load of xpm rounds to
+        }
     }
 }
 
@@ -435,15 +438,15 @@ extern "C" int mh_layernorm_fwd(const void* x, const float* gamma, const float* 
 }
 
 extern "C" int mh_layernorm_fwd_lm(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, void* xpm,
-                                   int batches, int rows, int D, int64_t x_bs, int pad, int l, float eps, mh_stream s) {
+                                   void* xpm_bf16, int batches, int rows, int D, int64_t x_bs, int pad, int l, float eps, mh_stream s) {
     MH_REQUIRE(l >= 1 && pad >= 0 && rows >= 1 && (pad + rows) % l == 0, "mh_layernorm_fwd_lm: pad + rows = %d must be a multiple of l = %d", pad + rows, l);
     MH_REQUIRE(D % 4 == 0 && D <= 2048 && x_bs % 4 == 0 && (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0 &&
-                   ((uintptr_t)y & 7) == 0 && ((uintptr_t)xpm & 15) == 0,
+                   ((uintptr_t)y & 7) == 0 && ((uintptr_t)xpm & 15) == 0 && ((uintptr_t)xpm_bf16 & 7) == 0,
                "mh_layernorm_fwd_lm: D %% 4 == 0, D <= 2048 and aligned buffers (D=%d)", D);
     if (batches == 0) return MH_OK;
     const int m = (pad + rows) / l, groups = batches * m;
     dim3 grid(mh_cdiv(groups, 4));
-#define LNL(NC) hipLaunchKernelGGL((layernorm_fwd_lm_kernel<NC>), grid, dim3(256), 0, (hipStream_t)s, x, gamma, beta, (bf16_t*)y, mean, rstd, (float*)xpm, groups, m, rows, D, (long)x_bs, pad, l, eps)
+#define LNL(NC) hipLaunchKernelGGL((layernorm_fwd_lm_kernel<NC>), grid, dim3(256), 0, (hipStream_t)s, x, gamma, beta, (bf16_t*)y, mean, rstd, (float*)xpm, (bf16_t*)xpm_bf16, groups, m, rows, D, (long)x_bs, pad, l, eps)
     if (D <= 512) LNL(2); else if (D <= 1024) LNL(4); else LNL(8);
 #undef LNL
     MH_LAUNCH_CHECK("mh_layernorm_fwd_lm");

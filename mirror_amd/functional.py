@@ -819,6 +819,10 @@ class LayerNormFn(Function):
         return dx, _gret(gamma, dg, sunk_g), _gret(beta, db, sunk_b), None, None, None, None, None, None
 
 
+_LM_BF16 = os.environ.get("MIRROR_LM_BF16", "1") != "0"      # A/B switch
+_xpm16: dict = {}      # data_ptr of the landmark means a LayerNormLmFn just produced -> their bf16 rounding (taken by LandmarkProjFn)
+
+
 class LayerNormLmFn(Function):
     """LayerNormFn for a Nystrom layer that also returns the landmark means of its output (mh_layernorm_fwd_lm): (xp bf16
     [B, pad + rows, D] behind `pad` zero rows, xpm f32 [B, m, D] = the mean of each group of l consecutive rows of xp).
@@ -835,7 +839,11 @@ class LayerNormLmFn(Function):
         xpm = torch.empty((Bn, n_p // l, D), device=x.device, dtype=f32)      # f32: its gradient arrives in f32, no cast launches
         mean = torch.empty((Bn * rows,), device=x.device, dtype=f32)
         rstd = torch.empty_like(mean)
-        K.layernorm_fwd_lm(x, gamma.detach(), beta.detach(), y, mean, rstd, xpm, Bn, rows, D, T * D, pad, l, eps)
+        xpm16 = torch.empty_like(xpm, dtype=bf16) if (_LM_BF16 and any(ctx.needs_input_grad)) else None     # (grad mode is off in here)
+        K.layernorm_fwd_lm(x, gamma.detach(), beta.detach(), y, mean, rstd, xpm, Bn, rows, D, T * D, pad, l, eps, xpm_bf16=xpm16)
+        if xpm16 is not None:
+            _xpm16.clear()
+            _xpm16[xpm.data_ptr()] = xpm16      # LandmarkProjFn's weight gradient takes bf16 operands (the tiled split-K kernel)
         ctx.save_for_backward(x, gamma, mean, rstd, beta)
         ctx.rows, ctx.pad, ctx.l = rows, pad, l
         return y, xpm
@@ -872,7 +880,10 @@ class LandmarkProjFn(Function):
         wa = shadow(w, prec)
         n2 = 2 * wa.shape[1]
         lm = K.gemm(xpm, wa[:n2].t(), mma=prec.mma, out_dtype=prec.act)
-        ctx.save_for_backward(xpm, wa, w)
+        x16 = _xpm16.pop(xpm.data_ptr(), None)
+        if x16 is not None and x16.shape != xpm.shape:
+            x16 = None
+        ctx.save_for_backward(xpm if x16 is None else x16, wa, w)
         ctx.prec, ctx.n2 = prec, n2
         return lm
 

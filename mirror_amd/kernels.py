@@ -555,13 +555,15 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, batches, rpb, D, 
               ws.numel() if ws is not None else 0, stream=_stream())
 
 
-def layernorm_fwd_lm(x, gamma, beta, y, mean, rstd, xpm, batches, rows, D, x_bs, pad, l, eps):
+def layernorm_fwd_lm(x, gamma, beta, y, mean, rstd, xpm, batches, rows, D, x_bs, pad, l, eps, xpm_bf16=None):
     """LayerNorm (f32 in, bf16 out behind `pad` zero rows, which this launch writes) + the landmark means xpm [batches, (pad + rows) / l, D]
     (f32) of its output rows (mh_layernorm_fwd_lm)."""
     _chk(x, gamma, beta, y, mean, rstd, xpm)
     if not (x.dtype == torch.float32 and y.dtype == torch.bfloat16 and xpm.dtype == torch.float32 and y.is_contiguous() and xpm.is_contiguous()):
         raise MirrorHipError("layernorm_fwd_lm: f32 input, contiguous bf16 rows and f32 landmark means")
-    _lib.call("mh_layernorm_fwd_lm", _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), _p(xpm), batches, rows, D, x_bs, int(pad),
+    if xpm_bf16 is not None and not (xpm_bf16.dtype == torch.bfloat16 and xpm_bf16.is_contiguous() and xpm_bf16.shape == xpm.shape):
+        raise MirrorHipError("layernorm_fwd_lm: xpm_bf16 must be a contiguous bf16 tensor of xpm's shape")
+    _lib.call("mh_layernorm_fwd_lm", _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), _p(xpm), _p(xpm_bf16), batches, rows, D, x_bs, int(pad),
               int(l), eps, stream=_stream())
 
 
