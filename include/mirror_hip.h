@@ -249,6 +249,11 @@ int mh_pinv_z0(const float* x, const uint64_t* stats64, float* z0, int BH, int m
 /* dx += dz0^T/(c r) + sub-gradients through the two max(); z0 may be NULL (m % 64 == 0): z0 = x^T / (c r) is then formed on the fly */
 int mh_pinv_z0_bwd(const float* x, const float* z0, const float* dz0, const uint64_t* stats64, float* dx,
                    float* scratch1, int BH, int m, mh_stream s);
+/* attn2's backward tail in one pass (m = 256, x = p = the softmax output of [3P] sim2, no key-padding mask): on entry dx holds the
+ * chain's d loss / d x; on exit dx = d loss / d sim2-logits = softmax_bwd(p, dx + dz0^T / (c r) + max sub-gradients).  Equals
+ * mh_pinv_z0_bwd(x = p, z0 = NULL) followed by mh_softmax_bwd up to the rounding of the row sums (the row maximum's constant cancels
+ * in a softmax backward; the column maximum's is applied as a rank-one correction of the one matrix that holds it). */
+int mh_pinv_s2_bwd(const float* p, const float* dz0, const uint64_t* stats64, float* dx, float* scratch1, int BH, int m, mh_stream s);
 /* The whole iteration as ONE launch per pass (bf16 policy, m = 256; other sizes return MH_EINVAL and the caller
  * composes mh_gemm): one 256-thread workgroup per (b,h) walks the chain of m x m products; a wave owns 64 columns of
  * every product, its B operand never leaves the register file, A is one LDS image (pinv_panel.hip).

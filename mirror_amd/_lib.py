@@ -111,6 +111,7 @@ _SIGS = {
     "mh_pinv_absmax": [P, P, I, I],
     "mh_pinv_z0": [P, P, P, I, I],
     "mh_pinv_z0_bwd": [P, P, P, P, P, P, I, I],
+    "mh_pinv_s2_bwd": [P, P, P, P, P, I, I],
     "mh_eye_minus": [P, P, F, I, I],
     "mh_pinv_chain_prep": [P, P, P, P, P, I, I],
     "mh_pinv_chain_pack": [P, P, I, I],

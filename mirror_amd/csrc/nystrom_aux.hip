@@ -624,6 +624,99 @@ extern "C" int mh_pinv_z0_bwd(const float* x, const float* z0, const float* dz0,
     return MH_OK;
 }
 
+// ---- attn2's whole backward tail in one pass (x = softmax output of [3P] sim2, no key-padding mask, m = 256) ------------------------
+// What mh_pinv_z0_bwd + the softmax backward do in three passes over four [BH, m, m] f32 tensors (each on the chain's stream, i.e.
+// on the critical path of the backward window):   dP = dX + dz0^T / (c r);   dS = P o (dP - rowsum(P o dP)).
+// The sub-gradients through the two torch.max() of moore_penrose_iter_pinv's start add g_r to ONE row and g_c to ONE column of dP
+// (of the matrices that hold the maxima).  After a softmax backward a constant added to a row of dP cancels (rows of P sum to one:
+// what is left is g_r (1 - rowsum) ~ 1e-7 g_r, the rounding of the sum), so only the column term survives, as a rank-one correction
+// of one matrix:  dS[i][j] += g_c P[i][j] ([j == j*] - P[i][j*]),  applied by pinv_s2_colfix_kernel once the dot product
+// S = sum dz0 o z0 (g_c = -S / (c r) * c) is complete.
+constexpr int S2_ROWS = 32;                 // rows of dS per workgroup
+constexpr int S2_PITCH = 260;               // floats: 16-byte aligned rows, the column writes of the transposed tile hit 64 distinct banks
+__global__ __launch_bounds__(256) void pinv_s2_bwd_kernel(const float* __restrict__ P, const float* __restrict__ dz0,
+                                                          const unsigned long long* __restrict__ st, float* __restrict__ dx,
+                                                          float* __restrict__ scratch) {
+    typedef float zf4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) float T[S2_ROWS * S2_PITCH];      // T[i][j] = dz0[j][i0 + i]
+    __shared__ float red[4];
+    const float inv = 1.f / (stat_val(st, 0) * stat_val(st, 1));
+    const long base = (long)blockIdx.y * 256 * 256;
+    const int i0 = blockIdx.x * S2_ROWS, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // this wave's 8 rows of P and dX are requested before the transposed tile is built
+    zf4 p[8], g[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const long off = base + (long)(i0 + 8 * wave + r) * 256 + 4 * lane;
+        p[r] = *reinterpret_cast<const zf4*>(P + off);
+        g[r] = *reinterpret_cast<const zf4*>(dx + off);
+    }
+    {
+        const float* src = dz0 + base + (long)tid * 256 + i0;                   // row j = tid, 32 consecutive i: 128 bytes
+        zf4 d[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) d[k] = *reinterpret_cast<const zf4*>(src + 4 * k);
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) T[(4 * k + e) * S2_PITCH + tid] = d[k][e];
+    }
+    __syncthreads();
+    float dot = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const zf4 t = *reinterpret_cast<const zf4*>(T + (8 * wave + r) * S2_PITCH + 4 * lane);
+        zf4 dp;
+        float rs = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            dp[e] = g[r][e] + t[e] * inv;
+            dot += t[e] * (p[r][e] * inv);                  // z0[j][i] = x[i][j] / (c r)
+            rs += p[r][e] * dp[e];
+        }
+        rs = wave_sum(rs);
+        zf4 o;
+#pragma unroll
+        for (int e = 0; e < 4; e++) o[e] = p[r][e] * (dp[e] - rs);
+        *reinterpret_cast<zf4*>(dx + base + (long)(i0 + 8 * wave + r) * 256 + 4 * lane) = o;
+    }
+    dot = block_sum256(dot, red);
+    if (tid == 0) atomicAdd(scratch, dot);
+}
+
+// the column maximum's sub-gradient through the softmax backward (see above): one wave per row of the matrix that holds it
+__global__ __launch_bounds__(256) void pinv_s2_colfix_kernel(const float* __restrict__ P, const unsigned long long* __restrict__ st,
+                                                             const float* __restrict__ scratch, float* __restrict__ dx) {
+    typedef float zf4 __attribute__((ext_vector_type(4)));
+    const float c = stat_val(st, 0), r = stat_val(st, 1);
+    const float gc = -scratch[0] / (c * r) * c;
+    const unsigned ci = (unsigned)(st[1] & 0xffffffffu);
+    const long base = (long)(ci / 256) * 256 * 256;
+    const int js = ci % 256, lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long off = base + (long)i * 256 + 4 * lane;
+    const float pj = P[base + (long)i * 256 + js];
+    const zf4 p = *reinterpret_cast<const zf4*>(P + off);
+    zf4 d = *reinterpret_cast<const zf4*>(dx + off);
+#pragma unroll
+    for (int e = 0; e < 4; e++) d[e] += gc * p[e] * ((4 * lane + e == js ? 1.f : 0.f) - pj);
+    *reinterpret_cast<zf4*>(dx + off) = d;
+}
+
+extern "C" int mh_pinv_s2_bwd(const float* p, const float* dz0, const uint64_t* stats64, float* dx, float* scratch1, int BH, int m,
+                              mh_stream s) {
+    MH_REQUIRE(m == 256, "mh_pinv_s2_bwd: built for m = 256 (m=%d): compose mh_pinv_z0_bwd + mh_softmax_bwd", m);
+    MH_REQUIRE(p && dz0 && stats64 && dx && scratch1 && (((uintptr_t)p | (uintptr_t)dz0 | (uintptr_t)dx) & 15) == 0,
+               "mh_pinv_s2_bwd: null / unaligned buffer");
+    if (BH == 0) return MH_OK;
+    hipError_t e = hipMemsetAsync(scratch1, 0, sizeof(float), (hipStream_t)s);
+    if (e != hipSuccess) { mh_set_error("mh_pinv_s2_bwd: memset failed"); return MH_EHIP; }
+    hipLaunchKernelGGL(pinv_s2_bwd_kernel, dim3(256 / S2_ROWS, BH), dim3(256), 0, (hipStream_t)s, p, dz0, (const unsigned long long*)stats64, dx,
+                       scratch1);
+    hipLaunchKernelGGL(pinv_s2_colfix_kernel, dim3(64), dim3(256), 0, (hipStream_t)s, p, (const unsigned long long*)stats64, scratch1, dx);
+    MH_LAUNCH_CHECK("mh_pinv_s2_bwd");
+    return MH_OK;
+}
+
 __global__ __launch_bounds__(256) void eye_minus_kernel(const float* __restrict__ P, float* __restrict__ T, float d, long total, int m) {
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int j = idx % m;

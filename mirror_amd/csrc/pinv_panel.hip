@@ -574,6 +574,7 @@ extern "C" int mh_pinv_chain_fwd(const void* XT, void* saved, void* zfT, int BH,
     if (BH == 0) return MH_OK;
 #ifdef MH_EXP       // timing-experiment builds only (make EXP=1): what the step costs without the chain; results are garbage
     if (getenv("MH_EXP_CHAIN_SKIP")) return MH_OK;
+    if (const char* e = getenv("MH_EXP_CHAIN_FWD_ITERS")) iters = atoi(e);     // what a faster chain would buy: fewer iterations, same launch
 #endif
     MH_REQUIRE(!z0f || (stats64 && ((uintptr_t)z0f & 15) == 0), "mh_pinv_chain_fwd: z0f needs the maxima and 16-byte alignment");
     hipLaunchKernelGGL(pinv_panel_fwd_kernel, dim3(BH), dim3(CT), chain_claim_bytes(), (hipStream_t)s, (const bf16_t*)XT, (bf16_t*)saved,
@@ -589,6 +590,7 @@ extern "C" int mh_pinv_chain_bwd(const void* XT, const void* saved, const void* 
     if (BH == 0) return MH_OK;
 #ifdef MH_EXP
     if (getenv("MH_EXP_CHAIN_SKIP")) return MH_OK;
+    if (const char* e = getenv("MH_EXP_CHAIN_BWD_ITERS")) iters = atoi(e);
 #endif
     hipLaunchKernelGGL(pinv_panel_bwd_kernel, dim3(BH), dim3(CT), chain_claim_bytes(), (hipStream_t)s, (const bf16_t*)XT, (const bf16_t*)saved,
                        (const bf16_t*)dzf, (bf16_t*)work, dX, dz0, BH, iters);

@@ -1298,6 +1298,10 @@ def _pair(first: torch.Tensor, second: torch.Tensor) -> torch.Tensor:
     return torch.as_strided(first, (2,) + tuple(first.shape), (first.numel(),) + tuple(first.stride()))
 
 
+_S2_TAIL = os.environ.get("MIRROR_S2_TAIL", "1") != "0"      # A/B switch
+_RCW_EARLY = os.environ.get("MIRROR_RCW_EARLY", "0") != "0"  # A/B switch: res_conv weight gradient in front of the chain fork (measured neutral: 1757 / 1758 / 1750 vs 1757 / 1761 / 1752)
+
+
 class NystromCoreFn(Function):
     """[3P] NystromAttention between to_qkv and to_out (called at models/mirror.py:312):
     qkv [B, n_p, 3D] -> out [B, n_p, D] = softmax(q k_l^T) . pinv(softmax(q_l k_l^T)) . softmax(q_l k^T) v + res_conv(v).
@@ -1448,6 +1452,8 @@ class NystromCoreFn(Function):
         dres, dres_sunk = _gbuf(res_w, (rw.numel(),))     # the 33-tap filters' gradient goes straight into the grad arena
         # out = a1 @ w2 ; w2 = Z @ av ; av = a3 @ v.  dZ first: it is all the pinv backward needs (the res_conv weight
         # gradient does not depend on it and runs beside the chain, below).
+        if _RCW_EARLY and chain:
+            K.resconv_wgrad(qkv[..., 2 * D:], dout, dres, h)      # alone on the chip (38 us) instead of beside the chain's first loads (144 us)
         if fused:
             lse1, lse3 = a1, a3
             dW2 = zeros((Bn, h, m, dh), qkv.device)
@@ -1471,10 +1477,14 @@ class NystromCoreFn(Function):
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 K.pinv_chain_bwd(xb, chain_saved, dzb, work, dS2, dz0, iters)
-                K.pinv_z0_bwd(a2, z0 if ctx.z0_stored else None, dz0, st, dS2)
-                sm_bwd(a2, dS2, mlm if kmask else None, mlm if kmask else None)
+                if _S2_TAIL and kmask is None and not ctx.z0_stored and a2.shape[-1] == 256:
+                    K.pinv_s2_bwd(a2, dz0, st, dS2)      # z_0 backward, the maxima's sub-gradients and attn2's softmax backward: one pass
+                else:
+                    K.pinv_z0_bwd(a2, z0 if ctx.z0_stored else None, dz0, st, dS2)
+                    sm_bwd(a2, dS2, mlm if kmask else None, mlm if kmask else None)
             K.shared_chip = True         # until the join below
-        K.resconv_wgrad(qkv[..., 2 * D:], dout, dres, h)
+        if not (_RCW_EARLY and chain):
+            K.resconv_wgrad(qkv[..., 2 * D:], dout, dres, h)
         dAV = K.gemm(tr(zf), dW2, mma=pio, out_dtype=A)                                  # [B,h,m,dh]
         if fused:
             K.nys_attn3_bwd(qkv, lm, av, dAV, lse3, dqkv, dlm, h, scale, kmask)         # dk, dv, dq_l

@@ -711,6 +711,17 @@ def pinv_z0_bwd(x, z0, dz0, stats, dx) -> None:
               x.numel() // (m * m), m, stream=_stream())
 
 
+def pinv_s2_bwd(p, dz0, stats, dx) -> None:
+    """dx (the chain's gradient wrt attn2 on entry) -> gradient wrt sim2's logits, one pass (mh_pinv_s2_bwd: m = 256, no mask)."""
+    _chk(p, dz0, stats, dx)
+    m = p.shape[-1]
+    if not (p.dtype == dz0.dtype == dx.dtype == torch.float32 and p.is_contiguous() and dz0.is_contiguous() and dx.is_contiguous()
+            and p.shape == dz0.shape == dx.shape and p.shape[-2] == m):
+        raise MirrorHipError("pinv_s2_bwd: contiguous f32 [.., m, m] tensors of one shape")
+    scratch = torch.empty(1, device=p.device, dtype=torch.float32)
+    _lib.call("mh_pinv_s2_bwd", _p(p), _p(dz0), _p(stats), _p(dx), _p(scratch), p.numel() // (m * m), m, stream=_stream())
+
+
 PINV_CHAIN_M = 256
 
 

@@ -395,3 +395,29 @@ def test_whole_model_nys_sim2_on_off(monkeypatch):
         if float(c.norm()) < 1e-10:
             continue
         assert float(a @ c / (a.norm() * c.norm())) >= 0.99, k
+
+
+def test_attn2_backward_tail_one_pass_equals_z0_bwd_plus_softmax_bwd():
+    """mh_pinv_s2_bwd (z_0 backward + the two max() sub-gradients + attn2's softmax backward in one pass, the column maximum as a
+    rank-one correction) against the composed mh_pinv_z0_bwd + mh_softmax_bwd on the same inputs ([3P] moore_penrose_iter_pinv's
+    start, called at models/mirror.py:312)."""
+    from mirror_amd import kernels as K
+    g = torch.Generator().manual_seed(5)
+    BH, m = 6, 256
+    p = torch.softmax(torch.randn(BH, m, m, generator=g) * 2.0, dim=-1).cuda().contiguous()
+    dz0 = torch.randn(BH, m, m, generator=g).cuda()
+    dx0 = torch.randn(BH, m, m, generator=g).cuda()
+    st = K.pinv_absmax(p, torch.zeros(4, device="cuda").view(torch.int64))
+    ref = dx0.clone()
+    K.pinv_z0_bwd(p, None, dz0, st, ref)
+    K.softmax_bwd(p, ref)
+    got = dx0.clone()
+    K.pinv_s2_bwd(p, dz0, st, got)
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 2e-6 * scale, (float((got - ref).abs().max()), scale)
+    # the matrix that holds the column maximum really is corrected (the test would pass trivially if the term were negligible)
+    ci = int(st.view(torch.int64)[1].item()) & 0xffffffff
+    raw = dx0 + dz0.transpose(-1, -2) / (float(p.sum(-1).max()) * float(p.sum(-2).max()))
+    nofix = p * (raw - (p * raw).sum(-1, keepdim=True))
+    assert float((nofix[ci // m] - ref[ci // m]).abs().max()) > 1e-4 * scale
