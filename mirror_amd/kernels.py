@@ -821,7 +821,9 @@ def pinv_chain_bwd(XT, saved, dzf, work, dX, dz0, iters: int) -> None:
     if gemm_profiler is None:
         fn()
     else:
-        gemm_profiler.launch_named("pinv_panel_bwd_kernel", iters * 8 * 2.0 * m ** 3 * BH, fn)
+        v = os.environ.get("MH_CHAIN_BWD2", "1")      # the library's A/B switch (pinv_panel.hip): which kernel the launch is
+        name = "pinv_panel_bwd_kernel" if v == "0" else ("pinv_panel_bwd2_kernel<false>" if v == "1" else "pinv_panel_bwd2_kernel<true>")
+        gemm_profiler.launch_named(name, iters * 8 * 2.0 * m ** 3 * BH, fn)
 
 
 # ------------------------------------------------------------------ fused Nystrom attention sides (nystrom_fused.hip)
