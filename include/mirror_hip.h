@@ -277,6 +277,10 @@ int mh_pinv_chain_fwd(const void* XP, void* saved, void* zfT, int BH, int m, int
  * mh_pinv_chain_prep on the fused path. */
 int mh_nys_sim2(const void* lm, float* a2, void* xp, float* z0f, uint64_t* stats64, int B, int m, int D, int heads, float scale,
                 mh_stream s);
+/* The two small products that open NystromAttention's backward around the chain, one launch (m = 256, dh = 64; dw2, av f32
+ * [BH, m, dh], zfT bf16 [BH, m, m] = the chain's column-major output): up = PN((dw2 av^T)^T) bf16, the input of mh_pinv_chain_bwd
+ * (what mh_gemm + mh_pinv_chain_pack produce), dav = Z^T dw2 bf16 [BH, m, dh]. */
+int mh_nys_dz_dav(const float* dw2, const float* av, const void* zfT, void* up, void* dav, int BH, int m, int dh, mh_stream s);
 int mh_pinv_chain_bwd(const void* XP, const void* saved, const void* dzf, void* work, float* dX, float* dz0, int BH, int m,
                       int iters, mh_stream s);
 /* Bytes of the chain's caller-allocated buffers: which = 0: `saved` (forward output, backward input: [iters, 4, BH, m, m]

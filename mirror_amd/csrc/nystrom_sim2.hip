@@ -181,6 +181,96 @@ __global__ __launch_bounds__(256) void nys_sim2_kernel(const bf16_t* __restrict_
     if (tid < 2) atomicMax(stats + tid, s_best[tid]);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// The two 256 x 256 x 64 products that open NystromAttention's backward around the Moore-Penrose chain, one launch per pass instead
+// of a batched GEMM + a packing pass + another batched GEMM (out = attn1 (Z (attn3 v)): w2 = Z av):
+//     dZ = dW2 av^T  -> the chain's input U = dZ^T = av dW2^T, written panel native in bf16 (as in pass 1 above, the accumulator
+//                       layout of the product IS the panel layout: no f32 dZ in HBM, no packing launch);
+//     dAV = Z^T dW2  =  zfT dW2   (zfT[j][i] = Z[i][j]: the chain's column-major output).
+// dW2, av: f32 [B h, 256, 64] (rounded to bf16 as MFMA operands, what mh_gemm does with f32 operands); dAV: bf16 [B h, 256, 64].
+constexpr int DWP = 72;          // pitch of the [256][64] bf16 image of dW2 (K-contiguous fragments, conflict free)
+constexpr int DTP = 264;         // pitch of its transpose [64][256]
+__device__ __forceinline__ bf16x8 cvt8(const float* p) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 4; e++) { o[e] = (__bf16)a[e]; o[4 + e] = (__bf16)b[e]; }
+    return o;
+}
+__global__ __launch_bounds__(256) void nys_dz_dav_kernel(const float* __restrict__ dw2, const float* __restrict__ av,
+                                                         const bf16_t* __restrict__ zfT, bf16_t* __restrict__ up, bf16_t* __restrict__ dav) {
+    __shared__ __attribute__((aligned(16))) bf16_t s_dw[SM * DWP];
+    __shared__ __attribute__((aligned(16))) bf16_t s_dt[SDH * DTP];
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hl = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bh = blockIdx.x;
+    const float* dwb = dw2 + (long)bh * SM * SDH;
+    const float* avb = av + (long)bh * SM * SDH;
+    // this wave's A operands are requested first: av rows (pass 1) and zfT rows (pass 2) of its two row blocks
+    bf16x8 af[2][4];
+#pragma unroll
+    for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) af[rb][ks] = cvt8(avb + (long)(32 * (2 * wave + rb) + r) * SDH + 16 * ks + 8 * hl);
+    bf16x8 zf[2][16];
+#pragma unroll
+    for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+        for (int ks = 0; ks < 16; ks++)
+            zf[rb][ks] = *reinterpret_cast<const bf16x8*>(zfT + (long)bh * SMAT + (long)(32 * (2 * wave + rb) + r) * SM + 16 * ks + 8 * hl);
+    // dW2 -> bf16 images, [i][d] and [d][i]
+#pragma unroll
+    for (int n = 0; n < 16; n++) {
+        const int e0 = 4 * (tid + 256 * n), i = e0 >> 6, d = e0 & 63;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(dwb + e0);
+        unsigned short h[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) h[e] = f2bf(v[e]);
+        *reinterpret_cast<u32x2*>(s_dw + i * DWP + d) = u32x2{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
+#pragma unroll
+        for (int e = 0; e < 4; e++) s_dt[(d + e) * DTP + i] = h[e];
+    }
+    __syncthreads();
+    // pass 1: U = av dW2^T, rows i of this wave's two row blocks x all 256 columns j
+    bf16_t* upb = up + (long)bh * SMAT;
+#pragma unroll
+    for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+        for (int cb = 0; cb < 8; cb++) {
+            f32x16 c;
+#pragma unroll
+            for (int e = 0; e < 16; e++) c[e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(s_dw + (32 * cb + r) * DWP + 16 * ks + 8 * hl);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rb][ks], b, c, 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+                *reinterpret_cast<u32x4*>(upb + ((cb * 16 + 2 * (2 * wave + rb) + t) * 512) + (lane << 3)) = pack8(c, t);
+        }
+    // pass 2: dAV = zfT dW2, rows j of the same row blocks x 64 columns d
+    bf16_t* davb = dav + (long)bh * SM * SDH;
+#pragma unroll
+    for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+        for (int nb = 0; nb < 2; nb++) {
+            f32x16 c;
+#pragma unroll
+            for (int e = 0; e < 16; e++) c[e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 16; ks++) {
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(s_dt + (32 * nb + r) * DTP + 16 * ks + 8 * hl);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[rb][ks], b, c, 0, 0, 0);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) {
+                const int row = 32 * (2 * wave + rb) + (reg & 3) + 8 * (reg >> 2) + 4 * hl;
+                davb[(long)row * SDH + 32 * nb + r] = f2bf(c[reg]);
+            }
+        }
+}
+
 }  // namespace
 
 extern "C" int mh_nys_sim2(const void* lm, float* a2, void* xp, float* z0f, uint64_t* stats64, int B, int m, int D, int heads, float scale,
@@ -193,5 +283,15 @@ extern "C" int mh_nys_sim2(const void* lm, float* a2, void* xp, float* z0f, uint
     hipLaunchKernelGGL(nys_sim2_kernel, dim3(B * heads), dim3(256), 0, (hipStream_t)s, (const bf16_t*)lm, D, heads, scale * 1.4426950408889634f,
                        a2, (bf16_t*)xp, z0f, (unsigned long long*)stats64);
     MH_LAUNCH_CHECK("mh_nys_sim2");
+    return MH_OK;
+}
+
+extern "C" int mh_nys_dz_dav(const float* dw2, const float* av, const void* zfT, void* up, void* dav, int BH, int m, int dh, mh_stream s) {
+    MH_REQUIRE(m == SM && dh == SDH, "mh_nys_dz_dav: built for m = %d landmarks and dh = %d (m=%d, dh=%d)", SM, SDH, m, dh);
+    MH_REQUIRE(dw2 && av && zfT && up && dav && (((uintptr_t)dw2 | (uintptr_t)av | (uintptr_t)zfT | (uintptr_t)up | (uintptr_t)dav) & 15) == 0,
+               "mh_nys_dz_dav: null / unaligned buffer");
+    if (BH == 0) return MH_OK;
+    hipLaunchKernelGGL(nys_dz_dav_kernel, dim3(BH), dim3(256), 0, (hipStream_t)s, dw2, av, (const bf16_t*)zfT, (bf16_t*)up, (bf16_t*)dav);
+    MH_LAUNCH_CHECK("mh_nys_dz_dav");
     return MH_OK;
 }

@@ -1299,6 +1299,7 @@ def _pair(first: torch.Tensor, second: torch.Tensor) -> torch.Tensor:
 
 
 _S2_TAIL = os.environ.get("MIRROR_S2_TAIL", "1") != "0"      # A/B switch
+_DZ_DAV = os.environ.get("MIRROR_DZ_DAV", "1") != "0"        # A/B switch
 _RCW_EARLY = os.environ.get("MIRROR_RCW_EARLY", "0") != "0"  # A/B switch: res_conv weight gradient in front of the chain fork (measured neutral: 1757 / 1758 / 1750 vs 1757 / 1761 / 1752)
 
 
@@ -1429,6 +1430,7 @@ class NystromCoreFn(Function):
         if kmask is not None:
             mrow, mlm, lscale = kmask
         sm_bwd = (lambda y, dy, rm, cm: K.softmax_bwd(y, dy)) if kmask is None else K.softmax_masked_bwd
+        zfT = zf if chain else None         # the chain's column-major output as saved
         if chain:
             zf = zf.transpose(-1, -2)       # saved as the column-major chain output
         saved = None if chain else [tuple(flat[i:i + 4]) for i in range(0, len(flat), 4)]
@@ -1464,15 +1466,22 @@ class NystromCoreFn(Function):
             dlm = torch.empty((Bn, m, 2 * D), device=qkv.device, dtype=f32)
         dql, dkl = _heads(dlm, 0, 2, h), _heads(dlm, 1, 2, h)
         sd = f32 if pm == MH_F32 else bf16
-        dZ = K.gemm(dW2, tr(av), mma=pm, out_dtype=f32)                                  # [B,h,m,m]
         pio = pm if (pm == MH_BF16 or A == f32) else mma
+        # dZ = dW2 av^T (the chain's input, packed) and dAV = Z^T dW2: ONE launch on the fused bf16 path (nystrom_sim2.hip)
+        one2 = (_DZ_DAV and chain and fused and A == bf16 and pio == MH_BF16 and dh == 64 and m == 256 and dW2.dtype == f32 and av.dtype == f32)
+        dAV = dzb = None
+        if one2:
+            dzb, dAV = K.nys_dz_dav(dW2, av.contiguous(), zfT)
+        else:
+            dZ = K.gemm(dW2, tr(av), mma=pm, out_dtype=f32)                              # [B,h,m,m]
         side = None
         if chain:
             xb, chain_saved, z0 = flat
             work = torch.empty_like(chain_saved)
             dS2 = torch.empty_like(a2)
             dz0 = torch.empty_like(a2)
-            dzb = K.pinv_chain_pack(dZ)
+            if dzb is None:
+                dzb = K.pinv_chain_pack(dZ)
             side = _side_stream(qkv.device)      # half-chip chain again, beside the softmax backward / dq / dk work
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -1485,7 +1494,8 @@ class NystromCoreFn(Function):
             K.shared_chip = True         # until the join below
         if not (_RCW_EARLY and chain):
             K.resconv_wgrad(qkv[..., 2 * D:], dout, dres, h)
-        dAV = K.gemm(tr(zf), dW2, mma=pio, out_dtype=A)                                  # [B,h,m,dh]
+        if dAV is None:
+            dAV = K.gemm(tr(zf), dW2, mma=pio, out_dtype=A)                              # [B,h,m,dh]
         if fused:
             K.nys_attn3_bwd(qkv, lm, av, dAV, lse3, dqkv, dlm, h, scale, kmask)         # dk, dv, dq_l
             K.resconv(dout, rw, dqkv[..., 2 * D:], h, transpose=True, accumulate=True)

@@ -766,6 +766,20 @@ def pinv_chain_pack(dz: torch.Tensor) -> torch.Tensor:
     return up
 
 
+def nys_dz_dav(dw2: torch.Tensor, av: torch.Tensor, zfT: torch.Tensor):
+    """(PN((dw2 av^T)^T) bf16 [.., m, m] for mh_pinv_chain_bwd, dAV = Z^T dw2 bf16 [.., m, dh]) in one launch (mh_nys_dz_dav)."""
+    _chk(dw2, av, zfT)
+    m, dh = dw2.shape[-2], dw2.shape[-1]
+    BH = dw2.numel() // (m * dh)
+    if not (dw2.dtype == av.dtype == torch.float32 and zfT.dtype == torch.bfloat16 and dw2.is_contiguous() and av.is_contiguous()
+            and zfT.is_contiguous() and av.shape == dw2.shape and zfT.numel() == BH * m * m):
+        raise MirrorHipError("nys_dz_dav: contiguous f32 [.., m, dh] gradients / products and the bf16 column-major chain output")
+    up = torch.empty(zfT.shape, device=dw2.device, dtype=torch.bfloat16)
+    dav = torch.empty(dw2.shape, device=dw2.device, dtype=torch.bfloat16)
+    _lib.call("mh_nys_dz_dav", _p(dw2), _p(av), _p(zfT), _p(up), _p(dav), BH, m, dh, stream=_stream())
+    return up, dav
+
+
 def nys_sim2_ok(lm: torch.Tensor, heads: int) -> bool:
     """mh_nys_sim2's geometry: bf16 landmarks [B, 256, 2 D] with D = heads * 64."""
     return (lm.dim() == 3 and lm.dtype == torch.bfloat16 and lm.is_contiguous() and lm.shape[1] == PINV_CHAIN_M

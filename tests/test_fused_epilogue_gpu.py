@@ -421,3 +421,26 @@ def test_attn2_backward_tail_one_pass_equals_z0_bwd_plus_softmax_bwd():
     raw = dx0 + dz0.transpose(-1, -2) / (float(p.sum(-1).max()) * float(p.sum(-2).max()))
     nofix = p * (raw - (p * raw).sum(-1, keepdim=True))
     assert float((nofix[ci // m] - ref[ci // m]).abs().max()) > 1e-4 * scale
+
+
+def test_dz_dav_one_launch_equals_gemm_pack_gemm():
+    """mh_nys_dz_dav (dZ = dW2 av^T packed panel native for the chain + dAV = Z^T dW2) against mh_gemm + mh_pinv_chain_pack + mh_gemm:
+    the products that open [3P] NystromAttention's backward around moore_penrose_iter_pinv (models/mirror.py:312)."""
+    from mirror_amd import kernels as K
+    from mirror_amd._lib import MH_BF16
+    g = torch.Generator().manual_seed(9)
+    B, h, m, dh = 2, 4, 256, 64
+    dw2 = torch.randn(B, h, m, dh, generator=g).cuda()
+    av = torch.randn(B, h, m, dh, generator=g).cuda()
+    zfT = (torch.randn(B, h, m, m, generator=g) * 0.1).cuda().to(bf16)
+    dz = K.gemm(dw2, av.transpose(-1, -2), mma=MH_BF16, out_dtype=torch.float32)
+    up_ref = K.pinv_chain_pack(dz)
+    dav_ref = K.gemm(zfT, dw2, mma=MH_BF16, out_dtype=bf16)             # Z^T dW2 with Z^T = zfT
+    up, dav = K.nys_dz_dav(dw2, av, zfT)
+    torch.cuda.synchronize()
+    assert up.shape == up_ref.shape and dav.shape == dav_ref.shape
+    # same bf16-rounded operands, f32 accumulation: results agree to the rounding of the bf16 outputs (summation order may differ)
+    du = (up.float() - up_ref.float()).abs().max() / up_ref.float().abs().max()
+    dd = (dav.float() - dav_ref.float()).abs().max() / dav_ref.float().abs().max()
+    assert float(du) <= 8e-3 and float(dd) <= 8e-3, (float(du), float(dd))
+    assert float((up.float() - up_ref.float()).abs().mean() / up_ref.float().abs().mean()) <= 5e-4
