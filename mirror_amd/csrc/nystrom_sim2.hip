@@ -11,6 +11,7 @@
 //   pass 2  S^T = k_l q_l^T with the same fragments in the other roles (bit-identical dot products), exponentiated against pass 1's
 //           row statistics (through LDS) -> PN(attn2^T) in f32, UNSCALED: the chain forward multiplies by 1 / (c r) when it loads
 //           z_0 (the maxima are only complete when every workgroup of this launch has finished).
+#include <cstdlib>
 #include "gemm_kernel.h"
 
 namespace {
@@ -44,6 +45,10 @@ __global__ __launch_bounds__(256) void nys_sim2_kernel(const bf16_t* __restrict_
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hl = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bh = blockIdx.x, b = bh / heads, h = bh % heads;
+    // Two workgroups per (b, h): the kernel is bound by its stores (640 KiB per (b, h), one workgroup per CU on half of the chip:
+    // ~60 us for 108 MB).  Both compute the whole of pass 1 (the column sums need every row) but each STORES one of every wave's two
+    // row blocks and computes + stores that half of pass 2; half 0 publishes the maxima.
+    const int half = blockIdx.y;
     const long ld = 2L * D;
     const bf16_t* ql = lm + (long)b * SM * ld + h * SDH;
     const bf16_t* kl = ql + D;
@@ -123,6 +128,7 @@ __global__ __launch_bounds__(256) void nys_sim2_kernel(const bf16_t* __restrict_
     for (int rb = 0; rb < 2; rb++)
 #pragma unroll
         for (int cb = 0; cb < 8; cb++) {
+            if (gridDim.y == 2 && rb != half) continue;          // the other workgroup of this (b, h) stores that row block
 #pragma unroll
             for (int reg = 0; reg < 16; reg++) {
                 const int row = 32 * (2 * wave + rb) + (reg & 3) + 8 * (reg >> 2) + 4 * hl;
@@ -162,6 +168,7 @@ __global__ __launch_bounds__(256) void nys_sim2_kernel(const bf16_t* __restrict_
         const float mxi = s_max[32 * cb + r], ivi = s_inv[32 * cb + r];      // statistics of attn2's row i = this lane's column
 #pragma unroll
         for (int rb = 0; rb < 2; rb++) {
+            if (gridDim.y == 2 && rb != half) continue;
             f32x16 c;
 #pragma unroll
             for (int e = 0; e < 16; e++) c[e] = 0.f;
@@ -178,7 +185,7 @@ __global__ __launch_bounds__(256) void nys_sim2_kernel(const bf16_t* __restrict_
         }
     }
     __syncthreads();
-    if (tid < 2) atomicMax(stats + tid, s_best[tid]);
+    if (tid < 2 && half == 0) atomicMax(stats + tid, s_best[tid]);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -280,7 +287,8 @@ extern "C" int mh_nys_sim2(const void* lm, float* a2, void* xp, float* z0f, uint
                "mh_nys_sim2: null / unaligned buffer");
     MH_REQUIRE((long)B * heads * m < (1L << 31), "mh_nys_sim2: index overflow");
     if (B == 0) return MH_OK;
-    hipLaunchKernelGGL(nys_sim2_kernel, dim3(B * heads), dim3(256), 0, (hipStream_t)s, (const bf16_t*)lm, D, heads, scale * 1.4426950408889634f,
+    static const int split = [] { const char* e = getenv("MH_SIM2_SPLIT"); return (e && e[0] == '1') ? 2 : 1; }();      // A/B switch: two workgroups per (b, h), each storing half (measured: same 60 us kernel, same step)
+    hipLaunchKernelGGL(nys_sim2_kernel, dim3(B * heads, split), dim3(256), 0, (hipStream_t)s, (const bf16_t*)lm, D, heads, scale * 1.4426950408889634f,
                        a2, (bf16_t*)xp, z0f, (unsigned long long*)stats64);
     MH_LAUNCH_CHECK("mh_nys_sim2");
     return MH_OK;
