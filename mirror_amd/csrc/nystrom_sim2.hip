@@ -16,19 +16,37 @@
 
 namespace {
 
+#ifndef SIM2_EXP
+#define SIM2_EXP 0               // timing experiments only (tools/exp/time_sim2.sh rebuilds this file with -DSIM2_EXP=n; results wrong for n > 1)
+#endif
 constexpr int SM = 256;          // landmarks
 constexpr int SDH = 64;          // head dim
 constexpr long SMAT = (long)SM * SM;
 
+// Reductions over the 32 lanes of this lane's half.  __shfl_xor is a ds_bpermute (an LDS-pipe round trip) per step and five dependent
+// steps per reduction, 96 reductions per wave: ~15 of the kernel's ~54 us.  The first four steps as DPP moves (VALU rate): xor 1 / xor 2
+// inside a quad, then the mirror of a row half and of a row (every lane already holds its group's sum, so a mirror is as good as a
+// butterfly); the last one (lanes 16 apart) as ds_swizzle.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float swz16_f(float v) {          // lane ^ 16 (bit-mask mode: and 0x1f, or 0, xor 0x10)
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
+}
 __device__ __forceinline__ float half_max(float v) {      // over the 32 lanes of this lane's half
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_f<0xB1>(v));       // quad_perm [1, 0, 3, 2]
+    v = fmaxf(v, dpp_f<0x4E>(v));       // quad_perm [2, 3, 0, 1]
+    v = fmaxf(v, dpp_f<0x141>(v));      // row_half_mirror
+    v = fmaxf(v, dpp_f<0x140>(v));      // row_mirror
+    return fmaxf(v, swz16_f(v));
 }
 __device__ __forceinline__ float half_sum(float v) {
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_f<0xB1>(v);
+    v += dpp_f<0x4E>(v);
+    v += dpp_f<0x141>(v);
+    v += dpp_f<0x140>(v);
+    return v + swz16_f(v);
 }
 __device__ __forceinline__ u32x4 pack8(const f32x16& a, int t) {
     u32x4 o;
@@ -91,25 +109,24 @@ __global__ __launch_bounds__(256) void nys_sim2_kernel(const bf16_t* __restrict_
             float mx = acc[rb][0][reg];
 #pragma unroll
             for (int cb = 1; cb < 8; cb++) mx = fmaxf(mx, acc[rb][cb][reg]);
-            mx = half_max(mx);
+            if (SIM2_EXP != 2) mx = half_max(mx);
             float sm = 0.f;
 #pragma unroll
             for (int cb = 0; cb < 8; cb++) {
-                const float e = exp2f(acc[rb][cb][reg] - mx);
+                const float e = __builtin_amdgcn_exp2f(acc[rb][cb][reg] - mx);
                 acc[rb][cb][reg] = e;
                 sm += e;
             }
-            sm = half_sum(sm);
+            if (SIM2_EXP != 2) sm = half_sum(sm);
             const float inv = 1.f / sm;
-            float rs = 0.f;
 #pragma unroll
             for (int cb = 0; cb < 8; cb++) {
                 const float p = acc[rb][cb][reg] * inv;
                 acc[rb][cb][reg] = p;
-                rs += p;
                 cs[cb] += p;
             }
-            rs = half_sum(rs);                            // sum_j |attn2[i][j]| (probabilities: no abs needed)
+            const float rs = sm * inv;                    // sum_j |attn2[i][j]| = 1 within rounding, as the sum of the rounded
+                                                          // probabilities is (a third butterfly per row bought nothing: 5 us)
             const int row = 32 * (2 * wave + rb) + (reg & 3) + 8 * (reg >> 2) + 4 * hl;
             if (r == 0) { s_max[row] = mx; s_inv[row] = inv; }
             const unsigned long long pk = ((unsigned long long)__float_as_uint(rs) << 32) | (unsigned)(bh * SM + row);
@@ -129,6 +146,7 @@ __global__ __launch_bounds__(256) void nys_sim2_kernel(const bf16_t* __restrict_
 #pragma unroll
         for (int cb = 0; cb < 8; cb++) {
             if (gridDim.y == 2 && rb != half) continue;          // the other workgroup of this (b, h) stores that row block
+            if (SIM2_EXP == 4) continue;
 #pragma unroll
             for (int reg = 0; reg < 16; reg++) {
                 const int row = 32 * (2 * wave + rb) + (reg & 3) + 8 * (reg >> 2) + 4 * hl;
@@ -165,6 +183,7 @@ __global__ __launch_bounds__(256) void nys_sim2_kernel(const bf16_t* __restrict_
     float* z0b = z0f + bh * SMAT;
 #pragma unroll
     for (int cb = 0; cb < 8; cb++) {
+        if (SIM2_EXP == 3) break;
         const float mxi = s_max[32 * cb + r], ivi = s_inv[32 * cb + r];      // statistics of attn2's row i = this lane's column
 #pragma unroll
         for (int rb = 0; rb < 2; rb++) {
@@ -175,7 +194,7 @@ __global__ __launch_bounds__(256) void nys_sim2_kernel(const bf16_t* __restrict_
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[rb][ks], kf[cb][ks], c, 0, 0, 0);
 #pragma unroll
-            for (int e = 0; e < 16; e++) c[e] = exp2f(c[e] * sl2 - mxi) * ivi;          // attn2[i][j] at (row j, column i)
+            for (int e = 0; e < 16; e++) c[e] = __builtin_amdgcn_exp2f(c[e] * sl2 - mxi) * ivi;          // attn2[i][j] at (row j, column i)
 #pragma unroll
             for (int t = 0; t < 2; t++) {
                 float* dst = z0b + ((long)(cb * 16 + 2 * (2 * wave + rb) + t) * 64 + lane) * 8;
