@@ -117,6 +117,11 @@ typedef struct {
     int32_t shared_chip;          /* hint: != 0 when another stream's kernel shares the chip with this launch (the half-chip pinv chain):
                                      the persistent kernel (one workgroup per CU for the whole launch) would keep the other kernel's
                                      workgroups from being scheduled until it ends, so the one-workgroup-per-tile kernel is used */
+    int32_t c_rows_per_batch, c_row_skip;   /* > 0 (bf16 C, with or without a_rows_per_batch, no `epi`): flat row r of the result is written to
+                                     C row r + (r / c_rows_per_batch) * c_row_skip.  [3P] NystromAttention pads the sequence in FRONT
+                                     (`F.pad(x, (0, 0, padding, 0))`, called at models/mirror.py:312): to_qkv of the pad rows is zero (no
+                                     bias), so only the B x n real rows are multiplied, as one flat problem from and into the padded buffers
+                                     (its data gradient likewise) */
 } mh_gemm_desc;
 int mh_gemm(const mh_gemm_desc* d, mh_stream s);
 /* Tuning switch for A/B timing in one process: which main loop the 256 x 256-tile launches use (2 = persistent direct-to-LDS

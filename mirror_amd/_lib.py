@@ -51,6 +51,7 @@ class GemmDesc(C.Structure):
         ("row_softmax", C.c_int32),
         ("epi", C.POINTER(GemmEpi)), ("a_rows_per_batch", C.c_int32), ("a_row_skip", C.c_int32),
         ("shared_chip", C.c_int32),
+        ("c_rows_per_batch", C.c_int32), ("c_row_skip", C.c_int32),
     ]
 
 

@@ -4,6 +4,7 @@
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 bool gemm_try_tile384(GemmArgs& a, int akc, int bkc, int dtC, int batch, void* c2, int r_bf16, hipStream_t s);   // gemm_tile.hip
 const char* gemm_big_epi(GemmArgs& a, int akc, int bkc, int dtC, int batch, hipStream_t s);                     // gemm_big.hip
+const char* gemm_big_window(GemmArgs& a, int akc, int bkc, int batch, hipStream_t s);                            // gemm_big.hip
 
 static int launch_one(const mh_gemm_desc* d, hipStream_t s) {
     const int split = d->split_k < 1 ? 1 : d->split_k;
@@ -19,6 +20,7 @@ static int launch_one(const mh_gemm_desc* d, hipStream_t s) {
     a.kseg = d->k_segments; a.sAk = d->sA_seg; a.sBk = d->sB_seg;
     a.row_softmax = d->row_softmax;
     a.shared_chip = d->shared_chip;
+    a.c_rpb = 0; a.c_skip = 0;
     const int BK = d->mma == MH_BF16 ? 64 : 16;
     const int kps = mh_cdiv(mh_cdiv(d->K, split), BK) * BK;
     a.k_per_split = kps;
@@ -42,7 +44,17 @@ static int launch_one(const mh_gemm_desc* d, hipStream_t s) {
         MH_LAUNCH_CHECK("mh_gemm(epi)");
         return MH_OK;
     }
-    MH_REQUIRE(d->a_rows_per_batch == 0, "mh_gemm: a_rows_per_batch is part of the fused-epilogue path (epi)");
+    if (d->a_rows_per_batch != 0 || d->c_rows_per_batch != 0) {      // plain product of row windows (no epilogue): the 256 x 256 direct-to-LDS kernels
+        MH_REQUIRE(d->mma == MH_BF16 && d->dtA == MH_BF16 && d->dtB == MH_BF16 && d->dtC == MH_BF16 && !d->C2 && !d->r_bf16 && d->k_segments <= 1 &&
+                       !d->row_softmax && !d->bias && d->act == MH_ACT_NONE,
+                   "mh_gemm: row windows (a_rows_per_batch / c_rows_per_batch) need plain bf16 operands and a bf16 result, no bias / activation");
+        a.a_rpb = d->a_rows_per_batch; a.a_skip = d->a_row_skip;
+        a.c_rpb = d->c_rows_per_batch; a.c_skip = d->c_row_skip;
+        const char* why = gemm_big_window(a, d->a_kc, d->b_kc, batch, s);
+        MH_REQUIRE(!why, "mh_gemm(row windows): %s", why);
+        MH_LAUNCH_CHECK("mh_gemm(windows)");
+        return MH_OK;
+    }
     const bool want_tile = d->C2 || d->r_bf16 || d->k_segments > 1 || d->row_softmax;
     if (d->mma == MH_BF16 && d->dtA == MH_BF16 && d->dtB == MH_BF16 && gemm_try_tile384(a, d->a_kc, d->b_kc, d->dtC, batch, d->C2, d->r_bf16, s)) {
         MH_LAUNCH_CHECK("mh_gemm(tile)");

@@ -39,6 +39,9 @@ __device__ __forceinline__ f32x4 epi_quad(const GemmArgs& g, f32x4 x, int grow, 
 }
 
 // accumulators -> f32 LDS tile [128][260] (one half of the rows at a time) -> 16-byte row-contiguous stores
+// physical row of C for flat result row r (GemmArgs.c_rpb / c_skip: row windows of larger batches, see mh_gemm_desc.c_rows_per_batch)
+__device__ __forceinline__ long c_phys_row(const GemmArgs& g, int r) { return g.c_rpb > 0 ? (long)r + (long)(r / g.c_rpb) * g.c_skip : (long)r; }
+
 template <typename TC, int MODE, int EPI = 0>
 __device__ __forceinline__ void epilogue_big(const GemmArgs& g, TC* C, f32x16 (&acc)[BWM][BWN], char* smem, int tile_row0,
                                              int tile_col0, int wm, int wn, int lane, int tid, bool lead, long ldc, float alpha) {
@@ -202,7 +205,7 @@ __device__ __forceinline__ void epilogue_big_t(const GemmArgs& g, bf16_t* C, f32
         const int cid = tid + i * NTB;
         const int lr = cid / CPR, c = cid % CPR;
         if (tile_row0 + lr >= g.M) continue;      // ragged last row tile (K-contiguous A only)
-        bf16_t* dst = C + (long)(tile_row0 + lr) * g.ldc + tile_col0 + c * 8;
+        bf16_t* dst = C + c_phys_row(g, tile_row0 + lr) * g.ldc + tile_col0 + c * 8;
         u32x2 lo = *reinterpret_cast<const u32x2*>(t + lr * PITCH + c * 8);
         u32x2 hi = *reinterpret_cast<const u32x2*>(t + lr * PITCH + c * 8 + 4);
         u32x4 o = {lo[0], lo[1], hi[0], hi[1]};
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(NTB) void gemm_big_kernel(GemmArgs g) {
     // ds_write pass (~80 B/clk per CU, ~800 cycles per K-tile) then drains under the MFMAs of the current tile instead
     // of sitting between the last MFMA and the barrier (8192^3: 732 -> 1094 TFLOP/s).
     int adj0 = 0, bnd = 1 << 30;
-    if constexpr (EPI != 0) {
+    if constexpr (AKC) {
         if (g.a_rpb > 0) {
             const int b0 = (tile_m * BIG) / g.a_rpb;
             adj0 = b0 * g.a_skip;
@@ -572,7 +575,7 @@ __global__ __launch_bounds__(NTB) void gemm_pp_kernel(GemmArgs g) {
     const int nt = (kend - kbeg) / 64;
 
     int adj0 = 0, bnd = 1 << 30;
-    if constexpr (EPI != 0) {
+    if constexpr (AKC) {
         if (g.a_rpb > 0) {
             const int bq = (tile_m * BIG) / g.a_rpb;
             adj0 = bq * g.a_skip;
@@ -800,7 +803,7 @@ __device__ __forceinline__ void pq_epilogue_bf16(const GemmArgs& g, bf16_t* C, f
             const int lr = cid / CPR, c = cid % CPR;
             const int grow = tile_row0 + half * HALF + lr;
             if (grow >= g.M) continue;               // ragged last row tile (K-contiguous A only)
-            bf16_t* dst = C + (long)grow * g.ldc + tile_col0 + c * 8;
+            bf16_t* dst = C + c_phys_row(g, grow) * g.ldc + tile_col0 + c * 8;
             u32x2 lo = *reinterpret_cast<const u32x2*>(t + lr * PITCH + c * 8);
             u32x2 hi = *reinterpret_cast<const u32x2*>(t + lr * PITCH + c * 8 + 4);
             u32x4 o = {lo[0], lo[1], hi[0], hi[1]};
@@ -982,7 +985,7 @@ __global__ __launch_bounds__(NTB) void gemm_pq_kernel(GemmArgs g, int units, int
         const int kbeg = sp * g.k_per_split;
         ntl = (min(g.K, kbeg + g.k_per_split) - kbeg) / 64;
         int adj0 = 0, bnd = 1 << 30;
-        if constexpr (EPI != 0) {
+        if constexpr (AKC) {
             if (g.a_rpb > 0) {
                 const int bq = (tm * BIG) / g.a_rpb;
                 adj0 = bq * g.a_skip;
@@ -1264,6 +1267,23 @@ const char* gemm_big_epi(GemmArgs& a, int akc, int bkc, int dtC, int batch, hipS
         return "unknown epilogue kind";
     }
 #undef EPI_LAUNCH_
+}
+
+// plain bf16 product whose A and / or C rows are row windows of larger batches (mh_gemm_desc.a_rows_per_batch / c_rows_per_batch):
+// 0 = launched, otherwise why not.  Only the direct-to-LDS kernels take row windows without a fused epilogue.
+const char* gemm_big_window(GemmArgs& a, int akc, int bkc, int batch, hipStream_t s) {
+    if (!pp_enabled()) return "row windows without an epilogue need the direct-to-LDS kernels (MH_GEMM_PP != 0)";
+    if (!(akc && a.M > BIG && a.M % BIG == 0 && a.N % BIG == 0 && a.K % 64 == 0 && a.split_k == 1 && a.k_per_split == a.K && !a.atomic && !a.accumulate &&
+          !a.R && a.diag == 0.f && a.vecA && a.vecB && a.vecC && batch == 1))
+        return "shape is not on the 256 x 256 kernel (K-contiguous bf16 A, M % 256 == 0, N % 256 == 0, K % 64 == 0, one batch, no split-K / accumulate / R / diag)";
+    if ((a.a_rpb != 0 && a.a_rpb < BIG) || (a.c_rpb != 0 && a.c_rpb < BIG)) return "rows_per_batch must be >= 256";
+    a.epi.kind = MH_EPI_NONE;
+    a.tiles_m = a.M / BIG;
+    a.tiles_n = a.N / BIG;
+    dim3 grid(a.tiles_m * a.tiles_n, 1, 1);
+    if (bkc) PP_LAUNCH_(bf16_t, true, true, false, 0, grid, s, a);
+    else PP_LAUNCH_(bf16_t, true, false, false, 0, grid, s, a);
+    return nullptr;
 }
 
 // true when the large-tile kernel took the launch

@@ -43,6 +43,7 @@ struct GemmArgs {
     mh_gemm_epi epi;              // fused epilogue (gemm_big.hip only; kind 0: none)
     int a_rpb, a_skip;            // row-window remap of A (gemm_big.hip, K-contiguous A): flat row r -> r + (r / a_rpb) * a_skip
     int shared_chip;              // mh_gemm_desc.shared_chip: no persistent kernel
+    int c_rpb, c_skip;            // row-window remap of C (gemm_big.hip, bf16 C): flat row r -> r + (r / c_rpb) * c_skip
 };
 
 template <int MMA, bool KC, int ROWS>

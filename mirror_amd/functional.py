@@ -274,6 +274,27 @@ def _gemm_rows(a, b, *, bias=None, act=ACT_NONE, mma, out_dtype, out=None, wt=No
     return K.gemm(a, b, out=out, bias=bias, act=act, mma=mma, out_dtype=out_dtype)
 
 
+_PAD_SKIP = os.environ.get("MIRROR_PAD_SKIP", "1") != "0"       # A/B switch: to_qkv / its data gradient skip the front-pad rows
+
+
+def _rows_window(a3, b2, out3, r0, R, *, mma, wt=None):
+    """out3[:, r0:r0 + R] = a3[:, r0:r0 + R] @ b2 over the B * R real rows as one flat problem (K.gemm_rows_window) + the few rows
+    past whole 256-row tiles through the weight-streaming kernel.  Rows outside the window are NOT written."""
+    Bn = a3.shape[0]
+    M = Bn * R
+    tail = M % 256
+    K.gemm_rows_window(a3, b2, out3, r0, R, m_rows=M - tail)
+    if tail:
+        if tail > R:
+            raise K.MirrorHipError("_rows_window: the ragged rows span more than one batch")
+        _tail_rows(a3[Bn - 1, r0 + R - tail:r0 + R], b2, out3[Bn - 1, r0 + R - tail:r0 + R], mma=mma, wt=wt)
+
+
+def _rows_window_ok(a3, out3, r0, R, N, prec) -> bool:
+    return (_PAD_SKIP and r0 > 0 and prec.mma == MH_BF16 and prec.act == bf16 and not prec.fp8_fwd and (a3.shape[0] * R) % 256 <= 32
+            and K.gemm_rows_window_ok(a3, out3, r0, R, N))
+
+
 _GEMM_WINDOW = os.environ.get("MIRROR_GEMM_WINDOW", "1") != "0"     # A/B switch
 
 
@@ -369,8 +390,11 @@ class LinearFn(Function):
     W: [N, K] f32 master.  Replaces nn.Linear (+ nn.ReLU for _fc1, models/mirror.py:346)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, act, prec, out_dtype, defer_from=None):
+    def forward(ctx, x, w, b, act, prec, out_dtype, defer_from=None, zero_rows=0):
+        """zero_rows = p > 0 (3-D x, no bias): the first p rows of every batch of x are zero rows ([3P] NystromAttention's front padding
+        behind LayerNormLmFn); their outputs are zero and are not computed, and the data gradient does not write those rows."""
         wa = shadow(w, prec)
+        ctx.zero_rows = 0
         # [B, D] activations: weight-streaming kernels, which take an f32 operand as it is (rounded to bf16 on load: no cast launch)
         ctx.skinny = prec.act == bf16 and _SKINNY_F32 and x.dtype == f32 and K.skinny_ok(x, wa)
         xa = x if (x.dtype == prec.act or ctx.skinny) else K.cast(x.contiguous(), prec.act)
@@ -382,8 +406,16 @@ class LinearFn(Function):
             # to_qkv: the q | k columns now, the v columns when NystromCoreFn asks for them (under the pinv chain)
             y = torch.empty(tuple(xa.shape[:-1]) + (wa.shape[0],), device=xa.device, dtype=out_dtype or prec.act)
             c0, od = defer_from, out_dtype or prec.act
-            _gemm_rows(xa, wa[:c0].t(), mma=prec.mma, out_dtype=od, out=y[..., :c0])
-            _deferred[y.data_ptr()] = lambda: _gemm_rows(xa, wa[c0:].t(), mma=prec.mma, out_dtype=od, out=y[..., c0:])
+            R = xa.shape[1] - zero_rows if xa.dim() == 3 else 0
+            if (zero_rows > 0 and xa.dim() == 3 and od == bf16 and c0 % 256 == 0 and (wa.shape[0] - c0) % 256 == 0
+                    and _rows_window_ok(xa, y[..., :c0], zero_rows, R, c0, prec)):
+                ctx.zero_rows = zero_rows
+                y[:, :zero_rows].zero_()          # q = k = v = 0 on the pad rows (they take part in the softmaxes as zero keys)
+                _rows_window(xa, wa[:c0].t(), y[..., :c0], zero_rows, R, mma=prec.mma)
+                _deferred[y.data_ptr()] = lambda: _rows_window(xa, wa[c0:].t(), y[..., c0:], zero_rows, R, mma=prec.mma)
+            else:
+                _gemm_rows(xa, wa[:c0].t(), mma=prec.mma, out_dtype=od, out=y[..., :c0])
+                _deferred[y.data_ptr()] = lambda: _gemm_rows(xa, wa[c0:].t(), mma=prec.mma, out_dtype=od, out=y[..., c0:])
         if ctx.skinny:
             y = K.skinny_fwd(xa, wa, bd, act, out_dtype or prec.act)
         elif prec.fp8_fwd:
@@ -420,6 +452,10 @@ class LinearFn(Function):
                     dx32 = zeros((rows, Kd), dy.device)
                     K.gemm(dy, wa, out=dx32, accumulate=True, split_k=max(2, min(32, N // 128)), mma=prec.mma)
                     dx = dx32 if ctx.x_dtype == f32 else K.cast(dx32, ctx.x_dtype)
+                elif ctx.zero_rows and dy.dim() == 3 and ctx.x_dtype == bf16 and _rows_window_ok(dy, xa, ctx.zero_rows, dy.shape[1] - ctx.zero_rows, Kd, prec):
+                    # the pad rows of dx are left unwritten: the LayerNorm backward that consumes dx reads the real rows only
+                    dx = torch.empty(xa.shape, device=dy.device, dtype=bf16)
+                    _rows_window(dy, wa, dx, ctx.zero_rows, dy.shape[1] - ctx.zero_rows, mma=prec.mma, wt=shadow_t(w, prec))
                 else:
                     dx = _gemm_rows(dy, wa, mma=prec.mma, out_dtype=ctx.x_dtype, wt=_wt_of(w, prec, dy))
         want_db = ctx.has_b and ctx.needs_input_grad[2]
@@ -434,7 +470,7 @@ class LinearFn(Function):
                 if _wgrad_queue is not None and sunk and (dbuf is None or sunk_b) and dy.dim() == 2:
                     # engine step: every [B, D]-row weight gradient of the backward goes into ONE launch at its end (flush_skinny_wgrads)
                     _wgrad_queue.append((dy, xa, dw, dbuf, w, b if fused_db else None, torch.cuda.current_stream()))
-                    return dx, None, None, None, None, None, None
+                    return dx, None, None, None, None, None, None, None
                 K.skinny_wgrad(dy, xa, dw, accumulate=True, db=dbuf)
                 if fused_db:
                     db = _gret(b, dbuf, sunk_b)
@@ -445,7 +481,7 @@ class LinearFn(Function):
             db, sunk = _gbuf(b, (N,))
             K.colsum(dy.reshape(-1, N), db)
             db = _gret(b, db, sunk)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 # deferred weight gradients of the skinny linears: a list while an engine step's backward runs (TrainEngine sets it), else None
@@ -505,10 +541,11 @@ def _wgrad(dy: torch.Tensor, x: torch.Tensor, N: int, Kd: int, prec: Precision, 
     return dw
 
 
-def linear(x, w, b=None, *, act=ACT_NONE, prec: Precision, out_dtype=None, defer_from=None):
+def linear(x, w, b=None, *, act=ACT_NONE, prec: Precision, out_dtype=None, defer_from=None, zero_rows=0):
     """defer_from = c: only output columns [0, c) are computed here; the rest is a pending launch that the consumer runs
-    with run_deferred(y) (NystromCoreFn does, right after it has forked the pinv chain)."""
-    return LinearFn.apply(x, w, b, act, prec, out_dtype, defer_from)
+    with run_deferred(y) (NystromCoreFn does, right after it has forked the pinv chain).
+    zero_rows = p: the first p rows of every batch of x are known to be zero (front padding): see LinearFn.forward."""
+    return LinearFn.apply(x, w, b, act, prec, out_dtype, defer_from, zero_rows)
 
 
 _DEFER_V = os.environ.get("MIRROR_DEFER_V", "1") != "0"       # A/B switch

@@ -235,6 +235,57 @@ def linear_fused(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],
     return out
 
 
+def gemm_rows_window(a3: torch.Tensor, b2: torch.Tensor, out3: torch.Tensor, r0: int, R: int, m_rows: Optional[int] = None) -> None:
+    """out3[:, r0:r0 + R] = a3[:, r0:r0 + R] @ b2 as ONE flat problem over the B * R real rows of buffers that hold T >= R rows per batch
+    (mh_gemm_desc.a_rows_per_batch / c_rows_per_batch): [3P] NystromAttention's front-padded sequence — the pad rows are never multiplied.
+    a3 [B, T, K] bf16 (rows K-contiguous), b2 a 2-D weight view [K, N] (W^T of an [N, K] row-major weight, or a row-major [K, N]),
+    out3 [B, T, N] bf16 (may be a column slice of a wider buffer).  m_rows: only the first m_rows flat rows (whole 256-row tiles)."""
+    _chk(a3, b2, out3)
+    Bn, T, Kd = a3.shape
+    N = b2.shape[1]
+    bf = torch.bfloat16
+    if not (a3.dtype == b2.dtype == out3.dtype == bf and a3.stride(2) == 1 and out3.stride(2) == 1 and a3.stride(0) == T * a3.stride(1)
+            and out3.stride(0) == T * out3.stride(1) and tuple(out3.shape) == (Bn, T, N) and b2.shape[0] == Kd and 0 <= r0 and r0 + R <= T):
+        raise MirrorHipError("gemm_rows_window: bad operands")
+    d = GemmDesc()
+    d.A, d.B, d.C, d.bias = a3.data_ptr() + r0 * a3.stride(1) * 2, b2.data_ptr(), out3.data_ptr() + r0 * out3.stride(1) * 2, None
+    d.M, d.N, d.K = (Bn * R if m_rows is None else int(m_rows)), N, Kd
+    d.lda, d.ldc = a3.stride(1), out3.stride(1)
+    if b2.stride(0) == 1:            # W^T of a row-major [N, K] weight: contraction index contiguous
+        d.ldb, d.b_kc = b2.stride(1), 1
+    elif b2.stride(1) == 1:          # row-major [K, N]
+        d.ldb, d.b_kc = b2.stride(0), 0
+    else:
+        raise MirrorHipError("gemm_rows_window: the weight view must have a unit stride")
+    d.a_kc = 1
+    d.dtA, d.dtB, d.dtC, d.mma = MH_BF16, MH_BF16, MH_BF16, MH_BF16
+    d.batch1 = d.batch2 = 1
+    d.alpha, d.split_k = 1.0, 1
+    if R != T and Bn > 1:
+        d.a_rows_per_batch, d.a_row_skip = R, T - R
+        d.c_rows_per_batch, d.c_row_skip = R, T - R
+    d.shared_chip = 1 if shared_chip else 0
+    prof = gemm_profiler
+    if prof is None:
+        _lib.call("mh_gemm", C.byref(d), stream=_stream())
+    else:
+        kern = ("gemm_big_kernel", "gemm_pp_kernel", "gemm_pq_kernel")[int(_lib.load().mh_gemm_select_pp(-1))]
+        if shared_chip and kern == "gemm_pq_kernel":
+            kern = "gemm_pp_kernel"
+        prof.launch_named(f"{kern}<bf16,true,{'true' if d.b_kc else 'false'}>", 2.0 * d.M * d.N * d.K,
+                          lambda: _lib.call("mh_gemm", C.byref(d), stream=_stream()))
+
+
+def gemm_rows_window_ok(a3: torch.Tensor, out3: torch.Tensor, r0: int, R: int, N: int) -> bool:
+    """shapes / build for which gemm_rows_window runs (the direct-to-LDS 256 x 256 kernels)."""
+    bf = torch.bfloat16
+    return (a3.dim() == 3 and out3.dim() == 3 and a3.dtype == bf and out3.dtype == bf and a3.is_cuda and R >= 256 and a3.shape[0] * R > 512
+            and N % 256 == 0 and a3.shape[2] % 64 == 0 and a3.stride(2) == 1 and out3.stride(2) == 1 and a3.stride(1) % 8 == 0
+            and out3.stride(1) % 8 == 0 and a3.data_ptr() % 16 == 0 and out3.data_ptr() % 16 == 0
+            and a3.stride(0) == a3.shape[1] * a3.stride(1) and out3.stride(0) == out3.shape[1] * out3.stride(1)
+            and int(_lib.load().mh_gemm_select_pp(-1)) != 0)
+
+
 def epi_dropadd(resid: torch.Tensor, p: float, seed: int, offset: int, dev_base) -> "_lib.GemmEpi":
     _chk(resid)
     e = _lib.GemmEpi()

@@ -214,7 +214,9 @@ class TransLayer(nn.Module):
             cnt = mrow.reshape(mrow.shape[0], (n + pad) // l, l).sum(-1)
             kmask = (mrow, (cnt > 0).float().contiguous(), (float(l) / (cnt + 1e-8)).contiguous())
             xp = Fn.RowScaleFn.apply(xp, mrow)           # to_qkv has no bias: zero rows in, zero q / k / v rows out
-        qkv = Fn.linear(xp, a.to_qkv.weight, None, prec=prec, defer_from=2 * a.to_qkv.weight.shape[1])
+        # behind LayerNormLmFn the pad rows of xp are exact zeros and its backward reads the real rows only: to_qkv skips them
+        qkv = Fn.linear(xp, a.to_qkv.weight, None, prec=prec, defer_from=2 * a.to_qkv.weight.shape[1],
+                        zero_rows=pad if (lm is not None and kmask is None) else 0)
         core = Fn.NystromCoreFn.apply(qkv, a.res_conv.weight, a.heads, l, a.pinv_iterations, prec, kmask,
                                       Fn.fp8_site_key(a.to_out[0].weight, prec) if prec.fp8_fwd else None, lm)
         # to_out(...)[:, -n:], its Dropout and the residual add: one launch when the shapes allow (Fn.to_out_dropout_add).

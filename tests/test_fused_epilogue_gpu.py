@@ -444,3 +444,33 @@ def test_dz_dav_one_launch_equals_gemm_pack_gemm():
     dd = (dav.float() - dav_ref.float()).abs().max() / dav_ref.float().abs().max()
     assert float(du) <= 8e-3 and float(dd) <= 8e-3, (float(du), float(dd))
     assert float((up.float() - up_ref.float()).abs().mean() / up_ref.float().abs().mean()) <= 5e-4
+
+
+@pytest.mark.parametrize("B,T,R,Kd,N,kc", [(2, 1280, 1025, 512, 1024, 1), (2, 1280, 1025, 1536, 512, 0), (3, 768, 513, 256, 256, 1)])
+@pytest.mark.parametrize("beside_chain", [False, True])
+def test_rows_window_product_skips_the_front_pad_rows(B, T, R, Kd, N, kc, beside_chain):
+    """to_qkv / its data gradient over the B x n real rows of [3P] NystromAttention's front-padded buffers as one flat problem
+    (mh_gemm_desc.a_rows_per_batch + c_rows_per_batch, the ragged rows through the weight-streaming kernel): equals the matmul of the
+    window, rows outside the window and columns outside the slice are untouched (models/mirror.py:312)."""
+    from mirror_amd import functional as Fn, kernels as K
+    from mirror_amd._lib import MH_BF16
+    g = torch.Generator().manual_seed(1)
+    r0 = T - R
+    a = torch.randn(B, T, Kd, generator=g).cuda().to(bf16)
+    if kc:
+        w = (torch.randn(N, Kd, generator=g) * 0.05).cuda().to(bf16)
+        b2, wt = w.t(), None
+    else:
+        w = (torch.randn(Kd, N, generator=g) * 0.05).cuda().to(bf16)
+        b2, wt = w, w.t().contiguous()
+    out = torch.full((B, T, N + 256), 7.0, device="cuda", dtype=bf16)
+    o3 = out[..., :N]
+    K.shared_chip = beside_chain            # the one-workgroup-per-tile kernel instead of the persistent one
+    try:
+        Fn._rows_window(a, b2, o3, r0, R, mma=MH_BF16, wt=wt)
+    finally:
+        K.shared_chip = False
+    torch.cuda.synchronize()
+    ref = (a[:, r0:].float() @ b2.float())
+    assert float((o3[:, r0:].float() - ref).abs().max()) <= 1e-2 * float(ref.abs().max())
+    assert bool((o3[:, :r0] == 7).all()) and bool((out[..., N:] == 7).all())
