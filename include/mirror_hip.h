@@ -424,6 +424,10 @@ int mh_dropout_lite(const float* a, const void* x, void* y, int64_t n, float p, 
  * Profiling aid (tools/exp/probe_timeline.py: where the branches of a replayed step really start and end, without a tracer
  * attached); nothing on the product path calls it. */
 int mh_timestamp(uint64_t* dst, mh_stream s);
+/* mh_dropout_lite's backward use on a [rows, N] f32 gradient -> bf16, which also adds the column sums of what it wrote to db [N]:
+ * the bias gradient of [3P] to_out[0] (models/mirror.py:312) without mh_colsum's pass over the bf16 gradient. */
+int mh_dropout_lite_colsum(const float* x, void* y, int64_t rows, int N, float p, uint64_t seed, uint64_t offset,
+                           const uint64_t* dev_base, float* db, mh_stream s);
 /* out[c] += sum_r x[r*ld + c]  (bias gradients; f32 atomics) */
 int mh_colsum(const void* x, float* out, int64_t rows, int cols, int64_t ld, int dt, mh_stream s);
 /* y[r] = x[r*x_rs .. +D] / max(||.||, eps) (F.normalize, models/mirror.py:540, :683); norm[r] saved */

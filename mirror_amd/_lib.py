@@ -145,6 +145,7 @@ _SIGS = {
     "mh_dropout_add": [P, P, P, L, F, U64, U64, P, I],
     "mh_dropout_lite": [P, P, P, L, F, U64, U64, P, I, I],
     "mh_timestamp": [P],
+    "mh_dropout_lite_colsum": [P, P, L, I, F, U64, U64, P, P],
     "mh_colsum": [P, P, L, I, L, I],
     "mh_l2norm_fwd": [P, P, P, I, I, L, F, I, I],
     "mh_l2norm_bwd": [P, P, P, P, I, I, L, F, I, I, I, I],

@@ -225,6 +225,81 @@ extern "C" int mh_dropout_lite(const float* a, const void* x, void* y, int64_t n
     return MH_OK;
 }
 
+// dropout backward of a [rows, N] gradient on the lite stream (f32 in, bf16 out) that also leaves the column sums of what it wrote:
+// the bias gradient of the Linear in front of the dropout ([3P] to_out = Sequential(Linear, Dropout), models/mirror.py:312) without
+// a second pass over the bf16 gradient.  Thread (cg = tid % (N / 8), rl = tid / (N / 8)) owns 8 columns and every (256 / (N / 8))-th
+// row of this workgroup's rows; column sums are folded through LDS and added to db with one atomic per column and workgroup.
+__global__ __launch_bounds__(256) void dropout8_colsum_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long rows, int N, int rows_per_wg,
+                                                              float p, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ dev_base,
+                                                              float* __restrict__ db) {
+    __shared__ float red[256 * 8];
+    if (dev_base) offset += *dev_base & ~7ull;
+    const uint32_t thr = drop16_thr(p);
+    const float scale = drop16_scale(thr);
+    const int groups = N >> 3, lanes = 256 / groups, cg = threadIdx.x % groups, rl = threadIdx.x / groups;
+    const long r0 = (long)blockIdx.x * rows_per_wg, r1 = min(rows, r0 + rows_per_wg);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 8;                         // rows in flight per thread
+    auto body = [&](long rb, bool full) {
+        f4_t v0[U], v1[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const long r = rb + (long)u * lanes;
+            const long q = (full || r < r1 ? r : r1 - 1) * groups + cg;          // clamped: the value is not used
+            v0[u] = ld4(x + 8 * q);
+            v1[u] = ld4(x + 8 * q + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const long r = rb + (long)u * lanes;
+            const bool on = full || r < r1;
+            const long q = (on ? r : r1 - 1) * groups + cg;
+            const uint32_t keep = drop16_keep8((offset >> 3) + (uint64_t)q, seed, thr);
+            f4_t o0, o1;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                o0[e] = (keep & (1u << e)) ? __fmul_rn(v0[u][e], scale) : 0.f;
+                o1[e] = (keep & (16u << e)) ? __fmul_rn(v1[u][e], scale) : 0.f;
+            }
+            if (on) {
+                st4(y + 8 * q, o0);
+                st4(y + 8 * q + 4, o1);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {    // the sums are those of the ROUNDED values (what mh_colsum reads back)
+                    acc[e] += bf2f(f2bf(o0[e]));
+                    acc[4 + e] += bf2f(f2bf(o1[e]));
+                }
+            }
+        }
+    };
+    long rb = r0 + rl;
+    for (; rb + (long)(U - 1) * lanes < r1; rb += (long)U * lanes) body(rb, true);
+    if (rb < r1) body(rb, false);
+#pragma unroll
+    for (int e = 0; e < 8; e++) red[rl * N + 8 * cg + e] = acc[e];
+    __syncthreads();
+    // one atomic per column and workgroup, consecutive columns in consecutive lanes (a lane adding its own 8 columns in turn spreads
+    // every wave-instruction over 16 cache lines: 4.5x slower end to end)
+    for (int c = threadIdx.x; c < N; c += 256) {
+        float t = 0.f;
+        for (int k = 0; k < lanes; k++) t += red[k * N + c];
+        if (t != 0.f) atomicAdd(db + c, t);
+    }
+}
+
+extern "C" int mh_dropout_lite_colsum(const float* x, void* y, int64_t rows, int N, float p, uint64_t seed, uint64_t offset,
+                                      const uint64_t* dev_base, float* db, mh_stream s) {
+    MH_REQUIRE(p >= 0.f && p < 1.f, "mh_dropout_lite_colsum: p=%f out of range", (double)p);
+    MH_REQUIRE(N >= 8 && N % 8 == 0 && N <= 2048 && 256 % (N / 8) == 0 && (offset & 7) == 0, "mh_dropout_lite_colsum: N=%d needs N %% 8 == 0 and 256 %% (N / 8) == 0", N);
+    MH_REQUIRE(db && (((uintptr_t)x | (uintptr_t)y) & 15) == 0, "mh_dropout_lite_colsum: aligned buffers and a bias-gradient destination");
+    if (rows == 0) return MH_OK;
+    static const int rows_per_wg = [] { const char* e = getenv("MH_DROPCS_ROWS"); return e ? atoi(e) : 192; }();      // rows per workgroup: 8 in flight per thread, one coalesced atomic per column and workgroup (64: 46 us, 128: 38, 192: 36, 512: 44; the two launches: 47)
+    hipLaunchKernelGGL(dropout8_colsum_kernel, dim3((unsigned)mh_cdiv(rows, rows_per_wg)), dim3(256), 0, (hipStream_t)s, x, (bf16_t*)y, (long)rows, N,
+                       rows_per_wg, p, seed, offset, dev_base, db);
+    MH_LAUNCH_CHECK("mh_dropout_lite_colsum");
+    return MH_OK;
+}
+
 extern "C" int mh_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, uint64_t offset, const uint64_t* dev_base,
                           int dt_x, int dt_y, mh_stream s) {
     MH_REQUIRE(p >= 0.f && p < 1.f, "mh_dropout: p=%f out of range", (double)p);

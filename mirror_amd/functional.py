@@ -629,6 +629,9 @@ def _linear_rows_bwd(ctx_needs, x, wa, w, b, r0, R, prec, dy, dx_dtype=None):
     return dx, dw, db
 
 
+_DROP_COLSUM = os.environ.get("MIRROR_DROP_COLSUM", "1") != "0"      # A/B switch
+
+
 class ToOutDropAddFn(Function):
     """resid + Dropout_p(core[:, r0:r0+R] @ W^T + b) -> f32 in ONE launch: [3P] to_out = Sequential(Linear, Dropout), the `[:, -n:]`
     slice and TransLayer's residual add (models/mirror.py:312-313) ride in the projection's epilogue (mh_gemm_epi DROPADD): the
@@ -661,9 +664,22 @@ class ToOutDropAddFn(Function):
         core, wa, w, b = ctx.saved_tensors
         dy = dy.contiguous()
         gb = torch.empty(dy.shape, device=dy.device, dtype=ctx.prec.act)
-        K.dropout_lite(dy, ctx.p, ctx.seed, ctx.offset, ctx.base, out=gb)           # masked, scaled gradient of the projection output
+        db_done, fused_db = None, False
+        if (_DROP_COLSUM and b is not None and ctx.needs_input_grad[3] and dy.dtype == f32 and gb.dtype == bf16
+                and K.dropout_lite_colsum_ok(dy.shape[-1])):
+            # the same pass leaves the bias gradient (column sums of the masked bf16 gradient): no mh_colsum launch over it
+            dbuf, sunk = _gbuf(b, (dy.shape[-1],))
+            K.dropout_lite_colsum(dy, ctx.p, ctx.seed, ctx.offset, ctx.base, gb, dbuf)
+            db_done, fused_db = _gret(b, dbuf, sunk), True
+        else:
+            K.dropout_lite(dy, ctx.p, ctx.seed, ctx.offset, ctx.base, out=gb)       # masked, scaled gradient of the projection output
         _res_grads[ctx.res_key] = dy         # the block's LayerNorm accumulates its dx into the residual gradient (see AddFn)
-        dcore, dw, db = _linear_rows_bwd(ctx.needs_input_grad[1:4], core, wa, w, b, ctx.r0, ctx.R, ctx.prec, gb)
+        needs = list(ctx.needs_input_grad[1:4])
+        if fused_db:
+            needs[2] = False
+        dcore, dw, db = _linear_rows_bwd(needs, core, wa, w, b, ctx.r0, ctx.R, ctx.prec, gb)
+        if fused_db:
+            db = db_done
         return dy, dcore, dw, db, None, None, None, None
 
 

@@ -1277,6 +1277,21 @@ def dropout_add(a: torch.Tensor, x: torch.Tensor, p: float, seed: int, offset: i
     return y
 
 
+def dropout_lite_colsum(x: torch.Tensor, p: float, seed: int, offset: int, dev_base, out: torch.Tensor, db: torch.Tensor) -> torch.Tensor:
+    """out (bf16) = dropout-backward of the f32 gradient x [.., N] on the lite stream, db [N] += column sums of out (mh_dropout_lite_colsum)."""
+    _chk(x, dev_base, out, db)
+    N = x.shape[-1]
+    if not (x.dtype == torch.float32 and out.dtype == torch.bfloat16 and x.is_contiguous() and out.is_contiguous() and out.shape == x.shape
+            and db.dtype == torch.float32 and db.is_contiguous() and db.numel() == N and offset % 8 == 0):
+        raise MirrorHipError("dropout_lite_colsum: contiguous f32 gradient, bf16 output of the same shape, f32 [N] bias gradient")
+    _lib.call("mh_dropout_lite_colsum", _p(x), _p(out), x.numel() // N, N, p, seed, offset, _p(dev_base), _p(db), stream=_stream())
+    return out
+
+
+def dropout_lite_colsum_ok(N: int) -> bool:
+    return N % 8 == 0 and 8 <= N <= 2048 and 256 % (N // 8) == 0
+
+
 def timestamp(slot: torch.Tensor) -> None:
     """*slot (int64, one element) = the device wall clock when the current stream reaches this point (mh_timestamp: profiling aid)."""
     assert slot.dtype == torch.int64 and slot.numel() == 1 and slot.is_cuda
