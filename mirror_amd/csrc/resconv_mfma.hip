@@ -11,6 +11,7 @@
 // The weight gradient dw[j] = sum_{b,t,c} dout[t, c] v[t + j - 16, c] is the diagonal sums of
 //     S[i][k] = sum_c dout[t0 + i, c] v[t0 - 16 + k, c]
 // accumulated over every row block: both operands are channel-contiguous rows, read straight from HBM as fragments.
+#include <cstdlib>
 #include "gemm_kernel.h"
 
 namespace {
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(256) void resconv_wgrad_mfma_kernel(const bf16_t* _
                                                                  const bf16_t* __restrict__ dout, long ldo, long o_bs,
                                                                  float* __restrict__ dw, int n_p) {
     __shared__ float gsum[64];
+    __shared__ float s_S[4 * 32 * 65];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 5, r = lane & 31;
     const int h = blockIdx.y, b = blockIdx.z;
     if (tid < 64) gsum[tid] = 0.f;
@@ -135,9 +137,10 @@ __global__ __launch_bounds__(256) void resconv_wgrad_mfma_kernel(const bf16_t* _
 #pragma unroll
         for (int e = 0; e < 16; e++) acc[kb][e] = 0.f;
     const int nblk = (n_p + 31) / 32;
-    for (int tb = blockIdx.x * 4 + wave; tb < nblk; tb += 4 * gridDim.x) {
+    // the fragments of block tb + stride are requested before the MFMAs of block tb: a wave walks ~17 blocks, and with one block's
+    // loads in flight at a time every step stood at the full memory latency (38 us alone, 143 us beside the chain's traffic)
+    auto fetch = [&](int tb, bf16x8 (&af)[4], bf16x8 (&bf)[2][4]) {
         const int t = 32 * tb + r;
-        bf16x8 af[4], bf[2][4];
         const bool tok = t < n_p;
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) {
@@ -156,21 +159,44 @@ __global__ __launch_bounds__(256) void resconv_wgrad_mfma_kernel(const bf16_t* _
                 bf[kb][ks] = __builtin_bit_cast(bf16x8, x);
             }
         }
+    };
+    auto mac = [&](const bf16x8 (&af)[4], const bf16x8 (&bf)[2][4]) {
 #pragma unroll
         for (int kb = 0; kb < 2; kb++)
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) acc[kb] = MFMA(af[ks], bf[kb][ks], acc[kb]);
+    };
+    const int stride = 4 * gridDim.x;
+    int tb = blockIdx.x * 4 + wave;
+    bf16x8 a0[4], b0[2][4], a1[4], b1[2][4];
+    if (tb < nblk) fetch(tb, a0, b0);
+    while (tb < nblk) {
+        if (tb + stride < nblk) fetch(tb + stride, a1, b1);
+        mac(a0, b0);
+        tb += stride;
+        if (tb >= nblk) break;
+        if (tb + stride < nblk) fetch(tb + stride, a0, b0);
+        mac(a1, b1);
+        tb += stride;
     }
     __syncthreads();
-    // diagonal sums: S[i][k] belongs to tap j = k - i
+    // diagonal sums: S[i][k] belongs to tap j = k - i.  The 32 x 64 result of every wave goes through LDS once and 33 lanes add up one
+    // diagonal each (2048 LDS atomics per wave onto 33 addresses serialised: most of the kernel's 38 us)
+    float* S = s_S + wave * (32 * 65);
 #pragma unroll
     for (int kb = 0; kb < 2; kb++)
 #pragma unroll
         for (int e = 0; e < 16; e++) {
             const int i = 8 * (e >> 2) + 4 * hl + (e & 3);
-            const int j = 32 * kb + r - i;
-            if (j >= 0 && j < RM_TAPS) atomicAdd(&gsum[j], acc[kb][e]);
+            S[i * 65 + 32 * kb + r] = acc[kb][e];
         }
+    __syncthreads();
+    if (lane < RM_TAPS) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; i++) t += S[i * 65 + lane + i];
+        atomicAdd(&gsum[lane], t);
+    }
     __syncthreads();
     if (tid < RM_TAPS) atomicAdd(dw + h * RM_TAPS + tid, gsum[tid]);
 }
@@ -195,7 +221,8 @@ bool resconv_wgrad_try_mfma(const void* v, long ldv, long v_bs, const void* dout
     const int nblk = mh_cdiv(n_p, 32);
     int splits = 1;
     // ~one workgroup per CU: every extra split adds a round of LDS + global atomics (16 splits: 64 us, 2: 37 us at c2)
-    while (splits * 2 * heads * B <= 256 && splits * 2 * 4 <= nblk) splits *= 2;
+    static const int target = [] { const char* e = getenv("MH_RCW_WGS"); return e ? atoi(e) : 256; }();      // workgroups aimed at (A/B switch)
+    while (splits * 2 * heads * B <= target && splits * 2 * 4 <= nblk) splits *= 2;
     dim3 grid(splits, heads, B);
     hipLaunchKernelGGL(resconv_wgrad_mfma_kernel, grid, dim3(256), 0, s, (const bf16_t*)v, ldv, v_bs, (const bf16_t*)dout, ldo, o_bs,
                        dw, n_p);
