@@ -1136,9 +1136,16 @@ static int pp_mode() {
     return g_pp;
 }
 static bool pp_enabled() { return pp_mode() != 0; }
-static int pq_grid(long units) {
+static int pq_grid(long units, int shared = 0) {
     static const int cus = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
-    return (int)(units < cus ? units : cus);
+    // beside the half-chip chain (mh_gemm_desc.shared_chip) the persistent kernel takes the OTHER half: 128 workgroups + the chain's
+    // 128 are one per CU in whatever order they arrive (MH_PQ_SHARED=0: the one-workgroup-per-tile kernel there, as before)
+    const int n = shared ? cus / 2 : cus;
+    return (int)(units < n ? units : n);
+}
+static bool pq_shared() {
+    static const bool on = [] { const char* e = getenv("MH_PQ_SHARED"); return e && e[0] == '1'; }();
+    return on;
 }
 template <typename K>
 static void pp_attr(K kern) {
@@ -1146,11 +1153,11 @@ static void pp_attr(K kern) {
 }
 #define PP_LAUNCH_(TC, AKC, BKC, PART, EPI, grid, s, a)                                              \
     do {                                                                                             \
-        if (pp_mode() == 2 && !(a).shared_chip) {                                                    \
+        if (pp_mode() == 2 && (!(a).shared_chip || pq_shared())) {                                   \
             static const bool attrq_ = (pp_attr(gemm_pq_kernel<TC, AKC, BKC, PART, EPI>), true);     \
             (void)attrq_;                                                                            \
             const long units_ = (long)(grid).x * (grid).y * (grid).z;                                \
-            hipLaunchKernelGGL((gemm_pq_kernel<TC, AKC, BKC, PART, EPI>), dim3(pq_grid(units_)), dim3(NTB), PQ_LDS, s, a, (int)units_, \
+            hipLaunchKernelGGL((gemm_pq_kernel<TC, AKC, BKC, PART, EPI>), dim3(pq_grid(units_, (a).shared_chip)), dim3(NTB), PQ_LDS, s, a, (int)units_, \
                                (int)(grid).x, (int)(grid).y);                                        \
         } else {                                                                                     \
             static const bool attr_ = (pp_attr(gemm_pp_kernel<TC, AKC, BKC, PART, EPI>), true);      \
