@@ -1,4 +1,5 @@
 // mh_gemm(): argument checks, split-K / vectorisation decisions, dispatch to the three kernel families.
+#include <cstdlib>
 #include "gemm_kernel.h"
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -102,11 +103,16 @@ __global__ __launch_bounds__(256) void rank_update_kernel(const TA* __restrict__
     C[(long)m * ldc + n] += alpha * acc;
 }
 
-static bool try_rank_update(const mh_gemm_desc* t, hipStream_t s) {
+static bool rank_update_ok(const mh_gemm_desc* t) {
     const int batch = t->batch1 * t->batch2;
     if (t->K > 16 || t->a_kc || t->b_kc || t->dtC != MH_F32 || !t->accumulate || t->bias || t->R || t->diag != 0.f || t->act != MH_ACT_NONE)
         return false;
     if ((t->batch1 != 1 && t->batch2 != 1) || (batch > 1 && (t->sC1 != 0 || t->sC2 != 0)) || t->M > 65535 || batch * t->K > 256) return false;
+    return true;
+}
+static bool try_rank_update(const mh_gemm_desc* t, hipStream_t s) {
+    const int batch = t->batch1 * t->batch2;
+    if (!rank_update_ok(t)) return false;
     const long sA = t->batch1 > 1 ? t->sA1 : t->sA2, sB = t->batch1 > 1 ? t->sB1 : t->sB2;     // the one batch axis in use
     dim3 grid(mh_cdiv(t->N, 256), t->M);
 #define RU_(TA, TB) hipLaunchKernelGGL((rank_update_kernel<TA, TB>), grid, dim3(256), 0, s, (const TA*)t->A, (long)t->lda, sA, (const TB*)t->B, (long)t->ldb, sB, (float*)t->C, (long)t->ldc, t->M, t->N, t->K, batch, t->alpha)
@@ -157,8 +163,23 @@ extern "C" int mh_gemm(const mh_gemm_desc* d, mh_stream stream) {
         t.R = nullptr;
         t.accumulate = 1;
         t.split_k = 1;
+        // offer the remainder to the main launch's fold pass (gemm_big.hip: partial tiles + fold): one launch less when it takes it
+        GemmTail* pt = gemm_pending_tail();
+        pt->KT = 0;
+        static const bool merge = [] { const char* e = getenv("MH_GEMM_TAIL_FOLD"); return !(e && e[0] == '0'); }();      // A/B switch
+        if (merge && m.accumulate && rank_update_ok(&t)) {
+            const int batch_t = t.batch1 * t.batch2;
+            *pt = GemmTail{t.A, t.B, (long)t.lda, t.batch1 > 1 ? (long)t.sA1 : (long)t.sA2, (long)t.ldb, t.batch1 > 1 ? (long)t.sB1 : (long)t.sB2,
+                           t.K, batch_t, t.dtA == MH_F32, t.dtB == MH_F32, t.alpha};
+        }
         const int rc = launch_one(&m, s);
+        const bool taken = merge && pt->KT == 0 && m.accumulate && rank_update_ok(&t);
+        pt->KT = 0;
         if (rc != MH_OK) return rc;
+        if (taken) {
+            MH_LAUNCH_CHECK("mh_gemm(tail in fold)");
+            return MH_OK;
+        }
         if (m.accumulate && try_rank_update(&t, s)) {
             MH_LAUNCH_CHECK("mh_gemm(tail)");
             return MH_OK;

@@ -13,6 +13,10 @@
 #define GEMM_EXP 0
 #endif
 
+// the tail mh_gemm offers to the next fold launch (gemm_kernel.h: GemmTail); host-side state of the calling thread's launch sequence
+static GemmTail g_tail = {nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, 0.f};
+GemmTail* gemm_pending_tail() { return &g_tail; }
+
 namespace {
 
 constexpr int BIG = 256, NTB = 512, BWM = 4, BWN = 2;
@@ -1108,9 +1112,10 @@ __global__ __launch_bounds__(NTB) void gemm_pq_kernel(GemmArgs g, int units, int
     }
 }
 
-// C[r][c] += sum_p P[p][r][c]: quads, 8 partials in flight
+// C[r][c] += sum_p P[p][r][c]: quads, 8 partials in flight; TAIL: + the rank-(batch x KT) remainder of the contraction (GemmTail)
+template <bool TAIL>
 __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restrict__ P, int parts, long mn, float* __restrict__ C, long ldc,
-                                                            int N) {
+                                                            int N, GemmTail t) {
     for (long q = (long)blockIdx.x * 256 + threadIdx.x; q * 4 < mn; q += (long)gridDim.x * 256) {
         const long i = q * 4, r = i / N, c = i % N;
         f32x4 s = *reinterpret_cast<const f32x4*>(C + r * ldc + c);
@@ -1123,7 +1128,47 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restr
             for (int u = 0; u < 8; u++) s += v[u];
         }
         for (; p < parts; p++) s += *reinterpret_cast<const f32x4*>(P + (long)p * mn + i);
+        if constexpr (TAIL) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const int total = t.batch * t.KT;
+            auto ld = [&](int k, float& a, f32x4& b) {
+                const int z = k / t.KT, kk = k - z * t.KT;
+                const long ia = z * t.sA + (long)kk * t.lda + r, ib = z * t.sB + (long)kk * t.ldb + c;
+                a = t.a_f32 ? reinterpret_cast<const float*>(t.A)[ia] : bf2f(reinterpret_cast<const bf16_t*>(t.A)[ia]);
+                if (t.b_f32) b = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(t.B) + ib);
+                else {
+                    const u32x2 w = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(t.B) + ib);
+                    b = f32x4{__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xffff0000u), __uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xffff0000u)};
+                }
+            };
+            int k = 0;
+            for (; k + 8 <= total; k += 8) {          // eight independent pairs in flight (one dependent pair at a time doubled the pass)
+                float a[8];
+                f32x4 b[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) ld(k + u, a[u], b[u]);
+#pragma unroll
+                for (int u = 0; u < 8; u++) acc += b[u] * a[u];
+            }
+            for (; k < total; k++) {
+                float a;
+                f32x4 b;
+                ld(k, a, b);
+                acc += b * a;
+            }
+            s += acc * t.alpha;
+        }
         *reinterpret_cast<f32x4*>(C + r * ldc + c) = s;
+    }
+}
+static void launch_fold(const float* ws, int parts, long mn, float* C, long ldc, int N, hipStream_t s) {
+    const dim3 grid((unsigned)min((long)mh_cdiv(mn / 4, 256), 2048L));
+    // the tail's B rows are read as aligned quads of the output's columns: 4-element alignment of its rows and base
+    if (g_tail.KT > 0 && (g_tail.ldb % 4) == 0 && (g_tail.sB % 4) == 0 && ((uintptr_t)g_tail.B & (g_tail.b_f32 ? 15 : 7)) == 0) {
+        hipLaunchKernelGGL(fold_partials_kernel<true>, grid, dim3(256), 0, s, ws, parts, mn, C, ldc, N, g_tail);
+        g_tail.KT = 0;
+    } else {
+        hipLaunchKernelGGL(fold_partials_kernel<false>, grid, dim3(256), 0, s, ws, parts, mn, C, ldc, N, g_tail);
     }
 }
 
@@ -1186,8 +1231,7 @@ void launch_big(GemmArgs& a, int akc, int bkc, int batch, hipStream_t s) {
         if constexpr (sizeof(TC) == 4) {
             if (partial_) {
                 PP_DISPATCH_(true);
-                hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)min((long)mh_cdiv(mn_ / 4, 256), 2048L)), dim3(256), 0, s, (const float*)a.ws,
-                                   (int)parts_, mn_, (float*)a.C, (long)a.ldc, a.N);
+                launch_fold((const float*)a.ws, (int)parts_, mn_, (float*)a.C, (long)a.ldc, a.N, s);
                 return;
             }
         }
@@ -1206,8 +1250,7 @@ void launch_big(GemmArgs& a, int akc, int bkc, int batch, hipStream_t s) {
             else if (akc) hipLaunchKernelGGL((gemm_big_kernel<TC, true, false, false, true>), grid, dim3(NTB), 0, s, a);
             else if (bkc) hipLaunchKernelGGL((gemm_big_kernel<TC, false, true, false, true>), grid, dim3(NTB), 0, s, a);
             else hipLaunchKernelGGL((gemm_big_kernel<TC, false, false, false, true>), grid, dim3(NTB), 0, s, a);
-            hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)min((long)mh_cdiv(mn / 4, 256), 2048L)), dim3(256), 0, s, (const float*)a.ws,
-                               (int)parts, mn, (float*)a.C, (long)a.ldc, a.N);
+            launch_fold((const float*)a.ws, (int)parts, mn, (float*)a.C, (long)a.ldc, a.N, s);
             return;
         }
     }

@@ -23,6 +23,17 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// The K % 64 remainder of a weight gradient (one row per slide: B x 4097 rows) as a rank-(batch x KT) update: when the main launch
+// reduces through partial tiles + a fold pass, the fold adds it (C[m][n] += alpha sum_{z, k < KT} A_z[k][m] B_z[k][n], both operands
+// with the contraction index as their row) instead of a launch of its own (gemm.hip: try_rank_update).
+struct GemmTail {
+    const void* A; const void* B;
+    long lda, sA, ldb, sB;
+    int KT, batch, a_f32, b_f32;
+    float alpha;
+};
+GemmTail* gemm_pending_tail();       // the tail mh_gemm offers to the next fold launch (KT == 0: none); the fold clears it when it takes it
+
 struct GemmArgs {
     const void* A; const void* B; void* C; const float* bias;
     int M, N, K;

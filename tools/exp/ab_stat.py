@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Interleaved A/B of environment switches on the replayed c2 step with statistics: ABBA order, N rounds, mean +- standard error of the
 paired difference (boxes drift by ~0.5 % within a minute: single runs cannot resolve +-0.5 % effects).
-usage: python3 tools/exp/ab_stat.py [--rounds 8] BASE_ENV VARIANT_ENV [VARIANT_ENV ...]      (each "K=V" or "K=V,K2=V2"; "-" = no change)"""
+usage: python3 tools/exp/ab_stat.py [--rounds 8] BASE_ENV VARIANT_ENV [VARIANT_ENV ...]      (each "K=V" or "K=V+K2=V2"; "-" = no change)"""
 import json, os, subprocess, sys, statistics
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 args = sys.argv[1:]
@@ -11,7 +11,7 @@ if args and args[0] == "--rounds":
 def run(spec):
     env = dict(os.environ, PYTHONPATH=R)
     if spec != "-":
-        for kv in spec.split(","):
+        for kv in spec.split("+"):
             k, v = kv.split("="); env[k] = v
     out = subprocess.run([sys.executable, os.path.join(R, "bench.py"), "--steps", "30", "--warmup", "5", "--no-cpu-baseline"], env=env, cwd="/tmp",
                          capture_output=True, text=True).stdout.strip().splitlines()[-1]
