@@ -273,7 +273,7 @@ int mh_pinv_s2_bwd(const float* p, const float* dz0, const uint64_t* stats64, fl
 int mh_pinv_chain_prep(const float* x, const uint64_t* stats64, float* z0, void* xp, void* z0p, int BH, int m, mh_stream s);
 int mh_pinv_chain_pack(const float* dz, void* up, int BH, int m, mh_stream s);
 int mh_pinv_chain_fwd(const void* XP, void* saved, void* zfT, int BH, int m, int iters, const float* z0f, const uint64_t* stats64,
-                      mh_stream s);     /* z0f != NULL: z_0 = z0f / (c r) (mh_nys_sim2's unscaled panel-native attn2^T, stats64 = its maxima),
+                      int z0_rowmajor, mh_stream s);     /* z0f != NULL: z_0 = z0f / (c r) (mh_nys_sim2's unscaled panel-native attn2^T, stats64 = its maxima),
                                            rounded to bf16 and written to saved[0] here; NULL: saved[0] is pre-filled (mh_pinv_chain_prep) */
 /* attn2 = softmax(scale q_l k_l^T) of [3P] NystromAttention (m = 256 landmarks, dh = 64) and what moore_penrose_iter_pinv's start
  * needs from it, one launch: lm bf16 [B, m, 2 D] (q | k landmarks) -> a2 f32 [B h, m, m] row-major, xp = panel-native bf16 a2 (the

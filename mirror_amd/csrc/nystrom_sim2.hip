@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void nys_sim2_kernel(const bf16_t* __restrict_
     float* z0b = z0f + bh * SMAT;
 #pragma unroll
     for (int cb = 0; cb < 8; cb++) {
-        if (SIM2_EXP == 3) break;
+        if (SIM2_EXP == 3 || z0f == nullptr) break;        // z0f NULL: the chain forward reads attn2's rows itself (mh_pinv_chain_fwd z0_rowmajor)
         const float mxi = s_max[32 * cb + r], ivi = s_inv[32 * cb + r];      // statistics of attn2's row i = this lane's column
 #pragma unroll
         for (int rb = 0; rb < 2; rb++) {
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void nys_dz_dav_kernel(const float* __restrict
 extern "C" int mh_nys_sim2(const void* lm, float* a2, void* xp, float* z0f, uint64_t* stats64, int B, int m, int D, int heads, float scale,
                            mh_stream s) {
     MH_REQUIRE(m == SM && heads >= 1 && D == heads * SDH, "mh_nys_sim2: built for m = %d landmarks and dh = %d (m=%d, D=%d, heads=%d)", SM, SDH, m, D, heads);
-    MH_REQUIRE(lm && a2 && xp && z0f && stats64 && (((uintptr_t)lm | (uintptr_t)a2 | (uintptr_t)xp | (uintptr_t)z0f) & 15) == 0,
+    MH_REQUIRE(lm && a2 && xp && stats64 && (((uintptr_t)lm | (uintptr_t)a2 | (uintptr_t)xp | (uintptr_t)z0f) & 15) == 0,
                "mh_nys_sim2: null / unaligned buffer");
     MH_REQUIRE((long)B * heads * m < (1L << 31), "mh_nys_sim2: index overflow");
     if (B == 0) return MH_OK;

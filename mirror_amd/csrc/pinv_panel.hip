@@ -416,7 +416,7 @@ __device__ __forceinline__ void publish() {
 // XP = PN(X); saved[k] = PN{z_k, P_k, T2_k, T3_k}, z_0 pre-filled; zfT[j][i] = z_iters[i][j] (column-major)
 __global__ __launch_bounds__(CT) void pinv_panel_fwd_kernel(const bf16_t* __restrict__ XT, bf16_t* __restrict__ saved,
                                                             bf16_t* __restrict__ zfT, int BH, int iters,
-                                                            const float* __restrict__ z0f, const unsigned long long* __restrict__ st) {
+                                                            const float* __restrict__ z0f, const unsigned long long* __restrict__ st, int z0_rm) {
     __shared__ __attribute__((aligned(16))) char img[IMG];
     const int tid = threadIdx.x, lane = tid & 63, hl = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: panel addresses become SGPR base + one VGPR
@@ -437,8 +437,12 @@ __global__ __launch_bounds__(CT) void pinv_panel_fwd_kernel(const bf16_t* __rest
         for (int jb = 0; jb < NJ; jb++)
 #pragma unroll
             for (int T = 0; T < 16; T++) {
-                const float* src = zb + (((2 * wave + jb) * 16 + T) * 512) + (lane << 3);
-                const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+                // z0_rm: z0f is x itself, row-major (mh_nys_sim2's attn2): column j of z_0 = x^T / (c r) is ROW j of x, and a panel entry is
+                // two runs of four consecutive elements of that row (the lane reads its own row: 1 KiB apart between lanes, L2-hot) —
+                // no transposed f32 copy of attn2 is ever written.  Otherwise: the unscaled panel-native f32 x^T
+                const float* src = z0_rm ? zb + (long)(64 * wave + 32 * jb + (lane & 31)) * CM + 16 * T + 4 * hl
+                                         : zb + (((2 * wave + jb) * 16 + T) * 512) + (lane << 3);
+                const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + (z0_rm ? 8 : 4));
                 bf16x8 o;
 #pragma unroll
                 for (int e = 0; e < 4; e++) { o[e] = (__bf16)(a[e] * inv); o[4 + e] = (__bf16)(b[e] * inv); }
@@ -846,7 +850,7 @@ __device__ __forceinline__ void copy_panel(bf16x8 (&d)[16][NJ], const bf16x8 (&s
 
 // forward: saved slot 0 of iteration k = PN(z_k) (slots 1..3 unused), zfT = column-major z_iters
 __global__ __launch_bounds__(CT) void pinv_q_fwd_kernel(const bf16_t* __restrict__ XT, bf16_t* __restrict__ saved, bf16_t* __restrict__ zfT, int BH,
-                                                        int iters, const float* __restrict__ z0f, const unsigned long long* __restrict__ st) {
+                                                        int iters, const float* __restrict__ z0f, const unsigned long long* __restrict__ st, int z0_rm) {
     __shared__ __attribute__((aligned(16))) char img[IMG];
     const int tid = threadIdx.x, lane = tid & 63, hl = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -862,8 +866,12 @@ __global__ __launch_bounds__(CT) void pinv_q_fwd_kernel(const bf16_t* __restrict
         for (int jb = 0; jb < NJ; jb++)
 #pragma unroll
             for (int T = 0; T < 16; T++) {
-                const float* src = zb + (((2 * wave + jb) * 16 + T) * 512) + (lane << 3);
-                const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+                // z0_rm: z0f is x itself, row-major (mh_nys_sim2's attn2): column j of z_0 = x^T / (c r) is ROW j of x, and a panel entry is
+                // two runs of four consecutive elements of that row (the lane reads its own row: 1 KiB apart between lanes, L2-hot) —
+                // no transposed f32 copy of attn2 is ever written.  Otherwise: the unscaled panel-native f32 x^T
+                const float* src = z0_rm ? zb + (long)(64 * wave + 32 * jb + (lane & 31)) * CM + 16 * T + 4 * hl
+                                         : zb + (((2 * wave + jb) * 16 + T) * 512) + (lane << 3);
+                const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + (z0_rm ? 8 : 4));
                 bf16x8 o;
 #pragma unroll
                 for (int e = 0; e < 4; e++) { o[e] = (__bf16)(a[e] * inv); o[4 + e] = (__bf16)(b[e] * inv); }
@@ -1089,7 +1097,7 @@ extern "C" int mh_pinv_chain_pack(const float* dz, void* up, int BH, int m, mh_s
 }
 
 extern "C" int mh_pinv_chain_fwd(const void* XT, void* saved, void* zfT, int BH, int m, int iters, const float* z0f, const uint64_t* stats64,
-                                 mh_stream s) {
+                                 int z0_rowmajor, mh_stream s) {
     MH_REQUIRE(m == CM, "mh_pinv_chain_fwd: m=%d unsupported (built for m = %d; other sizes use mh_gemm)", m, CM);
     MH_REQUIRE(iters >= 1 && BH >= 0, "mh_pinv_chain_fwd: bad arguments");
     if (BH == 0) return MH_OK;
@@ -1100,12 +1108,12 @@ extern "C" int mh_pinv_chain_fwd(const void* XT, void* saved, void* zfT, int BH,
     MH_REQUIRE(!z0f || (stats64 && ((uintptr_t)z0f & 15) == 0), "mh_pinv_chain_fwd: z0f needs the maxima and 16-byte alignment");
     if (chain_q()) {
         hipLaunchKernelGGL(pinv_q_fwd_kernel, dim3(BH), dim3(CT), chain_claim_bytes(), (hipStream_t)s, (const bf16_t*)XT, (bf16_t*)saved, (bf16_t*)zfT, BH,
-                           iters, z0f, (const unsigned long long*)stats64);
+                           iters, z0f, (const unsigned long long*)stats64, z0_rowmajor);
         MH_LAUNCH_CHECK("mh_pinv_chain_fwd(q)");
         return MH_OK;
     }
     hipLaunchKernelGGL(pinv_panel_fwd_kernel, dim3(BH), dim3(CT), chain_claim_bytes(), (hipStream_t)s, (const bf16_t*)XT, (bf16_t*)saved,
-                       (bf16_t*)zfT, BH, iters, z0f, (const unsigned long long*)stats64);
+                       (bf16_t*)zfT, BH, iters, z0f, (const unsigned long long*)stats64, z0_rowmajor);
     MH_LAUNCH_CHECK("mh_pinv_chain_fwd");
     return MH_OK;
 }

@@ -1352,6 +1352,7 @@ def _pair(first: torch.Tensor, second: torch.Tensor) -> torch.Tensor:
 
 
 _S2_TAIL = os.environ.get("MIRROR_S2_TAIL", "1") != "0"      # A/B switch
+_Z0_ROWS = os.environ.get("MIRROR_Z0_ROWS", "1") != "0"      # A/B switch
 _DZ_DAV = os.environ.get("MIRROR_DZ_DAV", "1") != "0"        # A/B switch
 _RCW_EARLY = os.environ.get("MIRROR_RCW_EARLY", "0") != "0"  # A/B switch: res_conv weight gradient in front of the chain fork (measured neutral: 1757 / 1758 / 1750 vs 1757 / 1761 / 1752)
 
@@ -1389,7 +1390,7 @@ class NystromCoreFn(Function):
         one = chain and kmask is None and dh == 64 and K.nys_sim2_ok(lm, h)
         z0f = None
         if one:
-            a2, xt, z0f, st = K.nys_sim2(lm, h, scale, zeros((4,), qkv.device).view(torch.int64))
+            a2, xt, z0f, st = K.nys_sim2(lm, h, scale, zeros((4,), qkv.device).view(torch.int64), want_z0f=not _Z0_ROWS)
         else:
             a2 = K.gemm(ql, kl.transpose(-1, -2), alpha=scale, mma=mma, out_dtype=f32)      # [B,h,m,m]
             if kmask is None:
@@ -1412,7 +1413,10 @@ class NystromCoreFn(Function):
             side = _side_stream(qkv.device)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                K.pinv_chain_fwd(xt, chain_saved, zfT, iters, z0f=z0f, stats=st if one else None)
+                if one and _Z0_ROWS:      # z_0 from the rows of attn2 inside the chain launch: nys_sim2 has no second pass and no f32 transpose
+                    K.pinv_chain_fwd(xt, chain_saved, zfT, iters, z0f=a2, stats=st, z0_rowmajor=True)
+                else:
+                    K.pinv_chain_fwd(xt, chain_saved, zfT, iters, z0f=z0f, stats=st if one else None)
             saved = [(xt, chain_saved, z0 if z0 is not None else st)]      # (no stored f32 z_0 on the one-launch path: a placeholder)
             ctx.z0_stored = z0 is not None
             K.shared_chip = True         # until the join below: no persistent GEMM kernel beside the half-chip chain

@@ -837,8 +837,10 @@ def nys_sim2_ok(lm: torch.Tensor, heads: int) -> bool:
             and lm.shape[2] == 2 * heads * 64 and os.environ.get("MIRROR_NYS_SIM2", "1") != "0")
 
 
-def nys_sim2(lm: torch.Tensor, heads: int, scale: float, stats: Optional[torch.Tensor] = None):
-    """(attn2 f32 [B, h, m, m], xt = panel-native bf16 attn2, z0f = panel-native f32 attn2^T (unscaled z_0), stats) in one launch."""
+def nys_sim2(lm: torch.Tensor, heads: int, scale: float, stats: Optional[torch.Tensor] = None, want_z0f: bool = False):
+    """(attn2 f32 [B, h, m, m], xt = panel-native bf16 attn2, z0f, stats) in one launch.  z0f (want_z0f) = panel-native f32 attn2^T, the
+    unscaled z_0; by default None: the chain forward forms z_0 from the ROWS of attn2 (pinv_chain_fwd(z0f=a2, z0_rowmajor=True)) and the
+    launch skips its second pass."""
     _chk(lm, stats)
     Bn, m, D2 = lm.shape
     D = D2 // 2
@@ -846,13 +848,13 @@ def nys_sim2(lm: torch.Tensor, heads: int, scale: float, stats: Optional[torch.T
         stats = torch.zeros(2, device=lm.device, dtype=torch.int64)
     a2 = torch.empty((Bn, heads, m, m), device=lm.device, dtype=torch.float32)
     xt = torch.empty((Bn, heads, m, m), device=lm.device, dtype=torch.bfloat16)
-    z0f = torch.empty((Bn, heads, m, m), device=lm.device, dtype=torch.float32)
+    z0f = torch.empty((Bn, heads, m, m), device=lm.device, dtype=torch.float32) if want_z0f else None
     _lib.call("mh_nys_sim2", _p(lm), _p(a2), _p(xt), _p(z0f), _p(stats), Bn, m, D, heads, float(scale), stream=_stream())
     return a2, xt, z0f, stats
 
 
 def pinv_chain_fwd(XT: torch.Tensor, saved: torch.Tensor, zfT: torch.Tensor, iters: int, z0f: Optional[torch.Tensor] = None,
-                   stats: Optional[torch.Tensor] = None) -> None:
+                   stats: Optional[torch.Tensor] = None, z0_rowmajor: bool = False) -> None:
     """XT = panel-native x, saved[0, 0] = panel-native z_0 (or z0f / stats from nys_sim2: the kernel then forms z_0 itself and
     writes saved[0, 0]); zfT receives the column-major z_iters (= pinv^T row-major)."""
     _chk(XT, saved, zfT, z0f, stats)
@@ -864,7 +866,7 @@ def pinv_chain_fwd(XT: torch.Tensor, saved: torch.Tensor, zfT: torch.Tensor, ite
         raise MirrorHipError("pinv_chain_fwd: bad operands")
     if z0f is not None and not (z0f.dtype == torch.float32 and z0f.is_contiguous() and z0f.numel() == BH * m * m and stats is not None):
         raise MirrorHipError("pinv_chain_fwd: bad z0f / stats")
-    fn = lambda: _lib.call("mh_pinv_chain_fwd", _p(XT), _p(saved), _p(zfT), BH, m, iters, _p(z0f), _p(stats), stream=_stream())  # noqa: E731
+    fn = lambda: _lib.call("mh_pinv_chain_fwd", _p(XT), _p(saved), _p(zfT), BH, m, iters, _p(z0f), _p(stats), int(z0_rowmajor), stream=_stream())  # noqa: E731
     if gemm_profiler is None:
         fn()
     else:

@@ -329,7 +329,7 @@ def test_nys_sim2_one_launch_equals_composed_chain_inputs():
     D = h * dh
     lm = (torch.randn(Bn, m, 2 * D, generator=g) * 0.7).cuda().to(bf16)
     scale = dh ** -0.5
-    a2, xt, z0f, st = K.nys_sim2(lm, h, scale)
+    a2, xt, z0f, st = K.nys_sim2(lm, h, scale, want_z0f=True)
     ql = lm.view(Bn, m, 2, h, dh)[:, :, 0].permute(0, 2, 1, 3)
     kl = lm.view(Bn, m, 2, h, dh)[:, :, 1].permute(0, 2, 1, 3)
     ref = K.gemm(ql, kl.transpose(-1, -2), alpha=scale, mma=MH_BF16, out_dtype=f32)
@@ -355,6 +355,26 @@ def test_nys_sim2_one_launch_equals_composed_chain_inputs():
     assert abs(float(z0f.sum()) * inv - float(z0_ref.sum())) <= 1e-3 * abs(float(z0_ref.sum()))
     d = float((zf1.float() - zf0.float()).norm()) / float(zf0.float().norm())
     assert d < 2e-2, d
+    # default path: no second pass in nys_sim2, the chain forward forms z_0 from the ROWS of attn2 — the same bf16 z_0, bit for bit
+    a2b, xtb, none, stb = K.nys_sim2(lm, h, scale, torch.zeros(2, device="cuda", dtype=torch.int64))
+    assert none is None and torch.equal(a2b, a2) and torch.equal(xtb, xt)
+    saved2 = K.pinv_chain_saved_alloc(6, Bn * h, m, "cuda")
+    zf2 = torch.empty_like(zf0)
+    K.pinv_chain_fwd(xtb, saved2, zf2, 6, z0f=a2b, stats=stb, z0_rowmajor=True)
+    torch.cuda.synchronize()
+    # (the second pass recomputes the logits with the operands in the other MFMA roles and a differently contracted exp argument: an
+    # f32 ulp now and then, i.e. a rare bf16 flip; the rows of attn2 ARE its transpose)
+    assert float((saved2[0, 0].float() - saved1[0, 0].float()).abs().max()) <= 2 ** -7 * float(saved1[0, 0].float().abs().max())
+    inv_t = 1.0 / float(v(stb)[0] * v(stb)[1])
+    z0_exact = (a2b.transpose(-1, -2) * inv_t).to(bf16)
+    it = torch.arange(m * m // 8, device="cuda")
+    lane, T, jblk = it & 63, (it >> 6) & 15, it >> 10
+    e = torch.arange(8, device="cuda")
+    I = (16 * T + 4 * (lane >> 5))[:, None] + (e & 3) + 8 * (e >> 2)
+    J = (32 * jblk + (lane & 31))[:, None].expand(-1, 8)
+    pn = z0_exact.reshape(Bn * h, m, m)[:, I, J].reshape(Bn * h, m, m)
+    assert float((saved2[0, 0].reshape(Bn * h, m, m).float() - pn.float()).abs().max()) <= 2 ** -8 * float(pn.float().abs().max())
+    assert float((zf2.float() - zf1.float()).norm()) <= 1e-2 * float(zf1.float().norm())
     # the backward's z0 adjoint without a stored z0
     dz0 = torch.randn(Bn, h, m, m, generator=g).cuda()
     dx_a, dx_b = torch.zeros_like(ref), torch.zeros_like(ref)
