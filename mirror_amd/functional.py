@@ -1353,6 +1353,7 @@ def _pair(first: torch.Tensor, second: torch.Tensor) -> torch.Tensor:
 
 _S2_TAIL = os.environ.get("MIRROR_S2_TAIL", "1") != "0"      # A/B switch
 _Z0_ROWS = os.environ.get("MIRROR_Z0_ROWS", "1") != "0"      # A/B switch
+_S2_SIDE = os.environ.get("MIRROR_S2_SIDE", "1") != "0"      # A/B switch: sim2's landmark gradients on the chain's stream
 _DZ_DAV = os.environ.get("MIRROR_DZ_DAV", "1") != "0"        # A/B switch
 _RCW_EARLY = os.environ.get("MIRROR_RCW_EARLY", "0") != "0"  # A/B switch: res_conv weight gradient in front of the chain fork (measured neutral: 1757 / 1758 / 1750 vs 1757 / 1761 / 1752)
 
@@ -1531,7 +1532,7 @@ class NystromCoreFn(Function):
             dzb, dAV = K.nys_dz_dav(dW2, av.contiguous(), zfT)
         else:
             dZ = K.gemm(dW2, tr(av), mma=pm, out_dtype=f32)                              # [B,h,m,m]
-        side = None
+        side = dlm2 = None
         if chain:
             xb, chain_saved, z0 = flat
             work = torch.empty_like(chain_saved)
@@ -1539,6 +1540,11 @@ class NystromCoreFn(Function):
             dz0 = torch.empty_like(a2)
             if dzb is None:
                 dzb = K.pinv_chain_pack(dZ)
+            if _S2_SIDE and fused and kmask is None:
+                # sim2's share of the landmark gradients leaves the serial tail behind the join: the chain's stream has slack
+                # in this window.  The attention kernels on the main stream add into dlm with atomics meanwhile, so the two
+                # products go to a buffer of their own and one add (which is also the cast) merges them after the join.
+                dlm2 = torch.empty_like(dlm)
             side = _side_stream(qkv.device)      # half-chip chain again, beside the softmax backward / dq / dk work
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -1548,6 +1554,9 @@ class NystromCoreFn(Function):
                 else:
                     K.pinv_z0_bwd(a2, z0 if ctx.z0_stored else None, dz0, st, dS2)
                     sm_bwd(a2, dS2, mlm if kmask else None, mlm if kmask else None)
+                if dlm2 is not None:
+                    K.gemm(tr(dS2), ql, out=_heads(dlm2, 1, 2, h), alpha=scale, mma=pio)
+                    K.gemm(dS2, kl, out=_heads(dlm2, 0, 2, h), alpha=scale, mma=pio)
             K.shared_chip = True         # until the join below
         if not (_RCW_EARLY and chain):
             K.resconv_wgrad(qkv[..., 2 * D:], dout, dres, h)
@@ -1579,8 +1588,11 @@ class NystromCoreFn(Function):
         else:
             dS2 = pinv_backward_tile(a2, saved, st, dZ) if ctx.tile else pinv_backward(a2, saved, st, dZ, pm, sd)
             sm_bwd(a2, dS2, mlm if kmask else None, mlm if kmask else None)
-        K.gemm(tr(dS2), ql, out=dkl, alpha=scale, accumulate=True, mma=pio)
-        K.gemm(dS2, kl, out=dql, alpha=scale, accumulate=True, mma=pio)
+        if dlm2 is not None:
+            dlm = K.add(dlm, dlm2, out_dtype=A)
+        else:
+            K.gemm(tr(dS2), ql, out=dkl, alpha=scale, accumulate=True, mma=pio)
+            K.gemm(dS2, kl, out=dql, alpha=scale, accumulate=True, mma=pio)
         if kmask is not None:
             dlm = K.row_scale(dlm, lscale)
         dres = _gret(res_w, dres, dres_sunk)
