@@ -284,8 +284,10 @@ int mh_nys_sim2(const void* lm, float* a2, void* xp, float* z0f, uint64_t* stats
                 mh_stream s);
 /* The two small products that open NystromAttention's backward around the chain, one launch (m = 256, dh = 64; dw2, av f32
  * [BH, m, dh], zfT bf16 [BH, m, m] = the chain's column-major output): up = PN((dw2 av^T)^T) bf16, the input of mh_pinv_chain_bwd
- * (what mh_gemm + mh_pinv_chain_pack produce), dav = Z^T dw2 bf16 [BH, m, dh]. */
-int mh_nys_dz_dav(const float* dw2, const float* av, const void* zfT, void* up, void* dav, int BH, int m, int dh, mh_stream s);
+ * (what mh_gemm + mh_pinv_chain_pack produce), dav = Z^T dw2 bf16 [BH, m, dh].  delta3 (f32 [BH, m], may be NULL) receives
+ * sum_d dav[., d] av[., d] of the rounded dav: hand it to mh_nys_attn3_bwd with av = NULL and that call skips its first launch. */
+int mh_nys_dz_dav(const float* dw2, const float* av, const void* zfT, void* up, void* dav, float* delta3, int BH, int m, int dh,
+                  mh_stream s);
 int mh_pinv_chain_bwd(const void* XP, const void* saved, const void* dzf, void* work, float* dX, float* dz0, int BH, int m,
                       int iters, mh_stream s);
 /* Bytes of the chain's caller-allocated buffers: which = 0: `saved` (forward output, backward input: [iters, 4, BH, m, m]
@@ -321,6 +323,7 @@ int mh_nys_attn3_fwd(const void* qkv, const void* lm, float* av, float* lse3, fl
 int mh_nys_attn1_bwd(const void* qkv, const void* lm, const void* w2, const void* dout, const float* lse1, float* delta1,
                      void* dqkv, float* dw2, float* dlm, const float* mrow, const float* mlm, int B, int h, int n_p, int m, int dh,
                      float scale, mh_stream s);
+/* av == NULL: delta3 already holds sum_d dav av (mh_nys_dz_dav wrote it); otherwise it is scratch this call fills first */
 int mh_nys_attn3_bwd(const void* qkv, const void* lm, const float* av, const void* dav, const float* lse3, float* delta3,
                      void* dqkv, float* dlm, const float* mrow, const float* mlm, int B, int h, int n_p, int m, int dh, float scale,
                      mh_stream s);

@@ -118,7 +118,7 @@ _SIGS = {
     "mh_pinv_chain_pack": [P, P, I, I],
     "mh_pinv_chain_fwd": [P, P, P, I, I, I, P, P, I],
     "mh_nys_sim2": [P, P, P, P, P, I, I, I, I, F],
-    "mh_nys_dz_dav": [P, P, P, P, P, I, I, I],
+    "mh_nys_dz_dav": [P, P, P, P, P, P, I, I, I],
     "mh_pinv_chain_bwd": [P, P, P, P, P, P, I, I, I],
     "mh_nys_attn1_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, F, I],
     "mh_nys_attn1_fwd_q8": [P, P, P, P, P, I, I, I, I, I, F, I, P, P, P, F, P],

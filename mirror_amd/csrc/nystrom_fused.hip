@@ -1029,7 +1029,7 @@ extern "C" int mh_nys_attn3_bwd(const void* qkv, const void* lm, const float* av
     if (int e = check_geo("mh_nys_attn3_bwd", B, h, n_p, m, dh)) return e;
     if (B == 0) return MH_OK;
     const Geo g{h, n_p, h * ND, scale, scale * LOG2E, mrow, mlm, 0};
-    hipLaunchKernelGGL(nys_delta3_kernel, dim3(B * h), dim3(NM), 0, (hipStream_t)s, av, (const bf16_t*)dav, delta3);
+    if (av) hipLaunchKernelGGL(nys_delta3_kernel, dim3(B * h), dim3(NM), 0, (hipStream_t)s, av, (const bf16_t*)dav, delta3);
     NYS_LAUNCH(nys_a3_bwd_dkv_kernel, dim3(pick_walkers(B * h, n_p), B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv,
                        (const bf16_t*)lm, (const float*)delta3, (const bf16_t*)dav, lse3, (bf16_t*)dqkv, g);
     MH_LAUNCH_CHECK("mh_nys_attn3_bwd(dkv)");

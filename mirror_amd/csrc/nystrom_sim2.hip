@@ -224,7 +224,8 @@ __device__ __forceinline__ bf16x8 cvt8(const float* p) {
     return o;
 }
 __global__ __launch_bounds__(256) void nys_dz_dav_kernel(const float* __restrict__ dw2, const float* __restrict__ av,
-                                                         const bf16_t* __restrict__ zfT, bf16_t* __restrict__ up, bf16_t* __restrict__ dav) {
+                                                         const bf16_t* __restrict__ zfT, bf16_t* __restrict__ up, bf16_t* __restrict__ dav,
+                                                         float* __restrict__ delta3) {
     __shared__ __attribute__((aligned(16))) bf16_t s_dw[SM * DWP];
     __shared__ __attribute__((aligned(16))) bf16_t s_dt[SDH * DTP];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hl = lane >> 5;
@@ -278,7 +279,10 @@ __global__ __launch_bounds__(256) void nys_dz_dav_kernel(const float* __restrict
     // pass 2: dAV = zfT dW2, rows j of the same row blocks x 64 columns d
     bf16_t* davb = dav + (long)bh * SM * SDH;
 #pragma unroll
-    for (int rb = 0; rb < 2; rb++)
+    for (int rb = 0; rb < 2; rb++) {
+        float dl[16];       // delta3[j] = sum_d dAV[j][d] av[j][d] with the rounded dAV (what mh_nys_attn3_bwd's first launch computes)
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) dl[reg] = 0.f;
 #pragma unroll
         for (int nb = 0; nb < 2; nb++) {
             f32x16 c;
@@ -292,9 +296,19 @@ __global__ __launch_bounds__(256) void nys_dz_dav_kernel(const float* __restrict
 #pragma unroll
             for (int reg = 0; reg < 16; reg++) {
                 const int row = 32 * (2 * wave + rb) + (reg & 3) + 8 * (reg >> 2) + 4 * hl;
-                davb[(long)row * SDH + 32 * nb + r] = f2bf(c[reg]);
+                const unsigned short o = f2bf(c[reg]);
+                davb[(long)row * SDH + 32 * nb + r] = o;
+                if (delta3) dl[reg] += __uint_as_float((unsigned)o << 16) * avb[(long)row * SDH + 32 * nb + r];
             }
         }
+        if (delta3) {
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) {
+                const float d = half_sum(dl[reg]);
+                if (r == 0) delta3[(long)bh * SM + 32 * (2 * wave + rb) + (reg & 3) + 8 * (reg >> 2) + 4 * hl] = d;
+            }
+        }
+    }
 }
 
 }  // namespace
@@ -313,12 +327,13 @@ extern "C" int mh_nys_sim2(const void* lm, float* a2, void* xp, float* z0f, uint
     return MH_OK;
 }
 
-extern "C" int mh_nys_dz_dav(const float* dw2, const float* av, const void* zfT, void* up, void* dav, int BH, int m, int dh, mh_stream s) {
+extern "C" int mh_nys_dz_dav(const float* dw2, const float* av, const void* zfT, void* up, void* dav, float* delta3, int BH, int m, int dh,
+                             mh_stream s) {
     MH_REQUIRE(m == SM && dh == SDH, "mh_nys_dz_dav: built for m = %d landmarks and dh = %d (m=%d, dh=%d)", SM, SDH, m, dh);
     MH_REQUIRE(dw2 && av && zfT && up && dav && (((uintptr_t)dw2 | (uintptr_t)av | (uintptr_t)zfT | (uintptr_t)up | (uintptr_t)dav) & 15) == 0,
                "mh_nys_dz_dav: null / unaligned buffer");
     if (BH == 0) return MH_OK;
-    hipLaunchKernelGGL(nys_dz_dav_kernel, dim3(BH), dim3(256), 0, (hipStream_t)s, dw2, av, (const bf16_t*)zfT, (bf16_t*)up, (bf16_t*)dav);
+    hipLaunchKernelGGL(nys_dz_dav_kernel, dim3(BH), dim3(256), 0, (hipStream_t)s, dw2, av, (const bf16_t*)zfT, (bf16_t*)up, (bf16_t*)dav, delta3);
     MH_LAUNCH_CHECK("mh_nys_dz_dav");
     return MH_OK;
 }

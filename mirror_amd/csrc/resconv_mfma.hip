@@ -54,6 +54,21 @@ __global__ __launch_bounds__(256) void resconv_mfma_kernel(const bf16_t* __restr
         if (t >= 0 && t < n_p) val = *reinterpret_cast<const u32x4*>(vb + (long)t * ldv + c * 8);
         *reinterpret_cast<u32x4*>(img + q * RM_P + c * 8) = val;
     }
+    // accumulate: the addend rows are requested here, beside the v tile, not behind the MFMAs (one more dependent round trip per
+    // workgroup otherwise: the transposed pass of the backward ran 125 us against the forward's 75 us beside the chain)
+    bf16_t* ob = out + (long)b * o_bs + h * RM_DH;
+    u32x4 old[2][64 * 8 / 256];
+    if (accumulate == 2) {
+#pragma unroll
+        for (int half = 0; half < 2; half++)
+#pragma unroll
+            for (int i = 0; i < 64 * 8 / 256; i++) {
+                const int cid = tid + i * 256, q = cid >> 3, c = cid & 7;
+                const int t = t0 + 64 * half + q;
+                old[half][i] = (u32x4){0u, 0u, 0u, 0u};
+                if (t < n_p) old[half][i] = *reinterpret_cast<const u32x4*>(ob + (long)t * ldo + 8 * c);
+            }
+    }
     // Toeplitz operand W^T[k][t = r] = w[k - r], k in the accumulator order of k-step ks
     const float* wh = w + h * RM_TAPS;
     bf16x8 wf[4];
@@ -79,7 +94,6 @@ __global__ __launch_bounds__(256) void resconv_mfma_kernel(const bf16_t* __restr
     // reuses the v tile's LDS (64 rows at a time: 17 KB inside the 23 KB tile) so that 6 workgroups fit a CU: the kernel is a
     // chain of dependent memory round trips per workgroup and lives on occupancy.
     float* stage = reinterpret_cast<float*>(img);
-    bf16_t* ob = out + (long)b * o_bs + h * RM_DH;
     __syncthreads();                                  // every wave is done reading the v tile
 #pragma unroll
     for (int half = 0; half < 2; half++) {
@@ -103,11 +117,11 @@ __global__ __launch_bounds__(256) void resconv_mfma_kernel(const bf16_t* __restr
             f4_t lo = *reinterpret_cast<const f4_t*>(sp), hi = *reinterpret_cast<const f4_t*>(sp + 4);
             bf16_t* p = ob + (long)t * ldo + 8 * c;
             if (accumulate) {
-                const u32x4 old = *reinterpret_cast<const u32x4*>(p);
-                lo[0] += __uint_as_float(old[0] << 16); lo[1] += __uint_as_float(old[0] & 0xffff0000u);
-                lo[2] += __uint_as_float(old[1] << 16); lo[3] += __uint_as_float(old[1] & 0xffff0000u);
-                hi[0] += __uint_as_float(old[2] << 16); hi[1] += __uint_as_float(old[2] & 0xffff0000u);
-                hi[2] += __uint_as_float(old[3] << 16); hi[3] += __uint_as_float(old[3] & 0xffff0000u);
+                const u32x4 od = accumulate == 2 ? old[half][i] : *reinterpret_cast<const u32x4*>(p);
+                lo[0] += __uint_as_float(od[0] << 16); lo[1] += __uint_as_float(od[0] & 0xffff0000u);
+                lo[2] += __uint_as_float(od[1] << 16); lo[3] += __uint_as_float(od[1] & 0xffff0000u);
+                hi[0] += __uint_as_float(od[2] << 16); hi[1] += __uint_as_float(od[2] & 0xffff0000u);
+                hi[2] += __uint_as_float(od[3] << 16); hi[3] += __uint_as_float(od[3] & 0xffff0000u);
             }
             u32x4 o;
             o[0] = (unsigned)f2bf(lo[0]) | ((unsigned)f2bf(lo[1]) << 16);
@@ -209,8 +223,9 @@ bool resconv_try_mfma(const void* v, long ldv, long v_bs, const float* w, void* 
     if (dt_v != MH_BF16 || dt_o != MH_BF16 || dh != RM_DH || taps != RM_TAPS) return false;
     if (ldv % 8 || v_bs % 8 || ldo % 8 || o_bs % 8 || ((uintptr_t)v & 15) || ((uintptr_t)out & 15)) return false;
     dim3 grid(mh_cdiv(n_p, RM_T), heads, B);
+    static const bool early = [] { const char* e = getenv("MH_RESCONV_EARLY_ADDEND"); return !(e && e[0] == '0'); }();      // A/B switch
     hipLaunchKernelGGL(resconv_mfma_kernel, grid, dim3(256), 0, s, (const bf16_t*)v, ldv, v_bs, w, (bf16_t*)out, ldo, o_bs, n_p,
-                       transpose, accumulate);
+                       transpose, accumulate ? (early ? 2 : 1) : 0);
     return true;
 }
 

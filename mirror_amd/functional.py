@@ -945,6 +945,7 @@ class LandmarkProjFn(Function):
         xpm, wa, w = ctx.saved_tensors
         prec, n2 = ctx.prec, ctx.n2
         dlm = dlm.contiguous()
+        _join_pending(dlm)
         if dlm.dtype != prec.act:
             dlm = K.cast(dlm, prec.act)
         Dm = wa.shape[1]
@@ -1353,7 +1354,26 @@ def _pair(first: torch.Tensor, second: torch.Tensor) -> torch.Tensor:
 
 _S2_TAIL = os.environ.get("MIRROR_S2_TAIL", "1") != "0"      # A/B switch
 _Z0_ROWS = os.environ.get("MIRROR_Z0_ROWS", "1") != "0"      # A/B switch
+_DELTA3 = os.environ.get("MIRROR_DELTA3_FUSED", "0") != "0"   # A/B switch: attn3's delta out of nys_dz_dav (measured: +0.32 % +- 0.06 step time, off)
 _S2_SIDE = os.environ.get("MIRROR_S2_SIDE", "1") != "0"      # A/B switch: sim2's landmark gradients on the chain's stream
+_JOIN_LATE = os.environ.get("MIRROR_JOIN_LATE", "0") != "0"  # A/B switch: the backward's chain branch joins in front of LandmarkProjFn.backward (measured: +0.02 % +- 0.05, off)
+_RCW_SIDE = os.environ.get("MIRROR_RCW_SIDE", "0") != "0"    # A/B switch: with the late join, res_conv's weight gradient on the chain's stream (measured: +0.26 % +- 0.02 step time, off)
+# The backward of the chain branch only feeds the landmarks' gradient, and autograd runs to_qkv's backward (created after LandmarkProjFn
+# in the forward) before LandmarkProjFn's: NystromCoreFn.backward returns without waiting for the chain's stream and leaves a record
+# here, keyed by the (still empty) bf16 gradient tensor it returned; LandmarkProjFn.backward joins and fills it.  The record holds every
+# buffer the side stream still reads or writes: a block freed on the main stream could be handed out again under the running kernels.
+_pending_join: dict = {}
+
+
+def _join_pending(dlm: torch.Tensor) -> None:
+    rec = _pending_join.pop(dlm.data_ptr(), None)
+    if rec is None:
+        return
+    side, main_part, side_part, keep = rec
+    torch.cuda.current_stream().wait_stream(side)
+    K.shared_chip = False
+    K.add(main_part, side_part, out=dlm)
+    del keep
 _DZ_DAV = os.environ.get("MIRROR_DZ_DAV", "1") != "0"        # A/B switch
 _RCW_EARLY = os.environ.get("MIRROR_RCW_EARLY", "0") != "0"  # A/B switch: res_conv weight gradient in front of the chain fork (measured neutral: 1757 / 1758 / 1750 vs 1757 / 1761 / 1752)
 
@@ -1527,12 +1547,16 @@ class NystromCoreFn(Function):
         pio = pm if (pm == MH_BF16 or A == f32) else mma
         # dZ = dW2 av^T (the chain's input, packed) and dAV = Z^T dW2: ONE launch on the fused bf16 path (nystrom_sim2.hip)
         one2 = (_DZ_DAV and chain and fused and A == bf16 and pio == MH_BF16 and dh == 64 and m == 256 and dW2.dtype == f32 and av.dtype == f32)
-        dAV = dzb = None
-        if one2:
+        dAV = dzb = delta3 = None
+        if one2 and _DELTA3:
+            dzb, dAV, delta3 = K.nys_dz_dav(dW2, av.contiguous(), zfT, want_delta3=True)
+        elif one2:
             dzb, dAV = K.nys_dz_dav(dW2, av.contiguous(), zfT)
         else:
             dZ = K.gemm(dW2, tr(av), mma=pm, out_dtype=f32)                              # [B,h,m,m]
         side = dlm2 = None
+        late = False
+        rcw_side = _RCW_SIDE and dres_sunk     # written into the grad arena, which is read behind the engine's join of the side streams only
         if chain:
             xb, chain_saved, z0 = flat
             work = torch.empty_like(chain_saved)
@@ -1540,6 +1564,7 @@ class NystromCoreFn(Function):
             dz0 = torch.empty_like(a2)
             if dzb is None:
                 dzb = K.pinv_chain_pack(dZ)
+            late = _S2_SIDE and fused and kmask is None and _JOIN_LATE and ctx.lm_ext and A == bf16
             if _S2_SIDE and fused and kmask is None:
                 # sim2's share of the landmark gradients leaves the serial tail behind the join: the chain's stream has slack
                 # in this window.  The attention kernels on the main stream add into dlm with atomics meanwhile, so the two
@@ -1557,13 +1582,15 @@ class NystromCoreFn(Function):
                 if dlm2 is not None:
                     K.gemm(tr(dS2), ql, out=_heads(dlm2, 1, 2, h), alpha=scale, mma=pio)
                     K.gemm(dS2, kl, out=_heads(dlm2, 0, 2, h), alpha=scale, mma=pio)
+                if late and rcw_side:
+                    K.resconv_wgrad(qkv[..., 2 * D:], dout, dres, h)     # this branch joins behind to_qkv's backward: room for it here
             K.shared_chip = True         # until the join below
-        if not (_RCW_EARLY and chain):
+        if not ((_RCW_EARLY and chain) or (late and rcw_side)):
             K.resconv_wgrad(qkv[..., 2 * D:], dout, dres, h)
         if dAV is None:
             dAV = K.gemm(tr(zf), dW2, mma=pio, out_dtype=A)                              # [B,h,m,dh]
         if fused:
-            K.nys_attn3_bwd(qkv, lm, av, dAV, lse3, dqkv, dlm, h, scale, kmask)         # dk, dv, dq_l
+            K.nys_attn3_bwd(qkv, lm, av, dAV, lse3, dqkv, dlm, h, scale, kmask, delta3=delta3)      # dk, dv, dq_l
             K.resconv(dout, rw, dqkv[..., 2 * D:], h, transpose=True, accumulate=True)
         else:
             if (kmask is None and A == bf16 and mma == MH_BF16 and a1.dtype == bf16 and a1.is_contiguous()
@@ -1581,6 +1608,12 @@ class NystromCoreFn(Function):
             K.gemm(tr(dS3), ql, out=dk, alpha=scale, mma=mma)
             K.gemm(tr(dS1), q, out=dkl, alpha=scale, mma=mma)
             K.gemm(dS3, k, out=dql, alpha=scale, mma=mma)
+        if late:
+            out = torch.empty(dlm.shape, device=dlm.device, dtype=A)
+            _pending_join[out.data_ptr()] = (side, dlm, dlm2, (work, dS2, dz0, dzb, xb, chain_saved, a2, st, lm, qkv, dout))
+            K.shared_chip = False      # the chain itself is over by the time the main stream gets to to_qkv's backward
+            dres = _gret(res_w, dres, dres_sunk)
+            return dqkv, (None if dres is None else dres.view_as(res_w)), None, None, None, None, None, None, out
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
             K.shared_chip = False

@@ -817,8 +817,9 @@ def pinv_chain_pack(dz: torch.Tensor) -> torch.Tensor:
     return up
 
 
-def nys_dz_dav(dw2: torch.Tensor, av: torch.Tensor, zfT: torch.Tensor):
-    """(PN((dw2 av^T)^T) bf16 [.., m, m] for mh_pinv_chain_bwd, dAV = Z^T dw2 bf16 [.., m, dh]) in one launch (mh_nys_dz_dav)."""
+def nys_dz_dav(dw2: torch.Tensor, av: torch.Tensor, zfT: torch.Tensor, want_delta3: bool = False):
+    """(PN((dw2 av^T)^T) bf16 [.., m, m] for mh_pinv_chain_bwd, dAV = Z^T dw2 bf16 [.., m, dh]) in one launch (mh_nys_dz_dav);
+    want_delta3: a third result, sum_d dAV av f32 [.., m], for nys_attn3_bwd(delta3=...)."""
     _chk(dw2, av, zfT)
     m, dh = dw2.shape[-2], dw2.shape[-1]
     BH = dw2.numel() // (m * dh)
@@ -827,8 +828,9 @@ def nys_dz_dav(dw2: torch.Tensor, av: torch.Tensor, zfT: torch.Tensor):
         raise MirrorHipError("nys_dz_dav: contiguous f32 [.., m, dh] gradients / products and the bf16 column-major chain output")
     up = torch.empty(zfT.shape, device=dw2.device, dtype=torch.bfloat16)
     dav = torch.empty(dw2.shape, device=dw2.device, dtype=torch.bfloat16)
-    _lib.call("mh_nys_dz_dav", _p(dw2), _p(av), _p(zfT), _p(up), _p(dav), BH, m, dh, stream=_stream())
-    return up, dav
+    delta3 = torch.empty(dw2.shape[:-1], device=dw2.device, dtype=torch.float32) if want_delta3 else None
+    _lib.call("mh_nys_dz_dav", _p(dw2), _p(av), _p(zfT), _p(up), _p(dav), _p(delta3), BH, m, dh, stream=_stream())
+    return (up, dav, delta3) if want_delta3 else (up, dav)
 
 
 def nys_sim2_ok(lm: torch.Tensor, heads: int) -> bool:
@@ -993,14 +995,18 @@ def nys_attn1_bwd(qkv, lm, w2, dout, lse1, dqkv, dw2, dlm, heads: int, scale: fl
                                   stream=_stream()))
 
 
-def nys_attn3_bwd(qkv, lm, av, dav, lse3, dqkv, dlm, heads: int, scale: float, kmask=None) -> None:
-    """Writes the k and v blocks of dqkv; ADDS into the q_l half of dlm."""
-    _chk(qkv, lm, av, dav, lse3, dqkv, dlm)
+def nys_attn3_bwd(qkv, lm, av, dav, lse3, dqkv, dlm, heads: int, scale: float, kmask=None, delta3=None) -> None:
+    """Writes the k and v blocks of dqkv; ADDS into the q_l half of dlm.  delta3: sum_d dav av from nys_dz_dav (skips a launch)."""
+    _chk(qkv, lm, av, dav, lse3, dqkv, dlm, delta3)
     B, n_p, _ = qkv.shape
     _nys_check("nys_attn3_bwd", B, heads, n_p, qkv=qkv, lm=lm, av=av, dav=dav, lse3=lse3, dqkv=dqkv, dlm=dlm)
-    delta3 = torch.empty_like(lse3)
+    given = delta3 is not None
+    if given and not (delta3.dtype == torch.float32 and delta3.is_contiguous() and delta3.numel() == lse3.numel()):
+        raise MirrorHipError("nys_attn3_bwd: delta3 must be contiguous f32 [B, h, m]")
+    if not given:
+        delta3 = torch.empty_like(lse3)
     _nys_launch("nys_a3_bwd_kernels", 7 * 2.0 * n_p * NYS_FUSED_M * NYS_FUSED_DH * B * heads,
-                lambda: _lib.call("mh_nys_attn3_bwd", _p(qkv), _p(lm), _p(av), _p(dav), _p(lse3), _p(delta3), _p(dqkv), _p(dlm),
+                lambda: _lib.call("mh_nys_attn3_bwd", _p(qkv), _p(lm), None if given else _p(av), _p(dav), _p(lse3), _p(delta3), _p(dqkv), _p(dlm),
                                   *_nys_masks(kmask, B, n_p), B, heads, n_p, NYS_FUSED_M, NYS_FUSED_DH, scale, stream=_stream()))
 
 

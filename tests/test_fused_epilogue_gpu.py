@@ -464,6 +464,12 @@ def test_dz_dav_one_launch_equals_gemm_pack_gemm():
     dd = (dav.float() - dav_ref.float()).abs().max() / dav_ref.float().abs().max()
     assert float(du) <= 8e-3 and float(dd) <= 8e-3, (float(du), float(dd))
     assert float((up.float() - up_ref.float()).abs().mean() / up_ref.float().abs().mean()) <= 5e-4
+    # the third result: attn3's delta = sum_d dAV av of the dAV this launch stored, exactly what mh_nys_attn3_bwd's first launch computes
+    up3, dav3, delta3 = K.nys_dz_dav(dw2, av, zfT, want_delta3=True)
+    torch.cuda.synchronize()
+    assert torch.equal(up3, up) and torch.equal(dav3, dav) and delta3.shape == (B, h, m)
+    dref = (dav.float() * av).sum(-1)
+    assert float((delta3 - dref).abs().max()) <= 1e-4 * float(dref.abs().max())
 
 
 @pytest.mark.parametrize("B,T,R,Kd,N,kc", [(2, 1280, 1025, 512, 1024, 1), (2, 1280, 1025, 1536, 512, 0), (3, 768, 513, 256, 256, 1)])

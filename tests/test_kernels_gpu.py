@@ -1007,6 +1007,10 @@ def test_nys_fused_attention_sides(B, h, l):
         close(got, ref, 0.0, 2e-2 * float(ref.abs().max()), name)
         rel = float((got.float().cpu().double() - ref).norm() / ref.norm())
         assert rel < 1e-2, (name, rel)
+    # delta3 handed in (what mh_nys_dz_dav leaves): the call skips its first launch and writes the same dk / dv
+    dqkv2 = torch.full_like(qkv_d, float("nan"))
+    K.nys_attn3_bwd(qkv_d, lm_d, av, dav_d, lse3, dqkv2, torch.zeros_like(dlm), h, scale, delta3=(dav_d.float().view(B, h, m, dh) * av).sum(-1))
+    assert float((dqkv2[..., D:].float() - dqkv[..., D:].float()).abs().max()) <= 1e-2 * float(dqkv[..., D:].float().abs().max())
 
 
 def test_nys_fused_rejects_other_geometry():
