@@ -410,39 +410,47 @@ extern "C" int mh_colsum(const void* x, float* out, int64_t rows, int cols, int6
 }
 
 // ------------------------------------------------------------------ masking
-// rank by ascending noise with index tie-break == argsort(argsort(noise)) of the reference for distinct values
-__global__ __launch_bounds__(256) void rank_mask_kernel(const float* __restrict__ noise, float* __restrict__ mask, int N, int len_keep) {
-    extern __shared__ __attribute__((aligned(16))) float row[];
-    const long b = blockIdx.y;
+// rank by ascending noise with index tie-break == argsort(argsort(noise)) of the reference for distinct values.
+// One workgroup per row sorts the row's (order-preserving key, index) pairs in LDS (bitonic network over the next power of two, the
+// tail padded with maximal keys) and scatters mask[index] = position >= len_keep.  The earlier all-pairs count was N^2 compares per
+// row: 16 x 4096 took 256 workgroups for ~150-400 us beside the WSI encoder's first layers; the network is N log^2 N / 2.
+__global__ __launch_bounds__(1024) void rank_mask_kernel(const float* __restrict__ noise, float* __restrict__ mask, int N, int P, int len_keep) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+    const long b = blockIdx.x;
     const float* nb = noise + b * N;
-    for (int j = threadIdx.x; j < N; j += 256) row[j] = nb[j];
+    for (int j = threadIdx.x; j < P; j += 1024) {
+        unsigned long long k = ~0ull;
+        if (j < N) {
+            unsigned u = __float_as_uint(nb[j]);
+            u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;      // total order of the floats as unsigned integers
+            k = ((unsigned long long)u << 32) | (unsigned)j;
+        }
+        keys[j] = k;
+    }
     __syncthreads();
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N) return;
-    const float v = row[i];
-    int rank = 0;
-    // four row values per (broadcast) 16-byte LDS read, eight reads in flight: one 4-byte read per dependent iteration left
-    // the loop at the LDS latency (146 us for 16 x 4096 at the head of the RNA stream)
-    typedef float rk_f4 __attribute__((ext_vector_type(4)));
-    const int n4 = N & ~3;
-    int j = 0;
-#pragma unroll 8
-    for (; j < n4; j += 4) {
-        const rk_f4 u = *reinterpret_cast<const rk_f4*>(row + j);
-#pragma unroll
-        for (int e = 0; e < 4; e++) rank += (u[e] < v) || (u[e] == v && j + e < i);
-    }
-    for (; j < N; j++) {
-        const float u = row[j];
-        rank += (u < v) || (u == v && j < i);
-    }
-    mask[b * N + i] = rank >= len_keep ? 1.f : 0.f;
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < (P >> 1); t += 1024) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+                const unsigned long long a = keys[lo], c = keys[hi];
+                const bool up = (lo & k) == 0;
+                if ((a > c) == up) { keys[lo] = c; keys[hi] = a; }
+            }
+            __syncthreads();
+        }
+    for (int j = threadIdx.x; j < N; j += 1024) mask[b * N + (unsigned)(keys[j] & 0xffffffffu)] = j >= len_keep ? 1.f : 0.f;
 }
 
 extern "C" int mh_rank_mask(const float* noise, float* mask, int B, int N, int len_keep, mh_stream s) {
     MH_REQUIRE(N >= 1 && N <= 16384, "mh_rank_mask: N=%d unsupported (max 16384)", N);
     if (B == 0) return MH_OK;
-    hipLaunchKernelGGL(rank_mask_kernel, dim3(mh_cdiv(N, 256), B), dim3(256), N * sizeof(float), (hipStream_t)s, noise, mask, N, len_keep);
+    int P = 2;
+    while (P < N) P <<= 1;
+    static const bool big = [] {       // above 64 KB of dynamic LDS the kernel needs the opt-in, once per process
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(rank_mask_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8) == hipSuccess;
+    }();
+    MH_REQUIRE(big || P * 8 <= 65536, "mh_rank_mask: %d bytes of LDS refused", P * 8);
+    hipLaunchKernelGGL(rank_mask_kernel, dim3(B), dim3(1024), (size_t)P * sizeof(unsigned long long), (hipStream_t)s, noise, mask, N, P, len_keep);
     MH_LAUNCH_CHECK("mh_rank_mask");
     return MH_OK;
 }

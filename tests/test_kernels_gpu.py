@@ -558,6 +558,13 @@ def test_rank_mask_matches_double_argsort():
         mask = K.rank_mask(noise.to(DEV), keep)
         rank = torch.argsort(torch.argsort(noise, dim=1), dim=1)
         assert torch.equal(mask.cpu(), (rank >= keep).float())
+    # the sizes of the hot path and the largest one, with ties (stable order = lower index first) and values of both signs
+    for B, N, keep in ((16, 4096, 1024), (2, 512, 384), (2, 16384, 5000), (3, 1000, 1), (1, 1, 0), (2, 3, 2)):
+        noise = (torch.randint(-50, 50, (B, N), generator=gen).float() / 64 if N >= 1000 else torch.rand(B, N, generator=gen))
+        mask = K.rank_mask(noise.to(DEV), keep)
+        rank = torch.argsort(torch.argsort(noise, dim=1, stable=True), dim=1, stable=True)
+        assert torch.equal(mask.cpu(), (rank >= keep).float()), (B, N, keep)
+        assert int(mask.sum()) == B * (N - keep)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
