@@ -1354,6 +1354,8 @@ def _pair(first: torch.Tensor, second: torch.Tensor) -> torch.Tensor:
 
 _S2_TAIL = os.environ.get("MIRROR_S2_TAIL", "1") != "0"      # A/B switch
 _Z0_ROWS = os.environ.get("MIRROR_Z0_ROWS", "1") != "0"      # A/B switch
+_DZDAV_SIDE = os.environ.get("MIRROR_DZDAV_SIDE", "0") != "0"  # A/B switch: nys_dz_dav opens the backward's chain branch (measured: +0.32 % +- 0.18 step time, off)
+_SIM2_SIDE = os.environ.get("MIRROR_SIM2_SIDE", "1") != "0"  # A/B switch: nys_sim2 opens the chain's branch instead of preceding the fork
 _DELTA3 = os.environ.get("MIRROR_DELTA3_FUSED", "0") != "0"   # A/B switch: attn3's delta out of nys_dz_dav (measured: +0.32 % +- 0.06 step time, off)
 _S2_SIDE = os.environ.get("MIRROR_S2_SIDE", "1") != "0"      # A/B switch: sim2's landmark gradients on the chain's stream
 _JOIN_LATE = os.environ.get("MIRROR_JOIN_LATE", "0") != "0"  # A/B switch: the backward's chain branch joins in front of LandmarkProjFn.backward (measured: +0.02 % +- 0.05, off)
@@ -1410,7 +1412,13 @@ class NystromCoreFn(Function):
         # sim2, its softmax, the tensor-wide abs-sum maxima and the chain's operand packing in ONE launch (nystrom_sim2.hip)
         one = chain and kmask is None and dh == 64 and K.nys_sim2_ok(lm, h)
         z0f = None
-        if one:
+        sim2_side = one and _SIM2_SIDE and _Z0_ROWS
+        if sim2_side:
+            # nothing on the main stream needs attn2 before the join: the launch (128 workgroups, half of the chip, ~45 us) opens the
+            # chain's branch instead of standing in front of the fork.  Buffers from the main stream's allocator, as chain_saved.
+            a2, xt = K.nys_sim2_alloc(lm, h)
+            st = zeros((4,), qkv.device).view(torch.int64)
+        elif one:
             a2, xt, z0f, st = K.nys_sim2(lm, h, scale, zeros((4,), qkv.device).view(torch.int64), want_z0f=not _Z0_ROWS)
         else:
             a2 = K.gemm(ql, kl.transpose(-1, -2), alpha=scale, mma=mma, out_dtype=f32)      # [B,h,m,m]
@@ -1434,6 +1442,8 @@ class NystromCoreFn(Function):
             side = _side_stream(qkv.device)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
+                if sim2_side:
+                    K.nys_sim2(lm, h, scale, st, out=(a2, xt))
                 if one and _Z0_ROWS:      # z_0 from the rows of attn2 inside the chain launch: nys_sim2 has no second pass and no f32 transpose
                     K.pinv_chain_fwd(xt, chain_saved, zfT, iters, z0f=a2, stats=st, z0_rowmajor=True)
                 else:
@@ -1548,7 +1558,14 @@ class NystromCoreFn(Function):
         # dZ = dW2 av^T (the chain's input, packed) and dAV = Z^T dW2: ONE launch on the fused bf16 path (nystrom_sim2.hip)
         one2 = (_DZ_DAV and chain and fused and A == bf16 and pio == MH_BF16 and dh == 64 and m == 256 and dW2.dtype == f32 and av.dtype == f32)
         dAV = dzb = delta3 = None
-        if one2 and _DELTA3:
+        dzdav_side = one2 and _DZDAV_SIDE and not _DELTA3
+        if dzdav_side:
+            # the launch (128 workgroups, ~22 us) opens the chain's branch; the main stream has the res_conv weight gradient to do
+            # before it needs dAV.  Buffers from the main stream's allocator.
+            avc = av.contiguous()
+            dzb = torch.empty(zfT.shape, device=qkv.device, dtype=bf16)
+            dAV = torch.empty(dW2.shape, device=qkv.device, dtype=bf16)
+        elif one2 and _DELTA3:
             dzb, dAV, delta3 = K.nys_dz_dav(dW2, av.contiguous(), zfT, want_delta3=True)
         elif one2:
             dzb, dAV = K.nys_dz_dav(dW2, av.contiguous(), zfT)
@@ -1572,7 +1589,11 @@ class NystromCoreFn(Function):
                 dlm2 = torch.empty_like(dlm)
             side = _side_stream(qkv.device)      # half-chip chain again, beside the softmax backward / dq / dk work
             side.wait_stream(torch.cuda.current_stream())
+            dav_ready = None
             with torch.cuda.stream(side):
+                if dzdav_side:
+                    K.nys_dz_dav(dW2, avc, zfT, out=(dzb, dAV))
+                    dav_ready = side.record_event()
                 K.pinv_chain_bwd(xb, chain_saved, dzb, work, dS2, dz0, iters)
                 if _S2_TAIL and kmask is None and not ctx.z0_stored and a2.shape[-1] == 256:
                     K.pinv_s2_bwd(a2, dz0, st, dS2)      # z_0 backward, the maxima's sub-gradients and attn2's softmax backward: one pass
@@ -1589,6 +1610,8 @@ class NystromCoreFn(Function):
             K.resconv_wgrad(qkv[..., 2 * D:], dout, dres, h)
         if dAV is None:
             dAV = K.gemm(tr(zf), dW2, mma=pio, out_dtype=A)                              # [B,h,m,dh]
+        if dzdav_side:
+            torch.cuda.current_stream().wait_event(dav_ready)
         if fused:
             K.nys_attn3_bwd(qkv, lm, av, dAV, lse3, dqkv, dlm, h, scale, kmask, delta3=delta3)      # dk, dv, dq_l
             K.resconv(dout, rw, dqkv[..., 2 * D:], h, transpose=True, accumulate=True)

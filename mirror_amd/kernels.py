@@ -817,17 +817,25 @@ def pinv_chain_pack(dz: torch.Tensor) -> torch.Tensor:
     return up
 
 
-def nys_dz_dav(dw2: torch.Tensor, av: torch.Tensor, zfT: torch.Tensor, want_delta3: bool = False):
+def nys_dz_dav(dw2: torch.Tensor, av: torch.Tensor, zfT: torch.Tensor, want_delta3: bool = False, out=None):
     """(PN((dw2 av^T)^T) bf16 [.., m, m] for mh_pinv_chain_bwd, dAV = Z^T dw2 bf16 [.., m, dh]) in one launch (mh_nys_dz_dav);
-    want_delta3: a third result, sum_d dAV av f32 [.., m], for nys_attn3_bwd(delta3=...)."""
+    want_delta3: a third result, sum_d dAV av f32 [.., m], for nys_attn3_bwd(delta3=...).  out: the two bf16 result buffers, for a
+    caller that launches on another stream than the one that owns the memory."""
     _chk(dw2, av, zfT)
     m, dh = dw2.shape[-2], dw2.shape[-1]
     BH = dw2.numel() // (m * dh)
     if not (dw2.dtype == av.dtype == torch.float32 and zfT.dtype == torch.bfloat16 and dw2.is_contiguous() and av.is_contiguous()
             and zfT.is_contiguous() and av.shape == dw2.shape and zfT.numel() == BH * m * m):
         raise MirrorHipError("nys_dz_dav: contiguous f32 [.., m, dh] gradients / products and the bf16 column-major chain output")
-    up = torch.empty(zfT.shape, device=dw2.device, dtype=torch.bfloat16)
-    dav = torch.empty(dw2.shape, device=dw2.device, dtype=torch.bfloat16)
+    if out is None:
+        up = torch.empty(zfT.shape, device=dw2.device, dtype=torch.bfloat16)
+        dav = torch.empty(dw2.shape, device=dw2.device, dtype=torch.bfloat16)
+    else:
+        up, dav = out
+        _chk(up, dav)
+        if not (up.dtype == dav.dtype == torch.bfloat16 and up.is_contiguous() and dav.is_contiguous() and up.numel() == zfT.numel()
+                and dav.shape == dw2.shape):
+            raise MirrorHipError("nys_dz_dav: out must be contiguous bf16 buffers shaped like zfT and dw2")
     delta3 = torch.empty(dw2.shape[:-1], device=dw2.device, dtype=torch.float32) if want_delta3 else None
     _lib.call("mh_nys_dz_dav", _p(dw2), _p(av), _p(zfT), _p(up), _p(dav), _p(delta3), BH, m, dh, stream=_stream())
     return (up, dav, delta3) if want_delta3 else (up, dav)
@@ -839,17 +847,27 @@ def nys_sim2_ok(lm: torch.Tensor, heads: int) -> bool:
             and lm.shape[2] == 2 * heads * 64 and os.environ.get("MIRROR_NYS_SIM2", "1") != "0")
 
 
-def nys_sim2(lm: torch.Tensor, heads: int, scale: float, stats: Optional[torch.Tensor] = None, want_z0f: bool = False):
+def nys_sim2_alloc(lm: torch.Tensor, heads: int):
+    """(attn2, xt) buffers of nys_sim2, for a caller that launches it on another stream than the one that owns the memory."""
+    Bn, m, _ = lm.shape
+    return (torch.empty((Bn, heads, m, m), device=lm.device, dtype=torch.float32),
+            torch.empty((Bn, heads, m, m), device=lm.device, dtype=torch.bfloat16))
+
+
+def nys_sim2(lm: torch.Tensor, heads: int, scale: float, stats: Optional[torch.Tensor] = None, want_z0f: bool = False, out=None):
     """(attn2 f32 [B, h, m, m], xt = panel-native bf16 attn2, z0f, stats) in one launch.  z0f (want_z0f) = panel-native f32 attn2^T, the
     unscaled z_0; by default None: the chain forward forms z_0 from the ROWS of attn2 (pinv_chain_fwd(z0f=a2, z0_rowmajor=True)) and the
-    launch skips its second pass."""
+    launch skips its second pass.  out: (attn2, xt) from nys_sim2_alloc."""
     _chk(lm, stats)
     Bn, m, D2 = lm.shape
     D = D2 // 2
     if stats is None:
         stats = torch.zeros(2, device=lm.device, dtype=torch.int64)
-    a2 = torch.empty((Bn, heads, m, m), device=lm.device, dtype=torch.float32)
-    xt = torch.empty((Bn, heads, m, m), device=lm.device, dtype=torch.bfloat16)
+    a2, xt = out if out is not None else nys_sim2_alloc(lm, heads)
+    _chk(a2, xt)
+    if not (a2.shape == xt.shape == (Bn, heads, m, m) and a2.dtype == torch.float32 and xt.dtype == torch.bfloat16
+            and a2.is_contiguous() and xt.is_contiguous()):
+        raise MirrorHipError("nys_sim2: out must be the contiguous (f32, bf16) [B, h, m, m] pair of nys_sim2_alloc")
     z0f = torch.empty((Bn, heads, m, m), device=lm.device, dtype=torch.float32) if want_z0f else None
     _lib.call("mh_nys_sim2", _p(lm), _p(a2), _p(xt), _p(z0f), _p(stats), Bn, m, D, heads, float(scale), stream=_stream())
     return a2, xt, z0f, stats
