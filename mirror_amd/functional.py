@@ -410,9 +410,16 @@ class LinearFn(Function):
             if (zero_rows > 0 and xa.dim() == 3 and od == bf16 and c0 % 256 == 0 and (wa.shape[0] - c0) % 256 == 0
                     and _rows_window_ok(xa, y[..., :c0], zero_rows, R, c0, prec)):
                 ctx.zero_rows = zero_rows
-                y[:, :zero_rows].zero_()          # q = k = v = 0 on the pad rows (they take part in the softmaxes as zero keys)
                 _rows_window(xa, wa[:c0].t(), y[..., :c0], zero_rows, R, mma=prec.mma)
-                _deferred[y.data_ptr()] = lambda: _rows_window(xa, wa[c0:].t(), y[..., c0:], zero_rows, R, mma=prec.mma)
+
+                def later():      # q = k = v = 0 on the pad rows (they take part in the softmaxes as zero keys): nobody reads them before
+                    y[:, :zero_rows].zero_()      # the attention kernels, so the fill waits with the v columns (the fork is 8 us earlier)
+                    _rows_window(xa, wa[c0:].t(), y[..., c0:], zero_rows, R, mma=prec.mma)
+                if _PAD_FILL_LATE:
+                    _deferred[y.data_ptr()] = later
+                else:
+                    y[:, :zero_rows].zero_()
+                    _deferred[y.data_ptr()] = lambda: _rows_window(xa, wa[c0:].t(), y[..., c0:], zero_rows, R, mma=prec.mma)
             else:
                 _gemm_rows(xa, wa[:c0].t(), mma=prec.mma, out_dtype=od, out=y[..., :c0])
                 _deferred[y.data_ptr()] = lambda: _gemm_rows(xa, wa[c0:].t(), mma=prec.mma, out_dtype=od, out=y[..., c0:])
@@ -629,6 +636,7 @@ def _linear_rows_bwd(ctx_needs, x, wa, w, b, r0, R, prec, dy, dx_dtype=None):
     return dx, dw, db
 
 
+_PAD_FILL_LATE = os.environ.get("MIRROR_PAD_FILL_LATE", "1") != "0"   # A/B switch: to_qkv's pad-row fill with the deferred v columns
 _DROP_COLSUM = os.environ.get("MIRROR_DROP_COLSUM", "1") != "0"      # A/B switch
 
 
