@@ -14,7 +14,7 @@
 #endif
 
 // the tail mh_gemm offers to the next fold launch (gemm_kernel.h: GemmTail); host-side state of the calling thread's launch sequence
-static GemmTail g_tail = {nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, 0.f};
+static thread_local GemmTail g_tail = {nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, 0.f};
 GemmTail* gemm_pending_tail() { return &g_tail; }
 
 namespace {

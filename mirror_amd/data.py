@@ -154,8 +154,12 @@ class HostFeeder:
                 pass
             cur = torch.cuda.current_stream(self.device)
             cur.wait_event(sl[5])
-            yield sl[3], sl[4]
-            ev = torch.cuda.Event()
-            ev.record(cur)                         # everything the consumer queued on this batch so far
-            sl[6] = ev
-            self._k = k
+            try:
+                yield sl[3], sl[4]
+            finally:
+                # also when the consumer breaks out of its loop (the generator is closed at the yield): the slot's next
+                # user must wait for everything queued on this batch, and the slot counter must keep running
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+                sl[6] = ev
+                self._k = k

@@ -72,8 +72,8 @@ class TrainEngine:
         self.grad_reduce_dtype = grad_reduce_dtype
         self.model, self.loss_fn = model, loss_fn
         # the fp8 delayed-scaling sites are keyed by weight-shadow addresses: a new engine's shadows may land where a freed
-        # engine's lived, and must not inherit its amax rings
-        Fn._fp8_state["sites"].clear()
+        # engine's lived, and must not inherit its amax rings — each engine owns its site table (installed around its steps)
+        self._fp8_sites: dict = {}
         self.lr, self.betas, self.eps = lr, betas, eps
         self.precision = precision
         self.wsi_mask_ratio, self.rna_mask_ratio = wsi_mask_ratio, rna_mask_ratio
@@ -91,8 +91,10 @@ class TrainEngine:
             clip.process_group = process_group       # gather size / label offset / reduce-scatter follow the gradient group
         # global-batch InfoNCE: the model issues the alignment all-gather itself, right behind the heads (asynchronous, on a
         # communication stream: losses.mirror_loss.prefetch_alignment_gather); the loss only awaits it
-        model._align_gather = ((clip.process_group,) if (clip is not None and getattr(clip, "gather_distributed", False) and self.world > 1
-                                                         and _ASYNC_GATHER) else None)
+        # (armed around the engine's own model calls only: a rank-local forward elsewhere must not issue an unmatched collective)
+        self._align_gather = ((clip.process_group,) if (clip is not None and getattr(clip, "gather_distributed", False) and self.world > 1
+                                                        and _ASYNC_GATHER) else None)
+        model._align_gather = None
         params = [p for p in model.parameters() if p.requires_grad]
         if not params or not params[0].is_cuda:
             raise Fn.K.MirrorHipError("TrainEngine needs the model on an MI355X device (model.to('cuda') first)")
@@ -191,8 +193,9 @@ class TrainEngine:
         through the model outside step() gets them rebuilt on its own stream first (functional.shadow_t calls this)."""
         self._refresh_transposes()
         if self._zero_pending and not torch.cuda.is_current_stream_capturing():
-            self.grad.zero_()                 # an out-of-step backward accumulates into p.grad = arena views: start from zero
-            self._zero_pending = False
+            # an out-of-step backward accumulates into p.grad = arena views: start from zero.  `_zero_pending` stays set — the
+            # next step (and a step captured next) must still clear what that backward leaves behind
+            self.grad.zero_()
 
     def _refresh_transposes(self) -> None:
         self._t_stale = False
@@ -398,6 +401,7 @@ class TrainEngine:
         Fn._res_grads.clear()
         Fn.probe("step_start")
         if POLICIES[self.precision].fp8_fwd:       # delayed fp8 scaling keys its amax rings on the device-side step counter
+            Fn._fp8_state["sites"] = self._fp8_sites
             Fn.fp8_delayed_scaling(self._state[0:1], self.step_count)
         def renorm_prototypes():
             if self._proto is not None:
@@ -427,7 +431,11 @@ class TrainEngine:
                     self._zero_pending = False
                 t_done = side.record_event()
         kw = {} if wsi_key_padding_mask is None else {"wsi_key_padding_mask": wsi_key_padding_mask}
-        outs = self.model(wsi, rna, wsi_mask_ratio=self.wsi_mask_ratio, rna_mask_ratio=self.rna_mask_ratio, noise=noise, **kw)
+        self.model._align_gather = self._align_gather
+        try:
+            outs = self.model(wsi, rna, wsi_mask_ratio=self.wsi_mask_ratio, rna_mask_ratio=self.rna_mask_ratio, noise=noise, **kw)
+        finally:
+            self.model._align_gather = None
         losses = self.loss_fn(*outs)
         if t_done is not None:
             torch.cuda.current_stream().wait_event(t_done)
@@ -521,8 +529,12 @@ class TrainEngine:
                 for i, (wsi, rna) in enumerate(loader):
                     wsi = wsi.to(self.device, non_blocking=True)
                     rna = rna.to(self.device, non_blocking=True)
-                    outs = self.model(wsi, rna, wsi_mask_ratio=self.wsi_mask_ratio, rna_mask_ratio=self.rna_mask_ratio,
-                                      noise=None if noise is None else noise[i])
+                    self.model._align_gather = self._align_gather
+                    try:
+                        outs = self.model(wsi, rna, wsi_mask_ratio=self.wsi_mask_ratio, rna_mask_ratio=self.rna_mask_ratio,
+                                          noise=None if noise is None else noise[i])
+                    finally:
+                        self.model._align_gather = None
                     losses = self.loss_fn(*outs)
                     b = float(wsi.shape[0])
                     acc[:6] += torch.stack([x.detach().reshape(()) for x in losses]).double() * b
@@ -573,6 +585,6 @@ class TrainEngine:
         self._state_lr = float(self.lr)
         self.step_count = int(t)
         self._graph, self._graph_warm = None, 0          # a captured step is still valid, but re-capture keeps this simple
-        Fn._fp8_state["sites"].clear()
+        self._fp8_sites.clear()
         self.sync_shadows()
 

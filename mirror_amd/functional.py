@@ -655,6 +655,7 @@ class ToOutDropAddFn(Function):
         out = torch.empty((Bn, R, N), device=core.device, dtype=f32)
         ctx.p, ctx.seed, ctx.offset, ctx.base = p, _dropout_state["seed"], _lite_offset(), _dropout_state["base"]
         _dropout_state["offset"] = ctx.offset + out.numel()
+        _tap(out.shape, p, ctx.seed, ctx.offset, True)
         M = Bn * R
         tail = K.linear_fused_tail(M)
         bd = None if b is None else b.detach()
@@ -1083,6 +1084,27 @@ def _lite_offset() -> int:
     return (_dropout_state["offset"] + 7) // 8 * 8
 
 
+# Test hook (train-mode parity): while this is a list, every dropout site of a forward pass appends
+# (shape, p, seed, host offset, lite) in launch order; dropout_tap_masks() then regenerates the multipliers the kernels applied
+# (0 or 1 / (1 - p)) so that an oracle run can be handed the very masks of a train-mode step.
+_dropout_tap: Optional[list] = None
+
+
+def _tap(shape, p, seed, offset, lite) -> None:
+    if _dropout_tap is not None:
+        _dropout_tap.append((tuple(shape), float(p), int(seed), int(offset), bool(lite)))
+
+
+def dropout_tap_masks(records, device, base: Optional[torch.Tensor] = None):
+    """The multiplier tensors (f32, 0 or 1 / (1 - p)) of the recorded dropout sites, regenerated by the dropout kernels
+    themselves from (seed, offset [+ the device base the step ran under])."""
+    out = []
+    for shape, p, seed, offset, lite in records:
+        ones = torch.ones(shape, device=device, dtype=f32)
+        out.append(K.dropout_lite(ones, p, seed, offset, base) if lite else K.dropout(ones, p, seed, offset, dev_base=base))
+    return out
+
+
 class DropoutFn(Function):
     """nn.Dropout in training mode; the Philox mask is regenerated in backward from (seed, offset [+ device base])."""
 
@@ -1090,6 +1112,7 @@ class DropoutFn(Function):
     def forward(ctx, x, p):
         ctx.p, ctx.seed, ctx.offset, ctx.base = p, _dropout_state["seed"], _dropout_state["offset"], _dropout_state["base"]
         _dropout_state["offset"] += (x.numel() + 3) // 4 * 4
+        _tap(x.shape, p, ctx.seed, ctx.offset, False)
         return K.dropout(x, p, ctx.seed, ctx.offset, dev_base=ctx.base)
 
     @staticmethod
@@ -1118,9 +1141,11 @@ class DropoutAddFn(Function):
         if ctx.lite:
             ctx.offset = _lite_offset()
             _dropout_state["offset"] = ctx.offset + b.numel()
+            _tap(b.shape, p, ctx.seed, ctx.offset, True)
             return K.dropout_lite(b, p, ctx.seed, ctx.offset, ctx.base, add_to=a)
         ctx.offset = _dropout_state["offset"]
         _dropout_state["offset"] += (b.numel() + 3) // 4 * 4
+        _tap(b.shape, p, ctx.seed, ctx.offset, False)
         return K.dropout_add(a, b, p, ctx.seed, ctx.offset, dev_base=ctx.base)
 
     @staticmethod
@@ -1892,7 +1917,12 @@ class RnaBlockFn(Function):
         ctx.drop = (float(p), st["seed"], st["offset"], st["base"]) if p > 0.0 else (0.0, 0, 0, None)
         if p > 0.0:
             q4 = lambda n: (n + 3) // 4 * 4  # noqa: E731
+            o0 = st["offset"]
             st["offset"] += 2 * q4(B * D) + q4(B * Hh)
+            # the kernels' three sites, in their offset order: proj output, fc1 activation, fc2 output
+            _tap((B, D), p, st["seed"], o0, False)
+            _tap((B, Hh), p, st["seed"], o0 + q4(B * D), False)
+            _tap((B, D), p, st["seed"], o0 + q4(B * D) + q4(B * Hh), False)
         y, saved = K.rna_block_fwd(x, params, H, eps, *ctx.drop)
         ctx.masters, ctx.saved, ctx.cfg = masters, saved, (H, eps, prec)
         ctx.save_for_backward(x)

@@ -66,6 +66,8 @@ class _AllGatherCat(torch.autograd.Function):
         if pre is not None and tuple(pre[0].shape) == (world * x.shape[0],) + tuple(x.shape[1:]):
             out, work, _ = pre
             work.wait()                     # RCCL: the current stream waits for the collective; gloo: the host does
+            if out.is_cuda:
+                out.record_stream(torch.cuda.current_stream())   # allocated on the heads stream, read on this one from here on
             return out
         out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)
         dist.all_gather_into_tensor(out, x, group=group)

@@ -7,9 +7,11 @@ fails loudly when the HIP library is missing.
 This is a *functional* fp32 restatement (plain torch CPU ops on a flat state-dict) of what
 the reference computes on the path `train_mirror.py` -> `models.mirror.MIRROR.forward`
 -> `losses.MIRRORLoss.forward` (+ `losses.InfoNCE`).  Every function cites the reference
-file:line (relative to /root/reference) it follows.  Dropout is not modelled (eval-mode
-numerics); the four random draws of the forward (`models/mirror.py:630`, `:516`,
-`:832-833` twice) are explicit `noise` inputs so that results are reproducible.
+file:line (relative to /root/reference) it follows.  The four random draws of the forward
+(`models/mirror.py:630`, `:516`, `:832-833` twice) are explicit `noise` inputs so that results
+are reproducible.  Dropout is eval-mode (identity) by default; train-mode numerics are
+modelled by handing the keep-multipliers in: `noise["dropout"] = {"wsi": [...], "rna": [...]}`,
+one f32 tensor (0 or 1/(1-p)) per nn.Dropout site in program order (see `_drop`).
 
 PINNING: checked against golden vectors produced by importing the reference itself in the
 build container (`tools/make_golden.py` -> `tests/golden/*.npz`; `tests/test_oracle.py`).
@@ -71,6 +73,16 @@ def _linear(x: Tensor, sd: SD, p: str) -> Tensor:
     return F.linear(x, sd[p + ".weight"], sd.get(p + ".bias"))
 
 
+def _drop(x: Tensor, drop) -> Tensor:
+    """nn.Dropout in train mode with the mask handed in: `drop` is an iterator over keep-multipliers (0 or 1/(1-p), shaped
+    like x) in program order, or None (eval mode: identity)."""
+    if drop is None:
+        return x
+    m = next(drop)
+    assert m.shape == x.shape, (tuple(m.shape), tuple(x.shape))
+    return x * m
+
+
 # ------------------------------------------------------------------- Nystrom attention
 def pinv_iter(x: Tensor, iters: int) -> Tensor:
     """[3P nystrom_attention] moore_penrose_iter_pinv: tensor-wide max in the initial scale."""
@@ -83,7 +95,7 @@ def pinv_iter(x: Tensor, iters: int) -> Tensor:
     return z
 
 
-def nystrom_attention(x: Tensor, sd: SD, p: str, cfg: Cfg, mask: Optional[Tensor] = None) -> Tensor:
+def nystrom_attention(x: Tensor, sd: SD, p: str, cfg: Cfg, mask: Optional[Tensor] = None, drop=None) -> Tensor:
     """[3P] NystromAttention.forward as configured at models/mirror.py:299-309.
 
     dim_head = D//8, heads = 8, landmarks m = D//2, 6 pinv iterations, residual 33-tap
@@ -129,12 +141,14 @@ def nystrom_attention(x: Tensor, sd: SD, p: str, cfg: Cfg, mask: Optional[Tensor
     out = out + F.conv2d(v, sd[p + ".res_conv.weight"], padding=(ks // 2, 0), groups=h)
     out = out.transpose(1, 2).reshape(b, n_p, h * dh)
     out = _linear(out, sd, p + ".to_out.0")
-    return out[:, -n:]
+    # to_out = Sequential(Linear, Dropout(0.1)) (models/mirror.py:308): the package drops on the padded sequence and slices
+    # afterwards; the masks are i.i.d. per element, so a mask drawn for the surviving rows only is the same experiment
+    return _drop(out[:, -n:], drop)
 
 
-def trans_layer(x: Tensor, sd: SD, p: str, cfg: Cfg, mask: Optional[Tensor] = None) -> Tensor:
+def trans_layer(x: Tensor, sd: SD, p: str, cfg: Cfg, mask: Optional[Tensor] = None, drop=None) -> Tensor:
     """TransLayer.forward, models/mirror.py:311-314 (nn.LayerNorm eps 1e-5, :296-298)."""
-    return x + nystrom_attention(_ln(x, sd, p + ".norm", 1e-5), sd, p + ".attn", cfg, mask)
+    return x + nystrom_attention(_ln(x, sd, p + ".norm", 1e-5), sd, p + ".attn", cfg, mask, drop)
 
 
 def ppeg(x: Tensor, sd: SD, p: str, hh: int, ww: int) -> Tensor:
@@ -149,7 +163,7 @@ def ppeg(x: Tensor, sd: SD, p: str, hh: int, ww: int) -> Tensor:
 
 
 # ---------------------------------------------------------------------------- WSI side
-def wsi_forward_encoder(wsi: Tensor, sd: SD, cfg: Cfg, p: str = "wsi_encoder", mask: Optional[Tensor] = None) -> Tensor:
+def wsi_forward_encoder(wsi: Tensor, sd: SD, cfg: Cfg, p: str = "wsi_encoder", mask: Optional[Tensor] = None, drop=None) -> Tensor:
     """FeatureTransMILHybrid.forward_encoder, models/mirror.py:651-679.  `mask` ([B, N] bool, True = real patch) is the
     BASELINE config-4 extension: the reference has no such argument; the sequence [cls, x, x[:add]] carries
     [True, mask, mask[:, :add]] into the package's key-padding `mask` of both Nystrom layers."""
@@ -160,9 +174,9 @@ def wsi_forward_encoder(wsi: Tensor, sd: SD, cfg: Cfg, p: str = "wsi_encoder", m
     h = torch.cat([h, h[:, :add]], dim=1)
     h = torch.cat([sd[p + ".cls_token"].expand(h.shape[0], -1, -1), h], dim=1)
     smask = None if mask is None else torch.cat([torch.ones_like(mask[:, :1]), mask, mask[:, :add]], dim=1)
-    h = trans_layer(h, sd, p + ".layer1", cfg, smask)
+    h = trans_layer(h, sd, p + ".layer1", cfg, smask, drop)
     h = ppeg(h, sd, p + ".pos_layer", side, side)
-    h = trans_layer(h, sd, p + ".layer2", cfg, smask)
+    h = trans_layer(h, sd, p + ".layer2", cfg, smask, drop)
     h = _ln(h, sd, p + ".norm", 1e-5)
     return h[:, : h.shape[1] - add]
 
@@ -174,7 +188,7 @@ def rank_mask(noise: Tensor, len_keep: int) -> Tensor:
 
 
 def wsi_forward_decoders(h: Tensor, sd: SD, cfg: Cfg, ratio: float, noise: Tensor,
-                         p: str = "wsi_encoder", kp_mask: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
+                         p: str = "wsi_encoder", kp_mask: Optional[Tensor] = None, drop=None) -> Tuple[Tensor, Tensor, Tensor]:
     """forward_decoders, models/mirror.py:701-706 (+ :681-699, :624-649)."""
     align = _linear(F.normalize(h, dim=-1, p=2, eps=1e-12)[:, 0], sd, p + ".alignment_head")
     r = _linear(h, sd, p + ".retention_embed")
@@ -184,7 +198,7 @@ def wsi_forward_decoders(h: Tensor, sd: SD, cfg: Cfg, ratio: float, noise: Tenso
     r = torch.cat([r[:, :1], tok], dim=1) + sd[p + ".retention_gene_embed"]
     kp = None if kp_mask is None else torch.cat([torch.ones_like(kp_mask[:, :1]), kp_mask], dim=1)
     for i in range(cfg.wsi_retention_decoder_depth):
-        r = trans_layer(r, sd, f"{p}.retention_blocks.{i}", cfg, kp)
+        r = trans_layer(r, sd, f"{p}.retention_blocks.{i}", cfg, kp, drop)
     r = _linear(_ln(r, sd, p + ".retention_norm", 1e-5), sd, p + ".retention_head")
     return align, r[:, 1:], mask
 
@@ -204,33 +218,35 @@ def rna_attention(x: Tensor, sd: SD, p: str, heads: int) -> Tensor:
     return _linear(o, sd, p + ".proj")
 
 
-def rna_block(x: Tensor, sd: SD, p: str, cfg: Cfg) -> Tensor:
-    """Block.forward, models/mirror.py:149-152 (LayerScale/DropPath are identities)."""
+def rna_block(x: Tensor, sd: SD, p: str, cfg: Cfg, drop=None) -> Tensor:
+    """Block.forward, models/mirror.py:149-152 (LayerScale/DropPath are identities).  Train mode: proj_drop behind the
+    attention's `proj` (:101) and timm Mlp's drop1 (behind the activation) / drop2 (behind fc2), all at rna_proj_drop_rate
+    (:128-129, :142); attn_drop is 0 (:733)."""
     e = cfg.rna_norm_eps
-    x = x + rna_attention(_ln(x, sd, p + ".norm1", e), sd, p + ".attn", cfg.rna_num_heads)
-    y = F.gelu(_linear(_ln(x, sd, p + ".norm2", e), sd, p + ".mlp.fc1"))
-    return x + _linear(y, sd, p + ".mlp.fc2")
+    x = x + _drop(rna_attention(_ln(x, sd, p + ".norm1", e), sd, p + ".attn", cfg.rna_num_heads), drop)
+    y = _drop(F.gelu(_linear(_ln(x, sd, p + ".norm2", e), sd, p + ".mlp.fc1")), drop)
+    return x + _drop(_linear(y, sd, p + ".mlp.fc2"), drop)
 
 
-def rna_forward_encoder(rna: Tensor, sd: SD, cfg: Cfg, p: str = "rna_encoder") -> Tensor:
+def rna_forward_encoder(rna: Tensor, sd: SD, cfg: Cfg, p: str = "rna_encoder", drop=None) -> Tensor:
     """TransFormer.forward, models/mirror.py:283-289; embedding = timm Mlp(G->2D->D, norm=LN(2D))."""
     x = F.gelu(_linear(rna, sd, p + ".embedding.fc1"))
     x = _linear(_ln(x, sd, p + ".embedding.norm", cfg.rna_norm_eps), sd, p + ".embedding.fc2")
     x = x + sd[p + ".gene_embed"]
     for i in range(cfg.rna_encoder_depth):
-        x = rna_block(x, sd, f"{p}.blocks.{i}", cfg)
+        x = rna_block(x, sd, f"{p}.blocks.{i}", cfg, drop)
     return _ln(x, sd, p + ".norm", cfg.rna_norm_eps)
 
 
 def rna_forward_decoders(x: Tensor, sd: SD, cfg: Cfg, ratio: float, noise: Tensor,
-                         p: str = "rna_encoder") -> Tuple[Tensor, Tensor, Tensor]:
+                         p: str = "rna_encoder", drop=None) -> Tuple[Tensor, Tensor, Tensor]:
     """forward_decoders, models/mirror.py:556-561 (+ :538-554, :510-533): channel masking."""
     align = _linear(F.normalize(x, dim=-1, p=2, eps=1e-12), sd, p + ".alignment_head")
     r = _linear(x, sd, p + ".retention_embed")
     mask = rank_mask(noise, int(r.shape[1] * (1 - ratio)))
     r = torch.where(mask > 0, sd[p + ".mask_token"].expand_as(r), r) + sd[p + ".retention_gene_embed"]
     for i in range(cfg.rna_retention_decoder_depth):
-        r = rna_block(r, sd, f"{p}.retention_blocks.{i}", cfg)
+        r = rna_block(r, sd, f"{p}.retention_blocks.{i}", cfg, drop)
     r = _linear(_ln(r, sd, p + ".retention_norm", cfg.rna_norm_eps), sd, p + ".retention_head")
     return align, r, mask
 
@@ -250,10 +266,15 @@ def mirror_forward(sd: SD, cfg: Cfg, wsi: Tensor, rna: Tensor, noise: Dict[str, 
     """MIRROR.forward, models/mirror.py:860-915.  noise keys: wsi_mask [B,N], rna_mask [B,D],
     wsi_eps [B,latent], rna_eps [B,latent] (the draw order of the reference).  `wsi_key_padding_mask` ([B, N] bool): the
     BASELINE config-4 extension (variable-length slides), see wsi_forward_encoder."""
-    w = wsi_forward_encoder(wsi, sd, cfg, mask=wsi_key_padding_mask)
-    w_align, w_ret, w_mask = wsi_forward_decoders(w, sd, cfg, wsi_mask_ratio, noise["wsi_mask"], kp_mask=wsi_key_padding_mask)
-    r = rna_forward_encoder(rna, sd, cfg)
-    r_align, r_ret, r_mask = rna_forward_decoders(r, sd, cfg, rna_mask_ratio, noise["rna_mask"])
+    dm = noise.get("dropout")          # train mode: {"wsi": [2 encoder layers, decoder blocks], "rna": [3 per Block, encoder then decoder]}
+    dw = None if dm is None else iter(dm["wsi"])
+    dr = None if dm is None else iter(dm["rna"])
+    w = wsi_forward_encoder(wsi, sd, cfg, mask=wsi_key_padding_mask, drop=dw)
+    w_align, w_ret, w_mask = wsi_forward_decoders(w, sd, cfg, wsi_mask_ratio, noise["wsi_mask"], kp_mask=wsi_key_padding_mask, drop=dw)
+    r = rna_forward_encoder(rna, sd, cfg, drop=dr)
+    r_align, r_ret, r_mask = rna_forward_decoders(r, sd, cfg, rna_mask_ratio, noise["rna_mask"], drop=dr)
+    if dm is not None:
+        assert next(dw, None) is None and next(dr, None) is None, "unused dropout masks"
     w_score, w_mu, w_ls = style_branch(w[:, 0], sd, noise["wsi_eps"])
     r_score, r_mu, r_ls = style_branch(r, sd, noise["rna_eps"])
     return (w_align, w_ret, w[:, 1:], w_mask, w_score, w_mu, w_ls,

@@ -463,6 +463,40 @@ def test_transposed_shadows_are_current_for_a_backward_outside_the_engine():
     assert checked > 0 and not eng._t_stale
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_a_backward_outside_step_never_leaks_into_the_next_update(graph):
+    """A backward pass between two steps accumulates into the arena views (p.grad).  The engine clears the arena for it
+    (refresh_transposes_now) AND the next step — eager, or the step that is captured next and every replay of it — must
+    still start from zero: step, outside backward, step equals the same steps without the outside backward."""
+    from mirror_amd import functional as Fn
+    from mirror_amd.engine import TrainEngine
+    from mirror_amd.losses import MIRRORLoss
+
+    def run(pollute):
+        torch.manual_seed(21)
+        Fn.manual_seed(22)
+        model = _make(seed=6)
+        eng = TrainEngine(model, MIRRORLoss(), lr=1e-4, precision="bf16", graph=graph, snapshot_grads=True)
+        wsi, rna, noise = _batch(2, 810)
+        wsi = wsi.to(torch.bfloat16)
+        snaps = []
+        for s in range(4):
+            eng.step(wsi, rna)
+            snaps.append(eng.grad_snap.clone())
+            if pollute and s == 1:                    # with graph=True: after the second warm step, before the capture
+                assert eng._zero_pending
+                MIRRORLoss()(*model(wsi, rna, noise=noise))[0].backward()
+                assert float(eng.grad.abs().max()) > 0.0 and eng._zero_pending
+        if graph:
+            assert eng._graph is not None, "the step was not captured"
+        torch.cuda.synchronize()
+        return snaps
+
+    clean, dirty = run(False), run(True)
+    for s, (a, b) in enumerate(zip(clean, dirty)):
+        assert float((a - b).norm()) < 5e-2 * float(a.norm()), (s, float((a - b).norm()), float(a.norm()))
+
+
 def test_force_update_flushes_a_partial_accumulation_window_and_ranks_seed_dropout_differently():
     """(1) train_mirror.py:1128-1131: `need_update = last_batch or (batch_idx + 1) % accum_steps == 0` — the last, partial
     window of an epoch still updates, and the reference divides its tail batches by `last_accum_steps`, the number of batches

@@ -155,3 +155,38 @@ def test_masked_nystrom_restatement_matches_package_standin():
         assert not torch.allclose(got, O.nystrom_attention(x, sd, "attn", cfg, None), atol=1e-3)      # the mask matters
         # (an all-True mask is NOT the unmasked path: with a mask the front-padding rows are masked out of the landmark
         #  means and the three softmaxes, without one they take part as zero rows — the package's quirk, kept)
+
+
+def test_oracle_train_mode_dropout_masks_are_consumed_in_program_order():
+    """noise["dropout"]: unit multipliers reproduce the eval-mode run exactly; real masks change the result; the RNA Block's
+    three sites equal torch's own nn.Dropout arithmetic (x * keep / (1 - p)) when applied by hand (models/mirror.py:101, :142)."""
+    from oracle import synth
+    cfg = O.Cfg(wsi_embed_dim=16, rna_embed_dim=12, embed_dim=32, wsi_num_tokens=20, rna_encoder_depth=2, rna_num_heads=8,
+                style_mlp_hidden_dim=16, style_mlp_out_dim=8, style_latent_dim=4, num_prototypes=9)
+    sd = synth.synth_state_dict(synth.param_shapes(cfg), seed=3)
+    wsi, rna, noise = synth.synth_batch(cfg, batch=2, seed=4)
+    base = O.mirror_forward(sd, cfg, wsi, rna, noise)
+    B, D, Hh = 2, 32, sd["rna_encoder.blocks.0.mlp.fc1.weight"].shape[0]
+    n = 20 + 1 + (25 - 20)
+    shapes_w = [(B, n, D), (B, n, D), (B, 21, D)]
+    shapes_r = [(B, D), (B, Hh), (B, D)] * 3
+    ones = {"wsi": [torch.ones(s) for s in shapes_w], "rna": [torch.ones(s) for s in shapes_r]}
+    same = O.mirror_forward(sd, cfg, wsi, rna, dict(noise, dropout=ones))
+    for a, b in zip(base, same):
+        assert torch.equal(a, b)
+    g = torch.Generator().manual_seed(5)
+    keep = lambda s: (torch.rand(s, generator=g) >= 0.1).float() / 0.9      # noqa: E731
+    masks = {"wsi": [keep(s) for s in shapes_w], "rna": [keep(s) for s in shapes_r]}
+    drop = O.mirror_forward(sd, cfg, wsi, rna, dict(noise, dropout=masks))
+    assert not torch.allclose(drop[1], base[1], atol=1e-4) and not torch.allclose(drop[8], base[8], atol=1e-4)
+    # one Block by hand
+    x = torch.randn(B, D, generator=g)
+    p = "rna_encoder.blocks.0"
+    m3 = masks["rna"][:3]
+    got = O.rna_block(x, sd, p, cfg, iter(m3))
+    h = x + O.rna_attention(O._ln(x, sd, p + ".norm1", 1e-6), sd, p + ".attn", 8) * m3[0]
+    y = torch.nn.functional.gelu(O._linear(O._ln(h, sd, p + ".norm2", 1e-6), sd, p + ".mlp.fc1")) * m3[1]
+    want = h + O._linear(y, sd, p + ".mlp.fc2") * m3[2]
+    assert torch.allclose(got, want, atol=1e-6)
+    with pytest.raises(AssertionError):                                       # a mask too many is an error, not silently ignored
+        O.mirror_forward(sd, cfg, wsi, rna, dict(noise, dropout={"wsi": masks["wsi"] + [torch.ones(1)], "rna": masks["rna"]}))
