@@ -122,6 +122,10 @@ typedef struct {
                                      (`F.pad(x, (0, 0, padding, 0))`, called at models/mirror.py:312): to_qkv of the pad rows is zero (no
                                      bias), so only the B x n real rows are multiplied, as one flat problem from and into the padded buffers
                                      (its data gradient likewise) */
+    int32_t window_batches;       /* > 0: the row windows above cover `window_batches` batches only; flat rows past them follow the last
+                                     window without a gap (row r lives at r + min(r / rows_per_batch, window_batches - 1) * row_skip).
+                                     The landmark rows of a Nystrom layer sit behind the padded sequences of all slides in to_qkv's
+                                     operand / result buffers and are multiplied by the same launch.  0: every flat row is window row */
 } mh_gemm_desc;
 int mh_gemm(const mh_gemm_desc* d, mh_stream s);
 /* Tuning switch for A/B timing in one process: which main loop the 256 x 256-tile launches use (2 = persistent direct-to-LDS
@@ -187,14 +191,15 @@ int mh_layernorm_bwd(const void* dy, const void* x, const float* gamma, const fl
  * front padding and `q_landmarks = reduce(q, '... (n l) d -> ... n d', 'sum') / l`): x f32 [batches, >= rows, D] (x_bs elements per
  * batch) -> y bf16 [batches, pad + rows, D] (pad zero rows first, written here) and xpm f32 [batches, (pad + rows) / l, D] =
  * the mean of each group of l consecutive rows of y.  to_qkv is linear and bias-free, so the landmarks are to_qkv(xpm)[:, :2D].
- * mh_layernorm_bwd_lm: mh_layernorm_bwd whose dy rows also receive gadd[b, (i + pad) / l] / l (gadd f32 = d loss / d xpm). */
+ * mh_layernorm_bwd_lm: mh_layernorm_bwd whose dy rows also receive gadd[b, (i + pad) / l] / l (gadd, in dy's dtype, = d loss / d xpm).
+ * xpm (f32) may be NULL when only the bf16 means are wanted (they are the landmark rows behind the sequence in to_qkv's operand). */
 int mh_layernorm_fwd_lm(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, void* xpm,
                         void* xpm_bf16, int batches, int rows, int D, int64_t x_bs, int pad, int l, float eps, mh_stream s);
                         /* xpm_bf16 (optional): the bf16 rounding of xpm, the B operand of the landmark projection's weight gradient */
 int mh_layernorm_bwd_lm(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                         void* dx, float* dgamma, float* dbeta, int batches, int rows_per_batch, int D, int64_t x_bs, int64_t y_bs,
                         int dt_x, int dt_dy, int dt_dx, int accumulate_dx, float* workspace, int64_t ws_floats,
-                        const float* gadd, int pad, int l, mh_stream s);
+                        const void* gadd, int pad, int l, mh_stream s);
 
 /* ---------------------------------------------------------------- fp8 forward projections (BASELINE config 5)
  * mh_quant_fp8: q[i] = e4m3(x[i] * 448 / max|x|) for a whole tensor (x f32 / bf16, n % 4 == 0), scale[0] = max|x| / 448
@@ -281,7 +286,7 @@ int mh_pinv_chain_fwd(const void* XP, void* saved, void* zfT, int BH, int m, int
  * column abs sums as mh_pinv_absmax leaves them (caller zeroes stats64).  Replaces mh_gemm + mh_softmax_fwd + mh_pinv_absmax +
  * mh_pinv_chain_prep on the fused path. */
 int mh_nys_sim2(const void* lm, float* a2, void* xp, float* z0f, uint64_t* stats64, int B, int m, int D, int heads, float scale,
-                mh_stream s);
+                int64_t lm_ld, mh_stream s);      /* lm_ld: row stride of lm in elements; 0 = contiguous [B, m, 2D] (see mh_nys_attn1_fwd) */
 /* The two small products that open NystromAttention's backward around the chain, one launch (m = 256, dh = 64; dw2, av f32
  * [BH, m, dh], zfT bf16 [BH, m, m] = the chain's column-major output): up = PN((dw2 av^T)^T) bf16, the input of mh_pinv_chain_bwd
  * (what mh_gemm + mh_pinv_chain_pack produce), dav = Z^T dw2 bf16 [BH, m, dh].  delta3 (f32 [BH, m], may be NULL) receives
@@ -308,8 +313,11 @@ int64_t mh_pinv_chain_workspace_bytes(int BH, int m, int iters, int which);
 /* mrow [B, n_p] / mlm [B, m] (f32 0 / 1, both or neither): the package's key-padding mask — valid sequence rows and landmark
  * groups that contain a valid row.  A logit whose row or landmark is invalid is masked_fill'ed before the softmax (a fully
  * masked row comes out uniform, as in the package) and gets no gradient.  NULL: no mask. */
+/* lm_ld (all mh_nys_attn*): row stride of `lm` in elements, 0 = 2 D (a contiguous [B, m, 2D]).  3 D when the landmarks are rows of
+ * to_qkv's output buffer behind the sequence (landmarks = to_qkv(group means): [3P] landmarks are means over l consecutive
+ * positions of q and k, and to_qkv is linear and bias-free); batch b's landmarks start at lm + b * m * lm_ld. */
 int mh_nys_attn1_fwd(const void* qkv, const void* lm, const void* w2, void* out, float* lse1, const float* mrow, const float* mlm,
-                     int B, int h, int n_p, int m, int dh, float scale, int accumulate, mh_stream s);
+                     int B, int h, int n_p, int m, int dh, float scale, int accumulate, int64_t lm_ld, mh_stream s);
 /* unmasked mh_nys_attn1_fwd that also writes the e4m3 copy q8 [B, n_p, D] bytes of `out` (delayed scaling: ring / tick / margin as
  * in mh_quant_fp8_delayed, q8_scale[0] = dequantisation factor): the fp8 forward of [3P] to_out needs no quantisation pass */
 int mh_nys_attn1_fwd_q8(const void* qkv, const void* lm, const void* w2, void* out, float* lse1, int B, int h, int n_p, int m, int dh,
@@ -319,14 +327,18 @@ int mh_nys_attn1_fwd_q8(const void* qkv, const void* lm, const void* w2, void* o
 int64_t mh_nys_attn3_ws_floats(int B, int h, int n_p);
 int64_t mh_nys_attn3_workspace_bytes(int B, int h, int n_p);         /* the same in bytes */
 int mh_nys_attn3_fwd(const void* qkv, const void* lm, float* av, float* lse3, float* workspace, int64_t ws_floats,
-                     const float* mrow, const float* mlm, int B, int h, int n_p, int m, int dh, float scale, mh_stream s);
+                     const float* mrow, const float* mlm, int B, int h, int n_p, int m, int dh, float scale, int64_t lm_ld, mh_stream s);
 int mh_nys_attn1_bwd(const void* qkv, const void* lm, const void* w2, const void* dout, const float* lse1, float* delta1,
                      void* dqkv, float* dw2, float* dlm, const float* mrow, const float* mlm, int B, int h, int n_p, int m, int dh,
-                     float scale, mh_stream s);
+                     float scale, int64_t lm_ld, mh_stream s);
 /* av == NULL: delta3 already holds sum_d dav av (mh_nys_dz_dav wrote it); otherwise it is scratch this call fills first */
 int mh_nys_attn3_bwd(const void* qkv, const void* lm, const float* av, const void* dav, const float* lse3, float* delta3,
                      void* dqkv, float* dlm, const float* mrow, const float* mlm, int B, int h, int n_p, int m, int dh, float scale,
-                     mh_stream s);
+                     int64_t lm_ld, mh_stream s);
+/* out[r, 0:cols] = bf16(a[r] + b[r]) (f32 [rows, cols], b may be NULL) at row stride out_ld, out[r, cols:cols + zero_cols] = 0: the
+ * landmark gradient (q_l | k_l halves from the attention kernels + sim2's products) written as rows [dq_l | dk_l | 0] of to_qkv's
+ * output gradient, where its data / weight gradient products pick it up together with the sequence rows. */
+int mh_lm_merge(const float* a, const float* b, void* out, int64_t rows, int cols, int64_t out_ld, int zero_cols, mh_stream s);
 /* T = d*I - P  (batched [BH,m,m] f32) */
 int mh_eye_minus(const float* P, float* T, float d, int BH, int m, mh_stream s);
 

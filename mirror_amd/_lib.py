@@ -52,6 +52,7 @@ class GemmDesc(C.Structure):
         ("epi", C.POINTER(GemmEpi)), ("a_rows_per_batch", C.c_int32), ("a_row_skip", C.c_int32),
         ("shared_chip", C.c_int32),
         ("c_rows_per_batch", C.c_int32), ("c_row_skip", C.c_int32),
+        ("window_batches", C.c_int32),
     ]
 
 
@@ -117,14 +118,14 @@ _SIGS = {
     "mh_pinv_chain_prep": [P, P, P, P, P, I, I],
     "mh_pinv_chain_pack": [P, P, I, I],
     "mh_pinv_chain_fwd": [P, P, P, I, I, I, P, P, I],
-    "mh_nys_sim2": [P, P, P, P, P, I, I, I, I, F],
+    "mh_nys_sim2": [P, P, P, P, P, I, I, I, I, F, L],
     "mh_nys_dz_dav": [P, P, P, P, P, P, I, I, I],
     "mh_pinv_chain_bwd": [P, P, P, P, P, P, I, I, I],
-    "mh_nys_attn1_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, F, I],
+    "mh_nys_attn1_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, F, I, L],
     "mh_nys_attn1_fwd_q8": [P, P, P, P, P, I, I, I, I, I, F, I, P, P, P, F, P],
-    "mh_nys_attn3_fwd": [P, P, P, P, P, L, P, P, I, I, I, I, I, F],
-    "mh_nys_attn1_bwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F],
-    "mh_nys_attn3_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F],
+    "mh_nys_attn3_fwd": [P, P, P, P, P, L, P, P, I, I, I, I, I, F, L],
+    "mh_nys_attn1_bwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, L],
+    "mh_nys_attn3_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, L],
     "mh_seq_finish": [P, P, I, I, I, I, I],
     "mh_seq_finish_bwd": [P, P, I, I, I, I, I],
     "mh_ppeg_merge": [P, P, P, P, P, P, P, P, I],
@@ -137,6 +138,7 @@ _SIGS = {
     "mh_headattn_fwd": [P, P, P, I, I, I, I],
     "mh_headattn_bwd": [P, P, P, P, I, I, I, I],
     "mh_add": [P, P, P, L, I, I, I],
+    "mh_lm_merge": [P, P, P, L, I, L, I],
     "mh_cast": [P, P, L, I, I],
     "mh_gelu_fwd": [P, P, L, I, I],
     "mh_gelu_bwd": [P, P, P, L, I, I, I],

@@ -73,6 +73,34 @@ extern "C" int mh_add(const void* a, const void* b, void* y, int64_t n, int dt_a
     return MH_OK;
 }
 
+// The landmark gradient of a Nystrom layer written where to_qkv's backward reads it: out[r, 0:cols] = a[r] + b[r] (f32 partial sums of
+// the attention kernels and of sim2's products, b may be NULL) rounded to bf16 at row stride out_ld, and out[r, cols:cols + zero_cols] = 0
+// (the v columns of the landmark rows that sit behind the sequence in the [rows, 3D] gradient buffer: landmarks have no v).
+__global__ __launch_bounds__(256) void lm_merge_kernel(const float* __restrict__ a, const float* __restrict__ b, bf16_t* __restrict__ out, long rows,
+                                                       int cols4, int tot4, long out_ld) {
+    EW4_LOOP(q, rows * tot4) {
+        const long r = q / tot4;
+        const int c = (int)(q - r * tot4);
+        f4_t v = {0.f, 0.f, 0.f, 0.f};
+        if (c < cols4) {
+            v = ld4(a + (r * cols4 + c) * 4);
+            if (b) v += ld4(b + (r * cols4 + c) * 4);
+        }
+        st4(out + r * out_ld + 4 * c, v);
+    }
+}
+
+extern "C" int mh_lm_merge(const float* a, const float* b, void* out, int64_t rows, int cols, int64_t out_ld, int zero_cols, mh_stream s) {
+    MH_REQUIRE(a && out && rows >= 0 && cols > 0 && cols % 4 == 0 && zero_cols >= 0 && zero_cols % 4 == 0 && out_ld >= cols + zero_cols && out_ld % 4 == 0,
+               "mh_lm_merge: cols, zero_cols, out_ld must be multiples of 4 with out_ld >= cols + zero_cols");
+    MH_REQUIRE(mh_quad_ok(a, 4) && (!b || mh_quad_ok(b, 4)) && mh_quad_ok(out, 2), "mh_lm_merge: unaligned buffer");
+    if (rows == 0) return MH_OK;
+    const int tot4 = (cols + zero_cols) / 4;
+    hipLaunchKernelGGL(lm_merge_kernel, EW_GRID(rows * tot4), dim3(256), 0, (hipStream_t)s, a, b, (bf16_t*)out, (long)rows, cols / 4, tot4, (long)out_ld);
+    MH_LAUNCH_CHECK("mh_lm_merge");
+    return MH_OK;
+}
+
 extern "C" int mh_cast(const void* x, void* y, int64_t n, int dt_x, int dt_y, mh_stream s) {
     if (n == 0) return MH_OK;
     if (n % 4 == 0 && mh_quad_ok(x, mh_dt_size(dt_x)) && mh_quad_ok(y, mh_dt_size(dt_y))) {

@@ -22,6 +22,7 @@ static int launch_one(const mh_gemm_desc* d, hipStream_t s) {
     a.row_softmax = d->row_softmax;
     a.shared_chip = d->shared_chip;
     a.c_rpb = 0; a.c_skip = 0;
+    a.w_last = d->window_batches > 0 ? d->window_batches - 1 : (1 << 30);
     const int BK = d->mma == MH_BF16 ? 64 : 16;
     const int kps = mh_cdiv(mh_cdiv(d->K, split), BK) * BK;
     a.k_per_split = kps;

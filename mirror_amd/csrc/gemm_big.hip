@@ -44,7 +44,7 @@ __device__ __forceinline__ f32x4 epi_quad(const GemmArgs& g, f32x4 x, int grow, 
 
 // accumulators -> f32 LDS tile [128][260] (one half of the rows at a time) -> 16-byte row-contiguous stores
 // physical row of C for flat result row r (GemmArgs.c_rpb / c_skip: row windows of larger batches, see mh_gemm_desc.c_rows_per_batch)
-__device__ __forceinline__ long c_phys_row(const GemmArgs& g, int r) { return g.c_rpb > 0 ? (long)r + (long)(r / g.c_rpb) * g.c_skip : (long)r; }
+__device__ __forceinline__ long c_phys_row(const GemmArgs& g, int r) { return g.c_rpb > 0 ? (long)r + (long)min(r / g.c_rpb, g.w_last) * g.c_skip : (long)r; }
 
 template <typename TC, int MODE, int EPI = 0>
 __device__ __forceinline__ void epilogue_big(const GemmArgs& g, TC* C, f32x16 (&acc)[BWM][BWN], char* smem, int tile_row0,
@@ -335,9 +335,9 @@ __global__ __launch_bounds__(NTB) void gemm_big_kernel(GemmArgs g) {
     int adj0 = 0, bnd = 1 << 30;
     if constexpr (AKC) {
         if (g.a_rpb > 0) {
-            const int b0 = (tile_m * BIG) / g.a_rpb;
+            const int b0 = min((tile_m * BIG) / g.a_rpb, g.w_last);
             adj0 = b0 * g.a_skip;
-            bnd = (b0 + 1) * g.a_rpb - tile_m * BIG;
+            bnd = b0 < g.w_last ? (b0 + 1) * g.a_rpb - tile_m * BIG : (1 << 30);
         }
     }
 #define LOAD_A_(K0_)                                                                                         \
@@ -581,9 +581,9 @@ __global__ __launch_bounds__(NTB) void gemm_pp_kernel(GemmArgs g) {
     int adj0 = 0, bnd = 1 << 30;
     if constexpr (AKC) {
         if (g.a_rpb > 0) {
-            const int bq = (tile_m * BIG) / g.a_rpb;
+            const int bq = min((tile_m * BIG) / g.a_rpb, g.w_last);
             adj0 = bq * g.a_skip;
-            bnd = (bq + 1) * g.a_rpb - tile_m * BIG;
+            bnd = bq < g.w_last ? (bq + 1) * g.a_rpb - tile_m * BIG : (1 << 30);
         }
     }
     PPStage<AKC> sa;
@@ -991,9 +991,9 @@ __global__ __launch_bounds__(NTB) void gemm_pq_kernel(GemmArgs g, int units, int
         int adj0 = 0, bnd = 1 << 30;
         if constexpr (AKC) {
             if (g.a_rpb > 0) {
-                const int bq = (tm * BIG) / g.a_rpb;
+                const int bq = min((tm * BIG) / g.a_rpb, g.w_last);
                 adj0 = bq * g.a_skip;
-                bnd = (bq + 1) * g.a_rpb - tm * BIG;
+                bnd = bq < g.w_last ? (bq + 1) * g.a_rpb - tm * BIG : (1 << 30);
             }
         }
         pa.init(A, g.lda, tm * BIG, g.M, kbeg, wave, lane, adj0, bnd, g.a_skip);

@@ -55,6 +55,7 @@ struct GemmArgs {
     int a_rpb, a_skip;            // row-window remap of A (gemm_big.hip, K-contiguous A): flat row r -> r + (r / a_rpb) * a_skip
     int shared_chip;              // mh_gemm_desc.shared_chip: no persistent kernel
     int c_rpb, c_skip;            // row-window remap of C (gemm_big.hip, bf16 C): flat row r -> r + (r / c_rpb) * c_skip
+    int w_last;                   // index of the last row window (mh_gemm_desc.window_batches - 1; 1 << 30: unlimited): rows past it follow it
 };
 
 template <int MMA, bool KC, int ROWS>

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_lm_kernel(const float* __re
     for (int k = 0; k < LNV_CH; k++) {
         const int c = 256 * k + 4 * lane;
         if (c < D) {
-            st4(xpm + ((long)b * m + g) * D + c, acc[k] * inv);
+            if (xpm) st4(xpm + ((long)b * m + g) * D + c, acc[k] * inv);
             if (xpm16) st4(xpm16 + ((long)b * m + g) * D + c, acc[k] * inv);      // what a bf16 MFMA operand load of xpm rounds to
         }
     }
@@ -498,9 +498,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_ws_kernel(const TDY* __rest
                                                                const float* __restrict__ rstd, TX* __restrict__ dx,
                                                                float* __restrict__ ws, int rows, int rpb, int D, long x_bs,
                                                                long y_bs, int acc_dx, int rows_per_block,
-                                                               const float* __restrict__ gadd = nullptr, int ga_pad = 0, int ga_l = 1,
+                                                               const TDY* __restrict__ gadd = nullptr, int ga_pad = 0, int ga_l = 1,
                                                                int ga_m = 0, float ga_scale = 0.f) {
-    // gadd [batches, ga_m, D] f32: dy of row i of batch b is dy + ga_scale * gadd[b, (i + ga_pad) / ga_l] (the gradient of the
+    // gadd [batches, ga_m, D] in dy's dtype: dy of row i of batch b is dy + ga_scale * gadd[b, (i + ga_pad) / ga_l] (the gradient of the
     // landmark means mh_layernorm_fwd_lm produced beside the rows)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f4 pg[LNV_CH], pb[LNV_CH], gm[LNV_CH];
@@ -617,7 +617,7 @@ extern "C" int64_t mh_layernorm_bwd_workspace_bytes(int64_t rows, int D) {
 static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                        void* dx, float* dgamma, float* dbeta, int batches, int rpb, int D, int64_t x_bs,
                        int64_t y_bs, int dt_x, int dt_dy, int dt_dx, int acc_dx, float* workspace, int64_t ws_floats,
-                       const float* gadd, int ga_pad, int ga_l, mh_stream s);
+                       const void* gadd, int ga_pad, int ga_l, mh_stream s);
 
 extern "C" int mh_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                 void* dx, float* dgamma, float* dbeta, int batches, int rpb, int D, int64_t x_bs,
@@ -628,11 +628,11 @@ extern "C" int mh_layernorm_bwd(const void* dy, const void* x, const float* gamm
 }
 
 // the backward of mh_layernorm_fwd_lm: dy of row i of batch b is dy[b, i] + gadd[b, (i + pad) / l] / l, gadd [batches, (pad + rpb) / l, D]
-// f32 = the gradient of the landmark means (needs the workspace form: D % 4 == 0, aligned buffers, a workspace)
+// in dy's dtype = the gradient of the landmark means (needs the workspace form: D % 4 == 0, aligned buffers, a workspace)
 extern "C" int mh_layernorm_bwd_lm(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                    void* dx, float* dgamma, float* dbeta, int batches, int rpb, int D, int64_t x_bs,
                                    int64_t y_bs, int dt_x, int dt_dy, int dt_dx, int acc_dx, float* workspace, int64_t ws_floats,
-                                   const float* gadd, int pad, int l, mh_stream s) {
+                                   const void* gadd, int pad, int l, mh_stream s) {
     MH_REQUIRE(gadd && l >= 1 && pad >= 0 && (pad + rpb) % l == 0 && ((uintptr_t)gadd & 15) == 0, "mh_layernorm_bwd_lm: gadd, l >= 1, (pad + rows) %% l == 0");
     return ln_bwd_impl(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, batches, rpb, D, x_bs, y_bs, dt_x, dt_dy, dt_dx, acc_dx, workspace,
                        ws_floats, gadd, pad, l, s);
@@ -641,7 +641,7 @@ extern "C" int mh_layernorm_bwd_lm(const void* dy, const void* x, const float* g
 static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                        void* dx, float* dgamma, float* dbeta, int batches, int rpb, int D, int64_t x_bs,
                        int64_t y_bs, int dt_x, int dt_dy, int dt_dx, int acc_dx, float* workspace, int64_t ws_floats,
-                       const float* gadd, int ga_pad, int ga_l, mh_stream s) {
+                       const void* gadd, int ga_pad, int ga_l, mh_stream s) {
     MH_REQUIRE(D >= 1 && D <= 64 * LN_MAXPL, "mh_layernorm_bwd: D=%d unsupported", D);
     MH_REQUIRE(dt_dx == dt_x, "mh_layernorm_bwd: dx dtype must equal x dtype");
     const long rows = (long)batches * rpb;
@@ -659,7 +659,7 @@ static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const 
         const int rows_per_block = (int)(mh_cdiv(mh_cdiv(rows, nb), 8) * 8);
         nb = mh_cdiv(rows, rows_per_block);
         dim3 g2((unsigned)nb);
-#define LN_BW1(TX, TDY, NC) hipLaunchKernelGGL((layernorm_bwd_ws_kernel<TX, TDY, NC>), g2, dim3(256), 0, (hipStream_t)s, (const TDY*)dy, (const TX*)x, gamma, mean, rstd, (TX*)dx, workspace, (int)rows, rpb, D, (long)x_bs, (long)y_bs, acc_dx, rows_per_block, gadd, ga_pad, ga_l, (ga_pad + rpb) / ga_l, 1.f / (float)ga_l)
+#define LN_BW1(TX, TDY, NC) hipLaunchKernelGGL((layernorm_bwd_ws_kernel<TX, TDY, NC>), g2, dim3(256), 0, (hipStream_t)s, (const TDY*)dy, (const TX*)x, gamma, mean, rstd, (TX*)dx, workspace, (int)rows, rpb, D, (long)x_bs, (long)y_bs, acc_dx, rows_per_block, (const TDY*)gadd, ga_pad, ga_l, (ga_pad + rpb) / ga_l, 1.f / (float)ga_l)
 #define LN_BW(TX, TDY) do { if (D <= 512) LN_BW1(TX, TDY, 2); else if (D <= 1024) LN_BW1(TX, TDY, 4); else LN_BW1(TX, TDY, 8); } while (0)
         if (dt_x == MH_F32 && dt_dy == MH_F32) LN_BW(float, float);
         else if (dt_x == MH_F32 && dt_dy == MH_BF16) LN_BW(float, bf16_t);

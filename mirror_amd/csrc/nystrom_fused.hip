@@ -185,6 +185,8 @@ struct Geo {
     const float* mrow;      // key-padding mask rows [B, n_p] (NULL: no mask)
     const float* mlm;       // valid landmarks [B, m]
     int accumulate;     // attn1 forward: add to `out` (the res_conv term is already there) instead of overwriting it
+    long lm_ld;         // row stride of `lm` in elements (2 D for a contiguous [B, m, 2D]; 3 D when the landmark rows live behind the
+                        // sequence in the to_qkv output buffer); batch b's landmarks start at lm + b * m * lm_ld
 };
 
 // ============================================================================ attn1 forward (N kernel)
@@ -201,6 +203,7 @@ __global__ __launch_bounds__(NT) void nys_a1_fwd_kernel(const bf16_t* __restrict
     __shared__ __attribute__((aligned(16))) float s_mlm_[NM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hl = lane >> 5;
     const int bh = blockIdx.y, b = bh / g.h, hd = bh % g.h, D = g.D;
+    const long LD = g.lm_ld;
     float q8mul = 1.f, q8max = 0.f;
     int q8cur = 0;
     if constexpr (Q8) {
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(NT) void nys_a1_fwd_kernel(const bf16_t* __restrict
             q8.ring[(t + 1) % 3] = 0u;
         }
     }
-    stage_rows<NM>(s_kl_, lm + (long)b * NM * 2 * D + D + hd * ND, 2 * D, tid);
+    stage_rows<NM>(s_kl_, lm + (long)b * NM * LD + D + hd * ND, LD, tid);
     stage_rows<NM>(s_w2_, w2 + (long)bh * NM * ND, ND, tid);
     constexpr bool masked = MASKED;
     s_mlm_[tid] = masked ? g.mlm[(long)b * NM + tid] : 1.f;
@@ -346,7 +349,8 @@ __global__ __launch_bounds__(NT, 2) void nys_a1_bwd_dq_kernel(const bf16_t* __re
     __shared__ __attribute__((aligned(16))) float s_mlm_[NM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hl = lane >> 5;
     const int bh = blockIdx.y, b = bh / g.h, hd = bh % g.h, D = g.D;
-    stage_rows<NM>(s_kl_, lm + (long)b * NM * 2 * D + D + hd * ND, 2 * D, tid);
+    const long LD = g.lm_ld;
+    stage_rows<NM>(s_kl_, lm + (long)b * NM * LD + D + hd * ND, LD, tid);
     stage_rows<NM>(s_w2_, w2 + (long)bh * NM * ND, ND, tid);
     constexpr bool masked = MASKED;
     s_mlm_[tid] = masked ? g.mlm[(long)b * NM + tid] : 1.f;
@@ -458,13 +462,14 @@ __global__ __launch_bounds__(NT) void nys_a1_bwd_dw_kernel(const bf16_t* __restr
     __shared__ __attribute__((aligned(16))) float s_mr[TR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hl = lane >> 5;
     const int bh = blockIdx.y, b = bh / g.h, hd = bh % g.h, D = g.D;
+    const long LD = g.lm_ld;
     const int ntiles = g.n_p / TR;
     const int t0 = blockIdx.x * tiles_per_wg, t1 = min(t0 + tiles_per_wg, ntiles);
     if (t0 >= t1) return;
     constexpr bool masked = MASKED;
     float ml[2] = {1.f, 1.f};
     if (masked) { ml[0] = g.mlm[(long)b * NM + 64 * wave + c]; ml[1] = g.mlm[(long)b * NM + 64 * wave + 32 + c]; }
-    const bf16_t* klb = lm + (long)b * NM * 2 * D + D + hd * ND;
+    const bf16_t* klb = lm + (long)b * NM * LD + D + hd * ND;
     const bf16_t* w2b = w2 + (long)bh * NM * ND;
     bf16x8 klf[2][4], w2f[2][4];
 #pragma unroll
@@ -472,7 +477,7 @@ __global__ __launch_bounds__(NT) void nys_a1_bwd_dw_kernel(const bf16_t* __restr
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) {
             const int l = 64 * wave + 32 * j + c;
-            klf[j][ks] = frag_g(klb + (long)l * 2 * D, 16 * ks, lane);
+            klf[j][ks] = frag_g(klb + (long)l * LD, 16 * ks, lane);
             w2f[j][ks] = frag_g(w2b + (long)l * ND, 16 * ks, lane);
         }
     const bf16_t* qb = qkv + (long)b * g.n_p * 3 * D + hd * ND;
@@ -571,16 +576,17 @@ __global__ __launch_bounds__(NT, 2) void nys_a3_fwd_kernel(const bf16_t* __restr
     __shared__ __attribute__((aligned(16))) float s_mr[TR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hl = lane >> 5;
     const int bh = blockIdx.y, b = bh / g.h, hd = bh % g.h, D = g.D;
+    const long LD = g.lm_ld;
     const int t0 = blockIdx.x * tiles_per_wg, t1 = min(t0 + tiles_per_wg, g.n_p / TR);
     constexpr bool masked = MASKED;
     float ml[2] = {1.f, 1.f};
     if (masked) { ml[0] = g.mlm[(long)b * NM + 64 * wave + c]; ml[1] = g.mlm[(long)b * NM + 64 * wave + 32 + c]; }
-    const bf16_t* qlb = lm + (long)b * NM * 2 * D + hd * ND;
+    const bf16_t* qlb = lm + (long)b * NM * LD + hd * ND;
     bf16x8 qlf[2][4];
 #pragma unroll
     for (int j = 0; j < 2; j++)
 #pragma unroll
-        for (int ks = 0; ks < 4; ks++) qlf[j][ks] = frag_g(qlb + (long)(64 * wave + 32 * j + c) * 2 * D, 16 * ks, lane);
+        for (int ks = 0; ks < 4; ks++) qlf[j][ks] = frag_g(qlb + (long)(64 * wave + 32 * j + c) * LD, 16 * ks, lane);
     const bf16_t* kb = qkv + (long)b * g.n_p * 3 * D + D + hd * ND;
     const bf16_t* vb = kb + D;
     float mrun[2] = {NEG_BIG, NEG_BIG}, lrun[2] = {0.f, 0.f};
@@ -728,7 +734,8 @@ __global__ __launch_bounds__(NT, 2) void nys_a3_bwd_dkv_kernel(const bf16_t* __r
     __shared__ __attribute__((aligned(16))) float s_mlm_[NM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hl = lane >> 5;
     const int bh = blockIdx.y, b = bh / g.h, hd = bh % g.h, D = g.D;
-    stage_rows<NM>(s_ql_, lm + (long)b * NM * 2 * D + hd * ND, 2 * D, tid);
+    const long LD = g.lm_ld;
+    stage_rows<NM>(s_ql_, lm + (long)b * NM * LD + hd * ND, LD, tid);
     stage_rows<NM>(s_g_, dav + (long)bh * NM * ND, ND, tid);
     s_del_[tid] = delta3[(long)bh * NM + tid] * g.scale;       // thread = landmark
     s_lse_[tid] = lse3[(long)bh * NM + tid] * LOG2E;
@@ -822,13 +829,14 @@ __global__ __launch_bounds__(NT) void nys_a3_bwd_dql_kernel(const bf16_t* __rest
     __shared__ __attribute__((aligned(16))) float s_mr[TR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hl = lane >> 5;
     const int bh = blockIdx.y, b = bh / g.h, hd = bh % g.h, D = g.D;
+    const long LD = g.lm_ld;
     const int ntiles = g.n_p / TR;
     const int t0 = blockIdx.x * tiles_per_wg, t1 = min(t0 + tiles_per_wg, ntiles);
     if (t0 >= t1) return;
     constexpr bool masked = MASKED;
     float ml[2] = {1.f, 1.f};
     if (masked) { ml[0] = g.mlm[(long)b * NM + 64 * wave + c]; ml[1] = g.mlm[(long)b * NM + 64 * wave + 32 + c]; }
-    const bf16_t* qlb = lm + (long)b * NM * 2 * D + hd * ND;
+    const bf16_t* qlb = lm + (long)b * NM * LD + hd * ND;
     bf16x8 qlf[2][4], gf[2][4];
     float lsev[2], delv[2];
 #pragma unroll
@@ -837,7 +845,7 @@ __global__ __launch_bounds__(NT) void nys_a3_bwd_dql_kernel(const bf16_t* __rest
         const bf16_t* gr = dav + ((long)bh * NM + lq) * ND;
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) {
-            qlf[j][ks] = frag_g(qlb + (long)lq * 2 * D, 16 * ks, lane);
+            qlf[j][ks] = frag_g(qlb + (long)lq * LD, 16 * ks, lane);
             gf[j][ks] = frag_g(gr, 16 * ks, lane);
         }
         delv[j] = delta3[(long)bh * NM + lq] * g.scale;
@@ -933,11 +941,12 @@ int check_geo(const char* fn, int B, int h, int n_p, int m, int dh) {
 }  // namespace
 
 extern "C" int mh_nys_attn1_fwd(const void* qkv, const void* lm, const void* w2, void* out, float* lse1, const float* mrow,
-                                const float* mlm, int B, int h, int n_p, int m, int dh, float scale, int accumulate, mh_stream s) {
+                                const float* mlm, int B, int h, int n_p, int m, int dh, float scale, int accumulate, int64_t lm_ld, mh_stream s) {
     if (int e = check_geo("mh_nys_attn1_fwd", B, h, n_p, m, dh)) return e;
+    MH_REQUIRE(lm_ld == 0 || (lm_ld >= 2L * h * ND && lm_ld % 8 == 0), "mh_nys_attn1_fwd: lm_ld must be 0 or a multiple of 8 >= 2 D");
     if (B == 0) return MH_OK;
     MH_REQUIRE((mrow == nullptr) == (mlm == nullptr), "mh_nys_attn1_fwd: mrow and mlm go together");
-    const Geo g{h, n_p, h * ND, scale, scale * LOG2E, mrow, mlm, accumulate};
+    const Geo g{h, n_p, h * ND, scale, scale * LOG2E, mrow, mlm, accumulate, lm_ld > 0 ? lm_ld : 2L * h * ND};
     NYS_LAUNCH(nys_a1_fwd_kernel, dim3(pick_walkers(B * h, n_p), B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv, (const bf16_t*)lm,
                        (const bf16_t*)w2, (bf16_t*)out, lse1, g, Q8Out{});
     MH_LAUNCH_CHECK("mh_nys_attn1_fwd");
@@ -950,7 +959,7 @@ extern "C" int mh_nys_attn1_fwd_q8(const void* qkv, const void* lm, const void* 
     if (int e = check_geo("mh_nys_attn1_fwd_q8", B, h, n_p, m, dh)) return e;
     if (B == 0) return MH_OK;
     MH_REQUIRE(q8 && ring && tick && q8_scale && margin >= 1.f && ((uintptr_t)q8 & 3) == 0, "mh_nys_attn1_fwd_q8: q8, ring, tick, scale and margin >= 1");
-    const Geo g{h, n_p, h * ND, scale, scale * LOG2E, nullptr, nullptr, accumulate};
+    const Geo g{h, n_p, h * ND, scale, scale * LOG2E, nullptr, nullptr, accumulate, 2L * h * ND};
     const Q8Out o{(unsigned char*)q8, ring, tick, margin, q8_scale};
     hipLaunchKernelGGL((nys_a1_fwd_kernel<false, true>), dim3(pick_walkers(B * h, n_p), B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv,
                        (const bf16_t*)lm, (const bf16_t*)w2, (bf16_t*)out, lse1, g, o);
@@ -969,10 +978,11 @@ extern "C" int64_t mh_nys_attn3_ws_floats(int B, int h, int n_p) {
 extern "C" int64_t mh_nys_attn3_workspace_bytes(int B, int h, int n_p) { return 4 * mh_nys_attn3_ws_floats(B, h, n_p); }
 
 extern "C" int mh_nys_attn3_fwd(const void* qkv, const void* lm, float* av, float* lse3, float* workspace, int64_t ws_floats,
-                                const float* mrow, const float* mlm, int B, int h, int n_p, int m, int dh, float scale, mh_stream s) {
+                                const float* mrow, const float* mlm, int B, int h, int n_p, int m, int dh, float scale, int64_t lm_ld, mh_stream s) {
     if (int e = check_geo("mh_nys_attn3_fwd", B, h, n_p, m, dh)) return e;
+    MH_REQUIRE(lm_ld == 0 || (lm_ld >= 2L * h * ND && lm_ld % 8 == 0), "mh_nys_attn3_fwd: lm_ld must be 0 or a multiple of 8 >= 2 D");
     if (B == 0) return MH_OK;
-    const Geo g{h, n_p, h * ND, scale, scale * LOG2E, mrow, mlm, 0};
+    const Geo g{h, n_p, h * ND, scale, scale * LOG2E, mrow, mlm, 0, lm_ld > 0 ? lm_ld : 2L * h * ND};
     const int ntiles = n_p / TR;
     int splits = pick_splits(B * h, ntiles, 0);
     if (!workspace || ws_floats < (int64_t)B * h * splits * A3_PART) splits = 1;      // no room for partials: one workgroup per (b, h)
@@ -1009,10 +1019,11 @@ int pick_splits(int BH, int ntiles, int which) {
 
 extern "C" int mh_nys_attn1_bwd(const void* qkv, const void* lm, const void* w2, const void* dout, const float* lse1,
                                 float* delta1, void* dqkv, float* dw2, float* dlm, const float* mrow, const float* mlm, int B, int h,
-                                int n_p, int m, int dh, float scale, mh_stream s) {
+                                int n_p, int m, int dh, float scale, int64_t lm_ld, mh_stream s) {
     if (int e = check_geo("mh_nys_attn1_bwd", B, h, n_p, m, dh)) return e;
+    MH_REQUIRE(lm_ld == 0 || (lm_ld >= 2L * h * ND && lm_ld % 8 == 0), "mh_nys_attn1_bwd: lm_ld must be 0 or a multiple of 8 >= 2 D");
     if (B == 0) return MH_OK;
-    const Geo g{h, n_p, h * ND, scale, scale * LOG2E, mrow, mlm, 0};
+    const Geo g{h, n_p, h * ND, scale, scale * LOG2E, mrow, mlm, 0, lm_ld > 0 ? lm_ld : 2L * h * ND};
     NYS_LAUNCH(nys_a1_bwd_dq_kernel, dim3(pick_walkers(B * h, n_p), B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv,
                        (const bf16_t*)lm, (const bf16_t*)w2, (const bf16_t*)dout, lse1, delta1, (bf16_t*)dqkv, g);
     MH_LAUNCH_CHECK("mh_nys_attn1_bwd(dq)");
@@ -1025,10 +1036,11 @@ extern "C" int mh_nys_attn1_bwd(const void* qkv, const void* lm, const void* w2,
 
 extern "C" int mh_nys_attn3_bwd(const void* qkv, const void* lm, const float* av, const void* dav, const float* lse3, float* delta3,
                                 void* dqkv, float* dlm, const float* mrow, const float* mlm, int B, int h, int n_p, int m, int dh,
-                                float scale, mh_stream s) {
+                                float scale, int64_t lm_ld, mh_stream s) {
     if (int e = check_geo("mh_nys_attn3_bwd", B, h, n_p, m, dh)) return e;
+    MH_REQUIRE(lm_ld == 0 || (lm_ld >= 2L * h * ND && lm_ld % 8 == 0), "mh_nys_attn3_bwd: lm_ld must be 0 or a multiple of 8 >= 2 D");
     if (B == 0) return MH_OK;
-    const Geo g{h, n_p, h * ND, scale, scale * LOG2E, mrow, mlm, 0};
+    const Geo g{h, n_p, h * ND, scale, scale * LOG2E, mrow, mlm, 0, lm_ld > 0 ? lm_ld : 2L * h * ND};
     if (av) hipLaunchKernelGGL(nys_delta3_kernel, dim3(B * h), dim3(NM), 0, (hipStream_t)s, av, (const bf16_t*)dav, delta3);
     NYS_LAUNCH(nys_a3_bwd_dkv_kernel, dim3(pick_walkers(B * h, n_p), B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv,
                        (const bf16_t*)lm, (const float*)delta3, (const bf16_t*)dav, lse3, (bf16_t*)dqkv, g);

@@ -55,7 +55,7 @@ __device__ __forceinline__ u32x4 pack8(const f32x16& a, int t) {
     return o;
 }
 
-__global__ __launch_bounds__(256) void nys_sim2_kernel(const bf16_t* __restrict__ lm, int D, int heads, float sl2, float* __restrict__ a2,
+__global__ __launch_bounds__(256) void nys_sim2_kernel(const bf16_t* __restrict__ lm, long ld, int D, int heads, float sl2, float* __restrict__ a2,
                                                        bf16_t* __restrict__ xp, float* __restrict__ z0f, unsigned long long* __restrict__ stats) {
     __shared__ float s_max[SM], s_inv[SM];
     __shared__ float s_col[4][SM];
@@ -63,11 +63,6 @@ __global__ __launch_bounds__(256) void nys_sim2_kernel(const bf16_t* __restrict_
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hl = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bh = blockIdx.x, b = bh / heads, h = bh % heads;
-    // Two workgroups per (b, h): the kernel is bound by its stores (640 KiB per (b, h), one workgroup per CU on half of the chip:
-    // ~60 us for 108 MB).  Both compute the whole of pass 1 (the column sums need every row) but each STORES one of every wave's two
-    // row blocks and computes + stores that half of pass 2; half 0 publishes the maxima.
-    const int half = blockIdx.y;
-    const long ld = 2L * D;
     const bf16_t* ql = lm + (long)b * SM * ld + h * SDH;
     const bf16_t* kl = ql + D;
     if (tid < 2) s_best[tid] = 0ull;
@@ -145,7 +140,6 @@ __global__ __launch_bounds__(256) void nys_sim2_kernel(const bf16_t* __restrict_
     for (int rb = 0; rb < 2; rb++)
 #pragma unroll
         for (int cb = 0; cb < 8; cb++) {
-            if (gridDim.y == 2 && rb != half) continue;          // the other workgroup of this (b, h) stores that row block
             if (SIM2_EXP == 4) continue;
 #pragma unroll
             for (int reg = 0; reg < 16; reg++) {
@@ -187,7 +181,6 @@ __global__ __launch_bounds__(256) void nys_sim2_kernel(const bf16_t* __restrict_
         const float mxi = s_max[32 * cb + r], ivi = s_inv[32 * cb + r];      // statistics of attn2's row i = this lane's column
 #pragma unroll
         for (int rb = 0; rb < 2; rb++) {
-            if (gridDim.y == 2 && rb != half) continue;
             f32x16 c;
 #pragma unroll
             for (int e = 0; e < 16; e++) c[e] = 0.f;
@@ -204,7 +197,7 @@ __global__ __launch_bounds__(256) void nys_sim2_kernel(const bf16_t* __restrict_
         }
     }
     __syncthreads();
-    if (tid < 2 && half == 0) atomicMax(stats + tid, s_best[tid]);
+    if (tid < 2) atomicMax(stats + tid, s_best[tid]);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -314,14 +307,14 @@ __global__ __launch_bounds__(256) void nys_dz_dav_kernel(const float* __restrict
 }  // namespace
 
 extern "C" int mh_nys_sim2(const void* lm, float* a2, void* xp, float* z0f, uint64_t* stats64, int B, int m, int D, int heads, float scale,
-                           mh_stream s) {
+                           int64_t lm_ld, mh_stream s) {
+    MH_REQUIRE(lm_ld == 0 || (lm_ld >= 2L * D && lm_ld % 8 == 0), "mh_nys_sim2: lm_ld must be 0 (contiguous [B, m, 2D]) or a multiple of 8 >= 2 D");
     MH_REQUIRE(m == SM && heads >= 1 && D == heads * SDH, "mh_nys_sim2: built for m = %d landmarks and dh = %d (m=%d, D=%d, heads=%d)", SM, SDH, m, D, heads);
     MH_REQUIRE(lm && a2 && xp && stats64 && (((uintptr_t)lm | (uintptr_t)a2 | (uintptr_t)xp | (uintptr_t)z0f) & 15) == 0,
                "mh_nys_sim2: null / unaligned buffer");
     MH_REQUIRE((long)B * heads * m < (1L << 31), "mh_nys_sim2: index overflow");
     if (B == 0) return MH_OK;
-    static const int split = [] { const char* e = getenv("MH_SIM2_SPLIT"); return (e && e[0] == '1') ? 2 : 1; }();      // A/B switch: two workgroups per (b, h), each storing half (measured: same 60 us kernel, same step)
-    hipLaunchKernelGGL(nys_sim2_kernel, dim3(B * heads, split), dim3(256), 0, (hipStream_t)s, (const bf16_t*)lm, D, heads, scale * 1.4426950408889634f,
+    hipLaunchKernelGGL(nys_sim2_kernel, dim3(B * heads, 1), dim3(256), 0, (hipStream_t)s, (const bf16_t*)lm, lm_ld > 0 ? (long)lm_ld : 2L * D, D, heads, scale * 1.4426950408889634f,
                        a2, (bf16_t*)xp, z0f, (unsigned long long*)stats64);
     MH_LAUNCH_CHECK("mh_nys_sim2");
     return MH_OK;

@@ -290,6 +290,18 @@ def _rows_window(a3, b2, out3, r0, R, *, mma, wt=None):
         _tail_rows(a3[Bn - 1, r0 + R - tail:r0 + R], b2, out3[Bn - 1, r0 + R - tail:r0 + R], mma=mma, wt=wt)
 
 
+def _rows_scatter(dy, b2, dx, r0, R, *, mma, wt=None):
+    """dx[:, r0:r0 + R] = dy @ b2 for a CONTIGUOUS dy [B, R, N] and a padded dx [B, T, K] (the data gradient of Nystrom's
+    `to_out(out)[:, -n:]`): one flat problem over the B * R rows whose results are scattered into the row windows
+    (mh_gemm_desc.c_rows_per_batch) — as a batched product every slide pays its own tile rounds (484 vs 790 TF/s)."""
+    Bn = dy.shape[0]
+    M = Bn * R
+    tail = M % 256
+    K.gemm_rows_window(dy, b2, dx, r0, R, m_rows=M - tail, a_r0=0)
+    if tail:
+        _tail_rows(dy[Bn - 1, R - tail:R], b2, dx[Bn - 1, r0 + R - tail:r0 + R], mma=mma, wt=wt)
+
+
 def _rows_window_ok(a3, out3, r0, R, N, prec) -> bool:
     return (_PAD_SKIP and r0 > 0 and prec.mma == MH_BF16 and prec.act == bf16 and not prec.fp8_fwd and (a3.shape[0] * R) % 256 <= 32
             and K.gemm_rows_window_ok(a3, out3, r0, R, N))
@@ -390,11 +402,8 @@ class LinearFn(Function):
     W: [N, K] f32 master.  Replaces nn.Linear (+ nn.ReLU for _fc1, models/mirror.py:346)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, act, prec, out_dtype, defer_from=None, zero_rows=0):
-        """zero_rows = p > 0 (3-D x, no bias): the first p rows of every batch of x are zero rows ([3P] NystromAttention's front padding
-        behind LayerNormLmFn); their outputs are zero and are not computed, and the data gradient does not write those rows."""
+    def forward(ctx, x, w, b, act, prec, out_dtype, defer_from=None):
         wa = shadow(w, prec)
-        ctx.zero_rows = 0
         # [B, D] activations: weight-streaming kernels, which take an f32 operand as it is (rounded to bf16 on load: no cast launch)
         ctx.skinny = prec.act == bf16 and _SKINNY_F32 and x.dtype == f32 and K.skinny_ok(x, wa)
         xa = x if (x.dtype == prec.act or ctx.skinny) else K.cast(x.contiguous(), prec.act)
@@ -406,23 +415,8 @@ class LinearFn(Function):
             # to_qkv: the q | k columns now, the v columns when NystromCoreFn asks for them (under the pinv chain)
             y = torch.empty(tuple(xa.shape[:-1]) + (wa.shape[0],), device=xa.device, dtype=out_dtype or prec.act)
             c0, od = defer_from, out_dtype or prec.act
-            R = xa.shape[1] - zero_rows if xa.dim() == 3 else 0
-            if (zero_rows > 0 and xa.dim() == 3 and od == bf16 and c0 % 256 == 0 and (wa.shape[0] - c0) % 256 == 0
-                    and _rows_window_ok(xa, y[..., :c0], zero_rows, R, c0, prec)):
-                ctx.zero_rows = zero_rows
-                _rows_window(xa, wa[:c0].t(), y[..., :c0], zero_rows, R, mma=prec.mma)
-
-                def later():      # q = k = v = 0 on the pad rows (they take part in the softmaxes as zero keys): nobody reads them before
-                    y[:, :zero_rows].zero_()      # the attention kernels, so the fill waits with the v columns (the fork is 8 us earlier)
-                    _rows_window(xa, wa[c0:].t(), y[..., c0:], zero_rows, R, mma=prec.mma)
-                if _PAD_FILL_LATE:
-                    _deferred[y.data_ptr()] = later
-                else:
-                    y[:, :zero_rows].zero_()
-                    _deferred[y.data_ptr()] = lambda: _rows_window(xa, wa[c0:].t(), y[..., c0:], zero_rows, R, mma=prec.mma)
-            else:
-                _gemm_rows(xa, wa[:c0].t(), mma=prec.mma, out_dtype=od, out=y[..., :c0])
-                _deferred[y.data_ptr()] = lambda: _gemm_rows(xa, wa[c0:].t(), mma=prec.mma, out_dtype=od, out=y[..., c0:])
+            _gemm_rows(xa, wa[:c0].t(), mma=prec.mma, out_dtype=od, out=y[..., :c0])
+            _deferred[y.data_ptr()] = lambda: _gemm_rows(xa, wa[c0:].t(), mma=prec.mma, out_dtype=od, out=y[..., c0:])
         if ctx.skinny:
             y = K.skinny_fwd(xa, wa, bd, act, out_dtype or prec.act)
         elif prec.fp8_fwd:
@@ -459,10 +453,6 @@ class LinearFn(Function):
                     dx32 = zeros((rows, Kd), dy.device)
                     K.gemm(dy, wa, out=dx32, accumulate=True, split_k=max(2, min(32, N // 128)), mma=prec.mma)
                     dx = dx32 if ctx.x_dtype == f32 else K.cast(dx32, ctx.x_dtype)
-                elif ctx.zero_rows and dy.dim() == 3 and ctx.x_dtype == bf16 and _rows_window_ok(dy, xa, ctx.zero_rows, dy.shape[1] - ctx.zero_rows, Kd, prec):
-                    # the pad rows of dx are left unwritten: the LayerNorm backward that consumes dx reads the real rows only
-                    dx = torch.empty(xa.shape, device=dy.device, dtype=bf16)
-                    _rows_window(dy, wa, dx, ctx.zero_rows, dy.shape[1] - ctx.zero_rows, mma=prec.mma, wt=shadow_t(w, prec))
                 else:
                     dx = _gemm_rows(dy, wa, mma=prec.mma, out_dtype=ctx.x_dtype, wt=_wt_of(w, prec, dy))
         want_db = ctx.has_b and ctx.needs_input_grad[2]
@@ -477,7 +467,7 @@ class LinearFn(Function):
                 if _wgrad_queue is not None and sunk and (dbuf is None or sunk_b) and dy.dim() == 2:
                     # engine step: every [B, D]-row weight gradient of the backward goes into ONE launch at its end (flush_skinny_wgrads)
                     _wgrad_queue.append((dy, xa, dw, dbuf, w, b if fused_db else None, torch.cuda.current_stream()))
-                    return dx, None, None, None, None, None, None, None
+                    return dx, None, None, None, None, None, None
                 K.skinny_wgrad(dy, xa, dw, accumulate=True, db=dbuf)
                 if fused_db:
                     db = _gret(b, dbuf, sunk_b)
@@ -488,7 +478,7 @@ class LinearFn(Function):
             db, sunk = _gbuf(b, (N,))
             K.colsum(dy.reshape(-1, N), db)
             db = _gret(b, db, sunk)
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
 # deferred weight gradients of the skinny linears: a list while an engine step's backward runs (TrainEngine sets it), else None
@@ -548,11 +538,10 @@ def _wgrad(dy: torch.Tensor, x: torch.Tensor, N: int, Kd: int, prec: Precision, 
     return dw
 
 
-def linear(x, w, b=None, *, act=ACT_NONE, prec: Precision, out_dtype=None, defer_from=None, zero_rows=0):
+def linear(x, w, b=None, *, act=ACT_NONE, prec: Precision, out_dtype=None, defer_from=None):
     """defer_from = c: only output columns [0, c) are computed here; the rest is a pending launch that the consumer runs
-    with run_deferred(y) (NystromCoreFn does, right after it has forked the pinv chain).
-    zero_rows = p: the first p rows of every batch of x are known to be zero (front padding): see LinearFn.forward."""
-    return LinearFn.apply(x, w, b, act, prec, out_dtype, defer_from, zero_rows)
+    with run_deferred(y) (NystromCoreFn does, right after it has forked the pinv chain)."""
+    return LinearFn.apply(x, w, b, act, prec, out_dtype, defer_from)
 
 
 _DEFER_V = os.environ.get("MIRROR_DEFER_V", "1") != "0"       # A/B switch
@@ -624,7 +613,10 @@ def _linear_rows_bwd(ctx_needs, x, wa, w, b, r0, R, prec, dy, dx_dtype=None):
             dx[:, :r0].zero_()
         if r0 + R < x.shape[1]:
             dx[:, r0 + R:].zero_()
-        _gemm_window(dy, wa, dx[:, r0:r0 + R], mma=prec.mma, wt=_wt_of(w, prec, dy))
+        if dy.dim() == 3 and dy.is_contiguous() and dx.dtype == bf16 and dy.shape[1] == R and (dy.shape[0] * R) % 256 <= R and _rows_window_ok(dy, dx, r0, R, Kd, prec):
+            _rows_scatter(dy, wa, dx, r0, R, mma=prec.mma, wt=_wt_of(w, prec, dy))
+        else:
+            _gemm_window(dy, wa, dx[:, r0:r0 + R], mma=prec.mma, wt=_wt_of(w, prec, dy))
     if ctx_needs[1]:
         dw, sunk = _gbuf(w, (N, Kd))
         _wgrad(dy, x[:, r0:r0 + R], N, Kd, prec, dw)
@@ -636,7 +628,6 @@ def _linear_rows_bwd(ctx_needs, x, wa, w, b, r0, R, prec, dy, dx_dtype=None):
     return dx, dw, db
 
 
-_PAD_FILL_LATE = os.environ.get("MIRROR_PAD_FILL_LATE", "1") != "0"   # A/B switch: to_qkv's pad-row fill with the deferred v columns
 _DROP_COLSUM = os.environ.get("MIRROR_DROP_COLSUM", "1") != "0"      # A/B switch
 
 
@@ -881,100 +872,132 @@ class LayerNormFn(Function):
         return dx, _gret(gamma, dg, sunk_g), _gret(beta, db, sunk_b), None, None, None, None, None, None
 
 
-_LM_BF16 = os.environ.get("MIRROR_LM_BF16", "1") != "0"      # A/B switch
-_xpm16: dict = {}      # data_ptr of the landmark means a LayerNormLmFn just produced -> their bf16 rounding (taken by LandmarkProjFn)
+def _alias(base: torch.Tensor, offset: int, size, stride) -> torch.Tensor:
+    """A tensor on `base`'s storage (offset in elements from base's first element) that autograd does NOT track as a view of it:
+    the two row ranges of one buffer handed out as separate Function outputs / gradients are written by raw kernels and by
+    in-place fills, which autograd forbids on the views of a multi-output node."""
+    t = torch.empty(0, device=base.device, dtype=base.dtype)
+    t.set_(base.untyped_storage(), base.storage_offset() + int(offset), tuple(size), tuple(stride))
+    return t
 
 
-class LayerNormLmFn(Function):
-    """LayerNormFn for a Nystrom layer that also returns the landmark means of its output (mh_layernorm_fwd_lm): (xp bf16
-    [B, pad + rows, D] behind `pad` zero rows, xpm f32 [B, m, D] = the mean of each group of l consecutive rows of xp).
-    [3P] NystromAttention's landmarks are means over l consecutive positions of q and k; to_qkv is linear and bias-free, so they
-    are to_qkv(xpm)[:, :2D] (LandmarkProjFn) — no pass over the q | k columns, and in the backward the landmark gradient reaches
-    the rows through THIS node (mh_layernorm_bwd_lm) instead of a read-modify-write of dqkv."""
+class NormQkvLmFn(Function):
+    """LayerNorm + to_qkv of a Nystrom layer with the landmarks as EXTRA ROWS of the same products (models/mirror.py:298, :312; [3P]
+    NystromAttention: front padding, to_qkv, `q_landmarks = reduce(q, '... (n l) d -> ... n d', 'sum') / l`).
+
+    The landmarks are means over l consecutive positions of q and k, and to_qkv is linear and bias-free: they are to_qkv(xpm)[:, :2D]
+    for xpm = the group means of the LayerNorm output.  mh_layernorm_fwd_lm writes those means (bf16) right BEHIND the padded
+    sequence, so the operand of to_qkv is one [B n_p + B m, D] buffer and the landmarks come out as the last B m rows of its
+    [B n_p + B m, 3D] result — no projection launch of their own, no pass over the q | k columns.  The backward is symmetric:
+    NystromCoreFn returns d qkv and d lm as the two row ranges of ONE gradient buffer ([dq_l | dk_l | 0] rows), so the data gradient
+    (whose last rows are d xpm, added to the rows' gradient by mh_layernorm_bwd_lm) and the weight gradient (one contraction over
+    all B n_p + B m rows) need no landmark launches either.  Returns (qkv [B, n_p, 3D], lm [B, m, 2D] with row stride 3D).
+    The v columns of the sequence rows are a deferred launch (run_deferred(qkv), under the pinv chain); the pad rows are skipped
+    by the flat row-window kernels (K.gemm_rows_ext) when the geometry allows, else every physical row is multiplied."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, rows, pad, l):
+    def forward(ctx, x, gamma, beta, eps, rows, pad, l, w, prec):
         x = x.contiguous()
         Bn, T, D = x.shape
         n_p = pad + rows
-        y = torch.empty((Bn, n_p, D), device=x.device, dtype=bf16)
-        xpm = torch.empty((Bn, n_p // l, D), device=x.device, dtype=f32)      # f32: its gradient arrives in f32, no cast launches
+        m = n_p // l
+        P, E = Bn * n_p, Bn * m
+        wa = shadow(w, prec)
+        N3, c0 = wa.shape[0], 2 * wa.shape[1]
+        xe = torch.empty((P + E, D), device=x.device, dtype=bf16)
         mean = torch.empty((Bn * rows,), device=x.device, dtype=f32)
         rstd = torch.empty_like(mean)
-        xpm16 = torch.empty_like(xpm, dtype=bf16) if (_LM_BF16 and any(ctx.needs_input_grad)) else None     # (grad mode is off in here)
-        K.layernorm_fwd_lm(x, gamma.detach(), beta.detach(), y, mean, rstd, xpm, Bn, rows, D, T * D, pad, l, eps, xpm_bf16=xpm16)
-        if xpm16 is not None:
-            _xpm16.clear()
-            _xpm16[xpm.data_ptr()] = xpm16      # LandmarkProjFn's weight gradient takes bf16 operands (the tiled split-K kernel)
-        ctx.save_for_backward(x, gamma, mean, rstd, beta)
-        ctx.rows, ctx.pad, ctx.l = rows, pad, l
-        return y, xpm
+        xs = xe[:P].view(Bn, n_p, D)
+        K.layernorm_fwd_lm(x, gamma.detach(), beta.detach(), xs, mean, rstd, None, Bn, rows, D, T * D, pad, l, eps, xpm_bf16=xe[P:])
+        qe = torch.empty((P + E, N3), device=x.device, dtype=bf16)
+        qkv = _alias(qe, 0, (Bn, n_p, N3), (n_p * N3, N3, 1))
+        fast = (pad > 0 and prec.mma == MH_BF16 and c0 % 256 == 0 and (N3 - c0) % 256 == 0
+                and K.gemm_rows_ext_ok(Bn, n_p, pad, rows, E, D, c0, xe, qe[:, :c0]) and _rows_window_ok(xs, qkv[..., c0:], pad, rows, N3 - c0, prec))
+        if fast:
+            tail = K.gemm_rows_ext(xe, wa[:c0].t(), qe[:, :c0], Bn, n_p, pad, rows, E)
+            if tail:
+                _tail_rows(xe[P + E - tail:], wa[:c0].t(), qe[P + E - tail:, :c0], mma=prec.mma)
+
+            def later():      # q = k = v = 0 on the pad rows (they take part in the softmaxes as zero keys): nobody reads them before
+                qkv[:, :pad].zero_()      # the attention kernels, so the fill waits with the v columns (the fork is 8 us earlier)
+                _rows_window(xs, wa[c0:].t(), qkv[..., c0:], pad, rows, mma=prec.mma)
+        else:
+            K.gemm(xe, wa[:c0].t(), out=qe[:, :c0], mma=prec.mma)      # zero pad rows in, zero rows out
+
+            def later():
+                K.gemm(xe[:P], wa[c0:].t(), out=qe[:P, c0:], mma=prec.mma)
+        _deferred[qkv.data_ptr()] = later
+        ctx.save_for_backward(x, gamma, mean, rstd, beta, xe, wa, w)
+        ctx.geo = (rows, pad, l, fast, prec)
+        return qkv, _alias(qe, P * N3, (Bn, m, c0), (m * N3, N3, 1))
 
     @staticmethod
-    def backward(ctx, dy, dxpm):
-        x, gamma, mean, rstd, beta = ctx.saved_tensors
+    def backward(ctx, dqkv, dlm):
+        x, gamma, mean, rstd, beta, xe, wa, w = ctx.saved_tensors
+        rows, pad, l, fast, prec = ctx.geo
         Bn, T, D = x.shape
-        rows, pad, l = ctx.rows, ctx.pad, ctx.l
-        if not dy.is_contiguous():
-            dy = dy.contiguous()
-        if dxpm is not None:
-            dxpm = dxpm.contiguous()
-            if dxpm.dtype != f32:
-                dxpm = K.cast(dxpm, f32)
+        n_p = pad + rows
+        m = n_p // l
+        P, E = Bn * n_p, Bn * m
+        N3, c0 = wa.shape[0], 2 * wa.shape[1]
+        de = ext_rows_of(dqkv, dlm, P, E, N3, c0)
+        dxe = torch.empty((P + E, D), device=x.device, dtype=bf16)
+        # data gradient: the pad rows of dxe stay unwritten on the flat path (the LayerNorm backward reads the real rows only)
+        if fast:
+            tail = K.gemm_rows_ext(de, wa, dxe, Bn, n_p, pad, rows, E)
+            if tail:
+                _tail_rows(de[P + E - tail:], wa, dxe[P + E - tail:], mma=prec.mma, wt=shadow_t(w, prec))
+        else:
+            K.gemm(de, wa, out=dxe, mma=prec.mma)
+        dw = None
+        if ctx.needs_input_grad[7]:
+            # one contraction over every physical row: the pad rows of xe are zero, the landmark rows carry [dq_l | dk_l | 0]
+            dwb, sunk = _gbuf(w, (N3, D))
+            _wgrad(de, xe, N3, D, prec, dwb)
+            dw = _gret(w, dwb, sunk)
         dg, sunk_g = _gbuf(gamma, (D,))
         db, sunk_b = _gbuf(beta, (D,))
+        dy = dxe[:P].view(Bn, n_p, D)
+        gadd = dxe[P:].view(Bn, m, D)
         G = _res_grads.pop(x.data_ptr(), None)
         if G is not None and G.numel() == x.numel() and G.dtype == x.dtype and G.is_contiguous():
-            K.layernorm_bwd(dy[:, pad:], x, gamma.detach(), mean, rstd, G.view(x.shape), dg, db, Bn, rows, D, T * D, (pad + rows) * D,
-                            accumulate_dx=True, gadd=dxpm, pad=pad, l=l)
-            return None, _gret(gamma, dg, sunk_g), _gret(beta, db, sunk_b), None, None, None, None
-        dx = torch.zeros_like(x) if rows < T else torch.empty_like(x)
-        K.layernorm_bwd(dy[:, pad:], x, gamma.detach(), mean, rstd, dx, dg, db, Bn, rows, D, T * D, (pad + rows) * D, gadd=dxpm, pad=pad, l=l)
-        return dx, _gret(gamma, dg, sunk_g), _gret(beta, db, sunk_b), None, None, None, None
+            K.layernorm_bwd(dy[:, pad:], x, gamma.detach(), mean, rstd, G.view(x.shape), dg, db, Bn, rows, D, T * D, n_p * D,
+                            accumulate_dx=True, gadd=gadd, pad=pad, l=l)
+            dx = None
+        else:
+            dx = torch.zeros_like(x) if rows < T else torch.empty_like(x)
+            K.layernorm_bwd(dy[:, pad:], x, gamma.detach(), mean, rstd, dx, dg, db, Bn, rows, D, T * D, n_p * D, gadd=gadd, pad=pad, l=l)
+        return dx, _gret(gamma, dg, sunk_g), _gret(beta, db, sunk_b), None, None, None, None, dw, None
 
 
-class LandmarkProjFn(Function):
-    """lm [B, m, 2D] = xpm @ W[:2D]^T: the q | k landmarks of [3P] NystromAttention from the landmark means of the LayerNorm output
-    (LayerNormLmFn); W is to_qkv.weight [3D, D] (rows 0..2D-1 = the q and k projections).  A [B m, D] x [D, 2D] product."""
-
-    @staticmethod
-    def forward(ctx, xpm, w, prec):
-        wa = shadow(w, prec)
-        n2 = 2 * wa.shape[1]
-        lm = K.gemm(xpm, wa[:n2].t(), mma=prec.mma, out_dtype=prec.act)
-        x16 = _xpm16.pop(xpm.data_ptr(), None)
-        if x16 is not None and x16.shape != xpm.shape:
-            x16 = None
-        ctx.save_for_backward(xpm if x16 is None else x16, wa, w)
-        ctx.prec, ctx.n2 = prec, n2
-        return lm
-
-    @staticmethod
-    def backward(ctx, dlm):
-        xpm, wa, w = ctx.saved_tensors
-        prec, n2 = ctx.prec, ctx.n2
-        dlm = dlm.contiguous()
-        _join_pending(dlm)
-        if dlm.dtype != prec.act:
-            dlm = K.cast(dlm, prec.act)
-        Dm = wa.shape[1]
-        dx = dw = None
-        if ctx.needs_input_grad[0]:
-            dx = K.gemm(dlm, wa[:n2], mma=prec.mma, out_dtype=f32)          # f32: mh_layernorm_bwd_lm's addend
-        if ctx.needs_input_grad[1]:
-            full, sunk = _gbuf(w, tuple(wa.shape))
-            rows = dlm.numel() // n2
-            K.gemm(dlm.reshape(rows, n2).t(), xpm.reshape(rows, Dm), out=full[:n2], accumulate=True,
-                   split_k=_split_k_for(rows, n2, Dm), mma=prec.mma)
-            dw = _gret(w, full, sunk)
-        return dx, dw, None
+def ext_rows_alloc(Bn: int, n_p: int, m: int, N3: int, c0: int, device):
+    """(de [B n_p + B m, N3] bf16, d qkv view [B, n_p, N3], d lm view [B, m, c0] with row stride N3): the gradient buffer NystromCoreFn
+    fills for NormQkvLmFn.backward."""
+    P, E = Bn * n_p, Bn * m
+    de = torch.empty((P + E, N3), device=device, dtype=bf16)
+    return de, _alias(de, 0, (Bn, n_p, N3), (n_p * N3, N3, 1)), _alias(de, P * N3, (Bn, m, c0), (m * N3, N3, 1))
 
 
-_LM_ALGEBRA = os.environ.get("MIRROR_LM_ALGEBRA", "1") != "0"     # A/B switch: landmarks from the LayerNorm's group means
+def ext_rows_of(dqkv, dlm, P: int, E: int, N3: int, c0: int):
+    """The [P + E, N3] buffer of which dqkv / dlm are the two row ranges (ext_rows_alloc), or a freshly assembled copy."""
+    if (dqkv.dtype == bf16 and dlm.dtype == bf16 and dqkv.is_contiguous() and dqkv.numel() == P * N3
+            and dlm.data_ptr() == dqkv.data_ptr() + P * N3 * 2 and dlm.dim() == 3 and tuple(dlm.stride()) == (dlm.shape[1] * N3, N3, 1)
+            and dlm.shape[0] * dlm.shape[1] == E and dlm.shape[2] == c0
+            and dqkv.untyped_storage().nbytes() - dqkv.storage_offset() * 2 >= (P + E) * N3 * 2):
+        return torch.as_strided(dqkv, (P + E, N3), (N3, 1))
+    de = torch.empty((P + E, N3), device=dqkv.device, dtype=bf16)
+    de[:P].copy_(dqkv.reshape(P, N3))
+    de[P:, :c0].copy_(dlm.reshape(E, c0))
+    de[P:, c0:].zero_()
+    return de
+
+
+_LM_ROWS = True       # test hook (tests/test_fused_epilogue_gpu.py): False = the landmark kernels on q | k instead of NormQkvLmFn
 
 
 def layer_norm_landmarks_ok(x, rows: int, pad: int, l: int, prec: Precision) -> bool:
-    return (_LM_ALGEBRA and prec.act == bf16 and not prec.fp8_fwd and x.dim() == 3 and x.dtype == f32 and x.shape[-1] % 4 == 0
+    """geometry / policy for NormQkvLmFn (bf16 activations: the landmark means are rounded like every other to_qkv operand row)"""
+    return (_LM_ROWS and prec.act == bf16 and not prec.fp8_fwd and x.dim() == 3 and x.dtype == f32 and x.shape[-1] % 4 == 0
             and x.shape[-1] <= 2048 and (pad + rows) % l == 0 and x.shape[0] * rows >= 64)
 
 
@@ -1387,30 +1410,12 @@ def _pair(first: torch.Tensor, second: torch.Tensor) -> torch.Tensor:
 
 _S2_TAIL = os.environ.get("MIRROR_S2_TAIL", "1") != "0"      # A/B switch
 _Z0_ROWS = os.environ.get("MIRROR_Z0_ROWS", "1") != "0"      # A/B switch
-_DZDAV_SIDE = os.environ.get("MIRROR_DZDAV_SIDE", "0") != "0"  # A/B switch: nys_dz_dav opens the backward's chain branch (measured: +0.32 % +- 0.18 step time, off)
 _SIM2_SIDE = os.environ.get("MIRROR_SIM2_SIDE", "1") != "0"  # A/B switch: nys_sim2 opens the chain's branch instead of preceding the fork
-_DELTA3 = os.environ.get("MIRROR_DELTA3_FUSED", "0") != "0"   # A/B switch: attn3's delta out of nys_dz_dav (measured: +0.32 % +- 0.06 step time, off)
 _S2_SIDE = os.environ.get("MIRROR_S2_SIDE", "1") != "0"      # A/B switch: sim2's landmark gradients on the chain's stream
-_JOIN_LATE = os.environ.get("MIRROR_JOIN_LATE", "0") != "0"  # A/B switch: the backward's chain branch joins in front of LandmarkProjFn.backward (measured: +0.02 % +- 0.05, off)
-_RCW_SIDE = os.environ.get("MIRROR_RCW_SIDE", "0") != "0"    # A/B switch: with the late join, res_conv's weight gradient on the chain's stream (measured: +0.26 % +- 0.02 step time, off)
-# The backward of the chain branch only feeds the landmarks' gradient, and autograd runs to_qkv's backward (created after LandmarkProjFn
-# in the forward) before LandmarkProjFn's: NystromCoreFn.backward returns without waiting for the chain's stream and leaves a record
-# here, keyed by the (still empty) bf16 gradient tensor it returned; LandmarkProjFn.backward joins and fills it.  The record holds every
-# buffer the side stream still reads or writes: a block freed on the main stream could be handed out again under the running kernels.
-_pending_join: dict = {}
-
-
-def _join_pending(dlm: torch.Tensor) -> None:
-    rec = _pending_join.pop(dlm.data_ptr(), None)
-    if rec is None:
-        return
-    side, main_part, side_part, keep = rec
-    torch.cuda.current_stream().wait_stream(side)
-    K.shared_chip = False
-    K.add(main_part, side_part, out=dlm)
-    del keep
 _DZ_DAV = os.environ.get("MIRROR_DZ_DAV", "1") != "0"        # A/B switch
-_RCW_EARLY = os.environ.get("MIRROR_RCW_EARLY", "0") != "0"  # A/B switch: res_conv weight gradient in front of the chain fork (measured neutral: 1757 / 1758 / 1750 vs 1757 / 1761 / 1752)
+# (measured and deleted in round 4, see DESIGN.md section 6 round 3: nys_dz_dav on the chain's branch +0.32 %, attn3's delta out of
+#  nys_dz_dav +0.32 %, the chain branch joined in front of the landmark projection's backward +0.02 %, res_conv's weight gradient on
+#  the chain's stream +0.26 % or in front of the fork: neutral)
 
 
 class NystromCoreFn(Function):
@@ -1421,7 +1426,7 @@ class NystromCoreFn(Function):
 
     @staticmethod
     def forward(ctx, qkv, res_w, heads, l, iters, prec, kmask=None, q8_key=None, lm_ext=None):
-        """lm_ext: the q | k landmarks [B, m, 2D] computed by the caller (LandmarkProjFn on the LayerNorm's group means); their
+        """lm_ext: the q | k landmarks [B, m, 2D] computed by the caller (NormQkvLmFn: rows of to_qkv's output, row stride 3D); their
         gradient is returned instead of being scattered into dqkv.
         kmask: None, or the package's key-padding mask prepared by TransLayer as (rows [B, n_p], landmarks [B, m],
         landmark scale [B, m]) float tensors: rows of qkv that are masked out are already zero (the caller zeroes the
@@ -1434,7 +1439,10 @@ class NystromCoreFn(Function):
         A, mma, pm = prec.act, prec.mma, prec.pinv_mma
         scale = dh ** -0.5
         q, k, v = (_heads(qkv, i, 3, h) for i in range(3))
-        lm = lm_ext.contiguous() if lm_ext is not None else K.landmark_fwd(qkv, l)
+        if lm_ext is not None:      # rows of to_qkv's output behind the sequence (NormQkvLmFn): row stride 3D, read in place
+            lm = lm_ext if K._lm_ld(lm_ext) > 0 else lm_ext.contiguous()
+        else:
+            lm = K.landmark_fwd(qkv, l)
         ctx.lm_ext = lm_ext is not None
         if kmask is not None:
             mrow, mlm, lscale = kmask
@@ -1569,14 +1577,18 @@ class NystromCoreFn(Function):
         q, k, v = (_heads(qkv, i, 3, h) for i in range(3))
         ql, kl = _heads(lm, 0, 2, h), _heads(lm, 1, 2, h)
         dO = _heads(dout, 0, 1, h)
-        dqkv = torch.empty_like(qkv)
+        # with caller-made landmarks (NormQkvLmFn) d qkv and d lm are the two row ranges of ONE buffer: to_qkv's backward then
+        # multiplies the landmark rows [dq_l | dk_l | 0] together with the sequence rows
+        de = dlm_out = None
+        if ctx.lm_ext and A == bf16:
+            de, dqkv, dlm_out = ext_rows_alloc(Bn, n_p, m, D3, 2 * D, qkv.device)
+        else:
+            dqkv = torch.empty_like(qkv)
         dq, dk, dv = (_heads(dqkv, i, 3, h) for i in range(3))
         rw = res_w.detach().contiguous()
         dres, dres_sunk = _gbuf(res_w, (rw.numel(),))     # the 33-tap filters' gradient goes straight into the grad arena
         # out = a1 @ w2 ; w2 = Z @ av ; av = a3 @ v.  dZ first: it is all the pinv backward needs (the res_conv weight
         # gradient does not depend on it and runs beside the chain, below).
-        if _RCW_EARLY and chain:
-            K.resconv_wgrad(qkv[..., 2 * D:], dout, dres, h)      # alone on the chip (38 us) instead of beside the chain's first loads (144 us)
         if fused:
             lse1, lse3 = a1, a3
             dW2 = zeros((Bn, h, m, dh), qkv.device)
@@ -1590,23 +1602,12 @@ class NystromCoreFn(Function):
         pio = pm if (pm == MH_BF16 or A == f32) else mma
         # dZ = dW2 av^T (the chain's input, packed) and dAV = Z^T dW2: ONE launch on the fused bf16 path (nystrom_sim2.hip)
         one2 = (_DZ_DAV and chain and fused and A == bf16 and pio == MH_BF16 and dh == 64 and m == 256 and dW2.dtype == f32 and av.dtype == f32)
-        dAV = dzb = delta3 = None
-        dzdav_side = one2 and _DZDAV_SIDE and not _DELTA3
-        if dzdav_side:
-            # the launch (128 workgroups, ~22 us) opens the chain's branch; the main stream has the res_conv weight gradient to do
-            # before it needs dAV.  Buffers from the main stream's allocator.
-            avc = av.contiguous()
-            dzb = torch.empty(zfT.shape, device=qkv.device, dtype=bf16)
-            dAV = torch.empty(dW2.shape, device=qkv.device, dtype=bf16)
-        elif one2 and _DELTA3:
-            dzb, dAV, delta3 = K.nys_dz_dav(dW2, av.contiguous(), zfT, want_delta3=True)
-        elif one2:
+        dAV = dzb = None
+        if one2:
             dzb, dAV = K.nys_dz_dav(dW2, av.contiguous(), zfT)
         else:
             dZ = K.gemm(dW2, tr(av), mma=pm, out_dtype=f32)                              # [B,h,m,m]
         side = dlm2 = None
-        late = False
-        rcw_side = _RCW_SIDE and dres_sunk     # written into the grad arena, which is read behind the engine's join of the side streams only
         if chain:
             xb, chain_saved, z0 = flat
             work = torch.empty_like(chain_saved)
@@ -1614,7 +1615,6 @@ class NystromCoreFn(Function):
             dz0 = torch.empty_like(a2)
             if dzb is None:
                 dzb = K.pinv_chain_pack(dZ)
-            late = _S2_SIDE and fused and kmask is None and _JOIN_LATE and ctx.lm_ext and A == bf16
             if _S2_SIDE and fused and kmask is None:
                 # sim2's share of the landmark gradients leaves the serial tail behind the join: the chain's stream has slack
                 # in this window.  The attention kernels on the main stream add into dlm with atomics meanwhile, so the two
@@ -1622,11 +1622,7 @@ class NystromCoreFn(Function):
                 dlm2 = torch.empty_like(dlm)
             side = _side_stream(qkv.device)      # half-chip chain again, beside the softmax backward / dq / dk work
             side.wait_stream(torch.cuda.current_stream())
-            dav_ready = None
             with torch.cuda.stream(side):
-                if dzdav_side:
-                    K.nys_dz_dav(dW2, avc, zfT, out=(dzb, dAV))
-                    dav_ready = side.record_event()
                 K.pinv_chain_bwd(xb, chain_saved, dzb, work, dS2, dz0, iters)
                 if _S2_TAIL and kmask is None and not ctx.z0_stored and a2.shape[-1] == 256:
                     K.pinv_s2_bwd(a2, dz0, st, dS2)      # z_0 backward, the maxima's sub-gradients and attn2's softmax backward: one pass
@@ -1636,17 +1632,12 @@ class NystromCoreFn(Function):
                 if dlm2 is not None:
                     K.gemm(tr(dS2), ql, out=_heads(dlm2, 1, 2, h), alpha=scale, mma=pio)
                     K.gemm(dS2, kl, out=_heads(dlm2, 0, 2, h), alpha=scale, mma=pio)
-                if late and rcw_side:
-                    K.resconv_wgrad(qkv[..., 2 * D:], dout, dres, h)     # this branch joins behind to_qkv's backward: room for it here
             K.shared_chip = True         # until the join below
-        if not ((_RCW_EARLY and chain) or (late and rcw_side)):
-            K.resconv_wgrad(qkv[..., 2 * D:], dout, dres, h)
+        K.resconv_wgrad(qkv[..., 2 * D:], dout, dres, h)
         if dAV is None:
             dAV = K.gemm(tr(zf), dW2, mma=pio, out_dtype=A)                              # [B,h,m,dh]
-        if dzdav_side:
-            torch.cuda.current_stream().wait_event(dav_ready)
         if fused:
-            K.nys_attn3_bwd(qkv, lm, av, dAV, lse3, dqkv, dlm, h, scale, kmask, delta3=delta3)      # dk, dv, dq_l
+            K.nys_attn3_bwd(qkv, lm, av, dAV, lse3, dqkv, dlm, h, scale, kmask)          # dk, dv, dq_l
             K.resconv(dout, rw, dqkv[..., 2 * D:], h, transpose=True, accumulate=True)
         else:
             if (kmask is None and A == bf16 and mma == MH_BF16 and a1.dtype == bf16 and a1.is_contiguous()
@@ -1664,12 +1655,6 @@ class NystromCoreFn(Function):
             K.gemm(tr(dS3), ql, out=dk, alpha=scale, mma=mma)
             K.gemm(tr(dS1), q, out=dkl, alpha=scale, mma=mma)
             K.gemm(dS3, k, out=dql, alpha=scale, mma=mma)
-        if late:
-            out = torch.empty(dlm.shape, device=dlm.device, dtype=A)
-            _pending_join[out.data_ptr()] = (side, dlm, dlm2, (work, dS2, dz0, dzb, xb, chain_saved, a2, st, lm, qkv, dout))
-            K.shared_chip = False      # the chain itself is over by the time the main stream gets to to_qkv's backward
-            dres = _gret(res_w, dres, dres_sunk)
-            return dqkv, (None if dres is None else dres.view_as(res_w)), None, None, None, None, None, None, out
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
             K.shared_chip = False
@@ -1677,18 +1662,27 @@ class NystromCoreFn(Function):
         else:
             dS2 = pinv_backward_tile(a2, saved, st, dZ) if ctx.tile else pinv_backward(a2, saved, st, dZ, pm, sd)
             sm_bwd(a2, dS2, mlm if kmask else None, mlm if kmask else None)
-        if dlm2 is not None:
-            dlm = K.add(dlm, dlm2, out_dtype=A)
-        else:
+        if dlm2 is None:
             K.gemm(tr(dS2), ql, out=dkl, alpha=scale, accumulate=True, mma=pio)
             K.gemm(dS2, kl, out=dql, alpha=scale, accumulate=True, mma=pio)
+        dres = _gret(res_w, dres, dres_sunk)
+        dres = None if dres is None else dres.view_as(res_w)
+        if de is not None and kmask is None:
+            # the merge of the two f32 partial sums is also the cast, written as rows [dq_l | dk_l | 0] behind the sequence rows
+            K.lm_merge(dlm, dlm2, de[Bn * n_p:], D3 - 2 * D)
+            return dqkv, dres, None, None, None, None, None, None, dlm_out
+        if dlm2 is not None:
+            dlm = K.add(dlm, dlm2, out_dtype=A)
         if kmask is not None:
             dlm = K.row_scale(dlm, lscale)
-        dres = _gret(res_w, dres, dres_sunk)
         if ctx.lm_ext:         # the landmarks came from the caller: their gradient goes back to it (no scatter into dqkv)
-            return dqkv, (None if dres is None else dres.view_as(res_w)), None, None, None, None, None, None, dlm
+            if de is not None:
+                dlm_out.copy_(dlm)
+                de[Bn * n_p:, 2 * D:].zero_()
+                return dqkv, dres, None, None, None, None, None, None, dlm_out
+            return dqkv, dres, None, None, None, None, None, None, dlm
         K.landmark_bwd(K.cast(dlm, A), dqkv, l)
-        return dqkv, (None if dres is None else dres.view_as(res_w)), None, None, None, None, None, None, None
+        return dqkv, dres, None, None, None, None, None, None, None
 
 
 class RowScaleFn(Function):

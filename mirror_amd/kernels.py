@@ -235,20 +235,25 @@ def linear_fused(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],
     return out
 
 
-def gemm_rows_window(a3: torch.Tensor, b2: torch.Tensor, out3: torch.Tensor, r0: int, R: int, m_rows: Optional[int] = None) -> None:
-    """out3[:, r0:r0 + R] = a3[:, r0:r0 + R] @ b2 as ONE flat problem over the B * R real rows of buffers that hold T >= R rows per batch
+def gemm_rows_window(a3: torch.Tensor, b2: torch.Tensor, out3: torch.Tensor, r0: int, R: int, m_rows: Optional[int] = None,
+                     a_r0: Optional[int] = None) -> None:
+    """out3[:, r0:r0 + R] = a3[:, a_r0:a_r0 + R] @ b2 as ONE flat problem over the B * R real rows of buffers that hold T >= R rows per batch
     (mh_gemm_desc.a_rows_per_batch / c_rows_per_batch): [3P] NystromAttention's front-padded sequence — the pad rows are never multiplied.
-    a3 [B, T, K] bf16 (rows K-contiguous), b2 a 2-D weight view [K, N] (W^T of an [N, K] row-major weight, or a row-major [K, N]),
-    out3 [B, T, N] bf16 (may be a column slice of a wider buffer).  m_rows: only the first m_rows flat rows (whole 256-row tiles)."""
+    a3 [B, Ta, K] bf16 (rows K-contiguous; a_r0 defaults to r0, Ta == R: a plain contiguous operand), b2 a 2-D weight view [K, N] (W^T of
+    an [N, K] row-major weight, or a row-major [K, N]), out3 [B, T, N] bf16 (may be a column slice of a wider buffer).  m_rows: only the
+    first m_rows flat rows (whole 256-row tiles)."""
     _chk(a3, b2, out3)
-    Bn, T, Kd = a3.shape
+    Bn, Ta, Kd = a3.shape
+    T = out3.shape[1]
     N = b2.shape[1]
     bf = torch.bfloat16
-    if not (a3.dtype == b2.dtype == out3.dtype == bf and a3.stride(2) == 1 and out3.stride(2) == 1 and a3.stride(0) == T * a3.stride(1)
-            and out3.stride(0) == T * out3.stride(1) and tuple(out3.shape) == (Bn, T, N) and b2.shape[0] == Kd and 0 <= r0 and r0 + R <= T):
+    a_r0 = r0 if a_r0 is None else a_r0
+    if not (a3.dtype == b2.dtype == out3.dtype == bf and a3.stride(2) == 1 and out3.stride(2) == 1 and a3.stride(0) == Ta * a3.stride(1)
+            and out3.stride(0) == T * out3.stride(1) and tuple(out3.shape) == (Bn, T, N) and b2.shape[0] == Kd and 0 <= r0 and r0 + R <= T
+            and 0 <= a_r0 and a_r0 + R <= Ta):
         raise MirrorHipError("gemm_rows_window: bad operands")
     d = GemmDesc()
-    d.A, d.B, d.C, d.bias = a3.data_ptr() + r0 * a3.stride(1) * 2, b2.data_ptr(), out3.data_ptr() + r0 * out3.stride(1) * 2, None
+    d.A, d.B, d.C, d.bias = a3.data_ptr() + a_r0 * a3.stride(1) * 2, b2.data_ptr(), out3.data_ptr() + r0 * out3.stride(1) * 2, None
     d.M, d.N, d.K = (Bn * R if m_rows is None else int(m_rows)), N, Kd
     d.lda, d.ldc = a3.stride(1), out3.stride(1)
     if b2.stride(0) == 1:            # W^T of a row-major [N, K] weight: contraction index contiguous
@@ -261,9 +266,11 @@ def gemm_rows_window(a3: torch.Tensor, b2: torch.Tensor, out3: torch.Tensor, r0:
     d.dtA, d.dtB, d.dtC, d.mma = MH_BF16, MH_BF16, MH_BF16, MH_BF16
     d.batch1 = d.batch2 = 1
     d.alpha, d.split_k = 1.0, 1
-    if R != T and Bn > 1:
-        d.a_rows_per_batch, d.a_row_skip = R, T - R
-        d.c_rows_per_batch, d.c_row_skip = R, T - R
+    if Bn > 1:
+        if R != Ta:
+            d.a_rows_per_batch, d.a_row_skip = R, Ta - R
+        if R != T:
+            d.c_rows_per_batch, d.c_row_skip = R, T - R
     d.shared_chip = 1 if shared_chip else 0
     prof = gemm_profiler
     if prof is None:
@@ -274,6 +281,61 @@ def gemm_rows_window(a3: torch.Tensor, b2: torch.Tensor, out3: torch.Tensor, r0:
             kern = "gemm_pp_kernel"
         prof.launch_named(f"{kern}<bf16,true,{'true' if d.b_kc else 'false'}>", 2.0 * d.M * d.N * d.K,
                           lambda: _lib.call("mh_gemm", C.byref(d), stream=_stream()))
+
+
+def gemm_rows_ext_ok(Bn: int, T: int, r0: int, R: int, extra: int, Kd: int, N: int, a2: torch.Tensor, out2: torch.Tensor) -> bool:
+    """shapes for which gemm_rows_ext runs on the direct-to-LDS 256 x 256 kernels."""
+    bf = torch.bfloat16
+    M = Bn * R + extra
+    return (a2.dim() == 2 and out2.dim() == 2 and a2.dtype == bf and out2.dtype == bf and a2.is_cuda and R >= 256 and M > 512 and 0 <= extra < R
+            and r0 + R == T and M % 256 <= extra
+            and N % 256 == 0 and Kd % 64 == 0 and a2.stride(1) == 1 and out2.stride(1) == 1 and a2.stride(0) % 8 == 0 and out2.stride(0) % 8 == 0
+            and a2.data_ptr() % 16 == 0 and out2.data_ptr() % 16 == 0 and a2.shape[0] == Bn * T + extra and out2.shape[0] == Bn * T + extra
+            and int(_lib.load().mh_gemm_select_pp(-1)) != 0)
+
+
+def gemm_rows_ext(a2: torch.Tensor, b2: torch.Tensor, out2: torch.Tensor, Bn: int, T: int, r0: int, R: int, extra: int) -> int:
+    """The row-window product of gemm_rows_window over buffers that hold `extra` more rows behind the Bn batches of T rows (the landmark
+    rows of a Nystrom layer: a2 [Bn * T + extra, K], out2 [Bn * T + extra, N], 2-D views with unit column stride): ONE flat problem over
+    the Bn * R real rows (r0 + R == T: the window ends with the batch) followed by the extra rows, M = Bn * R + extra.  The kernels'
+    row remap r -> r + min(r / R, Bn - 1) * (T - R) (mh_gemm_desc.window_batches) lands the extra rows right behind the last batch.
+    Only whole 256-row tiles are computed; returns the number of flat rows left over at the end (< 256, all of them extra rows) for the
+    caller to finish (a2[-tail:] @ b2 -> out2[-tail:])."""
+    _chk(a2, b2, out2)
+    Kd, N = a2.shape[1], b2.shape[1]
+    if not gemm_rows_ext_ok(Bn, T, r0, R, extra, Kd, N, a2, out2) or b2.shape[0] != Kd or b2.dtype != torch.bfloat16:
+        raise MirrorHipError("gemm_rows_ext: bad operands")
+    M = Bn * R + extra
+    tail = M % 256
+    d = GemmDesc()
+    d.A, d.B, d.C, d.bias = a2.data_ptr() + r0 * a2.stride(0) * 2, b2.data_ptr(), out2.data_ptr() + r0 * out2.stride(0) * 2, None
+    d.M, d.N, d.K = M - tail, N, Kd
+    d.lda, d.ldc = a2.stride(0), out2.stride(0)
+    if b2.stride(0) == 1:            # W^T of a row-major [N, K] weight: contraction index contiguous
+        d.ldb, d.b_kc = b2.stride(1), 1
+    elif b2.stride(1) == 1:          # row-major [K, N]
+        d.ldb, d.b_kc = b2.stride(0), 0
+    else:
+        raise MirrorHipError("gemm_rows_ext: the weight view must have a unit stride")
+    d.a_kc = 1
+    d.dtA, d.dtB, d.dtC, d.mma = MH_BF16, MH_BF16, MH_BF16, MH_BF16
+    d.batch1 = d.batch2 = 1
+    d.alpha, d.split_k = 1.0, 1
+    if R != T:
+        d.a_rows_per_batch, d.a_row_skip = R, T - R
+        d.c_rows_per_batch, d.c_row_skip = R, T - R
+        d.window_batches = Bn          # the extra rows follow the last batch's window without a gap
+    d.shared_chip = 1 if shared_chip else 0
+    prof = gemm_profiler
+    if prof is None:
+        _lib.call("mh_gemm", C.byref(d), stream=_stream())
+    else:
+        kern = ("gemm_big_kernel", "gemm_pp_kernel", "gemm_pq_kernel")[int(_lib.load().mh_gemm_select_pp(-1))]
+        if shared_chip and kern == "gemm_pq_kernel":
+            kern = "gemm_pp_kernel"
+        prof.launch_named(f"{kern}<bf16,true,{'true' if d.b_kc else 'false'}>", 2.0 * d.M * d.N * d.K,
+                          lambda: _lib.call("mh_gemm", C.byref(d), stream=_stream()))
+    return tail
 
 
 def gemm_rows_window_ok(a3: torch.Tensor, out3: torch.Tensor, r0: int, R: int, N: int) -> bool:
@@ -585,7 +647,7 @@ def layernorm_fwd_q8(x, gamma, beta, y, mean, rstd, batches, rpb, D, x_bs, y_bs,
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, batches, rpb, D, x_bs, y_bs, accumulate_dx=False, gadd=None,
                   pad: int = 0, l: int = 1):
-    """gadd (f32 [batches, (pad + rpb) / l, D]): the gradient of the landmark means layernorm_fwd_lm produced; every dy row also
+    """gadd ([batches, (pad + rpb) / l, D], dy's dtype): the gradient of the landmark means layernorm_fwd_lm produced; every dy row also
     receives gadd[b, (i + pad) / l] / l (mh_layernorm_bwd_lm)."""
     _chk(dy, x, gamma, mean, rstd, dx, dgamma, dbeta)
     rows = batches * rpb
@@ -595,8 +657,8 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, batches, rpb, D, 
         ws = torch.empty((nbytes // 4,), device=x.device, dtype=torch.float32)
     if gadd is not None:
         _chk(gadd)
-        if gadd.dtype != torch.float32 or not gadd.is_contiguous() or gadd.numel() != batches * ((pad + rpb) // l) * D:
-            raise MirrorHipError("layernorm_bwd: gadd must be contiguous f32 [batches, (pad + rows) / l, D]")
+        if gadd.dtype != dy.dtype or not gadd.is_contiguous() or gadd.numel() != batches * ((pad + rpb) // l) * D:
+            raise MirrorHipError("layernorm_bwd: gadd must be contiguous [batches, (pad + rows) / l, D] in dy's dtype")
         _lib.call("mh_layernorm_bwd_lm", _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma), _p(dbeta),
                   batches, rpb, D, x_bs, y_bs, dt(x), dt(dy), dt(dx), int(accumulate_dx), _p(ws) if ws is not None else 0,
                   ws.numel() if ws is not None else 0, _p(gadd), int(pad), int(l), stream=_stream())
@@ -609,11 +671,13 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, batches, rpb, D, 
 def layernorm_fwd_lm(x, gamma, beta, y, mean, rstd, xpm, batches, rows, D, x_bs, pad, l, eps, xpm_bf16=None):
     """LayerNorm (f32 in, bf16 out behind `pad` zero rows, which this launch writes) + the landmark means xpm [batches, (pad + rows) / l, D]
     (f32) of its output rows (mh_layernorm_fwd_lm)."""
-    _chk(x, gamma, beta, y, mean, rstd, xpm)
-    if not (x.dtype == torch.float32 and y.dtype == torch.bfloat16 and xpm.dtype == torch.float32 and y.is_contiguous() and xpm.is_contiguous()):
-        raise MirrorHipError("layernorm_fwd_lm: f32 input, contiguous bf16 rows and f32 landmark means")
-    if xpm_bf16 is not None and not (xpm_bf16.dtype == torch.bfloat16 and xpm_bf16.is_contiguous() and xpm_bf16.shape == xpm.shape):
-        raise MirrorHipError("layernorm_fwd_lm: xpm_bf16 must be a contiguous bf16 tensor of xpm's shape")
+    _chk(x, gamma, beta, y, mean, rstd, xpm, xpm_bf16)
+    if not (x.dtype == torch.float32 and y.dtype == torch.bfloat16 and y.is_contiguous() and (xpm is not None or xpm_bf16 is not None)
+            and (xpm is None or (xpm.dtype == torch.float32 and xpm.is_contiguous()))):
+        raise MirrorHipError("layernorm_fwd_lm: f32 input, contiguous bf16 rows and f32 (and / or bf16) landmark means")
+    n_lm = batches * ((pad + rows) // l) * D
+    if xpm_bf16 is not None and not (xpm_bf16.dtype == torch.bfloat16 and xpm_bf16.is_contiguous() and xpm_bf16.numel() == n_lm):
+        raise MirrorHipError("layernorm_fwd_lm: xpm_bf16 must be a contiguous bf16 tensor of batches * (pad + rows) / l * D elements")
     _lib.call("mh_layernorm_fwd_lm", _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), _p(xpm), _p(xpm_bf16), batches, rows, D, x_bs, int(pad),
               int(l), eps, stream=_stream())
 
@@ -843,8 +907,8 @@ def nys_dz_dav(dw2: torch.Tensor, av: torch.Tensor, zfT: torch.Tensor, want_delt
 
 def nys_sim2_ok(lm: torch.Tensor, heads: int) -> bool:
     """mh_nys_sim2's geometry: bf16 landmarks [B, 256, 2 D] with D = heads * 64."""
-    return (lm.dim() == 3 and lm.dtype == torch.bfloat16 and lm.is_contiguous() and lm.shape[1] == PINV_CHAIN_M
-            and lm.shape[2] == 2 * heads * 64 and os.environ.get("MIRROR_NYS_SIM2", "1") != "0")
+    return (lm.dim() == 3 and lm.dtype == torch.bfloat16 and _lm_ld(lm) > 0 and lm.shape[1] == PINV_CHAIN_M
+            and lm.shape[2] == 2 * heads * 64)
 
 
 def nys_sim2_alloc(lm: torch.Tensor, heads: int):
@@ -869,7 +933,7 @@ def nys_sim2(lm: torch.Tensor, heads: int, scale: float, stats: Optional[torch.T
             and a2.is_contiguous() and xt.is_contiguous()):
         raise MirrorHipError("nys_sim2: out must be the contiguous (f32, bf16) [B, h, m, m] pair of nys_sim2_alloc")
     z0f = torch.empty((Bn, heads, m, m), device=lm.device, dtype=torch.float32) if want_z0f else None
-    _lib.call("mh_nys_sim2", _p(lm), _p(a2), _p(xt), _p(z0f), _p(stats), Bn, m, D, heads, float(scale), stream=_stream())
+    _lib.call("mh_nys_sim2", _p(lm), _p(a2), _p(xt), _p(z0f), _p(stats), Bn, m, D, heads, float(scale), _lm_ld(lm), stream=_stream())
     return a2, xt, z0f, stats
 
 
@@ -934,9 +998,19 @@ def _nys_check(name: str, B: int, h: int, n_p: int, **tensors) -> None:
             "lse3": ((B, h, NYS_FUSED_M), torch.float32)}
     for k, t in tensors.items():
         shape, dtype = want[k]
+        if k == "lm" and tuple(t.shape) == shape and t.dtype == dtype and _lm_ld(t) > 0:
+            continue                       # landmark rows may sit in a wider buffer (row stride lm_ld, see _lm_ld)
         if tuple(t.shape) != shape or t.dtype != dtype or not t.is_contiguous():
             raise MirrorHipError(f"{name}: {k} must be contiguous {dtype} {shape}, got {t.dtype} {tuple(t.shape)} "
                                  f"contiguous={t.is_contiguous()}")
+
+
+def _lm_ld(lm: torch.Tensor) -> int:
+    """Row stride (elements) of a landmark tensor [B, m, 2D] whose rows are unit-stride, evenly spaced and batch-contiguous
+    (a contiguous tensor, or the landmark rows behind the sequence in to_qkv's [rows, 3D] output); 0 if it is neither."""
+    if lm.dim() != 3 or lm.stride(2) != 1 or lm.stride(0) != lm.shape[1] * lm.stride(1) or lm.stride(1) < lm.shape[2] or lm.stride(1) % 8:
+        return 0
+    return int(lm.stride(1))
 
 
 def _nys_launch(name: str, flops: float, fn) -> None:
@@ -965,7 +1039,7 @@ def nys_attn1_fwd(qkv, lm, w2, out, heads: int, scale: float, accumulate: bool =
     _nys_check("nys_attn1_fwd", B, heads, n_p, qkv=qkv, lm=lm, w2=w2, out=out)
     _nys_launch("nys_a1_fwd_kernel", 2 * 2.0 * n_p * NYS_FUSED_M * NYS_FUSED_DH * B * heads,
                 lambda: _lib.call("mh_nys_attn1_fwd", _p(qkv), _p(lm), _p(w2), _p(out), _p(lse1), *_nys_masks(kmask, B, n_p), B, heads,
-                                  n_p, NYS_FUSED_M, NYS_FUSED_DH, scale, int(accumulate), stream=_stream()))
+                                  n_p, NYS_FUSED_M, NYS_FUSED_DH, scale, int(accumulate), _lm_ld(lm), stream=_stream()))
     return lse1
 
 
@@ -979,7 +1053,8 @@ def nys_attn1_fwd_q8(qkv, lm, w2, out, heads: int, scale: float, accumulate: boo
         raise MirrorHipError("nys_attn1_fwd_q8: q8 uint8 shaped like out, int32[3] ring, f32 tick")
     lse1 = torch.empty((B, heads, n_p), device=qkv.device, dtype=torch.float32)
     sc = torch.empty((1,), device=qkv.device, dtype=torch.float32)
-    _nys_check("nys_attn1_fwd", B, heads, n_p, qkv=qkv, lm=lm, w2=w2, out=out)
+    _nys_check("nys_attn1_fwd", B, heads, n_p, qkv=qkv, lm=lm.contiguous(), w2=w2, out=out)
+    lm = lm.contiguous()
     _nys_launch("nys_a1_fwd_kernel", 2 * 2.0 * n_p * NYS_FUSED_M * NYS_FUSED_DH * B * heads,
                 lambda: _lib.call("mh_nys_attn1_fwd_q8", _p(qkv), _p(lm), _p(w2), _p(out), _p(lse1), B, heads, n_p, NYS_FUSED_M,
                                   NYS_FUSED_DH, scale, int(accumulate), _p(q8), _p(ring), _p(tick), float(margin), _p(sc), stream=_stream()))
@@ -997,7 +1072,7 @@ def nys_attn3_fwd(qkv, lm, heads: int, scale: float, kmask=None):
     ws = torch.empty((nws,), device=qkv.device, dtype=torch.float32) if nws else None
     _nys_launch("nys_a3_fwd_kernel", 2 * 2.0 * n_p * NYS_FUSED_M * NYS_FUSED_DH * B * heads,
                 lambda: _lib.call("mh_nys_attn3_fwd", _p(qkv), _p(lm), _p(av), _p(lse3), _p(ws), nws, *_nys_masks(kmask, B, n_p), B,
-                                  heads, n_p, NYS_FUSED_M, NYS_FUSED_DH, scale, stream=_stream()))
+                                  heads, n_p, NYS_FUSED_M, NYS_FUSED_DH, scale, _lm_ld(lm), stream=_stream()))
     return av, lse3
 
 
@@ -1010,7 +1085,7 @@ def nys_attn1_bwd(qkv, lm, w2, dout, lse1, dqkv, dw2, dlm, heads: int, scale: fl
     _nys_launch("nys_a1_bwd_kernels", 7 * 2.0 * n_p * NYS_FUSED_M * NYS_FUSED_DH * B * heads,
                 lambda: _lib.call("mh_nys_attn1_bwd", _p(qkv), _p(lm), _p(w2), _p(dout), _p(lse1), _p(delta1), _p(dqkv),
                                   _p(dw2), _p(dlm), *_nys_masks(kmask, B, n_p), B, heads, n_p, NYS_FUSED_M, NYS_FUSED_DH, scale,
-                                  stream=_stream()))
+                                  _lm_ld(lm), stream=_stream()))
 
 
 def nys_attn3_bwd(qkv, lm, av, dav, lse3, dqkv, dlm, heads: int, scale: float, kmask=None, delta3=None) -> None:
@@ -1025,7 +1100,7 @@ def nys_attn3_bwd(qkv, lm, av, dav, lse3, dqkv, dlm, heads: int, scale: float, k
         delta3 = torch.empty_like(lse3)
     _nys_launch("nys_a3_bwd_kernels", 7 * 2.0 * n_p * NYS_FUSED_M * NYS_FUSED_DH * B * heads,
                 lambda: _lib.call("mh_nys_attn3_bwd", _p(qkv), _p(lm), None if given else _p(av), _p(dav), _p(lse3), _p(delta3), _p(dqkv), _p(dlm),
-                                  *_nys_masks(kmask, B, n_p), B, heads, n_p, NYS_FUSED_M, NYS_FUSED_DH, scale, stream=_stream()))
+                                  *_nys_masks(kmask, B, n_p), B, heads, n_p, NYS_FUSED_M, NYS_FUSED_DH, scale, _lm_ld(lm), stream=_stream()))
 
 
 def eye_minus(P: torch.Tensor, d: float) -> torch.Tensor:
@@ -1227,6 +1302,17 @@ def add(a: torch.Tensor, b: torch.Tensor, out_dtype=None, out: Optional[torch.Te
     y = out if out is not None else torch.empty_like(a, dtype=out_dtype or a.dtype)
     _lib.call("mh_add", _p(a), _p(b), _p(y), a.numel(), dt(a), dt(b), dt(y), stream=_stream())
     return y
+
+
+def lm_merge(a: torch.Tensor, b: Optional[torch.Tensor], out2: torch.Tensor, zero_cols: int) -> None:
+    """out2[:, :cols] = bf16(a + b), out2[:, cols:cols + zero_cols] = 0 for f32 a / b [rows, cols] (b may be None) and a bf16 2-D
+    view out2 [rows, cols + zero_cols] with unit column stride (mh_lm_merge): the landmark gradient as rows of to_qkv's gradient buffer."""
+    _chk(a, b, out2)
+    rows, cols = a.numel() // a.shape[-1], a.shape[-1]
+    if not (a.dtype == torch.float32 and a.is_contiguous() and (b is None or (b.dtype == torch.float32 and b.is_contiguous() and b.numel() == a.numel()))
+            and out2.dim() == 2 and out2.dtype == torch.bfloat16 and out2.stride(1) == 1 and tuple(out2.shape) == (rows, cols + zero_cols)):
+        raise MirrorHipError("lm_merge: f32 contiguous a / b, bf16 out2 [rows, cols + zero_cols] with unit column stride")
+    _lib.call("mh_lm_merge", _p(a), _p(b), _p(out2), rows, cols, out2.stride(0), int(zero_cols), stream=_stream())
 
 
 def cast(x: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:

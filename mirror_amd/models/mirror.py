@@ -199,10 +199,9 @@ class TransLayer(nn.Module):
         l = math.ceil(n / m)  # noqa: E741
         lm = None
         if mask is None and Fn.layer_norm_landmarks_ok(x, n, pad, l, prec):
-            # the norm also leaves the landmark means of its output; to_qkv is linear and bias-free, so the q | k landmarks of
-            # [3P] NystromAttention are a [B m, D] x [D, 2D] product on them (Fn.LayerNormLmFn / Fn.LandmarkProjFn)
-            xp, xpm = Fn.LayerNormLmFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps, n, pad, l)
-            lm = Fn.LandmarkProjFn.apply(xpm, a.to_qkv.weight, prec)
+            # the norm also leaves the landmark means of its output behind the padded sequence; to_qkv is linear and bias-free, so the
+            # q | k landmarks of [3P] NystromAttention are the same projection's result for those extra rows (Fn.NormQkvLmFn)
+            qkv, lm = Fn.NormQkvLmFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps, n, pad, l, a.to_qkv.weight, prec)
         else:
             xp = Fn.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps, pad=pad, out_dtype=prec.act,
                                q8_key=Fn.fp8_site_key(a.to_qkv.weight, prec) if prec.fp8_fwd else None)
@@ -214,9 +213,8 @@ class TransLayer(nn.Module):
             cnt = mrow.reshape(mrow.shape[0], (n + pad) // l, l).sum(-1)
             kmask = (mrow, (cnt > 0).float().contiguous(), (float(l) / (cnt + 1e-8)).contiguous())
             xp = Fn.RowScaleFn.apply(xp, mrow)           # to_qkv has no bias: zero rows in, zero q / k / v rows out
-        # behind LayerNormLmFn the pad rows of xp are exact zeros and its backward reads the real rows only: to_qkv skips them
-        qkv = Fn.linear(xp, a.to_qkv.weight, None, prec=prec, defer_from=2 * a.to_qkv.weight.shape[1],
-                        zero_rows=pad if (lm is not None and kmask is None) else 0)
+        if lm is None:
+            qkv = Fn.linear(xp, a.to_qkv.weight, None, prec=prec, defer_from=2 * a.to_qkv.weight.shape[1])
         core = Fn.NystromCoreFn.apply(qkv, a.res_conv.weight, a.heads, l, a.pinv_iterations, prec, kmask,
                                       Fn.fp8_site_key(a.to_out[0].weight, prec) if prec.fp8_fwd else None, lm)
         # to_out(...)[:, -n:], its Dropout and the residual add: one launch when the shapes allow (Fn.to_out_dropout_add).

@@ -587,6 +587,8 @@ def test_host_feeder_graph_replay_trains_on_every_batch_across_epochs():
     assert eng._graph is not None, "the step was not captured: this test has to exercise the replay path"
     assert seen and all(seen), seen
     want, _, _ = run(False)
+    # two bf16 runs of six Adam steps at lr = 1e-3 differ by their f32 atomics order (measured up to 3e-3 on the smallest term); a batch
+    # that was skipped or fed twice moves every term by tens of percent
     for a, b in zip(got, want):
         for x, y in zip(a, b):
-            assert abs(x - y) <= 2e-3 * max(abs(y), 1e-3), (got, want)
+            assert abs(x - y) <= 1e-2 * max(abs(y), 1e-3), (got, want)

@@ -182,43 +182,52 @@ def test_whole_model_train_step_fused_epilogues_equal_composed():
 
 
 @pytest.mark.parametrize("Bn,n,D,m", [(3, 1025, 512, 256), (2, 300, 256, 128)])
-def test_layernorm_landmark_means_and_their_backward(Bn, n, D, m):
-    """mh_layernorm_fwd_lm / mh_layernorm_bwd_lm against LayerNormFn + explicit group means through torch autograd."""
+def test_norm_qkv_with_landmark_rows_and_its_backward(Bn, n, D, m):
+    """Fn.NormQkvLmFn (LayerNorm + to_qkv with the landmark means as extra rows of the same products: mh_layernorm_fwd_lm,
+    the flat row-window GEMM with mh_gemm_desc.window_batches, mh_layernorm_bwd_lm with a bf16 addend) against the composed
+    LayerNorm -> to_qkv -> explicit group means of q | k through torch autograd.  (3, 1025, 512, 256) runs the flat
+    row-window kernels (3 ragged rows through the weight-streaming kernel), (2, 300, 256, 128) the generic products."""
     import math
     from mirror_amd import functional as Fn
+    prec = Fn.POLICIES["bf16"]
     g = torch.Generator().manual_seed(9)
     pad = (m - n % m) % m
     l = math.ceil(n / m)
     assert (pad + n) == m * l
     x0 = torch.randn(Bn, n, D, generator=g).cuda()
     gm0, bt0 = (1 + 0.1 * torch.randn(D, generator=g)).cuda(), (0.1 * torch.randn(D, generator=g)).cuda()
-    up_y = torch.randn(Bn, pad + n, D, generator=g).cuda().to(bf16)
-    up_m = torch.randn(Bn, m, D, generator=g).cuda()
+    w0 = (torch.randn(3 * D, D, generator=g) * D ** -0.5).cuda()
+    up_q = torch.randn(Bn, pad + n, 3 * D, generator=g).cuda().to(bf16)
+    up_l = torch.randn(Bn, m, 2 * D, generator=g).cuda().to(bf16)
     res = []
     for fused in (True, False):
-        x, gm, bt = x0.clone().requires_grad_(True), gm0.clone().requires_grad_(True), bt0.clone().requires_grad_(True)
+        x, gm, bt, w = (t.clone().requires_grad_(True) for t in (x0, gm0, bt0, w0))
         if fused:
-            y, xpm = Fn.LayerNormLmFn.apply(x, gm, bt, 1e-5, n, pad, l)
-            xpm32 = xpm.float()
+            qkv, lm = Fn.NormQkvLmFn.apply(x, gm, bt, 1e-5, n, pad, l, w, prec)
+            assert lm.stride(1) == 3 * D and lm.data_ptr() == qkv.data_ptr() + qkv.numel() * 2      # rows of ONE buffer
+            Fn.run_deferred(qkv)
+            # the gradient arrives as NystromCoreFn hands it over: the two row ranges of one [B n_p + B m, 3D] buffer
+            de, dq, dl = Fn.ext_rows_alloc(Bn, pad + n, m, 3 * D, 2 * D, x.device)
+            dq.copy_(up_q)
+            dl.copy_(up_l)
+            de[Bn * (pad + n):, 2 * D:].zero_()
+            torch.autograd.backward([qkv, lm], [dq, dl])
         else:
             y = Fn.layer_norm(x, gm, bt, 1e-5, pad=pad, out_dtype=bf16)
-            xpm32 = y.float().reshape(Bn, m, l, D).mean(2)
-        (y.float() * up_y.float()).sum().backward(retain_graph=True)
-        if fused:
-            xpm.backward(up_m.to(bf16).float())
-        else:
-            (xpm32 * up_m.to(bf16).float()).sum().backward()
-        res.append((y.detach().clone(), xpm32.detach().clone(), x.grad.clone(), gm.grad.clone(), bt.grad.clone()))
+            qkv = Fn.linear(y, w, None, prec=prec)
+            lm = qkv[..., :2 * D].float().reshape(Bn, m, l, 2 * D).mean(2)
+            ((qkv.float() * up_q.float()).sum() + (lm * up_l.float()).sum()).backward()
+        res.append((qkv.detach().float().clone(), lm.detach().float().clone(), x.grad.clone(), gm.grad.clone(), bt.grad.clone(), w.grad.clone()))
     torch.cuda.synchronize()
-    (y1, m1, dx1, dg1, db1), (y2, m2, dx2, dg2, db2) = res
-    assert torch.equal(y1, y2) and float(y1[:, :pad].abs().max() if pad else 0.0) == 0.0
-    assert float((m1 - m2).abs().max()) <= 2 ** -8 * float(m2.abs().max())          # bf16 rounding of the mean
-    for a, c, tol in ((dx1, dx2, 3e-3), (dg1, dg2, 3e-3), (db1, db2, 3e-3)):
+    (q1, m1, dx1, dg1, db1, dw1), (q2, m2, dx2, dg2, db2, dw2) = res
+    assert torch.equal(q1, q2) and float(q1[:, :pad].abs().max() if pad else 0.0) == 0.0        # the same products on the same rows
+    assert float((m1 - m2).abs().max()) <= 2 ** -6 * float(m2.abs().max())          # mean rounded to bf16 before the projection, not after
+    for a, c, tol in ((dx1, dx2, 6e-3), (dg1, dg2, 6e-3), (db1, db2, 6e-3), (dw1, dw2, 6e-3)):
         assert float((a - c).norm()) <= tol * float(c.norm()), (float((a - c).norm()), float(c.norm()))
 
 
 def test_whole_model_landmarks_from_layernorm_means_equal_the_landmark_kernels():
-    """bf16 policy, train mode, D = 512: landmarks as to_qkv(group means of the LayerNorm output) (Fn._LM_ALGEBRA) against
+    """bf16 policy, train mode, D = 512: landmarks as to_qkv(group means of the LayerNorm output) (Fn.NormQkvLmFn) against
     the landmark kernels on q | k.  Algebraically identical ([3P] to_qkv is linear and bias-free); numerically the mean is
     rounded to bf16 before the projection instead of after it: losses within 2e-3, parameter gradients cosine >= 0.99 (the
     small bias vectors of the heads are the noisiest: 0.996 measured)."""
@@ -233,10 +242,10 @@ def test_whole_model_landmarks_from_layernorm_means_equal_the_landmark_kernels()
     noise = {"wsi_mask": torch.rand(2, 1024, generator=g).cuda(), "rna_mask": torch.rand(2, 512, generator=g).cuda(),
              "wsi_eps": torch.randn(2, 32, generator=g).cuda(), "rna_eps": torch.randn(2, 32, generator=g).cuda()}
     out = []
-    was = Fn._LM_ALGEBRA
+    was = Fn._LM_ROWS
     try:
         for on in (True, False):
-            Fn._LM_ALGEBRA = on
+            Fn._LM_ROWS = on
             torch.manual_seed(0)
             model = M.mirror(**cfg).cuda().train()
             model.precision = "bf16"
@@ -246,7 +255,7 @@ def test_whole_model_landmarks_from_layernorm_means_equal_the_landmark_kernels()
             torch.cuda.synchronize()
             out.append(([float(x) for x in losses], {k: p.grad.detach().clone() for k, p in model.named_parameters()}))
     finally:
-        Fn._LM_ALGEBRA = was
+        Fn._LM_ROWS = was
     (l1, g1), (l2, g2) = out
     for a, c in zip(l1, l2):
         assert abs(a - c) <= 2e-3 * max(abs(c), 1e-3), (l1, l2)
