@@ -132,6 +132,9 @@ int mh_gemm(const mh_gemm_desc* d, mh_stream s);
  * ping-pong kernel, the default; 1 = the same, one workgroup per tile; 0 = register-staged kernel; env MH_GEMM_PP selects one
  * at start; mode < 0 only queries).  Results are identical up to the f32 summation order of split-K.  Returns the previous value. */
 int mh_gemm_select_pp(int mode);
+/* The kernel instance the calling thread's last mh_gemm call launched (e.g. "gemm_pq_kernel<float,false,false,part>",
+ * "gemm_kernel<1,bf16,bf16,float,true,false,2,2,1>"): lets a profiler name launches without restating the dispatch rules. */
+const char* mh_gemm_variant_name(void);
 /* Bytes of `workspace` with which this call reduces through plain partial tiles + a fold pass instead of f32 atomics
  * (0: the call has no use for one — no split-K / batch broadcast, or the shape is not on the large-tile kernel). */
 int64_t mh_gemm_workspace_bytes(const mh_gemm_desc* d);
@@ -296,7 +299,8 @@ int mh_nys_dz_dav(const float* dw2, const float* av, const void* zfT, void* up, 
 int mh_pinv_chain_bwd(const void* XP, const void* saved, const void* dzf, void* work, float* dX, float* dz0, int BH, int m,
                       int iters, mh_stream s);
 /* Bytes of the chain's caller-allocated buffers: which = 0: `saved` (forward output, backward input: [iters, 4, BH, m, m]
- * bf16 = the iterates z_k, P_k, T2_k, T3_k); which = 1: `work` (backward scratch, same size). */
+ * bf16 = the iterates z_k, P_k, T2_k, T3_k); which = 1: `work` (backward scratch: [iters + 4, BH, m, m] bf16 = W_k of every
+ * iteration for dX, and four slots of per-iteration temporaries). */
 int64_t mh_pinv_chain_workspace_bytes(int BH, int m, int iters, int which);
 /* Fused attention sides of the Nystrom core (bf16 policy, dh = 64, m = 256 landmarks; anything else returns
  * MH_EINVAL and the caller composes mh_gemm + mh_softmax).  The [n_p x m] / [m x n_p] similarity matrices stay in MFMA

@@ -180,7 +180,7 @@ _SIGS = {
     "mh_loss_terms_fwd": [C.POINTER(LossTermsDesc)],
     "mh_loss_terms_bwd": [C.POINTER(LossTermsDesc)],
 }
-EXPORTS = sorted(list(_SIGS) + ["mh_last_error", "mh_version", "mh_exp_build", "mh_gemm_select_pp", "mh_device_ok", "mh_nys_attn3_ws_floats", "mh_rna_block_workspace_bytes",
+EXPORTS = sorted(list(_SIGS) + ["mh_last_error", "mh_version", "mh_exp_build", "mh_gemm_select_pp", "mh_gemm_variant_name", "mh_device_ok", "mh_nys_attn3_ws_floats", "mh_rna_block_workspace_bytes",
                                  "mh_gemm_workspace_bytes", "mh_layernorm_bwd_workspace_bytes", "mh_nys_attn3_workspace_bytes",
                                  "mh_pinv_chain_workspace_bytes"])
 
@@ -205,6 +205,8 @@ def load() -> C.CDLL:
     lib.mh_last_error.argtypes = []
     lib.mh_version.restype = C.c_int
     lib.mh_exp_build.restype = C.c_int
+    lib.mh_gemm_variant_name.restype = C.c_char_p
+    lib.mh_gemm_variant_name.argtypes = []
     lib.mh_gemm_select_pp.restype = C.c_int
     lib.mh_gemm_select_pp.argtypes = [C.c_int]
     lib.mh_device_ok.restype = C.c_int

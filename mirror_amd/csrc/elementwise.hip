@@ -321,7 +321,7 @@ extern "C" int mh_dropout_lite_colsum(const float* x, void* y, int64_t rows, int
     MH_REQUIRE(N >= 8 && N % 8 == 0 && N <= 2048 && 256 % (N / 8) == 0 && (offset & 7) == 0, "mh_dropout_lite_colsum: N=%d needs N %% 8 == 0 and 256 %% (N / 8) == 0", N);
     MH_REQUIRE(db && (((uintptr_t)x | (uintptr_t)y) & 15) == 0, "mh_dropout_lite_colsum: aligned buffers and a bias-gradient destination");
     if (rows == 0) return MH_OK;
-    static const int rows_per_wg = [] { const char* e = getenv("MH_DROPCS_ROWS"); return e ? atoi(e) : 192; }();      // rows per workgroup: 8 in flight per thread, one coalesced atomic per column and workgroup (64: 46 us, 128: 38, 192: 36, 512: 44; the two launches: 47)
+    constexpr int rows_per_wg = 192;      // rows per workgroup: 8 in flight per thread, one coalesced atomic per column and workgroup (64: 46 us, 128: 38, 192: 36, 512: 44; the two launches: 47)
     hipLaunchKernelGGL(dropout8_colsum_kernel, dim3((unsigned)mh_cdiv(rows, rows_per_wg)), dim3(256), 0, (hipStream_t)s, x, (bf16_t*)y, (long)rows, N,
                        rows_per_wg, p, seed, offset, dev_base, db);
     MH_LAUNCH_CHECK("mh_dropout_lite_colsum");

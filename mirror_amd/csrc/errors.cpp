@@ -14,6 +14,17 @@ void mh_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* mh_last_error(void) { return g_err; }
+
+// The kernel instance the calling thread's last mh_gemm launched ("gemm_pq_kernel<float,false,false,part>", ...): the launch sites
+// record it, so profilers name launches without restating the dispatch rules (mh_gemm_variant_name)
+static thread_local char g_variant[160] = "";
+void gemm_note_variant(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_variant, sizeof(g_variant), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* mh_gemm_variant_name(void) { return g_variant; }
 extern "C" int mh_version(void) { return 105; }   // 105 (round 4): lm_ld of the mh_nys_* entry points, mh_lm_merge, gadd in dy's dtype, xpm optional;   // 104 (round 3): mh_gemm_desc.epi / row windows, mh_layernorm_fwd_lm(xpm_bf16), mh_skinny_fwd(dt_x, dt_y), mh_pinv_chain_fwd(z0f, stats64), new entry points
 
 // 1 when the library was built with -DMH_EXP (make EXP=1): the timing-experiment switches (MH_EXP_CHAIN_SKIP, and MH_EXP_SKIP

@@ -167,7 +167,7 @@ extern "C" int mh_gemm(const mh_gemm_desc* d, mh_stream stream) {
         // offer the remainder to the main launch's fold pass (gemm_big.hip: partial tiles + fold): one launch less when it takes it
         GemmTail* pt = gemm_pending_tail();
         pt->KT = 0;
-        static const bool merge = [] { const char* e = getenv("MH_GEMM_TAIL_FOLD"); return !(e && e[0] == '0'); }();      // A/B switch
+        constexpr bool merge = true;
         if (merge && m.accumulate && rank_update_ok(&t)) {
             const int batch_t = t.batch1 * t.batch2;
             *pt = GemmTail{t.A, t.B, (long)t.lda, t.batch1 > 1 ? (long)t.sA1 : (long)t.sA2, (long)t.ldb, t.batch1 > 1 ? (long)t.sB1 : (long)t.sB2,

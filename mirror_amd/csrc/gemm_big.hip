@@ -1181,16 +1181,9 @@ static int pp_mode() {
     return g_pp;
 }
 static bool pp_enabled() { return pp_mode() != 0; }
-static int pq_grid(long units, int shared = 0) {
+static int pq_grid(long units) {
     static const int cus = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
-    // beside the half-chip chain (mh_gemm_desc.shared_chip) the persistent kernel takes the OTHER half: 128 workgroups + the chain's
-    // 128 are one per CU in whatever order they arrive (MH_PQ_SHARED=0: the one-workgroup-per-tile kernel there, as before)
-    const int n = shared ? cus / 2 : cus;
-    return (int)(units < n ? units : n);
-}
-static bool pq_shared() {
-    static const bool on = [] { const char* e = getenv("MH_PQ_SHARED"); return e && e[0] == '1'; }();
-    return on;
+    return (int)(units < cus ? units : cus);
 }
 template <typename K>
 static void pp_attr(K kern) {
@@ -1198,11 +1191,13 @@ static void pp_attr(K kern) {
 }
 #define PP_LAUNCH_(TC, AKC, BKC, PART, EPI, grid, s, a)                                              \
     do {                                                                                             \
-        if (pp_mode() == 2 && (!(a).shared_chip || pq_shared())) {                                   \
+        gemm_note_variant("%s<%s,%s,%s%s%s>", (pp_mode() == 2 && !(a).shared_chip) ? "gemm_pq_kernel" : "gemm_pp_kernel", gemm_tn<TC>(), \
+                          gemm_tf(AKC), gemm_tf(BKC), (PART) ? ",part" : "", (EPI) == 0 ? "" : ((EPI) == 1 ? ",epi1" : ((EPI) == 2 ? ",epi2" : ",epi3"))); \
+        if (pp_mode() == 2 && !(a).shared_chip) {                                                    \
             static const bool attrq_ = (pp_attr(gemm_pq_kernel<TC, AKC, BKC, PART, EPI>), true);     \
             (void)attrq_;                                                                            \
             const long units_ = (long)(grid).x * (grid).y * (grid).z;                                \
-            hipLaunchKernelGGL((gemm_pq_kernel<TC, AKC, BKC, PART, EPI>), dim3(pq_grid(units_, (a).shared_chip)), dim3(NTB), PQ_LDS, s, a, (int)units_, \
+            hipLaunchKernelGGL((gemm_pq_kernel<TC, AKC, BKC, PART, EPI>), dim3(pq_grid(units_)), dim3(NTB), PQ_LDS, s, a, (int)units_, \
                                (int)(grid).x, (int)(grid).y);                                        \
         } else {                                                                                     \
             static const bool attr_ = (pp_attr(gemm_pp_kernel<TC, AKC, BKC, PART, EPI>), true);      \
@@ -1240,6 +1235,7 @@ void launch_big(GemmArgs& a, int akc, int bkc, int batch, hipStream_t s) {
         return;
     }
     // reduction into one C: partial tiles in the caller's workspace when it is large enough, f32 atomics otherwise
+    gemm_note_variant("gemm_big_kernel<%s,%s,%s>", gemm_tn<TC>(), gemm_tf(akc), gemm_tf(bkc));
     const long parts = (long)a.split_k * batch, mn = (long)a.M * a.N;
     const bool partial = a.atomic && a.ws && a.M % BIG == 0 && a.ws_floats >= parts * mn && ((uintptr_t)a.ws & 15) == 0 && a.vecC &&
                          a.sC1 == 0 && a.sC2 == 0 && parts >= 8;
@@ -1278,6 +1274,7 @@ bool gemm_try_big_fp8(GemmArgs& a, int dtC, int batch, hipStream_t s) {
     a.tiles_m = (a.M + BIG - 1) / BIG;
     a.tiles_n = a.N / BIG;
     dim3 grid(a.tiles_m * a.tiles_n, 1, batch);
+    gemm_note_variant("gemm_big_kernel<%s,true,true,fp8>", dtC == MH_BF16 ? "bf16" : "float");
     if (dtC == MH_BF16) hipLaunchKernelGGL((gemm_big_kernel<bf16_t, true, true, true>), grid, dim3(NTB), 0, s, a);
     else hipLaunchKernelGGL((gemm_big_kernel<float, true, true, true>), grid, dim3(NTB), 0, s, a);
     return true;

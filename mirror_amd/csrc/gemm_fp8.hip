@@ -213,7 +213,7 @@ extern "C" int mh_gemm_fp8(const void* A, int64_t lda, int64_t a_bs, const void*
     MH_REQUIRE(lda % 16 == 0 && ldb % 16 == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0, "mh_gemm_fp8: operands must be 16-byte aligned");
     MH_REQUIRE(act == MH_ACT_NONE || act == MH_ACT_RELU, "mh_gemm_fp8: activation %d unsupported", act);
     // the large-tile pipeline (v_mfma_scale_f32_32x32x64_f8f6f4: twice the bf16 MFMA rate) when the shape fits it
-    if (K % 128 == 0 && N % 256 == 0 && lda % 2 == 0 && ldb % 2 == 0 && a_bs % 2 == 0 && getenv("MH_FP8_SMALL") == nullptr) {
+    if (K % 128 == 0 && N % 256 == 0 && lda % 2 == 0 && ldb % 2 == 0 && a_bs % 2 == 0) {
         GemmArgs a = {};
         a.A = A; a.B = B; a.C = C; a.bias = bias;
         a.M = M; a.N = N; a.K = K / 2;

@@ -32,6 +32,9 @@ struct GemmTail {
     int KT, batch, a_f32, b_f32;
     float alpha;
 };
+void gemm_note_variant(const char* fmt, ...);      // errors.cpp: names the instance a launch site picked (mh_gemm_variant_name)
+template <typename T> inline const char* gemm_tn() { return sizeof(T) == 4 ? "float" : "bf16"; }
+inline const char* gemm_tf(bool b) { return b ? "true" : "false"; }
 GemmTail* gemm_pending_tail();       // the tail mh_gemm offers to the next fold launch (KT == 0: none); the fold clears it when it takes it
 
 struct GemmArgs {
@@ -430,7 +433,7 @@ static void launch_w(GemmArgs& a, int batch, hipStream_t s) {
     constexpr int BK = MMA ? 64 : 16;
     // 128 x 64 tiles for N <= 64 -- and for launches that would leave more than a third of the CUs without a 128 x 128 tile
     // (the row remainders of the big-tile split: 4096 x 512 is 128 tiles, 256 half tiles finish in ~60 % of the time)
-    static const bool fill = [] { const char* e = getenv("MH_GEMM_HALF_TILES"); return !(e && e[0] == '0'); }();   // A/B switch
+    constexpr bool fill = true;
     const long wide_wgs = (long)mh_cdiv(a.M, 128) * mh_cdiv(a.N, 128) * a.split_k * batch;
     const bool narrow = a.N <= 64 || (fill && MMA == 1 && wide_wgs <= 160 && a.N % 64 == 0 && a.M >= 1024);
     const int BN = narrow ? 64 : 128;
@@ -447,6 +450,8 @@ static void launch_w(GemmArgs& a, int batch, hipStream_t s) {
     const bool ntail = MMA == 1 && !narrow && a.vecA && a.vecB && a.M % 128 == 0 && a.N % BN != 0 && a.N < BN && a.N % VMAX == 0 &&
                        a.K % BK == 0 && a.k_per_split % BK == 0 && a.K % a.k_per_split == 0;
     dim3 grid(a.tiles_m * a.tiles_n, a.split_k, batch);
+    gemm_note_variant("gemm_kernel<%d,%s,%s,%s,%s,%s,2,%d,%d>", MMA, gemm_tn<TA>(), gemm_tn<TB>(), MMA ? gemm_tn<TC>() : "float", gemm_tf(AKC), gemm_tf(BKC),
+                      narrow ? 1 : 2, full ? 1 : ((!narrow && MMA == 1 && sizeof(TA) == 2 && sizeof(TB) == 2) ? (ktail ? 2 : (ntail ? 3 : 0)) : 0));
     if (narrow) {
         if (full) hipLaunchKernelGGL((gemm_kernel<MMA, TA, TB, TC, AKC, BKC, 2, 1, 1>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((gemm_kernel<MMA, TA, TB, TC, AKC, BKC, 2, 1, 0>), grid, dim3(256), 0, s, a);

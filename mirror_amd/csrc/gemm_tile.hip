@@ -234,8 +234,7 @@ __global__ __launch_bounds__(NTT) void gemm_tile_kernel(GemmArgs g, bf16_t* __re
 
 // true when the tile kernel took the launch (bf16 operands only; no bias / activation / split-K)
 bool gemm_try_tile384(GemmArgs& a, int akc, int bkc, int dtC, int batch, void* c2, int r_bf16, hipStream_t s) {
-    static const bool on = [] { const char* e = getenv("MH_GEMM_TILE384"); return !(e && e[0] == '0'); }();
-    const bool ok = on && a.M % TM == 0 && a.N % TN == 0 && a.K % 8 == 0 && a.split_k == 1 && !a.atomic && !a.bias &&
+    const bool ok = a.M % TM == 0 && a.N % TN == 0 && a.K % 8 == 0 && a.split_k == 1 && !a.atomic && !a.bias &&
                     a.act == MH_ACT_NONE && a.vecA && a.vecB && a.vecC && !(akc == 0 && bkc == 1);
     if (!ok) return false;
     if (a.row_softmax && !(a.N == TN && dtC == MH_BF16 && (a.row_softmax == 2) == (a.R != nullptr) && !a.accumulate && a.diag == 0.f && !c2)) return false;
@@ -244,7 +243,8 @@ bool gemm_try_tile384(GemmArgs& a, int akc, int bkc, int dtC, int batch, void* c
     a.tiles_m = a.M / TM;
     a.tiles_n = a.N / TN;
     dim3 grid(a.tiles_m * a.tiles_n, 1, batch);
-#define TILE_(TC, AK, BK_) hipLaunchKernelGGL((gemm_tile_kernel<TC, AK, BK_>), grid, dim3(NTT), 0, s, a, (bf16_t*)c2, r_bf16)
+#define TILE_(TC, AK, BK_) do { gemm_note_variant("gemm_tile_kernel<%s,%s,%s>", gemm_tn<TC>(), gemm_tf(AK), gemm_tf(BK_)); \
+        hipLaunchKernelGGL((gemm_tile_kernel<TC, AK, BK_>), grid, dim3(NTT), 0, s, a, (bf16_t*)c2, r_bf16); } while (0)
     if (dtC == MH_BF16) {
         if (akc && bkc) TILE_(bf16_t, true, true); else if (akc) TILE_(bf16_t, true, false); else TILE_(bf16_t, false, false);
     } else {

@@ -606,7 +606,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_fold_kernel(const float* __
     atomicAdd(t < D ? dgamma + t : dbeta + (t - D), s);
 }
 
-static int ln_bwd_blocks() { static const int n = [] { const char* e = getenv("MH_LN_BWD_BLOCKS"); return e ? atoi(e) : 512; }(); return n; }
+static int ln_bwd_blocks() { return 512; }
 
 extern "C" int64_t mh_layernorm_bwd_workspace_bytes(int64_t rows, int D) {
     if (rows < 64 || D <= 0) return 0;

@@ -9,7 +9,7 @@ bool resconv_try_mfma(const void* v, long ldv, long v_bs, const float* w, void* 
                       int dh, int taps, int transpose, int accumulate, int dt_v, int dt_o, hipStream_t s);
 bool resconv_wgrad_try_mfma(const void* v, long ldv, long v_bs, const void* dout, long ldo, long o_bs, float* dw, int B, int n_p,
                             int heads, int dh, int taps, int dt_v, int dt_o, hipStream_t s);
-static bool resconv_mfma_on() { static const bool on = [] { const char* e = getenv("MH_RESCONV_MFMA"); return !(e && e[0] == '0'); }(); return on; }
+static bool resconv_mfma_on() { return true; }
 
 // ------------------------------------------------------------------ landmarks
 // lm[b, j, c] = (1/l) sum_t qkv[b, j*l + t, c], c < 2D (q and k column blocks)

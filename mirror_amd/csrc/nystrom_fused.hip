@@ -916,9 +916,6 @@ __global__ __launch_bounds__(NT) void nys_a3_bwd_dql_kernel(const bf16_t* __rest
 // workgroups per (b, h) of the sequence-walking N kernels: enough to put two workgroups on every CU (the landmark images
 // take 72 KB of LDS each), never more than one 32-row block per wave
 int pick_walkers(int BH, int n_p) {
-    static const char* env = getenv("MH_NYS_WALKERS");      // timing experiments: "max" = one 128-row tile per workgroup
-    if (env && env[0] == 'm') return n_p / TR;
-    if (env && atoi(env) > 0) return min(atoi(env), max(1, n_p / 128));
     int w = 1;
     while (BH * w < 512 && 4 * w * 2 <= n_p / 32) w *= 2;
     return w;
@@ -1004,14 +1001,6 @@ extern "C" int mh_nys_attn3_fwd(const void* qkv, const void* lm, float* av, floa
 // One workgroup per CU in all (B h x splits ~ 256): measured in the step at B h = 128, 2 ranges per (b, h) beat 4 by 1.7 %
 // (half the partial tiles / atomics, and these launches run beside the half-chip chain) and 1 by 1.2 %.
 int pick_splits(int BH, int ntiles, int which) {
-    static const char* env = getenv("MH_NYS_SPLITS");       // timing experiments: force the number of sequence ranges ("a,b,c" per kernel)
-    if (env && atoi(env) > 0) {
-        int v[3] = {atoi(env), 0, 0};
-        const char* p = env;
-        for (int i = 1; i < 3; i++) { p = strchr(p, ','); if (!p) break; v[i] = atoi(++p); }
-        const int f = v[which] > 0 ? v[which] : v[0];
-        return min(f, ntiles);
-    }
     int splits = 1;
     while (BH * splits < 256 && splits * 2 <= ntiles) splits *= 2;
     return splits;

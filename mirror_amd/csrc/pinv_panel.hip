@@ -41,21 +41,9 @@ constexpr int NJ = 2;          // 32-column blocks per wave
 constexpr int NCH = CM * CM / 8 / CT;   // 16-byte chunks per thread in a row copy
 constexpr long MAT = (long)CM * CM;
 constexpr int IMG = CM * CM * 2;
-// Optional (MH_CHAIN_CLAIM=1): claim the CU's whole 160 KiB of LDS so that no LDS-using workgroup of the main stream
-// shares the chain's SIMDs.  Measured neutral on the full step (the co-running kernels simply take twice as long on the
-// other half of the chip: what the chain costs is its CU-time), so it is off by default.
-constexpr int LDS_CLAIM = 160 * 1024;
-// MH_CHAIN_Q=1: the z_k-only kernels (row-quarter accumulators, three register panels) for BOTH passes; they share the saved / work
-// buffers of the kernels below but fill them differently, so the switch is read once per process
-static bool chain_q() {
-    static const bool on = [] { const char* e = getenv("MH_CHAIN_Q"); return e && e[0] == '1'; }();
-    return on;
-}
-static int chain_claim_bytes() {
-    static const int n = [] { const char* e = getenv("MH_CHAIN_CLAIM"); return (e && e[0] == '1') ? LDS_CLAIM - IMG : 0; }();
-    return n;
-}
-
+// (Measured and removed in round 4, DESIGN.md section 6: claiming the CU's whole 160 KiB of LDS - neutral; the z_k-only kernels with
+//  row-quarter accumulators and three register panels - forward 204 us, backward 708 us against 231 / 458: fewer bytes, more time;
+//  image fills whose first half is requested before the barrier - 471 vs 466 us; the round-1 backward kernel without panel prefetch - 496.)
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
@@ -356,40 +344,10 @@ __device__ __forceinline__ void image_from_global(char* img, const bf16_t* __res
         }
     }
 }
-// image_from_global in two halves whose first global batch is requested BEFORE the barrier that frees the image (the fragment
-// registers of the product that just ended are dead by then): the HBM latency of half of every image fill overlaps the barrier wait.
-__device__ __forceinline__ void image_ld16(u32x4 (&r)[16], const bf16_t* __restrict__ G, int tid, int n0) {
-    asm volatile("" : "+v"(tid));
-#pragma unroll
-    for (int n = 0; n < 16; n++) r[n] = *reinterpret_cast<const u32x4*>(G + ((long)(tid + CT * (n0 + n)) << 3));
-}
-template <int N0>
-__device__ __forceinline__ void image_st16(char* img, const u32x4 (&r)[16], int tid) {
-    asm volatile("" : "+v"(tid));
-    const int lane = tid & 63, c = lane & 31, hl = lane >> 5, s = swz(c), tw = tid >> 6;
-#pragma unroll
-    for (int n = 0; n < 16; n++) {
-        const int jblk = (N0 + n) >> 2, T = tw + 4 * ((N0 + n) & 3);
-        char* row = img + (32 * jblk + c) * 512;
-        *reinterpret_cast<u32x2*>(row + (((4 * T + hl) ^ s) << 3)) = u32x2{r[n][0], r[n][1]};
-        *reinterpret_cast<u32x2*>(row + (((4 * T + 2 + hl) ^ s) << 3)) = u32x2{r[n][2], r[n][3]};
-    }
-}
 // ... __syncthreads() on both sides included
-template <bool EARLY>
 __device__ __forceinline__ void image_swap(char* img, const bf16_t* __restrict__ G, int tid) {
-    if constexpr (!EARLY) {
-        __syncthreads();
-        image_from_global<16>(img, G, tid);
-        __syncthreads();
-        return;
-    }
-    u32x4 r[16];
-    image_ld16(r, G, tid, 0);
     __syncthreads();
-    image_st16<0>(img, r, tid);
-    image_ld16(r, G, tid, 16);
-    image_st16<16>(img, r, tid);
+    image_from_global<16>(img, G, tid);
     __syncthreads();
 }
 // LDS image -> column-major HBM matrix G[j][i] (row copy, coalesced): the form the caller's GEMMs read
@@ -489,117 +447,13 @@ __global__ __launch_bounds__(CT) void pinv_panel_fwd_kernel(const bf16_t* __rest
     image_to_global(img, zfT + bh * MAT, tid);
 }
 
-// --------------------------------------------------------------------------------------------------------- backward
-// dzf = PN(U), U = (d z_iters)^T;  work[k] = PN{V3, V2, 4 W, U_k};
-// dX (f32, row-major) = sum_k dP_k z_k^T;  dz0 (f32, row-major) = d z_0
-__global__ __launch_bounds__(CT) void pinv_panel_bwd_kernel(const bf16_t* __restrict__ XT, const bf16_t* __restrict__ saved,
-                                                            const bf16_t* __restrict__ dzf, bf16_t* __restrict__ work,
-                                                            float* __restrict__ dX, float* __restrict__ dz0, int BH, int iters) {
-    __shared__ __attribute__((aligned(16))) char img[IMG];
-    const int tid = threadIdx.x, lane = tid & 63, hl = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: panel addresses become SGPR base + one VGPR
-    const int j = 64 * wave + (lane & 31);
-    const int bh = blockIdx.x;
-    const int dreg = (hl == ((lane >> 2) & 1)) ? ((((lane & 31) >> 3) << 2) | (lane & 3)) : -1;
-    unsigned rlo[2][4], rhi[2][4];
-    read_bases(rlo, rhi, lane);
-    const bf16_t* Xb = XT + bh * MAT;
-    f32x16 acc[8][NJ];
-    bf16x8 p[16][NJ];       // one panel at a time besides the accumulators: reload from HBM (coalesced) rather than hold
-    const bf16_t* U = dzf + bh * MAT;
-    image_from_global<16>(img, U, tid);
-    __syncthreads();
-#pragma unroll 1
-    for (int k = iters - 1; k >= 0; k--) {
-        const bf16_t* sb = saved + ((long)k * 4 * BH + bh) * MAT;
-        const bf16_t* Z = sb;
-        const bf16_t* P = sb + (long)BH * MAT;
-        const bf16_t* T2 = sb + 2L * BH * MAT;
-        const bf16_t* T3 = sb + 3L * BH * MAT;
-        bf16_t* wb = work + ((long)k * 4 * BH + bh) * MAT;
-        bf16_t* V3 = wb;
-        bf16_t* V2 = wb + (long)BH * MAT;
-        bf16_t* W = wb + 2L * BH * MAT;
-        bf16_t* Un = wb + 3L * BH * MAT;
-        // V3 = 1/4 U Z                                                   (image: U)
-        load_panel(p, Z, wave, lane);
-        panel_gemm<true>(acc, img, rlo, rhi, p);
-        finish<false>(acc, 0.25f, 0.f, p, 0.f, p, wave, dreg);
-        store_panel(V3, p, wave, lane);
-        __syncthreads();
-        image_from_panel(img, p, j, hl);
-        __syncthreads();
-        // V2 = -V3 P                                                     (image: V3)
-        load_panel(p, P, wave, lane);
-        panel_gemm<true>(acc, img, rlo, rhi, p);
-        finish<false>(acc, -1.f, 0.f, p, 0.f, p, wave, dreg);
-        store_panel(V2, p, wave, lane);
-        __syncthreads();
-        image_from_panel(img, p, j, hl);
-        __syncthreads();
-        // W = V2 P - 7 V2 + P V2 - T2 V3
-        load_panel(p, P, wave, lane);
-        panel_gemm<true>(acc, img, rlo, rhi, p);                                // V2 P   (image: V2, panel: P)
-        publish();                                                         // V3 / V2 stores of this step are visible
-        image_from_global<16>(img, P, tid);
-        load_panel(p, V2, wave, lane);
-        __syncthreads();
-        panel_gemm<false>(acc, img, rlo, rhi, p);                                // + P V2 (image: P, panel: V2)
-        __syncthreads();
-        image_from_global<16>(img, T2, tid);
-        load_panel(p, V3, wave, lane);
-        negate_panel(p);
-        __syncthreads();
-        panel_gemm<false>(acc, img, rlo, rhi, p);                                // - T2 V3
-        // the - 7 V2 term rides on the epilogue (V2's panel comes back from L2: 64 KB per workgroup) instead of a VALU
-        // pass over the 256 accumulator registers in the middle of the phase, which also kept V2 alive across an image fill
-        // ... and W is kept as 4 W (exact in bf16): U' = W X + 1/4 T3 U = 1/4 (4W X + T3 U) then needs no rescaling of the 256
-        // accumulators between its two products, and dX = sum Z (4W) takes its 1/4 at the final store
-        load_panel(p, V2, wave, lane);
-        finish<true>(acc, 4.f, 0.f, p, -28.f, p, wave, dreg);
-        store_panel(W, p, wave, lane);
-        __syncthreads();
-        image_from_panel(img, p, j, hl);
-        __syncthreads();
-        // U' = W X + 1/4 T3 U  =  1/4 (4 W X + T3 U)
-        load_panel(p, Xb, wave, lane);
-        panel_gemm<true>(acc, img, rlo, rhi, p);                                // 4W X   (image: 4W, panel: X)
-        publish();                                                         // U stores of the previous step are visible
-        image_from_global<16>(img, T3, tid);
-        load_panel(p, U, wave, lane);
-        __syncthreads();
-        panel_gemm<false>(acc, img, rlo, rhi, p);                                // + T3 U
-        finish<false>(acc, 0.25f, 0.f, p, 0.f, p, wave, dreg);
-        store_panel(Un, p, wave, lane);
-        if (k == 0) store_f32(dz0 + bh * MAT, acc, 0.25f, j, hl);
-        __syncthreads();
-        image_from_panel(img, p, j, hl);                                  // next step's U
-        __syncthreads();
-        U = Un;
-    }
-    // dX^T = sum_k Z_k W_k
-    publish();
-    zero_acc(acc);
-#pragma unroll 1
-    for (int k = 0; k < iters; k++) {
-        const bf16_t* Z = saved + ((long)k * 4 * BH + bh) * MAT;
-        const bf16_t* W = work + ((long)k * 4 * BH + bh) * MAT + 2L * BH * MAT;
-        __syncthreads();
-        image_from_global<16>(img, Z, tid);
-        load_panel(p, W, wave, lane);
-        __syncthreads();
-        panel_gemm<false>(acc, img, rlo, rhi, p);
-    }
-    store_f32(dX + bh * MAT, acc, 0.25f, j, hl);      // the panels hold 4 W
-}
 
 // --------------------------------------------------------------------------------- backward, B panels requested a product ahead
-// Same algebra, same saved / work layout and the same 48 + 6 products as pinv_panel_bwd_kernel.  What changes is where results go
+// Same algebra, same saved / work layout and the same 48 + 6 products as the round-1 backward kernel.  What changes is where results go
 // and when operands arrive: a product's result leaves the accumulators for HBM + the LDS image directly (finish_out), so the panel
 // registers are free to receive the NEXT product's B operand entry by entry behind this product's k sweep (panel_gemm<.., PF>), and a
 // B operand that two consecutive products share (P in V2 = -V3 P and V2 P) is loaded once.  Of the 8 panel loads per iteration that
 // stood exposed in front of their product, one is left (X, after the epilogue that still needs V2 in the panel registers).
-template <bool EARLY>
 __global__ __launch_bounds__(CT) void pinv_panel_bwd2_kernel(const bf16_t* __restrict__ XT, const bf16_t* __restrict__ saved,
                                                              const bf16_t* __restrict__ dzf, bf16_t* __restrict__ work,
                                                              float* __restrict__ dX, float* __restrict__ dz0, int BH, int iters) {
@@ -625,11 +479,12 @@ __global__ __launch_bounds__(CT) void pinv_panel_bwd2_kernel(const bf16_t* __res
         const bf16_t* T2 = sb + 2L * BH * MAT;
         const bf16_t* T3 = sb + 3L * BH * MAT;
         const bf16_t* Zn = saved + ((long)(k > 0 ? k - 1 : 0) * 4 * BH + bh) * MAT;         // next iteration's Z (k == 0: a harmless reload)
-        bf16_t* wb = work + ((long)k * 4 * BH + bh) * MAT;
-        bf16_t* V3 = wb;
-        bf16_t* V2 = wb + (long)BH * MAT;
-        bf16_t* W = wb + 2L * BH * MAT;
-        bf16_t* Un = wb + 3L * BH * MAT;
+        // work = [iters + 4][BH] matrices: W_k (kept for dX below) in slot k, then V3, V2 (temporaries of one iteration) and two slots for
+        // U' (written in iteration k, read as U in iteration k - 1)
+        bf16_t* W = work + ((long)k * BH + bh) * MAT;
+        bf16_t* V3 = work + ((long)iters * BH + bh) * MAT;
+        bf16_t* V2 = work + ((long)(iters + 1) * BH + bh) * MAT;
+        bf16_t* Un = work + ((long)(iters + 2 + (k & 1)) * BH + bh) * MAT;
         // V3 = 1/4 U Z                                  (image U, panel Z; P arrives behind the sweep)
         panel_gemm<true, true>(acc, img, rlo, rhi, p, P, wave, lane);
         __syncthreads();
@@ -642,18 +497,18 @@ __global__ __launch_bounds__(CT) void pinv_panel_bwd2_kernel(const bf16_t* __res
         __syncthreads();
         // W = V2 P - 7 V2 + P V2 - T2 V3
         panel_gemm<true, true>(acc, img, rlo, rhi, p, V2, wave, lane);                    // V2 P   (image V2, panel P; V2's panel arrives: own stores)
-        image_swap<EARLY>(img, P, tid);
+        image_swap(img, P, tid);
         panel_gemm<false, true>(acc, img, rlo, rhi, p, V3, wave, lane);                   // + P V2 (image P, panel V2; V3 arrives)
         negate_panel(p);
-        image_swap<EARLY>(img, T2, tid);
+        image_swap(img, T2, tid);
         panel_gemm<false, true>(acc, img, rlo, rhi, p, V2, wave, lane);                   // - T2 V3 (image T2, panel -V3; V2 arrives for the epilogue)
         __syncthreads();
-        finish_out<true>(acc, 4.f, 0.f, p, -28.f, W, img, wave, dreg, j, hl, lane);        // 4 W (exact in bf16: see pinv_panel_bwd_kernel)
+        finish_out<true>(acc, 4.f, 0.f, p, -28.f, W, img, wave, dreg, j, hl, lane);        // 4 W (exact in bf16)
         load_panel(p, Xb, wave, lane);                                                    // the one panel load left in front of its product
         __syncthreads();
         // U' = 1/4 (4W X + T3 U)
         panel_gemm<true, true>(acc, img, rlo, rhi, p, U, wave, lane);                     // 4W X   (image 4W, panel X; U arrives)
-        image_swap<EARLY>(img, T3, tid);
+        image_swap(img, T3, tid);
         panel_gemm<false, false>(acc, img, rlo, rhi, p);                                  // + T3 U (image T3, panel U)
         __syncthreads();
         finish_out<false>(acc, 0.25f, 0.f, p, 0.f, Un, img, wave, dreg, j, hl, lane);
@@ -665,367 +520,17 @@ __global__ __launch_bounds__(CT) void pinv_panel_bwd2_kernel(const bf16_t* __res
     }
     // dX^T = sum_k Z_k W_k
     zero_acc(acc);
-    load_panel(p, work + ((long)bh) * MAT + 2L * BH * MAT, wave, lane);                     // W_0 (own stores)
+    load_panel(p, work + ((long)bh) * MAT, wave, lane);                                     // W_0 (own stores)
 #pragma unroll 1
     for (int k = 0; k < iters; k++) {
         const bf16_t* Z = saved + ((long)k * 4 * BH + bh) * MAT;
-        const bf16_t* Wn = work + ((long)(k + 1 < iters ? k + 1 : k) * 4 * BH + bh) * MAT + 2L * BH * MAT;
-        image_swap<EARLY>(img, Z, tid);
+        const bf16_t* Wn = work + ((long)(k + 1 < iters ? k + 1 : k) * BH + bh) * MAT;
+        image_swap(img, Z, tid);
         panel_gemm<false, true>(acc, img, rlo, rhi, p, Wn, wave, lane);
     }
     store_f32(dX + bh * MAT, acc, 0.25f, j, hl);      // the panels hold 4 W
 }
 
-// ================================================================== z_k-only chain: row-quarter accumulators, three register panels
-// The kernels above keep ONE 256 x 256 f32 result in the accumulators (256 registers) and one bf16 panel (128), so every other matrix a
-// later product needs waits in HBM: 23 transfers of 128 KiB per iteration and (b, h).  Here a product is computed a row quarter at a time
-// (2 row blocks x 2 column blocks = 64 accumulator registers), its result goes to a panel OTHER than its B operand, and THREE panels
-// (p, q, r) + the LDS image hold four matrices on the chip.  With that the forward saves only z_k (1 store + 1 image fill per iteration
-// instead of 4 + 2) and the backward recomputes P = X z_k and needs neither T2 nor T3 (both are polynomials in P, and every product whose
-// A operand they were becomes products whose A operand is P, which stays in the image):
-//     T2 V3 = 15 V3 - P (7 V3 - P V3)            T3 U = 13 U - P (15 U - P (7 U - P U))
-//     W  = V2 P - 7 V2 - 15 V3 + P g ,  g = V2 - P V3 + 7 V3        U' = 1/4 (4W X + e) ,  e = 13 U - P d ,  d = 15 U - 7 c + P c ,  c = P U
-// 10 products + the dX product per iteration instead of 8 + 1, 9 + 2 transfers instead of 15 + 2.
-// MEASURED (tools/exp/ab_chain.sh, same box): forward 204 us (231 for the full-accumulator kernel), backward 708 us (458): a quarter
-// product costs ~6.5 us against ~5 (four epilogues, 2 row blocks per fragment read instead of 8 to hide the LDS latency behind, three
-// panels + two addends leave ~500 live registers: 556 bytes of scratch per lane), and there are two more of them.  Fewer bytes, more
-// time: the kernels are OPT-IN (MH_CHAIN_Q=1, both passes), exercised by tests/test_kernels_gpu.py in a subprocess.  Partial sums of W are rounded to bf16
-// where the kernels above keep them in f32 (W1 = V2 P - 7 V2 - 15 V3 and g): see tests/test_kernels_gpu.py for what that costs.
-// Panel loads / stores through buffer instructions: the matrix base is a scalar resource descriptor, the lane's 16 bytes a single
-// VGPR offset, the entry (T, jb) an immediate / scalar offset.  With flat addresses the compiler materialises (and, at the register
-// pressure of three live panels, spills) a 64-bit VGPR address per entry.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t mat_rsrc(const bf16_t* G) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(G), 0, IMG, 0x00020000);
-}
-__device__ __forceinline__ void load_panel_b(bf16x8 (&p)[16][NJ], const bf16_t* __restrict__ G, int wave, int lane) {
-    const __amdgpu_buffer_rsrc_t rs = mat_rsrc(G);
-    const int vo = lane << 4;
-#pragma unroll
-    for (int jb = 0; jb < NJ; jb++)
-#pragma unroll
-        for (int T = 0; T < 16; T++)
-            p[T][jb] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, ((2 * wave + jb) * 16 + T) * 1024, 0));
-}
-__device__ __forceinline__ void store_panel_b(bf16_t* __restrict__ G, const bf16x8 (&p)[16][NJ], int wave, int lane) {
-    const __amdgpu_buffer_rsrc_t rs = mat_rsrc(G);
-    const int vo = lane << 4;
-#pragma unroll
-    for (int jb = 0; jb < NJ; jb++)
-#pragma unroll
-        for (int T = 0; T < 16; T++)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, p[T][jb]), rs, vo, ((2 * wave + jb) * 16 + T) * 1024, 0);
-}
-// fragment read bases of ONE quarter (row blocks 2 QR, 2 QR + 1): [k-step half][row block][lo / hi], recomputed per quarter so that
-// they are not 16 registers live across the whole kernel beside three panels (read_bases has the address algebra)
-struct QBases { unsigned a[2][2][2]; };
-template <int QR>
-__device__ __forceinline__ QBases qbases(int lane) {
-    asm volatile("" : "+v"(lane));
-    const int g16 = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-    const int kl = 4 * (g16 >> 1) + q, cl = 4 * (g16 & 1) + p;
-    const int slo = swz(kl), shi = swz(kl + 8);
-    QBases b;
-#pragma unroll
-    for (int bi = 0; bi < 2; bi++) {
-        const int bb = (2 * QR + bi) & 3;
-        b.a[0][bi][0] = kl * 512 + (((8 * bb + cl) ^ slo) << 3);
-        b.a[0][bi][1] = (kl + 8) * 512 + (((8 * bb + cl) ^ shi) << 3);
-        b.a[1][bi][0] = b.a[0][bi][0] + 65536;
-        b.a[1][bi][1] = b.a[0][bi][1] + 65536;
-        asm volatile("" : "+v"(b.a[0][bi][0]), "+v"(b.a[0][bi][1]), "+v"(b.a[1][bi][0]), "+v"(b.a[1][bi][1]));
-    }
-    return b;
-}
-template <int QR, int T>
-__device__ __forceinline__ void load_frags2(bf16x8 (&af)[2], const char* img, const QBases& qb) {
-#pragma unroll
-    for (int bi = 0; bi < 2; bi++) {
-        constexpr int hs = T >> 3;
-        const int blk = 2 * QR + bi;
-        const int off = (blk >> 2) * 256 + (T & 7) * 8192;
-        s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + qb.a[hs][bi][0] + off));
-        s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + qb.a[hs][bi][1] + off));
-        af[bi] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
-    }
-}
-template <int QR, int T>
-__device__ __forceinline__ void qstep(f32x16 (&acc)[2][NJ], bf16x8 (&cur)[2], bf16x8 (&nxt)[2], const char* img, const QBases& qb,
-                                      const bf16x8 (&pB)[16][NJ]) {
-    if constexpr (T + 1 < 16) load_frags2<QR, T + 1>(nxt, img, qb);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int bi = 0; bi < 2; bi++)
-#pragma unroll
-        for (int jb = 0; jb < NJ; jb++) {
-            if constexpr (T == 0) {
-                f32x16 z;
-#pragma unroll
-                for (int r = 0; r < 16; r++) z[r] = 0.f;
-                acc[bi][jb] = MFMA(cur[bi], pB[0][jb], z);
-            } else {
-                acc[bi][jb] = MFMA(cur[bi], pB[T][jb], acc[bi][jb]);
-            }
-        }
-    __builtin_amdgcn_sched_barrier(0);
-}
-__device__ __forceinline__ float bf_at(const u32x4& w, int e) { return __uint_as_float((e & 1) ? (w[e >> 1] & 0xffff0000u) : (w[e >> 1] << 16)); }
-// rows [64 QR, 64 QR + 64) of  O = alpha A B + diag I + c1 R1 + c2 R2  (A = the LDS image, B, R1, R2, O panels; O may be R1 or R2, never B);
-// F32: the unrounded values also go to `f32out` (column-major f32: the chain's d z_0)
-template <int QR, bool HR1, bool HR2, bool F32>
-__device__ __forceinline__ void quarter(const char* img, int qlane, const bf16x8 (&pB)[16][NJ],
-                                        bf16x8 (&pO)[16][NJ], float alpha, float diag, const bf16x8 (&pR1)[16][NJ], float c1,
-                                        const bf16x8 (&pR2)[16][NJ], float c2, int wave, int dreg, float* __restrict__ f32out, int j0, int hl) {
-    f32x16 acc[2][NJ];
-    bf16x8 f0[2], f1[2];
-    const QBases qb = qbases<QR>(qlane);
-    load_frags2<QR, 0>(f0, img, qb);
-    __builtin_amdgcn_sched_barrier(0);
-    qstep<QR, 0>(acc, f0, f1, img, qb, pB);
-    qstep<QR, 1>(acc, f1, f0, img, qb, pB);
-    qstep<QR, 2>(acc, f0, f1, img, qb, pB);
-    qstep<QR, 3>(acc, f1, f0, img, qb, pB);
-    qstep<QR, 4>(acc, f0, f1, img, qb, pB);
-    qstep<QR, 5>(acc, f1, f0, img, qb, pB);
-    qstep<QR, 6>(acc, f0, f1, img, qb, pB);
-    qstep<QR, 7>(acc, f1, f0, img, qb, pB);
-    qstep<QR, 8>(acc, f0, f1, img, qb, pB);
-    qstep<QR, 9>(acc, f1, f0, img, qb, pB);
-    qstep<QR, 10>(acc, f0, f1, img, qb, pB);
-    qstep<QR, 11>(acc, f1, f0, img, qb, pB);
-    qstep<QR, 12>(acc, f0, f1, img, qb, pB);
-    qstep<QR, 13>(acc, f1, f0, img, qb, pB);
-    qstep<QR, 14>(acc, f0, f1, img, qb, pB);
-    qstep<QR, 15>(acc, f1, f0, img, qb, pB);
-#pragma unroll
-    for (int bi = 0; bi < 2; bi++)
-#pragma unroll
-        for (int jb = 0; jb < NJ; jb++) {
-            const int blk = 2 * QR + bi;
-            const float dg = (blk == 2 * wave + jb) ? diag : 0.f;
-#pragma unroll
-            for (int t = 0; t < 2; t++) {
-                const int T = 2 * blk + t;
-                u32x4 w1 = __builtin_bit_cast(u32x4, pR1[T][jb]), w2 = __builtin_bit_cast(u32x4, pR2[T][jb]);
-                // opaque: otherwise the unpacked f32 values of an addend are "remembered" for the NEXT product that uses the same panel
-                // (V3, U and V2 are addends two or three times per iteration) and spilled: 300 dwords per lane
-                if constexpr (HR1) asm volatile("" : "+v"(w1));
-                if constexpr (HR2) asm volatile("" : "+v"(w2));
-                bf16x8 o;
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    const int r = 8 * t + e;
-                    v[e] = alpha * acc[bi][jb][r];
-                    if (r == dreg) v[e] += dg;
-                    if constexpr (HR1) v[e] += c1 * bf_at(w1, e);
-                    if constexpr (HR2) v[e] += c2 * bf_at(w2, e);
-                    o[e] = (__bf16)v[e];
-                }
-                pO[T][jb] = o;
-                if constexpr (F32) {          // rows 32 blk + 8 (r >> 2) + 4 hl + (r & 3), r = 8 t + e: two runs of four rows
-                    float* row = f32out + (long)(j0 + 32 * jb) * CM + 4 * hl + 32 * blk + 16 * t;
-                    *reinterpret_cast<f32x4*>(row) = f32x4{v[0], v[1], v[2], v[3]};
-                    *reinterpret_cast<f32x4*>(row + 8) = f32x4{v[4], v[5], v[6], v[7]};
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-}
-template <bool HR1, bool HR2, bool F32 = false>
-__device__ __forceinline__ void product(const char* img, int qlane, const bf16x8 (&pB)[16][NJ],
-                                        bf16x8 (&pO)[16][NJ], float alpha, float diag, const bf16x8 (&pR1)[16][NJ], float c1,
-                                        const bf16x8 (&pR2)[16][NJ], float c2, int wave, int dreg, float* __restrict__ f32out = nullptr, int j0 = 0,
-                                        int hl = 0) {
-    quarter<0, HR1, HR2, F32>(img, qlane, pB, pO, alpha, diag, pR1, c1, pR2, c2, wave, dreg, f32out, j0, hl);
-    quarter<1, HR1, HR2, F32>(img, qlane, pB, pO, alpha, diag, pR1, c1, pR2, c2, wave, dreg, f32out, j0, hl);
-    quarter<2, HR1, HR2, F32>(img, qlane, pB, pO, alpha, diag, pR1, c1, pR2, c2, wave, dreg, f32out, j0, hl);
-    quarter<3, HR1, HR2, F32>(img, qlane, pB, pO, alpha, diag, pR1, c1, pR2, c2, wave, dreg, f32out, j0, hl);
-}
-__device__ __forceinline__ void copy_panel(bf16x8 (&d)[16][NJ], const bf16x8 (&s)[16][NJ]) {
-#pragma unroll
-    for (int T = 0; T < 16; T++)
-#pragma unroll
-        for (int jb = 0; jb < NJ; jb++) d[T][jb] = s[T][jb];
-}
-
-// forward: saved slot 0 of iteration k = PN(z_k) (slots 1..3 unused), zfT = column-major z_iters
-__global__ __launch_bounds__(CT) void pinv_q_fwd_kernel(const bf16_t* __restrict__ XT, bf16_t* __restrict__ saved, bf16_t* __restrict__ zfT, int BH,
-                                                        int iters, const float* __restrict__ z0f, const unsigned long long* __restrict__ st, int z0_rm) {
-    __shared__ __attribute__((aligned(16))) char img[IMG];
-    const int tid = threadIdx.x, lane = tid & 63, hl = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = 64 * wave + (lane & 31);
-    const int bh = blockIdx.x;
-    const int dreg = (hl == ((lane >> 2) & 1)) ? ((((lane & 31) >> 3) << 2) | (lane & 3)) : -1;
-    const bf16_t* Xb = XT + bh * MAT;
-    bf16x8 p[16][NJ], q[16][NJ], r[16][NJ];
-    if (z0f) {
-        const float inv = 1.f / (__uint_as_float((unsigned)(st[0] >> 32)) * __uint_as_float((unsigned)(st[1] >> 32)));
-        const float* zb = z0f + bh * MAT;
-#pragma unroll
-        for (int jb = 0; jb < NJ; jb++)
-#pragma unroll
-            for (int T = 0; T < 16; T++) {
-                // z0_rm: z0f is x itself, row-major (mh_nys_sim2's attn2): column j of z_0 = x^T / (c r) is ROW j of x, and a panel entry is
-                // two runs of four consecutive elements of that row (the lane reads its own row: 1 KiB apart between lanes, L2-hot) —
-                // no transposed f32 copy of attn2 is ever written.  Otherwise: the unscaled panel-native f32 x^T
-                const float* src = z0_rm ? zb + (long)(64 * wave + 32 * jb + (lane & 31)) * CM + 16 * T + 4 * hl
-                                         : zb + (((2 * wave + jb) * 16 + T) * 512) + (lane << 3);
-                const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + (z0_rm ? 8 : 4));
-                bf16x8 o;
-#pragma unroll
-                for (int e = 0; e < 4; e++) { o[e] = (__bf16)(a[e] * inv); o[4 + e] = (__bf16)(b[e] * inv); }
-                p[T][jb] = o;
-            }
-        store_panel_b(saved + bh * MAT, p, wave, lane);
-    } else {
-        load_panel_b(p, saved + bh * MAT, wave, lane);
-    }
-    image_from_global<16>(img, Xb, tid);
-    __syncthreads();
-#pragma unroll 1
-    for (int k = 0; k < iters; k++) {
-        product<false, false>(img, lane, p, q, 1.f, 0.f, p, 0.f, p, 0.f, wave, dreg);              // q = P = X z            (image X)
-        __syncthreads();
-        image_from_panel(img, q, j, hl);
-        __syncthreads();
-        product<true, false>(img, lane, q, r, 1.f, 15.f, q, -7.f, q, 0.f, wave, dreg);             // r = T2 = 15 I - 7 P + P P (image P)
-        product<false, false>(img, lane, r, q, -1.f, 13.f, r, 0.f, r, 0.f, wave, dreg);            // q = T3 = 13 I - P T2
-        __syncthreads();
-        image_from_panel(img, p, j, hl);
-        __syncthreads();
-        product<false, false>(img, lane, q, r, 0.25f, 0.f, q, 0.f, q, 0.f, wave, dreg);            // r = z' = 1/4 z T3      (image z)
-        if (k + 1 < iters) store_panel_b(saved + ((long)(k + 1) * 4 * BH + bh) * MAT, r, wave, lane);
-        copy_panel(p, r);
-        __syncthreads();
-        if (k + 1 < iters) {
-            image_from_global<16>(img, Xb, tid);
-            __syncthreads();
-        }
-    }
-    image_from_panel(img, p, j, hl);
-    __syncthreads();
-    image_to_global(img, zfT + bh * MAT, tid);
-}
-
-// backward: work slots of iteration k: 0 = V3, 2 = 4 W, 3 = U' (the next iteration's U); dzf = PN(U), U = (d z_iters)^T
-__global__ __launch_bounds__(CT) void pinv_q_bwd_kernel(const bf16_t* __restrict__ XT, const bf16_t* __restrict__ saved, const bf16_t* __restrict__ dzf,
-                                                        bf16_t* __restrict__ work, float* __restrict__ dX, float* __restrict__ dz0, int BH, int iters) {
-    __shared__ __attribute__((aligned(16))) char img[IMG];
-    const int tid = threadIdx.x, lane = tid & 63, hl = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = 64 * wave + (lane & 31);
-    const int bh = blockIdx.x;
-    const int dreg = (hl == ((lane >> 2) & 1)) ? ((((lane & 31) >> 3) << 2) | (lane & 3)) : -1;
-    const bf16_t* Xb = XT + bh * MAT;
-    const bf16_t* Ug = dzf + bh * MAT;
-    {
-        bf16x8 p[16][NJ], q[16][NJ], r[16][NJ];
-        __builtin_amdgcn_sched_barrier(0);
-        load_panel_b(p, Ug, wave, lane);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll 1
-        for (int k = iters - 1; k >= 0; k--) {
-            const bf16_t* Z = saved + ((long)k * 4 * BH + bh) * MAT;
-            bf16_t* wb = work + ((long)k * 4 * BH + bh) * MAT;
-            bf16_t* V3g = wb;
-            bf16_t* Wg = wb + 2L * BH * MAT;
-            bf16_t* Un = wb + 3L * BH * MAT;
-            // 1. V3 = 1/4 U Z                                              (image U <- p, panel Z <- HBM)
-            __builtin_amdgcn_sched_barrier(0);
-            load_panel_b(q, Z, wave, lane);
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
-            __builtin_amdgcn_sched_barrier(0);
-            image_from_panel(img, p, j, hl);
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
-            product<false, false>(img, lane, q, r, 0.25f, 0.f, q, 0.f, q, 0.f, wave, dreg);        // r = V3
-            __builtin_amdgcn_sched_barrier(0);
-            store_panel_b(V3g, r, wave, lane);
-            __builtin_amdgcn_sched_barrier(0);
-            // 2. P = X Z                                                   (image X <- HBM, panel Z)
-            __syncthreads();
-            __builtin_amdgcn_sched_barrier(0);
-            image_from_global<16>(img, Xb, tid);
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
-            product<false, false>(img, lane, q, p, 1.f, 0.f, q, 0.f, q, 0.f, wave, dreg);          // p = P   (U is in HBM: Ug)
-            // 3. V2 = -V3 P                                                (image V3 <- r, panel P)
-            __syncthreads();
-            __builtin_amdgcn_sched_barrier(0);
-            image_from_panel(img, r, j, hl);
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
-            product<false, false>(img, lane, p, q, -1.f, 0.f, p, 0.f, p, 0.f, wave, dreg);         // q = V2
-            // 4. W1 = V2 P - 7 V2 - 15 V3                                  (image V2 <- q, panel P, in place on r = V3)
-            __syncthreads();
-            __builtin_amdgcn_sched_barrier(0);
-            image_from_panel(img, q, j, hl);
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
-            product<true, true>(img, lane, p, r, 1.f, 0.f, q, -7.f, r, -15.f, wave, dreg);         // r = W1
-            // 5. g = V2 - P V3 + 7 V3                                      (image P <- p, panel V3 <- HBM into p, in place on q = V2)
-            __syncthreads();
-            __builtin_amdgcn_sched_barrier(0);
-            image_from_panel(img, p, j, hl);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_sched_barrier(0);
-            load_panel_b(p, V3g, wave, lane);                                                            // own stores of step 1
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
-            product<true, true>(img, lane, p, q, -1.f, 0.f, q, 1.f, p, 7.f, wave, dreg);           // q = g
-            // 6. W = W1 + P g, kept as 4 W (exact in bf16)                 (image P, panel g, in place on r = W1)
-            product<true, false>(img, lane, q, r, 4.f, 0.f, r, 4.f, r, 0.f, wave, dreg);           // r = 4 W
-            __builtin_amdgcn_sched_barrier(0);
-            store_panel_b(Wg, r, wave, lane);
-            __builtin_amdgcn_sched_barrier(0);
-            // 7. c = P U                                                   (image P, panel U <- HBM)
-            __builtin_amdgcn_sched_barrier(0);
-            load_panel_b(p, Ug, wave, lane);
-            __builtin_amdgcn_sched_barrier(0);
-            product<false, false>(img, lane, p, q, 1.f, 0.f, p, 0.f, p, 0.f, wave, dreg);          // q = c
-            // 8. d = 15 U - 7 c + P c                                      (image P, panel c; r = 4 W is in HBM)
-            product<true, true>(img, lane, q, r, 1.f, 0.f, p, 15.f, q, -7.f, wave, dreg);          // r = d
-            // 9. e = 13 U - P d                                            (image P, panel d, in place on p = U)
-            product<true, false>(img, lane, r, p, -1.f, 0.f, p, 13.f, p, 0.f, wave, dreg);         // p = e
-            // 10. U' = 1/4 (4W X + e)                                      (image 4W <- HBM, panel X <- HBM, in place on p = e)
-            publish();                                    // the other waves' stores of 4 W (step 6) are read below
-            __builtin_amdgcn_sched_barrier(0);
-            load_panel_b(q, Xb, wave, lane);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_sched_barrier(0);
-            image_from_global<16>(img, Wg, tid);
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
-            if (k == 0) product<true, false, true>(img, lane, q, p, 0.25f, 0.f, p, 0.25f, p, 0.f, wave, dreg, dz0 + bh * MAT, j, hl);
-            else product<true, false>(img, lane, q, p, 0.25f, 0.f, p, 0.25f, p, 0.f, wave, dreg);  // p = U'
-            __builtin_amdgcn_sched_barrier(0);
-            store_panel_b(Un, p, wave, lane);
-            __builtin_amdgcn_sched_barrier(0);
-            Ug = Un;
-        }
-    }
-    // dX^T = sum_k Z_k W_k: one 256-register accumulator again (only one panel is live here)
-    {
-        unsigned rlo[2][4], rhi[2][4];
-        read_bases(rlo, rhi, lane);
-        f32x16 acc[8][NJ];
-        bf16x8 p[16][NJ];
-        zero_acc(acc);
-        load_panel(p, work + ((long)bh) * MAT + 2L * BH * MAT, wave, lane);
-#pragma unroll 1
-        for (int k = 0; k < iters; k++) {
-            const bf16_t* Z = saved + ((long)k * 4 * BH + bh) * MAT;
-            const bf16_t* Wn = work + ((long)(k + 1 < iters ? k + 1 : k) * 4 * BH + bh) * MAT + 2L * BH * MAT;
-            __syncthreads();
-            image_from_global<16>(img, Z, tid);
-            __syncthreads();
-            panel_gemm<false, true>(acc, img, rlo, rhi, p, Wn, wave, lane);
-        }
-        store_f32(dX + bh * MAT, acc, 0.25f, j, hl);
-    }
-}
 
 // One thread per panel-native item (bh, jblk, T, lane): i_e = 16T + 4hl + (e & 3) + 8 (e >> 2), j = 32 jblk + c.
 __device__ __forceinline__ void pn_item(int it, int& j, int& i0) {
@@ -1106,13 +611,7 @@ extern "C" int mh_pinv_chain_fwd(const void* XT, void* saved, void* zfT, int BH,
     if (const char* e = getenv("MH_EXP_CHAIN_FWD_ITERS")) iters = atoi(e);     // what a faster chain would buy: fewer iterations, same launch
 #endif
     MH_REQUIRE(!z0f || (stats64 && ((uintptr_t)z0f & 15) == 0), "mh_pinv_chain_fwd: z0f needs the maxima and 16-byte alignment");
-    if (chain_q()) {
-        hipLaunchKernelGGL(pinv_q_fwd_kernel, dim3(BH), dim3(CT), chain_claim_bytes(), (hipStream_t)s, (const bf16_t*)XT, (bf16_t*)saved, (bf16_t*)zfT, BH,
-                           iters, z0f, (const unsigned long long*)stats64, z0_rowmajor);
-        MH_LAUNCH_CHECK("mh_pinv_chain_fwd(q)");
-        return MH_OK;
-    }
-    hipLaunchKernelGGL(pinv_panel_fwd_kernel, dim3(BH), dim3(CT), chain_claim_bytes(), (hipStream_t)s, (const bf16_t*)XT, (bf16_t*)saved,
+    hipLaunchKernelGGL(pinv_panel_fwd_kernel, dim3(BH), dim3(CT), 0, (hipStream_t)s, (const bf16_t*)XT, (bf16_t*)saved,
                        (bf16_t*)zfT, BH, iters, z0f, (const unsigned long long*)stats64, z0_rowmajor);
     MH_LAUNCH_CHECK("mh_pinv_chain_fwd");
     return MH_OK;
@@ -1127,27 +626,13 @@ extern "C" int mh_pinv_chain_bwd(const void* XT, const void* saved, const void* 
     if (getenv("MH_EXP_CHAIN_SKIP")) return MH_OK;
     if (const char* e = getenv("MH_EXP_CHAIN_BWD_ITERS")) iters = atoi(e);
 #endif
-    if (chain_q()) {
-        hipLaunchKernelGGL(pinv_q_bwd_kernel, dim3(BH), dim3(CT), chain_claim_bytes(), (hipStream_t)s, (const bf16_t*)XT, (const bf16_t*)saved,
-                           (const bf16_t*)dzf, (bf16_t*)work, dX, dz0, BH, iters);
-        MH_LAUNCH_CHECK("mh_pinv_chain_bwd(q)");
-        return MH_OK;
-    }
-    static const int prefetch = [] { const char* e = getenv("MH_CHAIN_BWD2"); return e ? atoi(e) : 1; }();     // A/B switch: 0 old kernel, 1 (default) panel prefetch, 2 + early image loads (measured: 466 vs 471 us; old 496)
-    if (prefetch == 1)
-        hipLaunchKernelGGL(pinv_panel_bwd2_kernel<false>, dim3(BH), dim3(CT), chain_claim_bytes(), (hipStream_t)s, (const bf16_t*)XT, (const bf16_t*)saved,
-                           (const bf16_t*)dzf, (bf16_t*)work, dX, dz0, BH, iters);
-    else if (prefetch)
-        hipLaunchKernelGGL(pinv_panel_bwd2_kernel<true>, dim3(BH), dim3(CT), chain_claim_bytes(), (hipStream_t)s, (const bf16_t*)XT, (const bf16_t*)saved,
-                           (const bf16_t*)dzf, (bf16_t*)work, dX, dz0, BH, iters);
-    else
-        hipLaunchKernelGGL(pinv_panel_bwd_kernel, dim3(BH), dim3(CT), chain_claim_bytes(), (hipStream_t)s, (const bf16_t*)XT, (const bf16_t*)saved,
-                           (const bf16_t*)dzf, (bf16_t*)work, dX, dz0, BH, iters);
+    hipLaunchKernelGGL(pinv_panel_bwd2_kernel, dim3(BH), dim3(CT), 0, (hipStream_t)s, (const bf16_t*)XT, (const bf16_t*)saved,
+                       (const bf16_t*)dzf, (bf16_t*)work, dX, dz0, BH, iters);
     MH_LAUNCH_CHECK("mh_pinv_chain_bwd");
     return MH_OK;
 }
 
 extern "C" int64_t mh_pinv_chain_workspace_bytes(int BH, int m, int iters, int which) {
     if (BH <= 0 || m != CM || iters < 1 || which < 0 || which > 1) return 0;
-    return (int64_t)iters * 4 * BH * MAT * 2;
+    return (which == 0 ? (int64_t)iters * 4 : (int64_t)iters + 4) * BH * MAT * 2;
 }

@@ -47,16 +47,16 @@ def plan_buckets(sizes: Sequence[int], cap_elems: int, align: int = _ALIGN):
 
 
 # A/B switch: 1 (default) = the transposed weight copies are rebuilt at the start of a step on the RNA stream, 0 = behind Adam
-_ASYNC_GATHER = os.environ.get("MIRROR_ASYNC_GATHER", "1") != "0"      # A/B switch: alignment all-gather issued behind the heads
-_DEFER_SKINNY = os.environ.get("MIRROR_DEFER_SKINNY", "1") != "0"     # A/B switch: one multi-tensor launch for the skinny weight gradients
-_TRANSPOSE_AT_START = os.environ.get("MIRROR_TRANSPOSE_AT_START", "1") != "0"
+_ASYNC_GATHER = True      # alignment all-gather issued behind the heads
+_DEFER_SKINNY = True      # one multi-tensor launch for the skinny weight gradients
+_TRANSPOSE_AT_START = True      # (test hook)
 
 
 class TrainEngine:
     def __init__(self, model: torch.nn.Module, loss_fn, *, lr: float = 2e-5, betas=(0.9, 0.999), eps: float = 1e-8,
                  precision: str = "bf16", wsi_mask_ratio: float = 0.75, rna_mask_ratio: float = 0.75,
                  bucket_mb: float = 25.0, process_group=None, graph: Optional[bool] = None,
-                 clip_grad: Optional[float] = None, accum_steps: int = 1, seed: Optional[int] = None,
+                 clip_grad: Optional[float] = None, clip_mode: str = "norm", accum_steps: int = 1, seed: Optional[int] = None,
                  snapshot_grads: bool = False, grad_reduce_dtype: str = "f32"):
         """grad_reduce_dtype: "f32" (default: the f32 arena slices are all-reduced in place) or "bf16" (BASELINE config 5 /
         SURVEY.md §8e "bf16 grads optional": each bucket is rounded to bf16 for the wire — half the xGMI bytes — summed by
@@ -67,6 +67,11 @@ class TrainEngine:
         snapshot_grads: keep a copy of the (reduced) gradient arena of the last update in `self.grad_snap` (tests)."""
         if precision not in POLICIES:
             raise ValueError(f"unknown precision {precision!r}")
+        # timm's dispatch_clip_grad modes (train_mirror.py:1219-1229, --clip-mode): "norm" (the template's default: one fused
+        # kernel, the factor stays on the device) and "value" (element-wise clamp of the averaged gradient); "agc" is not built
+        if clip_mode not in ("norm", "value"):
+            raise NotImplementedError(f"clip_mode {clip_mode!r}: only 'norm' and 'value' are implemented (timm's 'agc' is not)")
+        self.clip_mode = clip_mode
         if grad_reduce_dtype not in ("f32", "bf16"):
             raise ValueError(f"grad_reduce_dtype must be 'f32' or 'bf16', got {grad_reduce_dtype!r}")
         self.grad_reduce_dtype = grad_reduce_dtype
@@ -409,12 +414,7 @@ class TrainEngine:
                 K.rownorm_(w.data)
                 if self.shadow is not None:
                     K.cast(w.data, bf16, out=Fn.shadow(w, POLICIES[self.precision]))
-        # the prototypes are read by the style / cluster heads, which run on the RNA branch's stream: renormalise them there (beside
-        # the WSI encoder's first GEMM) unless the heads were told to stay on the main stream
-        proto_on_side = (_TRANSPOSE_AT_START and os.environ.get("MIRROR_HEADS_SIDE", "1") != "0"
-                         and os.environ.get("MIRROR_DRAW_SIDE", "0") != "0")
-        if not proto_on_side:
-            renorm_prototypes()
+        renorm_prototypes()
         t_done = None
         if _TRANSPOSE_AT_START:
             # The transposed bf16 weight copies are read by BACKWARD kernels only (data gradients of the [B, D]-row linears): instead
@@ -423,8 +423,6 @@ class TrainEngine:
             main, side = torch.cuda.current_stream(), Fn._side_stream(self.device, 1)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                if proto_on_side:
-                    renorm_prototypes()
                 self._refresh_transposes()
                 if self._zero_pending:           # the gradient arena of the update that ended the previous step
                     self.grad.zero_()
@@ -482,7 +480,10 @@ class TrainEngine:
         # (train_mirror.py:1117-1131, :1192)
         gs = 1.0 / (self.world * n_micro)
         self.last_grad_scale = gs
-        if self.clip_grad is not None:
+        if self.clip_grad is not None and self.clip_mode == "value":
+            lim = float(self.clip_grad) / gs          # clamp(gs * g, -c, c) == gs * clamp(g, -c / gs, c / gs): Adam applies gs
+            self.grad.clamp_(-lim, lim)
+        elif self.clip_grad is not None:
             K.grad_clip(self.grad, gs, float(self.clip_grad), self._state)
         Fn.probe("adam_start")
         K.adam(self.master, self.grad, self.m, self.v, self.shadow, self.lr, b1, b2, self.eps, 1.0, 1.0,

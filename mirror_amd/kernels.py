@@ -8,7 +8,6 @@ from __future__ import annotations
 import ctypes as C
 from typing import Optional
 
-import os
 
 import torch
 
@@ -179,7 +178,7 @@ shared_chip = False
 
 
 EPI_DROPADD, EPI_MASKPOS, EPI_SQERR = 1, 2, 3
-_EPI_ON = os.environ.get("MIRROR_GEMM_EPI", "1") != "0"       # A/B switch: the fused projection epilogues (mh_gemm_epi)
+_EPI_ON = True       # the fused projection epilogues (mh_gemm_epi); test hook: False = composed projection + elementwise passes
 
 
 def linear_fused_ok(x: torch.Tensor, w: torch.Tensor, window: Optional[tuple] = None) -> bool:
@@ -228,10 +227,7 @@ def linear_fused(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],
     if prof is None:
         _lib.call("mh_gemm", C.byref(d), stream=_stream())
     else:
-        tc = "float" if out.dtype == torch.float32 else "bf16"
-        kern = ("gemm_big_kernel", "gemm_pp_kernel", "gemm_pq_kernel")[int(_lib.load().mh_gemm_select_pp(-1))]
-        prof.launch_named(f"{kern}<{tc},true,true,epi{epi.kind}>", 2.0 * d.M * d.N * d.K,
-                          lambda: _lib.call("mh_gemm", C.byref(d), stream=_stream()))
+        prof.launch(d, lambda: _lib.call("mh_gemm", C.byref(d), stream=_stream()))
     return out
 
 
@@ -276,11 +272,7 @@ def gemm_rows_window(a3: torch.Tensor, b2: torch.Tensor, out3: torch.Tensor, r0:
     if prof is None:
         _lib.call("mh_gemm", C.byref(d), stream=_stream())
     else:
-        kern = ("gemm_big_kernel", "gemm_pp_kernel", "gemm_pq_kernel")[int(_lib.load().mh_gemm_select_pp(-1))]
-        if shared_chip and kern == "gemm_pq_kernel":
-            kern = "gemm_pp_kernel"
-        prof.launch_named(f"{kern}<bf16,true,{'true' if d.b_kc else 'false'}>", 2.0 * d.M * d.N * d.K,
-                          lambda: _lib.call("mh_gemm", C.byref(d), stream=_stream()))
+        prof.launch(d, lambda: _lib.call("mh_gemm", C.byref(d), stream=_stream()))
 
 
 def gemm_rows_ext_ok(Bn: int, T: int, r0: int, R: int, extra: int, Kd: int, N: int, a2: torch.Tensor, out2: torch.Tensor) -> bool:
@@ -330,11 +322,7 @@ def gemm_rows_ext(a2: torch.Tensor, b2: torch.Tensor, out2: torch.Tensor, Bn: in
     if prof is None:
         _lib.call("mh_gemm", C.byref(d), stream=_stream())
     else:
-        kern = ("gemm_big_kernel", "gemm_pp_kernel", "gemm_pq_kernel")[int(_lib.load().mh_gemm_select_pp(-1))]
-        if shared_chip and kern == "gemm_pq_kernel":
-            kern = "gemm_pp_kernel"
-        prof.launch_named(f"{kern}<bf16,true,{'true' if d.b_kc else 'false'}>", 2.0 * d.M * d.N * d.K,
-                          lambda: _lib.call("mh_gemm", C.byref(d), stream=_stream()))
+        prof.launch(d, lambda: _lib.call("mh_gemm", C.byref(d), stream=_stream()))
     return tail
 
 
@@ -371,8 +359,7 @@ def epi_sqerr(mask: torch.Tensor, tgt: torch.Tensor, tgt_bs: int, sq: torch.Tens
 
 def gemm_softmax_ok(M: int, N: int, Kd: int, dta=torch.bfloat16, dtb=torch.bfloat16) -> bool:
     """Shapes whose row softmax the 192 x 384 tile kernel computes in its epilogue (a whole row of length N = 384 in one tile)."""
-    return (M % 192 == 0 and N == 384 and Kd % 8 == 0 and dta == torch.bfloat16 and dtb == torch.bfloat16
-            and os.environ.get("MH_GEMM_TILE384", "1")[:1] != "0" and os.environ.get("MH_GEMM_SOFTMAX", "1")[:1] != "0")
+    return M % 192 == 0 and N == 384 and Kd % 8 == 0 and dta == torch.bfloat16 and dtb == torch.bfloat16
 
 
 def gemm_ksum(a_stack: torch.Tensor, b_stack: torch.Tensor, out: Optional[torch.Tensor] = None, **kw) -> torch.Tensor:
@@ -386,81 +373,40 @@ def gemm_ksum(a_stack: torch.Tensor, b_stack: torch.Tensor, out: Optional[torch.
 
 def gemm_tile_ok(M: int, N: int, Kd: int, dta=torch.bfloat16, dtb=torch.bfloat16) -> bool:
     """Shapes the 192 x 384 tile kernel (csrc/gemm_tile.hip) takes: the batched 384-cubed products of the template's pinv."""
-    return (M % 192 == 0 and N % 384 == 0 and Kd % 64 == 0 and dta == torch.bfloat16 and dtb == torch.bfloat16
-            and os.environ.get("MH_GEMM_TILE384", "1")[:1] != "0")
+    return M % 192 == 0 and N % 384 == 0 and Kd % 64 == 0 and dta == torch.bfloat16 and dtb == torch.bfloat16
 
 
-_GEMM_WS = os.environ.get("MH_GEMM_WS", "1") != "0"      # A/B switch: split-K partials in a workspace vs f32 atomics
-_TN = {MH_F32: "float", MH_BF16: "bf16"}
-
-
-def gemm_variant(d: GemmDesc) -> str:
-    """The template instance mh_gemm dispatches to (matches the kernel symbol rocprofv3 reports)."""
-    wide = -(-d.M // 128) * -(-d.N // 128) * max(1, d.split_k) * d.batch1 * d.batch2
-    half = (d.mma == MH_BF16 and wide <= 160 and d.N % 64 == 0 and d.M >= 1024 and os.environ.get("MH_GEMM_HALF_TILES", "1")[:1] != "0")
-    wn = 1 if (d.N <= 64 or half) else 2
-    tc = "float" if d.mma == MH_F32 else _TN[d.dtC]
-    bk = 64 if d.mma == MH_BF16 else 16
-    vec = 4 if d.dtA == MH_F32 else 8
-    split = max(1, d.split_k)
-    kps = -(-(-(-d.K // split)) // bk) * bk
-
-    def ok(ptr, ld, s1, s2):
-        return ptr % 16 == 0 and ld % vec == 0 and s1 % vec == 0 and s2 % vec == 0
-
-    vb = 4 if d.dtB == MH_F32 else 8
-    kk = d.K
-    if d.K % bk and d.K >= 8 * bk and d.dtC == MH_F32 and d.act == 0:
-        kk = d.K - d.K % bk            # the ragged tail runs as a second, tiny launch
-        kps = -(-(-(-kk // split)) // bk) * bk
-    okb = d.B % 16 == 0 and d.ldb % vb == 0 and d.sB1 % vb == 0 and d.sB2 % vb == 0
-    oka = ok(d.A, d.lda, d.sA1, d.sA2)
-    # gemm_big.hip takes bf16 x bf16 problems tiled by 256 (same rule as gemm_try_big_bf16)
-    cvec = 4 if d.dtC == MH_F32 else 8
-    okc = d.C % 16 == 0 and d.ldc % cvec == 0 and d.sC1 % cvec == 0 and d.sC2 % cvec == 0
-    batch = d.batch1 * d.batch2
-    atomic = split > 1 or (d.accumulate and batch > 1 and d.sC1 == 0 and d.sC2 == 0)
-    if (d.mma == MH_BF16 and d.dtA == MH_BF16 and d.dtB == MH_BF16 and d.M % 192 == 0 and d.N % 384 == 0 and d.K % 8 == 0
-            and split == 1 and not atomic and not d.bias and d.act == 0 and oka and okb and okc and not (not d.a_kc and d.b_kc)
-            and ((d.M // 192) * (d.N // 384) * batch >= 64 or d.C2 or d.r_bf16) and os.environ.get("MH_GEMM_TILE384", "1")[:1] != "0"):
-        return f"gemm_tile_kernel<{_TN[d.dtC]},{'true' if d.a_kc else 'false'},{'true' if d.b_kc else 'false'}>"
-    if (d.mma == MH_BF16 and d.dtA == MH_BF16 and d.dtB == MH_BF16 and (d.M % 256 == 0 or (d.a_kc and d.M > 256))
-            and d.N % 256 == 0 and kk % 64 == 0
-            and kps % 64 == 0 and oka and okb and okc and not d.R and d.diag == 0.0
-            and not (atomic and (d.bias or d.act != 0 or d.dtC != MH_F32))
-            and -(-d.M // 256) * (d.N // 256) * -(-kk // kps) * batch >= 128 and os.environ.get("MH_GEMM_BIG", "1")[:1] != "0"):
-        mode = int(_lib.load().mh_gemm_select_pp(-1))
-        if mode == 2 and d.shared_chip:
-            mode = 1
-        kern = ("gemm_big_kernel", "gemm_pp_kernel", "gemm_pq_kernel")[mode]
-        return f"{kern}<{_TN[d.dtC]},{'true' if d.a_kc else 'false'},{'true' if d.b_kc else 'false'}>"
-    mn_ok = oka and okb and (d.a_kc or d.M % 128 == 0) and d.N % (64 * wn) == 0
-    full = mn_ok and kk % bk == 0 and kk % kps == 0
-    ktail = (d.mma == MH_BF16 and d.dtA == MH_BF16 and d.dtB == MH_BF16 and wn == 2 and mn_ok and not full and split == 1
-             and kk % 8 == 0 and kk > bk and d.M % 128 == 0)
-    ntail = (d.mma == MH_BF16 and d.dtA == MH_BF16 and d.dtB == MH_BF16 and wn == 2 and oka and okb and d.M % 128 == 0
-             and d.N % 128 != 0 and d.N < 128 and d.N % 8 == 0 and kk % bk == 0 and kk % kps == 0)
-    return (f"gemm_kernel<{d.mma},{_TN[d.dtA]},{_TN[d.dtB]},{tc},{'true' if d.a_kc else 'false'},"
-            f"{'true' if d.b_kc else 'false'},2,{wn},{1 if full else (2 if ktail else (3 if ntail else 0))}>")
+_GEMM_WS = True      # split-K partials in a workspace + fold pass (False: f32 atomics; test hook)
 
 
 class GemmProfiler:
-    """Times GEMM launches with HIP events on the launch stream (bench.py's roofline leg).
-    only=None: every launch; only=<variant>: just that template instance (cheap enough for the timed region)."""
+    """Times GEMM (and named fused-kernel) launches with HIP events on the launch stream (bench.py's roofline leg).  A GEMM launch is
+    named by the LIBRARY after the fact (mh_gemm_variant_name: the template instance mh_gemm dispatched to, as rocprofv3 reports
+    it), so nothing here restates the dispatch rules.  only=<variant>: summary() keeps just that instance."""
 
     def __init__(self, only: Optional[str] = None):
         self.only = only
         self.records = []   # (variant, flops, start_event, end_event)
 
     def launch(self, d: GemmDesc, fn) -> None:
-        self.launch_named(gemm_variant(d), 2.0 * d.M * d.N * d.K * d.batch1 * d.batch2, fn)
-
-    def launch_named(self, v: str, flops: float, fn) -> None:
-        if (self.only is not None and v != self.only) or torch.cuda.is_current_stream_capturing():
+        if torch.cuda.is_current_stream_capturing():
             fn()                 # events recorded inside a capture (the RNA branch graph) are not timing events
             return
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()          # recorded on the stream the kernel is launched on (torch's current stream)
+        fn()
+        e1.record()
+        name = (_lib.load().mh_gemm_variant_name() or b"").decode()
+        if d.epi and not name.endswith(f",epi{d.epi.contents.kind}>"):
+            name = name[:-1] + f",epi{d.epi.contents.kind}>"
+        self.records.append((name, 2.0 * d.M * d.N * d.K * d.batch1 * d.batch2, e0, e1))
+
+    def launch_named(self, v: str, flops: float, fn) -> None:
+        if (self.only is not None and v != self.only) or torch.cuda.is_current_stream_capturing():
+            fn()
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         fn()
         e1.record()
         self.records.append((v, flops, e0, e1))
@@ -469,6 +415,8 @@ class GemmProfiler:
         """variant -> dict(launches, total_ms, flops); call after a device synchronise."""
         out = {}
         for v, fl, e0, e1 in self.records:
+            if self.only is not None and v != self.only:
+                continue
             s = out.setdefault(v, {"launches": 0, "total_ms": 0.0, "flops": 0.0})
             s["launches"] += 1
             s["total_ms"] += e0.elapsed_time(e1)
@@ -849,6 +797,12 @@ def pinv_chain_saved_alloc(iters: int, BH: int, m: int, device) -> torch.Tensor:
     return torch.empty((iters, 4, BH, m, m), device=device, dtype=torch.bfloat16)
 
 
+def pinv_chain_work_alloc(iters: int, BH: int, m: int, device) -> torch.Tensor:
+    """The backward's scratch (mh_pinv_chain_workspace_bytes(which=1)): [iters + 4, BH, m, m] bf16."""
+    n = int(_lib.load().mh_pinv_chain_workspace_bytes(BH, m, iters, 1)) // 2
+    return torch.empty((n,), device=device, dtype=torch.bfloat16)
+
+
 def pinv_chain_z0_slot(saved: torch.Tensor) -> torch.Tensor:
     """Where mh_pinv_chain_prep has to put the panel-native z_0."""
     return saved[0, 0]
@@ -905,9 +859,12 @@ def nys_dz_dav(dw2: torch.Tensor, av: torch.Tensor, zfT: torch.Tensor, want_delt
     return (up, dav, delta3) if want_delta3 else (up, dav)
 
 
+_NYS_SIM2 = True       # test hook: False = sim2 as GEMM + softmax + absmax + operand packing (tests/test_fused_epilogue_gpu.py)
+
+
 def nys_sim2_ok(lm: torch.Tensor, heads: int) -> bool:
     """mh_nys_sim2's geometry: bf16 landmarks [B, 256, 2 D] with D = heads * 64."""
-    return (lm.dim() == 3 and lm.dtype == torch.bfloat16 and _lm_ld(lm) > 0 and lm.shape[1] == PINV_CHAIN_M
+    return (_NYS_SIM2 and lm.dim() == 3 and lm.dtype == torch.bfloat16 and _lm_ld(lm) > 0 and lm.shape[1] == PINV_CHAIN_M
             and lm.shape[2] == 2 * heads * 64)
 
 
@@ -965,16 +922,14 @@ def pinv_chain_bwd(XT, saved, dzf, work, dX, dz0, iters: int) -> None:
     bf = torch.bfloat16
     if not (all(t.dtype == bf and t.is_contiguous() for t in (XT, saved, dzf, work))
             and all(t.dtype == torch.float32 and t.is_contiguous() and t.numel() == BH * m * m for t in (dX, dz0))
-            and saved.numel() == iters * 4 * BH * m * m and work.numel() == saved.numel() and dzf.numel() == BH * m * m):
+            and saved.numel() == iters * 4 * BH * m * m and work.numel() >= (iters + 4) * BH * m * m and dzf.numel() == BH * m * m):
         raise MirrorHipError("pinv_chain_bwd: bad operands")
     fn = lambda: _lib.call("mh_pinv_chain_bwd", _p(XT), _p(saved), _p(dzf), _p(work), _p(dX), _p(dz0), BH, m, iters,  # noqa: E731
                            stream=_stream())
     if gemm_profiler is None:
         fn()
     else:
-        v = os.environ.get("MH_CHAIN_BWD2", "1")      # the library's A/B switch (pinv_panel.hip): which kernel the launch is
-        name = "pinv_panel_bwd_kernel" if v == "0" else ("pinv_panel_bwd2_kernel<false>" if v == "1" else "pinv_panel_bwd2_kernel<true>")
-        gemm_profiler.launch_named(name, iters * 8 * 2.0 * m ** 3 * BH, fn)
+        gemm_profiler.launch_named("pinv_panel_bwd2_kernel", iters * 8 * 2.0 * m ** 3 * BH, fn)
 
 
 # ------------------------------------------------------------------ fused Nystrom attention sides (nystrom_fused.hip)

@@ -30,13 +30,10 @@ f32 = torch.float32
 _DEFAULT_PRECISION: Optional[str] = None
 
 # program order of the two encoder branches in MIRROR.forward (see there): 1 = WSI encoder launches first (default)
-_RNA_LATE = os.environ.get("MIRROR_RNA_LATE", "1") != "0"
+_RNA_LATE = True      # (test hook)
 # 1 (default) = the alignment / style heads run on the RNA branch's helper stream, 0 = on the caller's stream (A/B switch)
-_HEADS_SIDE = os.environ.get("MIRROR_HEADS_SIDE", "1") != "0"
-# A/B switch (default off): the four noise draws + the prototype renorm on the RNA stream, so that the main stream opens with _fc1's
-# GEMM.  Measured on one box, interleaved: 1695 / 1692 / 1693 samples/s with it, 1701 / 1708 / 1704 without — six more launches at
-# the head of the RNA stream cost more than the ~60 us of tiny launches they take off the main stream's start.
-_DRAW_SIDE = os.environ.get("MIRROR_DRAW_SIDE", "0") != "0"
+_HEADS_SIDE = True      # (test hook)
+# (measured and removed: the four noise draws + the prototype renorm on the RNA stream cost 0.5 - 1 % of the step)
 
 
 def set_precision(name: Optional[str]) -> None:
@@ -539,25 +536,17 @@ class MIRROR(nn.Module):
         # backward overlaps the WSI backward as well.
         main = torch.cuda.current_stream()
         side = Fn._side_stream(dev, 1)
-        fork = main.record_event()       # (re-recorded behind the draws below when they stay on the main stream)
         wsi_in, rna_in = wsi_emb, rna_emb
-        # The four draws are consumed on the side stream only (token ranking, RNA channel mask, the two style samples): they are
-        # launched THERE, in the reference's order, so that the main stream opens with _fc1's GEMM instead of four tiny launches
-        # (the generator hands out its offsets in host program order whatever the stream).
-        draw_stream = side if (_HEADS_SIDE and _DRAW_SIDE and dev.type == "cuda") else main
-        if draw_stream is not main:
-            draw_stream.wait_event(fork)
-        with torch.cuda.stream(draw_stream):
-            if "wsi_mask" not in noise:
-                noise["wsi_mask"] = torch.rand(B, wsi_emb.shape[1], device=dev)
-            if "rna_mask" not in noise:
-                noise["rna_mask"] = torch.rand(B, self.embed_dim, device=dev)
-            if "wsi_eps" not in noise:
-                noise["wsi_eps"] = torch.randn(B, self.style_latent_dim, device=dev)
-            if "rna_eps" not in noise:
-                noise["rna_eps"] = torch.randn(B, self.style_latent_dim, device=dev)
-        if draw_stream is main:
-            fork = main.record_event()   # the side stream ranks / applies these draws: it has to start behind them
+        # the reference draws them in this order: rand(B,N) -> rand(B,D) -> eps_wsi -> eps_rna
+        if "wsi_mask" not in noise:
+            noise["wsi_mask"] = torch.rand(B, wsi_emb.shape[1], device=dev)
+        if "rna_mask" not in noise:
+            noise["rna_mask"] = torch.rand(B, self.embed_dim, device=dev)
+        if "wsi_eps" not in noise:
+            noise["wsi_eps"] = torch.randn(B, self.style_latent_dim, device=dev)
+        if "rna_eps" not in noise:
+            noise["rna_eps"] = torch.randn(B, self.style_latent_dim, device=dev)
+        fork = main.record_event()   # the side stream ranks / applies these draws: it has to start behind them
 
         def run_side():
             side.wait_event(fork)

@@ -209,6 +209,30 @@ def test_grad_clip_and_accumulation_match_torch():
     assert num ** 0.5 < 0.05 * den ** 0.5, (num, den)
 
 
+def test_clip_mode_value_clamps_the_averaged_gradient_and_agc_is_refused():
+    """timm's dispatch_clip_grad modes (train_mirror.py:1219-1229): 'value' = torch.nn.utils.clip_grad_value_ on the gradient Adam
+    sees; 'agc' is not built and says so."""
+    from mirror_amd.engine import TrainEngine
+    from mirror_amd.losses import MIRRORLoss
+    with pytest.raises(NotImplementedError):
+        TrainEngine(_make(), MIRRORLoss(), precision="fp32", clip_grad=0.1, clip_mode="agc")
+    ref = _make()
+    ref.precision = "fp32"
+    model = _make()
+    eng = TrainEngine(model, MIRRORLoss(), lr=1e-3, precision="fp32", clip_grad=1e-3, clip_mode="value", snapshot_grads=True)
+    wsi, rna, noise = _batch(4, 61)
+    with torch.no_grad():
+        ref.prototypes.weight.copy_(torch.nn.functional.normalize(ref.prototypes.weight, dim=1))
+    MIRRORLoss()(*ref(wsi, rna, noise=noise))[0].backward()
+    eng.step(wsi, rna, noise=noise)
+    torch.nn.utils.clip_grad_value_(ref.parameters(), 1e-3)
+    want = torch.cat([p.grad.reshape(-1) for p in reversed(list(ref.parameters()))])
+    got = torch.cat([eng.grad_snap[o:o + p.numel()] for p, o in zip(eng.params, eng.offsets)])
+    # grad_snap is taken before the clamp: apply it here and compare; then check the update used the clamped values
+    assert float((got.clamp(-1e-3, 1e-3) - want).norm()) < 2e-3 * float(want.norm())
+    assert float(want.abs().max()) == pytest.approx(1e-3) and float(got.abs().max()) > 1e-3      # the clamp was active
+
+
 def test_validate_matches_reference_loop_and_state_roundtrip(tmp_path):
     """validate() == the reference loop (eval mode, no grad, batch-size-weighted means), and the
     Adam state survives CheckpointSaver -> resume_checkpoint (train_mirror.py:772-780, :1053-1062)."""

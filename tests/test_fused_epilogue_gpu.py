@@ -406,8 +406,9 @@ def test_whole_model_nys_sim2_on_off(monkeypatch):
     noise = {"wsi_mask": torch.rand(2, 1024, generator=g).cuda(), "rna_mask": torch.rand(2, 512, generator=g).cuda(),
              "wsi_eps": torch.randn(2, 32, generator=g).cuda(), "rna_eps": torch.randn(2, 32, generator=g).cuda()}
     out = []
-    for on in ("1", "0"):
-        monkeypatch.setenv("MIRROR_NYS_SIM2", on)
+    from mirror_amd import kernels as K
+    for on in (True, False):
+        monkeypatch.setattr(K, "_NYS_SIM2", on)
         torch.manual_seed(0)
         model = M.mirror(**cfg).cuda().train()
         model.precision = "bf16"
