@@ -277,14 +277,19 @@ def test_validate_matches_reference_loop_and_state_roundtrip(tmp_path):
 
 # ---------------------------------------------------------------- graphed RNA branch of the eager step (mirror_amd/graphed.py)
 def _run_eager(rna_graph: bool, steps: int, gather: bool = False, cfg=CFG, batch: int = 4, bucket_mb: float = 0.05,
-               lr: float = 1e-3):
+               lr: float = 1e-3, grad_dtype: str = "f32", note=None):
     import mirror_amd.models as M
     from mirror_amd import functional as Fn
     from mirror_amd.engine import TrainEngine
     from mirror_amd.losses import MIRRORLoss
     torch.manual_seed(11)
     model = M.mirror(**cfg, rna_proj_drop_rate=0.1).cuda().train()
-    eng = TrainEngine(model, MIRRORLoss(gather_distributed=gather), lr=lr, precision="bf16", graph=False, bucket_mb=bucket_mb)
+    if note is not None:
+        note("model built")
+    eng = TrainEngine(model, MIRRORLoss(gather_distributed=gather), lr=lr, precision="bf16", graph=False, bucket_mb=bucket_mb,
+                      grad_reduce_dtype=grad_dtype)
+    if note is not None:
+        note(f"engine built, {len(getattr(eng, 'buckets', []))} buckets")
     if not rna_graph:
         eng._rna_branch_state = "off"
     Fn.manual_seed(5)                  # the same dropout stream on every rank and in every variant: runs stay comparable
@@ -301,6 +306,8 @@ def _run_eager(rna_graph: bool, steps: int, gather: bool = False, cfg=CFG, batch
     for s in range(steps):
         wsi, rna, noise = _batch(batch, 100 + 10 * s + rank, cfg)
         losses.append([float(x) for x in eng.step(wsi.to(torch.bfloat16), rna, noise=noise)])
+        if note is not None:
+            note(f"step {s} done")
     return eng, init, losses
 
 
@@ -519,6 +526,98 @@ def test_a_backward_outside_step_never_leaks_into_the_next_update(graph):
     clean, dirty = run(False), run(True)
     for s, (a, b) in enumerate(zip(clean, dirty)):
         assert float((a - b).norm()) < 5e-2 * float(a.norm()), (s, float((a - b).norm()), float(a.norm()))
+
+
+# BASELINE configs[2] / [4] composition at configs[1] shapes: two ranks, global-batch InfoNCE, bf16 gradient buckets on the wire
+CFG_C2 = dict(wsi_embed_dim=1024, rna_embed_dim=2048, embed_dim=512, wsi_num_tokens=4096, rna_encoder_depth=6, rna_num_heads=8,
+              rna_mlp_ratio=4.0, style_mlp_hidden_dim=512, style_mlp_out_dim=256, style_latent_dim=128, num_prototypes=3000)
+
+
+def _worker_c2(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import time
+        root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(root, exist_ok=True)
+
+        def note(msg):                      # heartbeat (a long silent GPU run is taken to be hung)
+            with open(os.path.join(root, f"r04_world2_c2_progress_rank{rank}.txt"), "a") as fh:
+                fh.write(f"{time.strftime('%H:%M:%S')} {msg}\n")
+        note("start")
+        kw = dict(gather=True, cfg=CFG_C2, batch=2, bucket_mb=25.0, lr=2e-5, grad_dtype="bf16")
+        e1, init, l1 = _run_eager(True, 4, note=note, **kw)
+        torch.cuda.synchronize()
+        note(f"4 steps done, losses {l1[-1]}")
+        # host time of one eager step (what every rank of an N > 1 job pays per step): steps 4.. with the RNA branch replayed
+        wsi, rna, noise = _batch(2, 555 + rank, CFG_C2)
+        wsi = wsi.to(torch.bfloat16)
+        host = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            e1.step(wsi, rna, noise=noise)
+            host.append((time.perf_counter() - t0) * 1e3)
+        torch.cuda.synchronize()
+        note(f"host ms {host}")
+        g1 = e1.grad_snaps[1].clone()
+        m1 = e1.master.cpu().numpy()
+        state1 = e1._rna_branch_state
+        nb = len(e1.buckets)
+        del e1
+        torch.cuda.empty_cache()
+        e2, _, l2 = _run_eager(True, 2, **kw)             # the same two steps again: the run-to-run floor of this configuration
+        floor = float((g1 - e2.grad_snaps[1]).norm() / g1.norm())
+        bf_exact = float((g1 - g1.to(torch.bfloat16).float()).abs().max())
+        note(f"rerun done, floor {floor}")
+        import hashlib
+        q.put((rank, hashlib.sha256(m1.tobytes()).hexdigest(), state1, l1[-1], floor, bf_exact, nb, host, torch.isfinite(g1).all().item()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_c2_shapes_world2_global_infonce_bf16_buckets():
+    """configs[1] shapes (4096 x 1024-d tokens, 2048 genes, D = 512, RNA depth 6, B = 2 per rank), two gloo ranks sharing the GPU,
+    `gather_distributed=True` (BASELINE config 3's global-batch InfoNCE) + bf16 gradient buckets (config 5's wire format), eager launch
+    with the RNA branch replayed from its HIP graphs — what every rank of the 8-GPU job runs.  Ranks end bit-identical, every reduced
+    gradient is a bf16 number, and a re-run reproduces the step-1 gradient arena to the run-to-run floor of this configuration.
+    Writes the wall time of the eager steps to gpurun_out/r04_world2_c2_host_ms.json (with gloo they are dominated by its blocking CPU
+    all-reduce of 6 x 25 MiB; the launch-side host time of the eager step is bench.py's MIRROR_GRAPH=0 MIRROR_BENCH_HOSTTIME=1 line)."""
+    import json
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 90)
+    procs = [ctx.Process(target=_worker_c2, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    import queue as _queue
+    res = []
+    for _ in range(600):                   # a worker that died must fail the test at once, not after the queue's timeout
+        try:
+            res.append(q.get(timeout=2))
+        except _queue.Empty:
+            assert all(p.exitcode in (None, 0) for p in procs), [p.exitcode for p in procs]
+        if len(res) == 2:
+            break
+    assert len(res) == 2, "workers timed out"
+    res.sort(key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0][2] == "on" and res[1][2] == "on"
+    assert res[0][1] == res[1][1], "ranks diverged"          # sha256 of the f32 master arena (136 MB per rank)
+    assert res[0][8] and res[1][8]
+    assert res[0][5] == 0.0 and res[1][5] == 0.0              # bf16 wire format: every reduced value is a bf16 number
+    assert res[0][4] < 3e-2 and res[1][4] < 3e-2, (res[0][4], res[1][4])
+    assert res[0][6] >= 4                                      # ~136 MB of f32 gradients in 25 MiB buckets
+    assert all(np.isfinite(res[0][3]))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "r04_world2_c2_host_ms.json"), "w") as fh:
+        json.dump({"config": "c2 shapes, B = 2 per rank, 2 gloo ranks on one GPU, gather_distributed, bf16 buckets, eager + graphed RNA branch",
+                   "wall_ms_per_step_rank0_incl_gloo_cpu_allreduce": res[0][7], "wall_ms_per_step_rank1_incl_gloo_cpu_allreduce": res[1][7],
+                   "buckets": res[0][6],
+                   "run_to_run_grad_floor": [res[0][4], res[1][4]]}, fh)
 
 
 def test_force_update_flushes_a_partial_accumulation_window_and_ranks_seed_dropout_differently():
