@@ -944,9 +944,11 @@ class NormQkvLmFn(Function):
         dxe = torch.empty((P + E, D), device=x.device, dtype=bf16)
         # data gradient: the pad rows of dxe stay unwritten on the flat path (the LayerNorm backward reads the real rows only)
         if fast:
-            tail = K.gemm_rows_ext(de, wa, dxe, Bn, n_p, pad, rows, E)
-            if tail:
-                _tail_rows(de[P + E - tail:], wa, dxe[P + E - tail:], mma=prec.mma, wt=shadow_t(w, prec))
+            # the sequence rows as whole rounds of the persistent kernel (B n rows x D columns = 2.0 rounds at c2; with the landmark
+            # rows appended its 24-K-tile units would start a third round for 6 % more rows: +50 us against a 19 us launch of their
+            # own on the 128 x 128 kernel, measured in the step's trace), the landmark rows [dq_l | dk_l] x W[:2D] separately
+            _rows_window(de[:P].view(Bn, n_p, N3), wa, dxe[:P].view(Bn, n_p, D), pad, rows, mma=prec.mma, wt=shadow_t(w, prec))
+            K.gemm(de[P:, :c0], wa[:c0], out=dxe[P:], mma=prec.mma)
         else:
             K.gemm(de, wa, out=dxe, mma=prec.mma)
         dw = None
