@@ -227,6 +227,34 @@ _CUS = 256       # MI355X compute units = workgroup slots of the one-workgroup-p
 _TAIL_SKINNY = True      # (test hook)
 
 
+_TAIL_ASIDE = True      # (test hook) the ragged-row launches of a captured step run on a parallel branch beside their tiled launch
+import contextlib
+
+
+def _tail_fork():
+    """Call BEFORE a tiled launch whose few ragged rows follow as tiny launches (_tail_rows): inside a HIP-graph capture it marks the
+    point from which those launches may run in parallel (an event on the capturing stream); None otherwise (eager: same stream)."""
+    if not (_TAIL_ASIDE and torch.cuda.is_current_stream_capturing()):
+        return None
+    return torch.cuda.current_stream().record_event()
+
+
+@contextlib.contextmanager
+def _tail_branch(fork, device):
+    """The ragged rows of a tiled launch (16 cls rows of B x 4097) are a dependent ~5 us launch that costs the replayed step 6-9 us of
+    serial time wherever it stands: ~25 of them per step.  Inside a capture they go to a helper stream forked at
+    `fork` (in front of the tiled launch, which they do not depend on) and the capturing stream joins behind the tiled launch: a
+    parallel branch of the graph instead of a link of the chain."""
+    if fork is None:
+        yield
+        return
+    main, side = torch.cuda.current_stream(), _side_stream(device, 2)
+    side.wait_event(fork)
+    with torch.cuda.stream(side):
+        yield
+    main.wait_stream(side)
+
+
 def _tail_rows(a2, b, out2, *, bias=None, act=ACT_NONE, mma, wt=None):
     """out2 [m, N] = act(a2 [m, K] @ b [K, N] + bias) for the few ragged rows a tiled launch leaves over (16 of B x 4097).  A 16-row
     product is the [B, D]-row shape of the RNA linears: the weight-streaming kernel (mh_skinny_fwd, ~6 us) instead of a tiled GEMM
@@ -256,8 +284,10 @@ def _gemm_rows(a, b, *, bias=None, act=ACT_NONE, mma, out_dtype, out=None, wt=No
             # 17th row tile for one row; flat, the 16 extra rows go to their own small launch
             a2 = a.reshape(R, Kd)
             o2 = torch.empty((R, N), device=a.device, dtype=out_dtype or a.dtype) if out is None else out.view(R, N)
+            fork = _tail_fork()
             _gemm_rows(a2[:R - rem], b, bias=bias, act=act, mma=mma, out_dtype=out_dtype, out=o2[:R - rem])
-            _tail_rows(a2[R - rem:], b, o2[R - rem:], bias=bias, act=act, mma=mma, wt=wt)
+            with _tail_branch(fork, a.device):
+                _tail_rows(a2[R - rem:], b, o2[R - rem:], bias=bias, act=act, mma=mma, wt=wt)
             return o2.reshape(*a.shape[:-1], N) if out is None else out
         if R % 256 == 0 and N % 256 == 0 and Kd % 64 == 0:
             tn = N // 256
@@ -283,11 +313,13 @@ def _rows_window(a3, b2, out3, r0, R, *, mma, wt=None):
     Bn = a3.shape[0]
     M = Bn * R
     tail = M % 256
+    fork = _tail_fork() if tail else None
     K.gemm_rows_window(a3, b2, out3, r0, R, m_rows=M - tail)
     if tail:
         if tail > R:
             raise K.MirrorHipError("_rows_window: the ragged rows span more than one batch")
-        _tail_rows(a3[Bn - 1, r0 + R - tail:r0 + R], b2, out3[Bn - 1, r0 + R - tail:r0 + R], mma=mma, wt=wt)
+        with _tail_branch(fork, a3.device):
+            _tail_rows(a3[Bn - 1, r0 + R - tail:r0 + R], b2, out3[Bn - 1, r0 + R - tail:r0 + R], mma=mma, wt=wt)
 
 
 def _rows_scatter(dy, b2, dx, r0, R, *, mma, wt=None):
@@ -297,9 +329,11 @@ def _rows_scatter(dy, b2, dx, r0, R, *, mma, wt=None):
     Bn = dy.shape[0]
     M = Bn * R
     tail = M % 256
+    fork = _tail_fork() if tail else None
     K.gemm_rows_window(dy, b2, dx, r0, R, m_rows=M - tail, a_r0=0)
     if tail:
-        _tail_rows(dy[Bn - 1, R - tail:R], b2, dx[Bn - 1, r0 + R - tail:r0 + R], mma=mma, wt=wt)
+        with _tail_branch(fork, dy.device):
+            _tail_rows(dy[Bn - 1, R - tail:R], b2, dx[Bn - 1, r0 + R - tail:r0 + R], mma=mma, wt=wt)
 
 
 def _rows_window_ok(a3, out3, r0, R, N, prec) -> bool:
@@ -650,11 +684,13 @@ class ToOutDropAddFn(Function):
         M = Bn * R
         tail = K.linear_fused_tail(M)
         bd = None if b is None else b.detach()
+        fork = _tail_fork() if tail else None
         K.linear_fused(core, wa, bd, out, K.epi_dropadd(resid, p, ctx.seed, ctx.offset, ctx.base), window=(r0, R), m_rows=M - tail)
-        if tail:     # the last rows of the last slide: composed ops on [tail, K] (same stream, same masks: the offsets are per element)
-            yt = _tail_rows(core[Bn - 1, r0 + R - tail:r0 + R], wa.t(), torch.empty((tail, N), device=core.device, dtype=bf16), bias=bd, mma=prec.mma)
-            K.dropout_lite(yt, p, ctx.seed, ctx.offset + (M - tail) * N, ctx.base, add_to=resid.view(M, N)[M - tail:],
-                           out=out.view(M, N)[M - tail:])
+        if tail:     # the last rows of the last slide: composed ops on [tail, K] (same masks: the offsets are per element)
+            with _tail_branch(fork, core.device):
+                yt = _tail_rows(core[Bn - 1, r0 + R - tail:r0 + R], wa.t(), torch.empty((tail, N), device=core.device, dtype=bf16), bias=bd, mma=prec.mma)
+                K.dropout_lite(yt, p, ctx.seed, ctx.offset + (M - tail) * N, ctx.base, add_to=resid.view(M, N)[M - tail:],
+                               out=out.view(M, N)[M - tail:])
         ctx.save_for_backward(core, wa, w, b)
         ctx.r0, ctx.R, ctx.prec, ctx.res_key = r0, R, prec, resid.data_ptr()
         return out
@@ -767,11 +803,13 @@ class EmbedMaskPosFn(Function):
         tail = K.linear_fused_tail(M)
         bd = None if b is None else b.detach()
         tok, ps = token.detach().reshape(-1).contiguous(), pos.detach().reshape(T, N).contiguous()
+        fork = _tail_fork() if tail else None
         K.linear_fused(h, wa, bd, out, K.epi_maskpos(mask, tok, ps, T, first), m_rows=M - tail)
         if tail and T - tail >= first:       # the last rows of the last slide through the composed ops
-            rt = _tail_rows(h[Bn - 1, T - tail:], wa.t(), torch.empty((tail, N), device=h.device, dtype=bf16), bias=bd, mma=prec.mma)
-            K.mask_apply_fwd(rt.view(1, tail, N), mask[Bn - 1, T - tail - first:].contiguous(), tok, ps[T - tail:].reshape(-1), 1, tail, N, 0, False,
-                             out=out[Bn - 1:, T - tail:])
+            with _tail_branch(fork, h.device):
+                rt = _tail_rows(h[Bn - 1, T - tail:], wa.t(), torch.empty((tail, N), device=h.device, dtype=bf16), bias=bd, mma=prec.mma)
+                K.mask_apply_fwd(rt.view(1, tail, N), mask[Bn - 1, T - tail - first:].contiguous(), tok, ps[T - tail:].reshape(-1), 1, tail, N, 0,
+                                 False, out=out[Bn - 1:, T - tail:])
         elif tail:
             raise K.MirrorHipError("EmbedMaskPosFn: the tail rows cross the unmasked prefix")
         ctx.save_for_backward(h, wa, w, b, mask)
@@ -914,9 +952,11 @@ class NormQkvLmFn(Function):
         fast = (pad > 0 and prec.mma == MH_BF16 and c0 % 256 == 0 and (N3 - c0) % 256 == 0
                 and K.gemm_rows_ext_ok(Bn, n_p, pad, rows, E, D, c0, xe, qe[:, :c0]) and _rows_window_ok(xs, qkv[..., c0:], pad, rows, N3 - c0, prec))
         if fast:
+            fork = _tail_fork()
             tail = K.gemm_rows_ext(xe, wa[:c0].t(), qe[:, :c0], Bn, n_p, pad, rows, E)
             if tail:
-                _tail_rows(xe[P + E - tail:], wa[:c0].t(), qe[P + E - tail:, :c0], mma=prec.mma)
+                with _tail_branch(fork, x.device):
+                    _tail_rows(xe[P + E - tail:], wa[:c0].t(), qe[P + E - tail:, :c0], mma=prec.mma)
 
             def later():      # q = k = v = 0 on the pad rows (they take part in the softmaxes as zero keys): nobody reads them before
                 qkv[:, :pad].zero_()      # the attention kernels, so the fill waits with the v columns (the fork is 8 us earlier)
