@@ -643,14 +643,16 @@ def _linear_rows_bwd(ctx_needs, x, wa, w, b, r0, R, prec, dy, dx_dtype=None):
     dx = dw = db = None
     if ctx_needs[0]:
         dx = torch.empty(x.shape, device=x.device, dtype=dx_dtype or x.dtype)
-        if r0:
-            dx[:, :r0].zero_()
-        if r0 + R < x.shape[1]:
-            dx[:, r0 + R:].zero_()
+        fork = _tail_fork()
         if dy.dim() == 3 and dy.is_contiguous() and dx.dtype == bf16 and dy.shape[1] == R and (dy.shape[0] * R) % 256 <= R and _rows_window_ok(dy, dx, r0, R, Kd, prec):
             _rows_scatter(dy, wa, dx, r0, R, mma=prec.mma, wt=_wt_of(w, prec, dy))
         else:
             _gemm_window(dy, wa, dx[:, r0:r0 + R], mma=prec.mma, wt=_wt_of(w, prec, dy))
+        with _tail_branch(fork, x.device):       # the fills of the rows outside the window: beside the product, not in front of it
+            if r0:
+                dx[:, :r0].zero_()
+            if r0 + R < x.shape[1]:
+                dx[:, r0 + R:].zero_()
     if ctx_needs[1]:
         dw, sunk = _gbuf(w, (N, Kd))
         _wgrad(dy, x[:, r0:r0 + R], N, Kd, prec, dw)
@@ -959,8 +961,10 @@ class NormQkvLmFn(Function):
                     _tail_rows(xe[P + E - tail:], wa[:c0].t(), qe[P + E - tail:, :c0], mma=prec.mma)
 
             def later():      # q = k = v = 0 on the pad rows (they take part in the softmaxes as zero keys): nobody reads them before
-                qkv[:, :pad].zero_()      # the attention kernels, so the fill waits with the v columns (the fork is 8 us earlier)
+                fork = _tail_fork()       # the attention kernels, so the fill waits with the v columns — and runs beside them
                 _rows_window(xs, wa[c0:].t(), qkv[..., c0:], pad, rows, mma=prec.mma)
+                with _tail_branch(fork, x.device):
+                    qkv[:, :pad].zero_()
         else:
             K.gemm(xe, wa[:c0].t(), out=qe[:, :c0], mma=prec.mma)      # zero pad rows in, zero rows out
 
