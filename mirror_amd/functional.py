@@ -1456,6 +1456,7 @@ _S2_TAIL = True      # (test hook)
 _Z0_ROWS = True      # (test hook)
 _SIM2_SIDE = True      # nys_sim2 opens the chain's branch instead of preceding the fork
 _S2_SIDE = True      # sim2's landmark gradients on the chain's stream
+_W2_ON_CHAIN = True      # (test hook) w2 = pinv (attn3 v) at the end of the chain's branch instead of behind the join (-0.22 % +- 0.06)
 _DZ_DAV = True      # (test hook)
 # (measured and deleted in round 4, see DESIGN.md section 6 round 3: nys_dz_dav on the chain's branch +0.32 %, attn3's delta out of
 #  nys_dz_dav +0.32 %, the chain branch joined in front of the landmark projection's backward +0.02 %, res_conv's weight gradient on
@@ -1565,14 +1566,25 @@ class NystromCoreFn(Function):
         if not fused:
             av = K.gemm(a3, v, mma=mma, out_dtype=f32)                                   # [B,h,m,dh]
         out = torch.empty((Bn, n_p, D), device=qkv.device, dtype=A)
+        # GEMMs that meet activation-dtype tensors cannot use the exact-f32 MFMA unless the activations are f32 too
+        pio = pm if (pm == MH_BF16 or A == f32) else mma
+        w2 = None
+        if side is not None and fused and _W2_ON_CHAIN:
+            # w2 = pinv(attn2) (attn3 v) is a [256 x 256] x [256 x 64] product per (b, h): ~11 us of launch that stood alone behind the
+            # join.  av is complete here (the main side of the window is past attn3), the pseudo-inverse when the chain's stream gets to
+            # it: the product goes to the END of the chain's branch, beside res_conv on the main side, and the join covers it.
+            w2 = torch.empty((Bn, h, m_l, dh), device=qkv.device, dtype=A)
+            av_ready = torch.cuda.current_stream().record_event()
+            with torch.cuda.stream(side):
+                side.wait_event(av_ready)
+                K.gemm(zf, av, out=w2, mma=pio)
         if fused:   # res_conv(v) does not need the pseudo-inverse: it runs under the chain, attn1 then adds to it
             K.resconv(qkv[..., 2 * D:], res_w.detach().contiguous(), out, h, transpose=False, accumulate=False)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
             K.shared_chip = False
-        # GEMMs that meet activation-dtype tensors cannot use the exact-f32 MFMA unless the activations are f32 too
-        pio = pm if (pm == MH_BF16 or A == f32) else mma
-        w2 = K.gemm(zf, av, mma=pio, out_dtype=A)
+        if w2 is None:
+            w2 = K.gemm(zf, av, mma=pio, out_dtype=A)
         if fused:
             # fp8 forward policy: once to_out's call site has a scale history, attn1 also writes the e4m3 copy that projection reads
             st8 = _fp8_state
