@@ -984,16 +984,23 @@ class NormQkvLmFn(Function):
         m = n_p // l
         P, E = Bn * n_p, Bn * m
         N3, c0 = wa.shape[0], 2 * wa.shape[1]
-        de = ext_rows_of(dqkv, dlm, P, E, N3, c0)
+        merge = _pending_lm_merge.pop(dlm.data_ptr(), None)        # NystromCoreFn.backward left the landmark rows' merge to this node
+        de = ext_rows_of(dqkv, dlm, P, E, N3, c0, copy_lm=merge is None)
         dxe = torch.empty((P + E, D), device=x.device, dtype=bf16)
         # data gradient: the pad rows of dxe stay unwritten on the flat path (the LayerNorm backward reads the real rows only)
         if fast:
+            fork = _tail_fork()
             # the sequence rows as whole rounds of the persistent kernel (B n rows x D columns = 2.0 rounds at c2; with the landmark
             # rows appended its 24-K-tile units would start a third round for 6 % more rows: +50 us against a 19 us launch of their
             # own on the 128 x 128 kernel, measured in the step's trace), the landmark rows [dq_l | dk_l] x W[:2D] separately
             _rows_window(de[:P].view(Bn, n_p, N3), wa, dxe[:P].view(Bn, n_p, D), pad, rows, mma=prec.mma, wt=shadow_t(w, prec))
-            K.gemm(de[P:, :c0], wa[:c0], out=dxe[P:], mma=prec.mma)
+            with _tail_branch(fork, x.device):      # beside the sequence rows' product (inside a capture): ~40 us off the chain per layer
+                if merge is not None:
+                    merge()
+                K.gemm(de[P:, :c0], wa[:c0], out=dxe[P:], mma=prec.mma)
         else:
+            if merge is not None:
+                merge()
             K.gemm(de, wa, out=dxe, mma=prec.mma)
         dw = None
         if ctx.needs_input_grad[7]:
@@ -1024,13 +1031,15 @@ def ext_rows_alloc(Bn: int, n_p: int, m: int, N3: int, c0: int, device):
     return de, _alias(de, 0, (Bn, n_p, N3), (n_p * N3, N3, 1)), _alias(de, P * N3, (Bn, m, c0), (m * N3, N3, 1))
 
 
-def ext_rows_of(dqkv, dlm, P: int, E: int, N3: int, c0: int):
+def ext_rows_of(dqkv, dlm, P: int, E: int, N3: int, c0: int, copy_lm: bool = True):
     """The [P + E, N3] buffer of which dqkv / dlm are the two row ranges (ext_rows_alloc), or a freshly assembled copy."""
     if (dqkv.dtype == bf16 and dlm.dtype == bf16 and dqkv.is_contiguous() and dqkv.numel() == P * N3
             and dlm.data_ptr() == dqkv.data_ptr() + P * N3 * 2 and dlm.dim() == 3 and tuple(dlm.stride()) == (dlm.shape[1] * N3, N3, 1)
             and dlm.shape[0] * dlm.shape[1] == E and dlm.shape[2] == c0
             and dqkv.untyped_storage().nbytes() - dqkv.storage_offset() * 2 >= (P + E) * N3 * 2):
         return torch.as_strided(dqkv, (P + E, N3), (N3, 1))
+    if not copy_lm:
+        raise K.MirrorHipError("NormQkvLmFn.backward: a pending landmark merge needs the gradient views of ext_rows_alloc")
     de = torch.empty((P + E, N3), device=dqkv.device, dtype=bf16)
     de[:P].copy_(dqkv.reshape(P, N3))
     de[P:, :c0].copy_(dlm.reshape(E, c0))
@@ -1456,6 +1465,8 @@ _S2_TAIL = True      # (test hook)
 _Z0_ROWS = True      # (test hook)
 _SIM2_SIDE = True      # nys_sim2 opens the chain's branch instead of preceding the fork
 _S2_SIDE = True      # sim2's landmark gradients on the chain's stream
+_LM_MERGE_LATE = True      # (test hook) the landmark rows' merge + data gradient beside the sequence rows' data gradient (-0.24 % +- 0.29)
+_pending_lm_merge: dict = {}      # data_ptr of the landmark-gradient view NystromCoreFn.backward returned -> its deferred merge launch
 _W2_ON_CHAIN = True      # (test hook) w2 = pinv (attn3 v) at the end of the chain's branch instead of behind the join (-0.22 % +- 0.06)
 _DZ_DAV = True      # (test hook)
 # (measured and deleted in round 4, see DESIGN.md section 6 round 3: nys_dz_dav on the chain's branch +0.32 %, attn3's delta out of
@@ -1724,8 +1735,14 @@ class NystromCoreFn(Function):
         dres = _gret(res_w, dres, dres_sunk)
         dres = None if dres is None else dres.view_as(res_w)
         if de is not None and kmask is None:
-            # the merge of the two f32 partial sums is also the cast, written as rows [dq_l | dk_l | 0] behind the sequence rows
-            K.lm_merge(dlm, dlm2, de[Bn * n_p:], D3 - 2 * D)
+            # the merge of the two f32 partial sums is also the cast, written as rows [dq_l | dk_l | 0] behind the sequence rows.
+            # Nothing but the landmark rows' own products needs it: NormQkvLmFn.backward runs it (and the landmark rows' data gradient)
+            # on a parallel branch beside the data gradient of the sequence rows instead of in front of it
+            merge = lambda: K.lm_merge(dlm, dlm2, de[Bn * n_p:], D3 - 2 * D)      # noqa: E731
+            if _LM_MERGE_LATE:
+                _pending_lm_merge[dlm_out.data_ptr()] = merge
+            else:
+                merge()
             return dqkv, dres, None, None, None, None, None, None, dlm_out
         if dlm2 is not None:
             dlm = K.add(dlm, dlm2, out_dtype=A)
