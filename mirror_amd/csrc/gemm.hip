@@ -132,7 +132,7 @@ extern "C" int64_t mh_gemm_workspace_bytes(const mh_gemm_desc* d) {
     const bool bcast = (d->sC1 == 0 || d->batch1 == 1) && (d->sC2 == 0 || d->batch2 == 1);
     const int64_t parts = (int64_t)split * (bcast ? (int64_t)d->batch1 * d->batch2 : 1);
     if (parts < 8) return 0;
-    return parts * d->M * d->N * 4;
+    return parts * d->M * d->N * 2;      // bf16 partial tiles
 }
 
 extern "C" int mh_gemm(const mh_gemm_desc* d, mh_stream stream) {

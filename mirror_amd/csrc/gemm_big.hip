@@ -445,9 +445,9 @@ __global__ __launch_bounds__(NTB) void gemm_big_kernel(GemmArgs g) {
         // partial tile -> workspace [part][M][N] with plain 16-byte stores (part = z * splits + split); 16.7 M same-matrix
         // f32 atomics of a 64-way split cost more than the whole K loop, a fold pass over the partials does not.  (Its own
         // instance: with three epilogues inlined into one kernel the compiler spilled in the f32 instances.)
-        if constexpr (sizeof(TC) == 4) {
-            float* P = g.ws + ((long)z * gridDim.y + split) * (long)g.M * g.N;
-            epilogue_big<float, 0>(g, P, acc, smem, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, false, (long)g.N, g.alpha);
+        if constexpr (sizeof(TC) == 4) {      // partial tiles are stored as bf16 (see fold_partials_kernel)
+            bf16_t* P = reinterpret_cast<bf16_t*>(g.ws) + ((long)z * gridDim.y + split) * (long)g.M * g.N;
+            epilogue_big<bf16_t, 0>(g, P, acc, smem, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, false, (long)g.N, g.alpha);
         }
         return;
     }
@@ -685,9 +685,9 @@ __global__ __launch_bounds__(NTB) void gemm_pp_kernel(GemmArgs g) {
         return;
     }
     if constexpr (PART) {
-        if constexpr (sizeof(TC) == 4) {
-            float* P = g.ws + ((long)z * gridDim.y + split) * (long)g.M * g.N;
-            epilogue_big<float, 0>(g, P, acc, smem, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, false, (long)g.N, g.alpha);
+        if constexpr (sizeof(TC) == 4) {      // partial tiles are stored as bf16 (see fold_partials_kernel)
+            bf16_t* P = reinterpret_cast<bf16_t*>(g.ws) + ((long)z * gridDim.y + split) * (long)g.M * g.N;
+            epilogue_big<bf16_t, 0>(g, P, acc, smem, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, false, (long)g.N, g.alpha);
         }
         return;
     }
@@ -859,7 +859,7 @@ __device__ __forceinline__ void pq_epilogue_bf16(const GemmArgs& g, bf16_t* C, f
 }
 
 // f32 C (a lane owns a column, its registers the rows): rows [64 q, +64) of the tile through `t`, q = 0 .. 3
-template <int MODE, int EPI>
+template <int MODE, int EPI, bool OUT16 = false>      // OUT16: C points to bf16 storage (the split-K partial tiles), rows of ldc ELEMENTS
 __device__ __forceinline__ void pq_epilogue_f32(const GemmArgs& g, float* C, f32x16 (&acc)[BWM][BWN], char* smem_c, int tile_row0, int tile_col0,
                                                 int wm, int wn, int lane, int tid, bool lead, long ldc, float alpha) {
     constexpr int PITCH = BIG + 4, QR = BIG / 4;
@@ -926,11 +926,19 @@ __device__ __forceinline__ void pq_epilogue_f32(const GemmArgs& g, float* C, f32
                 const int lr = cid / CPR, c = cid % CPR;
                 const int grow = tile_row0 + q * QR + lr;
                 if (grow >= g.M) continue;
-                float* dst = C + (long)grow * ldc + tile_col0 + c * 4;
                 f32x4 x0 = *reinterpret_cast<const f32x4*>(t + lr * PITCH + c * 4);
-                if constexpr (EPI != 0) x0 = epi_quad<EPI>(g, x0, grow, tile_col0 + c * 4);
-                if constexpr (MODE == 1) x0 += *reinterpret_cast<const f32x4*>(dst);
-                *reinterpret_cast<f32x4*>(dst) = x0;
+                if constexpr (OUT16) {
+                    bf16_t* d16 = reinterpret_cast<bf16_t*>(C) + (long)grow * ldc + tile_col0 + c * 4;
+                    u32x2 o;
+                    o[0] = (unsigned)f2bf(x0[0]) | ((unsigned)f2bf(x0[1]) << 16);
+                    o[1] = (unsigned)f2bf(x0[2]) | ((unsigned)f2bf(x0[3]) << 16);
+                    *reinterpret_cast<u32x2*>(d16) = o;
+                } else {
+                    float* dst = C + (long)grow * ldc + tile_col0 + c * 4;
+                    if constexpr (EPI != 0) x0 = epi_quad<EPI>(g, x0, grow, tile_col0 + c * 4);
+                    if constexpr (MODE == 1) x0 += *reinterpret_cast<const f32x4*>(dst);
+                    *reinterpret_cast<f32x4*>(dst) = x0;
+                }
             }
         }
         __syncthreads();
@@ -1099,8 +1107,8 @@ __global__ __launch_bounds__(NTB) void gemm_pq_kernel(GemmArgs g, int units, int
             if (g.accumulate) pq_epilogue_bf16<1, 0>(g, C, acc, cst, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, lead, g.alpha);
             else pq_epilogue_bf16<0, 0>(g, C, acc, cst, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, lead, g.alpha);
         } else if constexpr (PART) {
-            float* P = g.ws + ((long)z * splits + split) * (long)g.M * g.N;
-            pq_epilogue_f32<0, 0>(g, P, acc, cst, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, false, (long)g.N, g.alpha);
+            bf16_t* P = reinterpret_cast<bf16_t*>(g.ws) + ((long)z * splits + split) * (long)g.M * g.N;      // bf16 partial tiles
+            pq_epilogue_f32<0, 0, true>(g, reinterpret_cast<float*>(P), acc, cst, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, false, (long)g.N, g.alpha);
         } else {
             if (g.atomic) epilogue_atomic_big(g, reinterpret_cast<float*>(C), acc, tile_m * BIG + wm * BWM * 32, tile_n * BIG + wn * BWN * 32, lane);
             else if (g.accumulate) pq_epilogue_f32<1, 0>(g, reinterpret_cast<float*>(C), acc, cst, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, lead, g.ldc, g.alpha);
@@ -1112,9 +1120,16 @@ __global__ __launch_bounds__(NTB) void gemm_pq_kernel(GemmArgs g, int units, int
     }
 }
 
-// C[r][c] += sum_p P[p][r][c]: quads, 8 partials in flight; TAIL: + the rank-(batch x KT) remainder of the contraction (GemmTail)
+// C[r][c] += sum_p P[p][r][c]: quads, 8 partials in flight; TAIL: + the rank-(batch x KT) remainder of the contraction (GemmTail).
+// The partial tiles are bf16 (round 4): every K-slice's f32 accumulator is rounded ONCE on its way out — the same 2^-9 relative step
+// the bf16 operands already carry — and the sum over the slices runs in f32 here; half the bytes of the f32 form in both directions
+// (64 partials of a 512 x 512 gradient: 2 x 64 MB -> 2 x 32 MB per launch pair).
+__device__ __forceinline__ f32x4 ld4_bf16(const bf16_t* p) {
+    const u32x2 w = *reinterpret_cast<const u32x2*>(p);
+    return f32x4{__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xffff0000u), __uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xffff0000u)};
+}
 template <bool TAIL>
-__global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restrict__ P, int parts, long mn, float* __restrict__ C, long ldc,
+__global__ __launch_bounds__(256) void fold_partials_kernel(const bf16_t* __restrict__ P, int parts, long mn, float* __restrict__ C, long ldc,
                                                             int N, GemmTail t) {
     for (long q = (long)blockIdx.x * 256 + threadIdx.x; q * 4 < mn; q += (long)gridDim.x * 256) {
         const long i = q * 4, r = i / N, c = i % N;
@@ -1123,11 +1138,11 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restr
         for (; p + 8 <= parts; p += 8) {
             f32x4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const f32x4*>(P + (long)(p + u) * mn + i);
+            for (int u = 0; u < 8; u++) v[u] = ld4_bf16(P + (long)(p + u) * mn + i);
 #pragma unroll
             for (int u = 0; u < 8; u++) s += v[u];
         }
-        for (; p < parts; p++) s += *reinterpret_cast<const f32x4*>(P + (long)p * mn + i);
+        for (; p < parts; p++) s += ld4_bf16(P + (long)p * mn + i);
         if constexpr (TAIL) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             const int total = t.batch * t.KT;
@@ -1161,7 +1176,8 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restr
         *reinterpret_cast<f32x4*>(C + r * ldc + c) = s;
     }
 }
-static void launch_fold(const float* ws, int parts, long mn, float* C, long ldc, int N, hipStream_t s) {
+static void launch_fold(const float* ws_, int parts, long mn, float* C, long ldc, int N, hipStream_t s) {
+    const bf16_t* ws = reinterpret_cast<const bf16_t*>(ws_);
     const dim3 grid((unsigned)min((long)mh_cdiv(mn / 4, 256), 2048L));
     // the tail's B rows are read as aligned quads of the output's columns: 4-element alignment of its rows and base
     if (g_tail.KT > 0 && (g_tail.ldb % 4) == 0 && (g_tail.sB % 4) == 0 && ((uintptr_t)g_tail.B & (g_tail.b_f32 ? 15 : 7)) == 0) {
@@ -1213,7 +1229,7 @@ void launch_big(GemmArgs& a, int akc, int bkc, int batch, hipStream_t s) {
     dim3 grid(a.tiles_m * a.tiles_n, a.split_k, batch);
     if (pp_enabled()) {
         const long parts_ = (long)a.split_k * batch, mn_ = (long)a.M * a.N;
-        const bool partial_ = a.atomic && a.ws && a.M % BIG == 0 && a.ws_floats >= parts_ * mn_ && ((uintptr_t)a.ws & 15) == 0 && a.vecC &&
+        const bool partial_ = a.atomic && a.ws && a.M % BIG == 0 && a.ws_floats * 2 >= parts_ * mn_ && ((uintptr_t)a.ws & 15) == 0 && a.vecC &&
                               a.sC1 == 0 && a.sC2 == 0 && parts_ >= 8;
         if (!partial_) a.ws = nullptr;
 #define PP_DISPATCH_(PART)                                                                 \
@@ -1237,7 +1253,7 @@ void launch_big(GemmArgs& a, int akc, int bkc, int batch, hipStream_t s) {
     // reduction into one C: partial tiles in the caller's workspace when it is large enough, f32 atomics otherwise
     gemm_note_variant("gemm_big_kernel<%s,%s,%s>", gemm_tn<TC>(), gemm_tf(akc), gemm_tf(bkc));
     const long parts = (long)a.split_k * batch, mn = (long)a.M * a.N;
-    const bool partial = a.atomic && a.ws && a.M % BIG == 0 && a.ws_floats >= parts * mn && ((uintptr_t)a.ws & 15) == 0 && a.vecC &&
+    const bool partial = a.atomic && a.ws && a.M % BIG == 0 && a.ws_floats * 2 >= parts * mn && ((uintptr_t)a.ws & 15) == 0 && a.vecC &&
                          a.sC1 == 0 && a.sC2 == 0 && parts >= 8;
     if (!partial) a.ws = nullptr;
     if constexpr (sizeof(TC) == 4) {

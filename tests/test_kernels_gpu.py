@@ -93,7 +93,14 @@ def test_gemm_large_tile_kernel(a_rm, b_t, out_dtype):
     if out_dtype == torch.float32:
         dw = base[0].to(DEV).contiguous()
         K.gemm(a_dev, b_dev, out=dw.expand(Bt, M, N), accumulate=True, split_k=3, mma=MH_BF16)   # batch broadcast + split-K
-        close(dw, ref.sum(0) + base[0].double(), 0, 0, "large tile split-K atomics")
+        # 3 batches x 3 K-slices = 9 partial tiles, each f32 accumulator rounded ONCE to bf16 on its way to the fold pass (round 4):
+        # bit-exact against the same sums with that rounding (slices of 128, 128, 64 of K = 320)
+        want = base[0].double().clone()
+        for z in range(Bt):
+            for k0, k1 in ((0, 128), (128, 256), (256, 320)):
+                want += (a[z][:, k0:k1].double() @ b[z][k0:k1].double()).float().bfloat16().double()
+        close(dw, want, 0, 0, "large tile split-K partial tiles (bf16) + fold")
+        assert float((dw.cpu().double() - ref.sum(0) - base[0].double()).abs().max()) <= 2 ** -8 * 9 * float(ref.abs().max())
     if a_rm:        # ragged M (K-contiguous A rows): the last row tile clamps its loads and guards its stores
         Mr = 4 * 256 + 37
         ar_dev, ar = _mk(True, (Bt, Mr, Kd), gen, bf, True)
