@@ -32,6 +32,13 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
     return __builtin_bit_cast(bf16_t, b);
 }
+// two f32 -> one dword of bf16 (lo in bits 0-15): ONE v_cvt_pk_bf16_f32 (f2bf(lo) | f2bf(hi) << 16 costs two of them, a shift and an or)
+typedef __bf16 mh_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float mh_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    const mh_f32x2 f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, mh_bf16x2));
+}
 
 template <typename T> __device__ __forceinline__ float ldf(const T* p);
 template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
@@ -53,7 +60,7 @@ template <> __device__ __forceinline__ f4_t ld4<bf16_t>(const bf16_t* p) {
 template <typename T> __device__ __forceinline__ void st4(T* p, f4_t v);
 template <> __device__ __forceinline__ void st4<float>(float* p, f4_t v) { *reinterpret_cast<f4_t*>(p) = v; }
 template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, f4_t v) {
-    u2_t u = {(uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16)};
+    u2_t u = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
     *reinterpret_cast<u2_t*>(p) = u;
 }
 // host side: can `p` be accessed as quads of `esz`-byte elements?

@@ -136,10 +136,10 @@ __device__ __forceinline__ void epilogue_big(const GemmArgs& g, TC* C, f32x16 (&
                     x1[0] += __uint_as_float(old[2] << 16); x1[1] += __uint_as_float(old[2] & 0xffff0000u);
                     x1[2] += __uint_as_float(old[3] << 16); x1[3] += __uint_as_float(old[3] & 0xffff0000u);
                 }
-                o[0] = (unsigned)f2bf(x0[0]) | ((unsigned)f2bf(x0[1]) << 16);
-                o[1] = (unsigned)f2bf(x0[2]) | ((unsigned)f2bf(x0[3]) << 16);
-                o[2] = (unsigned)f2bf(x1[0]) | ((unsigned)f2bf(x1[1]) << 16);
-                o[3] = (unsigned)f2bf(x1[2]) | ((unsigned)f2bf(x1[3]) << 16);
+                o[0] = pack_bf2(x0[0], x0[1]);
+                o[1] = pack_bf2(x0[2], x0[3]);
+                o[2] = pack_bf2(x1[0], x1[1]);
+                o[3] = pack_bf2(x1[2], x1[3]);
             }
             *reinterpret_cast<u32x4*>(dst) = o;
         }
@@ -196,8 +196,8 @@ __device__ __forceinline__ void epilogue_big_t(const GemmArgs& g, bf16_t* C, f32
                     if (g.act == MH_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
                 }
                 u32x2 o;
-                o[0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-                o[1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                o[0] = pack_bf2(v[0], v[1]);
+                o[1] = pack_bf2(v[2], v[3]);
                 *reinterpret_cast<u32x2*>(t + lr * PITCH + lc) = o;
             }
         }
@@ -219,7 +219,7 @@ __device__ __forceinline__ void epilogue_big_t(const GemmArgs& g, bf16_t* C, f32
             for (int w = 0; w < 4; w++) {
                 const float a0 = __uint_as_float(o[w] << 16) + __uint_as_float(old[w] << 16);
                 const float a1 = __uint_as_float(o[w] & 0xffff0000u) + __uint_as_float(old[w] & 0xffff0000u);
-                o[w] = (unsigned)f2bf(a0) | ((unsigned)f2bf(a1) << 16);
+                o[w] = pack_bf2(a0, a1);
             }
         }
         if (GEMM_EXP == 5) { if (o[0] == 0x12345678u) *reinterpret_cast<u32x4*>(dst) = o; continue; }
@@ -713,6 +713,11 @@ __global__ __launch_bounds__(NTB) void gemm_pp_kernel(GemmArgs g) {
 //   * the C stores are only ISSUED in the epilogue: they drain underneath the next unit's K loop.
 // vmcnt counts stores and loads together, in order: the first wait of a unit's K loop (end of K-tile 0) also waits for the
 // stores issued ~1 us earlier; what is left of their drain time is the only exposed part of the epilogue's memory traffic.
+// Cycle stamps (round 4, tools/exp/pq_stamps_patch.py) of a K loop segment, per wave row: fragment reads + requests + wait ~880,
+// barrier ~140, 16 MFMAs ~700, barrier ~300: ~2000 cycles for 2 x 512 cycles of matrix-pipe work per SIMD.  Built and measured on one
+// box against this loop, none faster: a four-segment ring with the request for segment s + 3 issued between the MFMAs (the load
+// phase drops to ~350 cycles, the MFMA phase grows to ~800: same 2000), 1 / 2 / 3 of its 4 pieces in the load phase (equal; the
+// long-K gradient products 3-11 % slower), no requests at all (1750: the floor of the two-barrier structure).
 // ---- stage layout of gemm_pq_kernel: every operand tile is TWO k-half sub-images of 16 KiB (k in [0, 32) and [32, 64) of the K-tile),
 // so that a segment of two k-steps reads one sub-image per operand and the other half can be in flight:
 //   K-contiguous: [256 rows][64 B], 16-byte chunk c of row r stored at chunk c ^ ((r >> 2) & 3)      (ds_read_b128 conflict free)
@@ -763,64 +768,113 @@ __device__ __forceinline__ bf16x8 p2_frag_ks(const char* sub, unsigned off, int 
 constexpr int PQ_SLOT = 68 * 1024;            // LDS stage slot: A image 32 KiB | B image 32 KiB | 4 KiB that only the C staging uses
 constexpr int PQ_LDS = 2 * PQ_SLOT;
 
-// bf16 C (accumulators hold C^T: a lane owns 4 consecutive columns of a row): rows [128 half, +128) of the tile through `t`
-template <int MODE, int EPI>
-__device__ __forceinline__ void pq_epilogue_bf16(const GemmArgs& g, bf16_t* C, f32x16 (&acc)[BWM][BWN], char* smem_c, int tile_row0, int tile_col0,
-                                                 int wm, int wn, int lane, int tid, bool lead, float alpha) {
+// ---- epilogues of gemm_pq_kernel: C through the LDS stage the unit has just consumed.  Measured with in-kernel cycle stamps
+// (tools/exp/pq_stamps_patch.py; K = 512: a third of a unit's 48k cycles was epilogue): a write phase took ~4000 cycles because every
+// bias quad was a dependent load behind an s_waitcnt vmcnt(0) (emitted with or without a bias) and every element cost a multiply-add,
+// a max, a select and its own conversion.  Hence: activation and the plain case are template parameters (with a run-time flag in the
+// element loop the compiler computes both forms of all 128 values before it selects, and spills them), the bias quads of a column
+// block are requested together, two elements share one v_cvt_pk_bf16_f32, and the staging reads of a phase all land in registers
+// before the barrier that frees the image, so the stores are issued while the other wave row already writes the next phase.
+//
+// bf16 C (or the bf16 split-K partial tiles: C = the slice's partial matrix, ldc = N, remap = false).  The accumulators are in C^T
+// form (a lane owns 4 consecutive columns of a row); rows [128 half, +128) of the tile go through `t`, the wave row `half` writing,
+// everybody storing 16-byte row-contiguous chunks.  KIND 0: alpha == 1, no bias, no activation: both wave rows pack their
+// accumulators first (one v_cvt_pk_bf16_f32 per two elements, in place), so a write phase is 32 ds_write_b64 and nothing else;
+// 1: alpha, bias (the 4 quads of a column block requested together); 2: + ReLU.
+template <int MODE, int EPI, int KIND>
+__device__ __forceinline__ void pq_epilogue_bf16(const GemmArgs& g, bf16_t* C, long ldc, bool remap, f32x16 (&acc)[BWM][BWN], char* smem_c,
+                                                 int tile_row0, int tile_col0, int wm, int wn, int lane, int tid, bool has_bias, float alpha) {
     constexpr int PITCH = BIG + 4, HALF = BIG / 2;
+    // the staging addresses are recomputed per unit: hoisted out of the unit loop they would live (spilled) across the K loop
+    asm volatile("" : "+v"(lane), "+v"(tid));
     bf16_t* t = reinterpret_cast<bf16_t*>(smem_c);
     const int r = lane & 31, hh = lane >> 5;
-    const bool has_bias = g.bias && lead;
+    unsigned pk[BWM][BWN][8];
+    if constexpr (KIND == 0) {
+#pragma unroll
+        for (int i = 0; i < BWM; i++)
+#pragma unroll
+            for (int j = 0; j < BWN; j++)
+#pragma unroll
+                for (int w = 0; w < 8; w++) pk[i][j][w] = pack_bf2(acc[i][j][2 * w], acc[i][j][2 * w + 1]);
+    }
+    // physical rows of this tile (row windows, GemmArgs.c_rpb): a tile touches at most two windows when c_rpb >= 256
+    const bool win = remap && g.c_rpb > 0, win2 = win && g.c_rpb >= BIG;
+    long c_adj = 0;
+    int c_bnd = 1 << 30;
+    if (win2) {
+        const int bq = min(tile_row0 / g.c_rpb, g.w_last);
+        c_adj = (long)bq * g.c_skip;
+        if (bq < g.w_last) c_bnd = (bq + 1) * g.c_rpb;
+    }
     float sq_sum = 0.f, sq_cnt = 0.f;
 #pragma unroll
     for (int half = 0; half < 2; half++) {
         if (wm == half) {
 #pragma unroll
-            for (int j = 0; j < BWN; j++)
+            for (int j = 0; j < BWN; j++) {
+                f32x4 bv[4];
+                if constexpr (KIND != 0) {
 #pragma unroll
-                for (int gq = 0; gq < 4; gq++) {
-                    const int lc = wn * BWN * 32 + 32 * j + 8 * gq + 4 * hh;
-                    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                    if (has_bias) bv = *reinterpret_cast<const f32x4*>(g.bias + tile_col0 + lc);
+                    for (int gq = 0; gq < 4; gq++) bv[gq] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (has_bias) {
 #pragma unroll
-                    for (int i = 0; i < BWM; i++) {
-                        const int lr = 32 * i + r;
-                        float v[4];
-#pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            v[e] = alpha * acc[i][j][4 * gq + e] + bv[e];
-                            if (g.act == MH_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
-                        }
-                        u32x2 o;
-                        o[0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-                        o[1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-                        *reinterpret_cast<u32x2*>(t + lr * PITCH + lc) = o;
+                        for (int gq = 0; gq < 4; gq++) bv[gq] = *reinterpret_cast<const f32x4*>(g.bias + tile_col0 + wn * BWN * 32 + 32 * j + 8 * gq + 4 * hh);
                     }
                 }
+#pragma unroll
+                for (int i = 0; i < BWM; i++)
+#pragma unroll
+                    for (int gq = 0; gq < 4; gq++) {
+                        u32x2 o2;
+                        if constexpr (KIND == 0) {
+                            o2 = u32x2{pk[i][j][2 * gq], pk[i][j][2 * gq + 1]};
+                        } else {
+                            float v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                v[e] = alpha * acc[i][j][4 * gq + e] + bv[gq][e];
+                                if constexpr (KIND == 2) v[e] = fmaxf(v[e], 0.f);
+                            }
+                            o2 = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                        }
+                        *reinterpret_cast<u32x2*>(t + (32 * i + r) * PITCH + wn * BWN * 32 + 32 * j + 8 * gq + 4 * hh) = o2;
+                    }
+            }
         }
         __syncthreads();
         constexpr int CPR = BIG / 8;                 // 16-byte chunks per tile row
         constexpr int NCH = HALF * CPR / NTB;
+        u32x4 o[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; i++) {
+            const int cid = tid + i * NTB;
+            const int lr = cid / CPR, c = cid % CPR;
+            const u32x2 lo = *reinterpret_cast<const u32x2*>(t + lr * PITCH + c * 8);
+            const u32x2 hi = *reinterpret_cast<const u32x2*>(t + lr * PITCH + c * 8 + 4);
+            o[i] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
+        __syncthreads();
 #pragma unroll
         for (int i = 0; i < NCH; i++) {
             const int cid = tid + i * NTB;
             const int lr = cid / CPR, c = cid % CPR;
             const int grow = tile_row0 + half * HALF + lr;
             if (grow >= g.M) continue;               // ragged last row tile (K-contiguous A only)
-            bf16_t* dst = C + c_phys_row(g, grow) * g.ldc + tile_col0 + c * 8;
-            u32x2 lo = *reinterpret_cast<const u32x2*>(t + lr * PITCH + c * 8);
-            u32x2 hi = *reinterpret_cast<const u32x2*>(t + lr * PITCH + c * 8 + 4);
-            u32x4 o = {lo[0], lo[1], hi[0], hi[1]};
+            long prow = grow;
+            if (win2) prow = grow + c_adj + (grow >= c_bnd ? g.c_skip : 0);
+            else if (win) prow = c_phys_row(g, grow);
+            bf16_t* dst = C + prow * ldc + tile_col0 + c * 8;
             if constexpr (MODE == 1) {
                 const u32x4 old = *reinterpret_cast<const u32x4*>(dst);
 #pragma unroll
                 for (int w = 0; w < 4; w++) {
-                    const float a0 = __uint_as_float(o[w] << 16) + __uint_as_float(old[w] << 16);
-                    const float a1 = __uint_as_float(o[w] & 0xffff0000u) + __uint_as_float(old[w] & 0xffff0000u);
-                    o[w] = (unsigned)f2bf(a0) | ((unsigned)f2bf(a1) << 16);
+                    const float a0 = __uint_as_float(o[i][w] << 16) + __uint_as_float(old[w] << 16);
+                    const float a1 = __uint_as_float(o[i][w] & 0xffff0000u) + __uint_as_float(old[w] & 0xffff0000u);
+                    o[i][w] = pack_bf2(a0, a1);
                 }
             }
-            *reinterpret_cast<u32x4*>(dst) = o;
+            *reinterpret_cast<u32x4*>(dst) = o[i];
             if constexpr (EPI == MH_EPI_SQERR) {
                 const int rpb = g.epi.rows_per_batch;             // % 256 == 0: a tile lies inside one batch
                 const long b = tile_row0 / rpb;
@@ -830,18 +884,17 @@ __device__ __forceinline__ void pq_epilogue_bf16(const GemmArgs& g, bf16_t* C, f
                     const f32x4 t0 = *reinterpret_cast<const f32x4*>(tg), t1 = *reinterpret_cast<const f32x4*>(tg + 4);
 #pragma unroll
                     for (int w = 0; w < 4; w++) {
-                        const float d0 = __uint_as_float(o[w] << 16) - (w < 2 ? t0[2 * w] : t1[2 * w - 4]);
-                        const float d1 = __uint_as_float(o[w] & 0xffff0000u) - (w < 2 ? t0[2 * w + 1] : t1[2 * w - 3]);
+                        const float d0 = __uint_as_float(o[i][w] << 16) - (w < 2 ? t0[2 * w] : t1[2 * w - 4]);
+                        const float d1 = __uint_as_float(o[i][w] & 0xffff0000u) - (w < 2 ? t0[2 * w + 1] : t1[2 * w - 3]);
                         sq_sum += d0 * d0 + d1 * d1;
                     }
                     sq_cnt += 8.f;
                 }
             }
         }
-        __syncthreads();
     }
     if constexpr (EPI == MH_EPI_SQERR) {
-        float* red = reinterpret_cast<float*>(smem_c + HALF * PITCH * 2);     // behind the half-tile image (66560 of 69632 bytes)
+        float* red = reinterpret_cast<float*>(smem_c + HALF * PITCH * 2);     // behind the half-tile image (66560 of 69632 bytes): not a stage image
         sq_sum = wave_sum(sq_sum);
         sq_cnt = wave_sum(sq_cnt);
         if (lane == 0) { red[2 * (tid >> 6)] = sq_sum; red[2 * (tid >> 6) + 1] = sq_cnt; }
@@ -857,12 +910,12 @@ __device__ __forceinline__ void pq_epilogue_bf16(const GemmArgs& g, bf16_t* C, f
         __syncthreads();
     }
 }
-
 // f32 C (a lane owns a column, its registers the rows): rows [64 q, +64) of the tile through `t`, q = 0 .. 3
-template <int MODE, int EPI, bool OUT16 = false>      // OUT16: C points to bf16 storage (the split-K partial tiles), rows of ldc ELEMENTS
+template <int MODE, int EPI, bool RELU>
 __device__ __forceinline__ void pq_epilogue_f32(const GemmArgs& g, float* C, f32x16 (&acc)[BWM][BWN], char* smem_c, int tile_row0, int tile_col0,
                                                 int wm, int wn, int lane, int tid, bool lead, long ldc, float alpha) {
     constexpr int PITCH = BIG + 4, QR = BIG / 4;
+    asm volatile("" : "+v"(lane), "+v"(tid));        // see pq_epilogue_bf16
     float* t = reinterpret_cast<float*>(smem_c);
     const int r = lane & 31, hh = lane >> 5;
     uint64_t drop_blk0 = 0;
@@ -875,21 +928,23 @@ __device__ __forceinline__ void pq_epilogue_f32(const GemmArgs& g, float* C, f32
         thr = drop16_thr(g.epi.p);
         dscale = drop16_scale(thr);
     }
+    float bias[BWN];
+#pragma unroll
+    for (int j = 0; j < BWN; j++) bias[j] = (g.bias && lead) ? g.bias[tile_col0 + wn * BWN * 32 + j * 32 + r] : 0.f;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         if (wm == (q >> 1)) {
 #pragma unroll
             for (int j = 0; j < BWN; j++) {
                 const int lc = wn * BWN * 32 + j * 32 + r;
-                const float bias = (g.bias && lead) ? g.bias[tile_col0 + lc] : 0.f;
 #pragma unroll
                 for (int i2 = 0; i2 < 2; i2++) {
                     const int lr0 = i2 * 32 + 4 * hh;
 #pragma unroll
                     for (int reg = 0; reg < 16; reg++) {
                         const int lr = lr0 + (reg & 3) + 8 * (reg >> 2);
-                        float v = alpha * acc[2 * (q & 1) + i2][j][reg] + bias;
-                        if (g.act == MH_ACT_RELU) v = fmaxf(v, 0.f);
+                        float v = alpha * acc[2 * (q & 1) + i2][j][reg] + bias[j];
+                        if constexpr (RELU) v = fmaxf(v, 0.f);
                         t[lr * PITCH + lc] = v;
                     }
                 }
@@ -898,21 +953,29 @@ __device__ __forceinline__ void pq_epilogue_f32(const GemmArgs& g, float* C, f32
         __syncthreads();
         if constexpr (EPI == MH_EPI_DROPADD) {
             constexpr int CPR8 = BIG / 8, NCH8 = QR * CPR8 / NTB;
+            f32x4 x0[NCH8], x1[NCH8];
+#pragma unroll
+            for (int i = 0; i < NCH8; i++) {
+                const int cid = tid + i * NTB;
+                const float* src = t + (cid / CPR8) * PITCH + (cid % CPR8) * 8;
+                x0[i] = *reinterpret_cast<const f32x4*>(src);
+                x1[i] = *reinterpret_cast<const f32x4*>(src + 4);
+            }
+            __syncthreads();
 #pragma unroll
             for (int i = 0; i < NCH8; i++) {
                 const int cid = tid + i * NTB;
                 const int lr = cid / CPR8, c = cid % CPR8;
                 const int grow = tile_row0 + q * QR + lr, gcol = tile_col0 + c * 8;
                 if (grow >= g.M) continue;
-                const float* src = t + lr * PITCH + c * 8;
                 const float* rp = g.epi.resid + (long)grow * g.N + gcol;
                 f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
-                const f32x4 x0 = round_bf16_4(*reinterpret_cast<const f32x4*>(src)), x1 = round_bf16_4(*reinterpret_cast<const f32x4*>(src + 4));
+                const f32x4 y0 = round_bf16_4(x0[i]), y1 = round_bf16_4(x1[i]);
                 const uint32_t keep = drop16_keep8(drop_blk0 + (((uint64_t)grow * (uint64_t)g.N + (uint64_t)gcol) >> 3), g.epi.seed, thr);
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    r0[e] = __fadd_rn(r0[e], (keep & (1u << e)) ? __fmul_rn(x0[e], dscale) : 0.f);
-                    r1[e] = __fadd_rn(r1[e], (keep & (16u << e)) ? __fmul_rn(x1[e], dscale) : 0.f);
+                    r0[e] = __fadd_rn(r0[e], (keep & (1u << e)) ? __fmul_rn(y0[e], dscale) : 0.f);
+                    r1[e] = __fadd_rn(r1[e], (keep & (16u << e)) ? __fmul_rn(y1[e], dscale) : 0.f);
                 }
                 float* dst = C + (long)grow * ldc + gcol;
                 *reinterpret_cast<f32x4*>(dst) = r0;
@@ -920,34 +983,38 @@ __device__ __forceinline__ void pq_epilogue_f32(const GemmArgs& g, float* C, f32
             }
         } else {
             constexpr int CPR = BIG / 4, NCH = QR * CPR / NTB;
+            f32x4 x[NCH];
+#pragma unroll
+            for (int i = 0; i < NCH; i++) {
+                const int cid = tid + i * NTB;
+                x[i] = *reinterpret_cast<const f32x4*>(t + (cid / CPR) * PITCH + (cid % CPR) * 4);
+            }
+            __syncthreads();
 #pragma unroll
             for (int i = 0; i < NCH; i++) {
                 const int cid = tid + i * NTB;
                 const int lr = cid / CPR, c = cid % CPR;
                 const int grow = tile_row0 + q * QR + lr;
                 if (grow >= g.M) continue;
-                f32x4 x0 = *reinterpret_cast<const f32x4*>(t + lr * PITCH + c * 4);
-                if constexpr (OUT16) {
-                    bf16_t* d16 = reinterpret_cast<bf16_t*>(C) + (long)grow * ldc + tile_col0 + c * 4;
-                    u32x2 o;
-                    o[0] = (unsigned)f2bf(x0[0]) | ((unsigned)f2bf(x0[1]) << 16);
-                    o[1] = (unsigned)f2bf(x0[2]) | ((unsigned)f2bf(x0[3]) << 16);
-                    *reinterpret_cast<u32x2*>(d16) = o;
-                } else {
-                    float* dst = C + (long)grow * ldc + tile_col0 + c * 4;
-                    if constexpr (EPI != 0) x0 = epi_quad<EPI>(g, x0, grow, tile_col0 + c * 4);
-                    if constexpr (MODE == 1) x0 += *reinterpret_cast<const f32x4*>(dst);
-                    *reinterpret_cast<f32x4*>(dst) = x0;
-                }
+                float* dst = C + (long)grow * ldc + tile_col0 + c * 4;
+                f32x4 x0 = x[i];
+                if constexpr (EPI != 0) x0 = epi_quad<EPI>(g, x0, grow, tile_col0 + c * 4);
+                if constexpr (MODE == 1) x0 += *reinterpret_cast<const f32x4*>(dst);
+                *reinterpret_cast<f32x4*>(dst) = x0;
             }
         }
-        __syncthreads();
     }
 }
 
-template <typename TC, bool AKC, bool BKC, bool PART = false, int EPI = 0>
+// VAR = the epilogue variant, a template parameter so that each instance carries ONE epilogue (with several inlined side by side the
+// register allocator spilled loop invariants across the K loop and reloaded them in front of the stores, each reload a full drain of
+// the wave's memory queue): bf16 tiles (C or split-K partials): 0 = alpha == 1, no bias, no activation, 1 = alpha / bias, 2 = + ReLU;
+// f32 C: 0 = store, 1 = ReLU, 2 = accumulate.  Accumulating bf16 C and f32 atomics stay on gemm_pp_kernel (pq_variant()).
+template <typename TC, bool AKC, bool BKC, bool PART = false, int EPI = 0, int VAR = 0>
 __global__ __launch_bounds__(NTB) void gemm_pq_kernel(GemmArgs g, int units, int tiles, int splits) {
     static_assert(EPI == 0 || (AKC && !PART), "fused epilogues: K-contiguous A, no split-K");
+    // C^T accumulators (a lane owns 4 consecutive columns of a row) wherever the tile leaves as bf16: C itself, or a split-K partial tile
+    constexpr bool CT = sizeof(TC) == 2 || PART;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1084,7 +1151,7 @@ __global__ __launch_bounds__(NTB) void gemm_pq_kernel(GemmArgs g, int units, int
                     for (int i = 0; i < BWM; i++)
 #pragma unroll
                         for (int j = 0; j < BWN; j++) {
-                            if constexpr (sizeof(TC) == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);   // C^T
+                            if constexpr (CT) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);   // C^T
                             else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
                         }
                 __builtin_amdgcn_s_setprio(0);
@@ -1100,19 +1167,13 @@ __global__ __launch_bounds__(NTB) void gemm_pq_kernel(GemmArgs g, int units, int
         const int b1 = z / g.batch2, b2 = z % g.batch2;
         TC* C = reinterpret_cast<TC*>(g.C) + b1 * g.sC1 + b2 * g.sC2;
         const bool lead = (split == 0);
-        if constexpr (EPI != 0) {
-            if constexpr (sizeof(TC) == 2) pq_epilogue_bf16<0, EPI>(g, C, acc, cst, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, true, g.alpha);
-            else pq_epilogue_f32<0, EPI>(g, C, acc, cst, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, true, g.ldc, g.alpha);
-        } else if constexpr (sizeof(TC) == 2) {
-            if (g.accumulate) pq_epilogue_bf16<1, 0>(g, C, acc, cst, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, lead, g.alpha);
-            else pq_epilogue_bf16<0, 0>(g, C, acc, cst, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, lead, g.alpha);
-        } else if constexpr (PART) {
+        if constexpr (PART) {
             bf16_t* P = reinterpret_cast<bf16_t*>(g.ws) + ((long)z * splits + split) * (long)g.M * g.N;      // bf16 partial tiles
-            pq_epilogue_f32<0, 0, true>(g, reinterpret_cast<float*>(P), acc, cst, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, false, (long)g.N, g.alpha);
+            pq_epilogue_bf16<0, 0, VAR>(g, P, (long)g.N, false, acc, cst, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, false, g.alpha);
+        } else if constexpr (sizeof(TC) == 2) {
+            pq_epilogue_bf16<0, EPI, VAR>(g, C, g.ldc, true, acc, cst, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, g.bias && lead, g.alpha);
         } else {
-            if (g.atomic) epilogue_atomic_big(g, reinterpret_cast<float*>(C), acc, tile_m * BIG + wm * BWM * 32, tile_n * BIG + wn * BWN * 32, lane);
-            else if (g.accumulate) pq_epilogue_f32<1, 0>(g, reinterpret_cast<float*>(C), acc, cst, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, lead, g.ldc, g.alpha);
-            else pq_epilogue_f32<0, 0>(g, reinterpret_cast<float*>(C), acc, cst, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, lead, g.ldc, g.alpha);
+            pq_epilogue_f32<VAR == 2 ? 1 : 0, EPI, VAR == 1>(g, C, acc, cst, tile_m * BIG, tile_n * BIG, wm, wn, lane, tid, lead, g.ldc, g.alpha);
         }
         __syncthreads();
         tile_m = n_tile_m; tile_n = n_tile_n; z = n_z; split = n_split; nt = n_nt;
@@ -1201,20 +1262,39 @@ static int pq_grid(long units) {
     static const int cus = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
     return (int)(units < cus ? units : cus);
 }
+// the epilogue variant of gemm_pq_kernel for this launch (see its VAR), -1: not one of its cases
+static int pq_variant(const GemmArgs& a, bool bf16_tiles, bool part, int epi) {
+    const bool relu = a.act == MH_ACT_RELU;
+    if (part) return a.alpha == 1.f ? 0 : 1;
+    if (bf16_tiles) {
+        if (a.accumulate || (epi != 0 && relu)) return -1;
+        return relu ? 2 : (a.alpha == 1.f && !a.bias ? 0 : 1);
+    }
+    if (a.atomic || (epi != 0 && (relu || a.accumulate))) return -1;
+    return a.accumulate ? (relu ? -1 : 2) : (relu ? 1 : 0);
+}
 template <typename K>
 static void pp_attr(K kern) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
 }
+#define PQ_LAUNCH_VAR_(TC, AKC, BKC, PART, EPI, VAR, s, a, units_, grid)                                  \
+    do {                                                                                             \
+        static const bool attrq_ = (pp_attr(gemm_pq_kernel<TC, AKC, BKC, PART, EPI, VAR>), true);    \
+        (void)attrq_;                                                                                \
+        hipLaunchKernelGGL((gemm_pq_kernel<TC, AKC, BKC, PART, EPI, VAR>), dim3(pq_grid(units_)), dim3(NTB), PQ_LDS, s, a, (int)units_, \
+                           (int)(grid).x, (int)(grid).y);                                            \
+    } while (0)
 #define PP_LAUNCH_(TC, AKC, BKC, PART, EPI, grid, s, a)                                              \
     do {                                                                                             \
-        gemm_note_variant("%s<%s,%s,%s%s%s>", (pp_mode() == 2 && !(a).shared_chip) ? "gemm_pq_kernel" : "gemm_pp_kernel", gemm_tn<TC>(), \
+        const int var_ = pq_variant(a, sizeof(TC) == 2, PART, EPI);                                  \
+        const bool pq_ = pp_mode() == 2 && !(a).shared_chip && var_ >= 0;                            \
+        gemm_note_variant("%s<%s,%s,%s%s%s>", pq_ ? "gemm_pq_kernel" : "gemm_pp_kernel", gemm_tn<TC>(), \
                           gemm_tf(AKC), gemm_tf(BKC), (PART) ? ",part" : "", (EPI) == 0 ? "" : ((EPI) == 1 ? ",epi1" : ((EPI) == 2 ? ",epi2" : ",epi3"))); \
-        if (pp_mode() == 2 && !(a).shared_chip) {                                                    \
-            static const bool attrq_ = (pp_attr(gemm_pq_kernel<TC, AKC, BKC, PART, EPI>), true);     \
-            (void)attrq_;                                                                            \
+        if (pq_) {                                                                                   \
             const long units_ = (long)(grid).x * (grid).y * (grid).z;                                \
-            hipLaunchKernelGGL((gemm_pq_kernel<TC, AKC, BKC, PART, EPI>), dim3(pq_grid(units_)), dim3(NTB), PQ_LDS, s, a, (int)units_, \
-                               (int)(grid).x, (int)(grid).y);                                        \
+            if (var_ == 0) PQ_LAUNCH_VAR_(TC, AKC, BKC, PART, EPI, 0, s, a, units_, grid);           \
+            else if (var_ == 1) PQ_LAUNCH_VAR_(TC, AKC, BKC, PART, EPI, 1, s, a, units_, grid);      \
+            else if constexpr ((EPI) == 0 && !(PART)) PQ_LAUNCH_VAR_(TC, AKC, BKC, PART, EPI, 2, s, a, units_, grid); \
         } else {                                                                                     \
             static const bool attr_ = (pp_attr(gemm_pp_kernel<TC, AKC, BKC, PART, EPI>), true);      \
             (void)attr_;                                                                             \

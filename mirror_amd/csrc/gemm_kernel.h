@@ -153,8 +153,8 @@ struct Stager {
                 *reinterpret_cast<u32x4*>(tile + (r * G::PITCH + c * VEC) * G::ESZ) = v;
             } else {  // f32 in HBM -> bf16 in LDS
                 u32x2 p;
-                p[0] = (unsigned)f2bf(__uint_as_float(v[0])) | ((unsigned)f2bf(__uint_as_float(v[1])) << 16);
-                p[1] = (unsigned)f2bf(__uint_as_float(v[2])) | ((unsigned)f2bf(__uint_as_float(v[3])) << 16);
+                p[0] = pack_bf2(__uint_as_float(v[0]), __uint_as_float(v[1]));
+                p[1] = pack_bf2(__uint_as_float(v[2]), __uint_as_float(v[3]));
                 *reinterpret_cast<u32x2*>(tile + (r * G::PITCH + c * 4) * 2) = p;
             }
         }
@@ -298,10 +298,10 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& g, TC* C, const TC*
                 x1[0] += __uint_as_float(old[2] << 16); x1[1] += __uint_as_float(old[2] & 0xffff0000u);
                 x1[2] += __uint_as_float(old[3] << 16); x1[3] += __uint_as_float(old[3] & 0xffff0000u);
             }
-            o[0] = (unsigned)f2bf(x0[0]) | ((unsigned)f2bf(x0[1]) << 16);
-            o[1] = (unsigned)f2bf(x0[2]) | ((unsigned)f2bf(x0[3]) << 16);
-            o[2] = (unsigned)f2bf(x1[0]) | ((unsigned)f2bf(x1[1]) << 16);
-            o[3] = (unsigned)f2bf(x1[2]) | ((unsigned)f2bf(x1[3]) << 16);
+            o[0] = pack_bf2(x0[0], x0[1]);
+            o[1] = pack_bf2(x0[2], x0[3]);
+            o[2] = pack_bf2(x1[0], x1[1]);
+            o[3] = pack_bf2(x1[2], x1[3]);
         }
         *reinterpret_cast<u32x4*>(dst) = o;
     }

@@ -420,8 +420,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         reinterpret_cast<float4*>(v)[q] = vv;
         if (shadow) {
             uint2 sh;
-            sh.x = (uint32_t)f2bf(pa[0]) | ((uint32_t)f2bf(pa[1]) << 16);
-            sh.y = (uint32_t)f2bf(pa[2]) | ((uint32_t)f2bf(pa[3]) << 16);
+            sh.x = pack_bf2(pa[0], pa[1]);
+            sh.y = pack_bf2(pa[2], pa[3]);
             reinterpret_cast<uint2*>(shadow)[q] = sh;
         }
     }

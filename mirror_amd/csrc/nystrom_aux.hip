@@ -182,7 +182,7 @@ template <> __device__ __forceinline__ void st8<float>(float* p, const float (&v
 template <> __device__ __forceinline__ void st8<bf16_t>(bf16_t* p, const float (&v)[8]) {
     ru4 r;
 #pragma unroll
-    for (int e = 0; e < 4; e++) r[e] = (unsigned)f2bf(v[2 * e]) | ((unsigned)f2bf(v[2 * e + 1]) << 16);
+    for (int e = 0; e < 4; e++) r[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
     *reinterpret_cast<ru4*>(p) = r;
 }
 

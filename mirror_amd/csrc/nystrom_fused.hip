@@ -149,8 +149,8 @@ __device__ __forceinline__ void tile_store(const u32x4 (&regs)[ROWS * 8 / NT], b
 // accumulator rows 8g + 4hl + {0..3} of a [d][n]-oriented result -> 4 consecutive bf16 of the n-th row
 __device__ __forceinline__ void store_row4(bf16_t* p, const f32x16& a, int g) {
     u32x2 w;
-    w[0] = (unsigned)f2bf(a[4 * g + 0]) | ((unsigned)f2bf(a[4 * g + 1]) << 16);
-    w[1] = (unsigned)f2bf(a[4 * g + 2]) | ((unsigned)f2bf(a[4 * g + 3]) << 16);
+    w[0] = pack_bf2(a[4 * g + 0], a[4 * g + 1]);
+    w[1] = pack_bf2(a[4 * g + 2], a[4 * g + 3]);
     *reinterpret_cast<u32x2*>(p) = w;
 }
 

@@ -51,7 +51,7 @@ __device__ __forceinline__ float half_sum(float v) {
 __device__ __forceinline__ u32x4 pack8(const f32x16& a, int t) {
     u32x4 o;
 #pragma unroll
-    for (int w = 0; w < 4; w++) o[w] = (unsigned)f2bf(a[8 * t + 2 * w]) | ((unsigned)f2bf(a[8 * t + 2 * w + 1]) << 16);
+    for (int w = 0; w < 4; w++) o[w] = pack_bf2(a[8 * t + 2 * w], a[8 * t + 2 * w + 1]);
     return o;
 }
 

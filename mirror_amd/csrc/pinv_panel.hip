@@ -541,7 +541,7 @@ __device__ __forceinline__ void pn_item(int it, int& j, int& i0) {
 __device__ __forceinline__ u32x4 pack_bf16x8(const float (&v)[8]) {
     u32x4 o;
 #pragma unroll
-    for (int w = 0; w < 4; w++) o[w] = (unsigned)f2bf(v[2 * w]) | ((unsigned)f2bf(v[2 * w + 1]) << 16);
+    for (int w = 0; w < 4; w++) o[w] = pack_bf2(v[2 * w], v[2 * w + 1]);
     return o;
 }
 

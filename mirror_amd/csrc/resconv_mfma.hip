@@ -124,10 +124,10 @@ __global__ __launch_bounds__(256) void resconv_mfma_kernel(const bf16_t* __restr
                 hi[2] += __uint_as_float(od[3] << 16); hi[3] += __uint_as_float(od[3] & 0xffff0000u);
             }
             u32x4 o;
-            o[0] = (unsigned)f2bf(lo[0]) | ((unsigned)f2bf(lo[1]) << 16);
-            o[1] = (unsigned)f2bf(lo[2]) | ((unsigned)f2bf(lo[3]) << 16);
-            o[2] = (unsigned)f2bf(hi[0]) | ((unsigned)f2bf(hi[1]) << 16);
-            o[3] = (unsigned)f2bf(hi[2]) | ((unsigned)f2bf(hi[3]) << 16);
+            o[0] = pack_bf2(lo[0], lo[1]);
+            o[1] = pack_bf2(lo[2], lo[3]);
+            o[2] = pack_bf2(hi[0], hi[1]);
+            o[3] = pack_bf2(hi[2], hi[3]);
             *reinterpret_cast<u32x4*>(p) = o;
         }
         if (half == 0) __syncthreads();               // the first half is consumed before the second overwrites it

@@ -51,7 +51,7 @@ __device__ __forceinline__ rb_f4 drop4(const Drop& d, long i) {
 }
 
 __device__ __forceinline__ rb_u2 pack4(rb_f4 v) {
-    return rb_u2{(unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16)};
+    return rb_u2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
 }
 __device__ __forceinline__ rb_f4 unpack4(rb_u2 u) {
     return rb_f4{__uint_as_float(u[0] << 16), __uint_as_float(u[0] & 0xffff0000u), __uint_as_float(u[1] << 16), __uint_as_float(u[1] & 0xffff0000u)};
