@@ -718,6 +718,8 @@ __global__ __launch_bounds__(NTB) void gemm_pp_kernel(GemmArgs g) {
 // box against this loop, none faster: a four-segment ring with the request for segment s + 3 issued between the MFMAs (the load
 // phase drops to ~350 cycles, the MFMA phase grows to ~800: same 2000), 1 / 2 / 3 of its 4 pieces in the load phase (equal; the
 // long-K gradient products 3-11 % slower), no requests at all (1750: the floor of the two-barrier structure).
+// The unit decode (integer divisions, per-lane addresses: ~1.2k cycles in front of a unit's first segment) moved into the epilogue's
+// waiting time (a third unit record, decoded by the wave row that is not writing): no spills, products alone 0-3 % faster, step +0.28 % +- 0.11.
 // ---- stage layout of gemm_pq_kernel: every operand tile is TWO k-half sub-images of 16 KiB (k in [0, 32) and [32, 64) of the K-tile),
 // so that a segment of two k-steps reads one sub-image per operand and the other half can be in flight:
 //   K-contiguous: [256 rows][64 B], 16-byte chunk c of row r stored at chunk c ^ ((r >> 2) & 3)      (ds_read_b128 conflict free)
