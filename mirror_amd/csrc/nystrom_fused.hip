@@ -501,8 +501,8 @@ __global__ __launch_bounds__(NT) void nys_a1_bwd_dw_kernel(const bf16_t* __restr
         tile_store<TR>(rq, s_q, tid);
         tile_store<TR>(rg, s_g, tid);
         if (tid < TR) {
-            s_lse[tid] = rl;
-            s_del[tid] = rd;
+            s_lse[tid] = -rl * LOG2E;           // staged negated and scaled: the tile arithmetic is two multiply-adds per element
+            s_del[tid] = -rd * g.scale;
             s_mr[tid] = masked ? g.mrow[(long)b * g.n_p + (long)t * TR + tid] : 1.f;
         }
         __syncthreads();
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(NT) void nys_a1_bwd_dw_kernel(const bf16_t* __restr
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) {   // 32 q rows at a time
-            const f32x16 lv = rowvals16(s_lse + 32 * i, hl) * LOG2E, dv = rowvals16(s_del + 32 * i, hl) * g.scale;
+            const f32x16 lv = rowvals16(s_lse + 32 * i, hl), dv = rowvals16(s_del + 32 * i, hl);      // -lse1 log2(e), -delta1 scale
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 f32x16 s = zero16(), dp = zero16();   // S[q row][landmark], dP[q row][landmark]
@@ -529,14 +529,14 @@ __global__ __launch_bounds__(NT) void nys_a1_bwd_dw_kernel(const bf16_t* __restr
                     const f32x16 vr = rowvals16(s_mr + 32 * i, hl);
                     s = s * g.scale2;
                     mask_fill16(s, vr, ml[j]);
-                    s = s - lv;
+                    s = s + lv;
                     exp2_16(s);
-                    dp = s * (dp * g.scale - dv);
+                    dp = s * (dp * g.scale + dv);
                     mask_zero16(dp, vr, ml[j]);
                 } else {
-                    s = s * g.scale2 - lv;
+                    s = s * g.scale2 + lv;
                     exp2_16(s);
-                    dp = s * (dp * g.scale - dv);
+                    dp = s * (dp * g.scale + dv);
                 }
                 const bf16x8 p0 = pack8<0>(s), p1 = pack8<1>(s), d0 = pack8<0>(dp), d1 = pack8<1>(dp);
 #pragma unroll
@@ -737,8 +737,8 @@ __global__ __launch_bounds__(NT, 2) void nys_a3_bwd_dkv_kernel(const bf16_t* __r
     const long LD = g.lm_ld;
     stage_rows<NM>(s_ql_, lm + (long)b * NM * LD + hd * ND, LD, tid);
     stage_rows<NM>(s_g_, dav + (long)bh * NM * ND, ND, tid);
-    s_del_[tid] = delta3[(long)bh * NM + tid] * g.scale;       // thread = landmark
-    s_lse_[tid] = lse3[(long)bh * NM + tid] * LOG2E;
+    s_del_[tid] = -delta3[(long)bh * NM + tid] * g.scale;      // thread = landmark; staged negated (a subtraction of per-element values
+    s_lse_[tid] = -lse3[(long)bh * NM + tid] * LOG2E;          // costs a sign flip per element on top of the multiply-add)
     constexpr bool masked = MASKED;
     s_mlm_[tid] = masked ? g.mlm[(long)b * NM + tid] : 1.f;
     const int nblk = g.n_p / 32, stride = 4 * gridDim.x;
@@ -788,14 +788,14 @@ __global__ __launch_bounds__(NT, 2) void nys_a3_bwd_dkv_kernel(const bf16_t* __r
                 const f32x16 vr = rowvals16(s_mlm + 32 * blk, hl);
                 s = s * g.scale2;
                 mask_fill16(s, vr, mr);
-                s = s - rowvals16(s_lse + 32 * blk, hl);
+                s = s + rowvals16(s_lse + 32 * blk, hl);
                 exp2_16(s);
-                dp = s * (dp * g.scale - rowvals16(s_del + 32 * blk, hl));
+                dp = s * (dp * g.scale + rowvals16(s_del + 32 * blk, hl));
                 mask_zero16(dp, vr, mr);
             } else {
-                s = s * g.scale2 - rowvals16(s_lse + 32 * blk, hl);      // staged as lse3 * log2(e)
+                s = s * g.scale2 + rowvals16(s_lse + 32 * blk, hl);      // staged as -lse3 * log2(e)
                 exp2_16(s);
-                dp = s * (dp * g.scale - rowvals16(s_del + 32 * blk, hl));   // staged as delta3 * scale
+                dp = s * (dp * g.scale + rowvals16(s_del + 32 * blk, hl));   // staged as -delta3 * scale
             }
             const bf16x8 p0 = pack8<0>(s), p1 = pack8<1>(s), d0 = pack8<0>(dp), d1 = pack8<1>(dp);
 #pragma unroll
