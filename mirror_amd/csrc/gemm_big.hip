@@ -770,6 +770,11 @@ __device__ __forceinline__ bf16x8 p2_frag_ks(const char* sub, unsigned off, int 
 constexpr int PQ_SLOT = 68 * 1024;            // LDS stage slot: A image 32 KiB | B image 32 KiB | 4 KiB that only the C staging uses
 constexpr int PQ_LDS = 2 * PQ_SLOT;
 
+// pq_store_note: C leaves with NON-TEMPORAL stores (global_store_dwordx4 ... nt).  A C tile is written once and read by another kernel
+// tens of MB later; kept in L2 like ordinary lines it evicted the weight panel and the A tiles its own launch re-reads (every weight
+// tile is read by all 256 workgroups, an A tile by tiles_n of them): [65536 x 1536] x [1536 x 512] -> bf16 115.4 -> 103.6 us alone on
+// the chip, the K = 512 bf16 products -4 %, f32 C at K = 1024 -4 %, f32 C at K = 512 +4 % (choosing the form per launch by K through a
+// run-time flag made the non-temporal path itself 6 % slower and the step +0.39 % +- 0.08: one form everywhere); step -0.62 % +- 0.09.
 // ---- epilogues of gemm_pq_kernel: C through the LDS stage the unit has just consumed.  Measured with in-kernel cycle stamps
 // (tools/exp/pq_stamps_patch.py; K = 512: a third of a unit's 48k cycles was epilogue): a write phase took ~4000 cycles because every
 // bias quad was a dependent load behind an s_waitcnt vmcnt(0) (emitted with or without a bias) and every element cost a multiply-add,
@@ -876,7 +881,8 @@ __device__ __forceinline__ void pq_epilogue_bf16(const GemmArgs& g, bf16_t* C, l
                     o[i][w] = pack_bf2(a0, a1);
                 }
             }
-            *reinterpret_cast<u32x4*>(dst) = o[i];
+            if (remap) __builtin_nontemporal_store(o[i], reinterpret_cast<u32x4*>(dst));      // see pq_store_note
+            else *reinterpret_cast<u32x4*>(dst) = o[i];                                        // split-K partial tiles: the fold launch reads them next
             if constexpr (EPI == MH_EPI_SQERR) {
                 const int rpb = g.epi.rows_per_batch;             // % 256 == 0: a tile lies inside one batch
                 const long b = tile_row0 / rpb;
@@ -980,8 +986,8 @@ __device__ __forceinline__ void pq_epilogue_f32(const GemmArgs& g, float* C, f32
                     r1[e] = __fadd_rn(r1[e], (keep & (16u << e)) ? __fmul_rn(y1[e], dscale) : 0.f);
                 }
                 float* dst = C + (long)grow * ldc + gcol;
-                *reinterpret_cast<f32x4*>(dst) = r0;
-                *reinterpret_cast<f32x4*>(dst + 4) = r1;
+                __builtin_nontemporal_store(r0, reinterpret_cast<f32x4*>(dst));
+                __builtin_nontemporal_store(r1, reinterpret_cast<f32x4*>(dst + 4));
             }
         } else {
             constexpr int CPR = BIG / 4, NCH = QR * CPR / NTB;
@@ -1002,7 +1008,7 @@ __device__ __forceinline__ void pq_epilogue_f32(const GemmArgs& g, float* C, f32
                 f32x4 x0 = x[i];
                 if constexpr (EPI != 0) x0 = epi_quad<EPI>(g, x0, grow, tile_col0 + c * 4);
                 if constexpr (MODE == 1) x0 += *reinterpret_cast<const f32x4*>(dst);
-                *reinterpret_cast<f32x4*>(dst) = x0;
+                __builtin_nontemporal_store(x0, reinterpret_cast<f32x4*>(dst));
             }
         }
     }
