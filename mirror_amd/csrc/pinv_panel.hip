@@ -262,14 +262,20 @@ __device__ __forceinline__ void finish_out(const f32x16 (&acc)[8][NJ], float alp
 // HBM storage of chain-private matrices, "panel native": PN[jblk][T][lane][8] holds the bf16x8 that lane (c = lane & 31,
 // hl = lane >> 5) of column block jblk feeds to k-step T, i.e. M[16T + 4hl + {0..3}, 16T + 8 + 4hl + {0..3}][32 jblk + c]:
 // every panel load / store is one fully coalesced 16-byte access per lane.
+// NT: non-temporal stores for matrices that only the BACKWARD launch reads again (P_k, T2_k, T3_k: 3 x 128 KiB per workgroup and
+// iteration) — kept in L2 like ordinary lines they evict X and z_k, which this workgroup reads back as images one product later
+template <bool NT = false>
 __device__ __forceinline__ void store_panel(bf16_t* __restrict__ G, const bf16x8 (&p)[16][NJ], int wave, int lane) {
     if (EXP == 4) return;
     asm volatile("" : "+v"(lane));
 #pragma unroll
     for (int jb = 0; jb < NJ; jb++)
 #pragma unroll
-        for (int T = 0; T < 16; T++)
-            *reinterpret_cast<u32x4*>(G + (((2 * wave + jb) * 16 + T) * 512) + (lane << 3)) = __builtin_bit_cast(u32x4, p[T][jb]);
+        for (int T = 0; T < 16; T++) {
+            u32x4* dst = reinterpret_cast<u32x4*>(G + (((2 * wave + jb) * 16 + T) * 512) + (lane << 3));
+            if constexpr (NT) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, p[T][jb]), dst);
+            else *dst = __builtin_bit_cast(u32x4, p[T][jb]);
+        }
 }
 __device__ __forceinline__ void load_panel(bf16x8 (&p)[16][NJ], const bf16_t* __restrict__ G, int wave, int lane) {
     asm volatile("" : "+v"(lane));   // loop-invariant sources (X) would otherwise get 32 hoisted, spilled 64-bit pointers
@@ -420,16 +426,16 @@ __global__ __launch_bounds__(CT) void pinv_panel_fwd_kernel(const bf16_t* __rest
         bf16_t* T3 = base + 3L * BH * MAT;
         panel_gemm<true>(acc, img, rlo, rhi, p);                                // P = X z
         finish<false>(acc, 1.f, 0.f, p, 0.f, p, wave, dreg);
-        store_panel(P, p, wave, lane);
+        store_panel<true>(P, p, wave, lane);
         __syncthreads();
         image_from_panel(img, p, j, hl);
         __syncthreads();
         panel_gemm<true>(acc, img, rlo, rhi, p);                                // T2 = 15I - 7P + P P
         finish<true>(acc, 1.f, 15.f, p, -7.f, p, wave, dreg);
-        store_panel(T2, p, wave, lane);
+        store_panel<true>(T2, p, wave, lane);
         panel_gemm<true>(acc, img, rlo, rhi, p);                                // T3 = 13I - P T2
         finish<false>(acc, -1.f, 13.f, p, 0.f, p, wave, dreg);
-        store_panel(T3, p, wave, lane);
+        store_panel<true>(T3, p, wave, lane);
         publish();
         image_from_global<16>(img, base, tid);                            // z_k (written by this workgroup one step ago)
         __syncthreads();
