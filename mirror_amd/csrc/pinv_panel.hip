@@ -226,7 +226,7 @@ __device__ __forceinline__ void finish(const f32x16 (&acc)[8][NJ], float alpha, 
 // image_from_panel writes them), straight from the accumulators.  The panel registers therefore keep what they hold (a B operand that
 // the next product uses again, or the next operand that panel_gemm<.., PF> requested behind the k sweep).  Call it between two
 // barriers: every wave must have finished reading the image.
-template <bool HASR>
+template <bool HASR, bool NTS = false>      // NTS: the global copy is read again only much later (W_k: in the dX sum behind the loop)
 __device__ __forceinline__ void finish_out(const f32x16 (&acc)[8][NJ], float alpha, float diag, const bf16x8 (&pR)[16][NJ], float rcoef,
                                            bf16_t* __restrict__ G, char* img, int wave, int dreg, int j0, int hl, int lane) {
     asm volatile("" : "+v"(j0), "+v"(hl), "+v"(lane));
@@ -251,7 +251,8 @@ __device__ __forceinline__ void finish_out(const f32x16 (&acc)[8][NJ], float alp
                     o[e] = (__bf16)v;
                 }
                 const u32x4 v = __builtin_bit_cast(u32x4, o);
-                *reinterpret_cast<u32x4*>(G + (((2 * wave + jb) * 16 + T) * 512) + (lane << 3)) = v;
+                if constexpr (NTS) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(G + (((2 * wave + jb) * 16 + T) * 512) + (lane << 3)));
+                else *reinterpret_cast<u32x4*>(G + (((2 * wave + jb) * 16 + T) * 512) + (lane << 3)) = v;
                 *reinterpret_cast<u32x2*>(row + (((4 * T + hl) ^ s) << 3)) = u32x2{v[0], v[1]};
                 *reinterpret_cast<u32x2*>(row + (((4 * T + 2 + hl) ^ s) << 3)) = u32x2{v[2], v[3]};
                 __builtin_amdgcn_sched_barrier(0);   // one block at a time: hoisting all accumulator reads would spill
@@ -277,13 +278,16 @@ __device__ __forceinline__ void store_panel(bf16_t* __restrict__ G, const bf16x8
             else *dst = __builtin_bit_cast(u32x4, p[T][jb]);
         }
 }
+template <bool NT = false>      // NT: the LAST read of a matrix the forward launch saved (streamed through once): a non-temporal load
 __device__ __forceinline__ void load_panel(bf16x8 (&p)[16][NJ], const bf16_t* __restrict__ G, int wave, int lane) {
     asm volatile("" : "+v"(lane));   // loop-invariant sources (X) would otherwise get 32 hoisted, spilled 64-bit pointers
 #pragma unroll
     for (int jb = 0; jb < NJ; jb++)
 #pragma unroll
-        for (int T = 0; T < 16; T++)
-            p[T][jb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(G + (((2 * wave + jb) * 16 + T) * 512) + (lane << 3)));
+        for (int T = 0; T < 16; T++) {
+            const u32x4* src = reinterpret_cast<const u32x4*>(G + (((2 * wave + jb) * 16 + T) * 512) + (lane << 3));
+            p[T][jb] = __builtin_bit_cast(bf16x8, NT ? __builtin_nontemporal_load(src) : *src);
+        }
 }
 __device__ __forceinline__ void negate_panel(bf16x8 (&p)[16][NJ]) {
 #pragma unroll
@@ -331,7 +335,7 @@ __device__ __forceinline__ void image_from_panel(char* img, const bf16x8 (&p)[16
 }
 // panel-native HBM matrix -> LDS image, BATCH 16-byte items in flight per thread (fewer while an accumulator tile is
 // live).  Item it = tid + 256 n is lane (tid & 63) of k-step wave + 4 (n & 3) of column block n >> 2.
-template <int BATCH>
+template <int BATCH, bool NT = false>
 __device__ __forceinline__ void image_from_global(char* img, const bf16_t* __restrict__ G, int tid) {
     if (EXP == 3) return;
     asm volatile("" : "+v"(tid));   // recompute the addresses at every call instead of hoisting + spilling them
@@ -340,7 +344,10 @@ __device__ __forceinline__ void image_from_global(char* img, const bf16_t* __res
     for (int n0 = 0; n0 < 32; n0 += BATCH) {
         u32x4 r[BATCH];
 #pragma unroll
-        for (int n = 0; n < BATCH; n++) r[n] = *reinterpret_cast<const u32x4*>(G + ((long)(tid + CT * (n0 + n)) << 3));
+        for (int n = 0; n < BATCH; n++) {
+            const u32x4* src = reinterpret_cast<const u32x4*>(G + ((long)(tid + CT * (n0 + n)) << 3));
+            r[n] = NT ? __builtin_nontemporal_load(src) : *src;
+        }
 #pragma unroll
         for (int n = 0; n < BATCH; n++) {
             const int jblk = (n0 + n) >> 2, T = tw + 4 * ((n0 + n) & 3);
@@ -351,9 +358,10 @@ __device__ __forceinline__ void image_from_global(char* img, const bf16_t* __res
     }
 }
 // ... __syncthreads() on both sides included
+template <bool NT = false>
 __device__ __forceinline__ void image_swap(char* img, const bf16_t* __restrict__ G, int tid) {
     __syncthreads();
-    image_from_global<16>(img, G, tid);
+    image_from_global<16, NT>(img, G, tid);
     __syncthreads();
 }
 // LDS image -> column-major HBM matrix G[j][i] (row copy, coalesced): the form the caller's GEMMs read
@@ -503,18 +511,18 @@ __global__ __launch_bounds__(CT) void pinv_panel_bwd2_kernel(const bf16_t* __res
         __syncthreads();
         // W = V2 P - 7 V2 + P V2 - T2 V3
         panel_gemm<true, true>(acc, img, rlo, rhi, p, V2, wave, lane);                    // V2 P   (image V2, panel P; V2's panel arrives: own stores)
-        image_swap(img, P, tid);
+        image_swap<true>(img, P, tid);
         panel_gemm<false, true>(acc, img, rlo, rhi, p, V3, wave, lane);                   // + P V2 (image P, panel V2; V3 arrives)
         negate_panel(p);
-        image_swap(img, T2, tid);
+        image_swap<true>(img, T2, tid);
         panel_gemm<false, true>(acc, img, rlo, rhi, p, V2, wave, lane);                   // - T2 V3 (image T2, panel -V3; V2 arrives for the epilogue)
         __syncthreads();
-        finish_out<true>(acc, 4.f, 0.f, p, -28.f, W, img, wave, dreg, j, hl, lane);        // 4 W (exact in bf16)
+        finish_out<true, true>(acc, 4.f, 0.f, p, -28.f, W, img, wave, dreg, j, hl, lane);  // 4 W (exact in bf16)
         load_panel(p, Xb, wave, lane);                                                    // the one panel load left in front of its product
         __syncthreads();
         // U' = 1/4 (4W X + T3 U)
         panel_gemm<true, true>(acc, img, rlo, rhi, p, U, wave, lane);                     // 4W X   (image 4W, panel X; U arrives)
-        image_swap(img, T3, tid);
+        image_swap<true>(img, T3, tid);
         panel_gemm<false, false>(acc, img, rlo, rhi, p);                                  // + T3 U (image T3, panel U)
         __syncthreads();
         finish_out<false>(acc, 0.25f, 0.f, p, 0.f, Un, img, wave, dreg, j, hl, lane);
@@ -531,7 +539,7 @@ __global__ __launch_bounds__(CT) void pinv_panel_bwd2_kernel(const bf16_t* __res
     for (int k = 0; k < iters; k++) {
         const bf16_t* Z = saved + ((long)k * 4 * BH + bh) * MAT;
         const bf16_t* Wn = work + ((long)(k + 1 < iters ? k + 1 : k) * BH + bh) * MAT;
-        image_swap(img, Z, tid);
+        image_swap<true>(img, Z, tid);
         panel_gemm<false, true>(acc, img, rlo, rhi, p, Wn, wave, lane);
     }
     store_f32(dX + bh * MAT, acc, 0.25f, j, hl);      // the panels hold 4 W
