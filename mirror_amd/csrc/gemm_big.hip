@@ -141,7 +141,7 @@ __device__ __forceinline__ void epilogue_big(const GemmArgs& g, TC* C, f32x16 (&
                 o[2] = pack_bf2(x1[0], x1[1]);
                 o[3] = pack_bf2(x1[2], x1[3]);
             }
-            *reinterpret_cast<u32x4*>(dst) = o;
+            __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(dst));      // pq_store_note
         }
         __syncthreads();
     }
@@ -223,7 +223,7 @@ __device__ __forceinline__ void epilogue_big_t(const GemmArgs& g, bf16_t* C, f32
             }
         }
         if (GEMM_EXP == 5) { if (o[0] == 0x12345678u) *reinterpret_cast<u32x4*>(dst) = o; continue; }
-        *reinterpret_cast<u32x4*>(dst) = o;
+        __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(dst));      // pq_store_note
         if constexpr (EPI == MH_EPI_SQERR) {
             // masked squared error against the f32 target rows (losses/mirror_loss.py:98-103) on the bf16-rounded prediction
             const int rpb = g.epi.rows_per_batch;             // % 256 == 0: a tile lies inside one batch

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void resconv_mfma_kernel(const bf16_t* __restr
             o[1] = pack_bf2(lo[2], lo[3]);
             o[2] = pack_bf2(hi[0], hi[1]);
             o[3] = pack_bf2(hi[2], hi[3]);
-            *reinterpret_cast<u32x4*>(p) = o;
+            __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(p));      // written once, whole 128-byte rows: must not evict the v rows the next row tile's halo reads
         }
         if (half == 0) __syncthreads();               // the first half is consumed before the second overwrites it
     }
