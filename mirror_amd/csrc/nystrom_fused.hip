@@ -146,12 +146,27 @@ __device__ __forceinline__ void tile_store(const u32x4 (&regs)[ROWS * 8 / NT], b
         *reinterpret_cast<u32x4*>(img + r * NP + c * 8) = regs[i];
     }
 }
-// accumulator rows 8g + 4hl + {0..3} of a [d][n]-oriented result -> 4 consecutive bf16 of the n-th row
-__device__ __forceinline__ void store_row4(bf16_t* p, const f32x16& a, int g) {
-    u32x2 w;
-    w[0] = pack_bf2(a[4 * g + 0], a[4 * g + 1]);
-    w[1] = pack_bf2(a[4 * g + 2], a[4 * g + 3]);
-    *reinterpret_cast<u32x2*>(p) = w;
+// All 16 accumulator rows of a [d][n]-oriented result (d = 32 nb ..) -> this lane's row p[0 .. 31] as TWO 16-byte stores instead of four
+// 8-byte ones: lanes c and c + 32 hold columns 8 gq + {0..3} and 8 gq + 4 + {0..3} of the same row, so they trade packed words
+// (v_permlane32_swap: the upper lane half of one register against the lower half of another) until the lower lane owns column groups
+// 0 and 2 whole and the upper lane groups 1 and 3.  (The outputs of these kernels leave as per-lane pieces of 32 different rows; the
+// L2 has to merge them into lines, and the store tail is issue bound: half the instructions.)
+__device__ __forceinline__ void store_row8(bf16_t* p, const f32x16& a, int hl) {
+    unsigned w[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        w[g][0] = pack_bf2(a[4 * g + 0], a[4 * g + 1]);
+        w[g][1] = pack_bf2(a[4 * g + 2], a[4 * g + 3]);
+    }
+#pragma unroll
+    for (int pr = 0; pr < 2; pr++) {          // column groups (2 pr, 2 pr + 1)
+        const u32x2 s0 = __builtin_amdgcn_permlane32_swap(w[2 * pr][0], w[2 * pr + 1][0], false, false);
+        const u32x2 s1 = __builtin_amdgcn_permlane32_swap(w[2 * pr][1], w[2 * pr + 1][1], false, false);
+        // lower lane: s?[0] = its own words of group 2 pr, s?[1] = the upper lane's words of that group; upper lane: s?[0] = the lower
+        // lane's words of group 2 pr + 1, s?[1] = its own
+        const u32x4 v = {s0[0], s1[0], s0[1], s1[1]};
+        *reinterpret_cast<u32x4*>(p + 8 * (2 * pr + hl)) = v;
+    }
 }
 
 // Key-padding mask ([3P] NystromAttention.forward(x, mask=...), BASELINE config 4): mrow [B, n_p] and mlm [B, m] hold 0 / 1
@@ -312,8 +327,7 @@ __global__ __launch_bounds__(NT) void nys_a1_fwd_kernel(const bf16_t* __restrict
                     o[nb][4 * gq + 2] += __uint_as_float(old[nb][gq][1] << 16);
                     o[nb][4 * gq + 3] += __uint_as_float(old[nb][gq][1] & 0xffff0000u);
                 }
-                store_row4(orow + 32 * nb + 8 * gq + 4 * hl, o[nb], gq);
-                if constexpr (Q8) {       // the e4m3 copy of exactly the bf16 values just stored
+                if constexpr (Q8) {       // the e4m3 copy of exactly the bf16 values stored below
                     float v4[4];
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
@@ -327,6 +341,7 @@ __global__ __launch_bounds__(NT) void nys_a1_fwd_kernel(const bf16_t* __restrict
                     *reinterpret_cast<unsigned*>(q8.q + ((long)b * g.n_p + row) * D + hd * ND + 32 * nb + 8 * gq + 4 * hl) = w;
                 }
             }
+            store_row8(orow + 32 * nb, o[nb], hl);
         }
     }
     if constexpr (Q8) {       // one atomic per wave that raises the step's maximum
@@ -435,9 +450,7 @@ __global__ __launch_bounds__(NT, 2) void nys_a1_bwd_dq_kernel(const bf16_t* __re
         }
         bf16_t* drow = dqkv + ((long)b * g.n_p + row) * 3 * D + hd * ND;
 #pragma unroll
-        for (int nb = 0; nb < 2; nb++)
-#pragma unroll
-            for (int gq = 0; gq < 4; gq++) store_row4(drow + 32 * nb + 8 * gq + 4 * hl, dq[nb], gq);
+        for (int nb = 0; nb < 2; nb++) store_row8(drow + 32 * nb, dq[nb], hl);
     }
 }
 
@@ -808,12 +821,10 @@ __global__ __launch_bounds__(NT, 2) void nys_a3_bwd_dkv_kernel(const bf16_t* __r
         }
         bf16_t* dkrow = dqkv + ((long)b * g.n_p + row) * 3 * D + D + hd * ND;
 #pragma unroll
-        for (int nb = 0; nb < 2; nb++)
-#pragma unroll
-            for (int gq = 0; gq < 4; gq++) {
-                store_row4(dkrow + 32 * nb + 8 * gq + 4 * hl, adk[nb], gq);
-                store_row4(dkrow + D + 32 * nb + 8 * gq + 4 * hl, adv[nb], gq);
-            }
+        for (int nb = 0; nb < 2; nb++) {
+            store_row8(dkrow + 32 * nb, adk[nb], hl);
+            store_row8(dkrow + D + 32 * nb, adv[nb], hl);
+        }
     }
 }
 
