@@ -25,8 +25,8 @@ for blk in range(2):
     print(f"== workgroup {0 if blk == 0 else 129}: [{M} x {Kd}] x [{Kd} x {N}], {nt} K-tiles per unit")
     for wv in (0, 4):
         s = st[wv]; n = int((s != 0).sum())
-        # per unit: segments x (start, waited, past barrier 1, mfmas issued); loop end; packed; 2 halves x (written, waited, past barrier, read, past barrier, stores issued); unit end
-        pu = nt * 8 + 15
+        # per unit: segments x (start, waited, past barrier 1, mfmas issued); loop end; packed; 2 halves x (written, past barrier, read, past barrier, stores issued); unit end
+        pu = nt * 8 + 13
         units = n // pu
         print(f" wave {wv}: {n} stamps, {units} units of {pu}")
         for u in range(1, min(units, 4)):
@@ -40,5 +40,5 @@ for blk in range(2):
             print(f"    barrier1  {bar1}")
             print(f"    mfma      {mf}")
             print(f"    barrier2  {bar2}")
-            names = ["level+pack", "write0/idle", "vmcnt0", "sync", "read0", "sync", "stores0", "write1/idle", "(-)", "sync", "read1", "sync", "request+stores1", "zero+switch"]
+            names = ["level+pack", "write0", "sync", "read0", "sync", "stores0", "write1", "sync", "read1", "sync", "stores1", "sync+switch"]
             print(f"    K loop {d(e[0], b[0])}  epilogue: " + "  ".join(f"{nm} {d(e[i + 1], e[i])}" for i, nm in enumerate(names)))
