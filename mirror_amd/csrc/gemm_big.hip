@@ -1017,7 +1017,8 @@ __device__ __forceinline__ void pq_epilogue_f32(const GemmArgs& g, float* C, f32
 // VAR = the epilogue variant, a template parameter so that each instance carries ONE epilogue (with several inlined side by side the
 // register allocator spilled loop invariants across the K loop and reloaded them in front of the stores, each reload a full drain of
 // the wave's memory queue): bf16 tiles (C or split-K partials): 0 = alpha == 1, no bias, no activation, 1 = alpha / bias, 2 = + ReLU;
-// f32 C: 0 = store, 1 = ReLU, 2 = accumulate.  Accumulating bf16 C and f32 atomics stay on gemm_pp_kernel (pq_variant()).
+// f32 C: 0 = store, 1 = ReLU, 2 = accumulate.  f32 atomics stay on gemm_pp_kernel (pq_variant()); accumulating bf16 C is not taken by
+// the 256 x 256 kernels at all (gemm_try_big_bf16).
 template <typename TC, bool AKC, bool BKC, bool PART = false, int EPI = 0, int VAR = 0>
 __global__ __launch_bounds__(NTB) void gemm_pq_kernel(GemmArgs g, int units, int tiles, int splits) {
     static_assert(EPI == 0 || (AKC && !PART), "fused epilogues: K-contiguous A, no split-K");
@@ -1442,6 +1443,9 @@ bool gemm_try_big_bf16(GemmArgs& a, int akc, int bkc, int dtC, int batch, hipStr
     const bool shape_ok = (a.M % BIG == 0 || (akc && a.M > BIG)) && a.N % BIG == 0 && a.K % 64 == 0 && a.k_per_split % 64 == 0;
     if (!shape_ok || !a.vecA || !a.vecB || !a.vecC || a.R || a.diag != 0.f) return false;
     if (a.atomic && (a.bias || a.act != MH_ACT_NONE || dtC != MH_F32)) return false;
+    // accumulating into a bf16 C: these kernels stage the product as bf16 before they add (two roundings, torch's `c += a @ b`), the
+    // 128 x 128 kernel adds in f32 and rounds once (addmm): one semantics for the entry point, the latter (no caller in the model)
+    if (dtC == MH_BF16 && a.accumulate) return false;
     const long wgs = (long)((a.M + BIG - 1) / BIG) * (a.N / BIG) * a.split_k * batch;
     if (wgs < 128) return false;            // too few workgroups for one per CU: the 128 x 128 kernel spreads better
     if (dtC == MH_BF16) launch_big<bf16_t>(a, akc, bkc, batch, s);

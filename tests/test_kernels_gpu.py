@@ -115,6 +115,63 @@ def test_gemm_large_tile_kernel(a_rm, b_t, out_dtype):
         assert bool((outr[:, Mr:] == 7.0).all()), "rows past M were written"
 
 
+@pytest.mark.parametrize("a_rm,b_t", LAYOUTS)
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+def test_gemm_persistent_kernel_epilogue_variants(a_rm, b_t, out_dtype):
+    """gemm_pq_kernel (>= 128 tiles of 256 x 256: one workgroup per CU walks the units) carries ONE epilogue per instance, chosen by
+    the host: bf16 tiles plain / alpha + bias / + ReLU, f32 C store / ReLU / accumulate, bf16 split-K partial tiles (plain / alpha).
+    Every variant bit-exact on small integers, and the library says which kernel it launched."""
+    from mirror_amd import _lib
+    lib = _lib.load()
+    gen = g(311 + a_rm + 2 * b_t)
+    M, N, Kd = 4096, 2048, 320              # 16 x 8 = 128 units, 5 K-tiles each
+    bf = torch.bfloat16
+    a_dev, a = _mk(a_rm, (M, Kd), gen, bf, True)
+    b_dev, b = _mk(not b_t, (Kd, N), gen, bf, True)
+    bias = ints((N,), gen)
+    ref = a.double() @ b.double()
+    cast = lambda t: t.float().to(out_dtype).double()  # noqa: E731
+
+    def launched(prefix):
+        name = lib.mh_gemm_variant_name().decode()
+        assert name.startswith(prefix), f"{name} (expected {prefix}...)"
+
+    out = K.gemm(a_dev, b_dev, mma=MH_BF16, out_dtype=out_dtype)
+    launched("gemm_pq_kernel<")
+    close(out, cast(ref), 0, 0, "persistent plain")
+    out = K.gemm(a_dev, b_dev, bias=bias.to(DEV), alpha=0.5, mma=MH_BF16, out_dtype=out_dtype)
+    launched("gemm_pq_kernel<")
+    close(out, cast(0.5 * ref + bias.double()), 0, 0, "persistent alpha + bias")
+    out = K.gemm(a_dev, b_dev, bias=bias.to(DEV), act=ACT_RELU, alpha=0.5, mma=MH_BF16, out_dtype=out_dtype)
+    launched("gemm_pq_kernel<")
+    close(out, cast(torch.relu(0.5 * ref + bias.double())), 0, 0, "persistent alpha + bias + ReLU")
+    base = ints((M, N), gen)
+    acc = base.to(DEV, out_dtype)
+    K.gemm(a_dev, b_dev, out=acc, accumulate=True, mma=MH_BF16)
+    launched("gemm_pq_kernel<" if out_dtype == torch.float32 else "gemm_kernel<1,")      # accumulating bf16 C: the 128 x 128 kernel (f32 add, ONE rounding)
+    close(acc, cast(ref + base.double()), 0, 0, "accumulate")
+    if a_rm:        # ragged M: the last row tile clamps its loads and guards its stores
+        Mr = M - 256 + 37
+        outr = torch.full((Mr + 3, N), 7.0, device=DEV, dtype=out_dtype)
+        K.gemm(a_dev[:Mr], b_dev, out=outr[:Mr], mma=MH_BF16)
+        launched("gemm_pq_kernel<")
+        close(outr[:Mr], cast(ref[:Mr]), 0, 0, "persistent ragged M")
+        assert bool((outr[Mr:] == 7.0).all()), "rows past M were written"
+    if out_dtype == torch.float32:
+        # split-K into bf16 partial tiles + fold: few output tiles, a long contraction (the weight-gradient shape)
+        Mw, Nw, Kw = 512, 512, 16384
+        aw_dev, aw = _mk(a_rm, (Mw, Kw), gen, bf, True)
+        bw_dev, bw = _mk(not b_t, (Kw, Nw), gen, bf, True)
+        for alpha in (1.0, 0.5):
+            dw = torch.zeros((Mw, Nw), device=DEV, dtype=torch.float32)
+            K.gemm(aw_dev, bw_dev, out=dw, accumulate=True, split_k=32, alpha=alpha, mma=MH_BF16)
+            launched("gemm_pq_kernel<")
+            want = torch.zeros((Mw, Nw), dtype=torch.float64)
+            for k0 in range(0, Kw, Kw // 32):
+                want += (alpha * (aw[:, k0:k0 + Kw // 32].double() @ bw[k0:k0 + Kw // 32].double())).float().bfloat16().double()
+            close(dw, want, 0, 0, f"persistent split-K partial tiles, alpha = {alpha}")
+
+
 @pytest.mark.parametrize("a_rm,b_t", [(True, False), (False, False), (True, True)])
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
 def test_gemm_tile384_kernel(a_rm, b_t, out_dtype):
