@@ -589,10 +589,11 @@ def test_seq_finish(dtype, N, add):
     close(dcls, d[:, 0].sum(0), 0, 0, "dcls")
 
 
-@pytest.mark.parametrize("S,D", [(5, 32), (16, 256), (9, 300)])
-def test_ppeg(S, D):
+@pytest.mark.parametrize("S,D,B", [(5, 32, 2), (16, 256, 2), (9, 300, 2), (40, 64, 8), (33, 32, 4)])
+def test_ppeg(S, D, B):
+    """(40, 64, 8) and (33, 32, 4): two 32-row strips per image and (batch, strip) groups a multiple of 8 — the XCD-aware workgroup
+    order of ppeg_rows2_kernel (the x-tiles of a group on one XCD); the others take the plain order."""
     gen = g(S)
-    B = 2
     x = torch.randn(B, 1 + S * S, D, generator=gen)
     ws = [torch.randn(D, 1, k, k, generator=gen) * 0.2 for k in (7, 5, 3)]
     bs = [torch.randn(D, generator=gen) * 0.1 for _ in range(3)]
