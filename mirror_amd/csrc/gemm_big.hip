@@ -722,10 +722,17 @@ __global__ __launch_bounds__(NTB) void gemm_pp_kernel(GemmArgs g) {
 // waiting time (a third unit record, decoded by the wave row that is not writing): no spills, products alone 0-3 % faster, step +0.28 % +- 0.11.
 // ---- stage layout of gemm_pq_kernel: every operand tile is TWO k-half sub-images of 16 KiB (k in [0, 32) and [32, 64) of the K-tile),
 // so that a segment of two k-steps reads one sub-image per operand and the other half can be in flight:
-//   K-contiguous: [256 rows][64 B], 16-byte chunk c of row r stored at chunk c ^ ((r >> 2) & 3)      (ds_read_b128 conflict free)
-//   K-strided   : [32 k][512 B], byte offset o of row k stored at o ^ ((k & 3) << 6)                 (ds_read_b64_tr_b16 conflict free)
+//   K-contiguous: [256 rows][64 B], 16-byte chunk c of row r stored at chunk c ^ F[(r >> 2) & 3], F = {0, 2, 3, 1}
+//   K-strided   : [32 k][512 B], byte offset o of row k stored at o ^ ((k & 3) << 6) ^ (((k >> 3) & 1) << 5)
+// Both swizzles are made for the fragments of v_mfma_f32_16x16x32_bf16 (a lane = row l & 15, k = 8 (l >> 4) .. + 7: one ds_read_b128
+// of a K-contiguous row's chunk l >> 4, or two ds_read_b64_tr_b16 of k rows 8 (l >> 4) + q (+ 4) of a K-strided image): each lane
+// group of a wave instruction meets 64 distinct banks (F: the four chunk slots a 16-lane group of a b128 read takes from rows
+// r, r + 4, r + 8, r + 12 differ; K-strided: the eight (k >> 3 & 1, k & 3) combinations of a 32-lane half take eight different 32-byte
+// slots of a 256-byte span).  The 16 x 16 x 32 shape does the same flops per cycle as 32 x 32 x 16, but the chip holds a higher clock
+// under it and its shorter MFMAs interleave better with the partner wave's loads: the products of the step ran 4-8 % faster with it.
 // slot = A_k0 | A_k1 | B_k0 | B_k1 (16 KiB each) | 4 KiB that only the C staging uses.  A sub-image = 16 pieces of 1 KiB: 2 per wave.
 constexpr int P2_SUB = 16 * 1024;
+__device__ __forceinline__ int p2_f4(int q) { return (0x78 >> (2 * q)) & 3; }       // F = {0, 2, 3, 1}
 template <bool KC>
 struct P2Stage {
     const bf16_t* p0;      // this lane's source address of its wave's piece 0 of sub-image k0 at K-tile 0 (KS: the even-piece swizzle)
@@ -733,9 +740,9 @@ struct P2Stage {
     long kadv, hadv, step; // elements per K-tile, per k-half, (KS) per piece
     __device__ __forceinline__ void init(const bf16_t* base, long ld, int tile0, int dim, int kbeg, int wave, int lane, int adj0, int bnd, int skip) {
         if constexpr (KC) {
-            // piece i of wave w = rows 32 w + 16 i + (lane >> 2); LDS chunk lane & 3 holds source chunk (lane & 3) ^ ((row >> 2) & 3),
+            // piece i of wave w = rows 32 w + 16 i + (lane >> 2); LDS chunk lane & 3 holds source chunk (lane & 3) ^ F[(row >> 2) & 3],
             // (row >> 2) & 3 = (lane >> 4) & 3 for every piece
-            const int c = (lane & 3) ^ ((lane >> 4) & 3);
+            const int c = (lane & 3) ^ p2_f4((lane >> 4) & 3);
             const bf16_t* b0 = base + kbeg + c * 8;
             const int r0 = 32 * wave + (lane >> 2), r1 = r0 + 16;
             const int l0 = min(tile0 + r0, dim - 1) - tile0, l1 = min(tile0 + r1, dim - 1) - tile0;
@@ -744,9 +751,10 @@ struct P2Stage {
             kadv = 64; hadv = 32; step = 0;
         } else {
             // piece i of wave w = k rows 4 w + 2 i + (lane >> 5) of the sub-image; LDS 16-byte chunk lane & 31 holds source chunk
-            // (lane & 31) ^ ((k & 3) << 2), k & 3 = (2 i + (lane >> 5)) & 3
+            // (lane & 31) ^ ((k & 3) << 2) ^ (((k >> 3) & 1) << 1), k & 3 = (2 i + (lane >> 5)) & 3, k >> 3 = wave >> 1
             const int k = 4 * wave + (lane >> 5);
-            const int c0 = (lane & 31) ^ (((lane >> 5) & 3) << 2), c1 = (lane & 31) ^ (((2 + (lane >> 5)) & 3) << 2);
+            const int h8 = ((wave >> 1) & 1) << 1;
+            const int c0 = (lane & 31) ^ (((lane >> 5) & 3) << 2) ^ h8, c1 = (lane & 31) ^ (((2 + (lane >> 5)) & 3) << 2) ^ h8;
             p0 = base + (long)(kbeg + k) * ld + tile0 + c0 * 8;
             p1 = base + (long)(kbeg + k + 2) * ld + tile0 + c1 * 8;
             kadv = 64 * ld; hadv = 32 * ld; step = 0;
@@ -760,12 +768,30 @@ struct P2Stage {
         PP_GLDS(p1 + o, dst + 1024, 0);
     }
 };
-// K-contiguous sub-image: fragment of row block rb (32 rows) at k-step ks (0 / 1) of the half: lane offset off[ks], block stride 2048 B
-__device__ __forceinline__ bf16x8 p2_frag_kc(const char* sub, const unsigned (&off)[2], int rb, int ks) {
-    return *reinterpret_cast<const bf16x8*>(sub + off[ks] + rb * 2048);
+// fragments of v_mfma_f32_16x16x32_bf16 for 16 rows (A) / 16 columns (B) over the 32 k of a sub-image:
+// K-contiguous: ONE ds_read_b128 at this lane's offset (row l & 15, chunk (l >> 4) ^ F) + 1024 B per 16-row block
+__device__ __forceinline__ unsigned q_kc_off(int row0, int lane) {
+    const int r = lane & 15, c = lane >> 4;
+    return (unsigned)((row0 + r) * 64 + ((c ^ p2_f4((r >> 2) & 3)) << 4));
 }
-// K-strided sub-image: `off` = pp_ks_off of the 32-column block, k-step stride 8192 B, second 4-row group + 2048 B
-__device__ __forceinline__ bf16x8 p2_frag_ks(const char* sub, unsigned off, int ks) { return pp_frag_ks(sub, off, ks); }
+__device__ __forceinline__ bf16x8 q_frag_kc(const char* sub, unsigned off, int blk) {
+    return *reinterpret_cast<const bf16x8*>(sub + off + blk * 1024);
+}
+// K-strided: two ds_read_b64_tr_b16; lane 4 q + p of a 16-lane group g supplies k row 8 g + q (+ 4), columns 4 p .. 4 p + 3 of the
+// block's 16; the block's 32-byte slot index is XORed with (q << 1) ^ (g & 1) (the image's swizzle), so every block has its own offset
+__device__ __forceinline__ unsigned q_ks_off(int jb16, int lane) {
+    const int g = lane >> 4, q = (lane & 15) >> 2, p4 = lane & 3;
+    return (unsigned)((8 * g + q) * 512 + ((jb16 ^ ((q << 1) ^ (g & 1))) << 5) + 8 * p4);
+}
+__device__ __forceinline__ bf16x8 q_frag_ks(const char* sub, unsigned off) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sub + off));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sub + off + 2048));
+    s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+constexpr int QM = 8, QN = 4;                  // 16 x 16 accumulator blocks of a wave's 128 x 64 part of the tile
 
 constexpr int PQ_SLOT = 68 * 1024;            // LDS stage slot: A image 32 KiB | B image 32 KiB | 4 KiB that only the C staging uses
 constexpr int PQ_LDS = 2 * PQ_SLOT;
@@ -784,26 +810,28 @@ constexpr int PQ_LDS = 2 * PQ_SLOT;
 // before the barrier that frees the image, so the stores are issued while the other wave row already writes the next phase.
 //
 // bf16 C (or the bf16 split-K partial tiles: C = the slice's partial matrix, ldc = N, remap = false).  The accumulators are in C^T
-// form (a lane owns 4 consecutive columns of a row); rows [128 half, +128) of the tile go through `t`, the wave row `half` writing,
-// everybody storing 16-byte row-contiguous chunks.  KIND 0: alpha == 1, no bias, no activation: both wave rows pack their
-// accumulators first (one v_cvt_pk_bf16_f32 per two elements, in place), so a write phase is 32 ds_write_b64 and nothing else;
-// 1: alpha, bias (the 4 quads of a column block requested together); 2: + ReLU.
+// form: block (i, j) of lane (c16 = l & 15, g4 = l >> 4) holds columns 16 j + 4 g4 + {0..3} of row 16 i + c16 of the wave's
+// 128 x 64 part; rows [128 half, +128) of the tile go through `t`, the wave row `half` writing, everybody storing 16-byte
+// row-contiguous chunks.  KIND 0: alpha == 1, no bias, no activation: both wave rows pack their accumulators first (one
+// v_cvt_pk_bf16_f32 per two elements, in place), so a write phase is 32 ds_write_b64 and nothing else; 1: alpha, bias (the lane's four
+// bias quads requested together); 2: + ReLU.
 template <int MODE, int EPI, int KIND>
-__device__ __forceinline__ void pq_epilogue_bf16(const GemmArgs& g, bf16_t* C, long ldc, bool remap, f32x16 (&acc)[BWM][BWN], char* smem_c,
+__device__ __forceinline__ void pq_epilogue_bf16(const GemmArgs& g, bf16_t* C, long ldc, bool remap, f32x4 (&acc)[QM][QN], char* smem_c,
                                                  int tile_row0, int tile_col0, int wm, int wn, int lane, int tid, bool has_bias, float alpha) {
     constexpr int PITCH = BIG + 4, HALF = BIG / 2;
     // the staging addresses are recomputed per unit: hoisted out of the unit loop they would live (spilled) across the K loop
     asm volatile("" : "+v"(lane), "+v"(tid));
     bf16_t* t = reinterpret_cast<bf16_t*>(smem_c);
-    const int r = lane & 31, hh = lane >> 5;
-    unsigned pk[BWM][BWN][8];
+    const int c16 = lane & 15, g4 = lane >> 4;
+    unsigned pk[QM][QN][2];
     if constexpr (KIND == 0) {
 #pragma unroll
-        for (int i = 0; i < BWM; i++)
+        for (int i = 0; i < QM; i++)
 #pragma unroll
-            for (int j = 0; j < BWN; j++)
-#pragma unroll
-                for (int w = 0; w < 8; w++) pk[i][j][w] = pack_bf2(acc[i][j][2 * w], acc[i][j][2 * w + 1]);
+            for (int j = 0; j < QN; j++) {
+                pk[i][j][0] = pack_bf2(acc[i][j][0], acc[i][j][1]);
+                pk[i][j][1] = pack_bf2(acc[i][j][2], acc[i][j][3]);
+            }
     }
     // physical rows of this tile (row windows, GemmArgs.c_rpb): a tile touches at most two windows when c_rpb >= 256
     const bool win = remap && g.c_rpb > 0, win2 = win && g.c_rpb >= BIG;
@@ -818,36 +846,33 @@ __device__ __forceinline__ void pq_epilogue_bf16(const GemmArgs& g, bf16_t* C, l
 #pragma unroll
     for (int half = 0; half < 2; half++) {
         if (wm == half) {
+            f32x4 bv[QN];
+            if constexpr (KIND != 0) {
 #pragma unroll
-            for (int j = 0; j < BWN; j++) {
-                f32x4 bv[4];
-                if constexpr (KIND != 0) {
+                for (int j = 0; j < QN; j++) bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (has_bias) {
 #pragma unroll
-                    for (int gq = 0; gq < 4; gq++) bv[gq] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (has_bias) {
-#pragma unroll
-                        for (int gq = 0; gq < 4; gq++) bv[gq] = *reinterpret_cast<const f32x4*>(g.bias + tile_col0 + wn * BWN * 32 + 32 * j + 8 * gq + 4 * hh);
-                    }
+                    for (int j = 0; j < QN; j++) bv[j] = *reinterpret_cast<const f32x4*>(g.bias + tile_col0 + wn * QN * 16 + 16 * j + 4 * g4);
                 }
-#pragma unroll
-                for (int i = 0; i < BWM; i++)
-#pragma unroll
-                    for (int gq = 0; gq < 4; gq++) {
-                        u32x2 o2;
-                        if constexpr (KIND == 0) {
-                            o2 = u32x2{pk[i][j][2 * gq], pk[i][j][2 * gq + 1]};
-                        } else {
-                            float v[4];
-#pragma unroll
-                            for (int e = 0; e < 4; e++) {
-                                v[e] = alpha * acc[i][j][4 * gq + e] + bv[gq][e];
-                                if constexpr (KIND == 2) v[e] = fmaxf(v[e], 0.f);
-                            }
-                            o2 = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-                        }
-                        *reinterpret_cast<u32x2*>(t + (32 * i + r) * PITCH + wn * BWN * 32 + 32 * j + 8 * gq + 4 * hh) = o2;
-                    }
             }
+#pragma unroll
+            for (int i = 0; i < QM; i++)
+#pragma unroll
+                for (int j = 0; j < QN; j++) {
+                    u32x2 o2;
+                    if constexpr (KIND == 0) {
+                        o2 = u32x2{pk[i][j][0], pk[i][j][1]};
+                    } else {
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            v[e] = alpha * acc[i][j][e] + bv[j][e];
+                            if constexpr (KIND == 2) v[e] = fmaxf(v[e], 0.f);
+                        }
+                        o2 = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                    }
+                    *reinterpret_cast<u32x2*>(t + (16 * i + c16) * PITCH + wn * QN * 16 + 16 * j + 4 * g4) = o2;
+                }
         }
         __syncthreads();
         constexpr int CPR = BIG / 8;                 // 16-byte chunks per tile row
@@ -918,14 +943,14 @@ __device__ __forceinline__ void pq_epilogue_bf16(const GemmArgs& g, bf16_t* C, l
         __syncthreads();
     }
 }
-// f32 C (a lane owns a column, its registers the rows): rows [64 q, +64) of the tile through `t`, q = 0 .. 3
+// f32 C (block (i, j) of lane (c16, g4) holds rows 16 i + 4 g4 + {0..3} of column 16 j + c16): rows [64 q, +64) of the tile through `t`, q = 0 .. 3
 template <int MODE, int EPI, bool RELU>
-__device__ __forceinline__ void pq_epilogue_f32(const GemmArgs& g, float* C, f32x16 (&acc)[BWM][BWN], char* smem_c, int tile_row0, int tile_col0,
+__device__ __forceinline__ void pq_epilogue_f32(const GemmArgs& g, float* C, f32x4 (&acc)[QM][QN], char* smem_c, int tile_row0, int tile_col0,
                                                 int wm, int wn, int lane, int tid, bool lead, long ldc, float alpha) {
     constexpr int PITCH = BIG + 4, QR = BIG / 4;
     asm volatile("" : "+v"(lane), "+v"(tid));        // see pq_epilogue_bf16
     float* t = reinterpret_cast<float*>(smem_c);
-    const int r = lane & 31, hh = lane >> 5;
+    const int c16 = lane & 15, g4 = lane >> 4;
     uint64_t drop_blk0 = 0;
     uint32_t thr = 0;
     float dscale = 1.f;
@@ -936,27 +961,24 @@ __device__ __forceinline__ void pq_epilogue_f32(const GemmArgs& g, float* C, f32
         thr = drop16_thr(g.epi.p);
         dscale = drop16_scale(thr);
     }
-    float bias[BWN];
+    float bias[QN];
 #pragma unroll
-    for (int j = 0; j < BWN; j++) bias[j] = (g.bias && lead) ? g.bias[tile_col0 + wn * BWN * 32 + j * 32 + r] : 0.f;
+    for (int j = 0; j < QN; j++) bias[j] = (g.bias && lead) ? g.bias[tile_col0 + wn * QN * 16 + 16 * j + c16] : 0.f;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         if (wm == (q >> 1)) {
 #pragma unroll
-            for (int j = 0; j < BWN; j++) {
-                const int lc = wn * BWN * 32 + j * 32 + r;
+            for (int ii = 0; ii < 4; ii++)
 #pragma unroll
-                for (int i2 = 0; i2 < 2; i2++) {
-                    const int lr0 = i2 * 32 + 4 * hh;
+                for (int j = 0; j < QN; j++) {
+                    const int lc = wn * QN * 16 + 16 * j + c16;
 #pragma unroll
-                    for (int reg = 0; reg < 16; reg++) {
-                        const int lr = lr0 + (reg & 3) + 8 * (reg >> 2);
-                        float v = alpha * acc[2 * (q & 1) + i2][j][reg] + bias[j];
+                    for (int e = 0; e < 4; e++) {
+                        float v = alpha * acc[4 * (q & 1) + ii][j][e] + bias[j];
                         if constexpr (RELU) v = fmaxf(v, 0.f);
-                        t[lr * PITCH + lc] = v;
+                        t[(16 * ii + 4 * g4 + e) * PITCH + lc] = v;
                     }
                 }
-            }
         }
         __syncthreads();
         if constexpr (EPI == MH_EPI_DROPADD) {
@@ -1030,30 +1052,19 @@ __global__ __launch_bounds__(NTB) void gemm_pq_kernel(GemmArgs g, int units, int
     const int wm = wave >> 2, wn = wave & 3;
     const int q8 = units >> 3, r8 = units & 7;
 
-    // fragment read offsets within a sub-image: K-contiguous: one per k-step of the half (row block = immediate); K-strided: one per
-    // 32-column block of this wave (k-step = immediate)
-    unsigned offa[4], offb[4];
-    if constexpr (AKC) {
-        const int r = lane & 31, h = lane >> 5, f = (r >> 2) & 3;
-        offa[0] = wm * 4 * 2048 + r * 64 + (((0 + h) ^ f) << 4);
-        offa[1] = wm * 4 * 2048 + r * 64 + (((2 + h) ^ f) << 4);
-        offa[2] = offa[3] = 0;
-    } else {
+    // fragment read offsets within a sub-image (q_frag_kc / q_frag_ks): K-contiguous: one (the 16-row block is an immediate);
+    // K-strided: one per 16-column block of this wave's part
+    unsigned offa[AKC ? 1 : QM], offb[BKC ? 1 : QN];
+    if constexpr (AKC) offa[0] = q_kc_off(wm * QM * 16, lane);
+    else {
 #pragma unroll
-        for (int i = 0; i < 4; i++) offa[i] = pp_ks_off(wm * 4 + i, lane);
+        for (int i = 0; i < QM; i++) offa[i] = q_ks_off(wm * QM + i, lane);
     }
-    if constexpr (BKC) {
-        const int r = lane & 31, h = lane >> 5, f = (r >> 2) & 3;
-        offb[0] = wn * 2 * 2048 + r * 64 + (((0 + h) ^ f) << 4);
-        offb[1] = wn * 2 * 2048 + r * 64 + (((2 + h) ^ f) << 4);
-        offb[2] = offb[3] = 0;
-    } else {
+    if constexpr (BKC) offb[0] = q_kc_off(wn * QN * 16, lane);
+    else {
 #pragma unroll
-        for (int j = 0; j < 2; j++) offb[j] = pp_ks_off(wn * 2 + j, lane);
-        offb[2] = offb[3] = 0;
+        for (int j = 0; j < QN; j++) offb[j] = q_ks_off(wn * QN + j, lane);
     }
-    const unsigned (&offa2)[2] = reinterpret_cast<const unsigned (&)[2]>(offa);
-    const unsigned (&offb2)[2] = reinterpret_cast<const unsigned (&)[2]>(offb);
 
     // unit v of this workgroup -> (tile_m, tile_n, batch z, K-slice): XCD-aware order over all units (see gemm_big_kernel); the
     // workgroups of one launch run on XCD blockIdx.x % 8, and v = blockIdx.x + k gridDim.x keeps that residue when gridDim.x % 8 == 0
@@ -1101,13 +1112,11 @@ __global__ __launch_bounds__(NTB) void gemm_pq_kernel(GemmArgs g, int units, int
         const int vn = v + gridDim.x;
         const bool has_next = vn < units;
         if (has_next) decode(vn, n_tile_m, n_tile_n, n_z, n_split, n_nt, sa_n, sb_n);
-        f32x16 acc[BWM][BWN];
+        f32x4 acc[QM][QN];
 #pragma unroll
-        for (int i = 0; i < BWM; i++)
+        for (int i = 0; i < QM; i++)
 #pragma unroll
-            for (int j = 0; j < BWN; j++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+            for (int j = 0; j < QN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (wm == 1) __builtin_amdgcn_s_barrier();          // waves 4-7 run one barrier behind waves 0-3 inside the K loop
 #pragma unroll 1
         for (int t = 0; t < nt; t++, ctr++) {
@@ -1120,22 +1129,18 @@ __global__ __launch_bounds__(NTB) void gemm_pq_kernel(GemmArgs g, int units, int
                 // ---- LOAD segment: the fragments of both k-steps of this k-half, then the next K-tile's (or unit's) same k-half
                 const char* asub = cur + kh * P2_SUB;
                 const char* bsub = cur + (2 + kh) * P2_SUB;
-                bf16x8 af[2][BWM], bfr[2][BWN];
+                bf16x8 af[QM], bfr[QN];
 #pragma unroll
-                for (int ks = 0; ks < 2; ks++)
-#pragma unroll
-                    for (int j = 0; j < BWN; j++) {
-                        if constexpr (BKC) bfr[ks][j] = p2_frag_kc(bsub, offb2, j, ks);
-                        else bfr[ks][j] = p2_frag_ks(bsub, offb[j], ks);
-                    }
+                for (int j = 0; j < QN; j++) {
+                    if constexpr (BKC) bfr[j] = q_frag_kc(bsub, offb[0], j);
+                    else bfr[j] = q_frag_ks(bsub, offb[j]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int ks = 0; ks < 2; ks++)
-#pragma unroll
-                    for (int i = 0; i < BWM; i++) {
-                        if constexpr (AKC) af[ks][i] = p2_frag_kc(asub, offa2, i, ks);
-                        else af[ks][i] = p2_frag_ks(asub, offa[i], ks);
-                    }
+                for (int i = 0; i < QM; i++) {
+                    if constexpr (AKC) af[i] = q_frag_kc(asub, offa[0], i);
+                    else af[i] = q_frag_ks(asub, offa[i]);
+                }
                 if (feed) {
                     if (!last) {
                         sa.issue(nxt + kh * P2_SUB, wave, t + 1, kh);
@@ -1152,17 +1157,15 @@ __global__ __launch_bounds__(NTB) void gemm_pq_kernel(GemmArgs g, int units, int
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
-                // ---- COMPUTE segment: 16 MFMAs
+                // ---- COMPUTE segment: 32 MFMAs (16 x 16 x 32: the whole k-half each)
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int ks = 0; ks < 2; ks++)
+                for (int i = 0; i < QM; i++)
 #pragma unroll
-                    for (int i = 0; i < BWM; i++)
-#pragma unroll
-                        for (int j = 0; j < BWN; j++) {
-                            if constexpr (CT) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);   // C^T
-                            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
-                        }
+                    for (int j = 0; j < QN; j++) {
+                        if constexpr (CT) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // C^T
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    }
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
