@@ -141,9 +141,11 @@ int64_t mh_gemm_workspace_bytes(const mh_gemm_desc* d);
 
 /* ---------------------------------------------------------------- skinny-M linears (RNA encoder / style heads: every
  * tensor is [B, D], models/mirror.py:77-102, :217-224, :845-857): weight-streaming kernels, bf16 operands.
- * y[M<=32, N] = act(x[M,K] W[N,K]^T + bias); K % 32 == 0; the data gradient is the same call on the W^T shadow. */
-int mh_skinny_fwd(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, void* y, int64_t ldy,
-                  int M, int N, int K, int act, int dt_x, int dt_y, mh_stream s);      /* x bf16, or f32 rounded to bf16 on load */
+ * y[M<=32, N] = act(x[M,K] W[N,K]^T + bias + addend); K % 32 == 0; the data gradient is the same call on the W^T shadow, and
+ * `addend` (nullable f32 [M, N], row stride ldadd) is how the data gradients of two linears that read the same x are summed
+ * without a launch of their own (style_mu / style_logstd, models/mirror.py:845-857). */
+int mh_skinny_fwd(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, const float* addend, int64_t ldadd,
+                  void* y, int64_t ldy, int M, int N, int K, int act, int dt_x, int dt_y, mh_stream s);      /* x bf16, or f32 rounded to bf16 on load */
 /* dW[N,K] (+)= dy[M,N]^T x[M,K]  (f32, plain read-modify-write: one block owns each output tile) */
 int mh_skinny_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw, int64_t lddw, float* db, int M, int N,
                     int K, int accumulate, int dt_dy, int dt_x, mh_stream s);   /* db (optional, [N] f32): db += column sums of dy (the bias gradient) */
@@ -259,14 +261,16 @@ int mh_resconv_wgrad(const void* v, int64_t ldv, int64_t v_bs, const void* dout,
 int mh_pinv_absmax(const float* x, uint64_t* stats64, int BH, int m, mh_stream s);
 /* z0[bh,i,j] = x[bh,j,i] / (c*r) */
 int mh_pinv_z0(const float* x, const uint64_t* stats64, float* z0, int BH, int m, mh_stream s);
-/* dx += dz0^T/(c r) + sub-gradients through the two max(); z0 may be NULL (m % 64 == 0): z0 = x^T / (c r) is then formed on the fly */
+/* dx += dz0^T/(c r) + sub-gradients through the two max(); z0 may be NULL (m % 64 == 0): z0 = x^T / (c r) is then formed on the fly.
+ * scratch1 = one device float the kernels reduce into; scratch_zeroed != 0: the caller hands it over holding 0 (no memset here) */
 int mh_pinv_z0_bwd(const float* x, const float* z0, const float* dz0, const uint64_t* stats64, float* dx,
-                   float* scratch1, int BH, int m, mh_stream s);
+                   float* scratch1, int scratch_zeroed, int BH, int m, mh_stream s);
 /* attn2's backward tail in one pass (m = 256, x = p = the softmax output of [3P] sim2, no key-padding mask): on entry dx holds the
  * chain's d loss / d x; on exit dx = d loss / d sim2-logits = softmax_bwd(p, dx + dz0^T / (c r) + max sub-gradients).  Equals
  * mh_pinv_z0_bwd(x = p, z0 = NULL) followed by mh_softmax_bwd up to the rounding of the row sums (the row maximum's constant cancels
  * in a softmax backward; the column maximum's is applied as a rank-one correction of the one matrix that holds it). */
-int mh_pinv_s2_bwd(const float* p, const float* dz0, const uint64_t* stats64, float* dx, float* scratch1, int BH, int m, mh_stream s);
+int mh_pinv_s2_bwd(const float* p, const float* dz0, const uint64_t* stats64, float* dx, float* scratch1, int scratch_zeroed, int BH,
+                   int m, mh_stream s);
 /* The whole iteration as ONE launch per pass (bf16 policy, m = 256; other sizes return MH_EINVAL and the caller
  * composes mh_gemm): one 256-thread workgroup per (b,h) walks the chain of m x m products; a wave owns 64 columns of
  * every product, its B operand never leaves the register file, A is one LDS image (pinv_panel.hip).
@@ -454,10 +458,15 @@ int mh_l2norm_fwd(const void* x, void* y, float* nrm, int rows, int D, int64_t x
                   mh_stream s);
 int mh_l2norm_bwd(const void* y, const float* nrm, const void* dy, void* dx, int rows, int D, int64_t dx_rs,
                   float eps, int dt_y, int dt_dy, int dt_dx, int accumulate, mh_stream s);
-/* z = mu + eps*exp(0.5*logstd) (models/mirror.py:830-833) */
+/* y = exp(x) on a small f32 tensor (`logit_scale.exp()`, models/mirror.py:911); backward dx (+)= dy * y (accumulate != 0: summed
+   into dx, the parameter's gradient slot) */
+int mh_exp_fwd(const float* x, float* y, int64_t n, mh_stream s);
+int mh_exp_bwd(const float* dy, const float* y, float* dx, int64_t n, int accumulate, mh_stream s);
+/* z = mu + eps*exp(0.5*logstd) (models/mirror.py:830-833); backward: dmu = dz + add_mu, dlogstd = dz*eps*0.5*exp(0.5*logstd) +
+   add_logstd (add_* nullable: what reached mu / logstd from their other consumer, the KL term of losses/mirror_loss.py:112-117) */
 int mh_reparam_fwd(const float* mu, const float* logstd, const float* eps, float* z, int64_t n, mh_stream s);
-int mh_reparam_bwd(const float* logstd, const float* eps, const float* dz, float* dmu, float* dlogstd, int64_t n,
-                   mh_stream s);
+int mh_reparam_bwd(const float* logstd, const float* eps, const float* dz, const float* add_mu, const float* add_logstd,
+                   float* dmu, float* dlogstd, int64_t n, mh_stream s);
 
 /* ---------------------------------------------------------------- losses (losses/mirror_loss.py, losses/info_nce.py)
  * cross-entropy of rows of scale*G against label (label_off + row); G [R x C] f32.
@@ -556,15 +565,21 @@ int mh_loss_terms_fwd(const mh_loss_terms* d, mh_stream s);
 int mh_loss_terms_bwd(const mh_loss_terms* d, mh_stream s);
 
 /* ---------------------------------------------------------------- step glue (train_mirror.py:1133-1136, :1230, :1254-1255) */
-int mh_rownorm_(float* w, int rows, int D, float eps, mh_stream s);
+/* w[r] /= max(||w[r]||, eps) in place (the prototype renormalisation, train_mirror.py:1133-1136); shadow_bf16 (nullable, [rows, D]
+ * contiguous) receives the bf16 copy of the result in the same pass */
+int mh_rownorm_(float* w, void* shadow_bf16, int rows, int D, float eps, mh_stream s);
 int mh_clamp_(float* x, int64_t n, float lo, float hi, mh_stream s);
 /* torch.optim.Adam (wd=0): flat f32 params/grads/moments; optional bf16 shadow copy of the params.
  * dev_state (nullable, 6 device floats {t, 1-b1^t, 1-b2^t, lr, clip, |g|}): when given, t is advanced and the bias
  * corrections are refreshed ON THE DEVICE before the update, lr / bias_c1 / bias_c2 arguments are ignored and the
  * gradient is additionally scaled by dev_state[4] (1, or the factor mh_grad_clip left there) — nothing step-dependent
- * is a launch argument, so the whole step can be captured in a HIP graph (train_mirror.py:1254 optimizer.step()) */
+ * is a launch argument, so the whole step can be captured in a HIP graph (train_mirror.py:1254 optimizer.step()).
+ * Step glue that rides along instead of costing launches of its own: clamp_index >= 0 clamps that one parameter to
+ * [clamp_lo, clamp_hi] right behind its update, master and shadow (`logit_scale.clamp_(0, ln 100)`, train_mirror.py:1255; -1 =
+ * none); counter (nullable) += counter_add on the device (the dropout streams' per-step base). */
 int mh_adam(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr, float beta1,
-            float beta2, float eps, float bias_c1, float bias_c2, float grad_scale, float* dev_state, mh_stream s);
+            float beta2, float eps, float bias_c1, float bias_c2, float grad_scale, float* dev_state, int64_t clamp_index,
+            float clamp_lo, float clamp_hi, int64_t* counter, int64_t counter_add, mh_stream s);
 
 /* clip-grad "norm" mode (train_mirror.py:1206-1230): dev_state[5] = ||grad_scale * g||_2, dev_state[4] =
  * min(1, max_norm / (norm + 1e-6)) (1 when max_norm <= 0); scratch1 = one device float. */

@@ -93,7 +93,7 @@ class RnaBlockDesc(C.Structure):
 # name -> argtypes (the trailing stream argument is appended automatically)
 _SIGS = {
     "mh_gemm": [C.POINTER(GemmDesc)],
-    "mh_skinny_fwd": [P, L, P, L, P, P, L, I, I, I, I, I, I],
+    "mh_skinny_fwd": [P, L, P, L, P, P, L, P, L, I, I, I, I, I, I],
     "mh_skinny_wgrad": [P, L, P, L, P, L, P, I, I, I, I, I, I],
     "mh_skinny_wgrad_many": [C.POINTER(SkinnyWgradItem), I],
     "mh_transpose_bf16": [P, P, I, I],
@@ -112,8 +112,8 @@ _SIGS = {
     "mh_resconv_wgrad": [P, L, L, P, L, L, P, I, I, I, I, I, I, I],
     "mh_pinv_absmax": [P, P, I, I],
     "mh_pinv_z0": [P, P, P, I, I],
-    "mh_pinv_z0_bwd": [P, P, P, P, P, P, I, I],
-    "mh_pinv_s2_bwd": [P, P, P, P, P, I, I],
+    "mh_pinv_z0_bwd": [P, P, P, P, P, P, I, I, I],
+    "mh_pinv_s2_bwd": [P, P, P, P, P, I, I, I],
     "mh_eye_minus": [P, P, F, I, I],
     "mh_pinv_chain_prep": [P, P, P, P, P, I, I],
     "mh_pinv_chain_pack": [P, P, I, I],
@@ -151,8 +151,10 @@ _SIGS = {
     "mh_colsum": [P, P, L, I, L, I],
     "mh_l2norm_fwd": [P, P, P, I, I, L, F, I, I],
     "mh_l2norm_bwd": [P, P, P, P, I, I, L, F, I, I, I, I],
+    "mh_exp_fwd": [P, P, L],
+    "mh_exp_bwd": [P, P, P, L, I],
     "mh_reparam_fwd": [P, P, P, P, L],
-    "mh_reparam_bwd": [P, P, P, P, P, L],
+    "mh_reparam_bwd": [P, P, P, P, P, P, P, L],
     "mh_ce_rows_fwd": [P, L, P, F, I, I, I, F, P, P, P],
     "mh_ce_rows_bwd": [P, L, P, F, P, P, I, F, P, P, I, I, I],
     "mh_mse_masked_fwd": [P, P, P, P, L, I, L, L, I, I],
@@ -171,9 +173,9 @@ _SIGS = {
     "mh_kl_bwd": [P, P, P, P, P, L, F],
     "mh_symkl_fwd": [P, P, P, I, I, F],
     "mh_symkl_bwd": [P, P, P, P, P, I, I, F],
-    "mh_rownorm_": [P, I, I, F],
+    "mh_rownorm_": [P, P, I, I, F],
     "mh_clamp_": [P, L, F, F],
-    "mh_adam": [P, P, P, P, P, L, F, F, F, F, F, F, F, P],
+    "mh_adam": [P, P, P, P, P, L, F, F, F, F, F, F, F, P, L, F, F, P, L],
     "mh_grad_clip": [P, L, F, F, P, P],
     "mh_rna_block_fwd": [C.POINTER(RnaBlockDesc)],
     "mh_rna_block_bwd": [C.POINTER(RnaBlockDesc)],

@@ -788,10 +788,14 @@ extern "C" int mh_fanout_bwd(const float* gfull, const void* x, float alpha, con
 __global__ __launch_bounds__(256) void reparam_fwd_kernel(const float* mu, const float* ls, const float* eps, float* z, long n) {
     EW_LOOP(i, n) z[i] = mu[i] + eps[i] * __expf(0.5f * ls[i]);
 }
-__global__ __launch_bounds__(256) void reparam_bwd_kernel(const float* ls, const float* eps, const float* dz, float* dmu, float* dls, long n) {
+// add_mu / add_ls (nullable): gradients that reached mu / logstd by another road (the KL term reads both): summed in here, so
+// autograd has nothing to add afterwards
+__global__ __launch_bounds__(256) void reparam_bwd_kernel(const float* ls, const float* eps, const float* dz, const float* add_mu,
+                                                          const float* add_ls, float* dmu, float* dls, long n) {
     EW_LOOP(i, n) {
-        dmu[i] = dz[i];
-        dls[i] = dz[i] * eps[i] * 0.5f * __expf(0.5f * ls[i]);
+        const float g = dz[i];
+        dmu[i] = g + (add_mu ? add_mu[i] : 0.f);
+        dls[i] = g * eps[i] * 0.5f * __expf(0.5f * ls[i]) + (add_ls ? add_ls[i] : 0.f);
     }
 }
 extern "C" int mh_reparam_fwd(const float* mu, const float* logstd, const float* eps, float* z, int64_t n, mh_stream s) {
@@ -800,11 +804,36 @@ extern "C" int mh_reparam_fwd(const float* mu, const float* logstd, const float*
     MH_LAUNCH_CHECK("mh_reparam_fwd");
     return MH_OK;
 }
-extern "C" int mh_reparam_bwd(const float* logstd, const float* eps, const float* dz, float* dmu, float* dlogstd, int64_t n,
-                              mh_stream s) {
+extern "C" int mh_reparam_bwd(const float* logstd, const float* eps, const float* dz, const float* add_mu, const float* add_logstd,
+                              float* dmu, float* dlogstd, int64_t n, mh_stream s) {
     if (n == 0) return MH_OK;
-    hipLaunchKernelGGL(reparam_bwd_kernel, EW_GRID(n), dim3(256), 0, (hipStream_t)s, logstd, eps, dz, dmu, dlogstd, (long)n);
+    hipLaunchKernelGGL(reparam_bwd_kernel, EW_GRID(n), dim3(256), 0, (hipStream_t)s, logstd, eps, dz, add_mu, add_logstd, dmu, dlogstd,
+                       (long)n);
     MH_LAUNCH_CHECK("mh_reparam_bwd");
+    return MH_OK;
+}
+
+// ------------------------------------------------------------------ exp of a small f32 tensor (logit_scale.exp(), models/mirror.py:911)
+__global__ __launch_bounds__(256) void exp_fwd_kernel(const float* x, float* y, long n) {
+    EW_LOOP(i, n) y[i] = expf(x[i]);
+}
+// dx (+)= dy * y: with acc the parameter's gradient is summed straight into its arena slot (no mul + add pair on the autograd side)
+__global__ __launch_bounds__(256) void exp_bwd_kernel(const float* dy, const float* y, float* dx, long n, int acc) {
+    EW_LOOP(i, n) {
+        const float g = dy[i] * y[i];
+        dx[i] = acc ? dx[i] + g : g;
+    }
+}
+extern "C" int mh_exp_fwd(const float* x, float* y, int64_t n, mh_stream s) {
+    if (n == 0) return MH_OK;
+    hipLaunchKernelGGL(exp_fwd_kernel, EW_GRID(n), dim3(256), 0, (hipStream_t)s, x, y, (long)n);
+    MH_LAUNCH_CHECK("mh_exp_fwd");
+    return MH_OK;
+}
+extern "C" int mh_exp_bwd(const float* dy, const float* y, float* dx, int64_t n, int accumulate, mh_stream s) {
+    if (n == 0) return MH_OK;
+    hipLaunchKernelGGL(exp_bwd_kernel, EW_GRID(n), dim3(256), 0, (hipStream_t)s, dy, y, dx, (long)n, accumulate);
+    MH_LAUNCH_CHECK("mh_exp_bwd");
     return MH_OK;
 }
 

@@ -361,7 +361,7 @@ extern "C" int mh_symkl_bwd(const float* w, const float* r, const float* g, floa
 }
 
 // ------------------------------------------------------------------ step glue
-__global__ __launch_bounds__(256) void rownorm_kernel(float* w, int rows, int D, float eps) {
+__global__ __launch_bounds__(256) void rownorm_kernel(float* w, bf16_t* shadow, int rows, int D, float eps) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -369,11 +369,15 @@ __global__ __launch_bounds__(256) void rownorm_kernel(float* w, int rows, int D,
     float s = 0.f;
     for (int c = lane; c < D; c += 64) s += wr[c] * wr[c];
     const float n = fmaxf(sqrtf(wave_sum(s)), eps);
-    for (int c = lane; c < D; c += 64) wr[c] = wr[c] / n;
+    for (int c = lane; c < D; c += 64) {
+        const float v = wr[c] / n;
+        wr[c] = v;
+        if (shadow) shadow[(long)row * D + c] = f2bf(v);      // the bf16 copy the GEMMs read: no cast launch behind this one
+    }
 }
-extern "C" int mh_rownorm_(float* w, int rows, int D, float eps, mh_stream s) {
+extern "C" int mh_rownorm_(float* w, void* shadow_bf16, int rows, int D, float eps, mh_stream s) {
     if (rows == 0) return MH_OK;
-    hipLaunchKernelGGL(rownorm_kernel, dim3(mh_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)s, w, rows, D, eps);
+    hipLaunchKernelGGL(rownorm_kernel, dim3(mh_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)s, w, (bf16_t*)shadow_bf16, rows, D, eps);
     MH_LAUNCH_CHECK("mh_rownorm_");
     return MH_OK;
 }
@@ -392,7 +396,7 @@ extern "C" int mh_clamp_(float* x, int64_t n, float lo, float hi, mh_stream s) {
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, bf16_t* __restrict__ shadow, long n, float lr, float b1,
                                                    float b2, float eps, float bc1, float bc2, float gscale,
-                                                   const float* __restrict__ state) {
+                                                   const float* __restrict__ state, long clamp_i, float clamp_lo, float clamp_hi) {
     if (state) {   // device-resident step state {t, 1 - b1^t, 1 - b2^t, lr, clip}: nothing step-dependent is a launch argument
         bc1 = state[1];
         bc2 = state[2];
@@ -415,6 +419,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
             va[e] = b2 * va[e] + (1.f - b2) * gr * gr;
             pa[e] -= step * ma[e] / (sqrtf(va[e]) * isq + eps);
         }
+        // one element (logit_scale, train_mirror.py:1255) is clamped right behind its update: master and shadow get the clamped value
+        if ((clamp_i >> 2) == q && clamp_i >= 0) pa[clamp_i & 3] = fminf(fmaxf(pa[clamp_i & 3], clamp_lo), clamp_hi);
         reinterpret_cast<float4*>(p)[q] = pp;
         reinterpret_cast<float4*>(m)[q] = mm;
         reinterpret_cast<float4*>(v)[q] = vv;
@@ -430,14 +436,18 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         const float gr = g[i] * gscale;
         m[i] = b1 * m[i] + (1.f - b1) * gr;
         v[i] = b2 * v[i] + (1.f - b2) * gr * gr;
-        p[i] -= step * m[i] / (sqrtf(v[i]) * isq + eps);
-        if (shadow) shadow[i] = f2bf(p[i]);
+        float pn = p[i] - step * m[i] / (sqrtf(v[i]) * isq + eps);
+        if (i == clamp_i) pn = fminf(fmaxf(pn, clamp_lo), clamp_hi);
+        p[i] = pn;
+        if (shadow) shadow[i] = f2bf(pn);
     }
 }
 
 // state = {t, 1 - b1^t, 1 - b2^t, lr, clip, |g|}: t += 1 and the bias corrections are refreshed on the device, so a
 // captured HIP graph of the whole step replays with the right Adam step every time
-__global__ void adam_tick_kernel(float* state, float b1, float b2) {
+__global__ void adam_tick_kernel(float* state, float b1, float b2, long long* counter, long long counter_add) {
+    if (counter) *counter += counter_add;      // the dropout streams' device-side base (functional.dropout_step_end) rides along
+    if (!state) return;
     const float t = state[0] + 1.f;
     state[0] = t;
     state[1] = 1.f - powf(b1, t);
@@ -475,12 +485,16 @@ extern "C" int mh_grad_clip(const float* g, int64_t n, float grad_scale, float m
 }
 
 extern "C" int mh_adam(float* p, const float* g, float* m, float* v, void* shadow, int64_t n, float lr, float b1, float b2,
-                       float eps, float bc1, float bc2, float gscale, float* dev_state, mh_stream s) {
+                       float eps, float bc1, float bc2, float gscale, float* dev_state, int64_t clamp_index, float clamp_lo,
+                       float clamp_hi, int64_t* counter, int64_t counter_add, mh_stream s) {
     if (n == 0) return MH_OK;
     MH_REQUIRE(((uintptr_t)p & 15) == 0 && ((uintptr_t)g & 15) == 0 && ((uintptr_t)m & 15) == 0 && ((uintptr_t)v & 15) == 0 &&
                    ((uintptr_t)shadow & 7) == 0, "mh_adam: buffers must be 16-byte aligned");
-    if (dev_state) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, dev_state, b1, b2);
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)min((long)mh_cdiv(mh_cdiv(n, 4), 256), 8192L)), dim3(256), 0, (hipStream_t)s, p, g, m, v, (bf16_t*)shadow, (long)n, lr, b1, b2, eps, bc1, bc2, gscale, (const float*)dev_state);
+    MH_REQUIRE(clamp_index < n, "mh_adam: clamp_index %ld outside the %ld parameters", (long)clamp_index, (long)n);
+    if (dev_state || counter)
+        hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, dev_state, b1, b2, (long long*)counter, (long long)counter_add);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)min((long)mh_cdiv(mh_cdiv(n, 4), 256), 8192L)), dim3(256), 0, (hipStream_t)s, p, g, m, v, (bf16_t*)shadow, (long)n, lr, b1, b2, eps, bc1, bc2, gscale, (const float*)dev_state,
+                       clamp_index < 0 ? -1L : (long)clamp_index, clamp_lo, clamp_hi);
     MH_LAUNCH_CHECK("mh_adam");
     return MH_OK;
 }

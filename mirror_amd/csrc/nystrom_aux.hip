@@ -607,10 +607,12 @@ __global__ void pinv_max_bwd_kernel(const float* __restrict__ x, const unsigned 
 }
 
 extern "C" int mh_pinv_z0_bwd(const float* x, const float* z0, const float* dz0, const uint64_t* stats64, float* dx,
-                              float* scratch1, int BH, int m, mh_stream s) {
+                              float* scratch1, int scratch_zeroed, int BH, int m, mh_stream s) {
     if (BH == 0) return MH_OK;
-    hipError_t e = hipMemsetAsync(scratch1, 0, sizeof(float), (hipStream_t)s);
-    if (e != hipSuccess) { mh_set_error("mh_pinv_z0_bwd: memset failed"); return MH_EHIP; }
+    if (!scratch_zeroed) {      // a caller that carves scratch1 from a buffer it clears once per step saves this memset node
+        hipError_t e = hipMemsetAsync(scratch1, 0, sizeof(float), (hipStream_t)s);
+        if (e != hipSuccess) { mh_set_error("mh_pinv_z0_bwd: memset failed"); return MH_EHIP; }
+    }
     MH_REQUIRE(z0 || (m % 64 == 0 && (((uintptr_t)x | (uintptr_t)dz0 | (uintptr_t)dx) & 15) == 0), "mh_pinv_z0_bwd: z0 == NULL needs m %% 64 == 0 and aligned buffers");
     if (m % 64 == 0 && (((uintptr_t)z0 | (uintptr_t)dz0 | (uintptr_t)dx | (uintptr_t)x) & 15) == 0) {
         hipLaunchKernelGGL(pinv_z0_bwd_vec_kernel, dim3(m / 64, m / 64, BH), dim3(256), 0, (hipStream_t)s, z0, dz0,
@@ -702,14 +704,16 @@ __global__ __launch_bounds__(256) void pinv_s2_colfix_kernel(const float* __rest
     *reinterpret_cast<zf4*>(dx + off) = d;
 }
 
-extern "C" int mh_pinv_s2_bwd(const float* p, const float* dz0, const uint64_t* stats64, float* dx, float* scratch1, int BH, int m,
-                              mh_stream s) {
+extern "C" int mh_pinv_s2_bwd(const float* p, const float* dz0, const uint64_t* stats64, float* dx, float* scratch1,
+                              int scratch_zeroed, int BH, int m, mh_stream s) {
     MH_REQUIRE(m == 256, "mh_pinv_s2_bwd: built for m = 256 (m=%d): compose mh_pinv_z0_bwd + mh_softmax_bwd", m);
     MH_REQUIRE(p && dz0 && stats64 && dx && scratch1 && (((uintptr_t)p | (uintptr_t)dz0 | (uintptr_t)dx) & 15) == 0,
                "mh_pinv_s2_bwd: null / unaligned buffer");
     if (BH == 0) return MH_OK;
-    hipError_t e = hipMemsetAsync(scratch1, 0, sizeof(float), (hipStream_t)s);
-    if (e != hipSuccess) { mh_set_error("mh_pinv_s2_bwd: memset failed"); return MH_EHIP; }
+    if (!scratch_zeroed) {
+        hipError_t e = hipMemsetAsync(scratch1, 0, sizeof(float), (hipStream_t)s);
+        if (e != hipSuccess) { mh_set_error("mh_pinv_s2_bwd: memset failed"); return MH_EHIP; }
+    }
     hipLaunchKernelGGL(pinv_s2_bwd_kernel, dim3(256 / S2_ROWS, BH), dim3(256), 0, (hipStream_t)s, p, dz0, (const unsigned long long*)stats64, dx,
                        scratch1);
     hipLaunchKernelGGL(pinv_s2_colfix_kernel, dim3(64), dim3(256), 0, (hipStream_t)s, p, (const unsigned long long*)stats64, scratch1, dx);

@@ -26,8 +26,8 @@ template <> __device__ __forceinline__ sk_bf16x8 sk_load8<float>(const float* p)
 
 template <typename TX, typename TY, int MT>   // MT = number of 16-row tiles of x (1 or 2)
 __global__ __launch_bounds__(256) void skinny_fwd_kernel(const TX* __restrict__ x, long ldx, const bf16_t* __restrict__ w,
-                                                         long ldw, const float* __restrict__ bias, TY* __restrict__ y, long ldy,
-                                                         int M, int N, int K, int act) {
+                                                         long ldw, const float* __restrict__ bias, const float* __restrict__ addend,
+                                                         long ldadd, TY* __restrict__ y, long ldy, int M, int N, int K, int act) {
     __shared__ float red[4][MT][16][17];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n0 = blockIdx.x * 16;
@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const TX* __restrict__ 
         if (m < M && n < N) {
             float v = red[0][t][rr][cc] + red[1][t][rr][cc] + red[2][t][rr][cc] + red[3][t][rr][cc];
             if (bias) v += bias[n];
+            if (addend) v += addend[(long)m * ldadd + n];      // a data gradient that sums what another consumer of x already produced
             if (act == MH_ACT_RELU) v = fmaxf(v, 0.f);
             else if (act == MH_ACT_GELU) v = gelu_f(v);
             stf(y + (long)m * ldy + n, v);
@@ -70,14 +71,14 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const TX* __restrict__ 
     }
 }
 
-extern "C" int mh_skinny_fwd(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, void* y, int64_t ldy,
-                             int M, int N, int K, int act, int dt_x, int dt_y, mh_stream s) {
+extern "C" int mh_skinny_fwd(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, const float* addend,
+                             int64_t ldadd, void* y, int64_t ldy, int M, int N, int K, int act, int dt_x, int dt_y, mh_stream s) {
     MH_REQUIRE(M >= 1 && M <= 32, "mh_skinny_fwd: M=%d (needs 1..32)", M);
     MH_REQUIRE(K % 32 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0,
                "mh_skinny_fwd: K %% 32 == 0 and 16-byte aligned rows required (K=%d ldx=%ld ldw=%ld)", K, (long)ldx, (long)ldw);
     if (N == 0) return MH_OK;
     dim3 grid(mh_cdiv(N, 16));
-#define SKF(TX, TY, MT) hipLaunchKernelGGL((skinny_fwd_kernel<TX, TY, MT>), grid, dim3(256), 0, (hipStream_t)s, (const TX*)x, (long)ldx, (const bf16_t*)w, (long)ldw, bias, (TY*)y, (long)ldy, M, N, K, act)
+#define SKF(TX, TY, MT) hipLaunchKernelGGL((skinny_fwd_kernel<TX, TY, MT>), grid, dim3(256), 0, (hipStream_t)s, (const TX*)x, (long)ldx, (const bf16_t*)w, (long)ldw, bias, addend, (long)ldadd, (TY*)y, (long)ldy, M, N, K, act)
 #define SKF2(TX) do { if (dt_y == MH_F32) { if (M <= 16) SKF(TX, float, 1); else SKF(TX, float, 2); } else { if (M <= 16) SKF(TX, bf16_t, 1); else SKF(TX, bf16_t, 2); } } while (0)
     if (dt_x == MH_F32) SKF2(float); else SKF2(bf16_t);
 #undef SKF2

@@ -411,9 +411,7 @@ class TrainEngine:
         def renorm_prototypes():
             if self._proto is not None:
                 w = self._proto.weight
-                K.rownorm_(w.data)
-                if self.shadow is not None:
-                    K.cast(w.data, bf16, out=Fn.shadow(w, POLICIES[self.precision]))
+                K.rownorm_(w.data, shadow=Fn.shadow(w, POLICIES[self.precision]) if self.shadow is not None else None)
         renorm_prototypes()
         t_done = None
         if _TRANSPOSE_AT_START:
@@ -486,14 +484,21 @@ class TrainEngine:
         elif self.clip_grad is not None:
             K.grad_clip(self.grad, gs, float(self.clip_grad), self._state)
         Fn.probe("adam_start")
+        # step glue that rides on Adam's two launches instead of three of its own: the logit_scale clamp behind the update
+        # (train_mirror.py:1255; master and shadow) and the dropout streams' device-side base (functional.dropout_step_end)
+        clamp = None
+        if self._logit is not None and self._logit.requires_grad:
+            clamp = (self.offsets[self._index_of[id(self._logit)]], 0.0, math.log(100.0))
+        base, used = Fn.dropout_step_take()
         K.adam(self.master, self.grad, self.m, self.v, self.shadow, self.lr, b1, b2, self.eps, 1.0, 1.0,
                grad_scale=gs,                  # the DDP / accumulation average is folded into Adam
-               dev_state=self._state)          # t, bias corrections, lr and the clip factor live on the device
+               dev_state=self._state,          # t, bias corrections, lr and the clip factor live on the device
+               clamp=clamp, counter=base, counter_add=used)
         if _TRANSPOSE_AT_START:
             self._t_stale = self.shadow_t is not None
         else:
             self._refresh_transposes()
-        if self._logit is not None:
+        if self._logit is not None and clamp is None:          # a frozen logit_scale is not in the arena
             K.clamp_(self._logit.data.reshape(1), 0.0, math.log(100.0))
             if self.shadow is not None:
                 K.cast(self._logit.data.reshape(1), bf16, out=Fn.shadow(self._logit, POLICIES[self.precision]).reshape(1))
@@ -501,14 +506,19 @@ class TrainEngine:
             self._zero_pending = True        # cleared by the next step, beside its forward (nobody reads the arena in between)
         else:
             self.grad.zero_()
-        Fn.dropout_step_end()
         return self._loss_out(losses)
 
     @staticmethod
     def _loss_out(losses):
         """The six scalars as views of ONE freshly allocated tensor: some loss terms are slices of the step's zero arena,
-        which the next step's memset clears — a caller that keeps them (deferred logging) must not read zeros later."""
-        return tuple(torch.stack([x.detach().reshape(()).float() for x in losses]).unbind(0))
+        which the next step's memset clears — a caller that keeps them (deferred logging) must not read zeros later.
+        MirrorLossTermsFn already hands them over that way (six f32 views of its own 8-float result): no copy then."""
+        ls = [x.detach() for x in losses]
+        st = ls[0].untyped_storage()
+        if (all(x.dtype == f32 and x.dim() == 0 and x.untyped_storage().data_ptr() == st.data_ptr() for x in ls)
+                and st.nbytes() <= 64):
+            return tuple(ls)
+        return tuple(torch.stack([x.reshape(()).float() for x in ls]).unbind(0))
 
     # ------------------------------------------------------------------ validation (train_mirror.py:1382-1526)
     LOSS_NAMES = ("loss", "alignment_loss", "wsi_retention_loss", "rna_retention_loss", "style_loss", "cluster_loss")

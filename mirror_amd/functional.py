@@ -184,6 +184,11 @@ def zeros(shape, device) -> torch.Tensor:
     return torch.zeros(shape, device=device, dtype=f32)
 
 
+def _zeroed1(device):
+    """One zeroed f32 from the step's arena for an entry point that would otherwise memset its scratch itself; None outside a step."""
+    return zeros((1,), device) if _active_arena is not None else None
+
+
 # ------------------------------------------------------------------ gradient sink (TrainEngine's flat grad arena)
 # With a sink installed, weight/bias/LayerNorm gradients are accumulated straight into the arena view of the parameter
 # (no zeros() + autograd "grad += new" pass per parameter) and the Function returns None for them; the sink is told
@@ -201,6 +206,19 @@ def _gbuf(param: torch.Tensor, shape):
     if _sink is not None:
         v = _sink.slot(param)
         if v is not None:
+            return v.view(shape), True
+    return zeros(shape, param.device), False
+
+
+def _gbuf_n(param: torch.Tensor, shape):
+    """_gbuf for a parameter that reaches its Function reshaped (tokens, positional tables): the sink's slot only when it has exactly
+    the elements of `shape` (a slice of a longer table falls back to a buffer of its own, returned through autograd)."""
+    if _sink is not None:
+        v = _sink.slot(param)
+        n = 1
+        for d in shape:
+            n *= int(d)
+        if v is not None and v.numel() == n:
             return v.view(shape), True
     return zeros(shape, param.device), False
 
@@ -572,6 +590,78 @@ def _wgrad(dy: torch.Tensor, x: torch.Tensor, N: int, Kd: int, prec: Precision, 
     return dw
 
 
+def _skinny_param_grads(dy, xa, w, b, need_w, need_b):
+    """(dW, db) of a [B, D]-row Linear as LinearFn.backward forms them: into the gradient sink when there is one, queued for the
+    step's one weight-gradient launch when the engine collects them (both then come back as None)."""
+    N, Kd = w.shape
+    dw = db = None
+    if need_w:
+        dw, sunk = _gbuf(w, (N, Kd))
+        dbuf = sunk_b = None
+        if need_b:
+            dbuf, sunk_b = _gbuf(b, (N,))
+        if _wgrad_queue is not None and sunk and (dbuf is None or sunk_b) and dy.dim() == 2:
+            _wgrad_queue.append((dy, xa, dw, dbuf, w, b if need_b else None, torch.cuda.current_stream()))
+            return None, None
+        K.skinny_wgrad(dy, xa, dw, accumulate=True, db=dbuf)
+        if need_b:
+            db = _gret(b, dbuf, sunk_b)
+        dw = _gret(w, dw, sunk)
+    elif need_b:
+        db, sunk = _gbuf(b, (N,))
+        K.colsum(dy.reshape(-1, N), db)
+        db = _gret(b, db, sunk)
+    return dw, db
+
+
+class LinearPairFn(Function):
+    """(x @ W1^T + b1, x @ W2^T + b2) for [B, D] rows: style_mu and style_logstd read the same hidden vector
+    (models/mirror.py:845-857).  As ONE node x has a single consumer: its data gradient is the second launch's result with the
+    first one's as the addend, where two LinearFn nodes leave autograd an add launch."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, prec, out_dtype):
+        ctx.set_materialize_grads(False)
+        wa1, wa2 = shadow(w1, prec), shadow(w2, prec)
+        od = out_dtype or prec.act
+        y1 = K.skinny_fwd(x, wa1, None if b1 is None else b1.detach(), ACT_NONE, od)
+        y2 = K.skinny_fwd(x, wa2, None if b2 is None else b2.detach(), ACT_NONE, od)
+        ctx.save_for_backward(x, w1, b1, w2, b2)
+        ctx.prec = prec
+        return y1, y2
+
+    @staticmethod
+    def backward(ctx, dy1, dy2):
+        x, w1, b1, w2, b2 = ctx.saved_tensors
+        prec = ctx.prec
+        dx, part = None, None
+        grads = []
+        for k, (dy, w, b) in enumerate(((dy1, w1, b1), (dy2, w2, b2))):
+            if dy is None:
+                grads += [None, None]
+                continue
+            dy = dy.contiguous()
+            if dy.dtype not in (f32, bf16) or (dy.dtype == f32 and not _SKINNY_F32):
+                dy = K.cast(dy, prec.act)
+            if ctx.needs_input_grad[0]:
+                last = k == 1 or dy2 is None
+                part = K.skinny_fwd(dy, shadow_t(w, prec), None, ACT_NONE, x.dtype if last else f32, addend=part)
+                if last:
+                    dx = part
+            grads += list(_skinny_param_grads(dy, x, w, b, ctx.needs_input_grad[1 + 2 * k], b is not None and ctx.needs_input_grad[2 + 2 * k]))
+        return (dx, *grads, None, None)
+
+
+def linear_pair(x, w1, b1, w2, b2, *, prec: Precision, out_dtype=None):
+    """(linear(x, w1, b1), linear(x, w2, b2)); one autograd node on the [B, D]-row kernels, two plain linears otherwise."""
+    if (prec.act == bf16 and not prec.fp8_fwd and x.is_cuda and x.dim() == 2 and w1.shape == w2.shape and w1.shape[0] % 32 == 0
+            and (x.dtype == bf16 or (x.dtype == f32 and _SKINNY_F32))):
+        wa1, wa2 = shadow(w1, prec), shadow(w2, prec)
+        if K.skinny_ok(x, wa1) and K.skinny_ok(x, wa2):
+            return LinearPairFn.apply(x, w1, b1, w2, b2, prec, out_dtype)
+    return linear(x, w1, b1, prec=prec, out_dtype=out_dtype), linear(x, w2, b2, prec=prec, out_dtype=out_dtype)
+
+
 def linear(x, w, b=None, *, act=ACT_NONE, prec: Precision, out_dtype=None, defer_from=None):
     """defer_from = c: only output columns [0, c) are computed here; the rest is a pending launch that the consumer runs
     with run_deferred(y) (NystromCoreFn does, right after it has forked the pinv chain)."""
@@ -816,6 +906,7 @@ class EmbedMaskPosFn(Function):
             raise K.MirrorHipError("EmbedMaskPosFn: the tail rows cross the unmasked prefix")
         ctx.save_for_backward(h, wa, w, b, mask)
         ctx.geom = (Bn, T, N, first, token.shape, pos.shape, prec)
+        ctx.params = (token, pos)
         return out
 
     @staticmethod
@@ -824,13 +915,16 @@ class EmbedMaskPosFn(Function):
         Bn, T, N, first, tshape, pshape, prec = ctx.geom
         dy = dy.contiguous()
         dr = torch.empty(dy.shape, device=dy.device, dtype=prec.act)          # gradient of the projection output (zero at masked rows)
-        dtok = zeros((N,), dy.device)
-        dpos = zeros((T * N,), dy.device)
+        token, pos = ctx.params
+        dtok, s_tok = _gbuf_n(token, (N,))          # the kernel accumulates into both: straight into the gradient arena
+        dpos, s_pos = _gbuf_n(pos, (T * N,))
         K.mask_apply_bwd(dy, mask, dtok, dpos, Bn, T, N, first, False, out=dr)
+        dtok, dpos = _gret(token, dtok, s_tok), _gret(pos, dpos, s_pos)
         # f32 data gradient: EncFanoutFn sums it with the target / cls gradients in one pass (mh_fanout_bwd reads f32)
         needs = (ctx.needs_input_grad[0], ctx.needs_input_grad[2], ctx.needs_input_grad[3])
         dh, dw, db = _linear_rows_bwd(needs, h, wa, w, b, 0, T, prec, dr, dx_dtype=f32)
-        return dh, None, dw, db, None, dtok.reshape(tshape), dpos.reshape(pshape), None, None
+        return (dh, None, dw, db, None, None if dtok is None else dtok.reshape(tshape), None if dpos is None else dpos.reshape(pshape),
+                None, None)
 
 
 def embed_mask_pos(h, w, b, mask, token, pos, first: int, prec: Precision):
@@ -1153,6 +1247,14 @@ def dropout_step_end() -> None:
     _dropout_state["offset"] = 0
 
 
+def dropout_step_take():
+    """dropout_step_end for a caller that advances the device base inside a launch of its own (mh_adam's `counter`): returns
+    (base tensor or None, offsets this step consumed) and resets the host offset."""
+    base, used = _dropout_state["base"], _dropout_state["offset"]
+    _dropout_state["offset"] = 0
+    return (base, used) if (base is not None and used) else (None, 0)
+
+
 def dropout_device_base_off() -> None:
     _dropout_state["base"] = None
 
@@ -1262,7 +1364,7 @@ class Fc1SeqFn(Function):
             K.gemm(xa, wa.t(), out=seq[:, 1:1 + N], bias=b.detach(), act=ACT_RELU, mma=prec.mma)
         K.seq_finish(seq, cls.detach().reshape(-1).contiguous(), N, add_len)
         ctx.save_for_backward(xa, wa, seq, w, b)
-        ctx.add_len, ctx.prec = add_len, prec
+        ctx.add_len, ctx.prec, ctx.cls = add_len, prec, cls
         return seq
 
     @staticmethod
@@ -1274,8 +1376,9 @@ class Fc1SeqFn(Function):
         dseq = dseq.contiguous()
         if add_len:
             dseq = dseq.clone()  # the fold below is in place; autograd owns the incoming buffer
-        dcls = zeros((D,), dseq.device)
+        dcls, sunk_c = _gbuf_n(ctx.cls, (D,))
         K.seq_finish_bwd(dseq, dcls, N, add_len)
+        dcls = _gret(ctx.cls, dcls, sunk_c)
         dh = K.relu_bwd(seq[:, 1:1 + N], dseq[:, 1:1 + N], out_dtype=prec.act)   # [B,N,D] contiguous
         dw, sunk_w = _gbuf(w, (D, Fd))
         K.gemm(dh.reshape(Bn * N, D).t(), xa.reshape(Bn * N, Fd), out=dw, accumulate=True,
@@ -1287,7 +1390,7 @@ class Fc1SeqFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = K.gemm(dh, wa, mma=prec.mma, out_dtype=f32)
-        return dx, dw, db, dcls.reshape(1, 1, D), None, None
+        return dx, dw, db, None if dcls is None else dcls.reshape(1, 1, D), None, None
 
 
 _PPEG_SCATTER = True      # (test hook)
@@ -1692,9 +1795,9 @@ class NystromCoreFn(Function):
             with torch.cuda.stream(side):
                 K.pinv_chain_bwd(xb, chain_saved, dzb, work, dS2, dz0, iters)
                 if _S2_TAIL and kmask is None and not ctx.z0_stored and a2.shape[-1] == 256:
-                    K.pinv_s2_bwd(a2, dz0, st, dS2)      # z_0 backward, the maxima's sub-gradients and attn2's softmax backward: one pass
+                    K.pinv_s2_bwd(a2, dz0, st, dS2, _zeroed1(a2.device))      # z_0 backward, the maxima's sub-gradients and attn2's softmax backward: one pass
                 else:
-                    K.pinv_z0_bwd(a2, z0 if ctx.z0_stored else None, dz0, st, dS2)
+                    K.pinv_z0_bwd(a2, z0 if ctx.z0_stored else None, dz0, st, dS2, _zeroed1(a2.device))
                     sm_bwd(a2, dS2, mlm if kmask else None, mlm if kmask else None)
                 if dlm2 is not None:
                     K.gemm(tr(dS2), ql, out=_heads(dlm2, 1, 2, h), alpha=scale, mma=pio)
@@ -1843,6 +1946,7 @@ class MaskApplyFn(Function):
                          Bn, T, D, first, token_scalar, out=y)
         ctx.save_for_backward(mask)
         ctx.geom = (Bn, T, D, first, token_scalar, token.shape, pos.shape, x.dtype)
+        ctx.params = (token, pos)
         return y
 
     @staticmethod
@@ -1851,10 +1955,12 @@ class MaskApplyFn(Function):
         Bn, T, D, first, token_scalar, tshape, pshape, xdt = ctx.geom
         dy = dy.contiguous()
         dx = torch.empty(dy.shape, device=dy.device, dtype=xdt)
-        dtok = zeros((1 if token_scalar else D,), dy.device)
-        dpos = zeros((T * D,), dy.device)
+        token, pos = ctx.params
+        dtok, s_tok = _gbuf_n(token, (1 if token_scalar else D,))
+        dpos, s_pos = _gbuf_n(pos, (T * D,))
         K.mask_apply_bwd(dy, mask, dtok, dpos, Bn, T, D, first, token_scalar, out=dx)
-        return dx, None, dtok.reshape(tshape), dpos.reshape(pshape), None, None
+        dtok, dpos = _gret(token, dtok, s_tok), _gret(pos, dpos, s_pos)
+        return dx, None, None if dtok is None else dtok.reshape(tshape), None if dpos is None else dpos.reshape(pshape), None, None
 
 
 # ------------------------------------------------------------------ encoder-output fan-out
@@ -1915,25 +2021,32 @@ class L2NormRowFn(Function):
 
     @staticmethod
     def forward(ctx, x, eps, out_dtype):
-        x = x.contiguous()
-        if x.dim() == 3:
-            Bn, T, D = x.shape
-            rs = T * D
+        if x.dim() == 2 and x.stride(1) == 1 and x.stride(0) >= x.shape[1]:
+            (Bn, D), rs = x.shape, x.stride(0)      # rows of a larger buffer (the cls row of every slide): read in place
         else:
-            (Bn, D), rs = x.shape, x.shape[1]
+            x = x.contiguous()
+            if x.dim() == 3:
+                Bn, T, D = x.shape
+                rs = T * D
+            else:
+                (Bn, D), rs = x.shape, x.shape[1]
         y, nrm = K.l2norm_fwd(x, Bn, D, rs, eps, out_dtype)
         ctx.save_for_backward(y, nrm)
-        ctx.geom = (tuple(x.shape), rs, x.dtype)
+        ctx.geom = (tuple(x.shape), x.dtype)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         y, nrm = ctx.saved_tensors
-        shape, rs, xdt = ctx.geom
+        shape, xdt = ctx.geom
         dy = dy.contiguous()
         if dy.dtype != y.dtype:
             dy = K.cast(dy, y.dtype)
-        dx = torch.zeros(shape, device=dy.device, dtype=xdt)
+        if len(shape) == 2:          # every row is written: no fill
+            dx, rs = torch.empty(shape, device=dy.device, dtype=xdt), shape[1]
+        else:
+            dx = zeros(shape, dy.device) if xdt == f32 else torch.zeros(shape, device=dy.device, dtype=xdt)
+            rs = shape[1] * shape[2]
         K.l2norm_bwd(y, nrm, dy, dx, shape[0], shape[-1], rs, accumulate=False)
         return dx, None, None
 
@@ -2039,17 +2152,48 @@ def rna_block(x, blk, prec: Precision, training: bool):
                             a.num_heads, float(blk.norm1.eps), p, prec)
 
 
-class ReparamFn(Function):
-    @staticmethod
-    def forward(ctx, mu, logstd, eps):
-        mu, logstd, eps = mu.contiguous(), logstd.contiguous(), eps.contiguous()
-        ctx.save_for_backward(logstd, eps)
-        return K.reparam_fwd(mu, logstd, eps)
+class ExpFn(Function):
+    """x.exp() for a small f32 parameter (`logit_scale.exp()`, models/mirror.py:911): one launch each way, the gradient summed
+    straight into the parameter's arena slot (torch's exp costs a mul in the backward and an add in AccumulateGrad)."""
 
     @staticmethod
-    def backward(ctx, dz):
+    def forward(ctx, x):
+        y = K.exp_fwd(x.detach().contiguous())
+        ctx.save_for_backward(y)
+        ctx.x = x
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dx, sunk = _gbuf_n(ctx.x, tuple(y.shape))
+        K.exp_bwd(dy.contiguous().float(), y, dx, accumulate=True)      # _gbuf_n's own buffer starts at zero
+        return _gret(ctx.x, dx, sunk)
+
+
+def exp(x: torch.Tensor) -> torch.Tensor:
+    return ExpFn.apply(x) if (x.is_cuda and x.dtype == f32) else x.exp()
+
+
+class ReparamFn(Function):
+    """z = mu + eps * exp(0.5 * logstd) (models/mirror.py:830-833).  Returns (z, mu, logstd): the caller hands THESE mu / logstd on
+    (to the KL term), so what comes back for them arrives at this node and is summed inside its one backward launch — mu and logstd
+    keep a single consumer and autograd has no `grad += grad` launch to add (two per call)."""
+
+    @staticmethod
+    def forward(ctx, mu, logstd, eps):
+        ctx.set_materialize_grads(False)
+        mu_c, ls_c, eps = mu.contiguous(), logstd.contiguous(), eps.contiguous()
+        ctx.save_for_backward(ls_c, eps)
+        return K.reparam_fwd(mu_c, ls_c, eps), mu, logstd
+
+    @staticmethod
+    def backward(ctx, dz, dmu_o, dls_o):
         logstd, eps = ctx.saved_tensors
-        dmu, dls = K.reparam_bwd(logstd, eps, dz.contiguous())
+        if dz is None:
+            return dmu_o, dls_o, None
+        f = lambda g: None if g is None else (g if g.dtype == f32 else g.float()).contiguous()
+        dmu, dls = K.reparam_bwd(logstd, eps, dz.contiguous(), f(dmu_o), f(dls_o))
         return dmu, dls, None
 
 

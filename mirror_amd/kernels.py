@@ -488,16 +488,20 @@ def skinny_ok(x2d: torch.Tensor, w: torch.Tensor) -> bool:
             and (x2d.stride(1) == 1) and x2d.stride(0) % 8 == 0 and x2d.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0)
 
 
-def skinny_fwd(x2d: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act: int, out_dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out: optional [M, N] destination rows (any row stride that keeps rows 16-byte aligned, e.g. rows of a larger buffer)."""
-    _chk(x2d, w, bias, out)
+def skinny_fwd(x2d: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act: int, out_dtype, out: Optional[torch.Tensor] = None,
+               addend: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out: optional [M, N] destination rows (any row stride that keeps rows 16-byte aligned, e.g. rows of a larger buffer);
+    addend: optional f32 [M, N] summed in front of the activation (two data gradients of one x in two launches, no add)."""
+    _chk(x2d, w, bias, out, addend)
+    if addend is not None and (addend.dtype != torch.float32 or tuple(addend.shape) != (x2d.shape[0], w.shape[0]) or addend.stride(1) != 1):
+        raise MirrorHipError("skinny_fwd: the addend is f32 [M, N] with unit inner stride")
     M, Kd = x2d.shape
     N = w.shape[0]
     y = torch.empty((M, N), device=x2d.device, dtype=out_dtype) if out is None else out
     if tuple(y.shape) != (M, N) or y.stride(1) != 1 or x2d.stride(1) != 1 or w.stride(1) != 1:
         raise MirrorHipError("skinny_fwd: bad operands")
-    _lib.call("mh_skinny_fwd", _p(x2d), x2d.stride(0), _p(w), w.stride(0), _p(bias), _p(y), y.stride(0), M, N, Kd, act, dt(x2d), dt(y),
-              stream=_stream())
+    _lib.call("mh_skinny_fwd", _p(x2d), x2d.stride(0), _p(w), w.stride(0), _p(bias), _p(addend), 0 if addend is None else addend.stride(0),
+              _p(y), y.stride(0), M, N, Kd, act, dt(x2d), dt(y), stream=_stream())
     return y
 
 
@@ -765,24 +769,34 @@ def pinv_z0(x: torch.Tensor, stats: torch.Tensor) -> torch.Tensor:
     return z0
 
 
-def pinv_z0_bwd(x, z0, dz0, stats, dx) -> None:
+def _scratch1(scratch, like):
+    """(one-float scratch, zeroed flag): a caller-provided f32[1] that already holds 0 (a slice of the step's zero arena), else a
+    fresh one the entry point clears itself."""
+    if scratch is None:
+        return torch.empty(1, device=like.device, dtype=torch.float32), 0
+    if scratch.dtype != torch.float32 or scratch.numel() != 1 or scratch.device != like.device:
+        raise MirrorHipError("scratch: one f32 on the operands' device")
+    return scratch, 1
+
+
+def pinv_z0_bwd(x, z0, dz0, stats, dx, zeroed_scratch=None) -> None:
     """z0 None: formed on the fly from x and the maxima (nys_sim2 path: no stored f32 z_0)."""
-    _chk(x, z0, dz0, stats, dx)
+    _chk(x, z0, dz0, stats, dx, zeroed_scratch)
     m = x.shape[-1]
-    scratch = torch.empty(1, device=x.device, dtype=torch.float32)
-    _lib.call("mh_pinv_z0_bwd", _p(x), _p(z0), _p(_contig(dz0, "dz0")), _p(stats), _p(dx), _p(scratch),
+    scratch, zf = _scratch1(zeroed_scratch, x)
+    _lib.call("mh_pinv_z0_bwd", _p(x), _p(z0), _p(_contig(dz0, "dz0")), _p(stats), _p(dx), _p(scratch), zf,
               x.numel() // (m * m), m, stream=_stream())
 
 
-def pinv_s2_bwd(p, dz0, stats, dx) -> None:
+def pinv_s2_bwd(p, dz0, stats, dx, zeroed_scratch=None) -> None:
     """dx (the chain's gradient wrt attn2 on entry) -> gradient wrt sim2's logits, one pass (mh_pinv_s2_bwd: m = 256, no mask)."""
-    _chk(p, dz0, stats, dx)
+    _chk(p, dz0, stats, dx, zeroed_scratch)
     m = p.shape[-1]
     if not (p.dtype == dz0.dtype == dx.dtype == torch.float32 and p.is_contiguous() and dz0.is_contiguous() and dx.is_contiguous()
             and p.shape == dz0.shape == dx.shape and p.shape[-2] == m):
         raise MirrorHipError("pinv_s2_bwd: contiguous f32 [.., m, m] tensors of one shape")
-    scratch = torch.empty(1, device=p.device, dtype=torch.float32)
-    _lib.call("mh_pinv_s2_bwd", _p(p), _p(dz0), _p(stats), _p(dx), _p(scratch), p.numel() // (m * m), m, stream=_stream())
+    scratch, zf = _scratch1(zeroed_scratch, p)
+    _lib.call("mh_pinv_s2_bwd", _p(p), _p(dz0), _p(stats), _p(dx), _p(scratch), zf, p.numel() // (m * m), m, stream=_stream())
 
 
 PINV_CHAIN_M = 256
@@ -1394,6 +1408,22 @@ def colsum(x2d: torch.Tensor, out: torch.Tensor) -> None:
     _lib.call("mh_colsum", _p(x2d), _p(out), rows, cols, x2d.stride(0) if rows > 1 else cols, dt(x2d), stream=_stream())
 
 
+def exp_fwd(x: torch.Tensor) -> torch.Tensor:
+    _chk(x)
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise MirrorHipError("exp_fwd: contiguous f32")
+    y = torch.empty_like(x)
+    _lib.call("mh_exp_fwd", _p(x), _p(y), x.numel(), stream=_stream())
+    return y
+
+
+def exp_bwd(dy: torch.Tensor, y: torch.Tensor, dx: torch.Tensor, accumulate: bool) -> None:
+    _chk(dy, y, dx)
+    if not all(t.dtype == torch.float32 and t.is_contiguous() and t.numel() == y.numel() for t in (dy, y, dx)):
+        raise MirrorHipError("exp_bwd: contiguous f32 tensors of one size")
+    _lib.call("mh_exp_bwd", _p(dy), _p(y), _p(dx), y.numel(), int(accumulate), stream=_stream())
+
+
 def reparam_fwd(mu, logstd, eps) -> torch.Tensor:
     _chk(mu, logstd, eps)
     z = torch.empty_like(mu)
@@ -1402,10 +1432,15 @@ def reparam_fwd(mu, logstd, eps) -> torch.Tensor:
     return z
 
 
-def reparam_bwd(logstd, eps, dz):
-    _chk(logstd, eps, dz)
+def reparam_bwd(logstd, eps, dz, add_mu=None, add_ls=None):
+    """(dmu, dlogstd) of z = mu + eps * exp(0.5 * logstd); add_mu / add_ls: gradients of mu / logstd from elsewhere, summed in."""
+    _chk(logstd, eps, dz, add_mu, add_ls)
+    for a in (add_mu, add_ls):
+        if a is not None and (a.dtype != torch.float32 or not a.is_contiguous() or a.numel() != logstd.numel()):
+            raise MirrorHipError("reparam_bwd: bad addend")
     dmu, dls = torch.empty_like(logstd), torch.empty_like(logstd)
-    _lib.call("mh_reparam_bwd", _p(logstd), _p(eps), _p(_contig(dz, "dz")), _p(dmu), _p(dls), logstd.numel(), stream=_stream())
+    _lib.call("mh_reparam_bwd", _p(logstd), _p(eps), _p(_contig(dz, "dz")), _p(add_mu), _p(add_ls), _p(dmu), _p(dls), logstd.numel(),
+              stream=_stream())
     return dmu, dls
 
 
@@ -1562,10 +1597,13 @@ def symkl_bwd(w, r, g, coef):
     return dw, dr
 
 
-def rownorm_(w: torch.Tensor, eps: float = 1e-12) -> None:
-    _chk(w)
+def rownorm_(w: torch.Tensor, eps: float = 1e-12, shadow: Optional[torch.Tensor] = None) -> None:
+    """shadow: optional bf16 tensor of w's shape that receives the rounded result in the same launch."""
+    _chk(w, shadow)
     assert w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 2
-    _lib.call("mh_rownorm_", _p(w), w.shape[0], w.shape[1], eps, stream=_stream())
+    if shadow is not None and (shadow.dtype != torch.bfloat16 or not shadow.is_contiguous() or tuple(shadow.shape) != tuple(w.shape)):
+        raise MirrorHipError("rownorm_: the shadow is a contiguous bf16 tensor of w's shape")
+    _lib.call("mh_rownorm_", _p(w), _p(shadow), w.shape[0], w.shape[1], eps, stream=_stream())
 
 
 def clamp_(x: torch.Tensor, lo: float, hi: float) -> None:
@@ -1582,13 +1620,19 @@ def grad_clip(g: torch.Tensor, grad_scale: float, max_norm: float, dev_state: to
     _lib.call("mh_grad_clip", _p(g), g.numel(), grad_scale, max_norm, _p(scratch), _p(dev_state), stream=_stream())
 
 
-def adam(p, g, m, v, shadow, lr, b1, b2, eps, bc1, bc2, grad_scale=1.0, dev_state: Optional[torch.Tensor] = None) -> None:
+def adam(p, g, m, v, shadow, lr, b1, b2, eps, bc1, bc2, grad_scale=1.0, dev_state: Optional[torch.Tensor] = None,
+         clamp: Optional[tuple] = None, counter: Optional[torch.Tensor] = None, counter_add: int = 0) -> None:
     """dev_state: optional f32[6] device tensor {t, 1-b1^t, 1-b2^t, lr, clip, |g|}; when given the step count / bias
     corrections / lr live on the device (advanced by the launch itself), lr, bc1, bc2 are ignored and the gradient is
-    also scaled by dev_state[4] (the factor grad_clip left there, else 1)."""
-    _chk(p, g, m, v, shadow, dev_state)
+    also scaled by dev_state[4] (the factor grad_clip left there, else 1).  clamp = (index, lo, hi): that one parameter is clamped
+    behind its update (master and shadow); counter (int64[1]) += counter_add in the same launches."""
+    _chk(p, g, m, v, shadow, dev_state, counter)
+    assert counter is None or (counter.dtype == torch.int64 and counter.numel() == 1)
+    ci, clo, chi = (-1, 0.0, 0.0) if clamp is None else (int(clamp[0]), float(clamp[1]), float(clamp[2]))
+    if ci >= p.numel():
+        raise MirrorHipError("adam: clamp index outside the arena")
     for t in (p, g, m, v):
         assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel()
     assert dev_state is None or (dev_state.dtype == torch.float32 and dev_state.numel() == 6 and dev_state.is_contiguous())
     _lib.call("mh_adam", _p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), lr, b1, b2, eps, bc1, bc2, grad_scale,
-              _p(dev_state), stream=_stream())
+              _p(dev_state), ci, clo, chi, _p(counter), int(counter_add), stream=_stream())

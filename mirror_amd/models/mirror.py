@@ -492,13 +492,15 @@ class MIRROR(nn.Module):
     def reparameterize(self, mu, logstd, eps: Optional[torch.Tensor] = None):
         if eps is None:
             eps = torch.randn_like(mu)
-        return Fn.ReparamFn.apply(mu, logstd, eps)
+        return Fn.ReparamFn.apply(mu, logstd, eps)[0]
 
     def _style_branch(self, emb, eps, prec):
         h = self.style_encoder_mlp(emb, prec)
-        mu = Fn.linear(h, self.style_mu.weight, self.style_mu.bias, prec=prec, out_dtype=f32)
-        logstd = Fn.linear(h, self.style_logstd.weight, self.style_logstd.bias, prec=prec, out_dtype=f32)
-        z = self.reparameterize(mu, logstd, eps)
+        mu, logstd = Fn.linear_pair(h, self.style_mu.weight, self.style_mu.bias, self.style_logstd.weight, self.style_logstd.bias,
+                                    prec=prec, out_dtype=f32)      # one node: h's gradient needs no add launch
+        if eps is None:
+            eps = torch.randn_like(mu)
+        z, mu, logstd = Fn.ReparamFn.apply(mu, logstd, eps)      # mu / logstd pass through: their KL gradient comes back to this node
         z = Fn.linear(z, self.style_decoder.weight, self.style_decoder.bias, prec=prec)
         score = Fn.linear(z, self.prototypes.weight, None, prec=prec, out_dtype=f32)
         return score, mu, logstd
@@ -627,7 +629,7 @@ class MIRROR(nn.Module):
         rna_retention_target = rna_emb
         return (wsi_alignment_emb, wsi_retention_emb, wsi_retention_target, wsi_mask, wsi_score, wsi_mu, wsi_logstd,
                 rna_alignment_emb, rna_retention_emb, rna_retention_target, rna_mask, rna_score, rna_mu, rna_logstd,
-                self.logit_scale.exp())
+                Fn.exp(self.logit_scale))
 
 
 _ACCEPTED = {

@@ -828,6 +828,21 @@ def test_elementwise_family():
     dmu, dls = K.reparam_bwd(ls.to(DEV), eps.to(DEV), dz.to(DEV))
     close(dmu, mr.grad, 0, 0, "reparam dmu")
     close(dls, lr.grad, 1e-6, 1e-6, "reparam dls")
+    # the gradients that reach mu / logstd from their other consumer (the KL term) are summed inside the same launch
+    am, al = torch.randn(4, 16, generator=gen), torch.randn(4, 16, generator=gen)
+    dmu2, dls2 = K.reparam_bwd(ls.to(DEV), eps.to(DEV), dz.to(DEV), am.to(DEV), al.to(DEV))
+    close(dmu2, mr.grad + am, 1e-6, 1e-6, "reparam dmu + addend")
+    close(dls2, lr.grad + al, 1e-6, 1e-6, "reparam dls + addend")
+    from mirror_amd import functional as Fn
+    mg, lg = mu.to(DEV).requires_grad_(True), ls.to(DEV).requires_grad_(True)
+    z, mo, lo = Fn.ReparamFn.apply(mg, lg, eps.to(DEV))
+    ((z * dz.to(DEV)).sum() + (mo * am.to(DEV)).sum() + (lo * al.to(DEV)).sum()).backward()
+    close(mg.grad, mr.grad + am, 1e-6, 1e-6, "ReparamFn: mu through both outputs")
+    close(lg.grad, lr.grad + al, 1e-6, 1e-6, "ReparamFn: logstd through both outputs")
+    mg2 = mu.to(DEV).requires_grad_(True)
+    _, mo2, _ = Fn.ReparamFn.apply(mg2, ls.to(DEV), eps.to(DEV))
+    (mo2 * am.to(DEV)).sum().backward()          # z unused: the pass-through gradient alone
+    close(mg2.grad, am, 0, 0, "ReparamFn: pass-through only")
 
 
 def test_dropout_is_deterministic_and_unbiased():
@@ -916,6 +931,9 @@ def test_step_glue_rownorm_clamp_adam():
     wd = w.to(DEV)
     K.rownorm_(wd)
     close(wd, F.normalize(w, dim=1), 1e-6, 1e-7, "rownorm")
+    wd2, sh2 = w.to(DEV), torch.zeros(300, 40, device=DEV, dtype=torch.bfloat16)
+    K.rownorm_(wd2, shadow=sh2)            # the bf16 copy the GEMMs read, written by the same launch
+    assert torch.equal(wd2, wd) and torch.equal(sh2, wd.bfloat16())
     s = torch.tensor([5.3], device=DEV)
     K.clamp_(s, 0.0, math.log(100))
     assert float(s) == pytest.approx(math.log(100))
@@ -932,6 +950,21 @@ def test_step_glue_rownorm_clamp_adam():
         K.adam(pd, gstep.to(DEV), m, v, sh, 2e-5, 0.9, 0.999, 1e-8, 1 - 0.9 ** step, 1 - 0.999 ** step)
     close(pd, pr.detach(), 1e-6, 1e-7, "adam")
     close(sh, pr.detach().bfloat16().float(), 1e-2, 1e-6, "adam bf16 shadow")
+    # step glue riding on the Adam launches: one parameter clamped behind its update (logit_scale), a device counter advanced
+    for idx in (5, n - 2):                 # inside the 4-wide body / in the scalar tail (n % 4 == 3)
+        p2, m2, v2 = p.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        p3, m3, v3 = p.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        sh3 = torch.zeros(n, device=DEV, dtype=torch.bfloat16)
+        cnt = torch.tensor([40], device=DEV, dtype=torch.int64)
+        K.adam(p2, gr.to(DEV), m2, v2, None, 2e-5, 0.9, 0.999, 1e-8, 0.1, 0.001)
+        lo, hi = float(p2[idx]) + 0.25, float(p2[idx]) + 0.5
+        K.adam(p3, gr.to(DEV), m3, v3, sh3, 2e-5, 0.9, 0.999, 1e-8, 0.1, 0.001, clamp=(idx, lo, hi), counter=cnt, counter_add=7)
+        want = p2.clone()
+        want[idx] = lo
+        assert torch.equal(p3, want) and torch.equal(sh3, want.bfloat16()) and int(cnt) == 47
+    from mirror_amd import MirrorHipError
+    with pytest.raises(MirrorHipError):
+        K.adam(p2, gr.to(DEV), m2, v2, None, 2e-5, 0.9, 0.999, 1e-8, 0.1, 0.001, clamp=(n, 0.0, 1.0))
 
 
 # --------------------------------------------------------------------------------------- skinny-M linears
