@@ -253,10 +253,14 @@ def main():
         # step-level HBM traffic (sum over every kernel of the same PMC passes) and the dominant kernel's MFMA-pipe utilisation
         # (profiles/pmc_mfma_busy.json, its own PMC pass): both only when measured on exactly these kernel sources
         step_bytes, mfma_busy, mfma_note = None, None, "no profiles/pmc_mfma_busy.json entry for this kernel"
+        step_launches = None
         try:
             if pm.get("csrc_sha256") == csrc_digest() and pm.get("config", "c2") == a.config:
                 steps_prof = float(pm.get("steps", 9))
                 step_bytes = sum(v["bytes_per_launch"] * v["launches"] for v in pm["kernels"].values()) / steps_prof
+                if pm.get("replayed_step"):          # the replayed step alone (what is timed), not the 9-step average
+                    step_bytes = float(pm["replayed_step"]["hbm_bytes"])
+                    step_launches = int(pm["replayed_step"]["launches"])
         except (NameError, KeyError, TypeError):
             pass
         try:
@@ -293,6 +297,7 @@ def main():
                                         "is closer to the HBM roof than to the MFMA roof, see step_hbm_frac_of_6.3TBps"),
                          "mfma_busy_frac": mfma_busy, "mfma_busy_source": mfma_note,
                          "step_hbm_bytes": None if step_bytes is None else int(step_bytes),
+                         "step_launches": step_launches,      # dispatches of one replayed step in the same PMC passes
                          "step_hbm_frac_of_6.3TBps": None if step_bytes is None else round(step_bytes / (dt / a.steps) / 6.3e12, 4),
                          "launches_timed": prof["launches"],
                          "timed_in": ("eager re-run of min(K,5) steps right after the timed region (the timed region "

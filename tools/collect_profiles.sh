@@ -25,6 +25,9 @@ ff=$(find /tmp/p3 -name "*counter_collection.csv" | head -1); fw=$(find /tmp/p4 
 [ -n "$ff" ] && [ -n "$fw" ] && python3 $R/tools/pmc_summary.py $ff $fw > $OUT/pmc_traffic.json
 (cd $R && bash tools/pmc_mfma.sh > $OUT/pmc_mfma_busy.json 2>/dev/null)      # SQ_VALU_MFMA_BUSY_CYCLES per kernel, its own PMC pass, keyed by the csrc digest
 echo "[collect] pmc done"
+# one graph-replayed step, launch by launch (the fastest step of a traced bench run: the eager re-runs of the roofline leg are longer)
+(cd $R && bash tools/trace_step_raw.sh ${TAG}_graph > /dev/null 2>&1 && python3 tools/prof_step_listing.py gpurun_out/${TAG}_graph_kernel_trace.csv fastest > $OUT/${TAG}_c2_step_listing_graph_replay_traced.txt && rm -f gpurun_out/${TAG}_graph_kernel_trace.csv)
+echo "[collect] replayed-step listing done"
 fi
 if [ "$PART" = "core" ]; then ls -la $OUT; exit 0; fi
 python3 $R/bench.py --config template --no-cpu-baseline > $OUT/${TAG}_template_bench.json 2>/dev/null
@@ -42,5 +45,4 @@ python3 $R/bench.py --precision fp8 --no-cpu-baseline > $OUT/${TAG}_c5_fp8_bench
 python3 $R/tools/bench_chain.py 2>/dev/null | grep -v amdgpu > $OUT/${TAG}_chain_and_attention_isolated.txt
 python3 $R/tools/trace_gemms.py template 2>/dev/null | grep -v amdgpu > $OUT/${TAG}_template_gemm_calls.txt
 python3 $R/tools/trace_gemms.py c2 2>/dev/null | grep -v amdgpu > $OUT/${TAG}_c2_gemm_calls.txt
-(cd $R && bash tools/trace_step_raw.sh ${TAG}_graph > /dev/null 2>&1 && python3 tools/prof_step_listing.py gpurun_out/${TAG}_graph_kernel_trace.csv > $OUT/${TAG}_c2_step_listing_graph_replay_traced.txt && rm -f gpurun_out/${TAG}_graph_kernel_trace.csv)
 ls -la $OUT

@@ -1,17 +1,26 @@
 #!/usr/bin/env python3
 """List the kernels of ONE step of a rocprofv3 kernel trace in start order: start offset, duration, what else was running.
-usage: prof_step_listing.py <kernel_trace.csv> [step_from_end=1]"""
+usage: prof_step_listing.py <kernel_trace.csv> [step_from_end=1 | fastest]
+`fastest`: the step with the shortest wall span — in a bench trace a graph-REPLAYED step (the eager re-runs of the roofline leg
+at the end of the run, and the warm-up steps at its start, are longer and hold a few launches the captured step does not)."""
 import csv
 import re
 import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
-back = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+sel = sys.argv[2] if len(sys.argv) > 2 else "1"
+back = 1 if sel == "fastest" else int(sel)
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # a step ends with the (last) adam_kernel launch
 ends = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
 # group consecutive adam launches
 marks = [i for k, i in enumerate(ends) if k + 1 == len(ends) or ends[k + 1] - i > 50]
+if sel == "fastest":
+    spans = []
+    for k in range(1, len(marks)):
+        seg = rows[marks[k - 1] + 1:marks[k] + 1]
+        spans.append((max(int(r["End_Timestamp"]) for r in seg) - int(seg[0]["Start_Timestamp"]), k))
+    back = len(marks) - min(spans)[1]
 hi = marks[-back]
 lo = marks[-back - 1] + 1
 step = rows[lo:hi + 1]
