@@ -443,8 +443,15 @@ def test_attn2_backward_tail_one_pass_equals_z0_bwd_plus_softmax_bwd():
     K.softmax_bwd(p, ref)
     got = dx0.clone()
     K.pinv_s2_bwd(p, dz0, st, got)
+    got_z = dx0.clone()
+    K.pinv_s2_bwd(p, dz0, st, got_z, zeroed_scratch=torch.zeros(1, device="cuda"))     # the caller's pre-zeroed float: no memset node
+    ref_z = dx0.clone()
+    K.pinv_z0_bwd(p, None, dz0, st, ref_z, zeroed_scratch=torch.zeros(1, device="cuda"))
+    K.softmax_bwd(p, ref_z)
     torch.cuda.synchronize()
     scale = float(ref.abs().max())
+    # (the dot product behind the column term is a float-atomic sum: run-to-run rounding, not bit equality)
+    assert float((got_z - got).abs().max()) <= 2e-6 * scale and float((ref_z - ref).abs().max()) <= 2e-6 * scale
     assert float((got - ref).abs().max()) <= 2e-6 * scale, (float((got - ref).abs().max()), scale)
     # the matrix that holds the column maximum really is corrected (the test would pass trivially if the term were negligible)
     ci = int(st.view(torch.int64)[1].item()) & 0xffffffff

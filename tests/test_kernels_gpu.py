@@ -461,6 +461,19 @@ def test_l2norm():
     dx = torch.zeros_like(xd)
     K.l2norm_bwd(y, nrm, dy.to(DEV), dx, 4, 40, 6 * 40, accumulate=True)
     close(dx, xr.grad, 1e-5, 1e-6, "l2 bwd")
+    # L2NormRowFn on the cls rows of a [B, T, D] buffer handed over as a strided [B, D] view: read in place, gradient written whole
+    from mirror_amd import functional as Fn
+    xs = xd.clone().requires_grad_(True)
+    rows = xs[:, 0]
+    assert not rows.is_contiguous()
+    ys = Fn.L2NormRowFn.apply(rows, 1e-12, torch.float32)
+    close(ys, ref.detach(), 1e-6, 1e-6, "L2NormRowFn strided rows")
+    ys.backward(dy.to(DEV))
+    close(xs.grad, xr.grad, 1e-5, 1e-6, "L2NormRowFn strided rows bwd")
+    x3 = xd.clone().requires_grad_(True)
+    y3 = Fn.L2NormRowFn.apply(x3, 1e-12, torch.float32)          # the 3-D form: the other rows' gradient is zero
+    y3.backward(dy.to(DEV))
+    close(x3.grad, xr.grad, 1e-5, 1e-6, "L2NormRowFn 3-D bwd")
 
 
 # --------------------------------------------------------------------------------------- Nystrom pieces
@@ -845,6 +858,45 @@ def test_elementwise_family():
     close(mg2.grad, am, 0, 0, "ReparamFn: pass-through only")
 
 
+def test_exp_fn_and_linear_pair_fn_match_torch():
+    """ExpFn (`logit_scale.exp()`) and LinearPairFn (style_mu / style_logstd on one hidden vector, models/mirror.py:845-857) against
+    torch autograd on the same numbers."""
+    from mirror_amd import functional as Fn
+    from mirror_amd.functional import POLICIES
+    gen = g(29)
+    s0 = torch.tensor(2.6593)
+    sd = s0.to(DEV).requires_grad_(True)
+    y = Fn.exp(sd)
+    close(y, s0.exp(), 1e-6, 0, "exp fwd")
+    (y * 3.0).backward()
+    close(sd.grad, 3.0 * s0.exp(), 1e-6, 0, "exp bwd")
+    prec = POLICIES["bf16"]
+    M, Kd, N = 16, 256, 128
+    x = ints((M, Kd), gen)
+    w1, w2 = ints((N, Kd), gen), ints((N, Kd), gen)
+    b1, b2 = ints((N,), gen), ints((N,), gen)
+    g1, g2 = ints((M, N), gen), ints((M, N), gen)
+    leaves = [t.to(DEV).requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    xd = leaves[0].bfloat16()
+    y1, y2 = Fn.linear_pair(xd, leaves[1], leaves[2], leaves[3], leaves[4], prec=prec, out_dtype=torch.float32)
+    assert y1.grad_fn is y2.grad_fn and "LinearPair" in type(y1.grad_fn).__name__      # ONE node: x has a single consumer
+    close(y1, x.double() @ w1.double().t() + b1.double(), 0, 0, "pair y1")
+    close(y2, x.double() @ w2.double().t() + b2.double(), 0, 0, "pair y2")
+    ((y1 * g1.to(DEV)).sum() + (y2 * g2.to(DEV)).sum()).backward()
+    close(leaves[0].grad, (g1.double() @ w1.double() + g2.double() @ w2.double()).float().bfloat16().double(), 0, 0, "pair dx")
+    close(leaves[1].grad, g1.double().t() @ x.double(), 0, 0, "pair dw1")
+    close(leaves[3].grad, g2.double().t() @ x.double(), 0, 0, "pair dw2")
+    close(leaves[2].grad, g1.double().sum(0), 0, 0, "pair db1")
+    close(leaves[4].grad, g2.double().sum(0), 0, 0, "pair db2")
+    # only one of the two outputs is used: the other's gradients stay undefined, x gets the used one's alone
+    leaves = [t.to(DEV).requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    y1, y2 = Fn.linear_pair(leaves[0].bfloat16(), leaves[1], leaves[2], leaves[3], leaves[4], prec=prec, out_dtype=torch.float32)
+    (y2 * g2.to(DEV)).sum().backward()
+    close(leaves[0].grad, (g2.double() @ w2.double()).float().bfloat16().double(), 0, 0, "pair dx (second only)")
+    assert leaves[1].grad is None and leaves[2].grad is None
+    close(leaves[3].grad, g2.double().t() @ x.double(), 0, 0, "pair dw2 (second only)")
+
+
 def test_dropout_is_deterministic_and_unbiased():
     x = torch.ones(1 << 20, device=DEV)
     a = K.dropout(x, 0.1, seed=123, offset=0)
@@ -984,6 +1036,12 @@ def test_skinny_fwd_wgrad_transpose(M, N, Kd):
     if N % 32 == 0:
         dx = K.skinny_fwd(dyd, wt, None, ACT_NONE, torch.float32)
         close(dx, dy.double() @ w.double(), 0, 0, "skinny dgrad via W^T")
+        # an f32 addend (another consumer's data gradient of the same x) is summed in front of the activation, any row stride
+        add = ints((M, Kd + 8), gen).to(DEV)[:, :Kd]
+        dx2 = K.skinny_fwd(dyd, wt, None, ACT_NONE, torch.float32, addend=add)
+        close(dx2, dy.double() @ w.double() + add.double().cpu(), 0, 0, "skinny dgrad + addend")
+        dx3 = K.skinny_fwd(dyd, wt, None, ACT_RELU, torch.bfloat16, addend=add)
+        close(dx3, F.relu(dy.double() @ w.double() + add.double().cpu()).float().bfloat16().double(), 0, 0, "skinny relu(dgrad + addend) bf16")
     dw = torch.full((N, Kd), 2.0, device=DEV)
     K.skinny_wgrad(dyd, xd, dw, accumulate=True)
     close(dw, 2 + dy.double().t() @ x.double(), 0, 0, "skinny wgrad accumulate")
