@@ -1201,64 +1201,99 @@ __device__ __forceinline__ f32x4 ld4_bf16(const bf16_t* p) {
     const u32x2 w = *reinterpret_cast<const u32x2*>(p);
     return f32x4{__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xffff0000u), __uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xffff0000u)};
 }
-template <bool TAIL>
+// PS threads share a quad (PS = 4: small outputs WITH a tail): a 512 x 512 gradient is 64 K quads = 256 workgroups of one quad per
+// thread; its 64 partials stream at HBM rate (9 us for 33 MB), but the tail's rank-one terms behind them are two more dependent
+// rounds of scattered loads per thread (19 us).  With the partials and the tail's terms of a quad dealt to four threads and summed
+// through LDS the pass has four times the loads in flight (13 us).
+template <bool TAIL, int PS>
 __global__ __launch_bounds__(256) void fold_partials_kernel(const bf16_t* __restrict__ P, int parts, long mn, float* __restrict__ C, long ldc,
                                                             int N, GemmTail t) {
-    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q * 4 < mn; q += (long)gridDim.x * 256) {
-        const long i = q * 4, r = i / N, c = i % N;
-        f32x4 s = *reinterpret_cast<const f32x4*>(C + r * ldc + c);
-        int p = 0;
-        for (; p + 8 <= parts; p += 8) {
-            f32x4 v[8];
+    constexpr int QB = 256 / PS;                      // quads per workgroup
+    __shared__ f32x4 red[PS > 1 ? 256 : 1];
+    const int ql = threadIdx.x % QB, pg = threadIdx.x / QB;
+    const long quads = mn / 4;
+    for (long qb = blockIdx.x; qb * QB < quads; qb += gridDim.x) {
+        const long q = qb * QB + ql;
+        const bool live = q < quads;
+        const long i = q * 4, r = live ? i / N : 0, c = live ? i % N : 0;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        if (live) {
+            // this thread's share of the partials: p = pg, pg + PS, ...
+            int p = pg;
+            for (; p + 7 * PS < parts; p += 8 * PS) {
+                f32x4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = ld4_bf16(P + (long)(p + u) * mn + i);
+                for (int u = 0; u < 8; u++) v[u] = ld4_bf16(P + (long)(p + u * PS) * mn + i);
 #pragma unroll
-            for (int u = 0; u < 8; u++) s += v[u];
-        }
-        for (; p < parts; p++) s += ld4_bf16(P + (long)p * mn + i);
-        if constexpr (TAIL) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            const int total = t.batch * t.KT;
-            auto ld = [&](int k, float& a, f32x4& b) {
-                const int z = k / t.KT, kk = k - z * t.KT;
-                const long ia = z * t.sA + (long)kk * t.lda + r, ib = z * t.sB + (long)kk * t.ldb + c;
-                a = t.a_f32 ? reinterpret_cast<const float*>(t.A)[ia] : bf2f(reinterpret_cast<const bf16_t*>(t.A)[ia]);
-                if (t.b_f32) b = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(t.B) + ib);
-                else {
-                    const u32x2 w = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(t.B) + ib);
-                    b = f32x4{__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xffff0000u), __uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xffff0000u)};
+                for (int u = 0; u < 8; u++) s += v[u];
+            }
+            for (; p < parts; p += PS) s += ld4_bf16(P + (long)p * mn + i);
+            if constexpr (TAIL) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                const int total = t.batch * t.KT;
+                auto ld = [&](int k, float& a, f32x4& b) {
+                    const int z = k / t.KT, kk = k - z * t.KT;
+                    const long ia = z * t.sA + (long)kk * t.lda + r, ib = z * t.sB + (long)kk * t.ldb + c;
+                    a = t.a_f32 ? reinterpret_cast<const float*>(t.A)[ia] : bf2f(reinterpret_cast<const bf16_t*>(t.A)[ia]);
+                    if (t.b_f32) b = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(t.B) + ib);
+                    else {
+                        const u32x2 w = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(t.B) + ib);
+                        b = f32x4{__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xffff0000u), __uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xffff0000u)};
+                    }
+                };
+                int k = pg;
+                for (; k + 7 * PS < total; k += 8 * PS) {          // eight independent pairs in flight
+                    float a[8];
+                    f32x4 b[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) ld(k + u * PS, a[u], b[u]);
+#pragma unroll
+                    for (int u = 0; u < 8; u++) acc += b[u] * a[u];
                 }
-            };
-            int k = 0;
-            for (; k + 8 <= total; k += 8) {          // eight independent pairs in flight (one dependent pair at a time doubled the pass)
-                float a[8];
-                f32x4 b[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) ld(k + u, a[u], b[u]);
-#pragma unroll
-                for (int u = 0; u < 8; u++) acc += b[u] * a[u];
+                for (; k < total; k += PS) {
+                    float a;
+                    f32x4 b;
+                    ld(k, a, b);
+                    acc += b * a;
+                }
+                s += acc * t.alpha;
             }
-            for (; k < total; k++) {
-                float a;
-                f32x4 b;
-                ld(k, a, b);
-                acc += b * a;
-            }
-            s += acc * t.alpha;
         }
-        *reinterpret_cast<f32x4*>(C + r * ldc + c) = s;
+        if constexpr (PS > 1) {
+            __syncthreads();                          // (the previous round's readers are done with red)
+            red[threadIdx.x] = s;
+            __syncthreads();
+            if (pg == 0 && live) {
+#pragma unroll
+                for (int u = 1; u < PS; u++) s += red[u * QB + ql];
+            }
+        }
+        if (pg == 0 && live) {
+            f32x4* cp = reinterpret_cast<f32x4*>(C + r * ldc + c);
+            *cp = *cp + s;
+        }
     }
 }
 static void launch_fold(const float* ws_, int parts, long mn, float* C, long ldc, int N, hipStream_t s) {
+#ifdef MH_EXP
+    if (getenv("MH_EXP_SKIP_FOLD")) { g_tail.KT = 0; return; }      // timing experiment: what the fold passes cost inside the step
+#endif
     const bf16_t* ws = reinterpret_cast<const bf16_t*>(ws_);
-    const dim3 grid((unsigned)min((long)mh_cdiv(mn / 4, 256), 2048L));
+    const long blocks1 = mh_cdiv(mn / 4, 256);
     // the tail's B rows are read as aligned quads of the output's columns: 4-element alignment of its rows and base
-    if (g_tail.KT > 0 && (g_tail.ldb % 4) == 0 && (g_tail.sB % 4) == 0 && ((uintptr_t)g_tail.B & (g_tail.b_f32 ? 15 : 7)) == 0) {
-        hipLaunchKernelGGL(fold_partials_kernel<true>, grid, dim3(256), 0, s, ws, parts, mn, C, ldc, N, g_tail);
+    const bool tail = g_tail.KT > 0 && (g_tail.ldb % 4) == 0 && (g_tail.sB % 4) == 0 && ((uintptr_t)g_tail.B & (g_tail.b_f32 ? 15 : 7)) == 0;
+    // four threads per quad where the tail's dependent loads ride along on a small output (measured: 19.3 -> 13.2 us; the plain
+    // fold of the same 33 MB is at HBM rate with one thread per quad, 9.1 us, and 1.3 us slower shared)
+    const bool share = tail && blocks1 < 1024;
+    const dim3 grid((unsigned)min(share ? mh_cdiv(mn / 4, 64) : blocks1, share ? 4096L : 2048L));
+#define FOLD_(TAIL, PS) hipLaunchKernelGGL((fold_partials_kernel<TAIL, PS>), grid, dim3(256), 0, s, ws, parts, mn, C, ldc, N, g_tail)
+    if (tail) {
+        if (share) FOLD_(true, 4); else FOLD_(true, 1);
         g_tail.KT = 0;
     } else {
-        hipLaunchKernelGGL(fold_partials_kernel<false>, grid, dim3(256), 0, s, ws, parts, mn, C, ldc, N, g_tail);
+        FOLD_(false, 1);
     }
+#undef FOLD_
 }
 
 // MH_GEMM_PP=0 keeps every launch on gemm_big_kernel (A/B switch; default: the ping-pong kernel)
