@@ -224,20 +224,17 @@ __global__ __launch_bounds__(256) void nys_dz_dav_kernel(const float* __restrict
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hl = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bh = blockIdx.x;
+    const int rb = blockIdx.y;          // two workgroups per matrix (256 for B h = 128: every CU), one of a wave's two row blocks each
     const float* dwb = dw2 + (long)bh * SM * SDH;
     const float* avb = av + (long)bh * SM * SDH;
     // this wave's A operands are requested first: av rows (pass 1) and zfT rows (pass 2) of its two row blocks
-    bf16x8 af[2][4];
+    bf16x8 af[4];
 #pragma unroll
-    for (int rb = 0; rb < 2; rb++)
+    for (int ks = 0; ks < 4; ks++) af[ks] = cvt8(avb + (long)(32 * (2 * wave + rb) + r) * SDH + 16 * ks + 8 * hl);
+    bf16x8 zf[16];
 #pragma unroll
-        for (int ks = 0; ks < 4; ks++) af[rb][ks] = cvt8(avb + (long)(32 * (2 * wave + rb) + r) * SDH + 16 * ks + 8 * hl);
-    bf16x8 zf[2][16];
-#pragma unroll
-    for (int rb = 0; rb < 2; rb++)
-#pragma unroll
-        for (int ks = 0; ks < 16; ks++)
-            zf[rb][ks] = *reinterpret_cast<const bf16x8*>(zfT + (long)bh * SMAT + (long)(32 * (2 * wave + rb) + r) * SM + 16 * ks + 8 * hl);
+    for (int ks = 0; ks < 16; ks++)
+        zf[ks] = *reinterpret_cast<const bf16x8*>(zfT + (long)bh * SMAT + (long)(32 * (2 * wave + rb) + r) * SM + 16 * ks + 8 * hl);
     // dW2 -> bf16 images, [i][d] and [d][i]
 #pragma unroll
     for (int n = 0; n < 16; n++) {
@@ -254,8 +251,6 @@ __global__ __launch_bounds__(256) void nys_dz_dav_kernel(const float* __restrict
     // pass 1: U = av dW2^T, rows i of this wave's two row blocks x all 256 columns j
     bf16_t* upb = up + (long)bh * SMAT;
 #pragma unroll
-    for (int rb = 0; rb < 2; rb++)
-#pragma unroll
         for (int cb = 0; cb < 8; cb++) {
             f32x16 c;
 #pragma unroll
@@ -263,7 +258,7 @@ __global__ __launch_bounds__(256) void nys_dz_dav_kernel(const float* __restrict
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) {
                 const bf16x8 b = *reinterpret_cast<const bf16x8*>(s_dw + (32 * cb + r) * DWP + 16 * ks + 8 * hl);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rb][ks], b, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], b, c, 0, 0, 0);
             }
 #pragma unroll
             for (int t = 0; t < 2; t++)
@@ -271,8 +266,7 @@ __global__ __launch_bounds__(256) void nys_dz_dav_kernel(const float* __restrict
         }
     // pass 2: dAV = zfT dW2, rows j of the same row blocks x 64 columns d
     bf16_t* davb = dav + (long)bh * SM * SDH;
-#pragma unroll
-    for (int rb = 0; rb < 2; rb++) {
+    {
         float dl[16];       // delta3[j] = sum_d dAV[j][d] av[j][d] with the rounded dAV (what mh_nys_attn3_bwd's first launch computes)
 #pragma unroll
         for (int reg = 0; reg < 16; reg++) dl[reg] = 0.f;
@@ -284,7 +278,7 @@ __global__ __launch_bounds__(256) void nys_dz_dav_kernel(const float* __restrict
 #pragma unroll
             for (int ks = 0; ks < 16; ks++) {
                 const bf16x8 b = *reinterpret_cast<const bf16x8*>(s_dt + (32 * nb + r) * DTP + 16 * ks + 8 * hl);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[rb][ks], b, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[ks], b, c, 0, 0, 0);
             }
 #pragma unroll
             for (int reg = 0; reg < 16; reg++) {
@@ -326,7 +320,7 @@ extern "C" int mh_nys_dz_dav(const float* dw2, const float* av, const void* zfT,
     MH_REQUIRE(dw2 && av && zfT && up && dav && (((uintptr_t)dw2 | (uintptr_t)av | (uintptr_t)zfT | (uintptr_t)up | (uintptr_t)dav) & 15) == 0,
                "mh_nys_dz_dav: null / unaligned buffer");
     if (BH == 0) return MH_OK;
-    hipLaunchKernelGGL(nys_dz_dav_kernel, dim3(BH), dim3(256), 0, (hipStream_t)s, dw2, av, (const bf16_t*)zfT, (bf16_t*)up, (bf16_t*)dav, delta3);
+    hipLaunchKernelGGL(nys_dz_dav_kernel, dim3(BH, 2), dim3(256), 0, (hipStream_t)s, dw2, av, (const bf16_t*)zfT, (bf16_t*)up, (bf16_t*)dav, delta3);
     MH_LAUNCH_CHECK("mh_nys_dz_dav");
     return MH_OK;
 }
