@@ -607,6 +607,10 @@ class MIRROR(nn.Module):
             wsi_alignment_emb = self.wsi_encoder.forward_alignment_head(wsi_cls)
             wsi_score, wsi_mu, wsi_logstd, rna_score, rna_mu, rna_logstd = self.forward_style_clustering(
                 wsi_cls, rna_emb, noise.get("wsi_eps"), noise.get("rna_eps"))
+            # `logit_scale.exp()` (models/mirror.py:911) here, beside the retention decoder: at the end of forward() its one-thread
+            # launch (and its backward's, which autograd replays on this stream) would stand on the main stream between the last
+            # forward GEMM and the loss
+            logit_scale = Fn.exp(self.logit_scale)
             Fn.probe("heads_end")
         ag = getattr(self, "_align_gather", None)      # TrainEngine: the loss contrasts against all ranks (gather_distributed)
         if ag is not None:
@@ -624,12 +628,12 @@ class MIRROR(nn.Module):
         main.wait_stream(side)
         Fn.probe("fwd_joined")
         for t in (rna_emb, rna_alignment_emb, rna_retention_emb, rna_mask, wsi_alignment_emb, wsi_score, wsi_mu, wsi_logstd,
-                  rna_score, rna_mu, rna_logstd):
+                  rna_score, rna_mu, rna_logstd, logit_scale):
             t.record_stream(main)       # allocated in a helper stream's pool, consumed on the main stream
         rna_retention_target = rna_emb
         return (wsi_alignment_emb, wsi_retention_emb, wsi_retention_target, wsi_mask, wsi_score, wsi_mu, wsi_logstd,
                 rna_alignment_emb, rna_retention_emb, rna_retention_target, rna_mask, rna_score, rna_mu, rna_logstd,
-                Fn.exp(self.logit_scale))
+                logit_scale)
 
 
 _ACCEPTED = {
