@@ -209,3 +209,64 @@ def test_rna_block_ok_mirrors_the_kernel_limits():
     assert not K.rna_block_ok(torch.zeros(32, 1024), 1024, 4096, 8)     # 2 x 16 x 4104 x 2 B = 262 KiB operand image
     assert not K.rna_block_ok(torch.zeros(8, 4096), 4096, 4096, 8)      # D > 2048
     assert K.rna_block_ok(torch.zeros(16, 1024), 1024, 4096, 8)         # one row tile: 131 KiB
+
+
+def test_pmc_summary_reports_the_replayed_step_on_its_own(tmp_path):
+    """tools/pmc_summary.py cuts a PMC run into steps at the Adam launch and reports the step that repeats (the graph replays) apart
+    from the eager steps and the one-time work around them: the launch and byte counts bench.py prints (roofline.step_launches /
+    step_hbm_bytes) are those of a replayed step, not a run average."""
+    import csv
+    import json
+    import subprocess
+    import sys
+
+    def write(fn, per_kernel_value):
+        rows, did = [], 0
+        # first step: one-time work (5 extra copies); two replays of 3 launches; one eager step of 4 launches
+        plan = [["__amd_rocclr_copyBuffer"] * 5 + ["k_a", "k_b", "adam_kernel"], ["k_a", "k_b", "adam_kernel"], ["k_a", "k_b", "adam_kernel"],
+                ["k_a", "k_b", "k_c", "adam_kernel"]]
+        for step in plan:
+            for k in step:
+                did += 1
+                rows.append({"Dispatch_Id": did, "Kernel_Name": f"void (anonymous namespace)::{k}(float*)", "Counter_Value": per_kernel_value.get(k, 0.0)})
+        rows.reverse()          # the tool sorts by dispatch id
+        with open(fn, "w", newline="") as fh:
+            w = csv.DictWriter(fh, fieldnames=["Dispatch_Id", "Kernel_Name", "Counter_Value"])
+            w.writeheader()
+            w.writerows(rows)
+
+    f, wv = tmp_path / "f.csv", tmp_path / "w.csv"
+    write(f, {"k_a": 100.0, "k_b": 50.0, "adam_kernel": 10.0, "__amd_rocclr_copyBuffer": 1.0, "k_c": 7.0})     # KiB, counted at half
+    write(wv, {"k_a": 20.0, "k_b": 0.0, "adam_kernel": 10.0, "k_c": 1.0})
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_summary.py"), str(f), str(wv)], capture_output=True, text=True, check=True)
+    d = json.loads(out.stdout)
+    assert [p["launches"] for p in d["per_step"]] == [8, 3, 3, 4]
+    rp = d["replayed_step"]
+    assert rp["launches"] == 3 and rp["steps_averaged"] == 2
+    assert rp["hbm_bytes"] == int((2 * (100 + 50 + 10) + (20 + 0 + 10)) * 1024)
+    assert d["kernels"]["k_a"]["bytes_per_launch"] == int((2 * 100 + 20) * 1024) and d["kernels"]["k_a"]["launches"] == 4
+
+
+def test_step_listing_picks_a_replayed_step_as_the_fastest(tmp_path):
+    """tools/prof_step_listing.py <trace> fastest: the shortest step of a traced bench run (a graph replay), not the eager re-runs of
+    the roofline leg at its end."""
+    import csv
+    import subprocess
+    import sys
+    rows, t = [], 0
+    for step, dur in enumerate([900, 300, 310, 800]):          # eager, replay, replay, eager (ns per kernel)
+        # (the tool takes Adam launches more than 50 dispatches apart as step ends: 60 kernels per step, two more in an eager one)
+        for k in ["k_a"] * 60 + (["k_c"] * 2 if dur > 500 else []) + ["adam_kernel"]:
+            rows.append({"Kernel_Name": f"void {k}(float*)", "Start_Timestamp": t, "End_Timestamp": t + dur, "Queue_Id": 1,
+                         "Grid_Size_X": 256, "Grid_Size_Y": 1, "Grid_Size_Z": 1, "Workgroup_Size_X": 256})
+            t += dur + 10
+    fn = tmp_path / "trace.csv"
+    with open(fn, "w", newline="") as fh:
+        w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        w.writerows(rows)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "prof_step_listing.py"), str(fn), "fastest"], capture_output=True, text=True, check=True)
+    head = out.stdout.splitlines()[0]
+    assert head.startswith("step: 61 launches"), head          # a replay (61), not an eager step (63)
