@@ -270,3 +270,70 @@ def test_step_listing_picks_a_replayed_step_as_the_fastest(tmp_path):
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "prof_step_listing.py"), str(fn), "fastest"], capture_output=True, text=True, check=True)
     head = out.stdout.splitlines()[0]
     assert head.startswith("step: 61 launches"), head          # a replay (61), not an eager step (63)
+
+
+def test_gbuf_n_uses_the_sink_slot_only_when_it_has_exactly_the_elements():
+    """functional._gbuf_n (gradients of tokens / positional tables that reach their Function reshaped): the arena slot when it holds
+    exactly the requested elements, a buffer of its own (returned through autograd) for a slice of a longer table or without a sink."""
+    from mirror_amd import functional as Fn
+
+    class Sink:
+        def __init__(self, p):
+            self.p, self.g, self.finished = p, torch.zeros_like(p), []
+
+        def slot(self, t):
+            return self.g if t.data_ptr() == self.p.data_ptr() else None
+
+        def done(self, t):
+            self.finished.append(t.data_ptr())
+
+    pos = torch.randn(1, 9, 4)
+    sink = Sink(pos)
+    Fn.set_grad_sink(sink)
+    try:
+        buf, sunk = Fn._gbuf_n(pos, (36,))
+        assert sunk and buf.data_ptr() == sink.g.data_ptr() and tuple(buf.shape) == (36,)
+        assert Fn._gret(pos, buf, sunk) is None and sink.finished == [pos.data_ptr()]
+        part, sunk2 = Fn._gbuf_n(pos[:, :5], (20,))           # same data_ptr, fewer elements: not the slot
+        assert not sunk2 and part.data_ptr() != sink.g.data_ptr() and float(part.abs().sum()) == 0.0
+        assert Fn._gret(pos, part, sunk2) is part
+        other, sunk3 = Fn._gbuf_n(torch.randn(3), (3,))       # a tensor the sink does not know
+        assert not sunk3
+    finally:
+        Fn.set_grad_sink(None)
+    free, sunk4 = Fn._gbuf_n(pos, (36,))                      # no sink installed
+    assert not sunk4 and tuple(free.shape) == (36,)
+
+
+def test_loss_out_hands_over_views_of_one_small_tensor_without_a_copy():
+    """TrainEngine._loss_out: six f32 scalars that are views of ONE small fresh tensor (MirrorLossTermsFn's result) are returned as
+    they are; anything else (slices of a larger buffer such as the step's zero arena, separate tensors) is copied into a new tensor."""
+    from mirror_amd.engine import TrainEngine
+    out = torch.arange(8, dtype=torch.float32)
+    views = tuple(out[i].reshape(()) for i in range(6))
+    got = TrainEngine._loss_out(views)
+    assert all(g.untyped_storage().data_ptr() == out.untyped_storage().data_ptr() for g in got)
+    assert [float(g) for g in got] == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0]
+    arena = torch.arange(4096, dtype=torch.float32)
+    got2 = TrainEngine._loss_out(tuple(arena[64 * i].reshape(()) for i in range(6)))
+    assert all(g.untyped_storage().data_ptr() != arena.untyped_storage().data_ptr() for g in got2)
+    assert [float(g) for g in got2] == [0.0, 64.0, 128.0, 192.0, 256.0, 320.0]
+    sep = tuple(torch.tensor(float(i)) for i in range(6))
+    got3 = TrainEngine._loss_out(sep)
+    assert len({g.untyped_storage().data_ptr() for g in got3}) == 1 and [float(g) for g in got3] == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0]
+
+
+def test_dropout_step_take_hands_the_offset_to_the_caller_once():
+    from mirror_amd import functional as Fn
+    st = Fn._dropout_state
+    saved = dict(st)
+    try:
+        st["base"], st["offset"] = torch.zeros(1, dtype=torch.int64), 24
+        base, used = Fn.dropout_step_take()
+        assert base is st["base"] and used == 24 and st["offset"] == 0
+        assert Fn.dropout_step_take() == (None, 0)            # nothing consumed since: no counter for the caller to advance
+        st["base"], st["offset"] = None, 8
+        assert Fn.dropout_step_take() == (None, 0) and st["offset"] == 0
+    finally:
+        st.clear()
+        st.update(saved)
