@@ -95,9 +95,14 @@ typedef struct {
     const void* R; float rcoef;   /* optional addend: C (+)= ... + rcoef * R; R has C's dtype, ldc and batch strides
                                      (lets the pinv polynomial 15I - 7P + P.P come out of one launch) */
     float* workspace;             /* optional scratch for reductions into one C (split-K, batch broadcast): with at least
-                                     parts * M * N floats (parts = splits * batch) the large-tile kernel writes plain
-                                     partial tiles there and a fold pass adds them to C; NULL / too small: f32 atomics */
-    int64_t workspace_floats;
+                                     mh_gemm_workspace_bytes(d) BYTES = parts * M * N * 2 (parts = splits * batch) the large-tile kernel
+                                     writes plain partial tiles there and a fold pass adds them to C in f32.  The partial tiles are
+                                     **bf16**: every K-slice's f32 accumulator is rounded ONCE on its way to the workspace, so an element
+                                     of C carries an extra error <= parts * 2^-9 * max_slice |partial| (relative to the largest partial,
+                                     not to the final sum: slices that cancel keep their rounding).  NULL / too small: f32 atomics (exact
+                                     f32 partial sums, summation order not reproducible) — the caller's precision policy chooses
+                                     (mirror_amd: kernels.SPLITK_PARTIALS, env MIRROR_SPLITK_PARTIALS=f32) */
+    int64_t workspace_floats;     /* size of `workspace` in 4-byte units (the buffer is typed float* for alignment only) */
     void* C2;                     /* optional bf16 copy of the final C (C's ldc and batch strides), written by the same epilogue:
                                      the next product's operand without a cast launch.  192 x 384 tile kernel only (bf16
                                      operands, M % 192 == 0, N % 384 == 0, K % 64 == 0, no bias / activation / split-K) */
@@ -135,8 +140,9 @@ int mh_gemm_select_pp(int mode);
 /* The kernel instance the calling thread's last mh_gemm call launched (e.g. "gemm_pq_kernel<float,false,false,part>",
  * "gemm_kernel<1,bf16,bf16,float,true,false,2,2,1>"): lets a profiler name launches without restating the dispatch rules. */
 const char* mh_gemm_variant_name(void);
-/* Bytes of `workspace` with which this call reduces through plain partial tiles + a fold pass instead of f32 atomics
- * (0: the call has no use for one — no split-K / batch broadcast, or the shape is not on the large-tile kernel). */
+/* Bytes of `workspace` with which this call reduces through plain **bf16** partial tiles (parts * M * N * 2) + an f32 fold pass
+ * instead of f32 atomics (0: the call has no use for one — no split-K / batch broadcast, fewer than 8 parts, or the shape is not
+ * on the large-tile kernel). */
 int64_t mh_gemm_workspace_bytes(const mh_gemm_desc* d);
 
 /* ---------------------------------------------------------------- skinny-M linears (RNA encoder / style heads: every

@@ -188,6 +188,11 @@ EXPORTS = sorted(list(_SIGS) + ["mh_last_error", "mh_version", "mh_exp_build", "
 
 _lib = None
 
+# The ABI generation this binding was written against (mh_version() of csrc/errors.cpp).  _SIGS above restates the argument lists of
+# include/mirror_hip.h by hand: a library built from another generation would be called with shifted arguments (a stream where a
+# counter belongs) and corrupt device memory silently, so load() refuses anything but this exact number.
+ABI_VERSION = 107
+
 
 class MirrorHipError(RuntimeError):
     pass
@@ -206,6 +211,12 @@ def load() -> C.CDLL:
     lib.mh_last_error.restype = C.c_char_p
     lib.mh_last_error.argtypes = []
     lib.mh_version.restype = C.c_int
+    lib.mh_version.argtypes = []
+    got = int(lib.mh_version())
+    if got != ABI_VERSION:
+        raise MirrorHipError(
+            f"{LIB_PATH} is ABI v{got}, this binding (mirror_amd/_lib.py) is v{ABI_VERSION}: the argument lists differ — rebuild the "
+            "library (`make -C mirror_amd/csrc`, or __graft_entry__.build()); the same holds for a library named by MIRROR_HIP_LIB")
     lib.mh_exp_build.restype = C.c_int
     lib.mh_gemm_variant_name.restype = C.c_char_p
     lib.mh_gemm_variant_name.argtypes = []

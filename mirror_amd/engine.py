@@ -394,11 +394,18 @@ class TrainEngine:
         if not torch.cuda.is_current_stream_capturing() and (not self._use_graph or wsi_key_padding_mask is not None):
             self._maybe_graph_rna(rna)       # steps that are not replayed as one graph: N > 1, padded slides + mask
         Fn.zero_arena_begin(self.device, self._zarena)
+        # the per-engine fp8 call-site table (amax rings) is installed for the duration of THIS engine's step only: another engine's
+        # validate() or a bare model call must neither read nor advance these rings, and a freed engine's table must not stay
+        # reachable from the module global
+        sites_before = Fn._fp8_state["sites"]
+        Fn.pending_lm_merge_reset("TrainEngine.step (start)")
         try:
             return self._step_body(wsi, rna, noise, wsi_key_padding_mask)
         finally:
             Fn.zero_arena_end()      # also after an exception: nothing outside a step may carve from an arena that is not re-zeroed
             Fn.fp8_delayed_scaling(None)      # delayed fp8 scaling belongs to training steps only
+            Fn._fp8_state["sites"] = sites_before
+            Fn.pending_lm_merge_reset("TrainEngine.step (end)")      # an aborted backward must not pin its buffers
 
     def _step_body(self, wsi: torch.Tensor, rna: torch.Tensor, noise: Optional[dict],
                    wsi_key_padding_mask: Optional[torch.Tensor] = None):
@@ -447,6 +454,7 @@ class TrainEngine:
                 self._one = torch.ones((), device=losses[0].device, dtype=losses[0].dtype)
             Fn.probe("loss_done")
             losses[0].backward(self._one)        # a persistent root gradient: no ones_like fill launch per step
+            Fn.pending_lm_merge_reset("TrainEngine.step (after backward)", strict=True)
             if defer:
                 with torch.cuda.stream(Fn._side_stream(self.device, 1)):
                     Fn.probe("side_bwd_end")
@@ -532,6 +540,9 @@ class TrainEngine:
         was_training = self.model.training
         self.model.eval()
         acc = torch.zeros(7, device=self.device, dtype=torch.float64)        # 6 weighted sums + the sample count
+        sites_before = Fn._fp8_state["sites"]
+        if POLICIES[self.precision].fp8_fwd:
+            Fn._fp8_state["sites"] = self._fp8_sites      # this engine's call sites (no tick: the exact two-pass quantisation runs)
         try:
             with torch.no_grad():
                 for i, (wsi, rna) in enumerate(loader):
@@ -549,6 +560,7 @@ class TrainEngine:
                     acc[6] += b
         finally:
             self.model.train(was_training)
+            Fn._fp8_state["sites"] = sites_before
         if self.world > 1:      # mean over ranks of every batch's loss == summed weighted sums / summed counts for equal batch sizes
             dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=self.pg)
         vals = acc.cpu()

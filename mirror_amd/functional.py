@@ -254,7 +254,13 @@ def _tail_fork():
     point from which those launches may run in parallel (an event on the capturing stream); None otherwise (eager: same stream)."""
     if not (_TAIL_ASIDE and torch.cuda.is_current_stream_capturing()):
         return None
-    return torch.cuda.current_stream().record_event()
+    cur = torch.cuda.current_stream()
+    if any(st == cur for st in _side_streams.values()):
+        # issued from a helper stream (the chain's, the RNA / heads branch): ONE tail stream serving two originating branches would wait on
+        # forks of both, every join would then pick up the other branch's work (false serialisation), and a stream whose first node joins
+        # two branches is the pattern that makes hipStreamEndCapture segfault on ROCm 7.2 (models/mirror.py) — run those rows inline
+        return None
+    return cur.record_event()
 
 
 @contextlib.contextmanager
@@ -1078,8 +1084,12 @@ class NormQkvLmFn(Function):
         m = n_p // l
         P, E = Bn * n_p, Bn * m
         N3, c0 = wa.shape[0], 2 * wa.shape[1]
-        merge = _pending_lm_merge.pop(dlm.data_ptr(), None)        # NystromCoreFn.backward left the landmark rows' merge to this node
+        pend = _pending_lm_merge.pop(dlm.data_ptr(), None)         # NystromCoreFn.backward left the landmark rows' merge to this node
+        merge = None if pend is None else pend[1]
         de = ext_rows_of(dqkv, dlm, P, E, N3, c0, copy_lm=merge is None)
+        if pend is not None and de.data_ptr() != pend[0]:
+            raise K.MirrorHipError("NormQkvLmFn.backward: the pending landmark merge belongs to another gradient buffer (a stale entry "
+                                   "whose address was recycled)")
         dxe = torch.empty((P + E, D), device=x.device, dtype=bf16)
         # data gradient: the pad rows of dxe stay unwritten on the flat path (the LayerNorm backward reads the real rows only)
         if fast:
@@ -1569,7 +1579,20 @@ _Z0_ROWS = True      # (test hook)
 _SIM2_SIDE = True      # nys_sim2 opens the chain's branch instead of preceding the fork
 _S2_SIDE = True      # sim2's landmark gradients on the chain's stream
 _LM_MERGE_LATE = True      # (test hook) the landmark rows' merge + data gradient beside the sequence rows' data gradient (-0.24 % +- 0.29)
-_pending_lm_merge: dict = {}      # data_ptr of the landmark-gradient view NystromCoreFn.backward returned -> its deferred merge launch
+_pending_lm_merge: dict = {}      # data_ptr of the landmark-gradient view NystromCoreFn.backward returned -> (address of the buffer
+                                  # `de` the merge writes into, its deferred merge launch); see pending_lm_merge_reset
+
+
+def pending_lm_merge_reset(where: str, strict: bool = False) -> None:
+    """Entries left behind (a standalone TransLayer whose NormQkvLmFn never ran its backward, an aborted backward pass) pin tens of MB
+    through their closures and — once the allocator recycles the address — could match a later gradient view.  TrainEngine clears the
+    table at the start of a step and, with strict=True, raises behind loss.backward() if a merge was never consumed."""
+    if _pending_lm_merge:
+        n = len(_pending_lm_merge)
+        _pending_lm_merge.clear()
+        if strict:
+            raise K.MirrorHipError(f"{where}: {n} deferred landmark-gradient merge(s) were never run (NormQkvLmFn.backward did not follow "
+                                   "NystromCoreFn.backward)")
 _W2_ON_CHAIN = True      # (test hook) w2 = pinv (attn3 v) at the end of the chain's branch instead of behind the join (-0.22 % +- 0.06)
 _DZ_DAV = True      # (test hook)
 # (measured and deleted in round 4, see DESIGN.md section 6 round 3: nys_dz_dav on the chain's branch +0.32 %, attn3's delta out of
@@ -1843,7 +1866,7 @@ class NystromCoreFn(Function):
             # on a parallel branch beside the data gradient of the sequence rows instead of in front of it
             merge = lambda: K.lm_merge(dlm, dlm2, de[Bn * n_p:], D3 - 2 * D)      # noqa: E731
             if _LM_MERGE_LATE:
-                _pending_lm_merge[dlm_out.data_ptr()] = merge
+                _pending_lm_merge[dlm_out.data_ptr()] = (de.data_ptr(), merge)
             else:
                 merge()
             return dqkv, dres, None, None, None, None, None, None, dlm_out

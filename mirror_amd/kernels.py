@@ -159,7 +159,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *
     # reductions into one f32 C (split-K / a batch that broadcasts into C) on the large-tile kernel: give it room for plain
     # partial tiles + a fold pass (f32 atomics of a 64-way split cost more than the K loop).  `ws` stays alive until the call
     # is enqueued; the caching allocator keeps the block valid for stream-ordered use.
-    wsb = int(_lib.load().mh_gemm_workspace_bytes(C.byref(d))) if (accumulate and _GEMM_WS) else 0
+    wsb = int(_lib.load().mh_gemm_workspace_bytes(C.byref(d))) if (accumulate and _GEMM_WS and SPLITK_PARTIALS == "bf16") else 0
     if 0 < wsb <= (1 << 29):
         ws = torch.empty((wsb // 4,), device=a.device, dtype=torch.float32)
         d.workspace, d.workspace_floats = ws.data_ptr(), ws.numel()
@@ -377,6 +377,16 @@ def gemm_tile_ok(M: int, N: int, Kd: int, dta=torch.bfloat16, dtb=torch.bfloat16
 
 
 _GEMM_WS = True      # split-K partials in a workspace + fold pass (False: f32 atomics; test hook)
+# Precision policy of the split-K weight-gradient reductions.  "bf16": every K-slice's f32 accumulator is rounded to bf16 on
+# its way to the workspace and the fold sums in f32 (half the partial traffic: -0.77 % step time); the
+# extra error of an element is bounded by parts * 2^-9 * max |partial| — relative to the largest partial, not to the final sum
+# (tests/test_kernels_gpu.py::test_split_k_bf16_partials_error_bound_under_cancellation).  "f32": no workspace, f32 atomics into C
+# (exact f32 partial sums, order not reproducible).  The bf16 form is the bf16 training policy's default; MIRROR_SPLITK_PARTIALS=f32
+# selects the other for a run, and the fp32 parity policy never splits into bf16 (mh_gemm_workspace_bytes is 0 for f32 operands).
+import os as _os
+SPLITK_PARTIALS = _os.environ.get("MIRROR_SPLITK_PARTIALS", "bf16")
+if SPLITK_PARTIALS not in ("bf16", "f32"):
+    raise MirrorHipError(f"MIRROR_SPLITK_PARTIALS={SPLITK_PARTIALS!r}: 'bf16' or 'f32'")
 
 
 class GemmProfiler:

@@ -24,7 +24,19 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, missing
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert lib.mh_version() >= 100
+    assert lib.mh_version() == _lib.ABI_VERSION
+
+
+def test_load_refuses_a_library_of_another_abi_generation(monkeypatch):
+    """_SIGS restates the header's argument lists by hand, so a stale libmirror_hip.so (or one named by MIRROR_HIP_LIB)
+    must be an error at load time, not shifted arguments at call time."""
+    lib = _lib.load()
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "ABI_VERSION", lib.mh_version() + 1)
+    with pytest.raises(_lib.MirrorHipError, match="ABI v"):
+        _lib.load()
+    monkeypatch.setattr(_lib, "ABI_VERSION", lib.mh_version())
+    assert _lib.load().mh_version() == lib.mh_version()
 
 
 def _struct_fields(header: str, name: str):
@@ -337,3 +349,31 @@ def test_dropout_step_take_hands_the_offset_to_the_caller_once():
     finally:
         st.clear()
         st.update(saved)
+
+
+def test_pending_landmark_merges_are_cleared_per_step_and_a_leftover_is_an_error():
+    """entries of functional._pending_lm_merge pin their buffers through a closure and are keyed by a raw address; the engine
+    clears the table at the start / end of a step and raises behind backward() when a merge was never consumed."""
+    from mirror_amd import functional as Fn
+    Fn._pending_lm_merge.clear()
+    Fn._pending_lm_merge[1234] = (5678, lambda: None)
+    Fn.pending_lm_merge_reset("test (lenient)")
+    assert not Fn._pending_lm_merge
+    Fn._pending_lm_merge[1234] = (5678, lambda: None)
+    with pytest.raises(mirror_amd.MirrorHipError, match="never run"):
+        Fn.pending_lm_merge_reset("test (strict)", strict=True)
+    assert not Fn._pending_lm_merge          # cleared even when it raises: the next step starts clean
+
+
+def test_split_k_partials_policy_switch_is_validated(monkeypatch):
+    """kernels.SPLITK_PARTIALS (env MIRROR_SPLITK_PARTIALS) is 'bf16' (workspace + fold, the bf16 training policy's default) or 'f32'
+    (f32 atomics); anything else is refused at import."""
+    import importlib
+    assert K.SPLITK_PARTIALS in ("bf16", "f32")
+    monkeypatch.setenv("MIRROR_SPLITK_PARTIALS", "fp16")
+    with pytest.raises(mirror_amd.MirrorHipError):
+        importlib.reload(K)
+    monkeypatch.setenv("MIRROR_SPLITK_PARTIALS", "f32")
+    assert importlib.reload(K).SPLITK_PARTIALS == "f32"
+    monkeypatch.delenv("MIRROR_SPLITK_PARTIALS")
+    assert importlib.reload(K).SPLITK_PARTIALS == "bf16"

@@ -115,6 +115,44 @@ def test_gemm_large_tile_kernel(a_rm, b_t, out_dtype):
         assert bool((outr[:, Mr:] == 7.0).all()), "rows past M were written"
 
 
+def test_split_k_bf16_partials_error_bound_under_cancellation(monkeypatch):
+    """the split-K partial tiles of the f32 weight-gradient products are bf16 (kernels.SPLITK_PARTIALS), so the error of
+    an element is bounded relative to the LARGEST partial, not to the final sum.  A weight-gradient-shaped product (K = 64 slices of
+    1024 rows) whose slices cancel pairwise down to a small signal: the bf16-partial result against the f32-atomics result
+    (MIRROR_SPLITK_PARTIALS=f32 / kernels.SPLITK_PARTIALS) and against f64, per element, with the bound the header states
+    (parts * 2^-9 * max |partial|) — and the f32 policy itself at f32-summation accuracy."""
+    gen = g(4242)
+    bf = torch.bfloat16
+    M, N, parts, ks = 512, 512, 64, 1024
+    Kd = parts * ks
+    # slice 2i and 2i + 1 hold (almost) opposite contributions: x_{2i+1} = -x_{2i} + small signal
+    xa = (torch.randn(parts // 2, ks, M, generator=gen) * 1.0).to(bf)
+    sig = (torch.randn(parts // 2, ks, M, generator=gen) * 2.0 ** -8).to(bf)
+    xb = (-xa.float() + sig.float()).to(bf)
+    x = torch.stack([xa, xb], 1).reshape(Kd, M)                     # [K, M]: dy^T rows
+    y = (torch.randn(ks, N, generator=gen)).to(bf).repeat(parts, 1)  # the same activations under every slice: partials cancel pairwise
+    xd, yd = x.to(DEV), y.to(DEV)
+    ref = x.double().t() @ y.double()
+    partial_max = max(float((x[i * ks:(i + 1) * ks].double().t() @ y[i * ks:(i + 1) * ks].double()).abs().max()) for i in range(0, parts, 8))
+    assert partial_max > 20 * float(ref.abs().max()), "the construction must cancel"
+    from mirror_amd import _lib
+    outs = {}
+    for mode in ("bf16", "f32"):
+        monkeypatch.setattr(K, "SPLITK_PARTIALS", mode)
+        dw = torch.zeros(M, N, device=DEV)
+        K.gemm(xd.t(), yd, out=dw, accumulate=True, split_k=parts, mma=MH_BF16)
+        name = _lib.load().mh_gemm_variant_name().decode()
+        assert ("part" in name) == (mode == "bf16"), (mode, name)
+        outs[mode] = dw.cpu().double()
+    err_f32 = float((outs["f32"] - ref).abs().max())
+    err_bf = float((outs["bf16"] - ref).abs().max())
+    assert err_f32 <= 1e-5 * partial_max * parts ** 0.5, (err_f32, partial_max)          # f32 atomics: exact partial sums, f32 adds
+    assert err_bf <= parts * 2.0 ** -9 * partial_max, (err_bf, partial_max)               # the documented bound
+    assert float((outs["bf16"] - outs["f32"]).abs().max()) <= parts * 2.0 ** -9 * partial_max
+    # and it IS relative to the partials: on this input the bf16 form is far from the f32 form relative to the final sum
+    assert err_bf > 10 * err_f32
+
+
 @pytest.mark.parametrize("a_rm,b_t", LAYOUTS)
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
 def test_gemm_persistent_kernel_epilogue_variants(a_rm, b_t, out_dtype):
