@@ -262,6 +262,16 @@ int mh_resconv_fwd(const void* v, int64_t ldv, int64_t v_bs, const float* w, voi
 /* dw[h][j] += sum_{b,t,d} dout[b,t,h,d] * v[b,t+j-K/2,h,d]  (f32 atomics) */
 int mh_resconv_wgrad(const void* v, int64_t ldv, int64_t v_bs, const void* dout, int64_t ldo, int64_t o_bs,
                      float* dw, int B, int n_p, int heads, int dh, int taps, int dt_v, int dt_o, mh_stream s);
+/* Both gradients of res_conv in ONE pass over dout ([3P] `out += self.res_conv(v)`, called at models/mirror.py:312):
+ *   dv[b,t,h*dh+d] += sum_j w[h][j] * dout[b, t-j+K/2, h*dh+d]      (= mh_resconv_fwd(dout -> dv, transpose=1, accumulate=1))
+ *   dw[h][j]       += sum_{b,t,d} dout[b,t,h,d] * v[b,t+j-K/2,h,d]   (= mh_resconv_wgrad)
+ * bf16 operands with dh = 64, 33 taps and `workspace` of mh_resconv_bwd_workspace_bytes(..) bytes: one launch over 128-row tiles
+ * (the dout tile of a head sits in LDS for the adjoint conv; the tap gradient is 8 more MFMAs per 32 rows against v rows read
+ * beside it, its per-tile sums go through `workspace`) + a fold launch; anything else runs the two passes above. */
+int64_t mh_resconv_bwd_workspace_bytes(int B, int n_p, int heads, int dh, int taps);
+int mh_resconv_bwd(const void* dout, int64_t ldo, int64_t o_bs, const void* v, int64_t ldv, int64_t v_bs, const float* w, void* dv,
+                   int64_t lddv, int64_t dv_bs, float* dw, float* workspace, int64_t ws_floats, int B, int n_p, int heads, int dh,
+                   int taps, int dt_v, int dt_o, mh_stream s);
 /* moore_penrose_iter_pinv initial scaling: stats[0]=max_i sum_j|x|, stats[1]=max_j sum_i|x| over the
  * WHOLE [BH,m,m] tensor (couples the batch), with arg positions packed in stats64. */
 int mh_pinv_absmax(const float* x, uint64_t* stats64, int BH, int m, mh_stream s);
@@ -322,7 +332,11 @@ int64_t mh_pinv_chain_workspace_bytes(int BH, int m, int iters, int which);
  * attn1_fwd: out[:, :, head] (+)= softmax_m(scale q k_l^T) w2 (accumulate = 1 adds to what is there, e.g. the res_conv
  *            term computed while the pinv chain was running), lse1 = row logsumexp.
  * attn3_fwd: av = softmax_n(scale q_l k^T) v, lse3.
- * attn1_bwd: writes the q block of dqkv and delta1; ADDS (f32 atomics) into dw2 and the k_l half of dlm.
+ * attn1_bwd: two parts, selected by `which` (1, 2 or 3 = both, in this order):
+ *   1: ADDS (f32 atomics) dw2 = P1^T dO and dk_l = dS1^T q into dw2 and the k_l half of dlm, and WRITES delta1[b, h, n] =
+ *      sum_l P1 dP1 = sum_d dO[n, d] o1[n, d] — o1 = attn1's own output rows as mh_nys_attn1_fwd(o1 = ..) saved them (the
+ *      flash-attention identity).  dw2 is all the pinv chain's backward waits for, so this part runs first.
+ *   2: writes the q block of dqkv = dS1 k_l from delta1 (a single pass: 3 products); nothing the chain needs — it can run beside it.
  * attn3_bwd: writes the k and v blocks of dqkv and delta3 [B,h,m] f32 (scratch); ADDS into the q_l half of dlm. */
 /* mrow [B, n_p] / mlm [B, m] (f32 0 / 1, both or neither): the package's key-padding mask — valid sequence rows and landmark
  * groups that contain a valid row.  A logit whose row or landmark is invalid is masked_fill'ed before the softmax (a fully
@@ -330,25 +344,34 @@ int64_t mh_pinv_chain_workspace_bytes(int BH, int m, int iters, int which);
 /* lm_ld (all mh_nys_attn*): row stride of `lm` in elements, 0 = 2 D (a contiguous [B, m, 2D]).  3 D when the landmarks are rows of
  * to_qkv's output buffer behind the sequence (landmarks = to_qkv(group means): [3P] landmarks are means over l consecutive
  * positions of q and k, and to_qkv is linear and bias-free); batch b's landmarks start at lm + b * m * lm_ld. */
+/* o1 (nullable, bf16 [B, n_p, D]): attn1's own rows softmax(scale q k_l^T) w2, WITHOUT whatever `out` held under accumulate = 1
+ * (res_conv(v)): what mh_nys_attn1_bwd part 1 takes delta1 from. */
 int mh_nys_attn1_fwd(const void* qkv, const void* lm, const void* w2, void* out, float* lse1, const float* mrow, const float* mlm,
-                     int B, int h, int n_p, int m, int dh, float scale, int accumulate, int64_t lm_ld, mh_stream s);
+                     int B, int h, int n_p, int m, int dh, float scale, int accumulate, int64_t lm_ld, void* o1, mh_stream s);
 /* unmasked mh_nys_attn1_fwd that also writes the e4m3 copy q8 [B, n_p, D] bytes of `out` (delayed scaling: ring / tick / margin as
  * in mh_quant_fp8_delayed, q8_scale[0] = dequantisation factor): the fp8 forward of [3P] to_out needs no quantisation pass */
 int mh_nys_attn1_fwd_q8(const void* qkv, const void* lm, const void* w2, void* out, float* lse1, int B, int h, int n_p, int m, int dh,
-                        float scale, int accumulate, void* q8, unsigned* ring, const float* tick, float margin, float* q8_scale, mh_stream s);
+                        float scale, int accumulate, void* q8, unsigned* ring, const float* tick, float margin, float* q8_scale, void* o1,
+                        mh_stream s);
 /* attn3_fwd cuts the sequence into ranges (one workgroup each) when B*h alone would not fill the chip; the partial results
  * live in `workspace` (mh_nys_attn3_ws_floats(B, h, n_p) floats; NULL / too small: one workgroup per (b, h)). */
 int64_t mh_nys_attn3_ws_floats(int B, int h, int n_p);
 int64_t mh_nys_attn3_workspace_bytes(int B, int h, int n_p);         /* the same in bytes */
+/* rc_w / rc_out (both or neither): [3P] `out += self.res_conv(v)` computed by the same launch — rc_w = the 33-tap filters [h][33]
+ * (Conv2d(h, h, (33, 1), groups=h, bias=False), models/mirror.py:299-309), rc_out [B, n_p, D] bf16 receives res_conv(v) (every row
+ * written; mh_nys_attn1_fwd(accumulate=1) then adds its product): the conv reads the v tile this kernel stages anyway. */
 int mh_nys_attn3_fwd(const void* qkv, const void* lm, float* av, float* lse3, float* workspace, int64_t ws_floats,
-                     const float* mrow, const float* mlm, int B, int h, int n_p, int m, int dh, float scale, int64_t lm_ld, mh_stream s);
-int mh_nys_attn1_bwd(const void* qkv, const void* lm, const void* w2, const void* dout, const float* lse1, float* delta1,
+                     const float* mrow, const float* mlm, int B, int h, int n_p, int m, int dh, float scale, int64_t lm_ld,
+                     const float* rc_w, void* rc_out, mh_stream s);
+int mh_nys_attn1_bwd(const void* qkv, const void* lm, const void* w2, const void* dout, const float* lse1, const void* o1, float* delta1,
                      void* dqkv, float* dw2, float* dlm, const float* mrow, const float* mlm, int B, int h, int n_p, int m, int dh,
-                     float scale, int64_t lm_ld, mh_stream s);
+                     float scale, int64_t lm_ld, int which, mh_stream s);
 /* av == NULL: delta3 already holds sum_d dav av (mh_nys_dz_dav wrote it); otherwise it is scratch this call fills first */
+/* one_pass != 0 (round 5): dk, dv and dq_l from ONE kernel (every logit / dP / exponential computed once, k and v read once: the
+ * landmark-owning waves hand P and dS to the key-owning role through two LDS images); 0: the dk / dv kernel + the dq_l kernel */
 int mh_nys_attn3_bwd(const void* qkv, const void* lm, const float* av, const void* dav, const float* lse3, float* delta3,
-                     void* dqkv, float* dlm, const float* mrow, const float* mlm, int B, int h, int n_p, int m, int dh, float scale,
-                     int64_t lm_ld, mh_stream s);
+                     void* dqkv, float* dlm, const float* mrow, const float* mlm, int B, int h, int n_p, int m, int dh,
+                     float scale, int64_t lm_ld, int one_pass, mh_stream s);
 /* out[r, 0:cols] = bf16(a[r] + b[r]) (f32 [rows, cols], b may be NULL) at row stride out_ld, out[r, cols:cols + zero_cols] = 0: the
  * landmark gradient (q_l | k_l halves from the attention kernels + sim2's products) written as rows [dq_l | dk_l | 0] of to_qkv's
  * output gradient, where its data / weight gradient products pick it up together with the sequence rows. */

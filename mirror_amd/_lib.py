@@ -110,6 +110,7 @@ _SIGS = {
     "mh_landmark_bwd": [P, P, I, I, I, I, I],
     "mh_resconv_fwd": [P, L, L, P, P, L, L, I, I, I, I, I, I, I, I, I],
     "mh_resconv_wgrad": [P, L, L, P, L, L, P, I, I, I, I, I, I, I],
+    "mh_resconv_bwd": [P, L, L, P, L, L, P, P, L, L, P, P, L, I, I, I, I, I, I, I],
     "mh_pinv_absmax": [P, P, I, I],
     "mh_pinv_z0": [P, P, P, I, I],
     "mh_pinv_z0_bwd": [P, P, P, P, P, P, I, I, I],
@@ -121,11 +122,11 @@ _SIGS = {
     "mh_nys_sim2": [P, P, P, P, P, I, I, I, I, F, L],
     "mh_nys_dz_dav": [P, P, P, P, P, P, I, I, I],
     "mh_pinv_chain_bwd": [P, P, P, P, P, P, I, I, I],
-    "mh_nys_attn1_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, F, I, L],
-    "mh_nys_attn1_fwd_q8": [P, P, P, P, P, I, I, I, I, I, F, I, P, P, P, F, P],
-    "mh_nys_attn3_fwd": [P, P, P, P, P, L, P, P, I, I, I, I, I, F, L],
-    "mh_nys_attn1_bwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, L],
-    "mh_nys_attn3_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, L],
+    "mh_nys_attn1_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, F, I, L, P],
+    "mh_nys_attn1_fwd_q8": [P, P, P, P, P, I, I, I, I, I, F, I, P, P, P, F, P, P],
+    "mh_nys_attn3_fwd": [P, P, P, P, P, L, P, P, I, I, I, I, I, F, L, P, P],
+    "mh_nys_attn1_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, L, I],
+    "mh_nys_attn3_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, L, I],
     "mh_seq_finish": [P, P, I, I, I, I, I],
     "mh_seq_finish_bwd": [P, P, I, I, I, I, I],
     "mh_ppeg_merge": [P, P, P, P, P, P, P, P, I],
@@ -184,7 +185,7 @@ _SIGS = {
 }
 EXPORTS = sorted(list(_SIGS) + ["mh_last_error", "mh_version", "mh_exp_build", "mh_gemm_select_pp", "mh_gemm_variant_name", "mh_device_ok", "mh_nys_attn3_ws_floats", "mh_rna_block_workspace_bytes",
                                  "mh_gemm_workspace_bytes", "mh_layernorm_bwd_workspace_bytes", "mh_nys_attn3_workspace_bytes",
-                                 "mh_pinv_chain_workspace_bytes"])
+                                 "mh_pinv_chain_workspace_bytes", "mh_resconv_bwd_workspace_bytes"])
 
 _lib = None
 
@@ -233,6 +234,8 @@ def load() -> C.CDLL:
     lib.mh_nys_attn3_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.mh_pinv_chain_workspace_bytes.restype = C.c_int64
     lib.mh_pinv_chain_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.mh_resconv_bwd_workspace_bytes.restype = C.c_int64
+    lib.mh_resconv_bwd_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.mh_rna_block_workspace_bytes.restype = C.c_int64
     lib.mh_rna_block_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
     for name, sig in _SIGS.items():

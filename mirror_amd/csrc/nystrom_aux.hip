@@ -9,6 +9,10 @@ bool resconv_try_mfma(const void* v, long ldv, long v_bs, const float* w, void* 
                       int dh, int taps, int transpose, int accumulate, int dt_v, int dt_o, hipStream_t s);
 bool resconv_wgrad_try_mfma(const void* v, long ldv, long v_bs, const void* dout, long ldo, long o_bs, float* dw, int B, int n_p,
                             int heads, int dh, int taps, int dt_v, int dt_o, hipStream_t s);
+long resconv_bwd_part_floats(int B, int n_p, int heads, int dh, int taps);
+bool resconv_bwd_try_mfma(const void* dout, long ldo, long o_bs, const void* v, long ldv, long v_bs, const float* w, void* dv, long lddv,
+                          long dv_bs, float* dw, float* part, long part_floats, int B, int n_p, int heads, int dh, int taps, int dt,
+                          hipStream_t s);
 static bool resconv_mfma_on() { return true; }
 
 // ------------------------------------------------------------------ landmarks
@@ -395,6 +399,26 @@ extern "C" int mh_resconv_wgrad(const void* v, int64_t ldv, int64_t v_bs, const 
 #undef RW
     MH_LAUNCH_CHECK("mh_resconv_wgrad");
     return MH_OK;
+}
+
+extern "C" int64_t mh_resconv_bwd_workspace_bytes(int B, int n_p, int heads, int dh, int taps) {
+    return 4 * (int64_t)resconv_bwd_part_floats(B, n_p, heads, dh, taps);
+}
+
+extern "C" int mh_resconv_bwd(const void* dout, int64_t ldo, int64_t o_bs, const void* v, int64_t ldv, int64_t v_bs, const float* w, void* dv,
+                              int64_t lddv, int64_t dv_bs, float* dw, float* workspace, int64_t ws_floats, int B, int n_p, int heads, int dh,
+                              int taps, int dt_v, int dt_o, mh_stream s) {
+    MH_REQUIRE(taps >= 1 && taps <= 63 && (taps & 1), "mh_resconv_bwd: taps=%d unsupported", taps);
+    MH_REQUIRE(dout && v && w && dv && dw, "mh_resconv_bwd: null pointer");
+    if (B == 0 || n_p == 0) return MH_OK;
+    if (resconv_mfma_on() && dt_v == dt_o &&
+        resconv_bwd_try_mfma(dout, ldo, o_bs, v, ldv, v_bs, w, dv, lddv, dv_bs, dw, workspace, ws_floats, B, n_p, heads, dh, taps, dt_v, (hipStream_t)s)) {
+        MH_LAUNCH_CHECK("mh_resconv_bwd");
+        return MH_OK;
+    }
+    // other dtypes / geometries, or no workspace: the two passes
+    if (int e = mh_resconv_wgrad(v, ldv, v_bs, dout, ldo, o_bs, dw, B, n_p, heads, dh, taps, dt_v, dt_o, s)) return e;
+    return mh_resconv_fwd(dout, ldo, o_bs, w, dv, lddv, dv_bs, B, n_p, heads, dh, taps, 1, 1, dt_o, dt_v, s);
 }
 
 // ------------------------------------------------------------------ pinv initial scaling

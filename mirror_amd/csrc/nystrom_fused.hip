@@ -202,7 +202,10 @@ struct Geo {
     int accumulate;     // attn1 forward: add to `out` (the res_conv term is already there) instead of overwriting it
     long lm_ld;         // row stride of `lm` in elements (2 D for a contiguous [B, m, 2D]; 3 D when the landmark rows live behind the
                         // sequence in the to_qkv output buffer); batch b's landmarks start at lm + b * m * lm_ld
+    const float* rc_w;  // attn3 forward only: the 33-tap res_conv filters [h][33] (NULL: no res_conv) and the [B, n_p, D] buffer that
+    bf16_t* rc_out;     // receives res_conv(v) (attn1's forward then adds its product to it)
 };
+constexpr int RC_TAPS = 33, RC_HALO = 16;
 
 // ============================================================================ attn1 forward (N kernel)
 // grid (splits, B h).  out[b, n, hd*64 + d] = sum_l softmax_l(scale q k_l^T)[n, l] w2[l, d];  lse1 = row logsumexp.
@@ -212,7 +215,7 @@ struct Geo {
 template <bool MASKED, bool Q8 = false>
 __global__ __launch_bounds__(NT) void nys_a1_fwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ lm,
                                                         const bf16_t* __restrict__ w2, bf16_t* __restrict__ out,
-                                                        float* __restrict__ lse1, Geo g, Q8Out q8 = Q8Out{}) {
+                                                        float* __restrict__ lse1, Geo g, Q8Out q8 = Q8Out{}, bf16_t* __restrict__ o1 = nullptr) {
     __shared__ __attribute__((aligned(16))) bf16_t s_kl_[NM * NP];
     __shared__ __attribute__((aligned(16))) bf16_t s_w2_[NM * NP];
     __shared__ __attribute__((aligned(16))) float s_mlm_[NM];
@@ -319,6 +322,9 @@ __global__ __launch_bounds__(NT) void nys_a1_fwd_kernel(const bf16_t* __restrict
 #pragma unroll
         for (int nb = 0; nb < 2; nb++) {
             o[nb] *= inv;
+            // o1: attn1's OWN rows (without the res_conv addend), bf16: the backward takes delta[n] = sum_l P dP = sum_d dO[n, d] O1[n, d]
+            // from them (attn1 backward, dw2 kernel), so the dq kernel needs no first pass over dP and can run after the pinv chain's fork
+            if (o1) store_row8(o1 + ((long)b * g.n_p + row) * D + hd * ND + 32 * nb, o[nb], hl);
 #pragma unroll
             for (int gq = 0; gq < 4; gq++) {
                 if (g.accumulate) {
@@ -352,12 +358,16 @@ __global__ __launch_bounds__(NT) void nys_a1_fwd_kernel(const bf16_t* __restrict
     }
 }
 
-// ============================================================================ attn1 backward, dq + delta (N kernel)
-// grid (splits, B h), same walk as the forward.  dS1 = P1 o (dO w2^T - delta) scale, delta[n] = sum_l P1 dP1;  dq = dS1 k_l
+// ============================================================================ attn1 backward, dq (N kernel)
+// grid (splits, B h), same walk as the forward.  dS1 = P1 o (dO w2^T - delta) scale,  dq = dS1 k_l.
+// delta[n] = sum_l P1 dP1 is an INPUT (round 5: the dw2 kernel below computes it as sum_d dO[n, d] O1[n, d] from attn1's own saved output
+// rows, the flash-attention identity): with it known a 32-landmark block is finished in one go — S, dP, dS, dq — instead of all 8 blocks'
+// probabilities waiting in 128 registers for a first pass over dP (3 products instead of 4), and nothing the pinv chain needs comes out of
+// this kernel any more, so it runs BESIDE the chain (NystromCoreFn.backward) instead of in front of its fork.
 template <bool MASKED>
 __global__ __launch_bounds__(NT, 2) void nys_a1_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ lm,
                                                            const bf16_t* __restrict__ w2, const bf16_t* __restrict__ dout,
-                                                           const float* __restrict__ lse1, float* __restrict__ delta1,
+                                                           const float* __restrict__ lse1, const float* __restrict__ delta1,
                                                            bf16_t* __restrict__ dqkv, Geo g) {
     __shared__ __attribute__((aligned(16))) bf16_t s_kl_[NM * NP];
     __shared__ __attribute__((aligned(16))) bf16_t s_w2_[NM * NP];
@@ -374,7 +384,7 @@ __global__ __launch_bounds__(NT, 2) void nys_a1_bwd_dq_kernel(const bf16_t* __re
     const bf16_t* qb = qkv + (long)b * g.n_p * 3 * D + hd * ND;
     const bf16_t* gb = dout + (long)b * g.n_p * D + hd * ND;
     bf16x8 qn[4], gn[4];
-    float lsen = 0.f;
+    float lsen = 0.f, deln = 0.f;
     if (rb < nblk) {
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) {
@@ -382,6 +392,7 @@ __global__ __launch_bounds__(NT, 2) void nys_a1_bwd_dq_kernel(const bf16_t* __re
             gn[ks] = frag_g(gb + (long)(32 * rb + c) * D, 16 * ks, lane);
         }
         lsen = lse1[(long)bh * g.n_p + 32 * rb + c];
+        deln = delta1[(long)bh * g.n_p + 32 * rb + c];
     }
     __syncthreads();
 #pragma unroll 1
@@ -396,7 +407,7 @@ __global__ __launch_bounds__(NT, 2) void nys_a1_bwd_dq_kernel(const bf16_t* __re
         bf16x8 qf[4], gf[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) { qf[ks] = qn[ks]; gf[ks] = gn[ks]; }
-        const float lse2 = lsen * LOG2E;
+        const float lse2 = lsen * LOG2E, dsc = deln * g.scale;
         if (rb + stride < nblk) {
             const long nrow = 32L * (rb + stride) + c;
 #pragma unroll
@@ -405,41 +416,37 @@ __global__ __launch_bounds__(NT, 2) void nys_a1_bwd_dq_kernel(const bf16_t* __re
                 gn[ks] = frag_g(gb + nrow * D, 16 * ks, lane);
             }
             lsen = lse1[(long)bh * g.n_p + nrow];
+            deln = delta1[(long)bh * g.n_p + nrow];
         }
-        f32x16 s[8];   // P1^T[landmark][q row]
-#pragma unroll
-        for (int blk = 0; blk < 8; blk++) {
-            s[blk] = zero16();
-#pragma unroll
-            for (int ks = 0; ks < 4; ks++) s[blk] = MFMA(frag_kc(s_kl, 32 * blk, 16 * ks, lane), qf[ks], s[blk]);
-            if (masked) {
-                s[blk] = s[blk] * g.scale2;
-                mask_fill16(s[blk], rowvals16(s_mlm + 32 * blk, hl), mr);
-                s[blk] = fma_splat(s[blk], 1.f, -lse2);
-            } else {
-                s[blk] = fma_splat(s[blk], g.scale2, -lse2);
-            }
-            exp2_16(s[blk]);
-        }
-        // pass 1: delta = sum_l P dP   (dP^T[landmark][q row] = w2 dO^T, recomputed in pass 2 instead of held)
-        f32x16 dacc = zero16();
-#pragma unroll
-        for (int blk = 0; blk < 8; blk++) {
-            f32x16 dp = zero16();
-#pragma unroll
-            for (int ks = 0; ks < 4; ks++) dp = MFMA(frag_kc(s_w2, 32 * blk, 16 * ks, lane), gf[ks], dp);
-            dacc += s[blk] * dp;
-        }
-        float del = vsum16(dacc);
-        del += __shfl_xor(del, 32, 64);
-        if (hl == 0) delta1[(long)bh * g.n_p + row] = del;
         f32x16 dq[2] = {zero16(), zero16()};   // dq^T[d][q row]
+        // the two logits products of block blk + 1 are issued before the softmax arithmetic of block blk (as the forward does)
+        f32x16 sn = zero16(), dpn = zero16();   // S^T, dP^T [landmark 32 blk ..][q row]
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            sn = MFMA(frag_kc(s_kl, 0, 16 * ks, lane), qf[ks], sn);
+            dpn = MFMA(frag_kc(s_w2, 0, 16 * ks, lane), gf[ks], dpn);
+        }
 #pragma unroll
         for (int blk = 0; blk < 8; blk++) {
-            f32x16 dp = zero16();
+            f32x16 sb = sn, dp = dpn;
+            if (blk + 1 < 8) {
+                sn = zero16();
+                dpn = zero16();
 #pragma unroll
-            for (int ks = 0; ks < 4; ks++) dp = MFMA(frag_kc(s_w2, 32 * blk, 16 * ks, lane), gf[ks], dp);
-            dp = s[blk] * fma_splat(dp, g.scale, -del * g.scale);
+                for (int ks = 0; ks < 4; ks++) {
+                    sn = MFMA(frag_kc(s_kl, 32 * (blk + 1), 16 * ks, lane), qf[ks], sn);
+                    dpn = MFMA(frag_kc(s_w2, 32 * (blk + 1), 16 * ks, lane), gf[ks], dpn);
+                }
+            }
+            if (masked) {
+                sb = sb * g.scale2;
+                mask_fill16(sb, rowvals16(s_mlm + 32 * blk, hl), mr);
+                sb = fma_splat(sb, 1.f, -lse2);
+            } else {
+                sb = fma_splat(sb, g.scale2, -lse2);
+            }
+            exp2_16(sb);
+            dp = sb * fma_splat(dp, g.scale, -dsc);
             if (masked) mask_zero16(dp, rowvals16(s_mlm + 32 * blk, hl), mr);
             const bf16x8 d0 = pack8<0>(dp), d1 = pack8<1>(dp);
 #pragma unroll
@@ -461,11 +468,14 @@ __device__ __forceinline__ void atomic_tile(float* dst, long ld, const f32x16& a
 }
 
 // ============================================================================ attn1 backward, dw2 + dk_l (L kernel)
-// grid (splits, B h); wave w owns landmarks [64 w, 64 w + 64).  dw2 = P1^T dO,  dk_l = dS1^T q  (f32 atomics)
+// grid (splits, B h); wave w owns landmarks [64 w, 64 w + 64).  dw2 = P1^T dO,  dk_l = dS1^T q  (f32 atomics).
+// Also the producer of delta1[n] = sum_l P1 dP1 = sum_d dO[n, d] O1[n, d] (O1 = attn1's own output rows, saved by the forward): eight
+// threads share a row of the dO / O1 tiles they stage anyway.  It runs FIRST (dw2 is what the pinv chain's backward waits for).
 template <bool MASKED>
 __global__ __launch_bounds__(NT) void nys_a1_bwd_dw_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ lm,
                                                            const bf16_t* __restrict__ w2, const bf16_t* __restrict__ dout,
-                                                           const float* __restrict__ lse1, const float* __restrict__ delta1,
+                                                           const float* __restrict__ lse1, const bf16_t* __restrict__ o1,
+                                                           float* __restrict__ delta1,
                                                            float* __restrict__ dw2, float* __restrict__ dlm, Geo g,
                                                            int tiles_per_wg) {
     __shared__ __attribute__((aligned(16))) bf16_t s_q[TR * NP];
@@ -500,32 +510,46 @@ __global__ __launch_bounds__(NT) void nys_a1_bwd_dw_kernel(const bf16_t* __restr
     for (int j = 0; j < 2; j++)
 #pragma unroll
         for (int nb = 0; nb < 2; nb++) adw[j][nb] = adk[j][nb] = zero16();
-    u32x4 rq[TR * 8 / NT], rg[TR * 8 / NT];
-    float rl = 0.f, rd = 0.f;
+    const bf16_t* ob = o1 + (long)b * g.n_p * D + hd * ND;
+    u32x4 rq[TR * 8 / NT], rg[TR * 8 / NT], ro[TR * 8 / NT];
+    float rl = 0.f;
     tile_load<TR>(rq, qb + (long)t0 * TR * 3 * D, 3 * D, tid);
     tile_load<TR>(rg, gb + (long)t0 * TR * D, D, tid);
-    if (tid < TR) {
-        rl = lse1[(long)bh * g.n_p + (long)t0 * TR + tid];
-        rd = delta1[(long)bh * g.n_p + (long)t0 * TR + tid];
-    }
+    tile_load<TR>(ro, ob + (long)t0 * TR * D, D, tid);
+    if (tid < TR) rl = lse1[(long)bh * g.n_p + (long)t0 * TR + tid];
 #pragma unroll 1
     for (int t = t0; t < t1; t++) {
         __syncthreads();
         tile_store<TR>(rq, s_q, tid);
         tile_store<TR>(rg, s_g, tid);
+        // delta of the tile's rows: this thread holds 8 columns (chunk tid & 7) of rows (tid >> 3) + 32 i of both tiles
+#pragma unroll
+        for (int i = 0; i < TR * 8 / NT; i++) {
+            float d = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                d += __uint_as_float(rg[i][w] << 16) * __uint_as_float(ro[i][w] << 16);
+                d += __uint_as_float(rg[i][w] & 0xffff0000u) * __uint_as_float(ro[i][w] & 0xffff0000u);
+            }
+            d += __shfl_xor(d, 1, 64);
+            d += __shfl_xor(d, 2, 64);
+            d += __shfl_xor(d, 4, 64);
+            if ((tid & 7) == 0) {
+                const int r = (tid >> 3) + 32 * i;
+                s_del[r] = -d * g.scale;            // staged negated and scaled: the tile arithmetic is two multiply-adds per element
+                delta1[(long)bh * g.n_p + (long)t * TR + r] = d;
+            }
+        }
         if (tid < TR) {
-            s_lse[tid] = -rl * LOG2E;           // staged negated and scaled: the tile arithmetic is two multiply-adds per element
-            s_del[tid] = -rd * g.scale;
+            s_lse[tid] = -rl * LOG2E;
             s_mr[tid] = masked ? g.mrow[(long)b * g.n_p + (long)t * TR + tid] : 1.f;
         }
         __syncthreads();
         if (t + 1 < t1) {
             tile_load<TR>(rq, qb + (long)(t + 1) * TR * 3 * D, 3 * D, tid);
             tile_load<TR>(rg, gb + (long)(t + 1) * TR * D, D, tid);
-            if (tid < TR) {
-                rl = lse1[(long)bh * g.n_p + (long)(t + 1) * TR + tid];
-                rd = delta1[(long)bh * g.n_p + (long)(t + 1) * TR + tid];
-            }
+            tile_load<TR>(ro, ob + (long)(t + 1) * TR * D, D, tid);
+            if (tid < TR) rl = lse1[(long)bh * g.n_p + (long)(t + 1) * TR + tid];
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) {   // 32 q rows at a time
@@ -580,13 +604,19 @@ __global__ __launch_bounds__(NT) void nys_a1_bwd_dw_kernel(const bf16_t* __restr
 // ranges of tiles: each workgroup leaves its unnormalised O, running max and sum in `part` and nys_a3_combine_kernel
 // merges them (splits == 1: finished here, `part` unused).
 constexpr int A3_PART = NM * (ND + 2);     // floats per (b, h, split): O [256][64], m [256], l [256]
-template <bool MASKED>
+// RC: [3P] `out += self.res_conv(v)` (called at models/mirror.py:312) computed HERE, from the v tile this kernel stages anyway: the
+// 33-tap depthwise conv along the sequence is the banded Toeplitz product of resconv_mfma.hip (8 MFMAs per 32 x 64 output block against
+// the tile's rows, read with the same transposing fragments as the P V product); the tile carries a 16-row halo on both sides and
+// every wave writes the 32 rows of `rc_out` it owns.  Replaces a launch that re-read v (71 MB) beside the half-chip pinv chain.
+template <bool MASKED, bool RC = false>
 __global__ __launch_bounds__(NT, 2) void nys_a3_fwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ lm,
                                                         float* __restrict__ av, float* __restrict__ lse3, float* __restrict__ part,
                                                         Geo g, int tiles_per_wg) {
+    constexpr int VH = RC ? RC_HALO : 0;          // halo rows in front of (and behind) the v tile's image
     __shared__ __attribute__((aligned(16))) bf16_t s_k[TR * NP];
-    __shared__ __attribute__((aligned(16))) bf16_t s_v[TR * NP];
+    __shared__ __attribute__((aligned(16))) bf16_t s_v_[(TR + 2 * VH) * NP];
     __shared__ __attribute__((aligned(16))) float s_mr[TR];
+    bf16_t* const s_v = s_v_ + VH * NP;          // the tile proper: image row q <-> sequence row 128 t + q, q in [-VH, 128 + VH)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hl = lane >> 5;
     const int bh = blockIdx.y, b = bh / g.h, hd = bh % g.h, D = g.D;
     const long LD = g.lm_ld;
@@ -611,16 +641,61 @@ __global__ __launch_bounds__(NT, 2) void nys_a3_fwd_kernel(const bf16_t* __restr
     u32x4 rk[TR * 8 / NT], rv[TR * 8 / NT];
     tile_load<TR>(rk, kb + (long)t0 * TR * 3 * D, 3 * D, tid);
     tile_load<TR>(rv, vb + (long)t0 * TR * 3 * D, 3 * D, tid);
+    // RC: thread tid carries one 16-byte piece of the halo: rows 128 t - 16 + hq (hq < 16) in front, 128 t + 128 + (hq - 16) behind
+    u32x4 rh = {0u, 0u, 0u, 0u};
+    const int hq = tid >> 3, hc = tid & 7, hrow = hq < RC_HALO ? hq - RC_HALO : TR + hq - RC_HALO;
+    auto halo_load = [&](int t) {
+        const long sr = (long)t * TR + hrow;
+        rh = (u32x4){0u, 0u, 0u, 0u};
+        if (sr >= 0 && sr < g.n_p) rh = *reinterpret_cast<const u32x4*>(vb + sr * 3 * D + hc * 8);
+    };
+    // Toeplitz operand W^T[k][row c] = w[k - c], k in the accumulator order of k-step ks (resconv_mfma.hip): the same 4 fragments for
+    // every tile and every wave, parked in LDS (16 registers that this 256-register kernel does not have)
+    __shared__ __attribute__((aligned(16))) bf16x8 s_wf_[RC ? 4 * 64 : 1];
+    if constexpr (RC) {
+        halo_load(t0);
+        if (wave == 0) {
+            const float* wh = g.rc_w + hd * RC_TAPS;
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                bf16x8 wv;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int k = 16 * ks + (e < 4 ? 4 * hl + e : 8 + 4 * hl + (e - 4));
+                    const int jt = k - c;
+                    const float x = wh[min(max(jt, 0), RC_TAPS - 1)];      // unconditional load + select: no branch per element
+                    wv[e] = (__bf16)((jt >= 0 && jt < RC_TAPS) ? x : 0.f);
+                }
+                s_wf_[ks * 64 + lane] = wv;
+            }
+        }
+    }
 #pragma unroll 1
     for (int t = t0; t < t1; t++) {
         __syncthreads();
         tile_store<TR>(rk, s_k, tid);
         tile_store<TR>(rv, s_v, tid);
+        if constexpr (RC) *reinterpret_cast<u32x4*>(s_v + hrow * NP + hc * 8) = rh;
         if (tid < TR) s_mr[tid] = masked ? g.mrow[(long)b * g.n_p + (long)t * TR + tid] : 1.f;
         __syncthreads();
         if (t + 1 < t1) {
             tile_load<TR>(rk, kb + (long)(t + 1) * TR * 3 * D, 3 * D, tid);
             tile_load<TR>(rv, vb + (long)(t + 1) * TR * 3 * D, 3 * D, tid);
+            if constexpr (RC) halo_load(t + 1);
+        }
+        if constexpr (RC) {
+            // rows 128 t + 32 wave + c of res_conv(v): out^T[d][row] = sum_k V^T[d][k] W^T[k][row], k = image rows 32 wave - 16 + {0..63}
+            bf16_t* orow = g.rc_out + ((long)b * g.n_p + (long)t * TR + 32 * wave + c) * D + hd * ND;
+            int opq = 0;
+            asm volatile("" : "+v"(opq));          // per tile: no hoisting of the four fragment reads out of the loop
+            const bf16x8* s_wf = s_wf_ + opq;
+#pragma unroll
+            for (int nb = 0; nb < 2; nb++) {
+                f32x16 a = zero16();
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) a = MFMA(frag_tr(s_v, 32 * nb, 32 * wave - RC_HALO + 16 * ks, lane), s_wf[ks * 64 + lane], a);
+                store_row8(orow + 32 * nb, a, hl);
+            }
         }
 #pragma unroll
         for (int j = 0; j < 2; j++)
@@ -924,6 +999,147 @@ __global__ __launch_bounds__(NT) void nys_a3_bwd_dql_kernel(const bf16_t* __rest
             atomic_tile(dqb + (long)(64 * wave + 32 * j) * 2 * D + 32 * nb, 2 * D, acc[nb][j], hl, c);
 }
 
+// ============================================================================ attn3 backward in ONE pass (L kernel + LDS hand-over)
+// dk, dv (contraction over the landmarks) and dq_l (contraction over the keys) need the probabilities in two orientations; as two
+// kernels every logit, every dP and every exponential was computed twice (28 MFMAs per 32 x 32 tile instead of 20) and k / v were read
+// twice.  Here wave w owns landmarks [64 w, 64 w + 64) as in the dq_l kernel: S^T and dP^T [key][landmark] come out with the landmark
+// on the lane, dS^T is at once the A operand of dq_l += dS k (registers), and P / dS ALSO go to two LDS images [landmark][key] (the
+// lane's own row, four consecutive keys per 8-byte store).  Behind a barrier the same four waves switch roles: wave w takes 32 of the
+// 64 keys and 32 of the 64 channels and contracts over ALL 256 landmarks,  dv^T = dav^T P,  dk^T = q_l^T dS,  both operands read with
+// the transposing fragments (contraction index = image row).  One workgroup per CU (157 KB of LDS), 64 keys per step, 2 barriers per step;
+// the v rows are A fragments straight from HBM / L2 (the image budget has no room for a v tile).
+// grid (splits, B h): range of 64-key steps per workgroup; dq_l leaves as f32 atomics into the q_l half of dlm (as nys_a3_bwd_dql_kernel).
+constexpr int HT = 64;   // keys per step
+constexpr int NT8 = 512;  // 8 waves: two per SIMD, so one wave's softmax arithmetic / LDS traffic runs under the other's MFMAs
+// (first version: 4 waves of 64 landmarks, one per SIMD — 183 us alone against 192 for the two kernels, and 0.75 % SLOWER in the step)
+template <bool MASKED>
+__global__ __launch_bounds__(NT8) void nys_a3_bwd_one_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ lm,
+                                                             const float* __restrict__ delta3, const bf16_t* __restrict__ dav,
+                                                             const float* __restrict__ lse3, bf16_t* __restrict__ dqkv,
+                                                             float* __restrict__ dlm, Geo g, int steps_per_wg) {
+    __shared__ __attribute__((aligned(16))) bf16_t s_ql[NM * NP];
+    __shared__ __attribute__((aligned(16))) bf16_t s_g[NM * NP];
+    __shared__ __attribute__((aligned(16))) bf16_t s_p[NM * NP];       // P  [landmark][key 0..63]
+    __shared__ __attribute__((aligned(16))) bf16_t s_ds[NM * NP];      // dS [landmark][key 0..63]
+    __shared__ __attribute__((aligned(16))) bf16_t s_k[HT * NP];
+    __shared__ __attribute__((aligned(16))) float s_mr[HT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hl = lane >> 5;
+    const int bh = blockIdx.y, b = bh / g.h, hd = bh % g.h, D = g.D;
+    const long LD = g.lm_ld;
+    const int nsteps = g.n_p / HT;
+    const int h0 = blockIdx.x * steps_per_wg, h1 = min(h0 + steps_per_wg, nsteps);
+    if (h0 >= h1) return;
+    constexpr bool masked = MASKED;
+    const int lq = 32 * wave + c;                   // this lane's landmark (phase 1)
+    const float ml = masked ? g.mlm[(long)b * NM + lq] : 1.f;
+    const bf16_t* qlb = lm + (long)b * NM * LD + hd * ND;
+    const bf16_t* gvb = dav + (long)bh * NM * ND;
+#pragma unroll
+    for (int i = 0; i < NM * 8 / NT8; i++) {
+        const int cid = tid + i * NT8, r = cid >> 3, cc = cid & 7;
+        *reinterpret_cast<u32x4*>(s_ql + r * NP + cc * 8) = *reinterpret_cast<const u32x4*>(qlb + (long)r * LD + cc * 8);
+        *reinterpret_cast<u32x4*>(s_g + r * NP + cc * 8) = *reinterpret_cast<const u32x4*>(gvb + (long)r * ND + cc * 8);
+    }
+    bf16x8 qlf[4], gf[4];      // B fragments of this wave's 32 landmarks (phase 1)
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+        qlf[ks] = frag_g(qlb + (long)lq * LD, 16 * ks, lane);
+        gf[ks] = frag_g(gvb + (long)lq * ND, 16 * ks, lane);
+    }
+    const float delv = delta3[(long)bh * NM + lq] * g.scale, lsev = lse3[(long)bh * NM + lq] * LOG2E;
+    const bf16_t* kb = qkv + (long)b * g.n_p * 3 * D + D + hd * ND;
+    const bf16_t* vb = kb + D;
+    f32x16 accq[2] = {zero16(), zero16()};   // dq_l[landmark (registers)][d (nb block, lanes)]
+    // k tile: staged through registers one step ahead (one 16-byte piece per thread); v: A fragments (rows = keys) from global
+    const int kr = tid >> 3, kc = tid & 7;
+    u32x4 rk = *reinterpret_cast<const u32x4*>(kb + ((long)h0 * HT + kr) * 3 * D + kc * 8);
+    bf16x8 vn[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) vn[i][ks] = frag_g(vb + ((long)h0 * HT + 32 * i + c) * 3 * D, 16 * ks, lane);
+    *reinterpret_cast<u32x4*>(s_k + kr * NP + kc * 8) = rk;
+    if (tid < HT) s_mr[tid] = masked ? g.mrow[(long)b * g.n_p + (long)h0 * HT + tid] : 1.f;
+    __syncthreads();
+    const int kb2 = wave & 1, dhalf = (wave >> 1) & 1, isk = wave >> 2;      // phase 2 roles: keys 32 kb2 .., channels 32 dhalf .., dv (0) / dk (1)
+    const bf16_t* a_img = isk ? s_ql : s_g;
+    const bf16_t* b_img = isk ? s_ds : s_p;
+#pragma unroll 1
+    for (int ht = h0; ht < h1; ht++) {
+        bf16x8 vf[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) vf[i][ks] = vn[i][ks];
+        const bool more = ht + 1 < h1;
+        if (more) {
+            rk = *reinterpret_cast<const u32x4*>(kb + ((long)(ht + 1) * HT + kr) * 3 * D + kc * 8);
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) vn[i][ks] = frag_g(vb + ((long)(ht + 1) * HT + 32 * i + c) * 3 * D, 16 * ks, lane);
+        }
+        // ---- phase 1: this wave's 32 landmarks against the step's 64 keys
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            f32x16 sb = zero16(), dp = zero16();   // S3^T[key][landmark], dP3^T[key][landmark]
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                sb = MFMA(frag_kc(s_k, 32 * i, 16 * ks, lane), qlf[ks], sb);
+                dp = MFMA(vf[i][ks], gf[ks], dp);
+            }
+            if (masked) {
+                const f32x16 vr = rowvals16(s_mr + 32 * i, hl);
+                sb = sb * g.scale2;
+                mask_fill16(sb, vr, ml);
+                sb = fma_splat(sb, 1.f, -lsev);
+                exp2_16(sb);
+                dp = sb * fma_splat(dp, g.scale, -delv);
+                mask_zero16(dp, vr, ml);
+            } else {
+                sb = fma_splat(sb, g.scale2, -lsev);
+                exp2_16(sb);
+                dp = sb * fma_splat(dp, g.scale, -delv);
+            }
+            const bf16x8 p0 = pack8<0>(sb), p1 = pack8<1>(sb), d0 = pack8<0>(dp), d1 = pack8<1>(dp);
+            // dS^T in the accumulator layout IS dS as an A operand (row = landmark = lane, k = keys)
+#pragma unroll
+            for (int nb = 0; nb < 2; nb++) {
+                accq[nb] = MFMA(d0, frag_tr(s_k, 32 * nb, 32 * i, lane), accq[nb]);
+                accq[nb] = MFMA(d1, frag_tr(s_k, 32 * nb, 32 * i + 16, lane), accq[nb]);
+            }
+            // the lane's own image row (its landmark), keys 32 i + 8 gq + 4 hl + {0..3}: packed element 4 gq + e of p0 | p1 is
+            // accumulator register 4 gq + e = key 8 gq + 4 hl + e
+            bf16_t* prow = s_p + lq * NP + 32 * i + 4 * hl;
+            bf16_t* drow = s_ds + lq * NP + 32 * i + 4 * hl;
+            const u32x4 pw0 = __builtin_bit_cast(u32x4, p0), pw1 = __builtin_bit_cast(u32x4, p1);
+            const u32x4 dw0 = __builtin_bit_cast(u32x4, d0), dw1 = __builtin_bit_cast(u32x4, d1);
+            *reinterpret_cast<u32x2*>(prow) = u32x2{pw0[0], pw0[1]};
+            *reinterpret_cast<u32x2*>(prow + 8) = u32x2{pw0[2], pw0[3]};
+            *reinterpret_cast<u32x2*>(prow + 16) = u32x2{pw1[0], pw1[1]};
+            *reinterpret_cast<u32x2*>(prow + 24) = u32x2{pw1[2], pw1[3]};
+            *reinterpret_cast<u32x2*>(drow) = u32x2{dw0[0], dw0[1]};
+            *reinterpret_cast<u32x2*>(drow + 8) = u32x2{dw0[2], dw0[3]};
+            *reinterpret_cast<u32x2*>(drow + 16) = u32x2{dw1[0], dw1[1]};
+            *reinterpret_cast<u32x2*>(drow + 24) = u32x2{dw1[2], dw1[3]};
+        }
+        __syncthreads();      // the images are complete; nobody reads s_k / s_mr any more
+        // ---- phase 2: one of dv^T / dk^T, keys 32 kb2 .., channels 32 dhalf .., over all 256 landmarks; the next k tile moves in beside it
+        if (more) {
+            *reinterpret_cast<u32x4*>(s_k + kr * NP + kc * 8) = rk;
+            if (tid < HT) s_mr[tid] = masked ? g.mrow[(long)b * g.n_p + (long)(ht + 1) * HT + tid] : 1.f;
+        }
+        f32x16 a2 = zero16();      // dv^T or dk^T [d][key]
+#pragma unroll
+        for (int t = 0; t < NM / 16; t++) a2 = MFMA(frag_tr(a_img, 32 * dhalf, 16 * t, lane), frag_tr(b_img, 32 * kb2, 16 * t, lane), a2);
+        store_row8(dqkv + ((long)b * g.n_p + (long)ht * HT + 32 * kb2 + c) * 3 * D + (isk ? D : 2 * D) + hd * ND + 32 * dhalf, a2, hl);
+        __syncthreads();      // the images may be overwritten; the next k tile is in place
+    }
+    float* dqb = dlm + (long)b * NM * 2 * D + hd * ND;
+#pragma unroll
+    for (int nb = 0; nb < 2; nb++) atomic_tile(dqb + (long)(32 * wave) * 2 * D + 32 * nb, 2 * D, accq[nb], hl, c);
+}
+
 // workgroups per (b, h) of the sequence-walking N kernels: enough to put two workgroups on every CU (the landmark images
 // take 72 KB of LDS each), never more than one 32-row block per wave
 int pick_walkers(int BH, int n_p) {
@@ -949,28 +1165,30 @@ int check_geo(const char* fn, int B, int h, int n_p, int m, int dh) {
 }  // namespace
 
 extern "C" int mh_nys_attn1_fwd(const void* qkv, const void* lm, const void* w2, void* out, float* lse1, const float* mrow,
-                                const float* mlm, int B, int h, int n_p, int m, int dh, float scale, int accumulate, int64_t lm_ld, mh_stream s) {
+                                const float* mlm, int B, int h, int n_p, int m, int dh, float scale, int accumulate, int64_t lm_ld, void* o1,
+                                mh_stream s) {
     if (int e = check_geo("mh_nys_attn1_fwd", B, h, n_p, m, dh)) return e;
     MH_REQUIRE(lm_ld == 0 || (lm_ld >= 2L * h * ND && lm_ld % 8 == 0), "mh_nys_attn1_fwd: lm_ld must be 0 or a multiple of 8 >= 2 D");
     if (B == 0) return MH_OK;
     MH_REQUIRE((mrow == nullptr) == (mlm == nullptr), "mh_nys_attn1_fwd: mrow and mlm go together");
-    const Geo g{h, n_p, h * ND, scale, scale * LOG2E, mrow, mlm, accumulate, lm_ld > 0 ? lm_ld : 2L * h * ND};
+    const Geo g{h, n_p, h * ND, scale, scale * LOG2E, mrow, mlm, accumulate, lm_ld > 0 ? lm_ld : 2L * h * ND, nullptr, nullptr};
+    MH_REQUIRE((((uintptr_t)o1) & 15) == 0, "mh_nys_attn1_fwd: o1 must be 16-byte aligned");
     NYS_LAUNCH(nys_a1_fwd_kernel, dim3(pick_walkers(B * h, n_p), B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv, (const bf16_t*)lm,
-                       (const bf16_t*)w2, (bf16_t*)out, lse1, g, Q8Out{});
+                       (const bf16_t*)w2, (bf16_t*)out, lse1, g, Q8Out{}, (bf16_t*)o1);
     MH_LAUNCH_CHECK("mh_nys_attn1_fwd");
     return MH_OK;
 }
 
 extern "C" int mh_nys_attn1_fwd_q8(const void* qkv, const void* lm, const void* w2, void* out, float* lse1, int B, int h, int n_p, int m,
                                    int dh, float scale, int accumulate, void* q8, unsigned* ring, const float* tick, float margin,
-                                   float* q8_scale, mh_stream s) {
+                                   float* q8_scale, void* o1, mh_stream s) {
     if (int e = check_geo("mh_nys_attn1_fwd_q8", B, h, n_p, m, dh)) return e;
     if (B == 0) return MH_OK;
     MH_REQUIRE(q8 && ring && tick && q8_scale && margin >= 1.f && ((uintptr_t)q8 & 3) == 0, "mh_nys_attn1_fwd_q8: q8, ring, tick, scale and margin >= 1");
-    const Geo g{h, n_p, h * ND, scale, scale * LOG2E, nullptr, nullptr, accumulate, 2L * h * ND};
+    const Geo g{h, n_p, h * ND, scale, scale * LOG2E, nullptr, nullptr, accumulate, 2L * h * ND, nullptr, nullptr};
     const Q8Out o{(unsigned char*)q8, ring, tick, margin, q8_scale};
     hipLaunchKernelGGL((nys_a1_fwd_kernel<false, true>), dim3(pick_walkers(B * h, n_p), B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv,
-                       (const bf16_t*)lm, (const bf16_t*)w2, (bf16_t*)out, lse1, g, o);
+                       (const bf16_t*)lm, (const bf16_t*)w2, (bf16_t*)out, lse1, g, o, (bf16_t*)o1);
     MH_LAUNCH_CHECK("mh_nys_attn1_fwd_q8");
     return MH_OK;
 }
@@ -986,18 +1204,27 @@ extern "C" int64_t mh_nys_attn3_ws_floats(int B, int h, int n_p) {
 extern "C" int64_t mh_nys_attn3_workspace_bytes(int B, int h, int n_p) { return 4 * mh_nys_attn3_ws_floats(B, h, n_p); }
 
 extern "C" int mh_nys_attn3_fwd(const void* qkv, const void* lm, float* av, float* lse3, float* workspace, int64_t ws_floats,
-                                const float* mrow, const float* mlm, int B, int h, int n_p, int m, int dh, float scale, int64_t lm_ld, mh_stream s) {
+                                const float* mrow, const float* mlm, int B, int h, int n_p, int m, int dh, float scale, int64_t lm_ld,
+                                const float* rc_w, void* rc_out, mh_stream s) {
     if (int e = check_geo("mh_nys_attn3_fwd", B, h, n_p, m, dh)) return e;
     MH_REQUIRE(lm_ld == 0 || (lm_ld >= 2L * h * ND && lm_ld % 8 == 0), "mh_nys_attn3_fwd: lm_ld must be 0 or a multiple of 8 >= 2 D");
+    MH_REQUIRE((rc_w == nullptr) == (rc_out == nullptr) && (((uintptr_t)rc_out) & 15) == 0, "mh_nys_attn3_fwd: rc_w and rc_out (16-byte aligned) go together");
     if (B == 0) return MH_OK;
-    const Geo g{h, n_p, h * ND, scale, scale * LOG2E, mrow, mlm, 0, lm_ld > 0 ? lm_ld : 2L * h * ND};
+    const Geo g{h, n_p, h * ND, scale, scale * LOG2E, mrow, mlm, 0, lm_ld > 0 ? lm_ld : 2L * h * ND, rc_w, (bf16_t*)rc_out};
     const int ntiles = n_p / TR;
     int splits = pick_splits(B * h, ntiles, 0);
     if (!workspace || ws_floats < (int64_t)B * h * splits * A3_PART) splits = 1;      // no room for partials: one workgroup per (b, h)
     const int tpw = (ntiles + splits - 1) / splits;
     splits = (ntiles + tpw - 1) / tpw;                                                 // no empty ranges
-    NYS_LAUNCH(nys_a3_fwd_kernel, dim3(splits, B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv, (const bf16_t*)lm, av,
-                       lse3, workspace, g, tpw);
+    if (rc_w) {
+        if (g.mrow) hipLaunchKernelGGL((nys_a3_fwd_kernel<true, true>), dim3(splits, B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv,
+                                       (const bf16_t*)lm, av, lse3, workspace, g, tpw);
+        else hipLaunchKernelGGL((nys_a3_fwd_kernel<false, true>), dim3(splits, B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv,
+                                (const bf16_t*)lm, av, lse3, workspace, g, tpw);
+    } else {
+        NYS_LAUNCH(nys_a3_fwd_kernel, dim3(splits, B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv, (const bf16_t*)lm, av,
+                           lse3, workspace, g, tpw);
+    }
     MH_LAUNCH_CHECK("mh_nys_attn3_fwd");
     if (splits > 1) {
         hipLaunchKernelGGL(nys_a3_combine_kernel, dim3(ND / 16, B * h), dim3(NM), 0, (hipStream_t)s, (const float*)workspace, av, lse3,
@@ -1017,31 +1244,48 @@ int pick_splits(int BH, int ntiles, int which) {
     return splits;
 }
 
-extern "C" int mh_nys_attn1_bwd(const void* qkv, const void* lm, const void* w2, const void* dout, const float* lse1,
+extern "C" int mh_nys_attn1_bwd(const void* qkv, const void* lm, const void* w2, const void* dout, const float* lse1, const void* o1,
                                 float* delta1, void* dqkv, float* dw2, float* dlm, const float* mrow, const float* mlm, int B, int h,
-                                int n_p, int m, int dh, float scale, int64_t lm_ld, mh_stream s) {
+                                int n_p, int m, int dh, float scale, int64_t lm_ld, int which, mh_stream s) {
     if (int e = check_geo("mh_nys_attn1_bwd", B, h, n_p, m, dh)) return e;
     MH_REQUIRE(lm_ld == 0 || (lm_ld >= 2L * h * ND && lm_ld % 8 == 0), "mh_nys_attn1_bwd: lm_ld must be 0 or a multiple of 8 >= 2 D");
+    MH_REQUIRE(which >= 1 && which <= 3, "mh_nys_attn1_bwd: which = 1 (dw2, dk_l, delta1), 2 (dq from delta1) or 3 (both, in that order)");
+    MH_REQUIRE(delta1 && (!(which & 1) || (o1 && dw2 && dlm && (((uintptr_t)o1) & 15) == 0)) && (!(which & 2) || dqkv),
+               "mh_nys_attn1_bwd: missing buffer for the requested part");
     if (B == 0) return MH_OK;
-    const Geo g{h, n_p, h * ND, scale, scale * LOG2E, mrow, mlm, 0, lm_ld > 0 ? lm_ld : 2L * h * ND};
-    NYS_LAUNCH(nys_a1_bwd_dq_kernel, dim3(pick_walkers(B * h, n_p), B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv,
-                       (const bf16_t*)lm, (const bf16_t*)w2, (const bf16_t*)dout, lse1, delta1, (bf16_t*)dqkv, g);
-    MH_LAUNCH_CHECK("mh_nys_attn1_bwd(dq)");
-    const int ntiles = n_p / TR, splits = pick_splits(B * h, ntiles, 1), tpw = (ntiles + splits - 1) / splits;
-    NYS_LAUNCH(nys_a1_bwd_dw_kernel, dim3(splits, B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv,
-                       (const bf16_t*)lm, (const bf16_t*)w2, (const bf16_t*)dout, lse1, (const float*)delta1, dw2, dlm, g, tpw);
-    MH_LAUNCH_CHECK("mh_nys_attn1_bwd(dw)");
+    const Geo g{h, n_p, h * ND, scale, scale * LOG2E, mrow, mlm, 0, lm_ld > 0 ? lm_ld : 2L * h * ND, nullptr, nullptr};
+    if (which & 1) {
+        const int ntiles = n_p / TR, splits = pick_splits(B * h, ntiles, 1), tpw = (ntiles + splits - 1) / splits;
+        NYS_LAUNCH(nys_a1_bwd_dw_kernel, dim3(splits, B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv,
+                           (const bf16_t*)lm, (const bf16_t*)w2, (const bf16_t*)dout, lse1, (const bf16_t*)o1, delta1, dw2, dlm, g, tpw);
+        MH_LAUNCH_CHECK("mh_nys_attn1_bwd(dw)");
+    }
+    if (which & 2) {
+        NYS_LAUNCH(nys_a1_bwd_dq_kernel, dim3(pick_walkers(B * h, n_p), B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv,
+                           (const bf16_t*)lm, (const bf16_t*)w2, (const bf16_t*)dout, lse1, (const float*)delta1, (bf16_t*)dqkv, g);
+        MH_LAUNCH_CHECK("mh_nys_attn1_bwd(dq)");
+    }
     return MH_OK;
 }
 
 extern "C" int mh_nys_attn3_bwd(const void* qkv, const void* lm, const float* av, const void* dav, const float* lse3, float* delta3,
                                 void* dqkv, float* dlm, const float* mrow, const float* mlm, int B, int h, int n_p, int m, int dh,
-                                float scale, int64_t lm_ld, mh_stream s) {
+                                float scale, int64_t lm_ld, int one_pass, mh_stream s) {
     if (int e = check_geo("mh_nys_attn3_bwd", B, h, n_p, m, dh)) return e;
     MH_REQUIRE(lm_ld == 0 || (lm_ld >= 2L * h * ND && lm_ld % 8 == 0), "mh_nys_attn3_bwd: lm_ld must be 0 or a multiple of 8 >= 2 D");
     if (B == 0) return MH_OK;
-    const Geo g{h, n_p, h * ND, scale, scale * LOG2E, mrow, mlm, 0, lm_ld > 0 ? lm_ld : 2L * h * ND};
+    const Geo g{h, n_p, h * ND, scale, scale * LOG2E, mrow, mlm, 0, lm_ld > 0 ? lm_ld : 2L * h * ND, nullptr, nullptr};
     if (av) hipLaunchKernelGGL(nys_delta3_kernel, dim3(B * h), dim3(NM), 0, (hipStream_t)s, av, (const bf16_t*)dav, delta3);
+    if (one_pass) {
+        const int nsteps = n_p / HT;
+        int splits = 1;
+        while (B * h * splits < 256 && splits * 2 <= nsteps) splits *= 2;
+        const int spw = (nsteps + splits - 1) / splits;
+        NYS_LAUNCH(nys_a3_bwd_one_kernel, dim3((nsteps + spw - 1) / spw, B * h), dim3(NT8), 0, (hipStream_t)s, (const bf16_t*)qkv,
+                           (const bf16_t*)lm, (const float*)delta3, (const bf16_t*)dav, lse3, (bf16_t*)dqkv, dlm, g, spw);
+        MH_LAUNCH_CHECK("mh_nys_attn3_bwd(one pass)");
+        return MH_OK;
+    }
     NYS_LAUNCH(nys_a3_bwd_dkv_kernel, dim3(pick_walkers(B * h, n_p), B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv,
                        (const bf16_t*)lm, (const float*)delta3, (const bf16_t*)dav, lse3, (bf16_t*)dqkv, g);
     MH_LAUNCH_CHECK("mh_nys_attn3_bwd(dkv)");

@@ -467,7 +467,7 @@ __global__ __launch_bounds__(CT) void pinv_panel_fwd_kernel(const bf16_t* __rest
 // and when operands arrive: a product's result leaves the accumulators for HBM + the LDS image directly (finish_out), so the panel
 // registers are free to receive the NEXT product's B operand entry by entry behind this product's k sweep (panel_gemm<.., PF>), and a
 // B operand that two consecutive products share (P in V2 = -V3 P and V2 P) is loaded once.  Of the 8 panel loads per iteration that
-// stood exposed in front of their product, one is left (X, after the epilogue that still needs V2 in the panel registers).
+// stood exposed in front of their product, two are left (V2 for the W epilogue, and X after it).
 __global__ __launch_bounds__(CT) void pinv_panel_bwd2_kernel(const bf16_t* __restrict__ XT, const bf16_t* __restrict__ saved,
                                                              const bf16_t* __restrict__ dzf, bf16_t* __restrict__ work,
                                                              float* __restrict__ dX, float* __restrict__ dz0, int BH, int iters) {
@@ -515,7 +515,13 @@ __global__ __launch_bounds__(CT) void pinv_panel_bwd2_kernel(const bf16_t* __res
         panel_gemm<false, true>(acc, img, rlo, rhi, p, V3, wave, lane);                   // + P V2 (image P, panel V2; V3 arrives)
         negate_panel(p);
         image_swap<true>(img, T2, tid);
-        panel_gemm<false, true>(acc, img, rlo, rhi, p, V2, wave, lane);                   // - T2 V3 (image T2, panel -V3; V2 arrives for the epilogue)
+        // V2 (the epilogue's addend) is requested BEHIND this product (round 5).  Requested entry by entry behind the k sweep (round 3's
+        // form) the compiler found no registers for 7 of the 32 entries while the epilogue's temporaries are live: it waited for each of
+        // them on the spot (s_waitcnt vmcnt(0) inside the MFMA loop) and parked it in scratch — 28 of the kernel's 48 spilled VGPRs,
+        // 196 -> 84 B of scratch per lane (what is left: 17 loop-invariant address registers stored once, reloaded once per iteration).
+        // Alone on the chip 459-468 -> 443-446 us (profiles/r05_a_chain_bwd_w_epilogue_spill.txt)
+        panel_gemm<false, false>(acc, img, rlo, rhi, p);                                  // - T2 V3 (image T2, panel -V3)
+        load_panel(p, V2, wave, lane);
         __syncthreads();
         finish_out<true, true>(acc, 4.f, 0.f, p, -28.f, W, img, wave, dreg, j, hl, lane);  // 4 W (exact in bf16)
         load_panel(p, Xb, wave, lane);                                                    // the one panel load left in front of its product

@@ -455,6 +455,7 @@ class TrainEngine:
             Fn.probe("loss_done")
             losses[0].backward(self._one)        # a persistent root gradient: no ones_like fill launch per step
             Fn.pending_lm_merge_reset("TrainEngine.step (after backward)", strict=True)
+            Fn.flush_deferred_bwd()
             if defer:
                 with torch.cuda.stream(Fn._side_stream(self.device, 1)):
                     Fn.probe("side_bwd_end")

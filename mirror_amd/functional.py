@@ -733,8 +733,26 @@ class LinearRowsFn(Function):
         return dx, dw, db, None, None, None, None
 
 
-def _linear_rows_bwd(ctx_needs, x, wa, w, b, r0, R, prec, dy, dx_dtype=None):
-    """Backward of y = x[:, r0:r0+R] @ W^T + b given dy [B, R, N] in the activation dtype: (dx over all of x's rows, dW, db)."""
+_TO_OUT_WGRAD_IN_WINDOW = os.environ.get("MIRROR_TO_OUT_WGRAD_WINDOW", "1") != "0"      # (A/B switch of the round-5 window rebalance)
+_deferred_bwd: dict = {}    # data_ptr of a data gradient -> a weight-gradient launch that its consumer runs where it has idle CUs
+
+
+def run_deferred_bwd(dx: torch.Tensor) -> None:
+    t = _deferred_bwd.pop(dx.data_ptr(), None)
+    if t is not None:
+        t()
+
+
+def flush_deferred_bwd() -> None:
+    """Launch whatever nobody claimed (a to_out whose data gradient did not reach a NystromCoreFn.backward): never lose a gradient."""
+    while _deferred_bwd:
+        _deferred_bwd.popitem()[1]()
+
+
+def _linear_rows_bwd(ctx_needs, x, wa, w, b, r0, R, prec, dy, dx_dtype=None, defer_wgrad=False):
+    """Backward of y = x[:, r0:r0+R] @ W^T + b given dy [B, R, N] in the activation dtype: (dx over all of x's rows, dW, db).
+    defer_wgrad: when the weight gradient goes straight into the gradient sink, its launch is left to whoever consumes dx
+    (run_deferred_bwd(dx)): NystromCoreFn.backward issues to_out's weight gradient beside the half-chip pinv chain."""
     N, Kd = wa.shape
     dx = dw = db = None
     if ctx_needs[0]:
@@ -751,8 +769,17 @@ def _linear_rows_bwd(ctx_needs, x, wa, w, b, r0, R, prec, dy, dx_dtype=None):
                 dx[:, r0 + R:].zero_()
     if ctx_needs[1]:
         dw, sunk = _gbuf(w, (N, Kd))
-        _wgrad(dy, x[:, r0:r0 + R], N, Kd, prec, dw)
-        dw = _gret(w, dw, sunk)
+        if defer_wgrad and sunk and dx is not None and _TO_OUT_WGRAD_IN_WINDOW:
+            dwb = dw
+
+            def later():
+                _wgrad(dy, x[:, r0:r0 + R], N, Kd, prec, dwb)
+                _gret(w, dwb, True)
+            _deferred_bwd[dx.data_ptr()] = later
+            dw = None
+        else:
+            _wgrad(dy, x[:, r0:r0 + R], N, Kd, prec, dw)
+            dw = _gret(w, dw, sunk)
     if b is not None and ctx_needs[2]:
         db, sunk = _gbuf(b, (N,))
         K.colsum(dy.reshape(-1, N), db)
@@ -811,7 +838,7 @@ class ToOutDropAddFn(Function):
         needs = list(ctx.needs_input_grad[1:4])
         if fused_db:
             needs[2] = False
-        dcore, dw, db = _linear_rows_bwd(needs, core, wa, w, b, ctx.r0, ctx.R, ctx.prec, gb)
+        dcore, dw, db = _linear_rows_bwd(needs, core, wa, w, b, ctx.r0, ctx.R, ctx.prec, gb, defer_wgrad=True)
         if fused_db:
             db = db_done
         return dy, dcore, dw, db, None, None, None, None
@@ -1595,6 +1622,8 @@ def pending_lm_merge_reset(where: str, strict: bool = False) -> None:
                                    "NystromCoreFn.backward)")
 _W2_ON_CHAIN = True      # (test hook) w2 = pinv (attn3 v) at the end of the chain's branch instead of behind the join (-0.22 % +- 0.06)
 _DZ_DAV = True      # (test hook)
+_RC_FUSED = True      # (test hook) res_conv inside attn3's forward launch, its two gradients as one pass over dout (round 5)
+_A1_DQ_IN_WINDOW = os.environ.get("MIRROR_A1_DQ_WINDOW", "1") != "0"      # (A/B switch, round 5) attn1's dq kernel beside the pinv chain's backward
 # (measured and deleted in round 4, see DESIGN.md section 6 round 3: nys_dz_dav on the chain's branch +0.32 %, attn3's delta out of
 #  nys_dz_dav +0.32 %, the chain branch joined in front of the landmark projection's backward +0.02 %, res_conv's weight gradient on
 #  the chain's stream +0.26 % or in front of the fork: neutral)
@@ -1677,8 +1706,12 @@ class NystromCoreFn(Function):
         run_deferred(qkv)        # the v columns of to_qkv: nothing above reads them (landmarks are means of q and k)
         fused = K.nys_fused_ok(qkv, h, m_l) and lm.dtype == bf16      # nystrom_fused.hip: sim1 / sim3 never reach HBM (mask-aware)
         lse1 = lse3 = a1 = a3 = None
+        out = torch.empty((Bn, n_p, D), device=qkv.device, dtype=A)
+        rc_in_a3 = fused and _RC_FUSED and A == bf16 and res_w.numel() == h * 33
         if fused:
-            av, lse3 = K.nys_attn3_fwd(qkv, lm, h, scale, kmask)                         # [B,h,m,dh] f32
+            # res_conv(v) rides on attn3's forward (it stages the v tiles anyway): no launch of its own, no second read of v
+            av, lse3 = K.nys_attn3_fwd(qkv, lm, h, scale, kmask,
+                                       rc=(res_w.detach().reshape(-1).contiguous(), out) if rc_in_a3 else None)   # [B,h,m,dh] f32
         else:
             # sim1's rows (length m) fit one 192 x 384 tile at the template's m = 384: the softmax runs in that GEMM's epilogue
             sm1 = (kmask is None and A == bf16 and mma == MH_BF16 and q.dtype == bf16
@@ -1702,7 +1735,6 @@ class NystromCoreFn(Function):
             zf, saved, st = pinv_forward(a2, iters, pm, sd)
         if not fused:
             av = K.gemm(a3, v, mma=mma, out_dtype=f32)                                   # [B,h,m,dh]
-        out = torch.empty((Bn, n_p, D), device=qkv.device, dtype=A)
         # GEMMs that meet activation-dtype tensors cannot use the exact-f32 MFMA unless the activations are f32 too
         pio = pm if (pm == MH_BF16 or A == f32) else mma
         w2 = None
@@ -1715,29 +1747,33 @@ class NystromCoreFn(Function):
             with torch.cuda.stream(side):
                 side.wait_event(av_ready)
                 K.gemm(zf, av, out=w2, mma=pio)
-        if fused:   # res_conv(v) does not need the pseudo-inverse: it runs under the chain, attn1 then adds to it
+        if fused and not rc_in_a3:   # res_conv(v) does not need the pseudo-inverse: it runs under the chain, attn1 then adds to it
             K.resconv(qkv[..., 2 * D:], res_w.detach().contiguous(), out, h, transpose=False, accumulate=False)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
             K.shared_chip = False
         if w2 is None:
             w2 = K.gemm(zf, av, mma=pio, out_dtype=A)
+        o1 = None
         if fused:
+            # attn1's own rows (without res_conv's), kept for the backward: delta[n] = sum_d dO[n, d] o1[n, d] there
+            o1 = torch.empty_like(out)
             # fp8 forward policy: once to_out's call site has a scale history, attn1 also writes the e4m3 copy that projection reads
             st8 = _fp8_state
             site = st8["sites"].get(q8_key) if (q8_key is not None and st8["tick"] is not None and kmask is None) else None
             if site is not None and st8["host_step"] - site[1] >= 2 and _LN_Q8:
                 q8 = torch.empty(out.shape, device=out.device, dtype=torch.uint8)
-                lse1, sc8 = K.nys_attn1_fwd_q8(qkv, lm, w2, out, h, scale, True, q8, site[0], st8["tick"])
+                lse1, sc8 = K.nys_attn1_fwd_q8(qkv, lm, w2, out, h, scale, True, q8, site[0], st8["tick"], o1=o1)
                 _prequant[out.data_ptr()] = (q8, sc8)
             else:
-                lse1 = K.nys_attn1_fwd(qkv, lm, w2, out, h, scale, accumulate=True, kmask=kmask)
+                lse1 = K.nys_attn1_fwd(qkv, lm, w2, out, h, scale, accumulate=True, kmask=kmask, o1=o1)
         else:
             K.gemm(a1, w2, out=_heads(out, 0, 1, h), mma=mma)
             K.resconv(qkv[..., 2 * D:], res_w.detach().contiguous(), out, h, transpose=False, accumulate=True)
         stats = (lse1, lse3) if fused else (a1, a3)
+        ctx.has_o1 = o1 is not None
         ctx.save_for_backward(qkv, res_w, lm, stats[0], a2, stats[1], av, w2, st, zfT if chain else zf,
-                              *[t for it in saved for t in it])
+                              *([o1] if o1 is not None else []), *[t for it in saved for t in it])
         ctx.cfg = (heads, l, prec)
         ctx.chain = (chain, iters, fused)
         ctx.tile = tile
@@ -1747,6 +1783,9 @@ class NystromCoreFn(Function):
     @staticmethod
     def backward(ctx, dout):
         qkv, res_w, lm, a1, a2, a3, av, w2, st, zf, *flat = ctx.saved_tensors
+        o1 = None
+        if ctx.has_o1:
+            o1, flat = flat[0], flat[1:]
         chain, iters, fused = ctx.chain
         kmask = ctx.kmask
         if kmask is not None:
@@ -1786,7 +1825,11 @@ class NystromCoreFn(Function):
             lse1, lse3 = a1, a3
             dW2 = zeros((Bn, h, m, dh), qkv.device)
             dlm = zeros((Bn, m, 2 * D), qkv.device)
-            K.nys_attn1_bwd(qkv, lm, w2, dout, lse1, dqkv, dW2, dlm, h, scale, kmask)   # dq, dW2, dk_l
+            delta1 = torch.empty_like(lse1)
+            # dW2 and dk_l (+ delta1 from the saved rows of attn1): all the chain's backward waits for.  dq follows BESIDE the chain
+            K.nys_attn1_bwd(qkv, lm, w2, dout, lse1, o1, delta1, dqkv, dW2, dlm, h, scale, kmask, which=1)
+            if not (chain and _A1_DQ_IN_WINDOW):
+                K.nys_attn1_bwd(qkv, lm, w2, dout, lse1, o1, delta1, dqkv, dW2, dlm, h, scale, kmask, which=2)
         else:
             dW2 = K.gemm(tr(a1), dO, mma=mma, out_dtype=f32)                             # [B,h,m,dh]
             dlm = torch.empty((Bn, m, 2 * D), device=qkv.device, dtype=f32)
@@ -1826,12 +1869,20 @@ class NystromCoreFn(Function):
                     K.gemm(tr(dS2), ql, out=_heads(dlm2, 1, 2, h), alpha=scale, mma=pio)
                     K.gemm(dS2, kl, out=_heads(dlm2, 0, 2, h), alpha=scale, mma=pio)
             K.shared_chip = True         # until the join below
-        K.resconv_wgrad(qkv[..., 2 * D:], dout, dres, h)
+        run_deferred_bwd(dout)      # to_out's weight gradient (ToOutDropAddFn left it to us): beside the chain when there is one
+        if fused and chain and _A1_DQ_IN_WINDOW:
+            K.nys_attn1_bwd(qkv, lm, w2, dout, lse1, o1, delta1, dqkv, dW2, dlm, h, scale, kmask, which=2)     # dq: beside the chain
+        rc_bwd_one = fused and _RC_FUSED and A == bf16      # both res_conv gradients in ONE pass over dout, behind attn3's backward
+        if not rc_bwd_one:
+            K.resconv_wgrad(qkv[..., 2 * D:], dout, dres, h)
         if dAV is None:
             dAV = K.gemm(tr(zf), dW2, mma=pio, out_dtype=A)                              # [B,h,m,dh]
         if fused:
             K.nys_attn3_bwd(qkv, lm, av, dAV, lse3, dqkv, dlm, h, scale, kmask)          # dk, dv, dq_l
-            K.resconv(dout, rw, dqkv[..., 2 * D:], h, transpose=True, accumulate=True)
+            if rc_bwd_one:
+                K.resconv_bwd(dout, qkv[..., 2 * D:], rw, dqkv[..., 2 * D:], dres, h)
+            else:
+                K.resconv(dout, rw, dqkv[..., 2 * D:], h, transpose=True, accumulate=True)
         else:
             if (kmask is None and A == bf16 and mma == MH_BF16 and a1.dtype == bf16 and a1.is_contiguous()
                     and K.gemm_softmax_ok(n_p, m, dh, dO.dtype, w2.dtype)):

@@ -6,6 +6,7 @@ node down) and launches on torch's current stream.  There is no CPU / PyTorch fa
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 
@@ -761,6 +762,22 @@ def resconv_wgrad(v_src: torch.Tensor, dout: torch.Tensor, dw: torch.Tensor, hea
               _p(dw), B, n_p, heads, Cc // heads, taps, dt(v_src), dt(dout), stream=_stream())
 
 
+def resconv_bwd(dout: torch.Tensor, v_src: torch.Tensor, w: torch.Tensor, dv: torch.Tensor, dw: torch.Tensor, heads: int) -> None:
+    """Both gradients of res_conv in one pass over dout (mh_resconv_bwd): dv += conv^T(dout), dw += the tap gradient.  dout / v_src /
+    dv: [B, n_p, C] views with unit last stride (v_src, dv: the v column blocks of qkv / d qkv); dw f32 [heads * taps]."""
+    _chk(dout, v_src, w, dv, dw)
+    B, n_p, Cc = v_src.shape
+    if (tuple(dout.shape) != (B, n_p, Cc) or tuple(dv.shape) != (B, n_p, Cc) or v_src.stride(2) != 1 or dout.stride(2) != 1 or dv.stride(2) != 1
+            or dw.dtype != torch.float32 or dv.dtype != v_src.dtype):
+        raise MirrorHipError("resconv_bwd: bad views")
+    taps = dw.numel() // heads
+    nbytes = int(_lib.load().mh_resconv_bwd_workspace_bytes(B, n_p, heads, Cc // heads, taps))
+    ws = torch.empty((max(nbytes // 4, 1),), device=dout.device, dtype=torch.float32)
+    _lib.call("mh_resconv_bwd", _p(dout), dout.stride(1), dout.stride(0), _p(v_src), v_src.stride(1), v_src.stride(0),
+              _p(_contig(w, "res_conv weight")), _p(dv), dv.stride(1), dv.stride(0), _p(dw), _p(ws), nbytes // 4, B, n_p, heads, Cc // heads, taps,
+              dt(v_src), dt(dout), stream=_stream())
+
+
 def pinv_absmax(x: torch.Tensor, stats: Optional[torch.Tensor] = None) -> torch.Tensor:
     """stats: optional zeroed int64[2] (the caller's pre-zeroed arena saves the fill launch)."""
     _chk(x)
@@ -972,7 +989,7 @@ def _nys_check(name: str, B: int, h: int, n_p: int, **tensors) -> None:
             "lm": ((B, NYS_FUSED_M, 2 * D), torch.bfloat16), "dlm": ((B, NYS_FUSED_M, 2 * D), torch.float32),
             "w2": ((B, h, NYS_FUSED_M, NYS_FUSED_DH), torch.bfloat16), "dw2": ((B, h, NYS_FUSED_M, NYS_FUSED_DH), torch.float32),
             "av": ((B, h, NYS_FUSED_M, NYS_FUSED_DH), torch.float32), "dav": ((B, h, NYS_FUSED_M, NYS_FUSED_DH), torch.bfloat16),
-            "out": ((B, n_p, D), torch.bfloat16), "dout": ((B, n_p, D), torch.bfloat16),
+            "out": ((B, n_p, D), torch.bfloat16), "dout": ((B, n_p, D), torch.bfloat16), "o1": ((B, n_p, D), torch.bfloat16),
             "lse1": ((B, h, n_p), torch.float32), "delta1": ((B, h, n_p), torch.float32),
             "lse3": ((B, h, NYS_FUSED_M), torch.float32)}
     for k, t in tensors.items():
@@ -1010,19 +1027,20 @@ def _nys_masks(kmask, B: int, n_p: int):
     return _p(mrow), _p(mlm)
 
 
-def nys_attn1_fwd(qkv, lm, w2, out, heads: int, scale: float, accumulate: bool = False, kmask=None) -> torch.Tensor:
-    """out[:, :, head] (+)= softmax_m(scale q k_l^T) w2; returns the row logsumexp [B, h, n_p].  kmask: key-padding mask."""
-    _chk(qkv, lm, w2, out)
+def nys_attn1_fwd(qkv, lm, w2, out, heads: int, scale: float, accumulate: bool = False, kmask=None, o1=None) -> torch.Tensor:
+    """out[:, :, head] (+)= softmax_m(scale q k_l^T) w2; returns the row logsumexp [B, h, n_p].  kmask: key-padding mask.
+    o1: optional bf16 buffer shaped like out that receives the product alone (what nys_attn1_bwd takes delta1 from)."""
+    _chk(qkv, lm, w2, out, o1)
     B, n_p, _ = qkv.shape
     lse1 = torch.empty((B, heads, n_p), device=qkv.device, dtype=torch.float32)
-    _nys_check("nys_attn1_fwd", B, heads, n_p, qkv=qkv, lm=lm, w2=w2, out=out)
+    _nys_check("nys_attn1_fwd", B, heads, n_p, qkv=qkv, lm=lm, w2=w2, out=out, **({} if o1 is None else {"o1": o1}))
     _nys_launch("nys_a1_fwd_kernel", 2 * 2.0 * n_p * NYS_FUSED_M * NYS_FUSED_DH * B * heads,
                 lambda: _lib.call("mh_nys_attn1_fwd", _p(qkv), _p(lm), _p(w2), _p(out), _p(lse1), *_nys_masks(kmask, B, n_p), B, heads,
-                                  n_p, NYS_FUSED_M, NYS_FUSED_DH, scale, int(accumulate), _lm_ld(lm), stream=_stream()))
+                                  n_p, NYS_FUSED_M, NYS_FUSED_DH, scale, int(accumulate), _lm_ld(lm), _p(o1), stream=_stream()))
     return lse1
 
 
-def nys_attn1_fwd_q8(qkv, lm, w2, out, heads: int, scale: float, accumulate: bool, q8, ring, tick, margin: float = 1.25):
+def nys_attn1_fwd_q8(qkv, lm, w2, out, heads: int, scale: float, accumulate: bool, q8, ring, tick, margin: float = 1.25, o1=None):
     """nys_attn1_fwd (no mask) that also writes the e4m3 copy of `out` into q8 (uint8, out's shape) with the delayed scale of
     `ring` / `tick`; returns (lse1, dequantisation factor)."""
     _chk(qkv, lm, w2, out, q8, ring, tick)
@@ -1032,18 +1050,28 @@ def nys_attn1_fwd_q8(qkv, lm, w2, out, heads: int, scale: float, accumulate: boo
         raise MirrorHipError("nys_attn1_fwd_q8: q8 uint8 shaped like out, int32[3] ring, f32 tick")
     lse1 = torch.empty((B, heads, n_p), device=qkv.device, dtype=torch.float32)
     sc = torch.empty((1,), device=qkv.device, dtype=torch.float32)
-    _nys_check("nys_attn1_fwd", B, heads, n_p, qkv=qkv, lm=lm.contiguous(), w2=w2, out=out)
+    _chk(o1)
+    _nys_check("nys_attn1_fwd", B, heads, n_p, qkv=qkv, lm=lm.contiguous(), w2=w2, out=out, **({} if o1 is None else {"o1": o1}))
     lm = lm.contiguous()
     _nys_launch("nys_a1_fwd_kernel", 2 * 2.0 * n_p * NYS_FUSED_M * NYS_FUSED_DH * B * heads,
                 lambda: _lib.call("mh_nys_attn1_fwd_q8", _p(qkv), _p(lm), _p(w2), _p(out), _p(lse1), B, heads, n_p, NYS_FUSED_M,
-                                  NYS_FUSED_DH, scale, int(accumulate), _p(q8), _p(ring), _p(tick), float(margin), _p(sc), stream=_stream()))
+                                  NYS_FUSED_DH, scale, int(accumulate), _p(q8), _p(ring), _p(tick), float(margin), _p(sc), _p(o1),
+                                  stream=_stream()))
     return lse1, sc
 
 
-def nys_attn3_fwd(qkv, lm, heads: int, scale: float, kmask=None):
-    """av = softmax_n(scale q_l k^T) v as [B, h, m, dh] f32, and the row logsumexp [B, h, m]."""
+def nys_attn3_fwd(qkv, lm, heads: int, scale: float, kmask=None, rc=None):
+    """av = softmax_n(scale q_l k^T) v as [B, h, m, dh] f32, and the row logsumexp [B, h, m].
+    rc = (res_w f32 [h * 33] contiguous, out bf16 [B, n_p, D] contiguous): the same launch also writes out = res_conv(v)."""
     _chk(qkv, lm)
     B, n_p, _ = qkv.shape
+    rc_w = rc_out = None
+    if rc is not None:
+        rc_w, rc_out = rc
+        _chk(rc_w, rc_out)
+        if (rc_w.dtype != torch.float32 or rc_w.numel() != heads * 33 or not rc_w.is_contiguous() or rc_out.dtype != torch.bfloat16
+                or tuple(rc_out.shape) != (B, n_p, heads * NYS_FUSED_DH) or not rc_out.is_contiguous()):
+            raise MirrorHipError("nys_attn3_fwd: rc = (f32 [h * 33] filters, contiguous bf16 [B, n_p, D] output)")
     av = torch.empty((B, heads, NYS_FUSED_M, NYS_FUSED_DH), device=qkv.device, dtype=torch.float32)
     lse3 = torch.empty((B, heads, NYS_FUSED_M), device=qkv.device, dtype=torch.float32)
     _nys_check("nys_attn3_fwd", B, heads, n_p, qkv=qkv, lm=lm)
@@ -1051,24 +1079,35 @@ def nys_attn3_fwd(qkv, lm, heads: int, scale: float, kmask=None):
     ws = torch.empty((nws,), device=qkv.device, dtype=torch.float32) if nws else None
     _nys_launch("nys_a3_fwd_kernel", 2 * 2.0 * n_p * NYS_FUSED_M * NYS_FUSED_DH * B * heads,
                 lambda: _lib.call("mh_nys_attn3_fwd", _p(qkv), _p(lm), _p(av), _p(lse3), _p(ws), nws, *_nys_masks(kmask, B, n_p), B,
-                                  heads, n_p, NYS_FUSED_M, NYS_FUSED_DH, scale, _lm_ld(lm), stream=_stream()))
+                                  heads, n_p, NYS_FUSED_M, NYS_FUSED_DH, scale, _lm_ld(lm), _p(rc_w), _p(rc_out), stream=_stream()))
     return av, lse3
 
 
-def nys_attn1_bwd(qkv, lm, w2, dout, lse1, dqkv, dw2, dlm, heads: int, scale: float, kmask=None) -> None:
-    """Writes the q block of dqkv; ADDS into dw2 and into the k_l half of dlm (both f32, zeroed by the caller)."""
-    _chk(qkv, lm, w2, dout, lse1, dqkv, dw2, dlm)
+def nys_attn1_bwd(qkv, lm, w2, dout, lse1, o1, delta1, dqkv, dw2, dlm, heads: int, scale: float, kmask=None, which: int = 3) -> None:
+    """attn1's backward in two parts (mh_nys_attn1_bwd): which & 1 — ADDS into dw2 and into the k_l half of dlm (both f32, zeroed by the
+    caller) and WRITES delta1 [B, h, n_p] from the forward's saved rows o1; which & 2 — writes the q block of dqkv from delta1."""
+    _chk(qkv, lm, w2, dout, lse1, o1, delta1, dqkv, dw2, dlm)
     B, n_p, _ = qkv.shape
-    _nys_check("nys_attn1_bwd", B, heads, n_p, qkv=qkv, lm=lm, w2=w2, dout=dout, lse1=lse1, dqkv=dqkv, dw2=dw2, dlm=dlm)
-    delta1 = torch.empty_like(lse1)
-    _nys_launch("nys_a1_bwd_kernels", 7 * 2.0 * n_p * NYS_FUSED_M * NYS_FUSED_DH * B * heads,
-                lambda: _lib.call("mh_nys_attn1_bwd", _p(qkv), _p(lm), _p(w2), _p(dout), _p(lse1), _p(delta1), _p(dqkv),
+    ts = dict(qkv=qkv, lm=lm, w2=w2, dout=dout, lse1=lse1, delta1=delta1)
+    if which & 1:
+        ts.update(o1=o1, dw2=dw2, dlm=dlm)
+    if which & 2:
+        ts.update(dqkv=dqkv)
+    _nys_check("nys_attn1_bwd", B, heads, n_p, **ts)
+    prods = (4 if which & 1 else 0) + (3 if which & 2 else 0)
+    _nys_launch("nys_a1_bwd_kernels", prods * 2.0 * n_p * NYS_FUSED_M * NYS_FUSED_DH * B * heads,
+                lambda: _lib.call("mh_nys_attn1_bwd", _p(qkv), _p(lm), _p(w2), _p(dout), _p(lse1), _p(o1), _p(delta1), _p(dqkv),
                                   _p(dw2), _p(dlm), *_nys_masks(kmask, B, n_p), B, heads, n_p, NYS_FUSED_M, NYS_FUSED_DH, scale,
-                                  _lm_ld(lm), stream=_stream()))
+                                  _lm_ld(lm), int(which), stream=_stream()))
 
 
-def nys_attn3_bwd(qkv, lm, av, dav, lse3, dqkv, dlm, heads: int, scale: float, kmask=None, delta3=None) -> None:
-    """Writes the k and v blocks of dqkv; ADDS into the q_l half of dlm.  delta3: sum_d dav av from nys_dz_dav (skips a launch)."""
+NYS_A3_BWD_ONE_PASS = os.environ.get("MIRROR_A3_BWD_ONE_PASS", "1") != "0"      # (A/B switch, round 5)
+
+
+def nys_attn3_bwd(qkv, lm, av, dav, lse3, dqkv, dlm, heads: int, scale: float, kmask=None, delta3=None, one_pass=None) -> None:
+    """Writes the k and v blocks of dqkv; ADDS into the q_l half of dlm.  delta3: sum_d dav av from nys_dz_dav (skips a launch).
+    one_pass: dk, dv, dq_l from one kernel (default) or the dk / dv kernel + the dq_l kernel."""
+    one_pass = NYS_A3_BWD_ONE_PASS if one_pass is None else bool(one_pass)
     _chk(qkv, lm, av, dav, lse3, dqkv, dlm, delta3)
     B, n_p, _ = qkv.shape
     _nys_check("nys_attn3_bwd", B, heads, n_p, qkv=qkv, lm=lm, av=av, dav=dav, lse3=lse3, dqkv=dqkv, dlm=dlm)
@@ -1079,7 +1118,8 @@ def nys_attn3_bwd(qkv, lm, av, dav, lse3, dqkv, dlm, heads: int, scale: float, k
         delta3 = torch.empty_like(lse3)
     _nys_launch("nys_a3_bwd_kernels", 7 * 2.0 * n_p * NYS_FUSED_M * NYS_FUSED_DH * B * heads,
                 lambda: _lib.call("mh_nys_attn3_bwd", _p(qkv), _p(lm), None if given else _p(av), _p(dav), _p(lse3), _p(delta3), _p(dqkv), _p(dlm),
-                                  *_nys_masks(kmask, B, n_p), B, heads, n_p, NYS_FUSED_M, NYS_FUSED_DH, scale, _lm_ld(lm), stream=_stream()))
+                                  *_nys_masks(kmask, B, n_p), B, heads, n_p, NYS_FUSED_M, NYS_FUSED_DH, scale, _lm_ld(lm), int(one_pass),
+                                  stream=_stream()))
 
 
 def eye_minus(P: torch.Tensor, d: float) -> torch.Tensor:

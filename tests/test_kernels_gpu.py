@@ -593,6 +593,63 @@ def test_resconv_mfma_path_bf16(n_p):
     close(dw, gref, 2e-3, 2e-3 * float(gref.abs().max()), "resconv wgrad (mfma)")
 
 
+@pytest.mark.parametrize("n_p", [256, 100, 1152, 4352])
+def test_resconv_bwd_one_pass_equals_the_two_passes(n_p):
+    """mh_resconv_bwd (round 5): the adjoint conv accumulated into the v columns of d qkv AND the tap gradient in one pass over dout.
+    The adjoint part is the same MFMA product as mh_resconv_fwd(transpose=1, accumulate=1): bit-identical; the tap gradient against
+    conv2d autograd (f32 on the bf16-rounded operands) and against mh_resconv_wgrad; dw is ACCUMULATED (a non-zero start)."""
+    gen = g(7 * n_p + 1)
+    B, h, dh, taps = 2, 8, 64, 33
+    D = h * dh
+    bf = torch.bfloat16
+    qkv = torch.randn(B, n_p, 3 * D, generator=gen).to(bf)
+    w = (torch.randn(h, 1, taps, 1, generator=gen) * 0.2)
+    dout = torch.randn(B, n_p, D, generator=gen).to(bf)
+    base = torch.randn(B, n_p, 3 * D, generator=gen).to(bf)             # what the attention kernels left in d qkv
+    dw0 = torch.randn(h, taps, generator=gen)
+    qkv_d, dout_d, w_d = qkv.to(DEV), dout.to(DEV), w.to(DEV)
+    # the two passes
+    dq2 = base.to(DEV).clone()
+    K.resconv(dout_d, w_d, dq2[..., 2 * D:], h, transpose=True, accumulate=True)
+    dw2 = dw0.to(DEV).clone()
+    K.resconv_wgrad(qkv_d[..., 2 * D:], dout_d, dw2, h)
+    # one pass
+    dq1 = base.to(DEV).clone()
+    dw1 = dw0.to(DEV).clone()
+    K.resconv_bwd(dout_d, qkv_d[..., 2 * D:], w_d, dq1[..., 2 * D:], dw1, h)
+    assert torch.equal(dq1[..., :2 * D], base.to(DEV)[..., :2 * D]), "columns outside the v block were touched"
+    assert torch.equal(dq1[..., 2 * D:], dq2[..., 2 * D:]), "adjoint conv differs from mh_resconv_fwd(transpose=1, accumulate=1)"
+    # the tap gradient against autograd
+    v = qkv[..., 2 * D:].float().reshape(B, n_p, h, dh).permute(0, 2, 1, 3).contiguous()
+    wr = w.to(bf).float().clone().requires_grad_(True)
+    from oracle import mirror_oracle as O
+    with O.exact_cpu_convs():
+        F.conv2d(v, wr, padding=(taps // 2, 0), groups=h).backward(dout.float().reshape(B, n_p, h, dh).permute(0, 2, 1, 3))
+    gref = wr.grad.reshape(h, taps)
+    close(dw1 - dw0.to(DEV), gref, 2e-3, 2e-3 * float(gref.abs().max()), "tap gradient (one pass)")
+    close(dw1, dw2.cpu(), 1e-4, 1e-4 * float(gref.abs().max()), "tap gradient vs mh_resconv_wgrad")
+
+
+def test_resconv_bwd_other_dtypes_fall_back_to_the_two_passes():
+    """f32 tensors (the parity policy) take the composed passes behind the same entry point."""
+    gen = g(11)
+    B, h, dh, taps, n_p = 2, 4, 32, 33, 70
+    D = h * dh
+    qkv = torch.randn(B, n_p, 3 * D, generator=gen)
+    w = torch.randn(h, 1, taps, 1, generator=gen) * 0.2
+    dout = torch.randn(B, n_p, D, generator=gen)
+    v = qkv[..., 2 * D:].reshape(B, n_p, h, dh).permute(0, 2, 1, 3).contiguous().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    from oracle import mirror_oracle as O
+    with O.exact_cpu_convs():
+        F.conv2d(v, wr, padding=(taps // 2, 0), groups=h).backward(dout.reshape(B, n_p, h, dh).permute(0, 2, 1, 3))
+    dq = torch.zeros(B, n_p, 3 * D, device=DEV)
+    dw = torch.zeros(h, taps, device=DEV)
+    K.resconv_bwd(dout.to(DEV), qkv.to(DEV)[..., 2 * D:], w.to(DEV), dq[..., 2 * D:], dw, h)
+    close(dq[..., 2 * D:], v.grad.permute(0, 2, 1, 3).reshape(B, n_p, D), 1e-5, 1e-5, "adjoint (f32)")
+    close(dw, wr.grad.reshape(h, taps), 1e-4, 1e-3, "tap gradient (f32)")
+
+
 def test_pinv_init_and_adjoint():
     gen = g(2)
     BH, m = 6, 40
@@ -1194,8 +1251,10 @@ def test_nys_fused_attention_sides(B, h, l):
     out = torch.full((B, n_p, D), float("nan"), device=DEV, dtype=bf)
     lse1 = K.nys_attn1_fwd(qkv_d, lm_d, w2_d, out, h, scale)
     out_acc = torch.ones((B, n_p, D), device=DEV, dtype=bf)
-    K.nys_attn1_fwd(qkv_d, lm_d, w2_d, out_acc, h, scale, accumulate=True)
+    o1 = torch.full((B, n_p, D), float("nan"), device=DEV, dtype=bf)
+    K.nys_attn1_fwd(qkv_d, lm_d, w2_d, out_acc, h, scale, accumulate=True, o1=o1)
     close(out_acc, 1.0 + out.float().cpu(), 0.0, 2e-2 * float(out.float().abs().max()), "attn1 accumulate")
+    assert torch.equal(o1, out), "o1 = attn1's own rows, without the addend"
     av, lse3 = K.nys_attn3_fwd(qkv_d, lm_d, h, scale)
     out_ref, av_ref, s1, s3 = (t.detach() for t in (out_ref, av_ref, s1, s3))
     close(out, out_ref, 0.0, 2e-2 * float(out_ref.abs().max()), "attn1 out")
@@ -1206,16 +1265,55 @@ def test_nys_fused_attention_sides(B, h, l):
     dqkv = torch.full_like(qkv_d, float("nan"))
     dw2 = torch.zeros((B, h, m, dh), device=DEV)
     dlm = torch.zeros((B, m, 2 * D), device=DEV)
-    K.nys_attn1_bwd(qkv_d, lm_d, w2_d, dout_d, lse1, dqkv, dw2, dlm, h, scale)
+    # round 5: part 1 (dw2, dk_l, delta1 = sum_d dO o1) first, then part 2 (dq from delta1) — as NystromCoreFn.backward issues them
+    delta1 = torch.full((B, h, n_p), float("nan"), device=DEV)
+    K.nys_attn1_bwd(qkv_d, lm_d, w2_d, dout_d, lse1, o1, delta1, dqkv, dw2, dlm, h, scale, which=1)
+    p1 = torch.softmax(s1, -1)
+    dp1 = heads(dout, 0, 1) @ w2.double().transpose(-1, -2)
+    dref = (p1 * dp1).sum(-1)
+    close(delta1, dref, 0.0, 2e-2 * float(dref.abs().max()), "delta1 = sum_l P dP from the saved rows")
+    K.nys_attn1_bwd(qkv_d, lm_d, w2_d, dout_d, lse1, o1, delta1, dqkv, dw2, dlm, h, scale, which=2)
     K.nys_attn3_bwd(qkv_d, lm_d, av, dav_d, lse3, dqkv, dlm, h, scale)
     for name, got, ref in (("dqkv", dqkv, qkv_r.grad), ("dw2", dw2, w2_r.grad), ("dlm", dlm, lm_r.grad)):
         close(got, ref, 0.0, 2e-2 * float(ref.abs().max()), name)
         rel = float((got.float().cpu().double() - ref).norm() / ref.norm())
         assert rel < 1e-2, (name, rel)
+    # both forms of attn3's backward (round 5: one pass by default; the dk / dv + dq_l pair stays behind the switch)
+    for one in (True, False):
+        dq3 = torch.full_like(qkv_d, float("nan"))
+        dl3 = torch.zeros_like(dlm)
+        K.nys_attn3_bwd(qkv_d, lm_d, av, dav_d, lse3, dq3, dl3, h, scale, one_pass=one)
+        ref_kv = qkv_r.grad[..., D:]
+        close(dq3[..., D:], ref_kv, 0.0, 2e-2 * float(ref_kv.abs().max()), f"dk | dv (one_pass={one})")
+        ref_ql = lm_r.grad[..., :D] - 0.0      # attn3's share of d q_l: attn1 adds nothing to the q_l half
+        close(dl3[..., :D], ref_ql, 0.0, 2e-2 * float(ref_ql.abs().max()), f"dq_l (one_pass={one})")
+        assert float(dl3[..., D:].abs().max()) == 0.0
     # delta3 handed in (what mh_nys_dz_dav leaves): the call skips its first launch and writes the same dk / dv
     dqkv2 = torch.full_like(qkv_d, float("nan"))
     K.nys_attn3_bwd(qkv_d, lm_d, av, dav_d, lse3, dqkv2, torch.zeros_like(dlm), h, scale, delta3=(dav_d.float().view(B, h, m, dh) * av).sum(-1))
     assert float((dqkv2[..., D:].float() - dqkv[..., D:].float()).abs().max()) <= 1e-2 * float(dqkv[..., D:].float().abs().max())
+
+
+@pytest.mark.parametrize("B,h,l", [(1, 1, 1), (2, 2, 3), (1, 8, 17)])
+def test_nys_attn3_fwd_with_res_conv_inside(B, h, l):
+    """mh_nys_attn3_fwd(rc_w, rc_out) (round 5): the launch that stages the v tiles also writes res_conv(v) — the same Toeplitz MFMA
+    product as mh_resconv_fwd on the same operands, so the rows are bit-identical; av / lse3 do not change; every row of rc_out is
+    written (NaN-filled on entry), including the first / last 16 rows whose halo lies outside the sequence."""
+    gen = g(1000 * B + 10 * h + l)
+    m, dh, taps = 256, 64, 33
+    D, n_p, scale = h * dh, m * l, dh ** -0.5
+    bf = torch.bfloat16
+    qkv = (torch.randn((B, n_p, 3 * D), generator=gen) * 1.5).to(bf).to(DEV)
+    lm = (torch.randn((B, m, 2 * D), generator=gen) * 1.5).to(bf).to(DEV)
+    w = (torch.randn(h, 1, taps, 1, generator=gen) * 0.2).to(DEV)
+    av0, lse0 = K.nys_attn3_fwd(qkv, lm, h, scale)
+    want = torch.empty((B, n_p, D), device=DEV, dtype=bf)
+    K.resconv(qkv[..., 2 * D:], w, want, h, transpose=False, accumulate=False)
+    out = torch.full((B, n_p, D), float("nan"), device=DEV, dtype=bf)
+    av1, lse1 = K.nys_attn3_fwd(qkv, lm, h, scale, rc=(w.reshape(-1).contiguous(), out))
+    assert torch.equal(av0, av1) and torch.equal(lse0, lse1)
+    assert bool(torch.isfinite(out.float()).all()), "rows of rc_out left unwritten"
+    assert torch.equal(out, want), float((out.float() - want.float()).abs().max())
 
 
 def test_nys_fused_rejects_other_geometry():
@@ -1386,7 +1484,8 @@ def test_nys_fused_attention_sides_with_key_padding_mask(B, h, l):
     kmask = (mrow.to(DEV), mlm.to(DEV))
     qkv_d, lm_d, w2_d, dout_d, dav_d = (t.to(DEV) for t in (qkv, lm, w2, dout, dav))
     out = torch.full((B, n_p, D), float("nan"), device=DEV, dtype=bf)
-    lse1 = K.nys_attn1_fwd(qkv_d, lm_d, w2_d, out, h, scale, kmask=kmask)
+    o1 = torch.empty_like(out)
+    lse1 = K.nys_attn1_fwd(qkv_d, lm_d, w2_d, out, h, scale, kmask=kmask, o1=o1)
     av, lse3 = K.nys_attn3_fwd(qkv_d, lm_d, h, scale, kmask=kmask)
     out_ref, av_ref = out_ref.detach(), av_ref.detach()
     close(out, out_ref, 0.0, 2e-2 * float(out_ref.abs().max()), "masked attn1 out")
@@ -1397,7 +1496,7 @@ def test_nys_fused_attention_sides_with_key_padding_mask(B, h, l):
     dqkv = torch.full_like(qkv_d, float("nan"))
     dw2 = torch.zeros((B, h, m, dh), device=DEV)
     dlm = torch.zeros((B, m, 2 * D), device=DEV)
-    K.nys_attn1_bwd(qkv_d, lm_d, w2_d, dout_d, lse1, dqkv, dw2, dlm, h, scale, kmask=kmask)
+    K.nys_attn1_bwd(qkv_d, lm_d, w2_d, dout_d, lse1, o1, torch.empty_like(lse1), dqkv, dw2, dlm, h, scale, kmask=kmask)
     K.nys_attn3_bwd(qkv_d, lm_d, av, dav_d, lse3, dqkv, dlm, h, scale, kmask=kmask)
     for name, got, ref in (("dqkv", dqkv, qkv_r.grad), ("dw2", dw2, w2_r.grad), ("dlm", dlm, lm_r.grad)):
         close(got, ref, 0.0, 2e-2 * float(ref.abs().max()), "masked " + name)

@@ -46,7 +46,9 @@ w2 = torch.randn((B, h, m, 64), device=dev).to(bf)
 out = torch.empty((B, n_p, D), device=dev, dtype=bf)
 dout = torch.randn((B, n_p, D), device=dev).to(bf)
 dav = torch.randn((B, h, m, 64), device=dev).to(bf)
-lse1 = K.nys_attn1_fwd(qkv, lm, w2, out, h, 0.125)
+o1 = torch.empty_like(out)
+lse1 = K.nys_attn1_fwd(qkv, lm, w2, out, h, 0.125, o1=o1)
+delta1 = torch.empty_like(lse1)
 av, lse3 = K.nys_attn3_fwd(qkv, lm, h, 0.125)
 dqkv = torch.empty_like(qkv)
 dw2 = torch.zeros((B, h, m, 64), device=dev)
@@ -54,7 +56,7 @@ dlm = torch.zeros((B, m, 2 * D), device=dev)
 fl = 2.0 * n_p * m * 64 * B * h
 timeit("nys_attn1_fwd", lambda: K.nys_attn1_fwd(qkv, lm, w2, out, h, 0.125), 2 * fl)
 timeit("nys_attn3_fwd", lambda: K.nys_attn3_fwd(qkv, lm, h, 0.125), 2 * fl)
-timeit("nys_attn1_bwd (2 kernels)", lambda: K.nys_attn1_bwd(qkv, lm, w2, dout, lse1, dqkv, dw2, dlm, h, 0.125), 7 * fl)
+timeit("nys_attn1_bwd (2 kernels)", lambda: K.nys_attn1_bwd(qkv, lm, w2, dout, lse1, o1, delta1, dqkv, dw2, dlm, h, 0.125), 7 * fl)
 timeit("nys_attn3_bwd (2 kernels)", lambda: K.nys_attn3_bwd(qkv, lm, av, dav, lse3, dqkv, dlm, h, 0.125), 7 * fl)
 
 # ---- does the chain really overlap with the attn3 side?  (side stream vs same stream)
