@@ -41,6 +41,8 @@ constexpr int NJ = 2;          // 32-column blocks per wave
 constexpr int NCH = CM * CM / 8 / CT;   // 16-byte chunks per thread in a row copy
 constexpr long MAT = (long)CM * CM;
 constexpr int IMG = CM * CM * 2;
+// (round 5, measured and removed: the first 8 / 16 items of the forward's image fills requested in front of the epilogue that precedes
+//  them — 136-152 B of scratch, forward 224 -> 242 us)
 // (Measured and removed in round 4, DESIGN.md section 6: claiming the CU's whole 160 KiB of LDS - neutral; the z_k-only kernels with
 //  row-quarter accumulators and three register panels - forward 204 us, backward 708 us against 231 / 458: fewer bytes, more time;
 //  image fills whose first half is requested before the barrier - 471 vs 466 us; the round-1 backward kernel without panel prefetch - 496.)
@@ -226,9 +228,12 @@ __device__ __forceinline__ void finish(const f32x16 (&acc)[8][NJ], float alpha, 
 // image_from_panel writes them), straight from the accumulators.  The panel registers therefore keep what they hold (a B operand that
 // the next product uses again, or the next operand that panel_gemm<.., PF> requested behind the k sweep).  Call it between two
 // barriers: every wave must have finished reading the image.
-template <bool HASR, bool NTS = false>      // NTS: the global copy is read again only much later (W_k: in the dX sum behind the loop)
-__device__ __forceinline__ void finish_out(const f32x16 (&acc)[8][NJ], float alpha, float diag, const bf16x8 (&pR)[16][NJ], float rcoef,
-                                           bf16_t* __restrict__ G, char* img, int wave, int dreg, int j0, int hl, int lane) {
+template <bool HASR, bool NTS = false, bool NEXT = false>      // NTS: the global copy is read again only much later (W_k: in the dX sum behind the loop)
+__device__ __forceinline__ void finish_out(const f32x16 (&acc)[8][NJ], float alpha, float diag, bf16x8 (&pR)[16][NJ], float rcoef,
+                                           bf16_t* __restrict__ G, char* img, int wave, int dreg, int j0, int hl, int lane,
+                                           const bf16_t* __restrict__ nextG = nullptr) {
+    // NEXT: an entry of the addend panel is dead once its block is finished: the NEXT product's B operand (panel native, HBM) is
+    // requested into it right there, so that panel arrives under the rest of this epilogue instead of in front of its product
     asm volatile("" : "+v"(j0), "+v"(hl), "+v"(lane));
     const int s = swz(j0);
 #pragma unroll
@@ -255,6 +260,8 @@ __device__ __forceinline__ void finish_out(const f32x16 (&acc)[8][NJ], float alp
                 else *reinterpret_cast<u32x4*>(G + (((2 * wave + jb) * 16 + T) * 512) + (lane << 3)) = v;
                 *reinterpret_cast<u32x2*>(row + (((4 * T + hl) ^ s) << 3)) = u32x2{v[0], v[1]};
                 *reinterpret_cast<u32x2*>(row + (((4 * T + 2 + hl) ^ s) << 3)) = u32x2{v[2], v[3]};
+                if constexpr (NEXT)
+                    pR[T][jb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(nextG + (((2 * wave + jb) * 16 + T) * 512) + (lane << 3)));
                 __builtin_amdgcn_sched_barrier(0);   // one block at a time: hoisting all accumulator reads would spill
             }
         }
@@ -467,7 +474,8 @@ __global__ __launch_bounds__(CT) void pinv_panel_fwd_kernel(const bf16_t* __rest
 // and when operands arrive: a product's result leaves the accumulators for HBM + the LDS image directly (finish_out), so the panel
 // registers are free to receive the NEXT product's B operand entry by entry behind this product's k sweep (panel_gemm<.., PF>), and a
 // B operand that two consecutive products share (P in V2 = -V3 P and V2 P) is loaded once.  Of the 8 panel loads per iteration that
-// stood exposed in front of their product, two are left (V2 for the W epilogue, and X after it).
+// stood exposed in front of their product, none is left in round 5's order (V2 stays in the panel for the W epilogue, X is requested
+// inside that epilogue, the next Z behind the last product).
 __global__ __launch_bounds__(CT) void pinv_panel_bwd2_kernel(const bf16_t* __restrict__ XT, const bf16_t* __restrict__ saved,
                                                              const bf16_t* __restrict__ dzf, bf16_t* __restrict__ work,
                                                              float* __restrict__ dX, float* __restrict__ dz0, int BH, int iters) {
@@ -509,32 +517,27 @@ __global__ __launch_bounds__(CT) void pinv_panel_bwd2_kernel(const bf16_t* __res
         __syncthreads();
         finish_out<false>(acc, -1.f, 0.f, p, 0.f, V2, img, wave, dreg, j, hl, lane);
         __syncthreads();
-        // W = V2 P - 7 V2 + P V2 - T2 V3
-        panel_gemm<true, true>(acc, img, rlo, rhi, p, V2, wave, lane);                    // V2 P   (image V2, panel P; V2's panel arrives: own stores)
-        image_swap<true>(img, P, tid);
-        panel_gemm<false, true>(acc, img, rlo, rhi, p, V3, wave, lane);                   // + P V2 (image P, panel V2; V3 arrives)
+        // W = V2 P - 7 V2 + P V2 - T2 V3.  Order (round 5): V2 P, then - T2 V3, then P V2 LAST — its panel IS V2, the epilogue's addend, so
+        // nothing has to be re-read for the - 7 V2 term (round 3 had P V2 in the middle and requested V2 a third time behind the last
+        // product: entry by entry it cost 28 spilled registers and waits inside the MFMA loop, as one exposed panel load 1.8 us per iteration)
+        panel_gemm<true, true>(acc, img, rlo, rhi, p, V3, wave, lane);                    // V2 P   (image V2, panel P; V3 arrives: own stores)
         negate_panel(p);
         image_swap<true>(img, T2, tid);
-        // V2 (the epilogue's addend) is requested BEHIND this product (round 5).  Requested entry by entry behind the k sweep (round 3's
-        // form) the compiler found no registers for 7 of the 32 entries while the epilogue's temporaries are live: it waited for each of
-        // them on the spot (s_waitcnt vmcnt(0) inside the MFMA loop) and parked it in scratch — 28 of the kernel's 48 spilled VGPRs,
-        // 196 -> 84 B of scratch per lane (what is left: 17 loop-invariant address registers stored once, reloaded once per iteration).
-        // Alone on the chip 459-468 -> 443-446 us (profiles/r05_a_chain_bwd_w_epilogue_spill.txt)
-        panel_gemm<false, false>(acc, img, rlo, rhi, p);                                  // - T2 V3 (image T2, panel -V3)
-        load_panel(p, V2, wave, lane);
+        panel_gemm<false, true>(acc, img, rlo, rhi, p, V2, wave, lane);                   // - T2 V3 (image T2, panel -V3; V2 arrives: own stores)
+        image_swap<true>(img, P, tid);
+        panel_gemm<false, false>(acc, img, rlo, rhi, p);                                  // + P V2 (image P, panel V2: stays for the epilogue)
         __syncthreads();
-        finish_out<true, true>(acc, 4.f, 0.f, p, -28.f, W, img, wave, dreg, j, hl, lane);  // 4 W (exact in bf16)
-        load_panel(p, Xb, wave, lane);                                                    // the one panel load left in front of its product
+        // 4 W (exact in bf16); X, the next product's panel, is requested entry by entry behind the addend entries as they are consumed
+        finish_out<true, true, true>(acc, 4.f, 0.f, p, -28.f, W, img, wave, dreg, j, hl, lane, Xb);
         __syncthreads();
         // U' = 1/4 (4W X + T3 U)
         panel_gemm<true, true>(acc, img, rlo, rhi, p, U, wave, lane);                     // 4W X   (image 4W, panel X; U arrives)
         image_swap<true>(img, T3, tid);
         panel_gemm<false, false>(acc, img, rlo, rhi, p);                                  // + T3 U (image T3, panel U)
+        load_panel(p, Zn, wave, lane);            // the next iteration's Z: the panel is free from here on, the loads fly under the epilogue
         __syncthreads();
         finish_out<false>(acc, 0.25f, 0.f, p, 0.f, Un, img, wave, dreg, j, hl, lane);
         if (k == 0) store_f32(dz0 + bh * MAT, acc, 0.25f, j, hl);
-        __builtin_amdgcn_sched_barrier(0);
-        load_panel(p, Zn, wave, lane);            // the next Z (a prefetch carried across the loop edge was spilled by the compiler: 30 entries)
         __syncthreads();
         U = Un;
     }
