@@ -471,13 +471,16 @@ __device__ __forceinline__ void atomic_tile(float* dst, long ld, const f32x16& a
 // grid (splits, B h); wave w owns landmarks [64 w, 64 w + 64).  dw2 = P1^T dO,  dk_l = dS1^T q  (f32 atomics).
 // Also the producer of delta1[n] = sum_l P1 dP1 = sum_d dO[n, d] O1[n, d] (O1 = attn1's own output rows, saved by the forward): eight
 // threads share a row of the dO / O1 tiles they stage anyway.  It runs FIRST (dw2 is what the pinv chain's backward waits for).
+// 8 waves (two per SIMD, 32 landmarks each: round 5 — as 4 waves of 64 landmarks the kernel ran at one wave per SIMD with nothing to
+// cover a wave's softmax arithmetic and LDS traffic).
+constexpr int NTW = 512;
 template <bool MASKED>
-__global__ __launch_bounds__(NT) void nys_a1_bwd_dw_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ lm,
-                                                           const bf16_t* __restrict__ w2, const bf16_t* __restrict__ dout,
-                                                           const float* __restrict__ lse1, const bf16_t* __restrict__ o1,
-                                                           float* __restrict__ delta1,
-                                                           float* __restrict__ dw2, float* __restrict__ dlm, Geo g,
-                                                           int tiles_per_wg) {
+__global__ __launch_bounds__(NTW) void nys_a1_bwd_dw_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ lm,
+                                                            const bf16_t* __restrict__ w2, const bf16_t* __restrict__ dout,
+                                                            const float* __restrict__ lse1, const bf16_t* __restrict__ o1,
+                                                            float* __restrict__ delta1,
+                                                            float* __restrict__ dw2, float* __restrict__ dlm, Geo g,
+                                                            int tiles_per_wg) {
     __shared__ __attribute__((aligned(16))) bf16_t s_q[TR * NP];
     __shared__ __attribute__((aligned(16))) bf16_t s_g[TR * NP];
     __shared__ __attribute__((aligned(16))) float s_lse[TR];
@@ -490,41 +493,44 @@ __global__ __launch_bounds__(NT) void nys_a1_bwd_dw_kernel(const bf16_t* __restr
     const int t0 = blockIdx.x * tiles_per_wg, t1 = min(t0 + tiles_per_wg, ntiles);
     if (t0 >= t1) return;
     constexpr bool masked = MASKED;
-    float ml[2] = {1.f, 1.f};
-    if (masked) { ml[0] = g.mlm[(long)b * NM + 64 * wave + c]; ml[1] = g.mlm[(long)b * NM + 64 * wave + 32 + c]; }
+    const int lq = 32 * wave + c;                  // this lane's landmark
+    const float ml = masked ? g.mlm[(long)b * NM + lq] : 1.f;
     const bf16_t* klb = lm + (long)b * NM * LD + D + hd * ND;
     const bf16_t* w2b = w2 + (long)bh * NM * ND;
-    bf16x8 klf[2][4], w2f[2][4];
+    bf16x8 klf[4], w2f[4];
 #pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-        for (int ks = 0; ks < 4; ks++) {
-            const int l = 64 * wave + 32 * j + c;
-            klf[j][ks] = frag_g(klb + (long)l * LD, 16 * ks, lane);
-            w2f[j][ks] = frag_g(w2b + (long)l * ND, 16 * ks, lane);
-        }
+    for (int ks = 0; ks < 4; ks++) {
+        klf[ks] = frag_g(klb + (long)lq * LD, 16 * ks, lane);
+        w2f[ks] = frag_g(w2b + (long)lq * ND, 16 * ks, lane);
+    }
     const bf16_t* qb = qkv + (long)b * g.n_p * 3 * D + hd * ND;
     const bf16_t* gb = dout + (long)b * g.n_p * D + hd * ND;
-    f32x16 adw[2][2], adk[2][2];
-#pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-        for (int nb = 0; nb < 2; nb++) adw[j][nb] = adk[j][nb] = zero16();
     const bf16_t* ob = o1 + (long)b * g.n_p * D + hd * ND;
-    u32x4 rq[TR * 8 / NT], rg[TR * 8 / NT], ro[TR * 8 / NT];
+    f32x16 adw[2] = {zero16(), zero16()}, adk[2] = {zero16(), zero16()};
+    constexpr int NCH = TR * 8 / NTW;       // 16-byte pieces of a [128 x 64] tile per thread: rows (tid >> 3) + 64 i, columns 8 (tid & 7) ..
+    const int pr = tid >> 3, pc = tid & 7;
+    u32x4 rq[NCH], rg[NCH], ro[NCH];
     float rl = 0.f;
-    tile_load<TR>(rq, qb + (long)t0 * TR * 3 * D, 3 * D, tid);
-    tile_load<TR>(rg, gb + (long)t0 * TR * D, D, tid);
-    tile_load<TR>(ro, ob + (long)t0 * TR * D, D, tid);
-    if (tid < TR) rl = lse1[(long)bh * g.n_p + (long)t0 * TR + tid];
+    auto load_tiles = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < NCH; i++) {
+            const long row = (long)t * TR + pr + 64 * i;
+            rq[i] = *reinterpret_cast<const u32x4*>(qb + row * 3 * D + pc * 8);
+            rg[i] = *reinterpret_cast<const u32x4*>(gb + row * D + pc * 8);
+            ro[i] = *reinterpret_cast<const u32x4*>(ob + row * D + pc * 8);
+        }
+        if (tid < TR) rl = lse1[(long)bh * g.n_p + (long)t * TR + tid];
+    };
+    load_tiles(t0);
 #pragma unroll 1
     for (int t = t0; t < t1; t++) {
         __syncthreads();
-        tile_store<TR>(rq, s_q, tid);
-        tile_store<TR>(rg, s_g, tid);
-        // delta of the tile's rows: this thread holds 8 columns (chunk tid & 7) of rows (tid >> 3) + 32 i of both tiles
 #pragma unroll
-        for (int i = 0; i < TR * 8 / NT; i++) {
+        for (int i = 0; i < NCH; i++) {
+            const int r = pr + 64 * i;
+            *reinterpret_cast<u32x4*>(s_q + r * NP + pc * 8) = rq[i];
+            *reinterpret_cast<u32x4*>(s_g + r * NP + pc * 8) = rg[i];
+            // delta of row r: eight threads (pc = 0 .. 7) hold its 64 columns of both the dO and the O1 tile
             float d = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; w++) {
@@ -534,8 +540,7 @@ __global__ __launch_bounds__(NT) void nys_a1_bwd_dw_kernel(const bf16_t* __restr
             d += __shfl_xor(d, 1, 64);
             d += __shfl_xor(d, 2, 64);
             d += __shfl_xor(d, 4, 64);
-            if ((tid & 7) == 0) {
-                const int r = (tid >> 3) + 32 * i;
+            if (pc == 0) {
                 s_del[r] = -d * g.scale;            // staged negated and scaled: the tile arithmetic is two multiply-adds per element
                 delta1[(long)bh * g.n_p + (long)t * TR + r] = d;
             }
@@ -545,57 +550,46 @@ __global__ __launch_bounds__(NT) void nys_a1_bwd_dw_kernel(const bf16_t* __restr
             s_mr[tid] = masked ? g.mrow[(long)b * g.n_p + (long)t * TR + tid] : 1.f;
         }
         __syncthreads();
-        if (t + 1 < t1) {
-            tile_load<TR>(rq, qb + (long)(t + 1) * TR * 3 * D, 3 * D, tid);
-            tile_load<TR>(rg, gb + (long)(t + 1) * TR * D, D, tid);
-            tile_load<TR>(ro, ob + (long)(t + 1) * TR * D, D, tid);
-            if (tid < TR) rl = lse1[(long)bh * g.n_p + (long)(t + 1) * TR + tid];
-        }
+        if (t + 1 < t1) load_tiles(t + 1);
 #pragma unroll
         for (int i = 0; i < 4; i++) {   // 32 q rows at a time
             const f32x16 lv = rowvals16(s_lse + 32 * i, hl), dv = rowvals16(s_del + 32 * i, hl);      // -lse1 log2(e), -delta1 scale
+            f32x16 s = zero16(), dp = zero16();   // S[q row][landmark], dP[q row][landmark]
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
-                f32x16 s = zero16(), dp = zero16();   // S[q row][landmark], dP[q row][landmark]
+            for (int ks = 0; ks < 4; ks++) {
+                s = MFMA(frag_kc(s_q, 32 * i, 16 * ks, lane), klf[ks], s);
+                dp = MFMA(frag_kc(s_g, 32 * i, 16 * ks, lane), w2f[ks], dp);
+            }
+            if (masked) {
+                const f32x16 vr = rowvals16(s_mr + 32 * i, hl);
+                s = s * g.scale2;
+                mask_fill16(s, vr, ml);
+                s = s + lv;
+                exp2_16(s);
+                dp = s * (dp * g.scale + dv);
+                mask_zero16(dp, vr, ml);
+            } else {
+                s = s * g.scale2 + lv;
+                exp2_16(s);
+                dp = s * (dp * g.scale + dv);
+            }
+            const bf16x8 p0 = pack8<0>(s), p1 = pack8<1>(s), d0 = pack8<0>(dp), d1 = pack8<1>(dp);
 #pragma unroll
-                for (int ks = 0; ks < 4; ks++) {
-                    s = MFMA(frag_kc(s_q, 32 * i, 16 * ks, lane), klf[j][ks], s);
-                    dp = MFMA(frag_kc(s_g, 32 * i, 16 * ks, lane), w2f[j][ks], dp);
-                }
-                if (masked) {
-                    const f32x16 vr = rowvals16(s_mr + 32 * i, hl);
-                    s = s * g.scale2;
-                    mask_fill16(s, vr, ml[j]);
-                    s = s + lv;
-                    exp2_16(s);
-                    dp = s * (dp * g.scale + dv);
-                    mask_zero16(dp, vr, ml[j]);
-                } else {
-                    s = s * g.scale2 + lv;
-                    exp2_16(s);
-                    dp = s * (dp * g.scale + dv);
-                }
-                const bf16x8 p0 = pack8<0>(s), p1 = pack8<1>(s), d0 = pack8<0>(dp), d1 = pack8<1>(dp);
-#pragma unroll
-                for (int nb = 0; nb < 2; nb++) {
-                    adw[j][nb] = MFMA(p0, frag_tr(s_g, 32 * nb, 32 * i, lane), adw[j][nb]);
-                    adw[j][nb] = MFMA(p1, frag_tr(s_g, 32 * nb, 32 * i + 16, lane), adw[j][nb]);
-                    adk[j][nb] = MFMA(d0, frag_tr(s_q, 32 * nb, 32 * i, lane), adk[j][nb]);
-                    adk[j][nb] = MFMA(d1, frag_tr(s_q, 32 * nb, 32 * i + 16, lane), adk[j][nb]);
-                }
+            for (int nb = 0; nb < 2; nb++) {
+                adw[nb] = MFMA(p0, frag_tr(s_g, 32 * nb, 32 * i, lane), adw[nb]);
+                adw[nb] = MFMA(p1, frag_tr(s_g, 32 * nb, 32 * i + 16, lane), adw[nb]);
+                adk[nb] = MFMA(d0, frag_tr(s_q, 32 * nb, 32 * i, lane), adk[nb]);
+                adk[nb] = MFMA(d1, frag_tr(s_q, 32 * nb, 32 * i + 16, lane), adk[nb]);
             }
         }
     }
     float* dwb = dw2 + (long)bh * NM * ND;
     float* dkb = dlm + (long)b * NM * 2 * D + D + hd * ND;
 #pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-        for (int nb = 0; nb < 2; nb++) {
-            const int l0 = 64 * wave + 32 * j;
-            atomic_tile(dwb + (long)l0 * ND + 32 * nb, ND, adw[j][nb], hl, c);
-            atomic_tile(dkb + (long)l0 * 2 * D + 32 * nb, 2 * D, adk[j][nb], hl, c);
-        }
+    for (int nb = 0; nb < 2; nb++) {
+        atomic_tile(dwb + (long)(32 * wave) * ND + 32 * nb, ND, adw[nb], hl, c);
+        atomic_tile(dkb + (long)(32 * wave) * 2 * D + 32 * nb, 2 * D, adk[nb], hl, c);
+    }
 }
 
 // ============================================================================ attn3 forward (L kernel, online softmax)
@@ -1256,7 +1250,7 @@ extern "C" int mh_nys_attn1_bwd(const void* qkv, const void* lm, const void* w2,
     const Geo g{h, n_p, h * ND, scale, scale * LOG2E, mrow, mlm, 0, lm_ld > 0 ? lm_ld : 2L * h * ND, nullptr, nullptr};
     if (which & 1) {
         const int ntiles = n_p / TR, splits = pick_splits(B * h, ntiles, 1), tpw = (ntiles + splits - 1) / splits;
-        NYS_LAUNCH(nys_a1_bwd_dw_kernel, dim3(splits, B * h), dim3(NT), 0, (hipStream_t)s, (const bf16_t*)qkv,
+        NYS_LAUNCH(nys_a1_bwd_dw_kernel, dim3(splits, B * h), dim3(NTW), 0, (hipStream_t)s, (const bf16_t*)qkv,
                            (const bf16_t*)lm, (const bf16_t*)w2, (const bf16_t*)dout, lse1, (const bf16_t*)o1, delta1, dw2, dlm, g, tpw);
         MH_LAUNCH_CHECK("mh_nys_attn1_bwd(dw)");
     }

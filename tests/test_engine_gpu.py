@@ -430,6 +430,52 @@ def test_d512_graph_replay_matches_eager_launch():
     _traj_close(pa, pb, init)
 
 
+def test_d512_graph_replay_with_key_padding_mask_matches_eager_launch():
+    """BASELINE config 4 under the whole-step HIP graph (round 5): the key-padding mask is one more STATIC INPUT of the captured step,
+    refreshed like the batch.  Graph replay vs eager launch at D = 512 with padded slides (bf16 policy, train mode, same seeds): losses
+    of every step, the last step's gradients and the parameter trajectory agree to f32-atomics noise; a batch with a DIFFERENT mask in
+    the same tensor reaches the replay (its loss differs, and equals the eager run's), and a maskless batch on a masked graph falls
+    back to the eager step instead of replaying with a stale mask."""
+    import mirror_amd.models as M
+    from mirror_amd.engine import TrainEngine
+    from mirror_amd.losses import MIRRORLoss
+    n = CFG512["wsi_num_tokens"]
+    runs = []
+    for graph in (True, False):
+        torch.manual_seed(21)
+        model = M.mirror(**CFG512, rna_proj_drop_rate=0.1).cuda().train()
+        eng = TrainEngine(model, MIRRORLoss(), lr=1e-4, precision="bf16", graph=graph, seed=77, snapshot_grads=True)
+        if not graph:
+            eng._rna_branch_state = "off"
+        init = eng.master.clone()
+        wsi, rna, _ = _batch(4, 5, CFG512)
+        lens = torch.tensor([n, 700, 333, 512], device="cuda")
+        mask = torch.arange(n, device="cuda")[None, :] < lens[:, None]
+        wsi = (wsi * mask[..., None]).to(torch.bfloat16)
+        torch.manual_seed(123)
+        losses = [[float(x) for x in eng.step(wsi, rna, wsi_key_padding_mask=mask)] for _ in range(5)]
+        assert (eng._graph is not None) == graph
+        if graph:
+            assert eng._g_in[2] is not None and torch.equal(eng._g_in[2], mask)
+        # another mask written INTO the same tensor (the version counter moves): the replay must see it
+        mask.copy_(torch.arange(n, device="cuda")[None, :] < torch.tensor([600, n, 400, 900], device="cuda")[:, None])
+        losses.append([float(x) for x in eng.step(wsi, rna, wsi_key_padding_mask=mask)])
+        if graph:
+            assert torch.equal(eng._g_in[2], mask)
+        runs.append((losses, eng.master.clone(), eng.grad_snap.clone(), init))
+        if graph:        # a maskless batch must not replay the masked graph
+            before = eng._graph
+            eng.step(wsi, rna)
+            assert eng._graph is before
+    (la, pa, ga, init), (lb, pb, gb, _) = runs
+    for a, b in zip(la, lb):
+        for x, y in zip(a, b):
+            assert abs(x - y) <= 2e-3 * max(1.0, abs(y)), (la, lb)
+    assert abs(la[-1][0] - la[-2][0]) > 1e-4, "the second mask did not change the loss"
+    assert float((ga - gb).norm()) <= 2e-2 * float(gb.norm())
+    _traj_close(pa, pb, init)
+
+
 def _worker_d512(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)

@@ -26,7 +26,7 @@ rna = torch.randn(a.batch, G, device=dev, generator=g)
 lens = torch.randint(2048, N + 1, (a.batch,), device=dev, generator=g)
 mask = torch.arange(N, device=dev)[None, :] < lens[:, None]
 wsi = wsi * mask[..., None]                                   # padded rows are zeros, as a collate function would leave them
-for _ in range(4):      # two warm steps, the step that records the RNA-branch graphs, one replayed step
+for _ in range(4):      # two warm steps, the capture, one replayed step
     losses = eng.step(wsi, rna, wsi_key_padding_mask=mask)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
@@ -36,5 +36,5 @@ torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print(json.dumps({"config": "BASELINE c4: 8192 x 768-d patch tokens, valid length ~U[2048, 8192], key-padding mask", "precision": a.precision,
                   "batch": a.batch, "steps": a.steps, "ms_per_step": round(dt / a.steps * 1e3, 2), "samples_per_s": round(a.batch * a.steps / dt, 2),
-                  "valid_lengths": lens.tolist(), "losses": [round(float(x), 5) for x in losses],
+                  "step_launch": "hip_graph" if eng._graph is not None else "eager", "valid_lengths": lens.tolist(), "losses": [round(float(x), 5) for x in losses],
                   "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}))
