@@ -210,7 +210,11 @@ int mh_layernorm_fwd_lm(const float* x, const float* gamma, const float* beta, v
 int mh_layernorm_bwd_lm(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                         void* dx, float* dgamma, float* dbeta, int batches, int rows_per_batch, int D, int64_t x_bs, int64_t y_bs,
                         int dt_x, int dt_dy, int dt_dx, int accumulate_dx, float* workspace, int64_t ws_floats,
-                        const void* gadd, int pad, int l, mh_stream s);
+                        const void* gadd, int pad, int l, void* relu_out, int relu_first, int relu_rows, mh_stream s);
+                        /* relu_out (nullable, bf16 [batches, relu_rows, D]; f32 x): x rows [relu_first, relu_first + relu_rows) of every batch
+                           are the output of a ReLU (`_fc1 = Linear + ReLU`, models/mirror.py:346, :652-654, feeds layer 1's norm): their
+                           total gradient is written HERE as bf16 (x > 0 ? dx : 0), the operand of _fc1's weight gradient, and NOT as f32 dx
+                           (no separate ReLU-backward pass); the other rows (cls) keep their f32 dx */
 
 /* ---------------------------------------------------------------- fp8 forward projections (BASELINE config 5)
  * mh_quant_fp8: q[i] = e4m3(x[i] * 448 / max|x|) for a whole tensor (x f32 / bf16, n % 4 == 0), scale[0] = max|x| / 448

@@ -102,7 +102,7 @@ _SIGS = {
     "mh_layernorm_fwd_dual": [P, P, P, P, P, P, P, I, I, I, L, L, F],
     "mh_layernorm_fwd_q8": [P, P, P, P, P, P, I, I, I, L, L, F, P, P, P, F, P],
     "mh_layernorm_bwd": [P, P, P, P, P, P, P, P, I, I, I, L, L, I, I, I, I, P, L],
-    "mh_layernorm_bwd_lm": [P, P, P, P, P, P, P, P, I, I, I, L, L, I, I, I, I, P, L, P, I, I],
+    "mh_layernorm_bwd_lm": [P, P, P, P, P, P, P, P, I, I, I, L, L, I, I, I, I, P, L, P, I, I, P, I, I],
     "mh_layernorm_fwd_lm": [P, P, P, P, P, P, P, P, I, I, I, L, I, I, F],
     "mh_softmax_fwd": [P, P, L, I, L, L, I, I],
     "mh_softmax_bwd": [P, P, P, L, I, L, L, L, I, I, I],

@@ -26,15 +26,18 @@ constexpr int BIG = 256, NTB = 512, BWM = 4, BWN = 2;
 __device__ __forceinline__ f32x4 round_bf16_4(f32x4 x) {
     return f32x4{bf2f(f2bf(x[0])), bf2f(f2bf(x[1])), bf2f(f2bf(x[2])), bf2f(f2bf(x[3]))};
 }
+// (b0, t0) = batch and row-in-batch of the TILE's first row, computed once per tile: a 256-row tile crosses at most one batch edge
+// (rows_per_batch > 256 is checked by the host), so a quad's (b, t) is an add and a compare — as a 32-bit division per quad (no integer
+// divide instruction: ~25 VALU each, 32 quads per thread and tile) the retention_embed launch ran 84 us against 57 for the plain product
+struct TileRow { int b0, t0, row0; };
 template <int EPI>
-__device__ __forceinline__ f32x4 epi_quad(const GemmArgs& g, f32x4 x, int grow, int gcol) {
+__device__ __forceinline__ f32x4 epi_quad(const GemmArgs& g, f32x4 x, int grow, int gcol, const TileRow& tr) {
     if constexpr (EPI == MH_EPI_MASKPOS) {
-        // random_masking's token select + `+ retention_gene_embed` (models/mirror.py:636-643, :691-693); 32-bit row arithmetic
-        // (a 64-bit division per quad made this epilogue longer than the pass it replaces)
+        // random_masking's token select + `+ retention_gene_embed` (models/mirror.py:636-643, :691-693)
         x = round_bf16_4(x);
         const int rpb = g.epi.rows_per_batch, first = g.epi.first;
-        const int b = grow / rpb;
-        const int t = grow - b * rpb;
+        int t = tr.t0 + (grow - tr.row0), b = tr.b0;
+        if (t >= rpb) { t -= rpb; b += 1; }
         if (t >= first && g.epi.mask[(long)b * (rpb - first) + (t - first)] != 0.f) x = *reinterpret_cast<const f32x4*>(g.epi.token + gcol);
         return x + *reinterpret_cast<const f32x4*>(g.epi.pos + (long)t * g.N + gcol);
     } else {
@@ -62,6 +65,8 @@ __device__ __forceinline__ void epilogue_big(const GemmArgs& g, TC* C, f32x16 (&
     constexpr int PITCH = BIG + 4, HALF = BIG / 2;
     float* t = reinterpret_cast<float*>(smem);
     const int r = lane & 31, hh = lane >> 5;
+    TileRow trow{0, 0, tile_row0};
+    if constexpr (EPI == MH_EPI_MASKPOS) { trow.b0 = tile_row0 / g.epi.rows_per_batch; trow.t0 = tile_row0 - trow.b0 * g.epi.rows_per_batch; }
 #pragma unroll
     for (int half = 0; half < 2; half++) {
         if (wm == half) {
@@ -123,7 +128,7 @@ __device__ __forceinline__ void epilogue_big(const GemmArgs& g, TC* C, f32x16 (&
             f32x4 x0 = *reinterpret_cast<const f32x4*>(src);
             u32x4 o;
             if constexpr (sizeof(TC) == 4) {
-                if constexpr (EPI != 0) x0 = epi_quad<EPI>(g, x0, tile_row0 + half * HALF + lr, tile_col0 + c * EPC);
+                if constexpr (EPI != 0) x0 = epi_quad<EPI>(g, x0, tile_row0 + half * HALF + lr, tile_col0 + c * EPC, trow);
                 if constexpr (MODE == 1) x0 += *reinterpret_cast<const f32x4*>(dst);
                 o[0] = __float_as_uint(x0[0]); o[1] = __float_as_uint(x0[1]);
                 o[2] = __float_as_uint(x0[2]); o[3] = __float_as_uint(x0[3]);
@@ -951,6 +956,8 @@ __device__ __forceinline__ void pq_epilogue_f32(const GemmArgs& g, float* C, f32
     asm volatile("" : "+v"(lane), "+v"(tid));        // see pq_epilogue_bf16
     float* t = reinterpret_cast<float*>(smem_c);
     const int c16 = lane & 15, g4 = lane >> 4;
+    TileRow trow{0, 0, tile_row0};
+    if constexpr (EPI == MH_EPI_MASKPOS) { trow.b0 = tile_row0 / g.epi.rows_per_batch; trow.t0 = tile_row0 - trow.b0 * g.epi.rows_per_batch; }
     uint64_t drop_blk0 = 0;
     uint32_t thr = 0;
     float dscale = 1.f;
@@ -1011,6 +1018,37 @@ __device__ __forceinline__ void pq_epilogue_f32(const GemmArgs& g, float* C, f32
                 __builtin_nontemporal_store(r0, reinterpret_cast<f32x4*>(dst));
                 __builtin_nontemporal_store(r1, reinterpret_cast<f32x4*>(dst + 4));
             }
+        } else if constexpr (EPI == MH_EPI_MASKPOS) {
+            // mask token select + positional add with every operand REQUESTED beside the LDS reads, in front of the barrier (as quads
+            // looked up one by one inside the store loop — mask, then token, then pos, each behind the other — the launch ran 84 us
+            // against 56 for the plain f32 product): a thread's column quad is the same in all of its rows (NTB % CPR == 0), so the token
+            // quad is one load; the mask values and the positional quads of its QR * CPR / NTB rows are independent loads
+            constexpr int CPR = BIG / 4, NCH = QR * CPR / NTB;
+            static_assert(NTB % CPR == 0, "a thread keeps its column quad across rows");
+            const int c4 = (tid % CPR) * 4, gcol = tile_col0 + c4;
+            const int rpb = g.epi.rows_per_batch, first = g.epi.first;
+            f32x4 x[NCH], pq[NCH];
+            float mk[NCH];
+            const f32x4 tokq = *reinterpret_cast<const f32x4*>(g.epi.token + gcol);
+#pragma unroll
+            for (int i = 0; i < NCH; i++) {
+                const int lr = (tid + i * NTB) / CPR;
+                x[i] = *reinterpret_cast<const f32x4*>(t + lr * PITCH + c4);
+                const int grow = min(tile_row0 + q * QR + lr, g.M - 1);
+                int tt = trow.t0 + (grow - trow.row0), b = trow.b0;
+                if (tt >= rpb) { tt -= rpb; b += 1; }
+                pq[i] = *reinterpret_cast<const f32x4*>(g.epi.pos + (long)tt * g.N + gcol);
+                mk[i] = tt >= first ? g.epi.mask[(long)b * (rpb - first) + (tt - first)] : 0.f;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NCH; i++) {
+                const int lr = (tid + i * NTB) / CPR;
+                const int grow = tile_row0 + q * QR + lr;
+                if (grow >= g.M) continue;
+                const f32x4 v = (mk[i] != 0.f ? tokq : round_bf16_4(x[i])) + pq[i];
+                __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(C + (long)grow * ldc + gcol));
+            }
         } else {
             constexpr int CPR = BIG / 4, NCH = QR * CPR / NTB;
             f32x4 x[NCH];
@@ -1028,7 +1066,7 @@ __device__ __forceinline__ void pq_epilogue_f32(const GemmArgs& g, float* C, f32
                 if (grow >= g.M) continue;
                 float* dst = C + (long)grow * ldc + tile_col0 + c * 4;
                 f32x4 x0 = x[i];
-                if constexpr (EPI != 0) x0 = epi_quad<EPI>(g, x0, grow, tile_col0 + c * 4);
+                if constexpr (EPI != 0) x0 = epi_quad<EPI>(g, x0, grow, tile_col0 + c * 4, trow);
                 if constexpr (MODE == 1) x0 += *reinterpret_cast<const f32x4*>(dst);
                 __builtin_nontemporal_store(x0, reinterpret_cast<f32x4*>(dst));
             }
@@ -1444,7 +1482,7 @@ const char* gemm_big_epi(GemmArgs& a, int akc, int bkc, int dtC, int batch, hipS
         EPI_LAUNCH_(float, MH_EPI_DROPADD);
         return nullptr;
     case MH_EPI_MASKPOS:
-        if (dtC != MH_F32 || !e.mask || !e.token || !e.pos || e.rows_per_batch <= 0 || e.first < 0) return "MASKPOS: f32 C, mask / token / pos, rows_per_batch > 0";
+        if (dtC != MH_F32 || !e.mask || !e.token || !e.pos || e.rows_per_batch < BIG || e.first < 0) return "MASKPOS: f32 C, mask / token / pos, rows_per_batch >= 256";
         if (((uintptr_t)e.token & 15) || ((uintptr_t)e.pos & 15)) return "MASKPOS: token / pos must be 16-byte aligned";
         EPI_LAUNCH_(float, MH_EPI_MASKPOS);
         return nullptr;

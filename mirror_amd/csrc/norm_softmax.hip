@@ -492,14 +492,20 @@ extern "C" int mh_layernorm_fwd_q8(const float* x, const float* gamma, const flo
 // is a serial load -> reduce -> store chain: one row per wave left HBM at 1.8 TB/s), (b) 32-bit row arithmetic, and
 // (c) the per-block dgamma / dbeta partials go to ws[block][2][D] with plain stores — 2048 blocks adding into the same
 // 2 D addresses cost ~100 us of serialised atomics — and a second small kernel folds them.
-template <typename TX, typename TDY, int LNV_CH>
-__global__ __launch_bounds__(256) void layernorm_bwd_ws_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x,
+template <typename TX, typename TDY, int LNV_CH, bool RELU = false>
+// D <= 512 (LNV_CH == 2): held to 4 waves per SIMD — at 130 registers instead of 128 the ReLU-fused instance lost a wave and 30 us
+__global__ __launch_bounds__(256, LNV_CH == 2 ? 4 : 1) void layernorm_bwd_ws_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x,
                                                                const float* __restrict__ gamma, const float* __restrict__ mean,
                                                                const float* __restrict__ rstd, TX* __restrict__ dx,
                                                                float* __restrict__ ws, int rows, int rpb, int D, long x_bs,
                                                                long y_bs, int acc_dx, int rows_per_block,
                                                                const TDY* __restrict__ gadd = nullptr, int ga_pad = 0, int ga_l = 1,
-                                                               int ga_m = 0, float ga_scale = 0.f) {
+                                                               int ga_m = 0, float ga_scale = 0.f, bf16_t* __restrict__ relu_out = nullptr,
+                                                               int relu_first = 0, int relu_rows = 0) {
+    // relu_out (bf16 [batches, relu_rows, D], round 5): x is the OUTPUT of a ReLU on rows [relu_first, relu_first + relu_rows) of every batch
+    // (_fc1 of models/mirror.py:346, :652-654 writes the sequence LayerNorm 1 reads): those rows' total gradient leaves as
+    // bf16 (x > 0 ? dx : 0) — what the ReLU's own backward pass would make of it for the weight-gradient product — instead of as f32 dx
+    // (the pass that read x and dx again, 335 MB, is gone; rows outside the range, the cls row, keep their f32 dx).
     // gadd [batches, ga_m, D] in dy's dtype: dy of row i of batch b is dy + ga_scale * gadd[b, (i + ga_pad) / ga_l] (the gradient of the
     // landmark means mh_layernorm_fwd_lm produced beside the rows)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -515,7 +521,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_ws_kernel(const TDY* __rest
     for (int row = r0 + wave; row < r1; row += 8) {
         f4 dv[2][LNV_CH], xv[2][LNV_CH], ov[2][LNV_CH];
         float mu[2], rs[2];
-        long xo[2];
+        long xo[2], ro[2];
         bool ok[2];
 #pragma unroll
         for (int u = 0; u < 2; u++) {               // issue both rows' loads before anything is reduced
@@ -524,6 +530,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_ws_kernel(const TDY* __rest
             const int rc = ok[u] ? rr : row;
             const int b = rc / rpb, i = rc - b * rpb;
             xo[u] = b * x_bs + (long)i * D;
+            ro[u] = (RELU && i >= relu_first && i < relu_first + relu_rows) ? ((long)b * relu_rows + (i - relu_first)) * D : -1;
             const TDY* dyr = dy + b * y_bs + (long)i * D;
             mu[u] = mean[rc];
             rs[u] = rstd[rc];
@@ -542,12 +549,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_ws_kernel(const TDY* __rest
         for (int u = 0; u < 2; u++) {
             if (!ok[u]) continue;
             float s1 = 0.f, s2 = 0.f;
+            unsigned pos = 0;               // bit 4 k + e: x > 0 (the ReLU was active)
 #pragma unroll
             for (int k = 0; k < LNV_CH; k++) {
                 const int c = 256 * k + 4 * lane;
                 if (c < D) {
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
+                        if constexpr (RELU) pos |= (xv[u][k][e] > 0.f ? 1u : 0u) << (4 * k + e);
                         const float xh = (xv[u][k][e] - mu[u]) * rs[u];
                         const float d = dv[u][k][e];
                         const float gd = d * gm[k][e];
@@ -570,7 +579,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_ws_kernel(const TDY* __rest
 #pragma unroll
                     for (int e = 0; e < 4; e++) r[e] = rs[u] * (dv[u][k][e] - s1 - xv[u][k][e] * s2);
                     if (acc_dx) r += ov[u][k];
-                    st4(dx + xo[u] + c, r);
+                    if (RELU && ro[u] >= 0) {
+                        typedef unsigned ln_u32x2 __attribute__((ext_vector_type(2)));
+                        const ln_u32x2 w = {pack_bf2((pos >> (4 * k)) & 1u ? r[0] : 0.f, (pos >> (4 * k + 1)) & 1u ? r[1] : 0.f),
+                                         pack_bf2((pos >> (4 * k + 2)) & 1u ? r[2] : 0.f, (pos >> (4 * k + 3)) & 1u ? r[3] : 0.f)};
+                        *reinterpret_cast<ln_u32x2*>(relu_out + ro[u] + c) = w;
+                    } else {
+                        st4(dx + xo[u] + c, r);
+                    }
                 }
             }
         }
@@ -651,7 +667,7 @@ extern "C" int64_t mh_layernorm_bwd_workspace_bytes(int64_t rows, int D) {
 static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                        void* dx, float* dgamma, float* dbeta, int batches, int rpb, int D, int64_t x_bs,
                        int64_t y_bs, int dt_x, int dt_dy, int dt_dx, int acc_dx, float* workspace, int64_t ws_floats,
-                       const void* gadd, int ga_pad, int ga_l, mh_stream s);
+                       const void* gadd, int ga_pad, int ga_l, mh_stream s, void* relu_out = nullptr, int relu_first = 0, int relu_rows = 0);
 
 extern "C" int mh_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                 void* dx, float* dgamma, float* dbeta, int batches, int rpb, int D, int64_t x_bs,
@@ -666,16 +682,18 @@ extern "C" int mh_layernorm_bwd(const void* dy, const void* x, const float* gamm
 extern "C" int mh_layernorm_bwd_lm(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                    void* dx, float* dgamma, float* dbeta, int batches, int rpb, int D, int64_t x_bs,
                                    int64_t y_bs, int dt_x, int dt_dy, int dt_dx, int acc_dx, float* workspace, int64_t ws_floats,
-                                   const void* gadd, int pad, int l, mh_stream s) {
+                                   const void* gadd, int pad, int l, void* relu_out, int relu_first, int relu_rows, mh_stream s) {
     MH_REQUIRE(gadd && l >= 1 && pad >= 0 && (pad + rpb) % l == 0 && ((uintptr_t)gadd & 15) == 0, "mh_layernorm_bwd_lm: gadd, l >= 1, (pad + rows) %% l == 0");
+    MH_REQUIRE(!relu_out || (dt_x == MH_F32 && relu_first >= 0 && relu_rows >= 0 && relu_first + relu_rows <= rpb && ((uintptr_t)relu_out & 7) == 0 && D % 4 == 0),
+               "mh_layernorm_bwd_lm: relu_out needs f32 x and a row range inside the batch");
     return ln_bwd_impl(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, batches, rpb, D, x_bs, y_bs, dt_x, dt_dy, dt_dx, acc_dx, workspace,
-                       ws_floats, gadd, pad, l, s);
+                       ws_floats, gadd, pad, l, s, relu_out, relu_first, relu_rows);
 }
 
 static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                        void* dx, float* dgamma, float* dbeta, int batches, int rpb, int D, int64_t x_bs,
                        int64_t y_bs, int dt_x, int dt_dy, int dt_dx, int acc_dx, float* workspace, int64_t ws_floats,
-                       const void* gadd, int ga_pad, int ga_l, mh_stream s) {
+                       const void* gadd, int ga_pad, int ga_l, mh_stream s, void* relu_out, int relu_first, int relu_rows) {
     MH_REQUIRE(D >= 1 && D <= 64 * LN_MAXPL, "mh_layernorm_bwd: D=%d unsupported", D);
     MH_REQUIRE(dt_dx == dt_x, "mh_layernorm_bwd: dx dtype must equal x dtype");
     const long rows = (long)batches * rpb;
@@ -693,9 +711,12 @@ static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const 
         const int rows_per_block = (int)(mh_cdiv(mh_cdiv(rows, nb), 8) * 8);
         nb = mh_cdiv(rows, rows_per_block);
         dim3 g2((unsigned)nb);
-#define LN_BW1(TX, TDY, NC) hipLaunchKernelGGL((layernorm_bwd_ws_kernel<TX, TDY, NC>), g2, dim3(256), 0, (hipStream_t)s, (const TDY*)dy, (const TX*)x, gamma, mean, rstd, (TX*)dx, workspace, (int)rows, rpb, D, (long)x_bs, (long)y_bs, acc_dx, rows_per_block, (const TDY*)gadd, ga_pad, ga_l, (ga_pad + rpb) / ga_l, 1.f / (float)ga_l)
-#define LN_BW(TX, TDY) do { if (D <= 512) LN_BW1(TX, TDY, 2); else if (D <= 1024) LN_BW1(TX, TDY, 4); else LN_BW1(TX, TDY, 8); } while (0)
-        if (dt_x == MH_F32 && dt_dy == MH_F32) LN_BW(float, float);
+#define LN_BW1(TX, TDY, NC, RL) hipLaunchKernelGGL((layernorm_bwd_ws_kernel<TX, TDY, NC, RL>), g2, dim3(256), 0, (hipStream_t)s, (const TDY*)dy, (const TX*)x, gamma, mean, rstd, (TX*)dx, workspace, (int)rows, rpb, D, (long)x_bs, (long)y_bs, acc_dx, rows_per_block, (const TDY*)gadd, ga_pad, ga_l, (ga_pad + rpb) / ga_l, 1.f / (float)ga_l, (bf16_t*)relu_out, relu_first, relu_rows)
+#define LN_BW(TX, TDY) do { if (D <= 512) LN_BW1(TX, TDY, 2, false); else if (D <= 1024) LN_BW1(TX, TDY, 4, false); else LN_BW1(TX, TDY, 8, false); } while (0)
+        if (relu_out) {         // the ReLU-fused form (f32 x, bf16 dy: layer 1 of the bf16 policy) is an instance of its own
+            MH_REQUIRE(dt_x == MH_F32 && dt_dy == MH_BF16, "mh_layernorm_bwd_lm: relu_out needs f32 x and bf16 dy");
+            if (D <= 512) LN_BW1(float, bf16_t, 2, true); else if (D <= 1024) LN_BW1(float, bf16_t, 4, true); else LN_BW1(float, bf16_t, 8, true);
+        } else if (dt_x == MH_F32 && dt_dy == MH_F32) LN_BW(float, float);
         else if (dt_x == MH_F32 && dt_dy == MH_BF16) LN_BW(float, bf16_t);
         else if (dt_x == MH_BF16 && dt_dy == MH_BF16) LN_BW(bf16_t, bf16_t);
         else LN_BW(bf16_t, float);
@@ -710,7 +731,7 @@ static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const 
         MH_LAUNCH_CHECK("mh_layernorm_bwd");
         return MH_OK;
     }
-    MH_REQUIRE(!gadd, "mh_layernorm_bwd_lm: needs the workspace form (D %% 4 == 0, 16-byte aligned buffers, a workspace of >= 2 D floats, >= 64 rows)");
+    MH_REQUIRE(!gadd && !relu_out, "mh_layernorm_bwd_lm: needs the workspace form (D %% 4 == 0, 16-byte aligned buffers, a workspace of >= 2 D floats, >= 64 rows)");
     if (vecok) {
         if (dt_x == MH_F32 && dt_dy == MH_F32) LN_BV(float, float);
         else if (dt_x == MH_F32 && dt_dy == MH_BF16) LN_BV(float, bf16_t);

@@ -733,7 +733,7 @@ class LinearRowsFn(Function):
         return dx, dw, db, None, None, None, None
 
 
-_TO_OUT_WGRAD_IN_WINDOW = os.environ.get("MIRROR_TO_OUT_WGRAD_WINDOW", "1") != "0"      # (A/B switch of the round-5 window rebalance)
+_TO_OUT_WGRAD_IN_WINDOW = True      # (test hook, round 5) to_out's weight gradient beside the pinv chain's backward (-0.23 % +- 0.15)
 _deferred_bwd: dict = {}    # data_ptr of a data gradient -> a weight-gradient launch that its consumer runs where it has idle CUs
 
 
@@ -965,7 +965,7 @@ def embed_mask_pos(h, w, b, mask, token, pos, first: int, prec: Precision):
     bf16 itself and the shapes are on the 256 x 256-tile kernel; the composed ops otherwise."""
     hb = h if h.dtype == bf16 else getattr(h, "_bf16", None)
     if (hb is not None and prec.act == bf16 and not prec.fp8_fwd and hb.is_contiguous() and tuple(hb.shape) == tuple(h.shape)
-            and mask.dtype == f32 and mask.is_contiguous() and K.linear_fused_ok(hb, shadow(w, prec))
+            and mask.dtype == f32 and mask.is_contiguous() and hb.shape[1] >= 256 and K.linear_fused_ok(hb, shadow(w, prec))
             and token.numel() == w.shape[0] and pos.numel() == h.shape[1] * w.shape[0]):
         return EmbedMaskPosFn.apply(h, hb, w, b, mask, token, pos, first, prec)
     r = linear(h, w, b, prec=prec)
@@ -1145,8 +1145,15 @@ class NormQkvLmFn(Function):
         gadd = dxe[P:].view(Bn, m, D)
         G = _res_grads.pop(x.data_ptr(), None)
         if G is not None and G.numel() == x.numel() and G.dtype == x.dtype and G.is_contiguous():
+            # x = Fc1SeqFn's sequence [cls | relu(_fc1(wsi))] (layer 1): the rows behind the cls row leave as the ReLU-masked bf16 gradient
+            # _fc1's weight gradient multiplies (Fc1SeqFn.backward picks it up: no pass over x and dx of its own)
+            nrelu = _relu_rows.pop(x.data_ptr(), None) if _RELU_IN_LN_BWD else None
+            dh = None
+            if nrelu is not None and x.dtype == f32 and prec.act == bf16 and rows == T == nrelu + 1 and ctx.needs_input_grad[0]:
+                dh = torch.empty((Bn, nrelu, D), device=x.device, dtype=bf16)
+                _relu_grads[G.data_ptr()] = dh
             K.layernorm_bwd(dy[:, pad:], x, gamma.detach(), mean, rstd, G.view(x.shape), dg, db, Bn, rows, D, T * D, n_p * D,
-                            accumulate_dx=True, gadd=gadd, pad=pad, l=l)
+                            accumulate_dx=True, gadd=gadd, pad=pad, l=l, relu_out=dh, relu_first=1)
             dx = None
         else:
             dx = torch.zeros_like(x) if rows < T else torch.empty_like(x)
@@ -1179,6 +1186,9 @@ def ext_rows_of(dqkv, dlm, P: int, E: int, N3: int, c0: int, copy_lm: bool = Tru
 
 
 _LM_ROWS = True       # test hook (tests/test_fused_epilogue_gpu.py): False = the landmark kernels on q | k instead of NormQkvLmFn
+_RELU_IN_LN_BWD = True      # (test hook, round 5) _fc1's ReLU backward inside layer 1's LayerNorm backward
+_relu_rows: dict = {}       # data_ptr of an Fc1SeqFn output with no square-pad rows -> its token count N (rows 1 .. N are a ReLU's output)
+_relu_grads: dict = {}      # data_ptr of that sequence's f32 gradient buffer -> the bf16 ReLU-masked gradient layer 1's LayerNorm backward wrote
 
 
 def layer_norm_landmarks_ok(x, rows: int, pad: int, l: int, prec: Precision) -> bool:
@@ -1400,6 +1410,8 @@ class Fc1SeqFn(Function):
         if not (prec.fp8_fwd and xa.dtype == bf16 and _fp8_linear(xa, wa, b.detach(), ACT_RELU, seq[:, 1:1 + N])):
             K.gemm(xa, wa.t(), out=seq[:, 1:1 + N], bias=b.detach(), act=ACT_RELU, mma=prec.mma)
         K.seq_finish(seq, cls.detach().reshape(-1).contiguous(), N, add_len)
+        if add_len == 0 and prec.act == bf16:
+            _relu_rows[seq.data_ptr()] = N      # layer 1's LayerNorm backward may write the ReLU-masked gradient itself (NormQkvLmFn.backward)
         ctx.save_for_backward(xa, wa, seq, w, b)
         ctx.add_len, ctx.prec, ctx.cls = add_len, prec, cls
         return seq
@@ -1411,12 +1423,14 @@ class Fc1SeqFn(Function):
         Bn, N, Fd = xa.shape
         D = wa.shape[0]
         dseq = dseq.contiguous()
-        if add_len:
+        dh = _relu_grads.pop(dseq.data_ptr(), None)      # layer 1's LayerNorm backward already wrote relu'(x) * dx as bf16 (rows 1 .. N of
+        if add_len:                                       # dseq are then stale: only the cls row is read below)
             dseq = dseq.clone()  # the fold below is in place; autograd owns the incoming buffer
         dcls, sunk_c = _gbuf_n(ctx.cls, (D,))
         K.seq_finish_bwd(dseq, dcls, N, add_len)
         dcls = _gret(ctx.cls, dcls, sunk_c)
-        dh = K.relu_bwd(seq[:, 1:1 + N], dseq[:, 1:1 + N], out_dtype=prec.act)   # [B,N,D] contiguous
+        if dh is None or add_len or tuple(dh.shape) != (Bn, N, D):
+            dh = K.relu_bwd(seq[:, 1:1 + N], dseq[:, 1:1 + N], out_dtype=prec.act)   # [B,N,D] contiguous
         dw, sunk_w = _gbuf(w, (D, Fd))
         K.gemm(dh.reshape(Bn * N, D).t(), xa.reshape(Bn * N, Fd), out=dw, accumulate=True,
                split_k=_split_k_for(Bn * N, D, Fd), mma=prec.mma)
@@ -1623,7 +1637,7 @@ def pending_lm_merge_reset(where: str, strict: bool = False) -> None:
 _W2_ON_CHAIN = True      # (test hook) w2 = pinv (attn3 v) at the end of the chain's branch instead of behind the join (-0.22 % +- 0.06)
 _DZ_DAV = True      # (test hook)
 _RC_FUSED = True      # (test hook) res_conv inside attn3's forward launch, its two gradients as one pass over dout (round 5)
-_A1_DQ_IN_WINDOW = os.environ.get("MIRROR_A1_DQ_WINDOW", "1") != "0"      # (A/B switch, round 5) attn1's dq kernel beside the pinv chain's backward
+_A1_DQ_IN_WINDOW = True      # (test hook, round 5) attn1's dq kernel beside the pinv chain's backward (-0.35 % +- 0.02)
 # (measured and deleted in round 4, see DESIGN.md section 6 round 3: nys_dz_dav on the chain's branch +0.32 %, attn3's delta out of
 #  nys_dz_dav +0.32 %, the chain branch joined in front of the landmark projection's backward +0.02 %, res_conv's weight gradient on
 #  the chain's stream +0.26 % or in front of the fork: neutral)

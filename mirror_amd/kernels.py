@@ -609,10 +609,14 @@ def layernorm_fwd_q8(x, gamma, beta, y, mean, rstd, batches, rpb, D, x_bs, y_bs,
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, batches, rpb, D, x_bs, y_bs, accumulate_dx=False, gadd=None,
-                  pad: int = 0, l: int = 1):
+                  pad: int = 0, l: int = 1, relu_out=None, relu_first: int = 0):
     """gadd ([batches, (pad + rpb) / l, D], dy's dtype): the gradient of the landmark means layernorm_fwd_lm produced; every dy row also
-    receives gadd[b, (i + pad) / l] / l (mh_layernorm_bwd_lm)."""
-    _chk(dy, x, gamma, mean, rstd, dx, dgamma, dbeta)
+    receives gadd[b, (i + pad) / l] / l (mh_layernorm_bwd_lm).  relu_out (bf16 [batches, R, D], with gadd only): rows [relu_first,
+    relu_first + R) of x are a ReLU's output — their gradient leaves as bf16 (x > 0 ? dx : 0) in relu_out instead of f32 dx."""
+    _chk(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, relu_out)
+    if relu_out is not None and (gadd is None or relu_out.dtype != torch.bfloat16 or not relu_out.is_contiguous() or relu_out.dim() != 3
+                                 or relu_out.shape[0] != batches or relu_out.shape[2] != D or relu_first + relu_out.shape[1] > rpb):
+        raise MirrorHipError("layernorm_bwd: relu_out must be contiguous bf16 [batches, R, D] with relu_first + R <= rows (landmark form only)")
     rows = batches * rpb
     ws = None
     nbytes = int(_lib.load().mh_layernorm_bwd_workspace_bytes(rows, D))
@@ -624,7 +628,8 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, batches, rpb, D, 
             raise MirrorHipError("layernorm_bwd: gadd must be contiguous [batches, (pad + rows) / l, D] in dy's dtype")
         _lib.call("mh_layernorm_bwd_lm", _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma), _p(dbeta),
                   batches, rpb, D, x_bs, y_bs, dt(x), dt(dy), dt(dx), int(accumulate_dx), _p(ws) if ws is not None else 0,
-                  ws.numel() if ws is not None else 0, _p(gadd), int(pad), int(l), stream=_stream())
+                  ws.numel() if ws is not None else 0, _p(gadd), int(pad), int(l), _p(relu_out), int(relu_first),
+                  0 if relu_out is None else int(relu_out.shape[1]), stream=_stream())
         return
     _lib.call("mh_layernorm_bwd", _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma), _p(dbeta),
               batches, rpb, D, x_bs, y_bs, dt(x), dt(dy), dt(dx), int(accumulate_dx), _p(ws) if ws is not None else 0,
@@ -1101,7 +1106,7 @@ def nys_attn1_bwd(qkv, lm, w2, dout, lse1, o1, delta1, dqkv, dw2, dlm, heads: in
                                   _lm_ld(lm), int(which), stream=_stream()))
 
 
-NYS_A3_BWD_ONE_PASS = os.environ.get("MIRROR_A3_BWD_ONE_PASS", "1") != "0"      # (A/B switch, round 5)
+NYS_A3_BWD_ONE_PASS = True      # (test hook, round 5) attn3's backward as one kernel (-1.21 % +- 0.17 step time against the dk / dv + dq_l pair)
 
 
 def nys_attn3_bwd(qkv, lm, av, dav, lse3, dqkv, dlm, heads: int, scale: float, kmask=None, delta3=None, one_pass=None) -> None:

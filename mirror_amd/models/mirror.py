@@ -531,6 +531,8 @@ class MIRROR(nn.Module):
         Fn.K.shared_chip = False   # a forward that raised between a chain fork and its join must not leave the hint set
         Fn._deferred.clear()       # hand-over slots of a backward that never completed must not meet this step's tensors
         Fn._pending_lm_merge.clear()
+        Fn._relu_rows.clear()
+        Fn._relu_grads.clear()
         # the reference draws: rand(B,N) -> rand(B,D) -> eps_wsi -> eps_rna (models/mirror.py:630, :516, :832-833);
         # draw them up front in that order so the two encoders can then run on different streams
         B, dev = wsi_emb.shape[0], wsi_emb.device

@@ -427,6 +427,56 @@ def test_whole_model_nys_sim2_on_off(monkeypatch):
         assert float(a @ c / (a.norm() * c.norm())) >= 0.99, k
 
 
+def test_whole_model_round5_fusions_on_off(monkeypatch):
+    """Whole model, bf16, train mode, D = 512 / 1024 tokens (no square-pad rows: the ReLU fusion applies).  Round 5's fused forms against
+    the launches they replace, one switch at a time: (a) _fc1's ReLU backward inside layer 1's LayerNorm backward — the same f32 value
+    rounded once either way: _fc1's weight / bias gradients and the cls-token gradient at the run-to-run floor (f32 atomics above them);
+    (b) res_conv inside attn3's forward + its two gradients in one pass — same MFMA products (losses identical, gradient cosine >= 0.9999);
+    (c) attn3's backward as one kernel and (d) attn1's dq from the saved rows beside the chain / to_out's weight gradient in the
+    window — other summation orders of the same bf16 products (losses identical: the forward does not change; cosine >= 0.999)."""
+    import mirror_amd.models as M
+    from mirror_amd import functional as Fn
+    from mirror_amd import kernels as K
+    from mirror_amd.losses import MIRRORLoss
+    cfg = dict(wsi_embed_dim=128, rna_embed_dim=96, embed_dim=512, wsi_num_tokens=1024, rna_encoder_depth=1, rna_num_heads=8,
+               rna_mlp_ratio=4.0, style_mlp_hidden_dim=128, style_mlp_out_dim=64, style_latent_dim=32, num_prototypes=300)
+    g = torch.Generator().manual_seed(15)
+    wsi = torch.randn(2, 1024, 128, generator=g).cuda().to(bf16)
+    rna = torch.randn(2, 96, generator=g).cuda()
+    noise = {"wsi_mask": torch.rand(2, 1024, generator=g).cuda(), "rna_mask": torch.rand(2, 512, generator=g).cuda(),
+             "wsi_eps": torch.randn(2, 32, generator=g).cuda(), "rna_eps": torch.randn(2, 32, generator=g).cuda()}
+
+    def run():
+        torch.manual_seed(0)
+        model = M.mirror(**cfg).cuda().train()
+        model.precision = "bf16"
+        Fn.manual_seed(99)
+        losses = MIRRORLoss()(*model(wsi, rna, noise=noise))
+        losses[0].backward()
+        torch.cuda.synchronize()
+        return [float(x) for x in losses], {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+    base_l, base_g = run()
+    relu_keys = ("wsi_encoder._fc1.0.weight", "wsi_encoder._fc1.0.bias", "wsi_encoder.cls_token")
+    for target, name, floor, exact_losses in ((Fn, "_RELU_IN_LN_BWD", 1.0, True), (Fn, "_RC_FUSED", 0.9999, True),
+                                              (K, "NYS_A3_BWD_ONE_PASS", 0.999, True), (Fn, "_A1_DQ_IN_WINDOW", 0.999, True),
+                                              (Fn, "_TO_OUT_WGRAD_IN_WINDOW", 0.999, True)):
+        monkeypatch.setattr(target, name, False)
+        l2, g2 = run()
+        monkeypatch.setattr(target, name, True)
+        if exact_losses:          # the forward is the same arithmetic either way: equal up to the f32-atomics order of the loss sums
+            assert all(abs(x - y) <= 1e-5 * max(abs(y), 1e-3) for x, y in zip(l2, base_l)), (name, l2, base_l)
+        for k in base_g:
+            a, c = base_g[k].flatten().double(), g2[k].flatten().double()
+            if float(c.norm()) < 1e-10:
+                continue
+            cos = float(a @ c / (a.norm() * c.norm()))
+            if name == "_RELU_IN_LN_BWD" and k in relu_keys:
+                # the same f32 value rounded once to bf16 either way: only the run-to-run noise of the gradients above it is left
+                assert cos >= 0.99995 and abs(float(a.norm() / c.norm()) - 1.0) <= 1e-3, (name, k, cos)
+            assert cos >= min(floor, 0.9999), (name, k, cos)
+
+
 def test_attn2_backward_tail_one_pass_equals_z0_bwd_plus_softmax_bwd():
     """mh_pinv_s2_bwd (z_0 backward + the two max() sub-gradients + attn2's softmax backward in one pass, the column maximum as a
     rank-one correction) against the composed mh_pinv_z0_bwd + mh_softmax_bwd on the same inputs ([3P] moore_penrose_iter_pinv's
