@@ -948,7 +948,8 @@ __device__ __forceinline__ void pq_epilogue_bf16(const GemmArgs& g, bf16_t* C, l
         __syncthreads();
     }
 }
-// f32 C (block (i, j) of lane (c16, g4) holds rows 16 i + 4 g4 + {0..3} of column 16 j + c16): rows [64 q, +64) of the tile through `t`, q = 0 .. 3
+// f32 C (C^T accumulators: block (i, j) of lane (c16, g4) holds columns 16 j + 4 g4 + {0..3} of row 16 i + c16): rows [64 q, +64) of the
+// tile through `t`, q = 0 .. 3
 template <int MODE, int EPI, bool RELU>
 __device__ __forceinline__ void pq_epilogue_f32(const GemmArgs& g, float* C, f32x4 (&acc)[QM][QN], char* smem_c, int tile_row0, int tile_col0,
                                                 int wm, int wn, int lane, int tid, bool lead, long ldc, float alpha) {
@@ -968,9 +969,10 @@ __device__ __forceinline__ void pq_epilogue_f32(const GemmArgs& g, float* C, f32
         thr = drop16_thr(g.epi.p);
         dscale = drop16_scale(thr);
     }
-    float bias[QN];
+    f32x4 bias[QN];
 #pragma unroll
-    for (int j = 0; j < QN; j++) bias[j] = (g.bias && lead) ? g.bias[tile_col0 + wn * QN * 16 + 16 * j + c16] : 0.f;
+    for (int j = 0; j < QN; j++)
+        bias[j] = (g.bias && lead) ? *reinterpret_cast<const f32x4*>(g.bias + tile_col0 + wn * QN * 16 + 16 * j + 4 * g4) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         if (wm == (q >> 1)) {
@@ -978,13 +980,12 @@ __device__ __forceinline__ void pq_epilogue_f32(const GemmArgs& g, float* C, f32
             for (int ii = 0; ii < 4; ii++)
 #pragma unroll
                 for (int j = 0; j < QN; j++) {
-                    const int lc = wn * QN * 16 + 16 * j + c16;
+                    f32x4 v = acc[4 * (q & 1) + ii][j] * alpha + bias[j];
+                    if constexpr (RELU) {
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        float v = alpha * acc[4 * (q & 1) + ii][j][e] + bias[j];
-                        if constexpr (RELU) v = fmaxf(v, 0.f);
-                        t[(16 * ii + 4 * g4 + e) * PITCH + lc] = v;
+                        for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
                     }
+                    *reinterpret_cast<f32x4*>(t + (16 * ii + c16) * PITCH + wn * QN * 16 + 16 * j + 4 * g4) = v;
                 }
         }
         __syncthreads();
@@ -1082,8 +1083,9 @@ __device__ __forceinline__ void pq_epilogue_f32(const GemmArgs& g, float* C, f32
 template <typename TC, bool AKC, bool BKC, bool PART = false, int EPI = 0, int VAR = 0>
 __global__ __launch_bounds__(NTB) void gemm_pq_kernel(GemmArgs g, int units, int tiles, int splits) {
     static_assert(EPI == 0 || (AKC && !PART), "fused epilogues: K-contiguous A, no split-K");
-    // C^T accumulators (a lane owns 4 consecutive columns of a row) wherever the tile leaves as bf16: C itself, or a split-K partial tile
-    constexpr bool CT = sizeof(TC) == 2 || PART;
+    // C^T accumulators (a lane owns 4 consecutive columns of a row) for every result: bf16 C / split-K partial tiles since round 4, f32 C
+    // since round 5 (its staging writes were one 4-byte ds_write per ELEMENT: 16-byte writes now)
+    constexpr bool CT = true;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -79,15 +79,17 @@ class HostFeeder:
         for wsi, rna in feeder:          # device tensors; valid until the NEXT iteration step
             engine.step(wsi, rna)
 
+    Three slots by default (a slot is reused when the step that read it lies two steps back: the host-side wait for it never blocks).
     Host batches are staged in pinned buffers (allocated once, sized by the first batch); the f32 -> bf16 cast, when asked for,
     happens on the device on the copy stream (a host-side cast would cost more CPU time than the copy saves).  The consumer
     stream waits on an event, never on the host."""
 
-    def __init__(self, loader, device, wsi_dtype: Optional[torch.dtype] = None, depth: int = 2):
+    def __init__(self, loader, device, wsi_dtype: Optional[torch.dtype] = None, depth: int = 3):
         self.loader, self.device, self.wsi_dtype = loader, torch.device(device), wsi_dtype
         if self.device.type != "cuda":
             raise MirrorHipError("HostFeeder feeds an MI355X device")
-        self.depth = max(2, int(depth))
+        self.depth = max(3, int(depth))       # slots; batches in flight ahead of the consumer = depth - 2 (see _issue: the slot that is
+                                              # refilled was last read TWO steps back, so the host-side wait for it does not block)
         self.stream = torch.cuda.Stream(device=self.device)
         self._slots = []          # per slot: (pinned wsi, pinned rna, device wsi raw, device wsi, device rna, ready event, free event)
         self._k = 0               # running slot counter: NOT reset per epoch, so two consecutive batches never share a slot
@@ -117,7 +119,13 @@ class HostFeeder:
         if used:
             ready.synchronize()                   # the slot's previous host -> device copy has left the pinned buffer (depth steps ago)
         if free is not None:
-            self.stream.wait_event(free)          # the step that consumed this slot's device tensors has been queued and finished
+            # the step that consumed this slot's device tensors has finished: waited for on the HOST.  With three slots that step lies two
+            # steps back and the wait never blocks — and the copy stream must not carry a device-side wait: on this platform ANY
+            # hipStreamWaitEvent on the stream that issues the pinned -> device copy (even on an event that completed long ago) takes the
+            # copy out from under the replayed step, which then runs one whole PCIe transfer late (measured, tools/exp/h2d_overlap3.py:
+            # replay 7.81 ms; + copy behind a host wait 8.12; + copy behind a stream wait on the same, complete, event 9.52; behind the
+            # previous replay's event 10.24 — rounds 2-4 reported 22-37 % for --feed host-bf16 / host without finding this)
+            free.synchronize()
         sl[7] = True
         # a pinned batch (DataLoader(pin_memory=True), what train_mirror.py builds with --pin-mem) goes to the device as it is;
         # a pageable one is staged through the slot's pinned buffer first (one host memcpy: ~10 GB/s on one core, i.e. the
@@ -139,7 +147,7 @@ class HostFeeder:
         it = iter(self.loader)
         pending = []
         k = self._k
-        for _ in range(self.depth - 1):
+        for _ in range(self.depth - 2):
             try:
                 pending.append(self._issue(k % self.depth, next(it)))
                 k += 1

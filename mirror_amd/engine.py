@@ -50,6 +50,7 @@ def plan_buckets(sizes: Sequence[int], cap_elems: int, align: int = _ALIGN):
 _ASYNC_GATHER = True      # alignment all-gather issued behind the heads
 _DEFER_SKINNY = True      # one multi-tensor launch for the skinny weight gradients
 _TRANSPOSE_AT_START = True      # (test hook)
+_KERNEL_D2D = os.environ.get("MIRROR_KERNEL_D2D", "1") != "0"      # (A/B switch, round 5) the static-input refresh of a replayed step as a kernel
 
 
 class TrainEngine:
@@ -364,7 +365,16 @@ class TrainEngine:
             # key-padding mask is one more static input of the captured step, refreshed like the batch
             for k, t in enumerate((wsi, rna) if mask is None else (wsi, rna, mask)):
                 if self._g_src[k] is not t or self._g_ver[k] != t._version:
-                    self._g_in[k].copy_(t, non_blocking=True)
+                    dst = self._g_in[k]
+                    if (_KERNEL_D2D and t.dtype in (f32, bf16) and t.dtype == dst.dtype and t.is_contiguous() and t.numel() >= (1 << 20)
+                            and t.numel() % 4 == 0 and t.data_ptr() % 16 == 0):
+                        # a KERNEL, not the copy engine: a device-to-device hipMemcpyAsync is queued on the same in-order SDMA engine
+                        # as the feeder's host -> device copy of the NEXT batch, which the host enqueued first and which waits for the
+                        # previous step — the replay then started one PCIe copy (2.4 ms for 134 MB) late, every step (row f2:
+                        # --feed host-bf16 ran 22-37 % behind the resident batch for three rounds)
+                        K.cast(t, t.dtype, out=dst)
+                    else:
+                        dst.copy_(t, non_blocking=True)
                     self._g_src[k], self._g_ver[k] = t, t._version
             self._graph.replay()
             self.step_count += 1
