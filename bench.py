@@ -85,6 +85,9 @@ CONFIGS = {
     "c2": dict(N=4096, F=1024, G=2048, D=512, L=6, heads=8, mlp=4.0),
     "c1": dict(N=256, F=1024, G=512, D=256, L=2, heads=8, mlp=4.0),
     "template": dict(N=2048, F=768, G=10234, D=768, L=2, heads=12, mlp=2.572),
+    # BASELINE.json configs[3]: Phikon-dim features (768-d), 8192 patch tokens per slide, per-sample valid length ~U[2048, 8192] (seeded),
+    # padded + bool key-padding mask through every Nystrom layer; a separate bench line, B = 8 unless --batch says otherwise
+    "c4": dict(N=8192, F=768, G=2048, D=512, L=6, heads=8, mlp=4.0, mask=True, batch=8),
 }
 
 
@@ -93,7 +96,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (weak scaling); default 16 (the reference template's batch_size), 8 for --config c4")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16_pinv32", "fp32", "fp8"])
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -144,6 +147,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: " + lib.mh_last_error().decode())
 
     shp = CONFIGS[a.config]
+    if a.batch is None:
+        a.batch = shp.get("batch", 16)
     torch.manual_seed(42)   # configs/pretrain/mirror.template.yaml:123
     model = M.mirror(wsi_embed_dim=shp["F"], rna_embed_dim=shp["G"], embed_dim=shp["D"], wsi_num_tokens=shp["N"],
                      rna_encoder_depth=shp["L"], rna_mlp_ratio=shp["mlp"], rna_norm_layer="layernorm", rna_act_layer="gelu",
@@ -157,6 +162,14 @@ def main():
     in_dtype = torch.float32 if a.precision == "fp32" else torch.bfloat16
     wsi = torch.randn(a.batch, shp["N"], shp["F"], device=dev, generator=g).to(in_dtype)
     rna = torch.randn(a.batch, shp["G"], device=dev, generator=g)
+    kw, lens = {}, None
+    if shp.get("mask"):       # config 4: padded slides + key-padding mask (a static input of the captured step, refreshed like the batch)
+        lens = torch.randint(2048, shp["N"] + 1, (a.batch,), device=dev, generator=g)
+        kmask = torch.arange(shp["N"], device=dev)[None, :] < lens[:, None]
+        wsi = wsi * kmask[..., None]                  # padded rows are zeros, as a collate function would leave them
+        kw = {"wsi_key_padding_mask": kmask}
+        if a.feed != "resident":
+            raise SystemExit("bench.py: --feed host* is measured on c2 (the HostFeeder does not carry masks)")
 
     def sync_all():
         if world > 1:
@@ -174,12 +187,12 @@ def main():
         if i == min(1, nwarm - 1):
             torch.cuda.synchronize()
             K.gemm_profiler = K.GemmProfiler()
-            eng.step(wsi, rna)
+            eng.step(wsi, rna, **kw)
             torch.cuda.synchronize()
             summ = K.gemm_profiler.summary()
             K.gemm_profiler = None
         else:
-            eng.step(wsi, rna)
+            eng.step(wsi, rna, **kw)
     dominant = max(summ, key=lambda v: summ[v]["total_ms"])
 
     # ---- timed region: exactly K steps, barrier + synchronize on both sides.  On one GPU every step is ONE HIP-graph
@@ -201,7 +214,7 @@ def main():
     if feed is None:
         for _ in range(a.steps):
             h0 = time.perf_counter()
-            losses = eng.step(wsi, rna)
+            losses = eng.step(wsi, rna, **kw)
             host_us.append((time.perf_counter() - h0) * 1e6)
     else:
         for w_, r_ in it:
@@ -218,7 +231,7 @@ def main():
     eng._use_graph = False
     K.gemm_profiler = K.GemmProfiler(only=dominant)
     for _ in range(min(a.steps, 5)):
-        eng.step(wsi, rna)
+        eng.step(wsi, rna, **kw)
     torch.cuda.synchronize()
     prof = K.gemm_profiler.summary().get(dominant, {"launches": 0, "total_ms": 0.0, "flops": 0.0})
     K.gemm_profiler = None
@@ -285,6 +298,7 @@ def main():
                                    f"{'global' if (world > 1 and not a.no_gather) else 'local'}-batch InfoNCE",
                        "precision_policy": a.precision, "per_gpu_batch": a.batch, "global_batch": a.batch * world,
                        "parallelism": f"dp{world}", "untimed_steps": nwarm, "grad_bucket_dtype": a.grad_dtype,
+                       **({"valid_lengths": lens.tolist(), "mask": "key-padding mask through every Nystrom layer (static input of the captured step)"} if lens is not None else {}),
                        "step_launch": "hip_graph" if graphed else (
                            "eager + graphed RNA branch" if getattr(eng, "_rna_branch_state", "") == "on" else "eager")},
             "model_tflops_per_s": round(step_tflops, 2),
@@ -308,7 +322,7 @@ def main():
                          "flops_unit": "GFLOP (algorithmic: 2*M*N*K*batch per GEMM; 2*m^3 per chain product)",
                          "runner_up": sorted(((round(v["total_ms"], 3), k) for k, v in summ.items()), reverse=True)[1:4]},
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and not shp.get("mask"):      # (the CPU leg times the unmasked path; c4 is reported without it)
             from oracle import mirror_oracle as O
             from oracle.cpu_step import time_cpu_steps
             cfg = O.Cfg(wsi_embed_dim=shp["F"], rna_embed_dim=shp["G"], embed_dim=shp["D"], wsi_num_tokens=shp["N"],
