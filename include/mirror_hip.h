@@ -207,14 +207,25 @@ int mh_layernorm_bwd(const void* dy, const void* x, const float* gamma, const fl
 int mh_layernorm_fwd_lm(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, void* xpm,
                         void* xpm_bf16, int batches, int rows, int D, int64_t x_bs, int pad, int l, float eps, mh_stream s);
                         /* xpm_bf16 (optional): the bf16 rounding of xpm, the B operand of the landmark projection's weight gradient */
+/* mh_layernorm_bwd for a LayerNorm output that fans out (the WSI encoder's final norm: decoder input, retention target = rows 1..,
+ * cls row; models/mirror.py:684-700, :833): f32 x / dy / dx; dy row i >= 1 of batch b also receives fan_alpha * fan_bf16[b, i - 1]
+ * (fan_bf16 [batches, rows_per_batch - 1, D]: the masked MSE hands its target gradient over as -dpred) and row 0 fan_cls[b]
+ * (f32 [batches, D], may be NULL) — the three-way sum mh_fanout_bwd writes is formed while this launch reads its operands.
+ * Needs the workspace form (D % 4 == 0, 16-byte aligned buffers, >= 64 rows, mh_layernorm_bwd_workspace_bytes). */
+int mh_layernorm_bwd_fan(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                         void* dx, float* dgamma, float* dbeta, int batches, int rows_per_batch, int D, int64_t x_bs, int64_t y_bs,
+                         int accumulate_dx, float* workspace, int64_t ws_floats, const void* fan_bf16, float fan_alpha,
+                         const float* fan_cls, mh_stream s);
 int mh_layernorm_bwd_lm(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                         void* dx, float* dgamma, float* dbeta, int batches, int rows_per_batch, int D, int64_t x_bs, int64_t y_bs,
                         int dt_x, int dt_dy, int dt_dx, int accumulate_dx, float* workspace, int64_t ws_floats,
-                        const void* gadd, int pad, int l, void* relu_out, int relu_first, int relu_rows, mh_stream s);
+                        const void* gadd, int pad, int l, void* relu_out, int relu_first, int relu_rows, float* relu_db, mh_stream s);
                         /* relu_out (nullable, bf16 [batches, relu_rows, D]; f32 x): x rows [relu_first, relu_first + relu_rows) of every batch
                            are the output of a ReLU (`_fc1 = Linear + ReLU`, models/mirror.py:346, :652-654, feeds layer 1's norm): their
                            total gradient is written HERE as bf16 (x > 0 ? dx : 0), the operand of _fc1's weight gradient, and NOT as f32 dx
-                           (no separate ReLU-backward pass); the other rows (cls) keep their f32 dx */
+                           (no separate ReLU-backward pass); the other rows (cls) keep their f32 dx.
+                           relu_db (nullable, f32 [D], needs relu_out and a workspace of >= 3 D floats): += the column sums of relu_out as
+                           stored, i.e. _fc1's bias gradient, as a third partial row beside dgamma / dbeta (no mh_colsum pass over relu_out) */
 
 /* ---------------------------------------------------------------- fp8 forward projections (BASELINE config 5)
  * mh_quant_fp8: q[i] = e4m3(x[i] * 448 / max|x|) for a whole tensor (x f32 / bf16, n % 4 == 0), scale[0] = max|x| / 448
@@ -409,9 +420,13 @@ int mh_rank_mask(const float* noise, float* mask, int B, int N, int len_keep, mh
 /* y [B, T, D] (dt_y): rows t>=first take `token` where mask[b,t-first] != 0, else x (dt_x); then + pos[t]  (pos [T,D]) */
 int mh_mask_apply_fwd(const void* x, void* y, const float* mask, const float* token, const float* pos, int B, int T, int D,
                       int first, int token_scalar, int dt_x, int dt_y, mh_stream s);   /* y may be x (in place, same dtype) */
-/* dx (dt_dx) = dy*(1-mask) (dx may be dy when the dtypes agree); dtoken += sum mask*dy ; dpos[t] += sum_b dy */
+/* dx (dt_dx) = dy*(1-mask) (dx may be dy when the dtypes agree); dtoken += sum mask*dy ; dpos[t] += sum_b dy.
+ * dbias [D] f32 (may be NULL; only where mh_mask_apply_bwd_dbias_ok): += the column sums of dx, i.e. the bias gradient of the Linear
+ * whose output the forward masked (retention_embed, models/mirror.py:636-643) — the pass already holds both sums it is the
+ * difference of, so mh_colsum over dx is not launched. */
+int mh_mask_apply_bwd_dbias_ok(const void* dy, const void* dx, const float* dpos, int D, int dt_dy, int dt_dx);
 int mh_mask_apply_bwd(const void* dy, void* dx, const float* mask, float* dtoken, float* dpos, int B, int T, int D,
-                      int first, int token_scalar, int dt_dy, int dt_dx, mh_stream s);
+                      int first, int token_scalar, int dt_dy, int dt_dx, float* dbias, mh_stream s);
 
 /* ---------------------------------------------------------------- RNA encoder pieces (models/mirror.py:77-102)
  * qkv [B, 3D] -> softmax over the HEADS axis -> out[b, d*H + h]; attn [B,H,H] saved for backward */
@@ -515,10 +530,13 @@ int mh_ce_rows_bwd(const float* G, int64_t ldg, const float* scale, float scale_
  * (a row window of a larger buffer: the WSI target is encoder_output[:, 1:], models/mirror.py:700) */
 int mh_mse_masked_fwd(const void* pred, const void* tgt, const float* mask, float* acc, int64_t rows, int D,
                       int64_t rows_per_batch, int64_t tgt_bs, int dt_p, int dt_t, mh_stream s);
-/* dpred[rows, D] (dt_dp) = g[0] * gmul * 2*mask*(p-t)/(D*acc[1]) (gmul: the term's loss weight, host constant); dtgt[rows, D] (dt_t) = -dpred, not written when NULL */
+/* dpred[rows, D] (dt_dp) = g[0] * gmul * 2*mask*(p-t)/(D*acc[1]) (gmul: the term's loss weight, host constant); dtgt[rows, D] (dt_t) = -dpred, not written when NULL.
+ * colsum_ws [cs_blocks, D] f32 (may be NULL; bf16 pred / f32 target / bf16 dpred, D a multiple of 256 up to 1024): the launch runs cs_blocks blocks and block i
+ * leaves the column sums of the dpred rows it wrote in row i (every row is written, nothing to zero): mh_colsum over that table is the
+ * bias gradient of the Linear that produced pred (retention_head, models/mirror.py:698-699) without a second pass over dpred. */
 int mh_mse_masked_bwd(const void* pred, const void* tgt, const float* mask, const float* acc, const float* g, float gmul,
                       void* dpred, void* dtgt, int64_t rows, int D, int64_t rows_per_batch, int64_t tgt_bs, int dt_p, int dt_t,
-                      int dt_dp, mh_stream s);
+                      int dt_dp, float* colsum_ws, int cs_blocks, mh_stream s);
 /* Data feed (datasets/dataset_pretrain.py:150-167, `wsi_feature[sampled_indices]`): out[r, :] = src[row[r], :] for R rows of F
  * elements; src is the bank of all slides' patch features back to back ([src_rows, F]); row holds GLOBAL row indices
  * (slide offset + sampled index; clamped to the bank). */

@@ -102,7 +102,8 @@ _SIGS = {
     "mh_layernorm_fwd_dual": [P, P, P, P, P, P, P, I, I, I, L, L, F],
     "mh_layernorm_fwd_q8": [P, P, P, P, P, P, I, I, I, L, L, F, P, P, P, F, P],
     "mh_layernorm_bwd": [P, P, P, P, P, P, P, P, I, I, I, L, L, I, I, I, I, P, L],
-    "mh_layernorm_bwd_lm": [P, P, P, P, P, P, P, P, I, I, I, L, L, I, I, I, I, P, L, P, I, I, P, I, I],
+    "mh_layernorm_bwd_fan": [P, P, P, P, P, P, P, P, I, I, I, L, L, I, P, L, P, F, P],
+    "mh_layernorm_bwd_lm": [P, P, P, P, P, P, P, P, I, I, I, L, L, I, I, I, I, P, L, P, I, I, P, I, I, P],
     "mh_layernorm_fwd_lm": [P, P, P, P, P, P, P, P, I, I, I, L, I, I, F],
     "mh_softmax_fwd": [P, P, L, I, L, L, I, I],
     "mh_softmax_bwd": [P, P, P, L, I, L, L, L, I, I, I],
@@ -135,7 +136,7 @@ _SIGS = {
     "mh_ppeg_grad_scatter": [P, P, P, P, P, P, P, P, I],
     "mh_rank_mask": [P, P, I, I, I],
     "mh_mask_apply_fwd": [P, P, P, P, P, I, I, I, I, I, I, I],
-    "mh_mask_apply_bwd": [P, P, P, P, P, I, I, I, I, I, I, I],
+    "mh_mask_apply_bwd": [P, P, P, P, P, I, I, I, I, I, I, I, P],
     "mh_headattn_fwd": [P, P, P, I, I, I, I],
     "mh_headattn_bwd": [P, P, P, P, I, I, I, I],
     "mh_add": [P, P, P, L, I, I, I],
@@ -159,7 +160,7 @@ _SIGS = {
     "mh_ce_rows_fwd": [P, L, P, F, I, I, I, F, P, P, P],
     "mh_ce_rows_bwd": [P, L, P, F, P, P, I, F, P, P, I, I, I],
     "mh_mse_masked_fwd": [P, P, P, P, L, I, L, L, I, I],
-    "mh_mse_masked_bwd": [P, P, P, P, P, F, P, P, L, I, L, L, I, I, I],
+    "mh_mse_masked_bwd": [P, P, P, P, P, F, P, P, L, I, L, L, I, I, I, P, I],
     "mh_fanout_bwd": [P, P, F, P, P, I, I, I, I],
     "mh_gather_rows": [P, P, P, L, L, L, I],
     "mh_quant_fp8": [P, L, P, P, P, I],
@@ -185,14 +186,14 @@ _SIGS = {
 }
 EXPORTS = sorted(list(_SIGS) + ["mh_last_error", "mh_version", "mh_exp_build", "mh_gemm_select_pp", "mh_gemm_variant_name", "mh_device_ok", "mh_nys_attn3_ws_floats", "mh_rna_block_workspace_bytes",
                                  "mh_gemm_workspace_bytes", "mh_layernorm_bwd_workspace_bytes", "mh_nys_attn3_workspace_bytes",
-                                 "mh_pinv_chain_workspace_bytes", "mh_resconv_bwd_workspace_bytes"])
+                                 "mh_pinv_chain_workspace_bytes", "mh_resconv_bwd_workspace_bytes", "mh_mask_apply_bwd_dbias_ok"])
 
 _lib = None
 
 # The ABI generation this binding was written against (mh_version() of csrc/errors.cpp).  _SIGS above restates the argument lists of
 # include/mirror_hip.h by hand: a library built from another generation would be called with shifted arguments (a stream where a
 # counter belongs) and corrupt device memory silently, so load() refuses anything but this exact number.
-ABI_VERSION = 107
+ABI_VERSION = 108
 
 
 class MirrorHipError(RuntimeError):
@@ -236,6 +237,8 @@ def load() -> C.CDLL:
     lib.mh_pinv_chain_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     lib.mh_resconv_bwd_workspace_bytes.restype = C.c_int64
     lib.mh_resconv_bwd_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.mh_mask_apply_bwd_dbias_ok.restype = C.c_int
+    lib.mh_mask_apply_bwd_dbias_ok.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
     lib.mh_rna_block_workspace_bytes.restype = C.c_int64
     lib.mh_rna_block_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
     for name, sig in _SIGS.items():

@@ -420,8 +420,47 @@ __global__ __launch_bounds__(256) void colsum_bf16_vec_kernel(const bf16_t* __re
     }
 }
 
+// f32 rows of quads (a table of per-block partial sums, an f32 gradient): lane = one quad of columns, the rows dealt to gridDim.y x 4
+// waves with eight 16-byte loads in flight each, one atomic per column and workgroup.  (colsum_kernel<float> walks a 512 x 512 table
+// in 8 workgroups of serial 4-byte loads: 32 us where this takes ~5.)
+__global__ __launch_bounds__(256) void colsum_f32_vec_kernel(const float* __restrict__ x, float* __restrict__ out, long rows, int cols, long ld) {
+    typedef float cf4 __attribute__((ext_vector_type(4)));
+    __shared__ cf4 red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + lane) * 4;
+    const bool live = c < cols;
+    const long chunks = (long)gridDim.y * 4, per = (rows + chunks - 1) / chunks;
+    const long r0 = ((long)blockIdx.y * 4 + wave) * per, r1 = min(rows, r0 + per);
+    cf4 sum = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        long r = r0;
+        for (; r + 8 <= r1; r += 8) {
+            cf4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const cf4*>(x + (r + u) * ld + c);
+#pragma unroll
+            for (int u = 0; u < 8; u++) sum += v[u];
+        }
+        for (; r < r1; r++) sum += *reinterpret_cast<const cf4*>(x + r * ld + c);
+    }
+    red[wave][lane] = sum;
+    __syncthreads();
+    if (wave == 0 && live) {
+        sum = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            if (sum[e] != 0.f) atomicAdd(out + c + e, sum[e]);
+    }
+}
+
 extern "C" int mh_colsum(const void* x, float* out, int64_t rows, int cols, int64_t ld, int dt, mh_stream s) {
     if (rows == 0 || cols == 0) return MH_OK;
+    if (dt == MH_F32 && cols % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x & 15) == 0 && rows >= 32) {
+        dim3 gv(mh_cdiv(cols / 4, 64), (unsigned)min((long)mh_cdiv(rows, 32), 64L));
+        hipLaunchKernelGGL(colsum_f32_vec_kernel, gv, dim3(256), 0, (hipStream_t)s, (const float*)x, out, (long)rows, cols, (long)ld);
+        MH_LAUNCH_CHECK("mh_colsum");
+        return MH_OK;
+    }
     if (dt == MH_BF16 && cols % 8 == 0 && ld % 8 == 0 && ((uintptr_t)x & 15) == 0 && rows >= 1024) {
         const int cb = mh_cdiv(cols, 512);
         long nb = max(1L, 512L / cb);
@@ -558,12 +597,15 @@ typedef float mb_f4 __attribute__((ext_vector_type(4)));
 template <typename TDX>
 __global__ __launch_bounds__(256) void mask_apply_bwd_vec_kernel(const float* dy, TDX* dx, const float* __restrict__ mask,
                                                                  float* __restrict__ dtoken, float* __restrict__ dpos, int B, int Tn, int D,
-                                                                 int first, int token_scalar, int band) {
+                                                                 int first, int token_scalar, int band, float* __restrict__ dbias) {
+    // dbias [D] (round 5, may be null): += the column sums of dx AS STORED (rounded to TDX, what mh_colsum over dx would read): the
+    // bias gradient of the projection in front, without that pass
     __shared__ mb_f4 red[4][64];
+    __shared__ mb_f4 reda[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 256 + 4 * lane;
     const int t0 = blockIdx.y * band, t1 = min(Tn, t0 + band);
-    mb_f4 st = {0.f, 0.f, 0.f, 0.f};
+    mb_f4 st = {0.f, 0.f, 0.f, 0.f}, sa = {0.f, 0.f, 0.f, 0.f};
     if (c < D) {
         for (int t = t0 + wave; t < t1; t += 4) {
             mb_f4 sp = {0.f, 0.f, 0.f, 0.f};
@@ -582,6 +624,10 @@ __global__ __launch_bounds__(256) void mask_apply_bwd_vec_kernel(const float* dy
                     sp += g[u];
                     const bool msk = mk[u] != 0.f;
                     if (msk) st += g[u];
+                    else if constexpr (sizeof(TDX) == 2) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) sa[e] += bf2f(f2bf(g[u][e]));
+                    } else sa += g[u];
                     if (msk || (const void*)dx != (const void*)dy)
                         st4(dx + ((long)(b0 + u) * Tn + t) * D + c, msk ? (mb_f4){0.f, 0.f, 0.f, 0.f} : g[u]);
                 }
@@ -591,7 +637,14 @@ __global__ __launch_bounds__(256) void mask_apply_bwd_vec_kernel(const float* dy
         }
     }
     red[wave][lane] = st;
+    reda[wave][lane] = sa;
     __syncthreads();
+    if (wave == 1 && c < D && dbias) {
+        const mb_f4 un = reda[0][lane] + reda[1][lane] + reda[2][lane] + reda[3][lane];
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            if (un[e] != 0.f) atomicAdd(dbias + c + e, un[e]);
+    }
     if (wave == 0 && c < D) {
         const mb_f4 tot = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
         if (token_scalar) {
@@ -648,9 +701,16 @@ extern "C" int mh_mask_apply_fwd(const void* x, void* y, const float* mask, cons
     return MH_OK;
 }
 
+// the quad form below (the one that can leave the bias gradient too)
+extern "C" int mh_mask_apply_bwd_dbias_ok(const void* dy, const void* dx, const float* dpos, int D, int dt_dy, int dt_dx) {
+    return dt_dy == MH_F32 && D % 4 == 0 && D >= 256 && mh_quad_ok(dx, mh_dt_size(dt_dx)) && (((uintptr_t)dy | (uintptr_t)dpos) & 15) == 0;
+}
+
 extern "C" int mh_mask_apply_bwd(const void* dy, void* dx, const float* mask, float* dtoken, float* dpos, int B, int T, int D,
-                                 int first, int token_scalar, int dt_dy, int dt_dx, mh_stream s) {
+                                 int first, int token_scalar, int dt_dy, int dt_dx, float* dbias, mh_stream s) {
     if (T == 0 || D == 0 || B == 0) return MH_OK;
+    MH_REQUIRE(!dbias || mh_mask_apply_bwd_dbias_ok(dy, dx, dpos, D, dt_dy, dt_dx),
+               "mh_mask_apply_bwd: dbias needs the quad form (f32 dy, D %% 4 == 0, D >= 256, 16-byte aligned operands)");
     if (D == 1) {
 #define MAB1_(TDY, TDX) hipLaunchKernelGGL((mask_apply_bwd_d1_kernel<TDY, TDX>), dim3(mh_cdiv(T, 256)), dim3(256), 0, (hipStream_t)s, (const TDY*)dy, (TDX*)dx, mask, dtoken, dpos, B, T, first)
         DISPATCH2(dt_dy, dt_dx, MAB1_)
@@ -658,11 +718,11 @@ extern "C" int mh_mask_apply_bwd(const void* dy, void* dx, const float* mask, fl
         MH_LAUNCH_CHECK("mh_mask_apply_bwd");
         return MH_OK;
     }
-    if (dt_dy == MH_F32 && D % 4 == 0 && D >= 256 && mh_quad_ok(dx, mh_dt_size(dt_dx)) && (((uintptr_t)dy | (uintptr_t)dpos) & 15) == 0) {
+    if (mh_mask_apply_bwd_dbias_ok(dy, dx, dpos, D, dt_dy, dt_dx)) {
         const int band = 16;     // rows of t per block: T / 16 x D / 256 blocks, 4 waves x 8 rows of 1 KiB in flight each
         dim3 gv(mh_cdiv(D, 256), mh_cdiv(T, band));
-        if (dt_dx == MH_F32) hipLaunchKernelGGL((mask_apply_bwd_vec_kernel<float>), gv, dim3(256), 0, (hipStream_t)s, (const float*)dy, (float*)dx, mask, dtoken, dpos, B, T, D, first, token_scalar, band);
-        else hipLaunchKernelGGL((mask_apply_bwd_vec_kernel<bf16_t>), gv, dim3(256), 0, (hipStream_t)s, (const float*)dy, (bf16_t*)dx, mask, dtoken, dpos, B, T, D, first, token_scalar, band);
+        if (dt_dx == MH_F32) hipLaunchKernelGGL((mask_apply_bwd_vec_kernel<float>), gv, dim3(256), 0, (hipStream_t)s, (const float*)dy, (float*)dx, mask, dtoken, dpos, B, T, D, first, token_scalar, band, dbias);
+        else hipLaunchKernelGGL((mask_apply_bwd_vec_kernel<bf16_t>), gv, dim3(256), 0, (hipStream_t)s, (const float*)dy, (bf16_t*)dx, mask, dtoken, dpos, B, T, D, first, token_scalar, band, dbias);
         MH_LAUNCH_CHECK("mh_mask_apply_bwd");
         return MH_OK;
     }

@@ -179,6 +179,75 @@ __global__ __launch_bounds__(256) void mse_masked_bwd_vec_kernel(const TP* __res
     }
 }
 
+// the same pass with the column sums of dpred beside it (round 5): cs[block][D] gets the sums over the rows this block walked (plain
+// stores, every block writes its whole row — nothing to zero), which mh_colsum over the [blocks, D] table folds into the bias gradient of
+// the Linear that produced pred: the colsum pass over all of dpred (rows x D bf16 read again, 27 us at 65536 x 1024) is not launched.
+// The sums are of the values as stored (rounded to TD), like mh_colsum over dpred would see them.  NCH = D / 256.
+template <typename TP, typename TT, typename TD, int NCH>
+__global__ __launch_bounds__(256) void mse_masked_bwd_cs_kernel(const TP* __restrict__ pred, const TT* __restrict__ tgt,
+                                                                const float* __restrict__ mask, const float* __restrict__ acc,
+                                                                const float* __restrict__ g, TD* __restrict__ dpred, TT* __restrict__ dtgt,
+                                                                long rows, long rpb, long tgt_bs, float gmul, float* __restrict__ cs) {
+    constexpr int D = 256 * NCH;
+    constexpr int RIF = NCH <= 2 ? 4 : 2;       // rows in flight per wave (48 B per lane and row at NCH = 2)
+    __shared__ f4_t red[3][NCH][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float k = g[0] * gmul * 2.f / ((float)D * acc[1]);
+    f4_t sum[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; j++) sum[j] = (f4_t){0.f, 0.f, 0.f, 0.f};
+    for (long r0 = (long)blockIdx.x * (4 * RIF) + wave; r0 < rows; r0 += (long)gridDim.x * (4 * RIF)) {
+        float mk[RIF];
+        f4_t p[RIF][NCH], t[RIF][NCH];
+        bool ok[RIF];
+#pragma unroll
+        for (int u = 0; u < RIF; u++) {           // RIF rows per wave in flight
+            const long r = r0 + 4 * u;
+            ok[u] = r < rows;
+            mk[u] = ok[u] ? mask[r] : 0.f;
+            if (mk[u] != 0.f) {
+                const TP* pr = pred + r * D;
+                const TT* tr = tgt + (r / rpb) * tgt_bs + (r % rpb) * D;
+#pragma unroll
+                for (int j = 0; j < NCH; j++) {
+                    p[u][j] = ld4(pr + 256 * j + 4 * lane);
+                    t[u][j] = ld4(tr + 256 * j + 4 * lane);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RIF; u++) {
+            if (!ok[u]) continue;
+            const long r = r0 + 4 * u;
+            const float km = k * mk[u];
+#pragma unroll
+            for (int j = 0; j < NCH; j++) {
+                f4_t d = {0.f, 0.f, 0.f, 0.f};
+                if (mk[u] != 0.f) {
+                    d = (p[u][j] - t[u][j]) * km;
+                    if constexpr (sizeof(TD) == 2) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) d[e] = bf2f(f2bf(d[e]));
+                    }
+                    sum[j] += d;
+                }
+                st4(dpred + r * D + 256 * j + 4 * lane, d);
+                if (dtgt) st4(dtgt + r * D + 256 * j + 4 * lane, -d);
+            }
+        }
+    }
+    if (wave) {
+#pragma unroll
+        for (int j = 0; j < NCH; j++) red[wave - 1][j][lane] = sum[j];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int j = 0; j < NCH; j++)
+            *reinterpret_cast<f4_t*>(cs + (long)blockIdx.x * D + 256 * j + 4 * lane) = sum[j] + red[0][j][lane] + red[1][j][lane] + red[2][j][lane];
+    }
+}
+
 extern "C" int mh_mse_masked_fwd(const void* pred, const void* tgt, const float* mask, float* acc, int64_t rows, int D,
                                  int64_t rows_per_batch, int64_t tgt_bs, int dt_p, int dt_t, mh_stream s) {
     if (rows == 0) return MH_OK;
@@ -210,11 +279,21 @@ extern "C" int mh_mse_masked_fwd(const void* pred, const void* tgt, const float*
 
 extern "C" int mh_mse_masked_bwd(const void* pred, const void* tgt, const float* mask, const float* acc, const float* g,
                                  float gmul, void* dpred, void* dtgt, int64_t rows, int D, int64_t rows_per_batch, int64_t tgt_bs,
-                                 int dt_p, int dt_t, int dt_dp, mh_stream s) {
+                                 int dt_p, int dt_t, int dt_dp, float* colsum_ws, int cs_blocks, mh_stream s) {
     if (rows == 0) return MH_OK;
     MH_REQUIRE(rows_per_batch > 0, "mh_mse_masked_bwd: rows_per_batch must be positive");
     const bool vec = D % 4 == 0 && tgt_bs % 4 == 0 && mh_quad_ok(pred, mh_dt_size(dt_p)) && mh_quad_ok(tgt, mh_dt_size(dt_t)) &&
                      mh_quad_ok(dpred, mh_dt_size(dt_dp)) && (!dtgt || mh_quad_ok(dtgt, mh_dt_size(dt_t)));
+    if (colsum_ws) {
+        MH_REQUIRE(vec && D % 256 == 0 && D <= 1024 && cs_blocks >= 1 && cs_blocks <= 4096 && dt_p == MH_BF16 && dt_t == MH_F32 && dt_dp == MH_BF16 &&
+                       (((uintptr_t)colsum_ws) & 15) == 0,
+                   "mh_mse_masked_bwd: colsum_ws needs bf16 pred / f32 target / bf16 dpred on quads and D in {256, 512, 768, 1024} (got D=%d, dtypes %d %d %d)", D, dt_p, dt_t, dt_dp);
+#define MSECS(NCH) hipLaunchKernelGGL((mse_masked_bwd_cs_kernel<bf16_t, float, bf16_t, NCH>), dim3(cs_blocks), dim3(256), 0, (hipStream_t)s, (const bf16_t*)pred, (const float*)tgt, mask, acc, g, (bf16_t*)dpred, (float*)dtgt, (long)rows, (long)rows_per_batch, (long)tgt_bs, gmul, colsum_ws)
+        if (D == 256) MSECS(1); else if (D == 512) MSECS(2); else if (D == 768) MSECS(3); else MSECS(4);
+#undef MSECS
+        MH_LAUNCH_CHECK("mh_mse_masked_bwd");
+        return MH_OK;
+    }
     dim3 grid((unsigned)min((long)mh_cdiv(rows * D, 256), 16384L)), gv((unsigned)min((long)mh_cdiv(rows, 4), 16384L));
 #define MSEB3(TP, TT, TD)                                                                                                         \
     if (vec) hipLaunchKernelGGL((mse_masked_bwd_vec_kernel<TP, TT, TD>), gv, dim3(256), 0, (hipStream_t)s, (const TP*)pred, (const TT*)tgt, mask, acc, g, (TD*)dpred, (TT*)dtgt, (long)rows, D, (long)rows_per_batch, (long)tgt_bs, gmul); \

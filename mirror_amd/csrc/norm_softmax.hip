@@ -492,7 +492,7 @@ extern "C" int mh_layernorm_fwd_q8(const float* x, const float* gamma, const flo
 // is a serial load -> reduce -> store chain: one row per wave left HBM at 1.8 TB/s), (b) 32-bit row arithmetic, and
 // (c) the per-block dgamma / dbeta partials go to ws[block][2][D] with plain stores — 2048 blocks adding into the same
 // 2 D addresses cost ~100 us of serialised atomics — and a second small kernel folds them.
-template <typename TX, typename TDY, int LNV_CH, bool RELU = false>
+template <typename TX, typename TDY, int LNV_CH, bool RELU = false, bool FAN = false>
 // D <= 512 (LNV_CH == 2): held to 4 waves per SIMD — at 130 registers instead of 128 the ReLU-fused instance lost a wave and 30 us
 __global__ __launch_bounds__(256, LNV_CH == 2 ? 4 : 1) void layernorm_bwd_ws_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x,
                                                                const float* __restrict__ gamma, const float* __restrict__ mean,
@@ -501,7 +501,15 @@ __global__ __launch_bounds__(256, LNV_CH == 2 ? 4 : 1) void layernorm_bwd_ws_ker
                                                                long y_bs, int acc_dx, int rows_per_block,
                                                                const TDY* __restrict__ gadd = nullptr, int ga_pad = 0, int ga_l = 1,
                                                                int ga_m = 0, float ga_scale = 0.f, bf16_t* __restrict__ relu_out = nullptr,
-                                                               int relu_first = 0, int relu_rows = 0) {
+                                                               int relu_first = 0, int relu_rows = 0, int relu_cs = 0,
+                                                               const bf16_t* __restrict__ fan = nullptr, float fan_alpha = 0.f,
+                                                               const float* __restrict__ fan_cls = nullptr) {
+    // FAN (round 5; the WSI encoder's final norm, whose output feeds the decoder, the retention target and the cls heads,
+    // models/mirror.py:684-700): dy of row i >= 1 of batch b is dy + fan_alpha * fan[b, i - 1] (fan bf16 [batches, rpb - 1, D]: the
+    // masked MSE's -dpred), of row 0 dy + fan_cls[b] (f32 [batches, D], may be null) — the sum mh_fanout_bwd would have written as a
+    // [B, T, D] f32 tensor for this launch to read back
+    // relu_cs (RELU only): a third partial row ws[block][2][D] = column sums of what went to relu_out (as rounded to bf16): the bias
+    // gradient of the Linear in front of the ReLU, folded by the same fold launch — ws is then [blocks][3][D]
     // relu_out (bf16 [batches, relu_rows, D], round 5): x is the OUTPUT of a ReLU on rows [relu_first, relu_first + relu_rows) of every batch
     // (_fc1 of models/mirror.py:346, :652-654 writes the sequence LayerNorm 1 reads): those rows' total gradient leaves as
     // bf16 (x > 0 ? dx : 0) — what the ReLU's own backward pass would make of it for the weight-gradient product — instead of as f32 dx
@@ -509,14 +517,21 @@ __global__ __launch_bounds__(256, LNV_CH == 2 ? 4 : 1) void layernorm_bwd_ws_ker
     // gadd [batches, ga_m, D] in dy's dtype: dy of row i of batch b is dy + ga_scale * gadd[b, (i + ga_pad) / ga_l] (the gradient of the
     // landmark means mh_layernorm_fwd_lm produced beside the rows)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    f4 pg[LNV_CH], pb[LNV_CH], gm[LNV_CH];
+    // RELU: a third running sum (pr) — its 8 registers would cost the instance its 4th wave per SIMD (measured: 129 us instead of 99), and
+    // LDS atomics for it cost more still (256 us): gamma moves to LDS instead (read back per row, 2 x ds_read_b128) and pr takes its registers
+    __shared__ f4 sgm[RELU ? LNV_CH : 1][64];
+    f4 pg[LNV_CH], pb[LNV_CH], gm[RELU ? 1 : LNV_CH], pr[RELU ? LNV_CH : 1];
 #pragma unroll
     for (int k = 0; k < LNV_CH; k++) {
         pg[k] = (f4){0.f, 0.f, 0.f, 0.f};
         pb[k] = pg[k];
+        if constexpr (RELU) pr[k] = pg[k];
         const int c = 256 * k + 4 * lane;
-        gm[k] = (c < D) ? ld4(gamma + c) : pg[k];
+        if constexpr (RELU) {
+            if (wave == 0) sgm[k][lane] = (c < D) ? ld4(gamma + c) : pg[k];
+        } else gm[k] = (c < D) ? ld4(gamma + c) : pg[k];
     }
+    if constexpr (RELU) __syncthreads();
     const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
     for (int row = r0 + wave; row < r1; row += 8) {
         f4 dv[2][LNV_CH], xv[2][LNV_CH], ov[2][LNV_CH];
@@ -542,6 +557,10 @@ __global__ __launch_bounds__(256, LNV_CH == 2 ? 4 : 1) void layernorm_bwd_ws_ker
                     xv[u][k] = ld4(x + xo[u] + c);
                     if (acc_dx) ov[u][k] = ld4(dx + xo[u] + c);
                     if (gadd) dv[u][k] += ld4(gadd + ((long)b * ga_m + (i + ga_pad) / ga_l) * D + c) * ga_scale;
+                    if constexpr (FAN) {
+                        if (i >= 1) dv[u][k] += ld4(fan + ((long)b * (rpb - 1) + (i - 1)) * D + c) * fan_alpha;
+                        else if (fan_cls) dv[u][k] += ld4(fan_cls + (long)b * D + c);
+                    }
                 }
             }
         }
@@ -554,12 +573,14 @@ __global__ __launch_bounds__(256, LNV_CH == 2 ? 4 : 1) void layernorm_bwd_ws_ker
             for (int k = 0; k < LNV_CH; k++) {
                 const int c = 256 * k + 4 * lane;
                 if (c < D) {
+                    f4 gq;
+                    if constexpr (RELU) gq = sgm[k][lane]; else gq = gm[k];
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
                         if constexpr (RELU) pos |= (xv[u][k][e] > 0.f ? 1u : 0u) << (4 * k + e);
                         const float xh = (xv[u][k][e] - mu[u]) * rs[u];
                         const float d = dv[u][k][e];
-                        const float gd = d * gm[k][e];
+                        const float gd = d * gq[e];
                         pg[k][e] += d * xh;
                         pb[k][e] += d;
                         s1 += gd;
@@ -584,6 +605,8 @@ __global__ __launch_bounds__(256, LNV_CH == 2 ? 4 : 1) void layernorm_bwd_ws_ker
                         const ln_u32x2 w = {pack_bf2((pos >> (4 * k)) & 1u ? r[0] : 0.f, (pos >> (4 * k + 1)) & 1u ? r[1] : 0.f),
                                          pack_bf2((pos >> (4 * k + 2)) & 1u ? r[2] : 0.f, (pos >> (4 * k + 3)) & 1u ? r[3] : 0.f)};
                         *reinterpret_cast<ln_u32x2*>(relu_out + ro[u] + c) = w;
+                        pr[k] += (f4){__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xffff0000u),
+                                      __uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xffff0000u)};
                     } else {
                         st4(dx + xo[u] + c, r);
                     }
@@ -591,20 +614,24 @@ __global__ __launch_bounds__(256, LNV_CH == 2 ? 4 : 1) void layernorm_bwd_ws_ker
             }
         }
     }
-    __shared__ f4 red[2][4][64];
-    float* wsb = ws + (long)blockIdx.x * 2 * D;
+    __shared__ f4 red[RELU ? 3 : 2][4][64];
+    const int segs = (RELU && relu_cs) ? 3 : 2;
+    float* wsb = ws + (long)blockIdx.x * segs * D;
 #pragma unroll
     for (int k = 0; k < LNV_CH; k++) {
         if (256 * k >= D) break;
         __syncthreads();
         red[0][wave][lane] = pg[k];
         red[1][wave][lane] = pb[k];
+        if constexpr (RELU) red[2][wave][lane] = pr[k];
         __syncthreads();
         if (wave == 0) {
             const int c = 256 * k + 4 * lane;
             if (c < D) {
                 *reinterpret_cast<f4*>(wsb + c) = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
                 *reinterpret_cast<f4*>(wsb + D + c) = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
+                if constexpr (RELU)
+                    if (relu_cs) *reinterpret_cast<f4*>(wsb + 2 * D + c) = red[2][0][lane] + red[2][1][lane] + red[2][2][lane] + red[2][3][lane];
             }
         }
     }
@@ -625,13 +652,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_fold_kernel(const float* __
 // the same with one QUAD of columns per lane, the partial rows dealt to the four waves of a workgroup (eight loads in flight each) and
 // summed through LDS: the scalar form walks ~29 rows per thread one dependent 4-byte load at a time, and every same-address atomic
 // costs ~0.13 us (a 114-way row split was slower than the fold it replaced) — 64 row chunks, 16 atomics per address
+// segs = 3: a third partial row per block (the ReLU-fused instance's bias column sums) -> dthird
 __global__ __launch_bounds__(256) void layernorm_bwd_fold4_kernel(const float* __restrict__ ws, int nb, int D, float* __restrict__ dgamma,
-                                                                  float* __restrict__ dbeta) {
+                                                                  float* __restrict__ dbeta, int segs = 2, float* __restrict__ dthird = nullptr) {
     typedef float lf4 __attribute__((ext_vector_type(4)));
     __shared__ lf4 red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = (blockIdx.x * 64 + lane) * 4;
-    const bool live = t < 2 * D;
+    const bool live = t < segs * D;
     const int chunks = gridDim.y * 4, per = (nb + chunks - 1) / chunks;
     const int b0 = (blockIdx.y * 4 + wave) * per, b1 = min(nb, b0 + per);
     lf4 s = {0.f, 0.f, 0.f, 0.f};
@@ -640,17 +668,17 @@ __global__ __launch_bounds__(256) void layernorm_bwd_fold4_kernel(const float* _
         for (; b + 8 <= b1; b += 8) {
             lf4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const lf4*>(ws + (long)(b + u) * 2 * D + t);
+            for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const lf4*>(ws + (long)(b + u) * segs * D + t);
 #pragma unroll
             for (int u = 0; u < 8; u++) s += v[u];
         }
-        for (; b < b1; b++) s += *reinterpret_cast<const lf4*>(ws + (long)b * 2 * D + t);
+        for (; b < b1; b++) s += *reinterpret_cast<const lf4*>(ws + (long)b * segs * D + t);
     }
     red[wave][lane] = s;
     __syncthreads();
     if (wave == 0 && live) {
         s = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
-        float* dst = t < D ? dgamma + t : dbeta + (t - D);      // D % 4 == 0: a quad never straddles the two halves
+        float* dst = t < D ? dgamma + t : (t < 2 * D ? dbeta + (t - D) : dthird + (t - 2 * D));      // D % 4 == 0: a quad never straddles two segments
 #pragma unroll
         for (int e = 0; e < 4; e++) atomicAdd(dst + e, s[e]);
     }
@@ -661,13 +689,15 @@ static int ln_bwd_blocks() { return 512; }
 extern "C" int64_t mh_layernorm_bwd_workspace_bytes(int64_t rows, int D) {
     if (rows < 64 || D <= 0) return 0;
     const int64_t nb = rows / 16 < 1024 ? (rows / 16 < 1 ? 1 : rows / 16) : 1024;
-    return 2 * (int64_t)D * nb * 4;
+    return 3 * (int64_t)D * nb * 4;      // three partial rows per block: dgamma, dbeta and (relu_db) a bias gradient — at two the ReLU-fused
+                                         // instance ran 631 blocks instead of 911 (62 % of the chip's slots: 119 us instead of ~100)
 }
 
 static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                        void* dx, float* dgamma, float* dbeta, int batches, int rpb, int D, int64_t x_bs,
                        int64_t y_bs, int dt_x, int dt_dy, int dt_dx, int acc_dx, float* workspace, int64_t ws_floats,
-                       const void* gadd, int ga_pad, int ga_l, mh_stream s, void* relu_out = nullptr, int relu_first = 0, int relu_rows = 0);
+                       const void* gadd, int ga_pad, int ga_l, mh_stream s, void* relu_out = nullptr, int relu_first = 0, int relu_rows = 0,
+                       float* relu_db = nullptr, const void* fan = nullptr, float fan_alpha = 0.f, const float* fan_cls = nullptr);
 
 extern "C" int mh_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                 void* dx, float* dgamma, float* dbeta, int batches, int rpb, int D, int64_t x_bs,
@@ -682,18 +712,33 @@ extern "C" int mh_layernorm_bwd(const void* dy, const void* x, const float* gamm
 extern "C" int mh_layernorm_bwd_lm(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                    void* dx, float* dgamma, float* dbeta, int batches, int rpb, int D, int64_t x_bs,
                                    int64_t y_bs, int dt_x, int dt_dy, int dt_dx, int acc_dx, float* workspace, int64_t ws_floats,
-                                   const void* gadd, int pad, int l, void* relu_out, int relu_first, int relu_rows, mh_stream s) {
+                                   const void* gadd, int pad, int l, void* relu_out, int relu_first, int relu_rows, float* relu_db,
+                                   mh_stream s) {
     MH_REQUIRE(gadd && l >= 1 && pad >= 0 && (pad + rpb) % l == 0 && ((uintptr_t)gadd & 15) == 0, "mh_layernorm_bwd_lm: gadd, l >= 1, (pad + rows) %% l == 0");
     MH_REQUIRE(!relu_out || (dt_x == MH_F32 && relu_first >= 0 && relu_rows >= 0 && relu_first + relu_rows <= rpb && ((uintptr_t)relu_out & 7) == 0 && D % 4 == 0),
                "mh_layernorm_bwd_lm: relu_out needs f32 x and a row range inside the batch");
+    MH_REQUIRE(!relu_db || (relu_out && ((uintptr_t)workspace & 15) == 0 && ws_floats >= 3L * D), "mh_layernorm_bwd_lm: relu_db rides on relu_out (workspace of >= 3 D floats)");
     return ln_bwd_impl(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, batches, rpb, D, x_bs, y_bs, dt_x, dt_dy, dt_dx, acc_dx, workspace,
-                       ws_floats, gadd, pad, l, s, relu_out, relu_first, relu_rows);
+                       ws_floats, gadd, pad, l, s, relu_out, relu_first, relu_rows, relu_db);
+}
+
+// mh_layernorm_bwd whose dy rows also receive the other two gradients of a fanned-out LayerNorm output (see FAN above): needs the
+// workspace form with f32 x and f32 dy
+extern "C" int mh_layernorm_bwd_fan(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                    void* dx, float* dgamma, float* dbeta, int batches, int rpb, int D, int64_t x_bs,
+                                    int64_t y_bs, int accumulate_dx, float* workspace, int64_t ws_floats,
+                                    const void* fan_bf16, float fan_alpha, const float* fan_cls, mh_stream s) {
+    MH_REQUIRE(fan_bf16 && rpb >= 2 && ((uintptr_t)fan_bf16 & 7) == 0 && (!fan_cls || ((uintptr_t)fan_cls & 15) == 0) && D % 4 == 0,
+               "mh_layernorm_bwd_fan: fan [batches, rows - 1, D] bf16 on quads, rows >= 2");
+    return ln_bwd_impl(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, batches, rpb, D, x_bs, y_bs, MH_F32, MH_F32, MH_F32, accumulate_dx, workspace,
+                       ws_floats, nullptr, 0, 1, s, nullptr, 0, 0, nullptr, fan_bf16, fan_alpha, fan_cls);
 }
 
 static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                        void* dx, float* dgamma, float* dbeta, int batches, int rpb, int D, int64_t x_bs,
                        int64_t y_bs, int dt_x, int dt_dy, int dt_dx, int acc_dx, float* workspace, int64_t ws_floats,
-                       const void* gadd, int ga_pad, int ga_l, mh_stream s, void* relu_out, int relu_first, int relu_rows) {
+                       const void* gadd, int ga_pad, int ga_l, mh_stream s, void* relu_out, int relu_first, int relu_rows, float* relu_db,
+                       const void* fan, float fan_alpha, const float* fan_cls) {
     MH_REQUIRE(D >= 1 && D <= 64 * LN_MAXPL, "mh_layernorm_bwd: D=%d unsupported", D);
     MH_REQUIRE(dt_dx == dt_x, "mh_layernorm_bwd: dx dtype must equal x dtype");
     const long rows = (long)batches * rpb;
@@ -706,13 +751,19 @@ static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const 
 #define LN_BV(TX, TDY) do { if (D <= 512) LN_BV1(TX, TDY, 2); else if (D <= 1024) LN_BV1(TX, TDY, 4); else LN_BV1(TX, TDY, 8); } while (0)
     // workspace form: rows_per_block rows per block (a multiple of 8: two rows per wave per iteration), nb <= ws capacity
     if (vecok && workspace && ws_floats >= 2L * D && rows >= 64) {
-        const long cap = ws_floats / (2L * D);
+        const int segs = relu_db ? 3 : 2;       // partial rows per block: dgamma, dbeta (, the ReLU'd gradient's column sums)
+        const int relu_cs = relu_db ? 1 : 0;
+        const long cap = ws_floats / ((long)segs * D);
         long nb = min(cap, min((long)mh_cdiv(rows, 16), 1024L));
         const int rows_per_block = (int)(mh_cdiv(mh_cdiv(rows, nb), 8) * 8);
         nb = mh_cdiv(rows, rows_per_block);
         dim3 g2((unsigned)nb);
-#define LN_BW1(TX, TDY, NC, RL) hipLaunchKernelGGL((layernorm_bwd_ws_kernel<TX, TDY, NC, RL>), g2, dim3(256), 0, (hipStream_t)s, (const TDY*)dy, (const TX*)x, gamma, mean, rstd, (TX*)dx, workspace, (int)rows, rpb, D, (long)x_bs, (long)y_bs, acc_dx, rows_per_block, (const TDY*)gadd, ga_pad, ga_l, (ga_pad + rpb) / ga_l, 1.f / (float)ga_l, (bf16_t*)relu_out, relu_first, relu_rows)
+#define LN_BW1(TX, TDY, NC, RL) hipLaunchKernelGGL((layernorm_bwd_ws_kernel<TX, TDY, NC, RL>), g2, dim3(256), 0, (hipStream_t)s, (const TDY*)dy, (const TX*)x, gamma, mean, rstd, (TX*)dx, workspace, (int)rows, rpb, D, (long)x_bs, (long)y_bs, acc_dx, rows_per_block, (const TDY*)gadd, ga_pad, ga_l, (ga_pad + rpb) / ga_l, 1.f / (float)ga_l, (bf16_t*)relu_out, relu_first, relu_rows, relu_cs)
 #define LN_BW(TX, TDY) do { if (D <= 512) LN_BW1(TX, TDY, 2, false); else if (D <= 1024) LN_BW1(TX, TDY, 4, false); else LN_BW1(TX, TDY, 8, false); } while (0)
+#define LN_BWF(NC) hipLaunchKernelGGL((layernorm_bwd_ws_kernel<float, float, NC, false, true>), g2, dim3(256), 0, (hipStream_t)s, (const float*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, workspace, (int)rows, rpb, D, (long)x_bs, (long)y_bs, acc_dx, rows_per_block, (const float*)nullptr, 0, 1, 0, 0.f, (bf16_t*)nullptr, 0, 0, 0, (const bf16_t*)fan, fan_alpha, fan_cls)
+        if (fan) {              // the fanned-out form (f32 x, f32 dy) is an instance of its own too
+            if (D <= 512) LN_BWF(2); else if (D <= 1024) LN_BWF(4); else LN_BWF(8);
+        } else
         if (relu_out) {         // the ReLU-fused form (f32 x, bf16 dy: layer 1 of the bf16 policy) is an instance of its own
             MH_REQUIRE(dt_x == MH_F32 && dt_dy == MH_BF16, "mh_layernorm_bwd_lm: relu_out needs f32 x and bf16 dy");
             if (D <= 512) LN_BW1(float, bf16_t, 2, true); else if (D <= 1024) LN_BW1(float, bf16_t, 4, true); else LN_BW1(float, bf16_t, 8, true);
@@ -720,17 +771,19 @@ static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const 
         else if (dt_x == MH_F32 && dt_dy == MH_BF16) LN_BW(float, bf16_t);
         else if (dt_x == MH_BF16 && dt_dy == MH_BF16) LN_BW(bf16_t, bf16_t);
         else LN_BW(bf16_t, float);
+#undef LN_BWF
 #undef LN_BW
 #undef LN_BW1
         if (D % 4 == 0 && ((uintptr_t)workspace & 15) == 0)
-            hipLaunchKernelGGL(layernorm_bwd_fold4_kernel, dim3(mh_cdiv(2 * D / 4, 64), (unsigned)min(mh_cdiv(nb, 32), 16)), dim3(256), 0,
-                               (hipStream_t)s, (const float*)workspace, (int)nb, D, dgamma, dbeta);
+            hipLaunchKernelGGL(layernorm_bwd_fold4_kernel, dim3(mh_cdiv(segs * D / 4, 64), (unsigned)min(mh_cdiv(nb, 32), 16)), dim3(256), 0,
+                               (hipStream_t)s, (const float*)workspace, (int)nb, D, dgamma, dbeta, segs, relu_db);
         else
             hipLaunchKernelGGL(layernorm_bwd_fold_kernel, dim3(mh_cdiv(2 * D, 256), (unsigned)min(nb, 32L)), dim3(256), 0, (hipStream_t)s,
                                (const float*)workspace, (int)nb, D, dgamma, dbeta);
         MH_LAUNCH_CHECK("mh_layernorm_bwd");
         return MH_OK;
     }
+    MH_REQUIRE(!fan, "mh_layernorm_bwd_fan: needs the workspace form (D %% 4 == 0, 16-byte aligned buffers, a workspace of >= 2 D floats, >= 64 rows)");
     MH_REQUIRE(!gadd && !relu_out, "mh_layernorm_bwd_lm: needs the workspace form (D %% 4 == 0, 16-byte aligned buffers, a workspace of >= 2 D floats, >= 64 rows)");
     if (vecok) {
         if (dt_x == MH_F32 && dt_dy == MH_F32) LN_BV(float, float);

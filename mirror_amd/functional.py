@@ -749,7 +749,10 @@ def flush_deferred_bwd() -> None:
         _deferred_bwd.popitem()[1]()
 
 
-def _linear_rows_bwd(ctx_needs, x, wa, w, b, r0, R, prec, dy, dx_dtype=None, defer_wgrad=False):
+_BIAS_IN_PRODUCER = True     # (test hook, round 5) bias gradients left by the pass that wrote dy instead of an mh_colsum launch over it
+
+
+def _linear_rows_bwd(ctx_needs, x, wa, w, b, r0, R, prec, dy, dx_dtype=None, defer_wgrad=False, db_have=None, db_table=None):
     """Backward of y = x[:, r0:r0+R] @ W^T + b given dy [B, R, N] in the activation dtype: (dx over all of x's rows, dW, db).
     defer_wgrad: when the weight gradient goes straight into the gradient sink, its launch is left to whoever consumes dx
     (run_deferred_bwd(dx)): NystromCoreFn.backward issues to_out's weight gradient beside the half-chip pinv chain."""
@@ -781,9 +784,13 @@ def _linear_rows_bwd(ctx_needs, x, wa, w, b, r0, R, prec, dy, dx_dtype=None, def
             _wgrad(dy, x[:, r0:r0 + R], N, Kd, prec, dw)
             dw = _gret(w, dw, sunk)
     if b is not None and ctx_needs[2]:
-        db, sunk = _gbuf(b, (N,))
-        K.colsum(dy.reshape(-1, N), db)
-        db = _gret(b, db, sunk)
+        if db_have is not None:      # (buffer, came_from_sink): whoever wrote dy already accumulated its column sums
+            db = _gret(b, *db_have)
+        else:
+            db, sunk = _gbuf(b, (N,))
+            # db_table [blocks, N] f32: per-block column sums of dy left by the pass that wrote it
+            K.colsum(dy.reshape(-1, N) if db_table is None else db_table, db)
+            db = _gret(b, db, sunk)
     return dx, dw, db
 
 
@@ -854,6 +861,16 @@ def to_out_dropout_add(resid, core, w, b, r0: int, R: int, p: float, training: b
     return dropout_add(resid, y, p, training, lite=True)
 
 
+class _ColsumToken:
+    """Hand-over slot from the pass that writes a Linear's output gradient to that Linear's backward: `ws` [blocks, N] f32 holds the
+    per-block column sums of the gradient tensor whose data_ptr is `ptr` (mh_mse_masked_bwd(colsum_ws=...))."""
+    __slots__ = ("ws", "ptr")
+
+    def __init__(self):
+        self.ws = None
+        self.ptr = 0
+
+
 class HeadSqErrFn(Function):
     """pred = x[:, r0:r0+R] @ W^T + b (bf16) with the masked squared error against `tgt` accumulated by the same launch
     (mh_gemm_epi SQERR): retention_head + the WSI retention MSE of MIRRORLoss.forward (models/mirror.py:698-699,
@@ -862,7 +879,7 @@ class HeadSqErrFn(Function):
     pass when they are handed the same target and mask.  The backward is LinearRowsFn's."""
 
     @staticmethod
-    def forward(ctx, x, w, b, r0, R, prec, tgt, mask, acc):
+    def forward(ctx, x, w, b, r0, R, prec, tgt, mask, acc, cs_tok=None):
         wa = shadow(w, prec)
         Bn, T, Kd = x.shape
         N = wa.shape[0]
@@ -870,7 +887,7 @@ class HeadSqErrFn(Function):
         K.linear_fused(x, wa, None if b is None else b.detach(), y,
                        K.epi_sqerr(mask, tgt, tgt.stride(0), acc, R), window=(r0, R))
         ctx.save_for_backward(x, wa, w, b)
-        ctx.r0, ctx.R, ctx.prec = r0, R, prec
+        ctx.r0, ctx.R, ctx.prec, ctx.cs_tok = r0, R, prec, cs_tok
         return y
 
     @staticmethod
@@ -881,8 +898,18 @@ class HeadSqErrFn(Function):
             dy = dy.contiguous()
         if dy.dtype != prec.act:
             dy = K.cast(dy, prec.act)
-        dx, dw, db = _linear_rows_bwd(ctx.needs_input_grad[0:3], x, wa, w, b, ctx.r0, ctx.R, prec, dy)
-        return dx, dw, db, None, None, None, None, None, None
+        db_table, tok = None, ctx.cs_tok
+        if tok is not None and tok.ws is not None:
+            # the masked-MSE backward that wrote exactly this dy left its column sums per block: that small table is folded into the bias
+            # gradient instead of reading dy again (a dy that is not that tensor — a second consumer of pred — takes the plain colsum).
+            # The fold stays where the colsum launch stood, BEHIND the two products: in front of them it is the one child of the MSE
+            # kernel on this stream, the ragged-row fork moves behind it, and the replayed graph then starts the whole RNA / heads
+            # backward ~1 ms later (device probes, profiles/r05_h_*: +1.2 % of the step for a 7 us launch)
+            if tok.ptr == dy.data_ptr():
+                db_table = tok.ws
+            tok.ws = None
+        dx, dw, db = _linear_rows_bwd(ctx.needs_input_grad[0:3], x, wa, w, b, ctx.r0, ctx.R, prec, dy, db_table=db_table)
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
 def head_sqerr(x, w, b, r0: int, R: int, prec: Precision, tgt, mask):
@@ -894,10 +921,26 @@ def head_sqerr(x, w, b, r0: int, R: int, prec: Precision, tgt, mask):
             and mask.dtype == f32 and mask.is_contiguous() and tuple(mask.shape) == (x.shape[0], R) and R % 256 == 0
             and torch.is_grad_enabled() and K.linear_fused_ok(x, shadow(w, prec), (r0, R))):
         acc = zeros((2,), x.device)
-        y = HeadSqErrFn.apply(x, w, b, r0, R, prec, tgt, mask, acc)
+        tok = _ColsumToken() if (b is not None and _BIAS_IN_PRODUCER) else None
+        y = HeadSqErrFn.apply(x, w, b, r0, R, prec, tgt, mask, acc, tok)
         y._sq = (acc, tgt, mask)
+        y._sq_cs = tok
         return y
     return LinearRowsFn.apply(x, w, b, r0, R, prec, prec.act)
+
+
+def _cs_of(pred, acc):
+    """The column-sum hand-over slot of the HeadSqErrFn that produced `pred`, when `acc` is that launch's accumulator."""
+    sq, tok = getattr(pred, "_sq", None), getattr(pred, "_sq_cs", None)
+    return tok if (sq is not None and tok is not None and acc is not None and sq[0] is acc) else None
+
+
+def _mse_bwd_cs(tok, pred, tgt, dp, D):
+    """(colsum_ws or None): arm the hand-over slot for dp when the kernel can leave the sums."""
+    if tok is None or not K.mse_masked_bwd_colsum_ok(pred, tgt, dp, D):
+        return None
+    tok.ws, tok.ptr = torch.empty((K.MSE_CS_BLOCKS, D), device=dp.device, dtype=f32), dp.data_ptr()
+    return tok.ws
 
 
 def _sq_of(pred, tgt, mask):
@@ -951,11 +994,15 @@ class EmbedMaskPosFn(Function):
         token, pos = ctx.params
         dtok, s_tok = _gbuf_n(token, (N,))          # the kernel accumulates into both: straight into the gradient arena
         dpos, s_pos = _gbuf_n(pos, (T * N,))
-        K.mask_apply_bwd(dy, mask, dtok, dpos, Bn, T, N, first, False, out=dr)
+        # the bias gradient of the projection = column sums of dr: the same pass leaves them (round 5; no mh_colsum launch over dr)
+        db_in = None
+        if b is not None and ctx.needs_input_grad[3] and _BIAS_IN_PRODUCER and K.mask_apply_bwd_dbias_ok(dy, dr, dpos, N):
+            db_in = _gbuf(b, (N,))
+        K.mask_apply_bwd(dy, mask, dtok, dpos, Bn, T, N, first, False, out=dr, dbias=None if db_in is None else db_in[0])
         dtok, dpos = _gret(token, dtok, s_tok), _gret(pos, dpos, s_pos)
         # f32 data gradient: EncFanoutFn sums it with the target / cls gradients in one pass (mh_fanout_bwd reads f32)
         needs = (ctx.needs_input_grad[0], ctx.needs_input_grad[2], ctx.needs_input_grad[3])
-        dh, dw, db = _linear_rows_bwd(needs, h, wa, w, b, 0, T, prec, dr, dx_dtype=f32)
+        dh, dw, db = _linear_rows_bwd(needs, h, wa, w, b, 0, T, prec, dr, dx_dtype=f32, db_have=db_in)
         return (dh, None, dw, db, None, None if dtok is None else dtok.reshape(tshape), None if dpos is None else dpos.reshape(pshape),
                 None, None)
 
@@ -979,10 +1026,11 @@ class LayerNormFn(Function):
     [3P] NystromAttention).  Output [B, pad + rows, D] in `out_dtype`."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, rows, pad, out_dtype, q8_key=None, dual=None):
+    def forward(ctx, x, gamma, beta, eps, rows, pad, out_dtype, q8_key=None, dual=None, fan_slot=None):
         x = x.contiguous()
         Bn, T, D = x.shape
         y = torch.empty((Bn, pad + rows, D), device=x.device, dtype=out_dtype)
+        ctx.fan_slot = fan_slot
         if dual is not None:
             # f32 output + its bf16 copy in one pass (mh_layernorm_fwd_dual); the copy is handed over through `dual` (a
             # one-element list): it carries no gradient of its own, its consumers' gradients arrive through the f32 output
@@ -1025,6 +1073,14 @@ class LayerNormFn(Function):
             dy = dy.contiguous()
         dg, sunk_g = _gbuf(gamma, (D,))
         db, sunk_b = _gbuf(beta, (D,))
+        # this norm's output fans out (EncFanoutFn): the retention target's and the cls row's gradients were left in the slot instead of
+        # being summed into a [B, T, D] tensor — they are additive to whatever arrives here as dy, and the launch below adds them as it
+        # reads dy (mh_layernorm_bwd_fan), or mh_fanout_bwd materialises the sum when the shapes are off that form
+        fan = None
+        if ctx.fan_slot is not None and ctx.fan_slot.extra is not None:
+            fan, ctx.fan_slot.extra = ctx.fan_slot.extra, None
+            if pad or rows != T or not K.layernorm_bwd_fan_ok(dy, x, x, fan[0], fan[2], Bn, rows, D):
+                dy, fan = K.fanout_bwd(dy.float(), fan[0], fan[1], fan[2], Bn, T, D), None
         # pre-norm residual block  x + f(LN(x)):  the residual add's backward ran first and left its gradient for x in
         # _res_grads; LN adds its own dx INTO that tensor (mh_layernorm_bwd accumulate_dx) instead of handing autograd a
         # second [B, T, D] f32 gradient to sum (a 400 MB elementwise pass per block)
@@ -1032,11 +1088,11 @@ class LayerNormFn(Function):
         if G is not None and G.numel() == x.numel() and G.dtype == x.dtype and G.is_contiguous():
             G = G.view(x.shape)          # the RNA blocks run on [B, D]: layer_norm() added a leading 1
             K.layernorm_bwd(dy[:, pad:], x, gamma.detach(), mean, rstd, G, dg, db, Bn, rows, D, T * D, (pad + rows) * D,
-                            accumulate_dx=True)
-            return None, _gret(gamma, dg, sunk_g), _gret(beta, db, sunk_b), None, None, None, None, None, None
+                            accumulate_dx=True, fan=fan)
+            return None, _gret(gamma, dg, sunk_g), _gret(beta, db, sunk_b), None, None, None, None, None, None, None
         dx = torch.zeros_like(x) if rows < T else torch.empty_like(x)
-        K.layernorm_bwd(dy[:, pad:], x, gamma.detach(), mean, rstd, dx, dg, db, Bn, rows, D, T * D, (pad + rows) * D)
-        return dx, _gret(gamma, dg, sunk_g), _gret(beta, db, sunk_b), None, None, None, None, None, None
+        K.layernorm_bwd(dy[:, pad:], x, gamma.detach(), mean, rstd, dx, dg, db, Bn, rows, D, T * D, (pad + rows) * D, fan=fan)
+        return dx, _gret(gamma, dg, sunk_g), _gret(beta, db, sunk_b), None, None, None, None, None, None, None
 
 
 def _alias(base: torch.Tensor, offset: int, size, stride) -> torch.Tensor:
@@ -1147,13 +1203,15 @@ class NormQkvLmFn(Function):
         if G is not None and G.numel() == x.numel() and G.dtype == x.dtype and G.is_contiguous():
             # x = Fc1SeqFn's sequence [cls | relu(_fc1(wsi))] (layer 1): the rows behind the cls row leave as the ReLU-masked bf16 gradient
             # _fc1's weight gradient multiplies (Fc1SeqFn.backward picks it up: no pass over x and dx of its own)
-            nrelu = _relu_rows.pop(x.data_ptr(), None) if _RELU_IN_LN_BWD else None
-            dh = None
+            nrelu, fc1_b = _relu_rows.pop(x.data_ptr(), (None, None)) if _RELU_IN_LN_BWD else (None, None)
+            dh = rdb = None
             if nrelu is not None and x.dtype == f32 and prec.act == bf16 and rows == T == nrelu + 1 and ctx.needs_input_grad[0]:
                 dh = torch.empty((Bn, nrelu, D), device=x.device, dtype=bf16)
-                _relu_grads[G.data_ptr()] = dh
+                if fc1_b is not None and fc1_b.requires_grad and _BIAS_IN_PRODUCER:
+                    rdb = _gbuf(fc1_b, (D,))      # _fc1's bias gradient = the column sums of dh: a third partial row of this launch
+                _relu_grads[G.data_ptr()] = (dh, rdb)
             K.layernorm_bwd(dy[:, pad:], x, gamma.detach(), mean, rstd, G.view(x.shape), dg, db, Bn, rows, D, T * D, n_p * D,
-                            accumulate_dx=True, gadd=gadd, pad=pad, l=l, relu_out=dh, relu_first=1)
+                            accumulate_dx=True, gadd=gadd, pad=pad, l=l, relu_out=dh, relu_first=1, relu_db=None if rdb is None else rdb[0])
             dx = None
         else:
             dx = torch.zeros_like(x) if rows < T else torch.empty_like(x)
@@ -1207,6 +1265,17 @@ def fp8_site_key(w: torch.Tensor, prec: "Precision"):
 
 
 _LN_DUAL = True      # (test hook)
+_FAN_IN_LN_BWD = True      # (test hook, round 5) the fan-out sum of the encoder output's gradients inside its LayerNorm's backward
+
+
+class _FanSlot:
+    """Hand-over slot from EncFanoutFn.backward to the backward of the LayerNorm whose output it fanned out:
+    extra = (x bf16 [B, T - 1, D], alpha, cls f32 [B, D] or None) — the node's dy is (what autograd delivers) + alpha * x on rows 1.. + cls on row 0."""
+    __slots__ = ("extra",)
+
+    def __init__(self):
+        self.extra = None
+
 
 
 def layer_norm(x, gamma, beta, eps, *, rows=None, pad=0, out_dtype=f32, q8_key=None, bf16_copy=False):
@@ -1220,9 +1289,12 @@ def layer_norm(x, gamma, beta, eps, *, rows=None, pad=0, out_dtype=f32, q8_key=N
     if (bf16_copy and _LN_DUAL and not squeeze and x.dtype == f32 and out_dtype == f32 and pad == 0 and x.shape[-1] % 4 == 0
             and x.shape[-1] <= 2048 and q8_key is None):
         dual = []
-    y = LayerNormFn.apply(x, gamma, beta, eps, r, pad, out_dtype, q8_key, dual)
+    slot = _FanSlot() if (_FAN_IN_LN_BWD and not squeeze and pad == 0 and out_dtype == f32 and x.dtype == f32 and r == x.shape[1]) else None
+    y = LayerNormFn.apply(x, gamma, beta, eps, r, pad, out_dtype, q8_key, dual, slot)
     if dual:
         y._bf16 = dual[0]
+    if slot is not None:
+        y._fan_slot = slot        # enc_fanout(y) may leave two of its three gradients here for this node's backward
     return y.squeeze(0) if squeeze else y
 
 
@@ -1411,7 +1483,7 @@ class Fc1SeqFn(Function):
             K.gemm(xa, wa.t(), out=seq[:, 1:1 + N], bias=b.detach(), act=ACT_RELU, mma=prec.mma)
         K.seq_finish(seq, cls.detach().reshape(-1).contiguous(), N, add_len)
         if add_len == 0 and prec.act == bf16:
-            _relu_rows[seq.data_ptr()] = N      # layer 1's LayerNorm backward may write the ReLU-masked gradient itself (NormQkvLmFn.backward)
+            _relu_rows[seq.data_ptr()] = (N, b)      # layer 1's LayerNorm backward may write the ReLU-masked gradient itself (NormQkvLmFn.backward)
         ctx.save_for_backward(xa, wa, seq, w, b)
         ctx.add_len, ctx.prec, ctx.cls = add_len, prec, cls
         return seq
@@ -1423,21 +1495,28 @@ class Fc1SeqFn(Function):
         Bn, N, Fd = xa.shape
         D = wa.shape[0]
         dseq = dseq.contiguous()
-        dh = _relu_grads.pop(dseq.data_ptr(), None)      # layer 1's LayerNorm backward already wrote relu'(x) * dx as bf16 (rows 1 .. N of
-        if add_len:                                       # dseq are then stale: only the cls row is read below)
+        # layer 1's LayerNorm backward already wrote relu'(x) * dx as bf16 (rows 1 .. N of dseq are then stale: only the cls row is read
+        # below) and, with it, this Linear's bias gradient (the column sums of that tensor)
+        dh, db_have = _relu_grads.pop(dseq.data_ptr(), (None, None))
+        if add_len:
             dseq = dseq.clone()  # the fold below is in place; autograd owns the incoming buffer
         dcls, sunk_c = _gbuf_n(ctx.cls, (D,))
         K.seq_finish_bwd(dseq, dcls, N, add_len)
         dcls = _gret(ctx.cls, dcls, sunk_c)
-        if dh is None or add_len or tuple(dh.shape) != (Bn, N, D):
+        if dh is not None and (add_len or tuple(dh.shape) != (Bn, N, D)):
+            raise K.MirrorHipError("Fc1SeqFn.backward: the ReLU-masked gradient handed over by the LayerNorm backward has another shape")
+        if dh is None:
             dh = K.relu_bwd(seq[:, 1:1 + N], dseq[:, 1:1 + N], out_dtype=prec.act)   # [B,N,D] contiguous
         dw, sunk_w = _gbuf(w, (D, Fd))
         K.gemm(dh.reshape(Bn * N, D).t(), xa.reshape(Bn * N, Fd), out=dw, accumulate=True,
                split_k=_split_k_for(Bn * N, D, Fd), mma=prec.mma)
         dw = _gret(w, dw, sunk_w)
-        db, sunk_b = _gbuf(b, (D,))
-        K.colsum(dh.reshape(Bn * N, D), db)
-        db = _gret(b, db, sunk_b)
+        if db_have is not None:
+            db = _gret(b, *db_have)
+        else:
+            db, sunk_b = _gbuf(b, (D,))
+            K.colsum(dh.reshape(Bn * N, D), db)
+            db = _gret(b, db, sunk_b)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = K.gemm(dh, wa, mma=prec.mma, out_dtype=f32)
@@ -2067,9 +2146,9 @@ class EncFanoutFn(Function):
     MSE hands its target gradient over as -dpred instead of materialising it."""
 
     @staticmethod
-    def forward(ctx, E, tok):
+    def forward(ctx, E, tok, slot=None):
         ctx.set_materialize_grads(False)
-        ctx.tok, ctx.shape = tok, tuple(E.shape)
+        ctx.tok, ctx.shape, ctx.slot = tok, tuple(E.shape), slot
         return E.view_as(E), E[:, 1:], E[:, 0]
 
     @staticmethod
@@ -2085,10 +2164,15 @@ class EncFanoutFn(Function):
                 late = g_tgt
         gf = None if g_full is None else g_full.contiguous().float()
         c = None if g_cls is None else g_cls.contiguous().float()
+        if (ctx.slot is not None and _FAN_IN_LN_BWD and late is None and gf is not None and x is not None and x.dtype == bf16
+                and x.is_contiguous() and ctx.slot.extra is None):
+            # E is a LayerNorm's output: its backward adds the other two gradients while it reads this one (no [B, T, D] sum tensor)
+            ctx.slot.extra = (x, alpha, c)
+            return gf, None, None
         dE = K.fanout_bwd(gf, x, alpha, c, Bn, T, D)
         if late is not None:
             dE[:, 1:] += late
-        return dE, None
+        return dE, None, None
 
 
 def enc_fanout(E: torch.Tensor):
@@ -2096,7 +2180,7 @@ def enc_fanout(E: torch.Tensor):
     if not (torch.is_grad_enabled() and E.requires_grad and E.dim() == 3 and E.is_contiguous() and E.dtype == f32):
         return E, E[:, 1:], E[:, 0]
     tok = _FanToken()
-    full, tgt, cls = EncFanoutFn.apply(E, tok)
+    full, tgt, cls = EncFanoutFn.apply(E, tok, getattr(E, "_fan_slot", None))
     tgt._fan_token = tok
     if getattr(E, "_bf16", None) is not None:
         full._bf16 = E._bf16          # layer_norm(..., bf16_copy=True): the decoder's projection reads this copy
@@ -2321,6 +2405,7 @@ class MaskedMSEFn(Function):
         if not (tgt.is_contiguous() or (tgt.dim() == 3 and tgt.stride(2) == 1 and tgt.stride(1) == D)):
             tgt = tgt.contiguous()
         acc = _sq_of(pred, tgt, mask)        # filled by the projection that produced pred (HeadSqErrFn)
+        ctx.cs_tok = _cs_of(pred, acc)
         mask = mask.contiguous().float()
         rows = pred.numel() // D
         if acc is None:
@@ -2337,7 +2422,8 @@ class MaskedMSEFn(Function):
         dp = torch.empty_like(pred)
         hand_over = tok is not None and ctx.needs_input_grad[1]
         dtg = torch.empty(tgt.shape, device=tgt.device, dtype=tgt.dtype) if (ctx.needs_input_grad[1] and not hand_over) else None
-        K.mse_masked_bwd(pred, tgt, mask, acc, g.contiguous().float().reshape(1), dp, dtg, pred.numel() // D, D)
+        K.mse_masked_bwd(pred, tgt, mask, acc, g.contiguous().float().reshape(1), dp, dtg, pred.numel() // D, D,
+                         colsum_ws=_mse_bwd_cs(ctx.cs_tok, pred, tgt, dp, D))
         if hand_over:
             tok.grad = (dp, -1.0)          # EncFanoutFn.backward folds -dpred into the encoder-output gradient
         return dp, dtg, None, None, None
@@ -2440,6 +2526,7 @@ class MirrorLossTermsFn(Function):
         ctx.set_materialize_grads(False)
         dev = rp.device
         acc = _sq_of(wpred, wtgt, wmask)     # filled by the projection that produced wpred (HeadSqErrFn)
+        ctx.cs_tok = _cs_of(wpred, acc)
         wpred = wpred.contiguous()
         if not (wtgt.is_contiguous() or (wtgt.dim() == 3 and wtgt.stride(2) == 1 and wtgt.stride(1) == Dw)):
             wtgt = wtgt.contiguous()
@@ -2490,9 +2577,11 @@ class MirrorLossTermsFn(Function):
         dtg = torch.empty(wtgt.shape, device=dev, dtype=wtgt.dtype) if (ctx.needs_input_grad[6] and not hand_over) else None
         if "g_terms" in t or g_total is None:
             gb = t["g_terms"][1:2] + (weights[1] * t["g_total"] if g_total is not None else 0.0)
-            K.mse_masked_bwd(wpred, wtgt, wmask, acc, gb.contiguous(), dp, dtg, wpred.numel() // Dw, Dw)
+            K.mse_masked_bwd(wpred, wtgt, wmask, acc, gb.contiguous(), dp, dtg, wpred.numel() // Dw, Dw,
+                             colsum_ws=_mse_bwd_cs(ctx.cs_tok, wpred, wtgt, dp, Dw))
         else:
-            K.mse_masked_bwd(wpred, wtgt, wmask, acc, t["g_total"], dp, dtg, wpred.numel() // Dw, Dw, gmul=weights[1])
+            K.mse_masked_bwd(wpred, wtgt, wmask, acc, t["g_total"], dp, dtg, wpred.numel() // Dw, Dw, gmul=weights[1],
+                             colsum_ws=_mse_bwd_cs(ctx.cs_tok, wpred, wtgt, dp, Dw))
         if hand_over:
             tok.grad = (dp, -1.0)          # EncFanoutFn.backward folds -dpred into the encoder-output gradient
         ssh, ash = ctx.shapes

@@ -609,11 +609,16 @@ def layernorm_fwd_q8(x, gamma, beta, y, mean, rstd, batches, rpb, D, x_bs, y_bs,
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, batches, rpb, D, x_bs, y_bs, accumulate_dx=False, gadd=None,
-                  pad: int = 0, l: int = 1, relu_out=None, relu_first: int = 0):
+                  pad: int = 0, l: int = 1, relu_out=None, relu_first: int = 0, relu_db=None, fan=None):
     """gadd ([batches, (pad + rpb) / l, D], dy's dtype): the gradient of the landmark means layernorm_fwd_lm produced; every dy row also
     receives gadd[b, (i + pad) / l] / l (mh_layernorm_bwd_lm).  relu_out (bf16 [batches, R, D], with gadd only): rows [relu_first,
-    relu_first + R) of x are a ReLU's output — their gradient leaves as bf16 (x > 0 ? dx : 0) in relu_out instead of f32 dx."""
-    _chk(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, relu_out)
+    relu_first + R) of x are a ReLU's output — their gradient leaves as bf16 (x > 0 ? dx : 0) in relu_out instead of f32 dx;
+    relu_db (f32 [D], with relu_out): += the column sums of relu_out (the bias gradient of the Linear in front of the ReLU).
+    fan = (src bf16 [batches, rpb - 1, D], alpha, cls f32 [batches, D] or None), without gadd: dy rows 1.. also receive alpha * src, row 0
+    cls (mh_layernorm_bwd_fan; layernorm_bwd_fan_ok says whether the shapes are on that form)."""
+    _chk(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, relu_out, relu_db)
+    if relu_db is not None and (relu_out is None or relu_db.dtype != torch.float32 or relu_db.numel() != D or not relu_db.is_contiguous()):
+        raise MirrorHipError("layernorm_bwd: relu_db is a contiguous f32 [D] and rides on relu_out")
     if relu_out is not None and (gadd is None or relu_out.dtype != torch.bfloat16 or not relu_out.is_contiguous() or relu_out.dim() != 3
                                  or relu_out.shape[0] != batches or relu_out.shape[2] != D or relu_first + relu_out.shape[1] > rpb):
         raise MirrorHipError("layernorm_bwd: relu_out must be contiguous bf16 [batches, R, D] with relu_first + R <= rows (landmark form only)")
@@ -629,11 +634,27 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, batches, rpb, D, 
         _lib.call("mh_layernorm_bwd_lm", _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma), _p(dbeta),
                   batches, rpb, D, x_bs, y_bs, dt(x), dt(dy), dt(dx), int(accumulate_dx), _p(ws) if ws is not None else 0,
                   ws.numel() if ws is not None else 0, _p(gadd), int(pad), int(l), _p(relu_out), int(relu_first),
-                  0 if relu_out is None else int(relu_out.shape[1]), stream=_stream())
+                  0 if relu_out is None else int(relu_out.shape[1]), _p(relu_db), stream=_stream())
+        return
+    if fan is not None:
+        src, alpha, cls = fan
+        _chk(src, cls)
+        if not layernorm_bwd_fan_ok(dy, x, dx, src, cls, batches, rpb, D) or ws is None:
+            raise MirrorHipError("layernorm_bwd: fan needs f32 x / dy / dx, a contiguous bf16 [batches, rows - 1, D] source and >= 64 rows")
+        _lib.call("mh_layernorm_bwd_fan", _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma), _p(dbeta),
+                  batches, rpb, D, x_bs, y_bs, int(accumulate_dx), _p(ws), ws.numel(), _p(src), float(alpha), _p(cls), stream=_stream())
         return
     _lib.call("mh_layernorm_bwd", _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma), _p(dbeta),
               batches, rpb, D, x_bs, y_bs, dt(x), dt(dy), dt(dx), int(accumulate_dx), _p(ws) if ws is not None else 0,
               ws.numel() if ws is not None else 0, stream=_stream())
+
+
+def layernorm_bwd_fan_ok(dy, x, dx, src, cls, batches: int, rpb: int, D: int) -> bool:
+    f = torch.float32
+    return (dy.dtype == f and x.dtype == f and dx.dtype == f and src.dtype == torch.bfloat16 and src.is_contiguous()
+            and src.numel() == batches * (rpb - 1) * D and rpb >= 2 and batches * rpb >= 64 and D % 4 == 0
+            and (cls is None or (cls.dtype == f and cls.is_contiguous() and cls.numel() == batches * D and cls.data_ptr() % 16 == 0))
+            and all(t.data_ptr() % 16 == 0 for t in (dy, x, dx)) and src.data_ptr() % 8 == 0)
 
 
 def layernorm_fwd_lm(x, gamma, beta, y, mean, rstd, xpm, batches, rows, D, x_bs, pad, l, eps, xpm_bf16=None):
@@ -1223,14 +1244,22 @@ def mask_apply_fwd(x, mask, token, pos, B, T, D, first, token_scalar, out=None) 
               stream=_stream())
 
 
-def mask_apply_bwd(dy, mask, dtoken, dpos, B, T, D, first, token_scalar, out=None) -> None:
-    """out (same shape as dy, any dtype) receives dx; in place when omitted."""
+def mask_apply_bwd_dbias_ok(dy, out, dpos, D) -> bool:
+    """Can mask_apply_bwd leave the column sums of dx too (the bias gradient of the Linear in front)?"""
+    return bool(_lib.load().mh_mask_apply_bwd_dbias_ok(_p(dy), _p(out), _p(dpos), D, dt(dy), dt(out)))
+
+
+def mask_apply_bwd(dy, mask, dtoken, dpos, B, T, D, first, token_scalar, out=None, dbias=None) -> None:
+    """out (same shape as dy, any dtype) receives dx; in place when omitted.  dbias [D] f32: += column sums of dx."""
     out = dy if out is None else out
     _chk(dy, mask, dtoken, dpos, out)
     assert dy.is_contiguous() and dy.numel() == B * T * D and dpos.numel() == T * D
     assert out.is_contiguous() and out.numel() == dy.numel()
+    if dbias is not None:
+        _chk(dbias)
+        assert dbias.dtype == torch.float32 and dbias.numel() == D and dbias.is_contiguous()
     _lib.call("mh_mask_apply_bwd", _p(dy), _p(out), _p(mask), _p(dtoken), _p(dpos), B, T, D, first, int(token_scalar), dt(dy),
-              dt(out), stream=_stream())
+              dt(out), _p(dbias), stream=_stream())
 
 
 # ----------------------------------------------------------------------------- RNA attention
@@ -1535,13 +1564,27 @@ def mse_masked_fwd(pred, tgt, mask, acc, rows, D):
     _lib.call("mh_mse_masked_fwd", _p(pred), _p(tgt), _p(mask), _p(acc), rows, D, rpb, tbs, dt(pred), dt(tgt), stream=_stream())
 
 
-def mse_masked_bwd(pred, tgt, mask, acc, g, dpred, dtgt, rows, D, gmul: float = 1.0):
-    """dtgt None: the target's gradient (-dpred) is not materialised.  The upstream is g[0] * gmul."""
+MSE_CS_BLOCKS = 1024      # blocks (= rows of the column-sum table) of mse_masked_bwd(colsum_ws=...)
+
+
+def mse_masked_bwd_colsum_ok(pred, tgt, dpred, D: int) -> bool:
+    return (D in (256, 512, 768, 1024) and pred.dtype == torch.bfloat16 and tgt.dtype == torch.float32 and dpred.dtype == torch.bfloat16
+            and tgt.stride(0) % 4 == 0 and tgt.data_ptr() % 16 == 0 and pred.data_ptr() % 8 == 0 and dpred.data_ptr() % 8 == 0)
+
+
+def mse_masked_bwd(pred, tgt, mask, acc, g, dpred, dtgt, rows, D, gmul: float = 1.0, colsum_ws=None):
+    """dtgt None: the target's gradient (-dpred) is not materialised.  The upstream is g[0] * gmul.
+    colsum_ws [blocks, D] f32: every block's column sums of dpred (colsum(colsum_ws, db) is then the bias gradient in front of pred)."""
     _chk(pred, tgt, mask, acc, g, dpred, *([] if dtgt is None else [dtgt]))
     assert pred.is_contiguous() and dpred.is_contiguous() and (dtgt is None or (dtgt.is_contiguous() and dtgt.dtype == tgt.dtype))
     rpb, tbs = _tgt_rows(tgt, rows, D)
+    nb = 0
+    if colsum_ws is not None:
+        _chk(colsum_ws)
+        assert colsum_ws.dtype == torch.float32 and colsum_ws.is_contiguous() and colsum_ws.dim() == 2 and colsum_ws.shape[1] == D
+        nb = colsum_ws.shape[0]
     _lib.call("mh_mse_masked_bwd", _p(pred), _p(tgt), _p(mask), _p(acc), _p(g), float(gmul), _p(dpred), _p(dtgt), rows, D, rpb, tbs, dt(pred),
-              dt(tgt), dt(dpred), stream=_stream())
+              dt(tgt), dt(dpred), _p(colsum_ws), nb, stream=_stream())
 
 
 LOSS_TERMS_BMAX = 32          # alignment block of mh_loss_terms: B <= 32 and 2 B (D + 1) + B (B + 1) floats <= 150 KiB of LDS

@@ -444,7 +444,10 @@ def test_d512_graph_replay_with_key_padding_mask_matches_eager_launch():
     for graph in (True, False):
         torch.manual_seed(21)
         model = M.mirror(**CFG512, rna_proj_drop_rate=0.1).cuda().train()
-        eng = TrainEngine(model, MIRRORLoss(), lr=1e-4, precision="bf16", graph=graph, seed=77, snapshot_grads=True)
+        # lr 1e-6: at 1e-4 six Adam steps (each ~lr per element whatever the gradient's size) amplify the f32-atomics noise of step 1 into
+        # ~1 % of the step-6 gradient, and into 5 % of _fc1's bias gradient (a cancelling column sum) in 3 runs of 10 — measured on the
+        # round-4 kernels too; the trajectory check below is relative to the distance travelled, so it does not depend on lr
+        eng = TrainEngine(model, MIRRORLoss(), lr=1e-6, precision="bf16", graph=graph, seed=77, snapshot_grads=True)
         if not graph:
             eng._rna_branch_state = "off"
         init = eng.master.clone()

@@ -433,15 +433,18 @@ def test_whole_model_round5_fusions_on_off(monkeypatch):
     rounded once either way: _fc1's weight / bias gradients and the cls-token gradient at the run-to-run floor (f32 atomics above them);
     (b) res_conv inside attn3's forward + its two gradients in one pass — same MFMA products (losses identical, gradient cosine >= 0.9999);
     (c) attn3's backward as one kernel and (d) attn1's dq from the saved rows beside the chain / to_out's weight gradient in the
-    window — other summation orders of the same bf16 products (losses identical: the forward does not change; cosine >= 0.999)."""
+    window — other summation orders of the same bf16 products (losses identical: the forward does not change; cosine >= 0.999);
+    (e) the three bias gradients left by the pass that wrote their dy (masked-MSE backward -> retention_head, mask/pos backward ->
+    retention_embed, layer 1's LayerNorm backward -> _fc1) against mh_colsum over dy: the same stored values, another order;
+    (f) the fan-out sum of the encoder output's three gradients inside its LayerNorm's backward against mh_fanout_bwd in front of it."""
     import mirror_amd.models as M
     from mirror_amd import functional as Fn
     from mirror_amd import kernels as K
     from mirror_amd.losses import MIRRORLoss
-    cfg = dict(wsi_embed_dim=128, rna_embed_dim=96, embed_dim=512, wsi_num_tokens=1024, rna_encoder_depth=1, rna_num_heads=8,
+    cfg = dict(wsi_embed_dim=256, rna_embed_dim=96, embed_dim=512, wsi_num_tokens=1024, rna_encoder_depth=1, rna_num_heads=8,
                rna_mlp_ratio=4.0, style_mlp_hidden_dim=128, style_mlp_out_dim=64, style_latent_dim=32, num_prototypes=300)
     g = torch.Generator().manual_seed(15)
-    wsi = torch.randn(2, 1024, 128, generator=g).cuda().to(bf16)
+    wsi = torch.randn(2, 1024, 256, generator=g).cuda().to(bf16)
     rna = torch.randn(2, 96, generator=g).cuda()
     noise = {"wsi_mask": torch.rand(2, 1024, generator=g).cuda(), "rna_mask": torch.rand(2, 512, generator=g).cuda(),
              "wsi_eps": torch.randn(2, 32, generator=g).cuda(), "rna_eps": torch.randn(2, 32, generator=g).cuda()}
@@ -458,9 +461,14 @@ def test_whole_model_round5_fusions_on_off(monkeypatch):
 
     base_l, base_g = run()
     relu_keys = ("wsi_encoder._fc1.0.weight", "wsi_encoder._fc1.0.bias", "wsi_encoder.cls_token")
+    bias_keys = tuple(k for k in base_g if k in ("wsi_encoder._fc1.0.bias", "wsi_encoder.retention_embed.bias",
+                                                 "wsi_encoder.retention_head.bias"))
+    assert len(bias_keys) == 3, [k for k in base_g if k.endswith("bias")][:40]
+    seen_bias = set()
     for target, name, floor, exact_losses in ((Fn, "_RELU_IN_LN_BWD", 1.0, True), (Fn, "_RC_FUSED", 0.9999, True),
                                               (K, "NYS_A3_BWD_ONE_PASS", 0.999, True), (Fn, "_A1_DQ_IN_WINDOW", 0.999, True),
-                                              (Fn, "_TO_OUT_WGRAD_IN_WINDOW", 0.999, True)):
+                                              (Fn, "_TO_OUT_WGRAD_IN_WINDOW", 0.999, True), (Fn, "_BIAS_IN_PRODUCER", 0.9999, True),
+                                              (Fn, "_FAN_IN_LN_BWD", 0.9999, True)):
         monkeypatch.setattr(target, name, False)
         l2, g2 = run()
         monkeypatch.setattr(target, name, True)
@@ -471,10 +479,14 @@ def test_whole_model_round5_fusions_on_off(monkeypatch):
             if float(c.norm()) < 1e-10:
                 continue
             cos = float(a @ c / (a.norm() * c.norm()))
+            if name == "_BIAS_IN_PRODUCER" and k in bias_keys:
+                seen_bias.add(k)
+                assert cos >= 0.99995 and abs(float(a.norm() / c.norm()) - 1.0) <= 1e-3, (name, k, cos)
             if name == "_RELU_IN_LN_BWD" and k in relu_keys:
                 # the same f32 value rounded once to bf16 either way: only the run-to-run noise of the gradients above it is left
                 assert cos >= 0.99995 and abs(float(a.norm() / c.norm()) - 1.0) <= 1e-3, (name, k, cos)
             assert cos >= min(floor, 0.9999), (name, k, cos)
+    assert seen_bias == set(bias_keys)
 
 
 def test_attn2_backward_tail_one_pass_equals_z0_bwd_plus_softmax_bwd():

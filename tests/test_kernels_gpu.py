@@ -470,6 +470,70 @@ def test_layernorm_fwd_bwd(D, dtype):
     close(db, br.grad, 10 * tol, 20 * tol, "ln dbeta")
 
 
+@pytest.mark.parametrize("D,with_cls,acc", [(512, True, False), (1024, False, False), (1536, True, True)])
+def test_layernorm_bwd_with_the_fanout_sum_inside(D, with_cls, acc):
+    """mh_layernorm_bwd_fan against mh_fanout_bwd + mh_layernorm_bwd: the encoder output's three gradients (decoder input, retention
+    target = rows 1.. as alpha * bf16 source, cls row; models/mirror.py:684-700) summed while the LayerNorm backward reads dy, versus
+    the [B, T, D] sum tensor written first.  The sums are the same f32 additions in the same order per element."""
+    gen = g(D + 7)
+    B, T = 3, 67
+    x = (torch.randn(B, T, D, generator=gen) * 2 + 0.5).to(DEV)
+    gam, bet = torch.randn(D, generator=gen).to(DEV), torch.randn(D, generator=gen).to(DEV)
+    y = torch.empty((B, T, D), device=DEV)
+    mean, rstd = torch.empty(B * T, device=DEV), torch.empty(B * T, device=DEV)
+    K.layernorm_fwd(x, gam, bet, y, mean, rstd, B, T, D, T * D, T * D, 1e-5)
+    gf = torch.randn(B, T, D, generator=gen).to(DEV)
+    src = torch.randn(B, T - 1, D, generator=gen).to(DEV, torch.bfloat16)
+    cls = torch.randn(B, D, generator=gen).to(DEV) if with_cls else None
+    alpha = -1.0
+    base = torch.randn(B, T, D, generator=gen).to(DEV)
+    dE = K.fanout_bwd(gf, src, alpha, cls, B, T, D)
+    dx0 = base.clone() if acc else torch.empty_like(x)
+    dg0, db0 = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    K.layernorm_bwd(dE, x, gam, mean, rstd, dx0, dg0, db0, B, T, D, T * D, T * D, accumulate_dx=acc)
+    dx1 = base.clone() if acc else torch.empty_like(x)
+    dg1, db1 = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    assert K.layernorm_bwd_fan_ok(gf, x, dx1, src, cls, B, T, D)
+    K.layernorm_bwd(gf, x, gam, mean, rstd, dx1, dg1, db1, B, T, D, T * D, T * D, accumulate_dx=acc, fan=(src, alpha, cls))
+    close(dx1, dx0.cpu(), 1e-6, 1e-6, "dx with the fan-out inside")
+    close(dg1, dg0.cpu(), 1e-6, 1e-5, "dgamma")
+    close(db1, db0.cpu(), 1e-6, 1e-5, "dbeta")
+    with pytest.raises(K.MirrorHipError):       # off the form: loud
+        K.layernorm_bwd(gf.to(torch.bfloat16), x, gam, mean, rstd, dx1, dg1, db1, B, T, D, T * D, T * D, fan=(src, alpha, cls))
+
+
+def test_layernorm_bwd_lm_relu_rows_and_their_column_sums():
+    """mh_layernorm_bwd_lm(relu_out, relu_db): rows 1 .. R of x are a ReLU's output — their gradient leaves as bf16 (x > 0 ? dx : 0) and
+    relu_db receives the column sums of exactly those stored values (_fc1's bias gradient, models/mirror.py:346), the other outputs are
+    those of the launch without relu_db."""
+    gen = g(77)
+    B, T, D, l = 2, 129, 512, 2
+    pad = (l - T % l) % l
+    m = (pad + T) // l
+    x = torch.randn(B, T, D, generator=gen).to(DEV)
+    x[:, 1:] = x[:, 1:].clamp_min(0)
+    gam = torch.randn(D, generator=gen).to(DEV)
+    mean, rstd = x.mean(-1).reshape(-1).contiguous(), (x.var(-1, unbiased=False) + 1e-5).rsqrt().reshape(-1).contiguous()
+    dy = torch.randn(B, pad + T, D, generator=gen).to(DEV, torch.bfloat16)
+    gadd = torch.randn(B, m, D, generator=gen).to(DEV, torch.bfloat16)
+    outs = []
+    for with_db in (False, True):
+        G = torch.ones(B, T, D, device=DEV)
+        dg, db = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+        dh = torch.empty(B, T - 1, D, device=DEV, dtype=torch.bfloat16)
+        rdb = torch.full((D,), 2.0, device=DEV) if with_db else None
+        K.layernorm_bwd(dy[:, pad:], x, gam, mean, rstd, G, dg, db, B, T, D, T * D, (pad + T) * D, accumulate_dx=True, gadd=gadd, pad=pad, l=l,
+                        relu_out=dh, relu_first=1, relu_db=rdb)
+        outs.append((G[:, 0].clone(), dg, db, dh, rdb))
+    (c0, g0, b0, h0, _), (c1, g1, b1, h1, rdb) = outs
+    assert torch.equal(h0, h1) and torch.equal(c0, c1)
+    close(g1, g0.cpu(), 1e-6, 1e-5, "dgamma")
+    close(b1, b0.cpu(), 1e-6, 1e-5, "dbeta")
+    ref = 2.0 + h1.double().sum((0, 1))
+    close(rdb, ref.float().cpu(), 1e-5, 1e-4, "relu_db = colsum(relu_out)")
+    assert float((h1.float() * (x[:, 1:] <= 0)).abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("cols", [16, 256, 1000, 4352])
 @pytest.mark.parametrize("din,dout", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16)])
 def test_softmax_fwd_bwd(cols, din, dout):
@@ -811,6 +875,47 @@ def test_mask_apply_mixed_dtypes():
     close(dx, dy * keep, 0, 0, "mask dx f32 -> bf16")
     close(dtok, (dy[:, 1:] * mask[..., None]).sum((0, 1)), 0, 0, "dtoken")
     close(dpos, dy.sum(0), 0, 0, "dpos")
+    # round 5: the same pass leaves the bias gradient of the projection in front (column sums of dx), accumulating into dbias
+    dx2 = torch.empty(B, T, D, device=DEV, dtype=torch.bfloat16)
+    dtok2, dpos2 = torch.zeros(D, device=DEV), torch.zeros((T, D), device=DEV)
+    dbias = torch.full((D,), 3.0, device=DEV)
+    assert K.mask_apply_bwd_dbias_ok(dy.to(DEV), dx2, dpos2, D)
+    K.mask_apply_bwd(dy.to(DEV), mask.to(DEV), dtok2, dpos2, B, T, D, 1, False, out=dx2, dbias=dbias)
+    close(dx2, dy * keep, 0, 0, "mask dx with dbias")
+    close(dtok2, dtok.cpu(), 0, 0, "dtoken with dbias")
+    close(dpos2, dpos.cpu(), 0, 0, "dpos with dbias")
+    close(dbias, 3.0 + (dy * keep).sum((0, 1)), 0, 0, "dbias = colsum(dx)")      # small integers: exact in any order
+    with pytest.raises(K.MirrorHipError):       # the forms without quads cannot carry it: loud, not silently dropped
+        K.mask_apply_bwd(dy[:, :, :20].contiguous().to(DEV), mask.to(DEV), dtok2[:20].contiguous(), torch.zeros((T, 20), device=DEV), B, T, 20, 1, False,
+                         dbias=torch.zeros(20, device=DEV))
+
+
+@pytest.mark.parametrize("D,rows_b", [(1024, 300), (512, 37), (768, 129), (256, 64)])
+def test_masked_mse_bwd_leaves_column_sums(D, rows_b):
+    """mh_mse_masked_bwd(colsum_ws): the per-block column sums of dpred fold to exactly what mh_colsum over the stored bf16 dpred
+    gives (the bias gradient of retention_head, models/mirror.py:698-699), and dpred / dtgt are those of the plain launch."""
+    gen = g(63)
+    B, N = 3, rows_b
+    pred = torch.randn(B, N, D, generator=gen).to(DEV, torch.bfloat16)
+    E = torch.randn(B, N + 1, D, generator=gen).to(DEV)
+    mask = (torch.rand(B, N, generator=gen) > 0.4).float().to(DEV)
+    acc = torch.zeros(2, device=DEV)
+    K.mse_masked_fwd(pred, E[:, 1:], mask, acc, B * N, D)
+    gup = torch.full((1,), 0.7, device=DEV)
+    dp0, dt0 = torch.empty_like(pred), torch.empty(B, N, D, device=DEV)
+    K.mse_masked_bwd(pred, E[:, 1:], mask, acc, gup, dp0, dt0, B * N, D, gmul=0.15)
+    dp1, dt1 = torch.empty_like(pred), torch.empty(B, N, D, device=DEV)
+    assert K.mse_masked_bwd_colsum_ok(pred, E[:, 1:], dp1, D)
+    ws = torch.full((K.MSE_CS_BLOCKS, D), float("nan"), device=DEV)       # every row must be written
+    K.mse_masked_bwd(pred, E[:, 1:], mask, acc, gup, dp1, dt1, B * N, D, gmul=0.15, colsum_ws=ws)
+    assert torch.equal(dp0, dp1)
+    close(dt1, -dp1.float().cpu(), 0, 0, "dtgt = -dpred (as stored)")
+    db = torch.zeros(D, device=DEV)
+    K.colsum(ws, db)
+    ref = dp1.double().sum((0, 1))
+    close(db, ref.float().cpu(), 1e-5, 1e-6 * float(dp1.float().abs().max()) * B * N, "folded column sums")
+    with pytest.raises(K.MirrorHipError):
+        K.mse_masked_bwd(pred.float(), E[:, 1:], mask, acc, gup, dp0.float(), None, B * N, D, colsum_ws=ws)
 
 
 @pytest.mark.parametrize("D", [512, 24])

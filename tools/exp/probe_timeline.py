@@ -18,7 +18,11 @@ from mirror_amd import functional as Fn           # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=12)
 ap.add_argument("--pipelined", type=int, default=1, help="1: the timed steps are issued back to back (as bench.py does) and the last is read")
+ap.add_argument("--off", default="", help="comma-separated test hooks of mirror_amd.functional to turn off (e.g. _FAN_IN_LN_BWD)")
 a = ap.parse_args()
+for _name in filter(None, a.off.split(",")):
+    assert hasattr(Fn, _name), _name
+    setattr(Fn, _name, False)
 dev = torch.device("cuda", 0)
 torch.manual_seed(42)
 model = M.mirror(wsi_embed_dim=1024, rna_embed_dim=2048, embed_dim=512, wsi_num_tokens=4096, rna_encoder_depth=6, rna_mlp_ratio=4.0,
