@@ -627,10 +627,15 @@ int mh_clamp_(float* x, int64_t n, float lo, float hi, mh_stream s);
  * is a launch argument, so the whole step can be captured in a HIP graph (train_mirror.py:1254 optimizer.step()).
  * Step glue that rides along instead of costing launches of its own: clamp_index >= 0 clamps that one parameter to
  * [clamp_lo, clamp_hi] right behind its update, master and shadow (`logit_scale.clamp_(0, ln 100)`, train_mirror.py:1255; -1 =
- * none); counter (nullable) += counter_add on the device (the dropout streams' per-step base). */
+ * none); counter (nullable) += counter_add on the device (the dropout streams' per-step base).
+ * One optimizer step as TWO launches (round 5: the RNA encoder's parameters, 80 % of the arena, have their gradients 2 ms before the
+ * step's last one): tick = 0 reads dev_state without advancing it (the other launch of the step did), and elements [hole_lo, hole_hi)
+ * (quad-aligned, not holding clamp_index) are left untouched — the range the other launch updates.  tick = 1, hole_lo = hole_hi = 0:
+ * the whole arena in one launch, as before. */
 int mh_adam(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr, float beta1,
             float beta2, float eps, float bias_c1, float bias_c2, float grad_scale, float* dev_state, int64_t clamp_index,
-            float clamp_lo, float clamp_hi, int64_t* counter, int64_t counter_add, mh_stream s);
+            float clamp_lo, float clamp_hi, int64_t* counter, int64_t counter_add, int tick, int64_t hole_lo, int64_t hole_hi,
+            mh_stream s);
 
 /* clip-grad "norm" mode (train_mirror.py:1206-1230): dev_state[5] = ||grad_scale * g||_2, dev_state[4] =
  * min(1, max_norm / (norm + 1e-6)) (1 when max_norm <= 0); scratch1 = one device float. */

@@ -177,7 +177,7 @@ _SIGS = {
     "mh_symkl_bwd": [P, P, P, P, P, I, I, F],
     "mh_rownorm_": [P, P, I, I, F],
     "mh_clamp_": [P, L, F, F],
-    "mh_adam": [P, P, P, P, P, L, F, F, F, F, F, F, F, P, L, F, F, P, L],
+    "mh_adam": [P, P, P, P, P, L, F, F, F, F, F, F, F, P, L, F, F, P, L, I, L, L],
     "mh_grad_clip": [P, L, F, F, P, P],
     "mh_rna_block_fwd": [C.POINTER(RnaBlockDesc)],
     "mh_rna_block_bwd": [C.POINTER(RnaBlockDesc)],

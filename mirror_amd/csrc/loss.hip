@@ -475,7 +475,10 @@ extern "C" int mh_clamp_(float* x, int64_t n, float lo, float hi, mh_stream s) {
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, bf16_t* __restrict__ shadow, long n, float lr, float b1,
                                                    float b2, float eps, float bc1, float bc2, float gscale,
-                                                   const float* __restrict__ state, long clamp_i, float clamp_lo, float clamp_hi) {
+                                                   const float* __restrict__ state, long clamp_i, float clamp_lo, float clamp_hi,
+                                                   long hole_lo4, long hole_hi4) {
+    // quads [hole_lo4, hole_hi4) are left alone: a range another launch of the same step has already updated (the RNA encoder's
+    // parameters, whose gradients are complete 2 ms before the step's last one: TrainEngine's early update)
     if (state) {   // device-resident step state {t, 1 - b1^t, 1 - b2^t, lr, clip}: nothing step-dependent is a launch argument
         bc1 = state[1];
         bc2 = state[2];
@@ -485,7 +488,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     const float step = lr / bc1;
     const float isq = rsqrtf(bc2);
     const long n4 = n / 4;
-    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long)gridDim.x * 256) {
+    const long hole = hole_hi4 - hole_lo4, live4 = n4 - hole;
+    for (long q0 = (long)blockIdx.x * 256 + threadIdx.x; q0 < live4; q0 += (long)gridDim.x * 256) {
+        const long q = q0 < hole_lo4 ? q0 : q0 + hole;       // the live quads are numbered densely: no idle threads over the hole
         float4 pp = reinterpret_cast<float4*>(p)[q];
         const float4 gg = reinterpret_cast<const float4*>(g)[q];
         float4 mm = reinterpret_cast<float4*>(m)[q];
@@ -565,15 +570,20 @@ extern "C" int mh_grad_clip(const float* g, int64_t n, float grad_scale, float m
 
 extern "C" int mh_adam(float* p, const float* g, float* m, float* v, void* shadow, int64_t n, float lr, float b1, float b2,
                        float eps, float bc1, float bc2, float gscale, float* dev_state, int64_t clamp_index, float clamp_lo,
-                       float clamp_hi, int64_t* counter, int64_t counter_add, mh_stream s) {
+                       float clamp_hi, int64_t* counter, int64_t counter_add, int tick, int64_t hole_lo, int64_t hole_hi, mh_stream s) {
     if (n == 0) return MH_OK;
     MH_REQUIRE(((uintptr_t)p & 15) == 0 && ((uintptr_t)g & 15) == 0 && ((uintptr_t)m & 15) == 0 && ((uintptr_t)v & 15) == 0 &&
                    ((uintptr_t)shadow & 7) == 0, "mh_adam: buffers must be 16-byte aligned");
     MH_REQUIRE(clamp_index < n, "mh_adam: clamp_index %ld outside the %ld parameters", (long)clamp_index, (long)n);
-    if (dev_state || counter)
-        hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, dev_state, b1, b2, (long long*)counter, (long long)counter_add);
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)min((long)mh_cdiv(mh_cdiv(n, 4), 256), 8192L)), dim3(256), 0, (hipStream_t)s, p, g, m, v, (bf16_t*)shadow, (long)n, lr, b1, b2, eps, bc1, bc2, gscale, (const float*)dev_state,
-                       clamp_index < 0 ? -1L : (long)clamp_index, clamp_lo, clamp_hi);
+    MH_REQUIRE(hole_lo >= 0 && hole_lo <= hole_hi && hole_hi <= n && hole_lo % 4 == 0 && (hole_hi % 4 == 0 || hole_hi == hole_lo) &&
+                   (clamp_index < hole_lo || clamp_index >= hole_hi || hole_lo == hole_hi),
+               "mh_adam: hole [%ld, %ld) must be quad-aligned, inside the %ld parameters and not hold the clamped one", (long)hole_lo, (long)hole_hi, (long)n);
+    if ((dev_state && tick) || counter)
+        hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, tick ? dev_state : nullptr, b1, b2, (long long*)counter, (long long)counter_add);
+    const long live = n - (hole_hi - hole_lo);
+    if (live == 0) return MH_OK;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)min((long)mh_cdiv(mh_cdiv(live, 4), 256), 8192L)), dim3(256), 0, (hipStream_t)s, p, g, m, v, (bf16_t*)shadow, (long)n, lr, b1, b2, eps, bc1, bc2, gscale, (const float*)dev_state,
+                       clamp_index < 0 ? -1L : (long)clamp_index, clamp_lo, clamp_hi, (long)(hole_lo / 4), (long)(hole_hi / 4));
     MH_LAUNCH_CHECK("mh_adam");
     return MH_OK;
 }

@@ -50,6 +50,7 @@ def plan_buckets(sizes: Sequence[int], cap_elems: int, align: int = _ALIGN):
 _ASYNC_GATHER = True      # alignment all-gather issued behind the heads
 _DEFER_SKINNY = True      # one multi-tensor launch for the skinny weight gradients
 _TRANSPOSE_AT_START = True      # (test hook)
+_EARLY_ADAM = True      # (test hook, round 5) the RNA encoder's share of the optimizer step on its branch's stream, beside the WSI backward
 _KERNEL_D2D = os.environ.get("MIRROR_KERNEL_D2D", "1") != "0"      # (A/B switch, round 5) the static-input refresh of a replayed step as a kernel
 
 
@@ -118,6 +119,14 @@ class TrainEngine:
         self.v = torch.zeros(total, device=self.device, dtype=f32)
         self.shadow = torch.zeros(total, device=self.device, dtype=bf16) if POLICIES[precision].act == bf16 else None
         self.params, self.offsets = order, offs
+        # the RNA encoder's parameters (80 % of the arena at c2) are one contiguous range: their gradients are complete when the RNA
+        # branch's stream has flushed its deferred weight gradients, ~2 ms before the WSI encoder's last one (see _EARLY_ADAM)
+        self._early_range = None
+        pname = {id(p): n for n, p in model.named_parameters()}
+        idx = [i for i, p in enumerate(order) if pname.get(id(p), "").startswith("rna_encoder.")]
+        if idx and idx == list(range(idx[0], idx[-1] + 1)):
+            last = idx[-1]
+            self._early_range = (offs[idx[0]], offs[last] + (order[last].numel() + _ALIGN - 1) // _ALIGN * _ALIGN)
         with torch.no_grad():
             for p, o in zip(order, offs):
                 n = p.numel()
@@ -464,6 +473,10 @@ class TrainEngine:
         # the backward and run as ONE launch on the branch's stream behind it (with data parallelism they stay where they are: their
         # buckets should be reduced as early as possible)
         defer = _DEFER_SKINNY and self.world == 1 and self._rna_branch_state != "on" and self.shadow is not None
+        # two-launch optimizer step: only where nothing couples the ranges (no gradient reduction, no accumulation window, no global
+        # clipping norm) — otherwise the one launch behind the backward, as before
+        early = self._early_range if (_EARLY_ADAM and defer and self.accum_steps == 1 and self.clip_grad is None
+                                      and not self._force) else None
         if defer:
             Fn.skinny_wgrads_begin()
         try:
@@ -478,6 +491,15 @@ class TrainEngine:
                     Fn.probe("side_bwd_end")
                     Fn.flush_skinny_wgrads()
                     Fn.probe("flush_end")
+                    if early is not None:
+                        # every gradient of rna_encoder.* was written on this stream (the branch's forward ran here, so did its backward
+                        # nodes and the flush above): its share of the optimizer step runs now, beside the WSI encoder's backward,
+                        # instead of behind it — the step's tail keeps only the WSI / heads share of mh_adam's 28 B per parameter
+                        b1, b2 = self.betas
+                        lo, hi = early
+                        K.adam(self.master[lo:hi], self.grad[lo:hi], self.m[lo:hi], self.v[lo:hi],
+                               None if self.shadow is None else self.shadow[lo:hi], self.lr, b1, b2, self.eps, 1.0, 1.0,
+                               grad_scale=1.0, dev_state=self._state, tick=True)
         finally:
             Fn._wgrad_queue = None
             Fn.set_grad_sink(None)
@@ -519,7 +541,8 @@ class TrainEngine:
         K.adam(self.master, self.grad, self.m, self.v, self.shadow, self.lr, b1, b2, self.eps, 1.0, 1.0,
                grad_scale=gs,                  # the DDP / accumulation average is folded into Adam
                dev_state=self._state,          # t, bias corrections, lr and the clip factor live on the device
-               clamp=clamp, counter=base, counter_add=used)
+               clamp=clamp, counter=base, counter_add=used,
+               tick=early is None, hole=early)     # the RNA encoder's range was updated (and t advanced) beside the WSI backward
         if _TRANSPOSE_AT_START:
             self._t_stale = self.shadow_t is not None
         else:

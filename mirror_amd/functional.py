@@ -749,6 +749,7 @@ def flush_deferred_bwd() -> None:
         _deferred_bwd.popitem()[1]()
 
 
+_HEAD_FOLD_FIRST = False     # (experiment hook) retention_head's bias-gradient fold in front of its two products: graph topology probe
 _BIAS_IN_PRODUCER = True     # (test hook, round 5) bias gradients left by the pass that wrote dy instead of an mh_colsum launch over it
 
 
@@ -908,7 +909,12 @@ class HeadSqErrFn(Function):
             if tok.ptr == dy.data_ptr():
                 db_table = tok.ws
             tok.ws = None
-        dx, dw, db = _linear_rows_bwd(ctx.needs_input_grad[0:3], x, wa, w, b, ctx.r0, ctx.R, prec, dy, db_table=db_table)
+        db_have = None
+        if _HEAD_FOLD_FIRST and db_table is not None and b is not None and ctx.needs_input_grad[2]:
+            dbuf, sunk = _gbuf(b, (wa.shape[0],))        # the measured-slower order (see above), kept as a hook for the probe experiments
+            K.colsum(db_table, dbuf)
+            db_have, db_table = (dbuf, sunk), None
+        dx, dw, db = _linear_rows_bwd(ctx.needs_input_grad[0:3], x, wa, w, b, ctx.r0, ctx.R, prec, dy, db_table=db_table, db_have=db_have)
         return dx, dw, db, None, None, None, None, None, None, None
 
 

@@ -1719,11 +1719,13 @@ def grad_clip(g: torch.Tensor, grad_scale: float, max_norm: float, dev_state: to
 
 
 def adam(p, g, m, v, shadow, lr, b1, b2, eps, bc1, bc2, grad_scale=1.0, dev_state: Optional[torch.Tensor] = None,
-         clamp: Optional[tuple] = None, counter: Optional[torch.Tensor] = None, counter_add: int = 0) -> None:
+         clamp: Optional[tuple] = None, counter: Optional[torch.Tensor] = None, counter_add: int = 0, tick: bool = True,
+         hole: Optional[tuple] = None) -> None:
     """dev_state: optional f32[6] device tensor {t, 1-b1^t, 1-b2^t, lr, clip, |g|}; when given the step count / bias
     corrections / lr live on the device (advanced by the launch itself), lr, bc1, bc2 are ignored and the gradient is
     also scaled by dev_state[4] (the factor grad_clip left there, else 1).  clamp = (index, lo, hi): that one parameter is clamped
-    behind its update (master and shadow); counter (int64[1]) += counter_add in the same launches."""
+    behind its update (master and shadow); counter (int64[1]) += counter_add in the same launches.  tick=False: dev_state is read,
+    not advanced; hole = (lo, hi): those elements are left alone (the other launch of a two-launch step updates them)."""
     _chk(p, g, m, v, shadow, dev_state, counter)
     assert counter is None or (counter.dtype == torch.int64 and counter.numel() == 1)
     ci, clo, chi = (-1, 0.0, 0.0) if clamp is None else (int(clamp[0]), float(clamp[1]), float(clamp[2]))
@@ -1733,4 +1735,5 @@ def adam(p, g, m, v, shadow, lr, b1, b2, eps, bc1, bc2, grad_scale=1.0, dev_stat
         assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel()
     assert dev_state is None or (dev_state.dtype == torch.float32 and dev_state.numel() == 6 and dev_state.is_contiguous())
     _lib.call("mh_adam", _p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), lr, b1, b2, eps, bc1, bc2, grad_scale,
-              _p(dev_state), ci, clo, chi, _p(counter), int(counter_add), stream=_stream())
+              _p(dev_state), ci, clo, chi, _p(counter), int(counter_add), int(bool(tick)), *((0, 0) if hole is None else (int(hole[0]), int(hole[1]))),
+              stream=_stream())

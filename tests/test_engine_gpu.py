@@ -430,6 +430,58 @@ def test_d512_graph_replay_matches_eager_launch():
     _traj_close(pa, pb, init)
 
 
+def test_early_adam_for_the_rna_encoder_equals_the_single_launch(monkeypatch):
+    """Round 5: the RNA encoder's parameters (one contiguous range of the arena) are updated on the RNA branch's stream as soon as that
+    stream has flushed its weight gradients, the rest behind the backward with tick=False and a hole (TrainEngine.step, mh_adam).  Same
+    seeds, whole-step graph: losses, first / second moments and the parameter trajectory equal those of the one-launch step up to the
+    gradients' own f32-atomics noise; the device step counter advances once per step; configurations that couple the ranges (global
+    clipping norm, accumulation) keep the single launch."""
+    import mirror_amd.models as M
+    from mirror_amd import engine as E
+    from mirror_amd import kernels as K
+    from mirror_amd.engine import TrainEngine
+    from mirror_amd.losses import MIRRORLoss
+    calls = []
+    real = K.adam
+
+    def counting(*a, **kw):
+        calls.append((a[0].numel(), kw.get("tick", True), kw.get("hole")))
+        return real(*a, **kw)
+    monkeypatch.setattr(K, "adam", counting)
+    runs = []
+    for early in (True, False):
+        monkeypatch.setattr(E, "_EARLY_ADAM", early)
+        torch.manual_seed(21)
+        model = M.mirror(**CFG512, rna_proj_drop_rate=0.1).cuda().train()
+        eng = TrainEngine(model, MIRRORLoss(), lr=1e-6, precision="bf16", graph=True, seed=77)
+        lo, hi = eng._early_range
+        assert hi - lo > 0.3 * eng.numel and lo % 8 == 0 and hi % 8 == 0
+        init = eng.master.clone()
+        wsi, rna, _ = _batch(4, 5, CFG512)
+        wsi = wsi.to(torch.bfloat16)
+        calls.clear()
+        losses = [[float(x) for x in eng.step(wsi, rna)] for _ in range(5)]
+        assert eng._graph is not None and float(eng._state[0]) == 5.0
+        if early:       # (eager steps before the capture + the capture itself: two launches each)
+            assert any(c == (hi - lo, True, None) for c in calls) and any(c == (eng.numel, False, (lo, hi)) for c in calls)
+        else:
+            assert all(c[1] is True and c[2] is None and c[0] == eng.numel for c in calls)
+        runs.append((losses, eng.master.clone(), eng.m.clone(), eng.v.clone(), init))
+    (la, pa, ma, va, init), (lb, pb, mb, vb, _) = runs
+    for a, b in zip(la, lb):
+        for x, y in zip(a, b):
+            assert abs(x - y) <= 2e-3 * max(1.0, abs(y)), (la, lb)
+    _traj_close(pa, pb, init)
+    assert float((ma - mb).norm()) <= 2e-2 * float(mb.norm()) and float((va - vb).norm()) <= 4e-2 * float(vb.norm())
+    # a global clipping norm couples the two ranges: one launch behind the backward
+    monkeypatch.setattr(E, "_EARLY_ADAM", True)
+    torch.manual_seed(21)
+    eng = TrainEngine(M.mirror(**CFG512).cuda().train(), MIRRORLoss(), lr=1e-6, precision="bf16", graph=False, seed=77, clip_grad=1.0)
+    calls.clear()
+    eng.step(wsi, rna)
+    assert calls == [(eng.numel, True, None)]
+
+
 def test_d512_graph_replay_with_key_padding_mask_matches_eager_launch():
     """BASELINE config 4 under the whole-step HIP graph (round 5): the key-padding mask is one more STATIC INPUT of the captured step,
     refreshed like the batch.  Graph replay vs eager launch at D = 512 with padded slides (bf16 policy, train mode, same seeds): losses

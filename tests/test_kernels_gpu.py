@@ -1217,6 +1217,31 @@ def test_step_glue_rownorm_clamp_adam():
     from mirror_amd import MirrorHipError
     with pytest.raises(MirrorHipError):
         K.adam(p2, gr.to(DEV), m2, v2, None, 2e-5, 0.9, 0.999, 1e-8, 0.1, 0.001, clamp=(n, 0.0, 1.0))
+    # one optimizer step as two launches (round 5): a range updated first (and the device step state advanced by that launch), the
+    # rest later with tick=False and a hole — bit-identical to the single launch, the counter advanced once, the clamp honoured
+    for lo_, hi_ in ((1024, 7000), (0, 4096), (4096, 10004)):
+        outs = []
+        for split in (False, True):
+            pp, mm, vv = p.to(DEV), torch.full((n,), 0.01, device=DEV), torch.full((n,), 0.02, device=DEV)
+            shh = torch.zeros(n, device=DEV, dtype=torch.bfloat16)
+            st = torch.tensor([2.0, 0.0, 0.0, 3e-4, 1.0, 0.0], device=DEV)
+            cnt = torch.tensor([8], device=DEV, dtype=torch.int64)
+            gd = gr.to(DEV)
+            kw = dict(dev_state=st, clamp=(5 if lo_ else n - 2, -0.1, 0.1), counter=cnt, counter_add=16)
+            if split:
+                K.adam(pp[lo_:hi_], gd[lo_:hi_], mm[lo_:hi_], vv[lo_:hi_], shh[lo_:hi_], 0.0, 0.9, 0.999, 1e-8, 1.0, 1.0, dev_state=st, tick=True)
+                assert float(st[0]) == 3.0 and int(cnt) == 8
+                K.adam(pp, gd, mm, vv, shh, 0.0, 0.9, 0.999, 1e-8, 1.0, 1.0, tick=False, hole=(lo_, hi_), **kw)
+            else:
+                K.adam(pp, gd, mm, vv, shh, 0.0, 0.9, 0.999, 1e-8, 1.0, 1.0, **kw)
+            assert float(st[0]) == 3.0 and int(cnt) == 24
+            outs.append((pp, mm, vv, shh))
+        for a, b in zip(*outs):
+            assert torch.equal(a, b), (lo_, hi_)
+    with pytest.raises(MirrorHipError):        # the hole must be quad-aligned and must not hold the clamped parameter
+        K.adam(p2, gr.to(DEV), m2, v2, None, 2e-5, 0.9, 0.999, 1e-8, 0.1, 0.001, hole=(2, 8))
+    with pytest.raises(MirrorHipError):
+        K.adam(p2, gr.to(DEV), m2, v2, None, 2e-5, 0.9, 0.999, 1e-8, 0.1, 0.001, clamp=(5, 0.0, 1.0), hole=(4, 8))
 
 
 # --------------------------------------------------------------------------------------- skinny-M linears

@@ -18,8 +18,12 @@ from mirror_amd import functional as Fn           # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=12)
 ap.add_argument("--pipelined", type=int, default=1, help="1: the timed steps are issued back to back (as bench.py does) and the last is read")
+ap.add_argument("--on", default="", help="comma-separated hooks to turn on")
 ap.add_argument("--off", default="", help="comma-separated test hooks of mirror_amd.functional to turn off (e.g. _FAN_IN_LN_BWD)")
 a = ap.parse_args()
+for _name in filter(None, a.on.split(",")):
+    assert hasattr(Fn, _name), _name
+    setattr(Fn, _name, True)
 for _name in filter(None, a.off.split(",")):
     assert hasattr(Fn, _name), _name
     setattr(Fn, _name, False)
