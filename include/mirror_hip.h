@@ -477,6 +477,12 @@ int mh_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int dt_x, in
 /* dx = dy * (y > 0); `batches` blocks of n_per_batch contiguous elements at the given batch strides */
 int mh_relu_bwd(const void* y, const void* dy, void* dx, int64_t n_per_batch, int batches, int64_t y_bs, int64_t dy_bs,
                 int64_t dx_bs, int dt_y, int dt_dy, int dt_dx, mh_stream s);
+/* The four random draws of a training step in one launch (models/mirror.py:630 `torch.rand(B, N)`, :516 `torch.rand(B, D)`, :832-833
+ * `torch.randn_like` twice): out[0, n_uniform) uniform in [0, 1) on 24 random bits, out[n_uniform, n_uniform + n_normal) standard normal
+ * (Box-Muller); Philox4x32-10 on the dropout stream: element i = word (i & 3) of block (offset + *dev_base + i) >> 2 under `seed`.
+ * n_uniform and offset are multiples of 4.  The VALUES differ from torch's generator (as any seed change would); callers that pin the
+ * draws (parity tests) pass them in instead. */
+int mh_noise_draws(float* out, int64_t n_uniform, int64_t n_normal, uint64_t seed, uint64_t offset, const uint64_t* dev_base, mh_stream s);
 /* y = x * keep/(1-p); keep from Philox4x32-10(seed, offset + *dev_base + i)  ([3P] nn.Dropout in to_out; :75, :142).
  * dev_base (nullable, device memory): per-step base offset, so that a captured graph draws fresh masks at every replay */
 int mh_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, uint64_t offset, const uint64_t* dev_base,

@@ -188,6 +188,50 @@ __global__ __launch_bounds__(256) void dropout_kernel(const TX* x, TY* y, long n
     }
 }
 
+// The step's four random draws in ONE launch on the dropout stream (models/mirror.py:630, :516, :832-833: torch.rand(B, N), torch.rand(B, D),
+// torch.randn(B, L) twice): out[0, n_uniform) uniform in [0, 1) with 24 random bits like torch.rand's f32, out[n_uniform, + n_normal)
+// standard normal (Box-Muller on word pairs of a block).  n_uniform % 4 == 0.  Element i = word (i & 3) of block (offset + i) >> 2.
+// As torch draws they were four launches plus, under a captured graph, two generator-state fills in front of every replay.
+__global__ __launch_bounds__(256) void noise_draws_kernel(float* __restrict__ out, long n_uniform, long n_total, uint64_t seed, uint64_t offset,
+                                                          const uint64_t* __restrict__ dev_base) {
+    if (dev_base) offset += *dev_base & ~3ull;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q * 4 < n_total; q += (long)gridDim.x * 256) {
+        const uint64_t blk = (offset >> 2) + (uint64_t)q;
+        uint32_t ctr[4] = {(uint32_t)blk, (uint32_t)(blk >> 32), 0u, 0u};
+        philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
+        float v[4];
+        if (q * 4 < n_uniform) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = (float)(ctr[e] >> 8) * 5.9604644775390625e-8f;        // k / 2^24, k < 2^24
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const float u1 = ((float)(ctr[2 * h] >> 8) + 1.f) * 5.9604644775390625e-8f;           // (0, 1]
+                const float u2 = (float)(ctr[2 * h + 1] >> 8) * 5.9604644775390625e-8f;
+                const float r = sqrtf(-2.f * logf(u1));
+                float sn, cs;
+                sincosf(6.283185307179586f * u2, &sn, &cs);
+                v[2 * h] = r * cs;
+                v[2 * h + 1] = r * sn;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            if (q * 4 + e < n_total) out[q * 4 + e] = v[e];
+    }
+}
+
+extern "C" int mh_noise_draws(float* out, int64_t n_uniform, int64_t n_normal, uint64_t seed, uint64_t offset, const uint64_t* dev_base,
+                              mh_stream s) {
+    MH_REQUIRE(out && n_uniform >= 0 && n_normal >= 0 && n_uniform % 4 == 0 && (offset & 3) == 0, "mh_noise_draws: n_uniform and offset are multiples of 4");
+    const long n = n_uniform + n_normal;
+    if (n == 0) return MH_OK;
+    hipLaunchKernelGGL(noise_draws_kernel, dim3((unsigned)min((long)mh_cdiv(mh_cdiv(n, 4), 256), 2048L)), dim3(256), 0, (hipStream_t)s, out, (long)n_uniform, n, seed,
+                       offset, dev_base);
+    MH_LAUNCH_CHECK("mh_noise_draws");
+    return MH_OK;
+}
+
 // quad form (n % 4 == 0, quad-aligned pointers): one Philox block per thread iteration = one 8 / 16-byte access per tensor;
 // ADD: y = a + dropout(x) (the residual add behind to_out's Dropout, models/mirror.py:312 + [3P] to_out[1])
 template <typename TX, typename TY, bool ADD>

@@ -445,8 +445,9 @@ class TrainEngine:
             if self._proto is not None:
                 w = self._proto.weight
                 K.rownorm_(w.data, shadow=Fn.shadow(w, POLICIES[self.precision]) if self.shadow is not None else None)
-        renorm_prototypes()
         t_done = None
+        if not _TRANSPOSE_AT_START:
+            renorm_prototypes()
         if _TRANSPOSE_AT_START:
             # The transposed bf16 weight copies are read by BACKWARD kernels only (data gradients of the [B, D]-row linears): instead
             # of 50 us behind Adam at the end of every step they are rebuilt at the start of the next one, on the RNA branch's
@@ -454,6 +455,7 @@ class TrainEngine:
             main, side = torch.cuda.current_stream(), Fn._side_stream(self.device, 1)
             side.wait_stream(main)
             with torch.cuda.stream(side):
+                renorm_prototypes()          # read by the prototype head only, which runs on this stream (forward and backward)
                 self._refresh_transposes()
                 if self._zero_pending:           # the gradient arena of the update that ended the previous step
                     self.grad.zero_()

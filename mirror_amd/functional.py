@@ -1384,6 +1384,18 @@ def dropout_device_base_off() -> None:
     _dropout_state["base"] = None
 
 
+def noise_draws(B: int, N: int, D: int, L: int, device):
+    """(rand [B, N], rand [B, D], randn [B, L], randn [B, L]) — the step's four draws (models/mirror.py:630, :516, :832-833) as ONE launch on
+    the dropout stream (mh_noise_draws; seed / running offset / per-step device base of manual_seed and dropout_step_begin): under a
+    captured step torch's generator costs four launches plus two state fills in front of every replay."""
+    n0, n1 = (B * N + 3) // 4 * 4, (B * D + 3) // 4 * 4
+    off = (_dropout_state["offset"] + 3) // 4 * 4
+    buf = K.noise_draws(n0 + n1, 2 * B * L, _dropout_state["seed"], off, _dropout_state["base"], device)
+    _dropout_state["offset"] = off + (n0 + n1 + 2 * B * L + 3) // 4 * 4
+    e = n0 + n1
+    return (buf[:B * N].view(B, N), buf[n0:n0 + B * D].view(B, D), buf[e:e + B * L].view(B, L), buf[e + B * L:e + 2 * B * L].view(B, L))
+
+
 def _lite_offset() -> int:
     """The next offset of the lite dropout stream (8 elements per Philox block): the running offset rounded up to 8."""
     return (_dropout_state["offset"] + 7) // 8 * 8

@@ -1432,6 +1432,16 @@ def dropout(x: torch.Tensor, p: float, seed: int, offset: int, out: Optional[tor
     return y
 
 
+def noise_draws(n_uniform: int, n_normal: int, seed: int, offset: int, dev_base: Optional[torch.Tensor], device) -> torch.Tensor:
+    """f32 [n_uniform + n_normal]: uniform [0, 1) then standard normal draws on the dropout stream (mh_noise_draws); n_uniform % 4 == 0."""
+    _chk(dev_base)
+    assert n_uniform % 4 == 0 and offset % 4 == 0
+    out = torch.empty((n_uniform + n_normal,), device=device, dtype=torch.float32)
+    _chk(out)
+    _lib.call("mh_noise_draws", _p(out), n_uniform, n_normal, seed, offset, _p(dev_base), stream=_stream())
+    return out
+
+
 def dropout_add(a: torch.Tensor, x: torch.Tensor, p: float, seed: int, offset: int, dev_base: Optional[torch.Tensor] = None) -> torch.Tensor:
     """a + dropout(x) as f32 (a f32, x f32 / bf16, same shape, numel % 4 == 0)."""
     _chk(a, x, dev_base)

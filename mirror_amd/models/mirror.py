@@ -33,6 +33,7 @@ _DEFAULT_PRECISION: Optional[str] = None
 _RNA_LATE = True      # (test hook)
 # 1 (default) = the alignment / style heads run on the RNA branch's helper stream, 0 = on the caller's stream (A/B switch)
 _HEADS_SIDE = True      # (test hook)
+_OWN_NOISE = True      # (test hook, round 5) the step's four random draws as one launch on the dropout stream instead of torch's generator
 # (measured and removed: the four noise draws + the prototype renorm on the RNA stream cost 0.5 - 1 % of the step)
 
 
@@ -542,20 +543,27 @@ class MIRROR(nn.Module):
         main = torch.cuda.current_stream()
         side = Fn._side_stream(dev, 1)
         wsi_in, rna_in = wsi_emb, rna_emb
-        # the reference draws them in this order: rand(B,N) -> rand(B,D) -> eps_wsi -> eps_rna
-        if "wsi_mask" not in noise:
-            noise["wsi_mask"] = torch.rand(B, wsi_emb.shape[1], device=dev)
-        if "rna_mask" not in noise:
-            noise["rna_mask"] = torch.rand(B, self.embed_dim, device=dev)
-        if "wsi_eps" not in noise:
-            noise["wsi_eps"] = torch.randn(B, self.style_latent_dim, device=dev)
-        if "rna_eps" not in noise:
-            noise["rna_eps"] = torch.randn(B, self.style_latent_dim, device=dev)
+        # the reference draws them in this order: rand(B,N) -> rand(B,D) -> eps_wsi -> eps_rna.  None pinned (a training step): all four
+        # come from ONE launch on the dropout stream, issued on the side stream that consumes them (round 5: as torch draws they were four
+        # launches in front of the WSI encoder's first GEMM plus two generator-state fills in front of every graph replay)
+        own_draws = _OWN_NOISE and _HEADS_SIDE and not any(k in noise for k in ("wsi_mask", "rna_mask", "wsi_eps", "rna_eps"))
+        if not own_draws:
+            if "wsi_mask" not in noise:
+                noise["wsi_mask"] = torch.rand(B, wsi_emb.shape[1], device=dev)
+            if "rna_mask" not in noise:
+                noise["rna_mask"] = torch.rand(B, self.embed_dim, device=dev)
+            if "wsi_eps" not in noise:
+                noise["wsi_eps"] = torch.randn(B, self.style_latent_dim, device=dev)
+            if "rna_eps" not in noise:
+                noise["rna_eps"] = torch.randn(B, self.style_latent_dim, device=dev)
         fork = main.record_event()   # the side stream ranks / applies these draws: it has to start behind them
 
         def run_side():
             side.wait_event(fork)
             with torch.cuda.stream(side):
+                if own_draws:
+                    noise["wsi_mask"], noise["rna_mask"], noise["wsi_eps"], noise["rna_eps"] = Fn.noise_draws(
+                        B, wsi_in.shape[1], self.embed_dim, self.style_latent_dim, dev)
                 # the WSI token mask depends on the noise alone: rank it here, long before the retention decoder needs it
                 n_tok = wsi_in.shape[1]
                 mask_ = Fn.rank_mask(noise["wsi_mask"], int(n_tok * (1 - wsi_mask_ratio)))
@@ -577,7 +585,7 @@ class MIRROR(nn.Module):
         # The dropout offsets stay those of the RNA-first order (the RNA branch's HIP-graph replay has them baked in, and the
         # masks do not depend on the launch order): the RNA range is reserved up front once its length is known.
         st = Fn._dropout_state
-        key = (tuple(rna_emb.shape), self.training, torch.is_grad_enabled(), rna_mask_ratio)
+        key = (tuple(rna_emb.shape), self.training, torch.is_grad_enabled(), rna_mask_ratio, own_draws, tuple(wsi_emb.shape[:2]))
         n_rna = self._rna_drop_n.get(key) if _RNA_LATE else None
         if n_rna is not None:
             off0 = st["offset"]

@@ -1244,6 +1244,35 @@ def test_step_glue_rownorm_clamp_adam():
         K.adam(p2, gr.to(DEV), m2, v2, None, 2e-5, 0.9, 0.999, 1e-8, 0.1, 0.001, clamp=(5, 0.0, 1.0), hole=(4, 8))
 
 
+def test_noise_draws_one_launch_uniform_and_normal():
+    """mh_noise_draws: uniform [0, 1) on 24 bits and Box-Muller normals from the Philox dropout stream — a pure function of
+    (seed, offset + device base, element), the moments of the distributions they stand for (torch.rand / torch.randn at
+    models/mirror.py:630, :516, :832-833), and what Fn.noise_draws hands the model: four views, the host offset advanced past them."""
+    from mirror_amd import functional as Fn
+    nu, nn_ = 16 * 4096 + 16 * 512, 2 * 16 * 256
+    a = K.noise_draws(nu, nn_, 1234, 64, None, DEV)
+    b = K.noise_draws(nu, nn_, 1234, 64, None, DEV)
+    assert torch.equal(a, b)
+    base = torch.tensor([128], device=DEV, dtype=torch.int64)
+    c = K.noise_draws(nu, nn_, 1234, 64, base, DEV)
+    d = K.noise_draws(nu, nn_, 1234, 192, None, DEV)
+    assert torch.equal(c, d) and not torch.equal(a, c)
+    assert not torch.equal(a, K.noise_draws(nu, nn_, 1235, 64, None, DEV))
+    u, z = a[:nu].double().cpu(), a[nu:].double().cpu()
+    assert float(u.min()) >= 0.0 and float(u.max()) < 1.0
+    assert abs(float(u.mean()) - 0.5) < 5e-3 and abs(float(u.var()) - 1 / 12) < 2e-3
+    assert bool(torch.isfinite(z).all()) and abs(float(z.mean())) < 0.05 and abs(float(z.var()) - 1.0) < 0.05
+    assert abs(float((z ** 4).mean()) - 3.0) < 0.3 and 3.0 < float(z.abs().max()) < 6.5
+    assert len(torch.unique(u[:4096])) > 4000          # no stuck words
+    Fn.manual_seed(7)
+    Fn._dropout_state["offset"] = 6
+    m0, m1, e0, e1 = Fn.noise_draws(3, 10, 7, 5, DEV)
+    assert m0.shape == (3, 10) and m1.shape == (3, 7) and e0.shape == (3, 5) and e1.shape == (3, 5)
+    assert Fn._dropout_state["offset"] == 8 + 32 + 24 + 32 and Fn._dropout_state["offset"] % 4 == 0
+    assert not torch.equal(e0, e1)
+    Fn._dropout_state["offset"] = 0
+
+
 # --------------------------------------------------------------------------------------- skinny-M linears
 @pytest.mark.parametrize("M,N,Kd", [(16, 1024, 2048), (3, 3000, 512), (32, 96, 64), (20, 16, 32)])
 def test_skinny_fwd_wgrad_transpose(M, N, Kd):

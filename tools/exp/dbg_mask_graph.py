@@ -14,10 +14,10 @@ CFG512 = T.CFG512
 def once():
     n = CFG512["wsi_num_tokens"]
     runs = []
-    for graph in (True, False):
+    for graph in [bool(int(x)) for x in os.environ.get('MODES', '1,0').split(',')]:
         torch.manual_seed(21)
         model = M.mirror(**CFG512, rna_proj_drop_rate=0.1).cuda().train()
-        eng = TrainEngine(model, MIRRORLoss(), lr=1e-4, precision="bf16", graph=graph, seed=77, snapshot_grads=True)
+        eng = TrainEngine(model, MIRRORLoss(), lr=float(os.environ.get("LR", "1e-4")), precision="bf16", graph=graph, seed=77, snapshot_grads=True)
         if not graph:
             eng._rna_branch_state = "off"
         wsi, rna, _ = T._batch(4, 5, CFG512)
