@@ -203,7 +203,7 @@ def main():
         hdt = torch.float32 if a.feed == "host" else torch.bfloat16
         # two distinct host batches, alternated, in pinned memory as a DataLoader(pin_memory=True) hands them over
         host = [(wsi.float().cpu().to(hdt).roll(i, 0).pin_memory(), rna.cpu().roll(i, 0).pin_memory()) for i in range(2)]
-        feed = HostFeeder((host[i % 2] for i in range(a.steps + 2)), dev, wsi_dtype=in_dtype, depth=int(os.environ.get("MIRROR_FEED_DEPTH", "3")))
+        feed = HostFeeder((host[i % 2] for i in range(a.steps + 2)), dev, wsi_dtype=in_dtype, depth=3)
         it = iter(feed)
         for _ in range(2):                        # untimed: pinned buffers allocated, pipeline primed
             w_, r_ = next(it)

@@ -51,7 +51,7 @@ _ASYNC_GATHER = True      # alignment all-gather issued behind the heads
 _DEFER_SKINNY = True      # one multi-tensor launch for the skinny weight gradients
 _TRANSPOSE_AT_START = True      # (test hook)
 _EARLY_ADAM = True      # (test hook, round 5) the RNA encoder's share of the optimizer step on its branch's stream, beside the WSI backward
-_KERNEL_D2D = os.environ.get("MIRROR_KERNEL_D2D", "1") != "0"      # (A/B switch, round 5) the static-input refresh of a replayed step as a kernel
+_KERNEL_D2D = True      # (test hook, round 5) the static-input refresh of a replayed step as a kernel, not a copy-engine transfer
 
 
 class TrainEngine:

@@ -35,7 +35,7 @@ def ln_relu(with_db):
                     relu_out=dh, relu_first=1, **kw)
 
 
-print(f"LN bwd lm + relu_out: {timeit(lambda: ln_relu(False)):.1f} us" + (f"; + relu_db: {timeit(lambda: ln_relu(True)):.1f} us" if has_db else ""))
+print(f"LN bwd lm + relu_out: {timeit(lambda: ln_relu(False)):.1f} us" + (f"; + relu_db: {timeit(lambda: ln_relu(True)):.1f} us; again without {timeit(lambda: ln_relu(False)):.1f}, with {timeit(lambda: ln_relu(True)):.1f}" if has_db else ""))
 print(f"colsum bf16 [B*N, D]: {timeit(lambda: K.colsum(dh.reshape(-1, D), rdb)):.1f} us")
 # final norm: fan-out
 gf = torch.randn(B, T, D, device=dev, generator=g); src = torch.randn(B, T - 1, D, device=dev, generator=g).to(torch.bfloat16)
