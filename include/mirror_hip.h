@@ -136,6 +136,11 @@ int mh_gemm(const mh_gemm_desc* d, mh_stream s);
 /* Tuning switch for A/B timing in one process: which main loop the 256 x 256-tile launches use (2 = persistent direct-to-LDS
  * ping-pong kernel, the default; 1 = the same, one workgroup per tile; 0 = register-staged kernel; env MH_GEMM_PP selects one
  * at start; mode < 0 only queries).  Results are identical up to the f32 summation order of split-K.  Returns the previous value. */
+/* round-5 experiment (verdict item "GEMM structure"): C bf16 [M, N] = A [M, K] . B[N, K]^T + bias on the FOUR-wave form of the
+ * 256 x 256 x 64 tile (128 x 128 per wave, one wave per SIMD, fragment reads of the next k-half issued in front of the current MFMAs);
+ * whole tiles only (M, N % 256 == 0, K % 64 == 0), K-contiguous operands.  Measured against mh_gemm in tools/exp/time_w4.py. */
+int mh_gemm_w4(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
+               mh_stream s);
 int mh_gemm_select_pp(int mode);
 /* The kernel instance the calling thread's last mh_gemm call launched (e.g. "gemm_pq_kernel<float,false,false,part>",
  * "gemm_kernel<1,bf16,bf16,float,true,false,2,2,1>"): lets a profiler name launches without restating the dispatch rules. */

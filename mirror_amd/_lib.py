@@ -147,6 +147,7 @@ _SIGS = {
     "mh_relu_bwd": [P, P, P, L, I, L, L, L, I, I, I],
     "mh_dropout": [P, P, L, F, U64, U64, P, I, I],
     "mh_noise_draws": [P, L, L, U64, U64, P],
+    "mh_gemm_w4": [P, P, P, P, I, I, I, L, L, L],
     "mh_dropout_add": [P, P, P, L, F, U64, U64, P, I],
     "mh_dropout_lite": [P, P, P, L, F, U64, U64, P, I, I],
     "mh_timestamp": [P],

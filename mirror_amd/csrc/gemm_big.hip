@@ -1336,6 +1336,111 @@ static void launch_fold(const float* ws_, int parts, long mn, float* C, long ldc
 #undef FOLD_
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// gemm_w4_kernel (round 5 experiment, verdict item 4 "GEMM structure"): the same 256 x 256 x 64 tile on FOUR waves, one per SIMD, each
+// owning a 128 x 128 part (8 x 8 blocks of 16 x 16: 256 accumulator registers).  Per k-half a wave reads 16 fragments for 64 MFMAs (the
+// 8-wave kernels: 12 for 32): a K-tile is 32 ds_read_b128 and then 128 MFMAs back to back on AGPR accumulators, one barrier per K-tile.
+// K-contiguous A and B, bf16 C, alpha = 1, optional bias; whole tiles only; one workgroup per tile, two stages.
+// MEASURED (profiles/r05_l_gemm_four_wave_experiment.txt): bit-equal to mh_gemm, 0.78-0.81 x the persistent 8-wave kernel's rate (633-801
+// vs 780-1031 TF/s on the step's forward shapes).  What it lacks is everything around the K loop that the persistent kernel has (the
+// pipeline across tiles, stores draining under the next tile's loop) plus a prefetch deeper than one K-tile — its K-tile lasts half
+// as long, so one tile ahead no longer covers the L2 latency (without steady-state requests it runs at 786 TF/s at K = 512) — and the
+// fragment reads interleaved with the MFMAs: the first form, with the next k-half's reads in front of the current MFMAs, made the
+// compiler wait for lgkmcnt(0) anyway and shuffle 900 v_accvgpr copies through the loop (549-672 TF/s).  Not on the product path.
+constexpr int W4_NT = 256, W4_QM = 8, W4_QN = 8;
+constexpr int W4_STAGE = 4 * P2_SUB;                       // A_k0 | A_k1 | B_k0 | B_k1
+constexpr int W4_CPITCH = 128 + 8;                         // bf16 elements per staged C row of a wave's 128 x 128 part
+constexpr int W4_LDS = 4 * 128 * W4_CPITCH * 2;            // 139264 B: the C staging (4 waves) is larger than the two stages (131072)
+__global__ __launch_bounds__(W4_NT) void gemm_w4_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware tile order: workgroups of one launch run on XCD blockIdx.x % 8; consecutive tiles of an XCD share their A rows
+    const int tiles = g.tiles_m * g.tiles_n;
+    const int q8 = tiles >> 3, r8 = tiles & 7, xcd = blockIdx.x & 7;
+    const int unit = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    const int tile_m = unit / g.tiles_n, tile_n = unit % g.tiles_n;
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A);
+    const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B);
+    // each wave requests the pieces the 8-wave layout gives waves w and w + 4
+    P2Stage<true> sa0, sa1, sb0, sb1;
+    sa0.init(A, g.lda, tile_m * BIG, g.M, 0, wave, lane, 0, 1 << 30, 0);
+    sa1.init(A, g.lda, tile_m * BIG, g.M, 0, wave + 4, lane, 0, 1 << 30, 0);
+    sb0.init(B, g.ldb, tile_n * BIG, g.N, 0, wave, lane, 0, 1 << 30, 0);
+    sb1.init(B, g.ldb, tile_n * BIG, g.N, 0, wave + 4, lane, 0, 1 << 30, 0);
+    auto request = [&](char* st, int t) {
+#pragma unroll
+        for (int kh = 0; kh < 2; kh++) {
+            sa0.issue(st + kh * P2_SUB, wave, t, kh);
+            sa1.issue(st + kh * P2_SUB, wave + 4, t, kh);
+            sb0.issue(st + (2 + kh) * P2_SUB, wave, t, kh);
+            sb1.issue(st + (2 + kh) * P2_SUB, wave + 4, t, kh);
+        }
+    };
+    const unsigned offa = q_kc_off(wm * 128, lane), offb = q_kc_off(wn * 128, lane);
+    const int nt = g.K / 64;
+    request(smem, 0);
+    f32x4 acc[W4_QM][W4_QN];
+#pragma unroll
+    for (int i = 0; i < W4_QM; i++)
+#pragma unroll
+        for (int j = 0; j < W4_QN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int t = 0; t < nt; t++) {
+        const char* cur = smem + (t & 1) * W4_STAGE;
+        char* nxt = smem + ((t + 1) & 1) * W4_STAGE;
+        // stage t has landed for everybody, and everybody has read stage t - 1 (the other buffer) into registers: refill it
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 1 < nt) request(nxt, t + 1);
+        bf16x8 fa[2][W4_QM], fb[2][W4_QN];
+#pragma unroll
+        for (int kh = 0; kh < 2; kh++) {
+#pragma unroll
+            for (int i = 0; i < W4_QM; i++) fa[kh][i] = q_frag_kc(cur + kh * P2_SUB, offa, i);
+#pragma unroll
+            for (int j = 0; j < W4_QN; j++) fb[kh][j] = q_frag_kc(cur + (2 + kh) * P2_SUB, offb, j);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kh = 0; kh < 2; kh++)
+#pragma unroll
+            for (int i = 0; i < W4_QM; i++)
+#pragma unroll
+                for (int j = 0; j < W4_QN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kh][j], fa[kh][i], acc[i][j], 0, 0, 0);   // C^T
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- epilogue: C^T accumulators (lane: row 16 i + (l & 15), columns 16 j + 4 (l >> 4) .. + 3) -> the wave's own LDS part -> 16-byte
+    // row-contiguous stores
+    __syncthreads();
+    bf16_t* cw = reinterpret_cast<bf16_t*>(smem) + wave * 128 * W4_CPITCH;
+    const int c16 = lane & 15, g4 = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < W4_QN; j++) {
+        f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+        if (g.bias) bq = *reinterpret_cast<const f32x4*>(g.bias + tile_n * BIG + wn * 128 + 16 * j + 4 * g4);
+#pragma unroll
+        for (int i = 0; i < W4_QM; i++) {
+            const f32x4 v = acc[i][j] + bq;
+            u32x2 w = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+            *reinterpret_cast<u32x2*>(cw + (16 * i + c16) * W4_CPITCH + 16 * j + 4 * g4) = w;
+        }
+    }
+    // (a wave reads back only what it wrote: no barrier)
+    bf16_t* C = reinterpret_cast<bf16_t*>(g.C);
+    const int rr = lane >> 4, cc = lane & 15;             // 4 rows x 16 chunks of 16 bytes per wave-instruction
+#pragma unroll 4
+    for (int r = 0; r < 128; r += 4) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(cw + (r + rr) * W4_CPITCH + 8 * cc);
+        const long row = (long)tile_m * BIG + wm * 128 + r + rr;
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(C + row * g.ldc + tile_n * BIG + wn * 128 + 8 * cc));
+    }
+}
+
 // MH_GEMM_PP=0 keeps every launch on gemm_big_kernel (A/B switch; default: the ping-pong kernel)
 // which main loop the 256 x 256-tile launches use: 0 = gemm_big_kernel (register staging), 1 = gemm_pp_kernel (direct-to-LDS,
 // ping-pong), 2 = gemm_pq_kernel (the same, persistent: default).  env MH_GEMM_PP = 0 / 1 / 2, or mh_gemm_select_pp().
@@ -1440,6 +1545,23 @@ void launch_big(GemmArgs& a, int akc, int bkc, int batch, hipStream_t s) {
 }
 
 }  // namespace
+
+
+// experiment entry (round 5): C bf16 [M, N] = A [M, K] B^T ([N, K] weights) + bias on the 4-wave kernel; M, N % 256 == 0, K % 64 == 0
+extern "C" int mh_gemm_w4(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
+                          mh_stream s) {
+    MH_REQUIRE(M > 0 && M % BIG == 0 && N % BIG == 0 && K % 64 == 0 && K >= 64 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 &&
+                   (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0),
+               "mh_gemm_w4: whole 256 x 256 x 64 tiles and 16-byte aligned rows (M=%d N=%d K=%d)", M, N, K);
+    GemmArgs a{};
+    a.A = A; a.B = B; a.C = C; a.bias = bias; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+    a.tiles_m = M / BIG; a.tiles_n = N / BIG; a.alpha = 1.f;
+    static const bool attr = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS), true);
+    (void)attr;
+    hipLaunchKernelGGL(gemm_w4_kernel, dim3(a.tiles_m * a.tiles_n), dim3(W4_NT), W4_LDS, (hipStream_t)s, a);
+    MH_LAUNCH_CHECK("mh_gemm_w4");
+    return MH_OK;
+}
 
 // tuning switch (tools/bench_gemm_pp.py A/B in one process): 2 = persistent ping-pong kernel (default), 1 = ping-pong kernel,
 // 0 = gemm_big_kernel; returns the old value

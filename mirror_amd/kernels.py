@@ -1432,6 +1432,17 @@ def dropout(x: torch.Tensor, p: float, seed: int, offset: int, out: Optional[tor
     return y
 
 
+def gemm_w4(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(experiment) bf16 [M, N] = a [M, K] @ w[N, K]^T + bias on the four-wave 256 x 256 tile kernel (mh_gemm_w4)."""
+    _chk(a, w, bias, out)
+    M, Kd = a.shape
+    N = w.shape[0]
+    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.stride(1) == 1 and w.stride(1) == 1 and w.shape[1] == Kd
+    y = out if out is not None else torch.empty((M, N), device=a.device, dtype=torch.bfloat16)
+    _lib.call("mh_gemm_w4", _p(a), _p(w), _p(y), _p(bias), M, N, Kd, a.stride(0), w.stride(0), y.stride(0), stream=_stream())
+    return y
+
+
 def noise_draws(n_uniform: int, n_normal: int, seed: int, offset: int, dev_base: Optional[torch.Tensor], device) -> torch.Tensor:
     """f32 [n_uniform + n_normal]: uniform [0, 1) then standard normal draws on the dropout stream (mh_noise_draws); n_uniform % 4 == 0."""
     _chk(dev_base)

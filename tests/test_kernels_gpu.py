@@ -1244,6 +1244,23 @@ def test_step_glue_rownorm_clamp_adam():
         K.adam(p2, gr.to(DEV), m2, v2, None, 2e-5, 0.9, 0.999, 1e-8, 0.1, 0.001, clamp=(5, 0.0, 1.0), hole=(4, 8))
 
 
+@pytest.mark.parametrize("M,N,Kd", [(512, 256, 64), (1024, 512, 512), (768, 1024, 1536)])
+def test_gemm_four_wave_experiment_is_bit_equal_to_mh_gemm(M, N, Kd):
+    """mh_gemm_w4 (round 5 experiment: the 256 x 256 x 64 tile on four waves with 128 x 128 wave tiles) computes the same bf16 products in
+    the same k order as the 8-wave kernels behind mh_gemm: the results must be bit-identical, with and without a bias."""
+    gen = g(M + Kd)
+    a = torch.randn(M, Kd, generator=gen).to(DEV, torch.bfloat16)
+    w = (torch.randn(N, Kd, generator=gen) * 0.05).to(DEV, torch.bfloat16)
+    b = torch.randn(N, generator=gen).to(DEV)
+    for bias in (None, b):
+        ref = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        K.gemm(a, w.t(), out=ref, bias=bias, mma=MH_BF16)
+        got = K.gemm_w4(a, w, bias)
+        assert torch.equal(got, ref), float((got.float() - ref.float()).abs().max())
+    with pytest.raises(K.MirrorHipError):
+        K.gemm_w4(a[:, :Kd - 32].contiguous(), w[:, :Kd - 32].contiguous())
+
+
 def test_noise_draws_one_launch_uniform_and_normal():
     """mh_noise_draws: uniform [0, 1) on 24 bits and Box-Muller normals from the Philox dropout stream — a pure function of
     (seed, offset + device base, element), the moments of the distributions they stand for (torch.rand / torch.randn at
