@@ -221,6 +221,17 @@ int mh_layernorm_bwd_fan(const void* dy, const void* x, const float* gamma, cons
                          void* dx, float* dgamma, float* dbeta, int batches, int rows_per_batch, int D, int64_t x_bs, int64_t y_bs,
                          int accumulate_dx, float* workspace, int64_t ws_floats, const void* fan_bf16, float fan_alpha,
                          const float* fan_cls, mh_stream s);
+/* mh_layernorm_bwd (optionally with mh_layernorm_bwd_fan's two extra gradients: fan_bf16 may be NULL) for a LayerNorm whose input x is the
+ * output of `resid + Dropout_p(Linear(core))` ([3P] to_out = Sequential(Linear, Dropout) and TransLayer's residual add,
+ * models/mirror.py:312): this launch's dx is that Dropout's upstream gradient, so drop_out [batches * rows, D] bf16 receives
+ * mask * dx / (1 - p) on the lite Philox stream (the masks mh_gemm_epi DROPADD drew for (seed, offset + *dev_base, element)) — the operand of
+ * to_out's two gradient products — and drop_db [D] += its column sums (to_out's bias gradient): mh_dropout_lite_colsum's pass over dx is
+ * not launched.  f32 x / dx; dy f32 or bf16 (f32 with fan); the workspace form with >= 3 D floats per block; D % 8 == 0, D <= 1024. */
+int mh_layernorm_bwd_drop(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                          void* dx, float* dgamma, float* dbeta, int batches, int rows_per_batch, int D, int64_t x_bs, int64_t y_bs,
+                          int dt_dy, int accumulate_dx, float* workspace, int64_t ws_floats, const void* fan_bf16, float fan_alpha,
+                          const float* fan_cls, void* drop_out, float drop_p, uint64_t drop_seed, uint64_t drop_offset,
+                          const uint64_t* drop_base, float* drop_db, mh_stream s);
 int mh_layernorm_bwd_lm(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                         void* dx, float* dgamma, float* dbeta, int batches, int rows_per_batch, int D, int64_t x_bs, int64_t y_bs,
                         int dt_x, int dt_dy, int dt_dx, int accumulate_dx, float* workspace, int64_t ws_floats,

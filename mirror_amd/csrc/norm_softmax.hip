@@ -492,7 +492,7 @@ extern "C" int mh_layernorm_fwd_q8(const float* x, const float* gamma, const flo
 // is a serial load -> reduce -> store chain: one row per wave left HBM at 1.8 TB/s), (b) 32-bit row arithmetic, and
 // (c) the per-block dgamma / dbeta partials go to ws[block][2][D] with plain stores — 2048 blocks adding into the same
 // 2 D addresses cost ~100 us of serialised atomics — and a second small kernel folds them.
-template <typename TX, typename TDY, int LNV_CH, bool RELU = false, bool FAN = false>
+template <typename TX, typename TDY, int LNV_CH, bool RELU = false, bool FAN = false, bool DROP = false>
 // D <= 512 (LNV_CH == 2): held to 4 waves per SIMD — at 130 registers instead of 128 the ReLU-fused instance lost a wave and 30 us
 __global__ __launch_bounds__(256, LNV_CH == 2 ? 4 : 1) void layernorm_bwd_ws_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x,
                                                                const float* __restrict__ gamma, const float* __restrict__ mean,
@@ -503,7 +503,14 @@ __global__ __launch_bounds__(256, LNV_CH == 2 ? 4 : 1) void layernorm_bwd_ws_ker
                                                                int ga_m = 0, float ga_scale = 0.f, bf16_t* __restrict__ relu_out = nullptr,
                                                                int relu_first = 0, int relu_rows = 0, int relu_cs = 0,
                                                                const bf16_t* __restrict__ fan = nullptr, float fan_alpha = 0.f,
-                                                               const float* __restrict__ fan_cls = nullptr) {
+                                                               const float* __restrict__ fan_cls = nullptr,
+                                                               bf16_t* __restrict__ drop_out = nullptr, float drop_p = 0.f, uint64_t drop_seed = 0,
+                                                               uint64_t drop_offset = 0, const uint64_t* __restrict__ drop_base = nullptr) {
+    // DROP (round 5): x is the output of `resid + Dropout_p(Linear(.))` ([3P] to_out = Sequential(Linear, Dropout) + TransLayer's residual
+    // add, models/mirror.py:312), so this launch's dx IS that Dropout's upstream gradient: drop_out [rows, D] bf16 receives
+    // mask * dx / (1 - p) on the lite Philox stream (element (row, c) = 16-bit field of block (offset + row D + c) >> 3: the masks of the
+    // forward epilogue), the operand of to_out's two gradient products, and a third partial row its column sums (to_out's bias
+    // gradient) — mh_dropout_lite_colsum's pass over dx (read 4 B, write 2 B per element) is not launched
     // FAN (round 5; the WSI encoder's final norm, whose output feeds the decoder, the retention target and the cls heads,
     // models/mirror.py:684-700): dy of row i >= 1 of batch b is dy + fan_alpha * fan[b, i - 1] (fan bf16 [batches, rpb - 1, D]: the
     // masked MSE's -dpred), of row 0 dy + fan_cls[b] (f32 [batches, D], may be null) — the sum mh_fanout_bwd would have written as a
@@ -519,21 +526,56 @@ __global__ __launch_bounds__(256, LNV_CH == 2 ? 4 : 1) void layernorm_bwd_ws_ker
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // RELU: a third running sum (pr) — its 8 registers would cost the instance its 4th wave per SIMD (measured: 129 us instead of 99), and
     // LDS atomics for it cost more still (256 us): gamma moves to LDS instead (read back per row, 2 x ds_read_b128) and pr takes its registers
-    __shared__ f4 sgm[RELU ? LNV_CH : 1][64];
-    f4 pg[LNV_CH], pb[LNV_CH], gm[RELU ? 1 : LNV_CH], pr[RELU ? LNV_CH : 1];
+    constexpr bool THIRD = RELU || DROP;        // a third running column sum: gamma is parked in LDS to make room for it
+    __shared__ f4 sgm[THIRD ? LNV_CH : 1][64];
+    f4 pg[LNV_CH], pb[LNV_CH], gm[THIRD ? 1 : LNV_CH], pr[THIRD ? LNV_CH : 1];
+    uint32_t dthr = 0;
+    float dscale = 1.f;
+    if constexpr (DROP) {
+        if (drop_base) drop_offset += *drop_base & ~7ull;
+        dthr = drop16_thr(drop_p);
+        dscale = drop16_scale(dthr);
+    }
 #pragma unroll
     for (int k = 0; k < LNV_CH; k++) {
         pg[k] = (f4){0.f, 0.f, 0.f, 0.f};
         pb[k] = pg[k];
-        if constexpr (RELU) pr[k] = pg[k];
+        if constexpr (THIRD) pr[k] = pg[k];
         const int c = 256 * k + 4 * lane;
-        if constexpr (RELU) {
+        if constexpr (THIRD) {
             if (wave == 0) sgm[k][lane] = (c < D) ? ld4(gamma + c) : pg[k];
         } else gm[k] = (c < D) ? ld4(gamma + c) : pg[k];
     }
-    if constexpr (RELU) __syncthreads();
+    if constexpr (THIRD) __syncthreads();
     const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
     for (int row = r0 + wave; row < r1; row += 8) {
+        // DROP: the keep bits of this iteration's quads depend on (row, column) alone: drawn in FRONT of the loads (under them the Philox
+        // state competed with 48 load-destination registers).  A Philox block serves 8 elements = the quads of lanes 2 j and 2 j + 1 of
+        // one (row, chunk): the even lane draws the blocks of row `row`, the odd lane those of row `row + 4`, and they swap (one DPP move)
+        // — every block drawn once, as in mh_dropout_lite_colsum (drawn by both lanes the integer multiplies made this launch as long as
+        // the two it replaces).  keepbits: one nibble per (u, k) quad of this lane.
+        uint32_t keepbits = 0;
+        if constexpr (DROP) {
+            static_assert(LNV_CH <= 4, "one byte per chunk in a 32-bit word");
+            const int odd = lane & 1;
+            const int rr = row + 4 * odd;
+            uint32_t mine = 0;
+            if (rr < r1) {
+#pragma unroll
+                for (int k = 0; k < LNV_CH; k++) {
+                    const int c8 = 256 * k + 8 * (lane >> 1);
+                    if (c8 < D) mine |= drop16_keep8((drop_offset + (uint64_t)((long)rr * D + c8)) >> 3, drop_seed, dthr) << (8 * k);
+                }
+            }
+            const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xF, 0xF, true);      // quad_perm [1, 0, 3, 2]
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const uint32_t src = (odd == u) ? mine : other;
+#pragma unroll
+                for (int k = 0; k < LNV_CH; k++) keepbits |= (((src >> (8 * k)) >> (4 * odd)) & 15u) << (4 * (u * LNV_CH + k));
+            }
+            asm volatile("" : "+v"(keepbits));
+        }
         f4 dv[2][LNV_CH], xv[2][LNV_CH], ov[2][LNV_CH];
         float mu[2], rs[2];
         long xo[2], ro[2];
@@ -545,7 +587,8 @@ __global__ __launch_bounds__(256, LNV_CH == 2 ? 4 : 1) void layernorm_bwd_ws_ker
             const int rc = ok[u] ? rr : row;
             const int b = rc / rpb, i = rc - b * rpb;
             xo[u] = b * x_bs + (long)i * D;
-            ro[u] = (RELU && i >= relu_first && i < relu_first + relu_rows) ? ((long)b * relu_rows + (i - relu_first)) * D : -1;
+            ro[u] = (RELU && i >= relu_first && i < relu_first + relu_rows) ? ((long)b * relu_rows + (i - relu_first)) * D
+                    : (DROP ? ((long)b * rpb + i) * D : -1);          // DROP: the row's first element in the [rows, D] output
             const TDY* dyr = dy + b * y_bs + (long)i * D;
             mu[u] = mean[rc];
             rs[u] = rstd[rc];
@@ -574,7 +617,7 @@ __global__ __launch_bounds__(256, LNV_CH == 2 ? 4 : 1) void layernorm_bwd_ws_ker
                 const int c = 256 * k + 4 * lane;
                 if (c < D) {
                     f4 gq;
-                    if constexpr (RELU) gq = sgm[k][lane]; else gq = gm[k];
+                    if constexpr (THIRD) gq = sgm[k][lane]; else gq = gm[k];
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
                         if constexpr (RELU) pos |= (xv[u][k][e] > 0.f ? 1u : 0u) << (4 * k + e);
@@ -600,7 +643,7 @@ __global__ __launch_bounds__(256, LNV_CH == 2 ? 4 : 1) void layernorm_bwd_ws_ker
 #pragma unroll
                     for (int e = 0; e < 4; e++) r[e] = rs[u] * (dv[u][k][e] - s1 - xv[u][k][e] * s2);
                     if (acc_dx) r += ov[u][k];
-                    if (RELU && ro[u] >= 0) {
+                    if (RELU && !DROP && ro[u] >= 0) {
                         typedef unsigned ln_u32x2 __attribute__((ext_vector_type(2)));
                         const ln_u32x2 w = {pack_bf2((pos >> (4 * k)) & 1u ? r[0] : 0.f, (pos >> (4 * k + 1)) & 1u ? r[1] : 0.f),
                                          pack_bf2((pos >> (4 * k + 2)) & 1u ? r[2] : 0.f, (pos >> (4 * k + 3)) & 1u ? r[3] : 0.f)};
@@ -609,13 +652,23 @@ __global__ __launch_bounds__(256, LNV_CH == 2 ? 4 : 1) void layernorm_bwd_ws_ker
                                       __uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xffff0000u)};
                     } else {
                         st4(dx + xo[u] + c, r);
+                        if constexpr (DROP) {
+                            typedef unsigned ln_u32x2d __attribute__((ext_vector_type(2)));
+                            const long e0 = ro[u] + c;
+                            const uint32_t keep = keepbits >> (4 * (u * LNV_CH + k));
+                            const ln_u32x2d w = {pack_bf2((keep & 1u) ? __fmul_rn(r[0], dscale) : 0.f, (keep & 2u) ? __fmul_rn(r[1], dscale) : 0.f),
+                                                 pack_bf2((keep & 4u) ? __fmul_rn(r[2], dscale) : 0.f, (keep & 8u) ? __fmul_rn(r[3], dscale) : 0.f)};
+                            *reinterpret_cast<ln_u32x2d*>(drop_out + e0) = w;
+                            pr[k] += (f4){__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xffff0000u),
+                                          __uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xffff0000u)};
+                        }
                     }
                 }
             }
         }
     }
-    __shared__ f4 red[RELU ? 3 : 2][4][64];
-    const int segs = (RELU && relu_cs) ? 3 : 2;
+    __shared__ f4 red[THIRD ? 3 : 2][4][64];
+    const int segs = ((RELU && relu_cs) || DROP) ? 3 : 2;
     float* wsb = ws + (long)blockIdx.x * segs * D;
 #pragma unroll
     for (int k = 0; k < LNV_CH; k++) {
@@ -623,15 +676,15 @@ __global__ __launch_bounds__(256, LNV_CH == 2 ? 4 : 1) void layernorm_bwd_ws_ker
         __syncthreads();
         red[0][wave][lane] = pg[k];
         red[1][wave][lane] = pb[k];
-        if constexpr (RELU) red[2][wave][lane] = pr[k];
+        if constexpr (THIRD) red[2][wave][lane] = pr[k];
         __syncthreads();
         if (wave == 0) {
             const int c = 256 * k + 4 * lane;
             if (c < D) {
                 *reinterpret_cast<f4*>(wsb + c) = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
                 *reinterpret_cast<f4*>(wsb + D + c) = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
-                if constexpr (RELU)
-                    if (relu_cs) *reinterpret_cast<f4*>(wsb + 2 * D + c) = red[2][0][lane] + red[2][1][lane] + red[2][2][lane] + red[2][3][lane];
+                if constexpr (THIRD)
+                    if (DROP || relu_cs) *reinterpret_cast<f4*>(wsb + 2 * D + c) = red[2][0][lane] + red[2][1][lane] + red[2][2][lane] + red[2][3][lane];
             }
         }
     }
@@ -697,7 +750,9 @@ static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const 
                        void* dx, float* dgamma, float* dbeta, int batches, int rpb, int D, int64_t x_bs,
                        int64_t y_bs, int dt_x, int dt_dy, int dt_dx, int acc_dx, float* workspace, int64_t ws_floats,
                        const void* gadd, int ga_pad, int ga_l, mh_stream s, void* relu_out = nullptr, int relu_first = 0, int relu_rows = 0,
-                       float* relu_db = nullptr, const void* fan = nullptr, float fan_alpha = 0.f, const float* fan_cls = nullptr);
+                       float* relu_db = nullptr, const void* fan = nullptr, float fan_alpha = 0.f, const float* fan_cls = nullptr,
+                       void* drop_out = nullptr, float drop_p = 0.f, uint64_t drop_seed = 0, uint64_t drop_offset = 0,
+                       const uint64_t* drop_base = nullptr, float* drop_db = nullptr);
 
 extern "C" int mh_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                 void* dx, float* dgamma, float* dbeta, int batches, int rpb, int D, int64_t x_bs,
@@ -734,11 +789,31 @@ extern "C" int mh_layernorm_bwd_fan(const void* dy, const void* x, const float* 
                        ws_floats, nullptr, 0, 1, s, nullptr, 0, 0, nullptr, fan_bf16, fan_alpha, fan_cls);
 }
 
+// mh_layernorm_bwd (optionally with mh_layernorm_bwd_fan's two extra gradients) for a LayerNorm whose input x is the output of
+// `resid + Dropout_p(Linear(core))`: drop_out [batches * rows, D] bf16 = dropout backward of this launch's dx on the lite stream,
+// drop_db [D] += its column sums.  f32 x / dx, dy f32 or bf16 (f32 with fan), the workspace form
+extern "C" int mh_layernorm_bwd_drop(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                     void* dx, float* dgamma, float* dbeta, int batches, int rpb, int D, int64_t x_bs,
+                                     int64_t y_bs, int dt_dy, int accumulate_dx, float* workspace, int64_t ws_floats,
+                                     const void* fan_bf16, float fan_alpha, const float* fan_cls,
+                                     void* drop_out, float drop_p, uint64_t drop_seed, uint64_t drop_offset, const uint64_t* drop_base,
+                                     float* drop_db, mh_stream s) {
+    MH_REQUIRE(drop_out && drop_db && drop_p >= 0.f && drop_p < 1.f && (drop_offset & 7) == 0 && ((uintptr_t)drop_out & 7) == 0 && D % 8 == 0 &&
+                   ((uintptr_t)workspace & 15) == 0 && ws_floats >= 3L * D,
+               "mh_layernorm_bwd_drop: drop_out / drop_db, p in [0, 1), offset %% 8 == 0, D %% 8 == 0, a workspace of >= 3 D floats");
+    MH_REQUIRE(!fan_bf16 || (rpb >= 2 && ((uintptr_t)fan_bf16 & 7) == 0 && (!fan_cls || ((uintptr_t)fan_cls & 15) == 0) && dt_dy == MH_F32),
+               "mh_layernorm_bwd_drop: fan [batches, rows - 1, D] bf16 on quads with f32 dy");
+    return ln_bwd_impl(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, batches, rpb, D, x_bs, y_bs, MH_F32, dt_dy, MH_F32, accumulate_dx, workspace,
+                       ws_floats, nullptr, 0, 1, s, nullptr, 0, 0, nullptr, fan_bf16, fan_alpha, fan_cls, drop_out, drop_p, drop_seed, drop_offset,
+                       drop_base, drop_db);
+}
+
 static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                        void* dx, float* dgamma, float* dbeta, int batches, int rpb, int D, int64_t x_bs,
                        int64_t y_bs, int dt_x, int dt_dy, int dt_dx, int acc_dx, float* workspace, int64_t ws_floats,
                        const void* gadd, int ga_pad, int ga_l, mh_stream s, void* relu_out, int relu_first, int relu_rows, float* relu_db,
-                       const void* fan, float fan_alpha, const float* fan_cls) {
+                       const void* fan, float fan_alpha, const float* fan_cls, void* drop_out, float drop_p, uint64_t drop_seed,
+                       uint64_t drop_offset, const uint64_t* drop_base, float* drop_db) {
     MH_REQUIRE(D >= 1 && D <= 64 * LN_MAXPL, "mh_layernorm_bwd: D=%d unsupported", D);
     MH_REQUIRE(dt_dx == dt_x, "mh_layernorm_bwd: dx dtype must equal x dtype");
     const long rows = (long)batches * rpb;
@@ -751,7 +826,8 @@ static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const 
 #define LN_BV(TX, TDY) do { if (D <= 512) LN_BV1(TX, TDY, 2); else if (D <= 1024) LN_BV1(TX, TDY, 4); else LN_BV1(TX, TDY, 8); } while (0)
     // workspace form: rows_per_block rows per block (a multiple of 8: two rows per wave per iteration), nb <= ws capacity
     if (vecok && workspace && ws_floats >= 2L * D && rows >= 64) {
-        const int segs = relu_db ? 3 : 2;       // partial rows per block: dgamma, dbeta (, the ReLU'd gradient's column sums)
+        const int segs = (relu_db || drop_out) ? 3 : 2;       // partial rows per block: dgamma, dbeta (, a bias gradient's column sums)
+        if (drop_out) relu_db = drop_db;                      // the fold's third destination
         const int relu_cs = relu_db ? 1 : 0;
         const long cap = ws_floats / ((long)segs * D);
         long nb = min(cap, min((long)mh_cdiv(rows, 16), 1024L));
@@ -761,6 +837,13 @@ static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const 
 #define LN_BW1(TX, TDY, NC, RL) hipLaunchKernelGGL((layernorm_bwd_ws_kernel<TX, TDY, NC, RL>), g2, dim3(256), 0, (hipStream_t)s, (const TDY*)dy, (const TX*)x, gamma, mean, rstd, (TX*)dx, workspace, (int)rows, rpb, D, (long)x_bs, (long)y_bs, acc_dx, rows_per_block, (const TDY*)gadd, ga_pad, ga_l, (ga_pad + rpb) / ga_l, 1.f / (float)ga_l, (bf16_t*)relu_out, relu_first, relu_rows, relu_cs)
 #define LN_BW(TX, TDY) do { if (D <= 512) LN_BW1(TX, TDY, 2, false); else if (D <= 1024) LN_BW1(TX, TDY, 4, false); else LN_BW1(TX, TDY, 8, false); } while (0)
 #define LN_BWF(NC) hipLaunchKernelGGL((layernorm_bwd_ws_kernel<float, float, NC, false, true>), g2, dim3(256), 0, (hipStream_t)s, (const float*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, workspace, (int)rows, rpb, D, (long)x_bs, (long)y_bs, acc_dx, rows_per_block, (const float*)nullptr, 0, 1, 0, 0.f, (bf16_t*)nullptr, 0, 0, 0, (const bf16_t*)fan, fan_alpha, fan_cls)
+#define LN_BWD_(TDY, NC, FN) hipLaunchKernelGGL((layernorm_bwd_ws_kernel<float, TDY, NC, false, FN, true>), g2, dim3(256), 0, (hipStream_t)s, (const TDY*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, workspace, (int)rows, rpb, D, (long)x_bs, (long)y_bs, acc_dx, rows_per_block, (const TDY*)nullptr, 0, 1, 0, 0.f, (bf16_t*)nullptr, 0, 0, 0, (const bf16_t*)fan, fan_alpha, fan_cls, (bf16_t*)drop_out, drop_p, drop_seed, drop_offset, drop_base)
+        if (drop_out) {         // to_out's Dropout backward + bias gradient inside this launch: instances of their own (f32 x)
+            MH_REQUIRE(dt_x == MH_F32 && D <= 1024 && (fan ? dt_dy == MH_F32 : true), "mh_layernorm_bwd_drop: f32 x, D <= 1024");
+            if (fan) { if (D <= 512) LN_BWD_(float, 2, true); else LN_BWD_(float, 4, true); }
+            else if (dt_dy == MH_F32) { if (D <= 512) LN_BWD_(float, 2, false); else LN_BWD_(float, 4, false); }
+            else { if (D <= 512) LN_BWD_(bf16_t, 2, false); else LN_BWD_(bf16_t, 4, false); }
+        } else
         if (fan) {              // the fanned-out form (f32 x, f32 dy) is an instance of its own too
             if (D <= 512) LN_BWF(2); else if (D <= 1024) LN_BWF(4); else LN_BWF(8);
         } else
@@ -771,6 +854,7 @@ static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const 
         else if (dt_x == MH_F32 && dt_dy == MH_BF16) LN_BW(float, bf16_t);
         else if (dt_x == MH_BF16 && dt_dy == MH_BF16) LN_BW(bf16_t, bf16_t);
         else LN_BW(bf16_t, float);
+#undef LN_BWD_
 #undef LN_BWF
 #undef LN_BW
 #undef LN_BW1
@@ -783,6 +867,7 @@ static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const 
         MH_LAUNCH_CHECK("mh_layernorm_bwd");
         return MH_OK;
     }
+    MH_REQUIRE(!drop_out, "mh_layernorm_bwd_drop: needs the workspace form (D %% 4 == 0, 16-byte aligned buffers, a workspace of >= 3 D floats, >= 64 rows)");
     MH_REQUIRE(!fan, "mh_layernorm_bwd_fan: needs the workspace form (D %% 4 == 0, 16-byte aligned buffers, a workspace of >= 2 D floats, >= 64 rows)");
     MH_REQUIRE(!gadd && !relu_out, "mh_layernorm_bwd_lm: needs the workspace form (D %% 4 == 0, 16-byte aligned buffers, a workspace of >= 2 D floats, >= 64 rows)");
     if (vecok) {

@@ -796,6 +796,21 @@ def _linear_rows_bwd(ctx_needs, x, wa, w, b, r0, R, prec, dy, dx_dtype=None, def
 
 
 _DROP_COLSUM = True      # (test hook)
+_DROP_IN_LN_BWD = True      # (test hook, round 5) to_out's Dropout backward + bias gradient inside the LayerNorm backward that produces its dy
+
+
+class _DropSite:
+    """Hand-over between ToOutDropAddFn and the LayerNorm that reads its output: the forward leaves the Dropout's stream coordinates, the
+    LayerNorm's backward (whose dx is the Dropout's upstream gradient) leaves grad = (data_ptr of that dx, masked bf16 gradient, its column
+    sums [N] f32) for ToOutDropAddFn.backward."""
+    __slots__ = ("p", "seed", "offset", "base", "shape", "grad")
+
+    def __init__(self, p, seed, offset, base, shape):
+        self.p, self.seed, self.offset, self.base, self.shape, self.grad = p, seed, offset, base, tuple(shape), None
+
+
+_drop_sites: dict = {}      # data_ptr of a ToOutDropAddFn output -> its _DropSite (cleared per forward)
+
 
 
 class ToOutDropAddFn(Function):
@@ -826,15 +841,33 @@ class ToOutDropAddFn(Function):
                                out=out.view(M, N)[M - tail:])
         ctx.save_for_backward(core, wa, w, b)
         ctx.r0, ctx.R, ctx.prec, ctx.res_key = r0, R, prec, resid.data_ptr()
+        ctx.site = None
+        if _DROP_IN_LN_BWD and b is not None:
+            ctx.site = _drop_sites[out.data_ptr()] = _DropSite(p, ctx.seed, ctx.offset, ctx.base, out.shape)
         return out
 
     @staticmethod
     def backward(ctx, dy):
         core, wa, w, b = ctx.saved_tensors
         dy = dy.contiguous()
-        gb = torch.empty(dy.shape, device=dy.device, dtype=ctx.prec.act)
         db_done, fused_db = None, False
-        if (_DROP_COLSUM and b is not None and ctx.needs_input_grad[3] and dy.dtype == f32 and gb.dtype == bf16
+        site, handed = ctx.site, None
+        if site is not None and site.grad is not None:
+            handed, site.grad = site.grad, None
+            if handed[0] != dy.data_ptr() or tuple(handed[1].shape) != tuple(dy.shape):
+                handed = None       # dy is not the LayerNorm's dx alone (another consumer's gradient was summed in): the plain pass below
+        if handed is not None:
+            # the LayerNorm backward that produced dy already wrote the masked bf16 gradient and its column sums (mh_layernorm_bwd_drop)
+            gb = handed[1]
+            if b is not None and ctx.needs_input_grad[3]:
+                dbuf, sunk = _gbuf(b, (dy.shape[-1],))
+                dbuf.add_(handed[2])
+                db_done, fused_db = _gret(b, dbuf, sunk), True
+        else:
+            gb = torch.empty(dy.shape, device=dy.device, dtype=ctx.prec.act)
+        if handed is not None:
+            pass
+        elif (_DROP_COLSUM and b is not None and ctx.needs_input_grad[3] and dy.dtype == f32 and gb.dtype == bf16
                 and K.dropout_lite_colsum_ok(dy.shape[-1])):
             # the same pass leaves the bias gradient (column sums of the masked bf16 gradient): no mh_colsum launch over it
             dbuf, sunk = _gbuf(b, (dy.shape[-1],))
@@ -1037,6 +1070,10 @@ class LayerNormFn(Function):
         Bn, T, D = x.shape
         y = torch.empty((Bn, pad + rows, D), device=x.device, dtype=out_dtype)
         ctx.fan_slot = fan_slot
+        # x = resid + Dropout(to_out(.)) of the TransLayer in front: this norm's dx is that Dropout's upstream gradient (see backward)
+        ctx.drop_site = _drop_sites.get(x.data_ptr()) if (_DROP_IN_LN_BWD and pad == 0 and rows == T and x.dtype == f32) else None
+        if ctx.drop_site is not None and ctx.drop_site.shape != (Bn, T, D):
+            ctx.drop_site = None
         if dual is not None:
             # f32 output + its bf16 copy in one pass (mh_layernorm_fwd_dual); the copy is handed over through `dual` (a
             # one-element list): it carries no gradient of its own, its consumers' gradients arrive through the f32 output
@@ -1097,7 +1134,14 @@ class LayerNormFn(Function):
                             accumulate_dx=True, fan=fan)
             return None, _gret(gamma, dg, sunk_g), _gret(beta, db, sunk_b), None, None, None, None, None, None, None
         dx = torch.zeros_like(x) if rows < T else torch.empty_like(x)
-        K.layernorm_bwd(dy[:, pad:], x, gamma.detach(), mean, rstd, dx, dg, db, Bn, rows, D, T * D, (pad + rows) * D, fan=fan)
+        site, drop = ctx.drop_site, None
+        if site is not None:
+            gbd = torch.empty((Bn, T, D), device=x.device, dtype=bf16)
+            cs = zeros((D,), x.device)
+            if K.layernorm_bwd_drop_ok(dy, x, dx, gbd, cs, Bn, rows, D, site.offset) and (fan is None or dy.dtype == f32):
+                drop = (gbd, site.p, site.seed, site.offset, site.base, cs)
+                site.grad = (dx.data_ptr(), gbd, cs)
+        K.layernorm_bwd(dy[:, pad:], x, gamma.detach(), mean, rstd, dx, dg, db, Bn, rows, D, T * D, (pad + rows) * D, fan=fan, drop=drop)
         return dx, _gret(gamma, dg, sunk_g), _gret(beta, db, sunk_b), None, None, None, None, None, None, None
 
 

@@ -609,13 +609,15 @@ def layernorm_fwd_q8(x, gamma, beta, y, mean, rstd, batches, rpb, D, x_bs, y_bs,
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, batches, rpb, D, x_bs, y_bs, accumulate_dx=False, gadd=None,
-                  pad: int = 0, l: int = 1, relu_out=None, relu_first: int = 0, relu_db=None, fan=None):
+                  pad: int = 0, l: int = 1, relu_out=None, relu_first: int = 0, relu_db=None, fan=None, drop=None):
     """gadd ([batches, (pad + rpb) / l, D], dy's dtype): the gradient of the landmark means layernorm_fwd_lm produced; every dy row also
     receives gadd[b, (i + pad) / l] / l (mh_layernorm_bwd_lm).  relu_out (bf16 [batches, R, D], with gadd only): rows [relu_first,
     relu_first + R) of x are a ReLU's output — their gradient leaves as bf16 (x > 0 ? dx : 0) in relu_out instead of f32 dx;
     relu_db (f32 [D], with relu_out): += the column sums of relu_out (the bias gradient of the Linear in front of the ReLU).
     fan = (src bf16 [batches, rpb - 1, D], alpha, cls f32 [batches, D] or None), without gadd: dy rows 1.. also receive alpha * src, row 0
-    cls (mh_layernorm_bwd_fan; layernorm_bwd_fan_ok says whether the shapes are on that form)."""
+    cls (mh_layernorm_bwd_fan; layernorm_bwd_fan_ok says whether the shapes are on that form).
+    drop = (out bf16 [batches, rpb, D], p, seed, offset, dev_base, db f32 [D]), without gadd: x is the output of resid + Dropout_p(Linear),
+    so out receives the lite-stream dropout backward of this launch's dx and db its column sums (mh_layernorm_bwd_drop)."""
     _chk(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, relu_out, relu_db)
     if relu_db is not None and (relu_out is None or relu_db.dtype != torch.float32 or relu_db.numel() != D or not relu_db.is_contiguous()):
         raise MirrorHipError("layernorm_bwd: relu_db is a contiguous f32 [D] and rides on relu_out")
@@ -636,6 +638,17 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, batches, rpb, D, 
                   ws.numel() if ws is not None else 0, _p(gadd), int(pad), int(l), _p(relu_out), int(relu_first),
                   0 if relu_out is None else int(relu_out.shape[1]), _p(relu_db), stream=_stream())
         return
+    if drop is not None:
+        dout, p_, seed_, off_, base_, ddb = drop
+        src, alpha, cls = fan if fan is not None else (None, 0.0, None)
+        _chk(dout, base_, ddb, src, cls)
+        if (gadd is not None or ws is None or not layernorm_bwd_drop_ok(dy, x, dx, dout, ddb, batches, rpb, D, off_)
+                or (fan is not None and not layernorm_bwd_fan_ok(dy, x, dx, src, cls, batches, rpb, D))):
+            raise MirrorHipError("layernorm_bwd: drop needs f32 x / dx, a contiguous bf16 [batches, rows, D] output, D % 8 == 0, D <= 1024, offset % 8 == 0, >= 64 rows")
+        _lib.call("mh_layernorm_bwd_drop", _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma), _p(dbeta),
+                  batches, rpb, D, x_bs, y_bs, dt(dy), int(accumulate_dx), _p(ws), ws.numel(), _p(src), float(alpha), _p(cls),
+                  _p(dout), float(p_), int(seed_), int(off_), _p(base_), _p(ddb), stream=_stream())
+        return
     if fan is not None:
         src, alpha, cls = fan
         _chk(src, cls)
@@ -647,6 +660,13 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, batches, rpb, D, 
     _lib.call("mh_layernorm_bwd", _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma), _p(dbeta),
               batches, rpb, D, x_bs, y_bs, dt(x), dt(dy), dt(dx), int(accumulate_dx), _p(ws) if ws is not None else 0,
               ws.numel() if ws is not None else 0, stream=_stream())
+
+
+def layernorm_bwd_drop_ok(dy, x, dx, dout, ddb, batches: int, rpb: int, D: int, offset: int) -> bool:
+    f = torch.float32
+    return (x.dtype == f and dx.dtype == f and dy.dtype in (f, torch.bfloat16) and dout.dtype == torch.bfloat16 and dout.is_contiguous()
+            and dout.numel() == batches * rpb * D and ddb.dtype == f and ddb.is_contiguous() and ddb.numel() == D and D % 8 == 0 and D <= 1024
+            and offset % 8 == 0 and batches * rpb >= 64 and all(t.data_ptr() % 16 == 0 for t in (dy, x, dx, dout)))
 
 
 def layernorm_bwd_fan_ok(dy, x, dx, src, cls, batches: int, rpb: int, D: int) -> bool:

@@ -534,6 +534,7 @@ class MIRROR(nn.Module):
         Fn._pending_lm_merge.clear()
         Fn._relu_rows.clear()
         Fn._relu_grads.clear()
+        Fn._drop_sites.clear()
         # the reference draws: rand(B,N) -> rand(B,D) -> eps_wsi -> eps_rna (models/mirror.py:630, :516, :832-833);
         # draw them up front in that order so the two encoders can then run on different streams
         B, dev = wsi_emb.shape[0], wsi_emb.device

@@ -436,7 +436,9 @@ def test_whole_model_round5_fusions_on_off(monkeypatch):
     window — other summation orders of the same bf16 products (losses identical: the forward does not change; cosine >= 0.999);
     (e) the three bias gradients left by the pass that wrote their dy (masked-MSE backward -> retention_head, mask/pos backward ->
     retention_embed, layer 1's LayerNorm backward -> _fc1) against mh_colsum over dy: the same stored values, another order;
-    (f) the fan-out sum of the encoder output's three gradients inside its LayerNorm's backward against mh_fanout_bwd in front of it."""
+    (f) the fan-out sum of the encoder output's three gradients inside its LayerNorm's backward against mh_fanout_bwd in front of it;
+    (g) to_out's Dropout backward + bias gradient inside the LayerNorm backward that produces its dy (the final norms of the encoder and
+    of the retention decoder) against mh_dropout_lite_colsum: bit-equal masked gradients, the bias gradients another summation order."""
     import mirror_amd.models as M
     from mirror_amd import functional as Fn
     from mirror_amd import kernels as K
@@ -468,7 +470,7 @@ def test_whole_model_round5_fusions_on_off(monkeypatch):
     for target, name, floor, exact_losses in ((Fn, "_RELU_IN_LN_BWD", 1.0, True), (Fn, "_RC_FUSED", 0.9999, True),
                                               (K, "NYS_A3_BWD_ONE_PASS", 0.999, True), (Fn, "_A1_DQ_IN_WINDOW", 0.999, True),
                                               (Fn, "_TO_OUT_WGRAD_IN_WINDOW", 0.999, True), (Fn, "_BIAS_IN_PRODUCER", 0.9999, True),
-                                              (Fn, "_FAN_IN_LN_BWD", 0.9999, True)):
+                                              (Fn, "_FAN_IN_LN_BWD", 0.9999, True), (Fn, "_DROP_IN_LN_BWD", 0.9999, True)):
         monkeypatch.setattr(target, name, False)
         l2, g2 = run()
         monkeypatch.setattr(target, name, True)

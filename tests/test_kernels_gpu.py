@@ -502,6 +502,42 @@ def test_layernorm_bwd_with_the_fanout_sum_inside(D, with_cls, acc):
         K.layernorm_bwd(gf.to(torch.bfloat16), x, gam, mean, rstd, dx1, dg1, db1, B, T, D, T * D, T * D, fan=(src, alpha, cls))
 
 
+@pytest.mark.parametrize("D,dy_dtype,with_fan", [(512, torch.float32, True), (512, torch.bfloat16, False), (1024, torch.float32, False)])
+def test_layernorm_bwd_with_to_outs_dropout_backward_inside(D, dy_dtype, with_fan):
+    """mh_layernorm_bwd_drop against mh_layernorm_bwd(_fan) + mh_dropout_lite_colsum: x is the output of resid + Dropout(to_out(.))
+    ([3P] to_out + TransLayer's residual, models/mirror.py:312), so the LayerNorm backward's dx is that Dropout's upstream gradient:
+    the masked bf16 gradient must be BIT-equal to the two-launch path's (same Philox block per element, same rounding), its column
+    sums equal up to summation order, dx / dgamma / dbeta untouched; the device base of a graphed step shifts the masks the same way."""
+    gen = g(D + 11)
+    B, T = 3, 67
+    x = (torch.randn(B, T, D, generator=gen) * 2 + 0.5).to(DEV)
+    gam, bet = torch.randn(D, generator=gen).to(DEV), torch.randn(D, generator=gen).to(DEV)
+    y = torch.empty((B, T, D), device=DEV)
+    mean, rstd = torch.empty(B * T, device=DEV), torch.empty(B * T, device=DEV)
+    K.layernorm_fwd(x, gam, bet, y, mean, rstd, B, T, D, T * D, T * D, 1e-5)
+    dy = torch.randn(B, T, D, generator=gen).to(DEV, dy_dtype)
+    fan = (torch.randn(B, T - 1, D, generator=gen).to(DEV, torch.bfloat16), -1.0, torch.randn(B, D, generator=gen).to(DEV)) if with_fan else None
+    p, seed, off = 0.1, 4242, 4096
+    for base in (None, torch.tensor([1000 * 8], device=DEV, dtype=torch.int64)):
+        dx0 = torch.empty_like(x)
+        dg0, db0 = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+        K.layernorm_bwd(dy, x, gam, mean, rstd, dx0, dg0, db0, B, T, D, T * D, T * D, fan=fan)
+        gb0, bias0 = torch.empty(B, T, D, device=DEV, dtype=torch.bfloat16), torch.full((D,), 0.5, device=DEV)
+        K.dropout_lite_colsum(dx0, p, seed, off, base, gb0, bias0)
+        dx1 = torch.empty_like(x)
+        dg1, db1 = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+        gb1, bias1 = torch.full((B, T, D), float("nan"), device=DEV, dtype=torch.bfloat16), torch.full((D,), 0.5, device=DEV)
+        assert K.layernorm_bwd_drop_ok(dy, x, dx1, gb1, bias1, B, T, D, off)
+        K.layernorm_bwd(dy, x, gam, mean, rstd, dx1, dg1, db1, B, T, D, T * D, T * D, fan=fan, drop=(gb1, p, seed, off, base, bias1))
+        assert torch.equal(dx1, dx0) and torch.equal(gb1, gb0)
+        assert 0.05 < float((gb1 == 0).float().mean()) < 0.15
+        close(dg1, dg0.cpu(), 1e-6, 1e-5, "dgamma")
+        close(db1, db0.cpu(), 1e-6, 1e-5, "dbeta")
+        close(bias1, bias0.cpu(), 1e-5, 1e-4, "to_out bias gradient")
+    with pytest.raises(K.MirrorHipError):
+        K.layernorm_bwd(dy, x, gam, mean, rstd, dx1, dg1, db1, B, T, D, T * D, T * D, drop=(gb1, p, seed, off + 4, None, bias1))
+
+
 def test_layernorm_bwd_lm_relu_rows_and_their_column_sums():
     """mh_layernorm_bwd_lm(relu_out, relu_db): rows 1 .. R of x are a ReLU's output — their gradient leaves as bf16 (x > 0 ? dx : 0) and
     relu_db receives the column sums of exactly those stored values (_fc1's bias gradient, models/mirror.py:346), the other outputs are

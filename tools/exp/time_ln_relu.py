@@ -48,6 +48,22 @@ if "fan" in inspect.signature(K.layernorm_bwd).parameters:
     print(f"; LN bwd with the fan-out inside: {timeit(lambda: K.layernorm_bwd(gf, x, gam, mean, rstd, dx, dg, db, B, T, D, T * D, T * D, fan=(src, -1.0, cls))):.1f} us")
 else:
     print()
+# dropout backward + bias gradient inside the LayerNorm backward
+if "drop" in inspect.signature(K.layernorm_bwd).parameters:
+    gbo = torch.empty(B, T, D, device=dev, dtype=torch.bfloat16); dbo = torch.zeros(D, device=dev)
+    def two():
+        K.layernorm_bwd(gf, x, gam, mean, rstd, dx, dg, db, B, T, D, T * D, T * D, fan=(src, -1.0, cls))
+        K.dropout_lite_colsum(dx, 0.1, 77, 64, None, gbo, dbo)
+    def one():
+        K.layernorm_bwd(gf, x, gam, mean, rstd, dx, dg, db, B, T, D, T * D, T * D, fan=(src, -1.0, cls), drop=(gbo, 0.1, 77, 64, None, dbo))
+    print(f"LN bwd (fan) + dropout_lite_colsum: {timeit(two):.1f} us; one launch: {timeit(one):.1f} us")
+    dyb = dy[:, pad:pad + T].contiguous()
+    def two_b():
+        K.layernorm_bwd(dyb, x, gam, mean, rstd, dx, dg, db, B, T, D, T * D, T * D)
+        K.dropout_lite_colsum(dx, 0.1, 77, 64, None, gbo, dbo)
+    def one_b():
+        K.layernorm_bwd(dyb, x, gam, mean, rstd, dx, dg, db, B, T, D, T * D, T * D, drop=(gbo, 0.1, 77, 64, None, dbo))
+    print(f"LN bwd (bf16 dy) + dropout_lite_colsum: {timeit(two_b):.1f} us; one launch: {timeit(one_b):.1f} us")
 # masked MSE backward
 pred = torch.randn(B, T - 1, D, device=dev, generator=g).to(torch.bfloat16); E = torch.randn(B, T, D, device=dev, generator=g)
 mask = (torch.rand(B, T - 1, device=dev, generator=g) < 0.75).float(); acc = torch.zeros(2, device=dev)
