@@ -213,20 +213,21 @@ int mh_layernorm_fwd_lm(const float* x, const float* gamma, const float* beta, v
                         void* xpm_bf16, int batches, int rows, int D, int64_t x_bs, int pad, int l, float eps, mh_stream s);
                         /* xpm_bf16 (optional): the bf16 rounding of xpm, the B operand of the landmark projection's weight gradient */
 /* mh_layernorm_bwd for a LayerNorm output that fans out (the WSI encoder's final norm: decoder input, retention target = rows 1..,
- * cls row; models/mirror.py:684-700, :833): f32 x / dy / dx; dy row i >= 1 of batch b also receives fan_alpha * fan_bf16[b, i - 1]
+ * cls row; models/mirror.py:684-700, :833): f32 x / dx, dy f32 or bf16 (dt_dy; round 5: the decoder's data gradient arrives in
+ * bf16, as under autocast); dy row i >= 1 of batch b also receives fan_alpha * fan_bf16[b, i - 1]
  * (fan_bf16 [batches, rows_per_batch - 1, D]: the masked MSE hands its target gradient over as -dpred) and row 0 fan_cls[b]
  * (f32 [batches, D], may be NULL) — the three-way sum mh_fanout_bwd writes is formed while this launch reads its operands.
  * Needs the workspace form (D % 4 == 0, 16-byte aligned buffers, >= 64 rows, mh_layernorm_bwd_workspace_bytes). */
 int mh_layernorm_bwd_fan(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                          void* dx, float* dgamma, float* dbeta, int batches, int rows_per_batch, int D, int64_t x_bs, int64_t y_bs,
-                         int accumulate_dx, float* workspace, int64_t ws_floats, const void* fan_bf16, float fan_alpha,
+                         int dt_dy, int accumulate_dx, float* workspace, int64_t ws_floats, const void* fan_bf16, float fan_alpha,
                          const float* fan_cls, mh_stream s);
 /* mh_layernorm_bwd (optionally with mh_layernorm_bwd_fan's two extra gradients: fan_bf16 may be NULL) for a LayerNorm whose input x is the
  * output of `resid + Dropout_p(Linear(core))` ([3P] to_out = Sequential(Linear, Dropout) and TransLayer's residual add,
  * models/mirror.py:312): this launch's dx is that Dropout's upstream gradient, so drop_out [batches * rows, D] bf16 receives
  * mask * dx / (1 - p) on the lite Philox stream (the masks mh_gemm_epi DROPADD drew for (seed, offset + *dev_base, element)) — the operand of
  * to_out's two gradient products — and drop_db [D] += its column sums (to_out's bias gradient): mh_dropout_lite_colsum's pass over dx is
- * not launched.  f32 x / dx; dy f32 or bf16 (f32 with fan); the workspace form with >= 3 D floats per block; D % 8 == 0, D <= 1024. */
+ * not launched.  f32 x / dx; dy f32 or bf16; the workspace form with >= 3 D floats per block; D % 8 == 0, D <= 1024. */
 int mh_layernorm_bwd_drop(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                           void* dx, float* dgamma, float* dbeta, int batches, int rows_per_batch, int D, int64_t x_bs, int64_t y_bs,
                           int dt_dy, int accumulate_dx, float* workspace, int64_t ws_floats, const void* fan_bf16, float fan_alpha,

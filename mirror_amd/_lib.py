@@ -102,7 +102,7 @@ _SIGS = {
     "mh_layernorm_fwd_dual": [P, P, P, P, P, P, P, I, I, I, L, L, F],
     "mh_layernorm_fwd_q8": [P, P, P, P, P, P, I, I, I, L, L, F, P, P, P, F, P],
     "mh_layernorm_bwd": [P, P, P, P, P, P, P, P, I, I, I, L, L, I, I, I, I, P, L],
-    "mh_layernorm_bwd_fan": [P, P, P, P, P, P, P, P, I, I, I, L, L, I, P, L, P, F, P],
+    "mh_layernorm_bwd_fan": [P, P, P, P, P, P, P, P, I, I, I, L, L, I, I, P, L, P, F, P],
     "mh_layernorm_bwd_drop": [P, P, P, P, P, P, P, P, I, I, I, L, L, I, I, P, L, P, F, P, P, F, U64, U64, P, P],
     "mh_layernorm_bwd_lm": [P, P, P, P, P, P, P, P, I, I, I, L, L, I, I, I, I, P, L, P, I, I, P, I, I, P],
     "mh_layernorm_fwd_lm": [P, P, P, P, P, P, P, P, I, I, I, L, I, I, F],

@@ -781,11 +781,11 @@ extern "C" int mh_layernorm_bwd_lm(const void* dy, const void* x, const float* g
 // workspace form with f32 x and f32 dy
 extern "C" int mh_layernorm_bwd_fan(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                     void* dx, float* dgamma, float* dbeta, int batches, int rpb, int D, int64_t x_bs,
-                                    int64_t y_bs, int accumulate_dx, float* workspace, int64_t ws_floats,
+                                    int64_t y_bs, int dt_dy, int accumulate_dx, float* workspace, int64_t ws_floats,
                                     const void* fan_bf16, float fan_alpha, const float* fan_cls, mh_stream s) {
     MH_REQUIRE(fan_bf16 && rpb >= 2 && ((uintptr_t)fan_bf16 & 7) == 0 && (!fan_cls || ((uintptr_t)fan_cls & 15) == 0) && D % 4 == 0,
                "mh_layernorm_bwd_fan: fan [batches, rows - 1, D] bf16 on quads, rows >= 2");
-    return ln_bwd_impl(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, batches, rpb, D, x_bs, y_bs, MH_F32, MH_F32, MH_F32, accumulate_dx, workspace,
+    return ln_bwd_impl(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, batches, rpb, D, x_bs, y_bs, MH_F32, dt_dy, MH_F32, accumulate_dx, workspace,
                        ws_floats, nullptr, 0, 1, s, nullptr, 0, 0, nullptr, fan_bf16, fan_alpha, fan_cls);
 }
 
@@ -801,8 +801,8 @@ extern "C" int mh_layernorm_bwd_drop(const void* dy, const void* x, const float*
     MH_REQUIRE(drop_out && drop_db && drop_p >= 0.f && drop_p < 1.f && (drop_offset & 7) == 0 && ((uintptr_t)drop_out & 7) == 0 && D % 8 == 0 &&
                    ((uintptr_t)workspace & 15) == 0 && ws_floats >= 3L * D,
                "mh_layernorm_bwd_drop: drop_out / drop_db, p in [0, 1), offset %% 8 == 0, D %% 8 == 0, a workspace of >= 3 D floats");
-    MH_REQUIRE(!fan_bf16 || (rpb >= 2 && ((uintptr_t)fan_bf16 & 7) == 0 && (!fan_cls || ((uintptr_t)fan_cls & 15) == 0) && dt_dy == MH_F32),
-               "mh_layernorm_bwd_drop: fan [batches, rows - 1, D] bf16 on quads with f32 dy");
+    MH_REQUIRE(!fan_bf16 || (rpb >= 2 && ((uintptr_t)fan_bf16 & 7) == 0 && (!fan_cls || ((uintptr_t)fan_cls & 15) == 0)),
+               "mh_layernorm_bwd_drop: fan [batches, rows - 1, D] bf16 on quads");
     return ln_bwd_impl(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, batches, rpb, D, x_bs, y_bs, MH_F32, dt_dy, MH_F32, accumulate_dx, workspace,
                        ws_floats, nullptr, 0, 1, s, nullptr, 0, 0, nullptr, fan_bf16, fan_alpha, fan_cls, drop_out, drop_p, drop_seed, drop_offset,
                        drop_base, drop_db);
@@ -836,11 +836,13 @@ static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const 
         dim3 g2((unsigned)nb);
 #define LN_BW1(TX, TDY, NC, RL) hipLaunchKernelGGL((layernorm_bwd_ws_kernel<TX, TDY, NC, RL>), g2, dim3(256), 0, (hipStream_t)s, (const TDY*)dy, (const TX*)x, gamma, mean, rstd, (TX*)dx, workspace, (int)rows, rpb, D, (long)x_bs, (long)y_bs, acc_dx, rows_per_block, (const TDY*)gadd, ga_pad, ga_l, (ga_pad + rpb) / ga_l, 1.f / (float)ga_l, (bf16_t*)relu_out, relu_first, relu_rows, relu_cs)
 #define LN_BW(TX, TDY) do { if (D <= 512) LN_BW1(TX, TDY, 2, false); else if (D <= 1024) LN_BW1(TX, TDY, 4, false); else LN_BW1(TX, TDY, 8, false); } while (0)
-#define LN_BWF(NC) hipLaunchKernelGGL((layernorm_bwd_ws_kernel<float, float, NC, false, true>), g2, dim3(256), 0, (hipStream_t)s, (const float*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, workspace, (int)rows, rpb, D, (long)x_bs, (long)y_bs, acc_dx, rows_per_block, (const float*)nullptr, 0, 1, 0, 0.f, (bf16_t*)nullptr, 0, 0, 0, (const bf16_t*)fan, fan_alpha, fan_cls)
+#define LN_BWF_(TDY, NC) hipLaunchKernelGGL((layernorm_bwd_ws_kernel<float, TDY, NC, false, true>), g2, dim3(256), 0, (hipStream_t)s, (const TDY*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, workspace, (int)rows, rpb, D, (long)x_bs, (long)y_bs, acc_dx, rows_per_block, (const TDY*)nullptr, 0, 1, 0, 0.f, (bf16_t*)nullptr, 0, 0, 0, (const bf16_t*)fan, fan_alpha, fan_cls)
+#define LN_BWF(NC) do { if (dt_dy == MH_F32) LN_BWF_(float, NC); else LN_BWF_(bf16_t, NC); } while (0)
 #define LN_BWD_(TDY, NC, FN) hipLaunchKernelGGL((layernorm_bwd_ws_kernel<float, TDY, NC, false, FN, true>), g2, dim3(256), 0, (hipStream_t)s, (const TDY*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, workspace, (int)rows, rpb, D, (long)x_bs, (long)y_bs, acc_dx, rows_per_block, (const TDY*)nullptr, 0, 1, 0, 0.f, (bf16_t*)nullptr, 0, 0, 0, (const bf16_t*)fan, fan_alpha, fan_cls, (bf16_t*)drop_out, drop_p, drop_seed, drop_offset, drop_base)
         if (drop_out) {         // to_out's Dropout backward + bias gradient inside this launch: instances of their own (f32 x)
-            MH_REQUIRE(dt_x == MH_F32 && D <= 1024 && (fan ? dt_dy == MH_F32 : true), "mh_layernorm_bwd_drop: f32 x, D <= 1024");
-            if (fan) { if (D <= 512) LN_BWD_(float, 2, true); else LN_BWD_(float, 4, true); }
+            MH_REQUIRE(dt_x == MH_F32 && D <= 1024, "mh_layernorm_bwd_drop: f32 x, D <= 1024");
+            if (fan && dt_dy == MH_F32) { if (D <= 512) LN_BWD_(float, 2, true); else LN_BWD_(float, 4, true); }
+            else if (fan) { if (D <= 512) LN_BWD_(bf16_t, 2, true); else LN_BWD_(bf16_t, 4, true); }
             else if (dt_dy == MH_F32) { if (D <= 512) LN_BWD_(float, 2, false); else LN_BWD_(float, 4, false); }
             else { if (D <= 512) LN_BWD_(bf16_t, 2, false); else LN_BWD_(bf16_t, 4, false); }
         } else
@@ -856,6 +858,7 @@ static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const 
         else LN_BW(bf16_t, float);
 #undef LN_BWD_
 #undef LN_BWF
+#undef LN_BWF_
 #undef LN_BW
 #undef LN_BW1
         if (D % 4 == 0 && ((uintptr_t)workspace & 15) == 0)

@@ -653,9 +653,9 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, batches, rpb, D, 
         src, alpha, cls = fan
         _chk(src, cls)
         if not layernorm_bwd_fan_ok(dy, x, dx, src, cls, batches, rpb, D) or ws is None:
-            raise MirrorHipError("layernorm_bwd: fan needs f32 x / dy / dx, a contiguous bf16 [batches, rows - 1, D] source and >= 64 rows")
+            raise MirrorHipError("layernorm_bwd: fan needs f32 x / dx, a contiguous bf16 [batches, rows - 1, D] source and >= 64 rows")
         _lib.call("mh_layernorm_bwd_fan", _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma), _p(dbeta),
-                  batches, rpb, D, x_bs, y_bs, int(accumulate_dx), _p(ws), ws.numel(), _p(src), float(alpha), _p(cls), stream=_stream())
+                  batches, rpb, D, x_bs, y_bs, dt(dy), int(accumulate_dx), _p(ws), ws.numel(), _p(src), float(alpha), _p(cls), stream=_stream())
         return
     _lib.call("mh_layernorm_bwd", _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma), _p(dbeta),
               batches, rpb, D, x_bs, y_bs, dt(x), dt(dy), dt(dx), int(accumulate_dx), _p(ws) if ws is not None else 0,
@@ -671,7 +671,7 @@ def layernorm_bwd_drop_ok(dy, x, dx, dout, ddb, batches: int, rpb: int, D: int, 
 
 def layernorm_bwd_fan_ok(dy, x, dx, src, cls, batches: int, rpb: int, D: int) -> bool:
     f = torch.float32
-    return (dy.dtype == f and x.dtype == f and dx.dtype == f and src.dtype == torch.bfloat16 and src.is_contiguous()
+    return (dy.dtype in (f, torch.bfloat16) and x.dtype == f and dx.dtype == f and src.dtype == torch.bfloat16 and src.is_contiguous()
             and src.numel() == batches * (rpb - 1) * D and rpb >= 2 and batches * rpb >= 64 and D % 4 == 0
             and (cls is None or (cls.dtype == f and cls.is_contiguous() and cls.numel() == batches * D and cls.data_ptr() % 16 == 0))
             and all(t.data_ptr() % 16 == 0 for t in (dy, x, dx)) and src.data_ptr() % 8 == 0)

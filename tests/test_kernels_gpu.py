@@ -498,8 +498,18 @@ def test_layernorm_bwd_with_the_fanout_sum_inside(D, with_cls, acc):
     close(dx1, dx0.cpu(), 1e-6, 1e-6, "dx with the fan-out inside")
     close(dg1, dg0.cpu(), 1e-6, 1e-5, "dgamma")
     close(db1, db0.cpu(), 1e-6, 1e-5, "dbeta")
+    # the decoder's data gradient arrives in bf16 (round 5): the same launch reads bf16 dy, against the f32 copy of those bf16 values
+    gfb = gf.to(torch.bfloat16)
+    dx2 = base.clone() if acc else torch.empty_like(x)
+    dg2, db2 = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    K.layernorm_bwd(gfb, x, gam, mean, rstd, dx2, dg2, db2, B, T, D, T * D, T * D, accumulate_dx=acc, fan=(src, alpha, cls))
+    dx3 = base.clone() if acc else torch.empty_like(x)
+    dg3, db3 = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    K.layernorm_bwd(gfb.float(), x, gam, mean, rstd, dx3, dg3, db3, B, T, D, T * D, T * D, accumulate_dx=acc, fan=(src, alpha, cls))
+    close(dx2, dx3.cpu(), 1e-6, 1e-6, "dx, bf16 dy")
+    close(dg2, dg3.cpu(), 1e-6, 1e-5, "dgamma, bf16 dy")
     with pytest.raises(K.MirrorHipError):       # off the form: loud
-        K.layernorm_bwd(gf.to(torch.bfloat16), x, gam, mean, rstd, dx1, dg1, db1, B, T, D, T * D, T * D, fan=(src, alpha, cls))
+        K.layernorm_bwd(gf, x, gam, mean, rstd, dx1, dg1, db1, B, T, D, T * D, T * D, fan=(src.float(), alpha, cls))
 
 
 @pytest.mark.parametrize("D,dy_dtype,with_fan", [(512, torch.float32, True), (512, torch.bfloat16, False), (1024, torch.float32, False)])

@@ -2,7 +2,7 @@
 set -o pipefail
 mkdir -p gpurun_out
 export PYTHONPATH=$PWD
-timeout -k 10 1000 python -m pytest tests/test_fused_epilogue_gpu.py tests/test_engine_gpu.py tests/test_model_gpu.py -x -q -k "round5 or graph_replay or to_out or train_mode or engine_step or bf16" > gpurun_out/r5aa_tests.log 2>&1; rc=$?; echo "tests rc=$rc"; tail -4 gpurun_out/r5aa_tests.log
+timeout -k 10 1000 python -m pytest tests/test_kernels_gpu.py tests/test_fused_epilogue_gpu.py tests/test_engine_gpu.py tests/test_model_gpu.py -x -q -k "round5 or graph_replay or to_out or train_mode or engine_step or bf16 or fanout or retention" > gpurun_out/r5ab_tests.log 2>&1; rc=$?; echo "tests rc=$rc"; tail -4 gpurun_out/r5ab_tests.log
 [ $rc -ne 0 ] && exit 1
-bash tools/exp/ab_flags_n.sh 6 functional._DROP_IN_LN_BWD=False 2>&1 | tee gpurun_out/r5aa_drop_ab.txt
-for v in "" "--off _DROP_IN_LN_BWD"; do echo "== probes $v"; MIRROR_PROBE=1 python3 tools/exp/probe_timeline.py $v 2>&1 | grep -v amdgpu | awk 'NR>1{printf "%s=%s ", $NF, $1}' | tr ' ' '\n' | grep -E "rna_enc_out.bwd|wsi_enc_out.bwd|side_bwd_end|fc1_out.bwd|adam" | tr '\n' ' '; echo; done | tee gpurun_out/r5aa_probes.txt
+bash tools/exp/ab_flags_n.sh 6 functional._DGRAD_BF16=False 2>&1 | tee gpurun_out/r5ab_drop_ab.txt
+for v in "" "--off _DGRAD_BF16"; do echo "== probes $v"; MIRROR_PROBE=1 python3 tools/exp/probe_timeline.py $v 2>&1 | grep -v amdgpu | awk 'NR>1{printf "%s=%s ", $NF, $1}' | tr ' ' '\n' | grep -E "rna_enc_out.bwd|wsi_enc_out.bwd|side_bwd_end|fc1_out.bwd|adam" | tr '\n' ' '; echo; done | tee gpurun_out/r5ab_probes.txt
