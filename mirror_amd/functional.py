@@ -1428,16 +1428,25 @@ def dropout_device_base_off() -> None:
     _dropout_state["base"] = None
 
 
+_NOISE_OFFSET = 1 << 44      # the noise draws' own range of the Philox counter space: far above any dropout offset of a step
+
+
 def noise_draws(B: int, N: int, D: int, L: int, device):
     """(rand [B, N], rand [B, D], randn [B, L], randn [B, L]) — the step's four draws (models/mirror.py:630, :516, :832-833) as ONE launch on
-    the dropout stream (mh_noise_draws; seed / running offset / per-step device base of manual_seed and dropout_step_begin): under a
-    captured step torch's generator costs four launches plus two state fills in front of every replay."""
+    the dropout stream's generator (mh_noise_draws; seed and per-step device base of manual_seed / dropout_step_begin): under a captured
+    step torch's generator costs four launches plus two state fills in front of every replay.  The draws live at a FIXED offset of their
+    own and take nothing from the running dropout offset — the RNA branch's HIP-graph replay has its dropout offsets baked in from 0
+    (graphed.py) and the draws are issued in front of it; what makes them differ from step to step is the device base, so the caller
+    advances the running offset by noise_draws_advance() at the END of its forward (a step without a single dropout site would otherwise
+    repeat its masks)."""
     n0, n1 = (B * N + 3) // 4 * 4, (B * D + 3) // 4 * 4
-    off = (_dropout_state["offset"] + 3) // 4 * 4
-    buf = K.noise_draws(n0 + n1, 2 * B * L, _dropout_state["seed"], off, _dropout_state["base"], device)
-    _dropout_state["offset"] = off + (n0 + n1 + 2 * B * L + 3) // 4 * 4
+    buf = K.noise_draws(n0 + n1, 2 * B * L, _dropout_state["seed"], _NOISE_OFFSET, _dropout_state["base"], device)
     e = n0 + n1
     return (buf[:B * N].view(B, N), buf[n0:n0 + B * D].view(B, D), buf[e:e + B * L].view(B, L), buf[e + B * L:e + 2 * B * L].view(B, L))
+
+
+def noise_draws_advance() -> None:
+    _dropout_state["offset"] = (_dropout_state["offset"] + 7) // 8 * 8 + 8
 
 
 def _lite_offset() -> int:

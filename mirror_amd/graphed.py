@@ -60,6 +60,7 @@ class GraphedBranch:
             a.shape == b.shape and a.dtype == b.dtype and a.device == b.device for a, b in zip(inputs, self.static_in))
 
     def __call__(self, *inputs: torch.Tensor):
+        self.replays = getattr(self, "replays", 0) + 1       # (tests: the branch must actually be replayed, not only recorded)
         return _GraphedFn.apply(self, self.anchor, *inputs)
 
 

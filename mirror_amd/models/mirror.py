@@ -546,8 +546,9 @@ class MIRROR(nn.Module):
         wsi_in, rna_in = wsi_emb, rna_emb
         # the reference draws them in this order: rand(B,N) -> rand(B,D) -> eps_wsi -> eps_rna.  None pinned (a training step): all four
         # come from ONE launch on the dropout stream, issued on the side stream that consumes them (round 5: as torch draws they were four
-        # launches in front of the WSI encoder's first GEMM plus two generator-state fills in front of every graph replay)
-        own_draws = _OWN_NOISE and _HEADS_SIDE and not any(k in noise for k in ("wsi_mask", "rna_mask", "wsi_eps", "rna_eps"))
+        # launches in front of the WSI encoder's first GEMM plus two generator-state fills in front of every graph replay).  Eval mode keeps
+        # torch's generator: validate() runs outside the step protocol that advances the dropout stream's device base
+        own_draws = _OWN_NOISE and _HEADS_SIDE and self.training and not any(k in noise for k in ("wsi_mask", "rna_mask", "wsi_eps", "rna_eps"))
         if not own_draws:
             if "wsi_mask" not in noise:
                 noise["wsi_mask"] = torch.rand(B, wsi_emb.shape[1], device=dev)
@@ -586,7 +587,7 @@ class MIRROR(nn.Module):
         # The dropout offsets stay those of the RNA-first order (the RNA branch's HIP-graph replay has them baked in, and the
         # masks do not depend on the launch order): the RNA range is reserved up front once its length is known.
         st = Fn._dropout_state
-        key = (tuple(rna_emb.shape), self.training, torch.is_grad_enabled(), rna_mask_ratio, own_draws, tuple(wsi_emb.shape[:2]))
+        key = (tuple(rna_emb.shape), self.training, torch.is_grad_enabled(), rna_mask_ratio)
         n_rna = self._rna_drop_n.get(key) if _RNA_LATE else None
         if n_rna is not None:
             off0 = st["offset"]
@@ -642,6 +643,8 @@ class MIRROR(nn.Module):
                   rna_score, rna_mu, rna_logstd, logit_scale):
             t.record_stream(main)       # allocated in a helper stream's pool, consumed on the main stream
         rna_retention_target = rna_emb
+        if own_draws:
+            Fn.noise_draws_advance()      # the next step's draws must differ even if this one had no dropout site (Fn.noise_draws)
         return (wsi_alignment_emb, wsi_retention_emb, wsi_retention_target, wsi_mask, wsi_score, wsi_mu, wsi_logstd,
                 rna_alignment_emb, rna_retention_emb, rna_retention_target, rna_mask, rna_score, rna_mu, rna_logstd,
                 logit_scale)

@@ -324,6 +324,9 @@ def test_rna_branch_graph_matches_eager_launch():
     eng_on, _, l_on = _run_eager(True, 6)
     assert eng_off._rna_branch_state == "off" and eng_on._rna_branch_state == "on"
     assert len(eng_on.model._rna_graph[0].params) > 20          # the RNA encoder's parameters are finished by the graph
+    # ... and the recorded branch is what the later steps RUN (round 5: noise draws that took dropout offsets in front of the branch
+    # silently sent every step down the eager branch — its offsets are baked in from 0)
+    assert getattr(eng_on.model._rna_graph[0], "replays", 0) >= 3
     # step 2 is the first replayed one: every parameter's gradient must be there when Adam reads the arena (the replay
     # runs on the RNA side stream) and equal the eager gradient up to the f32-atomics noise of the two earlier steps
     g_off, g_on = eng_off.grad_snaps[2], eng_on.grad_snaps[2]
