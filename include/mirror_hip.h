@@ -654,7 +654,8 @@ int mh_clamp_(float* x, int64_t n, float lo, float hi, mh_stream s);
  * One optimizer step as TWO launches (round 5: the RNA encoder's parameters, 80 % of the arena, have their gradients 2 ms before the
  * step's last one): tick = 0 reads dev_state without advancing it (the other launch of the step did), and elements [hole_lo, hole_hi)
  * (quad-aligned, not holding clamp_index) are left untouched — the range the other launch updates.  tick = 1, hole_lo = hole_hi = 0:
- * the whole arena in one launch, as before. */
+ * the whole arena in one launch, as before.  tick = 2: like 1, for the EARLY launch of such a pair (it runs as `adam_range_kernel`, so that
+ * profiling tools that cut a kernel trace into steps at `adam_kernel` keep working). */
 int mh_adam(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr, float beta1,
             float beta2, float eps, float bias_c1, float bias_c2, float grad_scale, float* dev_state, int64_t clamp_index,
             float clamp_lo, float clamp_hi, int64_t* counter, int64_t counter_add, int tick, int64_t hole_lo, int64_t hole_hi,

@@ -501,7 +501,7 @@ class TrainEngine:
                         lo, hi = early
                         K.adam(self.master[lo:hi], self.grad[lo:hi], self.m[lo:hi], self.v[lo:hi],
                                None if self.shadow is None else self.shadow[lo:hi], self.lr, b1, b2, self.eps, 1.0, 1.0,
-                               grad_scale=1.0, dev_state=self._state, tick=True)
+                               grad_scale=1.0, dev_state=self._state, tick="early")
         finally:
             Fn._wgrad_queue = None
             Fn.set_grad_sink(None)

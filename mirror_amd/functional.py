@@ -366,6 +366,9 @@ def _rows_window_ok(a3, out3, r0, R, N, prec) -> bool:
 
 
 _GEMM_WINDOW = True      # (test hook)
+_DEFER_QK = False     # (experiment hook, round 5) the sequence rows of q | k under the pinv chain with the v columns (one launch), only the
+                      # landmark rows in front of the fork: measured +0.61 % +- 0.17 SLOWER (the window grows by more than the 93 us it
+                      # takes out of the serial part: in-window GEMMs run on the non-persistent kernel beside the half-chip chain)
 
 
 def _wt_of(w, prec, dy):
@@ -1186,7 +1189,17 @@ class NormQkvLmFn(Function):
         qkv = _alias(qe, 0, (Bn, n_p, N3), (n_p * N3, N3, 1))
         fast = (pad > 0 and prec.mma == MH_BF16 and c0 % 256 == 0 and (N3 - c0) % 256 == 0
                 and K.gemm_rows_ext_ok(Bn, n_p, pad, rows, E, D, c0, xe, qe[:, :c0]) and _rows_window_ok(xs, qkv[..., c0:], pad, rows, N3 - c0, prec))
-        if fast:
+        if fast and _DEFER_QK and E % 256 == 0 and _rows_window_ok(xs, qkv, pad, rows, N3, prec):
+            # (round 5 experiment, off) only the LANDMARK rows of q | k are needed in front of the fork (sim2 and the pinv chain read nothing
+            # else): a [B m, D] x [D, 2D] product on 64 workgroups; the sequence rows of q, k AND v as one launch under the chain
+            K.gemm(xe[P:], wa[:c0].t(), out=qe[P:, :c0], mma=prec.mma)
+
+            def later():      # q = k = v = 0 on the pad rows (they take part in the softmaxes as zero keys)
+                fork = _tail_fork()
+                _rows_window(xs, wa.t(), qkv, pad, rows, mma=prec.mma)
+                with _tail_branch(fork, x.device):
+                    qkv[:, :pad].zero_()
+        elif fast:
             fork = _tail_fork()
             tail = K.gemm_rows_ext(xe, wa[:c0].t(), qe[:, :c0], Bn, n_p, pad, rows, E)
             if tail:

@@ -1766,7 +1766,7 @@ def adam(p, g, m, v, shadow, lr, b1, b2, eps, bc1, bc2, grad_scale=1.0, dev_stat
     corrections / lr live on the device (advanced by the launch itself), lr, bc1, bc2 are ignored and the gradient is
     also scaled by dev_state[4] (the factor grad_clip left there, else 1).  clamp = (index, lo, hi): that one parameter is clamped
     behind its update (master and shadow); counter (int64[1]) += counter_add in the same launches.  tick=False: dev_state is read,
-    not advanced; hole = (lo, hi): those elements are left alone (the other launch of a two-launch step updates them)."""
+    not advanced (tick="early": advanced, by the first launch of a two-launch step); hole = (lo, hi): those elements are left alone (the other launch of a two-launch step updates them)."""
     _chk(p, g, m, v, shadow, dev_state, counter)
     assert counter is None or (counter.dtype == torch.int64 and counter.numel() == 1)
     ci, clo, chi = (-1, 0.0, 0.0) if clamp is None else (int(clamp[0]), float(clamp[1]), float(clamp[2]))
@@ -1776,5 +1776,5 @@ def adam(p, g, m, v, shadow, lr, b1, b2, eps, bc1, bc2, grad_scale=1.0, dev_stat
         assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel()
     assert dev_state is None or (dev_state.dtype == torch.float32 and dev_state.numel() == 6 and dev_state.is_contiguous())
     _lib.call("mh_adam", _p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), lr, b1, b2, eps, bc1, bc2, grad_scale,
-              _p(dev_state), ci, clo, chi, _p(counter), int(counter_add), int(bool(tick)), *((0, 0) if hole is None else (int(hole[0]), int(hole[1]))),
+              _p(dev_state), ci, clo, chi, _p(counter), int(counter_add), 2 if tick == "early" else int(bool(tick)), *((0, 0) if hole is None else (int(hole[0]), int(hole[1]))),
               stream=_stream())

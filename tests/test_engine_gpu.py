@@ -466,7 +466,7 @@ def test_early_adam_for_the_rna_encoder_equals_the_single_launch(monkeypatch):
         losses = [[float(x) for x in eng.step(wsi, rna)] for _ in range(5)]
         assert eng._graph is not None and float(eng._state[0]) == 5.0
         if early:       # (eager steps before the capture + the capture itself: two launches each)
-            assert any(c == (hi - lo, True, None) for c in calls) and any(c == (eng.numel, False, (lo, hi)) for c in calls)
+            assert any(c == (hi - lo, "early", None) for c in calls) and any(c == (eng.numel, False, (lo, hi)) for c in calls)
         else:
             assert all(c[1] is True and c[2] is None and c[0] == eng.numel for c in calls)
         runs.append((losses, eng.master.clone(), eng.m.clone(), eng.v.clone(), init))

@@ -38,7 +38,8 @@ python3 $R/bench.py --batch 32 --no-cpu-baseline > $OUT/${TAG}_c2_bench_B32.json
 python3 $R/bench.py --feed host-bf16 --steps 20 --no-cpu-baseline > $OUT/${TAG}_c2_bench_feed_host_bf16.json 2>/dev/null
 python3 $R/bench.py --feed host --steps 20 --no-cpu-baseline > $OUT/${TAG}_c2_bench_feed_host_f32.json 2>/dev/null
 MIRROR_GRAPH=0 python3 $R/bench.py --no-cpu-baseline > $OUT/${TAG}_c2_bench_eager_rna_graph.json 2>/dev/null
-python3 $R/tools/run_c4.py --batch 8 --steps 12 2>/dev/null | tail -1 > $OUT/${TAG}_c4_run.json
+python3 $R/bench.py --config c4 --no-cpu-baseline > $OUT/${TAG}_c4_bench.json 2>/dev/null
+python3 $R/bench.py --config c4 --batch 16 --no-cpu-baseline > $OUT/${TAG}_c4_bench_B16.json 2>/dev/null
 (cd $R && bash tools/bench_world2_dryrun.sh) > $OUT/${TAG}_world2_gloo_dryrun.txt 2>&1
 python3 $R/tools/bench_rna.py 2>/dev/null | tail -3 > $OUT/${TAG}_rna_branch_alone.txt
 python3 $R/bench.py --precision fp8 --no-cpu-baseline > $OUT/${TAG}_c5_fp8_bench.json 2>/dev/null
