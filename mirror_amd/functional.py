@@ -808,11 +808,15 @@ class _DropSite:
     sums [N] f32) for ToOutDropAddFn.backward."""
     __slots__ = ("p", "seed", "offset", "base", "shape", "grad")
 
-    def __init__(self, p, seed, offset, base, shape):
-        self.p, self.seed, self.offset, self.base, self.shape, self.grad = p, seed, offset, base, tuple(shape), None
+    def __init__(self):
+        self.p = self.seed = self.offset = self.base = self.shape = self.grad = None
+
+    def fill(self, p, seed, offset, base, shape):
+        self.p, self.seed, self.offset, self.base, self.shape = p, seed, offset, base, tuple(shape)
 
 
-_drop_sites: dict = {}      # data_ptr of a ToOutDropAddFn output -> its _DropSite (cleared per forward)
+# (the site travels ON the output tensor — `out._drop_site`, read by LayerNormFn.forward — not in a table keyed by its address: a stale
+#  address entry could meet an unrelated tensor once the allocator recycles the block, ADVICE r4 on _pending_lm_merge)
 
 
 
@@ -824,7 +828,7 @@ class ToOutDropAddFn(Function):
     one mh_dropout draws for the same (seed, offset, element))."""
 
     @staticmethod
-    def forward(ctx, resid, core, w, b, r0, R, p, prec):
+    def forward(ctx, resid, core, w, b, r0, R, p, prec, site=None):
         wa = shadow(w, prec)
         Bn, _, Kd = core.shape
         N = wa.shape[0]
@@ -844,9 +848,9 @@ class ToOutDropAddFn(Function):
                                out=out.view(M, N)[M - tail:])
         ctx.save_for_backward(core, wa, w, b)
         ctx.r0, ctx.R, ctx.prec, ctx.res_key = r0, R, prec, resid.data_ptr()
-        ctx.site = None
-        if _DROP_IN_LN_BWD and b is not None:
-            ctx.site = _drop_sites[out.data_ptr()] = _DropSite(p, ctx.seed, ctx.offset, ctx.base, out.shape)
+        ctx.site = site
+        if site is not None:
+            site.fill(p, ctx.seed, ctx.offset, ctx.base, out.shape)
         return out
 
     @staticmethod
@@ -885,7 +889,7 @@ class ToOutDropAddFn(Function):
         dcore, dw, db = _linear_rows_bwd(needs, core, wa, w, b, ctx.r0, ctx.R, ctx.prec, gb, defer_wgrad=True)
         if fused_db:
             db = db_done
-        return dy, dcore, dw, db, None, None, None, None
+        return dy, dcore, dw, db, None, None, None, None, None
 
 
 def to_out_dropout_add(resid, core, w, b, r0: int, R: int, p: float, training: bool, prec: Precision):
@@ -893,7 +897,11 @@ def to_out_dropout_add(resid, core, w, b, r0: int, R: int, p: float, training: b
     if (training and p > 0.0 and prec.act == bf16 and not prec.fp8_fwd and resid.dtype == f32 and resid.is_contiguous()
             and core.dtype == bf16 and tuple(resid.shape) == (core.shape[0], R, w.shape[0]) and (core.shape[0] * R * w.shape[0]) % 8 == 0
             and K.linear_fused_ok(core, shadow(w, prec), (r0, R))):
-        return ToOutDropAddFn.apply(resid, core, w, b, r0, R, p, prec)
+        site = _DropSite() if (_DROP_IN_LN_BWD and b is not None) else None
+        out = ToOutDropAddFn.apply(resid, core, w, b, r0, R, p, prec, site)
+        if site is not None:
+            out._drop_site = site       # a LayerNorm that reads this tensor may do the Dropout's backward in its own (LayerNormFn)
+        return out
     y = LinearRowsFn.apply(core, w, b, r0, R, prec, prec.act)
     return dropout_add(resid, y, p, training, lite=True)
 
@@ -1074,7 +1082,7 @@ class LayerNormFn(Function):
         y = torch.empty((Bn, pad + rows, D), device=x.device, dtype=out_dtype)
         ctx.fan_slot = fan_slot
         # x = resid + Dropout(to_out(.)) of the TransLayer in front: this norm's dx is that Dropout's upstream gradient (see backward)
-        ctx.drop_site = _drop_sites.get(x.data_ptr()) if (_DROP_IN_LN_BWD and pad == 0 and rows == T and x.dtype == f32) else None
+        ctx.drop_site = getattr(x, "_drop_site", None) if (_DROP_IN_LN_BWD and pad == 0 and rows == T and x.dtype == f32) else None
         if ctx.drop_site is not None and ctx.drop_site.shape != (Bn, T, D):
             ctx.drop_site = None
         if dual is not None:
@@ -1173,6 +1181,7 @@ class NormQkvLmFn(Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, rows, pad, l, w, prec):
+        ctx.relu_slot = getattr(x, "_relu_slot", None)      # x is Fc1SeqFn's sequence (layer 1): see backward
         x = x.contiguous()
         Bn, T, D = x.shape
         n_p = pad + rows
@@ -1266,13 +1275,14 @@ class NormQkvLmFn(Function):
         if G is not None and G.numel() == x.numel() and G.dtype == x.dtype and G.is_contiguous():
             # x = Fc1SeqFn's sequence [cls | relu(_fc1(wsi))] (layer 1): the rows behind the cls row leave as the ReLU-masked bf16 gradient
             # _fc1's weight gradient multiplies (Fc1SeqFn.backward picks it up: no pass over x and dx of its own)
-            nrelu, fc1_b = _relu_rows.pop(x.data_ptr(), (None, None)) if _RELU_IN_LN_BWD else (None, None)
+            rslot = ctx.relu_slot if _RELU_IN_LN_BWD else None
+            nrelu, fc1_b = (rslot.n, rslot.bias) if (rslot is not None and rslot.n is not None) else (None, None)
             dh = rdb = None
             if nrelu is not None and x.dtype == f32 and prec.act == bf16 and rows == T == nrelu + 1 and ctx.needs_input_grad[0]:
                 dh = torch.empty((Bn, nrelu, D), device=x.device, dtype=bf16)
                 if fc1_b is not None and fc1_b.requires_grad and _BIAS_IN_PRODUCER:
                     rdb = _gbuf(fc1_b, (D,))      # _fc1's bias gradient = the column sums of dh: a third partial row of this launch
-                _relu_grads[G.data_ptr()] = (dh, rdb)
+                rslot.grad = (G.data_ptr(), dh, rdb)
             K.layernorm_bwd(dy[:, pad:], x, gamma.detach(), mean, rstd, G.view(x.shape), dg, db, Bn, rows, D, T * D, n_p * D,
                             accumulate_dx=True, gadd=gadd, pad=pad, l=l, relu_out=dh, relu_first=1, relu_db=None if rdb is None else rdb[0])
             dx = None
@@ -1308,8 +1318,14 @@ def ext_rows_of(dqkv, dlm, P: int, E: int, N3: int, c0: int, copy_lm: bool = Tru
 
 _LM_ROWS = True       # test hook (tests/test_fused_epilogue_gpu.py): False = the landmark kernels on q | k instead of NormQkvLmFn
 _RELU_IN_LN_BWD = True      # (test hook, round 5) _fc1's ReLU backward inside layer 1's LayerNorm backward
-_relu_rows: dict = {}       # data_ptr of an Fc1SeqFn output with no square-pad rows -> its token count N (rows 1 .. N are a ReLU's output)
-_relu_grads: dict = {}      # data_ptr of that sequence's f32 gradient buffer -> the bf16 ReLU-masked gradient layer 1's LayerNorm backward wrote
+class _ReluSlot:
+    """Hand-over between Fc1SeqFn and the LayerNorm + to_qkv node that reads its sequence (carried on the tensor: `seq._relu_slot`):
+    rows 1 .. n of the sequence are a ReLU's output; grad = (data_ptr of the sequence's f32 gradient buffer, the bf16 ReLU-masked gradient
+    layer 1's LayerNorm backward wrote, (bias-gradient buffer, came_from_sink) or None)."""
+    __slots__ = ("n", "bias", "grad")
+
+    def __init__(self):
+        self.n = self.bias = self.grad = None
 
 
 def layer_norm_landmarks_ok(x, rows: int, pad: int, l: int, prec: Precision) -> bool:
@@ -1557,7 +1573,7 @@ class Fc1SeqFn(Function):
     The GEMM epilogue (bias + ReLU) writes straight into rows 1..N of the f32 sequence buffer."""
 
     @staticmethod
-    def forward(ctx, wsi, w, b, cls, add_len, prec):
+    def forward(ctx, wsi, w, b, cls, add_len, prec, slot=None):
         Bn, N, Fd = wsi.shape
         D = w.shape[0]
         xa = wsi if wsi.dtype == prec.act else K.cast(wsi.contiguous(), prec.act)
@@ -1566,8 +1582,10 @@ class Fc1SeqFn(Function):
         if not (prec.fp8_fwd and xa.dtype == bf16 and _fp8_linear(xa, wa, b.detach(), ACT_RELU, seq[:, 1:1 + N])):
             K.gemm(xa, wa.t(), out=seq[:, 1:1 + N], bias=b.detach(), act=ACT_RELU, mma=prec.mma)
         K.seq_finish(seq, cls.detach().reshape(-1).contiguous(), N, add_len)
-        if add_len == 0 and prec.act == bf16:
-            _relu_rows[seq.data_ptr()] = (N, b)      # layer 1's LayerNorm backward may write the ReLU-masked gradient itself (NormQkvLmFn.backward)
+        ctx.slot = None
+        if slot is not None and add_len == 0 and prec.act == bf16:
+            slot.n, slot.bias = N, b      # layer 1's LayerNorm backward may write the ReLU-masked gradient itself (NormQkvLmFn.backward)
+            ctx.slot = slot
         ctx.save_for_backward(xa, wa, seq, w, b)
         ctx.add_len, ctx.prec, ctx.cls = add_len, prec, cls
         return seq
@@ -1581,7 +1599,11 @@ class Fc1SeqFn(Function):
         dseq = dseq.contiguous()
         # layer 1's LayerNorm backward already wrote relu'(x) * dx as bf16 (rows 1 .. N of dseq are then stale: only the cls row is read
         # below) and, with it, this Linear's bias gradient (the column sums of that tensor)
-        dh, db_have = _relu_grads.pop(dseq.data_ptr(), (None, None))
+        dh = db_have = None
+        if ctx.slot is not None and ctx.slot.grad is not None:
+            (gptr, gdh, gdb), ctx.slot.grad = ctx.slot.grad, None
+            if gptr == dseq.data_ptr():
+                dh, db_have = gdh, gdb
         if add_len:
             dseq = dseq.clone()  # the fold below is in place; autograd owns the incoming buffer
         dcls, sunk_c = _gbuf_n(ctx.cls, (D,))
@@ -1604,7 +1626,17 @@ class Fc1SeqFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = K.gemm(dh, wa, mma=prec.mma, out_dtype=f32)
-        return dx, dw, db, None if dcls is None else dcls.reshape(1, 1, D), None, None
+        return dx, dw, db, None if dcls is None else dcls.reshape(1, 1, D), None, None, None
+
+
+def fc1_seq(wsi, w, b, cls, add_len: int, prec: Precision):
+    """[cls | relu(_fc1(wsi)) | first add_len tokens again] (Fc1SeqFn); the sequence carries the slot through which layer 1's LayerNorm
+    backward hands the ReLU-masked gradient back."""
+    slot = _ReluSlot() if _RELU_IN_LN_BWD else None
+    seq = Fc1SeqFn.apply(wsi, w, b, cls, add_len, prec, slot)
+    if slot is not None and slot.n is not None:
+        seq._relu_slot = slot
+    return seq
 
 
 _PPEG_SCATTER = True      # (test hook)
@@ -2171,8 +2203,9 @@ def probe_point(x: torch.Tensor, name: str) -> torch.Tensor:
     if not (_PROBE and x.requires_grad):
         return x
     y = ProbeFn.apply(x, name)
-    if getattr(x, "_bf16", None) is not None:
-        y._bf16 = x._bf16
+    for attr in ("_bf16", "_relu_slot", "_drop_site", "_fan_slot"):      # hand-over slots that travel on the tensor
+        if getattr(x, attr, None) is not None:
+            setattr(y, attr, getattr(x, attr))
     return y
 
 

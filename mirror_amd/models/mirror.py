@@ -258,7 +258,7 @@ class FeatureTransMIL(nn.Module):
         n_tok = h.shape[1]
         side = int(np.ceil(np.sqrt(n_tok)))
         add = side * side - n_tok
-        seq = Fn.probe_point(Fn.Fc1SeqFn.apply(h, self._fc1[0].weight, self._fc1[0].bias, self.cls_token, add, prec), "wsi_fc1_out")
+        seq = Fn.probe_point(Fn.fc1_seq(h, self._fc1[0].weight, self._fc1[0].bias, self.cls_token, add, prec), "wsi_fc1_out")
         smask = None
         if mask is not None:
             mask = mask.to(h.device, torch.bool)
@@ -532,9 +532,6 @@ class MIRROR(nn.Module):
         Fn.K.shared_chip = False   # a forward that raised between a chain fork and its join must not leave the hint set
         Fn._deferred.clear()       # hand-over slots of a backward that never completed must not meet this step's tensors
         Fn._pending_lm_merge.clear()
-        Fn._relu_rows.clear()
-        Fn._relu_grads.clear()
-        Fn._drop_sites.clear()
         # the reference draws: rand(B,N) -> rand(B,D) -> eps_wsi -> eps_rna (models/mirror.py:630, :516, :832-833);
         # draw them up front in that order so the two encoders can then run on different streams
         B, dev = wsi_emb.shape[0], wsi_emb.device
