@@ -1832,7 +1832,9 @@ def pending_lm_merge_reset(where: str, strict: bool = False) -> None:
 _W2_ON_CHAIN = True      # (test hook) w2 = pinv (attn3 v) at the end of the chain's branch instead of behind the join (-0.22 % +- 0.06)
 _DZ_DAV = True      # (test hook)
 _RC_FUSED = True      # (test hook) res_conv inside attn3's forward launch, its two gradients as one pass over dout (round 5)
-_A1_DQ_IN_WINDOW = True      # (test hook, round 5) attn1's dq kernel beside the pinv chain's backward (-0.35 % +- 0.02)
+_A1_DQ_IN_WINDOW = False     # (test hook, round 5) attn1's dq kernel beside the pinv chain's backward: -0.35 % +- 0.02 when it was built, but
+                             # +0.80 % +- 0.20 (8 ABBA rounds) on the round's final tree — the one-pass attn3 backward and the other kernels that joined the
+                             # window since made its main side the longer one; dq stands in front of the fork again (profiles/r05_p_*)
 # (measured and deleted in round 4, see DESIGN.md section 6 round 3: nys_dz_dav on the chain's branch +0.32 %, attn3's delta out of
 #  nys_dz_dav +0.32 %, the chain branch joined in front of the landmark projection's backward +0.02 %, res_conv's weight gradient on
 #  the chain's stream +0.26 % or in front of the fork: neutral)
