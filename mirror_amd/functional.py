@@ -1133,8 +1133,8 @@ class LayerNormFn(Function):
         fan = None
         if ctx.fan_slot is not None and ctx.fan_slot.extra is not None:
             fan, ctx.fan_slot.extra = ctx.fan_slot.extra, None
-            if pad or rows != T or not K.layernorm_bwd_fan_ok(dy, x, x, fan[0], fan[2], Bn, rows, D):
-                dy, fan = K.fanout_bwd(dy.float(), fan[0], fan[1], fan[2], Bn, T, D), None
+            if pad or not K.layernorm_bwd_fan_ok(dy, x, x, fan[0], fan[2], Bn, rows, D):     # (rows < T is fine: x_bs carries the stride)
+                dy, fan = K.fanout_bwd(dy.float(), fan[0], fan[1], fan[2], Bn, rows, D), None
         # pre-norm residual block  x + f(LN(x)):  the residual add's backward ran first and left its gradient for x in
         # _res_grads; LN adds its own dx INTO that tensor (mh_layernorm_bwd accumulate_dx) instead of handing autograd a
         # second [B, T, D] f32 gradient to sum (a 400 MB elementwise pass per block)
@@ -1144,7 +1144,9 @@ class LayerNormFn(Function):
             K.layernorm_bwd(dy[:, pad:], x, gamma.detach(), mean, rstd, G, dg, db, Bn, rows, D, T * D, (pad + rows) * D,
                             accumulate_dx=True, fan=fan)
             return None, _gret(gamma, dg, sunk_g), _gret(beta, db, sunk_b), None, None, None, None, None, None, None
-        dx = torch.zeros_like(x) if rows < T else torch.empty_like(x)
+        dx = torch.empty_like(x)
+        if rows < T:
+            dx[:, rows:].zero_()         # only the rows the norm never read (a zeros_like of [B, T, D] is a 268 MB fill at config 4)
         site, drop = ctx.drop_site, None
         if site is not None:
             gbd = torch.empty((Bn, T, D), device=x.device, dtype=bf16)
@@ -1287,7 +1289,9 @@ class NormQkvLmFn(Function):
                             accumulate_dx=True, gadd=gadd, pad=pad, l=l, relu_out=dh, relu_first=1, relu_db=None if rdb is None else rdb[0])
             dx = None
         else:
-            dx = torch.zeros_like(x) if rows < T else torch.empty_like(x)
+            dx = torch.empty_like(x)
+            if rows < T:
+                dx[:, rows:].zero_()         # only the rows the norm never read (a zeros_like of [B, T, D] is a 268 MB fill at config 4)
             K.layernorm_bwd(dy[:, pad:], x, gamma.detach(), mean, rstd, dx, dg, db, Bn, rows, D, T * D, n_p * D, gadd=gadd, pad=pad, l=l)
         return dx, _gret(gamma, dg, sunk_g), _gret(beta, db, sunk_b), None, None, None, None, dw, None
 
@@ -1368,7 +1372,7 @@ def layer_norm(x, gamma, beta, eps, *, rows=None, pad=0, out_dtype=f32, q8_key=N
     if (bf16_copy and _LN_DUAL and not squeeze and x.dtype == f32 and out_dtype == f32 and pad == 0 and x.shape[-1] % 4 == 0
             and x.shape[-1] <= 2048 and q8_key is None):
         dual = []
-    slot = _FanSlot() if (_FAN_IN_LN_BWD and not squeeze and pad == 0 and out_dtype == f32 and x.dtype == f32 and r == x.shape[1]) else None
+    slot = _FanSlot() if (_FAN_IN_LN_BWD and not squeeze and pad == 0 and out_dtype == f32 and x.dtype == f32) else None
     y = LayerNormFn.apply(x, gamma, beta, eps, r, pad, out_dtype, q8_key, dual, slot)
     if dual:
         y._bf16 = dual[0]
