@@ -27,6 +27,38 @@ def test_library_exports_every_declared_symbol():
     assert lib.mh_version() == _lib.ABI_VERSION
 
 
+def test_binding_signatures_restate_the_header_argument_lists():
+    """mirror_amd/_lib.py restates every entry point's argument list by hand (_SIGS, ctypes has no header parser): a drifted list calls the
+    library with shifted arguments.  Parse include/mirror_hip.h and compare, position by position, the CLASS of every parameter (pointer,
+    int, int64, uint64, float) with the ctypes type of the binding, plus the trailing stream."""
+    import ctypes as C
+    header = open(os.path.join(ROOT, "include", "mirror_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    decls = re.findall(r"^(?:int|int64_t|const char\*|void)\s+(mh_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", header, flags=re.M | re.S)
+    assert len(decls) >= 100
+
+    def cls(param):
+        param = " ".join(param.split())
+        if "*" in param or param.startswith("mh_stream"):
+            return C.c_void_p
+        t = param.rsplit(" ", 1)[0].replace("const ", "").strip()
+        return {"int": C.c_int, "unsigned": C.c_int, "int64_t": C.c_int64, "uint64_t": C.c_uint64, "float": C.c_float}[t]
+
+    checked, bad = 0, []
+    for name, params in decls:
+        if name not in _lib._SIGS:
+            continue
+        want = [cls(q) for q in params.split(",") if q.strip() and q.strip() != "void"]
+        sig = list(_lib._SIGS[name])
+        if sig and isinstance(sig[0], type) and issubclass(sig[0], C._Pointer):      # descriptor entry points: (struct *, stream)
+            sig[0] = C.c_void_p
+        got = sig + [C.c_void_p]
+        checked += 1
+        if len(got) != len(want) or any(g is not w for g, w in zip(got, want)):
+            bad.append((name, [t.__name__ for t in got], [t.__name__ for t in want]))
+    assert checked >= 90 and not bad, bad[:3]
+
+
 def test_load_refuses_a_library_of_another_abi_generation(monkeypatch):
     """_SIGS restates the header's argument lists by hand, so a stale libmirror_hip.so (or one named by MIRROR_HIP_LIB)
     must be an error at load time, not shifted arguments at call time."""
