@@ -232,7 +232,9 @@ int mh_layernorm_bwd_drop(const void* dy, const void* x, const float* gamma, con
                           void* dx, float* dgamma, float* dbeta, int batches, int rows_per_batch, int D, int64_t x_bs, int64_t y_bs,
                           int dt_dy, int accumulate_dx, float* workspace, int64_t ws_floats, const void* fan_bf16, float fan_alpha,
                           const float* fan_cls, void* drop_out, float drop_p, uint64_t drop_seed, uint64_t drop_offset,
-                          const uint64_t* drop_base, float* drop_db, mh_stream s);
+                          const uint64_t* drop_base, float* drop_db, int drop_rows_per_batch, mh_stream s);
+                          /* drop_rows_per_batch >= rows_per_batch: rows per batch of the Dropout's tensor [batches, ., D] (drop_out has its
+                             shape); a norm over the first rows of a square-padded sequence leaves the rows behind them to the caller (zeros) */
 int mh_layernorm_bwd_lm(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                         void* dx, float* dgamma, float* dbeta, int batches, int rows_per_batch, int D, int64_t x_bs, int64_t y_bs,
                         int dt_x, int dt_dy, int dt_dx, int accumulate_dx, float* workspace, int64_t ws_floats,

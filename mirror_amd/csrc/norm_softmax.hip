@@ -505,12 +505,14 @@ __global__ __launch_bounds__(256, LNV_CH == 2 ? 4 : 1) void layernorm_bwd_ws_ker
                                                                const bf16_t* __restrict__ fan = nullptr, float fan_alpha = 0.f,
                                                                const float* __restrict__ fan_cls = nullptr,
                                                                bf16_t* __restrict__ drop_out = nullptr, float drop_p = 0.f, uint64_t drop_seed = 0,
-                                                               uint64_t drop_offset = 0, const uint64_t* __restrict__ drop_base = nullptr) {
+                                                               uint64_t drop_offset = 0, const uint64_t* __restrict__ drop_base = nullptr,
+                                                               int drop_rpb = 0) {
     // DROP (round 5): x is the output of `resid + Dropout_p(Linear(.))` ([3P] to_out = Sequential(Linear, Dropout) + TransLayer's residual
     // add, models/mirror.py:312), so this launch's dx IS that Dropout's upstream gradient: drop_out [rows, D] bf16 receives
     // mask * dx / (1 - p) on the lite Philox stream (element (row, c) = 16-bit field of block (offset + row D + c) >> 3: the masks of the
     // forward epilogue), the operand of to_out's two gradient products, and a third partial row its column sums (to_out's bias
-    // gradient) — mh_dropout_lite_colsum's pass over dx (read 4 B, write 2 B per element) is not launched
+    // gradient) — mh_dropout_lite_colsum's pass over dx (read 4 B, write 2 B per element) is not launched.  drop_rpb >= rpb: rows per batch of
+    // the Dropout's tensor (the norm may read only the first rpb of them: square-padded sequences; the caller zero-fills the rest)
     // FAN (round 5; the WSI encoder's final norm, whose output feeds the decoder, the retention target and the cls heads,
     // models/mirror.py:684-700): dy of row i >= 1 of batch b is dy + fan_alpha * fan[b, i - 1] (fan bf16 [batches, rpb - 1, D]: the
     // masked MSE's -dpred), of row 0 dy + fan_cls[b] (f32 [batches, D], may be null) — the sum mh_fanout_bwd would have written as a
@@ -561,10 +563,11 @@ __global__ __launch_bounds__(256, LNV_CH == 2 ? 4 : 1) void layernorm_bwd_ws_ker
             const int rr = row + 4 * odd;
             uint32_t mine = 0;
             if (rr < r1) {
+                const long orow = drop_rpb == rpb ? (long)rr : (long)(rr / rpb) * drop_rpb + (rr % rpb);       // its row in the Dropout's tensor
 #pragma unroll
                 for (int k = 0; k < LNV_CH; k++) {
                     const int c8 = 256 * k + 8 * (lane >> 1);
-                    if (c8 < D) mine |= drop16_keep8((drop_offset + (uint64_t)((long)rr * D + c8)) >> 3, drop_seed, dthr) << (8 * k);
+                    if (c8 < D) mine |= drop16_keep8((drop_offset + (uint64_t)(orow * D + c8)) >> 3, drop_seed, dthr) << (8 * k);
                 }
             }
             const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xF, 0xF, true);      // quad_perm [1, 0, 3, 2]
@@ -588,7 +591,7 @@ __global__ __launch_bounds__(256, LNV_CH == 2 ? 4 : 1) void layernorm_bwd_ws_ker
             const int b = rc / rpb, i = rc - b * rpb;
             xo[u] = b * x_bs + (long)i * D;
             ro[u] = (RELU && i >= relu_first && i < relu_first + relu_rows) ? ((long)b * relu_rows + (i - relu_first)) * D
-                    : (DROP ? ((long)b * rpb + i) * D : -1);          // DROP: the row's first element in the [rows, D] output
+                    : (DROP ? ((long)b * drop_rpb + i) * D : -1);     // DROP: the row's first element in the Dropout's [batches, drop_rpb, D] tensor
             const TDY* dyr = dy + b * y_bs + (long)i * D;
             mu[u] = mean[rc];
             rs[u] = rstd[rc];
@@ -752,7 +755,7 @@ static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const 
                        const void* gadd, int ga_pad, int ga_l, mh_stream s, void* relu_out = nullptr, int relu_first = 0, int relu_rows = 0,
                        float* relu_db = nullptr, const void* fan = nullptr, float fan_alpha = 0.f, const float* fan_cls = nullptr,
                        void* drop_out = nullptr, float drop_p = 0.f, uint64_t drop_seed = 0, uint64_t drop_offset = 0,
-                       const uint64_t* drop_base = nullptr, float* drop_db = nullptr);
+                       const uint64_t* drop_base = nullptr, float* drop_db = nullptr, int drop_rpb = 0);
 
 extern "C" int mh_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                 void* dx, float* dgamma, float* dbeta, int batches, int rpb, int D, int64_t x_bs,
@@ -797,7 +800,8 @@ extern "C" int mh_layernorm_bwd_drop(const void* dy, const void* x, const float*
                                      int64_t y_bs, int dt_dy, int accumulate_dx, float* workspace, int64_t ws_floats,
                                      const void* fan_bf16, float fan_alpha, const float* fan_cls,
                                      void* drop_out, float drop_p, uint64_t drop_seed, uint64_t drop_offset, const uint64_t* drop_base,
-                                     float* drop_db, mh_stream s) {
+                                     float* drop_db, int drop_rows_per_batch, mh_stream s) {
+    MH_REQUIRE(drop_rows_per_batch >= rpb, "mh_layernorm_bwd_drop: the Dropout's tensor has %d rows per batch, the norm reads %d", drop_rows_per_batch, rpb);
     MH_REQUIRE(drop_out && drop_db && drop_p >= 0.f && drop_p < 1.f && (drop_offset & 7) == 0 && ((uintptr_t)drop_out & 7) == 0 && D % 8 == 0 &&
                    ((uintptr_t)workspace & 15) == 0 && ws_floats >= 3L * D,
                "mh_layernorm_bwd_drop: drop_out / drop_db, p in [0, 1), offset %% 8 == 0, D %% 8 == 0, a workspace of >= 3 D floats");
@@ -805,7 +809,7 @@ extern "C" int mh_layernorm_bwd_drop(const void* dy, const void* x, const float*
                "mh_layernorm_bwd_drop: fan [batches, rows - 1, D] bf16 on quads");
     return ln_bwd_impl(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, batches, rpb, D, x_bs, y_bs, MH_F32, dt_dy, MH_F32, accumulate_dx, workspace,
                        ws_floats, nullptr, 0, 1, s, nullptr, 0, 0, nullptr, fan_bf16, fan_alpha, fan_cls, drop_out, drop_p, drop_seed, drop_offset,
-                       drop_base, drop_db);
+                       drop_base, drop_db, drop_rows_per_batch);
 }
 
 static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
@@ -813,7 +817,7 @@ static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const 
                        int64_t y_bs, int dt_x, int dt_dy, int dt_dx, int acc_dx, float* workspace, int64_t ws_floats,
                        const void* gadd, int ga_pad, int ga_l, mh_stream s, void* relu_out, int relu_first, int relu_rows, float* relu_db,
                        const void* fan, float fan_alpha, const float* fan_cls, void* drop_out, float drop_p, uint64_t drop_seed,
-                       uint64_t drop_offset, const uint64_t* drop_base, float* drop_db) {
+                       uint64_t drop_offset, const uint64_t* drop_base, float* drop_db, int drop_rpb) {
     MH_REQUIRE(D >= 1 && D <= 64 * LN_MAXPL, "mh_layernorm_bwd: D=%d unsupported", D);
     MH_REQUIRE(dt_dx == dt_x, "mh_layernorm_bwd: dx dtype must equal x dtype");
     const long rows = (long)batches * rpb;
@@ -838,7 +842,7 @@ static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const 
 #define LN_BW(TX, TDY) do { if (D <= 512) LN_BW1(TX, TDY, 2, false); else if (D <= 1024) LN_BW1(TX, TDY, 4, false); else LN_BW1(TX, TDY, 8, false); } while (0)
 #define LN_BWF_(TDY, NC) hipLaunchKernelGGL((layernorm_bwd_ws_kernel<float, TDY, NC, false, true>), g2, dim3(256), 0, (hipStream_t)s, (const TDY*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, workspace, (int)rows, rpb, D, (long)x_bs, (long)y_bs, acc_dx, rows_per_block, (const TDY*)nullptr, 0, 1, 0, 0.f, (bf16_t*)nullptr, 0, 0, 0, (const bf16_t*)fan, fan_alpha, fan_cls)
 #define LN_BWF(NC) do { if (dt_dy == MH_F32) LN_BWF_(float, NC); else LN_BWF_(bf16_t, NC); } while (0)
-#define LN_BWD_(TDY, NC, FN) hipLaunchKernelGGL((layernorm_bwd_ws_kernel<float, TDY, NC, false, FN, true>), g2, dim3(256), 0, (hipStream_t)s, (const TDY*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, workspace, (int)rows, rpb, D, (long)x_bs, (long)y_bs, acc_dx, rows_per_block, (const TDY*)nullptr, 0, 1, 0, 0.f, (bf16_t*)nullptr, 0, 0, 0, (const bf16_t*)fan, fan_alpha, fan_cls, (bf16_t*)drop_out, drop_p, drop_seed, drop_offset, drop_base)
+#define LN_BWD_(TDY, NC, FN) hipLaunchKernelGGL((layernorm_bwd_ws_kernel<float, TDY, NC, false, FN, true>), g2, dim3(256), 0, (hipStream_t)s, (const TDY*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, workspace, (int)rows, rpb, D, (long)x_bs, (long)y_bs, acc_dx, rows_per_block, (const TDY*)nullptr, 0, 1, 0, 0.f, (bf16_t*)nullptr, 0, 0, 0, (const bf16_t*)fan, fan_alpha, fan_cls, (bf16_t*)drop_out, drop_p, drop_seed, drop_offset, drop_base, drop_rpb)
         if (drop_out) {         // to_out's Dropout backward + bias gradient inside this launch: instances of their own (f32 x)
             MH_REQUIRE(dt_x == MH_F32 && D <= 1024, "mh_layernorm_bwd_drop: f32 x, D <= 1024");
             if (fan && dt_dy == MH_F32) { if (D <= 512) LN_BWD_(float, 2, true); else LN_BWD_(float, 4, true); }

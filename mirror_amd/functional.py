@@ -1082,7 +1082,7 @@ class LayerNormFn(Function):
         y = torch.empty((Bn, pad + rows, D), device=x.device, dtype=out_dtype)
         ctx.fan_slot = fan_slot
         # x = resid + Dropout(to_out(.)) of the TransLayer in front: this norm's dx is that Dropout's upstream gradient (see backward)
-        ctx.drop_site = getattr(x, "_drop_site", None) if (_DROP_IN_LN_BWD and pad == 0 and rows == T and x.dtype == f32) else None
+        ctx.drop_site = getattr(x, "_drop_site", None) if (_DROP_IN_LN_BWD and pad == 0 and x.dtype == f32) else None
         if ctx.drop_site is not None and ctx.drop_site.shape != (Bn, T, D):
             ctx.drop_site = None
         if dual is not None:
@@ -1152,6 +1152,8 @@ class LayerNormFn(Function):
             gbd = torch.empty((Bn, T, D), device=x.device, dtype=bf16)
             cs = zeros((D,), x.device)
             if K.layernorm_bwd_drop_ok(dy, x, dx, gbd, cs, Bn, rows, D, site.offset) and (fan is None or dy.dtype == f32):
+                if rows < T:
+                    gbd[:, rows:].zero_()        # rows the norm never read: their gradient (and its Dropout backward) is zero
                 drop = (gbd, site.p, site.seed, site.offset, site.base, cs)
                 site.grad = (dx.data_ptr(), gbd, cs)
         K.layernorm_bwd(dy[:, pad:], x, gamma.detach(), mean, rstd, dx, dg, db, Bn, rows, D, T * D, (pad + rows) * D, fan=fan, drop=drop)

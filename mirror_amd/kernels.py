@@ -616,7 +616,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, batches, rpb, D, 
     relu_db (f32 [D], with relu_out): += the column sums of relu_out (the bias gradient of the Linear in front of the ReLU).
     fan = (src bf16 [batches, rpb - 1, D], alpha, cls f32 [batches, D] or None), without gadd: dy rows 1.. also receive alpha * src, row 0
     cls (mh_layernorm_bwd_fan; layernorm_bwd_fan_ok says whether the shapes are on that form).
-    drop = (out bf16 [batches, rpb, D], p, seed, offset, dev_base, db f32 [D]), without gadd: x is the output of resid + Dropout_p(Linear),
+    drop = (out bf16 [batches, >= rpb, D] (the Dropout's tensor; rows past rpb are the caller's), p, seed, offset, dev_base, db f32 [D]), without gadd: x is the output of resid + Dropout_p(Linear),
     so out receives the lite-stream dropout backward of this launch's dx and db its column sums (mh_layernorm_bwd_drop)."""
     _chk(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, relu_out, relu_db)
     if relu_db is not None and (relu_out is None or relu_db.dtype != torch.float32 or relu_db.numel() != D or not relu_db.is_contiguous()):
@@ -647,7 +647,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, batches, rpb, D, 
             raise MirrorHipError("layernorm_bwd: drop needs f32 x / dx, a contiguous bf16 [batches, rows, D] output, D % 8 == 0, D <= 1024, offset % 8 == 0, >= 64 rows")
         _lib.call("mh_layernorm_bwd_drop", _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma), _p(dbeta),
                   batches, rpb, D, x_bs, y_bs, dt(dy), int(accumulate_dx), _p(ws), ws.numel(), _p(src), float(alpha), _p(cls),
-                  _p(dout), float(p_), int(seed_), int(off_), _p(base_), _p(ddb), stream=_stream())
+                  _p(dout), float(p_), int(seed_), int(off_), _p(base_), _p(ddb), int(dout.shape[1]), stream=_stream())
         return
     if fan is not None:
         src, alpha, cls = fan
@@ -665,7 +665,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, batches, rpb, D, 
 def layernorm_bwd_drop_ok(dy, x, dx, dout, ddb, batches: int, rpb: int, D: int, offset: int) -> bool:
     f = torch.float32
     return (x.dtype == f and dx.dtype == f and dy.dtype in (f, torch.bfloat16) and dout.dtype == torch.bfloat16 and dout.is_contiguous()
-            and dout.numel() == batches * rpb * D and ddb.dtype == f and ddb.is_contiguous() and ddb.numel() == D and D % 8 == 0 and D <= 1024
+            and dout.dim() == 3 and dout.shape[0] == batches and dout.shape[1] >= rpb and dout.shape[2] == D and ddb.dtype == f and ddb.is_contiguous() and ddb.numel() == D and D % 8 == 0 and D <= 1024
             and offset % 8 == 0 and batches * rpb >= 64 and all(t.data_ptr() % 16 == 0 for t in (dy, x, dx, dout)))
 
 

@@ -546,6 +546,22 @@ def test_layernorm_bwd_with_to_outs_dropout_backward_inside(D, dy_dtype, with_fa
         close(bias1, bias0.cpu(), 1e-5, 1e-4, "to_out bias gradient")
     with pytest.raises(K.MirrorHipError):
         K.layernorm_bwd(dy, x, gam, mean, rstd, dx1, dg1, db1, B, T, D, T * D, T * D, drop=(gb1, p, seed, off + 4, None, bias1))
+    if not with_fan:
+        # a norm over the FIRST rows of a longer (square-padded) sequence: the Dropout's tensor has Tx > T rows per batch, its element
+        # indices (and so its masks) follow Tx; the rows behind the norm's are the caller's zeros
+        Tx = T + 5
+        xx = torch.zeros(B, Tx, D, device=DEV)
+        xx[:, :T] = x
+        dxa = torch.zeros_like(xx)
+        K.layernorm_bwd(dy, xx, gam, mean, rstd, dxa, torch.zeros(D, device=DEV), torch.zeros(D, device=DEV), B, T, D, Tx * D, T * D)
+        gba, biasa = torch.empty(B, Tx, D, device=DEV, dtype=torch.bfloat16), torch.zeros(D, device=DEV)
+        K.dropout_lite_colsum(dxa, p, seed, off, None, gba, biasa)
+        dxb = torch.zeros_like(xx)
+        gbb, biasb = torch.zeros(B, Tx, D, device=DEV, dtype=torch.bfloat16), torch.zeros(D, device=DEV)
+        K.layernorm_bwd(dy, xx, gam, mean, rstd, dxb, torch.zeros(D, device=DEV), torch.zeros(D, device=DEV), B, T, D, Tx * D, T * D,
+                        drop=(gbb, p, seed, off, None, biasb))
+        assert torch.equal(dxb, dxa) and torch.equal(gbb, gba)
+        close(biasb, biasa.cpu(), 1e-5, 1e-4, "to_out bias gradient, padded rows")
 
 
 def test_layernorm_bwd_lm_relu_rows_and_their_column_sums():
