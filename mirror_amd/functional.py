@@ -1184,7 +1184,9 @@ class NormQkvLmFn(Function):
     by the flat row-window kernels (K.gemm_rows_ext) when the geometry allows, else every physical row is multiplied."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, rows, pad, l, w, prec):
+    def forward(ctx, x, gamma, beta, eps, rows, pad, l, w, prec, rmask=None):
+        """rmask (f32 [B, pad + rows], BASELINE config 4): the front-padded key-padding mask — masked rows leave the norm as zero rows and
+        stay out of the landmark sums (mh_layernorm_fwd_lm); the caller scales the landmark rows by l / valid count (NystromCoreFn)."""
         ctx.relu_slot = getattr(x, "_relu_slot", None)      # x is Fc1SeqFn's sequence (layer 1): see backward
         x = x.contiguous()
         Bn, T, D = x.shape
@@ -1197,7 +1199,9 @@ class NormQkvLmFn(Function):
         mean = torch.empty((Bn * rows,), device=x.device, dtype=f32)
         rstd = torch.empty_like(mean)
         xs = xe[:P].view(Bn, n_p, D)
-        K.layernorm_fwd_lm(x, gamma.detach(), beta.detach(), xs, mean, rstd, None, Bn, rows, D, T * D, pad, l, eps, xpm_bf16=xe[P:])
+        K.layernorm_fwd_lm(x, gamma.detach(), beta.detach(), xs, mean, rstd, None, Bn, rows, D, T * D, pad, l, eps, xpm_bf16=xe[P:],
+                           row_mask=rmask)
+        ctx.rmask = rmask
         qe = torch.empty((P + E, N3), device=x.device, dtype=bf16)
         qkv = _alias(qe, 0, (Bn, n_p, N3), (n_p * N3, N3, 1))
         fast = (pad > 0 and prec.mma == MH_BF16 and c0 % 256 == 0 and (N3 - c0) % 256 == 0
@@ -1288,14 +1292,16 @@ class NormQkvLmFn(Function):
                     rdb = _gbuf(fc1_b, (D,))      # _fc1's bias gradient = the column sums of dh: a third partial row of this launch
                 rslot.grad = (G.data_ptr(), dh, rdb)
             K.layernorm_bwd(dy[:, pad:], x, gamma.detach(), mean, rstd, G.view(x.shape), dg, db, Bn, rows, D, T * D, n_p * D,
-                            accumulate_dx=True, gadd=gadd, pad=pad, l=l, relu_out=dh, relu_first=1, relu_db=None if rdb is None else rdb[0])
+                            accumulate_dx=True, gadd=gadd, pad=pad, l=l, relu_out=dh, relu_first=1, relu_db=None if rdb is None else rdb[0],
+                            row_mask=ctx.rmask)
             dx = None
         else:
             dx = torch.empty_like(x)
             if rows < T:
                 dx[:, rows:].zero_()         # only the rows the norm never read (a zeros_like of [B, T, D] is a 268 MB fill at config 4)
-            K.layernorm_bwd(dy[:, pad:], x, gamma.detach(), mean, rstd, dx, dg, db, Bn, rows, D, T * D, n_p * D, gadd=gadd, pad=pad, l=l)
-        return dx, _gret(gamma, dg, sunk_g), _gret(beta, db, sunk_b), None, None, None, None, dw, None
+            K.layernorm_bwd(dy[:, pad:], x, gamma.detach(), mean, rstd, dx, dg, db, Bn, rows, D, T * D, n_p * D, gadd=gadd, pad=pad, l=l,
+                            row_mask=ctx.rmask)
+        return dx, _gret(gamma, dg, sunk_g), _gret(beta, db, sunk_b), None, None, None, None, dw, None, None
 
 
 def ext_rows_alloc(Bn: int, n_p: int, m: int, N3: int, c0: int, device):
@@ -1874,7 +1880,8 @@ class NystromCoreFn(Function):
         ctx.lm_ext = lm_ext is not None
         if kmask is not None:
             mrow, mlm, lscale = kmask
-            lm = K.row_scale(lm, lscale)                       # sum over the group / (valid count + 1e-8)
+            lm = K.row_scale(lm if lm.is_contiguous() else lm.contiguous(), lscale)      # sum over the group / (valid count + 1e-8); (the
+            # landmark rows of NormQkvLmFn live behind the sequence with row stride 3 D: an 8 MB copy)
         ql, kl = _heads(lm, 0, 2, h), _heads(lm, 1, 2, h)
         m_l = lm.shape[1]
         chain = pm == MH_BF16 and m_l == K.PINV_CHAIN_M    # whole iteration in one launch (pinv_panel.hip)

@@ -33,6 +33,7 @@ _DEFAULT_PRECISION: Optional[str] = None
 _RNA_LATE = True      # (test hook)
 # 1 (default) = the alignment / style heads run on the RNA branch's helper stream, 0 = on the caller's stream (A/B switch)
 _HEADS_SIDE = True      # (test hook)
+_LM_MASKED = True      # (test hook, round 5) the landmark-row LayerNorm + to_qkv node also under a key-padding mask (BASELINE config 4)
 _OWN_NOISE = True      # (test hook, round 5) the step's four random draws as one launch on the dropout stream instead of torch's generator
 # (measured and removed: the four noise draws + the prototype renorm on the RNA stream cost 0.5 - 1 % of the step)
 
@@ -195,23 +196,24 @@ class TransLayer(nn.Module):
         n, m = x.shape[1], a.num_landmarks
         pad = (m - n % m) % m
         l = math.ceil(n / m)  # noqa: E741
-        lm = None
-        if mask is None and Fn.layer_norm_landmarks_ok(x, n, pad, l, prec):
-            # the norm also leaves the landmark means of its output behind the padded sequence; to_qkv is linear and bias-free, so the
-            # q | k landmarks of [3P] NystromAttention are the same projection's result for those extra rows (Fn.NormQkvLmFn)
-            qkv, lm = Fn.NormQkvLmFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps, n, pad, l, a.to_qkv.weight, prec)
-        else:
-            xp = Fn.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps, pad=pad, out_dtype=prec.act,
-                               q8_key=Fn.fp8_site_key(a.to_qkv.weight, prec) if prec.fp8_fwd else None)
-        kmask = None
+        lm = kmask = mrow = None
         if mask is not None:
             if mask.shape != x.shape[:2]:
                 raise ValueError(f"key-padding mask must be {tuple(x.shape[:2])}, got {tuple(mask.shape)}")
             mrow = torch.nn.functional.pad(mask.to(x.device, torch.float32), (pad, 0), value=0.0).contiguous()
             cnt = mrow.reshape(mrow.shape[0], (n + pad) // l, l).sum(-1)
             kmask = (mrow, (cnt > 0).float().contiguous(), (float(l) / (cnt + 1e-8)).contiguous())
-            xp = Fn.RowScaleFn.apply(xp, mrow)           # to_qkv has no bias: zero rows in, zero q / k / v rows out
-        if lm is None:
+        if (mask is None or _LM_MASKED) and Fn.layer_norm_landmarks_ok(x, n, pad, l, prec):
+            # the norm also leaves the landmark means of its output behind the padded sequence; to_qkv is linear and bias-free, so the
+            # q | k landmarks of [3P] NystromAttention are the same projection's result for those extra rows (Fn.NormQkvLmFn).  With a
+            # key-padding mask (round 5) the same launch zeroes the masked rows and keeps them out of the landmark sums: no row-scale
+            # pass over the norm's output, no landmark pass over q | k (NystromCoreFn scales the sums by l / valid count)
+            qkv, lm = Fn.NormQkvLmFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps, n, pad, l, a.to_qkv.weight, prec, mrow)
+        else:
+            xp = Fn.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps, pad=pad, out_dtype=prec.act,
+                               q8_key=Fn.fp8_site_key(a.to_qkv.weight, prec) if prec.fp8_fwd else None)
+            if mask is not None:
+                xp = Fn.RowScaleFn.apply(xp, mrow)           # to_qkv has no bias: zero rows in, zero q / k / v rows out
             qkv = Fn.linear(xp, a.to_qkv.weight, None, prec=prec, defer_from=2 * a.to_qkv.weight.shape[1])
         core = Fn.NystromCoreFn.apply(qkv, a.res_conv.weight, a.heads, l, a.pinv_iterations, prec, kmask,
                                       Fn.fp8_site_key(a.to_out[0].weight, prec) if prec.fp8_fwd else None, lm)

@@ -492,6 +492,48 @@ def test_whole_model_round5_fusions_on_off(monkeypatch):
     assert seen_bias == set(bias_keys)
 
 
+def test_masked_landmark_rows_node_equals_the_composed_masked_path(monkeypatch):
+    """BASELINE config 4 (key-padding mask), bf16, train mode: LayerNorm + to_qkv with the landmarks as extra rows UNDER A MASK
+    (mh_layernorm_fwd_lm / _bwd_lm row_mask: masked rows leave as zero rows and stay out of the landmark sums) against the composed
+    path it replaces (LayerNorm, mh_row_scale, to_qkv, mh_landmark_fwd): the same linear algebra in another rounding order — losses
+    within bf16 noise, every gradient within cosine 0.999 (landmark means of the norm's output vs of its projection)."""
+    import mirror_amd.models as M
+    from mirror_amd import functional as Fn
+    import importlib
+    MM = importlib.import_module("mirror_amd.models.mirror")
+    from mirror_amd.losses import MIRRORLoss
+    cfg = dict(wsi_embed_dim=128, rna_embed_dim=96, embed_dim=512, wsi_num_tokens=1000, rna_encoder_depth=1, rna_num_heads=8,
+               rna_mlp_ratio=4.0, style_mlp_hidden_dim=128, style_mlp_out_dim=64, style_latent_dim=32, num_prototypes=300)
+    g = torch.Generator().manual_seed(16)
+    n = 1000
+    wsi = torch.randn(3, n, 128, generator=g).cuda().to(bf16)
+    rna = torch.randn(3, 96, generator=g).cuda()
+    lens = torch.tensor([n, 611, 257]).cuda()
+    mask = torch.arange(n).cuda()[None, :] < lens[:, None]
+    noise = {"wsi_mask": torch.rand(3, n, generator=g).cuda(), "rna_mask": torch.rand(3, 512, generator=g).cuda(),
+             "wsi_eps": torch.randn(3, 32, generator=g).cuda(), "rna_eps": torch.randn(3, 32, generator=g).cuda()}
+
+    def run():
+        torch.manual_seed(0)
+        model = M.mirror(**cfg).cuda().train()
+        model.precision = "bf16"
+        Fn.manual_seed(99)
+        losses = MIRRORLoss()(*model(wsi, rna, noise=noise, wsi_key_padding_mask=mask))
+        losses[0].backward()
+        torch.cuda.synchronize()
+        return [float(x) for x in losses], {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+    l1, g1 = run()
+    monkeypatch.setattr(MM, "_LM_MASKED", False)
+    l0, g0 = run()
+    assert all(abs(x - y) <= 2e-3 * max(abs(y), 1e-2) for x, y in zip(l1, l0)), (l1, l0)
+    for k in g0:
+        a, c = g1[k].flatten().double(), g0[k].flatten().double()
+        if float(c.norm()) < 1e-10:
+            continue
+        assert float(a @ c / (a.norm() * c.norm())) >= 0.999, k
+
+
 def test_attn2_backward_tail_one_pass_equals_z0_bwd_plus_softmax_bwd():
     """mh_pinv_s2_bwd (z_0 backward + the two max() sub-gradients + attn2's softmax backward in one pass, the column maximum as a
     rank-one correction) against the composed mh_pinv_z0_bwd + mh_softmax_bwd on the same inputs ([3P] moore_penrose_iter_pinv's
