@@ -349,7 +349,10 @@ int mh_pinv_chain_fwd(const void* XP, void* saved, void* zfT, int BH, int m, int
  * column abs sums as mh_pinv_absmax leaves them (caller zeroes stats64).  Replaces mh_gemm + mh_softmax_fwd + mh_pinv_absmax +
  * mh_pinv_chain_prep on the fused path. */
 int mh_nys_sim2(const void* lm, float* a2, void* xp, float* z0f, uint64_t* stats64, int B, int m, int D, int heads, float scale,
-                int64_t lm_ld, mh_stream s);      /* lm_ld: row stride of lm in elements; 0 = contiguous [B, m, 2D] (see mh_nys_attn1_fwd) */
+                int64_t lm_ld, const float* mlm, mh_stream s);
+                /* lm_ld: row stride of lm in elements; 0 = contiguous [B, m, 2D] (see mh_nys_attn1_fwd).  mlm (nullable, f32 [B, m]; BASELINE
+                   config 4): valid-landmark flags of the key-padding mask — entries of an invalid row or column are filled with -FLT_MAX in
+                   front of the softmax ([3P] sim2.masked_fill_), z0f must then be NULL (mh_pinv_chain_fwd(z0_rowmajor) forms z_0) */
 /* The two small products that open NystromAttention's backward around the chain, one launch (m = 256, dh = 64; dw2, av f32
  * [BH, m, dh], zfT bf16 [BH, m, m] = the chain's column-major output): up = PN((dw2 av^T)^T) bf16, the input of mh_pinv_chain_bwd
  * (what mh_gemm + mh_pinv_chain_pack produce), dav = Z^T dw2 bf16 [BH, m, dh].  delta3 (f32 [BH, m], may be NULL) receives

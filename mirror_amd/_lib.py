@@ -121,7 +121,7 @@ _SIGS = {
     "mh_pinv_chain_prep": [P, P, P, P, P, I, I],
     "mh_pinv_chain_pack": [P, P, I, I],
     "mh_pinv_chain_fwd": [P, P, P, I, I, I, P, P, I],
-    "mh_nys_sim2": [P, P, P, P, P, I, I, I, I, F, L],
+    "mh_nys_sim2": [P, P, P, P, P, I, I, I, I, F, L, P],
     "mh_nys_dz_dav": [P, P, P, P, P, P, I, I, I],
     "mh_pinv_chain_bwd": [P, P, P, P, P, P, I, I, I],
     "mh_nys_attn1_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, F, I, L, P],
@@ -196,7 +196,7 @@ _lib = None
 # The ABI generation this binding was written against (mh_version() of csrc/errors.cpp).  _SIGS above restates the argument lists of
 # include/mirror_hip.h by hand: a library built from another generation would be called with shifted arguments (a stream where a
 # counter belongs) and corrupt device memory silently, so load() refuses anything but this exact number.
-ABI_VERSION = 112
+ABI_VERSION = 113
 
 
 class MirrorHipError(RuntimeError):

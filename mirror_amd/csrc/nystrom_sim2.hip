@@ -55,9 +55,15 @@ __device__ __forceinline__ u32x4 pack8(const f32x16& a, int t) {
     return o;
 }
 
+// MASKED (round 5, BASELINE config 4): mlm [B, m] holds the valid-landmark flags of the key-padding mask; an entry whose row or column
+// landmark is invalid is filled with -FLT_MAX in front of the softmax ([3P] `sim2.masked_fill_(~(mask_l[..., None] * mask_l[..., None, :]),
+// -finfo.max)`), so a fully masked row comes out uniform — what mh_softmax_masked_fwd does on the composed path
+template <bool MASKED>
 __global__ __launch_bounds__(256) void nys_sim2_kernel(const bf16_t* __restrict__ lm, long ld, int D, int heads, float sl2, float* __restrict__ a2,
-                                                       bf16_t* __restrict__ xp, float* __restrict__ z0f, unsigned long long* __restrict__ stats) {
+                                                       bf16_t* __restrict__ xp, float* __restrict__ z0f, unsigned long long* __restrict__ stats,
+                                                       const float* __restrict__ mlm) {
     __shared__ float s_max[SM], s_inv[SM];
+    __shared__ float s_mlm[MASKED ? SM : 1];
     __shared__ float s_col[4][SM];
     __shared__ unsigned long long s_best[2];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hl = lane >> 5;
@@ -66,6 +72,7 @@ __global__ __launch_bounds__(256) void nys_sim2_kernel(const bf16_t* __restrict_
     const bf16_t* ql = lm + (long)b * SM * ld + h * SDH;
     const bf16_t* kl = ql + D;
     if (tid < 2) s_best[tid] = 0ull;
+    if constexpr (MASKED) s_mlm[tid] = mlm[(long)b * SM + tid];
     __syncthreads();
 
     // fragments: lane (r, hl) holds k = 16 ks + 8 hl .. + 7 of row 32 blk + r (the A and the B operand of 32x32x16 read a
@@ -97,10 +104,22 @@ __global__ __launch_bounds__(256) void nys_sim2_kernel(const bf16_t* __restrict_
     float cs[8];
 #pragma unroll
     for (int cb = 0; cb < 8; cb++) cs[cb] = 0.f;
+    unsigned colv = 0xffu;            // MASKED: bit cb = this lane's column 32 cb + r is a valid landmark
+    if constexpr (MASKED) {
+        colv = 0;
+#pragma unroll
+        for (int cb = 0; cb < 8; cb++) colv |= (s_mlm[32 * cb + r] != 0.f ? 1u : 0u) << cb;
+    }
 #pragma unroll
     for (int rb = 0; rb < 2; rb++)
 #pragma unroll
         for (int reg = 0; reg < 16; reg++) {
+            if constexpr (MASKED) {
+                const bool rv = s_mlm[32 * (2 * wave + rb) + (reg & 3) + 8 * (reg >> 2) + 4 * hl] != 0.f;
+#pragma unroll
+                for (int cb = 0; cb < 8; cb++)
+                    if (!(rv && ((colv >> cb) & 1u))) acc[rb][cb][reg] = -3.402823466e38f;
+            }
             float mx = acc[rb][0][reg];
 #pragma unroll
             for (int cb = 1; cb < 8; cb++) mx = fmaxf(mx, acc[rb][cb][reg]);
@@ -301,15 +320,22 @@ __global__ __launch_bounds__(256) void nys_dz_dav_kernel(const float* __restrict
 }  // namespace
 
 extern "C" int mh_nys_sim2(const void* lm, float* a2, void* xp, float* z0f, uint64_t* stats64, int B, int m, int D, int heads, float scale,
-                           int64_t lm_ld, mh_stream s) {
+                           int64_t lm_ld, const float* mlm, mh_stream s) {
     MH_REQUIRE(lm_ld == 0 || (lm_ld >= 2L * D && lm_ld % 8 == 0), "mh_nys_sim2: lm_ld must be 0 (contiguous [B, m, 2D]) or a multiple of 8 >= 2 D");
     MH_REQUIRE(m == SM && heads >= 1 && D == heads * SDH, "mh_nys_sim2: built for m = %d landmarks and dh = %d (m=%d, D=%d, heads=%d)", SM, SDH, m, D, heads);
     MH_REQUIRE(lm && a2 && xp && stats64 && (((uintptr_t)lm | (uintptr_t)a2 | (uintptr_t)xp | (uintptr_t)z0f) & 15) == 0,
                "mh_nys_sim2: null / unaligned buffer");
     MH_REQUIRE((long)B * heads * m < (1L << 31), "mh_nys_sim2: index overflow");
     if (B == 0) return MH_OK;
-    hipLaunchKernelGGL(nys_sim2_kernel, dim3(B * heads, 1), dim3(256), 0, (hipStream_t)s, (const bf16_t*)lm, lm_ld > 0 ? (long)lm_ld : 2L * D, D, heads, scale * 1.4426950408889634f,
-                       a2, (bf16_t*)xp, z0f, (unsigned long long*)stats64);
+    if (mlm) {
+        MH_REQUIRE(z0f == nullptr, "mh_nys_sim2: the masked form has no second pass (z0f must be NULL: the chain forms z_0 from attn2's rows)");
+        hipLaunchKernelGGL(nys_sim2_kernel<true>, dim3(B * heads, 1), dim3(256), 0, (hipStream_t)s, (const bf16_t*)lm, lm_ld > 0 ? (long)lm_ld : 2L * D, D, heads, scale * 1.4426950408889634f,
+                           a2, (bf16_t*)xp, z0f, (unsigned long long*)stats64, mlm);
+        MH_LAUNCH_CHECK("mh_nys_sim2");
+        return MH_OK;
+    }
+    hipLaunchKernelGGL(nys_sim2_kernel<false>, dim3(B * heads, 1), dim3(256), 0, (hipStream_t)s, (const bf16_t*)lm, lm_ld > 0 ? (long)lm_ld : 2L * D, D, heads, scale * 1.4426950408889634f,
+                       a2, (bf16_t*)xp, z0f, (unsigned long long*)stats64, (const float*)nullptr);
     MH_LAUNCH_CHECK("mh_nys_sim2");
     return MH_OK;
 }

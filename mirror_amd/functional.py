@@ -1824,6 +1824,7 @@ def _pair(first: torch.Tensor, second: torch.Tensor) -> torch.Tensor:
 
 _S2_TAIL = True      # (test hook)
 _Z0_ROWS = True      # (test hook)
+_SIM2_MASKED = True      # (test hook, round 5) the one-launch sim2 + softmax + maxima + panels also under a key-padding mask (config 4)
 _SIM2_SIDE = True      # nys_sim2 opens the chain's branch instead of preceding the fork
 _S2_SIDE = True      # sim2's landmark gradients on the chain's stream
 _LM_MERGE_LATE = True      # (test hook) the landmark rows' merge + data gradient beside the sequence rows' data gradient (-0.24 % +- 0.29)
@@ -1886,7 +1887,8 @@ class NystromCoreFn(Function):
         m_l = lm.shape[1]
         chain = pm == MH_BF16 and m_l == K.PINV_CHAIN_M    # whole iteration in one launch (pinv_panel.hip)
         # sim2, its softmax, the tensor-wide abs-sum maxima and the chain's operand packing in ONE launch (nystrom_sim2.hip)
-        one = chain and kmask is None and dh == 64 and K.nys_sim2_ok(lm, h)
+        one = chain and (kmask is None or _SIM2_MASKED) and dh == 64 and K.nys_sim2_ok(lm, h)      # (mask-aware since round 5: mlm of mh_nys_sim2)
+        mlm_s2 = None if kmask is None else mlm
         z0f = None
         sim2_side = one and _SIM2_SIDE and _Z0_ROWS
         if sim2_side:
@@ -1895,7 +1897,7 @@ class NystromCoreFn(Function):
             a2, xt = K.nys_sim2_alloc(lm, h)
             st = zeros((4,), qkv.device).view(torch.int64)
         elif one:
-            a2, xt, z0f, st = K.nys_sim2(lm, h, scale, zeros((4,), qkv.device).view(torch.int64), want_z0f=not _Z0_ROWS)
+            a2, xt, z0f, st = K.nys_sim2(lm, h, scale, zeros((4,), qkv.device).view(torch.int64), want_z0f=not _Z0_ROWS, mlm=mlm_s2)
         else:
             a2 = K.gemm(ql, kl.transpose(-1, -2), alpha=scale, mma=mma, out_dtype=f32)      # [B,h,m,m]
             if kmask is None:
@@ -1919,7 +1921,7 @@ class NystromCoreFn(Function):
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 if sim2_side:
-                    K.nys_sim2(lm, h, scale, st, out=(a2, xt))
+                    K.nys_sim2(lm, h, scale, st, out=(a2, xt), mlm=mlm_s2)
                 if one and _Z0_ROWS:      # z_0 from the rows of attn2 inside the chain launch: nys_sim2 has no second pass and no f32 transpose
                     K.pinv_chain_fwd(xt, chain_saved, zfT, iters, z0f=a2, stats=st, z0_rowmajor=True)
                 else:

@@ -968,11 +968,14 @@ def nys_sim2_alloc(lm: torch.Tensor, heads: int):
             torch.empty((Bn, heads, m, m), device=lm.device, dtype=torch.bfloat16))
 
 
-def nys_sim2(lm: torch.Tensor, heads: int, scale: float, stats: Optional[torch.Tensor] = None, want_z0f: bool = False, out=None):
+def nys_sim2(lm: torch.Tensor, heads: int, scale: float, stats: Optional[torch.Tensor] = None, want_z0f: bool = False, out=None, mlm=None):
     """(attn2 f32 [B, h, m, m], xt = panel-native bf16 attn2, z0f, stats) in one launch.  z0f (want_z0f) = panel-native f32 attn2^T, the
     unscaled z_0; by default None: the chain forward forms z_0 from the ROWS of attn2 (pinv_chain_fwd(z0f=a2, z0_rowmajor=True)) and the
-    launch skips its second pass.  out: (attn2, xt) from nys_sim2_alloc."""
-    _chk(lm, stats)
+    launch skips its second pass.  out: (attn2, xt) from nys_sim2_alloc.  mlm (f32 [B, m]): valid-landmark flags of a key-padding mask
+    (masked_fill in front of the softmax; no z0f then)."""
+    _chk(lm, stats, mlm)
+    if mlm is not None and (want_z0f or mlm.dtype != torch.float32 or not mlm.is_contiguous() or mlm.numel() != lm.shape[0] * lm.shape[1]):
+        raise MirrorHipError("nys_sim2: mlm is a contiguous f32 [B, m] and excludes want_z0f")
     Bn, m, D2 = lm.shape
     D = D2 // 2
     if stats is None:
@@ -983,7 +986,7 @@ def nys_sim2(lm: torch.Tensor, heads: int, scale: float, stats: Optional[torch.T
             and a2.is_contiguous() and xt.is_contiguous()):
         raise MirrorHipError("nys_sim2: out must be the contiguous (f32, bf16) [B, h, m, m] pair of nys_sim2_alloc")
     z0f = torch.empty((Bn, heads, m, m), device=lm.device, dtype=torch.float32) if want_z0f else None
-    _lib.call("mh_nys_sim2", _p(lm), _p(a2), _p(xt), _p(z0f), _p(stats), Bn, m, D, heads, float(scale), _lm_ld(lm), stream=_stream())
+    _lib.call("mh_nys_sim2", _p(lm), _p(a2), _p(xt), _p(z0f), _p(stats), Bn, m, D, heads, float(scale), _lm_ld(lm), _p(mlm), stream=_stream())
     return a2, xt, z0f, stats
 
 

@@ -525,6 +525,7 @@ def test_masked_landmark_rows_node_equals_the_composed_masked_path(monkeypatch):
 
     l1, g1 = run()
     monkeypatch.setattr(MM, "_LM_MASKED", False)
+    monkeypatch.setattr(Fn, "_SIM2_MASKED", False)      # and the one-launch masked sim2 (mlm of mh_nys_sim2) against gemm + mh_softmax_masked_fwd + ...
     l0, g0 = run()
     assert all(abs(x - y) <= 2e-3 * max(abs(y), 1e-2) for x, y in zip(l1, l0)), (l1, l0)
     for k in g0:
