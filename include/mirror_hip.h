@@ -326,7 +326,9 @@ int mh_pinv_z0_bwd(const float* x, const float* z0, const float* dz0, const uint
  * mh_pinv_z0_bwd(x = p, z0 = NULL) followed by mh_softmax_bwd up to the rounding of the row sums (the row maximum's constant cancels
  * in a softmax backward; the column maximum's is applied as a rank-one correction of the one matrix that holds it). */
 int mh_pinv_s2_bwd(const float* p, const float* dz0, const uint64_t* stats64, float* dx, float* scratch1, int scratch_zeroed, int BH,
-                   int m, mh_stream s);
+                   int m, const float* mlm, int heads, mh_stream s);
+                   /* mlm (nullable, f32 [BH / heads, m]; BASELINE config 4): p came out of masked_fill + softmax (mh_nys_sim2(mlm) /
+                      mh_softmax_masked_fwd); entries of an invalid row or column landmark receive no gradient (dx = 0 there) */
 /* The whole iteration as ONE launch per pass (bf16 policy, m = 256; other sizes return MH_EINVAL and the caller
  * composes mh_gemm): one 256-thread workgroup per (b,h) walks the chain of m x m products; a wave owns 64 columns of
  * every product, its B operand never leaves the register file, A is one LDS image (pinv_panel.hip).

@@ -116,7 +116,7 @@ _SIGS = {
     "mh_pinv_absmax": [P, P, I, I],
     "mh_pinv_z0": [P, P, P, I, I],
     "mh_pinv_z0_bwd": [P, P, P, P, P, P, I, I, I],
-    "mh_pinv_s2_bwd": [P, P, P, P, P, I, I, I],
+    "mh_pinv_s2_bwd": [P, P, P, P, P, I, I, I, P, I],
     "mh_eye_minus": [P, P, F, I, I],
     "mh_pinv_chain_prep": [P, P, P, P, P, I, I],
     "mh_pinv_chain_pack": [P, P, I, I],
@@ -196,7 +196,7 @@ _lib = None
 # The ABI generation this binding was written against (mh_version() of csrc/errors.cpp).  _SIGS above restates the argument lists of
 # include/mirror_hip.h by hand: a library built from another generation would be called with shifted arguments (a stream where a
 # counter belongs) and corrupt device memory silently, so load() refuses anything but this exact number.
-ABI_VERSION = 113
+ABI_VERSION = 114
 
 
 class MirrorHipError(RuntimeError):

@@ -660,9 +660,11 @@ extern "C" int mh_pinv_z0_bwd(const float* x, const float* z0, const float* dz0,
 // S = sum dz0 o z0 (g_c = -S / (c r) * c) is complete.
 constexpr int S2_ROWS = 32;                 // rows of dS per workgroup
 constexpr int S2_PITCH = 260;               // floats: 16-byte aligned rows, the column writes of the transposed tile hit 64 distinct banks
+// mlm (nullable, [BH / heads, 256]; BASELINE config 4): valid-landmark flags — P came out of a masked_fill + softmax, whose backward passes
+// nothing to a filled entry (an invalid row or column): dS is zeroed there (a fully masked row is uniform, not zero, in P)
 __global__ __launch_bounds__(256) void pinv_s2_bwd_kernel(const float* __restrict__ P, const float* __restrict__ dz0,
                                                           const unsigned long long* __restrict__ st, float* __restrict__ dx,
-                                                          float* __restrict__ scratch) {
+                                                          float* __restrict__ scratch, const float* __restrict__ mlm, int heads) {
     typedef float zf4 __attribute__((ext_vector_type(4)));
     __shared__ __attribute__((aligned(16))) float T[S2_ROWS * S2_PITCH];      // T[i][j] = dz0[j][i0 + i]
     __shared__ float red[4];
@@ -689,9 +691,13 @@ __global__ __launch_bounds__(256) void pinv_s2_bwd_kernel(const float* __restric
     }
     __syncthreads();
     float dot = 0.f;
+    const float* mb = mlm ? mlm + (long)(blockIdx.y / heads) * 256 : nullptr;
+    zf4 cv = {1.f, 1.f, 1.f, 1.f};
+    if (mb) cv = *reinterpret_cast<const zf4*>(mb + 4 * lane);
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const zf4 t = *reinterpret_cast<const zf4*>(T + (8 * wave + r) * S2_PITCH + 4 * lane);
+        const bool rv = !mb || mb[i0 + 8 * wave + r] != 0.f;
         zf4 dp;
         float rs = 0.f;
 #pragma unroll
@@ -703,7 +709,7 @@ __global__ __launch_bounds__(256) void pinv_s2_bwd_kernel(const float* __restric
         rs = wave_sum(rs);
         zf4 o;
 #pragma unroll
-        for (int e = 0; e < 4; e++) o[e] = p[r][e] * (dp[e] - rs);
+        for (int e = 0; e < 4; e++) o[e] = (rv && cv[e] != 0.f) ? p[r][e] * (dp[e] - rs) : 0.f;
         *reinterpret_cast<zf4*>(dx + base + (long)(i0 + 8 * wave + r) * 256 + 4 * lane) = o;
     }
     dot = block_sum256(dot, red);
@@ -712,7 +718,8 @@ __global__ __launch_bounds__(256) void pinv_s2_bwd_kernel(const float* __restric
 
 // the column maximum's sub-gradient through the softmax backward (see above): one wave per row of the matrix that holds it
 __global__ __launch_bounds__(256) void pinv_s2_colfix_kernel(const float* __restrict__ P, const unsigned long long* __restrict__ st,
-                                                             const float* __restrict__ scratch, float* __restrict__ dx) {
+                                                             const float* __restrict__ scratch, float* __restrict__ dx,
+                                                             const float* __restrict__ mlm, int heads) {
     typedef float zf4 __attribute__((ext_vector_type(4)));
     const float c = stat_val(st, 0), r = stat_val(st, 1);
     const float gc = -scratch[0] / (c * r) * c;
@@ -723,13 +730,17 @@ __global__ __launch_bounds__(256) void pinv_s2_colfix_kernel(const float* __rest
     const float pj = P[base + (long)i * 256 + js];
     const zf4 p = *reinterpret_cast<const zf4*>(P + off);
     zf4 d = *reinterpret_cast<const zf4*>(dx + off);
+    const float* mb = mlm ? mlm + (long)((ci / 256) / heads) * 256 : nullptr;
+    const bool rv = !mb || mb[i] != 0.f;
 #pragma unroll
-    for (int e = 0; e < 4; e++) d[e] += gc * p[e] * ((4 * lane + e == js ? 1.f : 0.f) - pj);
+    for (int e = 0; e < 4; e++)
+        if (rv && (!mb || mb[4 * lane + e] != 0.f)) d[e] += gc * p[e] * ((4 * lane + e == js ? 1.f : 0.f) - pj);
     *reinterpret_cast<zf4*>(dx + off) = d;
 }
 
 extern "C" int mh_pinv_s2_bwd(const float* p, const float* dz0, const uint64_t* stats64, float* dx, float* scratch1,
-                              int scratch_zeroed, int BH, int m, mh_stream s) {
+                              int scratch_zeroed, int BH, int m, const float* mlm, int heads, mh_stream s) {
+    MH_REQUIRE(!mlm || (heads >= 1 && BH % heads == 0 && ((uintptr_t)mlm & 15) == 0), "mh_pinv_s2_bwd: mlm [BH / heads, m] f32, 16-byte aligned");
     MH_REQUIRE(m == 256, "mh_pinv_s2_bwd: built for m = 256 (m=%d): compose mh_pinv_z0_bwd + mh_softmax_bwd", m);
     MH_REQUIRE(p && dz0 && stats64 && dx && scratch1 && (((uintptr_t)p | (uintptr_t)dz0 | (uintptr_t)dx) & 15) == 0,
                "mh_pinv_s2_bwd: null / unaligned buffer");
@@ -739,8 +750,9 @@ extern "C" int mh_pinv_s2_bwd(const float* p, const float* dz0, const uint64_t* 
         if (e != hipSuccess) { mh_set_error("mh_pinv_s2_bwd: memset failed"); return MH_EHIP; }
     }
     hipLaunchKernelGGL(pinv_s2_bwd_kernel, dim3(256 / S2_ROWS, BH), dim3(256), 0, (hipStream_t)s, p, dz0, (const unsigned long long*)stats64, dx,
-                       scratch1);
-    hipLaunchKernelGGL(pinv_s2_colfix_kernel, dim3(64), dim3(256), 0, (hipStream_t)s, p, (const unsigned long long*)stats64, scratch1, dx);
+                       scratch1, mlm, heads > 0 ? heads : 1);
+    hipLaunchKernelGGL(pinv_s2_colfix_kernel, dim3(64), dim3(256), 0, (hipStream_t)s, p, (const unsigned long long*)stats64, scratch1, dx, mlm,
+                       heads > 0 ? heads : 1);
     MH_LAUNCH_CHECK("mh_pinv_s2_bwd");
     return MH_OK;
 }

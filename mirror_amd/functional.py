@@ -2086,8 +2086,9 @@ class NystromCoreFn(Function):
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 K.pinv_chain_bwd(xb, chain_saved, dzb, work, dS2, dz0, iters)
-                if _S2_TAIL and kmask is None and not ctx.z0_stored and a2.shape[-1] == 256:
-                    K.pinv_s2_bwd(a2, dz0, st, dS2, _zeroed1(a2.device))      # z_0 backward, the maxima's sub-gradients and attn2's softmax backward: one pass
+                if _S2_TAIL and (kmask is None or _SIM2_MASKED) and not ctx.z0_stored and a2.shape[-1] == 256:
+                    # z_0 backward, the maxima's sub-gradients and attn2's (masked) softmax backward: one pass
+                    K.pinv_s2_bwd(a2, dz0, st, dS2, _zeroed1(a2.device), mlm=mlm if kmask else None, heads=h)
                 else:
                     K.pinv_z0_bwd(a2, z0 if ctx.z0_stored else None, dz0, st, dS2, _zeroed1(a2.device))
                     sm_bwd(a2, dS2, mlm if kmask else None, mlm if kmask else None)

@@ -867,15 +867,18 @@ def pinv_z0_bwd(x, z0, dz0, stats, dx, zeroed_scratch=None) -> None:
               x.numel() // (m * m), m, stream=_stream())
 
 
-def pinv_s2_bwd(p, dz0, stats, dx, zeroed_scratch=None) -> None:
-    """dx (the chain's gradient wrt attn2 on entry) -> gradient wrt sim2's logits, one pass (mh_pinv_s2_bwd: m = 256, no mask)."""
-    _chk(p, dz0, stats, dx, zeroed_scratch)
+def pinv_s2_bwd(p, dz0, stats, dx, zeroed_scratch=None, mlm=None, heads: int = 1) -> None:
+    """dx (the chain's gradient wrt attn2 on entry) -> gradient wrt sim2's logits, one pass (mh_pinv_s2_bwd: m = 256).  mlm (f32 [B, m]) +
+    heads: the valid-landmark flags of a key-padding mask (p [B, heads, m, m]): filled entries get no gradient."""
+    _chk(p, dz0, stats, dx, zeroed_scratch, mlm)
+    if mlm is not None and not (mlm.dtype == torch.float32 and mlm.is_contiguous() and mlm.numel() * heads * p.shape[-1] == p.numel()):
+        raise MirrorHipError("pinv_s2_bwd: mlm is a contiguous f32 [B, m] with p [B, heads, m, m]")
     m = p.shape[-1]
     if not (p.dtype == dz0.dtype == dx.dtype == torch.float32 and p.is_contiguous() and dz0.is_contiguous() and dx.is_contiguous()
             and p.shape == dz0.shape == dx.shape and p.shape[-2] == m):
         raise MirrorHipError("pinv_s2_bwd: contiguous f32 [.., m, m] tensors of one shape")
     scratch, zf = _scratch1(zeroed_scratch, p)
-    _lib.call("mh_pinv_s2_bwd", _p(p), _p(dz0), _p(stats), _p(dx), _p(scratch), zf, p.numel() // (m * m), m, stream=_stream())
+    _lib.call("mh_pinv_s2_bwd", _p(p), _p(dz0), _p(stats), _p(dx), _p(scratch), zf, p.numel() // (m * m), m, _p(mlm), int(heads), stream=_stream())
 
 
 PINV_CHAIN_M = 256

@@ -568,6 +568,48 @@ def test_attn2_backward_tail_one_pass_equals_z0_bwd_plus_softmax_bwd():
     assert float((nofix[ci // m] - ref[ci // m]).abs().max()) > 1e-4 * scale
 
 
+def test_attn2_backward_tail_under_a_key_padding_mask_equals_the_composed_masked_path():
+    """mh_pinv_s2_bwd(mlm) (round 5, BASELINE config 4) against mh_pinv_z0_bwd + mh_softmax_masked_bwd: p comes from masked_fill + softmax
+    (mh_nys_sim2(mlm), checked here against mh_gemm + mh_softmax_masked_fwd too): filled entries get no gradient — also in a fully masked,
+    uniform row — and the column maximum's rank-one term stays out of them."""
+    from mirror_amd import kernels as K
+    from mirror_amd._lib import MH_BF16
+    g = torch.Generator().manual_seed(6)
+    B, h, m, dh = 3, 2, 256, 64
+    lm = (torch.randn(B, m, 2 * h * dh, generator=g) * 0.5).cuda().to(bf16)
+    mlm = torch.ones(B, m)
+    mlm[1, 200:] = 0
+    mlm[2, :17] = 0
+    mlm[2, 100] = 0
+    mlm = mlm.cuda().contiguous()
+    scale = dh ** -0.5
+    st = torch.zeros(4, device="cuda").view(torch.int64)
+    a2, xt, z0f, st = K.nys_sim2(lm, h, scale, st, mlm=mlm)
+    ql = lm[..., :h * dh].reshape(B, m, h, dh).permute(0, 2, 1, 3)
+    kl = lm[..., h * dh:].reshape(B, m, h, dh).permute(0, 2, 1, 3)
+    ref_p = K.gemm(ql, kl.transpose(-1, -2), alpha=scale, mma=MH_BF16, out_dtype=torch.float32)
+    K.softmax_masked_fwd(ref_p, mlm, mlm, ref_p)
+    assert float((a2 - ref_p).abs().max()) <= 2e-6
+    assert abs(float(a2[1, 0, 250].sum()) - 1.0) < 1e-5 and float((a2[1, 0, 250] - 1.0 / m).abs().max()) < 1e-7      # a fully masked row: uniform
+    assert float(a2[1, 0, 3, 200:].abs().max()) == 0.0                                                           # masked columns of a valid row
+    st_ref = K.pinv_absmax(ref_p, torch.zeros(4, device="cuda").view(torch.int64))
+    # the same maxima: values of both, position of the column maximum (every row's abs sum is 1 up to rounding: its argmax is a tie-break)
+    sv, sr = st.view(torch.int64)[:2], st_ref.view(torch.int64)[:2]
+    assert int(sv[1]) == int(sr[1]) and abs((int(sv[0]) >> 32) - (int(sr[0]) >> 32)) <= 8
+    p = a2.reshape(B * h, m, m).contiguous()
+    dz0 = torch.randn(B * h, m, m, generator=g).cuda()
+    dx0 = torch.randn(B * h, m, m, generator=g).cuda()
+    ref = dx0.clone()
+    K.pinv_z0_bwd(p, None, dz0, st, ref)
+    K.softmax_masked_bwd(p.view(B, h, m, m), ref.view(B, h, m, m), mlm, mlm)
+    got = dx0.clone()
+    K.pinv_s2_bwd(p, dz0, st, got, mlm=mlm, heads=h)
+    torch.cuda.synchronize()
+    sc = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 3e-6 * sc, (float((got - ref).abs().max()), sc)
+    assert float(got.view(B, h, m, m)[1, :, 200:].abs().max()) == 0.0 and float(got.view(B, h, m, m)[1, :, :, 200:].abs().max()) == 0.0
+
+
 def test_dz_dav_one_launch_equals_gemm_pack_gemm():
     """mh_nys_dz_dav (dZ = dW2 av^T packed panel native for the chain + dAV = Z^T dW2) against mh_gemm + mh_pinv_chain_pack + mh_gemm:
     the products that open [3P] NystromAttention's backward around moore_penrose_iter_pinv (models/mirror.py:312)."""
