@@ -2077,7 +2077,7 @@ class NystromCoreFn(Function):
             dz0 = torch.empty_like(a2)
             if dzb is None:
                 dzb = K.pinv_chain_pack(dZ)
-            if _S2_SIDE and fused and kmask is None:
+            if _S2_SIDE and fused and (kmask is None or _SIM2_MASKED):
                 # sim2's share of the landmark gradients leaves the serial tail behind the join: the chain's stream has slack
                 # in this window.  The attention kernels on the main stream add into dlm with atomics meanwhile, so the two
                 # products go to a buffer of their own and one add (which is also the cast) merges them after the join.
