@@ -1329,6 +1329,7 @@ def ext_rows_of(dqkv, dlm, P: int, E: int, N3: int, c0: int, copy_lm: bool = Tru
 
 
 _LM_ROWS = True       # test hook (tests/test_fused_epilogue_gpu.py): False = the landmark kernels on q | k instead of NormQkvLmFn
+_RELU_SQUARE_PAD = True      # (test hook, round 5) ... also when the sequence carries square-pad rows (N no square: config 4, template)
 _RELU_IN_LN_BWD = True      # (test hook, round 5) _fc1's ReLU backward inside layer 1's LayerNorm backward
 class _ReluSlot:
     """Hand-over between Fc1SeqFn and the LayerNorm + to_qkv node that reads its sequence (carried on the tensor: `seq._relu_slot`):
@@ -1595,8 +1596,10 @@ class Fc1SeqFn(Function):
             K.gemm(xa, wa.t(), out=seq[:, 1:1 + N], bias=b.detach(), act=ACT_RELU, mma=prec.mma)
         K.seq_finish(seq, cls.detach().reshape(-1).contiguous(), N, add_len)
         ctx.slot = None
-        if slot is not None and add_len == 0 and prec.act == bf16:
-            slot.n, slot.bias = N, b      # layer 1's LayerNorm backward may write the ReLU-masked gradient itself (NormQkvLmFn.backward)
+        if slot is not None and prec.act == bf16 and (add_len == 0 or _RELU_SQUARE_PAD):
+            # layer 1's LayerNorm backward may write the ReLU-masked gradient itself (NormQkvLmFn.backward): every row behind the cls row is
+            # a ReLU's output — the add_len square-pad rows are copies of rows 1 .. add_len
+            slot.n, slot.bias = N + add_len, b
             ctx.slot = slot
         ctx.save_for_backward(xa, wa, seq, w, b)
         ctx.add_len, ctx.prec, ctx.cls = add_len, prec, cls
@@ -1616,18 +1619,28 @@ class Fc1SeqFn(Function):
             (gptr, gdh, gdb), ctx.slot.grad = ctx.slot.grad, None
             if gptr == dseq.data_ptr():
                 dh, db_have = gdh, gdb
-        if add_len:
-            dseq = dseq.clone()  # the fold below is in place; autograd owns the incoming buffer
         dcls, sunk_c = _gbuf_n(ctx.cls, (D,))
-        K.seq_finish_bwd(dseq, dcls, N, add_len)
+        if dh is not None:
+            K.seq_finish_bwd(dseq, dcls, N + add_len, 0)      # the cls row only: the square-pad rows' fold happens on the handed-over rows
+        else:
+            if add_len:
+                dseq = dseq.clone()  # the fold below is in place; autograd owns the incoming buffer
+            K.seq_finish_bwd(dseq, dcls, N, add_len)
         dcls = _gret(ctx.cls, dcls, sunk_c)
-        if dh is not None and (add_len or tuple(dh.shape) != (Bn, N, D)):
+        if dh is not None and tuple(dh.shape) != (Bn, N + add_len, D):
             raise K.MirrorHipError("Fc1SeqFn.backward: the ReLU-masked gradient handed over by the LayerNorm backward has another shape")
-        if dh is None:
-            dh = K.relu_bwd(seq[:, 1:1 + N], dseq[:, 1:1 + N], out_dtype=prec.act)   # [B,N,D] contiguous
         dw, sunk_w = _gbuf(w, (D, Fd))
-        K.gemm(dh.reshape(Bn * N, D).t(), xa.reshape(Bn * N, Fd), out=dw, accumulate=True,
-               split_k=_split_k_for(Bn * N, D, Fd), mma=prec.mma)
+        if dh is not None and add_len:
+            # the square-pad rows are copies of rows 1 .. add_len: their (already ReLU-masked: same x, same gate) gradients fold onto those
+            # rows, then the weight gradient contracts the first N rows of every slide (a batch-strided operand: no 67 MB compaction)
+            dh[:, :add_len] += dh[:, N:N + add_len]
+            dh = dh[:, :N]
+            K.gemm(dh.transpose(-1, -2), xa, out=dw.expand(Bn, D, Fd), accumulate=True, split_k=_split_k_for(N, D, Fd, batch=Bn), mma=prec.mma)
+        else:
+            if dh is None:
+                dh = K.relu_bwd(seq[:, 1:1 + N], dseq[:, 1:1 + N], out_dtype=prec.act)   # [B,N,D] contiguous
+            K.gemm(dh.reshape(Bn * N, D).t(), xa.reshape(Bn * N, Fd), out=dw, accumulate=True,
+                   split_k=_split_k_for(Bn * N, D, Fd), mma=prec.mma)
         dw = _gret(w, dw, sunk_w)
         if db_have is not None:
             db = _gret(b, *db_have)
@@ -1637,7 +1650,7 @@ class Fc1SeqFn(Function):
             db = _gret(b, db, sunk_b)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = K.gemm(dh, wa, mma=prec.mma, out_dtype=f32)
+            dx = K.gemm(dh if dh.is_contiguous() else dh.contiguous(), wa, mma=prec.mma, out_dtype=f32)
         return dx, dw, db, None if dcls is None else dcls.reshape(1, 1, D), None, None, None
 
 

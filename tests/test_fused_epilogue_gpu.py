@@ -533,6 +533,18 @@ def test_masked_landmark_rows_node_equals_the_composed_masked_path(monkeypatch):
         if float(c.norm()) < 1e-10:
             continue
         assert float(a @ c / (a.norm() * c.norm())) >= 0.999, k
+    # 1000 tokens are no square (24 square-pad rows): _fc1's ReLU backward inside layer 1's LayerNorm backward with the pad rows' gradients
+    # folded onto the rows they copy (bf16 after the gate) against the f32 fold + mh_relu_bwd of the composed path
+    monkeypatch.setattr(MM, "_LM_MASKED", True)
+    monkeypatch.setattr(Fn, "_SIM2_MASKED", True)
+    monkeypatch.setattr(Fn, "_RELU_SQUARE_PAD", False)
+    l2, g2 = run()
+    assert all(abs(x - y) <= 1e-5 * max(abs(y), 1e-3) for x, y in zip(l2, l1)), (l2, l1)
+    for k in g1:
+        a, c = g1[k].flatten().double(), g2[k].flatten().double()
+        if float(c.norm()) < 1e-10:
+            continue
+        assert float(a @ c / (a.norm() * c.norm())) >= 0.9999, k
 
 
 def test_attn2_backward_tail_one_pass_equals_z0_bwd_plus_softmax_bwd():
