@@ -211,11 +211,12 @@ int mh_layernorm_bwd(const void* dy, const void* x, const float* gamma, const fl
  * xpm (f32) may be NULL when only the bf16 means are wanted (they are the landmark rows behind the sequence in to_qkv's operand). */
 int mh_layernorm_fwd_lm(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, void* xpm,
                         void* xpm_bf16, int batches, int rows, int D, int64_t x_bs, int pad, int l, float eps, const float* row_mask,
-                        mh_stream s);
+                        const float* lm_scale, mh_stream s);
                         /* row_mask (nullable, f32 [batches, pad + rows]; BASELINE config 4): the key-padding mask, front-padded like the
                            sequence — rows with a zero entry leave as zero rows ([3P] `q, k, v = t * mask[..., None]` through the bias-free
                            to_qkv) and stay out of their group's sum: the landmark rows are masked sums / l (the caller scales them by
-                           l / valid count); mh_layernorm_bwd_lm takes the same mask */
+                           l / valid count — or passes those factors as lm_scale, f32 [batches, (pad + rows) / l], nullable: the landmark rows then leave as
+                           the masked MEANS); mh_layernorm_bwd_lm takes the same mask and scale */
                         /* xpm_bf16 (optional): the bf16 rounding of xpm, the B operand of the landmark projection's weight gradient */
 /* mh_layernorm_bwd for a LayerNorm output that fans out (the WSI encoder's final norm: decoder input, retention target = rows 1..,
  * cls row; models/mirror.py:684-700, :833): f32 x / dx, dy f32 or bf16 (dt_dy; round 5: the decoder's data gradient arrives in
@@ -244,7 +245,7 @@ int mh_layernorm_bwd_lm(const void* dy, const void* x, const float* gamma, const
                         void* dx, float* dgamma, float* dbeta, int batches, int rows_per_batch, int D, int64_t x_bs, int64_t y_bs,
                         int dt_x, int dt_dy, int dt_dx, int accumulate_dx, float* workspace, int64_t ws_floats,
                         const void* gadd, int pad, int l, void* relu_out, int relu_first, int relu_rows, float* relu_db,
-                        const float* row_mask, mh_stream s);
+                        const float* row_mask, const float* lm_scale, mh_stream s);
                         /* relu_out (nullable, bf16 [batches, relu_rows, D]; f32 x): x rows [relu_first, relu_first + relu_rows) of every batch
                            are the output of a ReLU (`_fc1 = Linear + ReLU`, models/mirror.py:346, :652-654, feeds layer 1's norm): their
                            total gradient is written HERE as bf16 (x > 0 ? dx : 0), the operand of _fc1's weight gradient, and NOT as f32 dx

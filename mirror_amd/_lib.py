@@ -104,8 +104,8 @@ _SIGS = {
     "mh_layernorm_bwd": [P, P, P, P, P, P, P, P, I, I, I, L, L, I, I, I, I, P, L],
     "mh_layernorm_bwd_fan": [P, P, P, P, P, P, P, P, I, I, I, L, L, I, I, P, L, P, F, P],
     "mh_layernorm_bwd_drop": [P, P, P, P, P, P, P, P, I, I, I, L, L, I, I, P, L, P, F, P, P, F, U64, U64, P, P, I],
-    "mh_layernorm_bwd_lm": [P, P, P, P, P, P, P, P, I, I, I, L, L, I, I, I, I, P, L, P, I, I, P, I, I, P, P],
-    "mh_layernorm_fwd_lm": [P, P, P, P, P, P, P, P, I, I, I, L, I, I, F, P],
+    "mh_layernorm_bwd_lm": [P, P, P, P, P, P, P, P, I, I, I, L, L, I, I, I, I, P, L, P, I, I, P, I, I, P, P, P],
+    "mh_layernorm_fwd_lm": [P, P, P, P, P, P, P, P, I, I, I, L, I, I, F, P, P],
     "mh_softmax_fwd": [P, P, L, I, L, L, I, I],
     "mh_softmax_bwd": [P, P, P, L, I, L, L, L, I, I, I],
     "mh_landmark_fwd": [P, P, I, I, I, I, I],
@@ -196,7 +196,7 @@ _lib = None
 # The ABI generation this binding was written against (mh_version() of csrc/errors.cpp).  _SIGS above restates the argument lists of
 # include/mirror_hip.h by hand: a library built from another generation would be called with shifted arguments (a stream where a
 # counter belongs) and corrupt device memory silently, so load() refuses anything but this exact number.
-ABI_VERSION = 114
+ABI_VERSION = 115
 
 
 class MirrorHipError(RuntimeError):

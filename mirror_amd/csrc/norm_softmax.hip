@@ -168,7 +168,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_lm_kernel(const float* __re
                                                                const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                                float* __restrict__ mean, float* __restrict__ rstd,
                                                                float* __restrict__ xpm, bf16_t* __restrict__ xpm16, int groups, int m, int rows,
-                                                               int D, long x_bs, int pad, int l, float eps, const float* __restrict__ rmask) {
+                                                               int D, long x_bs, int pad, int l, float eps, const float* __restrict__ rmask,
+                                                               const float* __restrict__ lm_scale) {
+    // lm_scale [batches, m] (may be null): the landmark row of group g leaves as (masked) sum / l * lm_scale[b, g] — l / (valid count) turns
+    // it into the masked mean ([3P] `q_landmarks /= divisor`), so the caller needs no pass over the landmark rows
     // rmask [batches, pad + rows] (may be null; BASELINE config 4's key-padding mask, front-padded like the sequence): rows with a zero
     // entry leave as ZERO rows (to_qkv is bias-free: zero q / k / v, what the package's `t * mask[..., None]` makes of them) and add
     // nothing to their group's sum — the landmark rows are then masked SUMS / l, which the caller scales by l / (valid count)
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_lm_kernel(const float* __re
         if (j0 + 2 * LMU < jend) load_chunk(va, j0 + 2 * LMU);
         do_chunk(vb, j0 + LMU);
     }
-    const float inv = 1.f / (float)l;
+    const float inv = (lm_scale ? lm_scale[(long)b * m + g] : 1.f) / (float)l;
 #pragma unroll
     for (int k = 0; k < LNV_CH; k++) {
         const int c = 256 * k + 4 * lane;
@@ -443,7 +446,7 @@ extern "C" int mh_layernorm_fwd(const void* x, const float* gamma, const float* 
 
 extern "C" int mh_layernorm_fwd_lm(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, void* xpm,
                                    void* xpm_bf16, int batches, int rows, int D, int64_t x_bs, int pad, int l, float eps, const float* row_mask,
-                                   mh_stream s) {
+                                   const float* lm_scale, mh_stream s) {
     MH_REQUIRE(l >= 1 && pad >= 0 && rows >= 1 && (pad + rows) % l == 0, "mh_layernorm_fwd_lm: pad + rows = %d must be a multiple of l = %d", pad + rows, l);
     MH_REQUIRE(D % 4 == 0 && D <= 2048 && x_bs % 4 == 0 && (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0 &&
                    ((uintptr_t)y & 7) == 0 && ((uintptr_t)xpm & 15) == 0 && ((uintptr_t)xpm_bf16 & 7) == 0,
@@ -451,7 +454,7 @@ extern "C" int mh_layernorm_fwd_lm(const float* x, const float* gamma, const flo
     if (batches == 0) return MH_OK;
     const int m = (pad + rows) / l, groups = batches * m;
     dim3 grid(mh_cdiv(groups, 4));
-#define LNL(NC) hipLaunchKernelGGL((layernorm_fwd_lm_kernel<NC>), grid, dim3(256), 0, (hipStream_t)s, x, gamma, beta, (bf16_t*)y, mean, rstd, (float*)xpm, (bf16_t*)xpm_bf16, groups, m, rows, D, (long)x_bs, pad, l, eps, row_mask)
+#define LNL(NC) hipLaunchKernelGGL((layernorm_fwd_lm_kernel<NC>), grid, dim3(256), 0, (hipStream_t)s, x, gamma, beta, (bf16_t*)y, mean, rstd, (float*)xpm, (bf16_t*)xpm_bf16, groups, m, rows, D, (long)x_bs, pad, l, eps, row_mask, lm_scale)
     if (D <= 512) LNL(2); else if (D <= 1024) LNL(4); else LNL(8);
 #undef LNL
     MH_LAUNCH_CHECK("mh_layernorm_fwd_lm");
@@ -511,7 +514,8 @@ __global__ __launch_bounds__(256, LNV_CH == 2 ? 4 : 1) void layernorm_bwd_ws_ker
                                                                const float* __restrict__ fan_cls = nullptr,
                                                                bf16_t* __restrict__ drop_out = nullptr, float drop_p = 0.f, uint64_t drop_seed = 0,
                                                                uint64_t drop_offset = 0, const uint64_t* __restrict__ drop_base = nullptr,
-                                                               int drop_rpb = 0, const float* __restrict__ rmask = nullptr) {
+                                                               int drop_rpb = 0, const float* __restrict__ rmask = nullptr,
+                                                               const float* __restrict__ lm_scale = nullptr) {
     // rmask [batches, ga_pad + rpb] (with gadd; may be null): the forward's row mask — a masked row's output was zero whatever x was, so its
     // total dy (its own and its share of the landmark gradient) is zero
     // DROP (round 5): x is the output of `resid + Dropout_p(Linear(.))` ([3P] to_out = Sequential(Linear, Dropout) + TransLayer's residual
@@ -609,7 +613,8 @@ __global__ __launch_bounds__(256, LNV_CH == 2 ? 4 : 1) void layernorm_bwd_ws_ker
                     dv[u][k] = ld4(dyr + c);
                     xv[u][k] = ld4(x + xo[u] + c);
                     if (acc_dx) ov[u][k] = ld4(dx + xo[u] + c);
-                    if (gadd) dv[u][k] += ld4(gadd + ((long)b * ga_m + (i + ga_pad) / ga_l) * D + c) * ga_scale;
+                    if (gadd) dv[u][k] += ld4(gadd + ((long)b * ga_m + (i + ga_pad) / ga_l) * D + c) *
+                                          (lm_scale ? ga_scale * lm_scale[(long)b * ga_m + (i + ga_pad) / ga_l] : ga_scale);     // (the forward's landmark scale)
                     if (rmask && rmask[(long)b * (ga_pad + rpb) + ga_pad + i] == 0.f) dv[u][k] = (f4){0.f, 0.f, 0.f, 0.f};
                     if constexpr (FAN) {
                         if (i >= 1) dv[u][k] += ld4(fan + ((long)b * (rpb - 1) + (i - 1)) * D + c) * fan_alpha;
@@ -763,7 +768,7 @@ static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const 
                        const void* gadd, int ga_pad, int ga_l, mh_stream s, void* relu_out = nullptr, int relu_first = 0, int relu_rows = 0,
                        float* relu_db = nullptr, const void* fan = nullptr, float fan_alpha = 0.f, const float* fan_cls = nullptr,
                        void* drop_out = nullptr, float drop_p = 0.f, uint64_t drop_seed = 0, uint64_t drop_offset = 0,
-                       const uint64_t* drop_base = nullptr, float* drop_db = nullptr, int drop_rpb = 0, const float* rmask = nullptr);
+                       const uint64_t* drop_base = nullptr, float* drop_db = nullptr, int drop_rpb = 0, const float* rmask = nullptr, const float* lm_scale = nullptr);
 
 extern "C" int mh_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                 void* dx, float* dgamma, float* dbeta, int batches, int rpb, int D, int64_t x_bs,
@@ -779,14 +784,14 @@ extern "C" int mh_layernorm_bwd_lm(const void* dy, const void* x, const float* g
                                    void* dx, float* dgamma, float* dbeta, int batches, int rpb, int D, int64_t x_bs,
                                    int64_t y_bs, int dt_x, int dt_dy, int dt_dx, int acc_dx, float* workspace, int64_t ws_floats,
                                    const void* gadd, int pad, int l, void* relu_out, int relu_first, int relu_rows, float* relu_db,
-                                   const float* row_mask, mh_stream s) {
+                                   const float* row_mask, const float* lm_scale, mh_stream s) {
     MH_REQUIRE(gadd && l >= 1 && pad >= 0 && (pad + rpb) % l == 0 && ((uintptr_t)gadd & 15) == 0, "mh_layernorm_bwd_lm: gadd, l >= 1, (pad + rows) %% l == 0");
     MH_REQUIRE(!relu_out || (dt_x == MH_F32 && relu_first >= 0 && relu_rows >= 0 && relu_first + relu_rows <= rpb && ((uintptr_t)relu_out & 7) == 0 && D % 4 == 0),
                "mh_layernorm_bwd_lm: relu_out needs f32 x and a row range inside the batch");
     MH_REQUIRE(!relu_db || (relu_out && ((uintptr_t)workspace & 15) == 0 && ws_floats >= 3L * D), "mh_layernorm_bwd_lm: relu_db rides on relu_out (workspace of >= 3 D floats)");
     return ln_bwd_impl(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, batches, rpb, D, x_bs, y_bs, dt_x, dt_dy, dt_dx, acc_dx, workspace,
                        ws_floats, gadd, pad, l, s, relu_out, relu_first, relu_rows, relu_db, nullptr, 0.f, nullptr, nullptr, 0.f, 0, 0, nullptr, nullptr, 0,
-                       row_mask);
+                       row_mask, lm_scale);
 }
 
 // mh_layernorm_bwd whose dy rows also receive the other two gradients of a fanned-out LayerNorm output (see FAN above): needs the
@@ -826,7 +831,7 @@ static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const 
                        int64_t y_bs, int dt_x, int dt_dy, int dt_dx, int acc_dx, float* workspace, int64_t ws_floats,
                        const void* gadd, int ga_pad, int ga_l, mh_stream s, void* relu_out, int relu_first, int relu_rows, float* relu_db,
                        const void* fan, float fan_alpha, const float* fan_cls, void* drop_out, float drop_p, uint64_t drop_seed,
-                       uint64_t drop_offset, const uint64_t* drop_base, float* drop_db, int drop_rpb, const float* rmask) {
+                       uint64_t drop_offset, const uint64_t* drop_base, float* drop_db, int drop_rpb, const float* rmask, const float* lm_scale) {
     MH_REQUIRE(D >= 1 && D <= 64 * LN_MAXPL, "mh_layernorm_bwd: D=%d unsupported", D);
     MH_REQUIRE(dt_dx == dt_x, "mh_layernorm_bwd: dx dtype must equal x dtype");
     const long rows = (long)batches * rpb;
@@ -847,7 +852,7 @@ static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const 
         const int rows_per_block = (int)(mh_cdiv(mh_cdiv(rows, nb), 8) * 8);
         nb = mh_cdiv(rows, rows_per_block);
         dim3 g2((unsigned)nb);
-#define LN_BW1(TX, TDY, NC, RL) hipLaunchKernelGGL((layernorm_bwd_ws_kernel<TX, TDY, NC, RL>), g2, dim3(256), 0, (hipStream_t)s, (const TDY*)dy, (const TX*)x, gamma, mean, rstd, (TX*)dx, workspace, (int)rows, rpb, D, (long)x_bs, (long)y_bs, acc_dx, rows_per_block, (const TDY*)gadd, ga_pad, ga_l, (ga_pad + rpb) / ga_l, 1.f / (float)ga_l, (bf16_t*)relu_out, relu_first, relu_rows, relu_cs, (const bf16_t*)nullptr, 0.f, (const float*)nullptr, (bf16_t*)nullptr, 0.f, (uint64_t)0, (uint64_t)0, (const uint64_t*)nullptr, 0, rmask)
+#define LN_BW1(TX, TDY, NC, RL) hipLaunchKernelGGL((layernorm_bwd_ws_kernel<TX, TDY, NC, RL>), g2, dim3(256), 0, (hipStream_t)s, (const TDY*)dy, (const TX*)x, gamma, mean, rstd, (TX*)dx, workspace, (int)rows, rpb, D, (long)x_bs, (long)y_bs, acc_dx, rows_per_block, (const TDY*)gadd, ga_pad, ga_l, (ga_pad + rpb) / ga_l, 1.f / (float)ga_l, (bf16_t*)relu_out, relu_first, relu_rows, relu_cs, (const bf16_t*)nullptr, 0.f, (const float*)nullptr, (bf16_t*)nullptr, 0.f, (uint64_t)0, (uint64_t)0, (const uint64_t*)nullptr, 0, rmask, lm_scale)
 #define LN_BW(TX, TDY) do { if (D <= 512) LN_BW1(TX, TDY, 2, false); else if (D <= 1024) LN_BW1(TX, TDY, 4, false); else LN_BW1(TX, TDY, 8, false); } while (0)
 #define LN_BWF_(TDY, NC) hipLaunchKernelGGL((layernorm_bwd_ws_kernel<float, TDY, NC, false, true>), g2, dim3(256), 0, (hipStream_t)s, (const TDY*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, workspace, (int)rows, rpb, D, (long)x_bs, (long)y_bs, acc_dx, rows_per_block, (const TDY*)nullptr, 0, 1, 0, 0.f, (bf16_t*)nullptr, 0, 0, 0, (const bf16_t*)fan, fan_alpha, fan_cls)
 #define LN_BWF(NC) do { if (dt_dy == MH_F32) LN_BWF_(float, NC); else LN_BWF_(bf16_t, NC); } while (0)

@@ -1184,9 +1184,10 @@ class NormQkvLmFn(Function):
     by the flat row-window kernels (K.gemm_rows_ext) when the geometry allows, else every physical row is multiplied."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, rows, pad, l, w, prec, rmask=None):
+    def forward(ctx, x, gamma, beta, eps, rows, pad, l, w, prec, rmask=None, lscale=None):
         """rmask (f32 [B, pad + rows], BASELINE config 4): the front-padded key-padding mask — masked rows leave the norm as zero rows and
-        stay out of the landmark sums (mh_layernorm_fwd_lm); the caller scales the landmark rows by l / valid count (NystromCoreFn)."""
+        stay out of the landmark sums (mh_layernorm_fwd_lm); lscale (f32 [B, m]) = l / valid count per group: the landmark rows leave
+        as the masked MEANS ([3P] `q_landmarks /= divisor`), NystromCoreFn then gets kmask with a None scale."""
         ctx.relu_slot = getattr(x, "_relu_slot", None)      # x is Fc1SeqFn's sequence (layer 1): see backward
         x = x.contiguous()
         Bn, T, D = x.shape
@@ -1200,8 +1201,8 @@ class NormQkvLmFn(Function):
         rstd = torch.empty_like(mean)
         xs = xe[:P].view(Bn, n_p, D)
         K.layernorm_fwd_lm(x, gamma.detach(), beta.detach(), xs, mean, rstd, None, Bn, rows, D, T * D, pad, l, eps, xpm_bf16=xe[P:],
-                           row_mask=rmask)
-        ctx.rmask = rmask
+                           row_mask=rmask, lm_scale=lscale)
+        ctx.rmask, ctx.lscale = rmask, lscale
         qe = torch.empty((P + E, N3), device=x.device, dtype=bf16)
         qkv = _alias(qe, 0, (Bn, n_p, N3), (n_p * N3, N3, 1))
         fast = (pad > 0 and prec.mma == MH_BF16 and c0 % 256 == 0 and (N3 - c0) % 256 == 0
@@ -1293,15 +1294,15 @@ class NormQkvLmFn(Function):
                 rslot.grad = (G.data_ptr(), dh, rdb)
             K.layernorm_bwd(dy[:, pad:], x, gamma.detach(), mean, rstd, G.view(x.shape), dg, db, Bn, rows, D, T * D, n_p * D,
                             accumulate_dx=True, gadd=gadd, pad=pad, l=l, relu_out=dh, relu_first=1, relu_db=None if rdb is None else rdb[0],
-                            row_mask=ctx.rmask)
+                            row_mask=ctx.rmask, lm_scale=ctx.lscale)
             dx = None
         else:
             dx = torch.empty_like(x)
             if rows < T:
                 dx[:, rows:].zero_()         # only the rows the norm never read (a zeros_like of [B, T, D] is a 268 MB fill at config 4)
             K.layernorm_bwd(dy[:, pad:], x, gamma.detach(), mean, rstd, dx, dg, db, Bn, rows, D, T * D, n_p * D, gadd=gadd, pad=pad, l=l,
-                            row_mask=ctx.rmask)
-        return dx, _gret(gamma, dg, sunk_g), _gret(beta, db, sunk_b), None, None, None, None, dw, None, None
+                            row_mask=ctx.rmask, lm_scale=ctx.lscale)
+        return dx, _gret(gamma, dg, sunk_g), _gret(beta, db, sunk_b), None, None, None, None, dw, None, None, None
 
 
 def ext_rows_alloc(Bn: int, n_p: int, m: int, N3: int, c0: int, device):
@@ -1894,8 +1895,8 @@ class NystromCoreFn(Function):
         ctx.lm_ext = lm_ext is not None
         if kmask is not None:
             mrow, mlm, lscale = kmask
-            lm = K.row_scale(lm if lm.is_contiguous() else lm.contiguous(), lscale)      # sum over the group / (valid count + 1e-8); (the
-            # landmark rows of NormQkvLmFn live behind the sequence with row stride 3 D: an 8 MB copy)
+            if lscale is not None:       # (None: the caller's landmark rows are masked means already — NormQkvLmFn(lscale))
+                lm = K.row_scale(lm if lm.is_contiguous() else lm.contiguous(), lscale)      # sum over the group / (valid count + 1e-8)
         ql, kl = _heads(lm, 0, 2, h), _heads(lm, 1, 2, h)
         m_l = lm.shape[1]
         chain = pm == MH_BF16 and m_l == K.PINV_CHAIN_M    # whole iteration in one launch (pinv_panel.hip)
@@ -2151,7 +2152,7 @@ class NystromCoreFn(Function):
             K.gemm(dS2, kl, out=dql, alpha=scale, accumulate=True, mma=pio)
         dres = _gret(res_w, dres, dres_sunk)
         dres = None if dres is None else dres.view_as(res_w)
-        if de is not None and kmask is None:
+        if de is not None and (kmask is None or (lscale is None and dlm2 is not None)):
             # the merge of the two f32 partial sums is also the cast, written as rows [dq_l | dk_l | 0] behind the sequence rows.
             # Nothing but the landmark rows' own products needs it: NormQkvLmFn.backward runs it (and the landmark rows' data gradient)
             # on a parallel branch beside the data gradient of the sequence rows instead of in front of it
@@ -2163,7 +2164,7 @@ class NystromCoreFn(Function):
             return dqkv, dres, None, None, None, None, None, None, dlm_out
         if dlm2 is not None:
             dlm = K.add(dlm, dlm2, out_dtype=A)
-        if kmask is not None:
+        if kmask is not None and lscale is not None:
             dlm = K.row_scale(dlm, lscale)
         if ctx.lm_ext:         # the landmarks came from the caller: their gradient goes back to it (no scatter into dqkv)
             if de is not None:

@@ -609,7 +609,7 @@ def layernorm_fwd_q8(x, gamma, beta, y, mean, rstd, batches, rpb, D, x_bs, y_bs,
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, batches, rpb, D, x_bs, y_bs, accumulate_dx=False, gadd=None,
-                  pad: int = 0, l: int = 1, relu_out=None, relu_first: int = 0, relu_db=None, fan=None, drop=None, row_mask=None):
+                  pad: int = 0, l: int = 1, relu_out=None, relu_first: int = 0, relu_db=None, fan=None, drop=None, row_mask=None, lm_scale=None):
     """gadd ([batches, (pad + rpb) / l, D], dy's dtype): the gradient of the landmark means layernorm_fwd_lm produced; every dy row also
     receives gadd[b, (i + pad) / l] / l (mh_layernorm_bwd_lm).  relu_out (bf16 [batches, R, D], with gadd only): rows [relu_first,
     relu_first + R) of x are a ReLU's output — their gradient leaves as bf16 (x > 0 ? dx : 0) in relu_out instead of f32 dx;
@@ -629,6 +629,10 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, batches, rpb, D, 
     nbytes = int(_lib.load().mh_layernorm_bwd_workspace_bytes(rows, D))
     if nbytes:          # per-block dgamma / dbeta partials (folded by a second launch) instead of same-address atomics
         ws = torch.empty((nbytes // 4,), device=x.device, dtype=torch.float32)
+    if lm_scale is not None:
+        _chk(lm_scale)
+        if gadd is None or lm_scale.dtype != torch.float32 or not lm_scale.is_contiguous() or lm_scale.numel() != batches * ((pad + rpb) // l):
+            raise MirrorHipError("layernorm_bwd: lm_scale is a contiguous f32 [batches, (pad + rows) / l] and rides on the landmark form (gadd)")
     if row_mask is not None:
         _chk(row_mask)
         if gadd is None or row_mask.dtype != torch.float32 or not row_mask.is_contiguous() or row_mask.numel() != batches * (pad + rpb):
@@ -640,7 +644,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, batches, rpb, D, 
         _lib.call("mh_layernorm_bwd_lm", _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma), _p(dbeta),
                   batches, rpb, D, x_bs, y_bs, dt(x), dt(dy), dt(dx), int(accumulate_dx), _p(ws) if ws is not None else 0,
                   ws.numel() if ws is not None else 0, _p(gadd), int(pad), int(l), _p(relu_out), int(relu_first),
-                  0 if relu_out is None else int(relu_out.shape[1]), _p(relu_db), _p(row_mask), stream=_stream())
+                  0 if relu_out is None else int(relu_out.shape[1]), _p(relu_db), _p(row_mask), _p(lm_scale), stream=_stream())
         return
     if drop is not None:
         dout, p_, seed_, off_, base_, ddb = drop
@@ -681,10 +685,12 @@ def layernorm_bwd_fan_ok(dy, x, dx, src, cls, batches: int, rpb: int, D: int) ->
             and all(t.data_ptr() % 16 == 0 for t in (dy, x, dx)) and src.data_ptr() % 8 == 0)
 
 
-def layernorm_fwd_lm(x, gamma, beta, y, mean, rstd, xpm, batches, rows, D, x_bs, pad, l, eps, xpm_bf16=None, row_mask=None):
+def layernorm_fwd_lm(x, gamma, beta, y, mean, rstd, xpm, batches, rows, D, x_bs, pad, l, eps, xpm_bf16=None, row_mask=None, lm_scale=None):
     """LayerNorm (f32 in, bf16 out behind `pad` zero rows, which this launch writes) + the landmark means xpm [batches, (pad + rows) / l, D]
     (f32) of its output rows (mh_layernorm_fwd_lm)."""
-    _chk(x, gamma, beta, y, mean, rstd, xpm, xpm_bf16, row_mask)
+    _chk(x, gamma, beta, y, mean, rstd, xpm, xpm_bf16, row_mask, lm_scale)
+    if lm_scale is not None and not (lm_scale.dtype == torch.float32 and lm_scale.is_contiguous() and lm_scale.numel() == batches * ((pad + rows) // l)):
+        raise MirrorHipError("layernorm_fwd_lm: lm_scale is a contiguous f32 [batches, (pad + rows) / l]")
     if row_mask is not None and not (row_mask.dtype == torch.float32 and row_mask.is_contiguous() and row_mask.numel() == batches * (pad + rows)):
         raise MirrorHipError("layernorm_fwd_lm: row_mask is a contiguous f32 [batches, pad + rows]")
     if not (x.dtype == torch.float32 and y.dtype == torch.bfloat16 and y.is_contiguous() and (xpm is not None or xpm_bf16 is not None)
@@ -694,7 +700,7 @@ def layernorm_fwd_lm(x, gamma, beta, y, mean, rstd, xpm, batches, rows, D, x_bs,
     if xpm_bf16 is not None and not (xpm_bf16.dtype == torch.bfloat16 and xpm_bf16.is_contiguous() and xpm_bf16.numel() == n_lm):
         raise MirrorHipError("layernorm_fwd_lm: xpm_bf16 must be a contiguous bf16 tensor of batches * (pad + rows) / l * D elements")
     _lib.call("mh_layernorm_fwd_lm", _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), _p(xpm), _p(xpm_bf16), batches, rows, D, x_bs, int(pad),
-              int(l), eps, _p(row_mask), stream=_stream())
+              int(l), eps, _p(row_mask), _p(lm_scale), stream=_stream())
 
 
 def softmax_fwd(x: torch.Tensor, y: Optional[torch.Tensor] = None, out_dtype=None) -> torch.Tensor:

@@ -208,7 +208,10 @@ class TransLayer(nn.Module):
             # q | k landmarks of [3P] NystromAttention are the same projection's result for those extra rows (Fn.NormQkvLmFn).  With a
             # key-padding mask (round 5) the same launch zeroes the masked rows and keeps them out of the landmark sums: no row-scale
             # pass over the norm's output, no landmark pass over q | k (NystromCoreFn scales the sums by l / valid count)
-            qkv, lm = Fn.NormQkvLmFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps, n, pad, l, a.to_qkv.weight, prec, mrow)
+            lsc = None if kmask is None else kmask[2]
+            qkv, lm = Fn.NormQkvLmFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps, n, pad, l, a.to_qkv.weight, prec, mrow, lsc)
+            if kmask is not None:
+                kmask = (kmask[0], kmask[1], None)      # the landmark rows are masked means already
         else:
             xp = Fn.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps, pad=pad, out_dtype=prec.act,
                                q8_key=Fn.fp8_site_key(a.to_qkv.weight, prec) if prec.fp8_fwd else None)
