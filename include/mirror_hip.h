@@ -288,6 +288,12 @@ int mh_softmax_masked_bwd(const void* y, const void* dy, void* dx, const float* 
                           int h, int R, int cols, int dt_y, int dt_d, mh_stream s);
 /* y[r, :] = x[r, :] * scale[r] (masked rows zeroed before the bias-free to_qkv; masked-mean landmarks = sum / (count + 1e-8)) */
 int mh_row_scale(const void* x, const float* scale, void* y, int64_t rows, int D, int dt, mh_stream s);
+/* Key-padding plan of one Nystrom layer in one launch (BASELINE config 4; the `mask` argument of [3P] NystromAttention.forward).
+ * mask: [B, n_src] bool bytes (non-zero = real patch).  The layer's sequence is [pad zeros | lead ones (cls) | mask |
+ * mask[:, :wrap] (the square-pad rows of models/mirror.py:357-360)], pad + lead + n_src + wrap = m * l.  Out, all f32:
+ * mrow [B, m*l] row mask, mlm [B, m] = (valid rows of the group > 0), lscale [B, m] = l * (1 / (count + 1e-8)). */
+int mh_keymask_plan(const unsigned char* mask, float* mrow, float* mlm, float* lscale, int64_t B, int64_t n_src, int lead, int wrap,
+                    int pad, int l, mh_stream s);
 
 /* ---------------------------------------------------------------- Nystrom pieces ([3P], called at models/mirror.py:312)
  * qkv: [B, n_p, 3D] (q | k | v column blocks, heads are dh-wide column slices).

@@ -174,6 +174,7 @@ _SIGS = {
     "mh_softmax_masked_fwd": [P, P, P, P, L, I, I, I, I, I],
     "mh_softmax_masked_bwd": [P, P, P, P, P, L, I, I, I, I, I],
     "mh_row_scale": [P, P, P, L, I, I],
+    "mh_keymask_plan": [P, P, P, P, L, L, I, I, I, I],
     "mh_kl_fwd": [P, P, P, L, F],
     "mh_kl_bwd": [P, P, P, P, P, L, F],
     "mh_symkl_fwd": [P, P, P, I, I, F],
@@ -196,7 +197,7 @@ _lib = None
 # The ABI generation this binding was written against (mh_version() of csrc/errors.cpp).  _SIGS above restates the argument lists of
 # include/mirror_hip.h by hand: a library built from another generation would be called with shifted arguments (a stream where a
 # counter belongs) and corrupt device memory silently, so load() refuses anything but this exact number.
-ABI_VERSION = 115
+ABI_VERSION = 116
 
 
 class MirrorHipError(RuntimeError):

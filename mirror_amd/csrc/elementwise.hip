@@ -805,6 +805,46 @@ extern "C" int mh_row_scale(const void* x, const float* scale, void* y, int64_t 
     return MH_OK;
 }
 
+// ------------------------------------------------------------------ key-padding plan of a Nystrom layer (BASELINE config 4)
+// From the [B, n_src] bool mask of the patches, everything a layer's masked attention needs, in one launch (was ~10 ATen
+// launches per layer): the f32 row mask of the front-padded sequence [pad zeros | lead ones | mask | mask[:, :wrap]], and per
+// landmark group of l rows the valid flag (count > 0) and l * (1 / (count + 1e-8)).  One thread per group.
+__global__ __launch_bounds__(256) void keymask_plan_kernel(const unsigned char* __restrict__ mask, float* __restrict__ mrow,
+                                                           float* __restrict__ mlm, float* __restrict__ lscale, long B, long n_src,
+                                                           int lead, int wrap, int pad, int l, long m) {
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= B * m) return;
+    const long b = g / m, j0 = (g % m) * l;
+    const unsigned char* mb = mask + b * n_src;
+    float* out = mrow + b * (m * l) + j0;
+    float cnt = 0.f;
+    for (int i = 0; i < l; ++i) {
+        const long j = j0 + i - pad;                         // position in [lead ones | mask | wrapped head of the mask]
+        float v = 0.f;
+        if (j >= 0) {
+            if (j < lead) v = 1.f;
+            else if (j - lead < n_src) v = mb[j - lead] ? 1.f : 0.f;
+            else v = mb[j - lead - n_src] ? 1.f : 0.f;
+        }
+        out[i] = v;
+        cnt += v;
+    }
+    mlm[g] = cnt > 0.f ? 1.f : 0.f;
+    lscale[g] = (float)l * (1.0f / (cnt + 1e-8f));
+}
+extern "C" int mh_keymask_plan(const unsigned char* mask, float* mrow, float* mlm, float* lscale, int64_t B, int64_t n_src, int lead,
+                               int wrap, int pad, int l, mh_stream s) {
+    if (B == 0) return MH_OK;
+    MH_REQUIRE(l > 0 && lead >= 0 && wrap >= 0 && pad >= 0 && wrap <= n_src, "mh_keymask_plan: l > 0, 0 <= wrap <= n_src, lead / pad >= 0");
+    const long n_tot = (long)pad + lead + n_src + wrap;
+    MH_REQUIRE(n_tot % l == 0, "mh_keymask_plan: pad + lead + n_src + wrap = %ld is no multiple of l = %d", n_tot, l);
+    const long m = n_tot / l;
+    hipLaunchKernelGGL(keymask_plan_kernel, dim3((unsigned)mh_cdiv(B * m, 256)), dim3(256), 0, (hipStream_t)s, mask, mrow, mlm, lscale, (long)B,
+                       (long)n_src, lead, wrap, pad, l, m);
+    MH_LAUNCH_CHECK("mh_keymask_plan");
+    return MH_OK;
+}
+
 // ------------------------------------------------------------------ data feed: fixed-N resampling (datasets/dataset_pretrain.py:150-167)
 // out[r, :] = src[row[r], :]: the gather behind `wsi_feature[sampled_indices]`, for a whole batch at once (row = global row
 // index into the bank of concatenated slides).  One wave per row, 16-byte pieces; rows are F * esz bytes.

@@ -1329,6 +1329,39 @@ def ext_rows_of(dqkv, dlm, P: int, E: int, N3: int, c0: int, copy_lm: bool = Tru
     return de
 
 
+_KEYMASK_PLAN = True     # (test hook, round 5) the key-padding plan of a layer from ONE launch, shared by layers of one geometry
+class KeyMask:
+    """Key-padding mask of a token sequence [lead ones (cls) | src | src[:, :wrap] (square-pad rows)], src [B, n_src] bool
+    (True = real patch): the `mask` argument of [3P] NystromAttention.forward as mirror_amd's TransLayer takes it (BASELINE
+    config 4; the reference never passes one, models/mirror.py:312).  plan(pad, l) = (row mask of the front-padded sequence,
+    landmark-group valid flag, l / (valid count + 1e-8)), all f32, from one launch (K.keymask_plan) and kept per (pad, l):
+    layers of the same geometry (layer1 / layer2 of the encoder, both retention blocks) share it."""
+
+    def __init__(self, src: torch.Tensor, lead: int = 0, wrap: int = 0):
+        self.src = src if src.dtype == torch.bool else src.to(torch.bool)
+        self.src = self.src.contiguous()
+        self.lead, self.wrap = int(lead), int(wrap)
+        self.shape = (src.shape[0], self.lead + src.shape[1] + self.wrap)
+        self._plans = {}
+
+    def dense(self) -> torch.Tensor:
+        parts = ([torch.ones_like(self.src[:, :1]).expand(-1, self.lead)] if self.lead else []) + [self.src] + (
+            [self.src[:, :self.wrap]] if self.wrap else [])
+        return torch.cat(parts, dim=1) if len(parts) > 1 else self.src
+
+    def plan(self, pad: int, l: int):  # noqa: E741
+        key = (pad, l)
+        if key not in self._plans:
+            if _KEYMASK_PLAN:
+                self._plans[key] = K.keymask_plan(self.src, self.lead, self.wrap, pad, l)
+            else:
+                n = self.shape[1]
+                mrow = torch.nn.functional.pad(self.dense().to(torch.float32), (pad, 0), value=0.0).contiguous()
+                cnt = mrow.reshape(mrow.shape[0], (n + pad) // l, l).sum(-1)
+                self._plans[key] = (mrow, (cnt > 0).float().contiguous(), (float(l) / (cnt + 1e-8)).contiguous())
+        return self._plans[key]
+
+
 _LM_ROWS = True       # test hook (tests/test_fused_epilogue_gpu.py): False = the landmark kernels on q | k instead of NormQkvLmFn
 _RELU_SQUARE_PAD = True      # (test hook, round 5) ... also when the sequence carries square-pad rows (N no square: config 4, template)
 _RELU_IN_LN_BWD = True      # (test hook, round 5) _fc1's ReLU backward inside layer 1's LayerNorm backward

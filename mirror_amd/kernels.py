@@ -764,6 +764,22 @@ def row_scale(x: torch.Tensor, scale: torch.Tensor, out: Optional[torch.Tensor] 
     return out
 
 
+def keymask_plan(mask: torch.Tensor, lead: int, wrap: int, pad: int, l: int):  # noqa: E741
+    """(mrow [B, m*l], mlm [B, m], lscale [B, m]) f32 for the sequence [pad zeros | lead ones | mask | mask[:, :wrap]] (mh_keymask_plan)."""
+    _chk(mask)
+    _contig(mask, "key-padding mask")
+    assert mask.dtype == torch.bool and mask.dim() == 2
+    B, n_src = mask.shape
+    n_tot = pad + lead + n_src + wrap
+    assert l > 0 and n_tot % l == 0 and 0 <= wrap <= n_src, "the padded sequence must be m groups of l rows"
+    m = n_tot // l
+    mrow = torch.empty((B, n_tot), device=mask.device, dtype=torch.float32)
+    mlm = torch.empty((B, m), device=mask.device, dtype=torch.float32)
+    lsc = torch.empty((B, m), device=mask.device, dtype=torch.float32)
+    _lib.call("mh_keymask_plan", _p(mask), _p(mrow), _p(mlm), _p(lsc), B, n_src, lead, wrap, pad, l, stream=_stream())
+    return mrow, mlm, lsc
+
+
 def l2norm_fwd(x2d_rows: torch.Tensor, rows: int, D: int, x_rs: int, eps: float, out_dtype):
     _chk(x2d_rows)
     y = torch.empty((rows, D), device=x2d_rows.device, dtype=out_dtype)

@@ -189,7 +189,7 @@ class TransLayer(nn.Module):
                                      pinv_iterations=6, residual=True, dropout=0.1)
 
     def forward(self, x, prec: Precision, mask=None):
-        """mask: optional [B, n] bool key-padding mask (True = real token), the `mask` argument of [3P]
+        """mask: optional [B, n] bool key-padding mask (True = real token) or an Fn.KeyMask, the `mask` argument of [3P]
         NystromAttention.forward that the reference never passes (models/mirror.py:312); BASELINE config 4 uses it for
         variable-length slides.  It is front-padded with False like the sequence."""
         a = self.attn
@@ -198,11 +198,11 @@ class TransLayer(nn.Module):
         l = math.ceil(n / m)  # noqa: E741
         lm = kmask = mrow = None
         if mask is not None:
-            if mask.shape != x.shape[:2]:
-                raise ValueError(f"key-padding mask must be {tuple(x.shape[:2])}, got {tuple(mask.shape)}")
-            mrow = torch.nn.functional.pad(mask.to(x.device, torch.float32), (pad, 0), value=0.0).contiguous()
-            cnt = mrow.reshape(mrow.shape[0], (n + pad) // l, l).sum(-1)
-            kmask = (mrow, (cnt > 0).float().contiguous(), (float(l) / (cnt + 1e-8)).contiguous())
+            km = mask if isinstance(mask, Fn.KeyMask) else Fn.KeyMask(mask.to(x.device))
+            if tuple(km.shape) != tuple(x.shape[:2]):
+                raise ValueError(f"key-padding mask must be {tuple(x.shape[:2])}, got {tuple(km.shape)}")
+            kmask = km.plan(pad, l)     # (row mask, landmark valid flag, l / valid count): one launch, shared by layers of one geometry
+            mrow = kmask[0]
         if (mask is None or _LM_MASKED) and Fn.layer_norm_landmarks_ok(x, n, pad, l, prec):
             # the norm also leaves the landmark means of its output behind the padded sequence; to_qkv is linear and bias-free, so the
             # q | k landmarks of [3P] NystromAttention are the same projection's result for those extra rows (Fn.NormQkvLmFn).  With a
@@ -266,8 +266,7 @@ class FeatureTransMIL(nn.Module):
         seq = Fn.probe_point(Fn.fc1_seq(h, self._fc1[0].weight, self._fc1[0].bias, self.cls_token, add, prec), "wsi_fc1_out")
         smask = None
         if mask is not None:
-            mask = mask.to(h.device, torch.bool)
-            smask = torch.cat([torch.ones_like(mask[:, :1]), mask, mask[:, :add]], dim=1)
+            smask = Fn.KeyMask(mask.to(h.device, torch.bool), lead=1, wrap=add)
         seq = self.layer1(seq, prec, smask)
         seq = self.pos_layer(seq, side, side)
         seq = self.layer2(seq, prec, smask)
@@ -422,8 +421,7 @@ class FeatureTransMILHybrid(FeatureTransMIL):
                               self.retention_gene_embed, 1, prec)
         kp = None
         if key_padding_mask is not None:
-            kpm = key_padding_mask.to(h.device, torch.bool)
-            kp = torch.cat([torch.ones_like(kpm[:, :1]), kpm], dim=1)
+            kp = Fn.KeyMask(key_padding_mask.to(h.device, torch.bool), lead=1)
         for blk in self.retention_blocks:
             r = blk(r, prec, kp)
         r = Fn.layer_norm(r, self.retention_norm.weight, self.retention_norm.bias, self.retention_norm.eps,

@@ -1846,3 +1846,35 @@ def test_fp8_delayed_scaling_quantisation_uses_last_steps_amax_and_rotates_its_r
     tick.fill_(2.0)
     q3, sc3 = K.quant_fp8_delayed(x1, ring, tick, margin=1.0)
     assert abs(float(sc3) - got_amax / 448.0) <= 1e-6 * got_amax and int(ring[0]) == 0
+
+
+@pytest.mark.parametrize("B,n_src,lead,wrap,l", [(8, 8192, 1, 89, 22), (2, 100, 1, 0, 7), (3, 64, 0, 0, 4), (2, 37, 1, 12, 5), (1, 5, 1, 4, 3)])
+def test_keymask_plan_one_launch_equals_the_composed_plan(B, n_src, lead, wrap, l):  # noqa: E741
+    """mh_keymask_plan (BASELINE config 4): row mask of the front-padded sequence [pad zeros | cls | mask | mask[:, :wrap]],
+    landmark-group valid flags and l / (valid count + 1e-8), bit for bit what the ATen composition in Fn.KeyMask.plan gives
+    (the `mask` handling of [3P] NystromAttention.forward); an all-masked group keeps flag 0 and the huge finite scale."""
+    from mirror_amd import functional as Fn
+    g = torch.Generator().manual_seed(B * 1000 + n_src)
+    mask = torch.rand(B, n_src, generator=g) > 0.4
+    mask[0, : min(n_src, 3 * l)] = False                    # whole groups without a valid row
+    mask = mask.to(DEV)
+    n = lead + n_src + wrap
+    pad = (l - n % l) % l
+    km = Fn.KeyMask(mask, lead=lead, wrap=wrap)
+    assert tuple(km.shape) == (B, n)
+    got = km.plan(pad, l)
+    assert km.plan(pad, l) is got                           # kept per geometry: the next layer launches nothing
+    Fn._KEYMASK_PLAN = False
+    try:
+        ref = Fn.KeyMask(mask, lead=lead, wrap=wrap).plan(pad, l)
+    finally:
+        Fn._KEYMASK_PLAN = True
+    for a, b, name in zip(got, ref, ("mrow", "mlm", "lscale")):
+        assert a.shape == b.shape and a.dtype == b.dtype == torch.float32, name
+        assert torch.equal(a, b), (name, float((a - b).abs().max()))
+    assert bool(torch.isfinite(got[2]).all())
+    if n_src >= 4 * l:
+        assert float(got[1][0].min()) == 0.0 and float(got[2][0].max()) > 1e8
+    with pytest.raises(K.MirrorHipError):
+        K._lib.call("mh_keymask_plan", mask.data_ptr(), got[0].data_ptr(), got[1].data_ptr(), got[2].data_ptr(), B, n_src, lead, wrap, pad + 1, l,
+                    stream=torch.cuda.current_stream().cuda_stream)
