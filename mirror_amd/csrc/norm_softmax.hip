@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const TX* __rest
 // LayerNorm's backward (mh_layernorm_bwd gadd) instead of a read-modify-write of dqkv.
 // One wave per (batch, group): its l rows in chunks of LMU rows in flight; pad rows are written as zeros here.
 #define LMU 2
-template <int LNV_CH>
+template <int LNV_CH, int SPLIT>
 __global__ __launch_bounds__(256) void layernorm_fwd_lm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                                float* __restrict__ mean, float* __restrict__ rstd,
@@ -175,9 +175,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_lm_kernel(const float* __re
     // rmask [batches, pad + rows] (may be null; BASELINE config 4's key-padding mask, front-padded like the sequence): rows with a zero
     // entry leave as ZERO rows (to_qkv is bias-free: zero q / k / v, what the package's `t * mask[..., None]` makes of them) and add
     // nothing to their group's sum — the landmark rows are then masked SUMS / l, which the caller scales by l / (valid count)
-    const int lane = threadIdx.x & 63;
-    const int grp = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (grp >= groups) return;
+    // SPLIT waves share a group (its rows in SPLIT consecutive runs, partial landmark sums met in LDS): with few long groups (config 4:
+    // 2048 groups of 33 rows) one wave per group leaves 8 waves per CU walking rows one after the other (2.4 TB/s)
+    __shared__ f4 part[SPLIT > 1 ? 4 : 1][LNV_CH][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = wave % SPLIT;
+    const int grp = blockIdx.x * (4 / SPLIT) + wave / SPLIT;
+    if (SPLIT == 1 && grp >= groups) return;          // SPLIT > 1: the host launches whole blocks only (groups % (4 / SPLIT) == 0)
     const int b = grp / m, g = grp - b * m;
     const long n_p = (long)pad + rows;
     f4 gm[LNV_CH], bt[LNV_CH], acc[LNV_CH];
@@ -190,13 +193,16 @@ __global__ __launch_bounds__(256) void layernorm_fwd_lm_kernel(const float* __re
     }
     // the rows of chunk c + 1 are requested before chunk c is reduced and stored: with one chunk in flight the kernel alternated
     // between a load phase and a compute / store phase (4.5 TB/s)
-    const int jend = (g + 1) * l;
-    auto load_chunk = [&](f4 (&v)[LMU][LNV_CH], int j0) {
+    const int per = (l + SPLIT - 1) / SPLIT;
+    const int jbeg = g * l + sub * per;
+    const int jend = min(jbeg + per, (g + 1) * l);
+    auto load_chunk = [&](f4 (&v)[LMU][LNV_CH], float (&kp)[LMU], int j0) {
 #pragma unroll
         for (int u = 0; u < LMU; u++) {
             const int j = j0 + u;
             const bool live = j < jend && j >= pad;
             const float* xr = x + b * x_bs + (long)(live ? j - pad : 0) * D;
+            kp[u] = (rmask && live) ? rmask[b * n_p + j] : 1.f;        // asked for with the row, not when the row is normalised
 #pragma unroll
             for (int k = 0; k < LNV_CH; k++) {
                 const int c = 256 * k + 4 * lane;
@@ -204,7 +210,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_lm_kernel(const float* __re
             }
         }
     };
-    auto do_chunk = [&](f4 (&v)[LMU][LNV_CH], int j0) {
+    auto do_chunk = [&](f4 (&v)[LMU][LNV_CH], float (&kp)[LMU], int j0) {
 #pragma unroll
         for (int u = 0; u < LMU; u++) {
             const int j = j0 + u;
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_lm_kernel(const float* __re
                 }
             }
             const float rs = rsqrtf(wave_sum(q) / D + eps);
-            const bool keep = !rmask || rmask[b * n_p + j] != 0.f;
+            const bool keep = kp[u] != 0.f;
 #pragma unroll
             for (int k = 0; k < LNV_CH; k++) {
                 const int c = 256 * k + 4 * lane;
@@ -248,13 +254,26 @@ __global__ __launch_bounds__(256) void layernorm_fwd_lm_kernel(const float* __re
         }
     };
     f4 va[LMU][LNV_CH], vb[LMU][LNV_CH];
-    load_chunk(va, g * l);
-    for (int j0 = g * l; j0 < jend; j0 += 2 * LMU) {
-        if (j0 + LMU < jend) load_chunk(vb, j0 + LMU);
-        do_chunk(va, j0);
+    float ka[LMU], kb[LMU];
+    load_chunk(va, ka, jbeg);
+    for (int j0 = jbeg; j0 < jend; j0 += 2 * LMU) {
+        if (j0 + LMU < jend) load_chunk(vb, kb, j0 + LMU);
+        do_chunk(va, ka, j0);
         if (j0 + LMU >= jend) break;
-        if (j0 + 2 * LMU < jend) load_chunk(va, j0 + 2 * LMU);
-        do_chunk(vb, j0 + LMU);
+        if (j0 + 2 * LMU < jend) load_chunk(va, ka, j0 + 2 * LMU);
+        do_chunk(vb, kb, j0 + LMU);
+    }
+    if (SPLIT > 1) {
+        if (sub) {
+#pragma unroll
+            for (int k = 0; k < LNV_CH; k++) part[wave][k][lane] = acc[k];
+        }
+        __syncthreads();
+        if (sub) return;
+        for (int w = 1; w < SPLIT; w++) {
+#pragma unroll
+            for (int k = 0; k < LNV_CH; k++) acc[k] += part[wave + w][k][lane];
+        }
     }
     const float inv = (lm_scale ? lm_scale[(long)b * m + g] : 1.f) / (float)l;
 #pragma unroll
@@ -453,10 +472,20 @@ extern "C" int mh_layernorm_fwd_lm(const float* x, const float* gamma, const flo
                "mh_layernorm_fwd_lm: D %% 4 == 0, D <= 2048 and aligned buffers (D=%d)", D);
     if (batches == 0) return MH_OK;
     const int m = (pad + rows) / l, groups = batches * m;
-    dim3 grid(mh_cdiv(groups, 4));
-#define LNL(NC) hipLaunchKernelGGL((layernorm_fwd_lm_kernel<NC>), grid, dim3(256), 0, (hipStream_t)s, x, gamma, beta, (bf16_t*)y, mean, rstd, (float*)xpm, (bf16_t*)xpm_bf16, groups, m, rows, D, (long)x_bs, pad, l, eps, row_mask, lm_scale)
+    // waves per group: enough waves to fill the chip (>= 16 per CU) while a wave keeps >= 4 rows
+    // (config 4, B = 8: 2048 groups of 33 rows -> 2 waves each, 49 -> 38 us alone; c2's 4096 groups of 17 rows stay one wave each: 38.5 us vs 41)
+    int split = 1;
+    while (split < 4 && (long)groups * split < 4096 && l >= 8 * split && groups % (4 / (2 * split)) == 0) split *= 2;
+#ifdef MH_EXP
+    if (const char* e = getenv("MH_LN_LM_SPLIT")) split = atoi(e);      // tools/exp/time_ln_lm.py, tools/exp/ab_ln_lm_split.sh
+#endif
+    MH_REQUIRE((split == 1 || split == 2 || split == 4) && groups % (4 / split) == 0, "mh_layernorm_fwd_lm: %d waves per group with %d groups", split, groups);
+    dim3 grid(mh_cdiv(groups, 4 / split));
+#define LNL_(NC, SP) hipLaunchKernelGGL((layernorm_fwd_lm_kernel<NC, SP>), grid, dim3(256), 0, (hipStream_t)s, x, gamma, beta, (bf16_t*)y, mean, rstd, (float*)xpm, (bf16_t*)xpm_bf16, groups, m, rows, D, (long)x_bs, pad, l, eps, row_mask, lm_scale)
+#define LNL(NC) do { if (split == 1) LNL_(NC, 1); else if (split == 2) LNL_(NC, 2); else LNL_(NC, 4); } while (0)
     if (D <= 512) LNL(2); else if (D <= 1024) LNL(4); else LNL(8);
 #undef LNL
+#undef LNL_
     MH_LAUNCH_CHECK("mh_layernorm_fwd_lm");
     return MH_OK;
 }

@@ -181,12 +181,13 @@ def test_whole_model_train_step_fused_epilogues_equal_composed():
     print("fused vs composed: losses", l1, l2, "worst relative gradient difference", worst)
 
 
-@pytest.mark.parametrize("Bn,n,D,m", [(3, 1025, 512, 256), (2, 300, 256, 128)])
+@pytest.mark.parametrize("Bn,n,D,m", [(3, 1025, 512, 256), (2, 300, 256, 128), (2, 4200, 512, 256), (4, 2300, 512, 256)])
 def test_norm_qkv_with_landmark_rows_and_its_backward(Bn, n, D, m):
     """Fn.NormQkvLmFn (LayerNorm + to_qkv with the landmark means as extra rows of the same products: mh_layernorm_fwd_lm,
     the flat row-window GEMM with mh_gemm_desc.window_batches, mh_layernorm_bwd_lm with a bf16 addend) against the composed
     LayerNorm -> to_qkv -> explicit group means of q | k through torch autograd.  (3, 1025, 512, 256) runs the flat
-    row-window kernels (3 ragged rows through the weight-streaming kernel), (2, 300, 256, 128) the generic products."""
+    row-window kernels (3 ragged rows through the weight-streaming kernel), (2, 300, 256, 128) the generic products; (2, 4200, ..)
+    and (4, 2300, ..) have few long landmark groups (l = 17 / 9): four / two waves share a group in mh_layernorm_fwd_lm."""
     import math
     from mirror_amd import functional as Fn
     prec = Fn.POLICIES["bf16"]
