@@ -198,12 +198,13 @@ __global__ __launch_bounds__(256) void ppeg_strip2_kernel(const float* __restric
 #define PR_T 32       // grid rows per strip of ppeg_rows2_kernel
 #endif
 __global__ __launch_bounds__(256) void ppeg_rows2_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ merged,
-                                                         const float* __restrict__ bsum, int S, int D, int flip, int nb) {
+                                                         const float* __restrict__ bsum, int S, int D, int flip, int nb, int pr) {
+    // pr = grid rows per strip, chosen by the host so that the launch is whole rounds of resident workgroups (mh_ppeg_fwd)
     // 1-D grid, XCD-aware: workgroup L runs on XCD L % 8 and neighbours in time are L +- 8.  Six of the ten columns a thread loads per
     // row belong to the x-tiles next to its own, so the x-tiles of one (batch, strip) are walked by ONE XCD back to back (their halo
     // columns then come out of that XCD's L2; with x-tiles on consecutive workgroup ids every halo column was fetched from the fabric
     // by two or three XCDs: 73.2 -> 65.5 us alone on the chip at B = 16, S = 64, D = 512; 2 x 64-row strips or 2-pixel tiles: 91 / 68 us).  groups = (batch, strip) pairs, a multiple of 8 or the plain order.
-    const int tiles_x = (S + P2_T - 1) / P2_T, strips = (S + PR_T - 1) / PR_T;
+    const int tiles_x = (S + P2_T - 1) / P2_T, strips = (S + pr - 1) / pr;
     const int per_cb = tiles_x * strips * nb;
     const int cb = blockIdx.x / per_cb, L = blockIdx.x % per_cb;
     const int c = 2 * (cb * 256 + threadIdx.x);
@@ -211,8 +212,8 @@ __global__ __launch_bounds__(256) void ppeg_rows2_kernel(const float* __restrict
     int xt, grp;
     if ((strips * nb) % 8 == 0) { const int q = L >> 3; xt = q % tiles_x; grp = (q / tiles_x) * 8 + (L & 7); }
     else { xt = L % tiles_x; grp = L / tiles_x; }
-    const int y0 = (grp % strips) * PR_T, x0 = xt * P2_T;
-    const int rows = min(PR_T, S - y0);
+    const int y0 = (grp % strips) * pr, x0 = xt * P2_T;
+    const int rows = min(pr, S - y0);
     const long b = grp / strips;
     const bool first = (y0 == 0 && x0 == 0);
     const long n = 1 + (long)S * S;
@@ -278,8 +279,25 @@ extern "C" int mh_ppeg_fwd(const void* x, void* y, const float* merged, const fl
     if (B == 0) return MH_OK;
     if (dt_x == MH_F32 && dt_y == MH_F32 && D % 2 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)merged | (uintptr_t)bsum) & 7) == 0) {
 #if P2_FORM
-        dim3 g2(mh_cdiv(D / 2, 256) * mh_cdiv(S, PR_T) * mh_cdiv(S, P2_T) * B);
-        hipLaunchKernelGGL(ppeg_rows2_kernel, g2, dim3(256), 0, (hipStream_t)s, (const float*)x, (float*)y, merged, bsum, S, D, flip, B);
+        // rows per strip: two workgroups of ~200 VGPRs fit a CU, so the launch runs in rounds of 512; fewest (rounds x row steps of a
+        // strip, 6 of them halo), PR_T rows when that is as good (c2: 2 strips of 32 rows = 512 workgroups; config 4's 91 x 91 grid at B = 8:
+        // 3 strips were 552 workgroups = a second round for 40 of them)
+        int pr = PR_T;
+        {
+            const long per = (long)mh_cdiv(D / 2, 256) * mh_cdiv(S, P2_T) * B;
+            long best = -1;
+            for (int st = 1; st <= mh_cdiv(S, 8); st++) {
+                const int rows = mh_cdiv(S, st);
+                if (rows > 64) continue;
+                const long cost = mh_cdiv(per * mh_cdiv(S, rows), 512) * (rows + 6);
+                if (best < 0 || cost < best || (cost == best && rows == PR_T)) { best = cost; pr = rows; }
+            }
+#ifdef MH_EXP
+            if (const char* e = getenv("MH_PPEG_PR")) pr = atoi(e);      // tools/exp/ppeg_rows_per_strip.sh
+#endif
+        }
+        dim3 g2(mh_cdiv(D / 2, 256) * mh_cdiv(S, pr) * mh_cdiv(S, P2_T) * B);
+        hipLaunchKernelGGL(ppeg_rows2_kernel, g2, dim3(256), 0, (hipStream_t)s, (const float*)x, (float*)y, merged, bsum, S, D, flip, B, pr);
 #else
         dim3 g2(mh_cdiv(D / 2, 256), mh_cdiv(S, PY_T) * mh_cdiv(S, P2_T), B);
         hipLaunchKernelGGL(ppeg_strip2_kernel, g2, dim3(256), 0, (hipStream_t)s, (const float*)x, (float*)y, merged, bsum, S, D, flip);
@@ -380,7 +398,9 @@ __global__ __launch_bounds__(256) void ppeg_wgrad_kernel(const TX* __restrict__ 
 #endif
 template <typename TX, typename TO>
 __global__ __launch_bounds__(256) void ppeg_wgrad_strip_kernel(const TX* __restrict__ x, const TO* __restrict__ dout,
-                                                               float* __restrict__ dmerged, float* __restrict__ dbsum, int S, int D) {
+                                                               float* __restrict__ dmerged, float* __restrict__ dbsum, int S, int D, int pr) {
+    // pr = grid rows per strip (<= PW_ROWS): the host cuts the S rows into EQUAL strips (S = 91: 46 + 45 rows, not 64 + 27 — the long
+    // strips set the launch's time)
     const int tiles_x = (S + PW_X - 1) / PW_X;
 #if PW_RED
     // a workgroup = 64 channels x 4 strips (one per wave); the four partial filters are summed through LDS, so a
@@ -388,15 +408,15 @@ __global__ __launch_bounds__(256) void ppeg_wgrad_strip_kernel(const TX* __restr
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: addresses stay scalar
     const int c = blockIdx.x * 64 + lane;
     const int strip = blockIdx.y * 4 + wave;
-    const bool live = c < D && strip < tiles_x * ((S + PW_ROWS - 1) / PW_ROWS);
+    const bool live = c < D && strip < tiles_x * ((S + pr - 1) / pr);
 #else
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= D) return;
     const int strip = blockIdx.y;
     const bool live = true;
 #endif
-    const int y0 = (strip / tiles_x) * PW_ROWS, x0 = (strip % tiles_x) * PW_X;
-    const int y1 = live ? min(y0 + PW_ROWS, S) : y0;      // one past the last row of this strip
+    const int y0 = (strip / tiles_x) * pr, x0 = (strip % tiles_x) * PW_X;
+    const int y1 = live ? min(y0 + pr, S) : y0;      // one past the last row of this strip
     const long b = blockIdx.z;
     const long n = 1 + (long)S * S;
     const TX* xb = x + b * n * D + (live ? c : 0);
@@ -472,12 +492,13 @@ __global__ __launch_bounds__(256) void ppeg_wgrad_strip_kernel(const TX* __restr
 extern "C" int mh_ppeg_wgrad(const void* x, const void* dout, float* dmerged, float* dbsum, int B, int S, int D, int dt_x,
                              int dt_o, mh_stream s) {
     if (B == 0) return MH_OK;
+    const int pr = mh_cdiv(S, mh_cdiv(S, PW_ROWS));       // equal strips of at most PW_ROWS rows
 #if PW_RED
-    dim3 grid(mh_cdiv(D, 64), mh_cdiv(mh_cdiv(S, PW_ROWS) * mh_cdiv(S, PW_X), 4), B);
+    dim3 grid(mh_cdiv(D, 64), mh_cdiv(mh_cdiv(S, pr) * mh_cdiv(S, PW_X), 4), B);
 #else
-    dim3 grid(mh_cdiv(D, 256), mh_cdiv(S, PW_ROWS) * mh_cdiv(S, PW_X), B);
+    dim3 grid(mh_cdiv(D, 256), mh_cdiv(S, pr) * mh_cdiv(S, PW_X), B);
 #endif
-#define PW(TX, TO) hipLaunchKernelGGL((ppeg_wgrad_strip_kernel<TX, TO>), grid, dim3(256), 0, (hipStream_t)s, (const TX*)x, (const TO*)dout, dmerged, dbsum, S, D)
+#define PW(TX, TO) hipLaunchKernelGGL((ppeg_wgrad_strip_kernel<TX, TO>), grid, dim3(256), 0, (hipStream_t)s, (const TX*)x, (const TO*)dout, dmerged, dbsum, S, D, pr)
     if (dt_x == MH_F32 && dt_o == MH_F32) PW(float, float);
     else if (dt_x == MH_BF16 && dt_o == MH_BF16) PW(bf16_t, bf16_t);
     else if (dt_x == MH_F32 && dt_o == MH_BF16) PW(float, bf16_t);

@@ -823,10 +823,12 @@ def test_seq_finish(dtype, N, add):
     close(dcls, d[:, 0].sum(0), 0, 0, "dcls")
 
 
-@pytest.mark.parametrize("S,D,B", [(5, 32, 2), (16, 256, 2), (9, 300, 2), (40, 64, 8), (33, 32, 4)])
+@pytest.mark.parametrize("S,D,B", [(5, 32, 2), (16, 256, 2), (9, 300, 2), (40, 64, 8), (33, 32, 4), (91, 32, 2), (70, 64, 8)])
 def test_ppeg(S, D, B):
-    """(40, 64, 8) and (33, 32, 4): two 32-row strips per image and (batch, strip) groups a multiple of 8 — the XCD-aware workgroup
-    order of ppeg_rows2_kernel (the x-tiles of a group on one XCD); the others take the plain order."""
+    """(40, 64, 8) and (33, 32, 4): several strips per image and (batch, strip) groups a multiple of 8 — the XCD-aware workgroup
+    order of ppeg_rows2_kernel (the x-tiles of a group on one XCD); the others take the plain order.  (91, 32, 2) (config 4's grid) and
+    (70, 64, 8): more than 64 rows — the weight gradient walks two EQUAL strips (46 + 45, 35 + 35), the forward's rows per strip come
+    from mh_ppeg_fwd's round rule."""
     gen = g(S)
     x = torch.randn(B, 1 + S * S, D, generator=gen)
     ws = [torch.randn(D, 1, k, k, generator=gen) * 0.2 for k in (7, 5, 3)]
@@ -847,10 +849,11 @@ def test_ppeg(S, D, B):
     dm, dbs = torch.zeros_like(merged), torch.zeros_like(bsum)
     K.ppeg_wgrad(x.to(DEV), dy.to(DEV), dm, dbs, S)
     dm = dm.cpu().t().reshape(D, 7, 7)
-    close(dm, wr[0].grad[:, 0], 1e-4, 1e-3, "ppeg dw7")
-    close(dm[:, 1:6, 1:6], wr[1].grad[:, 0], 1e-4, 1e-3, "ppeg dw5")
-    close(dm[:, 2:5, 2:5], wr[2].grad[:, 0], 1e-4, 1e-3, "ppeg dw3")
-    close(dbs, br[0].grad, 1e-4, 1e-3, "ppeg db")
+    atol = 1e-3 * max(1.0, (B * S * S) ** 0.5 / 100)      # f32 sums of B S^2 unit-variance terms: the absolute error grows like their norm
+    close(dm, wr[0].grad[:, 0], 1e-4, atol, "ppeg dw7")
+    close(dm[:, 1:6, 1:6], wr[1].grad[:, 0], 1e-4, atol, "ppeg dw5")
+    close(dm[:, 2:5, 2:5], wr[2].grad[:, 0], 1e-4, atol, "ppeg dw3")
+    close(dbs, br[0].grad, 1e-4, atol, "ppeg db")
 
 
 # --------------------------------------------------------------------------------------- masking / RNA

@@ -68,15 +68,15 @@ if which in ("all", "pinv"):
     a2 = torch.randn(B, h, 256, 256, device=dev).softmax(-1)
     timeit("pinv_absmax [128,256,256]", lambda: K.pinv_absmax(a2), a2.numel() * 4)
 if which in ("all", "ppeg"):
-    S = 64
-    x = torch.randn(B, 1 + S * S, D, device=dev)
-    dout = torch.randn_like(x)
-    dm = torch.zeros(D * 49, device=dev)
-    dbs = torch.zeros(D, device=dev)
-    timeit("ppeg_wgrad f32", lambda: K.ppeg_wgrad(x, dout, dm, dbs, S), x.numel() * 8)
-    merged = torch.randn(49 * D, device=dev)
-    bsum = torch.randn(D, device=dev)
-    timeit("ppeg_fwd f32", lambda: K.ppeg(x, merged, bsum, S, False), x.numel() * 8)
+    for Bp, S in ((B, 64), (8, 91)):          # c2: 16 x 64 x 64 tokens; config 4: 8 x 91 x 91 (8192 + 89 square-pad tokens)
+        x = torch.randn(Bp, 1 + S * S, D, device=dev)
+        dout = torch.randn_like(x)
+        dm = torch.zeros(D * 49, device=dev)
+        dbs = torch.zeros(D, device=dev)
+        timeit(f"ppeg_wgrad f32 [{Bp}, {S}x{S}]", lambda: K.ppeg_wgrad(x, dout, dm, dbs, S), x.numel() * 8)
+        merged = torch.randn(49 * D, device=dev)
+        bsum = torch.randn(D, device=dev)
+        timeit(f"ppeg_fwd f32 [{Bp}, {S}x{S}]", lambda: K.ppeg(x, merged, bsum, S, False), x.numel() * 8)
 if which in ("all", "pinv"):
     a2 = torch.randn(B, h, 256, 256, device=dev).softmax(-1)
     stt = K.pinv_absmax(a2)
