@@ -60,6 +60,15 @@ if which in ("all", "mask"):
     dtok = torch.zeros(D, device=dev)
     dpos = torch.zeros(T, D, device=dev)
     timeit("mask_apply_bwd f32 [16,4097,512]", lambda: K.mask_apply_bwd(dy, mask, dtok, dpos, B, T, D, 1, False), B * T * D * 4)
+    # the step's form: bf16 dx out of place + the bias column sums; four gradient buffers in turn (536 MB: past the 256 MB Infinity Cache)
+    dys = [torch.randn(B, T, D, device=dev) for _ in range(4)]
+    dxb = torch.empty(B, T, D, device=dev, dtype=torch.bfloat16)
+    dbias = torch.zeros(D, device=dev)
+    turn = [0]
+    def step_form():
+        turn[0] = (turn[0] + 1) % 4
+        K.mask_apply_bwd(dys[turn[0]], mask, dtok, dpos, B, T, D, 1, False, out=dxb, dbias=dbias)
+    timeit("mask_apply_bwd f32 -> bf16 + dbias, cold", step_form, B * T * D * 6, reps=12)
     x = torch.randn(B, T, D, device=dev)
     tok = torch.zeros(D, device=dev)
     pos = torch.zeros(T, D, device=dev)
