@@ -152,7 +152,9 @@ int64_t mh_gemm_workspace_bytes(const mh_gemm_desc* d);
 
 /* ---------------------------------------------------------------- skinny-M linears (RNA encoder / style heads: every
  * tensor is [B, D], models/mirror.py:77-102, :217-224, :845-857): weight-streaming kernels, bf16 operands.
- * y[M<=32, N] = act(x[M,K] W[N,K]^T + bias + addend); K % 32 == 0; the data gradient is the same call on the W^T shadow, and
+ * y[M<=32, N] = act(x[M,K] W[N,K]^T + bias + addend); K % 32 == 0 with 16-byte aligned rows streams 16-byte fragments, any other K / row
+ * stride (the template's 10234 genes and 1975-wide MLP, configs/pretrain/mirror.template.yaml:27-46) the same kernel element-wise
+ * (v116+); the data gradient is the same call on the W^T shadow, and
  * `addend` (nullable f32 [M, N], row stride ldadd) is how the data gradients of two linears that read the same x are summed
  * without a launch of their own (style_mu / style_logstd, models/mirror.py:845-857). */
 int mh_skinny_fwd(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, const float* addend, int64_t ldadd,

@@ -24,7 +24,28 @@ template <> __device__ __forceinline__ sk_bf16x8 sk_load8<float>(const float* p)
     return sk_bf16x8{(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3], (__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
 }
 
-template <typename TX, typename TY, int MT>   // MT = number of 16-row tiles of x (1 or 2)
+// ANY (round 5): K and the row strides are arbitrary (the reference template's 10234 genes and its 1975-wide MLP, the 3000 prototypes as
+// a contraction): a lane's 8 k values arrive as 8 guarded 2-byte (4-byte for f32 x) loads instead of one 16-byte load — the same bytes
+// and the same coalescing across lanes, 8 x the load instructions, which a weight-streaming kernel of this size does not notice
+// (the guarded 128 x 128-tile GEMM ran these on 1-4 workgroups: 1570 us for the 31 MB of the gene embedding).
+template <typename TX> __device__ __forceinline__ sk_bf16x8 sk_load8_any(const TX* p, int valid);
+template <> __device__ __forceinline__ sk_bf16x8 sk_load8_any<bf16_t>(const bf16_t* p, int valid) {
+    sk_bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const bf16_t v = j < valid ? p[j] : (bf16_t)0;
+        r[j] = __builtin_bit_cast(__bf16, v);
+    }
+    return r;
+}
+template <> __device__ __forceinline__ sk_bf16x8 sk_load8_any<float>(const float* p, int valid) {
+    sk_bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; j++) r[j] = (__bf16)(j < valid ? p[j] : 0.f);
+    return r;
+}
+
+template <typename TX, typename TY, int MT, bool ANY = false>   // MT = number of 16-row tiles of x (1 or 2)
 __global__ __launch_bounds__(256) void skinny_fwd_kernel(const TX* __restrict__ x, long ldx, const bf16_t* __restrict__ w,
                                                          long ldw, const float* __restrict__ bias, const float* __restrict__ addend,
                                                          long ldadd, TY* __restrict__ y, long ldy, int M, int N, int K, int act) {
@@ -41,14 +62,24 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const TX* __restrict__ 
 #pragma unroll
     for (int t = 0; t < MT; t++) acc[t] = (sk_f4){0.f, 0.f, 0.f, 0.f};
     // wave `wave` owns k-steps wave, wave+4, ... (32 k per step): four independent 16-B streams per lane
-    const int steps = K / 32;
+    const int steps = ANY ? (K + 31) / 32 : K / 32;
 #pragma unroll 4
     for (int s = wave; s < steps; s += 4) {
-        const sk_bf16x8 b = *reinterpret_cast<const sk_bf16x8*>(wp + 32 * s);
+        if constexpr (ANY) {
+            const int valid = K - (32 * s + 8 * kq);           // <= 0: this lane's 8 k are past the end
+            const sk_bf16x8 b = sk_load8_any<bf16_t>(wp + 32 * s, valid);
 #pragma unroll
-        for (int t = 0; t < MT; t++) {
-            const sk_bf16x8 a = sk_load8<TX>(xp[t] + 32 * s);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[t], 0, 0, 0);
+            for (int t = 0; t < MT; t++) {
+                const sk_bf16x8 a = sk_load8_any<TX>(xp[t] + 32 * s, valid);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[t], 0, 0, 0);
+            }
+        } else {
+            const sk_bf16x8 b = *reinterpret_cast<const sk_bf16x8*>(wp + 32 * s);
+#pragma unroll
+            for (int t = 0; t < MT; t++) {
+                const sk_bf16x8 a = sk_load8<TX>(xp[t] + 32 * s);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[t], 0, 0, 0);
+            }
         }
     }
     // C/D map of 16x16x32: col = lane&15, row = (lane>>4)*4 + r
@@ -73,15 +104,17 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const TX* __restrict__ 
 
 extern "C" int mh_skinny_fwd(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, const float* addend,
                              int64_t ldadd, void* y, int64_t ldy, int M, int N, int K, int act, int dt_x, int dt_y, mh_stream s) {
-    MH_REQUIRE(M >= 1 && M <= 32, "mh_skinny_fwd: M=%d (needs 1..32)", M);
-    MH_REQUIRE(K % 32 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0,
-               "mh_skinny_fwd: K %% 32 == 0 and 16-byte aligned rows required (K=%d ldx=%ld ldw=%ld)", K, (long)ldx, (long)ldw);
+    MH_REQUIRE(M >= 1 && M <= 32 && K >= 1, "mh_skinny_fwd: M=%d (needs 1..32), K=%d", M, K);
     if (N == 0) return MH_OK;
+    // 16-byte fragments need K % 32 == 0 and 16-byte aligned rows; anything else takes the element-wise instance (ANY)
+    const bool vec = K % 32 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0;
     dim3 grid(mh_cdiv(N, 16));
-#define SKF(TX, TY, MT) hipLaunchKernelGGL((skinny_fwd_kernel<TX, TY, MT>), grid, dim3(256), 0, (hipStream_t)s, (const TX*)x, (long)ldx, (const bf16_t*)w, (long)ldw, bias, addend, (long)ldadd, (TY*)y, (long)ldy, M, N, K, act)
-#define SKF2(TX) do { if (dt_y == MH_F32) { if (M <= 16) SKF(TX, float, 1); else SKF(TX, float, 2); } else { if (M <= 16) SKF(TX, bf16_t, 1); else SKF(TX, bf16_t, 2); } } while (0)
+#define SKF(TX, TY, MT, ANY) hipLaunchKernelGGL((skinny_fwd_kernel<TX, TY, MT, ANY>), grid, dim3(256), 0, (hipStream_t)s, (const TX*)x, (long)ldx, (const bf16_t*)w, (long)ldw, bias, addend, (long)ldadd, (TY*)y, (long)ldy, M, N, K, act)
+#define SKF1(TX, TY, MT) do { if (vec) SKF(TX, TY, MT, false); else SKF(TX, TY, MT, true); } while (0)
+#define SKF2(TX) do { if (dt_y == MH_F32) { if (M <= 16) SKF1(TX, float, 1); else SKF1(TX, float, 2); } else { if (M <= 16) SKF1(TX, bf16_t, 1); else SKF1(TX, bf16_t, 2); } } while (0)
     if (dt_x == MH_F32) SKF2(float); else SKF2(bf16_t);
 #undef SKF2
+#undef SKF1
 #undef SKF
     MH_LAUNCH_CHECK("mh_skinny_fwd");
     return MH_OK;

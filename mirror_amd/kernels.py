@@ -492,11 +492,16 @@ def gemm_fp8(aq: torch.Tensor, sa: torch.Tensor, wq: torch.Tensor, sw: torch.Ten
 
 # ----------------------------------------------------------------------------- skinny-M linears
 def skinny_ok(x2d: torch.Tensor, w: torch.Tensor) -> bool:
-    """bf16 or f32 x [M<=32, K] (row-strided ok; f32 is rounded to bf16 on load: no cast launch) against bf16 W [N, K] contiguous,
-    K % 32 == 0, 16-B aligned rows."""
+    """bf16 or f32 x [M<=32, K] (row-strided ok; f32 is rounded to bf16 on load: no cast launch) against bf16 W [N, K] contiguous.
+    K % 32 == 0 with 16-byte aligned rows runs on 16-byte fragments, anything else (10234 genes, a 1975-wide MLP) on the element-wise
+    instance of the same kernel (skinny_vec_ok says which)."""
     return (x2d.dim() == 2 and w.dim() == 2 and x2d.dtype in (torch.bfloat16, torch.float32) and w.dtype == torch.bfloat16
-            and 1 <= x2d.shape[0] <= 32 and x2d.shape[1] == w.shape[1] and w.shape[1] % 32 == 0 and w.is_contiguous()
-            and (x2d.stride(1) == 1) and x2d.stride(0) % 8 == 0 and x2d.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0)
+            and 1 <= x2d.shape[0] <= 32 and x2d.shape[1] == w.shape[1] and w.shape[1] >= 1 and w.is_contiguous() and x2d.stride(1) == 1)
+
+
+def skinny_vec_ok(x2d: torch.Tensor, w: torch.Tensor) -> bool:
+    """The 16-byte-fragment instance of mh_skinny_fwd applies (what mh_skinny_fwd itself checks)."""
+    return (skinny_ok(x2d, w) and w.shape[1] % 32 == 0 and x2d.stride(0) % 8 == 0 and x2d.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0)
 
 
 def skinny_fwd(x2d: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act: int, out_dtype, out: Optional[torch.Tensor] = None,

@@ -1358,8 +1358,12 @@ def test_noise_draws_one_launch_uniform_and_normal():
 
 
 # --------------------------------------------------------------------------------------- skinny-M linears
-@pytest.mark.parametrize("M,N,Kd", [(16, 1024, 2048), (3, 3000, 512), (32, 96, 64), (20, 16, 32)])
+@pytest.mark.parametrize("M,N,Kd", [(16, 1024, 2048), (3, 3000, 512), (32, 96, 64), (20, 16, 32),
+                                    (16, 1536, 10234), (16, 768, 1975), (16, 1975, 768), (5, 37, 13), (32, 50, 1001)])
 def test_skinny_fwd_wgrad_transpose(M, N, Kd):
+    """(.., 10234), (.., 1975), (1975, ..) — the reference template's gene count and MLP width (configs/pretrain/mirror.template.yaml:27-46)
+    — and the small odd shapes run the element-wise instance of mh_skinny_fwd (K or N no multiple of 32, rows only 2-byte aligned);
+    integer operands: exact."""
     gen = g(M + N)
     x, w, dy = ints((M, Kd), gen), ints((N, Kd), gen), ints((M, N), gen)
     bias = ints((N,), gen)
@@ -1371,7 +1375,12 @@ def test_skinny_fwd_wgrad_transpose(M, N, Kd):
     close(yb, (x.double() @ w.double().t()).float().bfloat16().double(), 0, 0, "skinny fwd bf16")
     wt = K.transpose_bf16(wd)
     close(wt, w.t(), 0, 0, "transpose")
-    if N % 32 == 0:
+    assert K.skinny_vec_ok(xd, wd) == (Kd % 32 == 0)
+    if Kd % 32:      # f32 x straight into the element-wise instance, from a row-strided buffer
+        xs = torch.zeros(M, Kd + 3, device=DEV)
+        xs[:, :Kd] = x.to(DEV)
+        close(K.skinny_fwd(xs[:, :Kd], wd, None, ACT_NONE, torch.float32), x.double() @ w.double().t(), 0, 0, "skinny fwd, f32 x, odd row stride")
+    if True:
         dx = K.skinny_fwd(dyd, wt, None, ACT_NONE, torch.float32)
         close(dx, dy.double() @ w.double(), 0, 0, "skinny dgrad via W^T")
         # an f32 addend (another consumer's data gradient of the same x) is summed in front of the activation, any row stride
