@@ -106,7 +106,8 @@ typedef struct {
     void* C2;                     /* optional bf16 copy of the final C (C's ldc and batch strides), written by the same epilogue:
                                      the next product's operand without a cast launch.  192 x 384 tile kernel only (bf16
                                      operands, M % 192 == 0, N % 384 == 0, K % 64 == 0, no bias / activation / split-K) */
-    int32_t r_bf16;               /* 1: R is bf16 although C is f32 (same tile kernel only) */
+    int32_t r_bf16;               /* 1: R is bf16 although C is f32; 2 (v118): R is f32 although C is bf16 — a sum kept in f32 whose
+                                   * next consumer reads bf16 leaves as bf16 without the f32 read-modify-write (same tile kernel only) */
     int32_t k_segments;           /* > 1: C = sum_s A_s B_s over k_segments operand pairs of K each, A_s = A + s * sA_seg, B_s = B + s * sB_seg
                                      (elements): a sum of products in one accumulator, e.g. dX = sum_k dP_k z_k^T of the pinv reverse
                                      mode without an f32 read-modify-write of C per term.  Same tile kernel only; 0 / 1: one pair */

@@ -197,7 +197,7 @@ _lib = None
 # The ABI generation this binding was written against (mh_version() of csrc/errors.cpp).  _SIGS above restates the argument lists of
 # include/mirror_hip.h by hand: a library built from another generation would be called with shifted arguments (a stream where a
 # counter belongs) and corrupt device memory silently, so load() refuses anything but this exact number.
-ABI_VERSION = 117
+ABI_VERSION = 118
 
 
 class MirrorHipError(RuntimeError):

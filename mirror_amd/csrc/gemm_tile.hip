@@ -219,8 +219,9 @@ __global__ __launch_bounds__(NTT) void gemm_tile_kernel(GemmArgs g, bf16_t* __re
             if (g.diag != 0.f && grow >= gcol && grow < gcol + 4) v[grow - gcol] += g.diag;
             const long idx = (long)grow * g.ldc + gcol;
             if (g.R) {
-                if (r_bf16 || sizeof(TC) == 2) v += g.rcoef * ld4(reinterpret_cast<const bf16_t*>(g.R) + coff + idx);
-                else v += g.rcoef * ld4(reinterpret_cast<const float*>(g.R) + coff + idx);
+                // R in C's type, or (r_bf16 = 1) bf16 beside an f32 C, or (2) f32 beside a bf16 C
+                if (r_bf16 == 2 || (!r_bf16 && sizeof(TC) == 4)) v += g.rcoef * ld4(reinterpret_cast<const float*>(g.R) + coff + idx);
+                else v += g.rcoef * ld4(reinterpret_cast<const bf16_t*>(g.R) + coff + idx);
             }
             if (g.accumulate) v += ld4(C + idx);
             st4(C + idx, v);

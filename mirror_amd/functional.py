@@ -1832,6 +1832,9 @@ def pinv_forward_tile(a2: torch.Tensor, iters: int):
     return zs[iters], saved, st
 
 
+_PINV_R32 = True      # (test hook, round 5) f32 partial sums of the tile-kernel pinv backward as addends of bf16-output products
+
+
 def pinv_backward_tile(a2, saved, st, dZ):
     """Reverse mode of pinv_forward_tile, operands bf16.  Sums of products that share an operand layout run as ONE launch over
     several operand pairs (K.gemm_ksum: the f32 sum stays in the accumulators): dP's two `x @ y^T` terms per iteration, and
@@ -1858,9 +1861,17 @@ def pinv_backward_tile(a2, saved, st, dZ):
         else:
             dP = K.gemm(nT3, tr(T2), mma=MH_BF16, out_dtype=f32)
             K.gemm(dT2, tr(P), out=dP, accumulate=True, R=dT2, rcoef=-7.0, mma=MH_BF16)
-        K.gemm(tr(P), dT2, out=dP, accumulate=True, mma=MH_BF16, c2=dPb)
+        # the third term joins the f32 sum of the other two and leaves as bf16 — the only form the products below read: the f32 sum is
+        # an addend (R), not a read-modify-write destination (round 5: 75 MB of f32 stores less per product at the template's m = 384)
+        if _PINV_R32:
+            K.gemm(tr(P), dT2, out=dPb, R=dP, rcoef=1.0, mma=MH_BF16)
+        else:
+            K.gemm(tr(P), dT2, out=dP, accumulate=True, mma=MH_BF16, c2=dPb)
         dz = torch.empty(dzn.shape, device=dzn.device, dtype=bf16)
-        K.gemm(tr(a2b), dPb, out=dzn, accumulate=True, mma=MH_BF16, c2=dz)             # P = a2 z
+        if _PINV_R32 and k > 0:
+            K.gemm(tr(a2b), dPb, out=dz, R=dzn, rcoef=1.0, mma=MH_BF16)                    # P = a2 z; only the last d z (k = 0) is read in f32
+        else:
+            K.gemm(tr(a2b), dPb, out=dzn, accumulate=True, mma=MH_BF16, c2=dz)
     if stacked:
         zst = torch.as_strided(z0, (iters,) + tuple(z0.shape), (z0.numel(),) + tuple(z0.stride()))
         dX = K.gemm_ksum(dPs, tr(zst), mma=MH_BF16, out_dtype=f32)

@@ -131,10 +131,10 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *
         _chk(R)
         tile = gemm_tile_ok(M, N, K, a4.dtype, b4.dtype) and bias is None and act == ACT_NONE and d.split_k == 1
         if R.numel() != o4.numel() or tuple(R.stride()) != tuple(out.stride()) or not (
-                R.dtype == o4.dtype or (tile and R.dtype == torch.bfloat16)):
-            raise MirrorHipError("gemm: R must have the output's dtype (or bf16 on the 192 x 384 tile kernel), shape and strides")
+                R.dtype == o4.dtype or (tile and R.dtype in (torch.bfloat16, torch.float32))):
+            raise MirrorHipError("gemm: R must have the output's dtype (or bf16 / f32 on the 192 x 384 tile kernel), shape and strides")
         d.R, d.rcoef = R.data_ptr(), rcoef
-        d.r_bf16 = int(R.dtype == torch.bfloat16 and o4.dtype != torch.bfloat16)
+        d.r_bf16 = 0 if R.dtype == o4.dtype else (1 if R.dtype == torch.bfloat16 else 2)
     if c2 is not None:
         _chk(c2)
         if c2.dtype != torch.bfloat16 or c2.numel() != o4.numel() or tuple(c2.stride()) != tuple(out.stride()):

@@ -237,6 +237,11 @@ def test_gemm_tile384_kernel(a_rm, b_t, out_dtype):
     want = (ref + base.double() - 7.0 * Rm.double()).float()
     close(acc, want.to(out_dtype).double(), 0, 0, "tile accumulate + bf16 R")
     close(c2, want.to(bf).double(), 0, 0, "tile bf16 copy")
+    if out_dtype == bf:      # an f32 R beside a bf16 C (mh_gemm_desc.r_bf16 = 2): an f32 partial sum joins the product and leaves as bf16
+        R32 = (ints((Bt, M, N), gen) * 257.0 + 0.5).to(DEV)          # values bf16 cannot hold: read as f32 or the sum is wrong
+        outb = torch.empty((Bt, M, N), device=DEV, dtype=bf)
+        K.gemm(a_dev, b_dev, out=outb, R=R32, rcoef=1.0, mma=MH_BF16)
+        close(outb, (ref + R32.double().cpu()).float().to(bf).double(), 0, 0, "tile bf16 C + f32 R")
     # K = 96 (the 96-wide heads of the template geometry): the second K-tile is half empty and reads as zeros
     a_dev, a = _mk(a_rm, (Bt, M, 96), gen, bf, True)
     b_dev, b = _mk(not b_t, (Bt, 96, N), gen, bf, True)
@@ -334,6 +339,11 @@ def test_pinv_tile_path_matches_generic_path():
     assert torch.equal(st_t, st_g)
     close(z_t.float(), z_g.double().cpu(), 3e-2, 3e-2 * float(z_g.float().abs().max()), "pinv tile forward")
     dX_t = Fn.pinv_backward_tile(a2, saved_t, st_t, dZ)
+    Fn._PINV_R32 = False       # the f32 sums as read-modify-write destinations (the form before round 5): the same numbers up to the
+    try:                       # order of mh_pinv_z0_bwd's atomics (two runs of either form differ by ~1e-5 at a scale of ~160)
+        close(Fn.pinv_backward_tile(a2, saved_t, st_t, dZ), dX_t.double().cpu(), 0, 2e-4, "pinv tile backward: f32 sums as addends vs destinations")
+    finally:
+        Fn._PINV_R32 = True
     dX_g = Fn.pinv_backward(a2, saved_g, st_g, dZ, MH_BF16, torch.bfloat16)
     x64 = a2.double().cpu().requires_grad_(True)
     ax = x64.abs()
