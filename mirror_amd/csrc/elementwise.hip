@@ -808,17 +808,19 @@ extern "C" int mh_row_scale(const void* x, const float* scale, void* y, int64_t 
 // ------------------------------------------------------------------ key-padding plan of a Nystrom layer (BASELINE config 4)
 // From the [B, n_src] bool mask of the patches, everything a layer's masked attention needs, in one launch (was ~10 ATen
 // launches per layer): the f32 row mask of the front-padded sequence [pad zeros | lead ones | mask | mask[:, :wrap]], and per
-// landmark group of l rows the valid flag (count > 0) and l * (1 / (count + 1e-8)).  One thread per group.
+// landmark group of l rows the valid flag (count > 0) and l * (1 / (count + 1e-8)).  One WAVE per group: its l rows are l consecutive
+// floats of mrow (one coalesced store; one thread per group walked its 33 rows alone: 14 us on the critical path of config 4's first layer).
 __global__ __launch_bounds__(256) void keymask_plan_kernel(const unsigned char* __restrict__ mask, float* __restrict__ mrow,
                                                            float* __restrict__ mlm, float* __restrict__ lscale, long B, long n_src,
                                                            int lead, int wrap, int pad, int l, long m) {
-    const long g = (long)blockIdx.x * 256 + threadIdx.x;
-    if (g >= B * m) return;
+    const int lane = threadIdx.x & 63;
+    const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= B * m) return;                                  // wave-uniform
     const long b = g / m, j0 = (g % m) * l;
     const unsigned char* mb = mask + b * n_src;
     float* out = mrow + b * (m * l) + j0;
     float cnt = 0.f;
-    for (int i = 0; i < l; ++i) {
+    for (int i = lane; i < l; i += 64) {
         const long j = j0 + i - pad;                         // position in [lead ones | mask | wrapped head of the mask]
         float v = 0.f;
         if (j >= 0) {
@@ -829,8 +831,12 @@ __global__ __launch_bounds__(256) void keymask_plan_kernel(const unsigned char* 
         out[i] = v;
         cnt += v;
     }
-    mlm[g] = cnt > 0.f ? 1.f : 0.f;
-    lscale[g] = (float)l * (1.0f / (cnt + 1e-8f));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);      // counts: exact in any order
+    if (lane == 0) {
+        mlm[g] = cnt > 0.f ? 1.f : 0.f;
+        lscale[g] = (float)l * (1.0f / (cnt + 1e-8f));
+    }
 }
 extern "C" int mh_keymask_plan(const unsigned char* mask, float* mrow, float* mlm, float* lscale, int64_t B, int64_t n_src, int lead,
                                int wrap, int pad, int l, mh_stream s) {
@@ -839,7 +845,7 @@ extern "C" int mh_keymask_plan(const unsigned char* mask, float* mrow, float* ml
     const long n_tot = (long)pad + lead + n_src + wrap;
     MH_REQUIRE(n_tot % l == 0, "mh_keymask_plan: pad + lead + n_src + wrap = %ld is no multiple of l = %d", n_tot, l);
     const long m = n_tot / l;
-    hipLaunchKernelGGL(keymask_plan_kernel, dim3((unsigned)mh_cdiv(B * m, 256)), dim3(256), 0, (hipStream_t)s, mask, mrow, mlm, lscale, (long)B,
+    hipLaunchKernelGGL(keymask_plan_kernel, dim3((unsigned)mh_cdiv(B * m, 4)), dim3(256), 0, (hipStream_t)s, mask, mrow, mlm, lscale, (long)B,
                        (long)n_src, lead, wrap, pad, l, m);
     MH_LAUNCH_CHECK("mh_keymask_plan");
     return MH_OK;
