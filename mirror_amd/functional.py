@@ -1811,7 +1811,7 @@ def pinv_backward(a2, saved, st, dZ, pm, sd):
     return dX
 
 
-def pinv_forward_tile(a2: torch.Tensor, iters: int):
+def pinv_forward_tile(a2: torch.Tensor, iters: int, want_a2b: bool = False):
     """pinv_forward for landmark counts the 192 x 384 tile kernel takes (the template's m = 384): every operand bf16, f32
     accumulation inside a product, one launch per product at one workgroup per CU (csrc/gemm_tile.hip).  The iterates are
     written into stacks (zs[k] = z_k; pt[k] = (T2_k, P_k)) so that the backward pass can sum products over an iteration's or
@@ -1829,20 +1829,23 @@ def pinv_forward_tile(a2: torch.Tensor, iters: int):
         T3 = K.gemm(P, T2, alpha=-1.0, diag=13.0, mma=MH_BF16)
         K.gemm(z, T3, zs[k + 1], alpha=0.25, mma=MH_BF16)
         saved.append((z, P, T2, T3))
+    if want_a2b:        # the bf16 copy of attn2 is the backward's operand too: handed over instead of cast again (38 MB kept, a 113 MB pass saved)
+        return zs[iters], saved, st, a2b
     return zs[iters], saved, st
 
 
 _PINV_R32 = True      # (test hook, round 5) f32 partial sums of the tile-kernel pinv backward as addends of bf16-output products
 
 
-def pinv_backward_tile(a2, saved, st, dZ):
+def pinv_backward_tile(a2, saved, st, dZ, a2b=None):
     """Reverse mode of pinv_forward_tile, operands bf16.  Sums of products that share an operand layout run as ONE launch over
     several operand pairs (K.gemm_ksum: the f32 sum stays in the accumulators): dP's two `x @ y^T` terms per iteration, and
     dX = sum_k dP_k z_k^T over the whole chain at the end; the launch that completes a sum writes its bf16 copy (the next
     operand) in the same epilogue."""
     tr = lambda t: t.transpose(-1, -2)  # noqa: E731
     iters = len(saved)
-    a2b = K.cast(a2, bf16)
+    if a2b is None:
+        a2b = K.cast(a2, bf16)
     dz = K.cast(dZ, bf16) if dZ.dtype != bf16 else dZ
     dzn = dZ
     z0 = saved[0][0]
@@ -1879,7 +1882,8 @@ def pinv_backward_tile(a2, saved, st, dZ):
         dX = torch.zeros_like(a2)
         for k in range(iters):
             K.gemm(dPs[k], tr(saved[k][0]), out=dX, accumulate=True, mma=MH_BF16)
-    K.pinv_z0_bwd(a2, K.cast(z0, f32), dzn, st, dX)
+    # z_0 is formed on the fly from attn2 and the maxima (as on the chain path: no f32 copy of the bf16 z_0 the forward stored)
+    K.pinv_z0_bwd(a2, None, dzn, st, dX)
     return dX
 
 
@@ -2022,7 +2026,7 @@ class NystromCoreFn(Function):
                 a3 = K.softmax_masked_fwd(a3, mlm, mrow, a3 if A == f32 else None, out_dtype=A)
         tile = (not chain) and pm == MH_BF16 and K.gemm_tile_ok(m_l, m_l, m_l)
         if tile:
-            zf, saved, st = pinv_forward_tile(a2, iters)
+            zf, saved, st, ctx.a2b = pinv_forward_tile(a2, iters, want_a2b=True)
         elif not chain:
             zf, saved, st = pinv_forward(a2, iters, pm, sd)
         if not fused:
@@ -2197,7 +2201,7 @@ class NystromCoreFn(Function):
             K.shared_chip = False
             del work
         else:
-            dS2 = pinv_backward_tile(a2, saved, st, dZ) if ctx.tile else pinv_backward(a2, saved, st, dZ, pm, sd)
+            dS2 = pinv_backward_tile(a2, saved, st, dZ, getattr(ctx, "a2b", None)) if ctx.tile else pinv_backward(a2, saved, st, dZ, pm, sd)
             sm_bwd(a2, dS2, mlm if kmask else None, mlm if kmask else None)
         if dlm2 is None:
             K.gemm(tr(dS2), ql, out=dkl, alpha=scale, accumulate=True, mma=pio)
