@@ -1834,6 +1834,7 @@ def pinv_forward_tile(a2: torch.Tensor, iters: int, want_a2b: bool = False):
     return zs[iters], saved, st
 
 
+_TILE_SIDE = True      # (test hook, round 5) the tile-kernel pinv iteration (m = 384) on the side stream beside the attention sides' products
 _PINV_R32 = True      # (test hook, round 5) f32 partial sums of the tile-kernel pinv backward as addends of bf16-output products
 
 
@@ -1999,6 +2000,14 @@ class NystromCoreFn(Function):
             saved = [(xt, chain_saved, z0 if z0 is not None else st)]      # (no stored f32 z_0 on the one-launch path: a placeholder)
             ctx.z0_stored = z0 is not None
             K.shared_chip = True         # until the join below: no persistent GEMM kernel beside the half-chip chain
+        tile = (not chain) and pm == MH_BF16 and K.gemm_tile_ok(m_l, m_l, m_l)
+        if tile and _TILE_SIDE:
+            # the template's m = 384: the iteration is 24 dependent one-round launches (~36 us each, half of that fixed cost) that need
+            # attn2 only — they run on the side stream beside sim1 / sim3, their softmax and attn3 v, and meet them at w2 (round 5)
+            side = _side_stream(qkv.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                zf, saved, st, ctx.a2b = pinv_forward_tile(a2, iters, want_a2b=True)
         run_deferred(qkv)        # the v columns of to_qkv: nothing above reads them (landmarks are means of q and k)
         fused = K.nys_fused_ok(qkv, h, m_l) and lm.dtype == bf16      # nystrom_fused.hip: sim1 / sim3 never reach HBM (mask-aware)
         lse1 = lse3 = a1 = a3 = None
@@ -2024,10 +2033,9 @@ class NystromCoreFn(Function):
             else:
                 a1 = K.softmax_masked_fwd(a1, mrow, mlm, a1 if A == f32 else None, out_dtype=A)
                 a3 = K.softmax_masked_fwd(a3, mlm, mrow, a3 if A == f32 else None, out_dtype=A)
-        tile = (not chain) and pm == MH_BF16 and K.gemm_tile_ok(m_l, m_l, m_l)
-        if tile:
+        if tile and not _TILE_SIDE:
             zf, saved, st, ctx.a2b = pinv_forward_tile(a2, iters, want_a2b=True)
-        elif not chain:
+        elif not chain and not tile:
             zf, saved, st = pinv_forward(a2, iters, pm, sd)
         if not fused:
             av = K.gemm(a3, v, mma=mma, out_dtype=f32)                                   # [B,h,m,dh]
@@ -2047,7 +2055,8 @@ class NystromCoreFn(Function):
             K.resconv(qkv[..., 2 * D:], res_w.detach().contiguous(), out, h, transpose=False, accumulate=False)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
-            K.shared_chip = False
+            if chain:
+                K.shared_chip = False
         if w2 is None:
             w2 = K.gemm(zf, av, mma=pio, out_dtype=A)
         o1 = None
@@ -2166,6 +2175,14 @@ class NystromCoreFn(Function):
                     K.gemm(tr(dS2), ql, out=_heads(dlm2, 1, 2, h), alpha=scale, mma=pio)
                     K.gemm(dS2, kl, out=_heads(dlm2, 0, 2, h), alpha=scale, mma=pio)
             K.shared_chip = True         # until the join below
+        tile_side = ctx.tile and _TILE_SIDE and not chain
+        if tile_side:      # the 54 launches of the m = 384 iteration's backward beside the attention sides' gradient products
+            dZ_ready = torch.cuda.current_stream().record_event()
+            side = _side_stream(qkv.device)
+            with torch.cuda.stream(side):
+                side.wait_event(dZ_ready)
+                dS2 = pinv_backward_tile(a2, saved, st, dZ, getattr(ctx, "a2b", None))
+                sm_bwd(a2, dS2, mlm if kmask else None, mlm if kmask else None)
         run_deferred_bwd(dout)      # to_out's weight gradient (ToOutDropAddFn left it to us): beside the chain when there is one
         if fused and chain and _A1_DQ_IN_WINDOW:
             K.nys_attn1_bwd(qkv, lm, w2, dout, lse1, o1, delta1, dqkv, dW2, dlm, h, scale, kmask, which=2)     # dq: beside the chain
@@ -2196,7 +2213,9 @@ class NystromCoreFn(Function):
             K.gemm(tr(dS3), ql, out=dk, alpha=scale, mma=mma)
             K.gemm(tr(dS1), q, out=dkl, alpha=scale, mma=mma)
             K.gemm(dS3, k, out=dql, alpha=scale, mma=mma)
-        if side is not None:
+        if tile_side:
+            torch.cuda.current_stream().wait_stream(side)
+        elif side is not None:
             torch.cuda.current_stream().wait_stream(side)
             K.shared_chip = False
             del work
