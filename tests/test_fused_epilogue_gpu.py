@@ -42,7 +42,7 @@ def test_to_out_dropout_residual_epilogue_equals_composed(Bn, T, r0, R, Kd, N):
             y = Fn.ToOutDropAddFn.apply(resid, core, w, b, r0, R, 0.1, prec)
         else:
             y = Fn.dropout_add(resid, Fn.LinearRowsFn.apply(core, w, b, r0, R, prec, bf16), 0.1, True, lite=True)
-        y.backward(up)
+        y.backward(up.clone())      # the residual add hands its upstream gradient on in place: a fresh one per run
         res.append((y.detach().clone(), core.grad.clone(), resid.grad.clone(), w.grad.clone(), b.grad.clone(), Fn._dropout_state["offset"]))
     torch.cuda.synchronize()
     (y1, dc1, dr1, dw1, db1, o1), (y2, dc2, dr2, dw2, db2, o2) = res
@@ -76,7 +76,7 @@ def test_retention_embed_mask_pos_epilogue_equals_composed(Bn, T, Kd, N):
             assert y.grad_fn.__class__.__name__.startswith("EmbedMaskPosFn")
         else:
             y = Fn.MaskApplyFn.apply(Fn.linear(h, w, b, prec=prec), mask, token, pos, 1, False)
-        y.backward(up)
+        y.backward(up.clone())      # the residual add hands its upstream gradient on in place: a fresh one per run
         res.append([y.detach().clone()] + [t.grad.clone() for t in (h, w, b, token, pos)])
     torch.cuda.synchronize()
     for i, (a, c) in enumerate(zip(*res)):
@@ -680,3 +680,37 @@ def test_rows_window_product_skips_the_front_pad_rows(B, T, R, Kd, N, kc, beside
     ref = (a[:, r0:].float() @ b2.float())
     assert float((o3[:, r0:].float() - ref).abs().max()) <= 1e-2 * float(ref.abs().max())
     assert bool((o3[:, :r0] == 7).all()) and bool((out[..., N:] == 7).all())
+
+
+def test_template_geometry_pinv_on_the_side_stream_equals_the_serial_order():
+    """D = 768 (dh = 96, m = 384: the reference template, configs/pretrain/mirror.template.yaml:27-31): the tile-kernel Moore-Penrose
+    iteration beside the attention sides' products on the side stream (Fn._TILE_SIDE) and the f32 partial sums of its backward as
+    addends (Fn._PINV_R32) against the serial order / read-modify-write sums — the same launches in another order: output and gradients
+    agree to the run-to-run noise of mh_pinv_z0_bwd's atomics."""
+    import importlib
+    from mirror_amd import functional as Fn
+    MM = importlib.import_module("mirror_amd.models.mirror")
+    prec = Fn.POLICIES["bf16"]
+    g = torch.Generator().manual_seed(21)
+    x0 = torch.randn(2, 900, 768, generator=g).cuda()
+    up = torch.randn(2, 900, 768, generator=g).cuda()
+
+    def run():
+        torch.manual_seed(3)
+        layer = MM.TransLayer(768).cuda().eval()
+        x = x0.clone().requires_grad_(True)
+        y = layer(x, prec)
+        y.backward(up.clone())      # the residual add hands its upstream gradient on in place: a fresh one per run
+        torch.cuda.synchronize()
+        return y.detach().float(), x.grad.float(), {k: p.grad.float() for k, p in layer.named_parameters()}
+
+    y1, dx1, g1 = run()
+    Fn._TILE_SIDE, Fn._PINV_R32 = False, False
+    try:
+        y2, dx2, g2 = run()
+    finally:
+        Fn._TILE_SIDE, Fn._PINV_R32 = True, True
+    assert torch.equal(y1, y2)
+    for name, a, b in [("dx", dx1, dx2)] + [(k, g1[k], g2[k]) for k in g1]:
+        d = float((a - b).norm()) / max(float(b.norm()), 1e-12)
+        assert d <= 1e-3, (name, d)
