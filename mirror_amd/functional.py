@@ -504,10 +504,13 @@ class LinearFn(Function):
         N, Kd = wa.shape
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            if ctx.skinny and (N % 32 == 0 or (_SKINNY_ANY and N < 1024)):
+            t_managed = N % 32 == 0 and Kd % 32 == 0      # the engine keeps W^T current for these (engine.py: two_d); others are transposed per call
+            if ctx.skinny and (t_managed or (w.numel() <= (1 << 21) and (N % 32 == 0 or (_SKINNY_ANY and N < 1024)))):
                 # (a short N that is no multiple of 32 runs the element-wise instance of the kernel on a W^T that shadow_t transposes per
                 #  call: the engine keeps transposes for multiples of 32 only.  Long ones — the 3000 prototypes, the template's 1975-wide MLP
-                #  — keep the split contraction below: with the per-call transpose the skinny form measured +0.34 % +- 0.22 on the c2 step)
+                #  — keep the split contraction below: with the per-call transpose the skinny form measured +0.34 % +- 0.22 on the c2 step;
+                #  and a big weight whose transpose nobody keeps — the template's [1536, 10234] gene embedding, whose data gradient the mask
+                #  token needs — is not transposed per call either: 31 MB each way, three times per step)
                 dx = K.skinny_fwd(dy, shadow_t(w, prec), None, ACT_NONE, ctx.x_dtype)
             else:
                 rows = dy.numel() // N
@@ -2147,7 +2150,8 @@ class NystromCoreFn(Function):
         if one2:
             dzb, dAV = K.nys_dz_dav(dW2, av.contiguous(), zfT)
         else:
-            dZ = K.gemm(dW2, tr(av), mma=pm, out_dtype=f32)                              # [B,h,m,m]
+            # (the tile-kernel iteration reads d Z in bf16 only: the product rounds it itself instead of a cast pass behind an f32 copy)
+            dZ = K.gemm(dW2, tr(av), mma=pm, out_dtype=bf16 if (ctx.tile and _PINV_R32 and iters >= 1) else f32)      # [B,h,m,m]
         side = dlm2 = None
         if chain:
             xb, chain_saved, z0 = flat
