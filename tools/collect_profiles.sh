@@ -2,6 +2,8 @@
 # Evidence set for profiles/ (run on the GPU box from the repo root): bash tools/collect_profiles.sh <tag>
 # bench line, rocprofv3 kernel stats of the same command, eager-mode per-stream / top-launch views, PMC HBM traffic,
 # template config line + kernel stats, host-feed (PCIe-inclusive) lines, B = 32 line.
+# Afterwards, HERE: cp gpurun_out/prof_<tag>/<tag>_* gpurun_out/prof_<tag>/pmc_*.json profiles/   (bench.py reads profiles/pmc_*.json and
+# reports them as stale unless their csrc digest is the tree's: the two pmc files are part of the set)
 set -u
 TAG=${1:-r03_x}; PART=${2:-all}; R=$PWD; OUT=$R/gpurun_out/prof_$TAG; mkdir -p $OUT      # PART: core | rest | all (two calls fit gpurun's 20-minute limit)
 cd /tmp; export TMPDIR=/tmp; export PYTHONPATH=$R
