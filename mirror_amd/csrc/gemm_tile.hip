@@ -79,8 +79,18 @@ __global__ __launch_bounds__(NTT) void gemm_tile_kernel(GemmArgs g, bf16_t* __re
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / 6, wn = wave % 6;
-    const int tile_m = blockIdx.x / g.tiles_n, tile_n = blockIdx.x % g.tiles_n;
-    const int z = blockIdx.z;
+    // XCD-aware order (round 5): workgroup L runs on XCD L % 8.  The M-tiles of one matrix read the same B (all of it when N = 384: 295 KB at
+    // K = 384), so they take ids 8 apart — same XCD, neighbours in time — and the second one finds B in that XCD's L2 instead of fetching
+    // it from the fabric again (the pairs 2z, 2z + 1 of the plain order sat on different XCDs: 151 MB per 384-cubed product for 113)
+    int tile_m, tile_n, z;
+    if (g.tiles_n == 1 && g.tiles_m > 1 && gridDim.z % 8 == 0) {
+        const int L = blockIdx.x + gridDim.x * blockIdx.z, T = g.tiles_m;
+        z = (L / (8 * T)) * 8 + (L % 8);
+        tile_m = (L / 8) % T;
+        tile_n = 0;
+    } else {
+        tile_m = blockIdx.x / g.tiles_n; tile_n = blockIdx.x % g.tiles_n; z = blockIdx.z;
+    }
     const int b1 = z / g.batch2, b2 = z % g.batch2;
     const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A) + b1 * g.sA1 + b2 * g.sA2;
     const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B) + b1 * g.sB1 + b2 * g.sB2;
