@@ -366,6 +366,8 @@ def _rows_window_ok(a3, out3, r0, R, N, prec) -> bool:
 
 
 _GEMM_WINDOW = True      # (test hook)
+_LM_FIRST = False     # (experiment hook, round 5) tile-path geometries: only the landmark rows of to_qkv in front of the pinv fork, the sequence rows'
+                      # q | k | v as one launch beside the iteration: template +0.2 % +- 0.1 (20.137 vs 20.115 ms against the same base), off
 _DEFER_QK = False     # (experiment hook, round 5) the sequence rows of q | k under the pinv chain with the v columns (one launch), only the
                       # landmark rows in front of the fork: measured +0.61 % +- 0.17 SLOWER (the window grows by more than the 93 us it
                       # takes out of the serial part: in-window GEMMs run on the non-persistent kernel beside the half-chip chain)
@@ -1240,6 +1242,14 @@ class NormQkvLmFn(Function):
                 _rows_window(xs, wa[c0:].t(), qkv[..., c0:], pad, rows, mma=prec.mma)
                 with _tail_branch(fork, x.device):
                     qkv[:, :pad].zero_()
+        elif _LM_FIRST and _TILE_SIDE and prec.mma == MH_BF16 and prec.pinv_mma == MH_BF16 and m != K.PINV_CHAIN_M and K.gemm_tile_ok(m, m, m):
+            # the template's geometry (m = 384): the Moore-Penrose iteration is the longer side of the window it opens in NystromCoreFn and
+            # reads the landmarks only — their [B m, D] x [D, 2D] product stands in front of the fork, the sequence rows' q | k | v follow as
+            # ONE launch beside the iteration (run_deferred) instead of q | k (165 us) in front of it
+            K.gemm(xe[P:], wa[:c0].t(), out=qe[P:, :c0], mma=prec.mma)
+
+            def later():
+                K.gemm(xe[:P], wa.t(), out=qe[:P], mma=prec.mma)           # zero pad rows in, zero rows out
         else:
             K.gemm(xe, wa[:c0].t(), out=qe[:, :c0], mma=prec.mma)      # zero pad rows in, zero rows out
 
